@@ -1,0 +1,441 @@
+"""ctypes mirror of include/gfbe.h (the C-ABI drop-in boundary of Estimator::optimization(),
+reference: Ground-Fusion++/vins_estimator/src/estimator/estimator.cpp:2951-3698).
+
+A *window snapshot* is a plain dict of numpy arrays holding everything one optimization() call
+reads. `make_window` turns it into a `gfbe_window` whose pointers alias the
+numpy buffers (the returned holder keeps them alive).
+"""
+import ctypes as C
+import numpy as np
+
+WINDOW_SIZE = 10
+NFRAMES = 11
+DENSE_DIM = 182
+MAX_PRIOR_BLOCKS = 32
+PRIOR_X0_CAP = NFRAMES * 16 + 32
+
+OK, NO_CONVERGENCE, NUMERICAL_FAILURE, BAD_INPUT, DEVICE_ERROR, NO_DEVICE = range(6)
+MARGIN_OLD, MARGIN_SECOND_NEW, MARGIN_NONE = 0, 1, 2
+
+BLK_POSE0, BLK_SB0, BLK_EX_CAM, BLK_EX_WHEEL = 0, 11, 22, 23
+BLK_SX, BLK_SY, BLK_SW, BLK_TD, BLK_TD_WHEEL, BLK_COUNT = 24, 25, 26, 27, 28, 29
+
+c_d = C.c_double
+c_i = C.c_int32
+c_u8 = C.c_uint8
+PD = C.POINTER(c_d)
+PI = C.POINTER(c_i)
+PU8 = C.POINTER(c_u8)
+
+
+def block_global_size(bid):
+    if bid < BLK_SB0:
+        return 7
+    if bid < BLK_EX_CAM:
+        return 9
+    if bid in (BLK_EX_CAM, BLK_EX_WHEEL):
+        return 7
+    return 1
+
+
+def block_local_size(bid):
+    g = block_global_size(bid)
+    return 6 if g == 7 else g
+
+
+class State(C.Structure):
+    _fields_ = [("para_Pose", (c_d * 7) * NFRAMES),
+                ("para_SpeedBias", (c_d * 9) * NFRAMES),
+                ("para_Ex_Pose", c_d * 7),
+                ("para_Ex_Pose_wheel", c_d * 7),
+                ("para_Ix_wheel", c_d * 3),
+                ("para_Td", c_d),
+                ("para_Td_wheel", c_d)]
+
+
+class ImuPreint(C.Structure):
+    _fields_ = [("sum_dt", c_d), ("delta_p", c_d * 3), ("delta_q", c_d * 4), ("delta_v", c_d * 3),
+                ("linearized_ba", c_d * 3), ("linearized_bg", c_d * 3),
+                ("jacobian", c_d * 225), ("covariance", c_d * 225)]
+
+
+class WheelPreint(C.Structure):
+    _fields_ = [("sum_dt", c_d), ("delta_p", c_d * 3), ("delta_q", c_d * 4),
+                ("linearized_sx", c_d), ("linearized_sy", c_d), ("linearized_sw", c_d), ("linearized_td", c_d),
+                ("linearized_vel", c_d * 3), ("linearized_gyr", c_d * 3),
+                ("vel_1", c_d * 3), ("gyr_1", c_d * 3),
+                ("jacobian", c_d * 18), ("covariance", c_d * 36)]
+
+
+IMU_DOUBLES = C.sizeof(ImuPreint) // 8      # 467
+WHEEL_DOUBLES = C.sizeof(WheelPreint) // 8  # 78
+
+
+class Prior(C.Structure):
+    _fields_ = [("valid", c_i), ("n", c_i), ("n_blocks", c_i),
+                ("block_id", c_i * MAX_PRIOR_BLOCKS), ("block_size", c_i * MAX_PRIOR_BLOCKS),
+                ("block_idx", c_i * MAX_PRIOR_BLOCKS),
+                ("x0", c_d * PRIOR_X0_CAP),
+                ("J0", PD), ("r0", PD)]
+
+
+class Visual(C.Structure):
+    _fields_ = [("n_factor", c_i), ("feature_index", PI), ("imu_i", PI), ("imu_j", PI),
+                ("pts_i", PD), ("pts_j", PD), ("vel_i", PD), ("vel_j", PD), ("td_i", PD), ("td_j", PD)]
+
+
+class Window(C.Structure):
+    _fields_ = [("frame_count", c_i), ("state", State),
+                ("n_feature", c_i), ("para_Feature", PD), ("feature_const", PU8),
+                ("pose_const", c_u8 * NFRAMES), ("sb_const", c_u8 * NFRAMES),
+                ("ex_cam_const", c_u8), ("ex_wheel_const", c_u8), ("ix_wheel_const", c_u8),
+                ("td_const", c_u8), ("td_wheel_const", c_u8),
+                ("ex_cam_mask", c_u8 * 6), ("ex_wheel_mask", c_u8 * 6), ("_pad", c_u8 * 3),
+                ("n_imu", c_i), ("imu_frame", PI), ("imu", C.POINTER(ImuPreint)),
+                ("n_wheel", c_i), ("wheel_frame", PI), ("wheel", C.POINTER(WheelPreint)),
+                ("vis", Visual),
+                ("prior", C.POINTER(Prior))]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_num_iterations", c_i), ("huber_delta", c_d), ("vis_sqrt_info", c_d), ("g_norm", c_d),
+                ("initial_trust_region_radius", c_d), ("function_tolerance", c_d), ("gradient_tolerance", c_d),
+                ("parameter_tolerance", c_d), ("min_relative_decrease", c_d), ("jacobi_scaling", c_i),
+                ("marg_eps", c_d)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("status", c_i), ("iterations", c_i), ("num_successful", c_i), ("termination", c_i),
+                ("initial_cost", c_d), ("final_cost", c_d), ("final_radius", c_d),
+                ("cost_history", c_d * 16), ("accepted", c_u8 * 16)]
+
+
+class FeatureList(C.Structure):
+    _fields_ = [("n", c_i), ("start_frame", PI), ("n_obs", PI), ("obs_offset", PI),
+                ("obs", PD), ("obs_td", PD), ("estimated_depth", PD), ("estimate_flag", PI)]
+
+
+def default_options():
+    """Solver options the reference runs with (estimator.cpp:193,2959,3364-3376; m3dgr.yaml:108-117)."""
+    o = Options()
+    o.max_num_iterations = 8
+    o.huber_delta = 1.0
+    o.vis_sqrt_info = 600.0 / 1.5
+    o.g_norm = 9.7944
+    o.initial_trust_region_radius = 1e4
+    o.function_tolerance = 1e-6
+    o.gradient_tolerance = 1e-10
+    o.parameter_tolerance = 1e-8
+    o.min_relative_decrease = 1e-3
+    o.jacobi_scaling = 1
+    o.marg_eps = 1e-8
+    return o
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _pd(a):
+    return a.ctypes.data_as(PD)
+
+
+def _pi(a):
+    return a.ctypes.data_as(PI)
+
+
+def state_from_snapshot(snap, st=None):
+    st = st or State()
+    pose = _f64(snap["pose"]).reshape(NFRAMES, 7)
+    sb = _f64(snap["speed_bias"]).reshape(NFRAMES, 9)
+    for i in range(NFRAMES):
+        st.para_Pose[i][:] = pose[i].tolist()
+        st.para_SpeedBias[i][:] = sb[i].tolist()
+    st.para_Ex_Pose[:] = _f64(snap["ex_pose"]).tolist()
+    st.para_Ex_Pose_wheel[:] = _f64(snap["ex_pose_wheel"]).tolist()
+    st.para_Ix_wheel[:] = _f64(snap["ix_wheel"]).tolist()
+    st.para_Td = float(snap["td"])
+    st.para_Td_wheel = float(snap["td_wheel"])
+    return st
+
+
+def state_to_dict(st):
+    return {
+        "pose": np.array([list(st.para_Pose[i]) for i in range(NFRAMES)]),
+        "speed_bias": np.array([list(st.para_SpeedBias[i]) for i in range(NFRAMES)]),
+        "ex_pose": np.array(list(st.para_Ex_Pose)),
+        "ex_pose_wheel": np.array(list(st.para_Ex_Pose_wheel)),
+        "ix_wheel": np.array(list(st.para_Ix_wheel)),
+        "td": float(st.para_Td),
+        "td_wheel": float(st.para_Td_wheel),
+    }
+
+
+class PriorHolder:
+    """Owns J0/r0 storage for a gfbe_prior (capacity DENSE_DIM) and converts to/from dicts."""
+
+    def __init__(self, d=None):
+        self.J0 = np.zeros(DENSE_DIM * DENSE_DIM)
+        self.r0 = np.zeros(DENSE_DIM)
+        self.c = Prior()
+        self.c.J0 = _pd(self.J0)
+        self.c.r0 = _pd(self.r0)
+        self.c.valid = 0
+        if d is not None:
+            self.load(d)
+
+    def load(self, d):
+        n = int(d["n"])
+        nb = len(d["block_id"])
+        self.c.valid = int(d.get("valid", 1))
+        self.c.n = n
+        self.c.n_blocks = nb
+        for k in range(nb):
+            self.c.block_id[k] = int(d["block_id"][k])
+            self.c.block_size[k] = int(d["block_size"][k])
+            self.c.block_idx[k] = int(d["block_idx"][k])
+        x0 = _f64(d["x0"]).ravel()
+        for k in range(len(x0)):
+            self.c.x0[k] = x0[k]
+        self.J0[: n * n] = _f64(d["J0"]).ravel()
+        self.r0[:n] = _f64(d["r0"]).ravel()
+
+    def to_dict(self):
+        n, nb = self.c.n, self.c.n_blocks
+        sizes = [self.c.block_size[k] for k in range(nb)]
+        return {"valid": int(self.c.valid), "n": n,
+                "block_id": np.array([self.c.block_id[k] for k in range(nb)], dtype=np.int32),
+                "block_size": np.array(sizes, dtype=np.int32),
+                "block_idx": np.array([self.c.block_idx[k] for k in range(nb)], dtype=np.int32),
+                "x0": np.array([self.c.x0[k] for k in range(sum(sizes))]),
+                "J0": self.J0[: n * n].reshape(n, n).copy(), "r0": self.r0[:n].copy()}
+
+
+class WindowHolder:
+    """gfbe_window + the numpy buffers its pointers alias."""
+
+    def __init__(self, snap):
+        self.snap = snap
+        w = Window()
+        self.c = w
+        w.frame_count = int(snap.get("frame_count", WINDOW_SIZE))
+        state_from_snapshot(snap, w.state)
+        self.lam = _f64(snap["para_feature"])
+        L = self.lam.shape[0]
+        self.fconst = _u8(snap.get("feature_const", np.zeros(L, np.uint8)))
+        w.n_feature = L
+        w.para_Feature = _pd(self.lam)
+        w.feature_const = self.fconst.ctypes.data_as(PU8)
+        w.pose_const[:] = _u8(snap.get("pose_const", np.zeros(NFRAMES))).tolist()
+        w.sb_const[:] = _u8(snap.get("sb_const", np.zeros(NFRAMES))).tolist()
+        w.ex_cam_const = int(snap.get("ex_cam_const", 1))
+        w.ex_wheel_const = int(snap.get("ex_wheel_const", 0))
+        w.ix_wheel_const = int(snap.get("ix_wheel_const", 1))
+        w.td_const = int(snap.get("td_const", 1))
+        w.td_wheel_const = int(snap.get("td_wheel_const", 1))
+        w.ex_cam_mask[:] = _u8(snap.get("ex_cam_mask", np.zeros(6))).tolist()
+        w.ex_wheel_mask[:] = _u8(snap.get("ex_wheel_mask", np.zeros(6))).tolist()
+        # IMU / wheel
+        self.imu = _f64(snap.get("imu", np.zeros((0, IMU_DOUBLES)))).reshape(-1, IMU_DOUBLES)
+        self.imu_frame = _i32(snap.get("imu_frame", np.zeros(0)))
+        w.n_imu = self.imu.shape[0]
+        w.imu_frame = _pi(self.imu_frame)
+        w.imu = C.cast(self.imu.ctypes.data, C.POINTER(ImuPreint))
+        self.wheel = _f64(snap.get("wheel", np.zeros((0, WHEEL_DOUBLES)))).reshape(-1, WHEEL_DOUBLES)
+        self.wheel_frame = _i32(snap.get("wheel_frame", np.zeros(0)))
+        w.n_wheel = self.wheel.shape[0]
+        w.wheel_frame = _pi(self.wheel_frame)
+        w.wheel = C.cast(self.wheel.ctypes.data, C.POINTER(WheelPreint))
+        # visual
+        self.v_idx = _i32(snap["vis_feature_index"])
+        self.v_i = _i32(snap["vis_imu_i"])
+        self.v_j = _i32(snap["vis_imu_j"])
+        self.v_pi = _f64(snap["vis_pts_i"]).reshape(-1, 3)
+        self.v_pj = _f64(snap["vis_pts_j"]).reshape(-1, 3)
+        self.v_vi = _f64(snap["vis_vel_i"]).reshape(-1, 2)
+        self.v_vj = _f64(snap["vis_vel_j"]).reshape(-1, 2)
+        self.v_tdi = _f64(snap["vis_td_i"])
+        self.v_tdj = _f64(snap["vis_td_j"])
+        v = w.vis
+        v.n_factor = self.v_idx.shape[0]
+        v.feature_index, v.imu_i, v.imu_j = _pi(self.v_idx), _pi(self.v_i), _pi(self.v_j)
+        v.pts_i, v.pts_j, v.vel_i, v.vel_j = _pd(self.v_pi), _pd(self.v_pj), _pd(self.v_vi), _pd(self.v_vj)
+        v.td_i, v.td_j = _pd(self.v_tdi), _pd(self.v_tdj)
+        # prior
+        self.prior = None
+        if snap.get("prior") is not None:
+            self.prior = PriorHolder(snap["prior"])
+            w.prior = C.pointer(self.prior.c)
+
+    @property
+    def n_vis(self):
+        return self.c.vis.n_factor
+
+    @property
+    def n_feature(self):
+        return self.c.n_feature
+
+
+def bind(lib, prefix):
+    """Attach argtypes/restype for the entry points shared by the product (gfbe_) and oracle (gfo_)."""
+    P = C.POINTER
+    f = getattr(lib, prefix + "build_visual_factors")
+    f.restype = c_i
+    f.argtypes = [P(FeatureList), c_i, PI, PI, PI, PD, PD, PD, PD, PD, PD, PD, PU8]
+    f = getattr(lib, prefix + "feature_count")
+    f.restype = c_i
+    f.argtypes = [P(FeatureList)]
+    f = getattr(lib, prefix + "visual_factor_count")
+    f.restype = c_i
+    f.argtypes = [P(FeatureList), c_i]
+    f = getattr(lib, prefix + "set_depth")
+    f.restype = None
+    f.argtypes = [P(FeatureList), PD, PD, PI]
+    return lib
+
+
+def make_feature_list(fl):
+    """fl: dict(start_frame[n], n_obs[n], obs[sum,7], obs_td[sum], estimated_depth[n], estimate_flag[n])."""
+    h = {}
+    h["start_frame"] = _i32(fl["start_frame"])
+    h["n_obs"] = _i32(fl["n_obs"])
+    off = np.zeros(len(h["n_obs"]), np.int32)
+    if len(off) > 1:
+        off[1:] = np.cumsum(h["n_obs"])[:-1]
+    h["obs_offset"] = off
+    h["obs"] = _f64(fl["obs"]).reshape(-1, 7)
+    h["obs_td"] = _f64(fl["obs_td"])
+    h["estimated_depth"] = _f64(fl["estimated_depth"])
+    h["estimate_flag"] = _i32(fl["estimate_flag"])
+    c = FeatureList()
+    c.n = len(h["n_obs"])
+    c.start_frame, c.n_obs, c.obs_offset = _pi(h["start_frame"]), _pi(h["n_obs"]), _pi(h["obs_offset"])
+    c.obs, c.obs_td, c.estimated_depth = _pd(h["obs"]), _pd(h["obs_td"]), _pd(h["estimated_depth"])
+    c.estimate_flag = _pi(h["estimate_flag"])
+    h["c"] = c
+    return h
+
+
+class CApi:
+    """Pythonic calls shared by the product library (prefix gfbe_, first arg = gfbe_ctx*) and the
+    CPU oracle (prefix gfo_, first arg = const gfbe_options*). Subclasses set .lib/.prefix/.head."""
+
+    lib = None
+    prefix = ""
+    head = None          # ctypes object passed as the first argument of compute entry points
+
+    def _fn(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def check(self, rc, what):
+        if rc not in (OK, NO_CONVERGENCE):
+            raise RuntimeError("%s%s failed with status %d" % (self.prefix, what, rc))
+        return rc
+
+    # ---- a13 bookkeeping
+    def build_visual_factors(self, fl, only_start_frame0=False):
+        h = make_feature_list(fl)
+        c = C.byref(h["c"])
+        L = self._fn("feature_count")(c)
+        K = self._fn("visual_factor_count")(c, int(only_start_frame0))
+        idx, ii, jj = np.zeros(K, np.int32), np.zeros(K, np.int32), np.zeros(K, np.int32)
+        pi, pj = np.zeros((K, 3)), np.zeros((K, 3))
+        vi, vj = np.zeros((K, 2)), np.zeros((K, 2))
+        tdi, tdj = np.zeros(K), np.zeros(K)
+        lam, fc = np.zeros(L), np.zeros(L, np.uint8)
+        k = self._fn("build_visual_factors")(c, int(only_start_frame0), _pi(idx), _pi(ii), _pi(jj), _pd(pi), _pd(pj),
+                                            _pd(vi), _pd(vj), _pd(tdi), _pd(tdj), _pd(lam),
+                                            fc.ctypes.data_as(PU8))
+        assert k == K
+        return dict(vis_feature_index=idx, vis_imu_i=ii, vis_imu_j=jj, vis_pts_i=pi, vis_pts_j=pj,
+                    vis_vel_i=vi, vis_vel_j=vj, vis_td_i=tdi, vis_td_j=tdj, para_feature=lam, feature_const=fc)
+
+    def set_depth(self, fl, para_feature):
+        h = make_feature_list(fl)
+        est = h["estimated_depth"].copy()
+        flag = np.zeros(len(est), np.int32)
+        lam = _f64(para_feature)
+        self._fn("set_depth")(C.byref(h["c"]), _pd(lam), _pd(est), _pi(flag))
+        return est, flag
+
+    # ---- factor evaluation (block-CSR out)
+    def eval_factors(self, snap, robustify=False):
+        wh = snap if isinstance(snap, WindowHolder) else WindowHolder(snap)
+        K, ni, nw = wh.n_vis, wh.c.n_imu, wh.c.n_wheel
+        out = dict(vis_r=np.zeros((K, 2)), vis_J=np.zeros((K, 2, 20)), imu_r=np.zeros((ni, 15)),
+                   imu_J=np.zeros((ni, 15, 30)), wheel_r=np.zeros((nw, 6)), wheel_J=np.zeros((nw, 6, 22)))
+        npr = wh.prior.c.n if wh.prior is not None else 0
+        out["prior_r"] = np.zeros(npr)
+        cost = c_d(0.0)
+        f = self._fn("eval_factors")
+        f.restype = c_i
+        rc = f(self.head, C.byref(wh.c), int(robustify), _pd(out["vis_r"]), _pd(out["vis_J"]), _pd(out["imu_r"]),
+               _pd(out["imu_J"]), _pd(out["wheel_r"]), _pd(out["wheel_J"]),
+               _pd(out["prior_r"]) if npr else None, C.byref(cost))
+        self.check(rc, "eval_factors")
+        out["cost"] = cost.value
+        return out
+
+    # ---- pre-integration
+    def preintegrate_imu(self, intervals, lin_ba, lin_bg, noise):
+        """intervals: list of (samples[n,7], first[6])."""
+        n = len(intervals)
+        off = np.zeros(n + 1, np.int32)
+        off[1:] = np.cumsum([len(s) for s, _ in intervals])
+        samples = _f64(np.concatenate([s for s, _ in intervals]))
+        first = _f64(np.array([f for _, f in intervals]))
+        lin = _f64(np.tile(np.concatenate([lin_ba, lin_bg]), (n, 1)))
+        out = np.zeros((n, IMU_DOUBLES))
+        nz = _f64(noise)
+        f = self._fn("preintegrate_imu")
+        f.restype = c_i
+        args = [n, _pi(off), _pd(samples), _pd(first), _pd(lin), _pd(nz), C.cast(out.ctypes.data, C.POINTER(ImuPreint))]
+        rc = f(*(([self.head] if self.prefix == "gfbe_" else []) + args))
+        self.check(rc, "preintegrate_imu")
+        return out
+
+    def preintegrate_wheel(self, intervals, lin, noise):
+        n = len(intervals)
+        off = np.zeros(n + 1, np.int32)
+        off[1:] = np.cumsum([len(s) for s, _ in intervals])
+        samples = _f64(np.concatenate([s for s, _ in intervals]))
+        first = _f64(np.array([f for _, f in intervals]))
+        linv = _f64(np.tile(np.asarray(lin, float), (n, 1)))
+        out = np.zeros((n, WHEEL_DOUBLES))
+        nz = _f64(noise)
+        f = self._fn("preintegrate_wheel")
+        f.restype = c_i
+        args = [n, _pi(off), _pd(samples), _pd(first), _pd(linv), _pd(nz), C.cast(out.ctypes.data, C.POINTER(WheelPreint))]
+        rc = f(*(([self.head] if self.prefix == "gfbe_" else []) + args))
+        self.check(rc, "preintegrate_wheel")
+        return out
+
+    # ---- the whole optimization() call
+    def solve(self, snap, margin_flag=MARGIN_NONE):
+        wh = snap if isinstance(snap, WindowHolder) else WindowHolder(snap)
+        st = State()
+        feat = np.zeros(wh.n_feature)
+        pr = PriorHolder()
+        sm = Summary()
+        f = self._fn("solve_window")
+        f.restype = c_i
+        rc = f(self.head, C.byref(wh.c), int(margin_flag), C.byref(st), _pd(feat), C.byref(pr.c), C.byref(sm))
+        self.check(rc, "solve_window")
+        return dict(state=state_to_dict(st), feature=feat, prior=pr.to_dict() if pr.c.valid else None,
+                    summary=summary_to_dict(sm), status=rc)
+
+
+def summary_to_dict(sm):
+    n = sm.iterations + 1
+    return dict(status=sm.status, iterations=sm.iterations, num_successful=sm.num_successful,
+                termination=sm.termination, initial_cost=sm.initial_cost, final_cost=sm.final_cost,
+                final_radius=sm.final_radius, cost_history=list(sm.cost_history)[:n],
+                accepted=list(sm.accepted)[:n])

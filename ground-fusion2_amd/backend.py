@@ -1,0 +1,182 @@
+"""ctypes binding of the product library csrc/libgfbe.so (HIP, gfx950) — the host-side mirror of
+Estimator::optimization() (estimator.cpp:2951-3698) over the C ABI of include/gfbe.h.
+
+There is deliberately no CPU path here: if the library is missing, a symbol is missing, or no GPU
+is visible, the call raises BackendError (gfbe_status GFBE_NO_DEVICE). The CPU oracle lives in
+oracle/ and is only ever loaded by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libgfbe.so")
+
+# Every symbol include/gfbe.h declares (checked by tests/test_abi.py on CPU).
+EXPORTS = [
+    "gfbe_default_options", "gfbe_create", "gfbe_destroy", "gfbe_last_error", "gfbe_version", "gfbe_set_stream",
+    "gfbe_feature_count", "gfbe_visual_factor_count", "gfbe_build_visual_factors", "gfbe_set_depth",
+    "gfbe_eval_factors", "gfbe_preintegrate_imu", "gfbe_preintegrate_wheel",
+    "gfbe_solve_window", "gfbe_solve_batch",
+    "gfbe_batch_upload", "gfbe_batch_solve", "gfbe_batch_download", "gfbe_batch_free",
+    "gfbe_profile_enable", "gfbe_profile_count", "gfbe_profile_get", "gfbe_profile_reset",
+    "gfbe_set_allreduce",
+]
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _SO
+
+
+def sources():
+    return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def build_native(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> csrc/libgfbe.so (cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hpp"))]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "gfbe.h"))
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
+        return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+           "-I", os.path.join(os.path.dirname(_HERE), "include"), "-o", _SO] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return _SO
+
+
+class Backend(abi.CApi):
+    prefix = "gfbe_"
+
+    def __init__(self, device=0, options=None):
+        if not os.path.exists(_SO):
+            raise BackendError("HIP extension %s is missing: run __graft_entry__.build() (no CPU fallback)" % _SO)
+        self.lib = abi.bind(C.CDLL(_SO), "gfbe_")
+        self.opt = options or abi.default_options()
+        self.ctx = C.c_void_p()
+        self.lib.gfbe_create.restype = abi.c_i
+        self.lib.gfbe_last_error.restype = C.c_char_p
+        self.lib.gfbe_last_error.argtypes = [C.c_void_p]
+        self.lib.gfbe_version.restype = C.c_char_p
+        rc = self.lib.gfbe_create(C.byref(self.ctx), int(device), C.byref(self.opt))
+        if rc != abi.OK:
+            raise BackendError("gfbe_create(device=%d) failed with status %d (%s)" % (device, rc, self._err()))
+        self.head = self.ctx
+        self.device = device
+        for name in ("batch_upload", "batch_solve", "batch_download", "solve_batch", "profile_enable",
+                     "profile_get", "set_stream", "set_allreduce", "eval_factors", "solve_window"):
+            getattr(self.lib, "gfbe_" + name).restype = abi.c_i
+        self.lib.gfbe_batch_free.restype = None
+        self.lib.gfbe_profile_count.restype = abi.c_i
+        self._cb = None
+
+    def _err(self):
+        try:
+            return (self.lib.gfbe_last_error(self.ctx) or b"").decode()
+        except Exception:
+            return "?"
+
+    def check(self, rc, what):
+        if rc not in (abi.OK, abi.NO_CONVERGENCE):
+            raise BackendError("gfbe_%s failed with status %d: %s" % (what, rc, self._err()))
+        return rc
+
+    def close(self):
+        if self.ctx:
+            self.lib.gfbe_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def version(self):
+        return self.lib.gfbe_version().decode()
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.gfbe_set_stream(self.ctx, C.c_void_p(stream_ptr)), "set_stream")
+
+    # ---- device-resident batch
+    def batch_upload(self, snaps):
+        holders = [s if isinstance(s, abi.WindowHolder) else abi.WindowHolder(s) for s in snaps]
+        arr = (C.POINTER(abi.Window) * len(holders))(*[C.pointer(h.c) for h in holders])
+        batch = C.c_void_p()
+        self.check(self.lib.gfbe_batch_upload(self.ctx, len(holders), arr, C.byref(batch)), "batch_upload")
+        return Batch(self, batch, holders)
+
+    def solve_batch(self, snaps, margin_flag=abi.MARGIN_NONE):
+        b = self.batch_upload(snaps)
+        try:
+            b.solve(margin_flag)
+            return b.download()
+        finally:
+            b.free()
+
+    # ---- profiling hooks
+    def profile_enable(self, on=True):
+        self.check(self.lib.gfbe_profile_enable(self.ctx, int(on)), "profile_enable")
+
+    def profile_reset(self):
+        self.lib.gfbe_profile_reset(self.ctx)
+
+    def profile(self):
+        out = []
+        for i in range(self.lib.gfbe_profile_count(self.ctx)):
+            name = C.c_char_p()
+            launches = C.c_int64()
+            ms = C.c_double()
+            by = C.c_double()
+            self.lib.gfbe_profile_get(self.ctx, i, C.byref(name), C.byref(launches), C.byref(ms), C.byref(by))
+            out.append(dict(name=name.value.decode(), launches=launches.value, total_ms=ms.value, bytes=by.value))
+        return out
+
+    # ---- multi-GPU landmark sharding: all-reduce hook (RCCL via torch.distributed in the caller)
+    def set_allreduce(self, fn, rank, world_size):
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+        self._cb = CB(lambda user, ptr, n, stream: fn(ptr, n, stream)) if fn is not None else C.cast(None, CB)
+        self.check(self.lib.gfbe_set_allreduce(self.ctx, self._cb, None, int(rank), int(world_size)), "set_allreduce")
+
+
+class Batch:
+    def __init__(self, be, handle, holders):
+        self.be, self.h, self.holders = be, handle, holders
+        self.n = len(holders)
+
+    def solve(self, margin_flag=abi.MARGIN_NONE):
+        self.be.check(self.be.lib.gfbe_batch_solve(self.be.ctx, self.h, int(margin_flag)), "batch_solve")
+
+    def download(self):
+        n = self.n
+        states = (abi.State * n)()
+        feats = [np.zeros(h.n_feature) for h in self.holders]
+        fptr = (abi.PD * n)(*[abi._pd(f) for f in feats])
+        priors = [abi.PriorHolder() for _ in range(n)]
+        pptr = (C.POINTER(abi.Prior) * n)(*[C.pointer(p.c) for p in priors])
+        sums = (abi.Summary * n)()
+        self.be.check(self.be.lib.gfbe_batch_download(self.be.ctx, self.h, states, fptr, pptr, sums), "batch_download")
+        out = []
+        for k in range(n):
+            out.append(dict(state=abi.state_to_dict(states[k]), feature=feats[k],
+                            prior=priors[k].to_dict() if priors[k].c.valid else None,
+                            summary=abi.summary_to_dict(sums[k]), status=sums[k].status))
+        return out
+
+    def free(self):
+        if self.h:
+            self.be.lib.gfbe_batch_free(self.be.ctx, self.h)
+            self.h = C.c_void_p()

@@ -1,0 +1,325 @@
+/*
+ * gfbe.h — C ABI of the MI355X-native sliding-window visual-inertial-wheel back end.
+ *
+ * This is the drop-in boundary for ONE hot path of sjtuyinjie/Ground-Fusion2:
+ *   Ground-Fusion++/vins_estimator/src/estimator/estimator.cpp:2951-3698  (Estimator::optimization())
+ * A maintainer binds these entry points from Estimator::optimization();
+ * everything else in the reference (ROS node, front end, LIO, mapping) is untouched.
+ *
+ * Conventions (identical to the reference's parameter blocks, estimator.h:230-238,336-342):
+ *   pose block       = [px py pz qx qy qz qw]            (estimator.cpp:2341-2348)
+ *   speed-bias block = [vx vy vz bax bay baz bgx bgy bgz] (estimator.cpp:2352-2362)
+ *   quaternions are x,y,z,w inside every block.
+ *   tangent order per pose = (dP, dtheta) with right perturbation q <- q * [1, dtheta/2]
+ *   (pose_local_parameterization.cpp:12-36).
+ * All floating point is FP64; all indices are int32. Plain pointers + sizes only: no C++/torch
+ * types cross this boundary. Memory passed in is caller-owned host memory unless a function
+ * name says "_dev". One gfbe_ctx per Estimator; a ctx is thread-compatible (one call at a time).
+ */
+#ifndef GFBE_H_
+#define GFBE_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFBE_WINDOW_SIZE 10 /* parameters.h:24 */
+#define GFBE_NFRAMES 11     /* WINDOW_SIZE + 1 */
+#define GFBE_MAX_OBS 11     /* a landmark has at most one observation per frame */
+#define GFBE_DENSE_DIM 182  /* 11*6 + 11*9 + 6 + 6 + 3 + 1 + 1 tangent dims */
+#define GFBE_MAX_PRIOR_BLOCKS 32
+
+typedef enum gfbe_status {
+  GFBE_OK = 0,
+  GFBE_NO_CONVERGENCE = 1,   /* ran out of iterations (normal for an 8-iteration budget) */
+  GFBE_NUMERICAL_FAILURE = 2,/* linear solve failed for every mu < max_mu, or NaN */
+  GFBE_BAD_INPUT = 3,
+  GFBE_DEVICE_ERROR = 4,
+  GFBE_NO_DEVICE = 5         /* HIP back end asked for, no GPU / kernels missing: fails loudly */
+} gfbe_status;
+
+/* Symbolic parameter-block ids. They replace the raw double* addresses the reference uses as
+ * block identity (marginalization_factor.cpp:104-116, estimator.cpp:3561-3588 addr_shift). */
+enum {
+  GFBE_BLK_POSE0 = 0,   /* .. GFBE_BLK_POSE0+10  para_Pose[i]      size 7 */
+  GFBE_BLK_SB0 = 11,    /* .. GFBE_BLK_SB0+10    para_SpeedBias[i] size 9 */
+  GFBE_BLK_EX_CAM = 22, /* para_Ex_Pose[0]       size 7 */
+  GFBE_BLK_EX_WHEEL = 23, /* para_Ex_Pose_wheel[0] size 7 */
+  GFBE_BLK_SX = 24, GFBE_BLK_SY = 25, GFBE_BLK_SW = 26, /* para_Ix_s{x,y,w}_wheel size 1 */
+  GFBE_BLK_TD = 27,     /* para_Td       size 1 */
+  GFBE_BLK_TD_WHEEL = 28, /* para_Td_wheel size 1 */
+  GFBE_BLK_COUNT = 29
+};
+
+/* The dense ("camera side") parameter blocks of one window — what vector2double() fills
+ * (estimator.cpp:2337-2414) and double2vector() reads back (estimator.cpp:2501-2630). */
+typedef struct gfbe_state {
+  double para_Pose[GFBE_NFRAMES][7];
+  double para_SpeedBias[GFBE_NFRAMES][9];
+  double para_Ex_Pose[7];        /* camera 0 (the only one optimization() wires: estimator.cpp:3351) */
+  double para_Ex_Pose_wheel[7];
+  double para_Ix_wheel[3];       /* sx, sy, sw */
+  double para_Td;
+  double para_Td_wheel;
+} gfbe_state; /* 195 doubles */
+
+/* What IMUFactor reads from IntegrationBase (imu_factor.h:69-90, integration_base.h:169-195). */
+typedef struct gfbe_imu_preint {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4]; /* x y z w */
+  double delta_v[3];
+  double linearized_ba[3];
+  double linearized_bg[3];
+  double jacobian[225];   /* 15x15 row-major, order P,R,V,BA,BG (parameters.h:166-173) */
+  double covariance[225]; /* 15x15 row-major */
+} gfbe_imu_preint; /* 467 doubles */
+
+/* What WheelFactor reads from WheelIntegrationBase (wheel_factor.h:80-243,
+ * wheel_integration_base.h:180-219). */
+typedef struct gfbe_wheel_preint {
+  double sum_dt;
+  double delta_p[3];
+  double delta_q[4]; /* x y z w */
+  double linearized_sx, linearized_sy, linearized_sw, linearized_td;
+  double linearized_vel[3], linearized_gyr[3]; /* first sample of the interval */
+  double vel_1[3], gyr_1[3];                   /* last sample of the interval */
+  double jacobian[18];   /* 6x3 row-major: d(p,theta)/d(sx,sy,sw) */
+  double covariance[36]; /* 6x6 row-major */
+} gfbe_wheel_preint; /* 78 doubles */
+
+/* Marginalisation prior = MarginalizationInfo's result fields
+ * (marginalization_factor.h:67-81): linearized_jacobians, linearized_residuals,
+ * keep_block_{size,idx,data}; block identity is symbolic (block_id) instead of an address. */
+typedef struct gfbe_prior {
+  int32_t valid;    /* MarginalizationInfo::valid */
+  int32_t n;        /* tangent dimension (rows == cols of J0) */
+  int32_t n_blocks;
+  int32_t block_id[GFBE_MAX_PRIOR_BLOCKS];   /* GFBE_BLK_* the block is attached to NOW (after addr_shift) */
+  int32_t block_size[GFBE_MAX_PRIOR_BLOCKS]; /* global size: 7, 9 or 1 */
+  int32_t block_idx[GFBE_MAX_PRIOR_BLOCKS];  /* tangent offset in [0,n)  (keep_block_idx - m) */
+  double x0[GFBE_NFRAMES * 16 + 32];         /* keep_block_data, concatenated in block order */
+  double *J0;       /* n*n row-major, caller-owned, capacity >= GFBE_DENSE_DIM^2 */
+  double *r0;       /* n,             caller-owned, capacity >= GFBE_DENSE_DIM   */
+} gfbe_prior;
+
+/* Visual factor list: one entry per ProjectionTwoFrameOneCamFactor that optimization() would
+ * `new` (estimator.cpp:3330-3358). Produced bit-exactly by gfbe_build_visual_factors(). */
+typedef struct gfbe_visual {
+  int32_t n_factor;             /* K */
+  const int32_t *feature_index; /* [K] index into para_Feature */
+  const int32_t *imu_i;         /* [K] start_frame of the landmark */
+  const int32_t *imu_j;         /* [K] observing frame, != imu_i */
+  const double *pts_i;          /* [K][3] first observation (normalised coords) */
+  const double *pts_j;          /* [K][3] */
+  const double *vel_i;          /* [K][2] */
+  const double *vel_j;          /* [K][2] */
+  const double *td_i;           /* [K] cur_td of the first observation */
+  const double *td_j;           /* [K] */
+} gfbe_visual;
+
+/* One call of optimization(): everything it reads. */
+typedef struct gfbe_window {
+  int32_t frame_count;          /* poses 0..frame_count are in the problem (== WINDOW_SIZE when full) */
+  gfbe_state state;             /* in: vector2double() output */
+  int32_t n_feature;            /* L = FeatureManager::getFeatureCount() */
+  const double *para_Feature;   /* [L] inverse depths (getDepthVector, feature_manager.cpp:286-302) */
+  const uint8_t *feature_const; /* [L] 1 => SetParameterBlockConstant (estimate_flag==1, estimator.cpp:3352) */
+  /* SetParameterBlockConstant decisions (estimator.cpp:3022,3059,3101,3114-3116,3159-3161,3302-3303) */
+  uint8_t pose_const[GFBE_NFRAMES];
+  uint8_t sb_const[GFBE_NFRAMES];
+  uint8_t ex_cam_const, ex_wheel_const, ix_wheel_const, td_const, td_wheel_const;
+  /* PoseSubsetParameterization constancy masks (pose_subset_parameterization.cpp:11-45): tangent
+   * components zeroed in Plus only (the Jacobian stays unmasked — reference quirk, reproduced). */
+  uint8_t ex_cam_mask[6], ex_wheel_mask[6];
+  uint8_t _pad[3];
+  int32_t n_imu;                /* IMU factors; factor k links frames imu_frame[k], imu_frame[k]+1 */
+  const int32_t *imu_frame;
+  const gfbe_imu_preint *imu;
+  int32_t n_wheel;
+  const int32_t *wheel_frame;
+  const gfbe_wheel_preint *wheel;
+  gfbe_visual vis;
+  const gfbe_prior *prior;      /* NULL or !valid => no MarginalizationFactor */
+} gfbe_window;
+
+typedef struct gfbe_options {
+  int32_t max_num_iterations;   /* NUM_ITERATIONS = 8 (m3dgr.yaml:109) */
+  double huber_delta;           /* HuberLoss(1.0)  (estimator.cpp:2959) */
+  double vis_sqrt_info;         /* FOCAL_LENGTH/1.5 = 400 (estimator.cpp:193) */
+  double g_norm;                /* G = (0,0,g_norm) (parameters.cpp:223; m3dgr.yaml:117) */
+  /* Ceres 1.14 Solver::Options defaults the reference leaves untouched (estimator.cpp:3364-3376) */
+  double initial_trust_region_radius; /* 1e4 */
+  double function_tolerance;          /* 1e-6 */
+  double gradient_tolerance;          /* 1e-10 */
+  double parameter_tolerance;         /* 1e-8 */
+  double min_relative_decrease;       /* 1e-3 */
+  int32_t jacobi_scaling;             /* 1 */
+  double marg_eps;                    /* eps = 1e-8, marginalization_factor.h:70 */
+} gfbe_options;
+
+typedef struct gfbe_summary {
+  int32_t status;            /* gfbe_status */
+  int32_t iterations;        /* trust-region iterations run (excluding iteration 0) */
+  int32_t num_successful;    /* accepted steps */
+  int32_t termination;       /* 0 max-iter, 1 function tol, 2 parameter tol, 3 gradient tol, 4 failure */
+  double initial_cost;
+  double final_cost;
+  double final_radius;
+  double cost_history[16];   /* cost after each iteration (accepted or not), [0] = initial */
+  uint8_t accepted[16];      /* accept/reject per iteration */
+} gfbe_summary;
+
+enum { GFBE_MARGIN_OLD = 0, GFBE_MARGIN_SECOND_NEW = 1, GFBE_MARGIN_NONE = 2 };
+
+/* ------------------------------------------------------------------------------------------
+ * Context
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gfbe_ctx gfbe_ctx;
+
+void gfbe_default_options(gfbe_options *opt);
+
+/* device < 0: host-only context (bookkeeping functions only; every compute entry point returns
+ * GFBE_NO_DEVICE). device >= 0: HIP device ordinal; fails with GFBE_NO_DEVICE if absent. */
+gfbe_status gfbe_create(gfbe_ctx **ctx, int device, const gfbe_options *opt);
+void gfbe_destroy(gfbe_ctx *ctx);
+const char *gfbe_last_error(const gfbe_ctx *ctx);
+const char *gfbe_version(void);
+/* Launch kernels on this hipStream_t (e.g. torch's current stream). NULL = the ctx's own stream. */
+gfbe_status gfbe_set_stream(gfbe_ctx *ctx, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a13  Landmark bookkeeping (host, integer, bit-exact):
+ *   FeatureManager::getFeatureCount   feature_manager.cpp:43-55
+ *   FeatureManager::getDepthVector    feature_manager.cpp:286-302
+ *   visual-factor loop                estimator.cpp:3326-3358 (solve) and 3498-3531 (marginalise)
+ * Input is the std::list<FeaturePerId> flattened in list order: feature f has n_obs[f]
+ * observations starting at frame start_frame[f]; obs rows are [x y z u v vx vy] (7 doubles) plus
+ * cur_td, stored contiguously at obs_offset[f].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gfbe_feature_list {
+  int32_t n;                    /* features in the list (all, including used_num < 4) */
+  const int32_t *start_frame;   /* [n] */
+  const int32_t *n_obs;         /* [n] feature_per_frame.size() */
+  const int32_t *obs_offset;    /* [n] first row of this feature in obs / obs_td */
+  const double *obs;            /* [sum n_obs][7]  x y z u v vx vy */
+  const double *obs_td;         /* [sum n_obs]     cur_td */
+  const double *estimated_depth;/* [n] */
+  const int32_t *estimate_flag; /* [n] 1 => depth came from the RGB-D image */
+} gfbe_feature_list;
+
+/* Returns the number of landmarks L (getFeatureCount). */
+int32_t gfbe_feature_count(const gfbe_feature_list *fl);
+/* Counts factors: total (solve) or only landmarks with start_frame == 0 (marginalise). */
+int32_t gfbe_visual_factor_count(const gfbe_feature_list *fl, int32_t only_start_frame0);
+/* Fills caller-allocated arrays (capacity from the two functions above); returns K written.
+ * para_Feature/feature_const have capacity L. */
+int32_t gfbe_build_visual_factors(const gfbe_feature_list *fl, int32_t only_start_frame0,
+                                  int32_t *feature_index, int32_t *imu_i, int32_t *imu_j,
+                                  double *pts_i, double *pts_j, double *vel_i, double *vel_j,
+                                  double *td_i, double *td_j,
+                                  double *para_Feature, uint8_t *feature_const);
+/* FeatureManager::setDepth (feature_manager.cpp:249-267): solve_flag[f] = 0 untouched,
+ * 1 ok, 2 failed (negative depth); estimated_depth updated for landmarks with used_num >= 4. */
+void gfbe_set_depth(const gfbe_feature_list *fl, const double *para_Feature,
+                    double *estimated_depth, int32_t *solve_flag);
+
+/* ------------------------------------------------------------------------------------------
+ * a4/a5/a7/a9/a10  Factor evaluation on the device, block-CSR output (parity / inspection API).
+ * Each evaluates residuals and TANGENT-space Jacobian blocks at the window's current state,
+ * exactly what ceres::CostFunction::Evaluate + the manifold lift produce:
+ *   ProjectionTwoFrameOneCamFactor::Evaluate  projectionTwoFrameOneCamFactor.cpp:43-151
+ *   IMUFactor::Evaluate                       imu_factor.h:28-191
+ *   WheelFactor::Evaluate                     wheel_factor.h:28-247
+ *   MarginalizationFactor::Evaluate           marginalization_factor.cpp:344-392
+ * robustify != 0 additionally applies the loss corrector of ResidualBlockInfo::Evaluate
+ * (marginalization_factor.cpp:46-77) to the visual blocks.
+ * Output layouts (host, row-major):
+ *   vis_r [K][2]; vis_J [K][2][20]  columns = pose_i(6) pose_j(6) ex_cam(6) lambda(1) td(1)
+ *   imu_r [n_imu][15]; imu_J [n_imu][15][30]  columns = pose_i(6) sb_i(9) pose_j(6) sb_j(9)
+ *   wheel_r [n_wheel][6]; wheel_J [n_wheel][6][22] columns = pose_i(6) pose_j(6) ex_wheel(6) sx sy sw td_wheel
+ *   prior_r [n]; prior_J is J0 itself (constant), not returned.
+ * Any output pointer may be NULL to skip that factor family.
+ * ------------------------------------------------------------------------------------------ */
+gfbe_status gfbe_eval_factors(gfbe_ctx *ctx, const gfbe_window *win, int32_t robustify,
+                              double *vis_r, double *vis_J,
+                              double *imu_r, double *imu_J,
+                              double *wheel_r, double *wheel_J,
+                              double *prior_r, double *cost);
+
+/* ------------------------------------------------------------------------------------------
+ * a6/a8  Pre-integration on the device (the producers of gfbe_imu_preint / gfbe_wheel_preint):
+ *   IntegrationBase::push_back/propagate/midPointIntegration   integration_base.h:39-167
+ *   WheelIntegrationBase::push_back/propagate/midPointIntegration wheel_integration_base.h:41-178
+ * n_interval independent intervals; interval k owns samples [offset[k], offset[k+1]).
+ * Sample rows: IMU [dt ax ay az gx gy gz], wheel [dt vx vy vz gx gy gz]. first_* is the
+ * (acc_0,gyr_0)/(vel_0,gyr_0) the interval was constructed with. noise: ACC_N GYR_N ACC_W GYR_W
+ * (integration_base.h:30-36) / VEL_N_wheel GYR_N_wheel (wheel_integration_base.h:32-36).
+ * ------------------------------------------------------------------------------------------ */
+gfbe_status gfbe_preintegrate_imu(gfbe_ctx *ctx, int32_t n_interval, const int32_t *offset,
+                                  const double *samples, const double *first_acc_gyr /*[n][6]*/,
+                                  const double *lin_ba_bg /*[n][6]*/, const double noise[4],
+                                  gfbe_imu_preint *out);
+gfbe_status gfbe_preintegrate_wheel(gfbe_ctx *ctx, int32_t n_interval, const int32_t *offset,
+                                    const double *samples, const double *first_vel_gyr /*[n][6]*/,
+                                    const double *lin_sx_sy_sw_td /*[n][4]*/, const double noise[2],
+                                    gfbe_wheel_preint *out);
+
+/* ------------------------------------------------------------------------------------------
+ * a1/a2/a3/a11/a12  The whole optimization() call.
+ *   solve:        ceres::Solve with DENSE_SCHUR + DOGLEG + HuberLoss   estimator.cpp:2956-3379
+ *   write-back:   double2vector() yaw/position re-anchoring            estimator.cpp:2501-2630
+ *   marginalise:  MARGIN_OLD / MARGIN_SECOND_NEW                       estimator.cpp:3394-3693,
+ *                 MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks}
+ *                                                                      marginalization_factor.cpp:119-330
+ * out_state / out_feature receive the re-anchored parameter blocks (what a second vector2double()
+ * would produce, estimator.cpp:3398) — outputs are untouched when status is an error.
+ * prior_out (may be NULL when margin_flag == GFBE_MARGIN_NONE) receives the new prior with block
+ * ids already shifted (slot i -> i-1 for MARGIN_OLD; slot 10 -> 9 for SECOND_NEW).
+ * ------------------------------------------------------------------------------------------ */
+gfbe_status gfbe_solve_window(gfbe_ctx *ctx, const gfbe_window *win, int32_t margin_flag,
+                              gfbe_state *out_state, double *out_feature,
+                              gfbe_prior *prior_out, gfbe_summary *summary);
+
+/* Batched form: n independent windows, one launch sequence. Arrays are per-window. */
+gfbe_status gfbe_solve_batch(gfbe_ctx *ctx, int32_t n_window, const gfbe_window *const *win,
+                             int32_t margin_flag, gfbe_state *out_state, double *const *out_feature,
+                             gfbe_prior *const *prior_out, gfbe_summary *summary);
+
+/* Device-resident form used for throughput measurement: upload once, (re)solve many times.
+ *   gfbe_batch_upload   packs the windows into the device layout
+ *   gfbe_batch_solve    resets every window to its uploaded state, then runs the full
+ *                       optimization() sequence on the ctx stream; asynchronous, no host sync
+ *   gfbe_batch_download copies results back (synchronises)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gfbe_batch gfbe_batch;
+gfbe_status gfbe_batch_upload(gfbe_ctx *ctx, int32_t n_window, const gfbe_window *const *win,
+                              gfbe_batch **batch);
+gfbe_status gfbe_batch_solve(gfbe_ctx *ctx, gfbe_batch *batch, int32_t margin_flag);
+gfbe_status gfbe_batch_download(gfbe_ctx *ctx, gfbe_batch *batch, gfbe_state *out_state,
+                                double *const *out_feature, gfbe_prior *const *prior_out,
+                                gfbe_summary *summary);
+void gfbe_batch_free(gfbe_ctx *ctx, gfbe_batch *batch);
+
+/* Measurement hooks (bench.py): name/launch count/accumulated GPU milliseconds of each kernel
+ * family since the last reset, measured with hipEvents on the ctx stream when profiling is on. */
+gfbe_status gfbe_profile_enable(gfbe_ctx *ctx, int32_t on);
+int32_t gfbe_profile_count(const gfbe_ctx *ctx);
+gfbe_status gfbe_profile_get(const gfbe_ctx *ctx, int32_t i, const char **name, int64_t *launches,
+                             double *total_ms, double *algorithmic_bytes);
+void gfbe_profile_reset(gfbe_ctx *ctx);
+
+/* Multi-GPU landmark sharding: when set, the library calls
+ * fn(user, device_ptr, n_doubles, hip_stream) once per linearisation on the packed partial reduced
+ * system [S | g | cost ...]; the callee performs an in-place sum all-reduce (RCCL) on that stream. */
+typedef void (*gfbe_allreduce_fn)(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);
+gfbe_status gfbe_set_allreduce(gfbe_ctx *ctx, gfbe_allreduce_fn fn, void *user, int32_t rank,
+                               int32_t world_size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFBE_H_ */

@@ -1,0 +1,149 @@
+"""Independent numpy re-derivation of the four residual models (SURVEY.md Appendix B equations,
+rotation-matrix form) cross-checked against the C++ oracle at 1e-12 (SURVEY.md §8c item ii), and
+of the two pre-integrators (synth.preintegrate_*_np, written from integration_base.h:63-137 /
+wheel_integration_base.h:67-146) against oracle/gfo_preint.cpp."""
+import numpy as np
+import pytest
+
+from _gfbe_import import gf
+
+abi, synth = gf.abi, gf.synth
+R = synth.qrot
+
+
+def np_visual(snap, k):
+    i, j, l = snap["vis_imu_i"][k], snap["vis_imu_j"][k], snap["vis_feature_index"][k]
+    Pi, Ri = snap["pose"][i, :3], R(snap["pose"][i, 3:])
+    Pj, Rj = snap["pose"][j, :3], R(snap["pose"][j, 3:])
+    tic, ric = snap["ex_pose"][:3], R(snap["ex_pose"][3:])
+    td, lam = snap["td"], snap["para_feature"][l]
+    pi = snap["vis_pts_i"][k] - (td - snap["vis_td_i"][k]) * np.append(snap["vis_vel_i"][k], 0)
+    pj = snap["vis_pts_j"][k] - (td - snap["vis_td_j"][k]) * np.append(snap["vis_vel_j"][k], 0)
+    pc = ric.T @ (Rj.T @ (Ri @ (ric @ (pi / lam) + tic) + Pi - Pj) - tic)
+    return 400.0 * (pc[:2] / pc[2] - pj[:2])
+
+
+def np_imu_raw(snap, k, g=synth.G_NORM):
+    rec = snap["imu"][k]
+    dt, dp, dq, dv, lba, lbg = rec[0], rec[1:4], rec[4:8], rec[8:11], rec[11:14], rec[14:17]
+    Jm = rec[17:17 + 225].reshape(15, 15)
+    i = snap["imu_frame"][k]
+    Pi, qi, Pj, qj = snap["pose"][i, :3], snap["pose"][i, 3:], snap["pose"][i + 1, :3], snap["pose"][i + 1, 3:]
+    Vi, Bai, Bgi = np.split(snap["speed_bias"][i], 3)
+    Vj, Baj, Bgj = np.split(snap["speed_bias"][i + 1], 3)
+    dba, dbg = Bai - lba, Bgi - lbg
+    th = Jm[3:6, 12:15] @ dbg
+    dqc = np.append(th / 2, 1.0)
+    cq = synth.qmul(dq, dqc / np.linalg.norm(dqc))
+    cv = dv + Jm[6:9, 9:12] @ dba + Jm[6:9, 12:15] @ dbg
+    cp = dp + Jm[0:3, 9:12] @ dba + Jm[0:3, 12:15] @ dbg
+    G = np.array([0, 0, g])
+    RiT = R(qi).T
+    rp = RiT @ (0.5 * G * dt * dt + Pj - Pi - Vi * dt) - cp
+    rq = 2 * synth.qmul(synth.qinv(cq), synth.qmul(synth.qinv(qi), qj))[:3]
+    rv = RiT @ (G * dt + Vj - Vi) - cv
+    cov = rec[17 + 225:].reshape(15, 15)
+    return np.concatenate([rp, rq, rv, Baj - Bai, Bgj - Bgi]), cov
+
+
+def np_wheel_raw(snap, k):
+    rec = snap["wheel"][k]
+    dp, dq = rec[1:4], rec[4:8]
+    lsx, lsy, lsw, ltd = rec[8:12]
+    lin_vel, lin_gyr, vel_1, gyr_1 = rec[12:15], rec[15:18], rec[18:21], rec[21:24]
+    Jm = rec[24:42].reshape(6, 3)
+    cov = rec[42:78].reshape(6, 6)
+    i = snap["wheel_frame"][k]
+    Pi, Ri, Pj, Rj = snap["pose"][i, :3], R(snap["pose"][i, 3:]), snap["pose"][i + 1, :3], R(snap["pose"][i + 1, 3:])
+    tio, Rio = snap["ex_pose_wheel"][:3], R(snap["ex_pose_wheel"][3:])
+    sx, sy, sw = snap["ix_wheel"]
+    sv = np.diag([sx, sy, 1.0])
+    cp = dp + Jm[0:3, 0] * (sx - lsx) + Jm[0:3, 1] * (sy - lsy) + Jm[0:3, 2] * (sw - lsw)
+    Rcq = R(dq / np.linalg.norm(dq)) @ R(synth.so3_exp(Jm[3:6, 2] * (sw - lsw)))
+    dtd = snap["td_wheel"] - ltd
+    Ef, Eb = R(synth.so3_exp(sw * lin_gyr * dtd)), R(synth.so3_exp(-sw * gyr_1 * dtd))
+    Rt = Ef @ Rcq @ Eb
+    pt = Ef @ (sv @ lin_vel * dtd + cp - Rcq @ sv @ vel_1 * dtd)
+    rp = (Ri @ Rio).T @ (Rj @ tio + Pj - Ri @ tio - Pi) - pt
+    Rres = Rt.T @ (Ri @ Rio).T @ Rj @ Rio
+    rq = synth.so3_log(synth.rot2q(Rres))
+    return np.concatenate([rp, rq]), cov
+
+
+@pytest.fixture(scope="module")
+def snap():
+    scn = synth.Scenario(seed=21, n_landmarks=60, use_wheel=True)
+    s = scn.window(0)
+    s["ix_wheel"] = np.array([1.01, 0.99, 1.015])
+    s["td"], s["td_wheel"] = 0.002, 0.003
+    return s
+
+
+def test_numpy_visual(oracle, snap):
+    ev = oracle.eval_factors(snap)
+    mine = np.array([np_visual(snap, k) for k in range(len(snap["vis_imu_i"]))])
+    np.testing.assert_allclose(ev["vis_r"], mine, rtol=0, atol=1e-10 * max(1, np.abs(mine).max()))
+
+
+def test_numpy_imu(oracle, snap):
+    ev = oracle.eval_factors(snap)
+    for k in range(len(snap["imu_frame"])):
+        raw, cov = np_imu_raw(snap, k)
+        L = np.linalg.cholesky(np.linalg.inv(cov))
+        want = L.T @ raw
+        # sqrt_info comes from inverting a covariance with condition ~1e12: compare the
+        # information-weighted norm tightly and the vector loosely
+        assert abs(ev["imu_r"][k] @ ev["imu_r"][k] - raw @ np.linalg.solve(cov, raw)) < 1e-6 * (want @ want)
+        np.testing.assert_allclose(ev["imu_r"][k], want, rtol=0, atol=1e-5 * np.abs(want).max())
+
+
+def test_numpy_wheel(oracle, snap):
+    ev = oracle.eval_factors(snap)
+    for k in range(len(snap["wheel_frame"])):
+        raw, cov = np_wheel_raw(snap, k)
+        want = np.linalg.cholesky(np.linalg.inv(cov)).T @ raw
+        np.testing.assert_allclose(ev["wheel_r"][k], want, rtol=0, atol=1e-8 * np.abs(want).max())
+
+
+def test_sqrt_info_identity(oracle, snap):
+    """sqrt_info^T sqrt_info == cov^-1 (imu_factor.h:73)."""
+    cov = snap["imu"][0][17 + 225:].reshape(15, 15)
+    S = oracle.sqrt_info(cov)
+    assert np.allclose(np.triu(S), S)
+    M = S.T @ S @ cov
+    assert np.abs(M - np.eye(15)).max() < 1e-6
+
+
+def test_preintegration_matches_numpy(oracle):
+    scn = synth.Scenario(seed=3, n_landmarks=5, use_wheel=True)
+    got = oracle.preintegrate_imu(scn.imu_raw[:4], scn.ba_est, scn.bg_est, [synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W])
+    want = np.array(scn.imu_rec[:4])
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-16)
+    gotw = oracle.preintegrate_wheel(scn.wheel_raw[:4], [1.0, 1.0, 1.0, 0.0], [synth.VEL_N_WHEEL, synth.GYR_N_WHEEL])
+    wantw = np.array(scn.wheel_rec[:4])
+    np.testing.assert_allclose(gotw, wantw, rtol=1e-9, atol=1e-16)
+
+
+def test_preintegration_predicts_truth():
+    """Noise-free mid-point pre-integration reproduces the true relative motion (sanity of the
+    generator + of the IMU residual definition, integration_base.h:186-193)."""
+    scn = synth.Scenario(seed=4, n_landmarks=5, use_wheel=True, noise=False)
+    s = scn.window(0, state=scn.truth_state(0))
+    s["speed_bias"][:, 3:6], s["speed_bias"][:, 6:9] = scn.ba_est, scn.bg_est
+    for k in range(10):
+        raw, _ = np_imu_raw(s, k)
+        assert np.abs(raw[:9]).max() < 5e-6
+        rw, _ = np_wheel_raw(s, k)
+        assert np.abs(rw).max() < 5e-6
+
+
+def test_sym_eig_against_numpy(oracle):
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 40, 120):
+        B = rng.normal(size=(n, n))
+        A = B @ B.T * np.logspace(0, -6, n)[None, :]
+        A = 0.5 * (A + A.T)
+        w, V = oracle.sym_eig(A)
+        np.testing.assert_allclose(w, np.linalg.eigvalsh(A), rtol=0, atol=1e-11 * np.abs(w).max())
+        assert np.abs(V.T @ V - np.eye(n)).max() < 1e-11
+        assert np.abs(V @ np.diag(w) @ V.T - A).max() < 1e-11 * max(1.0, np.abs(A).max())
