@@ -335,7 +335,7 @@ static void solve(const Problem &P, Solution &sol) {
   int it = 0;
   while (true) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue
-    if (it >= o.max_num_iterations) { S.termination = 0; break; }
+    if (it >= std::min(o.max_num_iterations, 15)) { S.termination = 0; break; }   // summary arrays hold 16 entries
     if (grad_max() <= o.gradient_tolerance) { S.termination = 3; S.status = GFBE_OK; break; }
     if (radius < 1e-32) { S.termination = 4; break; }
     it++;
