@@ -1,0 +1,192 @@
+// gfbe_device.h — HBM data layout of a batch of sliding windows + kernel launch prototypes.
+// Shared by the host side (gfbe_host.cpp) and the kernels (gfbe_kernels.hip, gfbe_marg.hip).
+// See DESIGN.md §3 for the rationale; names follow the reference's domain (window, landmark,
+// factor, prior), file:line citations are to Ground-Fusion++/vins_estimator/src/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gfbe.h"
+
+namespace gfd {
+
+// ---- dimensions -----------------------------------------------------------------------------
+enum {
+  NF = GFBE_NFRAMES,          // 11 frames
+  ND = GFBE_DENSE_DIM,        // 182 tangent dims of the dense (pose/IMU/extrinsic) block
+  NV = 73,                    // leading dims visual factors touch: 11 poses * 6 + ex_cam 6 + td 1
+  NA = 195,                   // ambient doubles of gfbe_state
+  MAXOBS = 10,                // factors per landmark (n_obs - 1)
+  REC = 42,                   // doubles per visual block-CSR record: r(2) + J(2 x 20)   = 336 B
+  NPAIR = NF * NF,            // (imu_i, imu_j) pair slots, index i * 11 + j
+  PAIR_E = 19 * 20 / 2 + 19,  // 190 J^T J entries + 19 J^T r entries of a pose-pair block = 209
+  PAIR_STRIDE = 216,
+  TRI_NV = NV * (NV + 1) / 2, // 2701
+  SCHUR_STRIDE = TRI_NV + NV + 2,   // E (packed) + e_g + pad = 2776
+  LM_TILE = 64,               // landmarks per workgroup in the landmark kernels
+  SCHUR_CHUNK = 64,           // landmarks per Schur work item
+  IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost
+  WHEEL_PART = 22 * 22 + 22 + 2,
+  MAX_IMU = 10, MAX_WHEEL = 10,
+  HC = 13                     // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
+};
+
+// tangent offsets (same convention as the ABI's block order)
+__host__ __device__ inline int T_POSE(int k) { return 6 * k; }
+enum { T_EX = 66, T_TD = 72, T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181 };
+__host__ __device__ inline int T_SB(int k) { return 73 + 9 * k; }
+// ambient offsets inside gfbe_state (195 doubles)
+__host__ __device__ inline int A_POSE(int k) { return 7 * k; }
+__host__ __device__ inline int A_SB(int k) { return 77 + 9 * k; }
+enum { A_EX = 176, A_EXW = 183, A_IX = 190, A_TD = 193, A_TDW = 194 };
+
+__host__ __device__ inline int blk_tan(int id) {
+  if (id < GFBE_BLK_SB0) return T_POSE(id);
+  if (id < GFBE_BLK_EX_CAM) return T_SB(id - GFBE_BLK_SB0);
+  switch (id) {
+    case GFBE_BLK_EX_CAM: return T_EX;
+    case GFBE_BLK_EX_WHEEL: return T_EXW;
+    case GFBE_BLK_SX: return T_SX;
+    case GFBE_BLK_SY: return T_SY;
+    case GFBE_BLK_SW: return T_SW;
+    case GFBE_BLK_TD: return T_TD;
+    default: return T_TDW;
+  }
+}
+__host__ __device__ inline int blk_amb(int id) {
+  if (id < GFBE_BLK_SB0) return A_POSE(id);
+  if (id < GFBE_BLK_EX_CAM) return A_SB(id - GFBE_BLK_SB0);
+  switch (id) {
+    case GFBE_BLK_EX_CAM: return A_EX;
+    case GFBE_BLK_EX_WHEEL: return A_EXW;
+    case GFBE_BLK_SX: return A_IX;
+    case GFBE_BLK_SY: return A_IX + 1;
+    case GFBE_BLK_SW: return A_IX + 2;
+    case GFBE_BLK_TD: return A_TD;
+    default: return A_TDW;
+  }
+}
+__host__ __device__ inline int blk_gsize(int id) {
+  if (id < GFBE_BLK_SB0) return 7;
+  if (id < GFBE_BLK_EX_CAM) return 9;
+  if (id == GFBE_BLK_EX_CAM || id == GFBE_BLK_EX_WHEEL) return 7;
+  return 1;
+}
+__host__ __device__ inline int blk_lsize(int id) { const int g = blk_gsize(id); return g == 7 ? 6 : g; }
+
+// ---- per-window descriptor (constant during a solve) ----------------------------------------
+struct WinDesc {
+  int L, K;                  // landmarks, visual factors
+  int lm_off;                // first landmark slot of this window in the per-landmark arrays (64-aligned)
+  int lm_slots;              // padded landmark slots (multiple of LM_TILE; start-frame groups are tile aligned)
+  int rec_off;               // first visual record
+  int n_tiles;               // lm_slots / LM_TILE
+  int tile_off;              // first entry of this window in tile_start[] (start frame of each tile)
+  int n_imu, n_wheel;
+  int imu_off, wheel_off;    // into the batch-wide preintegration arrays
+  int imu_frame[MAX_IMU], wheel_frame[MAX_WHEEL];
+  int prior_n, prior_nblk;   // 0 => no prior
+  int prior_blk_id[GFBE_MAX_PRIOR_BLOCKS], prior_blk_size[GFBE_MAX_PRIOR_BLOCKS], prior_blk_idx[GFBE_MAX_PRIOR_BLOCKS];
+  int prior_x0_off[GFBE_MAX_PRIOR_BLOCKS];
+  int prior_map[ND];         // tangent dim -> prior column (-1 if none)
+  int frame_count;
+  int pair_begin[NPAIR + 1]; // records of pair (i,j) are [pair_begin[i*11+j], pair_begin[i*11+j+1]) relative to rec_off
+  int sf_tile_begin[NF + 1]; // tiles of start frame s are [sf_tile_begin[s], sf_tile_begin[s+1])
+  unsigned char act[ND];     // tangent dim is in the reduced program (not constant, touched by a factor)
+  unsigned char blk_free[GFBE_BLK_COUNT];
+  unsigned char ex_cam_mask[6], ex_wheel_mask[6];
+  unsigned char pad_[3];
+};
+
+// ---- per-window solver state (mutated by kernels; mirrors TrustRegionMinimizer + DoglegStrategy)
+struct WinCtl {
+  int cur;                   // index (0/1) of the current parameter buffer; 1-cur is the candidate
+  int iter;                  // trust-region iterations started
+  int done;                  // solve finished
+  int reuse;                 // DoglegStrategy::reuse_ : GN/Cauchy vectors valid, only the radius changed
+  int have_step;             // k_step produced a valid candidate this iteration
+  int num_successful, termination, status, invalid_steps, lin_fail;
+  int n_clamped;
+  int pad0;
+  double radius, mu, cost, cand_cost, x_norm, cand_norm2, step_amb2;
+  double G2, N2, gy, vHv, vHy, yHy, alpha, grad_max;
+  double c1, c2, step_norm, model_change;
+  double initial_cost;
+  double cost_history[16];
+  unsigned char accepted[16];
+};
+
+// ---- batch: all device pointers ----------------------------------------------------------------
+struct BatchDev {
+  int B;
+  int tot_lm;                 // total padded landmark slots
+  int max_tiles;              // max n_tiles over windows
+  WinDesc *desc;              // [B]
+  WinCtl *ctl;                // [B]
+  gfbe_options opt;
+  // dense parameters: x0 = uploaded state, x[2] = current/candidate, xout = re-anchored result
+  double *x0, *x, *xout;      // [B][NA], [B][2][NA], [B][NA]
+  // landmarks (internal order: sorted by start frame, tile aligned). SoA over tot_lm slots.
+  int *lm_info;               // start | m << 8 | const << 16 | valid << 24
+  int *lm_abi;                // ABI feature_index of the slot (-1 for padding)
+  double *lm_pts;             // [6][tot_lm]: pix piy piz vix viy td_i
+  double *lm_obs;             // [MAXOBS][5][tot_lm]: pjx pjy vjx vjy td_j
+  int *lm_rec;                // [MAXOBS][tot_lm]: record position (relative to rec_off) of factor k
+  double *lam0, *lam;         // [tot_lm], [2][tot_lm]
+  double *lm_Hll, *lm_gl;     // [tot_lm]
+  double *lm_hC;              // [HC][tot_lm]
+  double *lm_hP;              // [MAXOBS][6][tot_lm]
+  double *lm_sl, *lm_yl, *lm_vl;   // Jacobi scale, GN component, Cauchy direction component
+  // visual block-CSR records, pair-major: [tot_rec][REC]
+  double *rec;
+  int tot_rec;
+  int *tile_start;            // start frame per tile (batch-wide list)
+  // factor inputs
+  gfbe_imu_preint *imu; gfbe_wheel_preint *wheel;
+  double *imu_sqrt, *wheel_sqrt;     // [n][225], [n][36]
+  double *prior_J0, *prior_r0, *prior_x0, *prior_H;   // [B][ND*ND], [B][ND], [B][PRIOR_X0], [B][ND*ND]
+  // partial results
+  double *pair_part;          // [B][NPAIR][PAIR_STRIDE]
+  double *schur_part;         // [B][max_tiles][SCHUR_STRIDE]
+  double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
+  double *prior_g;            // [B][ND + 2]  J0^T r, cost
+  double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
+  double *tile_cand;          // [B][max_tiles][4] candidate: cost, |x-xc|^2, |xc|^2, pad
+  double *tile_gram;          // [B][max_tiles][8] landmark parts of G2 N2 gy vHv vHy yHy gradmax
+  double *dense_cand;         // [B][4] dense-factor candidate cost, |x-xc|^2, |xc|^2
+  // assembled system
+  double *H, *g;              // [B][ND*ND], [B][ND]  unscaled J^T J, J^T r of the dense block
+  double *E, *eg;             // [B][NV*NV], [B][NV]  sum_l w_l h_l h_l^T, sum_l w_l h_l gl  (unscaled h)
+  double *S;                  // [B][ND*ND]  scaled, regularised, Schur-reduced system / its Cholesky factor
+  double *sp, *Dp, *gts, *vp, *yp, *step;   // [B][ND] each
+  // debug / inspection outputs (gfbe_eval_factors)
+  double *dbg_imu, *dbg_wheel, *dbg_prior;  // [B][MAX_IMU][15*31], [B][MAX_WHEEL][6*23], [B][ND]
+  // marginalisation
+  double *mA, *mb;            // [B][ND*ND], [B][ND]
+  double *mJ0, *mr0;          // [B][ND*ND], [B][ND]
+  double *mV;                 // [B][ND*ND] eigenvectors scratch
+  int *mmeta;                 // [B][4 + 3*GFBE_MAX_PRIOR_BLOCKS]: valid, n, n_blocks, pad, ids, sizes, idx
+  double *mx0;                // [B][PRIOR_X0]
+  int *tri_tab;               // [TRI_NV] packed (a' << 8 | b') lookup for the reversed lower-triangular enumeration
+};
+
+enum { PRIOR_X0 = GFBE_NFRAMES * 16 + 32 };
+
+// ---- kernel launchers (gfbe_kernels.hip / gfbe_marg.hip) -------------------------------------------
+void launch_prep(const BatchDev &d, hipStream_t s);
+void launch_reset(const BatchDev &d, hipStream_t s);
+// mode 0: linearise at the current parameters (writes records, landmark sums, cost partials)
+// mode 1: candidate cost only   mode 2: linearise the marginalisation set at xout (start frame 0 only)
+void launch_vis(const BatchDev &d, int mode, hipStream_t s);
+void launch_pair(const BatchDev &d, int marg, hipStream_t s);
+void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
+void launch_schur(const BatchDev &d, int marg, hipStream_t s);
+void launch_assemble(const BatchDev &d, hipStream_t s);
+void launch_solve(const BatchDev &d, hipStream_t s);
+void launch_lm_step(const BatchDev &d, hipStream_t s);
+void launch_step(const BatchDev &d, hipStream_t s);
+void launch_candidate(const BatchDev &d, hipStream_t s);
+void launch_accept(const BatchDev &d, hipStream_t s);
+void launch_reanchor(const BatchDev &d, hipStream_t s);
+void launch_marginalize(const BatchDev &d, int flag, hipStream_t s);
+
+}  // namespace gfd

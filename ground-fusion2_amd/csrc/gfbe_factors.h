@@ -1,0 +1,326 @@
+// gfbe_factors.h — residual + analytic tangent-space Jacobian of the four factor families, as
+// __host__ __device__ functions used by the HIP kernels (gfbe_kernels.hip). Reference semantics:
+//   visual  Ground-Fusion++/vins_estimator/src/factor/projectionTwoFrameOneCamFactor.cpp:43-151
+//   IMU     Ground-Fusion++/vins_estimator/src/factor/imu_factor.h:28-191, integration_base.h:169-195
+//   wheel   Ground-Fusion++/vins_estimator/src/factor/wheel_factor.h:28-247, wheel_integration_base.h:180-219
+//   prior   Ground-Fusion++/vins_estimator/src/factor/marginalization_factor.cpp:344-392
+//   robust-loss corrector  marginalization_factor.cpp:46-77 (ceres::HuberLoss)
+// Tangent-space Jacobian of a pose block = first 6 columns of the 7-wide global block
+// (pose_local_parameterization.cpp:27-34).
+#pragma once
+#include "gfbe_math.h"
+#include "../../include/gfbe.h"
+
+namespace gfd {
+
+// A pose staged for factor evaluation: translation + rotation matrix (computed once per
+// workgroup into LDS instead of once per factor as the reference does, :83-85).
+struct PoseRT {
+  vec3 t;
+  mat3 R;
+};
+GF_HD PoseRT make_pose(const double *p7) {
+  PoseRT o;
+  o.t = ld3(p7);
+  o.R = qrot(ldq(p7 + 3));
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Visual factor. Outputs r[2]; if JAC: Ji/Jj/Je [2][6] row-major, Jl[2] (d/d inverse depth), Jt[2].
+// ---------------------------------------------------------------------------------------------
+template <bool JAC>
+GF_HD void visual_eval(const PoseRT &Fi, const PoseRT &Fj, const PoseRT &Ex, double inv_dep, double td,
+                       double pix, double piy, double piz, double pjx, double pjy,
+                       double vix, double viy, double vjx, double vjy, double td_i, double td_j, double sqrt_info,
+                       double *r, double *Ji, double *Jj, double *Je, double *Jl, double *Jt) {
+  const double dti = td - td_i, dtj = td - td_j;
+  const vec3 pi_td = mk3(pix - dti * vix, piy - dti * viy, piz);
+  const double pjx_td = pjx - dtj * vjx, pjy_td = pjy - dtj * vjy;
+  const double inv_l = 1.0 / inv_dep;
+  const vec3 p_ci = scl(inv_l, pi_td);
+  const vec3 p_bi = add(mv(Ex.R, p_ci), Ex.t);
+  const vec3 p_w = add(mv(Fi.R, p_bi), Fi.t);
+  const vec3 p_bj = tmv(Fj.R, sub(p_w, Fj.t));
+  const vec3 p_cj = tmv(Ex.R, sub(p_bj, Ex.t));
+  const double dep = p_cj[2];
+  const double inv_z = 1.0 / dep;
+  r[0] = sqrt_info * (p_cj[0] * inv_z - pjx_td);
+  r[1] = sqrt_info * (p_cj[1] * inv_z - pjy_td);
+  if (!JAC) return;
+  // reduce = sqrt_info * d(pi(P))/dP   (:97-101)
+  const double r00 = sqrt_info * inv_z, r02 = -sqrt_info * p_cj[0] * inv_z * inv_z;
+  const double r11 = sqrt_info * inv_z, r12 = -sqrt_info * p_cj[1] * inv_z * inv_z;
+  // A = ric^T Rj^T ; B = A Ri
+  const mat3 A = tmul(Ex.R, transp(Fj.R));
+  const mat3 B = mul(A, Fi.R);
+  const mat3 Tm = mul(B, Ex.R);                       // ric^T Rj^T Ri ric  (:129)
+  const mat3 ji_r = mneg(mul(B, hat(p_bi)));          // :107
+  const mat3 jj_r = tmul(Ex.R, hat(p_bj));            // :119
+  const mat3 je_p = tmul(Ex.R, msub(tmul(Fj.R, Fi.R), ident3()));   // :128
+  const vec3 Tp = mv(Tm, p_ci);
+  const vec3 lev = tmv(Ex.R, sub(tmv(Fj.R, sub(add(mv(Fi.R, Ex.t), Fi.t), Fj.t)), Ex.t));
+  const mat3 je_r = madd(madd(mneg(mul(Tm, hat(p_ci))), hat(Tp)), hat(lev));   // :130-131
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    Ji[c] = r00 * A(0, c) + r02 * A(2, c);          Ji[6 + c] = r11 * A(1, c) + r12 * A(2, c);
+    Ji[3 + c] = r00 * ji_r(0, c) + r02 * ji_r(2, c); Ji[9 + c] = r11 * ji_r(1, c) + r12 * ji_r(2, c);
+    Jj[c] = -Ji[c];                                  Jj[6 + c] = -Ji[6 + c];
+    Jj[3 + c] = r00 * jj_r(0, c) + r02 * jj_r(2, c); Jj[9 + c] = r11 * jj_r(1, c) + r12 * jj_r(2, c);
+    Je[c] = r00 * je_p(0, c) + r02 * je_p(2, c);     Je[6 + c] = r11 * je_p(1, c) + r12 * je_p(2, c);
+    Je[3 + c] = r00 * je_r(0, c) + r02 * je_r(2, c); Je[9 + c] = r11 * je_r(1, c) + r12 * je_r(2, c);
+  }
+  const vec3 tl = scl(-inv_l * inv_l, mv(Tm, pi_td));              // :139
+  Jl[0] = r00 * tl[0] + r02 * tl[2];
+  Jl[1] = r11 * tl[1] + r12 * tl[2];
+  const vec3 tt = scl(-inv_l, mv(Tm, mk3(vix, viy, 0.0)));         // :144
+  Jt[0] = r00 * tt[0] + r02 * tt[2] + sqrt_info * vjx;             // :145
+  Jt[1] = r11 * tt[1] + r12 * tt[2] + sqrt_info * vjy;
+}
+
+// ceres::HuberLoss::Evaluate
+GF_HD void huber_rho(double s, double delta, double *rho) {
+  const double b = delta * delta;
+  if (s > b) {
+    const double rt = sqrt(s);
+    rho[0] = 2.0 * delta * rt - b;
+    const double r1 = delta / rt;
+    rho[1] = r1 > 2.2250738585072014e-308 ? r1 : 2.2250738585072014e-308;
+    rho[2] = -rho[1] / (2.0 * s);
+  } else {
+    rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+// Corrector coefficients (marginalization_factor.cpp:57-70): J <- sqrt_rho1 (J - alpha_sq_norm r r^T J),
+// r <- residual_scaling r. Returns 0.5 rho(s).
+GF_HD double corrector(double s, double delta, double *sqrt_rho1, double *residual_scaling, double *alpha_sq_norm) {
+  double rho[3];
+  huber_rho(s, delta, rho);
+  *sqrt_rho1 = sqrt(rho[1]);
+  if (s == 0.0 || rho[2] <= 0.0) {
+    *residual_scaling = *sqrt_rho1;
+    *alpha_sq_norm = 0.0;
+  } else {
+    const double D = 1.0 + 2.0 * s * rho[2] / rho[1];
+    const double alpha = 1.0 - sqrt(D);
+    *residual_scaling = *sqrt_rho1 / (1.0 - alpha);
+    *alpha_sq_norm = alpha / s;
+  }
+  return 0.5 * rho[0];
+}
+// Apply to a 2-row block with columns given as separate row arrays.
+GF_HD void correct_cols(double *row0, double *row1, int n, double r0, double r1, double sqrt_rho1, double asn) {
+  for (int c = 0; c < n; c++) {
+    const double rtj = r0 * row0[c] + r1 * row1[c];
+    row0[c] = sqrt_rho1 * (row0[c] - asn * r0 * rtj);
+    row1[c] = sqrt_rho1 * (row1[c] - asn * r1 * rtj);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:73, wheel_factor.h:85): partial-pivot LU inverse
+// (Eigen's inverse() for n > 4) followed by a lower Cholesky. Single-thread, n <= 15.
+// work: 2*n*n doubles. Returns 0 on success.
+// ---------------------------------------------------------------------------------------------
+GF_HD int sqrt_info_from_cov(const double *cov, int n, double *out, double *work) {
+  double *lu = work, *inv = work + n * n;
+  int perm[15];
+  for (int i = 0; i < n * n; i++) lu[i] = cov[i];
+  for (int i = 0; i < n; i++) perm[i] = i;
+  for (int k = 0; k < n; k++) {
+    int piv = k;
+    double best = fabs(lu[k * n + k]);
+    for (int i = k + 1; i < n; i++) { const double a = fabs(lu[i * n + k]); if (a > best) { best = a; piv = i; } }
+    if (best == 0.0) return 1;
+    if (piv != k) {
+      for (int j = 0; j < n; j++) { const double t = lu[k * n + j]; lu[k * n + j] = lu[piv * n + j]; lu[piv * n + j] = t; }
+      const int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+    }
+    for (int i = k + 1; i < n; i++) {
+      lu[i * n + k] /= lu[k * n + k];
+      const double f = lu[i * n + k];
+      for (int j = k + 1; j < n; j++) lu[i * n + j] -= f * lu[k * n + j];
+    }
+  }
+  for (int c = 0; c < n; c++) {
+    double y[15];
+    for (int i = 0; i < n; i++) {
+      double s = (perm[i] == c) ? 1.0 : 0.0;
+      for (int j = 0; j < i; j++) s -= lu[i * n + j] * y[j];
+      y[i] = s;
+    }
+    for (int i = n - 1; i >= 0; i--) {
+      double s = y[i];
+      for (int j = i + 1; j < n; j++) s -= lu[i * n + j] * inv[j * n + c];
+      inv[i * n + c] = s / lu[i * n + i];
+    }
+  }
+  // lower Cholesky of inv, written transposed (upper) into out
+  for (int i = 0; i < n * n; i++) out[i] = 0.0;
+  for (int j = 0; j < n; j++) {
+    double d = inv[j * n + j];
+    for (int k = 0; k < j; k++) d -= out[k * n + j] * out[k * n + j];
+    if (!(d > 0.0)) return 2;
+    d = sqrt(d);
+    out[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = inv[i * n + j];
+      for (int k = 0; k < j; k++) s -= out[k * n + i] * out[k * n + j];
+      out[j * n + i] = s / d;      // L(i,j) stored at out(j,i)
+    }
+  }
+  return 0;
+}
+
+GF_HD void put3(double *A, int lda, int r0, int c0, const mat3 &B) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[(r0 + i) * lda + c0 + j] = B(i, j);
+}
+GF_HD mat3 get3(const double *A, int lda, int r0, int c0) {
+  mat3 B; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) B(i, j) = A[(r0 + i) * lda + c0 + j]; return B;
+}
+
+// ---------------------------------------------------------------------------------------------
+// IMU factor, un-whitened: raw[15] and (if Jraw) Jraw[15][30] (caller zero-fills), columns
+// pose_i(6) sb_i(9) pose_j(6) sb_j(9). Whitening by sqrt_info is done by the caller (in parallel).
+// ---------------------------------------------------------------------------------------------
+GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose_i, const double *sb_i,
+                   const double *pose_j, const double *sb_j, double *raw, double *Jraw) {
+  const vec3 Pi = ld3(pose_i), Pj = ld3(pose_j);
+  const quat Qi = ldq(pose_i + 3), Qj = ldq(pose_j + 3);
+  const vec3 Vi = ld3(sb_i), Bai = ld3(sb_i + 3), Bgi = ld3(sb_i + 6);
+  const vec3 Vj = ld3(sb_j), Baj = ld3(sb_j + 3), Bgj = ld3(sb_j + 6);
+  const double dt = pre->sum_dt;
+  const mat3 dp_dba = get3(pre->jacobian, 15, 0, 9), dp_dbg = get3(pre->jacobian, 15, 0, 12);
+  const mat3 dq_dbg = get3(pre->jacobian, 15, 3, 12);
+  const mat3 dv_dba = get3(pre->jacobian, 15, 6, 9), dv_dbg = get3(pre->jacobian, 15, 6, 12);
+  const vec3 dba = sub(Bai, ld3(pre->linearized_ba)), dbg = sub(Bgi, ld3(pre->linearized_bg));
+  const quat dq = ldq(pre->delta_q);
+  const quat cq = qmul(dq, small_rot(mv(dq_dbg, dbg)));
+  const vec3 cv = add(ld3(pre->delta_v), add(mv(dv_dba, dba), mv(dv_dbg, dbg)));
+  const vec3 cp = add(ld3(pre->delta_p), add(mv(dp_dba, dba), mv(dp_dbg, dbg)));
+  const quat Qi_inv = qinv(Qi);
+  const mat3 RiT = qrot(Qi_inv);
+  const vec3 G = mk3(0.0, 0.0, g_norm);
+  const vec3 a_p = mv(RiT, sub(add(scl(0.5 * dt * dt, G), sub(Pj, Pi)), scl(dt, Vi)));
+  const vec3 a_v = mv(RiT, add(scl(dt, G), sub(Vj, Vi)));
+  const vec3 rp = sub(a_p, cp);
+  const vec3 rq = scl(2.0, qvec(qmul(qinv(cq), qmul(Qi_inv, Qj))));
+  const vec3 rv = sub(a_v, cv);
+  for (int k = 0; k < 3; k++) {
+    raw[k] = rp[k]; raw[3 + k] = rq[k]; raw[6 + k] = rv[k];
+    raw[9 + k] = Baj[k] - Bai[k]; raw[12 + k] = Bgj[k] - Bgi[k];
+  }
+  if (!Jraw) return;
+  const mat3 I = ident3();
+  put3(Jraw, 30, 0, 0, mneg(RiT));                                                  // imu_factor.h:107
+  put3(Jraw, 30, 0, 3, hat(a_p));                                                   // :108
+  put3(Jraw, 30, 3, 3, mneg(qleft_qright3(qmul(qinv(Qj), Qi), cq)));                // :113-114
+  put3(Jraw, 30, 6, 3, hat(a_v));                                                   // :117
+  put3(Jraw, 30, 0, 6, mscl(-dt, RiT));                                             // :133
+  put3(Jraw, 30, 0, 9, mneg(dp_dba));
+  put3(Jraw, 30, 0, 12, mneg(dp_dbg));
+  put3(Jraw, 30, 3, 12, mneg(mul(qleft3(qmul(qmul(qinv(Qj), Qi), dq)), dq_dbg)));   // :142 (uncorrected delta_q)
+  put3(Jraw, 30, 6, 6, mneg(RiT));
+  put3(Jraw, 30, 6, 9, mneg(dv_dba));
+  put3(Jraw, 30, 6, 12, mneg(dv_dbg));
+  put3(Jraw, 30, 9, 9, mneg(I));
+  put3(Jraw, 30, 12, 12, mneg(I));
+  put3(Jraw, 30, 0, 15, RiT);                                                       // :162
+  put3(Jraw, 30, 3, 18, qleft3(qmul(qmul(qinv(cq), Qi_inv), Qj)));                  // :168
+  put3(Jraw, 30, 6, 21, RiT);                                                       // :179
+  put3(Jraw, 30, 9, 24, I);
+  put3(Jraw, 30, 12, 27, I);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wheel factor, un-whitened: raw[6], Jraw[6][22] (caller zero-fills), columns pose_i(6) pose_j(6)
+// ex_wheel(6) sx sy sw td_wheel.
+// ---------------------------------------------------------------------------------------------
+GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const double *pose_j, const double *exw,
+                     double sx, double sy, double sw, double td, double *raw, double *Jraw) {
+  const vec3 Pi = ld3(pose_i), Pj = ld3(pose_j), tio = ld3(exw);
+  const quat Qi = ldq(pose_i + 3), Qj = ldq(pose_j + 3), qio = ldq(exw + 3);
+  const double *Jm = pre->jacobian;   // 6x3
+  const vec3 dp_dsx = mk3(Jm[0], Jm[3], Jm[6]), dp_dsy = mk3(Jm[1], Jm[4], Jm[7]), dp_dsw = mk3(Jm[2], Jm[5], Jm[8]);
+  const vec3 dq_dsw = mk3(Jm[11], Jm[14], Jm[17]);
+  const double dsx = sx - pre->linearized_sx, dsy = sy - pre->linearized_sy, dsw = sw - pre->linearized_sw;
+  const mat3 sv = diagm(sx, sy, 1.0);
+  const mat3 Ri = qrot(Qi), Rj = qrot(Qj), rio = qrot(qio);
+  const vec3 lin_vel = ld3(pre->linearized_vel), lin_gyr = ld3(pre->linearized_gyr);
+  const vec3 vel_1 = ld3(pre->vel_1), gyr_1 = ld3(pre->gyr_1);
+  const vec3 cp = add(ld3(pre->delta_p), add(add(scl(dsx, dp_dsx), scl(dsy, dp_dsy)), scl(dsw, dp_dsw)));   // :201
+  const quat cq = qmul(qnormalize(ldq(pre->delta_q)), so3exp(scl(dsw, dq_dsw)));                             // :202
+  const double dtd = td - pre->linearized_td;
+  const quat e_fw = so3exp(scl(sw * dtd, lin_gyr));
+  const quat q_time = qmul(qmul(e_fw, cq), so3exp(scl(-sw * dtd, gyr_1)));                                    // :205
+  const mat3 Rcq = qrot(cq);
+  const vec3 p_time = mv(qrot(e_fw), sub(add(mv(sv, scl(dtd, lin_vel)), cp), mv(Rcq, mv(sv, scl(dtd, vel_1)))));   // :206
+  const mat3 RR = mul(Ri, rio);
+  const vec3 world_d = sub(sub(add(mv(Rj, tio), Pj), mv(Ri, tio)), Pi);
+  const vec3 rp = sub(tmv(RR, world_d), p_time);                                                              // :211
+  const vec3 rq = so3log(qnormalize(qmul(qmul(qmul(qinv(q_time), qinv(qmul(Qi, qio))), Qj), qio)));           // :212
+  for (int k = 0; k < 3; k++) { raw[k] = rp[k]; raw[3 + k] = rq[k]; }
+  if (!Jraw) return;
+  const mat3 RRT = transp(RR);
+  const mat3 Jr_inv = jr_inv_so3(rq);                                    // wheel_factor.h:106-108
+  const vec3 drdsw = scl(dsw, dq_dsw);
+  const mat3 Jr_drdsw = jr_so3(drdsw);                                   // :110-112
+  put3(Jraw, 22, 0, 0, mneg(RRT));                                                                            // :121
+  put3(Jraw, 22, 0, 3, madd(mul(RRT, mul(Ri, hat(tio))), tmul(rio, hat(tmv(Ri, world_d)))));                  // :123
+  put3(Jraw, 22, 3, 3, mneg(mul(Jr_inv, qrot(qmul(qinv(qmul(Qj, qio)), Qi)))));                               // :131
+  put3(Jraw, 22, 0, 6, RRT);                                                                                  // :150
+  put3(Jraw, 22, 0, 9, mneg(mul(qrot(qmul(qinv(qmul(Qi, qio)), Qj)), hat(tio))));                             // :151
+  put3(Jraw, 22, 3, 9, mul(Jr_inv, qrot(qinv(qio))));                                                         // :157
+  put3(Jraw, 22, 0, 12, mul(RRT, msub(Rj, Ri)));                                                              // :170
+  put3(Jraw, 22, 0, 15, hat(mv(RRT, world_d)));                                                               // :172
+  put3(Jraw, 22, 3, 15, mul(Jr_inv, msub(ident3(), qrot(qmul(qmul(qinv(qmul(Qj, qio)), Qi), qio)))));         // :174
+  const vec3 fw = scl(sw * dtd, lin_gyr), fv = mv(sv, scl(dtd, lin_vel));
+  const vec3 bv = mv(sv, scl(dtd, vel_1)), bw = scl(sw * dtd, gyr_1);
+  const mat3 Jrtd = jr_so3(fw), Jr_mtd = jr_so3(neg(fw));
+  const mat3 Efv = qrot(so3exp(fv)), Efw = qrot(so3exp(fw));
+  const mat3 I1 = diagm(1.0, 0.0, 0.0), I2 = diagm(0.0, 1.0, 0.0);
+  const vec3 c_sx = neg(mv(Efv, sub(add(mv(I1, scl(dtd, lin_vel)), dp_dsx), mv(Rcq, mv(I1, scl(dtd, vel_1))))));   // :199
+  const vec3 c_sy = neg(mv(Efv, sub(add(mv(I2, scl(dtd, lin_vel)), dp_dsy), mv(Rcq, mv(I2, scl(dtd, vel_1))))));   // :211
+  const vec3 inner = sub(add(fv, cp), mv(Rcq, bv));
+  const vec3 t1 = mv(Rcq, mv(hat(mv(Jr_drdsw, dq_dsw)), mv(sv, scl(dtd, vel_1))));
+  const vec3 t2 = mv(hat(mv(Jrtd, scl(dtd, lin_gyr))), inner);
+  const vec3 c_sw_p = neg(mv(Efw, add(sub(dp_dsw, t1), t2)));                                                  // :223
+  const mat3 Emr = qrot(so3exp(neg(rq))), Ebw = qrot(so3exp(bw)), RcqT = qrot(qinv(cq));
+  const vec3 u1 = add(mv(RcqT, mv(Jrtd, scl(dtd, lin_gyr))), mv(Jr_drdsw, dq_dsw));
+  const vec3 c_sw_r = neg(mv(Jr_inv, mv(Emr, mv(Ebw, u1))));                                                   // :225
+  const vec3 t3 = mv(hat(mv(Jrtd, scl(sw, lin_gyr))), inner);
+  const vec3 c_td_p = neg(mv(Efw, add(sub(mv(sv, lin_vel), mv(Rcq, mv(sv, vel_1))), t3)));                     // :236
+  const vec3 u2 = sub(mv(Ebw, mv(RcqT, mv(Jrtd, scl(sw, lin_gyr)))), mv(Jr_mtd, scl(sw, gyr_1)));
+  const vec3 c_td_r = neg(mv(Jr_inv, mv(Emr, u2)));                                                            // :237
+  for (int k = 0; k < 3; k++) {
+    Jraw[k * 22 + 18] = c_sx[k];
+    Jraw[k * 22 + 19] = c_sy[k];
+    Jraw[k * 22 + 20] = c_sw_p[k]; Jraw[(3 + k) * 22 + 20] = c_sw_r[k];
+    Jraw[k * 22 + 21] = c_td_p[k]; Jraw[(3 + k) * 22 + 21] = c_td_r[k];
+  }
+}
+
+// Prior: tangent difference of one kept block w.r.t. its linearisation point
+// (marginalization_factor.cpp:359-374). size 7 -> 6 outputs, otherwise `size` outputs.
+GF_HD void prior_block_dx(const double *x, const double *x0, int size, double *dx) {
+  if (size != 7) {
+    for (int k = 0; k < size; k++) dx[k] = x[k] - x0[k];
+    return;
+  }
+  for (int k = 0; k < 3; k++) dx[k] = x[k] - x0[k];
+  const quat d = qmul(qinv(ldq(x0 + 3)), ldq(x + 3));
+  const double sgn = (d.w >= 0.0) ? 2.0 : -2.0;
+  dx[3] = sgn * d.x; dx[4] = sgn * d.y; dx[5] = sgn * d.z;
+}
+
+// PoseLocalParameterization::Plus with an optional PoseSubsetParameterization mask
+// (pose_local_parameterization.cpp:12-27, pose_subset_parameterization.cpp:27-55).
+GF_HD void pose_plus(const double *x, const double *d6, const unsigned char *mask6, double *y) {
+  double d[6];
+  for (int k = 0; k < 6; k++) d[k] = (mask6 && mask6[k]) ? 0.0 : d6[k];
+  for (int k = 0; k < 3; k++) y[k] = x[k] + d[k];
+  const quat q = qnormalize(qmul(ldq(x + 3), small_rot(mk3(d[3], d[4], d[5]))));
+  y[3] = q.x; y[4] = q.y; y[5] = q.z; y[6] = q.w;
+}
+
+}  // namespace gfd

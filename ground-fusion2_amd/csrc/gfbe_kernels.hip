@@ -1,0 +1,1119 @@
+// gfbe_kernels.hip — hand-written HIP kernels (gfx950 / MI355X, FP64) for the sliding-window solve.
+//
+// One launch sequence runs a whole batch of windows; grid.y = window. Every kernel early-exits for
+// windows whose trust-region state says it has nothing to do, so the host enqueues a fixed
+// sequence and never synchronises inside a solve.
+//
+// What each kernel stands in for (reference = Ground-Fusion++/vins_estimator/src):
+//   k_vis          ProjectionTwoFrameOneCamFactor::Evaluate (factor/projectionTwoFrameOneCamFactor.cpp:43-151)
+//                  + loss Corrector (factor/marginalization_factor.cpp:46-77) + the landmark row of J^T J
+//   k_pair         J^T J / J^T r of the visual factors of one (imu_i, imu_j) pose pair, from the
+//                  block-CSR records (what Ceres' BlockSparseMatrix + SchurEliminator hold)
+//   k_dense        IMUFactor / WheelFactor / MarginalizationFactor ::Evaluate
+//                  (factor/imu_factor.h:28-191, factor/wheel_factor.h:28-247, factor/marginalization_factor.cpp:344-392)
+//   k_schur        SchurEliminator: sum_l H_pl H_ll^-1 H_lp over the 1-D inverse-depth blocks
+//   k_assemble     reduced camera system assembly (fixed-order, owner-computes => deterministic)
+//   k_solve        DoglegStrategy::ComputeStep dense part: Jacobi scaling, mu-regularised Cholesky, GN step
+//   k_lm_step      back-substitution of the eliminated landmarks + their share of the dogleg scalars
+//   k_step         DoglegStrategy::ComputeTraditionalDoglegStep + TrustRegionMinimizer bookkeeping
+//   k_candidate    x (+) delta  (factor/pose_local_parameterization.cpp:12-27)
+//   k_accept       TrustRegionMinimizer: step acceptance, radius update, termination tests
+//   k_reanchor     Estimator::double2vector gauge fix (estimator/estimator.cpp:2501-2555)
+#include "gfbe_device.h"
+#include "gfbe_factors.h"
+
+namespace gfd {
+
+#define GF_MIN_DIAG 1e-6
+#define GF_MAX_DIAG 1e32
+#define GF_MIN_MU 1e-8
+#define GF_MAX_MU 1.0
+#define GF_MU_INC 10.0
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  return v;
+}
+// Deterministic block reduction (sum) for blockDim.x <= 1024; result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *scratch /*>=16*/) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)((blockDim.x + 63) >> 6); i++) r += scratch[i];
+  return r;
+}
+__device__ __forceinline__ double block_max(double v, double *scratch) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) for (int i = 0; i < (int)((blockDim.x + 63) >> 6); i++) r = fmax(r, scratch[i]);
+  return r;
+}
+
+__device__ __forceinline__ double clamp_diag(double x) { return fmin(fmax(x, GF_MIN_DIAG), GF_MAX_DIAG); }
+
+// =============================================================================================
+// k_prep: once per upload. sqrt_info of every IMU / wheel factor (imu_factor.h:73, wheel_factor.h:85,
+// hoisted out of Evaluate: SURVEY App. A.5) and H_prior = J0^T J0.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_prep(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  __shared__ double work[MAX_IMU][450];
+  __shared__ double wwork[MAX_WHEEL][72];
+  const int t = threadIdx.x;
+  if (t < ds.n_imu) {
+    double *out = d.imu_sqrt + (size_t)(ds.imu_off + t) * 225;
+    double tmp[225];
+    const int rc = sqrt_info_from_cov(d.imu[ds.imu_off + t].covariance, 15, tmp, work[t]);
+    for (int i = 0; i < 225; i++) out[i] = rc ? nan("") : tmp[i];
+  } else if (t >= 64 && t < 64 + ds.n_wheel) {
+    const int k = t - 64;
+    double *out = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
+    double tmp[36];
+    const int rc = sqrt_info_from_cov(d.wheel[ds.wheel_off + k].covariance, 6, tmp, wwork[k]);
+    for (int i = 0; i < 36; i++) out[i] = rc ? nan("") : tmp[i];
+  }
+  const int n = ds.prior_n;
+  if (n > 0) {
+    const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
+    double *Hp = d.prior_H + (size_t)w * ND * ND;
+    for (int e = t; e < n * n; e += blockDim.x) {
+      const int i = e / n, j = e % n;
+      double s = 0.0;
+      for (int r = 0; r < n; r++) s += J0[(size_t)r * n + i] * J0[(size_t)r * n + j];
+      Hp[e] = s;
+    }
+  }
+}
+
+// =============================================================================================
+// k_reset: start of every solve — restore the uploaded state, reset the trust-region bookkeeping.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_reset(BatchDev d) {
+  const int w = blockIdx.y;
+  const WinDesc &ds = d.desc[w];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < NA) {
+      const double v = d.x0[(size_t)w * NA + threadIdx.x];
+      d.x[((size_t)w * 2) * NA + threadIdx.x] = v;
+      d.x[((size_t)w * 2 + 1) * NA + threadIdx.x] = v;
+    }
+    if (threadIdx.x == 0) {
+      WinCtl c;
+      c.cur = 0; c.iter = 0; c.done = 0; c.reuse = 0; c.have_step = 0;
+      c.num_successful = 0; c.termination = 0; c.status = GFBE_NO_CONVERGENCE; c.invalid_steps = 0; c.lin_fail = 0;
+      c.n_clamped = 0; c.pad0 = 0;
+      c.radius = d.opt.initial_trust_region_radius; c.mu = GF_MIN_MU; c.cost = 0; c.cand_cost = 0; c.x_norm = 0;
+      c.cand_norm2 = 0; c.step_amb2 = 0;
+      c.G2 = c.N2 = c.gy = c.vHv = c.vHy = c.yHy = c.alpha = c.grad_max = 0;
+      c.c1 = c.c2 = c.step_norm = c.model_change = 0; c.initial_cost = 0;
+      for (int i = 0; i < 16; i++) { c.cost_history[i] = 0; c.accepted[i] = 0; }
+      d.ctl[w] = c;
+    }
+  }
+  if (t < ds.lm_slots) {
+    const double v = d.lam0[ds.lm_off + t];
+    d.lam[ds.lm_off + t] = v;
+    d.lam[(size_t)d.tot_lm + ds.lm_off + t] = v;
+  }
+}
+
+// =============================================================================================
+// k_vis: one lane = one landmark, looping over its observations (all lanes of a tile share the
+// start frame, so at step k the whole wave evaluates the same pose pair). SE(3) state tiles are
+// staged once per workgroup in LDS as (t, R).
+// MODE 0: linearise at the current point; MODE 1: candidate cost; MODE 2: marginalisation set
+// (landmarks with start_frame 0, estimator.cpp:3498-3531) at the re-anchored state.
+// =============================================================================================
+template <int MODE>
+__global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
+  const int w = blockIdx.y, tile = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  if (tile >= ds.n_tiles) return;
+  const WinCtl &c = d.ctl[w];
+  if (MODE == 0 && (c.done || c.reuse)) return;
+  if (MODE == 1 && (c.done || !c.have_step)) return;
+  const int sframe = d.tile_start[ds.tile_off + tile];
+  if (MODE == 2 && sframe != 0) return;
+  const int buf = (MODE == 1) ? 1 - c.cur : c.cur;
+  const double *X = (MODE == 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
+  const double *lamv = d.lam + (size_t)buf * d.tot_lm;
+
+  __shared__ PoseRT sp[NF + 1];
+  if (threadIdx.x < NF) sp[threadIdx.x] = make_pose(X + A_POSE(threadIdx.x));
+  if (threadIdx.x == NF) sp[NF] = make_pose(X + A_EX);
+  __syncthreads();
+  const double td = X[A_TD];
+  const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
+
+  const int slot = ds.lm_off + tile * LM_TILE + threadIdx.x;
+  const int info = d.lm_info[slot];
+  const bool valid = (info >> 24) & 1;
+  const int m = valid ? ((info >> 8) & 0xff) : 0;
+  const bool is_const = (info >> 16) & 1;
+  const size_t TL = d.tot_lm;
+  double cost = 0.0;
+  if (valid) {
+    const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
+    const double vix = d.lm_pts[3 * TL + slot], viy = d.lm_pts[4 * TL + slot], tdi = d.lm_pts[5 * TL + slot];
+    const double lam = lamv[slot];
+    const PoseRT Fi = sp[sframe];
+    double hC[HC], Hll = 0.0, gl = 0.0;
+#pragma unroll
+    for (int q = 0; q < HC; q++) hC[q] = 0.0;
+    for (int k = 0; k < m; k++) {
+      const double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
+      const double pjx = ob[0], pjy = ob[TL], vjx = ob[2 * TL], vjy = ob[3 * TL], tdj = ob[4 * TL];
+      double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
+      visual_eval<MODE != 1>(Fi, sp[sframe + 1 + k], sp[NF], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
+                             sq, r, Ji, Jj, Je, Jl, Jt);
+      double s1, rs, asn;
+      cost += corrector(r[0] * r[0] + r[1] * r[1], delta, &s1, &rs, &asn);
+      if (MODE != 1) {
+        correct_cols(Ji, Ji + 6, 6, r[0], r[1], s1, asn);
+        correct_cols(Jj, Jj + 6, 6, r[0], r[1], s1, asn);
+        correct_cols(Je, Je + 6, 6, r[0], r[1], s1, asn);
+        correct_cols(Jl, Jl + 1, 1, r[0], r[1], s1, asn);
+        correct_cols(Jt, Jt + 1, 1, r[0], r[1], s1, asn);
+        r[0] *= rs; r[1] *= rs;
+        // block-CSR record: r(2) | row0: Ji Jj Je Jl Jt | row1: ...
+        double *rec = d.rec + ((size_t)ds.rec_off + d.lm_rec[(size_t)k * TL + slot]) * REC;
+        rec[0] = r[0]; rec[1] = r[1];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          rec[2 + q] = Ji[q]; rec[8 + q] = Jj[q]; rec[14 + q] = Je[q];
+          rec[22 + q] = Ji[6 + q]; rec[28 + q] = Jj[6 + q]; rec[34 + q] = Je[6 + q];
+        }
+        rec[20] = Jl[0]; rec[21] = Jt[0]; rec[40] = Jl[1]; rec[41] = Jt[1];
+        // landmark row of the normal equations (w = Jl)
+        const double w0 = (is_const && MODE == 0) ? 0.0 : Jl[0], w1 = (is_const && MODE == 0) ? 0.0 : Jl[1];
+        Hll += w0 * w0 + w1 * w1;
+        gl += w0 * r[0] + w1 * r[1];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+          hC[q] += Ji[q] * w0 + Ji[6 + q] * w1;
+          hC[6 + q] += Je[q] * w0 + Je[6 + q] * w1;
+          d.lm_hP[((size_t)k * 6 + q) * TL + slot] = Jj[q] * w0 + Jj[6 + q] * w1;
+        }
+        hC[12] += Jt[0] * w0 + Jt[1] * w1;
+      }
+    }
+    if (MODE != 1) {
+      d.lm_Hll[slot] = Hll;
+      d.lm_gl[slot] = gl;
+#pragma unroll
+      for (int q = 0; q < HC; q++) d.lm_hC[(size_t)q * TL + slot] = hC[q];
+    }
+  }
+  cost = wave_sum(cost);
+  if (threadIdx.x == 0) {
+    if (MODE == 1) d.tile_cand[((size_t)w * d.max_tiles + tile) * 4] = cost;
+    else d.tile_cost[(size_t)w * d.max_tiles + tile] = cost;
+  }
+}
+
+// =============================================================================================
+// k_pair: J^T J and J^T r of the records of one (imu_i, imu_j) pair. Records of a pair are
+// contiguous (pair-major block-CSR) so the chunk load is a flat coalesced copy into LDS; thread e
+// owns output entry e and walks the chunk's rows. 19 compact columns: pose_i 0..5, pose_j 6..11,
+// ex 12..17, td 18.
+// =============================================================================================
+__device__ __forceinline__ int rec_col(int c) { return c < 18 ? c : 19; }   // skip the lambda column (18)
+
+__global__ __launch_bounds__(256) void k_pair(BatchDev d, int marg) {
+  const int w = blockIdx.y;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (!marg && (c.done || c.reuse)) return;
+  // decode pair index: blockIdx.x in [0,55) -> (i,j), i<j
+  int i = 0, rem = blockIdx.x;
+  while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
+  const int j = i + 1 + rem;
+  if (marg && i != 0) return;
+  const int p = i * NF + j;
+  const int rb = ds.pair_begin[p], re = ds.pair_begin[p + 1];
+  double *out = d.pair_part + ((size_t)w * NPAIR + p) * PAIR_STRIDE;
+  if (rb == re) return;   // stays zero (zeroed at upload; the structure never changes)
+  __shared__ double tile[64 * REC];
+  const int e = threadIdx.x;
+  int ca = 0, cb = 0;
+  bool is_g = false;
+  if (e < 190) {
+    // upper-triangular enumeration of 19 x 19
+    int a = 0, rr = e;
+    while (rr >= 19 - a) { rr -= 19 - a; a++; }
+    ca = rec_col(a); cb = rec_col(a + rr);
+  } else if (e < PAIR_E) {
+    ca = rec_col(e - 190); is_g = true;
+  }
+  double acc = 0.0;
+  for (int base = rb; base < re; base += 64) {
+    const int n = min(64, re - base);
+    const double *src = d.rec + ((size_t)ds.rec_off + base) * REC;
+    __syncthreads();
+    for (int q = threadIdx.x; q < n * REC; q += blockDim.x) tile[q] = src[q];
+    __syncthreads();
+    if (e < PAIR_E) {
+      if (!is_g) {
+        for (int f = 0; f < n; f++) {
+          const double *rc = tile + f * REC;
+          acc += rc[2 + ca] * rc[2 + cb] + rc[22 + ca] * rc[22 + cb];
+        }
+      } else {
+        for (int f = 0; f < n; f++) {
+          const double *rc = tile + f * REC;
+          acc += rc[2 + ca] * rc[0] + rc[22 + ca] * rc[1];
+        }
+      }
+    }
+  }
+  if (e < PAIR_E) out[e] = acc;
+}
+
+// index of (a,b) in the 209-entry pair block (a,b compact columns 0..18)
+__device__ __forceinline__ int pair_tri(int a, int b) {
+  if (a > b) { const int t = a; a = b; b = t; }
+  return a * 19 - a * (a - 1) / 2 + (b - a);
+}
+
+// =============================================================================================
+// k_dense: blocks 0..9 IMU factors, 10..19 wheel factors, 20 the prior. 64 threads each.
+// mode 0 linearise at current; 1 candidate cost; 2 MARGIN_OLD set at xout (frame-0 IMU/wheel + prior);
+// 3 MARGIN_SECOND_NEW set at xout (prior only).
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_dense(BatchDev d, int mode, int debug_out) {
+  const int w = blockIdx.y, f = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (mode == 0 && (c.done || c.reuse)) return;
+  if (mode == 1 && (c.done || !c.have_step)) return;
+  const int buf = (mode == 1) ? 1 - c.cur : c.cur;
+  const double *X = (mode >= 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
+  const int t = threadIdx.x;
+  __shared__ double raw[16], rw[16], Jraw[15 * 30], Jw[15 * 30], red[16];
+  __shared__ double dx[ND], rp[ND];
+
+  if (f < MAX_IMU) {
+    double *part = d.imu_part + ((size_t)w * MAX_IMU + f) * IMU_PART;
+    if (f >= ds.n_imu) { if (mode == 1 && t == 0) part[IMU_PART - 1] = 0.0; return; }
+    const int fi = ds.imu_frame[f];
+    if (mode >= 2 && !(mode == 2 && fi == 0 && d.imu[ds.imu_off + f].sum_dt < 10.0)) { if (t == 0) part[IMU_PART - 2] = -1.0; return; }
+    for (int q = t; q < 450; q += 64) Jraw[q] = 0.0;
+    __syncthreads();
+    if (t == 0)
+      imu_raw(&d.imu[ds.imu_off + f], d.opt.g_norm, X + A_POSE(fi), X + A_SB(fi), X + A_POSE(fi + 1), X + A_SB(fi + 1), raw,
+              mode == 1 ? nullptr : Jraw);
+    __syncthreads();
+    const double *S = d.imu_sqrt + (size_t)(ds.imu_off + f) * 225;   // upper triangular
+    if (t < 15) { double s = 0.0; for (int b = t; b < 15; b++) s += S[t * 15 + b] * raw[b]; rw[t] = s; }
+    if (mode != 1 && t >= 16 && t < 46) {
+      const int col = t - 16;
+      for (int a = 0; a < 15; a++) { double s = 0.0; for (int b = a; b < 15; b++) s += S[a * 15 + b] * Jraw[b * 30 + col]; Jw[a * 30 + col] = s; }
+    }
+    __syncthreads();
+    double cst = 0.0;
+    if (t == 0) for (int a = 0; a < 15; a++) cst += 0.5 * rw[a] * rw[a];
+    if (mode == 1) { if (t == 0) part[IMU_PART - 1] = cst; return; }
+    for (int e = t; e < 930; e += 64) {
+      double s = 0.0;
+      if (e < 900) { const int a = e / 30, b = e % 30; for (int r = 0; r < 15; r++) s += Jw[r * 30 + a] * Jw[r * 30 + b]; }
+      else { const int a = e - 900; for (int r = 0; r < 15; r++) s += Jw[r * 30 + a] * rw[r]; }
+      part[e] = s;
+    }
+    if (t == 0) part[IMU_PART - 2] = cst;
+    if (debug_out) {
+      double *dbg = d.dbg_imu + ((size_t)w * MAX_IMU + f) * (15 * 31);
+      for (int q = t; q < 450; q += 64) dbg[15 + q] = Jw[q];
+      if (t < 15) dbg[t] = rw[t];
+    }
+  } else if (f < MAX_IMU + MAX_WHEEL) {
+    const int k = f - MAX_IMU;
+    double *part = d.wheel_part + ((size_t)w * MAX_WHEEL + k) * WHEEL_PART;
+    if (k >= ds.n_wheel) { if (mode == 1 && t == 0) part[WHEEL_PART - 1] = 0.0; return; }
+    const int fi = ds.wheel_frame[k];
+    if (mode >= 2 && !(mode == 2 && fi == 0 && d.wheel[ds.wheel_off + k].sum_dt < 10.0)) { if (t == 0) part[WHEEL_PART - 2] = -1.0; return; }
+    for (int q = t; q < 132; q += 64) Jraw[q] = 0.0;
+    __syncthreads();
+    if (t == 0)
+      wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
+                X[A_TDW], raw, mode == 1 ? nullptr : Jraw);
+    __syncthreads();
+    const double *S = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
+    if (t < 6) { double s = 0.0; for (int b = t; b < 6; b++) s += S[t * 6 + b] * raw[b]; rw[t] = s; }
+    if (mode != 1 && t >= 16 && t < 38) {
+      const int col = t - 16;
+      for (int a = 0; a < 6; a++) { double s = 0.0; for (int b = a; b < 6; b++) s += S[a * 6 + b] * Jraw[b * 22 + col]; Jw[a * 22 + col] = s; }
+    }
+    __syncthreads();
+    double cst = 0.0;
+    if (t == 0) for (int a = 0; a < 6; a++) cst += 0.5 * rw[a] * rw[a];
+    if (mode == 1) { if (t == 0) part[WHEEL_PART - 1] = cst; return; }
+    for (int e = t; e < 506; e += 64) {
+      double s = 0.0;
+      if (e < 484) { const int a = e / 22, b = e % 22; for (int r = 0; r < 6; r++) s += Jw[r * 22 + a] * Jw[r * 22 + b]; }
+      else { const int a = e - 484; for (int r = 0; r < 6; r++) s += Jw[r * 22 + a] * rw[r]; }
+      part[e] = s;
+    }
+    if (t == 0) part[WHEEL_PART - 2] = cst;
+    if (debug_out) {
+      double *dbg = d.dbg_wheel + ((size_t)w * MAX_WHEEL + k) * (6 * 23);
+      for (int q = t; q < 132; q += 64) dbg[6 + q] = Jw[q];
+      if (t < 6) dbg[t] = rw[t];
+    }
+  } else {
+    // prior: r = r0 + J0 dx ; g = J0^T r   (marginalization_factor.cpp:375-389)
+    double *pg = d.prior_g + (size_t)w * (ND + 2);
+    const int n = ds.prior_n;
+    if (n == 0) { if (t == 0) { pg[ND] = 0.0; pg[ND + 1] = 0.0; } return; }
+    if (t < ds.prior_nblk)
+      prior_block_dx(X + blk_amb(ds.prior_blk_id[t]), d.prior_x0 + (size_t)w * PRIOR_X0 + ds.prior_x0_off[t], ds.prior_blk_size[t],
+                     dx + ds.prior_blk_idx[t]);
+    __syncthreads();
+    const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
+    const double *r0 = d.prior_r0 + (size_t)w * ND;
+    double cst = 0.0;
+    for (int i = t; i < n; i += 64) {
+      double s = r0[i];
+      for (int k = 0; k < n; k++) s += J0[(size_t)i * n + k] * dx[k];
+      rp[i] = s;
+      cst += 0.5 * s * s;
+    }
+    cst = block_sum(cst, red);
+    if (mode == 1) { if (t == 0) pg[ND + 1] = cst; return; }
+    __syncthreads();
+    for (int k = t; k < n; k += 64) {
+      double s = 0.0;
+      for (int i = 0; i < n; i++) s += J0[(size_t)i * n + k] * rp[i];
+      pg[k] = s;
+    }
+    if (t == 0) pg[ND] = cst;
+    if (debug_out) for (int i = t; i < n; i += 64) d.dbg_prior[(size_t)w * ND + i] = rp[i];
+  }
+}
+
+// =============================================================================================
+// k_schur: one workgroup per landmark tile (all landmarks share the start frame s, so their H_pl
+// rows live on the contiguous dims [6s, 73)). Rows are staged in LDS pre-multiplied by sqrt(w_l);
+// thread-owned entries of the packed (reversed lower-triangular) block accumulate over the tile.
+//   solve:  w_l = s_l^2 / (s_l^2 Hll + mu clamp(s_l^2 Hll))      (Jacobi-scaled, mu-regularised)
+//   marg :  w_l = 1 / Hll                                         (marginalization_factor.cpp:286-292)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
+  const int w = blockIdx.y, tile = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  if (tile >= ds.n_tiles) return;
+  WinCtl &c = d.ctl[w];
+  if (!marg && (c.done || c.reuse)) return;
+  const int s = d.tile_start[ds.tile_off + tile];
+  if (marg && s != 0) return;
+  __shared__ double hs[NV][LM_TILE + 1];
+  __shared__ double gs[LM_TILE];
+  const size_t TL = d.tot_lm;
+  const int slot0 = ds.lm_off + tile * LM_TILE;
+  const int t = threadIdx.x;
+  const bool first = (c.iter == 0);   // Jacobi scaling is fixed at iteration 0 (TrustRegionMinimizer::IterationZero)
+  for (int q = t; q < NV * LM_TILE; q += blockDim.x) hs[q / LM_TILE][q % LM_TILE] = 0.0;
+  __syncthreads();
+  if (t < LM_TILE) {
+    const int slot = slot0 + t;
+    const int info = d.lm_info[slot];
+    const bool valid = (info >> 24) & 1;
+    const int m = (info >> 8) & 0xff;
+    const bool is_const = (info >> 16) & 1;
+    double sw = 0.0, wl = 0.0;
+    const double Hll = d.lm_Hll[slot];
+    if (valid && m > 0 && (marg || !is_const)) {
+      if (marg) {
+        wl = (Hll > d.opt.marg_eps) ? 1.0 / Hll : 0.0;
+      } else {
+        double sl;
+        if (first) { sl = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hll)) : 1.0; d.lm_sl[slot] = sl; }
+        else sl = d.lm_sl[slot];
+        const double hs2 = sl * sl * Hll;
+        wl = sl * sl / (hs2 + c.mu * clamp_diag(hs2));
+      }
+      sw = sqrt(wl);
+      for (int q = 0; q < 6; q++) {
+        hs[6 * s + q][t] = sw * d.lm_hC[(size_t)q * TL + slot];
+        hs[T_EX + q][t] = sw * d.lm_hC[(size_t)(6 + q) * TL + slot];
+      }
+      hs[T_TD][t] = sw * d.lm_hC[(size_t)12 * TL + slot];
+      for (int k = 0; k < m; k++)
+        for (int q = 0; q < 6; q++) hs[6 * (s + 1 + k) + q][t] = sw * d.lm_hP[((size_t)k * 6 + q) * TL + slot];
+    } else if (!marg && first && valid) {
+      d.lm_sl[slot] = 1.0;
+    }
+    gs[t] = sw * d.lm_gl[slot];
+  }
+  __syncthreads();
+  const int ns = NV - 6 * s;
+  const int ne = ns * (ns + 1) / 2;
+  double *out = d.schur_part + ((size_t)w * d.max_tiles + tile) * SCHUR_STRIDE;
+  for (int e = t; e < ne; e += blockDim.x) {
+    const int ab = d.tri_tab[e];
+    const int a = (NV - 1) - (ab >> 8), b = (NV - 1) - (ab & 0xff);
+    double acc = 0.0;
+#pragma unroll 8
+    for (int l = 0; l < LM_TILE; l++) acc += hs[a][l] * hs[b][l];
+    out[e] = acc;
+  }
+  for (int a = 6 * s + t; a < NV; a += blockDim.x) {
+    double acc = 0.0;
+    for (int l = 0; l < LM_TILE; l++) acc += hs[a][l] * gs[l];
+    out[TRI_NV + a] = acc;
+  }
+}
+
+// =============================================================================================
+// k_assemble: owner-computes gather of every partial into the dense normal equations (fixed
+// summation order => bit-reproducible). Writes H (unscaled, constant dims removed), g, E, eg.
+// =============================================================================================
+__device__ __forceinline__ int vis_loc(int a, int i, int j) {   // compact column of visual dim a in pair (i,j)
+  if (a < 66) { const int f = a / 6; if (f == i) return a - 6 * f; if (f == j) return 6 + a - 6 * f; return -1; }
+  if (a < 72) return 12 + (a - 66);
+  return 18;
+}
+__device__ __forceinline__ int imu_loc(int a, int i) {          // column of dim a in the IMU factor (i, i+1)
+  if (a < 66) { const int f = a / 6; if (f == i) return a - 6 * f; if (f == i + 1) return 15 + a - 6 * f; return -1; }
+  if (a >= 73 && a < 172) { const int f = (a - 73) / 9; if (f == i) return 6 + (a - 73 - 9 * f); if (f == i + 1) return 21 + (a - 73 - 9 * f); }
+  return -1;
+}
+__device__ __forceinline__ int wheel_loc(int a, int i) {
+  if (a < 66) { const int f = a / 6; if (f == i) return a - 6 * f; if (f == i + 1) return 6 + a - 6 * f; return -1; }
+  if (a >= T_EXW && a < T_EXW + 6) return 12 + (a - T_EXW);
+  if (a >= T_SX && a <= T_TDW) return 18 + (a - T_SX);
+  return -1;
+}
+
+template <bool MARG>
+__device__ double gather_H(const BatchDev &d, const WinDesc &ds, int w, int a, int b) {
+  double s = 0.0;
+  if (a < NV && b < NV) {
+    const double *pp = d.pair_part + (size_t)w * NPAIR * PAIR_STRIDE;
+    for (int i = 0; i < (MARG ? 1 : NF - 1); i++)
+      for (int j = i + 1; j < NF; j++) {
+        const int la = vis_loc(a, i, j), lb = vis_loc(b, i, j);
+        if (la >= 0 && lb >= 0) s += pp[(size_t)(i * NF + j) * PAIR_STRIDE + pair_tri(la, lb)];
+      }
+  }
+  for (int q = 0; q < ds.n_imu; q++) {
+    const double *part = d.imu_part + ((size_t)w * MAX_IMU + q) * IMU_PART;
+    if (MARG && part[IMU_PART - 2] < 0.0) continue;
+    const int la = imu_loc(a, ds.imu_frame[q]), lb = imu_loc(b, ds.imu_frame[q]);
+    if (la >= 0 && lb >= 0) s += part[la * 30 + lb];
+  }
+  for (int q = 0; q < ds.n_wheel; q++) {
+    const double *part = d.wheel_part + ((size_t)w * MAX_WHEEL + q) * WHEEL_PART;
+    if (MARG && part[WHEEL_PART - 2] < 0.0) continue;
+    const int la = wheel_loc(a, ds.wheel_frame[q]), lb = wheel_loc(b, ds.wheel_frame[q]);
+    if (la >= 0 && lb >= 0) s += part[la * 22 + lb];
+  }
+  if (ds.prior_n > 0) {
+    const int pa = ds.prior_map[a], pb = ds.prior_map[b];
+    if (pa >= 0 && pb >= 0) s += d.prior_H[(size_t)w * ND * ND + (size_t)pa * ds.prior_n + pb];
+  }
+  return s;
+}
+template <bool MARG>
+__device__ double gather_g(const BatchDev &d, const WinDesc &ds, int w, int a) {
+  double s = 0.0;
+  if (a < NV) {
+    const double *pp = d.pair_part + (size_t)w * NPAIR * PAIR_STRIDE;
+    for (int i = 0; i < (MARG ? 1 : NF - 1); i++)
+      for (int j = i + 1; j < NF; j++) {
+        const int la = vis_loc(a, i, j);
+        if (la >= 0) s += pp[(size_t)(i * NF + j) * PAIR_STRIDE + 190 + la];
+      }
+  }
+  for (int q = 0; q < ds.n_imu; q++) {
+    const double *part = d.imu_part + ((size_t)w * MAX_IMU + q) * IMU_PART;
+    if (MARG && part[IMU_PART - 2] < 0.0) continue;
+    const int la = imu_loc(a, ds.imu_frame[q]);
+    if (la >= 0) s += part[900 + la];
+  }
+  for (int q = 0; q < ds.n_wheel; q++) {
+    const double *part = d.wheel_part + ((size_t)w * MAX_WHEEL + q) * WHEEL_PART;
+    if (MARG && part[WHEEL_PART - 2] < 0.0) continue;
+    const int la = wheel_loc(a, ds.wheel_frame[q]);
+    if (la >= 0) s += part[484 + la];
+  }
+  if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
+  return s;
+}
+// E(a,b), a <= b < NV: sum over tiles whose start frame s satisfies 6 s <= a
+__device__ double gather_E(const BatchDev &d, const WinDesc &ds, int w, int a, int b, bool marg) {
+  if (a > b) { const int t = a; a = b; b = t; }
+  const int ap = (NV - 1) - a, bp = (NV - 1) - b;
+  const int e = ap * (ap + 1) / 2 + bp;
+  double s = 0.0;
+  const int smax = marg ? 0 : min(a / 6, NF - 1);
+  const int t_end = ds.sf_tile_begin[smax + 1];
+  const double *sp = d.schur_part + (size_t)w * d.max_tiles * SCHUR_STRIDE;
+  for (int t = 0; t < t_end; t++) s += sp[(size_t)t * SCHUR_STRIDE + e];
+  return s;
+}
+__device__ double gather_eg(const BatchDev &d, const WinDesc &ds, int w, int a, bool marg) {
+  double s = 0.0;
+  const int smax = marg ? 0 : min(a / 6, NF - 1);
+  const int t_end = ds.sf_tile_begin[smax + 1];
+  const double *sp = d.schur_part + (size_t)w * d.max_tiles * SCHUR_STRIDE;
+  for (int t = 0; t < t_end; t++) s += sp[(size_t)t * SCHUR_STRIDE + TRI_NV + a];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_assemble(BatchDev d) {
+  const int w = blockIdx.y;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
+  double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
+  const int nthreads = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
+  // lower triangle + diagonal, mirrored
+  for (int e = tid; e < ND * (ND + 1) / 2; e += nthreads) {
+    int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= e) a++;
+    while (a * (a + 1) / 2 > e) a--;
+    const int b = e - a * (a + 1) / 2;   // b <= a
+    double v = 0.0;
+    if (ds.act[a] && ds.act[b]) v = gather_H<false>(d, ds, w, b, a);
+    H[(size_t)a * ND + b] = v;
+    H[(size_t)b * ND + a] = v;
+    if (a < NV) {
+      double ev = 0.0;
+      if (ds.act[a] && ds.act[b]) ev = gather_E(d, ds, w, b, a, false);
+      E[a * NV + b] = ev;
+      E[b * NV + a] = ev;
+    }
+  }
+  for (int a = tid; a < ND; a += nthreads) {
+    g[a] = ds.act[a] ? gather_g<false>(d, ds, w, a) : 0.0;
+    if (a < NV) eg[a] = ds.act[a] ? gather_eg(d, ds, w, a, false) : 0.0;
+  }
+}
+
+// =============================================================================================
+// k_solve: one workgroup per window. Jacobi scaling (iteration 0), D = sqrt(clamp(diag)), the
+// mu-regularised reduced system, packed Cholesky in LDS, Gauss-Newton step y_p, dense shares of
+// the dogleg scalars. (Ceres 1.14 DoglegStrategy::ComputeStep / ComputeGaussNewtonStep.)
+// =============================================================================================
+#define SOLVE_THREADS 256
+__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }   // j <= i
+
+// Rebuild E for a new mu directly from the landmark rows (slow path: only after a failed Cholesky).
+__device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu) {
+  double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
+  const size_t TL = d.tot_lm;
+  for (int e = threadIdx.x; e < NV * NV + NV; e += blockDim.x) {
+    const bool isg = e >= NV * NV;
+    const int a = isg ? e - NV * NV : e / NV, b = isg ? 0 : e % NV;
+    double acc = 0.0;
+    if (ds.act[a] && (isg || ds.act[b]) && (isg || a <= b)) {
+      for (int tile = 0; tile < ds.n_tiles; tile++) {
+        const int s = d.tile_start[ds.tile_off + tile];
+        if (6 * s > a) break;   // tiles are ordered by start frame
+        for (int l = 0; l < LM_TILE; l++) {
+          const int slot = ds.lm_off + tile * LM_TILE + l;
+          const int info = d.lm_info[slot];
+          const int m = (info >> 8) & 0xff;
+          if (!((info >> 24) & 1) || ((info >> 16) & 1) || m == 0) continue;
+          const double sl = d.lm_sl[slot], hs2 = sl * sl * d.lm_Hll[slot];
+          const double wl = sl * sl / (hs2 + mu * clamp_diag(hs2));
+          auto hval = [&](int x) -> double {
+            if (x >= T_EX) return d.lm_hC[(size_t)(x == T_TD ? 12 : 6 + x - T_EX) * TL + slot];
+            const int f = x / 6, q = x % 6;
+            if (f == s) return d.lm_hC[(size_t)q * TL + slot];
+            const int k = f - s - 1;
+            if (k < 0 || k >= m) return 0.0;
+            return d.lm_hP[((size_t)k * 6 + q) * TL + slot];
+          };
+          acc += wl * hval(a) * (isg ? d.lm_gl[slot] : hval(b));
+        }
+      }
+    }
+    if (isg) eg[a] = acc;
+    else if (a <= b) { E[a * NV + b] = acc; E[b * NV + a] = acc; }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *Lp = smem;                         // packed lower triangle, ND*(ND+1)/2
+  double *sp = Lp + ND * (ND + 1) / 2;       // ND
+  double *Dp = sp + ND, *gts = Dp + ND, *rhs = gts + ND, *yv = rhs + ND, *vv = yv + ND, *tmp = vv + ND;   // ND each
+  double *red = tmp + ND;                    // 16
+  int *flag = (int *)(red + 16);
+  const int t = threadIdx.x;
+  const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
+  const bool first = (c.iter == 0);
+
+  // total cost of this linearisation point (fixed order)
+  if (first && t == 0) {
+    double cost = 0.0;
+    for (int q = 0; q < ds.n_tiles; q++) cost += d.tile_cost[(size_t)w * d.max_tiles + q];
+    for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
+    for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
+    cost += d.prior_g[(size_t)w * (ND + 2) + ND];
+    c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
+  }
+  // scaling, diagonal, scaled gradient, Cauchy direction
+  double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
+  for (int a = t; a < ND; a += blockDim.x) {
+    double s = 1.0;
+    if (ds.act[a]) {
+      if (first) { s = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[(size_t)a * ND + a])) : 1.0; d.sp[(size_t)w * ND + a] = s; }
+      else s = d.sp[(size_t)w * ND + a];
+      const double d2 = clamp_diag(s * s * H[(size_t)a * ND + a]);
+      sp[a] = s; Dp[a] = sqrt(d2); gts[a] = s * g[a]; vv[a] = gts[a] / d2;
+      g2 += gts[a] * gts[a] / d2;
+      gmax = fmax(gmax, fabs(g[a]));
+    } else {
+      if (first) d.sp[(size_t)w * ND + a] = 1.0;
+      sp[a] = 1.0; Dp[a] = 1.0; gts[a] = 0.0; vv[a] = 0.0;
+    }
+  }
+  // |x|^2 over the free dense blocks (ambient)
+  {
+    const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
+    for (int b = t; b < GFBE_BLK_COUNT; b += blockDim.x)
+      if (ds.blk_free[b]) for (int k = 0; k < blk_gsize(b); k++) { const double v = X[blk_amb(b) + k]; xn2 += v * v; }
+  }
+  g2 = block_sum(g2, red);
+  gmax = block_max(gmax, red);
+  xn2 = block_sum(xn2, red);
+  __syncthreads();
+
+  // mu-regularised Gauss-Newton solve with retries
+  double mu = c.mu;
+  bool solved = false;
+  const double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
+  bool e_valid_for_mu = true;
+  while (mu < GF_MAX_MU) {
+    if (!e_valid_for_mu) rebuild_E(d, ds, w, mu);
+    // S = s H s + mu D^2 - s E s  (packed lower); constant dims -> identity
+    for (int e = t; e < ND * (ND + 1) / 2; e += blockDim.x) {
+      int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((a + 1) * (a + 2) / 2 <= e) a++;
+      while (a * (a + 1) / 2 > e) a--;
+      const int b = e - a * (a + 1) / 2;
+      double v;
+      if (!ds.act[a] || !ds.act[b]) v = (a == b) ? 1.0 : 0.0;
+      else {
+        v = H[(size_t)a * ND + b];
+        if (a < NV) v -= E[a * NV + b];
+        v *= sp[a] * sp[b];
+        if (a == b) v += mu * Dp[a] * Dp[a];
+      }
+      Lp[e] = v;
+    }
+    for (int a = t; a < ND; a += blockDim.x) rhs[a] = ds.act[a] ? gts[a] - (a < NV ? sp[a] * eg[a] : 0.0) : 0.0;
+    if (t == 0) *flag = 0;
+    __syncthreads();
+    // right-looking Cholesky, 16 x 16 thread grid over the trailing block
+    const int ti = t >> 4, tj = t & 15;
+    for (int k = 0; k < ND; k++) {
+      if (t == 0) {
+        const double dkk = Lp[pk(k, k)];
+        if (!(dkk > 0.0) || !isfinite(dkk)) *flag = 1;
+        else Lp[pk(k, k)] = sqrt(dkk);
+      }
+      __syncthreads();
+      if (*flag) break;
+      const double inv = 1.0 / Lp[pk(k, k)];
+      for (int i = k + 1 + t; i < ND; i += blockDim.x) Lp[pk(i, k)] *= inv;
+      __syncthreads();
+      for (int i = k + 1 + ti; i < ND; i += 16) {
+        const double lik = Lp[pk(i, k)];
+        for (int j = k + 1 + tj; j <= i; j += 16) Lp[pk(i, j)] -= lik * Lp[pk(j, k)];
+      }
+      __syncthreads();
+    }
+    bool ok = (*flag == 0);
+    if (ok) {
+      // forward / backward substitution by wave 0 (no block barriers)
+      if (t < 64) {
+        for (int k = 0; k < ND; k++) {
+          const double zk = rhs[k] / Lp[pk(k, k)];
+          for (int i = k + 1 + t; i < ND; i += 64) rhs[i] -= Lp[pk(i, k)] * zk;
+          if (t == 0) rhs[k] = zk;
+          __builtin_amdgcn_wave_barrier();
+          __threadfence_block();
+        }
+        for (int k = ND - 1; k >= 0; k--) {
+          const double yk = rhs[k] / Lp[pk(k, k)];
+          for (int i = t; i < k; i += 64) rhs[i] -= Lp[pk(k, i)] * yk;
+          if (t == 0) { rhs[k] = yk; }
+          __builtin_amdgcn_wave_barrier();
+          __threadfence_block();
+        }
+      }
+      __syncthreads();
+      int bad = 0;
+      for (int a = t; a < ND; a += blockDim.x) { yv[a] = ds.act[a] ? rhs[a] : 0.0; if (!isfinite(yv[a])) bad = 1; }
+      if (bad) *flag = 1;
+      __syncthreads();
+      ok = (*flag == 0);
+    }
+    __syncthreads();
+    if (ok) { solved = true; break; }
+    mu *= GF_MU_INC;
+    e_valid_for_mu = false;
+  }
+  if (!solved) {
+    if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
+    return;
+  }
+  // dense shares of the dogleg scalars: t_v = Ht v, t_y = Ht y  (Ht = s H s)
+  double n2 = 0.0, gyv = 0.0, vhv = 0.0, vhy = 0.0, yhy = 0.0;
+  for (int a = t; a < ND; a += blockDim.x) {
+    if (!ds.act[a]) continue;
+    double tv = 0.0, ty = 0.0;
+    const double *row = H + (size_t)a * ND;
+    for (int b = 0; b < ND; b++) { const double hb = sp[b] * row[b]; tv += hb * vv[b]; ty += hb * yv[b]; }
+    tv *= sp[a]; ty *= sp[a];
+    vhv += vv[a] * tv; vhy += yv[a] * tv; yhy += yv[a] * ty;
+    n2 += Dp[a] * Dp[a] * yv[a] * yv[a];
+    gyv += gts[a] * yv[a];
+  }
+  n2 = block_sum(n2, red); gyv = block_sum(gyv, red); vhv = block_sum(vhv, red); vhy = block_sum(vhy, red); yhy = block_sum(yhy, red);
+  for (int a = t; a < ND; a += blockDim.x) {
+    d.Dp[(size_t)w * ND + a] = Dp[a]; d.gts[(size_t)w * ND + a] = gts[a];
+    d.vp[(size_t)w * ND + a] = vv[a]; d.yp[(size_t)w * ND + a] = yv[a];
+  }
+  if (t == 0) {
+    c.mu = mu;
+    c.G2 = g2; c.N2 = n2; c.gy = gyv; c.vHv = vhv; c.vHy = vhy; c.yHy = yhy; c.grad_max = gmax;
+    c.x_norm = xn2;        // dense share; k_step adds the landmarks and takes the square root
+    c.have_step = 2;       // "fresh linearisation" marker consumed by k_step
+  }
+}
+
+// =============================================================================================
+// k_lm_step: back-substitution of the eliminated landmarks and their share of the dogleg scalars.
+// =============================================================================================
+__global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
+  const int w = blockIdx.y, tile = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  if (tile >= ds.n_tiles) return;
+  const WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  __shared__ double sy[NV], sv[NV];
+  const int t = threadIdx.x;
+  for (int a = t; a < NV; a += LM_TILE) {
+    const double s = d.sp[(size_t)w * ND + a];
+    sy[a] = s * d.yp[(size_t)w * ND + a];
+    sv[a] = s * d.vp[(size_t)w * ND + a];
+  }
+  __syncthreads();
+  const int s0 = d.tile_start[ds.tile_off + tile];
+  const int slot = ds.lm_off + tile * LM_TILE + t;
+  const int info = d.lm_info[slot];
+  const int m = (info >> 8) & 0xff;
+  const bool free_lm = ((info >> 24) & 1) && !((info >> 16) & 1) && m > 0;
+  const size_t TL = d.tot_lm;
+  double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (free_lm) {
+    double hy = 0.0, hv = 0.0;
+    for (int q = 0; q < 6; q++) {
+      const double hi = d.lm_hC[(size_t)q * TL + slot], he = d.lm_hC[(size_t)(6 + q) * TL + slot];
+      hy += hi * sy[6 * s0 + q] + he * sy[T_EX + q];
+      hv += hi * sv[6 * s0 + q] + he * sv[T_EX + q];
+    }
+    { const double ht = d.lm_hC[(size_t)12 * TL + slot]; hy += ht * sy[T_TD]; hv += ht * sv[T_TD]; }
+    for (int k = 0; k < m; k++)
+      for (int q = 0; q < 6; q++) {
+        const double h = d.lm_hP[((size_t)k * 6 + q) * TL + slot];
+        hy += h * sy[6 * (s0 + 1 + k) + q];
+        hv += h * sv[6 * (s0 + 1 + k) + q];
+      }
+    const double sl = d.lm_sl[slot], Hll = d.lm_Hll[slot], gl = d.lm_gl[slot];
+    const double hll = sl * sl * Hll, d2 = clamp_diag(hll), glt = sl * gl;
+    const double yl = (glt - sl * hy) / (hll + c.mu * d2);
+    const double vl = glt / d2;
+    d.lm_yl[slot] = yl; d.lm_vl[slot] = vl;
+    p[0] = glt * glt / d2;                                   // G2
+    p[1] = d2 * yl * yl;                                     // N2
+    p[2] = glt * yl;                                         // gy
+    p[3] = 2.0 * vl * sl * hv + hll * vl * vl;               // vHv
+    p[4] = vl * sl * hy + yl * sl * hv + hll * vl * yl;      // vHy
+    p[5] = 2.0 * yl * sl * hy + hll * yl * yl;               // yHy
+    p[6] = fabs(gl);                                         // gradient max-norm share
+    const double lam = d.lam[(size_t)c.cur * TL + slot];
+    p[7] = lam * lam;                                        // |x|^2 share
+  }
+  double *out = d.tile_gram + ((size_t)w * d.max_tiles + tile) * 8;
+  for (int q = 0; q < 8; q++) {
+    const double r = (q == 6) ? wave_max(p[q]) : wave_sum(p[q]);
+    if (t == 0) out[q] = r;
+  }
+}
+
+// =============================================================================================
+// k_step: scalar trust-region logic of one iteration (one thread per window).
+// =============================================================================================
+__global__ void k_step(BatchDev d) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.B) return;
+  const WinDesc &ds = d.desc[w];
+  WinCtl &c = d.ctl[w];
+  if (c.done) return;
+  if (c.have_step == 2) {   // fresh linearisation: fold in the landmark shares
+    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < ds.n_tiles; q++) {
+      const double *tg = d.tile_gram + ((size_t)w * d.max_tiles + q) * 8;
+      for (int k = 0; k < 8; k++) p[k] = (k == 6) ? fmax(p[k], tg[k]) : p[k] + tg[k];
+    }
+    c.G2 += p[0]; c.N2 += p[1]; c.gy += p[2]; c.vHv += p[3]; c.vHy += p[4]; c.yHy += p[5];
+    c.grad_max = fmax(c.grad_max, p[6]);
+    c.x_norm = sqrt(c.x_norm + p[7]);
+    c.alpha = c.G2 / c.vHv;
+    c.reuse = 1;
+  }
+  c.have_step = 0;
+  // TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue
+  const int max_it = min(d.opt.max_num_iterations, 15);
+  if (c.iter >= max_it) { c.done = 1; c.termination = 0; return; }
+  if (c.grad_max <= d.opt.gradient_tolerance) { c.done = 1; c.termination = 3; c.status = GFBE_OK; return; }
+  if (c.radius < 1e-32) { c.done = 1; c.termination = 4; return; }
+  c.iter++;
+  const int it = c.iter;
+  const double radius = c.radius;
+  const double g_norm = sqrt(c.G2), gn_norm = sqrt(c.N2);
+  double c1, c2, step_norm;
+  if (gn_norm <= radius) { c1 = 0.0; c2 = -1.0; step_norm = gn_norm; }
+  else if (g_norm * c.alpha >= radius) { c1 = -radius / g_norm; c2 = 0.0; step_norm = radius; }
+  else {
+    const double b_dot_a = c.alpha * c.gy;
+    const double a_sq = (c.alpha * g_norm) * (c.alpha * g_norm);
+    const double bma = a_sq - 2.0 * b_dot_a + c.N2;
+    const double cc = b_dot_a - a_sq;
+    const double dd = sqrt(cc * cc + bma * (radius * radius - a_sq));
+    const double beta = (cc <= 0.0) ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
+    c1 = -c.alpha * (1.0 - beta); c2 = -beta;
+    step_norm = sqrt(fmax(0.0, c1 * c1 * c.G2 + 2.0 * c1 * c2 * c.gy + c2 * c2 * c.N2));
+  }
+  const double model_change = -(c1 * c.G2 + c2 * c.gy) - 0.5 * (c1 * c1 * c.vHv + 2.0 * c1 * c2 * c.vHy + c2 * c2 * c.yHy);
+  c.c1 = c1; c.c2 = c2; c.step_norm = step_norm; c.model_change = model_change;
+  if (!(model_change > 0.0)) {   // TrustRegionMinimizer::HandleInvalidStep
+    c.accepted[it] = 0; c.cost_history[it] = c.cost;
+    if (++c.invalid_steps >= 5) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; return; }
+    c.mu *= GF_MU_INC; c.reuse = 0;
+    return;
+  }
+  c.invalid_steps = 0;
+  c.have_step = 1;
+}
+
+// =============================================================================================
+// k_candidate: x_cand = x (+) s * (c1 v + c2 y). Blocks [0, max_tiles) landmarks, block max_tiles
+// the dense parameter blocks.
+// =============================================================================================
+__global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
+  const int w = blockIdx.y;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (c.done || !c.have_step) return;
+  const int t = threadIdx.x;
+  const size_t TL = d.tot_lm;
+  if ((int)blockIdx.x < d.max_tiles) {
+    const int tile = blockIdx.x;
+    if (tile >= ds.n_tiles) return;
+    const int slot = ds.lm_off + tile * LM_TILE + t;
+    const int info = d.lm_info[slot];
+    const bool valid = (info >> 24) & 1;
+    const bool free_lm = valid && !((info >> 16) & 1) && ((info >> 8) & 0xff) > 0;
+    const double lam = d.lam[(size_t)c.cur * TL + slot];
+    double lc = lam, d2 = 0.0, n2 = 0.0;
+    if (free_lm) {
+      lc = lam + d.lm_sl[slot] * (c.c1 * d.lm_vl[slot] + c.c2 * d.lm_yl[slot]);
+      d2 = (lam - lc) * (lam - lc);
+      n2 = lc * lc;
+    }
+    d.lam[(size_t)(1 - c.cur) * TL + slot] = lc;
+    d2 = wave_sum(d2); n2 = wave_sum(n2);
+    if (t == 0) {
+      double *o = d.tile_cand + ((size_t)w * d.max_tiles + tile) * 4;
+      o[1] = d2; o[2] = n2;
+    }
+  } else {
+    const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
+    double *Y = d.x + ((size_t)w * 2 + 1 - c.cur) * NA;
+    double d2 = 0.0, n2 = 0.0;
+    if (t < GFBE_BLK_COUNT) {
+      const int b = t, off = blk_tan(b), am = blk_amb(b), gs = blk_gsize(b);
+      if (ds.blk_free[b]) {
+        double dl[9];
+        for (int k = 0; k < blk_lsize(b); k++) {
+          const size_t a = (size_t)w * ND + off + k;
+          dl[k] = d.sp[a] * (c.c1 * d.vp[a] + c.c2 * d.yp[a]);
+          d.step[a] = dl[k];
+        }
+        if (gs == 7) {
+          const unsigned char *mask = (b == GFBE_BLK_EX_CAM) ? ds.ex_cam_mask : (b == GFBE_BLK_EX_WHEEL ? ds.ex_wheel_mask : nullptr);
+          pose_plus(X + am, dl, mask, Y + am);
+        } else {
+          for (int k = 0; k < gs; k++) Y[am + k] = X[am + k] + dl[k];
+        }
+        for (int k = 0; k < gs; k++) { const double df = X[am + k] - Y[am + k]; d2 += df * df; n2 += Y[am + k] * Y[am + k]; }
+      } else {
+        for (int k = 0; k < gs; k++) Y[am + k] = X[am + k];
+      }
+    }
+    d2 = wave_sum(d2); n2 = wave_sum(n2);
+    if (t == 0) { d.dense_cand[(size_t)w * 4 + 1] = d2; d.dense_cand[(size_t)w * 4 + 2] = n2; }
+  }
+}
+
+// =============================================================================================
+// k_accept: candidate cost, tolerances, step acceptance, radius / mu update
+// (TrustRegionMinimizer::{ParameterToleranceReached,FunctionToleranceReached,IsStepSuccessful,
+//  HandleSuccessfulStep,HandleUnsuccessfulStep}, DoglegStrategy::{StepAccepted,StepRejected}).
+// =============================================================================================
+__global__ void k_accept(BatchDev d) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.B) return;
+  const WinDesc &ds = d.desc[w];
+  WinCtl &c = d.ctl[w];
+  if (c.done || !c.have_step) return;
+  double cand = 0.0, d2 = d.dense_cand[(size_t)w * 4 + 1], n2 = d.dense_cand[(size_t)w * 4 + 2];
+  for (int q = 0; q < ds.n_tiles; q++) {
+    const double *o = d.tile_cand + ((size_t)w * d.max_tiles + q) * 4;
+    cand += o[0]; d2 += o[1]; n2 += o[2];
+  }
+  for (int q = 0; q < ds.n_imu; q++) cand += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 1];
+  for (int q = 0; q < ds.n_wheel; q++) cand += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 1];
+  cand += d.prior_g[(size_t)w * (ND + 2) + ND + 1];
+  if (!isfinite(cand)) cand = 1.7976931348623157e308;
+  const int it = c.iter;
+  c.cand_cost = cand;
+  c.cost_history[it] = c.cost;
+  const double step_amb = sqrt(d2);
+  if (step_amb <= d.opt.parameter_tolerance * (c.x_norm + d.opt.parameter_tolerance)) {
+    c.done = 1; c.termination = 2; c.status = GFBE_OK; c.have_step = 0; return;
+  }
+  const double cost_change = c.cost - cand;
+  if (fabs(cost_change) <= d.opt.function_tolerance * c.cost) {
+    c.done = 1; c.termination = 1; c.status = GFBE_OK; c.have_step = 0; return;
+  }
+  const double quality = cost_change / c.model_change;
+  if (quality > d.opt.min_relative_decrease) {
+    c.cur = 1 - c.cur;
+    c.cost = cand;
+    c.x_norm = sqrt(n2);
+    c.accepted[it] = 1; c.num_successful++;
+    c.cost_history[it] = cand;
+    if (quality < 0.25) c.radius *= 0.5;
+    if (quality > 0.75) c.radius = fmax(c.radius, 3.0 * c.step_norm);
+    c.mu = fmax(GF_MIN_MU, 2.0 * c.mu / GF_MU_INC);
+    c.reuse = 0;
+  } else {
+    c.accepted[it] = 0;
+    c.radius *= 0.5;
+    c.reuse = 1;
+  }
+  c.have_step = 0;
+}
+
+// =============================================================================================
+// k_reanchor: double2vector()'s yaw / position gauge fix followed by vector2double()
+// (estimator.cpp:2501-2555, 2341-2362): the result is what optimization() leaves in para_*.
+// =============================================================================================
+__global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinCtl &c = d.ctl[w];
+  const double *X0 = d.x0 + (size_t)w * NA;
+  const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
+  double *Y = d.xout + (size_t)w * NA;
+  const int t = threadIdx.x;
+  for (int q = t; q < NA; q += 64) Y[q] = X[q];
+  __syncthreads();
+  const mat3 R0 = qrot(ldq(X0 + A_POSE(0) + 3));
+  const mat3 R00 = qrot(ldq(X + A_POSE(0) + 3));
+  const vec3 o0 = rot_to_ypr_deg(R0), o00 = rot_to_ypr_deg(R00);
+  mat3 rd = yaw_rot_deg(o0[0] - o00[0]);
+  if (fabs(fabs(o0[1]) - 90.0) < 1.0 || fabs(fabs(o00[1]) - 90.0) < 1.0) rd = mul(R0, transp(R00));
+  if (t < NF) {
+    const mat3 Ri = mul(rd, qrot(qnormalize(ldq(X + A_POSE(t) + 3))));
+    const vec3 Pi = add(mv(rd, sub(ld3(X + A_POSE(t)), ld3(X + A_POSE(0)))), ld3(X0 + A_POSE(0)));
+    const vec3 Vi = mv(rd, ld3(X + A_SB(t)));
+    const quat q = rot2quat(Ri);
+    double *p = Y + A_POSE(t);
+    p[0] = Pi[0]; p[1] = Pi[1]; p[2] = Pi[2]; p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
+    double *v = Y + A_SB(t);
+    v[0] = Vi[0]; v[1] = Vi[1]; v[2] = Vi[2];
+  } else if (t == NF) {
+    const quat q = rot2quat(qrot(ldq(X + A_EX + 3)));
+    Y[A_EX + 3] = q.x; Y[A_EX + 4] = q.y; Y[A_EX + 5] = q.z; Y[A_EX + 6] = q.w;
+  } else if (t == NF + 1) {
+    const quat q = rot2quat(qrot(qnormalize(ldq(X + A_EXW + 3))));
+    Y[A_EXW + 3] = q.x; Y[A_EXW + 4] = q.y; Y[A_EXW + 5] = q.z; Y[A_EXW + 6] = q.w;
+  }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+static size_t solve_smem_bytes() { return sizeof(double) * (ND * (ND + 1) / 2 + 7 * ND + 16) + 16; }
+
+void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B), dim3(256), 0, s, d); }
+void launch_reset(const BatchDev &d, hipStream_t s) {
+  const int slots = d.max_tiles * LM_TILE;
+  hipLaunchKernelGGL(k_reset, dim3((slots + 255) / 256 > 0 ? (slots + 255) / 256 : 1, d.B), dim3(256), 0, s, d);
+}
+void launch_vis(const BatchDev &d, int mode, hipStream_t s) {
+  if (d.max_tiles == 0) return;
+  const dim3 g(d.max_tiles, d.B), b(LM_TILE);
+  if (mode == 0) hipLaunchKernelGGL(k_vis<0>, g, b, 0, s, d);
+  else if (mode == 1) hipLaunchKernelGGL(k_vis<1>, g, b, 0, s, d);
+  else hipLaunchKernelGGL(k_vis<2>, g, b, 0, s, d);
+}
+void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
+  hipLaunchKernelGGL(k_pair, dim3(NF * (NF - 1) / 2, d.B), dim3(256), 0, s, d, marg);
+}
+void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_dense, dim3(MAX_IMU + MAX_WHEEL + 1, d.B), dim3(64), 0, s, d, mode, debug_out);
+}
+void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
+  if (d.max_tiles == 0) return;
+  hipLaunchKernelGGL(k_schur, dim3(d.max_tiles, d.B), dim3(256), 0, s, d, marg);
+}
+void launch_assemble(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(16, d.B), dim3(256), 0, s, d); }
+void launch_solve(const BatchDev &d, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem_bytes());
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d);
+}
+void launch_lm_step(const BatchDev &d, hipStream_t s) {
+  if (d.max_tiles == 0) return;
+  hipLaunchKernelGGL(k_lm_step, dim3(d.max_tiles, d.B), dim3(LM_TILE), 0, s, d);
+}
+void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3((d.B + 63) / 64), dim3(64), 0, s, d); }
+void launch_candidate(const BatchDev &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_candidate, dim3(d.max_tiles + 1, d.B), dim3(LM_TILE), 0, s, d);
+}
+void launch_accept(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_accept, dim3((d.B + 63) / 64), dim3(64), 0, s, d); }
+void launch_reanchor(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_reanchor, dim3(d.B), dim3(64), 0, s, d); }
+
+}  // namespace gfd

@@ -1,0 +1,312 @@
+// gfbe_marg.hip — marginalisation of the departing frame on the device.
+//
+// Reference: Estimator::optimization() marginalisation branches
+//   Ground-Fusion++/vins_estimator/src/estimator/estimator.cpp:3394-3693
+// and MarginalizationInfo::{preMarginalize, marginalize, getParameterBlocks}
+//   Ground-Fusion++/vins_estimator/src/factor/marginalization_factor.cpp:119-330.
+//
+// The factor set is linearised by the same kernels as the solve (k_vis<2>, k_pair, k_dense mode 2/3,
+// k_schur marg) at the re-anchored state; k_marg then does, per window in one workgroup:
+//   A, b assembly  ->  eliminate the inverse depths of the landmarks starting at frame 0 (diagonal
+//   block, done by k_schur)  ->  eliminate Pose[0] + SpeedBias[0] (or Pose[9]) through an
+//   eigen-decomposition pseudo-inverse with eps = 1e-8  ->  A' = V S V^T, J0 = sqrt(S) V^T,
+//   r0 = 1/sqrt(S) V^T b'  (marginalization_factor.cpp:278-302).
+// The reference eigen-decomposes the whole (15 + #landmarks) block Amm at once; eliminating the
+// diagonal landmark block first is the same Schur complement whenever every eigenvalue of Amm is
+// above eps (then pinv == inverse) — landmarks with H_ll <= eps are dropped like the reference's
+// thresholding does.
+#include "gfbe_device.h"
+#include "gfbe_factors.h"
+
+namespace gfd {
+
+// device functions defined in gfbe_kernels.hip are not visible here; re-declare the small index
+// helpers locally (kept in sync by tests/test_gpu_marginalize.py).
+__device__ __forceinline__ int m_pair_tri(int a, int b) {
+  if (a > b) { const int t = a; a = b; b = t; }
+  return a * 19 - a * (a - 1) / 2 + (b - a);
+}
+__device__ __forceinline__ int m_vis_loc(int a, int j) {   // pair (0, j)
+  if (a < 66) { const int f = a / 6; if (f == 0) return a; if (f == j) return 6 + a - 6 * f; return -1; }
+  if (a < 72) return 12 + (a - 66);
+  if (a == 72) return 18;
+  return -1;
+}
+__device__ __forceinline__ int m_imu_loc(int a) {          // IMU factor (0, 1)
+  if (a < 6) return a;
+  if (a < 12) return 15 + a - 6;
+  if (a >= 73 && a < 82) return 6 + a - 73;
+  if (a >= 82 && a < 91) return 21 + a - 82;
+  return -1;
+}
+__device__ __forceinline__ int m_wheel_loc(int a) {        // wheel factor (0, 1)
+  if (a < 6) return a;
+  if (a < 12) return 6 + a - 6;
+  if (a >= T_EXW && a < T_EXW + 6) return 12 + (a - T_EXW);
+  if (a >= T_SX && a <= T_TDW) return 18 + (a - T_SX);
+  return -1;
+}
+
+struct MargShared {
+  int touched[GFBE_BLK_COUNT];
+  int keep_id[GFBE_MAX_PRIOR_BLOCKS];
+  int n_keep, n, m;
+  int drop_dim[16];       // tangent dims being eliminated densely (15 for OLD, 6 for SECOND_NEW)
+  int keep_dim[ND];       // tangent dim of kept column k
+  int use_imu, use_wheel;
+  int passthrough;
+};
+
+// Parallel one-sided (Hestenes) Jacobi on a symmetric n x n matrix held column-major in G
+// (G is overwritten by A V); V accumulates the rotations. lambda_j = v_j . g_j.
+__device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int *conv_flag) {
+  const int t = threadIdx.x, nt = blockDim.x;
+  const int np = (n + 1) & ~1;                 // even number of "players"; player n (if odd) is a bye
+  const int grp = t >> 4, gl = t & 15, ngrp = nt >> 4;
+  for (int e = t; e < n * n; e += nt) V[(e / n) * ld + (e % n)] = ((e / n) == (e % n)) ? 1.0 : 0.0;
+  __syncthreads();
+  for (int sweep = 0; sweep < 40; sweep++) {
+    if (t == 0) *conv_flag = 0;
+    __syncthreads();
+    for (int r = 0; r < np - 1; r++) {
+      for (int k = grp; k < np / 2; k += ngrp) {
+        int p, q;
+        if (k == 0) { p = np - 1; q = r; }
+        else { p = (r + k) % (np - 1); q = (r - k + (np - 1)) % (np - 1); }
+        if (p >= n || q >= n) continue;
+        if (p > q) { const int tt = p; p = q; q = tt; }
+        double *gp = G + (size_t)p * ld, *gq = G + (size_t)q * ld;
+        double a = 0.0, b = 0.0, c = 0.0;
+        for (int i = gl; i < n; i += 16) { const double x = gp[i], y = gq[i]; a += x * x; b += y * y; c += x * y; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 16); b += __shfl_xor(b, o, 16); c += __shfl_xor(c, o, 16); }
+        if (fabs(c) <= 1e-15 * sqrt(a * b) || c == 0.0) continue;
+        if (gl == 0) *conv_flag = 1;
+        const double zeta = (b - a) / (2.0 * c);
+        const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
+        double *vp = V + (size_t)p * ld, *vq = V + (size_t)q * ld;
+        for (int i = gl; i < n; i += 16) {
+          const double x = gp[i], y = gq[i];
+          gp[i] = cs * x - sn * y; gq[i] = sn * x + cs * y;
+          const double u = vp[i], v = vq[i];
+          vp[i] = cs * u - sn * v; vq[i] = sn * u + cs * v;
+        }
+      }
+      __syncthreads();
+    }
+    const int any = *conv_flag;
+    __syncthreads();
+    if (!any) break;
+  }
+  for (int j = t; j < n; j += nt) {
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += V[(size_t)j * ld + i] * G[(size_t)j * ld + i];
+    lam[j] = s;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_marg(BatchDev d, int flag) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  const int t = threadIdx.x;
+  __shared__ MargShared sh;
+  __shared__ double Pm[16 * 16], Pv[16 * 16], Pl[16], Pinv[16 * 16], bm[16];
+  __shared__ int cflag;
+  int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
+  const double *Xo = d.xout + (size_t)w * NA;
+  double *A = d.mA + (size_t)w * ND * ND;      // working matrices (global / L2)
+  double *bv = d.mb + (size_t)w * ND;
+  double *J0 = d.mJ0 + (size_t)w * ND * ND;
+  double *r0 = d.mr0 + (size_t)w * ND;
+  const bool old = (flag == GFBE_MARGIN_OLD);
+
+  if (t == 0) {
+    for (int q = 0; q < GFBE_BLK_COUNT; q++) sh.touched[q] = 0;
+    for (int q = 0; q < ds.prior_nblk; q++) sh.touched[ds.prior_blk_id[q]] = 1;
+    sh.use_imu = sh.use_wheel = 0; sh.passthrough = 0;
+    if (old) {
+      for (int q = 0; q < ds.n_imu; q++) if (d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2] >= 0.0 && ds.imu_frame[q] == 0) sh.use_imu = 1 + q;
+      for (int q = 0; q < ds.n_wheel; q++) if (d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2] >= 0.0 && ds.wheel_frame[q] == 0) sh.use_wheel = 1 + q;
+      if (sh.use_imu) sh.touched[0] = sh.touched[GFBE_BLK_SB0] = sh.touched[1] = sh.touched[GFBE_BLK_SB0 + 1] = 1;
+      if (sh.use_wheel) sh.touched[0] = sh.touched[1] = sh.touched[GFBE_BLK_EX_WHEEL] = sh.touched[GFBE_BLK_SX] = sh.touched[GFBE_BLK_SY] = sh.touched[GFBE_BLK_SW] = sh.touched[GFBE_BLK_TD_WHEEL] = 1;
+      for (int j = 1; j < NF; j++)
+        if (ds.pair_begin[j + 1] > ds.pair_begin[j]) sh.touched[0] = sh.touched[j] = sh.touched[GFBE_BLK_EX_CAM] = sh.touched[GFBE_BLK_TD] = 1;
+    }
+    int m = 0;
+    if (old) {
+      if (sh.touched[0]) for (int k = 0; k < 6; k++) sh.drop_dim[m++] = k;
+      if (sh.touched[GFBE_BLK_SB0]) for (int k = 0; k < 9; k++) sh.drop_dim[m++] = T_SB(0) + k;
+    } else {
+      const int pb = GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1;
+      if (ds.prior_n > 0 && sh.touched[pb]) for (int k = 0; k < 6; k++) sh.drop_dim[m++] = T_POSE(GFBE_WINDOW_SIZE - 1) + k;
+      else sh.passthrough = 1;                      // estimator.cpp:3600-3601: prior does not touch Pose[9]
+    }
+    sh.m = m;
+    int nk = 0, n = 0;
+    for (int q = 0; q < GFBE_BLK_COUNT; q++) {
+      if (!sh.touched[q]) continue;
+      bool dropped = old ? (q == 0 || q == GFBE_BLK_SB0) : (q == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1);
+      if (dropped) continue;
+      sh.keep_id[nk++] = q;
+      for (int k = 0; k < blk_lsize(q); k++) sh.keep_dim[n++] = blk_tan(q) + k;
+    }
+    sh.n_keep = nk; sh.n = n;
+  }
+  __syncthreads();
+  if (sh.passthrough) {
+    // nothing to marginalise: the prior is handed back unchanged
+    const int n = ds.prior_n;
+    for (int e = t; e < n * n; e += blockDim.x) J0[e] = d.prior_J0[(size_t)w * ND * ND + e];
+    for (int e = t; e < n; e += blockDim.x) r0[e] = d.prior_r0[(size_t)w * ND + e];
+    for (int e = t; e < PRIOR_X0; e += blockDim.x) d.mx0[(size_t)w * PRIOR_X0 + e] = d.prior_x0[(size_t)w * PRIOR_X0 + e];
+    if (t == 0) {
+      meta[0] = n > 0 ? 1 : 0; meta[1] = n; meta[2] = ds.prior_nblk; meta[3] = 1;
+      for (int q = 0; q < ds.prior_nblk; q++) { meta[4 + q] = ds.prior_blk_id[q]; meta[4 + GFBE_MAX_PRIOR_BLOCKS + q] = ds.prior_blk_size[q]; meta[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q] = ds.prior_blk_idx[q]; }
+    }
+    return;
+  }
+  if (sh.m == 0) {   // marginalization_factor.cpp:205-210: "unstable tracking", valid = false
+    if (t == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; meta[3] = 0; }
+    return;
+  }
+  const int n = sh.n, m = sh.m;
+  // ---- full A (ND x ND, landmark block already eliminated) and b over all tangent dims
+  const double *pp = d.pair_part + (size_t)w * NPAIR * PAIR_STRIDE;
+  const double *sp = d.schur_part + (size_t)w * d.max_tiles * SCHUR_STRIDE;
+  const int t_end = ds.sf_tile_begin[1];
+  const double *ipart = sh.use_imu ? d.imu_part + ((size_t)w * MAX_IMU + sh.use_imu - 1) * IMU_PART : nullptr;
+  const double *wpart = sh.use_wheel ? d.wheel_part + ((size_t)w * MAX_WHEEL + sh.use_wheel - 1) * WHEEL_PART : nullptr;
+  for (int e = t; e < ND * ND; e += blockDim.x) {
+    const int a = e / ND, b = e % ND;
+    if (b > a) continue;
+    double s = 0.0;
+    if (old && a < NV) {
+      for (int j = 1; j < NF; j++) {
+        const int la = m_vis_loc(a, j), lb = m_vis_loc(b, j);
+        if (la >= 0 && lb >= 0) s += pp[(size_t)j * PAIR_STRIDE + m_pair_tri(la, lb)];
+      }
+      const int ap = (NV - 1) - b, bp = (NV - 1) - a;     // b <= a  ->  reversed coords ap >= bp
+      const int pe = ap * (ap + 1) / 2 + bp;
+      for (int q = 0; q < t_end; q++) s -= sp[(size_t)q * SCHUR_STRIDE + pe];
+    }
+    if (ipart) { const int la = m_imu_loc(a), lb = m_imu_loc(b); if (la >= 0 && lb >= 0) s += ipart[la * 30 + lb]; }
+    if (wpart) { const int la = m_wheel_loc(a), lb = m_wheel_loc(b); if (la >= 0 && lb >= 0) s += wpart[la * 22 + lb]; }
+    if (ds.prior_n > 0) { const int pa = ds.prior_map[a], pb = ds.prior_map[b]; if (pa >= 0 && pb >= 0) s += d.prior_H[(size_t)w * ND * ND + (size_t)pa * ds.prior_n + pb]; }
+    A[(size_t)a * ND + b] = s; A[(size_t)b * ND + a] = s;
+  }
+  for (int a = t; a < ND; a += blockDim.x) {
+    double s = 0.0;
+    if (old && a < NV) {
+      for (int j = 1; j < NF; j++) { const int la = m_vis_loc(a, j); if (la >= 0) s += pp[(size_t)j * PAIR_STRIDE + 190 + la]; }
+      for (int q = 0; q < t_end; q++) s -= sp[(size_t)q * SCHUR_STRIDE + TRI_NV + a];
+    }
+    if (ipart) { const int la = m_imu_loc(a); if (la >= 0) s += ipart[900 + la]; }
+    if (wpart) { const int la = m_wheel_loc(a); if (la >= 0) s += wpart[484 + la]; }
+    if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
+    bv[a] = s;
+  }
+  __syncthreads();
+  // ---- dense elimination of the m dropped dims: Amm = V diag(l) V^T, pinv with eps
+  for (int e = t; e < m * m; e += blockDim.x) {
+    const int i = e / m, j = e % m;
+    Pm[j * 16 + i] = 0.5 * (A[(size_t)sh.drop_dim[i] * ND + sh.drop_dim[j]] + A[(size_t)sh.drop_dim[j] * ND + sh.drop_dim[i]]);
+  }
+  if (t < m) bm[t] = bv[sh.drop_dim[t]];
+  __syncthreads();
+  jacobi_eig(Pm, Pv, m, 16, Pl, &cflag);
+  for (int e = t; e < m * m; e += blockDim.x) {
+    const int i = e / m, j = e % m;
+    double s = 0.0;
+    for (int k = 0; k < m; k++) if (Pl[k] > d.opt.marg_eps) s += Pv[k * 16 + i] * Pv[k * 16 + j] / Pl[k];
+    Pinv[i * 16 + j] = s;
+  }
+  __syncthreads();
+  // T = A_rm * Pinv (n x m) kept in J0's storage; then A' and b' (compact, n x n) into r0/J0 staging
+  double *T = J0;   // n x 16
+  for (int e = t; e < n * m; e += blockDim.x) {
+    const int i = e / m, j = e % m;
+    double s = 0.0;
+    for (int k = 0; k < m; k++) s += A[(size_t)sh.keep_dim[i] * ND + sh.drop_dim[k]] * Pinv[k * 16 + j];
+    T[i * 16 + j] = s;
+  }
+  __syncthreads();
+  double *Ap = J0 + (size_t)ND * 16;   // compact A' (n x n, ld = n) — fits: 16*ND + n*n <= ND*ND for n <= 166
+  for (int e = t; e < n * n; e += blockDim.x) {
+    const int i = e / n, j = e % n;
+    double s = A[(size_t)sh.keep_dim[i] * ND + sh.keep_dim[j]];
+    for (int k = 0; k < m; k++) s -= T[i * 16 + k] * A[(size_t)sh.drop_dim[k] * ND + sh.keep_dim[j]];
+    Ap[(size_t)i * n + j] = s;
+  }
+  for (int i = t; i < n; i += blockDim.x) {
+    double s = bv[sh.keep_dim[i]];
+    for (int k = 0; k < m; k++) s -= T[i * 16 + k] * bm[k];
+    r0[i] = s;           // b' staged in r0
+  }
+  __syncthreads();
+  // keep A', b' for inspection (tests compare J0^T J0 with A'): copy into mA / mb compactly
+  for (int e = t; e < n * n; e += blockDim.x) {
+    const int i = e / n, j = e % n;
+    A[e] = 0.5 * (Ap[(size_t)i * n + j] + Ap[(size_t)j * n + i]);
+  }
+  for (int i = t; i < n; i += blockDim.x) bv[i] = r0[i];
+  __syncthreads();
+  // ---- A' = V S V^T  (column-major G = copy of A', V in the tail of the J0 buffer)
+  double *G = J0;                       // n x n, overwrites T / Ap (both already consumed into A)
+  double *Vm = d.mV + (size_t)w * ND * ND;
+  for (int e = t; e < n * n; e += blockDim.x) G[e] = A[e];
+  __syncthreads();
+  double *lam = d.gts + (size_t)w * ND;           // solver scratch is dead by now
+  jacobi_eig(G, Vm, n, n, lam, &cflag);
+  // J0 = diag(sqrt(S)) V^T, r0 = diag(1/sqrt(S)) V^T b'   (marginalization_factor.cpp:294-302)
+  // rows are ordered by ascending eigenvalue like Eigen's solver
+  __shared__ int order[ND];
+  if (t == 0) {
+    for (int i = 0; i < n; i++) order[i] = i;
+    for (int i = 1; i < n; i++) { const int v = order[i]; int j = i - 1; while (j >= 0 && lam[order[j]] > lam[v]) { order[j + 1] = order[j]; j--; } order[j + 1] = v; }
+  }
+  __syncthreads();
+  for (int k = t; k < n; k += blockDim.x) {
+    const int src = order[k];
+    const double S = lam[src] > d.opt.marg_eps ? lam[src] : 0.0;
+    const double Sinv = lam[src] > d.opt.marg_eps ? 1.0 / lam[src] : 0.0;
+    double vb = 0.0;
+    for (int i = 0; i < n; i++) vb += Vm[(size_t)src * n + i] * bv[i];
+    r0[k] = sqrt(Sinv) * vb;
+    d.Dp[(size_t)w * ND + k] = sqrt(S);
+  }
+  __syncthreads();
+  for (int e = t; e < n * n; e += blockDim.x) {
+    const int k = e / n, i = e % n;
+    G[e] = d.Dp[(size_t)w * ND + k] * Vm[(size_t)order[k] * n + i];   // G aliases J0: row k of J0
+  }
+  // ---- getParameterBlocks + addr_shift (estimator.cpp:3561-3590, 3644-3687)
+  if (t == 0) {
+    meta[0] = 1; meta[1] = n; meta[2] = sh.n_keep; meta[3] = 0;
+    int idx = 0, xo = 0;
+    for (int q = 0; q < sh.n_keep; q++) {
+      const int id = sh.keep_id[q];
+      int nid = id;
+      if (old) { if (id < GFBE_BLK_EX_CAM) nid = id - 1; }
+      else if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE) nid = id - 1;
+      meta[4 + q] = nid; meta[4 + GFBE_MAX_PRIOR_BLOCKS + q] = blk_gsize(id); meta[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q] = idx;
+      for (int k = 0; k < blk_gsize(id); k++) d.mx0[(size_t)w * PRIOR_X0 + xo + k] = Xo[blk_amb(id) + k];
+      idx += blk_lsize(id); xo += blk_gsize(id);
+    }
+  }
+}
+
+void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {
+  if (flag == GFBE_MARGIN_OLD) {
+    launch_vis(d, 2, s);
+    launch_pair(d, 1, s);
+    launch_dense_factors(d, 2, 0, s);
+    launch_schur(d, 1, s);
+  } else {
+    launch_dense_factors(d, 3, 0, s);
+  }
+  hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(256), 0, s, d, flag);
+}
+
+}  // namespace gfd

@@ -748,8 +748,18 @@ int32_t gfo_solve_window(const gfbe_options *opt, const gfbe_window *w, int32_t 
   if (sol.sum.status == GFBE_NUMERICAL_FAILURE) { if (summary) *summary = sol.sum; return GFBE_NUMERICAL_FAILURE; }
   gfbe_state anchored;
   reanchor(w->state, sol.x, w->frame_count, anchored);
-  if (margin_flag != GFBE_MARGIN_NONE && prior_out && w->frame_count == GFBE_WINDOW_SIZE)
-    marginalize(P, anchored, sol.lam.data(), margin_flag, prior_out, nullptr, nullptr);
+  if (margin_flag != GFBE_MARGIN_NONE && prior_out && w->frame_count == GFBE_WINDOW_SIZE) {
+    const int rc = marginalize(P, anchored, sol.lam.data(), margin_flag, prior_out, nullptr, nullptr);
+    if (rc == 1 && P.has_prior) {      // estimator.cpp:3600-3601 not satisfied: last_marginalization_info stays
+      const gfbe_prior &pr = *w->prior;
+      prior_out->valid = pr.valid; prior_out->n = pr.n; prior_out->n_blocks = pr.n_blocks;
+      int xo = 0;
+      for (int q = 0; q < pr.n_blocks; q++) { prior_out->block_id[q] = pr.block_id[q]; prior_out->block_size[q] = pr.block_size[q]; prior_out->block_idx[q] = pr.block_idx[q]; xo += pr.block_size[q]; }
+      std::memcpy(prior_out->x0, pr.x0, sizeof(double) * xo);
+      std::memcpy(prior_out->J0, pr.J0, sizeof(double) * pr.n * pr.n);
+      std::memcpy(prior_out->r0, pr.r0, sizeof(double) * pr.n);
+    }
+  }
   *out_state = anchored;
   if (out_feature) std::memcpy(out_feature, sol.lam.data(), sizeof(double) * P.L);
   if (summary) *summary = sol.sum;

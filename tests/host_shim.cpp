@@ -1,0 +1,66 @@
+// tests/host_shim.cpp — TEST HARNESS ONLY. Compiles the product's __host__ __device__ factor
+// arithmetic (ground-fusion2_amd/csrc/gfbe_factors.h) for the HOST so that `-m "not gpu"` tests
+// can pin it against the oracle in a container without a GPU. Never loaded by the package: the
+// product path calls these functions only from HIP kernels.
+#include "../ground-fusion2_amd/csrc/gfbe_factors.h"
+#include <cstring>
+#include <vector>
+
+using namespace gfd;
+
+extern "C" int shim_eval_factors(const gfbe_options *opt, const gfbe_window *w, int robust, double *vis_r, double *vis_J,
+                                 double *imu_r, double *imu_J, double *wheel_r, double *wheel_J, double *prior_r) {
+  const gfbe_state &st = w->state;
+  const PoseRT Ex = make_pose(st.para_Ex_Pose);
+  const gfbe_visual &v = w->vis;
+  for (int k = 0; k < v.n_factor; k++) {
+    const PoseRT Fi = make_pose(st.para_Pose[v.imu_i[k]]), Fj = make_pose(st.para_Pose[v.imu_j[k]]);
+    double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
+    visual_eval<true>(Fi, Fj, Ex, w->para_Feature[v.feature_index[k]], st.para_Td, v.pts_i[3 * k], v.pts_i[3 * k + 1],
+                      v.pts_i[3 * k + 2], v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_i[2 * k], v.vel_i[2 * k + 1],
+                      v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_i[k], v.td_j[k], opt->vis_sqrt_info, r, Ji, Jj, Je, Jl, Jt);
+    if (robust) {
+      double s1, rs, asn;
+      corrector(r[0] * r[0] + r[1] * r[1], opt->huber_delta, &s1, &rs, &asn);
+      correct_cols(Ji, Ji + 6, 6, r[0], r[1], s1, asn);
+      correct_cols(Jj, Jj + 6, 6, r[0], r[1], s1, asn);
+      correct_cols(Je, Je + 6, 6, r[0], r[1], s1, asn);
+      correct_cols(Jl, Jl + 1, 1, r[0], r[1], s1, asn);
+      correct_cols(Jt, Jt + 1, 1, r[0], r[1], s1, asn);
+      r[0] *= rs; r[1] *= rs;
+    }
+    vis_r[2 * k] = r[0]; vis_r[2 * k + 1] = r[1];
+    double *J = vis_J + 40 * (size_t)k;
+    for (int row = 0; row < 2; row++) {
+      for (int c = 0; c < 6; c++) { J[row * 20 + c] = Ji[row * 6 + c]; J[row * 20 + 6 + c] = Jj[row * 6 + c]; J[row * 20 + 12 + c] = Je[row * 6 + c]; }
+      J[row * 20 + 18] = Jl[row]; J[row * 20 + 19] = Jt[row];
+    }
+  }
+  for (int k = 0; k < w->n_imu; k++) {
+    const int i = w->imu_frame[k];
+    double S[225], work[450], raw[15], Jraw[450];
+    if (sqrt_info_from_cov(w->imu[k].covariance, 15, S, work)) return 1;
+    std::memset(Jraw, 0, sizeof Jraw);
+    imu_raw(&w->imu[k], opt->g_norm, st.para_Pose[i], st.para_SpeedBias[i], st.para_Pose[i + 1], st.para_SpeedBias[i + 1], raw, Jraw);
+    for (int a = 0; a < 15; a++) {
+      double s = 0; for (int b = 0; b < 15; b++) s += S[a * 15 + b] * raw[b];
+      imu_r[15 * k + a] = s;
+      for (int c = 0; c < 30; c++) { double t = 0; for (int b = 0; b < 15; b++) t += S[a * 15 + b] * Jraw[b * 30 + c]; imu_J[450 * k + a * 30 + c] = t; }
+    }
+  }
+  for (int k = 0; k < w->n_wheel; k++) {
+    const int i = w->wheel_frame[k];
+    double S[36], work[72], raw[6], Jraw[132];
+    if (sqrt_info_from_cov(w->wheel[k].covariance, 6, S, work)) return 1;
+    std::memset(Jraw, 0, sizeof Jraw);
+    wheel_raw(&w->wheel[k], st.para_Pose[i], st.para_Pose[i + 1], st.para_Ex_Pose_wheel, st.para_Ix_wheel[0], st.para_Ix_wheel[1],
+              st.para_Ix_wheel[2], st.para_Td_wheel, raw, Jraw);
+    for (int a = 0; a < 6; a++) {
+      double s = 0; for (int b = 0; b < 6; b++) s += S[a * 6 + b] * raw[b];
+      wheel_r[6 * k + a] = s;
+      for (int c = 0; c < 22; c++) { double t = 0; for (int b = 0; b < 6; b++) t += S[a * 6 + b] * Jraw[b * 22 + c]; wheel_J[132 * k + a * 22 + c] = t; }
+    }
+  }
+  (void)prior_r;
+  return 0;
+}
