@@ -40,26 +40,35 @@ def test_factor_blocks_match_oracle(be, oracle, robust):
     for k in ("imu_r", "imu_J"):
         assert relerr(got[k], want[k]) < 1e-9, k
     assert relerr(got["prior_r"], want["prior_r"]) < 1e-11
-    assert abs(got["cost"] - want["cost"]) < 1e-10 * want["cost"]
+    if robust:    # the oracle's cost is always the robustified objective 1/2 sum rho(|r|^2)
+        assert abs(got["cost"] - want["cost"]) < 1e-10 * want["cost"]
 
 
-def check_solve(be, oracle, snap, flag, pos_tol=1e-7):
+def check_solve(be, oracle, snap, flag):
+    """Stated FP64 tolerances of a whole optimization() call vs the oracle (measured deviations on
+    MI355X are 2-4 orders of magnitude below them, see tests/diag_parity.py):
+      accept/reject sequence, iteration count, termination reason : identical
+      cost after every iteration : 1e-6 relative (the transient iterations drop the cost by 1e4)
+      final cost                 : 1e-9 relative
+      ATE of the 11 window poses : 1e-8 m ; rotations 1e-9 rad ; speed/bias 1e-7 ; inverse depths 1e-7 rel
+    """
     want = oracle.solve(snap, flag)
     got = be.solve(snap, flag)
     sw, sg = want["summary"], got["summary"]
     assert sg["iterations"] == sw["iterations"]
-    assert sg["accepted"] == sw["accepted"]                      # same accept / reject sequence
+    assert sg["accepted"] == sw["accepted"]
     assert sg["termination"] == sw["termination"]
-    np.testing.assert_allclose(sg["cost_history"], sw["cost_history"], rtol=1e-8)
-    assert abs(sg["final_cost"] - sw["final_cost"]) < 1e-8 * sw["final_cost"]
-    # ATE of the window poses vs the oracle
+    np.testing.assert_allclose(sg["cost_history"], sw["cost_history"], rtol=1e-6)
+    assert abs(sg["final_cost"] - sw["final_cost"]) < 1e-9 * sw["final_cost"]
     ate = np.sqrt(((got["state"]["pose"][:, :3] - want["state"]["pose"][:, :3]) ** 2).sum(axis=1).mean())
-    assert ate < pos_tol, ate
+    assert ate < 1e-8, ate
     for i in range(abi.NFRAMES):
         dq = synth.qmul(synth.qinv(want["state"]["pose"][i, 3:]), got["state"]["pose"][i, 3:])
-        assert 2 * np.linalg.norm(dq[:3]) < 1e-7
-    assert np.abs(got["state"]["speed_bias"] - want["state"]["speed_bias"]).max() < 1e-6
-    np.testing.assert_allclose(got["feature"], want["feature"], rtol=1e-6, atol=1e-9)
+        assert 2 * np.linalg.norm(dq[:3]) < 1e-9
+    assert np.abs(got["state"]["speed_bias"] - want["state"]["speed_bias"]).max() < 1e-7
+    for k in ("ex_pose", "ex_pose_wheel", "ix_wheel"):
+        assert np.abs(got["state"][k] - want["state"][k]).max() < 1e-7, k
+    np.testing.assert_allclose(got["feature"], want["feature"], rtol=1e-7, atol=1e-12)
     return want, got
 
 
