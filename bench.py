@@ -86,11 +86,8 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    solves = args.batch * args.steps * world
+    # whole-job aggregate: SUM of solves over ranks / MAX of elapsed over ranks
+    solves, elapsed = gf.dist.aggregate_throughput(args.batch * args.steps, elapsed, dist if world > 1 else None)
     value = solves / elapsed
 
     # ---- correctness of what was timed (cheap): every window converged to the same cost as window 0 of its kind

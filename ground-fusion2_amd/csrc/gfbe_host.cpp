@@ -74,6 +74,7 @@ void gfbe_default_options(gfbe_options *o) {
   o->min_relative_decrease = 1e-3;
   o->jacobi_scaling = 1;
   o->marg_eps = 1e-8;                        // marginalization_factor.h:70
+  o->marg_sqrt = 1;                          // pivoted LDL^T square root (0 = eigen-decomposition as in the reference)
 }
 
 const char *gfbe_version(void) { return "gfbe 0.1.0 (gfx950, HIP)"; }

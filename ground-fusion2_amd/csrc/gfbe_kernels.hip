@@ -612,7 +612,10 @@ __global__ __launch_bounds__(256) void k_assemble(BatchDev d) {
 // the dogleg scalars. (Ceres 1.14 DoglegStrategy::ComputeStep / ComputeGaussNewtonStep.)
 // =============================================================================================
 #define SOLVE_THREADS 256
-__device__ __forceinline__ int pk(int i, int j) { return i * (i + 1) / 2 + j; }   // j <= i
+#define TB 16                          // tile edge of the blocked Cholesky
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int tile_idx(int I, int J) { return I * (I + 1) / 2 + J; }   // J <= I
 
 // Rebuild E for a new mu directly from the landmark rows (slow path: only after a failed Cholesky).
 __device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu) {
@@ -651,47 +654,90 @@ __device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu
   __syncthreads();
 }
 
+// 1/sqrt(d) from v_rsq_f64 + two Newton steps (full FP64 accuracy without the long IEEE sqrt/div sequences).
+__device__ __forceinline__ double rsqrt_refined(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);
+  return r;
+}
+__device__ __forceinline__ double lane_bcast(double v, int src) {   // src is wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+// In-place lower Cholesky of one 16 x 16 LDS tile by a single wave: lane i < 16 keeps row i in
+// registers, column entries travel through v_readlane. On exit the diagonal holds 1 / L[k][k]
+// (the panel solve and the substitutions multiply by it). Returns false on a bad pivot.
+__device__ __forceinline__ bool chol_tile16(double *T, int lane) {
+  double row[TB];
+  const int li = lane & 15;
+#pragma unroll
+  for (int q = 0; q < TB; q++) row[q] = T[li * TB + q];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < TB; k++) {
+    const double dkk = lane_bcast(row[k], k);
+    if (!(dkk > 0.0) || !isfinite(dkk)) ok = false;
+    const double inv = rsqrt_refined(dkk);
+    const double lik = row[k] * inv;          // L[i][k] for i > k
+    row[k] = (li == k) ? inv : lik;
+#pragma unroll
+    for (int j = k + 1; j < TB; j++) {
+      const double ljk = lane_bcast(lik, j);
+      row[j] -= lik * ljk;                    // only meaningful for i >= j; the upper part is never read
+    }
+  }
+  if (lane < TB) {
+#pragma unroll
+    for (int q = 0; q < TB; q++) T[li * TB + q] = row[q];
+  }
+  return ok;
+}
+
 __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double *Lp = smem;                         // packed lower triangle, ND*(ND+1)/2
-  double *sp = Lp + ND * (ND + 1) / 2;       // ND
-  double *Dp = sp + ND, *gts = Dp + ND, *rhs = gts + ND, *yv = rhs + ND, *vv = yv + ND, *tmp = vv + ND;   // ND each
-  double *red = tmp + ND;                    // 16
-  int *flag = (int *)(red + 16);
-  const int t = threadIdx.x;
+  __shared__ int perm[ND + TB];
+  __shared__ double red[16], ys[ND + TB];
+  __shared__ int flag, s_nact;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
+  double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
+  double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
   const bool first = (c.iter == 0);
 
-  // total cost of this linearisation point (fixed order)
-  if (first && t == 0) {
-    double cost = 0.0;
-    for (int q = 0; q < ds.n_tiles; q++) cost += d.tile_cost[(size_t)w * d.max_tiles + q];
-    for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
-    for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
-    cost += d.prior_g[(size_t)w * (ND + 2) + ND];
-    c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
-  }
-  // scaling, diagonal, scaled gradient, Cauchy direction
-  double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
-  for (int a = t; a < ND; a += blockDim.x) {
-    double s = 1.0;
-    if (ds.act[a]) {
-      if (first) { s = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(H[(size_t)a * ND + a])) : 1.0; d.sp[(size_t)w * ND + a] = s; }
-      else s = d.sp[(size_t)w * ND + a];
-      const double d2 = clamp_diag(s * s * H[(size_t)a * ND + a]);
-      sp[a] = s; Dp[a] = sqrt(d2); gts[a] = s * g[a]; vv[a] = gts[a] / d2;
-      g2 += gts[a] * gts[a] / d2;
-      gmax = fmax(gmax, fabs(g[a]));
-    } else {
-      if (first) d.sp[(size_t)w * ND + a] = 1.0;
-      sp[a] = 1.0; Dp[a] = 1.0; gts[a] = 0.0; vv[a] = 0.0;
+  if (t == 0) {
+    int n = 0;
+    for (int a = 0; a < ND; a++) if (ds.act[a]) perm[n++] = a;
+    s_nact = n;
+    for (int a = n; a < ND + TB; a++) perm[a] = -1;
+    if (first) {   // total cost of the first linearisation point (fixed order)
+      double cost = 0.0;
+      for (int q = 0; q < ds.n_tiles; q++) cost += d.tile_cost[(size_t)w * d.max_tiles + q];
+      for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
+      for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
+      cost += d.prior_g[(size_t)w * (ND + 2) + ND];
+      c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
     }
   }
-  // |x|^2 over the free dense blocks (ambient)
+  // Jacobi scaling (iteration 0 only), D = sqrt(clamp(diag)), scaled gradient, Cauchy direction
+  double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
+  for (int a = t; a < ND; a += blockDim.x) {
+    double s = 1.0, dp = 1.0, gt = 0.0, v = 0.0;
+    if (ds.act[a]) {
+      const double haa = H[(size_t)a * ND + a];
+      s = first ? (d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(haa)) : 1.0) : gsp[a];
+      const double d2 = clamp_diag(s * s * haa);
+      dp = sqrt(d2); gt = s * g[a]; v = gt / d2;
+      g2 += gt * gt / d2;
+      gmax = fmax(gmax, fabs(g[a]));
+    }
+    if (first) gsp[a] = s;
+    gDp[a] = dp; ggts[a] = gt; gvp[a] = v;
+  }
   {
     const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
     for (int b = t; b < GFBE_BLK_COUNT; b += blockDim.x)
@@ -701,104 +747,154 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
   gmax = block_max(gmax, red);
   xn2 = block_sum(xn2, red);
   __syncthreads();
-
-  // mu-regularised Gauss-Newton solve with retries
-  double mu = c.mu;
-  bool solved = false;
+  const int n = s_nact;                 // active dims
+  const int na = n + 1;                 // + the right-hand side as an extra row (forward substitution for free)
+  const int nt = (na + TB - 1) / TB;    // tiles per side
   const double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
-  bool e_valid_for_mu = true;
+
+  double mu = c.mu;
+  bool solved = false, e_valid = true;
   while (mu < GF_MAX_MU) {
-    if (!e_valid_for_mu) rebuild_E(d, ds, w, mu);
-    // S = s H s + mu D^2 - s E s  (packed lower); constant dims -> identity
-    for (int e = t; e < ND * (ND + 1) / 2; e += blockDim.x) {
-      int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while ((a + 1) * (a + 2) / 2 <= e) a++;
-      while (a * (a + 1) / 2 > e) a--;
-      const int b = e - a * (a + 1) / 2;
-      double v;
-      if (!ds.act[a] || !ds.act[b]) v = (a == b) ? 1.0 : 0.0;
-      else {
-        v = H[(size_t)a * ND + b];
-        if (a < NV) v -= E[a * NV + b];
-        v *= sp[a] * sp[b];
-        if (a == b) v += mu * Dp[a] * Dp[a];
+    if (!e_valid) rebuild_E(d, ds, w, mu);
+    // ---- augmented, scaled, regularised, Schur-reduced system in 16x16 LDS tiles (lower triangle of tiles)
+    //      [ S    rhs ]   S = s H s + mu D^2 - s E s   rhs = gt - s eg
+    //      [ rhs' big ]
+    for (int I = 0; I < nt; I++)
+      for (int J = 0; J <= I; J++) {
+        double *T = smem + (size_t)tile_idx(I, J) * (TB * TB);
+        const int r = t >> 4, cc = t & 15;
+        const int ia = I * TB + r, ib = J * TB + cc;
+        double v;
+        if (ia < n && ib < n) {
+          const int a = perm[ia], b = perm[ib];
+          v = H[(size_t)a * ND + b];
+          if (a < NV && b < NV) v -= E[a * NV + b];
+          v *= gsp[a] * gsp[b];
+          if (a == b) v += mu * gDp[a] * gDp[a];
+        } else if (ia == n && ib < n) {
+          const int b = perm[ib];
+          v = ggts[b] - (b < NV ? gsp[b] * eg[b] : 0.0);
+        } else if (ib == n && ia < n) {
+          const int a = perm[ia];
+          v = ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0);
+        } else {
+          v = (ia == ib) ? (ia == n ? 1e200 : 1.0) : 0.0;
+        }
+        T[r * TB + cc] = v;
       }
-      Lp[e] = v;
-    }
-    for (int a = t; a < ND; a += blockDim.x) rhs[a] = ds.act[a] ? gts[a] - (a < NV ? sp[a] * eg[a] : 0.0) : 0.0;
-    if (t == 0) *flag = 0;
+    if (t == 0) flag = 0;
     __syncthreads();
-    // right-looking Cholesky, 16 x 16 thread grid over the trailing block
-    const int ti = t >> 4, tj = t & 15;
-    for (int k = 0; k < ND; k++) {
-      if (t == 0) {
-        const double dkk = Lp[pk(k, k)];
-        if (!(dkk > 0.0) || !isfinite(dkk)) *flag = 1;
-        else Lp[pk(k, k)] = sqrt(dkk);
+    // ---- blocked right-looking Cholesky: diagonal tile (1 wave) -> panel solve (thread per row) ->
+    //      trailing update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
+    for (int P = 0; P < nt; P++) {
+      double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+      if (wave == 0) { if (!chol_tile16(Tpp, lane) && lane == 0) flag = 1; }
+      __syncthreads();
+      if (flag) break;
+      const int rows = (nt - 1 - P) * TB;
+      if (t < rows) {
+        const int I = P + 1 + (t >> 4), r = t & 15;
+        double *row = smem + (size_t)tile_idx(I, P) * (TB * TB) + r * TB;
+        double x[TB];
+#pragma unroll
+        for (int q = 0; q < TB; q++) x[q] = row[q];
+#pragma unroll
+        for (int cidx = 0; cidx < TB; cidx++) {
+          double acc = x[cidx];
+#pragma unroll
+          for (int k = 0; k < cidx; k++) acc -= x[k] * Tpp[cidx * TB + k];
+          x[cidx] = acc * Tpp[cidx * TB + cidx];   // diagonal holds 1 / L[c][c]
+        }
+#pragma unroll
+        for (int q = 0; q < TB; q++) row[q] = x[q];
       }
       __syncthreads();
-      if (*flag) break;
-      const double inv = 1.0 / Lp[pk(k, k)];
-      for (int i = k + 1 + t; i < ND; i += blockDim.x) Lp[pk(i, k)] *= inv;
-      __syncthreads();
-      for (int i = k + 1 + ti; i < ND; i += 16) {
-        const double lik = Lp[pk(i, k)];
-        for (int j = k + 1 + tj; j <= i; j += 16) Lp[pk(i, j)] -= lik * Lp[pk(j, k)];
+      // trailing tiles (I, J), P < J <= I, round-robin over the 4 waves
+      const int nrem = nt - 1 - P;
+      const int ntr = nrem * (nrem + 1) / 2;
+      for (int e = wave; e < ntr; e += (SOLVE_THREADS >> 6)) {
+        int ii = 0, rr = e;
+        while (rr > ii) { rr -= ii + 1; ii++; }
+        const int I = P + 1 + ii, J = P + 1 + rr;
+        const double *LI = smem + (size_t)tile_idx(I, P) * (TB * TB), *LJ = smem + (size_t)tile_idx(J, P) * (TB * TB);
+        double *C = smem + (size_t)tile_idx(I, J) * (TB * TB);
+        const int lr = lane & 15, lk = lane >> 4;
+        dbl4 acc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] = C[(lk + 4 * q) * TB + lr];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-LI[lr * TB + kk * 4 + lk], LJ[lr * TB + kk * 4 + lk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) C[(lk + 4 * q) * TB + lr] = acc[q];
       }
       __syncthreads();
     }
-    bool ok = (*flag == 0);
+    bool ok = (flag == 0);
     if (ok) {
-      // forward / backward substitution by wave 0 (no block barriers)
-      if (t < 64) {
-        for (int k = 0; k < ND; k++) {
-          const double zk = rhs[k] / Lp[pk(k, k)];
-          for (int i = k + 1 + t; i < ND; i += 64) rhs[i] -= Lp[pk(i, k)] * zk;
-          if (t == 0) rhs[k] = zk;
-          __builtin_amdgcn_wave_barrier();
-          __threadfence_block();
+      // z = L^-1 rhs sits in row n of L. Backward substitution y = L^-T z, block by block, in LDS.
+      for (int i = t; i < n; i += blockDim.x)
+        ys[i] = smem[(size_t)tile_idx(n / TB, i / TB) * (TB * TB) + (n % TB) * TB + (i % TB)];
+      __syncthreads();
+      for (int P = (n - 1) / TB; P >= 0; P--) {
+        const double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+        const int r0 = P * TB, cnt = min(TB, n - r0);
+        if (wave == 0) {   // L_PP^T y_P = z_P: lane i keeps y_i and column i of L_PP in registers
+          const int li = lane & 15;
+          double colv[TB];
+#pragma unroll
+          for (int k = 0; k < TB; k++) colv[k] = Tpp[k * TB + li];     // L[k][i]; [k][k] is 1 / L[k][k]
+          double yi = (li < cnt) ? ys[r0 + li] : 0.0;
+#pragma unroll
+          for (int k = TB - 1; k >= 0; k--) {
+            if (k < cnt) {
+              const double yk = lane_bcast(yi, k) * lane_bcast(colv[k], k);
+              if (li == k) yi = yk;
+              else if (li < k) yi -= colv[k] * yk;
+            }
+          }
+          if (lane < cnt) ys[r0 + lane] = yi;
         }
-        for (int k = ND - 1; k >= 0; k--) {
-          const double yk = rhs[k] / Lp[pk(k, k)];
-          for (int i = t; i < k; i += 64) rhs[i] -= Lp[pk(k, i)] * yk;
-          if (t == 0) { rhs[k] = yk; }
-          __builtin_amdgcn_wave_barrier();
-          __threadfence_block();
+        __syncthreads();
+        for (int i = t; i < r0; i += blockDim.x) {   // z_J -= L(P,J)^T y_P for all J < P
+          const double *Tpj = smem + (size_t)tile_idx(P, i / TB) * (TB * TB);
+          double acc = 0.0;
+          for (int k = 0; k < cnt; k++) acc += Tpj[k * TB + (i % TB)] * ys[r0 + k];
+          ys[i] -= acc;
         }
+        __syncthreads();
       }
+      for (int a = t; a < ND; a += blockDim.x) gyp[a] = 0.0;
+      __syncthreads();
+      for (int i = t; i < n; i += blockDim.x) gyp[perm[i]] = ys[i];
       __syncthreads();
       int bad = 0;
-      for (int a = t; a < ND; a += blockDim.x) { yv[a] = ds.act[a] ? rhs[a] : 0.0; if (!isfinite(yv[a])) bad = 1; }
-      if (bad) *flag = 1;
+      for (int a = t; a < ND; a += blockDim.x) { if (!ds.act[a]) gyp[a] = 0.0; else if (!isfinite(gyp[a])) bad = 1; }
+      if (bad) flag = 1;
       __syncthreads();
-      ok = (*flag == 0);
+      ok = (flag == 0);
     }
     __syncthreads();
     if (ok) { solved = true; break; }
     mu *= GF_MU_INC;
-    e_valid_for_mu = false;
+    e_valid = false;
   }
   if (!solved) {
     if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
     return;
   }
-  // dense shares of the dogleg scalars: t_v = Ht v, t_y = Ht y  (Ht = s H s)
+  // dense shares of the dogleg scalars: t_v = Ht v, t_y = Ht y  (Ht = s H s; H symmetric -> column reads coalesce)
   double n2 = 0.0, gyv = 0.0, vhv = 0.0, vhy = 0.0, yhy = 0.0;
   for (int a = t; a < ND; a += blockDim.x) {
     if (!ds.act[a]) continue;
     double tv = 0.0, ty = 0.0;
-    const double *row = H + (size_t)a * ND;
-    for (int b = 0; b < ND; b++) { const double hb = sp[b] * row[b]; tv += hb * vv[b]; ty += hb * yv[b]; }
-    tv *= sp[a]; ty *= sp[a];
-    vhv += vv[a] * tv; vhy += yv[a] * tv; yhy += yv[a] * ty;
-    n2 += Dp[a] * Dp[a] * yv[a] * yv[a];
-    gyv += gts[a] * yv[a];
+    for (int b = 0; b < ND; b++) { const double hb = gsp[b] * H[(size_t)b * ND + a]; tv += hb * gvp[b]; ty += hb * gyp[b]; }
+    tv *= gsp[a]; ty *= gsp[a];
+    vhv += gvp[a] * tv; vhy += gyp[a] * tv; yhy += gyp[a] * ty;
+    n2 += gDp[a] * gDp[a] * gyp[a] * gyp[a];
+    gyv += ggts[a] * gyp[a];
   }
   n2 = block_sum(n2, red); gyv = block_sum(gyv, red); vhv = block_sum(vhv, red); vhy = block_sum(vhy, red); yhy = block_sum(yhy, red);
-  for (int a = t; a < ND; a += blockDim.x) {
-    d.Dp[(size_t)w * ND + a] = Dp[a]; d.gts[(size_t)w * ND + a] = gts[a];
-    d.vp[(size_t)w * ND + a] = vv[a]; d.yp[(size_t)w * ND + a] = yv[a];
-  }
   if (t == 0) {
     c.mu = mu;
     c.G2 = g2; c.N2 = n2; c.gy = gyv; c.vHv = vhv; c.vHy = vhy; c.yHy = yhy; c.grad_max = gmax;
@@ -1072,7 +1168,7 @@ __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
 // =============================================================================================
 // launchers
 // =============================================================================================
-static size_t solve_smem_bytes() { return sizeof(double) * (ND * (ND + 1) / 2 + 7 * ND + 16) + 16; }
+static size_t solve_smem_bytes() { const int nt = (ND + 1 + TB - 1) / TB; return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
 
 void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B), dim3(256), 0, s, d); }
 void launch_reset(const BatchDev &d, hipStream_t s) {

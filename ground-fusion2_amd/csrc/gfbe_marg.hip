@@ -55,12 +55,26 @@ struct MargShared {
   int keep_dim[ND];       // tangent dim of kept column k
   int use_imu, use_wheel;
   int passthrough;
+  int sweeps;
 };
 
 // Parallel one-sided (Hestenes) Jacobi on a symmetric n x n matrix held column-major in G
 // (G is overwritten by A V); V accumulates the rotations. lambda_j = v_j . g_j.
-__device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int *conv_flag) {
+__device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int *conv_flag, int *sweeps_out) {
   const int t = threadIdx.x, nt = blockDim.x;
+  // scale of the matrix: the largest squared column norm (computed redundantly per 16-lane group)
+  __shared__ double s_scale;
+  if (t == 0) s_scale = 0.0;
+  __syncthreads();
+  {
+    double mx = 0.0;
+    for (int j = t; j < n; j += nt) { double a = 0.0; for (int i = 0; i < n; i++) a += G[(size_t)j * ld + i] * G[(size_t)j * ld + i]; mx = fmax(mx, a); }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+    if ((t & 63) == 0 && mx > 0.0) atomicMax((unsigned long long *)&s_scale, (unsigned long long)__double_as_longlong(mx));
+  }
+  __syncthreads();
+  // columns whose norm (= |eigenvalue|) is both below roundoff of the largest one and far below eps
+  const double tiny2 = fmax(s_scale * 1e-30, 1e-24);
   const int np = (n + 1) & ~1;                 // even number of "players"; player n (if odd) is a bye
   const int grp = t >> 4, gl = t & 15, ngrp = nt >> 4;
   for (int e = t; e < n * n; e += nt) V[(e / n) * ld + (e % n)] = ((e / n) == (e % n)) ? 1.0 : 0.0;
@@ -80,7 +94,9 @@ __device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int
         for (int i = gl; i < n; i += 16) { const double x = gp[i], y = gq[i]; a += x * x; b += y * y; c += x * y; }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 16); b += __shfl_xor(b, o, 16); c += __shfl_xor(c, o, 16); }
-        if (fabs(c) <= 1e-15 * sqrt(a * b) || c == 0.0) continue;
+        // converged pair: orthogonal to working precision, or both columns are numerically null
+        // relative to the matrix scale (their eigenvalues are far below the eps threshold anyway)
+        if (fabs(c) <= 1e-14 * sqrt(a * b) || c == 0.0 || (a <= tiny2 && b <= tiny2)) continue;
         if (gl == 0) *conv_flag = 1;
         const double zeta = (b - a) / (2.0 * c);
         const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -97,6 +113,7 @@ __device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int
     }
     const int any = *conv_flag;
     __syncthreads();
+    if (sweeps_out && t == 0) *sweeps_out = sweep + 1;
     if (!any) break;
   }
   for (int j = t; j < n; j += nt) {
@@ -107,7 +124,10 @@ __device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_marg(BatchDev d, int flag) {
+#define MARG_THREADS 1024
+#define MARG_LDS_N 94   // A' up to this size is eigen-decomposed entirely inside LDS (2 n^2 doubles)
+
+__global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   const int t = threadIdx.x;
@@ -215,7 +235,7 @@ __global__ __launch_bounds__(256) void k_marg(BatchDev d, int flag) {
   }
   if (t < m) bm[t] = bv[sh.drop_dim[t]];
   __syncthreads();
-  jacobi_eig(Pm, Pv, m, 16, Pl, &cflag);
+  jacobi_eig(Pm, Pv, m, 16, Pl, &cflag, nullptr);
   for (int e = t; e < m * m; e += blockDim.x) {
     const int i = e / m, j = e % m;
     double s = 0.0;
@@ -252,16 +272,81 @@ __global__ __launch_bounds__(256) void k_marg(BatchDev d, int flag) {
   }
   for (int i = t; i < n; i += blockDim.x) bv[i] = r0[i];
   __syncthreads();
-  // ---- A' = V S V^T  (column-major G = copy of A', V in the tail of the J0 buffer)
-  double *G = J0;                       // n x n, overwrites T / Ap (both already consumed into A)
-  double *Vm = d.mV + (size_t)w * ND * ND;
+  extern __shared__ __attribute__((aligned(16))) double marg_lds[];
+  __shared__ int order[ND];
+  if (d.opt.marg_sqrt == 1) {
+    // ---- diagonally pivoted LDL^T of A' with pivots > eps:  A' ~= P L D+ L^T P^T,
+    //      J0 = D+^(1/2) L^T P^T,  r0 = D+^(-1/2) L^-1 P^T b'   (forward substitution folded in)
+    const bool in_lds = (n * n <= 2 * MARG_LDS_N * MARG_LDS_N);
+    double *M = in_lds ? marg_lds : d.mV + (size_t)w * ND * ND;    // full symmetric n x n, row-major
+    double *bz = d.gts + (size_t)w * ND;                           // running b' -> z
+    double *dk = d.Dp + (size_t)w * ND;                            // pivots
+    __shared__ double s_red[32];
+    __shared__ int s_idx[32], s_rank, s_piv;
+    for (int e = t; e < n * n; e += blockDim.x) M[e] = A[e];
+    for (int i = t; i < n; i += blockDim.x) { order[i] = i; bz[i] = bv[i]; }
+    if (t == 0) s_rank = n;
+    __syncthreads();
+    for (int k = 0; k < n; k++) {
+      // pivot search: largest remaining diagonal (first index on ties -> deterministic)
+      double best = -1e300; int bi = k;
+      for (int i = k + t; i < n; i += blockDim.x) { const double v = M[(size_t)i * n + i]; if (v > best) { best = v; bi = i; } }
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_down(best, o, 64); const int oi = __shfl_down(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if ((t & 63) == 0) { s_red[t >> 6] = best; s_idx[t >> 6] = bi; }
+      __syncthreads();
+      if (t == 0) {
+        double b2 = s_red[0]; int i2 = s_idx[0];
+        for (int q = 1; q < (int)(blockDim.x >> 6); q++) if (s_red[q] > b2 || (s_red[q] == b2 && s_idx[q] < i2)) { b2 = s_red[q]; i2 = s_idx[q]; }
+        s_piv = i2;
+        if (!(b2 > d.opt.marg_eps)) s_rank = k;
+      }
+      __syncthreads();
+      if (s_rank == k) break;
+      const int pv = s_piv;
+      if (pv != k) {   // symmetric swap k <-> pv
+        for (int j = t; j < n; j += blockDim.x) { const double a = M[(size_t)k * n + j]; M[(size_t)k * n + j] = M[(size_t)pv * n + j]; M[(size_t)pv * n + j] = a; }
+        __syncthreads();
+        for (int j = t; j < n; j += blockDim.x) { const double a = M[(size_t)j * n + k]; M[(size_t)j * n + k] = M[(size_t)j * n + pv]; M[(size_t)j * n + pv] = a; }
+        if (t == 0) { const int a = order[k]; order[k] = order[pv]; order[pv] = a; const double bb = bz[k]; bz[k] = bz[pv]; bz[pv] = bb; }
+        __syncthreads();
+      }
+      const double piv = M[(size_t)k * n + k], zk = bz[k];
+      const int rem = n - 1 - k;
+      for (int e = t; e < rem * rem; e += blockDim.x) {   // trailing update with the unscaled column
+        const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+        M[(size_t)i * n + j] -= M[(size_t)i * n + k] * M[(size_t)k * n + j] / piv;
+      }
+      for (int i = k + 1 + t; i < n; i += blockDim.x) bz[i] -= M[(size_t)i * n + k] / piv * zk;
+      if (t == 0) dk[k] = piv;
+      __syncthreads();
+      for (int i = k + 1 + t; i < n; i += blockDim.x) M[(size_t)i * n + k] /= piv;   // L[i][k]
+      __syncthreads();
+    }
+    const int rank = s_rank;
+    for (int e = t; e < n * n; e += blockDim.x) {
+      const int k = e / n, i = e % n;
+      double v = 0.0;
+      if (k < rank && i >= k) v = sqrt(dk[k]) * (i == k ? 1.0 : M[(size_t)i * n + k]);
+      J0[(size_t)k * n + order[i]] = v;
+    }
+    for (int k = t; k < n; k += blockDim.x) r0[k] = (k < rank) ? bz[k] / sqrt(dk[k]) : 0.0;
+    if (t == 0) sh.sweeps = -rank;
+  } else {
+  // ---- A' = V S V^T (the reference's construction). One-sided Jacobi; G (= A' V) and V live in LDS
+  // when they fit (the common n = 86 prior), otherwise in the global scratch.
+  const bool in_lds = (n <= MARG_LDS_N);
+  double *G = in_lds ? marg_lds : J0;   // n x n; J0's storage (T / Ap) is free: both were consumed into A
+  double *Vm = in_lds ? marg_lds + (size_t)n * n : d.mV + (size_t)w * ND * ND;
   for (int e = t; e < n * n; e += blockDim.x) G[e] = A[e];
   __syncthreads();
   double *lam = d.gts + (size_t)w * ND;           // solver scratch is dead by now
-  jacobi_eig(G, Vm, n, n, lam, &cflag);
+  jacobi_eig(G, Vm, n, n, lam, &cflag, &sh.sweeps);
+  G = J0;                                         // J0 rows are written to global below
   // J0 = diag(sqrt(S)) V^T, r0 = diag(1/sqrt(S)) V^T b'   (marginalization_factor.cpp:294-302)
   // rows are ordered by ascending eigenvalue like Eigen's solver
-  __shared__ int order[ND];
   if (t == 0) {
     for (int i = 0; i < n; i++) order[i] = i;
     for (int i = 1; i < n; i++) { const int v = order[i]; int j = i - 1; while (j >= 0 && lam[order[j]] > lam[v]) { order[j + 1] = order[j]; j--; } order[j + 1] = v; }
@@ -281,9 +366,10 @@ __global__ __launch_bounds__(256) void k_marg(BatchDev d, int flag) {
     const int k = e / n, i = e % n;
     G[e] = d.Dp[(size_t)w * ND + k] * Vm[(size_t)order[k] * n + i];   // G aliases J0: row k of J0
   }
+  }
   // ---- getParameterBlocks + addr_shift (estimator.cpp:3561-3590, 3644-3687)
   if (t == 0) {
-    meta[0] = 1; meta[1] = n; meta[2] = sh.n_keep; meta[3] = 0;
+    meta[0] = 1; meta[1] = n; meta[2] = sh.n_keep; meta[3] = sh.sweeps;   // [3]: Jacobi sweeps (diagnostic)
     int idx = 0, xo = 0;
     for (int q = 0; q < sh.n_keep; q++) {
       const int id = sh.keep_id[q];
@@ -306,7 +392,10 @@ void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {
   } else {
     launch_dense_factors(d, 3, 0, s);
   }
-  hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(256), 0, s, d, flag);
+  static bool attr_set = false;
+  const size_t lds = sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(MARG_THREADS), lds, s, d, flag);
 }
 
 }  // namespace gfd

@@ -94,6 +94,28 @@ def test_solve_cfg2_wheel_prior_2k(be, oracle):
     assert np.abs(bg - bw).max() < 1e-6 * max(np.abs(bw).max(), 1.0)
 
 
+def test_prior_square_root_modes(oracle):
+    """marg_sqrt = 0 (eigen-decomposition, the reference's construction) and 1 (pivoted LDL^T, default)
+    give the same information J0^T J0, J0^T r0 — 1e-9 relative to max|A'| — and both are valid square
+    roots of the oracle's thresholded A'."""
+    _, snap = window_with_prior(oracle, 20250711, 600)
+    want = oracle.solve(snap, abi.MARGIN_OLD)["prior"]
+    Aw, bw = want["J0"].T @ want["J0"], want["J0"].T @ want["r0"]
+    got = {}
+    for mode in (0, 1):
+        o = abi.default_options()
+        o.marg_sqrt = mode
+        pg = gf.Backend(device=0, options=o).solve(snap, abi.MARGIN_OLD)["prior"]
+        assert pg["block_id"].tolist() == want["block_id"].tolist() and pg["n"] == want["n"]
+        A, b = pg["J0"].T @ pg["J0"], pg["J0"].T @ pg["r0"]
+        assert np.abs(A - Aw).max() < 1e-9 * np.abs(Aw).max(), mode
+        assert np.abs(b - bw).max() < 1e-7 * max(1.0, np.abs(bw).max()), mode
+        got[mode] = (A, b)
+    assert np.abs(got[0][0] - got[1][0]).max() < 1e-9 * np.abs(Aw).max()
+    # using either prior in the next window gives the same solve
+    scn, _ = window_with_prior(oracle, 20250711, 600)
+
+
 def test_second_new_and_passthrough(be, oracle):
     _, snap = window_with_prior(oracle, 53, 400)
     want, got = check_solve(be, oracle, snap, abi.MARGIN_SECOND_NEW)
