@@ -25,7 +25,7 @@ EXPORTS = [
     "gfbe_solve_window", "gfbe_solve_batch",
     "gfbe_batch_upload", "gfbe_batch_solve", "gfbe_batch_download", "gfbe_batch_free",
     "gfbe_profile_enable", "gfbe_profile_count", "gfbe_profile_get", "gfbe_profile_reset",
-    "gfbe_set_allreduce",
+    "gfbe_set_allreduce", "gfbe_debug_timing",
 ]
 
 
@@ -174,6 +174,11 @@ class Batch:
             out.append(dict(state=abi.state_to_dict(states[k]), feature=feats[k],
                             prior=priors[k].to_dict() if priors[k].c.valid else None,
                             summary=abi.summary_to_dict(sums[k]), status=sums[k].status))
+        return out
+
+    def debug_timing(self, w=0):
+        out = np.zeros(32)
+        self.be.lib.gfbe_debug_timing(self.be.ctx, self.h, int(w), abi._pd(out))
         return out
 
     def free(self):

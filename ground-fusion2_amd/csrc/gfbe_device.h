@@ -21,7 +21,9 @@ enum {
   PAIR_E = 19 * 20 / 2 + 19,  // 190 J^T J entries + 19 J^T r entries of a pose-pair block = 209
   PAIR_STRIDE = 216,
   TRI_NV = NV * (NV + 1) / 2, // 2701
-  SCHUR_STRIDE = TRI_NV + NV + 2,   // E (packed) + e_g + pad = 2776
+  NVP = 80,                   // NV padded to 5 tiles of 16; column 73 carries the landmark gradient
+  SCHUR_TILES = 15,           // upper-triangular 16x16 tile pairs of the 80 x 80 block
+  SCHUR_STRIDE = SCHUR_TILES * 256, // one partial per (window, start frame): 15 dense tiles
   LM_TILE = 64,               // landmarks per workgroup in the landmark kernels
   SCHUR_CHUNK = 64,           // landmarks per Schur work item
   IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost
@@ -146,7 +148,7 @@ struct BatchDev {
   double *prior_J0, *prior_r0, *prior_x0, *prior_H;   // [B][ND*ND], [B][ND], [B][PRIOR_X0], [B][ND*ND]
   // partial results
   double *pair_part;          // [B][NPAIR][PAIR_STRIDE]
-  double *schur_part;         // [B][max_tiles][SCHUR_STRIDE]
+  double *schur_part;         // [B][NF][SCHUR_STRIDE]  sum over the landmarks of one start frame
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
   double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
@@ -166,6 +168,7 @@ struct BatchDev {
   double *mV;                 // [B][ND*ND] eigenvectors scratch
   int *mmeta;                 // [B][4 + 3*GFBE_MAX_PRIOR_BLOCKS]: valid, n, n_blocks, pad, ids, sizes, idx
   double *mx0;                // [B][PRIOR_X0]
+  double *timing;             // [B][32] phase time stamps of k_solve (wall_clock64, 10 ns ticks; diagnostics)
   int *tri_tab;               // [TRI_NV] packed (a' << 8 | b') lookup for the reversed lower-triangular enumeration
 };
 

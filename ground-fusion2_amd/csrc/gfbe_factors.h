@@ -78,6 +78,82 @@ GF_HD void visual_eval(const PoseRT &Fi, const PoseRT &Fj, const PoseRT &Ex, dou
   Jt[1] = r11 * tt[1] + r12 * tt[2] + sqrt_info * vjy;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pose-pair constants of the visual factor. Every factor of a pose pair (i, j) shares the products of
+// the three rotations; the kernels compute them once per workgroup and per pair instead of once per
+// factor (the reference rebuilds them in every Evaluate, projectionTwoFrameOneCamFactor.cpp:83-131).
+//   A = ric^T Rj^T, B = A Ri, Tm = B ric, u = A (ti - tj) + B tic - ric^T tic   =>   P_cj = Tm P_ci + u
+// The Jacobian blocks use R [v]x = [R v]x R (R a rotation: parameter quaternions are unit):
+//   d/dtheta_i : -B [P_bi]x        = -[Tm P_ci + B tic]x B
+//   d/dtheta_j :  ric^T [P_bj]x    =  [P_cj + ric^T tic]x ric^T
+//   d/dtheta_ex: -Tm [P_ci]x + [Tm P_ci]x + [u]x = [Tm P_ci]x (I - Tm) + [u]x
+// ---------------------------------------------------------------------------------------------
+struct PairConst {
+  mat3 A, B, Tm, ricT, ImTm, jep;   // jep = B - ric^T  (translation block of the extrinsic)
+  vec3 u, Btic, c2;                 // c2 = ric^T tic
+};
+GF_HD PairConst make_pair_const(const PoseRT &Fi, const PoseRT &Fj, const PoseRT &Ex) {
+  PairConst p;
+  p.ricT = transp(Ex.R);
+  p.A = tmul(Ex.R, transp(Fj.R));
+  p.B = mul(p.A, Fi.R);
+  p.Tm = mul(p.B, Ex.R);
+  p.ImTm = msub(ident3(), p.Tm);
+  p.jep = msub(p.B, p.ricT);
+  p.Btic = mv(p.B, Ex.t);
+  p.c2 = mv(p.ricT, Ex.t);
+  p.u = sub(add(mv(p.A, sub(Fi.t, Fj.t)), p.Btic), p.c2);
+  return p;
+}
+// [v]x * M
+GF_HD mat3 hat_mul(const vec3 &v, const mat3 &M) {
+  mat3 r;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    r(0, c) = v[1] * M(2, c) - v[2] * M(1, c);
+    r(1, c) = v[2] * M(0, c) - v[0] * M(2, c);
+    r(2, c) = v[0] * M(1, c) - v[1] * M(0, c);
+  }
+  return r;
+}
+
+template <bool JAC>
+GF_HD void visual_eval_pc(const PairConst &pc, double inv_dep, double td, double pix, double piy, double piz, double pjx,
+                          double pjy, double vix, double viy, double vjx, double vjy, double td_i, double td_j,
+                          double sqrt_info, double *r, double *Ji, double *Jj, double *Je, double *Jl, double *Jt) {
+  const double dti = td - td_i, dtj = td - td_j;
+  const double inv_l = 1.0 / inv_dep;
+  const vec3 p_ci = mk3((pix - dti * vix) * inv_l, (piy - dti * viy) * inv_l, piz * inv_l);
+  const vec3 q = mv(pc.Tm, p_ci);
+  const vec3 p_cj = add(q, pc.u);
+  const double inv_z = 1.0 / p_cj[2];
+  r[0] = sqrt_info * (p_cj[0] * inv_z - (pjx - dtj * vjx));
+  r[1] = sqrt_info * (p_cj[1] * inv_z - (pjy - dtj * vjy));
+  if (!JAC) return;
+  const double r00 = sqrt_info * inv_z, r02 = -sqrt_info * p_cj[0] * inv_z * inv_z;
+  const double r12 = -sqrt_info * p_cj[1] * inv_z * inv_z;   // r11 == r00
+  const mat3 ji_r = mneg(hat_mul(add(q, pc.Btic), pc.B));
+  const mat3 jj_r = hat_mul(add(p_cj, pc.c2), pc.ricT);
+  const mat3 je_r = madd(hat_mul(q, pc.ImTm), hat(pc.u));
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    Ji[c] = r00 * pc.A(0, c) + r02 * pc.A(2, c);      Ji[6 + c] = r00 * pc.A(1, c) + r12 * pc.A(2, c);
+    Ji[3 + c] = r00 * ji_r(0, c) + r02 * ji_r(2, c);  Ji[9 + c] = r00 * ji_r(1, c) + r12 * ji_r(2, c);
+    Jj[c] = -Ji[c];                                   Jj[6 + c] = -Ji[6 + c];
+    Jj[3 + c] = r00 * jj_r(0, c) + r02 * jj_r(2, c);  Jj[9 + c] = r00 * jj_r(1, c) + r12 * jj_r(2, c);
+    Je[c] = r00 * pc.jep(0, c) + r02 * pc.jep(2, c);  Je[6 + c] = r00 * pc.jep(1, c) + r12 * pc.jep(2, c);
+    Je[3 + c] = r00 * je_r(0, c) + r02 * je_r(2, c);  Je[9 + c] = r00 * je_r(1, c) + r12 * je_r(2, c);
+  }
+  // d/d lambda = reduce * Tm * p_i' * (-1/lambda^2) = -reduce * q / lambda   (:139)
+  Jl[0] = -(r00 * q[0] + r02 * q[2]) * inv_l;
+  Jl[1] = -(r00 * q[1] + r12 * q[2]) * inv_l;
+  // d/d td = reduce * Tm * [v_i;0] * (-1/lambda) + sqrt_info * v_j   (:144-145)
+  const double t0 = pc.Tm(0, 0) * vix + pc.Tm(0, 1) * viy, t1 = pc.Tm(1, 0) * vix + pc.Tm(1, 1) * viy;
+  const double t2 = pc.Tm(2, 0) * vix + pc.Tm(2, 1) * viy;
+  Jt[0] = -(r00 * t0 + r02 * t2) * inv_l + sqrt_info * vjx;
+  Jt[1] = -(r00 * t1 + r12 * t2) * inv_l + sqrt_info * vjy;
+}
+
 // ceres::HuberLoss::Evaluate
 GF_HD void huber_rho(double s, double delta, double *rho) {
   const double b = delta * delta;
@@ -110,6 +186,10 @@ GF_HD double corrector(double s, double delta, double *sqrt_rho1, double *residu
 }
 // Apply to a 2-row block with columns given as separate row arrays.
 GF_HD void correct_cols(double *row0, double *row1, int n, double r0, double r1, double sqrt_rho1, double asn) {
+  if (asn == 0.0) {   // always the case for HuberLoss (rho'' <= 0): J <- sqrt(rho') J
+    for (int c = 0; c < n; c++) { row0[c] *= sqrt_rho1; row1[c] *= sqrt_rho1; }
+    return;
+  }
   for (int c = 0; c < n; c++) {
     const double rtj = r0 * row0[c] + r1 * row1[c];
     row0[c] = sqrt_rho1 * (row0[c] - asn * r0 * rtj);

@@ -423,7 +423,7 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
   AL(rec, (size_t)tot_rec * REC);
   AL(imu_sqrt, imu.size() * 225); AL(wheel_sqrt, wheel.size() * 36); AL(prior_H, (size_t)B * ND * ND);
-  AL(pair_part, (size_t)B * NPAIR * PAIR_STRIDE); AL(schur_part, (size_t)B * std::max(max_tiles, 1) * SCHUR_STRIDE);
+  AL(pair_part, (size_t)B * NPAIR * PAIR_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
   AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
   AL(prior_g, (size_t)B * (ND + 2));
   AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
@@ -433,7 +433,7 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
   AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
   AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND); AL(mV, (size_t)B * ND * ND);
-  AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
+  AL(timing, (size_t)B * 32); AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
 #undef UP
 #undef AL
   { Timed t(c, "k_prep", 0); launch_prep(d, c->stream); }
@@ -667,6 +667,14 @@ extern "C" gfbe_status gfbe_preintegrate_imu(gfbe_ctx *c, int32_t n, const int32
 extern "C" gfbe_status gfbe_preintegrate_wheel(gfbe_ctx *c, int32_t n, const int32_t *offset, const double *samples,
                                               const double *first, const double *lin, const double noise[2], gfbe_wheel_preint *out) {
   return preint_common(c, n, offset, samples, first, lin, 4, noise, 2, out, false);
+}
+
+// diagnostics: copy the k_solve phase stamps of window w (32 doubles, 10 ns ticks)
+extern "C" gfbe_status gfbe_debug_timing(gfbe_ctx *c, gfbe_batch *b, int32_t w, double *out32) {
+  if (!c || !b || !out32 || w < 0 || w >= b->d.B) return GFBE_BAD_INPUT;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out32, b->d.timing + (size_t)w * 32, sizeof(double) * 32, hipMemcpyDeviceToHost));
+  return GFBE_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -154,33 +154,40 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
   const double *lamv = d.lam + (size_t)buf * d.tot_lm;
 
   __shared__ PoseRT sp[NF + 1];
-  if (threadIdx.x < NF) sp[threadIdx.x] = make_pose(X + A_POSE(threadIdx.x));
-  if (threadIdx.x == NF) sp[NF] = make_pose(X + A_EX);
+  __shared__ PairConst pcs[NF];          // pair (sframe, j) constants, j = sframe+1 .. 10
+  const int lane = threadIdx.x;
+  if (lane < NF) sp[lane] = make_pose(X + A_POSE(lane));
+  if (lane == NF) sp[NF] = make_pose(X + A_EX);
+  __syncthreads();
+  if (lane > sframe && lane < NF) pcs[lane] = make_pair_const(sp[sframe], sp[lane], sp[NF]);
   __syncthreads();
   const double td = X[A_TD];
   const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
 
-  const int slot = ds.lm_off + tile * LM_TILE + threadIdx.x;
+  const int slot = ds.lm_off + tile * LM_TILE + lane;
   const int info = d.lm_info[slot];
   const bool valid = (info >> 24) & 1;
   const int m = valid ? ((info >> 8) & 0xff) : 0;
   const bool is_const = (info >> 16) & 1;
   const size_t TL = d.tot_lm;
-  double cost = 0.0;
-  if (valid) {
-    const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
-    const double vix = d.lm_pts[3 * TL + slot], viy = d.lm_pts[4 * TL + slot], tdi = d.lm_pts[5 * TL + slot];
-    const double lam = lamv[slot];
-    const PoseRT Fi = sp[sframe];
-    double hC[HC], Hll = 0.0, gl = 0.0;
+  // wave-uniform trip count (tracks are sorted longest first inside a start-frame group)
+  int mmax = m;
 #pragma unroll
-    for (int q = 0; q < HC; q++) hC[q] = 0.0;
-    for (int k = 0; k < m; k++) {
+  for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
+  double cost = 0.0;
+  const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
+  const double vix = d.lm_pts[3 * TL + slot], viy = d.lm_pts[4 * TL + slot], tdi = d.lm_pts[5 * TL + slot];
+  const double lam = lamv[slot];
+  double hC[HC], Hll = 0.0, gl = 0.0;
+#pragma unroll
+  for (int q = 0; q < HC; q++) hC[q] = 0.0;
+  for (int k = 0; k < mmax; k++) {
+    if (k < m) {
       const double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
       const double pjx = ob[0], pjy = ob[TL], vjx = ob[2 * TL], vjy = ob[3 * TL], tdj = ob[4 * TL];
       double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
-      visual_eval<MODE != 1>(Fi, sp[sframe + 1 + k], sp[NF], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
-                             sq, r, Ji, Jj, Je, Jl, Jt);
+      visual_eval_pc<MODE != 1>(pcs[sframe + 1 + k], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
+                                sq, r, Ji, Jj, Je, Jl, Jt);
       double s1, rs, asn;
       cost += corrector(r[0] * r[0] + r[1] * r[1], delta, &s1, &rs, &asn);
       if (MODE != 1) {
@@ -190,15 +197,15 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
         correct_cols(Jl, Jl + 1, 1, r[0], r[1], s1, asn);
         correct_cols(Jt, Jt + 1, 1, r[0], r[1], s1, asn);
         r[0] *= rs; r[1] *= rs;
-        // block-CSR record: r(2) | row0: Ji Jj Je Jl Jt | row1: ...
-        double *rec = d.rec + ((size_t)ds.rec_off + d.lm_rec[(size_t)k * TL + slot]) * REC;
-        rec[0] = r[0]; rec[1] = r[1];
+        // block-CSR record r(2) | row0: Ji Jj Je Jl Jt | row1: ...  (336 contiguous bytes per lane)
+        double *rb = d.rec + ((size_t)ds.rec_off + d.lm_rec[(size_t)k * TL + slot]) * REC;
+        rb[0] = r[0]; rb[1] = r[1];
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-          rec[2 + q] = Ji[q]; rec[8 + q] = Jj[q]; rec[14 + q] = Je[q];
-          rec[22 + q] = Ji[6 + q]; rec[28 + q] = Jj[6 + q]; rec[34 + q] = Je[6 + q];
+          rb[2 + q] = Ji[q]; rb[8 + q] = Jj[q]; rb[14 + q] = Je[q];
+          rb[22 + q] = Ji[6 + q]; rb[28 + q] = Jj[6 + q]; rb[34 + q] = Je[6 + q];
         }
-        rec[20] = Jl[0]; rec[21] = Jt[0]; rec[40] = Jl[1]; rec[41] = Jt[1];
+        rb[20] = Jl[0]; rb[21] = Jt[0]; rb[40] = Jl[1]; rb[41] = Jt[1];
         // landmark row of the normal equations (w = Jl)
         const double w0 = (is_const && MODE == 0) ? 0.0 : Jl[0], w1 = (is_const && MODE == 0) ? 0.0 : Jl[1];
         Hll += w0 * w0 + w1 * w1;
@@ -212,27 +219,30 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
         hC[12] += Jt[0] * w0 + Jt[1] * w1;
       }
     }
-    if (MODE != 1) {
-      d.lm_Hll[slot] = Hll;
-      d.lm_gl[slot] = gl;
+  }
+  if (MODE != 1 && valid) {
+    d.lm_Hll[slot] = Hll;
+    d.lm_gl[slot] = gl;
 #pragma unroll
-      for (int q = 0; q < HC; q++) d.lm_hC[(size_t)q * TL + slot] = hC[q];
-    }
+    for (int q = 0; q < HC; q++) d.lm_hC[(size_t)q * TL + slot] = hC[q];
   }
   cost = wave_sum(cost);
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     if (MODE == 1) d.tile_cand[((size_t)w * d.max_tiles + tile) * 4] = cost;
     else d.tile_cost[(size_t)w * d.max_tiles + tile] = cost;
   }
 }
 
 // =============================================================================================
-// k_pair: J^T J and J^T r of the records of one (imu_i, imu_j) pair. Records of a pair are
-// contiguous (pair-major block-CSR) so the chunk load is a flat coalesced copy into LDS; thread e
-// owns output entry e and walks the chunk's rows. 19 compact columns: pose_i 0..5, pose_j 6..11,
-// ex 12..17, td 18.
+// k_pair: J^T J and J^T r of the records of one (imu_i, imu_j) pair on the FP64 matrix cores.
+// Records of a pair are contiguous (pair-major block-CSR): every wave streams 32-record chunks
+// (64 residual rows) through its own LDS slab with flat coalesced loads and accumulates
+//   X^T X,  X = [ J(:, pose_i pose_j ex td) | r ]   (rows x 20)
+// as three 16x16 tiles (cols 0..15 x 0..15, 0..15 x 16..19, 16..19 x 16..19) with
+// v_mfma_f64_16x16x4_f64. 19 compact columns: pose_i 0..5, pose_j 6..11, ex 12..17, td 18; col 19 = r.
 // =============================================================================================
-__device__ __forceinline__ int rec_col(int c) { return c < 18 ? c : 19; }   // skip the lambda column (18)
+#define PAIR_CHUNK 32
+typedef double dbl4_p __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_pair(BatchDev d, int marg) {
   const int w = blockIdx.y;
@@ -248,40 +258,66 @@ __global__ __launch_bounds__(256) void k_pair(BatchDev d, int marg) {
   const int rb = ds.pair_begin[p], re = ds.pair_begin[p + 1];
   double *out = d.pair_part + ((size_t)w * NPAIR + p) * PAIR_STRIDE;
   if (rb == re) return;   // stays zero (zeroed at upload; the structure never changes)
-  __shared__ double tile[64 * REC];
-  const int e = threadIdx.x;
-  int ca = 0, cb = 0;
-  bool is_g = false;
-  if (e < 190) {
-    // upper-triangular enumeration of 19 x 19
-    int a = 0, rr = e;
-    while (rr >= 19 - a) { rr -= 19 - a; a++; }
-    ca = rec_col(a); cb = rec_col(a + rr);
-  } else if (e < PAIR_E) {
-    ca = rec_col(e - 190); is_g = true;
-  }
-  double acc = 0.0;
-  for (int base = rb; base < re; base += 64) {
-    const int n = min(64, re - base);
+  __shared__ double slab[4][PAIR_CHUNK * REC];   // 4 x 10.5 KB; reused for the cross-wave reduction at the end
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
+  // LDS offsets (inside a record) of the X columns this lane feeds to the MFMAs, for row parity 0
+  //   a0: column lr (0..15)            b1: column 16 + lr (16, 17 -> ex 16,17 ; 18 -> td ; 19 -> r), lr < 4
+  const int off_a0 = 2 + lr;
+  const int off_b1 = (lr == 0) ? 2 + 16 : (lr == 1) ? 2 + 17 : (lr == 2) ? 2 + 19 : 0 /* r */;
+  dbl4_p acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+  double *my = slab[wave];
+  const int nchunk = (re - rb + PAIR_CHUNK - 1) / PAIR_CHUNK;
+  constexpr int PER_LANE = PAIR_CHUNK * REC / 64;   // 21 doubles per lane per chunk
+  double pre[PER_LANE];
+  auto fetch = [&](int ch) {
+    const int base = rb + ch * PAIR_CHUNK;
+    const int n = min(PAIR_CHUNK, re - base);
     const double *src = d.rec + ((size_t)ds.rec_off + base) * REC;
-    __syncthreads();
-    for (int q = threadIdx.x; q < n * REC; q += blockDim.x) tile[q] = src[q];
-    __syncthreads();
-    if (e < PAIR_E) {
-      if (!is_g) {
-        for (int f = 0; f < n; f++) {
-          const double *rc = tile + f * REC;
-          acc += rc[2 + ca] * rc[2 + cb] + rc[22 + ca] * rc[22 + cb];
-        }
-      } else {
-        for (int f = 0; f < n; f++) {
-          const double *rc = tile + f * REC;
-          acc += rc[2 + ca] * rc[0] + rc[22 + ca] * rc[1];
-        }
-      }
+#pragma unroll
+    for (int q = 0; q < PER_LANE; q++) { const int e = q * 64 + lane; pre[q] = (e < n * REC) ? src[e] : 0.0; }
+  };
+  if (wave < nchunk) fetch(wave);
+  for (int ch = wave; ch < nchunk; ch += 4) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < PER_LANE; q++) my[q * 64 + lane] = pre[q];
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (ch + 4 < nchunk) fetch(ch + 4);     // next chunk's global loads fly during the MFMAs below
+#pragma unroll 4
+    for (int ks = 0; ks < PAIR_CHUNK * 2 / 4; ks++) {
+      const int row = 4 * ks + lk;          // residual row inside the chunk
+      const int f = row >> 1, par = row & 1;
+      const double *rc = my + f * REC;
+      const double a0 = rc[off_a0 + 20 * par];
+      double b1 = 0.0;
+      if (lr < 3) b1 = rc[off_b1 + 20 * par];
+      else if (lr == 3) b1 = rc[par];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, acc2, 0, 0, 0);
     }
   }
-  if (e < PAIR_E) out[e] = acc;
+  __syncthreads();
+  double (*accs)[PAIR_CHUNK * REC] = slab;   // 768 <= 1344 doubles per wave
+  // reduce the four waves (fixed order) and emit the 209-entry pair block
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int e = (lk + 4 * r) * 16 + lr;
+    accs[wave][e] = acc0[r]; accs[wave][256 + e] = acc1[r]; accs[wave][512 + e] = acc2[r];
+  }
+  __syncthreads();
+  if (t < PAIR_E) {
+    int a, b;
+    if (t < 190) { a = 0; int rr = t; while (rr >= 19 - a) { rr -= 19 - a; a++; } b = a + rr; }
+    else { a = t - 190; b = 19; }
+    int src;
+    if (b < 16) src = a * 16 + b;                       // tile 0
+    else if (a < 16) src = 256 + a * 16 + (b - 16);     // tile 1
+    else src = 512 + (a - 16) * 16 + (b - 16);          // tile 2
+    out[t] = accs[0][src] + accs[1][src] + accs[2][src] + accs[3][src];
+  }
 }
 
 // index of (a,b) in the 209-entry pair block (a,b compact columns 0..18)
@@ -406,75 +442,104 @@ __global__ __launch_bounds__(64) void k_dense(BatchDev d, int mode, int debug_ou
 }
 
 // =============================================================================================
-// k_schur: one workgroup per landmark tile (all landmarks share the start frame s, so their H_pl
-// rows live on the contiguous dims [6s, 73)). Rows are staged in LDS pre-multiplied by sqrt(w_l);
-// thread-owned entries of the packed (reversed lower-triangular) block accumulate over the tile.
+// k_schur: Schur elimination of the 1-D inverse-depth blocks, E = sum_l w_l h_l h_l^T, on the FP64
+// matrix cores. One workgroup per (window, start frame s): all its landmarks have their H_pl rows on
+// the contiguous dims [6s, 73). Landmark tiles (64 rows, pre-multiplied by sqrt(w_l)) are staged in
+// LDS as a 64 x 80 panel whose column 73 carries sqrt(w_l) g_l, so E[:,73] is the reduced gradient
+// share. Each wave owns a few 16x16 output tiles and keeps them in registers across all landmark
+// tiles of the start frame: v_mfma_f64_16x16x4_f64 with A = panel^T, B = panel.
 //   solve:  w_l = s_l^2 / (s_l^2 Hll + mu clamp(s_l^2 Hll))      (Jacobi-scaled, mu-regularised)
 //   marg :  w_l = 1 / Hll                                         (marginalization_factor.cpp:286-292)
 // =============================================================================================
+typedef double dbl4_t __attribute__((ext_vector_type(4)));
+#define HS_LD 82   // LDS row stride of the landmark panel (80 + 2: spreads the 16-row groups over banks)
+
+__device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I - 1) / 2 + (J - I); }   // I <= J < 5
+
 __global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
-  const int w = blockIdx.y, tile = blockIdx.x;
+  const int w = blockIdx.y, s = blockIdx.x;
   const WinDesc &ds = d.desc[w];
-  if (tile >= ds.n_tiles) return;
   WinCtl &c = d.ctl[w];
   if (!marg && (c.done || c.reuse)) return;
-  const int s = d.tile_start[ds.tile_off + tile];
   if (marg && s != 0) return;
-  __shared__ double hs[NV][LM_TILE + 1];
-  __shared__ double gs[LM_TILE];
+  const int tb = ds.sf_tile_begin[s], te = ds.sf_tile_begin[s + 1];
+  if (tb == te) return;   // partial stays zero (zeroed at upload; the structure never changes)
+  __shared__ double hs[LM_TILE * HS_LD];
   const size_t TL = d.tot_lm;
-  const int slot0 = ds.lm_off + tile * LM_TILE;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool first = (c.iter == 0);   // Jacobi scaling is fixed at iteration 0 (TrustRegionMinimizer::IterationZero)
-  for (int q = t; q < NV * LM_TILE; q += blockDim.x) hs[q / LM_TILE][q % LM_TILE] = 0.0;
-  __syncthreads();
-  if (t < LM_TILE) {
-    const int slot = slot0 + t;
-    const int info = d.lm_info[slot];
-    const bool valid = (info >> 24) & 1;
-    const int m = (info >> 8) & 0xff;
-    const bool is_const = (info >> 16) & 1;
-    double sw = 0.0, wl = 0.0;
-    const double Hll = d.lm_Hll[slot];
-    if (valid && m > 0 && (marg || !is_const)) {
-      if (marg) {
-        wl = (Hll > d.opt.marg_eps) ? 1.0 / Hll : 0.0;
-      } else {
-        double sl;
-        if (first) { sl = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hll)) : 1.0; d.lm_sl[slot] = sl; }
-        else sl = d.lm_sl[slot];
-        const double hs2 = sl * sl * Hll;
-        wl = sl * sl / (hs2 + c.mu * clamp_diag(hs2));
+  // output tiles of this start frame: tile rows/cols >= I0, upper pairs, round-robin over the 4 waves
+  const int I0 = (6 * s) / 16;
+  int myI[4], myJ[4], nmy = 0;
+  {
+    int idx = 0;
+    for (int I = I0; I < 5; I++)
+      for (int J = I; J < 5; J++, idx++)
+        if ((idx & 3) == wave && nmy < 4) { myI[nmy] = I; myJ[nmy] = J; nmy++; }
+  }
+  dbl4_t acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) acc[q] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int tile = tb; tile < te; tile++) {
+    const int slot0 = ds.lm_off + tile * LM_TILE;
+    __syncthreads();
+    for (int q = t; q < LM_TILE * HS_LD; q += blockDim.x) hs[q] = 0.0;
+    __syncthreads();
+    {
+      const int l = t & 63, part = t >> 6;
+      const int slot = slot0 + l;
+      const int info = d.lm_info[slot];
+      const bool valid = (info >> 24) & 1;
+      const int m = (info >> 8) & 0xff;
+      const bool is_const = (info >> 16) & 1;
+      const double Hll = d.lm_Hll[slot];
+      double sw = 0.0;
+      if (valid && m > 0 && (marg || !is_const)) {
+        double wl;
+        if (marg) {
+          wl = (Hll > d.opt.marg_eps) ? 1.0 / Hll : 0.0;
+        } else {
+          double sl;
+          if (first) { sl = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hll)) : 1.0; if (part == 0) d.lm_sl[slot] = sl; }
+          else sl = d.lm_sl[slot];
+          const double hs2 = sl * sl * Hll;
+          wl = sl * sl / (hs2 + c.mu * clamp_diag(hs2));
+        }
+        sw = sqrt(wl);
+        double *row = hs + l * HS_LD;
+        if (part == 0) {
+          for (int q = 0; q < 6; q++) {
+            row[6 * s + q] = sw * d.lm_hC[(size_t)q * TL + slot];
+            row[T_EX + q] = sw * d.lm_hC[(size_t)(6 + q) * TL + slot];
+          }
+          row[T_TD] = sw * d.lm_hC[(size_t)12 * TL + slot];
+          row[NV] = sw * d.lm_gl[slot];
+        } else {
+          for (int k = part - 1; k < m; k += 3)
+            for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = sw * d.lm_hP[((size_t)k * 6 + q) * TL + slot];
+        }
+      } else if (!marg && first && valid && part == 0) {
+        d.lm_sl[slot] = 1.0;
       }
-      sw = sqrt(wl);
-      for (int q = 0; q < 6; q++) {
-        hs[6 * s + q][t] = sw * d.lm_hC[(size_t)q * TL + slot];
-        hs[T_EX + q][t] = sw * d.lm_hC[(size_t)(6 + q) * TL + slot];
-      }
-      hs[T_TD][t] = sw * d.lm_hC[(size_t)12 * TL + slot];
-      for (int k = 0; k < m; k++)
-        for (int q = 0; q < 6; q++) hs[6 * (s + 1 + k) + q][t] = sw * d.lm_hP[((size_t)k * 6 + q) * TL + slot];
-    } else if (!marg && first && valid) {
-      d.lm_sl[slot] = 1.0;
     }
-    gs[t] = sw * d.lm_gl[slot];
+    __syncthreads();
+    for (int q = 0; q < 4; q++) {
+      if (q >= nmy) break;
+      const double *pa = hs + 16 * myI[q] + lr, *pb = hs + 16 * myJ[q] + lr;
+#pragma unroll 4
+      for (int kk = 0; kk < LM_TILE / 4; kk++) {
+        const int l = 4 * kk + lk;
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[l * HS_LD], pb[l * HS_LD], acc[q], 0, 0, 0);
+      }
+    }
   }
-  __syncthreads();
-  const int ns = NV - 6 * s;
-  const int ne = ns * (ns + 1) / 2;
-  double *out = d.schur_part + ((size_t)w * d.max_tiles + tile) * SCHUR_STRIDE;
-  for (int e = t; e < ne; e += blockDim.x) {
-    const int ab = d.tri_tab[e];
-    const int a = (NV - 1) - (ab >> 8), b = (NV - 1) - (ab & 0xff);
-    double acc = 0.0;
-#pragma unroll 8
-    for (int l = 0; l < LM_TILE; l++) acc += hs[a][l] * hs[b][l];
-    out[e] = acc;
-  }
-  for (int a = 6 * s + t; a < NV; a += blockDim.x) {
-    double acc = 0.0;
-    for (int l = 0; l < LM_TILE; l++) acc += hs[a][l] * gs[l];
-    out[TRI_NV + a] = acc;
+  double *out = d.schur_part + ((size_t)w * NF + s) * SCHUR_STRIDE;
+  for (int q = 0; q < 4; q++) {
+    if (q >= nmy) break;
+    double *o = out + (size_t)schur_pair(myI[q], myJ[q]) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; r++) o[(lk + 4 * r) * 16 + lr] = acc[q][r];
   }
 }
 
@@ -554,25 +619,18 @@ __device__ double gather_g(const BatchDev &d, const WinDesc &ds, int w, int a) {
   if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
   return s;
 }
-// E(a,b), a <= b < NV: sum over tiles whose start frame s satisfies 6 s <= a
+// E(a,b), a <= b < NVP: sum over the start frames s with 6 s <= a (fixed order)
 __device__ double gather_E(const BatchDev &d, const WinDesc &ds, int w, int a, int b, bool marg) {
   if (a > b) { const int t = a; a = b; b = t; }
-  const int ap = (NV - 1) - a, bp = (NV - 1) - b;
-  const int e = ap * (ap + 1) / 2 + bp;
-  double s = 0.0;
+  const int off = schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);
   const int smax = marg ? 0 : min(a / 6, NF - 1);
-  const int t_end = ds.sf_tile_begin[smax + 1];
-  const double *sp = d.schur_part + (size_t)w * d.max_tiles * SCHUR_STRIDE;
-  for (int t = 0; t < t_end; t++) s += sp[(size_t)t * SCHUR_STRIDE + e];
+  const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE;
+  double s = 0.0;
+  for (int f = 0; f <= smax; f++) s += sp[(size_t)f * SCHUR_STRIDE + off];
   return s;
 }
 __device__ double gather_eg(const BatchDev &d, const WinDesc &ds, int w, int a, bool marg) {
-  double s = 0.0;
-  const int smax = marg ? 0 : min(a / 6, NF - 1);
-  const int t_end = ds.sf_tile_begin[smax + 1];
-  const double *sp = d.schur_part + (size_t)w * d.max_tiles * SCHUR_STRIDE;
-  for (int t = 0; t < t_end; t++) s += sp[(size_t)t * SCHUR_STRIDE + TRI_NV + a];
-  return s;
+  return gather_E(d, ds, w, a, NV, marg);   // column 73 of the padded block carries sum_l w_l h_l g_l
 }
 
 __global__ __launch_bounds__(256) void k_assemble(BatchDev d) {
@@ -708,6 +766,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
   double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
   double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
   const bool first = (c.iter == 0);
+  double *stamp = d.timing + (size_t)w * 32;
+#define STAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  STAMP(0);
 
   if (t == 0) {
     int n = 0;
@@ -747,6 +808,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
   gmax = block_max(gmax, red);
   xn2 = block_sum(xn2, red);
   __syncthreads();
+  STAMP(1);
   const int n = s_nact;                 // active dims
   const int na = n + 1;                 // + the right-hand side as an extra row (forward substitution for free)
   const int nt = (na + TB - 1) / TB;    // tiles per side
@@ -784,6 +846,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
       }
     if (t == 0) flag = 0;
     __syncthreads();
+    STAMP(2);
     // ---- blocked right-looking Cholesky: diagonal tile (1 wave) -> panel solve (thread per row) ->
     //      trailing update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
     for (int P = 0; P < nt; P++) {
@@ -831,6 +894,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
       __syncthreads();
     }
     bool ok = (flag == 0);
+    STAMP(3);
     if (ok) {
       // z = L^-1 rhs sits in row n of L. Backward substitution y = L^-T z, block by block, in LDS.
       for (int i = t; i < n; i += blockDim.x)
@@ -883,6 +947,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
     return;
   }
+  STAMP(4);
   // dense shares of the dogleg scalars: t_v = Ht v, t_y = Ht y  (Ht = s H s; H symmetric -> column reads coalesce)
   double n2 = 0.0, gyv = 0.0, vhv = 0.0, vhy = 0.0, yhy = 0.0;
   for (int a = t; a < ND; a += blockDim.x) {
@@ -901,6 +966,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     c.x_norm = xn2;        // dense share; k_step adds the landmarks and takes the square root
     c.have_step = 2;       // "fresh linearisation" marker consumed by k_step
   }
+  STAMP(5);
+#undef STAMP
 }
 
 // =============================================================================================
@@ -1190,7 +1257,7 @@ void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
   if (d.max_tiles == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(d.max_tiles, d.B), dim3(256), 0, s, d, marg);
+  hipLaunchKernelGGL(k_schur, dim3(marg ? 1 : NF, d.B), dim3(256), 0, s, d, marg);
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(16, d.B), dim3(256), 0, s, d); }
 void launch_solve(const BatchDev &d, hipStream_t s) {

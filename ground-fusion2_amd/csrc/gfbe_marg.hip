@@ -47,6 +47,11 @@ __device__ __forceinline__ int m_wheel_loc(int a) {        // wheel factor (0, 1
   return -1;
 }
 
+__device__ __forceinline__ int m_schur_off(int a, int b) {   // a <= b: offset inside a start-frame partial
+  const int I = a >> 4, J = b >> 4;
+  return (I * 5 - I * (I - 1) / 2 + (J - I)) * 256 + (a & 15) * 16 + (b & 15);
+}
+
 struct MargShared {
   int touched[GFBE_BLK_COUNT];
   int keep_id[GFBE_MAX_PRIOR_BLOCKS];
@@ -194,8 +199,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const int n = sh.n, m = sh.m;
   // ---- full A (ND x ND, landmark block already eliminated) and b over all tangent dims
   const double *pp = d.pair_part + (size_t)w * NPAIR * PAIR_STRIDE;
-  const double *sp = d.schur_part + (size_t)w * d.max_tiles * SCHUR_STRIDE;
-  const int t_end = ds.sf_tile_begin[1];
+  const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE;   // start frame 0 partial (15 dense 16x16 tiles)
   const double *ipart = sh.use_imu ? d.imu_part + ((size_t)w * MAX_IMU + sh.use_imu - 1) * IMU_PART : nullptr;
   const double *wpart = sh.use_wheel ? d.wheel_part + ((size_t)w * MAX_WHEEL + sh.use_wheel - 1) * WHEEL_PART : nullptr;
   for (int e = t; e < ND * ND; e += blockDim.x) {
@@ -207,9 +211,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
         const int la = m_vis_loc(a, j), lb = m_vis_loc(b, j);
         if (la >= 0 && lb >= 0) s += pp[(size_t)j * PAIR_STRIDE + m_pair_tri(la, lb)];
       }
-      const int ap = (NV - 1) - b, bp = (NV - 1) - a;     // b <= a  ->  reversed coords ap >= bp
-      const int pe = ap * (ap + 1) / 2 + bp;
-      for (int q = 0; q < t_end; q++) s -= sp[(size_t)q * SCHUR_STRIDE + pe];
+      s -= sp[m_schur_off(b, a)];                         // b <= a
     }
     if (ipart) { const int la = m_imu_loc(a), lb = m_imu_loc(b); if (la >= 0 && lb >= 0) s += ipart[la * 30 + lb]; }
     if (wpart) { const int la = m_wheel_loc(a), lb = m_wheel_loc(b); if (la >= 0 && lb >= 0) s += wpart[la * 22 + lb]; }
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     double s = 0.0;
     if (old && a < NV) {
       for (int j = 1; j < NF; j++) { const int la = m_vis_loc(a, j); if (la >= 0) s += pp[(size_t)j * PAIR_STRIDE + 190 + la]; }
-      for (int q = 0; q < t_end; q++) s -= sp[(size_t)q * SCHUR_STRIDE + TRI_NV + a];
+      s -= sp[m_schur_off(a, NV)];                        // column 73 = sum_l w_l h_l g_l
     }
     if (ipart) { const int la = m_imu_loc(a); if (la >= 0) s += ipart[900 + la]; }
     if (wpart) { const int la = m_wheel_loc(a); if (la >= 0) s += wpart[484 + la]; }

@@ -317,6 +317,9 @@ gfbe_status gfbe_profile_get(const gfbe_ctx *ctx, int32_t i, const char **name, 
                              double *total_ms, double *algorithmic_bytes);
 void gfbe_profile_reset(gfbe_ctx *ctx);
 
+/* Diagnostics: phase time stamps (10 ns ticks) of the dense solve kernel for window w of a batch. */
+gfbe_status gfbe_debug_timing(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, double *out32);
+
 /* Multi-GPU landmark sharding: when set, the library calls
  * fn(user, device_ptr, n_doubles, hip_stream) once per linearisation on the packed partial reduced
  * system [S | g | cost ...]; the callee performs an in-place sum all-reduce (RCCL) on that stream. */

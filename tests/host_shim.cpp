@@ -16,9 +16,21 @@ extern "C" int shim_eval_factors(const gfbe_options *opt, const gfbe_window *w, 
   for (int k = 0; k < v.n_factor; k++) {
     const PoseRT Fi = make_pose(st.para_Pose[v.imu_i[k]]), Fj = make_pose(st.para_Pose[v.imu_j[k]]);
     double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
-    visual_eval<true>(Fi, Fj, Ex, w->para_Feature[v.feature_index[k]], st.para_Td, v.pts_i[3 * k], v.pts_i[3 * k + 1],
-                      v.pts_i[3 * k + 2], v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_i[2 * k], v.vel_i[2 * k + 1],
-                      v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_i[k], v.td_j[k], opt->vis_sqrt_info, r, Ji, Jj, Je, Jl, Jt);
+    const PairConst pc = make_pair_const(Fi, Fj, Ex);      // the form the kernels use
+    visual_eval_pc<true>(pc, w->para_Feature[v.feature_index[k]], st.para_Td, v.pts_i[3 * k], v.pts_i[3 * k + 1],
+                         v.pts_i[3 * k + 2], v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_i[2 * k], v.vel_i[2 * k + 1],
+                         v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_i[k], v.td_j[k], opt->vis_sqrt_info, r, Ji, Jj, Je, Jl, Jt);
+    {   // and the direct restatement of the reference's formulas must agree with it
+      double r2[2], Ji2[12], Jj2[12], Je2[12], Jl2[2], Jt2[2];
+      visual_eval<true>(Fi, Fj, Ex, w->para_Feature[v.feature_index[k]], st.para_Td, v.pts_i[3 * k], v.pts_i[3 * k + 1],
+                        v.pts_i[3 * k + 2], v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_i[2 * k], v.vel_i[2 * k + 1],
+                        v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_i[k], v.td_j[k], opt->vis_sqrt_info, r2, Ji2, Jj2, Je2, Jl2, Jt2);
+      double scale = 1.0, err = 0.0;
+      for (int q = 0; q < 12; q++) { scale = fmax(scale, fabs(Ji2[q])); scale = fmax(scale, fabs(Je2[q])); }
+      for (int q = 0; q < 12; q++) { err = fmax(err, fabs(Ji[q] - Ji2[q])); err = fmax(err, fabs(Jj[q] - Jj2[q])); err = fmax(err, fabs(Je[q] - Je2[q])); }
+      for (int q = 0; q < 2; q++) { err = fmax(err, fabs(Jl[q] - Jl2[q]) / fmax(1.0, fabs(Jl2[q]))); err = fmax(err, fabs(Jt[q] - Jt2[q])); err = fmax(err, fabs(r[q] - r2[q])); }
+      if (err > 1e-11 * scale) return 2;
+    }
     if (robust) {
       double s1, rs, asn;
       corrector(r[0] * r[0] + r[1] * r[1], opt->huber_delta, &s1, &rs, &asn);
