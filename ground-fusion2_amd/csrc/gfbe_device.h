@@ -20,6 +20,8 @@ enum {
   NPAIR = NF * NF,            // (imu_i, imu_j) pair slots, index i * 11 + j
   PAIR_E = 19 * 20 / 2 + 19,  // 190 J^T J entries + 19 J^T r entries of a pose-pair block = 209
   PAIR_STRIDE = 216,
+  VP_STRIDE = 336,            // fused visual partial of one (tile, observation step): T0 16x16 | T1 16x4 | T2 4x4
+  XS_LD = 21,                 // LDS row stride of the [J | r] panel (20 + 1)
   TRI_NV = NV * (NV + 1) / 2, // 2701
   NVP = 80,                   // NV padded to 5 tiles of 16; column 73 carries the landmark gradient
   SCHUR_TILES = 15,           // upper-triangular 16x16 tile pairs of the 80 x 80 block
@@ -147,7 +149,8 @@ struct BatchDev {
   double *imu_sqrt, *wheel_sqrt;     // [n][225], [n][36]
   double *prior_J0, *prior_r0, *prior_x0, *prior_H;   // [B][ND*ND], [B][ND], [B][PRIOR_X0], [B][ND*ND]
   // partial results
-  double *pair_part;          // [B][NPAIR][PAIR_STRIDE]
+  double *pair_part;          // [B][NPAIR][VP_STRIDE]   X^T X per pose pair (sum of vis_part over the tiles of the start frame)
+  double *vis_part;           // [B][max_tiles][MAXOBS][VP_STRIDE]  X^T X of the 64 factors of one tile at one step, X = [J | r]
   double *schur_part;         // [B][NF][SCHUR_STRIDE]  sum over the landmarks of one start frame
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
@@ -179,7 +182,7 @@ void launch_prep(const BatchDev &d, hipStream_t s);
 void launch_reset(const BatchDev &d, hipStream_t s);
 // mode 0: linearise at the current parameters (writes records, landmark sums, cost partials)
 // mode 1: candidate cost only   mode 2: linearise the marginalisation set at xout (start frame 0 only)
-void launch_vis(const BatchDev &d, int mode, hipStream_t s);
+void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records = 0);
 void launch_pair(const BatchDev &d, int marg, hipStream_t s);
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s);

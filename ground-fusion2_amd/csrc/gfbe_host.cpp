@@ -8,6 +8,7 @@
 #include "gfbe_device.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -423,7 +424,7 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
   AL(rec, (size_t)tot_rec * REC);
   AL(imu_sqrt, imu.size() * 225); AL(wheel_sqrt, wheel.size() * 36); AL(prior_H, (size_t)B * ND * ND);
-  AL(pair_part, (size_t)B * NPAIR * PAIR_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
+  AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
   AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
   AL(prior_g, (size_t)B * (ND + 2));
   AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
@@ -456,7 +457,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, bool first) {
   // the first linearisation has every window active; later ones skip windows that only shrink the radius
   { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, c->stream); }
   { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, c->stream); }
-  { Timed t(c, "k_pair", 0); launch_pair(d, 0, c->stream); }
+  { Timed t(c, "k_pairsum", 0); launch_pair(d, 0, c->stream); }
   { Timed t(c, "k_schur", 0); launch_schur(d, 0, c->stream); }
   { Timed t(c, "k_assemble", 0); launch_assemble(d, c->stream); }
   { Timed t(c, "k_solve", 0); launch_solve(d, c->stream); }
@@ -576,7 +577,7 @@ extern "C" gfbe_status gfbe_eval_factors(gfbe_ctx *c, const gfbe_window *win, in
   if (st != GFBE_OK) { gfbe_batch_free(c, b); return st; }
   BatchDev &d = b->d;
   launch_reset(d, c->stream);
-  launch_vis(d, 0, c->stream);
+  launch_vis(d, 0, c->stream, /*write_records=*/1);
   launch_dense_factors(d, 0, 1, c->stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 // (landmarks with start_frame 0, estimator.cpp:3498-3531) at the re-anchored state.
 // =============================================================================================
 template <int MODE>
-__global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
+__global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_records) {
   const int w = blockIdx.y, tile = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles) return;
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
 
   __shared__ PoseRT sp[NF + 1];
   __shared__ PairConst pcs[NF];          // pair (sframe, j) constants, j = sframe+1 .. 10
+  __shared__ double xs[(MODE == 1) ? 1 : 2 * LM_TILE * XS_LD];   // [J | r] rows of the wave's 64 factors at one step
   const int lane = threadIdx.x;
   if (lane < NF) sp[lane] = make_pose(X + A_POSE(lane));
   if (lane == NF) sp[NF] = make_pose(X + A_EX);
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
   for (int k = 0; k < mmax; k++) {
     if (k < m) {
       const double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
-      const double pjx = ob[0], pjy = ob[TL], vjx = ob[2 * TL], vjy = ob[3 * TL], tdj = ob[4 * TL];
+      double pjx, pjy, vjx, vjy, tdj;
+      pjx = ob[0]; pjy = ob[TL]; vjx = ob[2 * TL]; vjy = ob[3 * TL]; tdj = ob[4 * TL];
       double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
       visual_eval_pc<MODE != 1>(pcs[sframe + 1 + k], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
                                 sq, r, Ji, Jj, Je, Jl, Jt);
@@ -197,15 +199,26 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
         correct_cols(Jl, Jl + 1, 1, r[0], r[1], s1, asn);
         correct_cols(Jt, Jt + 1, 1, r[0], r[1], s1, asn);
         r[0] *= rs; r[1] *= rs;
-        // block-CSR record r(2) | row0: Ji Jj Je Jl Jt | row1: ...  (336 contiguous bytes per lane)
-        double *rb = d.rec + ((size_t)ds.rec_off + d.lm_rec[(size_t)k * TL + slot]) * REC;
-        rb[0] = r[0]; rb[1] = r[1];
+        if (write_records) {   // inspection path (gfbe_eval_factors): block-CSR record r(2) | row0: Ji Jj Je Jl Jt | row1
+          double *rb = d.rec + ((size_t)ds.rec_off + d.lm_rec[(size_t)k * TL + slot]) * REC;
+          rb[0] = r[0]; rb[1] = r[1];
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-          rb[2 + q] = Ji[q]; rb[8 + q] = Jj[q]; rb[14 + q] = Je[q];
-          rb[22 + q] = Ji[6 + q]; rb[28 + q] = Jj[6 + q]; rb[34 + q] = Je[6 + q];
+          for (int q = 0; q < 6; q++) {
+            rb[2 + q] = Ji[q]; rb[8 + q] = Jj[q]; rb[14 + q] = Je[q];
+            rb[22 + q] = Ji[6 + q]; rb[28 + q] = Jj[6 + q]; rb[34 + q] = Je[6 + q];
+          }
+          rb[20] = Jl[0]; rb[21] = Jt[0]; rb[40] = Jl[1]; rb[41] = Jt[1];
         }
-        rb[20] = Jl[0]; rb[21] = Jt[0]; rb[40] = Jl[1]; rb[41] = Jt[1];
+        // X = [J(pose_i pose_j ex td) | r]: this lane's two rows of the step's 128 x 20 panel
+        {
+          double *x0 = xs + (2 * lane) * XS_LD, *x1 = x0 + XS_LD;
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+            x0[q] = Ji[q]; x0[6 + q] = Jj[q]; x0[12 + q] = Je[q];
+            x1[q] = Ji[6 + q]; x1[6 + q] = Jj[6 + q]; x1[12 + q] = Je[6 + q];
+          }
+          x0[18] = Jt[0]; x0[19] = r[0]; x1[18] = Jt[1]; x1[19] = r[1];
+        }
         // landmark row of the normal equations (w = Jl)
         const double w0 = (is_const && MODE == 0) ? 0.0 : Jl[0], w1 = (is_const && MODE == 0) ? 0.0 : Jl[1];
         Hll += w0 * w0 + w1 * w1;
@@ -218,6 +231,36 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
         }
         hC[12] += Jt[0] * w0 + Jt[1] * w1;
       }
+    } else if (MODE != 1) {
+      double *x0 = xs + (2 * lane) * XS_LD;
+#pragma unroll
+      for (int q = 0; q < 2 * XS_LD; q++) x0[q] = 0.0;
+    }
+    if (MODE != 1) {
+      // X^T X of the step's 128 x 20 panel on the FP64 matrix cores (the J^T J / J^T r of this tile's
+      // factors of pose pair (sframe, sframe+1+k)); J never leaves the CU.
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      typedef double dbl4_v __attribute__((ext_vector_type(4)));
+      dbl4_v acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+      const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+      for (int ks = 0; ks < 2 * LM_TILE / 4; ks++) {
+        const double *rowp = xs + (4 * ks + lk) * XS_LD;
+        const double a0 = rowp[lr];
+        const double b1 = (lr < 4) ? rowp[16 + lr] : 0.0;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, acc2, 0, 0, 0);
+      }
+      double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VP_STRIDE;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        vo[(lk + 4 * q) * 16 + lr] = acc0[q];
+        if (lr < 4) vo[256 + (lk + 4 * q) * 4 + lr] = acc1[q];
+      }
+      if (lr < 4) vo[320 + lk * 4 + lr] = acc2[0];
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (MODE != 1 && valid) {
@@ -234,90 +277,25 @@ __global__ __launch_bounds__(LM_TILE) void k_vis(BatchDev d) {
 }
 
 // =============================================================================================
-// k_pair: J^T J and J^T r of the records of one (imu_i, imu_j) pair on the FP64 matrix cores.
-// Records of a pair are contiguous (pair-major block-CSR): every wave streams 32-record chunks
-// (64 residual rows) through its own LDS slab with flat coalesced loads and accumulates
-//   X^T X,  X = [ J(:, pose_i pose_j ex td) | r ]   (rows x 20)
-// as three 16x16 tiles (cols 0..15 x 0..15, 0..15 x 16..19, 16..19 x 16..19) with
-// v_mfma_f64_16x16x4_f64. 19 compact columns: pose_i 0..5, pose_j 6..11, ex 12..17, td 18; col 19 = r.
+// k_pairsum: sums the fused visual partials over the landmark tiles of a start frame (fixed order):
+//   pair_part[w][(i,j)][:] = sum_{tiles t of start frame i} vis_part[w][t][j-i-1][:]
+// so that the assembly gathers one block per pose pair.
 // =============================================================================================
-#define PAIR_CHUNK 32
-typedef double dbl4_p __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256) void k_pair(BatchDev d, int marg) {
+__global__ __launch_bounds__(VP_STRIDE) void k_pairsum(BatchDev d, int marg) {
   const int w = blockIdx.y;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   if (!marg && (c.done || c.reuse)) return;
-  // decode pair index: blockIdx.x in [0,55) -> (i,j), i<j
   int i = 0, rem = blockIdx.x;
   while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
   const int j = i + 1 + rem;
   if (marg && i != 0) return;
   const int p = i * NF + j;
-  const int rb = ds.pair_begin[p], re = ds.pair_begin[p + 1];
-  double *out = d.pair_part + ((size_t)w * NPAIR + p) * PAIR_STRIDE;
-  if (rb == re) return;   // stays zero (zeroed at upload; the structure never changes)
-  __shared__ double slab[4][PAIR_CHUNK * REC];   // 4 x 10.5 KB; reused for the cross-wave reduction at the end
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  // LDS offsets (inside a record) of the X columns this lane feeds to the MFMAs, for row parity 0
-  //   a0: column lr (0..15)            b1: column 16 + lr (16, 17 -> ex 16,17 ; 18 -> td ; 19 -> r), lr < 4
-  const int off_a0 = 2 + lr;
-  const int off_b1 = (lr == 0) ? 2 + 16 : (lr == 1) ? 2 + 17 : (lr == 2) ? 2 + 19 : 0 /* r */;
-  dbl4_p acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-  double *my = slab[wave];
-  const int nchunk = (re - rb + PAIR_CHUNK - 1) / PAIR_CHUNK;
-  constexpr int PER_LANE = PAIR_CHUNK * REC / 64;   // 21 doubles per lane per chunk
-  double pre[PER_LANE];
-  auto fetch = [&](int ch) {
-    const int base = rb + ch * PAIR_CHUNK;
-    const int n = min(PAIR_CHUNK, re - base);
-    const double *src = d.rec + ((size_t)ds.rec_off + base) * REC;
-#pragma unroll
-    for (int q = 0; q < PER_LANE; q++) { const int e = q * 64 + lane; pre[q] = (e < n * REC) ? src[e] : 0.0; }
-  };
-  if (wave < nchunk) fetch(wave);
-  for (int ch = wave; ch < nchunk; ch += 4) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < PER_LANE; q++) my[q * 64 + lane] = pre[q];
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
-    if (ch + 4 < nchunk) fetch(ch + 4);     // next chunk's global loads fly during the MFMAs below
-#pragma unroll 4
-    for (int ks = 0; ks < PAIR_CHUNK * 2 / 4; ks++) {
-      const int row = 4 * ks + lk;          // residual row inside the chunk
-      const int f = row >> 1, par = row & 1;
-      const double *rc = my + f * REC;
-      const double a0 = rc[off_a0 + 20 * par];
-      double b1 = 0.0;
-      if (lr < 3) b1 = rc[off_b1 + 20 * par];
-      else if (lr == 3) b1 = rc[par];
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc1, 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, acc2, 0, 0, 0);
-    }
-  }
-  __syncthreads();
-  double (*accs)[PAIR_CHUNK * REC] = slab;   // 768 <= 1344 doubles per wave
-  // reduce the four waves (fixed order) and emit the 209-entry pair block
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int e = (lk + 4 * r) * 16 + lr;
-    accs[wave][e] = acc0[r]; accs[wave][256 + e] = acc1[r]; accs[wave][512 + e] = acc2[r];
-  }
-  __syncthreads();
-  if (t < PAIR_E) {
-    int a, b;
-    if (t < 190) { a = 0; int rr = t; while (rr >= 19 - a) { rr -= 19 - a; a++; } b = a + rr; }
-    else { a = t - 190; b = 19; }
-    int src;
-    if (b < 16) src = a * 16 + b;                       // tile 0
-    else if (a < 16) src = 256 + a * 16 + (b - 16);     // tile 1
-    else src = 512 + (a - 16) * 16 + (b - 16);          // tile 2
-    out[t] = accs[0][src] + accs[1][src] + accs[2][src] + accs[3][src];
-  }
+  if (ds.pair_begin[p + 1] == ds.pair_begin[p]) return;   // no factor on this pose pair: block stays zero
+  const double *vp = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VP_STRIDE + (size_t)(j - i - 1) * VP_STRIDE + threadIdx.x;
+  double s = 0.0;
+  for (int t = ds.sf_tile_begin[i]; t < ds.sf_tile_begin[i + 1]; t++) s += vp[(size_t)t * MAXOBS * VP_STRIDE];
+  d.pair_part[((size_t)w * NPAIR + p) * VP_STRIDE + threadIdx.x] = s;
 }
 
 // index of (a,b) in the 209-entry pair block (a,b compact columns 0..18)
@@ -564,15 +542,26 @@ __device__ __forceinline__ int wheel_loc(int a, int i) {
   return -1;
 }
 
+__device__ __forceinline__ int vp_off(int a, int b) {   // entry (a <= b) of the 20-column X^T X inside a fused visual partial
+  if (a > b) { const int t = a; a = b; b = t; }
+  if (b < 16) return a * 16 + b;
+  if (a < 16) return 256 + a * 4 + (b - 16);
+  return 320 + (a - 16) * 4 + (b - 16);
+}
+// (la, lb) entry of the X^T X block of pose pair (i, j) (k_pairsum output)
+__device__ __forceinline__ double vis_pair_entry(const BatchDev &d, const WinDesc &ds, int w, int i, int j, int la, int lb) {
+  return d.pair_part[((size_t)w * NPAIR + i * NF + j) * VP_STRIDE + vp_off(la, lb)];
+}
+
 template <bool MARG>
 __device__ double gather_H(const BatchDev &d, const WinDesc &ds, int w, int a, int b) {
   double s = 0.0;
   if (a < NV && b < NV) {
-    const double *pp = d.pair_part + (size_t)w * NPAIR * PAIR_STRIDE;
     for (int i = 0; i < (MARG ? 1 : NF - 1); i++)
       for (int j = i + 1; j < NF; j++) {
+        if (ds.pair_begin[i * NF + j + 1] == ds.pair_begin[i * NF + j]) continue;   // no factor on this pose pair
         const int la = vis_loc(a, i, j), lb = vis_loc(b, i, j);
-        if (la >= 0 && lb >= 0) s += pp[(size_t)(i * NF + j) * PAIR_STRIDE + pair_tri(la, lb)];
+        if (la >= 0 && lb >= 0) s += vis_pair_entry(d, ds, w, i, j, la, lb);
       }
   }
   for (int q = 0; q < ds.n_imu; q++) {
@@ -597,11 +586,11 @@ template <bool MARG>
 __device__ double gather_g(const BatchDev &d, const WinDesc &ds, int w, int a) {
   double s = 0.0;
   if (a < NV) {
-    const double *pp = d.pair_part + (size_t)w * NPAIR * PAIR_STRIDE;
     for (int i = 0; i < (MARG ? 1 : NF - 1); i++)
       for (int j = i + 1; j < NF; j++) {
+        if (ds.pair_begin[i * NF + j + 1] == ds.pair_begin[i * NF + j]) continue;
         const int la = vis_loc(a, i, j);
-        if (la >= 0) s += pp[(size_t)(i * NF + j) * PAIR_STRIDE + 190 + la];
+        if (la >= 0) s += vis_pair_entry(d, ds, w, i, j, la, 19);   // column 19 of X is the residual
       }
   }
   for (int q = 0; q < ds.n_imu; q++) {
@@ -1242,15 +1231,15 @@ void launch_reset(const BatchDev &d, hipStream_t s) {
   const int slots = d.max_tiles * LM_TILE;
   hipLaunchKernelGGL(k_reset, dim3((slots + 255) / 256 > 0 ? (slots + 255) / 256 : 1, d.B), dim3(256), 0, s, d);
 }
-void launch_vis(const BatchDev &d, int mode, hipStream_t s) {
+void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   if (d.max_tiles == 0) return;
   const dim3 g(d.max_tiles, d.B), b(LM_TILE);
-  if (mode == 0) hipLaunchKernelGGL(k_vis<0>, g, b, 0, s, d);
-  else if (mode == 1) hipLaunchKernelGGL(k_vis<1>, g, b, 0, s, d);
-  else hipLaunchKernelGGL(k_vis<2>, g, b, 0, s, d);
+  if (mode == 0) hipLaunchKernelGGL(k_vis<0>, g, b, 0, s, d, write_records);
+  else if (mode == 1) hipLaunchKernelGGL(k_vis<1>, g, b, 0, s, d, 0);
+  else hipLaunchKernelGGL(k_vis<2>, g, b, 0, s, d, write_records);
 }
 void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
-  hipLaunchKernelGGL(k_pair, dim3(NF * (NF - 1) / 2, d.B), dim3(256), 0, s, d, marg);
+  hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);
 }
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s) {
   hipLaunchKernelGGL(k_dense, dim3(MAX_IMU + MAX_WHEEL + 1, d.B), dim3(64), 0, s, d, mode, debug_out);

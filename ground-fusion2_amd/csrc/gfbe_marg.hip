@@ -52,6 +52,13 @@ __device__ __forceinline__ int m_schur_off(int a, int b) {   // a <= b: offset i
   return (I * 5 - I * (I - 1) / 2 + (J - I)) * 256 + (a & 15) * 16 + (b & 15);
 }
 
+__device__ __forceinline__ int m_vp_off(int a, int b) {   // entry (a <= b) of the 20-column X^T X inside a fused visual partial
+  if (a > b) { const int t = a; a = b; b = t; }
+  if (b < 16) return a * 16 + b;
+  if (a < 16) return 256 + a * 4 + (b - 16);
+  return 320 + (a - 16) * 4 + (b - 16);
+}
+
 struct MargShared {
   int touched[GFBE_BLK_COUNT];
   int keep_id[GFBE_MAX_PRIOR_BLOCKS];
@@ -129,6 +136,51 @@ __device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int
   __syncthreads();
 }
 
+// Same one-sided Jacobi for n <= 16, run by ONE wave (8 column pairs x 8 lanes, wave-level
+// synchronisation only): used for the dense pseudo-inverse of the dropped pose / speed-bias block.
+__device__ void jacobi_eig_wave16(double *G, double *V, int n, double *lam, int lane) {
+  const int grp = lane >> 3, gl = lane & 7;
+  for (int e = lane; e < 16 * 16; e += 64) V[e] = ((e >> 4) == (e & 15)) ? 1.0 : 0.0;
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  double scale = 0.0;
+  for (int j = 0; j < n; j++) { double a = 0.0; for (int i = 0; i < n; i++) a += G[j * 16 + i] * G[j * 16 + i]; scale = fmax(scale, a); }
+  const double tiny2 = fmax(scale * 1e-30, 1e-24);
+  const int np = (n + 1) & ~1;
+  for (int sweep = 0; sweep < 40; sweep++) {
+    int rotated = 0;
+    for (int r = 0; r < np - 1; r++) {
+      const int k = grp;
+      int p, q;
+      if (k == 0) { p = np - 1; q = r; }
+      else { p = (r + k) % (np - 1); q = (r - k + (np - 1)) % (np - 1); }
+      const bool live = (k < np / 2) && p < n && q < n;
+      if (p > q) { const int tt = p; p = q; q = tt; }
+      double a = 0.0, b = 0.0, c = 0.0;
+      if (live) for (int i = gl; i < n; i += 8) { const double x = G[p * 16 + i], y = G[q * 16 + i]; a += x * x; b += y * y; c += x * y; }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o, 8); b += __shfl_xor(b, o, 8); c += __shfl_xor(c, o, 8); }
+      const bool rot = live && !(fabs(c) <= 1e-14 * sqrt(a * b) || c == 0.0 || (a <= tiny2 && b <= tiny2));
+      if (rot) {
+        const double zeta = (b - a) / (2.0 * c);
+        const double tn = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + tn * tn), sn = cs * tn;
+        for (int i = gl; i < n; i += 8) {
+          const double x = G[p * 16 + i], y = G[q * 16 + i];
+          G[p * 16 + i] = cs * x - sn * y; G[q * 16 + i] = sn * x + cs * y;
+          const double u = V[p * 16 + i], v = V[q * 16 + i];
+          V[p * 16 + i] = cs * u - sn * v; V[q * 16 + i] = sn * u + cs * v;
+        }
+      }
+      rotated |= __any(rot) ? 1 : 0;
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!rotated) break;
+  }
+  if (lane < n) { double sum = 0.0; for (int i = 0; i < n; i++) sum += V[lane * 16 + i] * G[lane * 16 + i]; lam[lane] = sum; }
+}
+
 #define MARG_THREADS 1024
 #define MARG_LDS_N 94   // A' up to this size is eigen-decomposed entirely inside LDS (2 n^2 doubles)
 
@@ -198,7 +250,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
   const int n = sh.n, m = sh.m;
   // ---- full A (ND x ND, landmark block already eliminated) and b over all tangent dims
-  const double *pp = d.pair_part + (size_t)w * NPAIR * PAIR_STRIDE;
+  const double *pp = d.pair_part + (size_t)w * NPAIR * VP_STRIDE;   // pairs (0, j): index j
   const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE;   // start frame 0 partial (15 dense 16x16 tiles)
   const double *ipart = sh.use_imu ? d.imu_part + ((size_t)w * MAX_IMU + sh.use_imu - 1) * IMU_PART : nullptr;
   const double *wpart = sh.use_wheel ? d.wheel_part + ((size_t)w * MAX_WHEEL + sh.use_wheel - 1) * WHEEL_PART : nullptr;
@@ -209,7 +261,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     if (old && a < NV) {
       for (int j = 1; j < NF; j++) {
         const int la = m_vis_loc(a, j), lb = m_vis_loc(b, j);
-        if (la >= 0 && lb >= 0) s += pp[(size_t)j * PAIR_STRIDE + m_pair_tri(la, lb)];
+        if (la >= 0 && lb >= 0) s += pp[(size_t)j * VP_STRIDE + m_vp_off(la, lb)];
       }
       s -= sp[m_schur_off(b, a)];                         // b <= a
     }
@@ -221,7 +273,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   for (int a = t; a < ND; a += blockDim.x) {
     double s = 0.0;
     if (old && a < NV) {
-      for (int j = 1; j < NF; j++) { const int la = m_vis_loc(a, j); if (la >= 0) s += pp[(size_t)j * PAIR_STRIDE + 190 + la]; }
+      for (int j = 1; j < NF; j++) {
+        const int la = m_vis_loc(a, j);
+        if (la >= 0) s += pp[(size_t)j * VP_STRIDE + m_vp_off(la, 19)];
+      }
       s -= sp[m_schur_off(a, NV)];                        // column 73 = sum_l w_l h_l g_l
     }
     if (ipart) { const int la = m_imu_loc(a); if (la >= 0) s += ipart[900 + la]; }
@@ -237,7 +292,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
   if (t < m) bm[t] = bv[sh.drop_dim[t]];
   __syncthreads();
-  jacobi_eig(Pm, Pv, m, 16, Pl, &cflag, nullptr);
+  if (t < 64) jacobi_eig_wave16(Pm, Pv, m, Pl, t);
+  __syncthreads();
   for (int e = t; e < m * m; e += blockDim.x) {
     const int i = e / m, j = e % m;
     double s = 0.0;
