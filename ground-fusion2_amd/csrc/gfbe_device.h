@@ -88,6 +88,7 @@ struct WinDesc {
   int n_imu, n_wheel;
   int imu_off, wheel_off;    // into the batch-wide preintegration arrays
   int imu_frame[MAX_IMU], wheel_frame[MAX_WHEEL];
+  int imu_of_frame[NF], wheel_of_frame[NF];   // factor whose first frame is f, or -1
   int prior_n, prior_nblk;   // 0 => no prior
   int prior_blk_id[GFBE_MAX_PRIOR_BLOCKS], prior_blk_size[GFBE_MAX_PRIOR_BLOCKS], prior_blk_idx[GFBE_MAX_PRIOR_BLOCKS];
   int prior_x0_off[GFBE_MAX_PRIOR_BLOCKS];

@@ -361,10 +361,17 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
     // dense state
     std::memcpy(&x0[(size_t)w * NA], &win.state, sizeof(double) * NA);
     // inertial factors
+    for (int q = 0; q < NF; q++) ds.imu_of_frame[q] = ds.wheel_of_frame[q] = -1;
     ds.n_imu = win.n_imu; ds.imu_off = (int)imu.size();
-    for (int k = 0; k < win.n_imu; k++) { imu.push_back(win.imu[k]); ds.imu_frame[k] = win.imu_frame[k]; }
+    for (int k = 0; k < win.n_imu; k++) {
+      if (win.imu_frame[k] < 0 || win.imu_frame[k] >= win.frame_count) { c->err = "bad imu_frame"; return GFBE_BAD_INPUT; }
+      imu.push_back(win.imu[k]); ds.imu_frame[k] = win.imu_frame[k]; ds.imu_of_frame[win.imu_frame[k]] = k;
+    }
     ds.n_wheel = win.n_wheel; ds.wheel_off = (int)wheel.size();
-    for (int k = 0; k < win.n_wheel; k++) { wheel.push_back(win.wheel[k]); ds.wheel_frame[k] = win.wheel_frame[k]; }
+    for (int k = 0; k < win.n_wheel; k++) {
+      if (win.wheel_frame[k] < 0 || win.wheel_frame[k] >= win.frame_count) { c->err = "bad wheel_frame"; return GFBE_BAD_INPUT; }
+      wheel.push_back(win.wheel[k]); ds.wheel_frame[k] = win.wheel_frame[k]; ds.wheel_of_frame[win.wheel_frame[k]] = k;
+    }
     // prior
     bool used[GFBE_BLK_COUNT];
     for (int q = 0; q < GFBE_BLK_COUNT; q++) used[q] = false;

@@ -241,25 +241,43 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
       // factors of pose pair (sframe, sframe+1+k)); J never leaves the CU.
       __threadfence_block();
       __builtin_amdgcn_wave_barrier();
+      // T0 = X(:,0:16)^T X(:,0:16) with v_mfma_f64_16x16x4_f64 (64 clk / 4 rows); the thin blocks use
+      // v_mfma_f64_4x4x4_4b_f64 (18 clk, lane layout measured in profiles/ubench/mfma_f64_4x4x4_layout.hip:
+      // A_blk[i][k] at lane 16k+4blk+i, B_blk[k][j] at 16k+4blk+j, D_blk[i][j] at 16i+4blk+j):
+      //   T1 = X(:,0:16)^T X(:,16:20): block blk = rows 4blk..4blk+3 of T1, same A operand as T0
+      //   T2 = X(:,16:20)^T X(:,16:20): the four blocks take four different row quads, summed at the end
       typedef double dbl4_v __attribute__((ext_vector_type(4)));
-      dbl4_v acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-      const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll 4
-      for (int ks = 0; ks < 2 * LM_TILE / 4; ks++) {
-        const double *rowp = xs + (4 * ks + lk) * XS_LD;
-        const double a0 = rowp[lr];
-        const double b1 = (lr < 4) ? rowp[16 + lr] : 0.0;
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, b1, acc2, 0, 0, 0);
+      dbl4_v acc0 = {0, 0, 0, 0};
+      double acc1 = 0.0, acc2 = 0.0;
+      const int lr = lane & 15, lk = lane >> 4, lj = lane & 3, lb = (lane & 15) >> 2;
+#pragma unroll
+      for (int blk = 0; blk < 2 * LM_TILE / 4 / 8; blk++) {   // 8 row-quads at a time: operands first, then the MFMAs
+        double va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const double *rowp = xs + (4 * (8 * blk + u) + lk) * XS_LD;
+          va[u] = rowp[lr]; vb[u] = rowp[16 + lj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(va[u], vb[u], acc1, 0, 0, 0);
+        }
       }
+      {
+        double vc[2 * LM_TILE / 16];
+#pragma unroll
+        for (int qd = 0; qd < 2 * LM_TILE / 16; qd++) vc[qd] = xs[(16 * qd + 4 * lb + lk) * XS_LD + 16 + lj];
+#pragma unroll
+        for (int qd = 0; qd < 2 * LM_TILE / 16; qd++) acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(vc[qd], vc[qd], acc2, 0, 0, 0);
+      }
+      acc2 += __shfl_xor(acc2, 4, 64);
+      acc2 += __shfl_xor(acc2, 8, 64);
       double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VP_STRIDE;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        vo[(lk + 4 * q) * 16 + lr] = acc0[q];
-        if (lr < 4) vo[256 + (lk + 4 * q) * 4 + lr] = acc1[q];
-      }
-      if (lr < 4) vo[320 + lk * 4 + lr] = acc2[0];
+      for (int q = 0; q < 4; q++) vo[(lk + 4 * q) * 16 + lr] = acc0[q];
+      vo[256 + (4 * lb + lk) * 4 + lj] = acc1;        // T1[row 4 blk + i][col j], i = lane >> 4
+      if (lb == 0) vo[320 + lk * 4 + lj] = acc2;       // T2[i][j]
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -448,77 +466,121 @@ __global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
   const bool first = (c.iter == 0);   // Jacobi scaling is fixed at iteration 0 (TrustRegionMinimizer::IterationZero)
   // output tiles of this start frame: tile rows/cols >= I0, upper pairs, round-robin over the 4 waves
   const int I0 = (6 * s) / 16;
-  int myI[4], myJ[4], nmy = 0;
-  {
-    int idx = 0;
-    for (int I = I0; I < 5; I++)
-      for (int J = I; J < 5; J++, idx++)
-        if ((idx & 3) == wave && nmy < 4) { myI[nmy] = I; myJ[nmy] = J; nmy++; }
-  }
-  dbl4_t acc[4];
+  // slot q of this wave owns the (4 q + wave)-th upper tile pair (I, J), I0 <= I <= J < 5 — all wave-uniform
+  // scalars, and the four accumulators are separate named registers (no dynamic indexing of AGPRs).
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int nside = 5 - I0, npairs = nside * (nside + 1) / 2;
+  int pI[4], pJ[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) acc[q] = (dbl4_t){0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < 4; q++) {
+    int idx = 4 * q + wv, I = I0;
+    pI[q] = -1; pJ[q] = -1;
+    if (idx < npairs) { while (idx >= 5 - I) { idx -= 5 - I; I++; } pI[q] = I; pJ[q] = I + idx; }
+  }
+  dbl4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   const int lr = lane & 15, lk = lane >> 4;
+  // thread (l, part): landmark l of the tile; part 0 stages the common columns (start pose, extrinsic, td,
+  // gradient), parts 1..3 the observing poses s+1+k with k = part-1, part+2, ... All global loads of a tile
+  // are issued together (rows beyond a track's length are zero in memory) and the NEXT tile's loads are
+  // in flight while the matrix cores work on the current one.
+  const int l = t & 63, part = t >> 6;
+  const int kmax = NF - 1 - s;          // observing poses s+1 .. 10
+  double pre[24];
+  double pHll = 0.0, psl = 1.0;
+  int pinfo = 0;
+  auto prefetch = [&](int tile) {
+    const int slot = ds.lm_off + tile * LM_TILE + l;
+    pinfo = d.lm_info[slot];
+    pHll = d.lm_Hll[slot];
+    psl = first ? 1.0 : d.lm_sl[slot];
+    if (part == 0) {
+#pragma unroll
+      for (int q = 0; q < HC; q++) pre[q] = d.lm_hC[(size_t)q * TL + slot];
+      pre[HC] = d.lm_gl[slot];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int k = part - 1 + 3 * u;
+#pragma unroll
+        for (int q = 0; q < 6; q++) pre[u * 6 + q] = (k < kmax) ? d.lm_hP[((size_t)k * 6 + q) * TL + slot] : 0.0;
+      }
+    }
+  };
+  const bool stamp_wg = (w == 0 && s == 0 && t == 0 && !marg);
+  double *stamp = d.timing + 8;
+  if (stamp_wg) { stamp[0] = (double)wall_clock64(); stamp[5] = (double)clock64(); }
+  prefetch(tb);
   for (int tile = tb; tile < te; tile++) {
-    const int slot0 = ds.lm_off + tile * LM_TILE;
     __syncthreads();
-    for (int q = t; q < LM_TILE * HS_LD; q += blockDim.x) hs[q] = 0.0;
-    __syncthreads();
+    if (stamp_wg && tile == tb) stamp[1] = (double)wall_clock64();
     {
-      const int l = t & 63, part = t >> 6;
-      const int slot = slot0 + l;
-      const int info = d.lm_info[slot];
-      const bool valid = (info >> 24) & 1;
-      const int m = (info >> 8) & 0xff;
-      const bool is_const = (info >> 16) & 1;
-      const double Hll = d.lm_Hll[slot];
+      const int slot = ds.lm_off + tile * LM_TILE + l;
+      const bool valid = (pinfo >> 24) & 1;
+      const int m = (pinfo >> 8) & 0xff;
+      const bool is_const = (pinfo >> 16) & 1;
       double sw = 0.0;
       if (valid && m > 0 && (marg || !is_const)) {
         double wl;
         if (marg) {
-          wl = (Hll > d.opt.marg_eps) ? 1.0 / Hll : 0.0;
+          wl = (pHll > d.opt.marg_eps) ? 1.0 / pHll : 0.0;
         } else {
-          double sl;
-          if (first) { sl = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hll)) : 1.0; if (part == 0) d.lm_sl[slot] = sl; }
-          else sl = d.lm_sl[slot];
-          const double hs2 = sl * sl * Hll;
+          double sl = psl;
+          if (first) { sl = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(pHll)) : 1.0; if (part == 0) d.lm_sl[slot] = sl; }
+          const double hs2 = sl * sl * pHll;
           wl = sl * sl / (hs2 + c.mu * clamp_diag(hs2));
         }
         sw = sqrt(wl);
-        double *row = hs + l * HS_LD;
-        if (part == 0) {
-          for (int q = 0; q < 6; q++) {
-            row[6 * s + q] = sw * d.lm_hC[(size_t)q * TL + slot];
-            row[T_EX + q] = sw * d.lm_hC[(size_t)(6 + q) * TL + slot];
-          }
-          row[T_TD] = sw * d.lm_hC[(size_t)12 * TL + slot];
-          row[NV] = sw * d.lm_gl[slot];
-        } else {
-          for (int k = part - 1; k < m; k += 3)
-            for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = sw * d.lm_hP[((size_t)k * 6 + q) * TL + slot];
-        }
       } else if (!marg && first && valid && part == 0) {
         d.lm_sl[slot] = 1.0;
       }
-    }
-    __syncthreads();
-    for (int q = 0; q < 4; q++) {
-      if (q >= nmy) break;
-      const double *pa = hs + 16 * myI[q] + lr, *pb = hs + 16 * myJ[q] + lr;
-#pragma unroll 4
-      for (int kk = 0; kk < LM_TILE / 4; kk++) {
-        const int l = 4 * kk + lk;
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[l * HS_LD], pb[l * HS_LD], acc[q], 0, 0, 0);
+      double *row = hs + l * HS_LD;
+      if (part == 0) {
+        for (int q = 16 * I0; q < 6 * s; q++) row[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { row[6 * s + q] = sw * pre[q]; row[T_EX + q] = sw * pre[6 + q]; }
+        row[T_TD] = sw * pre[12];
+        row[NV] = sw * pre[HC];
+#pragma unroll
+        for (int q = NV + 1; q < NVP; q++) row[q] = 0.0;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = part - 1 + 3 * u;
+          if (k < kmax) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = sw * pre[u * 6 + q];
+          }
+        }
       }
     }
+    __syncthreads();
+    if (stamp_wg && tile == tb) stamp[2] = (double)wall_clock64();
+    if (tile + 1 < te) prefetch(tile + 1);
+#define SCHUR_SLOT(Q, ACC)                                                                          \
+    if (pI[Q] >= 0) {                                                                               \
+      const double *pa = hs + 16 * pI[Q] + lr + lk * HS_LD, *pb = hs + 16 * pJ[Q] + lr + lk * HS_LD; \
+      double va[LM_TILE / 4], vb[LM_TILE / 4];                                                      \
+      _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 4; kk++) { va[kk] = pa[4 * kk * HS_LD]; vb[kk] = pb[4 * kk * HS_LD]; } \
+      _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 4; kk++) ACC = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], ACC, 0, 0, 0); \
+    }
+    SCHUR_SLOT(0, acc0)
+    SCHUR_SLOT(1, acc1)
+    SCHUR_SLOT(2, acc2)
+    SCHUR_SLOT(3, acc3)
+#undef SCHUR_SLOT
   }
+  if (stamp_wg) { stamp[3] = (double)wall_clock64(); stamp[4] = (double)(te - tb); stamp[6] = (double)clock64(); }
   double *out = d.schur_part + ((size_t)w * NF + s) * SCHUR_STRIDE;
-  for (int q = 0; q < 4; q++) {
-    if (q >= nmy) break;
-    double *o = out + (size_t)schur_pair(myI[q], myJ[q]) * 256;
-#pragma unroll
-    for (int r = 0; r < 4; r++) o[(lk + 4 * r) * 16 + lr] = acc[q][r];
+#define SCHUR_OUT(Q, ACC)                                                         \
+  if (pI[Q] >= 0) {                                                               \
+    double *o = out + (size_t)schur_pair(pI[Q], pJ[Q]) * 256;                     \
+    _Pragma("unroll") for (int r = 0; r < 4; r++) o[(lk + 4 * r) * 16 + lr] = ACC[r]; \
   }
+  SCHUR_OUT(0, acc0)
+  SCHUR_OUT(1, acc1)
+  SCHUR_OUT(2, acc2)
+  SCHUR_OUT(3, acc3)
+#undef SCHUR_OUT
 }
 
 // =============================================================================================
@@ -553,28 +615,59 @@ __device__ __forceinline__ double vis_pair_entry(const BatchDev &d, const WinDes
   return d.pair_part[((size_t)w * NPAIR + i * NF + j) * VP_STRIDE + vp_off(la, lb)];
 }
 
-template <bool MARG>
+// Frame of a pose / speed-bias tangent dim (-1 for the global blocks).
+__device__ __forceinline__ int dim_frame(int a) {
+  if (a < 66) return a / 6;
+  if (a >= 73 && a < 172) return (a - 73) / 9;
+  return -1;
+}
+
+// Entry (a, b) of J^T J of the dense block. Only the factors that can touch both dims are visited:
+// a pose pair (fa, fb) for visual factors, the <= 2 inertial factors adjacent to the frames.
 __device__ double gather_H(const BatchDev &d, const WinDesc &ds, int w, int a, int b) {
   double s = 0.0;
+  const int fa = dim_frame(a), fb = dim_frame(b);
   if (a < NV && b < NV) {
-    for (int i = 0; i < (MARG ? 1 : NF - 1); i++)
-      for (int j = i + 1; j < NF; j++) {
-        if (ds.pair_begin[i * NF + j + 1] == ds.pair_begin[i * NF + j]) continue;   // no factor on this pose pair
-        const int la = vis_loc(a, i, j), lb = vis_loc(b, i, j);
-        if (la >= 0 && lb >= 0) s += vis_pair_entry(d, ds, w, i, j, la, lb);
+    const int pa = (a < 66) ? fa : -1, pb = (b < 66) ? fb : -1;   // pose frames (-1: extrinsic / td)
+    if (pa >= 0 && pb >= 0 && pa != pb) {
+      const int i = min(pa, pb), j = max(pa, pb);
+      if (ds.pair_begin[i * NF + j + 1] != ds.pair_begin[i * NF + j]) s += vis_pair_entry(d, ds, w, i, j, vis_loc(a, i, j), vis_loc(b, i, j));
+    } else if (pa >= 0 || pb >= 0) {
+      const int f = max(pa, pb);   // all pairs containing frame f
+      for (int j = f + 1; j < NF; j++)
+        if (ds.pair_begin[f * NF + j + 1] != ds.pair_begin[f * NF + j]) s += vis_pair_entry(d, ds, w, f, j, vis_loc(a, f, j), vis_loc(b, f, j));
+      for (int i = 0; i < f; i++)
+        if (ds.pair_begin[i * NF + f + 1] != ds.pair_begin[i * NF + f]) s += vis_pair_entry(d, ds, w, i, f, vis_loc(a, i, f), vis_loc(b, i, f));
+    } else {
+      for (int i = 0; i < NF - 1; i++)
+        for (int j = i + 1; j < NF; j++)
+          if (ds.pair_begin[i * NF + j + 1] != ds.pair_begin[i * NF + j]) s += vis_pair_entry(d, ds, w, i, j, vis_loc(a, i, j), vis_loc(b, i, j));
+    }
+  }
+  if (fa >= 0 && fb >= 0 && abs(fa - fb) <= 1) {   // IMU factor (i, i+1): both dims in frames {i, i+1}
+    const int lo = min(fa, fb);
+    for (int i = (fa == fb ? lo - 1 : lo); i <= lo; i++) {
+      if (i < 0 || i >= NF) continue;
+      const int q = ds.imu_of_frame[i];
+      if (q < 0) continue;
+      const int la = imu_loc(a, i), lb = imu_loc(b, i);
+      if (la >= 0 && lb >= 0) s += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + la * 30 + lb];
+    }
+  }
+  if (ds.n_wheel > 0) {
+    const bool ga = (a >= T_EXW), gb = (b >= T_EXW);            // wheel extrinsic / intrinsics / td_wheel
+    const int wa = (a < 66) ? fa : -1, wb = (b < 66) ? fb : -1;
+    if ((ga || wa >= 0) && (gb || wb >= 0)) {
+      int i0 = 0, i1 = NF - 2;
+      if (wa >= 0 && wb >= 0) { if (abs(wa - wb) > 1) { i0 = 1; i1 = 0; } else { const int lo = min(wa, wb); i0 = (wa == wb) ? lo - 1 : lo; i1 = lo; } }
+      else if (wa >= 0 || wb >= 0) { const int f = max(wa, wb); i0 = f - 1; i1 = f; }
+      for (int i = max(i0, 0); i <= min(i1, NF - 2); i++) {
+        const int q = ds.wheel_of_frame[i];
+        if (q < 0) continue;
+        const int la = wheel_loc(a, i), lb = wheel_loc(b, i);
+        if (la >= 0 && lb >= 0) s += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + la * 22 + lb];
       }
-  }
-  for (int q = 0; q < ds.n_imu; q++) {
-    const double *part = d.imu_part + ((size_t)w * MAX_IMU + q) * IMU_PART;
-    if (MARG && part[IMU_PART - 2] < 0.0) continue;
-    const int la = imu_loc(a, ds.imu_frame[q]), lb = imu_loc(b, ds.imu_frame[q]);
-    if (la >= 0 && lb >= 0) s += part[la * 30 + lb];
-  }
-  for (int q = 0; q < ds.n_wheel; q++) {
-    const double *part = d.wheel_part + ((size_t)w * MAX_WHEEL + q) * WHEEL_PART;
-    if (MARG && part[WHEEL_PART - 2] < 0.0) continue;
-    const int la = wheel_loc(a, ds.wheel_frame[q]), lb = wheel_loc(b, ds.wheel_frame[q]);
-    if (la >= 0 && lb >= 0) s += part[la * 22 + lb];
+    }
   }
   if (ds.prior_n > 0) {
     const int pa = ds.prior_map[a], pb = ds.prior_map[b];
@@ -582,28 +675,37 @@ __device__ double gather_H(const BatchDev &d, const WinDesc &ds, int w, int a, i
   }
   return s;
 }
-template <bool MARG>
 __device__ double gather_g(const BatchDev &d, const WinDesc &ds, int w, int a) {
   double s = 0.0;
+  const int fa = dim_frame(a);
   if (a < NV) {
-    for (int i = 0; i < (MARG ? 1 : NF - 1); i++)
-      for (int j = i + 1; j < NF; j++) {
-        if (ds.pair_begin[i * NF + j + 1] == ds.pair_begin[i * NF + j]) continue;
-        const int la = vis_loc(a, i, j);
-        if (la >= 0) s += vis_pair_entry(d, ds, w, i, j, la, 19);   // column 19 of X is the residual
-      }
+    if (a < 66) {
+      for (int j = fa + 1; j < NF; j++)
+        if (ds.pair_begin[fa * NF + j + 1] != ds.pair_begin[fa * NF + j]) s += vis_pair_entry(d, ds, w, fa, j, vis_loc(a, fa, j), 19);
+      for (int i = 0; i < fa; i++)
+        if (ds.pair_begin[i * NF + fa + 1] != ds.pair_begin[i * NF + fa]) s += vis_pair_entry(d, ds, w, i, fa, vis_loc(a, i, fa), 19);
+    } else {
+      for (int i = 0; i < NF - 1; i++)
+        for (int j = i + 1; j < NF; j++)
+          if (ds.pair_begin[i * NF + j + 1] != ds.pair_begin[i * NF + j]) s += vis_pair_entry(d, ds, w, i, j, vis_loc(a, i, j), 19);
+    }
   }
-  for (int q = 0; q < ds.n_imu; q++) {
-    const double *part = d.imu_part + ((size_t)w * MAX_IMU + q) * IMU_PART;
-    if (MARG && part[IMU_PART - 2] < 0.0) continue;
-    const int la = imu_loc(a, ds.imu_frame[q]);
-    if (la >= 0) s += part[900 + la];
-  }
-  for (int q = 0; q < ds.n_wheel; q++) {
-    const double *part = d.wheel_part + ((size_t)w * MAX_WHEEL + q) * WHEEL_PART;
-    if (MARG && part[WHEEL_PART - 2] < 0.0) continue;
-    const int la = wheel_loc(a, ds.wheel_frame[q]);
-    if (la >= 0) s += part[484 + la];
+  if (fa >= 0)
+    for (int i = fa - 1; i <= fa; i++) {
+      if (i < 0) continue;
+      const int q = ds.imu_of_frame[i];
+      if (q < 0) continue;
+      const int la = imu_loc(a, i);
+      if (la >= 0) s += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + 900 + la];
+    }
+  if (ds.n_wheel > 0 && (a < 66 || a >= T_EXW)) {
+    const int i0 = (a < 66) ? fa - 1 : 0, i1 = (a < 66) ? fa : NF - 2;
+    for (int i = max(i0, 0); i <= min(i1, NF - 2); i++) {
+      const int q = ds.wheel_of_frame[i];
+      if (q < 0) continue;
+      const int la = wheel_loc(a, i);
+      if (la >= 0) s += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + 484 + la];
+    }
   }
   if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
   return s;
@@ -637,7 +739,7 @@ __global__ __launch_bounds__(256) void k_assemble(BatchDev d) {
     while (a * (a + 1) / 2 > e) a--;
     const int b = e - a * (a + 1) / 2;   // b <= a
     double v = 0.0;
-    if (ds.act[a] && ds.act[b]) v = gather_H<false>(d, ds, w, b, a);
+    if (ds.act[a] && ds.act[b]) v = gather_H(d, ds, w, b, a);
     H[(size_t)a * ND + b] = v;
     H[(size_t)b * ND + a] = v;
     if (a < NV) {
@@ -648,7 +750,7 @@ __global__ __launch_bounds__(256) void k_assemble(BatchDev d) {
     }
   }
   for (int a = tid; a < ND; a += nthreads) {
-    g[a] = ds.act[a] ? gather_g<false>(d, ds, w, a) : 0.0;
+    g[a] = ds.act[a] ? gather_g(d, ds, w, a) : 0.0;
     if (a < NV) eg[a] = ds.act[a] ? gather_eg(d, ds, w, a, false) : 0.0;
   }
 }
@@ -872,11 +974,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
         double *C = smem + (size_t)tile_idx(I, J) * (TB * TB);
         const int lr = lane & 15, lk = lane >> 4;
         dbl4 acc;
+        double va[4], vb[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) acc[q] = C[(lk + 4 * q) * TB + lr];
+        for (int q = 0; q < 4; q++) { acc[q] = C[(lk + 4 * q) * TB + lr]; va[q] = -LI[lr * TB + q * 4 + lk]; vb[q] = LJ[lr * TB + q * 4 + lk]; }
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-LI[lr * TB + kk * 4 + lk], LJ[lr * TB + kk * 4 + lk], acc, 0, 0, 0);
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; q++) C[(lk + 4 * q) * TB + lr] = acc[q];
       }

@@ -53,5 +53,14 @@ int main() {
       printf("v_fma_f64         blocks %3d threads %3d : %.1f shader-clk per FMA  per wave, %.2f TFLOP/s\n", blocks, threads, h, flops / ms * 1e-9);
     }
   }
+  // dependent-accumulator latency: 1, 2, 4 independent chains per wave (one wave per SIMD)
+  {
+    hipLaunchKernelGGL(k_mfma<1>, dim3(256), dim3(256), 0, 0, d, 20000); hipDeviceSynchronize(); hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    printf("mfma_f64_16x16x4 1 chain : %.1f clk per MFMA\n", h);
+    hipLaunchKernelGGL(k_mfma<2>, dim3(256), dim3(256), 0, 0, d, 20000); hipDeviceSynchronize(); hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    printf("mfma_f64_16x16x4 2 chains: %.1f clk per MFMA\n", h);
+    hipLaunchKernelGGL(k_mfma<4>, dim3(256), dim3(256), 0, 0, d, 20000); hipDeviceSynchronize(); hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+    printf("mfma_f64_16x16x4 4 chains: %.1f clk per MFMA\n", h);
+  }
   return 0;
 }

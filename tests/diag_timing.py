@@ -15,3 +15,13 @@ names = ["perm+scale+reduce", "tile build", "cholesky", "backsub", "gram+store"]
 for i, n in enumerate(names):
     print("%-20s %8.2f us" % (n, (t[i + 1] - t[i]) * 0.01))
 print("total %.2f us" % ((t[5] - t[0]) * 0.01))
+
+print("k_schur WG(0,0): first prefetch %.2f us, first LDS stage %.2f us, all %d tiles %.2f us" % ((t[9]-t[8])*0.01, (t[10]-t[9])*0.01, int(t[12]), (t[11]-t[8])*0.01))
+print("k_schur WG(0,0) shader clock during the kernel: %.0f MHz" % ((t[14]-t[13]) / ((t[11]-t[8])*0.01)))
+# the same under load: 256 windows
+b2 = be.batch_upload([snap] * 256)
+b2.solve(abi.MARGIN_OLD); b2.solve(abi.MARGIN_OLD)
+t = b2.debug_timing(0)
+for i, n in enumerate(names):
+    print("B=256 %-20s %8.2f us" % (n, (t[i + 1] - t[i]) * 0.01))
+print("B=256 k_schur WG(0,0): all %d tiles %.2f us, shader clock %.0f MHz" % (int(t[12]), (t[11]-t[8])*0.01, (t[14]-t[13]) / ((t[11]-t[8])*0.01)))
