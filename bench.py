@@ -109,14 +109,19 @@ def main():
         tot_ms = sum(p["total_ms"] for p in prof.values())
         dom = max((p for p in prof.values()), key=lambda p: p["total_ms"])
         lin0 = prof.get("k_vis_lin_iter0", prof.get("k_vis_lin"))
-        # algorithmic bytes of one visual linearisation launch over the batch: 108 B in + 336 B out per
-        # residual block (the block-CSR J IS materialised, its 336 B re-read is k_pair's)
-        algo_bytes = 444.0 * K_batch
+        # Dominant hot-path kernel: k_vis<0> = visual evaluate + linearise with J^T J fused on the FP64
+        # matrix cores (J is never materialised). SURVEY.md §8d per-unit figures for one visual residual
+        # block: 108 B of input (fused form) and 1.6 kflop of J^T J. At 14.8 flop/B the kernel sits to the
+        # right of the FP64 ridge point (78.6 TF / 8 TB/s = 9.8 flop/B): the matrix-core roofline bounds it.
         lin_ms = lin0["total_ms"] / max(lin0["launches"], 1)
-        achieved = algo_bytes / (lin_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_vis<0> (visual evaluate+linearise, first iteration: all windows active)",
-                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                    "avg_launch_ms": lin_ms, "algorithmic_bytes_per_launch": algo_bytes,
+        algo_flops = 1600.0 * K_batch
+        algo_bytes = 108.0 * K_batch
+        achieved_tf = algo_flops / (lin_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "k_vis<0> (visual evaluate + linearise + fused J^T J; first iteration: all windows active)",
+                    "achieved": achieved_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved_tf / 78.6, "traffic": None,
+                    "avg_launch_ms": lin_ms, "algorithmic_flops_per_launch": algo_flops,
+                    "algorithmic_bytes_per_launch": algo_bytes, "hbm_view_GBps": algo_bytes / (lin_ms * 1e-3) / 1e9,
+                    "hbm_view_frac_of_8TBps": algo_bytes / (lin_ms * 1e-3) / 8e12,
                     "dominant_by_time": dom["name"],
                     "time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}}
 

@@ -760,11 +760,15 @@ __global__ __launch_bounds__(256) void k_assemble(BatchDev d) {
 // mu-regularised reduced system, packed Cholesky in LDS, Gauss-Newton step y_p, dense shares of
 // the dogleg scalars. (Ceres 1.14 DoglegStrategy::ComputeStep / ComputeGaussNewtonStep.)
 // =============================================================================================
-#define SOLVE_THREADS 256
+#define SOLVE_THREADS 1024
 #define TB 16                          // tile edge of the blocked Cholesky
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int tile_idx(int I, int J) { return I * (I + 1) / 2 + J; }   // J <= I
+// Element (r, c) of a 16x16 LDS tile. The column is XOR-swizzled with the row so that the column-wise
+// accesses of the panel solve / MFMA operand loads (16 lanes, same column, 16 rows) hit 16 different banks
+// instead of two (a row stride of 16 doubles = 32 dwords is the worst case for the 64-bank LDS).
+__device__ __forceinline__ int tsw(int r, int c) { return r * TB + (c ^ r); }
 
 // Rebuild E for a new mu directly from the landmark rows (slow path: only after a failed Cholesky).
 __device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu) {
@@ -821,7 +825,7 @@ __device__ __forceinline__ bool chol_tile16(double *T, int lane) {
   double row[TB];
   const int li = lane & 15;
 #pragma unroll
-  for (int q = 0; q < TB; q++) row[q] = T[li * TB + q];
+  for (int q = 0; q < TB; q++) row[q] = T[tsw(li, q)];
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < TB; k++) {
@@ -838,7 +842,7 @@ __device__ __forceinline__ bool chol_tile16(double *T, int lane) {
   }
   if (lane < TB) {
 #pragma unroll
-    for (int q = 0; q < TB; q++) T[li * TB + q] = row[q];
+    for (int q = 0; q < TB; q++) T[tsw(li, q)] = row[q];
   }
   return ok;
 }
@@ -861,19 +865,29 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
 #define STAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   STAMP(0);
 
-  if (t == 0) {
-    int n = 0;
-    for (int a = 0; a < ND; a++) if (ds.act[a]) perm[n++] = a;
-    s_nact = n;
-    for (int a = n; a < ND + TB; a++) perm[a] = -1;
-    if (first) {   // total cost of the first linearisation point (fixed order)
-      double cost = 0.0;
-      for (int q = 0; q < ds.n_tiles; q++) cost += d.tile_cost[(size_t)w * d.max_tiles + q];
-      for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
-      for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
-      cost += d.prior_g[(size_t)w * (ND + 2) + ND];
-      c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
+  // active-dim list by a wave-level prefix count (dims 0..191 live in waves 0..2)
+  __shared__ int wcount[4];
+  {
+    const bool on = (t < ND) && ds.act[t];
+    const unsigned long long m = __ballot(on);
+    if (t < 192 && lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    if (t < 192) {
+      int base = 0;
+      for (int q = 0; q < wave; q++) base += wcount[q];
+      if (on) perm[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+      if (t == 0) s_nact = wcount[0] + wcount[1] + wcount[2];
     }
+    __syncthreads();
+    for (int a = s_nact + t; a < ND + TB; a += blockDim.x) perm[a] = -1;
+  }
+  if (first && t == 0) {   // total cost of the first linearisation point (fixed order)
+    double cost = 0.0;
+    for (int q = 0; q < ds.n_tiles; q++) cost += d.tile_cost[(size_t)w * d.max_tiles + q];
+    for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
+    for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
+    cost += d.prior_g[(size_t)w * (ND + 2) + ND];
+    c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
   }
   // Jacobi scaling (iteration 0 only), D = sqrt(clamp(diag)), scaled gradient, Cauchy direction
   double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
@@ -912,10 +926,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     // ---- augmented, scaled, regularised, Schur-reduced system in 16x16 LDS tiles (lower triangle of tiles)
     //      [ S    rhs ]   S = s H s + mu D^2 - s E s   rhs = gt - s eg
     //      [ rhs' big ]
-    for (int I = 0; I < nt; I++)
-      for (int J = 0; J <= I; J++) {
-        double *T = smem + (size_t)tile_idx(I, J) * (TB * TB);
-        const int r = t >> 4, cc = t & 15;
+    const int ntile_all = nt * (nt + 1) / 2;
+    for (int te = t >> 8; te < ntile_all; te += SOLVE_THREADS >> 8) {
+        int I = 0, J = te;
+        while (J > I) { J -= I + 1; I++; }
+        double *T = smem + (size_t)te * (TB * TB);
+        const int r = (t & 255) >> 4, cc = t & 15;
         const int ia = I * TB + r, ib = J * TB + cc;
         double v;
         if (ia < n && ib < n) {
@@ -933,8 +949,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
         } else {
           v = (ia == ib) ? (ia == n ? 1e200 : 1.0) : 0.0;
         }
-        T[r * TB + cc] = v;
-      }
+        T[tsw(r, cc)] = v;
+    }
     if (t == 0) flag = 0;
     __syncthreads();
     STAMP(2);
@@ -942,28 +958,31 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     //      trailing update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
     for (int P = 0; P < nt; P++) {
       double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+      if (P == 0) STAMP(16);
       if (wave == 0) { if (!chol_tile16(Tpp, lane) && lane == 0) flag = 1; }
       __syncthreads();
+      if (P == 0) STAMP(17);
       if (flag) break;
       const int rows = (nt - 1 - P) * TB;
       if (t < rows) {
         const int I = P + 1 + (t >> 4), r = t & 15;
-        double *row = smem + (size_t)tile_idx(I, P) * (TB * TB) + r * TB;
+        double *tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
         double x[TB];
 #pragma unroll
-        for (int q = 0; q < TB; q++) x[q] = row[q];
+        for (int q = 0; q < TB; q++) x[q] = tip[tsw(r, q)];
 #pragma unroll
         for (int cidx = 0; cidx < TB; cidx++) {
           double acc = x[cidx];
 #pragma unroll
-          for (int k = 0; k < cidx; k++) acc -= x[k] * Tpp[cidx * TB + k];
-          x[cidx] = acc * Tpp[cidx * TB + cidx];   // diagonal holds 1 / L[c][c]
+          for (int k = 0; k < cidx; k++) acc -= x[k] * Tpp[tsw(cidx, k)];
+          x[cidx] = acc * Tpp[tsw(cidx, cidx)];   // diagonal holds 1 / L[c][c]
         }
 #pragma unroll
-        for (int q = 0; q < TB; q++) row[q] = x[q];
+        for (int q = 0; q < TB; q++) tip[tsw(r, q)] = x[q];
       }
       __syncthreads();
-      // trailing tiles (I, J), P < J <= I, round-robin over the 4 waves
+      if (P == 0) STAMP(18);
+      // trailing tiles (I, J), P < J <= I, round-robin over the waves
       const int nrem = nt - 1 - P;
       const int ntr = nrem * (nrem + 1) / 2;
       for (int e = wave; e < ntr; e += (SOLVE_THREADS >> 6)) {
@@ -976,20 +995,22 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
         dbl4 acc;
         double va[4], vb[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { acc[q] = C[(lk + 4 * q) * TB + lr]; va[q] = -LI[lr * TB + q * 4 + lk]; vb[q] = LJ[lr * TB + q * 4 + lk]; }
+        for (int q = 0; q < 4; q++) { acc[q] = C[tsw(lk + 4 * q, lr)]; va[q] = -LI[tsw(lr, q * 4 + lk)]; vb[q] = LJ[tsw(lr, q * 4 + lk)]; }
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; q++) C[(lk + 4 * q) * TB + lr] = acc[q];
+        for (int q = 0; q < 4; q++) C[tsw(lk + 4 * q, lr)] = acc[q];
       }
+      if (P == 0) STAMP(20);
       __syncthreads();
+      if (P == 0) STAMP(19);
     }
     bool ok = (flag == 0);
     STAMP(3);
     if (ok) {
       // z = L^-1 rhs sits in row n of L. Backward substitution y = L^-T z, block by block, in LDS.
       for (int i = t; i < n; i += blockDim.x)
-        ys[i] = smem[(size_t)tile_idx(n / TB, i / TB) * (TB * TB) + (n % TB) * TB + (i % TB)];
+        ys[i] = smem[(size_t)tile_idx(n / TB, i / TB) * (TB * TB) + tsw(n % TB, i % TB)];
       __syncthreads();
       for (int P = (n - 1) / TB; P >= 0; P--) {
         const double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
@@ -998,7 +1019,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
           const int li = lane & 15;
           double colv[TB];
 #pragma unroll
-          for (int k = 0; k < TB; k++) colv[k] = Tpp[k * TB + li];     // L[k][i]; [k][k] is 1 / L[k][k]
+          for (int k = 0; k < TB; k++) colv[k] = Tpp[tsw(k, li)];     // L[k][i]; [k][k] is 1 / L[k][k]
           double yi = (li < cnt) ? ys[r0 + li] : 0.0;
 #pragma unroll
           for (int k = TB - 1; k >= 0; k--) {
@@ -1014,7 +1035,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
         for (int i = t; i < r0; i += blockDim.x) {   // z_J -= L(P,J)^T y_P for all J < P
           const double *Tpj = smem + (size_t)tile_idx(P, i / TB) * (TB * TB);
           double acc = 0.0;
-          for (int k = 0; k < cnt; k++) acc += Tpj[k * TB + (i % TB)] * ys[r0 + k];
+          for (int k = 0; k < cnt; k++) acc += Tpj[tsw(k, i % TB)] * ys[r0 + k];
           ys[i] -= acc;
         }
         __syncthreads();
