@@ -1145,24 +1145,32 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
 // =============================================================================================
 // k_step: scalar trust-region logic of one iteration (one thread per window).
 // =============================================================================================
-__global__ void k_step(BatchDev d) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= d.B) return;
+__global__ __launch_bounds__(64) void k_step(BatchDev d) {
+  const int w = blockIdx.x, lane = threadIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (c.done) return;
-  if (c.have_step == 2) {   // fresh linearisation: fold in the landmark shares
+  if (c.have_step == 2) {   // fresh linearisation: fold in the landmark shares (lanes stride the tiles; fixed tree order)
     double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = 0; q < ds.n_tiles; q++) {
+    for (int q = lane; q < ds.n_tiles; q += 64) {
       const double *tg = d.tile_gram + ((size_t)w * d.max_tiles + q) * 8;
+#pragma unroll
       for (int k = 0; k < 8; k++) p[k] = (k == 6) ? fmax(p[k], tg[k]) : p[k] + tg[k];
     }
-    c.G2 += p[0]; c.N2 += p[1]; c.gy += p[2]; c.vHv += p[3]; c.vHy += p[4]; c.yHy += p[5];
-    c.grad_max = fmax(c.grad_max, p[6]);
-    c.x_norm = sqrt(c.x_norm + p[7]);
-    c.alpha = c.G2 / c.vHv;
-    c.reuse = 1;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const double other = __shfl_xor(p[k], o, 64); p[k] = (k == 6) ? fmax(p[k], other) : p[k] + other; }
+    }
+    if (lane == 0) {
+      c.G2 += p[0]; c.N2 += p[1]; c.gy += p[2]; c.vHv += p[3]; c.vHy += p[4]; c.yHy += p[5];
+      c.grad_max = fmax(c.grad_max, p[6]);
+      c.x_norm = sqrt(c.x_norm + p[7]);
+      c.alpha = c.G2 / c.vHv;
+      c.reuse = 1;
+    }
   }
+  if (lane != 0) return;
   c.have_step = 0;
   // TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue
   const int max_it = min(d.opt.max_num_iterations, 15);
@@ -1263,20 +1271,22 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
 // (TrustRegionMinimizer::{ParameterToleranceReached,FunctionToleranceReached,IsStepSuccessful,
 //  HandleSuccessfulStep,HandleUnsuccessfulStep}, DoglegStrategy::{StepAccepted,StepRejected}).
 // =============================================================================================
-__global__ void k_accept(BatchDev d) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= d.B) return;
+__global__ __launch_bounds__(64) void k_accept(BatchDev d) {
+  const int w = blockIdx.x, lane = threadIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (c.done || !c.have_step) return;
-  double cand = 0.0, d2 = d.dense_cand[(size_t)w * 4 + 1], n2 = d.dense_cand[(size_t)w * 4 + 2];
-  for (int q = 0; q < ds.n_tiles; q++) {
+  double cand = 0.0, d2 = 0.0, n2 = 0.0;
+  for (int q = lane; q < ds.n_tiles; q += 64) {
     const double *o = d.tile_cand + ((size_t)w * d.max_tiles + q) * 4;
     cand += o[0]; d2 += o[1]; n2 += o[2];
   }
-  for (int q = 0; q < ds.n_imu; q++) cand += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 1];
-  for (int q = 0; q < ds.n_wheel; q++) cand += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 1];
-  cand += d.prior_g[(size_t)w * (ND + 2) + ND + 1];
+  if (lane < ds.n_imu) cand += d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 1];
+  if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 1];
+  if (lane == 32) { cand += d.prior_g[(size_t)w * (ND + 2) + ND + 1]; d2 += d.dense_cand[(size_t)w * 4 + 1]; n2 += d.dense_cand[(size_t)w * 4 + 2]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o, 64); d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
+  if (lane != 0) return;
   if (!isfinite(cand)) cand = 1.7976931348623157e308;
   const int it = c.iter;
   c.cand_cost = cand;
@@ -1384,11 +1394,11 @@ void launch_lm_step(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles == 0) return;
   hipLaunchKernelGGL(k_lm_step, dim3(d.max_tiles, d.B), dim3(LM_TILE), 0, s, d);
 }
-void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3((d.B + 63) / 64), dim3(64), 0, s, d); }
+void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
 void launch_candidate(const BatchDev &d, hipStream_t s) {
   hipLaunchKernelGGL(k_candidate, dim3(d.max_tiles + 1, d.B), dim3(LM_TILE), 0, s, d);
 }
-void launch_accept(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_accept, dim3((d.B + 63) / 64), dim3(64), 0, s, d); }
+void launch_accept(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_accept, dim3(d.B), dim3(64), 0, s, d); }
 void launch_reanchor(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_reanchor, dim3(d.B), dim3(64), 0, s, d); }
 
 }  // namespace gfd

@@ -198,6 +198,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   double *J0 = d.mJ0 + (size_t)w * ND * ND;
   double *r0 = d.mr0 + (size_t)w * ND;
   const bool old = (flag == GFBE_MARGIN_OLD);
+  double *stamp = d.timing + 24;
+#define MSTAMP(i) do { if (w == 0 && t == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  MSTAMP(0);
 
   if (t == 0) {
     for (int q = 0; q < GFBE_BLK_COUNT; q++) sh.touched[q] = 0;
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     return;
   }
   const int n = sh.n, m = sh.m;
+  MSTAMP(1);
   // ---- full A (ND x ND, landmark block already eliminated) and b over all tangent dims
   const double *pp = d.pair_part + (size_t)w * NPAIR * VP_STRIDE;   // pairs (0, j): index j
   const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE;   // start frame 0 partial (15 dense 16x16 tiles)
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     bv[a] = s;
   }
   __syncthreads();
+  MSTAMP(2);
   // ---- dense elimination of the m dropped dims: Amm = V diag(l) V^T, pinv with eps
   for (int e = t; e < m * m; e += blockDim.x) {
     const int i = e / m, j = e % m;
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     Pinv[i * 16 + j] = s;
   }
   __syncthreads();
+  MSTAMP(3);
   // T = A_rm * Pinv (n x m) kept in J0's storage; then A' and b' (compact, n x n) into r0/J0 staging
   double *T = J0;   // n x 16
   for (int e = t; e < n * m; e += blockDim.x) {
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
   for (int i = t; i < n; i += blockDim.x) bv[i] = r0[i];
   __syncthreads();
+  MSTAMP(4);
   extern __shared__ __attribute__((aligned(16))) double marg_lds[];
   __shared__ int order[ND];
   if (d.opt.marg_sqrt == 1) {
@@ -339,58 +346,50 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     double *M = in_lds ? marg_lds : d.mV + (size_t)w * ND * ND;    // full symmetric n x n, row-major
     double *bz = d.gts + (size_t)w * ND;                           // running b' -> z
     double *dk = d.Dp + (size_t)w * ND;                            // pivots
-    __shared__ double s_red[32];
-    __shared__ int s_idx[32], s_rank, s_piv;
+    // In-place elimination WITHOUT data movement: step k picks the largest remaining diagonal entry p_k
+    // (every wave finds it redundantly: no cross-wave reduction), subtracts its rank-1 term from the rows /
+    // columns not yet eliminated and leaves row/column p_k untouched afterwards, so L(:,k) = M(:,p_k) / d_k
+    // can be read off at the end. One block barrier per step.
+    __shared__ int elim_step[ND];
+    __shared__ double zsave[ND];
     for (int e = t; e < n * n; e += blockDim.x) M[e] = A[e];
-    for (int i = t; i < n; i += blockDim.x) { order[i] = i; bz[i] = bv[i]; }
-    if (t == 0) s_rank = n;
+    for (int i = t; i < n; i += blockDim.x) { elim_step[i] = 0x7fffffff; bz[i] = bv[i]; }
     __syncthreads();
+    const int lane = t & 63;
+    int rank = n;
     for (int k = 0; k < n; k++) {
-      // pivot search: largest remaining diagonal (first index on ties -> deterministic)
-      double best = -1e300; int bi = k;
-      for (int i = k + t; i < n; i += blockDim.x) { const double v = M[(size_t)i * n + i]; if (v > best) { best = v; bi = i; } }
+      double best = -1e300; int bi = -1;
+      for (int i = lane; i < n; i += 64)
+        if (elim_step[i] > k) { const double v = M[(size_t)i * n + i]; if (v > best || bi < 0) { best = v; bi = i; } }
+#pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_down(best, o, 64); const int oi = __shfl_down(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
       }
-      if ((t & 63) == 0) { s_red[t >> 6] = best; s_idx[t >> 6] = bi; }
-      __syncthreads();
-      if (t == 0) {
-        double b2 = s_red[0]; int i2 = s_idx[0];
-        for (int q = 1; q < (int)(blockDim.x >> 6); q++) if (s_red[q] > b2 || (s_red[q] == b2 && s_idx[q] < i2)) { b2 = s_red[q]; i2 = s_idx[q]; }
-        s_piv = i2;
-        if (!(b2 > d.opt.marg_eps)) s_rank = k;
+      if (!(best > d.opt.marg_eps)) { rank = k; break; }     // identical in every wave
+      const int pv = bi;
+      const double piv = M[(size_t)pv * n + pv], inv = 1.0 / piv, zk = bz[pv];
+      for (int e = t; e < n * n; e += blockDim.x) {
+        const int i = e / n, j = e - i * n;
+        if (i == pv || j == pv || elim_step[i] < k || elim_step[j] < k) continue;
+        M[e] -= M[(size_t)i * n + pv] * M[(size_t)pv * n + j] * inv;
       }
-      __syncthreads();
-      if (s_rank == k) break;
-      const int pv = s_piv;
-      if (pv != k) {   // symmetric swap k <-> pv
-        for (int j = t; j < n; j += blockDim.x) { const double a = M[(size_t)k * n + j]; M[(size_t)k * n + j] = M[(size_t)pv * n + j]; M[(size_t)pv * n + j] = a; }
-        __syncthreads();
-        for (int j = t; j < n; j += blockDim.x) { const double a = M[(size_t)j * n + k]; M[(size_t)j * n + k] = M[(size_t)j * n + pv]; M[(size_t)j * n + pv] = a; }
-        if (t == 0) { const int a = order[k]; order[k] = order[pv]; order[pv] = a; const double bb = bz[k]; bz[k] = bz[pv]; bz[pv] = bb; }
-        __syncthreads();
-      }
-      const double piv = M[(size_t)k * n + k], zk = bz[k];
-      const int rem = n - 1 - k;
-      for (int e = t; e < rem * rem; e += blockDim.x) {   // trailing update with the unscaled column
-        const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-        M[(size_t)i * n + j] -= M[(size_t)i * n + k] * M[(size_t)k * n + j] / piv;
-      }
-      for (int i = k + 1 + t; i < n; i += blockDim.x) bz[i] -= M[(size_t)i * n + k] / piv * zk;
-      if (t == 0) dk[k] = piv;
-      __syncthreads();
-      for (int i = k + 1 + t; i < n; i += blockDim.x) M[(size_t)i * n + k] /= piv;   // L[i][k]
+      for (int i = t; i < n; i += blockDim.x)
+        if (i != pv && elim_step[i] > k) bz[i] -= M[(size_t)i * n + pv] * inv * zk;
+      if (t == 0) { elim_step[pv] = k; order[k] = pv; dk[k] = piv; zsave[k] = zk; }
       __syncthreads();
     }
-    const int rank = s_rank;
     for (int e = t; e < n * n; e += blockDim.x) {
-      const int k = e / n, i = e % n;
+      const int k = e / n, i = e - k * n;
       double v = 0.0;
-      if (k < rank && i >= k) v = sqrt(dk[k]) * (i == k ? 1.0 : M[(size_t)i * n + k]);
-      J0[(size_t)k * n + order[i]] = v;
+      if (k < rank) {
+        const int pk = order[k];
+        if (i == pk) v = sqrt(dk[k]);
+        else if (elim_step[i] > k) v = M[(size_t)i * n + pk] / sqrt(dk[k]);   // sqrt(d_k) * L(i,k), L(i,k) = M(i,p_k) / d_k
+      }
+      J0[(size_t)k * n + i] = v;
     }
-    for (int k = t; k < n; k += blockDim.x) r0[k] = (k < rank) ? bz[k] / sqrt(dk[k]) : 0.0;
+    for (int k = t; k < n; k += blockDim.x) r0[k] = (k < rank) ? zsave[k] / sqrt(dk[k]) : 0.0;
     if (t == 0) sh.sweeps = -rank;
   } else {
   // ---- A' = V S V^T (the reference's construction). One-sided Jacobi; G (= A' V) and V live in LDS
@@ -425,6 +424,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     G[e] = d.Dp[(size_t)w * ND + k] * Vm[(size_t)order[k] * n + i];   // G aliases J0: row k of J0
   }
   }
+  MSTAMP(5);
   // ---- getParameterBlocks + addr_shift (estimator.cpp:3561-3590, 3644-3687)
   if (t == 0) {
     meta[0] = 1; meta[1] = n; meta[2] = sh.n_keep; meta[3] = sh.sweeps;   // [3]: Jacobi sweeps (diagnostic)
