@@ -51,7 +51,7 @@ def build_native(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(os.path.dirname(_HERE), "include"), "-o", _SO] + srcs
+           "-I", os.path.join(os.path.dirname(_HERE), "include"), "-o", _SO] + os.environ.get("GFBE_EXTRA_FLAGS", "").split() + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -24,6 +24,9 @@
 
 namespace gfd {
 
+#ifndef GFBE_ABLATE
+#define GFBE_ABLATE 0   // timing ablations of k_vis (tests/diag_ablate.sh); 0 in every shipped build
+#endif
 #define GF_MIN_DIAG 1e-6
 #define GF_MAX_DIAG 1e32
 #define GF_MIN_MU 1e-8
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
 
   __shared__ PoseRT sp[NF + 1];
   __shared__ PairConst pcs[NF];          // pair (sframe, j) constants, j = sframe+1 .. 10
-  __shared__ double xs[(MODE == 1) ? 1 : 2 * LM_TILE * XS_LD];   // [J | r] rows of the wave's 64 factors at one step
+  __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XS_LD];   // one [J | r] row of each of the wave's 64 factors
   const int lane = threadIdx.x;
   if (lane < NF) sp[lane] = make_pose(X + A_POSE(lane));
   if (lane == NF) sp[NF] = make_pose(X + A_EX);
@@ -183,11 +186,16 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
 #pragma unroll
   for (int q = 0; q < HC; q++) hC[q] = 0.0;
   for (int k = 0; k < mmax; k++) {
+    double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
     if (k < m) {
       const double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
       double pjx, pjy, vjx, vjy, tdj;
       pjx = ob[0]; pjy = ob[TL]; vjx = ob[2 * TL]; vjy = ob[3 * TL]; tdj = ob[4 * TL];
-      double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
+      if (GFBE_ABLATE == 4 && MODE == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; q++) { Ji[q] = pjx + q; Jj[q] = pjy * q; Je[q] = vjx - q; }
+        Jl[0] = lam; Jl[1] = tdj; Jt[0] = vjy; Jt[1] = pix; r[0] = piy * 1e-3; r[1] = piz * 1e-3;
+      } else
       visual_eval_pc<MODE != 1>(pcs[sframe + 1 + k], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
                                 sq, r, Ji, Jj, Je, Jl, Jt);
       double s1, rs, asn;
@@ -209,16 +217,6 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
           }
           rb[20] = Jl[0]; rb[21] = Jt[0]; rb[40] = Jl[1]; rb[41] = Jt[1];
         }
-        // X = [J(pose_i pose_j ex td) | r]: this lane's two rows of the step's 128 x 20 panel
-        {
-          double *x0 = xs + (2 * lane) * XS_LD, *x1 = x0 + XS_LD;
-#pragma unroll
-          for (int q = 0; q < 6; q++) {
-            x0[q] = Ji[q]; x0[6 + q] = Jj[q]; x0[12 + q] = Je[q];
-            x1[q] = Ji[6 + q]; x1[6 + q] = Jj[6 + q]; x1[12 + q] = Je[6 + q];
-          }
-          x0[18] = Jt[0]; x0[19] = r[0]; x1[18] = Jt[1]; x1[19] = r[1];
-        }
         // landmark row of the normal equations (w = Jl)
         const double w0 = (is_const && MODE == 0) ? 0.0 : Jl[0], w1 = (is_const && MODE == 0) ? 0.0 : Jl[1];
         Hll += w0 * w0 + w1 * w1;
@@ -227,20 +225,19 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
         for (int q = 0; q < 6; q++) {
           hC[q] += Ji[q] * w0 + Ji[6 + q] * w1;
           hC[6 + q] += Je[q] * w0 + Je[6 + q] * w1;
-          d.lm_hP[((size_t)k * 6 + q) * TL + slot] = Jj[q] * w0 + Jj[6 + q] * w1;
+          if (GFBE_ABLATE != 3 || w0 == 1.2345) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = Jj[q] * w0 + Jj[6 + q] * w1;
         }
         hC[12] += Jt[0] * w0 + Jt[1] * w1;
       }
     } else if (MODE != 1) {
-      double *x0 = xs + (2 * lane) * XS_LD;
 #pragma unroll
-      for (int q = 0; q < 2 * XS_LD; q++) x0[q] = 0.0;
+      for (int q = 0; q < 12; q++) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
+      Jt[0] = Jt[1] = 0.0; r[0] = r[1] = 0.0;
     }
-    if (MODE != 1) {
-      // X^T X of the step's 128 x 20 panel on the FP64 matrix cores (the J^T J / J^T r of this tile's
-      // factors of pose pair (sframe, sframe+1+k)); J never leaves the CU.
-      __threadfence_block();
-      __builtin_amdgcn_wave_barrier();
+    if (MODE != 1 && GFBE_ABLATE != 1) {
+      // X^T X of the step's 128 x 20 panel X = [J(pose_i pose_j ex td) | r] on the FP64 matrix cores (the
+      // J^T J / J^T r of this tile's factors of pose pair (sframe, sframe+1+k)); J never leaves the CU.
+      // The panel goes through LDS 64 rows at a time (row h of every lane's factor, h = 0, 1).
       // T0 = X(:,0:16)^T X(:,0:16) with v_mfma_f64_16x16x4_f64 (64 clk / 4 rows); the thin blocks use
       // v_mfma_f64_4x4x4_4b_f64 (18 clk, lane layout measured in profiles/ubench/mfma_f64_4x4x4_layout.hip:
       // A_blk[i][k] at lane 16k+4blk+i, B_blk[k][j] at 16k+4blk+j, D_blk[i][j] at 16i+4blk+j):
@@ -251,29 +248,42 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
       double acc1 = 0.0, acc2 = 0.0;
       const int lr = lane & 15, lk = lane >> 4, lj = lane & 3, lb = (lane & 15) >> 2;
 #pragma unroll
-      for (int blk = 0; blk < 2 * LM_TILE / 4 / 8; blk++) {   // 8 row-quads at a time: operands first, then the MFMAs
-        double va[8], vb[8];
+      for (int h = 0; h < 2; h++) {
+        {
+          double *xr = xs + lane * XS_LD;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const double *rowp = xs + (4 * (8 * blk + u) + lk) * XS_LD;
-          va[u] = rowp[lr]; vb[u] = rowp[16 + lj];
+          for (int q = 0; q < 6; q++) { xr[q] = Ji[6 * h + q]; xr[6 + q] = Jj[6 * h + q]; xr[12 + q] = Je[6 * h + q]; }
+          xr[18] = Jt[h]; xr[19] = r[h];
         }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(va[u], vb[u], acc1, 0, 0, 0);
+        for (int blk = 0; blk < LM_TILE / 4 / 8; blk++) {   // 8 row-quads at a time: operands first, then the MFMAs
+          double va[8], vb[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const double *rowp = xs + (4 * (8 * blk + u) + lk) * XS_LD;
+            va[u] = rowp[lr]; vb[u] = rowp[16 + lj];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(va[u], vb[u], acc1, 0, 0, 0);
+          }
         }
-      }
-      {
-        double vc[2 * LM_TILE / 16];
+        {
+          double vc[LM_TILE / 16];
 #pragma unroll
-        for (int qd = 0; qd < 2 * LM_TILE / 16; qd++) vc[qd] = xs[(16 * qd + 4 * lb + lk) * XS_LD + 16 + lj];
+          for (int qd = 0; qd < LM_TILE / 16; qd++) vc[qd] = xs[(16 * qd + 4 * lb + lk) * XS_LD + 16 + lj];
 #pragma unroll
-        for (int qd = 0; qd < 2 * LM_TILE / 16; qd++) acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(vc[qd], vc[qd], acc2, 0, 0, 0);
+          for (int qd = 0; qd < LM_TILE / 16; qd++) acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(vc[qd], vc[qd], acc2, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
       }
       acc2 += __shfl_xor(acc2, 4, 64);
       acc2 += __shfl_xor(acc2, 8, 64);
       double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VP_STRIDE;
+      if (GFBE_ABLATE == 2 && acc0[0] != 1.2345) continue;
 #pragma unroll
       for (int q = 0; q < 4; q++) vo[(lk + 4 * q) * 16 + lr] = acc0[q];
       vo[256 + (4 * lb + lk) * 4 + lj] = acc1;        // T1[row 4 blk + i][col j], i = lane >> 4

@@ -182,6 +182,7 @@ __device__ void jacobi_eig_wave16(double *G, double *V, int n, double *lam, int 
 }
 
 #define MARG_THREADS 1024
+#define MARG_SQRT_PENDING (-1000000)
 #define MARG_LDS_N 94   // A' up to this size is eigen-decomposed entirely inside LDS (2 n^2 doubles)
 
 __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
@@ -340,57 +341,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   extern __shared__ __attribute__((aligned(16))) double marg_lds[];
   __shared__ int order[ND];
   if (d.opt.marg_sqrt == 1) {
-    // ---- diagonally pivoted LDL^T of A' with pivots > eps:  A' ~= P L D+ L^T P^T,
-    //      J0 = D+^(1/2) L^T P^T,  r0 = D+^(-1/2) L^-1 P^T b'   (forward substitution folded in)
-    const bool in_lds = (n * n <= 2 * MARG_LDS_N * MARG_LDS_N);
-    double *M = in_lds ? marg_lds : d.mV + (size_t)w * ND * ND;    // full symmetric n x n, row-major
-    double *bz = d.gts + (size_t)w * ND;                           // running b' -> z
-    double *dk = d.Dp + (size_t)w * ND;                            // pivots
-    // In-place elimination WITHOUT data movement: step k picks the largest remaining diagonal entry p_k
-    // (every wave finds it redundantly: no cross-wave reduction), subtracts its rank-1 term from the rows /
-    // columns not yet eliminated and leaves row/column p_k untouched afterwards, so L(:,k) = M(:,p_k) / d_k
-    // can be read off at the end. One block barrier per step.
-    __shared__ int elim_step[ND];
-    __shared__ double zsave[ND];
-    for (int e = t; e < n * n; e += blockDim.x) M[e] = A[e];
-    for (int i = t; i < n; i += blockDim.x) { elim_step[i] = 0x7fffffff; bz[i] = bv[i]; }
-    __syncthreads();
-    const int lane = t & 63;
-    int rank = n;
-    for (int k = 0; k < n; k++) {
-      double best = -1e300; int bi = -1;
-      for (int i = lane; i < n; i += 64)
-        if (elim_step[i] > k) { const double v = M[(size_t)i * n + i]; if (v > best || bi < 0) { best = v; bi = i; } }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-        if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
-      }
-      if (!(best > d.opt.marg_eps)) { rank = k; break; }     // identical in every wave
-      const int pv = bi;
-      const double piv = M[(size_t)pv * n + pv], inv = 1.0 / piv, zk = bz[pv];
-      for (int e = t; e < n * n; e += blockDim.x) {
-        const int i = e / n, j = e - i * n;
-        if (i == pv || j == pv || elim_step[i] < k || elim_step[j] < k) continue;
-        M[e] -= M[(size_t)i * n + pv] * M[(size_t)pv * n + j] * inv;
-      }
-      for (int i = t; i < n; i += blockDim.x)
-        if (i != pv && elim_step[i] > k) bz[i] -= M[(size_t)i * n + pv] * inv * zk;
-      if (t == 0) { elim_step[pv] = k; order[k] = pv; dk[k] = piv; zsave[k] = zk; }
-      __syncthreads();
-    }
-    for (int e = t; e < n * n; e += blockDim.x) {
-      const int k = e / n, i = e - k * n;
-      double v = 0.0;
-      if (k < rank) {
-        const int pk = order[k];
-        if (i == pk) v = sqrt(dk[k]);
-        else if (elim_step[i] > k) v = M[(size_t)i * n + pk] / sqrt(dk[k]);   // sqrt(d_k) * L(i,k), L(i,k) = M(i,p_k) / d_k
-      }
-      J0[(size_t)k * n + i] = v;
-    }
-    for (int k = t; k < n; k += blockDim.x) r0[k] = (k < rank) ? zsave[k] / sqrt(dk[k]) : 0.0;
-    if (t == 0) sh.sweeps = -rank;
+    // the square root itself is taken by k_marg_ldlt (own kernel: the matrix is register-resident there)
+    if (t == 0) sh.sweeps = MARG_SQRT_PENDING;
   } else {
   // ---- A' = V S V^T (the reference's construction). One-sided Jacobi; G (= A' V) and V live in LDS
   // when they fit (the common n = 86 prior), otherwise in the global scratch.
@@ -441,6 +393,120 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
 }
 
+
+// ---- diagonally pivoted LDL^T of A' with pivots > eps:  A' ~= P L D+ L^T P^T,
+//      J0 = D+^(1/2) L^T P^T,  r0 = D+^(-1/2) L^-1 P^T b'   (forward substitution folded in)
+#define LDLT_THREADS 512
+template <int R>
+__device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, const double *__restrict__ bv, double *__restrict__ J0,
+                                              double *__restrict__ r0, const int n, const double eps) {
+  const int t = threadIdx.x;
+    // The matrix lives in REGISTERS: thread (ti, tj) of a G x G grid (G = ceil(n / R)) owns the R x R tile
+    // A'(R ti .. R ti + R - 1, R tj .. R tj + R - 1). Step k: every wave finds the largest remaining diagonal entry p_k
+    // from its own register copy of the diagonal (no cross-wave reduction), the owners of row p_k publish it
+    // through a double-buffered LDS vector, one block barrier, and every thread subtracts the rank-1 term
+    // from its tile. Nothing is moved: eliminated rows / columns simply stay behind (masked on output), and
+    // row k of J0 = sqrt(d_k) L(:,k)^T is streamed to HBM from the published vector as it is produced.
+    __shared__ double colbuf[2][192];
+    const int G = (n + R - 1) / R;
+    const int ti = t / G, tj = t - ti * G;
+    const bool owner_active = t < G * G;
+    const int lane = t & 63, wv = t >> 6;
+    double a[R][R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int c = 0; c < R; c++) {
+        const int i = ti * R + r, j = tj * R + c;
+        a[r][c] = (owner_active && i < n && j < n) ? A[(size_t)i * n + j] : 0.0;
+      }
+    double dg[3], bzr[3];
+    bool alive[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int i = lane + 64 * q;
+      alive[q] = i < n;
+      dg[q] = alive[q] ? A[(size_t)i * n + i] : 0.0;
+      bzr[q] = alive[q] ? bv[i] : 0.0;
+    }
+    int rank = n;
+    for (int k = 0; k < n; k++) {
+      double best = -1e300; int bi = -1;
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        if (alive[q] && (bi < 0 || dg[q] > best)) { best = dg[q]; bi = lane + 64 * q; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+      }
+      if (!(best > eps)) { rank = k; break; }     // identical in every wave
+      const int pv = bi, pq = pv >> 6, pl = pv & 63;
+      const double piv = best, inv = 1.0 / piv;
+      const double zsel = pq == 0 ? bzr[0] : (pq == 1 ? bzr[1] : bzr[2]);
+      const double zk = __shfl(zsel, pl, 64);
+      double *cb = colbuf[k & 1];
+      const int pr = pv / R, pc = pv - pr * R;
+      if (owner_active && ti == pr) {                         // symmetric: row p_k == column p_k
+#pragma unroll
+        for (int c = 0; c < R; c++) {
+          double v = a[0][c];
+#pragma unroll
+          for (int r = 1; r < R; r++) v = pc == r ? a[r][c] : v;
+          cb[tj * R + c] = v;
+        }
+      }
+      __syncthreads();
+      double cx[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) cx[q] = cb[lane + 64 * q];
+      if (wv == (k & (LDLT_THREADS / 64 - 1))) {                                   // row k of J0, r0[k]
+        const double rs = 1.0 / sqrt(piv);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int i = lane + 64 * q;
+          if (i < n) J0[(size_t)k * n + i] = i == pv ? sqrt(piv) : (alive[q] ? cx[q] * rs : 0.0);
+        }
+        if (lane == 0) r0[k] = zk * rs;
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double li = cx[q] * inv;
+        dg[q] -= li * cx[q];
+        bzr[q] -= li * zk;
+        if (lane + 64 * q == pv) alive[q] = false;
+      }
+      if (owner_active) {
+        double ci[R], cj[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { ci[r] = cb[ti * R + r] * inv; cj[r] = cb[tj * R + r]; }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+          for (int c = 0; c < R; c++) a[r][c] -= ci[r] * cj[c];
+      }
+    }
+    for (int e = t + rank * n; e < n * n; e += blockDim.x) J0[e] = 0.0;
+    for (int k = t + rank; k < n; k += blockDim.x) r0[k] = 0.0;
+    return rank;
+}
+
+__global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
+  const int w = blockIdx.x;
+  int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
+  if (meta[0] != 1 || meta[3] != MARG_SQRT_PENDING) return;
+  const int n = meta[1];
+  const double *A = d.mA + (size_t)w * ND * ND;
+  const double *bv = d.mb + (size_t)w * ND;
+  double *J0 = d.mJ0 + (size_t)w * ND * ND;
+  double *r0 = d.mr0 + (size_t)w * ND;
+  double *stamp = d.timing + 24;
+  int rank;
+  if (n <= 4 * 22) rank = ldlt_registers<4>(A, bv, J0, r0, n, d.opt.marg_eps);
+  else rank = ldlt_registers<8>(A, bv, J0, r0, n, d.opt.marg_eps);
+  if (threadIdx.x == 0) { meta[3] = -rank; if (w == 0) stamp[6] = (double)wall_clock64(); }
+}
+
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {
   if (flag == GFBE_MARGIN_OLD) {
     launch_vis(d, 2, s);
@@ -454,6 +520,7 @@ void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {
   const size_t lds = sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N;
   if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(MARG_THREADS), lds, s, d, flag);
+  if (d.opt.marg_sqrt == 1) hipLaunchKernelGGL(k_marg_ldlt, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
 }
 
 }  // namespace gfd

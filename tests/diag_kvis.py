@@ -1,0 +1,22 @@
+"""Diagnostic: per-launch time of the first-iteration k_vis<0> launch at B=256 (ablation builds allowed to fail numerically)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from _gfbe_import import gf
+abi, synth = gf.abi, gf.synth
+be = gf.Backend(0)
+scns = [synth.Scenario(seed=20250708 + 2 + 100 * u, n_landmarks=int(os.environ.get("L", "2000")), use_wheel=True) for u in range(8)]
+snaps = [s.window(0) for s in scns]
+B = int(os.environ.get("B", "256"))
+batch = be.batch_upload([snaps[i % 8] for i in range(B)])
+def run():
+    try:
+        batch.solve(abi.MARGIN_OLD)
+    except Exception as e:
+        pass
+run(); torch.cuda.synchronize()
+be.profile_enable(True); be.profile_reset()
+for _ in range(3): run()
+torch.cuda.synchronize()
+for p in sorted(be.profile(), key=lambda p: -p["total_ms"]):
+    print("%-20s launches %4d  avg %.4f ms  total %.3f" % (p["name"], p["launches"], p["total_ms"] / max(p["launches"], 1), p["total_ms"]))
