@@ -155,6 +155,9 @@ struct BatchDev {
   double *schur_part;         // [B][NF][SCHUR_STRIDE]  sum over the landmarks of one start frame
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
+  double *vis_H;              // [B][73][74]  visual block of the normal equations + gradient column (k_visblock)
+  int *asm_tab;               // [ND (ND + 1) / 2][4]  window-independent assembly table (k_asm_table)
+  double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble
   double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
   double *tile_cand;          // [B][max_tiles][4] candidate: cost, |x-xc|^2, |xc|^2, pad
   double *tile_gram;          // [B][max_tiles][8] landmark parts of G2 N2 gy vHv vHy yHy gradmax
@@ -188,6 +191,7 @@ void launch_pair(const BatchDev &d, int marg, hipStream_t s);
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s);
 void launch_assemble(const BatchDev &d, hipStream_t s);
+void launch_asm_table(const BatchDev &d, hipStream_t s);
 void launch_solve(const BatchDev &d, hipStream_t s);
 void launch_lm_step(const BatchDev &d, hipStream_t s);
 void launch_step(const BatchDev &d, hipStream_t s);

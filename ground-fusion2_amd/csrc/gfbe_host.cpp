@@ -426,7 +426,7 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   UP(desc, desc); UP(lm_info, lm_info); UP(lm_abi, lm_abi); UP(lm_pts, lm_pts); UP(lm_obs, lm_obs); UP(lm_rec, lm_rec);
   UP(lam0, lam0); UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
   UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0); UP(tri_tab, tri);
-  AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
+  AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1)); AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
   AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
   AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
   AL(rec, (size_t)tot_rec * REC);
@@ -444,7 +444,7 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   AL(timing, (size_t)B * 32); AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
 #undef UP
 #undef AL
-  { Timed t(c, "k_prep", 0); launch_prep(d, c->stream); }
+  { Timed t(c, "k_prep", 0); launch_prep(d, c->stream); launch_asm_table(d, c->stream); }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
   return GFBE_OK;
@@ -464,7 +464,6 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, bool first) {
   // the first linearisation has every window active; later ones skip windows that only shrink the radius
   { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, c->stream); }
   { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, c->stream); }
-  { Timed t(c, "k_pairsum", 0); launch_pair(d, 0, c->stream); }
   { Timed t(c, "k_schur", 0); launch_schur(d, 0, c->stream); }
   { Timed t(c, "k_assemble", 0); launch_assemble(d, c->stream); }
   { Timed t(c, "k_solve", 0); launch_solve(d, c->stream); }

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
 // =============================================================================================
 // k_pairsum: sums the fused visual partials over the landmark tiles of a start frame (fixed order):
 //   pair_part[w][(i,j)][:] = sum_{tiles t of start frame i} vis_part[w][t][j-i-1][:]
-// so that the assembly gathers one block per pose pair.
+// Used by the marginalisation (pairs (0, j)); the solve loop sums the tiles inside k_assemble.
 // =============================================================================================
 __global__ __launch_bounds__(VP_STRIDE) void k_pairsum(BatchDev d, int marg) {
   const int w = blockIdx.y;
@@ -594,8 +594,8 @@ __global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
 }
 
 // =============================================================================================
-// k_assemble: owner-computes gather of every partial into the dense normal equations (fixed
-// summation order => bit-reproducible). Writes H (unscaled, constant dims removed), g, E, eg.
+// k_assemble: every partial into the dense normal equations (fixed summation order =>
+// bit-reproducible). Writes H (unscaled, constant dims removed), g, E, eg.
 // =============================================================================================
 __device__ __forceinline__ int vis_loc(int a, int i, int j) {   // compact column of visual dim a in pair (i,j)
   if (a < 66) { const int f = a / 6; if (f == i) return a - 6 * f; if (f == j) return 6 + a - 6 * f; return -1; }
@@ -620,11 +620,6 @@ __device__ __forceinline__ int vp_off(int a, int b) {   // entry (a <= b) of the
   if (a < 16) return 256 + a * 4 + (b - 16);
   return 320 + (a - 16) * 4 + (b - 16);
 }
-// (la, lb) entry of the X^T X block of pose pair (i, j) (k_pairsum output)
-__device__ __forceinline__ double vis_pair_entry(const BatchDev &d, const WinDesc &ds, int w, int i, int j, int la, int lb) {
-  return d.pair_part[((size_t)w * NPAIR + i * NF + j) * VP_STRIDE + vp_off(la, lb)];
-}
-
 // Frame of a pose / speed-bias tangent dim (-1 for the global blocks).
 __device__ __forceinline__ int dim_frame(int a) {
   if (a < 66) return a / 6;
@@ -632,94 +627,6 @@ __device__ __forceinline__ int dim_frame(int a) {
   return -1;
 }
 
-// Entry (a, b) of J^T J of the dense block. Only the factors that can touch both dims are visited:
-// a pose pair (fa, fb) for visual factors, the <= 2 inertial factors adjacent to the frames.
-__device__ double gather_H(const BatchDev &d, const WinDesc &ds, int w, int a, int b) {
-  double s = 0.0;
-  const int fa = dim_frame(a), fb = dim_frame(b);
-  if (a < NV && b < NV) {
-    const int pa = (a < 66) ? fa : -1, pb = (b < 66) ? fb : -1;   // pose frames (-1: extrinsic / td)
-    if (pa >= 0 && pb >= 0 && pa != pb) {
-      const int i = min(pa, pb), j = max(pa, pb);
-      if (ds.pair_begin[i * NF + j + 1] != ds.pair_begin[i * NF + j]) s += vis_pair_entry(d, ds, w, i, j, vis_loc(a, i, j), vis_loc(b, i, j));
-    } else if (pa >= 0 || pb >= 0) {
-      const int f = max(pa, pb);   // all pairs containing frame f
-      for (int j = f + 1; j < NF; j++)
-        if (ds.pair_begin[f * NF + j + 1] != ds.pair_begin[f * NF + j]) s += vis_pair_entry(d, ds, w, f, j, vis_loc(a, f, j), vis_loc(b, f, j));
-      for (int i = 0; i < f; i++)
-        if (ds.pair_begin[i * NF + f + 1] != ds.pair_begin[i * NF + f]) s += vis_pair_entry(d, ds, w, i, f, vis_loc(a, i, f), vis_loc(b, i, f));
-    } else {
-      for (int i = 0; i < NF - 1; i++)
-        for (int j = i + 1; j < NF; j++)
-          if (ds.pair_begin[i * NF + j + 1] != ds.pair_begin[i * NF + j]) s += vis_pair_entry(d, ds, w, i, j, vis_loc(a, i, j), vis_loc(b, i, j));
-    }
-  }
-  if (fa >= 0 && fb >= 0 && abs(fa - fb) <= 1) {   // IMU factor (i, i+1): both dims in frames {i, i+1}
-    const int lo = min(fa, fb);
-    for (int i = (fa == fb ? lo - 1 : lo); i <= lo; i++) {
-      if (i < 0 || i >= NF) continue;
-      const int q = ds.imu_of_frame[i];
-      if (q < 0) continue;
-      const int la = imu_loc(a, i), lb = imu_loc(b, i);
-      if (la >= 0 && lb >= 0) s += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + la * 30 + lb];
-    }
-  }
-  if (ds.n_wheel > 0) {
-    const bool ga = (a >= T_EXW), gb = (b >= T_EXW);            // wheel extrinsic / intrinsics / td_wheel
-    const int wa = (a < 66) ? fa : -1, wb = (b < 66) ? fb : -1;
-    if ((ga || wa >= 0) && (gb || wb >= 0)) {
-      int i0 = 0, i1 = NF - 2;
-      if (wa >= 0 && wb >= 0) { if (abs(wa - wb) > 1) { i0 = 1; i1 = 0; } else { const int lo = min(wa, wb); i0 = (wa == wb) ? lo - 1 : lo; i1 = lo; } }
-      else if (wa >= 0 || wb >= 0) { const int f = max(wa, wb); i0 = f - 1; i1 = f; }
-      for (int i = max(i0, 0); i <= min(i1, NF - 2); i++) {
-        const int q = ds.wheel_of_frame[i];
-        if (q < 0) continue;
-        const int la = wheel_loc(a, i), lb = wheel_loc(b, i);
-        if (la >= 0 && lb >= 0) s += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + la * 22 + lb];
-      }
-    }
-  }
-  if (ds.prior_n > 0) {
-    const int pa = ds.prior_map[a], pb = ds.prior_map[b];
-    if (pa >= 0 && pb >= 0) s += d.prior_H[(size_t)w * ND * ND + (size_t)pa * ds.prior_n + pb];
-  }
-  return s;
-}
-__device__ double gather_g(const BatchDev &d, const WinDesc &ds, int w, int a) {
-  double s = 0.0;
-  const int fa = dim_frame(a);
-  if (a < NV) {
-    if (a < 66) {
-      for (int j = fa + 1; j < NF; j++)
-        if (ds.pair_begin[fa * NF + j + 1] != ds.pair_begin[fa * NF + j]) s += vis_pair_entry(d, ds, w, fa, j, vis_loc(a, fa, j), 19);
-      for (int i = 0; i < fa; i++)
-        if (ds.pair_begin[i * NF + fa + 1] != ds.pair_begin[i * NF + fa]) s += vis_pair_entry(d, ds, w, i, fa, vis_loc(a, i, fa), 19);
-    } else {
-      for (int i = 0; i < NF - 1; i++)
-        for (int j = i + 1; j < NF; j++)
-          if (ds.pair_begin[i * NF + j + 1] != ds.pair_begin[i * NF + j]) s += vis_pair_entry(d, ds, w, i, j, vis_loc(a, i, j), 19);
-    }
-  }
-  if (fa >= 0)
-    for (int i = fa - 1; i <= fa; i++) {
-      if (i < 0) continue;
-      const int q = ds.imu_of_frame[i];
-      if (q < 0) continue;
-      const int la = imu_loc(a, i);
-      if (la >= 0) s += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + 900 + la];
-    }
-  if (ds.n_wheel > 0 && (a < 66 || a >= T_EXW)) {
-    const int i0 = (a < 66) ? fa - 1 : 0, i1 = (a < 66) ? fa : NF - 2;
-    for (int i = max(i0, 0); i <= min(i1, NF - 2); i++) {
-      const int q = ds.wheel_of_frame[i];
-      if (q < 0) continue;
-      const int la = wheel_loc(a, i);
-      if (la >= 0) s += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + 484 + la];
-    }
-  }
-  if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
-  return s;
-}
 // E(a,b), a <= b < NVP: sum over the start frames s with 6 s <= a (fixed order)
 __device__ double gather_E(const BatchDev &d, const WinDesc &ds, int w, int a, int b, bool marg) {
   if (a > b) { const int t = a; a = b; b = t; }
@@ -734,34 +641,268 @@ __device__ double gather_eg(const BatchDev &d, const WinDesc &ds, int w, int a, 
   return gather_E(d, ds, w, a, NV, marg);   // column 73 of the padded block carries sum_l w_l h_l g_l
 }
 
-__global__ __launch_bounds__(256) void k_assemble(BatchDev d) {
+// Tables of the window descriptor the assembly consults per entry, staged in LDS once per workgroup.
+struct AsmTab {
+  int prior_map[ND];
+  int imu_of_frame[NF], wheel_of_frame[NF];
+  int prior_n, n_wheel;
+  unsigned char act[ND + 2];
+};
+
+// Window-independent part of the assembly of entry e = (a, b), b <= a, of the lower triangle: which (at most
+// two) inertial and (at most two) wheel factors reach it and where inside their J^T J blocks. Built once per
+// batch by k_asm_table; k_assemble only resolves frame -> factor and the prior column per window.
+//   x = a | b << 8
+//   y = IMU:   slot0 = (i0 + 1) | off0 << 4 (bits 0..13), slot1 the same in bits 16..29; i + 1 == 0: none
+//   z = wheel: same packing (the wheel-global x wheel-global block is handled separately)
+__device__ __forceinline__ void tri_decode(int e, int &a, int &b) {
+  a = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+  while ((a + 1) * (a + 2) / 2 <= e) a++;
+  while (a * (a + 1) / 2 > e) a--;
+  b = e - a * (a + 1) / 2;   // b <= a
+}
+#define ASM_NTRI (ND * (ND + 1) / 2)
+__global__ __launch_bounds__(256) void k_asm_table(int4 *tab) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ASM_NTRI) return;
+  int hi, lo_;
+  tri_decode(e, hi, lo_);
+  const int a = lo_, b = hi;          // gather convention: a <= b
+  int4 r = make_int4(hi | (lo_ << 8), 0, 0, 0);
+  const int fa = dim_frame(a), fb = dim_frame(b);
+  if (fa >= 0 && fb >= 0 && abs(fa - fb) <= 1) {   // IMU factors (lo-1, lo) and (lo, lo+1)
+    const int lo = min(fa, fb);
+    const int i0 = (fa == fb) ? lo - 1 : -1, i1 = lo;
+    if (i0 >= 0) { const int la = imu_loc(a, i0), lb = imu_loc(b, i0); if (la >= 0 && lb >= 0) r.y |= (i0 + 1) | ((la * 30 + lb) << 4); }
+    if (i1 <= NF - 2) { const int la = imu_loc(a, i1), lb = imu_loc(b, i1); if (la >= 0 && lb >= 0) r.y |= ((i1 + 1) | ((la * 30 + lb) << 4)) << 16; }
+  }
+  {
+    const bool ga = (a >= T_EXW), gb = (b >= T_EXW);            // wheel extrinsic / intrinsics / td_wheel
+    const int wa = (a < 66) ? fa : -1, wb = (b < 66) ? fb : -1;
+    int i0 = -1, i1 = -1;
+    if (wa >= 0 && wb >= 0) { if (abs(wa - wb) <= 1) { const int lo = min(wa, wb); i0 = (wa == wb) ? lo - 1 : -1; i1 = lo; } }
+    else if ((wa >= 0 && gb) || (wb >= 0 && ga)) { const int f = max(wa, wb); i0 = f - 1; i1 = f; }
+    if (i0 >= 0 && i0 <= NF - 2) { const int la = wheel_loc(a, i0), lb = wheel_loc(b, i0); if (la >= 0 && lb >= 0) r.z |= (i0 + 1) | ((la * 22 + lb) << 4); }
+    if (i1 >= 0 && i1 <= NF - 2) { const int la = wheel_loc(a, i1), lb = wheel_loc(b, i1); if (la >= 0 && lb >= 0) r.z |= ((i1 + 1) | ((la * 22 + lb) << 4)) << 16; }
+  }
+  tab[e] = r;
+}
+void launch_asm_table(const BatchDev &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_asm_table, dim3((ASM_NTRI + 255) / 256), dim3(256), 0, s, (int4 *)d.asm_tab);
+}
+
+__device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab &tb, const double *Z, int w, int a) {
+  const int fa = dim_frame(a);
+  const double *p[2] = {Z, Z};
+  if (fa >= 0) {
+    if (fa >= 1) { const int q = tb.imu_of_frame[fa - 1], la = imu_loc(a, fa - 1); if (q >= 0 && la >= 0) p[0] = d.imu_part + ((size_t)w * MAX_IMU + q) * IMU_PART + 900 + la; }
+    { const int q = tb.imu_of_frame[fa], la = imu_loc(a, fa); if (q >= 0 && la >= 0) p[1] = d.imu_part + ((size_t)w * MAX_IMU + q) * IMU_PART + 900 + la; }
+  }
+  double s = *p[0] + *p[1];
+  if (tb.n_wheel > 0 && (a < 66 || a >= T_EXW)) {
+    const int i0 = (a < 66) ? fa - 1 : 0, i1 = (a < 66) ? fa : NF - 2;
+#pragma unroll
+    for (int i = 0; i <= NF - 2; i++) {
+      const int q = tb.wheel_of_frame[i], la = wheel_loc(a, i);
+      const bool use = i >= i0 && i <= i1 && q >= 0 && la >= 0;
+      s += *(use ? d.wheel_part + ((size_t)w * MAX_WHEEL + q) * WHEEL_PART + 484 + la : Z);
+    }
+  }
+  if (tb.prior_n > 0 && tb.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + tb.prior_map[a]];
+  return s;
+}
+// E(a,b), a <= b < NVP (b = 73: the gradient column): the 11 start-frame Schur partials, loads unconditional in flight
+__device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z, int w, int a, int b) {
+  const int off = schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);
+  const int smax = min(a / 6, NF - 1);
+  const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE + off;
+  double v[NF];
+#pragma unroll
+  for (int f = 0; f < NF; f++) v[f] = *(f <= smax ? sp + (size_t)f * SCHUR_STRIDE : Z);
+  double s = 0.0;
+#pragma unroll
+  for (int f = 0; f < NF; f++) s += v[f];
+  return s;
+}
+
+// k_visblock (one workgroup per window): the visual block of the normal equations.
+//   For every start frame i, thread e sums entry e of the fused X^T X partials (k_vis) of the pose pairs
+//   (i, i+1..10) over the landmark tiles of that start frame (registers, all loads in flight at once; two thread
+//   groups take the tiles alternately) and adds them into a 73 x 74 LDS accumulator (column 73 = gradient).
+//   Inside one start frame no two threads of a group touch the same entry; the groups add one after the other,
+//   so every entry is summed in one fixed order. The block goes to HBM as vis_H[w][73][74].
+// k_assemble (16 workgroups per window): owner-computes over the lower triangle of the 182 x 182 system: visual
+//   entry + the <= 5 inertial / wheel / prior contributions through the window-independent table of
+//   k_asm_table (independent loads, four entries in flight per thread); E and eg = sums of the start-frame
+//   Schur partials.
+#define VB_THREADS 1024
+#define VB_GROUP 512
+#define V_LD 74
+__global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  __shared__ double V[NV * V_LD];
+  __shared__ int s_tile_begin[NF + 1];
+  const int t = threadIdx.x;
+  const double *Z = d.zero;
+  double *stamp = d.timing + (size_t)w * 32;
+#define ASTAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  ASTAMP(6);
+  for (int e = t; e < NV * V_LD; e += VB_THREADS) V[e] = 0.0;
+  if (t <= NF) s_tile_begin[t] = ds.sf_tile_begin[t];
+  __syncthreads();
+  const int grp = t / VB_GROUP, e = t - grp * VB_GROUP;
+  const bool live = e < VP_STRIDE;
+  // compact column pair (la, lb) of this thread's entry of a fused partial (layout of k_vis: T0 16x16, T1 16x4, T2 4x4)
+  int la = 0, lb = 0; bool mirror = false;
+  if (e < 256) { la = e >> 4; lb = e & 15; }
+  else if (e < 320) { la = (e - 256) >> 2; lb = 16 + ((e - 256) & 3); mirror = true; }
+  else if (live) { la = 16 + ((e - 320) >> 2); lb = 16 + ((e - 320) & 3); }
+  // target of step k of start frame i: row da, column db with
+  //   d = 6 i + l (l < 6: pose i) | 6 (i + 1 + k) + l - 6 (l < 12: pose j) | 54 + l (extrinsic, td, gradient)
+  const bool aj = la >= 6 && la < 12, bj = lb >= 6 && lb < 12;
+  const int a_i = la < 6 ? 6 : (aj ? 6 : 0), b_i = lb < 6 ? 6 : (bj ? 6 : 0);        // d(d)/d(i)
+  const int a_0 = la < 6 ? la : (aj ? la : 54 + la), b_0 = lb < 6 ? lb : (bj ? lb : 54 + lb);   // at i = 0, k = 0 (j = 1)
+  const int step0 = (aj ? 6 * V_LD : 0) + (bj ? 6 : 0), step1 = (bj ? 6 * V_LD : 0) + (aj ? 6 : 0);   // per k
+  const bool row_ok = live && la != 19, mir_ok = live && mirror && lb != 19;
+  const bool uses_j = aj || bj;
+  const double *vp = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VP_STRIDE + e;
+  for (int i = 0; i < NF - 1; i++) {
+    const int t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
+    if (t0 == t1) continue;
+    const int nk = NF - 1 - i;
+    double s[MAXOBS];
+#pragma unroll
+    for (int k = 0; k < MAXOBS; k++) s[k] = 0.0;
+    if (live) {
+      for (int tt = t0 + grp; tt < t1; tt += 4) {
+        const double *q0 = vp + (size_t)tt * MAXOBS * VP_STRIDE, *q1 = q0 + (size_t)2 * MAXOBS * VP_STRIDE;
+        const bool two = tt + 2 < t1;
+        double v0[MAXOBS], v1[MAXOBS];
+#pragma unroll
+        for (int k = 0; k < MAXOBS; k++) {   // steps a tile never runs stay zero in vis_part
+          v0[k] = *(k < nk ? q0 + k * VP_STRIDE : Z);
+          v1[k] = *((two && k < nk) ? q1 + k * VP_STRIDE : Z);
+        }
+#pragma unroll
+        for (int k = 0; k < MAXOBS; k++) { s[k] += v0[k]; s[k] += v1[k]; }
+      }
+    }
+    const int da0 = a_0 + a_i * i, db0 = b_0 + b_i * i;
+    const int i0 = da0 * V_LD + db0, i1 = db0 * V_LD + da0;
+    for (int gsel = 0; gsel < 2; gsel++) {
+      if (gsel >= t1 - t0) break;
+      if (grp == gsel) {
+        if (!uses_j) {
+          double tot = 0.0;
+#pragma unroll
+          for (int k = 0; k < MAXOBS; k++) tot += s[k];
+          if (row_ok) V[i0] += tot;
+          if (mir_ok) V[i1] += tot;
+        } else {
+          // the targets of this thread are distinct entries: read them all, then write them all
+          double o0[MAXOBS], o1[MAXOBS];
+#pragma unroll
+          for (int k = 0; k < MAXOBS; k++) {
+            o0[k] = (row_ok && k < nk) ? V[i0 + k * step0] : 0.0;
+            o1[k] = (mir_ok && k < nk) ? V[i1 + k * step1] : 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < MAXOBS; k++) {
+            if (row_ok && k < nk) V[i0 + k * step0] = o0[k] + s[k];
+            if (mir_ok && k < nk) V[i1 + k * step1] = o1[k] + s[k];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  double *out = d.vis_H + (size_t)w * NV * V_LD;
+  for (int q = t; q < NV * V_LD; q += VB_THREADS) out[q] = V[q];
+  ASTAMP(7);
+#undef ASTAMP
+}
+
+#define ASM_THREADS 256
+#define ASM_WGS 16
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   const int w = blockIdx.y;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
+  __shared__ AsmTab tb;
+  const int t = threadIdx.x;
+  const double *Z = d.zero;
+  for (int a = t; a < ND; a += ASM_THREADS) { tb.prior_map[a] = ds.prior_map[a]; tb.act[a] = ds.act[a]; }
+  if (t < NF) { tb.imu_of_frame[t] = ds.imu_of_frame[t]; tb.wheel_of_frame[t] = ds.wheel_of_frame[t]; }
+  if (t == 0) { tb.prior_n = ds.prior_n; tb.n_wheel = ds.n_wheel; }
+  __syncthreads();
+  const int gt = blockIdx.x * ASM_THREADS + t, gn = ASM_WGS * ASM_THREADS;
   double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
-  const int nthreads = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x;
-  // lower triangle + diagonal, mirrored
-  for (int e = tid; e < ND * (ND + 1) / 2; e += nthreads) {
-    int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-    while ((a + 1) * (a + 2) / 2 <= e) a++;
-    while (a * (a + 1) / 2 > e) a--;
-    const int b = e - a * (a + 1) / 2;   // b <= a
-    double v = 0.0;
-    if (ds.act[a] && ds.act[b]) v = gather_H(d, ds, w, b, a);
-    H[(size_t)a * ND + b] = v;
-    H[(size_t)b * ND + a] = v;
-    if (a < NV) {
-      double ev = 0.0;
-      if (ds.act[a] && ds.act[b]) ev = gather_E(d, ds, w, b, a, false);
-      E[a * NV + b] = ev;
-      E[b * NV + a] = ev;
+  const int4 *tab = (const int4 *)d.asm_tab;
+  const double *imu_w = d.imu_part + (size_t)w * MAX_IMU * IMU_PART, *wheel_w = d.wheel_part + (size_t)w * MAX_WHEEL * WHEEL_PART;
+  const double *prior_w = d.prior_H + (size_t)w * ND * ND, *vis_w = d.vis_H + (size_t)w * NV * V_LD;
+  for (int e0 = gt; e0 < ASM_NTRI; e0 += 4 * gn) {
+    int4 ent[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int e = e0 + u * gn; ent[u] = e < ASM_NTRI ? tab[e] : make_int4(-1, 0, 0, 0); }
+    const double *p[4][6];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
+      on[u] = ent[u].x >= 0 && tb.act[a] && tb.act[b];
+      const int y = on[u] ? ent[u].y : 0, z = (on[u] && tb.n_wheel > 0) ? ent[u].z : 0;
+      const int i0 = (y & 15) - 1, i1 = ((y >> 16) & 15) - 1, j0 = (z & 15) - 1, j1 = ((z >> 16) & 15) - 1;
+      const int q0 = i0 >= 0 ? tb.imu_of_frame[i0] : -1, q1 = i1 >= 0 ? tb.imu_of_frame[i1] : -1;
+      const int r0 = j0 >= 0 ? tb.wheel_of_frame[j0] : -1, r1 = j1 >= 0 ? tb.wheel_of_frame[j1] : -1;
+      p[u][0] = q0 >= 0 ? imu_w + q0 * IMU_PART + ((y >> 4) & 1023) : Z;
+      p[u][1] = q1 >= 0 ? imu_w + q1 * IMU_PART + ((y >> 20) & 1023) : Z;
+      p[u][2] = r0 >= 0 ? wheel_w + r0 * WHEEL_PART + ((z >> 4) & 1023) : Z;
+      p[u][3] = r1 >= 0 ? wheel_w + r1 * WHEEL_PART + ((z >> 20) & 1023) : Z;
+      const int pa = on[u] && tb.prior_n > 0 ? tb.prior_map[b] : -1, pb = on[u] && tb.prior_n > 0 ? tb.prior_map[a] : -1;
+      p[u][4] = (pa >= 0 && pb >= 0) ? prior_w + (size_t)pa * tb.prior_n + pb : Z;
+      p[u][5] = (on[u] && a < NV) ? vis_w + b * V_LD + a : Z;
+    }
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = *p[u][0] + *p[u][1] + *p[u][2] + *p[u][3] + *p[u][4] + *p[u][5];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (ent[u].x < 0) continue;
+      const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
+      double x = v[u];
+      if (b >= T_EXW && on[u] && tb.n_wheel > 0) {
+        // wheel extrinsic / intrinsic / td_wheel block: every wheel factor contributes (10 loads in flight)
+        const int off = wheel_loc(b, 0) * 22 + wheel_loc(a, 0);   // global dims: the column does not depend on the factor
+        double ws = 0.0;
+#pragma unroll
+        for (int i = 0; i <= NF - 2; i++) {
+          const int q = tb.wheel_of_frame[i];
+          ws += *(q >= 0 ? wheel_w + q * WHEEL_PART + off : Z);
+        }
+        x += ws;
+      }
+      H[(size_t)a * ND + b] = x;
+      H[(size_t)b * ND + a] = x;
     }
   }
-  for (int a = tid; a < ND; a += nthreads) {
-    g[a] = ds.act[a] ? gather_g(d, ds, w, a) : 0.0;
-    if (a < NV) eg[a] = ds.act[a] ? gather_eg(d, ds, w, a, false) : 0.0;
+  // E (73 x 73, symmetric), eg
+  for (int e = gt; e < NV * (NV + 1) / 2; e += gn) {
+    int a, b;
+    tri_decode(e, a, b);
+    const double ev = (tb.act[a] && tb.act[b]) ? gather_E11(d, Z, w, b, a) : 0.0;
+    E[a * NV + b] = ev;
+    E[b * NV + a] = ev;
+  }
+  for (int a = gt; a < ND; a += gn) {
+    double v = 0.0;
+    if (tb.act[a]) { v = gather_g_dense(d, tb, Z, w, a); if (a < NV) v += vis_w[a * V_LD + NV]; }
+    g[a] = v;
+    if (a < NV) eg[a] = tb.act[a] ? gather_E11(d, Z, w, a, NV) : 0.0;
   }
 }
 
@@ -864,7 +1005,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
   if (c.done || c.reuse) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ int perm[ND + TB];
-  __shared__ double red[16], ys[ND + TB];
+  __shared__ double red[16], ys[2 * ND + TB];
   __shared__ int flag, s_nact;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
@@ -1070,14 +1211,26 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     return;
   }
   STAMP(4);
-  // dense shares of the dogleg scalars: t_v = Ht v, t_y = Ht y  (Ht = s H s; H symmetric -> column reads coalesce)
+  // dense shares of the dogleg scalars: v^T Ht v, y^T Ht v, y^T Ht y with Ht = s H s, as double sums over (a, b):
+  // wave `wave` takes rows a = wave, wave + 16, ...; lane l the columns l, l + 64, l + 128 (coalesced row
+  // reads; rows / columns of constant dims are zero in H). One block reduction at the end, fixed order.
   double n2 = 0.0, gyv = 0.0, vhv = 0.0, vhy = 0.0, yhy = 0.0;
+  for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }
+  __syncthreads();
+  {
+    double svb[3], syb[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { const int b = lane + 64 * q; svb[q] = b < ND ? ys[b] : 0.0; syb[q] = b < ND ? ys[ND + b] : 0.0; }
+    for (int a = wave; a < ND; a += SOLVE_THREADS >> 6) {
+      const double *Ha = H + (size_t)a * ND;
+      double hv = 0.0, hy = 0.0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) { const int b = lane + 64 * q; const double h = b < ND ? Ha[b] : 0.0; hv += h * svb[q]; hy += h * syb[q]; }
+      const double sva = ys[a], sya = ys[ND + a];
+      vhv += sva * hv; vhy += sya * hv; yhy += sya * hy;
+    }
+  }
   for (int a = t; a < ND; a += blockDim.x) {
-    if (!ds.act[a]) continue;
-    double tv = 0.0, ty = 0.0;
-    for (int b = 0; b < ND; b++) { const double hb = gsp[b] * H[(size_t)b * ND + a]; tv += hb * gvp[b]; ty += hb * gyp[b]; }
-    tv *= gsp[a]; ty *= gsp[a];
-    vhv += gvp[a] * tv; vhy += gyp[a] * tv; yhy += gyp[a] * ty;
     n2 += gDp[a] * gDp[a] * gyp[a] * gyp[a];
     gyv += ggts[a] * gyp[a];
   }
@@ -1391,7 +1544,10 @@ void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
   if (d.max_tiles == 0) return;
   hipLaunchKernelGGL(k_schur, dim3(marg ? 1 : NF, d.B), dim3(256), 0, s, d, marg);
 }
-void launch_assemble(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(16, d.B), dim3(256), 0, s, d); }
+void launch_assemble(const BatchDev &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d);
+  hipLaunchKernelGGL(k_assemble, dim3(ASM_WGS, d.B), dim3(ASM_THREADS), 0, s, d);
+}
 void launch_solve(const BatchDev &d, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {

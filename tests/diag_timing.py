@@ -20,6 +20,9 @@ print("   wave 0 own trailing work %.2f us" % ((t[20]-t[18])*0.01))
 
 print("k_schur WG(0,0): first prefetch %.2f us, first LDS stage %.2f us, all %d tiles %.2f us" % ((t[9]-t[8])*0.01, (t[10]-t[9])*0.01, int(t[12]), (t[11]-t[8])*0.01))
 print("k_schur WG(0,0) shader clock during the kernel: %.0f MHz" % ((t[14]-t[13]) / ((t[11]-t[8])*0.01)))
+an = [(6, 7, "k_visblock")]
+for i0, i1, nme in an:
+    print("k_assemble %-24s %8.2f us" % (nme, (t[i1] - t[i0]) * 0.01))
 mn = ["setup", "assemble A,b", "15x15 eig", "Schur (T, A', b')", "tail + meta", "k_marg_ldlt (incl. launch gap)"]
 for i, nme in enumerate(mn):
     print("k_marg %-20s %8.2f us" % (nme, (t[25 + i] - t[24 + i]) * 0.01))
