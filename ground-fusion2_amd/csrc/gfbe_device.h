@@ -31,6 +31,7 @@ enum {
   IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost
   WHEEL_PART = 22 * 22 + 22 + 2,
   MAX_IMU = 10, MAX_WHEEL = 10,
+  XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
   HC = 13                     // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
 };
 
@@ -155,6 +156,11 @@ struct BatchDev {
   double *schur_part;         // [B][NF][SCHUR_STRIDE]  sum over the landmarks of one start frame
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
+  // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
+  int rank, world;
+  double *xa, *xb, *xc;       // [B][world][XCHG] scalar exchange rows (own row written, the others zeroed, then sum all-reduce):
+                              //   xa: visual cost of the linearisation point; xb: landmark shares of the dogleg scalars;
+                              //   xc: candidate cost / step norms
   double *vis_H;              // [B][73][74]  visual block of the normal equations + gradient column (k_visblock)
   int *asm_tab;               // [ND (ND + 1) / 2][4]  window-independent assembly table (k_asm_table)
   double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble
@@ -192,6 +198,11 @@ void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_
 void launch_schur(const BatchDev &d, int marg, hipStream_t s);
 void launch_assemble(const BatchDev &d, hipStream_t s);
 void launch_asm_table(const BatchDev &d, hipStream_t s);
+void launch_xchg_gram(const BatchDev &d, hipStream_t s);
+void launch_xchg_cand(const BatchDev &d, hipStream_t s);
+void launch_lam_mask(const BatchDev &d, hipStream_t s);
+void launch_marginalize_partials(const BatchDev &d, hipStream_t s);
+void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s);
 void launch_solve(const BatchDev &d, hipStream_t s);
 void launch_lm_step(const BatchDev &d, hipStream_t s);
 void launch_step(const BatchDev &d, hipStream_t s);

@@ -50,6 +50,7 @@ struct gfbe_batch {
   std::vector<std::vector<int>> slot_of;   // per window: ABI landmark -> global slot
   std::vector<int> L;
   double algo_bytes_lin = 0.0;             // algorithmic bytes of one visual linearisation of the batch
+  size_t slab_n = 0;                       // doubles of the [H | g | E | eg | xa] slab
 };
 
 #define HIPCHK(ctx, call)                                                                        \
@@ -119,7 +120,9 @@ gfbe_status gfbe_set_stream(gfbe_ctx *c, void *s) {
 
 gfbe_status gfbe_set_allreduce(gfbe_ctx *c, gfbe_allreduce_fn fn, void *user, int32_t rank, int32_t world) {
   if (!c) return GFBE_BAD_INPUT;
-  c->allreduce = fn; c->allreduce_user = user; c->rank = rank; c->world = world < 1 ? 1 : world;
+  if (fn && (world < 1 || world > 64 || rank < 0 || rank >= world)) { c->err = "gfbe_set_allreduce: rank / world_size out of range"; return GFBE_BAD_INPUT; }
+  c->allreduce = fn; c->allreduce_user = user;
+  c->rank = fn ? rank : 0; c->world = fn ? world : 1;   // a null hook switches the landmark sharding off
   return GFBE_OK;
 }
 
@@ -436,7 +439,16 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   AL(prior_g, (size_t)B * (ND + 2));
   AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
   AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
-  AL(H, (size_t)B * ND * ND); AL(g, (size_t)B * ND); AL(E, (size_t)B * NV * NV); AL(eg, (size_t)B * NV);
+  // the partial reduced system [H | g | E | eg | xa] is one slab: a single all-reduce per linearisation when the
+  // landmarks are sharded over ranks
+  d.rank = c->rank; d.world = c->world;
+  {
+    const size_t nH = (size_t)B * ND * ND, ng = (size_t)B * ND, nE = (size_t)B * NV * NV, ne = (size_t)B * NV, nx = (size_t)B * d.world * XCHG;
+    AL(H, nH + ng + nE + ne + nx);
+    d.g = d.H + nH; d.E = d.g + ng; d.eg = d.E + nE; d.xa = d.eg + ne;
+    b->slab_n = nH + ng + nE + ne + nx;
+  }
+  AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
   AL(S, 1); AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
   AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
   AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
@@ -466,14 +478,21 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, bool first) {
   { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, c->stream); }
   { Timed t(c, "k_schur", 0); launch_schur(d, 0, c->stream); }
   { Timed t(c, "k_assemble", 0); launch_assemble(d, c->stream); }
+  if (d.world > 1) { Timed t(c, "allreduce_system", 0); c->allreduce(c->allreduce_user, d.H, (int64_t)b->slab_n, c->stream); }
   { Timed t(c, "k_solve", 0); launch_solve(d, c->stream); }
   { Timed t(c, "k_lm_step", 0); launch_lm_step(d, c->stream); }
+  if (d.world > 1) {
+    Timed t(c, "allreduce_scalars", 0);
+    launch_xchg_gram(d, c->stream);
+    c->allreduce(c->allreduce_user, d.xb, (int64_t)d.B * d.world * XCHG, c->stream);
+  }
 }
 
 extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t margin_flag) {
   if (!c || !b) return GFBE_BAD_INPUT;
   if (c->device < 0) return GFBE_NO_DEVICE;
   const BatchDev &d = b->d;
+  if (d.world > 1 && !c->allreduce) { c->err = "batch was uploaded for landmark sharding but the all-reduce hook is gone"; return GFBE_BAD_INPUT; }
   { Timed t(c, "k_reset", 0); launch_reset(d, c->stream); }
   const int iters = std::min(c->opt.max_num_iterations, 15);
   for (int it = 0; it < iters; it++) {
@@ -482,12 +501,29 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
     { Timed t(c, "k_candidate", 0); launch_candidate(d, c->stream); }
     { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, c->stream); }
     { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, c->stream); }
+    if (d.world > 1) {
+      Timed t(c, "allreduce_scalars", 0);
+      launch_xchg_cand(d, c->stream);
+      c->allreduce(c->allreduce_user, d.xc, (int64_t)d.B * d.world * XCHG, c->stream);
+    }
     { Timed t(c, "k_accept", 0); launch_accept(d, c->stream); }
   }
   { Timed t(c, "k_reanchor", 0); launch_reanchor(d, c->stream); }
   if (margin_flag != GFBE_MARGIN_NONE) {
     Timed t(c, "marginalize", 0);
-    launch_marginalize(d, margin_flag, c->stream);
+    if (d.world > 1 && margin_flag == GFBE_MARGIN_OLD) {
+      // the partials of the landmarks that start in frame 0 are summed over the ranks before k_marg reads them
+      launch_marginalize_partials(d, c->stream);
+      c->allreduce(c->allreduce_user, d.pair_part, (int64_t)d.B * NPAIR * VP_STRIDE, c->stream);
+      c->allreduce(c->allreduce_user, d.schur_part, (int64_t)d.B * NF * SCHUR_STRIDE, c->stream);
+      launch_marginalize_finish(d, margin_flag, c->stream);
+    } else {
+      launch_marginalize(d, margin_flag, c->stream);
+    }
+  }
+  if (d.world > 1) {   // every rank ends with all inverse depths: owners contribute theirs, the others zeros
+    launch_lam_mask(d, c->stream);
+    c->allreduce(c->allreduce_user, d.lam, (int64_t)2 * d.tot_lm, c->stream);
   }
   HIPCHK(c, hipGetLastError());
   return GFBE_OK;

@@ -65,6 +65,9 @@ __device__ __forceinline__ double block_max(double v, double *scratch) {
   return r;
 }
 
+// landmark sharding: tile t of a window is evaluated by rank t % world (gfbe_set_allreduce)
+#define TILE_OWNED(d, tile) ((d).world == 1 || (tile) % (d).world == (d).rank)
+
 __device__ __forceinline__ double clamp_diag(double x) { return fmin(fmax(x, GF_MIN_DIAG), GF_MAX_DIAG); }
 
 // =============================================================================================
@@ -146,7 +149,7 @@ template <int MODE>
 __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_records) {
   const int w = blockIdx.y, tile = blockIdx.x;
   const WinDesc &ds = d.desc[w];
-  if (tile >= ds.n_tiles) return;
+  if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
   if (MODE == 0 && (c.done || c.reuse)) return;
   if (MODE == 1 && (c.done || !c.have_step)) return;
@@ -519,10 +522,13 @@ __global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
   const bool stamp_wg = (w == 0 && s == 0 && t == 0 && !marg);
   double *stamp = d.timing + 8;
   if (stamp_wg) { stamp[0] = (double)wall_clock64(); stamp[5] = (double)clock64(); }
-  prefetch(tb);
-  for (int tile = tb; tile < te; tile++) {
+  const int tstep = d.world;
+  const int tfirst = tb + ((d.rank - tb) % d.world + d.world) % d.world;   // first tile of this rank (world 1: tb)
+  if (tfirst >= te) return;
+  prefetch(tfirst);
+  for (int tile = tfirst; tile < te; tile += tstep) {
     __syncthreads();
-    if (stamp_wg && tile == tb) stamp[1] = (double)wall_clock64();
+    if (stamp_wg && tile == tfirst) stamp[1] = (double)wall_clock64();
     {
       const int slot = ds.lm_off + tile * LM_TILE + l;
       const bool valid = (pinfo >> 24) & 1;
@@ -564,8 +570,8 @@ __global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
       }
     }
     __syncthreads();
-    if (stamp_wg && tile == tb) stamp[2] = (double)wall_clock64();
-    if (tile + 1 < te) prefetch(tile + 1);
+    if (stamp_wg && tile == tfirst) stamp[2] = (double)wall_clock64();
+    if (tile + tstep < te) prefetch(tile + tstep);
 #define SCHUR_SLOT(Q, ACC)                                                                          \
     if (pI[Q] >= 0) {                                                                               \
       const double *pa = hs + 16 * pI[Q] + lr + lk * HS_LD, *pb = hs + 16 * pJ[Q] + lr + lk * HS_LD; \
@@ -821,6 +827,14 @@ __global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
   }
   double *out = d.vis_H + (size_t)w * NV * V_LD;
   for (int q = t; q < NV * V_LD; q += VB_THREADS) out[q] = V[q];
+  // robustified visual cost of this linearisation point (this rank's tiles; lanes stride the tiles, fixed tree order)
+  if (t < 64) {
+    double cs = 0.0;
+    for (int q = t; q < ds.n_tiles; q += 64) cs += d.tile_cost[(size_t)w * d.max_tiles + q];
+    cs = wave_sum(cs);
+    for (int r = 0; r < d.world; r++)
+      if (t < XCHG) d.xa[((size_t)w * d.world + r) * XCHG + t] = (r == d.rank && t == 0) ? cs : 0.0;
+  }
   ASTAMP(7);
 #undef ASTAMP
 }
@@ -840,6 +854,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   if (t == 0) { tb.prior_n = ds.prior_n; tb.n_wheel = ds.n_wheel; }
   __syncthreads();
   const int gt = blockIdx.x * ASM_THREADS + t, gn = ASM_WGS * ASM_THREADS;
+  const bool dense_here = (d.rank == 0);   // landmark sharding: the inertial / wheel / prior factors are added once (rank 0)
   double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
   const int4 *tab = (const int4 *)d.asm_tab;
@@ -855,7 +870,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
     for (int u = 0; u < 4; u++) {
       const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
       on[u] = ent[u].x >= 0 && tb.act[a] && tb.act[b];
-      const int y = on[u] ? ent[u].y : 0, z = (on[u] && tb.n_wheel > 0) ? ent[u].z : 0;
+      const int y = (on[u] && dense_here) ? ent[u].y : 0, z = (on[u] && dense_here && tb.n_wheel > 0) ? ent[u].z : 0;
       const int i0 = (y & 15) - 1, i1 = ((y >> 16) & 15) - 1, j0 = (z & 15) - 1, j1 = ((z >> 16) & 15) - 1;
       const int q0 = i0 >= 0 ? tb.imu_of_frame[i0] : -1, q1 = i1 >= 0 ? tb.imu_of_frame[i1] : -1;
       const int r0 = j0 >= 0 ? tb.wheel_of_frame[j0] : -1, r1 = j1 >= 0 ? tb.wheel_of_frame[j1] : -1;
@@ -863,7 +878,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
       p[u][1] = q1 >= 0 ? imu_w + q1 * IMU_PART + ((y >> 20) & 1023) : Z;
       p[u][2] = r0 >= 0 ? wheel_w + r0 * WHEEL_PART + ((z >> 4) & 1023) : Z;
       p[u][3] = r1 >= 0 ? wheel_w + r1 * WHEEL_PART + ((z >> 20) & 1023) : Z;
-      const int pa = on[u] && tb.prior_n > 0 ? tb.prior_map[b] : -1, pb = on[u] && tb.prior_n > 0 ? tb.prior_map[a] : -1;
+      const int pa = on[u] && dense_here && tb.prior_n > 0 ? tb.prior_map[b] : -1, pb = on[u] && dense_here && tb.prior_n > 0 ? tb.prior_map[a] : -1;
       p[u][4] = (pa >= 0 && pb >= 0) ? prior_w + (size_t)pa * tb.prior_n + pb : Z;
       p[u][5] = (on[u] && a < NV) ? vis_w + b * V_LD + a : Z;
     }
@@ -875,7 +890,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
       if (ent[u].x < 0) continue;
       const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
       double x = v[u];
-      if (b >= T_EXW && on[u] && tb.n_wheel > 0) {
+      if (b >= T_EXW && on[u] && dense_here && tb.n_wheel > 0) {
         // wheel extrinsic / intrinsic / td_wheel block: every wheel factor contributes (10 loads in flight)
         const int off = wheel_loc(b, 0) * 22 + wheel_loc(a, 0);   // global dims: the column does not depend on the factor
         double ws = 0.0;
@@ -900,7 +915,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   }
   for (int a = gt; a < ND; a += gn) {
     double v = 0.0;
-    if (tb.act[a]) { v = gather_g_dense(d, tb, Z, w, a); if (a < NV) v += vis_w[a * V_LD + NV]; }
+    if (tb.act[a]) { v = dense_here ? gather_g_dense(d, tb, Z, w, a) : 0.0; if (a < NV) v += vis_w[a * V_LD + NV]; }
     g[a] = v;
     if (a < NV) eg[a] = tb.act[a] ? gather_E11(d, Z, w, a, NV) : 0.0;
   }
@@ -1034,7 +1049,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
   }
   if (first && t == 0) {   // total cost of the first linearisation point (fixed order)
     double cost = 0.0;
-    for (int q = 0; q < ds.n_tiles; q++) cost += d.tile_cost[(size_t)w * d.max_tiles + q];
+    for (int r = 0; r < d.world; r++) cost += d.xa[((size_t)w * d.world + r) * XCHG];   // visual cost (k_visblock; summed over the ranks)
     for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
     for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
     cost += d.prior_g[(size_t)w * (ND + 2) + ND];
@@ -1073,7 +1088,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
   double mu = c.mu;
   bool solved = false, e_valid = true;
   while (mu < GF_MAX_MU) {
-    if (!e_valid) rebuild_E(d, ds, w, mu);
+    if (!e_valid) {
+      if (d.world > 1) break;   // landmark sharding: E would need another all-reduce; reported as a failed linear solve
+      rebuild_E(d, ds, w, mu);
+    }
     // ---- augmented, scaled, regularised, Schur-reduced system in 16x16 LDS tiles (lower triangle of tiles)
     //      [ S    rhs ]   S = s H s + mu D^2 - s E s   rhs = gt - s eg
     //      [ rhs' big ]
@@ -1251,7 +1269,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
 __global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
   const int w = blockIdx.y, tile = blockIdx.x;
   const WinDesc &ds = d.desc[w];
-  if (tile >= ds.n_tiles) return;
+  if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   __shared__ double sy[NV], sv[NV];
@@ -1308,22 +1326,73 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
 // =============================================================================================
 // k_step: scalar trust-region logic of one iteration (one thread per window).
 // =============================================================================================
+// landmark shares of the dogleg scalars: the tiles' partials (k_lm_step), lanes stride the tiles, fixed tree order.
+// p = [G2, N2, gy, vHv, vHy, yHy, max |gradient|, |x|^2]; every lane returns the totals.
+__device__ __forceinline__ void tile_gram_sum(const BatchDev &d, const WinDesc &ds, int w, int lane, double p[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) p[k] = 0.0;
+  for (int q = lane; q < ds.n_tiles; q += 64) {
+    const double *tg = d.tile_gram + ((size_t)w * d.max_tiles + q) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) p[k] = (k == 6) ? fmax(p[k], tg[k]) : p[k] + tg[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double other = __shfl_xor(p[k], o, 64); p[k] = (k == 6) ? fmax(p[k], other) : p[k] + other; }
+  }
+}
+// landmark sharding: this rank's row of the exchange blocks (the other rows zeroed), all-reduced by the host loop
+__global__ __launch_bounds__(64) void k_xchg_gram(BatchDev d) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  double p[8];
+  tile_gram_sum(d, d.desc[w], w, lane, p);
+  for (int r = 0; r < d.world; r++)
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (lane == k) d.xb[((size_t)w * d.world + r) * XCHG + k] = (r == d.rank) ? p[k] : 0.0;
+}
+__device__ __forceinline__ void tile_cand_sum(const BatchDev &d, const WinDesc &ds, int w, int lane, double &cand, double &d2, double &n2) {
+  cand = 0.0; d2 = 0.0; n2 = 0.0;
+  for (int q = lane; q < ds.n_tiles; q += 64) {
+    const double *o = d.tile_cand + ((size_t)w * d.max_tiles + q) * 4;
+    cand += o[0]; d2 += o[1]; n2 += o[2];
+  }
+}
+__global__ __launch_bounds__(64) void k_xchg_cand(BatchDev d) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  double cand, d2, n2;
+  tile_cand_sum(d, d.desc[w], w, lane, cand, d2, n2);
+  cand = wave_sum(cand); d2 = wave_sum(d2); n2 = wave_sum(n2);
+  for (int r = 0; r < d.world; r++)
+    if (lane < XCHG) d.xc[((size_t)w * d.world + r) * XCHG + lane] = (r != d.rank) ? 0.0 : (lane == 0 ? cand : (lane == 1 ? d2 : (lane == 2 ? n2 : 0.0)));
+}
+// landmark sharding: inverse depths of the other ranks' tiles are zeroed before the final sum all-reduce
+__global__ __launch_bounds__(LM_TILE) void k_lam_mask(BatchDev d) {
+  const int w = blockIdx.y, tile = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  if (tile >= ds.n_tiles || TILE_OWNED(d, tile)) return;
+  const int slot = ds.lm_off + tile * LM_TILE + threadIdx.x;
+  d.lam[slot] = 0.0;
+  d.lam[(size_t)d.tot_lm + slot] = 0.0;
+}
+
 __global__ __launch_bounds__(64) void k_step(BatchDev d) {
   const int w = blockIdx.x, lane = threadIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (c.done) return;
   if (c.have_step == 2) {   // fresh linearisation: fold in the landmark shares (lanes stride the tiles; fixed tree order)
-    double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = lane; q < ds.n_tiles; q += 64) {
-      const double *tg = d.tile_gram + ((size_t)w * d.max_tiles + q) * 8;
+    double p[8];
+    if (d.world == 1) tile_gram_sum(d, ds, w, lane, p);
+    else {   // landmark sharding: the ranks' shares (k_xchg_gram + all-reduce), combined in rank order
 #pragma unroll
-      for (int k = 0; k < 8; k++) p[k] = (k == 6) ? fmax(p[k], tg[k]) : p[k] + tg[k];
-    }
+      for (int k = 0; k < 8; k++) p[k] = 0.0;
+      for (int r = 0; r < d.world; r++) {
+        const double *xr = d.xb + ((size_t)w * d.world + r) * XCHG;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { const double other = __shfl_xor(p[k], o, 64); p[k] = (k == 6) ? fmax(p[k], other) : p[k] + other; }
+        for (int k = 0; k < 8; k++) p[k] = (k == 6) ? fmax(p[k], xr[k]) : p[k] + xr[k];
+      }
     }
     if (lane == 0) {
       c.G2 += p[0]; c.N2 += p[1]; c.gy += p[2]; c.vHv += p[3]; c.vHy += p[4]; c.yHy += p[5];
@@ -1382,7 +1451,7 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
   const size_t TL = d.tot_lm;
   if ((int)blockIdx.x < d.max_tiles) {
     const int tile = blockIdx.x;
-    if (tile >= ds.n_tiles) return;
+    if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
     const int slot = ds.lm_off + tile * LM_TILE + t;
     const int info = d.lm_info[slot];
     const bool valid = (info >> 24) & 1;
@@ -1440,9 +1509,10 @@ __global__ __launch_bounds__(64) void k_accept(BatchDev d) {
   WinCtl &c = d.ctl[w];
   if (c.done || !c.have_step) return;
   double cand = 0.0, d2 = 0.0, n2 = 0.0;
-  for (int q = lane; q < ds.n_tiles; q += 64) {
-    const double *o = d.tile_cand + ((size_t)w * d.max_tiles + q) * 4;
-    cand += o[0]; d2 += o[1]; n2 += o[2];
+  if (d.world == 1) tile_cand_sum(d, ds, w, lane, cand, d2, n2);
+  else if (lane < d.world) {   // landmark sharding: the ranks' sums (k_xchg_cand + all-reduce)
+    const double *xr = d.xc + ((size_t)w * d.world + lane) * XCHG;
+    cand = xr[0]; d2 = xr[1]; n2 = xr[2];
   }
   if (lane < ds.n_imu) cand += d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 1];
   if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 1];
@@ -1543,6 +1613,11 @@ void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_
 void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
   if (d.max_tiles == 0) return;
   hipLaunchKernelGGL(k_schur, dim3(marg ? 1 : NF, d.B), dim3(256), 0, s, d, marg);
+}
+void launch_xchg_gram(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_gram, dim3(d.B), dim3(64), 0, s, d); }
+void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_cand, dim3(d.B), dim3(64), 0, s, d); }
+void launch_lam_mask(const BatchDev &d, hipStream_t s) {
+  if (d.max_tiles > 0) hipLaunchKernelGGL(k_lam_mask, dim3(d.max_tiles, d.B), dim3(LM_TILE), 0, s, d);
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
   hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d);

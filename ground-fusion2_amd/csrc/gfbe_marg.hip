@@ -507,15 +507,20 @@ __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   if (threadIdx.x == 0) { meta[3] = -rank; if (w == 0) stamp[6] = (double)wall_clock64(); }
 }
 
+// MARGIN_OLD: the partials of the marginalisation set at the re-anchored state (visual factors of the landmarks
+// starting in frame 0, the inertial / wheel factor of frame 0, their Schur partial)
+void launch_marginalize_partials(const BatchDev &d, hipStream_t s) {
+  launch_vis(d, 2, s);
+  launch_pair(d, 1, s);
+  launch_dense_factors(d, 2, 0, s);
+  launch_schur(d, 1, s);
+}
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {
-  if (flag == GFBE_MARGIN_OLD) {
-    launch_vis(d, 2, s);
-    launch_pair(d, 1, s);
-    launch_dense_factors(d, 2, 0, s);
-    launch_schur(d, 1, s);
-  } else {
-    launch_dense_factors(d, 3, 0, s);
-  }
+  if (flag == GFBE_MARGIN_OLD) launch_marginalize_partials(d, s);
+  else launch_dense_factors(d, 3, 0, s);
+  launch_marginalize_finish(d, flag, s);
+}
+void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s) {
   static bool attr_set = false;
   const size_t lds = sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N;
   if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }

@@ -4,9 +4,12 @@ RCCL on ROCm; "gloo" in the CPU tests).
 Primary mode — *replica / window sharding*: windows are independent units, rank r owns windows
 r, r+world, ...; no data-path collective, only the timing barrier + max-over-ranks.
 
-Secondary mode — *landmark sharding of one window*: each rank linearises its share of the landmarks,
-eliminates them locally and contributes a partial reduced system [S | g | cost]; ONE sum all-reduce
-per linearisation (182*182 + 182 + 1 doubles) makes every rank hold the full reduced system.
+Secondary mode — *landmark sharding of one window* (BASELINE.json configs[2]): every rank uploads the
+same window, evaluates the landmark tiles t with t % world == rank, eliminates them locally and
+contributes partial normal equations; libgfbe calls the hook installed with gfbe_set_allreduce to sum
+them in place: one all-reduce of [H | g | E | eg | cost] (~38.7k doubles per window) per linearisation
+plus two 8-doubles-per-rank scalar exchanges per trust-region iteration. The dense solve is then
+redundant (and bit-identical) on every rank. `torch_allreduce_hook` is that hook over torch.distributed.
 """
 import numpy as np
 
@@ -59,3 +62,30 @@ def reduced_system(lin, mu=0.0):
     H[:73, :73] -= (hp * w[:, None]).T @ hp
     g[:73] -= hp.T @ (w * lin["gl"])
     return np.concatenate([H.ravel(), g, [lin["cost"]]])
+
+
+class _DevicePtr:
+    """A device buffer of n float64 handed over by libgfbe, viewed through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def torch_allreduce_hook(group=None):
+    """In-place sum all-reduce of a libgfbe device buffer over torch.distributed — the callable for
+    Backend.set_allreduce(fn, rank, world). backend "nccl" (= RCCL over xGMI) reduces the device buffer
+    directly on the solver's stream; "gloo" (tests: several ranks sharing one GPU) stages through the host."""
+    import torch
+    import torch.distributed as dist
+
+    def hook(ptr, n, stream):
+        t = torch.as_tensor(_DevicePtr(ptr, n), device="cuda")
+        st = torch.cuda.ExternalStream(int(stream)) if stream else torch.cuda.default_stream()
+        with torch.cuda.stream(st):
+            if dist.get_backend(group) == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                t.copy_(h)
+    return hook

@@ -94,6 +94,13 @@ def test_solve_cfg2_wheel_prior_2k(be, oracle):
     assert np.abs(bg - bw).max() < 1e-6 * max(np.abs(bw).max(), 1.0)
 
 
+def test_solve_cfg3_10k_landmarks(be, oracle):
+    """BASELINE.json configs[2] on one GPU: 10-kf VI-wheel window, 10 000 landmarks (K ~ 47k factors,
+    157 landmark tiles), with a marginalisation prior."""
+    _, snap = window_with_prior(oracle, 20250710, 10000)
+    check_solve(be, oracle, snap, abi.MARGIN_OLD)
+
+
 def test_prior_square_root_modes(oracle):
     """marg_sqrt = 0 (eigen-decomposition, the reference's construction) and 1 (pivoted LDL^T, default)
     give the same information J0^T J0, J0^T r0 — 1e-9 relative to max|A'| — and both are valid square
