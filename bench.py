@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows (tiled to --batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-landmarks", action="store_true",
+                    help="N > 1 only: every rank holds the SAME windows and evaluates its share of the landmark tiles; the partial "
+                         "normal equations are summed with RCCL all-reduces (BASELINE configs[2]; strong scaling of one solve)")
     args = ap.parse_args()
 
     import torch
@@ -51,12 +54,15 @@ def main():
     torch.cuda.set_device(local_rank)
     be = gf.Backend(device=local_rank)          # raises if the HIP extension / GPU is missing
     be.set_stream(torch.cuda.current_stream().cuda_stream)
+    shard = args.shard_landmarks and world > 1
+    if shard:
+        be.set_allreduce(gf.dist.torch_allreduce_hook(), rank, world)
 
     # ---- synthetic input (untimed). The prior of each window comes from the back end itself:
     # window k of the run is solved + marginalised (MARGIN_OLD) on the GPU, its prior and shifted
     # state seed window k+1 — exactly what consecutive optimization() calls do.
     t0 = time.time()
-    scns = [synth.Scenario(seed=20250708 + 2 + 100 * u + 7919 * rank, n_landmarks=args.landmarks, use_wheel=True)
+    scns = [synth.Scenario(seed=20250708 + 2 + 100 * u + (0 if shard else 7919 * rank), n_landmarks=args.landmarks, use_wheel=True)
             for u in range(args.unique)]
     firsts = be.solve_batch([s.window(0) for s in scns], abi.MARGIN_OLD)
     snaps = []
@@ -88,6 +94,8 @@ def main():
     elapsed = time.perf_counter() - t_start
     # whole-job aggregate: SUM of solves over ranks / MAX of elapsed over ranks
     solves, elapsed = gf.dist.aggregate_throughput(args.batch * args.steps, elapsed, dist if world > 1 else None)
+    if shard:
+        solves //= world          # every rank worked on the same windows
     value = solves / elapsed
 
     # ---- correctness of what was timed (cheap): every window converged to the same cost as window 0 of its kind
@@ -96,7 +104,8 @@ def main():
     iters = [r["summary"]["iterations"] for r in res[: args.unique]]
 
     out = None
-    if rank == 0:
+    prof = None
+    if rank == 0 or shard:   # (landmark sharding: the all-reduces need every rank to take the same steps)
         # ---- roofline of the dominant kernel, measured live with hipEvents on the launch stream
         be.profile_enable(True)
         be.profile_reset()
@@ -106,6 +115,7 @@ def main():
         torch.cuda.synchronize()
         prof = {p["name"]: p for p in be.profile()}
         be.profile_enable(False)
+    if rank == 0:
         tot_ms = sum(p["total_ms"] for p in prof.values())
         dom = max((p for p in prof.values()), key=lambda p: p["total_ms"])
         lin0 = prof.get("k_vis_lin_iter0", prof.get("k_vis_lin"))
@@ -126,16 +136,18 @@ def main():
                     "time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}}
 
         # ---- single-window latency (B = 1), same workload
-        one = be.batch_upload(batch_snaps[:1])
-        for _ in range(3):
-            one.solve(abi.MARGIN_OLD)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            one.solve(abi.MARGIN_OLD)
-        torch.cuda.synchronize()
-        single_ms = (time.perf_counter() - t1) / 10 * 1e3
-        one.free()
+        single_ms = None
+        if not shard:
+            one = be.batch_upload(batch_snaps[:1])
+            for _ in range(3):
+                one.solve(abi.MARGIN_OLD)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                one.solve(abi.MARGIN_OLD)
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - t1) / 10 * 1e3
+            one.free()
 
         # ---- CPU baseline: the oracle (Ceres stand-in "port", 1 core) on the same windows, bounded sample
         cpu = None
@@ -159,21 +171,49 @@ def main():
                              "oracle/ C++ restatement, -O3 -march=native, 1 thread like the reference's ceres::Solve" %
                              (n_done, args.landmarks, t_cpu),
                    "ms_per_solve": 1e3 * t_cpu / n_done}
+            # the same port on every host core (one window per thread; ctypes drops the GIL): SURVEY.md §8d (b)
+            import threading
+            ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            counts = [0] * ncore
+            deadline = time.perf_counter() + min(args.cpu_seconds, 10.0)
+            import ctypes as C
+            fsolve = orc._fn("solve_window")
+            fsolve.restype = abi.c_i
+            def worker(k):   # the bare C call in the loop: no Python-side result conversion under the GIL
+                hs = [abi.WindowHolder(s) for s in snaps]
+                st, pr, sm = abi.State(), abi.PriorHolder(), abi.Summary()
+                feat = np.zeros(max(h.n_feature for h in hs))
+                i = k
+                while time.perf_counter() < deadline:
+                    fsolve(orc.head, C.byref(hs[i % len(hs)].c), int(abi.MARGIN_OLD), C.byref(st), abi._pd(feat), C.byref(pr.c), C.byref(sm))
+                    counts[k] += 1
+                    i += 1
+            t_all = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(ncore)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            t_all = time.perf_counter() - t_all
+            cpu["all_cores"] = {"value": sum(counts) / t_all, "unit": "solves/s", "cores": ncore,
+                                "sample": "%d solves on %d threads in %.1f s" % (sum(counts), ncore, t_all)}
         out = {
             "metric": "sliding-window solves/sec (10-kf, 2k landmarks)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 10-keyframe VI-wheel window, %d landmarks (K=%d visual factors avg), "
                                    "marginalisation prior n=%d, full optimization() = <=8 dogleg iterations + re-anchor + MARGIN_OLD" %
                                    (args.landmarks, int(np.mean(K_per)), snaps[0]["prior"]["n"]),
-                       "windows_per_gpu": args.batch, "unique_windows": args.unique, "parallelism": "windows sharded over %d rank(s), no collective" % world},
+                       "windows_per_gpu": args.batch, "unique_windows": args.unique, "parallelism": ("landmark tiles of every window sharded over %d ranks, RCCL all-reduce of the partial normal equations" % world) if shard
+                                      else "windows sharded over %d rank(s), no collective" % world},
             "roofline": roofline, "cpu_baseline": cpu,
-            "single_window_ms": single_ms, "single_window_solves_per_s": 1e3 / single_ms,
+            "single_window_ms": single_ms, "single_window_solves_per_s": (1e3 / single_ms) if single_ms else None,
             "iterations": iters, "final_cost": final_costs, "setup_s": setup_s,
         }
         if cpu:
             out["speedup_vs_cpu_1core"] = value / cpu["value"]
-            out["single_window_speedup_vs_cpu_1core"] = (1e3 / single_ms) / cpu["value"]
+            if single_ms:
+                out["single_window_speedup_vs_cpu_1core"] = (1e3 / single_ms) / cpu["value"]
     batch.free()
     if world > 1:
         dist.barrier()

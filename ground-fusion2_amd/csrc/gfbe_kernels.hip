@@ -188,12 +188,22 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
   double hC[HC], Hll = 0.0, gl = 0.0;
 #pragma unroll
   for (int q = 0; q < HC; q++) hC[q] = 0.0;
+  // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length are zero in memory)
+  double nob[5];
+  {
+    const double *ob = d.lm_obs + slot;
+#pragma unroll
+    for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
+  }
   for (int k = 0; k < mmax; k++) {
     double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
+    const double pjx = nob[0], pjy = nob[1], vjx = nob[2], vjy = nob[3], tdj = nob[4];
+    if (k + 1 < mmax) {
+      const double *ob = d.lm_obs + (size_t)(k + 1) * 5 * TL + slot;
+#pragma unroll
+      for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
+    }
     if (k < m) {
-      const double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
-      double pjx, pjy, vjx, vjy, tdj;
-      pjx = ob[0]; pjy = ob[TL]; vjx = ob[2 * TL]; vjy = ob[3 * TL]; tdj = ob[4 * TL];
       if (GFBE_ABLATE == 4 && MODE == 0) {
 #pragma unroll
         for (int q = 0; q < 12; q++) { Ji[q] = pjx + q; Jj[q] = pjy * q; Je[q] = vjx - q; }
@@ -340,7 +350,7 @@ __device__ __forceinline__ int pair_tri(int a, int b) {
 // mode 0 linearise at current; 1 candidate cost; 2 MARGIN_OLD set at xout (frame-0 IMU/wheel + prior);
 // 3 MARGIN_SECOND_NEW set at xout (prior only).
 // =============================================================================================
-__global__ __launch_bounds__(64) void k_dense(BatchDev d, int mode, int debug_out) {
+__global__ __launch_bounds__(64, 2) void k_dense(BatchDev d, int mode, int debug_out) {
   const int w = blockIdx.y, f = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
@@ -1096,40 +1106,57 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     //      [ S    rhs ]   S = s H s + mu D^2 - s E s   rhs = gt - s eg
     //      [ rhs' big ]
     const int ntile_all = nt * (nt + 1) / 2;
-    for (int te = t >> 8; te < ntile_all; te += SOLVE_THREADS >> 8) {
+    // scaling and right-hand side staged in LDS (ys is free until the back-substitution)
+    for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0); }
+    __syncthreads();
+    for (int te0 = t >> 8; te0 < ntile_all; te0 += 4 * (SOLVE_THREADS >> 8)) {   // four tiles per thread group in flight
+      const int r = (t & 255) >> 4, cc = t & 15;
+      double hv[4], ev[4];
+      int aa[4], bb[4], kind[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int te = te0 + u * (SOLVE_THREADS >> 8);
         int I = 0, J = te;
         while (J > I) { J -= I + 1; I++; }
-        double *T = smem + (size_t)te * (TB * TB);
-        const int r = (t & 255) >> 4, cc = t & 15;
         const int ia = I * TB + r, ib = J * TB + cc;
-        double v;
-        if (ia < n && ib < n) {
-          const int a = perm[ia], b = perm[ib];
-          v = H[(size_t)a * ND + b];
-          if (a < NV && b < NV) v -= E[a * NV + b];
-          v *= gsp[a] * gsp[b];
-          if (a == b) v += mu * gDp[a] * gDp[a];
-        } else if (ia == n && ib < n) {
-          const int b = perm[ib];
-          v = ggts[b] - (b < NV ? gsp[b] * eg[b] : 0.0);
-        } else if (ib == n && ia < n) {
-          const int a = perm[ia];
-          v = ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0);
-        } else {
-          v = (ia == ib) ? (ia == n ? 1e200 : 1.0) : 0.0;
+        kind[u] = 0; aa[u] = 0; bb[u] = 0; hv[u] = 0.0; ev[u] = 0.0;
+        if (te < ntile_all) {
+          if (ia < n && ib < n) {
+            const int a = perm[ia], b = perm[ib];
+            aa[u] = a; bb[u] = b; kind[u] = 1;
+            hv[u] = H[(size_t)a * ND + b];
+            if (a < NV && b < NV) ev[u] = E[a * NV + b];
+          } else if (ia == n && ib < n) { bb[u] = perm[ib]; kind[u] = 2; }
+          else if (ib == n && ia < n) { bb[u] = perm[ia]; kind[u] = 2; }
+          else kind[u] = (ia == ib) ? (ia == n ? 4 : 3) : 5;
         }
-        T[tsw(r, cc)] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int te = te0 + u * (SOLVE_THREADS >> 8);
+        if (te >= ntile_all) continue;
+        double v;
+        if (kind[u] == 1) {
+          v = hv[u];
+          if (aa[u] < NV && bb[u] < NV) v -= ev[u];
+          v *= ys[aa[u]] * ys[bb[u]];
+          if (aa[u] == bb[u]) { const double dp = gDp[aa[u]]; v += mu * dp * dp; }
+        } else if (kind[u] == 2) v = ys[ND + bb[u]];
+        else v = kind[u] == 4 ? 1e200 : (kind[u] == 3 ? 1.0 : 0.0);
+        smem[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
+      }
     }
     if (t == 0) flag = 0;
     __syncthreads();
     STAMP(2);
     // ---- blocked right-looking Cholesky: diagonal tile (1 wave) -> panel solve (thread per row) ->
     //      trailing update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
+    // The diagonal tile of panel P + 1 is factorised by the wave that has just updated it (wave 0 takes it first
+    // in the trailing update), while the other waves are still updating: only panel 0 pays for its own diagonal tile.
+    if (wave == 0) { if (!chol_tile16(smem + (size_t)tile_idx(0, 0) * (TB * TB), lane) && lane == 0) flag = 1; }
+    __syncthreads();
     for (int P = 0; P < nt; P++) {
       double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
-      if (P == 0) STAMP(16);
-      if (wave == 0) { if (!chol_tile16(Tpp, lane) && lane == 0) flag = 1; }
-      __syncthreads();
       if (P == 0) STAMP(17);
       if (flag) break;
       const int rows = (nt - 1 - P) * TB;
@@ -1169,6 +1196,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
         for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; q++) C[tsw(lk + 4 * q, lr)] = acc[q];
+        if (e == 0) {   // tile (P+1, P+1) is final now: factorise it here (wave 0), ahead of the block barrier
+          __threadfence_block();
+          __builtin_amdgcn_wave_barrier();
+          if (!chol_tile16(C, lane) && lane == 0) flag = 1;
+        }
       }
       if (P == 0) STAMP(20);
       __syncthreads();
