@@ -937,6 +937,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 // the dogleg scalars. (Ceres 1.14 DoglegStrategy::ComputeStep / ComputeGaussNewtonStep.)
 // =============================================================================================
 #define SOLVE_THREADS 1024
+#define BUILD_UNROLL 4
 #define TB 16                          // tile edge of the blocked Cholesky
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
@@ -997,7 +998,7 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {   // src is wa
 // In-place lower Cholesky of one 16 x 16 LDS tile by a single wave: lane i < 16 keeps row i in
 // registers, column entries travel through v_readlane. On exit the diagonal holds 1 / L[k][k]
 // (the panel solve and the substitutions multiply by it). Returns false on a bad pivot.
-__device__ __forceinline__ bool chol_tile16(double *T, int lane) {
+__device__ __noinline__ bool chol_tile16(double *T, int lane) {
   double row[TB];
   const int li = lane & 15;
 #pragma unroll
@@ -1109,12 +1110,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     // scaling and right-hand side staged in LDS (ys is free until the back-substitution)
     for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0); }
     __syncthreads();
-    for (int te0 = t >> 8; te0 < ntile_all; te0 += 4 * (SOLVE_THREADS >> 8)) {   // four tiles per thread group in flight
+    for (int te0 = t >> 8; te0 < ntile_all; te0 += BUILD_UNROLL * (SOLVE_THREADS >> 8)) {   // BUILD_UNROLL tiles per thread group in flight
       const int r = (t & 255) >> 4, cc = t & 15;
-      double hv[4], ev[4];
-      int aa[4], bb[4], kind[4];
+      double hv[BUILD_UNROLL], ev[BUILD_UNROLL];
+      int aa[BUILD_UNROLL], bb[BUILD_UNROLL], kind[BUILD_UNROLL];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < BUILD_UNROLL; u++) {
         const int te = te0 + u * (SOLVE_THREADS >> 8);
         int I = 0, J = te;
         while (J > I) { J -= I + 1; I++; }
@@ -1132,7 +1133,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < BUILD_UNROLL; u++) {
         const int te = te0 + u * (SOLVE_THREADS >> 8);
         if (te >= ntile_all) continue;
         double v;
