@@ -31,6 +31,7 @@ enum {
   IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost
   WHEEL_PART = 22 * 22 + 22 + 2,
   MAX_IMU = 10, MAX_WHEEL = 10,
+  DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
   HC = 13                     // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
 };
@@ -162,6 +163,7 @@ struct BatchDev {
                               //   xa: visual cost of the linearisation point; xb: landmark shares of the dogleg scalars;
                               //   xc: candidate cost / step norms
   double *vis_H;              // [B][73][74]  visual block of the normal equations + gradient column (k_visblock)
+  double *raw_imu, *raw_wheel; // [MAX_IMU][15 + 450][B], [MAX_WHEEL][6 + 132][B]  un-whitened residuals / Jacobians (k_dense_raw), window-minor
   int *asm_tab;               // [ND (ND + 1) / 2][4]  window-independent assembly table (k_asm_table)
   double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble
   double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
@@ -196,6 +198,7 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records = 
 void launch_pair(const BatchDev &d, int marg, hipStream_t s);
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s);
+void launch_visblock(const BatchDev &d, hipStream_t s);
 void launch_assemble(const BatchDev &d, hipStream_t s);
 void launch_asm_table(const BatchDev &d, hipStream_t s);
 void launch_xchg_gram(const BatchDev &d, hipStream_t s);

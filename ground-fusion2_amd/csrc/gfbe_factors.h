@@ -252,8 +252,9 @@ GF_HD int sqrt_info_from_cov(const double *cov, int n, double *out, double *work
   return 0;
 }
 
-GF_HD void put3(double *A, int lda, int r0, int c0, const mat3 &B) {
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[(r0 + i) * lda + c0 + j] = B(i, j);
+// es = element stride of the destination (1: dense row-major; B: the window-minor layout of k_dense_raw)
+GF_HD void put3(double *A, int lda, int r0, int c0, const mat3 &B, size_t es = 1) {
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[(size_t)((r0 + i) * lda + c0 + j) * es] = B(i, j);
 }
 GF_HD mat3 get3(const double *A, int lda, int r0, int c0) {
   mat3 B; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) B(i, j) = A[(r0 + i) * lda + c0 + j]; return B;
@@ -264,7 +265,7 @@ GF_HD mat3 get3(const double *A, int lda, int r0, int c0) {
 // pose_i(6) sb_i(9) pose_j(6) sb_j(9). Whitening by sqrt_info is done by the caller (in parallel).
 // ---------------------------------------------------------------------------------------------
 GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose_i, const double *sb_i,
-                   const double *pose_j, const double *sb_j, double *raw, double *Jraw) {
+                   const double *pose_j, const double *sb_j, double *raw, double *Jraw, size_t es = 1) {
   const vec3 Pi = ld3(pose_i), Pj = ld3(pose_j);
   const quat Qi = ldq(pose_i + 3), Qj = ldq(pose_j + 3);
   const vec3 Vi = ld3(sb_i), Bai = ld3(sb_i + 3), Bgi = ld3(sb_i + 6);
@@ -287,29 +288,29 @@ GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose
   const vec3 rq = scl(2.0, qvec(qmul(qinv(cq), qmul(Qi_inv, Qj))));
   const vec3 rv = sub(a_v, cv);
   for (int k = 0; k < 3; k++) {
-    raw[k] = rp[k]; raw[3 + k] = rq[k]; raw[6 + k] = rv[k];
-    raw[9 + k] = Baj[k] - Bai[k]; raw[12 + k] = Bgj[k] - Bgi[k];
+    raw[k * es] = rp[k]; raw[(3 + k) * es] = rq[k]; raw[(6 + k) * es] = rv[k];
+    raw[(9 + k) * es] = Baj[k] - Bai[k]; raw[(12 + k) * es] = Bgj[k] - Bgi[k];
   }
   if (!Jraw) return;
   const mat3 I = ident3();
-  put3(Jraw, 30, 0, 0, mneg(RiT));                                                  // imu_factor.h:107
-  put3(Jraw, 30, 0, 3, hat(a_p));                                                   // :108
-  put3(Jraw, 30, 3, 3, mneg(qleft_qright3(qmul(qinv(Qj), Qi), cq)));                // :113-114
-  put3(Jraw, 30, 6, 3, hat(a_v));                                                   // :117
-  put3(Jraw, 30, 0, 6, mscl(-dt, RiT));                                             // :133
-  put3(Jraw, 30, 0, 9, mneg(dp_dba));
-  put3(Jraw, 30, 0, 12, mneg(dp_dbg));
-  put3(Jraw, 30, 3, 12, mneg(mul(qleft3(qmul(qmul(qinv(Qj), Qi), dq)), dq_dbg)));   // :142 (uncorrected delta_q)
-  put3(Jraw, 30, 6, 6, mneg(RiT));
-  put3(Jraw, 30, 6, 9, mneg(dv_dba));
-  put3(Jraw, 30, 6, 12, mneg(dv_dbg));
-  put3(Jraw, 30, 9, 9, mneg(I));
-  put3(Jraw, 30, 12, 12, mneg(I));
-  put3(Jraw, 30, 0, 15, RiT);                                                       // :162
-  put3(Jraw, 30, 3, 18, qleft3(qmul(qmul(qinv(cq), Qi_inv), Qj)));                  // :168
-  put3(Jraw, 30, 6, 21, RiT);                                                       // :179
-  put3(Jraw, 30, 9, 24, I);
-  put3(Jraw, 30, 12, 27, I);
+  put3(Jraw, 30, 0, 0, mneg(RiT), es);                                                  // imu_factor.h:107
+  put3(Jraw, 30, 0, 3, hat(a_p), es);                                                   // :108
+  put3(Jraw, 30, 3, 3, mneg(qleft_qright3(qmul(qinv(Qj), Qi), cq)), es);                // :113-114
+  put3(Jraw, 30, 6, 3, hat(a_v), es);                                                   // :117
+  put3(Jraw, 30, 0, 6, mscl(-dt, RiT), es);                                             // :133
+  put3(Jraw, 30, 0, 9, mneg(dp_dba), es);
+  put3(Jraw, 30, 0, 12, mneg(dp_dbg), es);
+  put3(Jraw, 30, 3, 12, mneg(mul(qleft3(qmul(qmul(qinv(Qj), Qi), dq)), dq_dbg)), es);   // :142 (uncorrected delta_q)
+  put3(Jraw, 30, 6, 6, mneg(RiT), es);
+  put3(Jraw, 30, 6, 9, mneg(dv_dba), es);
+  put3(Jraw, 30, 6, 12, mneg(dv_dbg), es);
+  put3(Jraw, 30, 9, 9, mneg(I), es);
+  put3(Jraw, 30, 12, 12, mneg(I), es);
+  put3(Jraw, 30, 0, 15, RiT, es);                                                       // :162
+  put3(Jraw, 30, 3, 18, qleft3(qmul(qmul(qinv(cq), Qi_inv), Qj)), es);                  // :168
+  put3(Jraw, 30, 6, 21, RiT, es);                                                       // :179
+  put3(Jraw, 30, 9, 24, I, es);
+  put3(Jraw, 30, 12, 27, I, es);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -317,7 +318,7 @@ GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose
 // ex_wheel(6) sx sy sw td_wheel.
 // ---------------------------------------------------------------------------------------------
 GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const double *pose_j, const double *exw,
-                     double sx, double sy, double sw, double td, double *raw, double *Jraw) {
+                     double sx, double sy, double sw, double td, double *raw, double *Jraw, size_t es = 1) {
   const vec3 Pi = ld3(pose_i), Pj = ld3(pose_j), tio = ld3(exw);
   const quat Qi = ldq(pose_i + 3), Qj = ldq(pose_j + 3), qio = ldq(exw + 3);
   const double *Jm = pre->jacobian;   // 6x3
@@ -339,21 +340,21 @@ GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const d
   const vec3 world_d = sub(sub(add(mv(Rj, tio), Pj), mv(Ri, tio)), Pi);
   const vec3 rp = sub(tmv(RR, world_d), p_time);                                                              // :211
   const vec3 rq = so3log(qnormalize(qmul(qmul(qmul(qinv(q_time), qinv(qmul(Qi, qio))), Qj), qio)));           // :212
-  for (int k = 0; k < 3; k++) { raw[k] = rp[k]; raw[3 + k] = rq[k]; }
+  for (int k = 0; k < 3; k++) { raw[k * es] = rp[k]; raw[(3 + k) * es] = rq[k]; }
   if (!Jraw) return;
   const mat3 RRT = transp(RR);
   const mat3 Jr_inv = jr_inv_so3(rq);                                    // wheel_factor.h:106-108
   const vec3 drdsw = scl(dsw, dq_dsw);
   const mat3 Jr_drdsw = jr_so3(drdsw);                                   // :110-112
-  put3(Jraw, 22, 0, 0, mneg(RRT));                                                                            // :121
-  put3(Jraw, 22, 0, 3, madd(mul(RRT, mul(Ri, hat(tio))), tmul(rio, hat(tmv(Ri, world_d)))));                  // :123
-  put3(Jraw, 22, 3, 3, mneg(mul(Jr_inv, qrot(qmul(qinv(qmul(Qj, qio)), Qi)))));                               // :131
-  put3(Jraw, 22, 0, 6, RRT);                                                                                  // :150
-  put3(Jraw, 22, 0, 9, mneg(mul(qrot(qmul(qinv(qmul(Qi, qio)), Qj)), hat(tio))));                             // :151
-  put3(Jraw, 22, 3, 9, mul(Jr_inv, qrot(qinv(qio))));                                                         // :157
-  put3(Jraw, 22, 0, 12, mul(RRT, msub(Rj, Ri)));                                                              // :170
-  put3(Jraw, 22, 0, 15, hat(mv(RRT, world_d)));                                                               // :172
-  put3(Jraw, 22, 3, 15, mul(Jr_inv, msub(ident3(), qrot(qmul(qmul(qinv(qmul(Qj, qio)), Qi), qio)))));         // :174
+  put3(Jraw, 22, 0, 0, mneg(RRT), es);                                                                            // :121
+  put3(Jraw, 22, 0, 3, madd(mul(RRT, mul(Ri, hat(tio))), tmul(rio, hat(tmv(Ri, world_d)))), es);                  // :123
+  put3(Jraw, 22, 3, 3, mneg(mul(Jr_inv, qrot(qmul(qinv(qmul(Qj, qio)), Qi)))), es);                               // :131
+  put3(Jraw, 22, 0, 6, RRT, es);                                                                                  // :150
+  put3(Jraw, 22, 0, 9, mneg(mul(qrot(qmul(qinv(qmul(Qi, qio)), Qj)), hat(tio))), es);                             // :151
+  put3(Jraw, 22, 3, 9, mul(Jr_inv, qrot(qinv(qio))), es);                                                         // :157
+  put3(Jraw, 22, 0, 12, mul(RRT, msub(Rj, Ri)), es);                                                              // :170
+  put3(Jraw, 22, 0, 15, hat(mv(RRT, world_d)), es);                                                               // :172
+  put3(Jraw, 22, 3, 15, mul(Jr_inv, msub(ident3(), qrot(qmul(qmul(qinv(qmul(Qj, qio)), Qi), qio)))), es);         // :174
   const vec3 fw = scl(sw * dtd, lin_gyr), fv = mv(sv, scl(dtd, lin_vel));
   const vec3 bv = mv(sv, scl(dtd, vel_1)), bw = scl(sw * dtd, gyr_1);
   const mat3 Jrtd = jr_so3(fw), Jr_mtd = jr_so3(neg(fw));
@@ -373,10 +374,10 @@ GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const d
   const vec3 u2 = sub(mv(Ebw, mv(RcqT, mv(Jrtd, scl(sw, lin_gyr)))), mv(Jr_mtd, scl(sw, gyr_1)));
   const vec3 c_td_r = neg(mv(Jr_inv, mv(Emr, u2)));                                                            // :237
   for (int k = 0; k < 3; k++) {
-    Jraw[k * 22 + 18] = c_sx[k];
-    Jraw[k * 22 + 19] = c_sy[k];
-    Jraw[k * 22 + 20] = c_sw_p[k]; Jraw[(3 + k) * 22 + 20] = c_sw_r[k];
-    Jraw[k * 22 + 21] = c_td_p[k]; Jraw[(3 + k) * 22 + 21] = c_td_r[k];
+    Jraw[(size_t)(k * 22 + 18) * es] = c_sx[k];
+    Jraw[(size_t)(k * 22 + 19) * es] = c_sy[k];
+    Jraw[(size_t)(k * 22 + 20) * es] = c_sw_p[k]; Jraw[(size_t)((3 + k) * 22 + 20) * es] = c_sw_r[k];
+    Jraw[(size_t)(k * 22 + 21) * es] = c_td_p[k]; Jraw[(size_t)((3 + k) * 22 + 21) * es] = c_td_r[k];
   }
 }
 

@@ -35,6 +35,9 @@ struct gfbe_ctx {
   gfbe_options opt;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // second stream: the inertial / wheel / prior factors (few, latency-bound workgroups) run beside the visual kernels
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   bool profiling = false;
   std::vector<ProfEntry> prof;
@@ -99,6 +102,12 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
     return GFBE_DEVICE_ERROR;
   }
   c->own_stream = true;
+  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    c->err = "hipStreamCreate/hipEventCreate (aux stream) failed";
+    return GFBE_DEVICE_ERROR;
+  }
   return GFBE_OK;
 }
 
@@ -107,6 +116,9 @@ void gfbe_destroy(gfbe_ctx *c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   for (auto &p : c->prof) for (auto &ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   delete c;
 }
 
@@ -429,6 +441,7 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   UP(desc, desc); UP(lm_info, lm_info); UP(lm_abi, lm_abi); UP(lm_pts, lm_pts); UP(lm_obs, lm_obs); UP(lm_rec, lm_rec);
   UP(lam0, lam0); UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
   UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0); UP(tri_tab, tri);
+  AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
   AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1)); AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
   AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
   AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
@@ -474,9 +487,19 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
 static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, bool first) {
   const BatchDev &d = b->d;
   // the first linearisation has every window active; later ones skip windows that only shrink the radius
+  // fork: dense factors on the aux stream (serial and timed on the main stream when profiling)
+  const bool overlap = !c->profiling && c->aux && d.B >= DENSE_SPLIT_MIN_B;
+  if (overlap) {
+    (void)hipEventRecord(c->ev_fork, c->stream);
+    (void)hipStreamWaitEvent(c->aux, c->ev_fork, 0);
+    launch_dense_factors(d, 0, 0, c->aux);
+    (void)hipEventRecord(c->ev_join, c->aux);
+  }
   { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, c->stream); }
-  { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, c->stream); }
+  if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, c->stream); }
   { Timed t(c, "k_schur", 0); launch_schur(d, 0, c->stream); }
+  { Timed t(c, "k_visblock", 0); launch_visblock(d, c->stream); }
+  if (overlap) (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);   // join
   { Timed t(c, "k_assemble", 0); launch_assemble(d, c->stream); }
   if (d.world > 1) { Timed t(c, "allreduce_system", 0); c->allreduce(c->allreduce_user, d.H, (int64_t)b->slab_n, c->stream); }
   { Timed t(c, "k_solve", 0); launch_solve(d, c->stream); }
@@ -499,8 +522,16 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
     enqueue_linearize(c, b, it == 0);
     { Timed t(c, "k_step", 0); launch_step(d, c->stream); }
     { Timed t(c, "k_candidate", 0); launch_candidate(d, c->stream); }
+    const bool overlap = !c->profiling && c->aux && d.B >= DENSE_SPLIT_MIN_B;
+    if (overlap) {
+      (void)hipEventRecord(c->ev_fork, c->stream);
+      (void)hipStreamWaitEvent(c->aux, c->ev_fork, 0);
+      launch_dense_factors(d, 1, 0, c->aux);
+      (void)hipEventRecord(c->ev_join, c->aux);
+    }
     { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, c->stream); }
-    { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, c->stream); }
+    if (!overlap) { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, c->stream); }
+    else (void)hipStreamWaitEvent(c->stream, c->ev_join, 0);
     if (d.world > 1) {
       Timed t(c, "allreduce_scalars", 0);
       launch_xchg_cand(d, c->stream);

@@ -350,7 +350,60 @@ __device__ __forceinline__ int pair_tri(int a, int b) {
 // mode 0 linearise at current; 1 candidate cost; 2 MARGIN_OLD set at xout (frame-0 IMU/wheel + prior);
 // 3 MARGIN_SECOND_NEW set at xout (prior only).
 // =============================================================================================
-__global__ __launch_bounds__(64, 2) void k_dense(BatchDev d, int mode, int debug_out) {
+// Structural non-zeros of the un-whitened Jacobians written by imu_raw (15 x 30) / wheel_raw (6 x 22).
+__device__ __forceinline__ bool imu_nz(int r, int c) {
+  const int mask[5] = {0x03F, 0x052, 0x09E, 0x108, 0x210};   // 3 x 3 column blocks present in row block r / 3
+  return (mask[r / 3] >> (c / 3)) & 1;
+}
+__device__ __forceinline__ bool wheel_nz(int r, int c) {
+  if (c >= 20) return true;
+  if (c >= 18) return r < 3;
+  return r < 3 || ((c / 3) & 1);
+}
+// Which inertial / wheel factors a pass evaluates (shared by k_dense_raw and k_dense):
+//   mode 0 linearise, 1 candidate cost, 2 MARGIN_OLD set at the re-anchored state (factor of frame 0), 3 nothing.
+__device__ __forceinline__ bool dense_pass_active(const WinCtl &c, int mode) {
+  if (mode == 0 && (c.done || c.reuse)) return false;
+  if (mode == 1 && (c.done || !c.have_step)) return false;
+  return true;
+}
+#define RAW_IMU (15 + 15 * 30)
+#define RAW_WHEEL (6 + 6 * 22)
+// k_dense_raw: the SE(3) / quaternion algebra of the inertial and wheel factors (imu_factor.h:69-190,
+// wheel_factor.h:80-243) is scalar code; here one LANE = one window (factor f of 64 windows per wave), so the 64
+// lanes of the wave are all busy. Output: raw residual + raw Jacobian non-zeros, window-minor
+// (raw_imu[f][q][B]: coalesced stores here, one 32-byte sector per value for the per-factor workgroup of k_dense).
+__global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode) {
+  const int f = blockIdx.x, w = blockIdx.y * 64 + threadIdx.x;
+  if (w >= d.B) return;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (!dense_pass_active(c, mode)) return;
+  const int buf = (mode == 1) ? 1 - c.cur : c.cur;
+  const double *X = (mode >= 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
+  const size_t B = d.B;
+  if (f < MAX_IMU) {
+    if (f >= ds.n_imu) return;
+    const int fi = ds.imu_frame[f];
+    if (mode >= 2 && !(mode == 2 && fi == 0 && d.imu[ds.imu_off + f].sum_dt < 10.0)) return;
+    double *out = d.raw_imu + (size_t)f * RAW_IMU * B + w;
+    imu_raw(&d.imu[ds.imu_off + f], d.opt.g_norm, X + A_POSE(fi), X + A_SB(fi), X + A_POSE(fi + 1), X + A_SB(fi + 1), out,
+            mode == 1 ? nullptr : out + 15 * B, B);
+  } else {
+    const int k = f - MAX_IMU;
+    if (k >= ds.n_wheel) return;
+    const int fi = ds.wheel_frame[k];
+    if (mode >= 2 && !(mode == 2 && fi == 0 && d.wheel[ds.wheel_off + k].sum_dt < 10.0)) return;
+    double *out = d.raw_wheel + (size_t)k * RAW_WHEEL * B + w;
+    wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
+              X[A_TDW], out, mode == 1 ? nullptr : out + 6 * B, B);
+  }
+}
+
+// FUSED: small batches evaluate the raw factor inline (lane 0) — one launch less on the latency path of a single
+// window; otherwise the raw residuals / Jacobians come from k_dense_raw.
+template <bool FUSED>
+__global__ __launch_bounds__(64, FUSED ? 1 : 2) void k_dense(BatchDev d, int mode, int debug_out) {
   const int w = blockIdx.y, f = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
@@ -367,11 +420,18 @@ __global__ __launch_bounds__(64, 2) void k_dense(BatchDev d, int mode, int debug
     if (f >= ds.n_imu) { if (mode == 1 && t == 0) part[IMU_PART - 1] = 0.0; return; }
     const int fi = ds.imu_frame[f];
     if (mode >= 2 && !(mode == 2 && fi == 0 && d.imu[ds.imu_off + f].sum_dt < 10.0)) { if (t == 0) part[IMU_PART - 2] = -1.0; return; }
-    for (int q = t; q < 450; q += 64) Jraw[q] = 0.0;
-    __syncthreads();
-    if (t == 0)
-      imu_raw(&d.imu[ds.imu_off + f], d.opt.g_norm, X + A_POSE(fi), X + A_SB(fi), X + A_POSE(fi + 1), X + A_SB(fi + 1), raw,
-              mode == 1 ? nullptr : Jraw);
+    if (FUSED) {
+      for (int q = t; q < 450; q += 64) Jraw[q] = 0.0;
+      __syncthreads();
+      if (t == 0)
+        imu_raw(&d.imu[ds.imu_off + f], d.opt.g_norm, X + A_POSE(fi), X + A_SB(fi), X + A_POSE(fi + 1), X + A_SB(fi + 1), raw,
+                mode == 1 ? nullptr : Jraw);
+    } else {   // raw residual / Jacobian of this factor from k_dense_raw (window-minor layout)
+      const double *in = d.raw_imu + (size_t)f * RAW_IMU * d.B + w;
+      if (t < 15) raw[t] = in[(size_t)t * d.B];
+      if (mode != 1)
+        for (int q = t; q < 450; q += 64) Jraw[q] = imu_nz(q / 30, q % 30) ? in[(size_t)(15 + q) * d.B] : 0.0;
+    }
     __syncthreads();
     const double *S = d.imu_sqrt + (size_t)(ds.imu_off + f) * 225;   // upper triangular
     if (t < 15) { double s = 0.0; for (int b = t; b < 15; b++) s += S[t * 15 + b] * raw[b]; rw[t] = s; }
@@ -401,11 +461,18 @@ __global__ __launch_bounds__(64, 2) void k_dense(BatchDev d, int mode, int debug
     if (k >= ds.n_wheel) { if (mode == 1 && t == 0) part[WHEEL_PART - 1] = 0.0; return; }
     const int fi = ds.wheel_frame[k];
     if (mode >= 2 && !(mode == 2 && fi == 0 && d.wheel[ds.wheel_off + k].sum_dt < 10.0)) { if (t == 0) part[WHEEL_PART - 2] = -1.0; return; }
-    for (int q = t; q < 132; q += 64) Jraw[q] = 0.0;
-    __syncthreads();
-    if (t == 0)
-      wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
-                X[A_TDW], raw, mode == 1 ? nullptr : Jraw);
+    if (FUSED) {
+      for (int q = t; q < 132; q += 64) Jraw[q] = 0.0;
+      __syncthreads();
+      if (t == 0)
+        wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
+                  X[A_TDW], raw, mode == 1 ? nullptr : Jraw);
+    } else {
+      const double *in = d.raw_wheel + (size_t)k * RAW_WHEEL * d.B + w;
+      if (t < 6) raw[t] = in[(size_t)t * d.B];
+      if (mode != 1)
+        for (int q = t; q < 132; q += 64) Jraw[q] = wheel_nz(q / 22, q % 22) ? in[(size_t)(6 + q) * d.B] : 0.0;
+    }
     __syncthreads();
     const double *S = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
     if (t < 6) { double s = 0.0; for (int b = t; b < 6; b++) s += S[t * 6 + b] * raw[b]; rw[t] = s; }
@@ -911,8 +978,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
         }
         x += ws;
       }
-      H[(size_t)a * ND + b] = x;
-      H[(size_t)b * ND + a] = x;
+      H[(size_t)a * ND + b] = x;   // lower triangle only (b <= a): k_solve never reads the mirror
     }
   }
   // E (73 x 73, symmetric), eg
@@ -1125,7 +1191,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
           if (ia < n && ib < n) {
             const int a = perm[ia], b = perm[ib];
             aa[u] = a; bb[u] = b; kind[u] = 1;
-            hv[u] = H[(size_t)a * ND + b];
+            hv[u] = H[(size_t)max(a, b) * ND + min(a, b)];   // H holds its lower triangle
             if (a < NV && b < NV) ev[u] = E[a * NV + b];
           } else if (ia == n && ib < n) { bb[u] = perm[ib]; kind[u] = 2; }
           else if (ib == n && ia < n) { bb[u] = perm[ia]; kind[u] = 2; }
@@ -1262,9 +1328,9 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     return;
   }
   STAMP(4);
-  // dense shares of the dogleg scalars: v^T Ht v, y^T Ht v, y^T Ht y with Ht = s H s, as double sums over (a, b):
-  // wave `wave` takes rows a = wave, wave + 16, ...; lane l the columns l, l + 64, l + 128 (coalesced row
-  // reads; rows / columns of constant dims are zero in H). One block reduction at the end, fixed order.
+  // dense shares of the dogleg scalars: v^T Ht v, y^T Ht v, y^T Ht y with Ht = s H s, as double sums over the lower
+  // triangle (a, b <= a): wave `wave` takes rows a = wave, wave + 16, ...; lane l the columns l, l + 64, l + 128
+  // (coalesced row reads; rows / columns of constant dims are zero in H). One block reduction at the end, fixed order.
   double n2 = 0.0, gyv = 0.0, vhv = 0.0, vhy = 0.0, yhy = 0.0;
   for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }
   __syncthreads();
@@ -1273,12 +1339,20 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
 #pragma unroll
     for (int q = 0; q < 3; q++) { const int b = lane + 64 * q; svb[q] = b < ND ? ys[b] : 0.0; syb[q] = b < ND ? ys[ND + b] : 0.0; }
     for (int a = wave; a < ND; a += SOLVE_THREADS >> 6) {
+      // row a of the lower triangle: sum_{b<a} H_ab (.)_b counts twice (symmetry), the diagonal once
       const double *Ha = H + (size_t)a * ND;
-      double hv = 0.0, hy = 0.0;
+      double hv = 0.0, hy = 0.0, dg = 0.0;
 #pragma unroll
-      for (int q = 0; q < 3; q++) { const int b = lane + 64 * q; const double h = b < ND ? Ha[b] : 0.0; hv += h * svb[q]; hy += h * syb[q]; }
+      for (int q = 0; q < 3; q++) {
+        const int b = lane + 64 * q;
+        const double h = b <= a ? Ha[b] : 0.0;
+        if (b == a) dg = h;
+        else { hv += h * svb[q]; hy += h * syb[q]; }
+      }
       const double sva = ys[a], sya = ys[ND + a];
-      vhv += sva * hv; vhy += sya * hv; yhy += sya * hy;
+      vhv += 2.0 * sva * hv + dg * sva * sva;
+      vhy += sya * hv + sva * hy + dg * sya * sva;
+      yhy += 2.0 * sya * hy + dg * sya * sya;
     }
   }
   for (int a = t; a < ND; a += blockDim.x) {
@@ -1641,7 +1715,12 @@ void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
   hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);
 }
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_dense, dim3(MAX_IMU + MAX_WHEEL + 1, d.B), dim3(64), 0, s, d, mode, debug_out);
+  if (d.B < DENSE_SPLIT_MIN_B) {
+    hipLaunchKernelGGL(k_dense<true>, dim3(MAX_IMU + MAX_WHEEL + 1, d.B), dim3(64), 0, s, d, mode, debug_out);
+    return;
+  }
+  if (mode != 3) hipLaunchKernelGGL(k_dense_raw, dim3(MAX_IMU + MAX_WHEEL, (d.B + 63) / 64), dim3(64), 0, s, d, mode);
+  hipLaunchKernelGGL(k_dense<false>, dim3(MAX_IMU + MAX_WHEEL + 1, d.B), dim3(64), 0, s, d, mode, debug_out);
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
   if (d.max_tiles == 0) return;
@@ -1652,8 +1731,8 @@ void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_x
 void launch_lam_mask(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles > 0) hipLaunchKernelGGL(k_lam_mask, dim3(d.max_tiles, d.B), dim3(LM_TILE), 0, s, d);
 }
+void launch_visblock(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d); }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d);
   hipLaunchKernelGGL(k_assemble, dim3(ASM_WGS, d.B), dim3(ASM_THREADS), 0, s, d);
 }
 void launch_solve(const BatchDev &d, hipStream_t s) {

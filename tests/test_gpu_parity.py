@@ -160,6 +160,26 @@ def test_batch_equals_single_and_is_deterministic(be, oracle):
         assert a["summary"]["cost_history"] == b["summary"]["cost_history"]
 
 
+def test_large_batch_throughput_path(be, oracle):
+    """Batches of >= 32 windows take the throughput path (k_dense_raw with one lane per window, the dense factors on
+    a second stream beside the visual kernels): same results as the single-window path — 1e-12 relative on the
+    costs (different kernels, same FP64 formulas), poses to 1e-12 m — and repeatable bit for bit."""
+    snaps = [synth.Scenario(seed=160 + k, n_landmarks=120 + 30 * k, use_wheel=bool(k % 2)).window(0) for k in range(4)]
+    single = [be.solve(s, abi.MARGIN_OLD) for s in snaps]
+    big = [snaps[i % 4] for i in range(40)]
+    batch = be.solve_batch(big, abi.MARGIN_OLD)
+    again = be.solve_batch(big, abi.MARGIN_OLD)
+    for i, (b, c) in enumerate(zip(batch, again)):
+        a = single[i % 4]
+        assert b["summary"]["accepted"] == a["summary"]["accepted"]
+        np.testing.assert_allclose(b["summary"]["cost_history"], a["summary"]["cost_history"], rtol=1e-12)
+        assert np.abs(b["state"]["pose"] - a["state"]["pose"]).max() < 1e-12
+        np.testing.assert_allclose(b["feature"], a["feature"], rtol=1e-11, atol=1e-14)
+        np.testing.assert_array_equal(b["state"]["pose"], c["state"]["pose"])
+        np.testing.assert_array_equal(b["feature"], c["feature"])
+        assert np.abs(b["prior"]["J0"] - c["prior"]["J0"]).max() == 0.0
+
+
 def test_partial_window_and_empty_visual(be, oracle):
     """frame_count < WINDOW_SIZE (estimator.cpp:3391: no marginalisation) and a window without
     any visual factor (IMU + wheel only)."""
