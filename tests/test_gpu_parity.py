@@ -180,6 +180,28 @@ def test_large_batch_throughput_path(be, oracle):
         assert np.abs(b["prior"]["J0"] - c["prior"]["J0"]).max() == 0.0
 
 
+def test_graph_replay_is_bit_identical(oracle):
+    """gfbe_options.use_graph = 1: the third solve of a resident batch replays the captured hipGraph — same bits as the
+    eager launches."""
+    snaps = [synth.Scenario(seed=170 + k, n_landmarks=200, use_wheel=True).window(0) for k in range(3)]
+    outs = []
+    for use_graph in (0, 1):
+        o = abi.default_options()
+        o.use_graph = use_graph
+        b = gf.Backend(device=0, options=o)
+        batch = b.batch_upload(snaps)
+        for _ in range(4):
+            batch.solve(abi.MARGIN_OLD)
+        outs.append(batch.download())
+        batch.free()
+        b.close()
+    for a, g in zip(*outs):
+        np.testing.assert_array_equal(a["state"]["pose"], g["state"]["pose"])
+        np.testing.assert_array_equal(a["feature"], g["feature"])
+        np.testing.assert_array_equal(a["prior"]["J0"], g["prior"]["J0"])
+        assert a["summary"]["cost_history"] == g["summary"]["cost_history"]
+
+
 def test_partial_window_and_empty_visual(be, oracle):
     """frame_count < WINDOW_SIZE (estimator.cpp:3391: no marginalisation) and a window without
     any visual factor (IMU + wheel only)."""
