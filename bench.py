@@ -127,8 +127,23 @@ def main():
         algo_flops = 1600.0 * K_batch
         algo_bytes = 108.0 * K_batch
         achieved_tf = algo_flops / (lin_ms * 1e-3) / 1e12
+        # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
+        # passes (profiles/r1_pmc_fetch.txt / _write.txt, tests/diag_pmc.sh) hold FETCH_SIZE / WRITE_SIZE per dispatch
+        # for exactly the default workload, so they are quoted for it and left null for any other configuration.
+        traffic = None
+        if args.batch == 256 and args.landmarks == 2000 and args.unique == 8:
+            try:
+                tot = 0.0
+                for fn, key in (("r1_pmc_fetch.txt", "FETCH_SIZE"), ("r1_pmc_write.txt", "WRITE_SIZE")):
+                    lines = open(os.path.join(ROOT, "profiles", fn)).read().splitlines()
+                    i = [k for k, ln in enumerate(lines) if "k_visILi0E" in ln and "grid=(2304,256,1)" in ln][0]
+                    tot += float([ln for ln in lines[i + 1:i + 4] if key in ln][0].split()[1]) * 1024.0
+                traffic = tot
+            except Exception:
+                traffic = None
         roofline = {"bound": "mfma", "kernel": "k_vis<0> (visual evaluate + linearise + fused J^T J; first iteration: all windows active)",
-                    "achieved": achieved_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved_tf / 78.6, "traffic": None,
+                    "achieved": achieved_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved_tf / 78.6, "traffic": traffic,
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same workload, bytes per launch: profiles/r1_pmc_fetch.txt + r1_pmc_write.txt" if traffic else None,
                     "avg_launch_ms": lin_ms, "algorithmic_flops_per_launch": algo_flops,
                     "algorithmic_bytes_per_launch": algo_bytes, "hbm_view_GBps": algo_bytes / (lin_ms * 1e-3) / 1e9,
                     "hbm_view_frac_of_8TBps": algo_bytes / (lin_ms * 1e-3) / 8e12,
