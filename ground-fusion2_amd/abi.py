@@ -441,3 +441,143 @@ def summary_to_dict(sm):
                 termination=sm.termination, initial_cost=sm.initial_cost, final_cost=sm.final_cost,
                 final_radius=sm.final_radius, cost_history=list(sm.cost_history)[:n],
                 accepted=list(sm.accepted)[:n])
+
+
+# ---------------------------------------------------------------------------------------------
+# f1: feature tables (FeatureManager / slideWindow operations), shared by gfbe_ (device) and gfo_ (oracle)
+# ---------------------------------------------------------------------------------------------
+class FtabOptions(C.Structure):
+    _fields_ = [("init_depth", c_d), ("min_parallax", c_d), ("focal_length", c_d), ("depth_threshold", c_d)]
+
+
+def pose_rows(pose7):
+    """[p, q(xyzw)] rows -> [P(3) | R(9, row-major)] rows, the pose argument of the feature-table calls."""
+    pose7 = np.asarray(pose7, float).reshape(-1, 7)
+    out = np.zeros((len(pose7), 12))
+    for k, r in enumerate(pose7):
+        x, y, z, w = r[3:] / np.linalg.norm(r[3:])
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        out[k, :3] = r[:3]
+        out[k, 3:] = R.ravel()
+    return out
+
+
+class FeatureTables:
+    """W feature tables behind `lib` (prefix gfbe_: device-resident, ctx = gfbe_ctx*; prefix gfo_: the CPU oracle,
+    ctx ignored). Per-table arguments are lists of length W."""
+
+    def __init__(self, lib, prefix, ctx, n_tables=1, capacity=4096, options=None):
+        self.lib, self.prefix, self.ctx, self.W, self.cap = lib, prefix, ctx, n_tables, capacity
+        self.h = C.c_void_p()
+        for name in ("create", "add_frame", "remove_back_shift_depth", "remove_back", "remove_front", "remove_outlier",
+                     "remove_failures", "clear_depth", "set_depth", "get_depth_vector", "triangulate", "check_outliers",
+                     "size", "download"):
+            self._f(name).restype = c_i
+        self._f("destroy").restype = None
+        opt = None
+        if options is not None:
+            opt = FtabOptions()
+            self._f("default_options")(C.byref(opt))
+            for k, v in options.items():
+                setattr(opt, k, v)
+        self._check(self._f("create")(self.ctx, int(n_tables), int(capacity), C.byref(opt) if opt is not None else None,
+                                      C.byref(self.h)), "create")
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + "ftab_" + name)
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise RuntimeError("%sftab_%s failed with status %d" % (self.prefix, what, rc))
+
+    def close(self):
+        if self.h:
+            self._f("destroy")(self.ctx, self.h)
+            self.h = C.c_void_p()
+
+    @staticmethod
+    def _ragged(rows, dtype, width=None):
+        off = np.zeros(len(rows) + 1, np.int32)
+        off[1:] = np.cumsum([len(r) for r in rows])
+        flat = np.concatenate([np.asarray(r, dtype).reshape(len(r), -1) if width else np.asarray(r, dtype).ravel() for r in rows]) \
+            if off[-1] else np.zeros((0, width) if width else 0, dtype)
+        return off, np.ascontiguousarray(flat)
+
+    def add_frame(self, frame_count, ids, obs8, td):
+        """ids[w]: ascending feature ids; obs8[w]: [n, 8]. Returns (keyframe[W], counters[W, 3], avg_parallax[W])."""
+        off, fid = self._ragged(ids, np.int32)
+        _, ob = self._ragged(obs8, np.float64, 8)
+        fc, tdv = _i32(frame_count), _f64(td)
+        kf, cnt, avg = np.zeros(self.W, np.int32), np.zeros((self.W, 3), np.int32), np.zeros(self.W)
+        self._check(self._f("add_frame")(self.ctx, self.h, _pi(fc), _pi(off), _pi(fid), _pd(ob), _pd(tdv), _pi(kf), _pi(cnt), _pd(avg)), "add_frame")
+        return kf, cnt, avg
+
+    def remove_back_shift_depth(self, marg_pr, new_pr):
+        a, b = _f64(marg_pr).reshape(self.W, 12), _f64(new_pr).reshape(self.W, 12)
+        self._check(self._f("remove_back_shift_depth")(self.ctx, self.h, _pd(a), _pd(b)), "remove_back_shift_depth")
+
+    def remove_back(self):
+        self._check(self._f("remove_back")(self.ctx, self.h), "remove_back")
+
+    def remove_front(self, frame_count):
+        fc = _i32(frame_count)
+        self._check(self._f("remove_front")(self.ctx, self.h, _pi(fc)), "remove_front")
+
+    def remove_outlier(self, ids):
+        off, flat = self._ragged(ids, np.int32)
+        self._check(self._f("remove_outlier")(self.ctx, self.h, _pi(off), _pi(flat)), "remove_outlier")
+
+    def remove_failures(self):
+        self._check(self._f("remove_failures")(self.ctx, self.h), "remove_failures")
+
+    def clear_depth(self):
+        self._check(self._f("clear_depth")(self.ctx, self.h), "clear_depth")
+
+    def set_depth(self, x):
+        off, flat = self._ragged(x, np.float64)
+        self._check(self._f("set_depth")(self.ctx, self.h, _pi(off), _pd(flat)), "set_depth")
+
+    def get_depth_vector(self):
+        off = (np.arange(self.W + 1) * self.cap).astype(np.int32)
+        x, cnt = np.zeros(self.W * self.cap), np.zeros(self.W, np.int32)
+        self._check(self._f("get_depth_vector")(self.ctx, self.h, _pi(off), _pd(x), _pi(cnt)), "get_depth_vector")
+        return [x[off[w]:off[w] + cnt[w]].copy() for w in range(self.W)]
+
+    def triangulate(self, poses, tic_ric, with_depth=False):
+        p, e = _f64(poses).reshape(self.W, 11 * 12), _f64(tic_ric).reshape(self.W, 12)
+        self._check(self._f("triangulate")(self.ctx, self.h, _pd(p), _pd(e), int(with_depth)), "triangulate")
+
+    def check_outliers(self, poses, tic_ric, mode):
+        p, e = _f64(poses).reshape(self.W, 11 * 12), _f64(tic_ric).reshape(self.W, 12)
+        off = (np.arange(self.W + 1) * self.cap).astype(np.int32)
+        ids, cnt = np.zeros(self.W * self.cap, np.int32), np.zeros(self.W, np.int32)
+        self._check(self._f("check_outliers")(self.ctx, self.h, _pd(p), _pd(e), int(mode), _pi(off), _pi(ids), _pi(cnt)), "check_outliers")
+        return [ids[off[w]:off[w] + cnt[w]].copy() for w in range(self.W)]
+
+    def size(self):
+        n = np.zeros(self.W, np.int32)
+        self._check(self._f("size")(self.ctx, self.h, _pi(n)), "size")
+        return n
+
+    def download(self, w=0):
+        n = int(self.size()[w])
+        out = dict(feature_id=np.zeros(n, np.int32), start_frame=np.zeros(n, np.int32), n_obs=np.zeros(n, np.int32),
+                   obs8=np.zeros((n, 11, 8)), obs_td=np.zeros((n, 11)), estimated_depth=np.zeros(n),
+                   estimate_flag=np.zeros(n, np.int32), solve_flag=np.zeros(n, np.int32))
+        self._check(self._f("download")(self.ctx, self.h, int(w), _pi(out["feature_id"]), _pi(out["start_frame"]), _pi(out["n_obs"]),
+                                        _pd(out["obs8"]), _pd(out["obs_td"]), _pd(out["estimated_depth"]), _pi(out["estimate_flag"]),
+                                        _pi(out["solve_flag"])), "download")
+        return out
+
+
+def ftab_to_feature_list(tab):
+    """FeatureTables.download() -> the flattened list gfbe_build_visual_factors consumes."""
+    rows, tds = [], []
+    for k in range(len(tab["n_obs"])):
+        for o in range(tab["n_obs"][k]):
+            rows.append(tab["obs8"][k, o, :7])
+            tds.append(tab["obs_td"][k, o])
+    return dict(start_frame=tab["start_frame"], n_obs=tab["n_obs"], obs=np.array(rows).reshape(-1, 7), obs_td=np.array(tds),
+                estimated_depth=tab["estimated_depth"], estimate_flag=tab["estimate_flag"])

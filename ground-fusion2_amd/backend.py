@@ -26,6 +26,10 @@ EXPORTS = [
     "gfbe_batch_upload", "gfbe_batch_solve", "gfbe_batch_download", "gfbe_batch_free",
     "gfbe_profile_enable", "gfbe_profile_count", "gfbe_profile_get", "gfbe_profile_reset",
     "gfbe_set_allreduce", "gfbe_debug_timing",
+    "gfbe_ftab_default_options", "gfbe_ftab_create", "gfbe_ftab_destroy", "gfbe_ftab_add_frame",
+    "gfbe_ftab_remove_back_shift_depth", "gfbe_ftab_remove_back", "gfbe_ftab_remove_front", "gfbe_ftab_remove_outlier",
+    "gfbe_ftab_remove_failures", "gfbe_ftab_clear_depth", "gfbe_ftab_set_depth", "gfbe_ftab_get_depth_vector",
+    "gfbe_ftab_triangulate", "gfbe_ftab_check_outliers", "gfbe_ftab_size", "gfbe_ftab_download", "gfbe_slide_window_state",
 ]
 
 

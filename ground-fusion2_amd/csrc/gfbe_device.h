@@ -201,6 +201,10 @@ void launch_schur(const BatchDev &d, int marg, hipStream_t s);
 void launch_visblock(const BatchDev &d, hipStream_t s);
 void launch_assemble(const BatchDev &d, hipStream_t s);
 void launch_asm_table(const BatchDev &d, hipStream_t s);
+// context accessors for the translation units that do not see the gfbe_ctx definition (gfbe_host.cpp)
+hipStream_t ctx_stream(gfbe_ctx *c);
+int ctx_device(const gfbe_ctx *c);
+void ctx_set_error(gfbe_ctx *c, const char *msg);
 void launch_xchg_gram(const BatchDev &d, hipStream_t s);
 void launch_xchg_cand(const BatchDev &d, hipStream_t s);
 void launch_lam_mask(const BatchDev &d, hipStream_t s);

@@ -69,6 +69,12 @@ struct gfbe_batch {
     }                                                                                            \
   } while (0)
 
+namespace gfd {
+hipStream_t ctx_stream(gfbe_ctx *c) { return c->stream; }
+int ctx_device(const gfbe_ctx *c) { return c ? c->device : -1; }
+void ctx_set_error(gfbe_ctx *c, const char *msg) { if (c) c->err = msg; }
+}  // namespace gfd
+
 extern "C" {
 
 void gfbe_default_options(gfbe_options *o) {

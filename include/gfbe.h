@@ -237,6 +237,71 @@ void gfbe_set_depth(const gfbe_feature_list *fl, const double *para_Feature,
                     double *estimated_depth, int32_t *solve_flag);
 
 /* ------------------------------------------------------------------------------------------
+ * f1  FeatureManager / slideWindow operations on device-resident feature tables
+ *     (SURVEY.md section 8f rank 1 — the step either side of the solve):
+ *       FeatureManager::addFeatureCheckParallax   feature_manager.cpp:57-116 (+ compensatedParallax2 :978-1011)
+ *       setDepth / removeFailures / clearDepth / getDepthVector   :249-302
+ *       triangulate :669-724, triangulateWithDepth :726-799
+ *       removeOutlier :801-816, removeBackShiftDepth :818-856, removeBack :858-874, removeFront :914-934
+ *       Estimator::slideWindow / slideWindowNew / slideWindowOld   estimator.cpp:3700-3899
+ *       Estimator::outliersRejection :3971-4028, movingConsistencyCheckW :4030-4074
+ * A gfbe_ftab holds W independent tables in HBM (one per window; every call applies the same operation to
+ * all W tables, per-table arguments are arrays of length W). A table is FeatureManager's
+ * std::list<FeaturePerId> in insertion order — the order that defines para_Feature[k]
+ * (getFeatureCount / getDepthVector) — with at most WINDOW_SIZE+1 observations per feature, each
+ * [x y z u v vx vy depth] + cur_td (FeaturePerFrame, feature_manager.h:30-64). Erasures keep the order.
+ * Integer contents are bit-exact against the CPU oracle; depths to the tolerance stated in the tests.
+ * Pose arguments: [P(3) | R(9, row-major)] per frame; extrinsic: [tic(3) | ric(9, row-major)].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gfbe_ftab gfbe_ftab;
+typedef struct gfbe_ftab_options {
+  double init_depth;       /* INIT_DEPTH = 5.0 (parameters.cpp:484) */
+  double min_parallax;     /* MIN_PARALLAX = keyframe_parallax / FOCAL_LENGTH = 10 / 600 (parameters.cpp:351-352, m3dgr.yaml:110) */
+  double focal_length;     /* FOCAL_LENGTH = 600 (parameters.h:23) in the parallax / outlier thresholds */
+  double depth_threshold;  /* triangulateWithDepth: RGB-D depths in [0.1, depth_threshold] are trusted (parameters.cpp:178; yaml) */
+} gfbe_ftab_options;
+void gfbe_ftab_default_options(gfbe_ftab_options *opt);
+gfbe_status gfbe_ftab_create(gfbe_ctx *ctx, int32_t n_tables, int32_t feature_capacity,
+                             const gfbe_ftab_options *opt, gfbe_ftab **out);
+void gfbe_ftab_destroy(gfbe_ctx *ctx, gfbe_ftab *t);
+/* addFeatureCheckParallax. Table w receives the features [offset[w], offset[w+1]) — ascending feature_id, the
+ * iteration order of the reference's std::map — with observation rows obs8 [x y z u v vx vy depth].
+ * Outputs per table: keyframe (1 = the function returns true = MARGIN_OLD), counters
+ * [last_track_num, new_feature_num, long_track_num], avg_parallax (last_average_parallax). */
+gfbe_status gfbe_ftab_add_frame(gfbe_ctx *ctx, gfbe_ftab *t, const int32_t *frame_count, const int32_t *offset,
+                                const int32_t *feature_id, const double *obs8, const double *td,
+                                int32_t *keyframe, int32_t *counters, double *avg_parallax);
+/* removeBackShiftDepth(marg_R, marg_P, new_R, new_P); *_PR = [W][12]. */
+gfbe_status gfbe_ftab_remove_back_shift_depth(gfbe_ctx *ctx, gfbe_ftab *t, const double *marg_PR, const double *new_PR);
+gfbe_status gfbe_ftab_remove_back(gfbe_ctx *ctx, gfbe_ftab *t);
+gfbe_status gfbe_ftab_remove_front(gfbe_ctx *ctx, gfbe_ftab *t, const int32_t *frame_count);
+/* removeOutlier: ids of table w are [offset[w], offset[w+1]). */
+gfbe_status gfbe_ftab_remove_outlier(gfbe_ctx *ctx, gfbe_ftab *t, const int32_t *offset, const int32_t *ids);
+gfbe_status gfbe_ftab_remove_failures(gfbe_ctx *ctx, gfbe_ftab *t);
+gfbe_status gfbe_ftab_clear_depth(gfbe_ctx *ctx, gfbe_ftab *t);
+/* setDepth(x) / getDepthVector(): para_Feature of table w starts at offset[w] (capacity offset[w+1]-offset[w]);
+ * count[w] = getFeatureCount(). */
+gfbe_status gfbe_ftab_set_depth(gfbe_ctx *ctx, gfbe_ftab *t, const int32_t *offset, const double *para_Feature);
+gfbe_status gfbe_ftab_get_depth_vector(gfbe_ctx *ctx, gfbe_ftab *t, const int32_t *offset, double *para_Feature,
+                                       int32_t *count);
+/* triangulate (with_depth = 0) / triangulateWithDepth (1). poses [W][11][12], tic_ric [W][12]. */
+gfbe_status gfbe_ftab_triangulate(gfbe_ctx *ctx, gfbe_ftab *t, const double *poses, const double *tic_ric,
+                                  int32_t with_depth);
+/* mode 0: outliersRejection, 1: movingConsistencyCheckW. ids_out of table w start at offset[w] (ascending, the
+ * iteration order of the reference's std::set); count_out[w] ids are written. */
+gfbe_status gfbe_ftab_check_outliers(gfbe_ctx *ctx, gfbe_ftab *t, const double *poses, const double *tic_ric,
+                                     int32_t mode, const int32_t *offset, int32_t *ids_out, int32_t *count_out);
+gfbe_status gfbe_ftab_size(gfbe_ctx *ctx, gfbe_ftab *t, int32_t *n_features);
+/* Snapshot of table w in list order; obs8 [n][11][8], obs_td [n][11] (rows >= n_obs are zero). Any pointer may be NULL. */
+gfbe_status gfbe_ftab_download(gfbe_ctx *ctx, gfbe_ftab *t, int32_t w, int32_t *feature_id, int32_t *start_frame,
+                               int32_t *n_obs, double *obs8, double *obs_td, double *estimated_depth,
+                               int32_t *estimate_flag, int32_t *solve_flag);
+/* slideWindow()'s shift of the state blocks (estimator.cpp:3700-3858): MARGIN_OLD moves frames 1..WINDOW_SIZE to
+ * 0..WINDOW_SIZE-1 and leaves the newest duplicated at WINDOW_SIZE; MARGIN_SECOND_NEW copies frame WINDOW_SIZE
+ * onto WINDOW_SIZE-1. Host function (the caller owns the state). */
+void gfbe_slide_window_state(gfbe_state *state, int32_t margin_flag);
+
+/* ------------------------------------------------------------------------------------------
  * a4/a5/a7/a9/a10  Factor evaluation on the device, block-CSR output (parity / inspection API).
  * Each evaluates residuals and TANGENT-space Jacobian blocks at the window's current state,
  * exactly what ceres::CostFunction::Evaluate + the manifold lift produce:

@@ -1,0 +1,123 @@
+"""Device-resident feature tables (csrc/gfbe_ftab.hip) vs the CPU oracle (oracle/gfo_ftab.cpp), through the C ABI.
+Integer contents and moved observations are bit-exact; depths: the hand-over of removeBackShiftDepth and setDepth to
+1e-13 relative (same formulas), SVD triangulation to 1e-8 relative (4x4 Gram + Jacobi eigen on the device, one-sided
+Jacobi SVD in the oracle)."""
+import numpy as np
+import pytest
+
+import ftab_model as fm
+from _gfbe_import import gf
+
+abi, synth = gf.abi, gf.synth
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    return gf.Backend(device=0)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_sequences_match_oracle(be, oracle, seed):
+    dev = abi.FeatureTables(be.lib, "gfbe_", be.ctx, n_tables=1, capacity=4096)
+    ref = abi.FeatureTables(oracle.lib, "gfo_", None, n_tables=1, capacity=4096)
+    a, b = fm.OneTable(ref), fm.OneTable(dev)
+    log = fm.drive(np.random.default_rng(seed), [a, b], n_steps=45)
+    for la, lb in log:
+        assert la[0] == lb[0] and tuple(la[1]) == tuple(lb[1])            # keyframe decision, counters
+        assert abs(la[2] - lb[2]) <= 1e-12 * max(1.0, abs(la[2]))         # average parallax (summation order)
+    fm.assert_same_tables(a.snapshot(), b.snapshot(), depth_rtol=1e-13)
+    np.testing.assert_allclose(a.depth_vector(), b.depth_vector(), rtol=1e-13)
+    assert len(a.snapshot()["feature_id"]) > 50
+    dev.close(); ref.close()
+
+
+def test_three_tables_in_one_launch(be, oracle):
+    """W = 3 tables with different contents in every launch == three single-table oracles."""
+    W = 3
+    dev = abi.FeatureTables(be.lib, "gfbe_", be.ctx, n_tables=W, capacity=1024)
+    refs = [abi.FeatureTables(oracle.lib, "gfo_", None, n_tables=1, capacity=1024) for _ in range(W)]
+    rngs = [np.random.default_rng(100 + w) for w in range(W)]
+    state = [dict(next_id=0, alive=[]) for _ in range(W)]
+    for fc_step in range(16):
+        fc = min(fc_step, 10)
+        ids, obs = [], []
+        for w in range(W):
+            i, o, state[w]["alive"], state[w]["next_id"] = fm.random_frame(rngs[w], state[w]["next_id"], state[w]["alive"], 10 + 5 * w)
+            ids.append(i); obs.append(o)
+        kf, cnt, avg = dev.add_frame([fc] * W, ids, obs, [0.001 * w for w in range(W)])
+        for w in range(W):
+            k1, c1, a1 = refs[w].add_frame([fc], [ids[w]], [obs[w]], [0.001 * w])
+            assert kf[w] == k1[0] and cnt[w].tolist() == c1[0].tolist() and abs(avg[w] - a1[0]) <= 1e-12 * max(1, abs(a1[0]))
+        if fc < 10:
+            continue
+        xs = []
+        for w in range(W):
+            L = int((refs[w].download(0)["n_obs"] >= 4).sum())
+            x = 1.0 / rngs[w].uniform(0.5, 9.0, L)
+            x[rngs[w].random(L) < 0.1] *= -1
+            xs.append(x)
+            refs[w].set_depth([x]); refs[w].remove_failures()
+        dev.set_depth(xs); dev.remove_failures()
+        if fc_step % 2:
+            PR = [np.concatenate([rngs[w].normal(0, 0.1, 3), np.eye(3).ravel()]) for w in range(W)]
+            PN = [np.concatenate([rngs[w].normal(0, 0.1, 3), np.eye(3).ravel()]) for w in range(W)]
+            dev.remove_back_shift_depth(PR, PN)
+            for w in range(W):
+                refs[w].remove_back_shift_depth([PR[w]], [PN[w]])
+        else:
+            dev.remove_front([10] * W)
+            for w in range(W):
+                refs[w].remove_front([10])
+    assert dev.size().tolist() == [int(r.size()[0]) for r in refs]
+    for w in range(W):
+        fm.assert_same_tables(refs[w].download(0), dev.download(w), depth_rtol=1e-13)
+    dev.close()
+    for r in refs:
+        r.close()
+
+
+def test_triangulation_and_outlier_checks_match_oracle(be, oracle):
+    scn = synth.Scenario(seed=31, n_landmarks=400, use_wheel=False)
+    fl = scn.feature_list(0, extra_short=30)
+    st = scn.initial_state(0)
+    poses = abi.pose_rows(st["pose"])
+    tic_ric = np.concatenate([scn.tic, scn.ric.ravel()])
+    # replay the list as a tracker stream: feature k (id = k) observed in frames start .. start + n_obs - 1
+    off = np.concatenate([[0], np.cumsum(fl["n_obs"])])
+    frames = {fc: ([], []) for fc in range(11)}
+    rng = np.random.default_rng(4)
+    for k in range(len(fl["n_obs"])):
+        for o in range(fl["n_obs"][k]):
+            fc = fl["start_frame"][k] + o
+            row = fl["obs"][off[k] + o]
+            frames[fc][0].append(k)
+            frames[fc][1].append(list(row) + [rng.uniform(0.05, 12.0)])
+    tabs = [abi.FeatureTables(be.lib, "gfbe_", be.ctx, 1, 1024, options=dict(depth_threshold=10.0)),
+            abi.FeatureTables(oracle.lib, "gfo_", None, 1, 1024, options=dict(depth_threshold=10.0))]
+    for t in tabs:
+        for fc in range(11):
+            t.add_frame([fc], [frames[fc][0]], [np.array(frames[fc][1]).reshape(-1, 8)], [0.0])
+        t.triangulate([poses], [tic_ric])
+    a, b = tabs[1].download(0), tabs[0].download(0)
+    fm.assert_same_tables(a, b, depth_rtol=1e-8)
+    assert (a["estimate_flag"] == 2).sum() > 300
+    # reprojection-error based rejection on the triangulated depths (some are poor: noisy initial poses)
+    for mode in (0, 1):
+        ra, rb = tabs[1].check_outliers([poses], [tic_ric], mode)[0], tabs[0].check_outliers([poses], [tic_ric], mode)[0]
+        assert ra.tolist() == rb.tolist()
+    assert len(tabs[1].check_outliers([poses], [tic_ric], 1)[0]) > 0
+    # RGB-D flavour
+    for t in tabs:
+        t.clear_depth()
+        t.triangulate([poses], [tic_ric], with_depth=True)
+    fm.assert_same_tables(tabs[1].download(0), tabs[0].download(0), depth_rtol=1e-12)
+    for t in tabs:
+        t.close()
+
+
+def test_capacity_overflow_fails_loudly(be):
+    t = abi.FeatureTables(be.lib, "gfbe_", be.ctx, n_tables=1, capacity=8)
+    with pytest.raises(RuntimeError):
+        t.add_frame([0], [list(range(9))], [np.ones((9, 8))], [0.0])
+    t.close()
