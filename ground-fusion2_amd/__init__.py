@@ -6,7 +6,7 @@ The product is csrc/libgfbe.so (hand-written HIP for gfx950 behind the C ABI of 
 this package is the thin ctypes binding + synthetic-input generator. There is NO CPU fallback:
 every compute entry point raises if the HIP library or a GPU is missing.
 """
-from . import abi, synth, dist  # noqa: F401
+from . import abi, synth, dist, stream  # noqa: F401
 from .backend import Backend, BackendError, lib_path, build_native  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,45 @@
+"""Trajectory-level parity: the same 28-keyframe synthetic stream through the HIP library
+(device feature tables + device solve + device pre-integration) and through the CPU oracle. Integer decisions
+(keyframe / marginalisation flag, table sizes, landmark counts, iteration counts) must be identical; poses to
+1e-7 m (RGB-D: 5e-6 m) over 18 consecutive solves (every solve starts from the previous one's output, prior and depths)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _gfbe_import import gf
+
+abi, stream = gf.abi, gf.stream
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rgbd", [False, True])
+def test_stream_matches_oracle(oracle, rgbd):
+    be = gf.Backend(device=0)
+    S = stream.Stream(seed=3, n_kf=28, new_per_frame=50, rgbd=rgbd)
+    opts = dict(min_parallax=14.0 / 600, depth_threshold=6.0)
+    To = abi.FeatureTables(oracle.lib, "gfo_", None, 1, 8192, options=opts)
+    Tg = abi.FeatureTables(be.lib, "gfbe_", be.ctx, 1, 8192, options=opts)
+    ref = stream.run_stream(oracle, To, S, lambda st, flag: oracle.lib.gfo_slide_window_state(C.byref(st), int(flag)), rgbd=rgbd)
+    got = stream.run_stream(be, Tg, S, lambda st, flag: be.lib.gfbe_slide_window_state(C.byref(st), int(flag)), rgbd=rgbd)
+    assert got["flags"] == ref["flags"]
+    assert abi.MARGIN_OLD in ref["flags"] and abi.MARGIN_SECOND_NEW in ref["flags"]
+    assert got["n_features"] == ref["n_features"] and got["n_landmarks"] == ref["n_landmarks"]
+    assert got["iterations"] == ref["iterations"]
+    np.testing.assert_allclose(got["parallax"], ref["parallax"], rtol=1e-12)
+    # the cost carries the prior's constant 1/2 b'^T A'^+ b' — ill-conditioned (cond(A') ~ 1e14, measured 7e-5 relative
+    # between the two implementations, with either square root) and irrelevant for the optimum: the poses below agree to 6e-9 m
+    np.testing.assert_allclose(got["final_cost"], ref["final_cost"], rtol=1e-3)
+    assert abs(got["final_cost"][0] - ref["final_cost"][0]) < 1e-9 * ref["final_cost"][0]    # first solve: no prior yet
+    # mono: 6e-9 m measured. RGB-D (most landmarks constant, the 8-iteration budget ends the solves before convergence, so
+    # the 1e-9 differences of the ill-conditioned prior are amplified): 9e-7 m measured, not growing along the stream.
+    assert np.abs(got["traj"][:, :3] - ref["traj"][:, :3]).max() < (5e-6 if rgbd else 1e-7)
+    assert np.abs(got["traj"][:, 3:] - ref["traj"][:, 3:]).max() < (2e-6 if rgbd else 1e-8)
+    # the final tables: same features, same integer contents, depths to 1e-6 relative after 18 hand-overs
+    a, b = To.download(0), Tg.download(0)
+    for k in ("feature_id", "start_frame", "n_obs", "estimate_flag", "solve_flag"):
+        np.testing.assert_array_equal(a[k], b[k])
+    np.testing.assert_allclose(b["estimated_depth"], a["estimated_depth"], rtol=1e-5 if rgbd else 1e-6)
+    err = np.array([np.linalg.norm(got["traj"][i, :3] - S.truth_pose(10 + i)[0]) for i in range(len(got["traj"]))])
+    assert err.max() < 0.05
+    To.close(); Tg.close(); be.close()
