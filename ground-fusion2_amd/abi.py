@@ -552,7 +552,7 @@ class FeatureTables:
     def check_outliers(self, poses, tic_ric, mode):
         p, e = _f64(poses).reshape(self.W, 11 * 12), _f64(tic_ric).reshape(self.W, 12)
         off = (np.arange(self.W + 1) * self.cap).astype(np.int32)
-        ids, cnt = np.zeros(self.W * self.cap, np.int32), np.zeros(self.W, np.int32)
+        ids, cnt = np.full(self.W * self.cap, -1, np.int32), np.zeros(self.W, np.int32)   # (touched pages: cheap pageable D2H)
         self._check(self._f("check_outliers")(self.ctx, self.h, _pd(p), _pd(e), int(mode), _pi(off), _pi(ids), _pi(cnt)), "check_outliers")
         return [ids[off[w]:off[w] + cnt[w]].copy() for w in range(self.W)]
 

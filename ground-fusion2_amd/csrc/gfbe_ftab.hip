@@ -37,6 +37,8 @@ struct FtabDev {
   double *depth[2], *obs[2], *td[2];   // obs [W][F][NOBS][OW], td [W][F][NOBS]
   int *keep;            // [W][F] scratch: survivor flag / erased observation (+2) / match index
   double *ndepth;       // [W][F] scratch: edited depth
+  int *ids_scratch;     // [W][F] flagged ids of check_outliers (ascending)
+  int *cnt_scratch;     // [W]
   int *err;             // [W] sticky error flags (capacity / more than NOBS observations)
   gfbe_ftab_options opt;
 };
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void k_ftab_triangulate(FtabDev T, int cur, co
 // outliersRejection (mode 0) / movingConsistencyCheckW (mode 1): flags in keep[], then the flagged ids in
 // ascending order (the iteration order of the reference's std::set)
 __global__ __launch_bounds__(FT_THREADS) void k_ftab_outliers(FtabDev T, int cur, const double *poses, const double *tic_ric, int mode,
-                                                              const int *offset, int *ids_out, int *count_out) {
+                                                              int *ids_out, int *count_out) {
   const int w = blockIdx.x, t = threadIdx.x;
   __shared__ int lds[20];
   const int n = T.count[w];
@@ -376,18 +378,32 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_outliers(FtabDev T, int cur
     mine += bad;
   }
   int total;
-  block_exclusive_scan(mine, &total, lds);
-  __threadfence_block();
+  int dst = block_exclusive_scan(mine, &total, lds);
+  // the flagged ids, compacted into LDS; the rank of an id among them is its position in the ascending output
+  extern __shared__ int flagged[];
+  for (int f = f0; f < f1; f++) if (keep[f]) flagged[dst++] = id[f];
   __syncthreads();
-  // rank of each flagged id among the flagged ids (k^2 compares; k is small)
-  const int cap = offset[w + 1] - offset[w];
   for (int f = f0; f < f1; f++) {
     if (!keep[f]) continue;
+    const int me = id[f];
     int rank = 0;
-    for (int g = 0; g < n; g++) rank += (keep[g] && id[g] < id[f]) ? 1 : 0;
-    if (rank < cap) ids_out[offset[w] + rank] = id[f];
+    for (int g = 0; g < total; g++) rank += flagged[g] < me;
+    ids_out[base + rank] = me;
   }
   if (t == 0) count_out[w] = total;
+}
+
+// rows [W][F] with cnt[w] used entries -> one contiguous list (so that the host copies exactly sum(cnt) values)
+__global__ __launch_bounds__(FT_THREADS) void k_ftab_pack(int W, int F, const int *cnt, const int *rows, int *packed) {
+  __shared__ int s_off[2];
+  for (int w = 0, run = 0; w < W; w++) {
+    if (threadIdx.x == 0) { s_off[0] = run; s_off[1] = cnt[w]; }
+    __syncthreads();
+    const int o = s_off[0], n = s_off[1];
+    for (int k = threadIdx.x; k < n; k += FT_THREADS) packed[o + k] = rows[(size_t)w * F + k];
+    run = o + n;
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -458,7 +474,7 @@ void gfbe_ftab_default_options(gfbe_ftab_options *o) {
 }
 
 gfbe_status gfbe_ftab_create(gfbe_ctx *c, int32_t n_tables, int32_t cap, const gfbe_ftab_options *opt, gfbe_ftab **out) {
-  if (!c || !out || n_tables < 1 || cap < 1) return GFBE_BAD_INPUT;
+  if (!c || !out || n_tables < 1 || cap < 1 || cap > 16384) return GFBE_BAD_INPUT;   // 16384: the LDS id list of check_outliers (64 KB)
   if (ctx_device(c) < 0) return GFBE_NO_DEVICE;
   gfbe_ftab *t = new gfbe_ftab();
   *out = t;
@@ -468,7 +484,7 @@ gfbe_status gfbe_ftab_create(gfbe_ctx *c, int32_t n_tables, int32_t cap, const g
   const size_t N = (size_t)n_tables * cap;
   gfbe_status st;
 #define FA(p, n) if ((st = ft_alloc(c, t, &p, n)) != GFBE_OK) return st
-  FA(d.count, n_tables); FA(d.err, n_tables); FA(d.keep, N); FA(d.ndepth, N);
+  FA(d.count, n_tables); FA(d.err, n_tables); FA(d.keep, N); FA(d.ndepth, N); FA(d.ids_scratch, N); FA(d.cnt_scratch, n_tables);
   for (int b = 0; b < 2; b++) {
     FA(d.id[b], N); FA(d.start[b], N); FA(d.nobs[b], N); FA(d.eflag[b], N); FA(d.sflag[b], N);
     FA(d.depth[b], N); FA(d.obs[b], N * NOBS * OW); FA(d.td[b], N * NOBS);
@@ -575,9 +591,22 @@ gfbe_status gfbe_ftab_check_outliers(gfbe_ctx *c, gfbe_ftab *t, const double *po
   {
     Staged s(c);
     double *dp = s.up(poses, 132 * (size_t)W), *de = s.up(tic_ric, 12 * (size_t)W);
-    int *doff = s.up(offset, W + 1), *dids = s.up<int>(nullptr, offset[W]), *dcnt = s.up<int>(nullptr, W);
-    hipLaunchKernelGGL(k_ftab_outliers, dim3(W), dim3(FT_THREADS), 0, ctx_stream(c), t->d, t->cur, dp, de, mode, doff, dids, dcnt);
-    s.down(ids_out, dids, offset[W]); s.down(count_out, dcnt, W);
+    hipLaunchKernelGGL(k_ftab_outliers, dim3(W), dim3(FT_THREADS), sizeof(int) * (size_t)t->d.F, ctx_stream(c), t->d, t->cur, dp, de, mode,
+                       t->d.ids_scratch, t->d.cnt_scratch);
+    hipLaunchKernelGGL(k_ftab_pack, dim3(1), dim3(FT_THREADS), 0, ctx_stream(c), W, t->d.F, t->d.cnt_scratch, t->d.ids_scratch, t->d.keep);
+    s.down(count_out, t->d.cnt_scratch, W);
+  }
+  size_t total = 0;
+  for (int w = 0; w < W; w++) total += count_out[w];
+  if (total) {   // the host copy moves exactly the flagged ids (a pageable device-to-host copy runs at a few 100 MB/s)
+    std::vector<int32_t> tmp(total);
+    FT_CHECK(c, hipMemcpyAsync(tmp.data(), t->d.keep, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx_stream(c)));
+    FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
+    size_t run = 0;
+    for (int w = 0; w < W; w++) {
+      std::memcpy(ids_out + offset[w], tmp.data() + run, sizeof(int32_t) * std::min<size_t>(offset[w + 1] - offset[w], count_out[w]));
+      run += count_out[w];
+    }
   }
   return ft_finish(c, t);
 }

@@ -261,6 +261,7 @@ typedef struct gfbe_ftab_options {
   double depth_threshold;  /* triangulateWithDepth: RGB-D depths in [0.1, depth_threshold] are trusted (parameters.cpp:178; yaml) */
 } gfbe_ftab_options;
 void gfbe_ftab_default_options(gfbe_ftab_options *opt);
+/* feature_capacity <= 16384 features per table. */
 gfbe_status gfbe_ftab_create(gfbe_ctx *ctx, int32_t n_tables, int32_t feature_capacity,
                              const gfbe_ftab_options *opt, gfbe_ftab **out);
 void gfbe_ftab_destroy(gfbe_ctx *ctx, gfbe_ftab *t);

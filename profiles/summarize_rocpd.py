@@ -22,7 +22,7 @@ def main(db_path, out_path=None):
     tot = sum(v[1] for v in stats.values())
     lines = ["%-70s %8s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct")]
     for name, v in sorted(stats.items(), key=lambda kv: -kv[1][1]):
-        short = name.split("(")[0][-70:]
+        short = name.replace("(anonymous namespace)::", "").split("(")[0][-70:]
         lines.append("%-70s %8d %14.1f %12.2f %12.2f %12.2f %6.2f%%" % (short, v[0], v[1], v[1] / v[0], v[2], v[3], 100 * v[1] / tot))
     text = "\n".join(lines)
     print(text)
