@@ -101,7 +101,7 @@ class Options(C.Structure):
     _fields_ = [("max_num_iterations", c_i), ("huber_delta", c_d), ("vis_sqrt_info", c_d), ("g_norm", c_d),
                 ("initial_trust_region_radius", c_d), ("function_tolerance", c_d), ("gradient_tolerance", c_d),
                 ("parameter_tolerance", c_d), ("min_relative_decrease", c_d), ("jacobi_scaling", c_i),
-                ("marg_eps", c_d), ("marg_sqrt", c_i), ("use_graph", c_i)]
+                ("marg_eps", c_d), ("marg_sqrt", c_i), ("use_graph", c_i), ("split_batch", c_i)]
 
 
 class Summary(C.Structure):
@@ -131,6 +131,7 @@ def default_options():
     o.marg_eps = 1e-8
     o.marg_sqrt = 1
     o.use_graph = 0
+    o.split_batch = 1
     return o
 
 

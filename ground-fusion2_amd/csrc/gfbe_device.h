@@ -31,6 +31,7 @@ enum {
   IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost
   WHEEL_PART = 22 * 22 + 22 + 2,
   MAX_IMU = 10, MAX_WHEEL = 10,
+  BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
   HC = 13                     // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)

@@ -168,6 +168,10 @@ typedef struct gfbe_options {
    * call eager, second captured); 0 (default): eager launches — on ROCm 7.2 / MI355X the replay measured 2.50 vs
    * 2.54 ms for one window and 3 % slower at 256 windows. Ignored while profiling / landmark sharding. */
   int32_t use_graph;
+  /* 1 (default): gfbe_batch_upload splits batches of >= 128 windows into two halves that gfbe_batch_solve runs side by
+   * side on two pairs of streams (kernels of different stages share the GPU: +13 % at 256 windows); results per
+   * window are unchanged (every window is independent). 0: one launch sequence for the whole batch. */
+  int32_t split_batch;
 } gfbe_options;
 
 typedef struct gfbe_summary {

@@ -666,7 +666,8 @@ void gfo_default_options(gfbe_options *o) {
   o->initial_trust_region_radius = 1e4; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8; o->min_relative_decrease = 1e-3; o->jacobi_scaling = 1; o->marg_eps = 1e-8;
   o->marg_sqrt = 0;   // the oracle always uses the reference's eigen-decomposition
-  o->use_graph = 0;   // (device option; meaningless on the CPU)
+  o->use_graph = 0;   // (device options; meaningless on the CPU)
+  o->split_batch = 1;
 }
 
 int32_t gfo_sqrt_info(const double *cov, double *out, int32_t n) { return sqrt_info_from_cov(cov, out, n) ? 0 : 1; }

@@ -160,13 +160,15 @@ def test_batch_equals_single_and_is_deterministic(be, oracle):
         assert a["summary"]["cost_history"] == b["summary"]["cost_history"]
 
 
-def test_large_batch_throughput_path(be, oracle):
+@pytest.mark.parametrize("B", [40, 131])
+def test_large_batch_throughput_path(be, oracle, B):
     """Batches of >= 32 windows take the throughput path (k_dense_raw with one lane per window, the dense factors on
-    a second stream beside the visual kernels): same results as the single-window path — 1e-12 relative on the
-    costs (different kernels, same FP64 formulas), poses to 1e-12 m — and repeatable bit for bit."""
+    a second stream beside the visual kernels), batches of >= 128 are additionally solved as two halves side by side
+    on two pairs of streams: same results as the single-window path — 1e-12 relative on the costs (different
+    kernels, same FP64 formulas), poses to 1e-12 m — and repeatable bit for bit."""
     snaps = [synth.Scenario(seed=160 + k, n_landmarks=120 + 30 * k, use_wheel=bool(k % 2)).window(0) for k in range(4)]
     single = [be.solve(s, abi.MARGIN_OLD) for s in snaps]
-    big = [snaps[i % 4] for i in range(40)]
+    big = [snaps[i % 4] for i in range(B)]
     batch = be.solve_batch(big, abi.MARGIN_OLD)
     again = be.solve_batch(big, abi.MARGIN_OLD)
     for i, (b, c) in enumerate(zip(batch, again)):
