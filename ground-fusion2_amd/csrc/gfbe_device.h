@@ -18,11 +18,8 @@ enum {
   MAXOBS = 10,                // factors per landmark (n_obs - 1)
   REC = 42,                   // doubles per visual block-CSR record: r(2) + J(2 x 20)   = 336 B
   NPAIR = NF * NF,            // (imu_i, imu_j) pair slots, index i * 11 + j
-  PAIR_E = 19 * 20 / 2 + 19,  // 190 J^T J entries + 19 J^T r entries of a pose-pair block = 209
-  PAIR_STRIDE = 216,
   VP_STRIDE = 336,            // fused visual partial of one (tile, observation step): T0 16x16 | T1 16x4 | T2 4x4
   XS_LD = 21,                 // LDS row stride of the [J | r] panel (20 + 1)
-  TRI_NV = NV * (NV + 1) / 2, // 2701
   NVP = 80,                   // NV padded to 5 tiles of 16; column 73 carries the landmark gradient
   SCHUR_TILES = 15,           // upper-triangular 16x16 tile pairs of the 80 x 80 block
   SCHUR_STRIDE = SCHUR_TILES * 256, // one partial per (window, start frame): 15 dense tiles
@@ -174,7 +171,6 @@ struct BatchDev {
   // assembled system
   double *H, *g;              // [B][ND*ND], [B][ND]  unscaled J^T J, J^T r of the dense block
   double *E, *eg;             // [B][NV*NV], [B][NV]  sum_l w_l h_l h_l^T, sum_l w_l h_l gl  (unscaled h)
-  double *S;                  // [B][ND*ND]  scaled, regularised, Schur-reduced system / its Cholesky factor
   double *sp, *Dp, *gts, *vp, *yp, *step;   // [B][ND] each
   // debug / inspection outputs (gfbe_eval_factors)
   double *dbg_imu, *dbg_wheel, *dbg_prior;  // [B][MAX_IMU][15*31], [B][MAX_WHEEL][6*23], [B][ND]
@@ -185,7 +181,6 @@ struct BatchDev {
   int *mmeta;                 // [B][4 + 3*GFBE_MAX_PRIOR_BLOCKS]: valid, n, n_blocks, pad, ids, sizes, idx
   double *mx0;                // [B][PRIOR_X0]
   double *timing;             // [B][32] phase time stamps of k_solve (wall_clock64, 10 ns ticks; diagnostics)
-  int *tri_tab;               // [TRI_NV] packed (a' << 8 | b') lookup for the reversed lower-triangular enumeration
 };
 
 enum { PRIOR_X0 = GFBE_NFRAMES * 16 + 32 };

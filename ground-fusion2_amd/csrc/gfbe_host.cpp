@@ -452,16 +452,12 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     std::memcpy(ds.ex_wheel_mask, win.ex_wheel_mask, 6);
   }
   b->algo_bytes_lin = algo_bytes;
-  // reversed lower-triangular enumeration table for the Schur blocks
-  std::vector<int> tri(TRI_NV);
-  for (int a = 0, e = 0; a < NV; a++) for (int bb = 0; bb <= a; bb++, e++) tri[e] = (a << 8) | bb;
-
   gfbe_status st;
 #define UP(field, vec) if ((st = dev_upload(c, b, &d.field, vec)) != GFBE_OK) return st
 #define AL(field, n) if ((st = dev_alloc(c, b, &d.field, (size_t)(n))) != GFBE_OK) return st
   UP(desc, desc); UP(lm_info, lm_info); UP(lm_abi, lm_abi); UP(lm_pts, lm_pts); UP(lm_obs, lm_obs); UP(lm_rec, lm_rec);
   UP(lam0, lam0); UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
-  UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0); UP(tri_tab, tri);
+  UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0);
   AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
   AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1)); AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
   AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
@@ -483,7 +479,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     b->slab_n = nH + ng + nE + ne + nx;
   }
   AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
-  AL(S, 1); AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
+  AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
   AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
   AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
   AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND); AL(mV, (size_t)B * ND * ND);

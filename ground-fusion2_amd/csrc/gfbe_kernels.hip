@@ -339,12 +339,6 @@ __global__ __launch_bounds__(VP_STRIDE) void k_pairsum(BatchDev d, int marg) {
   d.pair_part[((size_t)w * NPAIR + p) * VP_STRIDE + threadIdx.x] = s;
 }
 
-// index of (a,b) in the 209-entry pair block (a,b compact columns 0..18)
-__device__ __forceinline__ int pair_tri(int a, int b) {
-  if (a > b) { const int t = a; a = b; b = t; }
-  return a * 19 - a * (a - 1) / 2 + (b - a);
-}
-
 // =============================================================================================
 // k_dense: blocks 0..9 IMU factors, 10..19 wheel factors, 20 the prior. 64 threads each.
 // mode 0 linearise at current; 1 candidate cost; 2 MARGIN_OLD set at xout (frame-0 IMU/wheel + prior);

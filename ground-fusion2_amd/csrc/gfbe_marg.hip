@@ -21,11 +21,7 @@
 namespace gfd {
 
 // device functions defined in gfbe_kernels.hip are not visible here; re-declare the small index
-// helpers locally (kept in sync by tests/test_gpu_marginalize.py).
-__device__ __forceinline__ int m_pair_tri(int a, int b) {
-  if (a > b) { const int t = a; a = b; b = t; }
-  return a * 19 - a * (a - 1) / 2 + (b - a);
-}
+// helpers locally (the marginalisation parity tests of tests/test_gpu_parity.py exercise both copies).
 __device__ __forceinline__ int m_vis_loc(int a, int j) {   // pair (0, j)
   if (a < 66) { const int f = a / 6; if (f == 0) return a; if (f == j) return 6 + a - 6 * f; return -1; }
   if (a < 72) return 12 + (a - 66);

@@ -8,9 +8,10 @@ scns = [synth.Scenario(seed=20250708 + 2 + 100 * u, n_landmarks=2000, use_wheel=
 be0 = gf.Backend(0)
 firsts = be0.solve_batch([s.window(0) for s in scns], abi.MARGIN_OLD)
 snaps = [s.window(1, state=synth.shift_state_for_next_window(s, r["state"], 1), prior=r["prior"]) for s, r in zip(scns, firsts)]
-B = 256
-for G in (1, 2, 4):
-    bes = [gf.Backend(0) for _ in range(G)]
+B = int(os.environ.get('B', '1024'))
+opt = abi.default_options(); opt.split_batch = 0
+for G in (1, 2, 3, 4, 6, 8):
+    bes = [gf.Backend(0, options=opt) for _ in range(G)]
     batches = [b.batch_upload([snaps[i % 8] for i in range(B // G)]) for b in bes]
     def step():
         for bt in batches:
@@ -21,5 +22,5 @@ for G in (1, 2, 4):
     for _ in range(10): step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
-    print("groups %d: %.3f ms per 256 solves = %.0f solves/s" % (G, dt * 1e3, B / dt))
+    print("groups %d: %.3f ms per %d solves = %.0f solves/s" % (G, dt * 1e3, B // G * G, (B // G * G) / dt))
     for bt in batches: bt.free()
