@@ -204,6 +204,29 @@ def test_graph_replay_is_bit_identical(oracle):
         assert a["summary"]["cost_history"] == g["summary"]["cost_history"]
 
 
+def test_bad_inputs_fail_loudly(be, oracle):
+    """gfbe_status instead of garbage (SURVEY §8b "Errors" row): a factor with imu_j <= imu_i or an out-of-range landmark
+    index is GFBE_BAD_INPUT (3) before anything is launched; a NaN state makes every linear solve fail ->
+    GFBE_NUMERICAL_FAILURE (2), on the device and in the oracle alike."""
+    snap = synth.Scenario(seed=9, n_landmarks=100, use_wheel=True).window(0)
+    bad = dict(snap, vis_imu_j=snap["vis_imu_j"].copy())
+    bad["vis_imu_j"][3] = bad["vis_imu_i"][3]
+    with pytest.raises(RuntimeError, match="status 3"):
+        be.solve(bad, abi.MARGIN_OLD)
+    bad = dict(snap, vis_feature_index=snap["vis_feature_index"].copy())
+    bad["vis_feature_index"][0] = len(snap["para_feature"]) + 5
+    with pytest.raises(RuntimeError, match="status 3"):
+        be.solve(bad, abi.MARGIN_OLD)
+    nan = dict(snap, pose=snap["pose"].copy())
+    nan["pose"][4, 1] = np.nan
+    with pytest.raises(RuntimeError, match="status 2"):
+        be.solve(nan, abi.MARGIN_OLD)
+    with pytest.raises(RuntimeError, match="status 2"):
+        oracle.solve(nan, abi.MARGIN_OLD)
+    # the context stays usable after a failure
+    check_solve(be, oracle, snap, abi.MARGIN_OLD)
+
+
 def test_partial_window_and_empty_visual(be, oracle):
     """frame_count < WINDOW_SIZE (estimator.cpp:3391: no marginalisation) and a window without
     any visual factor (IMU + wheel only)."""
