@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from _gfbe_import import gf
 abi, synth = gf.abi, gf.synth
-be = gf.Backend(0)
+opt = abi.default_options(); opt.split_batch = int(os.environ.get('SPLIT', '0'))
+be = gf.Backend(0, options=opt)
 scns = [synth.Scenario(seed=20250708 + 2 + 100 * u, n_landmarks=int(os.environ.get("L", "2000")), use_wheel=True) for u in range(8)]
 snaps = [s.window(0) for s in scns]
 B = int(os.environ.get("B", "256"))
