@@ -147,7 +147,9 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 // =============================================================================================
 template <int MODE>
 __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_records) {
-  const int w = blockIdx.y, tile = blockIdx.x;
+  // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
+  // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
+  const int w = blockIdx.x, tile = blockIdx.y;
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
@@ -537,7 +539,7 @@ typedef double dbl4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I - 1) / 2 + (J - I); }   // I <= J < 5
 
 __global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
-  const int w = blockIdx.y, s = blockIdx.x;
+  const int w = blockIdx.x, s = blockIdx.y;   // start-frame-major dispatch: the heavy start frame 0 of every window first
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (!marg && (c.done || c.reuse)) return;
@@ -1368,7 +1370,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
 // k_lm_step: back-substitution of the eliminated landmarks and their share of the dogleg scalars.
 // =============================================================================================
 __global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
-  const int w = blockIdx.y, tile = blockIdx.x;
+  const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
@@ -1700,7 +1702,7 @@ void launch_reset(const BatchDev &d, hipStream_t s) {
 }
 void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   if (d.max_tiles == 0) return;
-  const dim3 g(d.max_tiles, d.B), b(LM_TILE);
+  const dim3 g(d.B, d.max_tiles), b(LM_TILE);
   if (mode == 0) hipLaunchKernelGGL(k_vis<0>, g, b, 0, s, d, write_records);
   else if (mode == 1) hipLaunchKernelGGL(k_vis<1>, g, b, 0, s, d, 0);
   else hipLaunchKernelGGL(k_vis<2>, g, b, 0, s, d, write_records);
@@ -1718,7 +1720,7 @@ void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
   if (d.max_tiles == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(marg ? 1 : NF, d.B), dim3(256), 0, s, d, marg);
+  hipLaunchKernelGGL(k_schur, dim3(d.B, marg ? 1 : NF), dim3(256), 0, s, d, marg);
 }
 void launch_xchg_gram(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_gram, dim3(d.B), dim3(64), 0, s, d); }
 void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_cand, dim3(d.B), dim3(64), 0, s, d); }
@@ -1739,7 +1741,7 @@ void launch_solve(const BatchDev &d, hipStream_t s) {
 }
 void launch_lm_step(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles == 0) return;
-  hipLaunchKernelGGL(k_lm_step, dim3(d.max_tiles, d.B), dim3(LM_TILE), 0, s, d);
+  hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
 }
 void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
 void launch_candidate(const BatchDev &d, hipStream_t s) {
