@@ -186,7 +186,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const WinDesc &ds = d.desc[w];
   const int t = threadIdx.x;
   __shared__ MargShared sh;
-  __shared__ double Pm[16 * 16], Pv[16 * 16], Pl[16], Pinv[16 * 16], bm[16];
+  __shared__ double Pm[16 * 16], Pv[16 * 16], Pw[16 * 16], Pl[16], Pinv[16 * 16], bm[16];
   __shared__ int cflag;
   int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
   const double *Xo = d.xout + (size_t)w * NA;
@@ -255,9 +255,15 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE;   // start frame 0 partial (15 dense 16x16 tiles)
   const double *ipart = sh.use_imu ? d.imu_part + ((size_t)w * MAX_IMU + sh.use_imu - 1) * IMU_PART : nullptr;
   const double *wpart = sh.use_wheel ? d.wheel_part + ((size_t)w * MAX_WHEEL + sh.use_wheel - 1) * WHEEL_PART : nullptr;
-  for (int e = t; e < ND * ND; e += blockDim.x) {
-    const int a = e / ND, b = e % ND;
-    if (b > a) continue;
+  // only the dims of the marginalisation (dropped + kept, nn <= 101 of 182) are ever read back: pairs (ia >= ib) of that list
+  const int nn = n + m;
+  for (int e = t; e < nn * (nn + 1) / 2; e += blockDim.x) {
+    int ia = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+    while ((ia + 1) * (ia + 2) / 2 <= e) ia++;
+    while (ia * (ia + 1) / 2 > e) ia--;
+    const int ib = e - ia * (ia + 1) / 2;
+    const int da = ia < m ? sh.drop_dim[ia] : sh.keep_dim[ia - m], db = ib < m ? sh.drop_dim[ib] : sh.keep_dim[ib - m];
+    const int a = max(da, db), b = min(da, db);
     double s = 0.0;
     if (old && a < NV) {
       for (int j = 1; j < NF; j++) {
@@ -294,15 +300,71 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
   if (t < m) bm[t] = bv[sh.drop_dim[t]];
   __syncthreads();
-  if (t < 64) jacobi_eig_wave16(Pm, Pv, m, Pl, t);
-  __syncthreads();
-  for (int e = t; e < m * m; e += blockDim.x) {
-    const int i = e / m, j = e % m;
-    double s = 0.0;
-    for (int k = 0; k < m; k++) if (Pl[k] > d.opt.marg_eps) s += Pv[k * 16 + i] * Pv[k * 16 + j] / Pl[k];
-    Pinv[i * 16 + j] = s;
+  // Fast path: when every eigenvalue of Amm is safely above eps the thresholded pseudo-inverse IS the inverse. One wave
+  // takes the Cholesky factor L (lane = row), the lanes invert it column by column, Pinv = L^-T L^-1, and
+  // lambda_min >= 1 / |Pinv|_F > 4 eps certifies it. Otherwise (rank-deficient / tiny eigenvalues) the eigen-decomposition
+  // with the reference's thresholding runs as before.
+  if (t < 64) {
+    const int li = t & 15;
+    double row[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) row[q] = (li < m && q < m) ? Pm[li * 16 + q] : (li == q ? 1.0 : 0.0);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const double dkk = __shfl(row[k], k, 16);
+      if (!(dkk > 0.0) || !isfinite(dkk)) ok = false;
+      const double lkk = sqrt(dkk), lik = row[k] / lkk;
+      row[k] = (li == k) ? lkk : lik;
+#pragma unroll
+      for (int j = k + 1; j < 16; j++) { const double ljk = __shfl(lik, j, 16); row[j] -= lik * ljk; }
+    }
+    if (t < 16) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) Pv[li * 16 + q] = row[q];      // L (lower part meaningful)
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (t < 16) {                                                   // lane j: column j of L^-1 into Pw
+      const int j = li;
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) if (k >= j) acc -= Pv[i * 16 + k] * x[k];
+        x[i] = i < j ? 0.0 : acc / Pv[i * 16 + i];
+        Pw[i * 16 + j] = x[i];
+      }
+    }
+    if (t == 0) cflag = ok ? 1 : 0;
   }
   __syncthreads();
+  double fro = 0.0;
+  for (int e = t; e < 256; e += blockDim.x) {
+    const int i = e >> 4, j = e & 15;
+    double s = 0.0;
+    for (int k = 0; k < 16; k++) s += Pw[k * 16 + i] * Pw[k * 16 + j];
+    s = (i < m && j < m) ? s : 0.0;
+    Pinv[e] = s;
+    fro += s * s;
+  }
+  for (int o = 32; o > 0; o >>= 1) fro += __shfl_down(fro, o, 64);
+  if ((t & 63) == 0 && t < 256) Pl[t >> 6] = fro;
+  __syncthreads();
+  const bool fast = cflag == 1 && isfinite(Pl[0] + Pl[1] + Pl[2] + Pl[3]) && 1.0 / sqrt(Pl[0] + Pl[1] + Pl[2] + Pl[3]) > 4.0 * d.opt.marg_eps;
+  __syncthreads();
+  if (!fast) {
+    if (t < 64) jacobi_eig_wave16(Pm, Pv, m, Pl, t);
+    __syncthreads();
+    for (int e = t; e < m * m; e += blockDim.x) {
+      const int i = e / m, j = e % m;
+      double s = 0.0;
+      for (int k = 0; k < m; k++) if (Pl[k] > d.opt.marg_eps) s += Pv[k * 16 + i] * Pv[k * 16 + j] / Pl[k];
+      Pinv[i * 16 + j] = s;
+    }
+    __syncthreads();
+  }
   MSTAMP(3);
   // T = A_rm * Pinv (n x m) kept in J0's storage; then A' and b' (compact, n x n) into r0/J0 staging
   double *T = J0;   // n x 16
