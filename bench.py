@@ -138,7 +138,7 @@ def main():
                 tot = 0.0
                 for fn, key in (("r1_pmc_fetch.txt", "FETCH_SIZE"), ("r1_pmc_write.txt", "WRITE_SIZE")):
                     lines = open(os.path.join(ROOT, "profiles", fn)).read().splitlines()
-                    i = [k for k, ln in enumerate(lines) if "k_visILi0E" in ln and "grid=(2304,512,1)" in ln][0]   # one half of the batch
+                    i = [k for k, ln in enumerate(lines) if "k_visILi0E" in ln and "grid=(32768,36,1)" in ln][0]   # one half of the batch
                     tot += float([ln for ln in lines[i + 1:i + 4] if key in ln][0].split()[1]) * 1024.0
                 traffic = tot
             except Exception:
