@@ -582,3 +582,53 @@ def ftab_to_feature_list(tab):
             tds.append(tab["obs_td"][k, o])
     return dict(start_frame=tab["start_frame"], n_obs=tab["n_obs"], obs=np.array(rows).reshape(-1, 7), obs_td=np.array(tds),
                 estimated_depth=tab["estimated_depth"], estimate_flag=tab["estimate_flag"])
+
+
+# ---------------------------------------------------------------------------------------------
+# f3: global_fusion pose graph (gfbe_pg_* on the device, gfo_pg_* in the oracle)
+# ---------------------------------------------------------------------------------------------
+class PoseGraph:
+    """Chain pose graph: poses [n,7] = t(3) q(wxyz); rel_i [m]; rel_meas [m,7]; fix_i [k]; fix_meas [k,4] = x y z var."""
+
+    def __init__(self, lib, prefix, ctx):
+        self.lib, self.prefix, self.ctx = lib, prefix, ctx
+        for name in ("pg_eval", "pg_solve"):
+            f = getattr(lib, prefix + name)
+            f.restype = c_i
+        getattr(lib, prefix + "pg_eval").argtypes = [C.c_void_p, c_i, PD, c_i, PI, PD, c_d, c_d, c_i, PI, PD, c_d, PD, PD, PD, PD]
+        getattr(lib, prefix + "pg_solve").argtypes = [C.c_void_p, c_i, PD, c_i, PI, PD, c_d, c_d, c_i, PI, PD, c_d, c_i, PD, C.POINTER(Summary)]
+
+    def _args(self, g):
+        pose = _f64(g["pose"]).reshape(-1, 7)
+        ri, rm = _i32(g["rel_i"]), _f64(g["rel_meas"]).reshape(-1, 7)
+        fi, fmm = _i32(g["fix_i"]), _f64(g["fix_meas"]).reshape(-1, 4)
+        return pose, ri, rm, fi, fmm
+
+    def eval(self, g, t_var=0.1, q_var=0.01, huber=1.0):
+        pose, ri, rm, fi, fmm = self._args(g)
+        r, J, fr, cost = np.zeros((len(ri), 6)), np.zeros((len(ri), 6, 12)), np.zeros((len(fi), 3)), np.zeros(1)
+        rc = getattr(self.lib, self.prefix + "pg_eval")(self.ctx, len(pose), _pd(pose), len(ri), _pi(ri), _pd(rm), t_var, q_var, len(fi),
+                                                        _pi(fi), _pd(fmm), huber, _pd(r), _pd(J), _pd(fr), _pd(cost))
+        if rc != OK:
+            raise RuntimeError("%spg_eval failed with status %d" % (self.prefix, rc))
+        return dict(rel_r=r, rel_J=J, fix_r=fr, cost=float(cost[0]))
+
+    def solve(self, g, t_var=0.1, q_var=0.01, huber=1.0, max_iterations=5):
+        pose, ri, rm, fi, fmm = self._args(g)
+        out, sm = np.zeros_like(pose), Summary()
+        rc = getattr(self.lib, self.prefix + "pg_solve")(self.ctx, len(pose), _pd(pose), len(ri), _pi(ri), _pd(rm), t_var, q_var, len(fi),
+                                                         _pi(fi), _pd(fmm), huber, int(max_iterations), _pd(out), C.byref(sm))
+        if rc not in (OK, NO_CONVERGENCE):
+            raise RuntimeError("%spg_solve failed with status %d" % (self.prefix, rc))
+        return dict(pose=out, summary=summary_to_dict(sm), status=rc)
+
+
+def pg_plus(x, d6):
+    """ceres::QuaternionParameterization::Plus on q (w,x,y,z) + identity on t; d6 = [dq(3), dt(3)]."""
+    x, d6 = np.asarray(x, float), np.asarray(d6, float)
+    nrm = np.linalg.norm(d6[:3])
+    dq = np.concatenate([[np.cos(nrm)], np.sin(nrm) / nrm * d6[:3]]) if nrm > 0 else np.array([1.0, 0, 0, 0])
+    a, b = dq, x[3:]
+    q = np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                  a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+    return np.concatenate([x[:3] + d6[3:], q])

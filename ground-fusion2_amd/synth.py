@@ -449,3 +449,53 @@ def shift_state_for_next_window(scn, solved_state, k_next):
     for key in ("ex_pose", "ex_pose_wheel", "ix_wheel", "td", "td_wheel"):
         st[key] = solved_state[key]
     return st
+
+
+# ------------------------------------------------------------------ BASELINE configs[3]: global_fusion pose graph
+def pose_graph(n=5000, seed=20250708 + 4, fix_every=10, noise=True):
+    """n poses on a planar random walk, one RelativeRTError per consecutive pair (the VIO
+    odometry: sigma_t 0.1 * |step|, sigma_q 0.01 rad — weights t_var 0.1, q_var 0.01 as in globalOpt.cpp:171-173), a
+    position fix TError every `fix_every`-th pose (sigma 0.5 m). Poses are [t(3), q(w,x,y,z)] (globalOpt.cpp:46-47).
+    The initial guess is the dead-reckoned (drifting) chain, as the reference seeds globalPoseMap from the VIO poses."""
+    rng = np.random.default_rng(seed)
+    sc = 1.0 if noise else 0.0
+
+    def q_wxyz(yaw, pitch=0.0, roll=0.0):
+        q = rot2q(rz(yaw) @ ry(pitch) @ rx(roll))          # x y z w
+        q = q / np.linalg.norm(q)
+        return np.array([q[3], q[0], q[1], q[2]])
+
+    def qm(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    def R_of(q):
+        w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    truth = np.zeros((n, 7))
+    yaw, p = 0.0, np.zeros(3)
+    for i in range(n):
+        truth[i] = np.concatenate([p, q_wxyz(yaw, 0.01 * np.sin(0.01 * i), 0.01 * np.cos(0.013 * i))])
+        yaw += rng.normal(0, 0.05)
+        p = p + np.array([np.cos(yaw), np.sin(yaw), 0.0]) * 0.1 + np.array([0, 0, rng.normal(0, 0.002)])
+    rel_i = np.arange(n - 1, dtype=np.int32)
+    rel_meas = np.zeros((n - 1, 7))
+    for k in range(n - 1):
+        Ri = R_of(truth[k, 3:])
+        t = Ri.T @ (truth[k + 1, :3] - truth[k, :3]) + sc * rng.normal(0, 0.002, 3)
+        q = qm(truth[k, 3:] * np.array([1, -1, -1, -1]), truth[k + 1, 3:])
+        dth = sc * rng.normal(0, 0.0005, 3)
+        q = qm(q, np.concatenate([[1.0], 0.5 * dth]))
+        rel_meas[k] = np.concatenate([t, q / np.linalg.norm(q)])
+    fix_i = np.arange(0, n, fix_every, dtype=np.int32)
+    fix_meas = np.column_stack([truth[fix_i, :3] + sc * rng.normal(0, 0.5, (len(fix_i), 3)), np.full(len(fix_i), 0.5)])
+    init = np.zeros((n, 7))
+    init[0] = truth[0]
+    for k in range(n - 1):
+        Ri = R_of(init[k, 3:])
+        q = qm(init[k, 3:], rel_meas[k, 3:])
+        init[k + 1] = np.concatenate([init[k, :3] + Ri @ rel_meas[k, :3], q / np.linalg.norm(q)])
+    return dict(pose=init, truth=truth, rel_i=rel_i, rel_meas=rel_meas, fix_i=fix_i, fix_meas=fix_meas)

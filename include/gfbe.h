@@ -307,6 +307,31 @@ gfbe_status gfbe_ftab_download(gfbe_ctx *ctx, gfbe_ftab *t, int32_t w, int32_t *
 void gfbe_slide_window_state(gfbe_state *state, int32_t margin_flag);
 
 /* ------------------------------------------------------------------------------------------
+ * f3  global_fusion pose graph (BASELINE configs[3]):
+ *       GlobalOptimization::optimize     global_fusion/src/globalOpt.cpp:107-236
+ *       RelativeRTError / TError         global_fusion/src/Factors.h:26-114 (ceres::AutoDiffCostFunction in the
+ *                                        reference; analytic tangent Jacobians here)
+ * A chain of n poses [t(3) | q(w,x,y,z)] (the quaternion order of globalOpt.cpp:46-47, NOT the x,y,z,w of the VIO
+ * blocks), one RelativeRTError between consecutive poses (rel_i[k], rel_i[k] + 1) with measurement [t(3) | q(wxyz)]
+ * and the reference's constant weights 1 / t_var, 1 / q_var (0.1, 0.01: globalOpt.cpp:171-173), and Huber-robustified
+ * (delta 1.0) position fixes TError [x y z var] on a subset of the poses (GPS / AprilTag, :177-185). Solver = what
+ * ceres::Solve does with the reference's options (:117-121): Levenberg-Marquardt trust region, Jacobi scaling,
+ * max_num_iterations 5, quaternions on ceres::QuaternionParameterization (x <- [cos|d|, sin|d|/|d| d] * x) — the normal
+ * equations are block-tridiagonal (6 x 6 blocks), factorised by a block Cholesky recurrence instead of
+ * SPARSE_NORMAL_CHOLESKY's general sparse factorisation.
+ * gfbe_pg_eval: residuals and tangent Jacobians at `pose` (columns: dq_i(3) t_i(3) dq_j(3) t_j(3)); cost includes the
+ * Huber loss of the fixes. Any output pointer may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+gfbe_status gfbe_pg_eval(gfbe_ctx *ctx, int32_t n_poses, const double *pose, int32_t n_rel, const int32_t *rel_i,
+                         const double *rel_meas, double t_var, double q_var, int32_t n_fix, const int32_t *fix_i,
+                         const double *fix_meas, double huber_delta, double *rel_r, double *rel_J, double *fix_r,
+                         double *cost);
+gfbe_status gfbe_pg_solve(gfbe_ctx *ctx, int32_t n_poses, const double *pose_in, int32_t n_rel, const int32_t *rel_i,
+                          const double *rel_meas, double t_var, double q_var, int32_t n_fix, const int32_t *fix_i,
+                          const double *fix_meas, double huber_delta, int32_t max_num_iterations, double *pose_out,
+                          gfbe_summary *summary);
+
+/* ------------------------------------------------------------------------------------------
  * a4/a5/a7/a9/a10  Factor evaluation on the device, block-CSR output (parity / inspection API).
  * Each evaluates residuals and TANGENT-space Jacobian blocks at the window's current state,
  * exactly what ceres::CostFunction::Evaluate + the manifold lift produce:
