@@ -30,7 +30,7 @@ EXPORTS = [
     "gfbe_ftab_remove_back_shift_depth", "gfbe_ftab_remove_back", "gfbe_ftab_remove_front", "gfbe_ftab_remove_outlier",
     "gfbe_ftab_remove_failures", "gfbe_ftab_clear_depth", "gfbe_ftab_set_depth", "gfbe_ftab_get_depth_vector",
     "gfbe_ftab_triangulate", "gfbe_ftab_check_outliers", "gfbe_ftab_size", "gfbe_ftab_download", "gfbe_slide_window_state",
-    "gfbe_pg_eval", "gfbe_pg_solve",
+    "gfbe_pg_eval", "gfbe_pg_solve", "gfbe_lio_linearize",
 ]
 
 

@@ -332,6 +332,24 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *ctx, int32_t n_poses, const double *pose_in,
                           gfbe_summary *summary);
 
 /* ------------------------------------------------------------------------------------------
+ * f4  LIO scan residuals (BASELINE configs[4]): point-to-plane factors of the LiDAR
+ *     odometry, evaluated and reduced to normal equations on the device (the voxel neighbour search that produces
+ *     the planes stays on the CPU):
+ *       LidarPlaneNormFactor::Evaluate     lio/src/liw/lidarFactor.cpp:18-51   (ct = 0: one pose [t | q(x,y,z,w)])
+ *       CTLidarPlaneNormFactor::Evaluate   lio/src/liw/lidarFactor.cpp:59-120  (ct = 1: begin and end pose, the point
+ *                                          is taken at slerp(alpha) / lerp(alpha) between them)
+ *     residual = sqrt_info * weight * (n . (R p + t) + offset); tangent = RotationParameterization (q * deltaQ(d),
+ *     poseParameterization.cpp:31-42). Jacobian columns: ct = 0: [t(3) | theta(3)]; ct = 1: [t_b | theta_b | t_e | theta_e]
+ *     (the parameter-block order of the factor). pts are the points the factor stores (point_body / raw_keypoint,
+ *     already in the IMU frame). Outputs (any may be NULL): r [n], J [n][6 or 12], H [d][d] = J^T J, g [d] = J^T r,
+ *     cost = 1/2 sum r^2.
+ * ------------------------------------------------------------------------------------------ */
+gfbe_status gfbe_lio_linearize(gfbe_ctx *ctx, int32_t ct, int32_t n, const double *pts, const double *normals,
+                               const double *offsets, const double *alpha, const double *weights, double sqrt_info,
+                               const double *pose_begin, const double *pose_end, double *r, double *J, double *H,
+                               double *g, double *cost);
+
+/* ------------------------------------------------------------------------------------------
  * a4/a5/a7/a9/a10  Factor evaluation on the device, block-CSR output (parity / inspection API).
  * Each evaluates residuals and TANGENT-space Jacobian blocks at the window's current state,
  * exactly what ceres::CostFunction::Evaluate + the manifold lift produce:
