@@ -50,7 +50,10 @@ def main():
     if args.gpus > 1 or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm. GFBE_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
+        # ranks (ranks then share devices): a test aid, never used by the driver.
+        dist.init_process_group(os.environ.get("GFBE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     be = gf.Backend(device=local_rank)          # raises if the HIP extension / GPU is missing
     be.set_stream(torch.cuda.current_stream().cuda_stream)
