@@ -294,19 +294,30 @@ __global__ __launch_bounds__(128) void k_pg_candidate(int n, const double *Bs, c
   step2_i[i] = s2; xn2_i[i] = x2;
 }
 
+// All device buffers of one call come out of ONE allocation (a bump allocator over a slab sized by a dry run):
+// the solve makes ~30 buffers, and hipMalloc / hipFree cost more than the kernels at this problem size.
 struct PgBuffers {
   gfbe_ctx *c;
-  std::vector<void *> allocs;
+  char *slab = nullptr;
+  size_t cap = 0, used = 0;
+  bool dry = true;
   explicit PgBuffers(gfbe_ctx *ctx) : c(ctx) {}
-  ~PgBuffers() { (void)hipStreamSynchronize(ctx_stream(c)); for (void *p : allocs) (void)hipFree(p); }
+  ~PgBuffers() { (void)hipStreamSynchronize(ctx_stream(c)); if (slab) (void)hipFree(slab); }
+  bool commit() {   // end of the dry run: allocate what was asked for, restart
+    cap = used; used = 0; dry = false;
+    if (hipMalloc((void **)&slab, std::max<size_t>(cap, 256)) != hipSuccess) return false;
+    (void)hipMemsetAsync(slab, 0, std::max<size_t>(cap, 256), ctx_stream(c));
+    return true;
+  }
   template <typename T>
   T *dev(size_t n, const T *h = nullptr) {
-    void *q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-    allocs.push_back(q);
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    const size_t at = used;
+    used += bytes;
+    if (dry) return nullptr;
+    T *q = (T *)(slab + at);
     if (h && n) (void)hipMemcpyAsync(q, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_stream(c));
-    else (void)hipMemsetAsync(q, 0, std::max<size_t>(n, 1) * sizeof(T), ctx_stream(c));
-    return (T *)q;
+    return q;
   }
 };
 
@@ -351,11 +362,16 @@ gfbe_status gfbe_pg_eval(gfbe_ctx *c, int32_t n, const double *pose, int32_t n_r
   gfbe_status st = pg_prepare(c, n, n_rel, rel_i, n_fix, fix_i, fix_meas, rel_of, fix_begin, fix_sorted, fix_order);
   if (st != GFBE_OK) return st;
   PgBuffers buf(c);
-  PgDev P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
-             buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
-  double *dpose = buf.dev<double>((size_t)7 * n, pose), *dcost = buf.dev<double>(n), *dr = buf.dev<double>((size_t)6 * n_rel),
-         *dJ = buf.dev<double>((size_t)72 * n_rel), *dfr = buf.dev<double>((size_t)3 * n_fix);
-  double *Hd = buf.dev<double>((size_t)36 * n), *Ho = buf.dev<double>((size_t)36 * n), *g = buf.dev<double>((size_t)6 * n);
+  PgDev P;
+  double *dpose, *dcost, *dr, *dJ, *dfr, *Hd, *Ho, *g;
+  for (int pass = 0; pass < 2; pass++) {
+    P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
+         buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
+    dpose = buf.dev<double>((size_t)7 * n, pose); dcost = buf.dev<double>(n); dr = buf.dev<double>((size_t)6 * n_rel);
+    dJ = buf.dev<double>((size_t)72 * n_rel); dfr = buf.dev<double>((size_t)3 * n_fix);
+    Hd = buf.dev<double>((size_t)36 * n); Ho = buf.dev<double>((size_t)36 * n); g = buf.dev<double>((size_t)6 * n);
+    if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_eval: device allocation failed"); return GFBE_DEVICE_ERROR; }
+  }
   hipLaunchKernelGGL(k_pg_lin, dim3((n + 127) / 128), dim3(128), 0, ctx_stream(c), P, dpose, dcost, Hd, Ho, g, dr, dJ, dfr);
   std::vector<double> tmp;
   const double total = host_sum(c, dcost, n, tmp);
@@ -381,17 +397,25 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
   max_it = std::min(max_it, 15);
   hipStream_t s = ctx_stream(c);
   PgBuffers buf(c);
-  PgDev P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
-             buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
-  double *x = buf.dev<double>((size_t)7 * n, pose_in), *cand = buf.dev<double>((size_t)7 * n);
-  double *per = buf.dev<double>(n), *per2 = buf.dev<double>(n), *per3 = buf.dev<double>(n);
-  double *Hd = buf.dev<double>((size_t)36 * n), *Ho = buf.dev<double>((size_t)36 * n), *g = buf.dev<double>((size_t)6 * n);
-  double *scale = buf.dev<double>((size_t)6 * n), *diag2 = buf.dev<double>((size_t)6 * n), *Bs = buf.dev<double>((size_t)36 * n);
-  double *A0 = buf.dev<double>((size_t)36 * n), *C0 = buf.dev<double>((size_t)36 * n);
-  double *Ab[2] = {buf.dev<double>((size_t)36 * n), buf.dev<double>((size_t)36 * n)}, *Bb[2] = {buf.dev<double>((size_t)36 * n), buf.dev<double>((size_t)36 * n)};
-  double *Cb[2] = {buf.dev<double>((size_t)36 * n), buf.dev<double>((size_t)36 * n)}, *db[2] = {buf.dev<double>((size_t)6 * n), buf.dev<double>((size_t)6 * n)};
-  double *d0 = buf.dev<double>((size_t)6 * n), *y = buf.dev<double>((size_t)6 * n);
-  int *fail = buf.dev<int>(1);
+  PgDev P;
+  double *x, *cand, *per, *per2, *per3, *Hd, *Ho, *g, *scale, *diag2, *Bs, *A0, *C0, *Ab[2], *Bb[2], *Cb[2], *db[2], *d0, *y;
+  int *fail;
+  for (int pass = 0; pass < 2; pass++) {
+    P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
+         buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
+    x = buf.dev<double>((size_t)7 * n, pose_in); cand = buf.dev<double>((size_t)7 * n);
+    per = buf.dev<double>(n); per2 = buf.dev<double>(n); per3 = buf.dev<double>(n);
+    Hd = buf.dev<double>((size_t)36 * n); Ho = buf.dev<double>((size_t)36 * n); g = buf.dev<double>((size_t)6 * n);
+    scale = buf.dev<double>((size_t)6 * n); diag2 = buf.dev<double>((size_t)6 * n); Bs = buf.dev<double>((size_t)36 * n);
+    A0 = buf.dev<double>((size_t)36 * n); C0 = buf.dev<double>((size_t)36 * n);
+    for (int q = 0; q < 2; q++) {
+      Ab[q] = buf.dev<double>((size_t)36 * n); Bb[q] = buf.dev<double>((size_t)36 * n); Cb[q] = buf.dev<double>((size_t)36 * n);
+      db[q] = buf.dev<double>((size_t)6 * n);
+    }
+    d0 = buf.dev<double>((size_t)6 * n); y = buf.dev<double>((size_t)6 * n);
+    fail = buf.dev<int>(1);
+    if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_solve: device allocation failed"); return GFBE_DEVICE_ERROR; }
+  }
   const dim3 g128((n + 127) / 128), b128(128), g64((n + 63) / 64), b64(64);
   std::vector<double> tmp;
   gfbe_summary sm;
