@@ -30,7 +30,7 @@ EXPORTS = [
     "gfbe_ftab_remove_back_shift_depth", "gfbe_ftab_remove_back", "gfbe_ftab_remove_front", "gfbe_ftab_remove_outlier",
     "gfbe_ftab_remove_failures", "gfbe_ftab_clear_depth", "gfbe_ftab_set_depth", "gfbe_ftab_get_depth_vector",
     "gfbe_ftab_triangulate", "gfbe_ftab_check_outliers", "gfbe_ftab_size", "gfbe_ftab_download", "gfbe_slide_window_state",
-    "gfbe_pg_eval", "gfbe_pg_solve", "gfbe_lio_linearize",
+    "gfbe_pg_eval", "gfbe_pg_solve", "gfbe_lio_linearize", "gfbe_batch_upload_tables", "gfbe_batch_feature_count",
 ]
 
 
@@ -124,6 +124,24 @@ class Backend(abi.CApi):
         self.check(self.lib.gfbe_batch_upload(self.ctx, len(holders), arr, C.byref(batch)), "batch_upload")
         return Batch(self, batch, holders)
 
+    def batch_upload_tables(self, tables, snaps):
+        """snaps: window snapshots WITHOUT visual factors (state, pre-integrations, prior, flags); the landmarks of window w
+        come from table w of `tables` (abi.FeatureTables on this library) without leaving the device."""
+        holders = []
+        for s in snaps:
+            s = dict(s)
+            for k in ("vis_feature_index", "vis_imu_i", "vis_imu_j", "vis_pts_i", "vis_pts_j", "vis_vel_i", "vis_vel_j", "vis_td_i", "vis_td_j"):
+                s[k] = np.zeros(0)
+            s["para_feature"], s["feature_const"] = np.zeros(0), np.zeros(0, np.uint8)
+            holders.append(abi.WindowHolder(s))
+        arr = (C.POINTER(abi.Window) * len(holders))(*[C.pointer(h.c) for h in holders])
+        batch = C.c_void_p()
+        self.lib.gfbe_batch_upload_tables.restype = abi.c_i
+        self.check(self.lib.gfbe_batch_upload_tables(self.ctx, tables.h, len(holders), arr, C.byref(batch)), "batch_upload_tables")
+        for w, h in enumerate(holders):
+            h.n_feature_override = int(self.lib.gfbe_batch_feature_count(batch, w))
+        return Batch(self, batch, holders)
+
     def solve_batch(self, snaps, margin_flag=abi.MARGIN_NONE):
         b = self.batch_upload(snaps)
         try:
@@ -168,7 +186,7 @@ class Batch:
     def download(self):
         n = self.n
         states = (abi.State * n)()
-        feats = [np.zeros(h.n_feature) for h in self.holders]
+        feats = [np.zeros(getattr(h, "n_feature_override", h.n_feature)) for h in self.holders]
         fptr = (abi.PD * n)(*[abi._pd(f) for f in feats])
         priors = [abi.PriorHolder() for _ in range(n)]
         pptr = (C.POINTER(abi.Prior) * n)(*[C.pointer(p.c) for p in priors])

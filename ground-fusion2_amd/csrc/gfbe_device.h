@@ -5,6 +5,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <vector>
+
 #include "../../include/gfbe.h"
 
 namespace gfd {
@@ -214,4 +217,31 @@ void launch_accept(const BatchDev &d, hipStream_t s);
 void launch_reanchor(const BatchDev &d, hipStream_t s);
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s);
 
+// ---- device-resident feature tables (gfbe_ftab.hip; shared with the batch upload that reads them)
+enum { FT_NOBS = GFBE_WINDOW_SIZE + 1, FT_OW = 8, FT_BINS = NF * 8,
+       FT_LAY_BIN = 1, FT_LAY_GRP = 1 + FT_BINS, FT_LAY_PAIR = 1 + FT_BINS + NF, FT_LAY_STRIDE = 1 + FT_BINS + NF + NPAIR + 1 };   // bins: (start frame, factors 3..10) of a landmark
+struct FtabDev {
+  int W, F;             // tables, capacity (features per table)
+  int *count;           // [W]
+  int *id[2], *start[2], *nobs[2], *eflag[2], *sflag[2];
+  double *depth[2], *obs[2], *td[2];   // obs [W][F][FT_NOBS][FT_OW], td [W][F][FT_NOBS]
+  int *keep;            // [W][F] scratch: survivor flag / erased observation (+2) / match index
+  double *ndepth;       // [W][F] scratch: edited depth
+  int *ids_scratch;     // [W][F] flagged ids of check_outliers (ascending)
+  int *cnt_scratch;     // [W]
+  int *err;             // [W] sticky error flags (capacity / more than FT_NOBS observations)
+  gfbe_ftab_options opt;
+};
+// landmarks (features with >= 4 observations) of tables [w0, w0 + n): counts[w][0] = L, [1] = K, [2 + bin] per (start, factors)
+void launch_ftab_count(const FtabDev &T, int cur, int w0, int n, int *counts, hipStream_t s);
+// fills the landmark arrays of a batch from the tables (layout tables from the host: per window FT_BINS slot bases, NF group
+// bases, NPAIR + 1 pair_begin, lm_off); slot_of [n][F] receives the slot of landmark k (list order) for the download
+void launch_ftab_pack(const FtabDev &T, int cur, int w0, int n, const BatchDev &d, const int *layout, int *slot_of, hipStream_t s);
+
 }  // namespace gfd
+
+struct gfbe_ftab {
+  gfd::FtabDev d;
+  int cur = 0;
+  std::vector<void *> allocs;
+};

@@ -26,22 +26,9 @@ using namespace gfd;
 
 namespace {
 
-constexpr int NOBS = GFBE_WINDOW_SIZE + 1;   // observation slots per feature
-constexpr int OW = 8;                        // x y z u v vx vy depth
+constexpr int NOBS = FT_NOBS;   // observation slots per feature
+constexpr int OW = FT_OW;       // x y z u v vx vy depth
 constexpr int FT_THREADS = 1024;
-
-struct FtabDev {
-  int W, F;             // tables, capacity (features per table)
-  int *count;           // [W]
-  int *id[2], *start[2], *nobs[2], *eflag[2], *sflag[2];
-  double *depth[2], *obs[2], *td[2];   // obs [W][F][NOBS][OW], td [W][F][NOBS]
-  int *keep;            // [W][F] scratch: survivor flag / erased observation (+2) / match index
-  double *ndepth;       // [W][F] scratch: edited depth
-  int *ids_scratch;     // [W][F] flagged ids of check_outliers (ascending)
-  int *cnt_scratch;     // [W]
-  int *err;             // [W] sticky error flags (capacity / more than NOBS observations)
-  gfbe_ftab_options opt;
-};
 
 enum { OP_BACK_SHIFT = 0, OP_BACK = 1, OP_FRONT = 2, OP_OUTLIER = 3, OP_FAILURES = 4 };
 
@@ -393,6 +380,83 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_outliers(FtabDev T, int cur
   if (t == 0) count_out[w] = total;
 }
 
+// ---- landmarks of a table -> the solver's landmark arrays (gfbe_batch_upload_tables) ------------------------
+// Landmarks = features with >= 4 observations, in list order (getFeatureCount / the factor loop of
+// estimator.cpp:3330-3358). Bin of a landmark: (start frame s, m = observations - 1 in 3..10) -> s * 8 + (m - 3).
+__global__ __launch_bounds__(FT_THREADS) void k_ftab_count(FtabDev T, int cur, int w0, int *counts) {
+  const int w = w0 + blockIdx.x, t = threadIdx.x;
+  __shared__ int hist[FT_BINS + 2];
+  for (int q = t; q < FT_BINS + 2; q += FT_THREADS) hist[q] = 0;
+  __syncthreads();
+  const int n = T.count[w];
+  const size_t base = (size_t)w * T.F;
+  for (int f = t; f < n; f += FT_THREADS) {
+    const int m = T.nobs[cur][base + f] - 1, s = T.start[cur][base + f];
+    if (m < 3) continue;
+    atomicAdd(&hist[0], 1);
+    atomicAdd(&hist[1], m);
+    atomicAdd(&hist[2 + s * 8 + (m - 3)], 1);
+  }
+  __syncthreads();
+  for (int q = t; q < FT_BINS + 2; q += FT_THREADS) counts[(size_t)blockIdx.x * (FT_BINS + 2) + q] = hist[q];
+}
+
+// layout per window (ints): [0] lm_off, [1 .. 1+FT_BINS) first slot of every bin relative to lm_off (groups sorted by start
+// frame, longer tracks first), [.. + NF) first slot of every start-frame group, [.. + NPAIR+1) pair_begin.
+enum { LAY_BIN = FT_LAY_BIN, LAY_GRP = FT_LAY_GRP, LAY_PAIR = FT_LAY_PAIR, LAY_STRIDE = FT_LAY_STRIDE };
+__global__ __launch_bounds__(FT_THREADS) void k_ftab_landmarks(FtabDev T, int cur, int w0, BatchDev d, const int *layout, int *slot_of) {
+  const int wl = blockIdx.x, w = w0 + wl, t = threadIdx.x;
+  __shared__ int lds[20];
+  const int *lay = layout + (size_t)wl * LAY_STRIDE;
+  const int n = T.count[w];
+  const size_t base = (size_t)w * T.F, TL = d.tot_lm;
+  const int *start = T.start[cur] + base, *nobs = T.nobs[cur] + base, *eflag = T.eflag[cur] + base;
+  const double *depth = T.depth[cur] + base, *obs = T.obs[cur] + base * NOBS * OW, *td = T.td[cur] + base * NOBS;
+  int *keep = T.keep + base;       // scratch: slot of feature f (or -1)
+  const int chunk = (n + FT_THREADS - 1) / FT_THREADS, f0 = t * chunk, f1 = min(n, f0 + chunk);
+  // landmark index in list order
+  int mine = 0;
+  for (int f = f0; f < f1; f++) mine += nobs[f] >= 4;
+  int total;
+  int lidx = block_exclusive_scan(mine, &total, lds);
+  // rank inside its bin in list order: one block scan per non-empty bin
+  for (int f = f0; f < f1; f++) keep[f] = -1;
+  for (int bin = 0; bin < FT_BINS; bin++) {
+    const int bin_first = lay[LAY_BIN + bin];
+    int v = 0;
+    for (int f = f0; f < f1; f++) v += (nobs[f] >= 4 && start[f] * 8 + (nobs[f] - 4) == bin) ? 1 : 0;
+    int tot_bin;
+    int r = block_exclusive_scan(v, &tot_bin, lds);
+    if (tot_bin == 0) continue;     // (uniform)
+    for (int f = f0; f < f1; f++)
+      if (nobs[f] >= 4 && start[f] * 8 + (nobs[f] - 4) == bin) keep[f] = bin_first + r++;
+  }
+  const int lm_off = lay[0];
+  for (int f = f0; f < f1; f++) {
+    if (nobs[f] < 4) continue;
+    const int s = start[f], m = nobs[f] - 1, rel = keep[f], slot = lm_off + rel;
+    d.lm_info[slot] = s | (m << 8) | ((eflag[f] == 1 ? 1 : 0) << 16) | (1 << 24);
+    d.lm_abi[slot] = lidx;
+    d.lam0[slot] = 1.0 / depth[f];
+    slot_of[(size_t)wl * T.F + lidx] = slot;
+    lidx++;
+    const double *o0 = obs + (size_t)f * NOBS * OW;
+    d.lm_pts[0 * TL + slot] = o0[0]; d.lm_pts[1 * TL + slot] = o0[1]; d.lm_pts[2 * TL + slot] = o0[2];
+    d.lm_pts[3 * TL + slot] = o0[5]; d.lm_pts[4 * TL + slot] = o0[6]; d.lm_pts[5 * TL + slot] = td[(size_t)f * NOBS];
+    const int in_group = rel - lay[LAY_GRP + s];
+    for (int k = 0; k < m; k++) {
+      const double *oj = o0 + (size_t)(1 + k) * OW;
+      double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
+      ob[0] = oj[0]; ob[TL] = oj[1]; ob[2 * TL] = oj[5]; ob[3 * TL] = oj[6]; ob[4 * TL] = td[(size_t)f * NOBS + 1 + k];
+      d.lm_rec[(size_t)k * TL + slot] = lay[LAY_PAIR + s * NF + s + 1 + k] + in_group;   // slot order inside a pair = group order
+    }
+  }
+}
+__global__ void k_fill(double *p, size_t n, double v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 // rows [W][F] with cnt[w] used entries -> one contiguous list (so that the host copies exactly sum(cnt) values)
 __global__ __launch_bounds__(FT_THREADS) void k_ftab_pack(int W, int F, const int *cnt, const int *rows, int *packed) {
   __shared__ int s_off[2];
@@ -409,12 +473,6 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_pack(int W, int F, const in
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------
-struct gfbe_ftab {
-  FtabDev d;
-  int cur = 0;
-  std::vector<void *> allocs;
-};
-
 namespace {
 #define FT_CHECK(c, call)                                                                                      \
   do {                                                                                                         \
@@ -463,6 +521,17 @@ gfbe_status ft_finish(gfbe_ctx *c, gfbe_ftab *t) {
   return GFBE_OK;
 }
 }  // namespace
+
+namespace gfd {
+void launch_ftab_count(const FtabDev &T, int cur, int w0, int n, int *counts, hipStream_t s) {
+  hipLaunchKernelGGL(k_ftab_count, dim3(n), dim3(FT_THREADS), 0, s, T, cur, w0, counts);
+}
+void launch_ftab_pack(const FtabDev &T, int cur, int w0, int n, const BatchDev &d, const int *layout, int *slot_of, hipStream_t s) {
+  if (d.tot_lm > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)((d.tot_lm + 255) / 256)), dim3(256), 0, s, d.lam0, (size_t)d.tot_lm, 1.0);
+  (void)hipMemsetAsync(d.lm_abi, 0xFF, sizeof(int) * (size_t)d.tot_lm, s);     // padding slots: -1
+  hipLaunchKernelGGL(k_ftab_landmarks, dim3(n), dim3(FT_THREADS), 0, s, T, cur, w0, d, layout, slot_of);
+}
+}  // namespace gfd
 
 extern "C" {
 

@@ -273,7 +273,10 @@ gfbe_status dev_upload(gfbe_ctx *c, gfbe_batch *b, T **p, const std::vector<T> &
 // ---------------------------------------------------------------------------------------------
 // Upload: pack windows into the device layout.
 // ---------------------------------------------------------------------------------------------
-static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out) {
+// tabs != nullptr: the visual factors of window w come from table tab0 + w of the device-resident feature tables
+// (wins[w]->vis, n_feature, para_Feature, feature_const are ignored); the landmark arrays are then filled on the device.
+static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs = nullptr,
+                              int tab0 = 0) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   if (c->device < 0 || !c->stream) { c->err = "HIP device context required (no CPU fallback)"; return GFBE_NO_DEVICE; }
   HIPCHK(c, hipSetDevice(c->device));
@@ -295,15 +298,53 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   struct LmTmp { int start, m, abi; std::vector<int> fac; };
   std::vector<std::vector<LmTmp>> all_lms(B);
   int tot_lm = 0, tot_rec = 0, max_tiles = 0;
+  std::vector<int> tcounts, tlayout;     // table source: per window [L, K, bins], layout table for the pack kernel
+  if (tabs) {
+    if (tab0 < 0 || tab0 + B > tabs->d.W) { c->err = "gfbe_batch_upload_tables: more windows than tables"; return GFBE_BAD_INPUT; }
+    int *dcounts = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dcounts, sizeof(int) * (size_t)B * (FT_BINS + 2)));
+    launch_ftab_count(tabs->d, tabs->cur, tab0, B, dcounts, c->stream);
+    tcounts.resize((size_t)B * (FT_BINS + 2));
+    HIPCHK(c, hipMemcpyAsync(tcounts.data(), dcounts, sizeof(int) * tcounts.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dcounts);
+    tlayout.assign((size_t)B * FT_LAY_STRIDE, 0);
+  }
   for (int w = 0; w < B; w++) {
     const gfbe_window &win = *wins[w];
     WinDesc &ds = desc[w];
     std::memset(&ds, 0, sizeof ds);
-    const int L = win.n_feature, K = win.vis.n_factor;
+    const int L = tabs ? tcounts[(size_t)w * (FT_BINS + 2)] : win.n_feature, K = tabs ? tcounts[(size_t)w * (FT_BINS + 2) + 1] : win.vis.n_factor;
     if (L < 0 || K < 0 || win.frame_count < 0 || win.frame_count > GFBE_WINDOW_SIZE || win.n_imu > MAX_IMU || win.n_wheel > MAX_WHEEL) {
       c->err = "window " + std::to_string(w) + ": bad sizes"; return GFBE_BAD_INPUT;
     }
     ds.L = L; ds.K = K; ds.frame_count = win.frame_count;
+    if (tabs) {   // layout from the per-bin counts: groups by start frame (tile aligned), longer tracks first inside a group
+      const int *cnt = &tcounts[(size_t)w * (FT_BINS + 2) + 2];
+      int *lay = &tlayout[(size_t)w * FT_LAY_STRIDE];
+      ds.lm_off = tot_lm;
+      ds.tile_off = (int)tile_start.size();
+      b->L[w] = L;
+      lay[0] = tot_lm;
+      int slots = 0;
+      for (int s = 0; s < NF; s++) {
+        ds.sf_tile_begin[s] = slots / LM_TILE;
+        lay[FT_LAY_GRP + s] = slots;
+        int in_group = 0;
+        for (int m = MAXOBS; m >= 3; m--) { lay[FT_LAY_BIN + s * 8 + (m - 3)] = slots + in_group; in_group += cnt[s * 8 + (m - 3)]; }
+        const int padded = (in_group + LM_TILE - 1) / LM_TILE * LM_TILE;
+        for (int t = 0; t < padded / LM_TILE; t++) tile_start.push_back(s);
+        slots += padded;
+      }
+      ds.sf_tile_begin[NF] = slots / LM_TILE;
+      ds.lm_slots = slots;
+      ds.n_tiles = slots / LM_TILE;
+      max_tiles = std::max(max_tiles, ds.n_tiles);
+      tot_lm += slots;
+      ds.rec_off = tot_rec;
+      tot_rec += K;
+      continue;
+    }
     std::vector<LmTmp> &lms = all_lms[w];
     lms.resize(L);
     for (int l = 0; l < L; l++) { lms[l].start = -1; lms[l].m = 0; lms[l].abi = l; }
@@ -363,13 +404,21 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     std::vector<LmTmp> &lms = all_lms[w];
     // pair-major record positions, assigned in slot order
     std::vector<int> pair_cnt(NPAIR + 1, 0);
-    for (int k = 0; k < ds.K; k++) pair_cnt[win.vis.imu_i[k] * NF + win.vis.imu_j[k]]++;
+    if (tabs) {   // factors of pair (s, s+1+k) = landmarks of start frame s with more than k factors
+      const int *cnt = &tcounts[(size_t)w * (FT_BINS + 2) + 2];
+      for (int s = 0; s < NF; s++)
+        for (int k = 0; k < MAXOBS && s + 1 + k < NF; k++)
+          for (int m = std::max(k + 1, 3); m <= MAXOBS; m++) pair_cnt[s * NF + s + 1 + k] += cnt[s * 8 + (m - 3)];
+    } else {
+      for (int k = 0; k < ds.K; k++) pair_cnt[win.vis.imu_i[k] * NF + win.vis.imu_j[k]]++;
+    }
     int run = 0;
     for (int p = 0; p < NPAIR; p++) { ds.pair_begin[p] = run; run += pair_cnt[p]; }
     ds.pair_begin[NPAIR] = run;
+    if (tabs) std::memcpy(&tlayout[(size_t)w * FT_LAY_STRIDE + FT_LAY_PAIR], ds.pair_begin, sizeof(int) * (NPAIR + 1));
     std::vector<int> fill(ds.pair_begin, ds.pair_begin + NPAIR);
     std::vector<std::pair<int, int>> by_slot;
-    for (int l = 0; l < ds.L; l++) by_slot.emplace_back(b->slot_of[w][l], l);
+    if (!tabs) for (int l = 0; l < ds.L; l++) by_slot.emplace_back(b->slot_of[w][l], l);
     std::sort(by_slot.begin(), by_slot.end());
     for (auto &sl : by_slot) {
       const int slot = sl.first, l = sl.second;
@@ -435,7 +484,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       const int i = win.wheel_frame[k];
       used[i] = used[i + 1] = used[GFBE_BLK_EX_WHEEL] = used[GFBE_BLK_SX] = used[GFBE_BLK_SY] = used[GFBE_BLK_SW] = used[GFBE_BLK_TD_WHEEL] = true;
     }
-    for (int k = 0; k < ds.K; k++) { used[win.vis.imu_i[k]] = used[win.vis.imu_j[k]] = used[GFBE_BLK_EX_CAM] = used[GFBE_BLK_TD] = true; }
+    for (int p = 0; p < NPAIR; p++) if (pair_cnt[p] > 0) { used[p / NF] = used[p % NF] = used[GFBE_BLK_EX_CAM] = used[GFBE_BLK_TD] = true; }
     for (int q = 0; q < GFBE_BLK_COUNT; q++) {
       bool cst;
       if (q < GFBE_BLK_SB0) cst = win.pose_const[q] || q > win.frame_count;
@@ -455,8 +504,13 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   gfbe_status st;
 #define UP(field, vec) if ((st = dev_upload(c, b, &d.field, vec)) != GFBE_OK) return st
 #define AL(field, n) if ((st = dev_alloc(c, b, &d.field, (size_t)(n))) != GFBE_OK) return st
-  UP(desc, desc); UP(lm_info, lm_info); UP(lm_abi, lm_abi); UP(lm_pts, lm_pts); UP(lm_obs, lm_obs); UP(lm_rec, lm_rec);
-  UP(lam0, lam0); UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
+  UP(desc, desc);
+  if (tabs) {
+    AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL); AL(lam0, TL);
+  } else {
+    UP(lm_info, lm_info); UP(lm_abi, lm_abi); UP(lm_pts, lm_pts); UP(lm_obs, lm_obs); UP(lm_rec, lm_rec); UP(lam0, lam0);
+  }
+  UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
   UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0);
   AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
   AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1)); AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
@@ -486,6 +540,18 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   AL(timing, (size_t)B * 32); AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
 #undef UP
 #undef AL
+  if (tabs) {   // landmark arrays straight from the device-resident tables; the slot of every landmark comes back for the download
+    int *dlay = nullptr, *dslot = nullptr;
+    HIPCHK(c, hipMalloc((void **)&dlay, sizeof(int) * tlayout.size()));
+    HIPCHK(c, hipMalloc((void **)&dslot, sizeof(int) * (size_t)B * tabs->d.F));
+    HIPCHK(c, hipMemcpyAsync(dlay, tlayout.data(), sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, c->stream));
+    launch_ftab_pack(tabs->d, tabs->cur, tab0, B, d, dlay, dslot, c->stream);
+    std::vector<int> hs((size_t)B * tabs->d.F);
+    HIPCHK(c, hipMemcpyAsync(hs.data(), dslot, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dlay); (void)hipFree(dslot);
+    for (int w = 0; w < B; w++) b->slot_of[w].assign(hs.begin() + (size_t)w * tabs->d.F, hs.begin() + (size_t)w * tabs->d.F + b->L[w]);
+  }
   { Timed t(c, "k_prep", 0); launch_prep(d, c->stream); launch_asm_table(d, c->stream); }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
@@ -494,14 +560,15 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
 
 extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b);
 
-extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out) {
+// Batches of >= BATCH_SPLIT_MIN_B windows become two halves solved side by side on two stream pairs.
+static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   const bool split = B >= BATCH_SPLIT_MIN_B && c->world == 1 && c->opt.split_batch;
   const int nA = split ? (B + 1) / 2 : B;
-  gfbe_status st = upload_one(c, nA, wins, out);
+  gfbe_status st = upload_one(c, nA, wins, out, tabs, 0);
   if (st != GFBE_OK || !split) return st;
   gfbe_batch *a = *out;
-  st = upload_one(c, B - nA, wins + nA, &a->second);
+  st = upload_one(c, B - nA, wins + nA, &a->second, tabs, nA);
   if (st == GFBE_OK && (hipStreamCreateWithFlags(&a->lane2.s, hipStreamNonBlocking) != hipSuccess ||
                         hipStreamCreateWithFlags(&a->lane2.aux, hipStreamNonBlocking) != hipSuccess ||
                         hipEventCreateWithFlags(&a->lane2.fork, hipEventDisableTiming) != hipSuccess ||
@@ -513,6 +580,24 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
   }
   if (st != GFBE_OK) { gfbe_batch_free(c, a); *out = nullptr; }
   return st;
+}
+
+extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out) {
+  return upload_halves(c, B, wins, out, nullptr);
+}
+
+// Same as gfbe_batch_upload, with the visual factors of window w taken from table w of `t` on the device.
+extern "C" gfbe_status gfbe_batch_upload_tables(gfbe_ctx *c, gfbe_ftab *t, int32_t B, const gfbe_window *const *wins, gfbe_batch **out) {
+  if (!c || !t || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
+  if (c->world > 1) { c->err = "gfbe_batch_upload_tables: not available with landmark sharding"; return GFBE_BAD_INPUT; }
+  return upload_halves(c, B, wins, out, t);
+}
+
+extern "C" int32_t gfbe_batch_feature_count(const gfbe_batch *b, int32_t w) {
+  if (!b || w < 0) return -1;
+  const int nA = (int)b->L.size();
+  if (w < nA) return b->L[w];
+  return b->second && w - nA < (int)b->second->L.size() ? b->second->L[w - nA] : -1;
 }
 
 extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {

@@ -77,8 +77,10 @@ def propagate(pose, sb, samples, first, g_norm):
     return np.concatenate([P, q]), np.concatenate([V, ba, bg])
 
 
-def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True):
-    """engine: abi.CApi (solve / build_visual_factors / preintegrate_*); tables: abi.FeatureTables (W = 1) of the same
+def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True, device_handoff=False):
+    """device_handoff (HIP library only): the solver reads its landmarks from the resident tables (gfbe_batch_upload_tables)
+    instead of the host building the factor list from a table download.
+    engine: abi.CApi (solve / build_visual_factors / preintegrate_*); tables: abi.FeatureTables (W = 1) of the same
     library; slide_fn(state_struct, flag): the library's slide_window_state. Returns dict(traj [n,7], flags, costs, sizes)."""
     scn = stream.scn
     W = abi.WINDOW_SIZE
@@ -105,10 +107,10 @@ def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True):
         if rgbd:
             tables.triangulate([poses], [tic_ric], with_depth=True)       # if (DEPTH) triangulateWithDepth (estimator.cpp:1143-1146)
         tables.triangulate([poses], [tic_ric], with_depth=False)
-        fl = abi.ftab_to_feature_list(tables.download(0))
         snap = dict(st)
         snap["frame_count"] = W
-        snap.update(engine.build_visual_factors(fl))
+        if not device_handoff:
+            snap.update(engine.build_visual_factors(abi.ftab_to_feature_list(tables.download(0))))
         snap["imu"] = engine.preintegrate_imu([merged(s) for s in imu_slots], scn.ba_est, scn.bg_est,
                                               (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W))
         snap["imu_frame"] = np.arange(W, dtype=np.int32)
@@ -117,7 +119,13 @@ def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True):
                                                       (synth.VEL_N_WHEEL, synth.GYR_N_WHEEL))
             snap["wheel_frame"] = np.arange(W, dtype=np.int32)
         snap.update(ex_cam_const=1, ex_wheel_const=1, ix_wheel_const=1, td_const=1, td_wheel_const=1, prior=prior)
-        res = engine.solve(snap, flag)
+        if device_handoff:
+            batch = engine.batch_upload_tables(tables, [snap])
+            batch.solve(flag)
+            res = batch.download()[0]
+            batch.free()
+        else:
+            res = engine.solve(snap, flag)
         st = res["state"]
         prior = res["prior"]
         tables.set_depth([res["feature"]])

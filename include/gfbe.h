@@ -301,6 +301,17 @@ gfbe_status gfbe_ftab_size(gfbe_ctx *ctx, gfbe_ftab *t, int32_t *n_features);
 gfbe_status gfbe_ftab_download(gfbe_ctx *ctx, gfbe_ftab *t, int32_t w, int32_t *feature_id, int32_t *start_frame,
                                int32_t *n_obs, double *obs8, double *obs_td, double *estimated_depth,
                                int32_t *estimate_flag, int32_t *solve_flag);
+struct gfbe_batch;
+/* gfbe_batch_upload with the visual part of window w read from table w of `t` ON THE DEVICE (landmarks = features with
+ * >= 4 observations in list order, para_Feature[k] = 1 / estimated_depth, constant when estimate_flag == 1:
+ * estimator.cpp:3330-3358): wins[w]->vis, n_feature, para_Feature and feature_const are ignored; state, pre-integrations,
+ * prior and the constant flags come from wins[w]. gfbe_batch_download returns the features in list order, ready for
+ * gfbe_ftab_set_depth. n_windows <= the number of tables. */
+gfbe_status gfbe_batch_upload_tables(gfbe_ctx *ctx, gfbe_ftab *t, int32_t n_windows, const gfbe_window *const *win,
+                                     struct gfbe_batch **out);
+/* Landmarks of window w of a batch (= the length of out_feature[w] in gfbe_batch_download; getFeatureCount(),
+ * feature_manager.cpp:56-68); -1 for a bad index. */
+int32_t gfbe_batch_feature_count(const struct gfbe_batch *batch, int32_t w);
 /* slideWindow()'s shift of the state blocks (estimator.cpp:3700-3858): MARGIN_OLD moves frames 1..WINDOW_SIZE to
  * 0..WINDOW_SIZE-1 and leaves the newest duplicated at WINDOW_SIZE; MARGIN_SECOND_NEW copies frame WINDOW_SIZE
  * onto WINDOW_SIZE-1. Host function (the caller owns the state). */

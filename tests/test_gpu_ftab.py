@@ -121,3 +121,106 @@ def test_capacity_overflow_fails_loudly(be):
     with pytest.raises(RuntimeError):
         t.add_frame([0], [list(range(9))], [np.ones((9, 8))], [0.0])
     t.close()
+
+
+def _fill_tables(tables, streams):
+    for fc in range(abi.WINDOW_SIZE + 1):
+        tables.add_frame([fc] * len(streams), [S.frames[fc][0] for S in streams], [S.frames[fc][1] for S in streams], [0.0] * len(streams))
+
+
+def _stream_window(be, S):
+    """The window snapshot of frames 0..10 of stream S without its visual part, the pose rows, [tic | ric]."""
+    scn = S.scn
+    Wn = abi.WINDOW_SIZE
+    st = scn.initial_state(0)
+    snap = dict(st)
+    snap["frame_count"] = Wn
+    snap["imu"] = be.preintegrate_imu([scn.imu_raw[i] for i in range(Wn)], scn.ba_est, scn.bg_est, (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W))
+    snap["imu_frame"] = np.arange(Wn, dtype=np.int32)
+    snap["wheel"] = be.preintegrate_wheel([scn.wheel_raw[i] for i in range(Wn)], [1.0, 1.0, 1.0, 0.0], (synth.VEL_N_WHEEL, synth.GYR_N_WHEEL))
+    snap["wheel_frame"] = np.arange(Wn, dtype=np.int32)
+    snap.update(ex_cam_const=1, ex_wheel_const=1, ix_wheel_const=1, td_const=1, td_wheel_const=1, prior=None)
+    return snap, abi.pose_rows(st["pose"]), np.concatenate([scn.tic, scn.ric.ravel()])
+
+
+def test_table_fed_batch_equals_host_upload(be):
+    """gfbe_batch_upload_tables (landmark arrays packed on the device from the resident tables) == gfbe_batch_upload of
+    the factors the host builds from the downloaded tables: same slots, same records, so every output is bit-identical."""
+    W = 3
+    stream = gf.stream
+    tables = abi.FeatureTables(be.lib, "gfbe_", be.ctx, n_tables=W, capacity=4096, options=dict(min_parallax=14.0 / 600, depth_threshold=6.0))
+    streams = [stream.Stream(seed=21 + w, n_kf=12, new_per_frame=40 + 25 * w, rgbd=(w == 1)) for w in range(W)]
+    _fill_tables(tables, streams)
+    snaps, poses, tr = [], [], []
+    for w in range(W):
+        s, p, t = _stream_window(be, streams[w])
+        snaps.append(s); poses.append(p); tr.append(t)
+    tables.triangulate(poses, tr, with_depth=True)         # table 1 holds measured depths: constant landmarks (estimate_flag 1)
+    tables.triangulate(poses, tr, with_depth=False)
+    full = []
+    for w in range(W):
+        tab = tables.download(w)
+        assert (tab["estimate_flag"] == 1).any() == (w == 1)
+        s = dict(snaps[w])
+        s.update(be.build_visual_factors(abi.ftab_to_feature_list(tab)))
+        full.append(s)
+    assert len({len(s["para_feature"]) for s in full}) == W and min(len(s["para_feature"]) for s in full) > 100
+    for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
+        a = be.batch_upload(full)
+        b = be.batch_upload_tables(tables, snaps)
+        a.solve(flag); b.solve(flag)
+        ra, rb = a.download(), b.download()
+        a.free(); b.free()
+        for x, y in zip(ra, rb):
+            assert x["status"] == y["status"]
+            assert x["summary"] == y["summary"]
+            np.testing.assert_array_equal(x["feature"], y["feature"])
+            for k in x["state"]:
+                np.testing.assert_array_equal(np.asarray(x["state"][k]), np.asarray(y["state"][k]))
+            assert (x["prior"] is None) == (y["prior"] is None) == (flag == abi.MARGIN_SECOND_NEW)   # no previous prior: nothing to carry
+            for k in ("J0", "r0", "x0", "block_id", "block_idx") if x["prior"] else ():
+                np.testing.assert_array_equal(x["prior"][k], y["prior"][k])
+    # the solved depths go back into the tables exactly as through the host list
+    tables.set_depth([r["feature"] for r in rb])
+    for w in range(W):
+        lm = tables.download(w)["n_obs"] >= 4
+        np.testing.assert_array_equal(tables.download(w)["estimated_depth"][lm], 1.0 / rb[w]["feature"])
+    tables.close()
+
+
+def test_table_fed_batch_bad_inputs(be):
+    tables = abi.FeatureTables(be.lib, "gfbe_", be.ctx, n_tables=1, capacity=1024)
+    S = gf.stream.Stream(seed=5, n_kf=12, new_per_frame=5)
+    _fill_tables(tables, [S])
+    snap, _, _ = _stream_window(be, S)
+    with pytest.raises(RuntimeError, match="more windows than tables"):
+        be.batch_upload_tables(tables, [snap, snap])
+    tables.close()
+
+
+def test_table_fed_large_batch_two_halves(be):
+    """130 tables -> the batch is split into two halves (tables 0..64 and 65..129) exactly as gfbe_batch_upload splits it."""
+    W = 130
+    base = [gf.stream.Stream(seed=31 + q, n_kf=12, new_per_frame=12 + 6 * q) for q in range(4)]
+    streams = [base[w % 4] for w in range(W)]
+    tables = abi.FeatureTables(be.lib, "gfbe_", be.ctx, n_tables=W, capacity=512)
+    _fill_tables(tables, streams)
+    win = [_stream_window(be, S) for S in base]
+    snaps = [win[w % 4][0] for w in range(W)]
+    tables.triangulate([win[w % 4][1] for w in range(W)], [win[w % 4][2] for w in range(W)], with_depth=False)
+    full = []
+    for w in range(W):
+        s = dict(snaps[w])
+        s.update(be.build_visual_factors(abi.ftab_to_feature_list(tables.download(w))))
+        full.append(s)
+    a, b = be.batch_upload(full), be.batch_upload_tables(tables, snaps)
+    assert [be.lib.gfbe_batch_feature_count(b.h, w) for w in (0, 64, 65, 129, 130)] == [len(full[w]["para_feature"]) for w in (0, 64, 65, 129)] + [-1]
+    a.solve(abi.MARGIN_OLD); b.solve(abi.MARGIN_OLD)
+    ra, rb = a.download(), b.download()
+    a.free(); b.free()
+    for x, y in zip(ra, rb):
+        assert x["summary"] == y["summary"]
+        np.testing.assert_array_equal(x["feature"], y["feature"])
+        np.testing.assert_array_equal(x["state"]["pose"], y["state"]["pose"])
+        np.testing.assert_array_equal(x["prior"]["J0"], y["prior"]["J0"])
+    tables.close()

@@ -43,3 +43,25 @@ def test_stream_matches_oracle(oracle, rgbd):
     err = np.array([np.linalg.norm(got["traj"][i, :3] - S.truth_pose(10 + i)[0]) for i in range(len(got["traj"]))])
     assert err.max() < 0.05
     To.close(); Tg.close(); be.close()
+
+
+def test_stream_device_handoff_is_bit_identical():
+    """The same stream with the solver fed from the resident tables (gfbe_batch_upload_tables: no table download, no host
+    factor list) — every pose, cost and depth equals the host-list path bit for bit."""
+    be = gf.Backend(device=0)
+    S = stream.Stream(seed=4, n_kf=20, new_per_frame=50, rgbd=True)
+    opts = dict(min_parallax=14.0 / 600, depth_threshold=6.0)
+    outs, tabs = [], []
+    for handoff in (False, True):
+        T = abi.FeatureTables(be.lib, "gfbe_", be.ctx, 1, 8192, options=opts)
+        outs.append(stream.run_stream(be, T, S, lambda st, flag: be.lib.gfbe_slide_window_state(C.byref(st), int(flag)), rgbd=True,
+                                      device_handoff=handoff))
+        tabs.append(T.download(0))
+        T.close()
+    a, b = outs
+    assert a["flags"] == b["flags"] and a["iterations"] == b["iterations"] and a["n_landmarks"] == b["n_landmarks"]
+    assert a["final_cost"] == b["final_cost"]
+    np.testing.assert_array_equal(a["traj"], b["traj"])
+    for k in tabs[0]:
+        np.testing.assert_array_equal(tabs[0][k], tabs[1][k])
+    be.close()
