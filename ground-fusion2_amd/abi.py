@@ -653,3 +653,42 @@ def lio_linearize(lib, prefix, ctx, ct, pts, normals, offsets, alpha, weights, s
     if rc != OK:
         raise RuntimeError("%slio_linearize failed with status %d" % (prefix, rc))
     return dict(r=r, J=J, H=H, g=g, cost=float(cost[0]))
+
+
+# ---------------------------------------------------------------------------------------------
+# f2: optional in-window factors, evaluation only (gfbe_plane_eval / gfbe_anchor_eval / gfbe_orientation_subset_plus)
+# ---------------------------------------------------------------------------------------------
+def plane_eval(lib, prefix, ctx, pose, ex_wheel, plane_R, plane_Z, noise_inv):
+    pose = _f64(pose).reshape(-1, 7)
+    n = len(pose)
+    ex, q, ni = _f64(ex_wheel), _f64(plane_R), _f64(noise_inv)
+    r, J, cost = np.zeros((n, 3)), np.zeros((n, 3, 16)), np.zeros(1)
+    f = getattr(lib, prefix + "plane_eval")
+    f.restype = c_i
+    f.argtypes = [C.c_void_p, c_i, PD, PD, PD, c_d, PD, PD, PD, PD]
+    rc = f(ctx, n, _pd(pose), _pd(ex), _pd(q), float(plane_Z), _pd(ni), _pd(r), _pd(J), _pd(cost))
+    if rc != OK:
+        raise RuntimeError("%splane_eval failed with status %d" % (prefix, rc))
+    return dict(r=r, J=J, cost=float(cost[0]))
+
+
+def anchor_eval(lib, prefix, ctx, pose, anchor, sqrt_info=120.0):
+    pose, anchor = _f64(pose).reshape(-1, 7), _f64(anchor).reshape(-1, 7)
+    n = len(pose)
+    r, J, cost = np.zeros((n, 6)), np.zeros((n, 6, 6)), np.zeros(1)
+    f = getattr(lib, prefix + "anchor_eval")
+    f.restype = c_i
+    f.argtypes = [C.c_void_p, c_i, PD, PD, c_d, PD, PD, PD]
+    rc = f(ctx, n, _pd(pose), _pd(anchor), float(sqrt_info), _pd(r), _pd(J), _pd(cost))
+    if rc != OK:
+        raise RuntimeError("%sanchor_eval failed with status %d" % (prefix, rc))
+    return dict(r=r, J=J, cost=float(cost[0]))
+
+
+def orientation_subset_plus(lib, prefix, q, delta, constant=(0, 0, 1)):
+    q, d, m, out = _f64(q), _f64(delta), _u8(constant), np.zeros(4)
+    f = getattr(lib, prefix + "orientation_subset_plus")
+    f.restype = None
+    f.argtypes = [PD, PD, PU8, PD]
+    f(_pd(q), _pd(d), m.ctypes.data_as(PU8), _pd(out))
+    return out

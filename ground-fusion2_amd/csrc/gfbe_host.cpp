@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -45,14 +46,22 @@ struct gfbe_ctx {
   gfbe_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   int rank = 0, world = 1;
+  // Device memory of freed batches, kept for the next upload: one window per camera frame is the reference's call
+  // pattern, and ~70 hipMalloc / hipFree pairs per call cost more than its solve (3.6 ms of 4.1 ms measured).
+  std::vector<std::pair<void *, size_t>> slab_cache;
 };
+enum : size_t { SLAB_CACHE_ENTRIES = 4, SLAB_CACHE_MAX_BYTES = (size_t)512 << 20 };
 
 // The streams / events one (sub-)batch runs on: main stream, the aux stream of its dense factors, fork / join events.
 struct Lane { hipStream_t s, aux; hipEvent_t fork, join; };
 
 struct gfbe_batch {
   BatchDev d;
-  std::vector<void *> allocs;
+  // every device array of the batch is carved from ONE slab: a dry pass over the allocation sequence adds up the sizes,
+  // the slab comes from the context's cache (or hipMalloc), the second pass hands out the pointers
+  char *slab = nullptr;
+  size_t slab_bytes = 0, slab_off = 0;
+  bool dry = false;
   std::vector<std::vector<int>> slot_of;   // per window: ABI landmark -> global slot
   std::vector<int> L;
   double algo_bytes_lin = 0.0;             // algorithmic bytes of one visual linearisation of the batch
@@ -140,6 +149,7 @@ void gfbe_destroy(gfbe_ctx *c) {
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  for (auto &sl : c->slab_cache) (void)hipFree(sl.first);
   delete c;
 }
 
@@ -250,22 +260,62 @@ void prof_collect(gfbe_ctx *c) {
   }
 }
 
+// (the slab is zeroed once, before the second pass)
 template <typename T>
-gfbe_status dev_alloc(gfbe_ctx *c, gfbe_batch *b, T **p, size_t n, bool zero = true) {
-  void *q = nullptr;
-  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-  HIPCHK(c, hipMalloc(&q, bytes));
-  b->allocs.push_back(q);
-  if (zero) HIPCHK(c, hipMemsetAsync(q, 0, bytes, c->stream));
-  *p = (T *)q;
+gfbe_status dev_alloc(gfbe_ctx *c, gfbe_batch *b, T **p, size_t n) {
+  const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+  if (b->dry) { b->slab_bytes += bytes; *p = nullptr; return GFBE_OK; }
+  if (b->slab_off + bytes > b->slab_bytes) { c->err = "batch slab overrun"; return GFBE_DEVICE_ERROR; }
+  *p = (T *)(b->slab + b->slab_off);
+  b->slab_off += bytes;
   return GFBE_OK;
 }
 template <typename T>
 gfbe_status dev_upload(gfbe_ctx *c, gfbe_batch *b, T **p, const std::vector<T> &h) {
-  gfbe_status st = dev_alloc(c, b, p, h.size(), h.empty());
-  if (st != GFBE_OK) return st;
+  gfbe_status st = dev_alloc(c, b, p, h.size());
+  if (st != GFBE_OK || b->dry) return st;
   if (!h.empty()) HIPCHK(c, hipMemcpyAsync(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
   return GFBE_OK;
+}
+// the smallest cached slab that fits (and is not more than twice too large), else a new one
+gfbe_status slab_acquire(gfbe_ctx *c, gfbe_batch *b) {
+  int best = -1;
+  for (size_t i = 0; i < c->slab_cache.size(); i++) {
+    const size_t cap = c->slab_cache[i].second;
+    if (cap >= b->slab_bytes && cap <= 2 * b->slab_bytes && (best < 0 || cap < c->slab_cache[best].second)) best = (int)i;
+  }
+  if (best >= 0) {
+    b->slab = (char *)c->slab_cache[best].first;
+    b->slab_bytes = c->slab_cache[best].second;
+    c->slab_cache.erase(c->slab_cache.begin() + best);
+  } else {
+    // sizes in steps of 1/4 of the leading power of two: the windows of consecutive frames (slightly different landmark
+    // counts) land on the same cached slab
+    size_t grain = (size_t)1 << 20;
+    while (grain * 8 <= b->slab_bytes) grain *= 2;
+    b->slab_bytes = (b->slab_bytes + grain - 1) / grain * grain;
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, b->slab_bytes);
+    if (e != hipSuccess) {      // make room: drop the cache and retry once
+      for (auto &sl : c->slab_cache) (void)hipFree(sl.first);
+      c->slab_cache.clear();
+      e = hipMalloc(&q, b->slab_bytes);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); c->err = std::string("hipMalloc(batch slab): ") + hipGetErrorString(e); return GFBE_DEVICE_ERROR; }
+    b->slab = (char *)q;
+  }
+  HIPCHK(c, hipMemsetAsync(b->slab, 0, b->slab_bytes, c->stream));
+  return GFBE_OK;
+}
+void slab_release(gfbe_ctx *c, gfbe_batch *b) {
+  if (!b->slab) return;
+  if (c && b->slab_bytes <= SLAB_CACHE_MAX_BYTES) {
+    if (c->slab_cache.size() >= SLAB_CACHE_ENTRIES) { (void)hipFree(c->slab_cache.front().first); c->slab_cache.erase(c->slab_cache.begin()); }
+    c->slab_cache.emplace_back(b->slab, b->slab_bytes);
+  } else {
+    (void)hipFree(b->slab);
+  }
+  b->slab = nullptr;
 }
 
 }  // namespace
@@ -279,7 +329,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
                               int tab0 = 0) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   if (c->device < 0 || !c->stream) { c->err = "HIP device context required (no CPU fallback)"; return GFBE_NO_DEVICE; }
+  const bool dbg_t = getenv("GFBE_DEBUG_UPLOAD") != nullptr;   // phase times of the upload on stderr (tests/diag_e2e_latency.py)
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   HIPCHK(c, hipSetDevice(c->device));
+  const double T0 = now();
   gfbe_batch *b = new gfbe_batch();
   *out = b;
   BatchDev &d = b->d;
@@ -502,6 +555,11 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   }
   b->algo_bytes_lin = algo_bytes;
   gfbe_status st;
+  const double T1 = now();
+  d.rank = c->rank; d.world = c->world;
+  for (int pass = 0; pass < 2; pass++) {
+  b->dry = pass == 0;
+  if (pass == 1 && (st = slab_acquire(c, b)) != GFBE_OK) return st;
 #define UP(field, vec) if ((st = dev_upload(c, b, &d.field, vec)) != GFBE_OK) return st
 #define AL(field, n) if ((st = dev_alloc(c, b, &d.field, (size_t)(n))) != GFBE_OK) return st
   UP(desc, desc);
@@ -525,11 +583,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
   // the partial reduced system [H | g | E | eg | xa] is one slab: a single all-reduce per linearisation when the
   // landmarks are sharded over ranks
-  d.rank = c->rank; d.world = c->world;
   {
     const size_t nH = (size_t)B * ND * ND, ng = (size_t)B * ND, nE = (size_t)B * NV * NV, ne = (size_t)B * NV, nx = (size_t)B * d.world * XCHG;
     AL(H, nH + ng + nE + ne + nx);
-    d.g = d.H + nH; d.E = d.g + ng; d.eg = d.E + nE; d.xa = d.eg + ne;
+    if (!b->dry) { d.g = d.H + nH; d.E = d.g + ng; d.eg = d.E + nE; d.xa = d.eg + ne; }
     b->slab_n = nH + ng + nE + ne + nx;
   }
   AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
@@ -540,6 +597,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   AL(timing, (size_t)B * 32); AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
 #undef UP
 #undef AL
+  }
   if (tabs) {   // landmark arrays straight from the device-resident tables; the slot of every landmark comes back for the download
     int *dlay = nullptr, *dslot = nullptr;
     HIPCHK(c, hipMalloc((void **)&dlay, sizeof(int) * tlayout.size()));
@@ -552,9 +610,13 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     (void)hipFree(dlay); (void)hipFree(dslot);
     for (int w = 0; w < B; w++) b->slot_of[w].assign(hs.begin() + (size_t)w * tabs->d.F, hs.begin() + (size_t)w * tabs->d.F + b->L[w]);
   }
+  const double T2 = now();
+  if (dbg_t) (void)hipStreamSynchronize(c->stream);
+  const double T3 = now();
   { Timed t(c, "k_prep", 0); launch_prep(d, c->stream); launch_asm_table(d, c->stream); }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
+  if (dbg_t) fprintf(stderr, "upload: host pack %.3f ms, slab+copies enqueue %.3f ms, drain %.3f ms, k_prep+table %.3f ms (slab %.1f MB)\n", T1 - T0, T2 - T1, T3 - T2, now() - T3, b->slab_bytes / 1048576.0);
   return GFBE_OK;
 }
 
@@ -563,10 +625,12 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b);
 // Batches of >= BATCH_SPLIT_MIN_B windows become two halves solved side by side on two stream pairs.
 static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
+  *out = nullptr;
   const bool split = B >= BATCH_SPLIT_MIN_B && c->world == 1 && c->opt.split_batch;
   const int nA = split ? (B + 1) / 2 : B;
   gfbe_status st = upload_one(c, nA, wins, out, tabs, 0);
-  if (st != GFBE_OK || !split) return st;
+  if (st != GFBE_OK) { gfbe_batch_free(c, *out); *out = nullptr; return st; }
+  if (!split) return st;
   gfbe_batch *a = *out;
   st = upload_one(c, B - nA, wins + nA, &a->second, tabs, nA);
   if (st == GFBE_OK && (hipStreamCreateWithFlags(&a->lane2.s, hipStreamNonBlocking) != hipSuccess ||
@@ -611,7 +675,7 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
     for (hipEvent_t e : {b->lane2.fork, b->lane2.join, b->ev_start2, b->ev_done2}) if (e) (void)hipEventDestroy(e);
   }
   for (auto &g : b->graph) if (g) (void)hipGraphExecDestroy(g);
-  for (void *p : b->allocs) (void)hipFree(p);
+  slab_release(c, b);
   delete b;
 }
 

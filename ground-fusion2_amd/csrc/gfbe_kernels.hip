@@ -74,33 +74,41 @@ __device__ __forceinline__ double clamp_diag(double x) { return fmin(fmax(x, GF_
 // k_prep: once per upload. sqrt_info of every IMU / wheel factor (imu_factor.h:73, wheel_factor.h:85,
 // hoisted out of Evaluate: SURVEY App. A.5) and H_prior = J0^T J0.
 // =============================================================================================
+// Grid (B, 1 + PREP_PRIOR_WGS): y = 0 factorises the covariances (one lane per factor), the others share H_prior.
+enum { PREP_PRIOR_WGS = 8 };
 __global__ __launch_bounds__(256) void k_prep(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   __shared__ double work[MAX_IMU][450];
   __shared__ double wwork[MAX_WHEEL][72];
   const int t = threadIdx.x;
-  if (t < ds.n_imu) {
-    double *out = d.imu_sqrt + (size_t)(ds.imu_off + t) * 225;
-    double tmp[225];
-    const int rc = sqrt_info_from_cov(d.imu[ds.imu_off + t].covariance, 15, tmp, work[t]);
-    for (int i = 0; i < 225; i++) out[i] = rc ? nan("") : tmp[i];
-  } else if (t >= 64 && t < 64 + ds.n_wheel) {
-    const int k = t - 64;
-    double *out = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
-    double tmp[36];
-    const int rc = sqrt_info_from_cov(d.wheel[ds.wheel_off + k].covariance, 6, tmp, wwork[k]);
-    for (int i = 0; i < 36; i++) out[i] = rc ? nan("") : tmp[i];
+  if (blockIdx.y == 0) {
+    if (t < ds.n_imu) {
+      double *out = d.imu_sqrt + (size_t)(ds.imu_off + t) * 225;
+      double tmp[225];
+      const int rc = sqrt_info_from_cov(d.imu[ds.imu_off + t].covariance, 15, tmp, work[t]);
+      for (int i = 0; i < 225; i++) out[i] = rc ? nan("") : tmp[i];
+    } else if (t >= 64 && t < 64 + ds.n_wheel) {
+      const int k = t - 64;
+      double *out = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
+      double tmp[36];
+      const int rc = sqrt_info_from_cov(d.wheel[ds.wheel_off + k].covariance, 6, tmp, wwork[k]);
+      for (int i = 0; i < 36; i++) out[i] = rc ? nan("") : tmp[i];
+    }
+    return;
   }
   const int n = ds.prior_n;
   if (n > 0) {
     const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
     double *Hp = d.prior_H + (size_t)w * ND * ND;
-    for (int e = t; e < n * n; e += blockDim.x) {
+    // lower triangle (i >= j), mirrored: consecutive lanes read consecutive columns j of every row r
+    for (int e = (blockIdx.y - 1) * blockDim.x + t; e < n * n; e += PREP_PRIOR_WGS * blockDim.x) {
       const int i = e / n, j = e % n;
+      if (j > i) continue;
       double s = 0.0;
       for (int r = 0; r < n; r++) s += J0[(size_t)r * n + i] * J0[(size_t)r * n + j];
-      Hp[e] = s;
+      Hp[(size_t)i * n + j] = s;
+      Hp[(size_t)j * n + i] = s;
     }
   }
 }
@@ -1695,7 +1703,7 @@ __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
 // =============================================================================================
 static size_t solve_smem_bytes() { const int nt = (ND + 1 + TB - 1) / TB; return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
 
-void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B), dim3(256), 0, s, d); }
+void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B, 1 + PREP_PRIOR_WGS), dim3(256), 0, s, d); }
 void launch_reset(const BatchDev &d, hipStream_t s) {
   const int slots = d.max_tiles * LM_TILE;
   hipLaunchKernelGGL(k_reset, dim3((slots + 255) / 256 > 0 ? (slots + 255) / 256 : 1, d.B), dim3(256), 0, s, d);

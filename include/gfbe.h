@@ -361,6 +361,30 @@ gfbe_status gfbe_lio_linearize(gfbe_ctx *ctx, int32_t ct, int32_t n, const doubl
                                double *g, double *cost);
 
 /* ------------------------------------------------------------------------------------------
+ * f2  Optional in-window factors, EVALUATION ONLY — they are not wired into
+ *     gfbe_solve_window (every shipped yaml has plane: 0 and gnss_enable: 0); the GNSS pseudo-range / Doppler factors
+ *     are not provided (they need gnss_comm's ephemeris / atmosphere models, which the reference does not vendor).
+ *       PlaneFactor::Evaluate        factor/plane_factor.h:25-122  — n factors sharing ex_wheel [p | q(x,y,z,w)],
+ *           plane_R [q(x,y,z,w)] and plane_Z (estimator.cpp:3214-3220: one factor per window pose);
+ *           noise_inv = {PITCH_N_INV, ROLL_N_INV, ZPW_N_INV} (parameters.cpp:340-345).
+ *           r [n][3]; J [n][3][16], tangent columns = pose_i(6) ex_wheel(6) plane_R(3) plane_Z(1).
+ *       PoseAnchorFactor::Evaluate   factor/pose_anchor_factor.cpp:8-32 — sqrt_info = 120 in the reference
+ *           (pose_anchor_factor.h:19). r [n][6]; J [n][6][6] (tangent of the pose). The reference's Jacobian is 2 sqrt_info
+ *           times [I 0; 0 Qright(q_anchor^-1)] — twice the derivative of its own position residual; reproduced as it is.
+ *       OrientationSubsetParameterization::Plus   factor/orientation_subset_parameterization.cpp:27-45 (host function):
+ *           out = normalize(q * deltaQ(delta with the constant components zeroed)); plane_R uses constant = {0, 0, 1}
+ *           (estimator.cpp:3122).
+ *     r, J, cost may be NULL. cost = 1/2 sum r^2.
+ * ------------------------------------------------------------------------------------------ */
+gfbe_status gfbe_plane_eval(gfbe_ctx *ctx, int32_t n, const double *pose /*[n][7]*/, const double *ex_wheel /*[7]*/,
+                            const double *plane_R /*[4]*/, double plane_Z, const double *noise_inv /*[3]*/, double *r,
+                            double *J, double *cost);
+gfbe_status gfbe_anchor_eval(gfbe_ctx *ctx, int32_t n, const double *pose /*[n][7]*/, const double *anchor /*[n][7]*/,
+                             double sqrt_info, double *r, double *J, double *cost);
+void gfbe_orientation_subset_plus(const double *q /*[4] x y z w*/, const double *delta /*[3]*/,
+                                  const uint8_t *constant /*[3]*/, double *out /*[4]*/);
+
+/* ------------------------------------------------------------------------------------------
  * a4/a5/a7/a9/a10  Factor evaluation on the device, block-CSR output (parity / inspection API).
  * Each evaluates residuals and TANGENT-space Jacobian blocks at the window's current state,
  * exactly what ceres::CostFunction::Evaluate + the manifold lift produce:
