@@ -84,6 +84,11 @@ class Visual(C.Structure):
                 ("pts_i", PD), ("pts_j", PD), ("vel_i", PD), ("vel_j", PD), ("td_i", PD), ("td_j", PD)]
 
 
+class LioBlock(C.Structure):
+    _fields_ = [("n", c_i), ("frame", c_i), ("pts", PD), ("normals", PD), ("offsets", PD), ("weights", PD),
+                ("sqrt_info", c_d), ("huber_delta", c_d)]
+
+
 class Window(C.Structure):
     _fields_ = [("frame_count", c_i), ("state", State),
                 ("n_feature", c_i), ("para_Feature", PD), ("feature_const", PU8),
@@ -94,7 +99,8 @@ class Window(C.Structure):
                 ("n_imu", c_i), ("imu_frame", PI), ("imu", C.POINTER(ImuPreint)),
                 ("n_wheel", c_i), ("wheel_frame", PI), ("wheel", C.POINTER(WheelPreint)),
                 ("vis", Visual),
-                ("prior", C.POINTER(Prior))]
+                ("prior", C.POINTER(Prior)),
+                ("lio", LioBlock)]
 
 
 class Options(C.Structure):
@@ -277,6 +283,17 @@ class WindowHolder:
         if snap.get("prior") is not None:
             self.prior = PriorHolder(snap["prior"])
             w.prior = C.pointer(self.prior.c)
+        # LiDAR factors on one pose: snap["lio"] = dict(frame, pts, normals, offsets, weights=None, sqrt_info, huber_delta)
+        lio = snap.get("lio")
+        if lio is not None and len(lio["pts"]):
+            self.lio_pts, self.lio_normals = _f64(lio["pts"]).reshape(-1, 3), _f64(lio["normals"]).reshape(-1, 3)
+            self.lio_offsets = _f64(lio["offsets"])
+            self.lio_weights = _f64(lio["weights"]) if lio.get("weights") is not None else None
+            w.lio.n, w.lio.frame = len(self.lio_pts), int(lio.get("frame", w.frame_count))
+            w.lio.pts, w.lio.normals, w.lio.offsets = _pd(self.lio_pts), _pd(self.lio_normals), _pd(self.lio_offsets)
+            if self.lio_weights is not None:
+                w.lio.weights = _pd(self.lio_weights)
+            w.lio.sqrt_info, w.lio.huber_delta = float(lio.get("sqrt_info", 1.0)), float(lio.get("huber_delta", 0.5))
 
     @property
     def n_vis(self):

@@ -33,6 +33,7 @@ enum {
   MAX_IMU = 10, MAX_WHEEL = 10,
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
+  LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)
   XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
   HC = 13                     // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
 };
@@ -103,6 +104,8 @@ struct WinDesc {
   unsigned char blk_free[GFBE_BLK_COUNT];
   unsigned char ex_cam_mask[6], ex_wheel_mask[6];
   unsigned char pad_[3];
+  int lio_n, lio_off, lio_frame, lio_pad;   // LiDAR point-to-plane factors on pose lio_frame (gfbe_lio_block)
+  double lio_sqrt_info, lio_huber;
 };
 
 // ---- per-window solver state (mutated by kernels; mirrors TrustRegionMinimizer + DoglegStrategy)
@@ -171,6 +174,9 @@ struct BatchDev {
   double *tile_cand;          // [B][max_tiles][4] candidate: cost, |x-xc|^2, |xc|^2, pad
   double *tile_gram;          // [B][max_tiles][8] landmark parts of G2 N2 gy vHv vHy yHy gradmax
   double *dense_cand;         // [B][4] dense-factor candidate cost, |x-xc|^2, |xc|^2
+  int tot_lio;                // LiDAR factors of the whole batch (0: the kernels are not launched)
+  double *lio;                // [tot_lio][8]  p(3) n(3) offset weight
+  double *lio_part;           // [B][LIOW_WGS][LIOW_PART]
   // assembled system
   double *H, *g;              // [B][ND*ND], [B][ND]  unscaled J^T J, J^T r of the dense block
   double *E, *eg;             // [B][NV*NV], [B][NV]  sum_l w_l h_l h_l^T, sum_l w_l h_l gl  (unscaled h)
@@ -198,6 +204,7 @@ void launch_pair(const BatchDev &d, int marg, hipStream_t s);
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s);
 void launch_visblock(const BatchDev &d, hipStream_t s);
+void launch_lio_window(const BatchDev &d, int mode, hipStream_t s);
 void launch_assemble(const BatchDev &d, hipStream_t s);
 void launch_asm_table(const BatchDev &d, hipStream_t s);
 // context accessors for the translation units that do not see the gfbe_ctx definition (gfbe_host.cpp)

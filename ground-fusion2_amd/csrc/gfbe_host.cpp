@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -344,6 +345,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<double> lm_pts, lm_obs, lam0, x0((size_t)B * NA);
   std::vector<gfbe_imu_preint> imu;
   std::vector<gfbe_wheel_preint> wheel;
+  std::vector<double> lio;
   std::vector<double> pJ0((size_t)B * ND * ND, 0.0), pr0((size_t)B * ND, 0.0), px0((size_t)B * PRIOR_X0, 0.0);
   b->slot_of.resize(B);
   b->L.resize(B);
@@ -510,9 +512,22 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       if (win.wheel_frame[k] < 0 || win.wheel_frame[k] >= win.frame_count) { c->err = "bad wheel_frame"; return GFBE_BAD_INPUT; }
       wheel.push_back(win.wheel[k]); ds.wheel_frame[k] = win.wheel_frame[k]; ds.wheel_of_frame[win.wheel_frame[k]] = k;
     }
+    // LiDAR factors on one pose
+    ds.lio_n = win.lio.n > 0 ? win.lio.n : 0; ds.lio_off = (int)(lio.size() / 8); ds.lio_frame = win.lio.frame;
+    ds.lio_sqrt_info = win.lio.sqrt_info; ds.lio_huber = win.lio.huber_delta;
+    if (ds.lio_n > 0) {
+      if (win.lio.frame < 0 || win.lio.frame > win.frame_count || !win.lio.pts || !win.lio.normals || !win.lio.offsets) { c->err = "bad lio block"; return GFBE_BAD_INPUT; }
+      for (int k = 0; k < ds.lio_n; k++) {
+        for (int q = 0; q < 3; q++) lio.push_back(win.lio.pts[3 * k + q]);
+        for (int q = 0; q < 3; q++) lio.push_back(win.lio.normals[3 * k + q]);
+        lio.push_back(win.lio.offsets[k]);
+        lio.push_back(win.lio.weights ? win.lio.weights[k] : 1.0);
+      }
+    }
     // prior
     bool used[GFBE_BLK_COUNT];
     for (int q = 0; q < GFBE_BLK_COUNT; q++) used[q] = false;
+    if (ds.lio_n > 0) used[ds.lio_frame] = true;
     for (int q = 0; q < ND; q++) ds.prior_map[q] = -1;
     if (win.prior && win.prior->valid && win.prior->n > 0) {
       const gfbe_prior &pr = *win.prior;
@@ -569,6 +584,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     UP(lm_info, lm_info); UP(lm_abi, lm_abi); UP(lm_pts, lm_pts); UP(lm_obs, lm_obs); UP(lm_rec, lm_rec); UP(lam0, lam0);
   }
   UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
+  d.tot_lio = (int)(lio.size() / 8);
+  UP(lio, lio); AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
   UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0);
   AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
   AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1)); AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
@@ -646,15 +663,26 @@ static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *cons
   return st;
 }
 
+// No C++ exception crosses the C ABI (host staging vectors can throw std::bad_alloc).
+static gfbe_status upload_guarded(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs) {
+  try {
+    return upload_halves(c, B, wins, out, tabs);
+  } catch (const std::exception &e) {
+    if (c) c->err = std::string("gfbe_batch_upload: ") + e.what();
+    if (out && *out) { gfbe_batch_free(c, *out); *out = nullptr; }
+    return GFBE_BAD_INPUT;
+  }
+}
+
 extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out) {
-  return upload_halves(c, B, wins, out, nullptr);
+  return upload_guarded(c, B, wins, out, nullptr);
 }
 
 // Same as gfbe_batch_upload, with the visual factors of window w taken from table w of `t` on the device.
 extern "C" gfbe_status gfbe_batch_upload_tables(gfbe_ctx *c, gfbe_ftab *t, int32_t B, const gfbe_window *const *wins, gfbe_batch **out) {
   if (!c || !t || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   if (c->world > 1) { c->err = "gfbe_batch_upload_tables: not available with landmark sharding"; return GFBE_BAD_INPUT; }
-  return upload_halves(c, B, wins, out, t);
+  return upload_guarded(c, B, wins, out, t);
 }
 
 extern "C" int32_t gfbe_batch_feature_count(const gfbe_batch *b, int32_t w) {
@@ -694,6 +722,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   }
   { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
   if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
+  if (d.tot_lio > 0) { Timed t(c, "k_lio_window", 0); launch_lio_window(d, 0, ln.s); }
   { Timed t(c, "k_schur", 0); launch_schur(d, 0, ln.s); }
   { Timed t(c, "k_visblock", 0); launch_visblock(d, ln.s); }
   if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);   // join
@@ -724,6 +753,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       (void)hipEventRecord(ln.join, ln.aux);
     }
     { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
+    if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
     if (!overlap) { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, ln.s); }
     else (void)hipStreamWaitEvent(ln.s, ln.join, 0);
     if (d.world > 1) {

@@ -328,6 +328,72 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
 }
 
 // =============================================================================================
+// k_lio_window: LiDAR point-to-plane factors attached to one window pose (gfbe_lio_block; the joint LIO + VIO solve,
+// LidarPlaneNormFactor lidarFactor.cpp:18-51 + HuberLoss lidarodom.cpp:539). LIOW_WGS workgroups stride over the
+// window's factors; every thread keeps its share of the 6 x 6 J^T J (upper triangle), J^T r and the cost in registers,
+// the workgroup reduces in a fixed order and writes one partial. MODE 0: linearise; MODE 1: candidate cost.
+// k_visblock adds the partials into the pose block / gradient / cost of the visual part; k_accept adds the candidate cost.
+// =============================================================================================
+template <int MODE>
+__global__ __launch_bounds__(256) void k_lio_window(BatchDev d) {
+  const int w = blockIdx.y, wg = blockIdx.x, t = threadIdx.x;
+  const WinDesc &ds = d.desc[w];
+  if (ds.lio_n == 0) return;
+  const WinCtl &c = d.ctl[w];
+  if (MODE == 0 && (c.done || c.reuse)) return;
+  if (MODE == 1 && (c.done || !c.have_step)) return;
+  const int buf = (MODE == 1) ? 1 - c.cur : c.cur;
+  const double *X = d.x + ((size_t)w * 2 + buf) * NA + A_POSE(ds.lio_frame);
+  const vec3 tw = ld3(X);
+  const mat3 R = qrot(ldq(X + 3));
+  constexpr int NACC = (MODE == 0) ? 28 : 1;
+  double acc[NACC];
+#pragma unroll
+  for (int q = 0; q < NACC; q++) acc[q] = 0.0;
+  const double sq = ds.lio_sqrt_info, delta = ds.lio_huber;
+  for (int k = wg * 256 + t; k < ds.lio_n; k += LIOW_WGS * 256) {
+    const double *f = d.lio + (size_t)(ds.lio_off + k) * 8;
+    const vec3 p = ld3(f), nv = ld3(f + 3);
+    const double sw = sq * f[7];
+    double r = sw * (dot3(nv, add(mv(R, p), tw)) + f[6]);
+    double scale = 1.0, cost = 0.5 * r * r;
+    if (delta > 0.0) {
+      double s1, rs, asn;
+      cost = corrector(r * r, delta, &s1, &rs, &asn);     // 1-D residual under HuberLoss: rho'' <= 0, so J <- sqrt(rho') J, r <- sqrt(rho') r
+      scale = s1;
+    }
+    if (MODE == 1) { acc[0] += cost; continue; }
+    const vec3 nR = tmv(R, nv);
+    double J[6];
+    J[0] = sw * nv[0]; J[1] = sw * nv[1]; J[2] = sw * nv[2];
+    J[3] = -sw * (nR[1] * p[2] - nR[2] * p[1]); J[4] = -sw * (nR[2] * p[0] - nR[0] * p[2]); J[5] = -sw * (nR[0] * p[1] - nR[1] * p[0]);
+#pragma unroll
+    for (int a = 0; a < 6; a++) J[a] *= scale;
+    r *= scale;
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+      for (int b = a; b < 6; b++) acc[e++] += J[a] * J[b];
+#pragma unroll
+    for (int a = 0; a < 6; a++) acc[21 + a] += J[a] * r;
+    acc[27] += cost;
+  }
+  __shared__ double red[4][NACC];
+  const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int q = 0; q < NACC; q++) {
+    double v = acc[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[wave][q] = v;
+  }
+  __syncthreads();
+  double *out = d.lio_part + ((size_t)w * LIOW_WGS + wg) * LIOW_PART;
+  if (t < NACC) out[MODE == 1 ? 28 : t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+}
+
+// =============================================================================================
 // k_pairsum: sums the fused visual partials over the landmark tiles of a start frame (fixed order):
 //   pair_part[w][(i,j)][:] = sum_{tiles t of start frame i} vis_part[w][t][j-i-1][:]
 // Used by the marginalisation (pairs (0, j)); the solve loop sums the tiles inside k_assemble.
@@ -906,6 +972,21 @@ __global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
       __syncthreads();
     }
   }
+  if (ds.lio_n > 0 && d.rank == 0 && t < 27) {   // LiDAR factors of pose lio_frame (k_lio_window): 6 x 6 block, gradient
+    double v = 0.0;
+    for (int q = 0; q < LIOW_WGS; q++) v += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + t];
+    const int o = 6 * ds.lio_frame;
+    if (t < 21) {
+      int a = 0, e = t;
+      while (e >= 6 - a) { e -= 6 - a; a++; }
+      const int b = a + e;
+      V[(o + a) * V_LD + o + b] += v;
+      if (a != b) V[(o + b) * V_LD + o + a] += v;
+    } else {
+      V[(o + t - 21) * V_LD + NV] += v;
+    }
+  }
+  __syncthreads();
   double *out = d.vis_H + (size_t)w * NV * V_LD;
   for (int q = t; q < NV * V_LD; q += VB_THREADS) out[q] = V[q];
   // robustified visual cost of this linearisation point (this rank's tiles; lanes stride the tiles, fixed tree order)
@@ -913,6 +994,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
     double cs = 0.0;
     for (int q = t; q < ds.n_tiles; q += 64) cs += d.tile_cost[(size_t)w * d.max_tiles + q];
     cs = wave_sum(cs);
+    if (ds.lio_n > 0 && d.rank == 0) for (int q = 0; q < LIOW_WGS; q++) cs += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + 27];
     for (int r = 0; r < d.world; r++)
       if (t < XCHG) d.xa[((size_t)w * d.world + r) * XCHG + t] = (r == d.rank && t == 0) ? cs : 0.0;
   }
@@ -1006,7 +1088,12 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 // mu-regularised reduced system, packed Cholesky in LDS, Gauss-Newton step y_p, dense shares of
 // the dogleg scalars. (Ceres 1.14 DoglegStrategy::ComputeStep / ComputeGaussNewtonStep.)
 // =============================================================================================
+#ifndef SOLVE_THREADS
 #define SOLVE_THREADS 1024
+#endif
+#ifndef SOLVE_WAVES_PER_EU
+#define SOLVE_WAVES_PER_EU 4
+#endif
 #define BUILD_UNROLL 4
 #define TB 16                          // tile edge of the blocked Cholesky
 typedef double dbl4 __attribute__((ext_vector_type(4)));
@@ -1094,7 +1181,7 @@ __device__ __noinline__ bool chol_tile16(double *T, int lane) {
   return ok;
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
+__global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
@@ -1280,19 +1367,38 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
     bool ok = (flag == 0);
     STAMP(3);
     if (ok) {
-      // z = L^-1 rhs sits in row n of L. Backward substitution y = L^-T z, block by block, in LDS.
+      // z = L^-1 rhs sits in row n of L. Backward substitution y = L^-T z by ONE wave without block barriers (two
+      // 1024-thread barriers per panel cost more than the arithmetic): for panel P, lane (c, part) gathers
+      // sum_{I > P, I = P + 1 + part mod 4} L(I,P)^T y_I for column c, the four parts meet through two shuffles, then
+      // the 16 x 16 triangular solve runs in registers (lane i keeps y_i and column i of L_PP).
       for (int i = t; i < n; i += blockDim.x)
         ys[i] = smem[(size_t)tile_idx(n / TB, i / TB) * (TB * TB) + tsw(n % TB, i % TB)];
       __syncthreads();
-      for (int P = (n - 1) / TB; P >= 0; P--) {
-        const double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
-        const int r0 = P * TB, cnt = min(TB, n - r0);
-        if (wave == 0) {   // L_PP^T y_P = z_P: lane i keeps y_i and column i of L_PP in registers
-          const int li = lane & 15;
+      if (wave == 0) {
+        const int li = lane & 15, part = lane >> 4;
+        const int np = (n - 1) / TB;
+        for (int P = np; P >= 0; P--) {
+          const double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+          const int r0 = P * TB, cnt = min(TB, n - r0);
+          double sacc = 0.0;
+          for (int I = P + 1 + part; I <= np; I += 4) {
+            const double *Tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
+            const int rI = I * TB, cI = min(TB, n - rI);
+#pragma unroll
+            for (int h = 0; h < TB; h += 8) {
+              double lv[8], yv[8];
+#pragma unroll
+              for (int k = 0; k < 8; k++) { lv[k] = Tip[tsw(h + k, li)]; yv[k] = ys[rI + h + k]; }   // (ys has TB slack behind n)
+#pragma unroll
+              for (int k = 0; k < 8; k++) if (h + k < cI) sacc += lv[k] * yv[k];
+            }
+          }
+          sacc += __shfl_xor(sacc, 16, 64);
+          sacc += __shfl_xor(sacc, 32, 64);
           double colv[TB];
 #pragma unroll
           for (int k = 0; k < TB; k++) colv[k] = Tpp[tsw(k, li)];     // L[k][i]; [k][k] is 1 / L[k][k]
-          double yi = (li < cnt) ? ys[r0 + li] : 0.0;
+          double yi = (li < cnt) ? ys[r0 + li] - sacc : 0.0;
 #pragma unroll
           for (int k = TB - 1; k >= 0; k--) {
             if (k < cnt) {
@@ -1302,16 +1408,11 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_solve(BatchDev d) {
             }
           }
           if (lane < cnt) ys[r0 + lane] = yi;
+          __threadfence_block();
+          __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
-        for (int i = t; i < r0; i += blockDim.x) {   // z_J -= L(P,J)^T y_P for all J < P
-          const double *Tpj = smem + (size_t)tile_idx(P, i / TB) * (TB * TB);
-          double acc = 0.0;
-          for (int k = 0; k < cnt; k++) acc += Tpj[tsw(k, i % TB)] * ys[r0 + k];
-          ys[i] -= acc;
-        }
-        __syncthreads();
       }
+      __syncthreads();
       for (int a = t; a < ND; a += blockDim.x) gyp[a] = 0.0;
       __syncthreads();
       for (int i = t; i < n; i += blockDim.x) gyp[perm[i]] = ys[i];
@@ -1628,6 +1729,7 @@ __global__ __launch_bounds__(64) void k_accept(BatchDev d) {
   if (lane < ds.n_imu) cand += d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 1];
   if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 1];
   if (lane == 32) { cand += d.prior_g[(size_t)w * (ND + 2) + ND + 1]; d2 += d.dense_cand[(size_t)w * 4 + 1]; n2 += d.dense_cand[(size_t)w * 4 + 2]; }
+  if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 28];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o, 64); d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
   if (lane != 0) return;
@@ -1734,6 +1836,10 @@ void launch_xchg_gram(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_x
 void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_cand, dim3(d.B), dim3(64), 0, s, d); }
 void launch_lam_mask(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles > 0) hipLaunchKernelGGL(k_lam_mask, dim3(d.max_tiles, d.B), dim3(LM_TILE), 0, s, d);
+}
+void launch_lio_window(const BatchDev &d, int mode, hipStream_t s) {
+  if (mode == 0) hipLaunchKernelGGL(k_lio_window<0>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(k_lio_window<1>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
 }
 void launch_visblock(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d); }
 void launch_assemble(const BatchDev &d, hipStream_t s) {

@@ -499,3 +499,21 @@ def pose_graph(n=5000, seed=20250708 + 4, fix_every=10, noise=True):
         q = qm(init[k, 3:], rel_meas[k, 3:])
         init[k + 1] = np.concatenate([init[k, :3] + Ri @ rel_meas[k, :3], q / np.linalg.norm(q)])
     return dict(pose=init, truth=truth, rel_i=rel_i, rel_meas=rel_meas, fix_i=fix_i, fix_meas=fix_meas)
+
+
+def lidar_block(scn, k0, n=2000, seed=0, noise=0.02, sqrt_info=20.0, huber_delta=0.5, frame=None, outliers=0.0):
+    """BASELINE configs[4]: n point-to-plane factors of a LiDAR scan taken at the newest pose of window k0 (max_num_residuals:
+    2000, lio/config/m3dgr.yaml:45): body-frame points at 2-20 m, a plane through every point's true world position with
+    a random unit normal, range noise `noise` along the normal (a fraction `outliers` of them displaced by 1 m)."""
+    frame = abi.WINDOW_SIZE if frame is None else frame
+    rng = np.random.default_rng(seed + 31 * k0)
+    p, R = scn.pose(scn.kf_t[k0 + frame])
+    d = rng.normal(size=(n, 3))
+    pts = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(2.0, 20.0, (n, 1))
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pw = pts @ R.T + p
+    err = rng.normal(0, noise, n) + np.where(rng.random(n) < outliers, 1.0, 0.0)
+    offs = -(nrm * pw).sum(axis=1) + err
+    return dict(frame=frame, pts=pts, normals=nrm, offsets=offs, weights=rng.uniform(0.5, 1.0, n), sqrt_info=sqrt_info,
+                huber_delta=huber_delta)

@@ -121,6 +121,22 @@ typedef struct gfbe_visual {
   const double *td_j;           /* [K] */
 } gfbe_visual;
 
+/* f4 (BASELINE configs[4]): LiDAR point-to-plane factors attached to ONE window pose — the
+ * joint LIO + VIO solve, a capability the reference does not have (its LIO solves them alone, lidarodom.cpp:538-581).
+ * Factor k: residual = sqrt_info * weight[k] * (normal[k] . (R p[k] + t) + offset[k]) on pose `frame` = [t | q]
+ * (LidarPlaneNormFactor::Evaluate, lio/src/liw/lidarFactor.cpp:18-51; points already in the IMU frame), robustified by
+ * ceres::HuberLoss(huber_delta) as the LIO does (lidarodom.cpp:539: 0.5); huber_delta <= 0: no loss. n == 0: no block. */
+typedef struct gfbe_lio_block {
+  int32_t n;
+  int32_t frame;                /* window pose the scan belongs to (the newest: frame_count) */
+  const double *pts;            /* [n][3] */
+  const double *normals;        /* [n][3] */
+  const double *offsets;        /* [n] */
+  const double *weights;        /* [n] or NULL (= 1) */
+  double sqrt_info;
+  double huber_delta;
+} gfbe_lio_block;
+
 /* One call of optimization(): everything it reads. */
 typedef struct gfbe_window {
   int32_t frame_count;          /* poses 0..frame_count are in the problem (== WINDOW_SIZE when full) */
@@ -144,6 +160,7 @@ typedef struct gfbe_window {
   const gfbe_wheel_preint *wheel;
   gfbe_visual vis;
   const gfbe_prior *prior;      /* NULL or !valid => no MarginalizationFactor */
+  gfbe_lio_block lio;           /* optional LiDAR factors on one pose (n = 0: none) */
 } gfbe_window;
 
 typedef struct gfbe_options {

@@ -108,6 +108,10 @@ static bool setup(Problem &P, const gfbe_window *win, const gfbe_options *opt) {
   }
   if (P.has_prior)
     for (int b = 0; b < win->prior->n_blocks; b++) P.blk_used[win->prior->block_id[b]] = true;
+  if (win->lio.n > 0) {
+    if (win->lio.frame < 0 || win->lio.frame > win->frame_count) return false;
+    P.blk_used[GFBE_BLK_POSE0 + win->lio.frame] = true;
+  }
   for (int b = 0; b < GFBE_BLK_COUNT; b++) {
     bool c;
     if (b < GFBE_BLK_SB0) c = win->pose_const[b] || b > win->frame_count;
@@ -215,6 +219,24 @@ static double evaluate(const Problem &P, const gfbe_state &st, const double *lam
         double *h = &lin->Hpl[(size_t)l * NV];
         for (int a = 0; a < 20; a++) if (map[a] >= 0) h[map[a]] += J[a] * w0 + J[20 + a] * w1;
       }
+    }
+  }
+  // --- LiDAR point-to-plane factors on one pose (the joint LIO + VIO solve; LidarPlaneNormFactor, lidarFactor.cpp:18-51;
+  //     HuberLoss as in lidarodom.cpp:539)
+  for (int k = 0; k < w.lio.n; k++) {
+    const double *x = st.para_Pose[w.lio.frame], *p = w.lio.pts + 3 * k, *nv = w.lio.normals + 3 * k;
+    const double sw = w.lio.sqrt_info * (w.lio.weights ? w.lio.weights[k] : 1.0);
+    const M3 R = rot(q4(x + 3));
+    const V3 pw = R * v3(p) + v3(x), nR = T(R) * v3(nv);
+    double r[1] = {sw * (dot(v3(nv), pw) + w.lio.offsets[k])};
+    const V3 jr = cross(nR, v3(p));            // n^T R [p]x = (R^T n x p)^T
+    double J[6] = {sw * nv[0], sw * nv[1], sw * nv[2], -sw * jr.x, -sw * jr.y, -sw * jr.z};
+    if (w.lio.huber_delta > 0) cost += robustify(r, lin ? J : nullptr, 1, 6, w.lio.huber_delta);
+    else cost += 0.5 * r[0] * r[0];
+    if (lin) {
+      int map[6];
+      for (int q = 0; q < 6; q++) map[q] = T_POSE(w.lio.frame) + q;
+      accum(*lin, r, J, 1, 6, map);
     }
   }
   if (lin) {
