@@ -201,6 +201,7 @@ void launch_reset(const BatchDev &d, hipStream_t s);
 // mode 1: candidate cost only   mode 2: linearise the marginalisation set at xout (start frame 0 only)
 void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records = 0);
 void launch_pair(const BatchDev &d, int marg, hipStream_t s);
+void launch_lin_small(const BatchDev &d, int mode, hipStream_t s);
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s);
 void launch_visblock(const BatchDev &d, hipStream_t s);

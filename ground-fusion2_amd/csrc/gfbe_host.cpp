@@ -720,8 +720,12 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     launch_dense_factors(d, 0, 0, ln.aux);
     (void)hipEventRecord(ln.join, ln.aux);
   }
-  { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
-  if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
+  const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;   // one launch for visual tiles + dense factors (k_lin_small)
+  if (small) launch_lin_small(d, 0, ln.s);
+  else {
+    { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
+    if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
+  }
   if (d.tot_lio > 0) { Timed t(c, "k_lio_window", 0); launch_lio_window(d, 0, ln.s); }
   { Timed t(c, "k_schur", 0); launch_schur(d, 0, ln.s); }
   { Timed t(c, "k_visblock", 0); launch_visblock(d, ln.s); }
@@ -752,10 +756,12 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       launch_dense_factors(d, 1, 0, ln.aux);
       (void)hipEventRecord(ln.join, ln.aux);
     }
-    { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
+    const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;
+    if (small) launch_lin_small(d, 1, ln.s);
+    else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
-    if (!overlap) { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, ln.s); }
-    else (void)hipStreamWaitEvent(ln.s, ln.join, 0);
+    if (!small && !overlap) { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, ln.s); }
+    else if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);
     if (d.world > 1) {
       Timed t(c, "allreduce_scalars", 0);
       launch_xchg_cand(d, ln.s);

@@ -154,10 +154,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 // (landmarks with start_frame 0, estimator.cpp:3498-3531) at the re-anchored state.
 // =============================================================================================
 template <int MODE>
-__global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_records) {
-  // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
-  // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
-  const int w = blockIdx.x, tile = blockIdx.y;
+__device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile) {
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
@@ -327,6 +324,13 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_records) {
+  // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
+  // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
+  vis_body<MODE>(d, write_records, blockIdx.x, blockIdx.y);
+}
+
 // =============================================================================================
 // k_lio_window: LiDAR point-to-plane factors attached to one window pose (gfbe_lio_block; the joint LIO + VIO solve,
 // LidarPlaneNormFactor lidarFactor.cpp:18-51 + HuberLoss lidarodom.cpp:539). LIOW_WGS workgroups stride over the
@@ -473,8 +477,7 @@ __global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode) {
 // FUSED: small batches evaluate the raw factor inline (lane 0) — one launch less on the latency path of a single
 // window; otherwise the raw residuals / Jacobians come from k_dense_raw.
 template <bool FUSED>
-__global__ __launch_bounds__(64, FUSED ? 1 : 2) void k_dense(BatchDev d, int mode, int debug_out) {
-  const int w = blockIdx.y, f = blockIdx.x;
+__device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debug_out, const int w, const int f) {
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   if (mode == 0 && (c.done || c.reuse)) return;
@@ -595,6 +598,21 @@ __global__ __launch_bounds__(64, FUSED ? 1 : 2) void k_dense(BatchDev d, int mod
     if (t == 0) pg[ND] = cst;
     if (debug_out) for (int i = t; i < n; i += 64) d.dbg_prior[(size_t)w * ND + i] = rp[i];
   }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(64, FUSED ? 1 : 2) void k_dense(BatchDev d, int mode, int debug_out) {
+  dense_body<FUSED>(d, mode, debug_out, blockIdx.y, blockIdx.x);
+}
+
+// Small batches (one window per camera frame is the reference's call pattern): the visual tiles and the inertial / wheel /
+// prior factors of a linearisation (MODE 0) or of a candidate evaluation (MODE 1) in ONE launch — the ~35 us of a single
+// lane evaluating an IMU factor hide behind the visual tiles instead of following them on the stream.
+template <int MODE>
+__global__ __launch_bounds__(64, 1) void k_lin_small(BatchDev d) {
+  const int w = blockIdx.x, y = blockIdx.y;
+  if (y < d.max_tiles) vis_body<MODE>(d, 0, w, y);
+  else dense_body<true>(d, MODE, 0, w, y - d.max_tiles);
 }
 
 // =============================================================================================
@@ -1816,6 +1834,11 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   if (mode == 0) hipLaunchKernelGGL(k_vis<0>, g, b, 0, s, d, write_records);
   else if (mode == 1) hipLaunchKernelGGL(k_vis<1>, g, b, 0, s, d, 0);
   else hipLaunchKernelGGL(k_vis<2>, g, b, 0, s, d, write_records);
+}
+void launch_lin_small(const BatchDev &d, int mode, hipStream_t s) {
+  const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1), b(LM_TILE);
+  if (mode == 0) hipLaunchKernelGGL(k_lin_small<0>, g, b, 0, s, d);
+  else hipLaunchKernelGGL(k_lin_small<1>, g, b, 0, s, d);
 }
 void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
   hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);
