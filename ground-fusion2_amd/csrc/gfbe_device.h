@@ -237,6 +237,7 @@ struct FtabDev {
   double *ndepth;       // [W][F] scratch: edited depth
   int *ids_scratch;     // [W][F] flagged ids of check_outliers (ascending)
   int *cnt_scratch;     // [W]
+  int *hist, *layout;   // [W][FT_BINS + 2], [W][FT_LAY_STRIDE]: landmark histogram / slot layout of gfbe_batch_upload_tables
   int *err;             // [W] sticky error flags (capacity / more than FT_NOBS observations)
   gfbe_ftab_options opt;
 };
@@ -252,4 +253,8 @@ struct gfbe_ftab {
   gfd::FtabDev d;
   int cur = 0;
   std::vector<void *> allocs;
+  // argument staging of the table operations: one device chunk + its pinned host mirror, grown on demand and kept (a
+  // hipMalloc / hipFree pair per argument cost more than the kernels: 0.4 ms per call measured)
+  char *stage_d = nullptr, *stage_h = nullptr;
+  size_t stage_cap = 0;
 };

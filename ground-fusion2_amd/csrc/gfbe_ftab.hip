@@ -60,7 +60,9 @@ __device__ __forceinline__ void tmm3(const double *A, const double *B, double *C
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0.0; for (int k = 0; k < 3; k++) s += A[3 * k + i] * B[3 * k + j]; C[3 * i + j] = s; }
 }
 
-// ---- erasing operations: decide per feature, scan, copy survivors into the other buffer -------------------
+// ---- erasing operations: decide per feature, scan (k_ftab_erase: one workgroup per table), copy the survivors into the
+//      other buffer (k_ftab_erase_copy: one thread per (feature, observation slot), any number of workgroups — a single
+//      table keeps the whole GPU busy instead of one CU) -------------------------------------------------------------
 __global__ __launch_bounds__(FT_THREADS) void k_ftab_erase(FtabDev T, int cur, int op, const double *argA, const double *argB,
                                                            const int *iarg, const int *ids_off, const int *ids) {
   const int w = blockIdx.x, t = threadIdx.x;
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_erase(FtabDev T, int cur, i
   const int n = T.count[w];
   const size_t base = (size_t)w * T.F;
   const int *id = T.id[cur] + base, *start = T.start[cur] + base, *nobs = T.nobs[cur] + base;
-  const int *eflag = T.eflag[cur] + base, *sflag = T.sflag[cur] + base;
-  const double *depth = T.depth[cur] + base, *obs = T.obs[cur] + base * NOBS * OW, *td = T.td[cur] + base * NOBS;
+  const int *sflag = T.sflag[cur] + base;
+  const double *depth = T.depth[cur] + base, *obs = T.obs[cur] + base * NOBS * OW;
   int *keep = T.keep + base;
   double *nd = T.ndepth + base;
   const int chunk = (n + FT_THREADS - 1) / FT_THREADS, f0 = t * chunk, f1 = min(n, f0 + chunk);
@@ -108,33 +110,48 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_erase(FtabDev T, int cur, i
   }
   int total;
   int dst = block_exclusive_scan(survivors, &total, lds);
+  int *dsti = T.ids_scratch + base;          // destination of feature f in the other buffer
+  for (int f = f0; f < f1; f++) dsti[f] = keep[f] ? dst++ : -1;
+  if (t == 0) { T.cnt_scratch[w] = n; T.count[w] = total; }
+}
+__global__ __launch_bounds__(256) void k_ftab_erase_copy(FtabDev T, int cur) {
+  const int w = blockIdx.y;
+  const int n = T.cnt_scratch[w];            // features before the operation
+  const int g = blockIdx.x * 256 + threadIdx.x, f = g / NOBS, q = g - f * NOBS;
+  if (f >= n) return;
+  const size_t base = (size_t)w * T.F;
+  const int k = T.keep[base + f], dst = T.ids_scratch[base + f];
+  if (k == 0) return;
   const int o = 1 - cur;
-  int *oid = T.id[o] + base, *ostart = T.start[o] + base, *onobs = T.nobs[o] + base, *oe = T.eflag[o] + base, *os = T.sflag[o] + base;
-  double *odepth = T.depth[o] + base, *oobs = T.obs[o] + base * NOBS * OW, *otd = T.td[o] + base * NOBS;
-  for (int f = f0; f < f1; f++) {
-    const int k = keep[f];
-    if (k == 0) continue;
-    oid[dst] = id[f]; oe[dst] = eflag[f]; os[dst] = sflag[f]; odepth[dst] = nd[f];
-    ostart[dst] = k == 2 ? start[f] - 1 : start[f];
-    const int drop = k >= 3 ? k - 3 : -1, m = nobs[f];
-    onobs[dst] = drop >= 0 ? m - 1 : m;
-    const double *src = obs + (size_t)f * NOBS * OW, *srct = td + (size_t)f * NOBS;
-    double *d8 = oobs + (size_t)dst * NOBS * OW, *dt = otd + (size_t)dst * NOBS;
-    int wr = 0;
-    for (int q = 0; q < NOBS; q++) {
-      if (q == drop) continue;
-      const bool live = q < m;
-      for (int c = 0; c < OW; c++) d8[wr * OW + c] = live ? src[q * OW + c] : 0.0;
-      dt[wr] = live ? srct[q] : 0.0;
-      wr++;
-    }
-    for (; wr < NOBS; wr++) { for (int c = 0; c < OW; c++) d8[wr * OW + c] = 0.0; dt[wr] = 0.0; }
-    dst++;
+  const int drop = k >= 3 ? k - 3 : -1, m = T.nobs[cur][base + f];
+  if (q == 0) {
+    T.id[o][base + dst] = T.id[cur][base + f]; T.eflag[o][base + dst] = T.eflag[cur][base + f]; T.sflag[o][base + dst] = T.sflag[cur][base + f];
+    T.depth[o][base + dst] = T.ndepth[base + f];
+    T.start[o][base + dst] = k == 2 ? T.start[cur][base + f] - 1 : T.start[cur][base + f];
+    T.nobs[o][base + dst] = drop >= 0 ? m - 1 : m;
   }
-  if (t == 0) T.count[w] = total;
+  // output slot q <- source slot q (+ 1 behind the erased observation); slots past the track are zero
+  const int sq = (drop >= 0 && q >= drop) ? q + 1 : q;
+  const bool live = sq < m && sq < NOBS;
+  const double *src = T.obs[cur] + ((base + f) * NOBS + (live ? sq : 0)) * OW;
+  double *d8 = T.obs[o] + ((base + dst) * NOBS + q) * OW;
+#pragma unroll
+  for (int c = 0; c < OW; c++) d8[c] = live ? src[c] : 0.0;
+  T.td[o][(base + dst) * NOBS + q] = live ? T.td[cur][(base + f) * NOBS + sq] : 0.0;
 }
 
 // ---- addFeatureCheckParallax ------------------------------------------------------------------------------
+// find_if over the list for every incoming feature (ids are unique inside a table): one thread per incoming feature, any
+// number of workgroups
+__global__ __launch_bounds__(64) void k_ftab_match(FtabDev T, int cur, const int *offset, const int *fid, int *match) {
+  const int w = blockIdx.y, j0 = offset[w], m = offset[w + 1] - j0, a = blockIdx.x * 64 + threadIdx.x;
+  if (a >= m) return;
+  const int n = T.count[w], want = fid[j0 + a];
+  const int *id = T.id[cur] + (size_t)w * T.F;
+  int hit = -1;
+  for (int f = 0; f < n; f++) if (id[f] == want) { hit = f; break; }
+  match[j0 + a] = hit;
+}
 __global__ __launch_bounds__(FT_THREADS) void k_ftab_add(FtabDev T, int cur, const int *frame_count, const int *offset, const int *fid,
                                                          const double *obs8, const double *tdv, int *match, int *keyframe,
                                                          int *counters, double *avg_parallax) {
@@ -149,16 +166,10 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_add(FtabDev T, int cur, con
   const int j0 = offset[w], m = offset[w + 1] - j0;
   if (t < 3) s_cnt[t] = 0;
   __syncthreads();
-  // find_if over the list for every incoming feature (ids are unique inside a table)
+  // match[] = find_if over the list for every incoming feature (k_ftab_match)
   const int chunk = (m + FT_THREADS - 1) / FT_THREADS, a0 = t * chunk, a1 = min(m, a0 + chunk);
   int fresh = 0;
-  for (int a = a0; a < a1; a++) {
-    const int want = fid[j0 + a];
-    int hit = -1;
-    for (int f = 0; f < n; f++) if (id[f] == want) { hit = f; break; }
-    match[j0 + a] = hit;
-    fresh += hit < 0;
-  }
+  for (int a = a0; a < a1; a++) fresh += match[j0 + a] < 0;
   int total_new;
   int dst = n + block_exclusive_scan(fresh, &total_new, lds);
   if (n + total_new > T.F) { if (t == 0) T.err[w] |= 1; total_new = 0; }
@@ -419,18 +430,30 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_landmarks(FtabDev T, int cu
   for (int f = f0; f < f1; f++) mine += nobs[f] >= 4;
   int total;
   int lidx = block_exclusive_scan(mine, &total, lds);
-  // rank inside its bin in list order: one block scan per non-empty bin
-  for (int f = f0; f < f1; f++) keep[f] = -1;
-  for (int bin = 0; bin < FT_BINS; bin++) {
-    const int bin_first = lay[LAY_BIN + bin];
-    int v = 0;
-    for (int f = f0; f < f1; f++) v += (nobs[f] >= 4 && start[f] * 8 + (nobs[f] - 4) == bin) ? 1 : 0;
-    int tot_bin;
-    int r = block_exclusive_scan(v, &tot_bin, lds);
-    if (tot_bin == 0) continue;     // (uniform)
-    for (int f = f0; f < f1; f++)
-      if (nobs[f] >= 4 && start[f] * 8 + (nobs[f] - 4) == bin) keep[f] = bin_first + r++;
+  // rank inside its bin in list order: RANKERS threads take contiguous pieces of the list and count their landmarks per bin
+  // in LDS (bin-major), thread b scans bin b over the rankers, then every ranker numbers its own landmarks — three barriers
+  // instead of one block scan per bin
+  enum { RANKERS = 256 };
+  __shared__ unsigned short hb[FT_BINS][RANKERS + 2];     // (+2: rows one bank apart)
+  for (int q = t; q < FT_BINS * (RANKERS + 2); q += FT_THREADS) (&hb[0][0])[q] = 0;
+  __syncthreads();
+  const int rchunk = (n + RANKERS - 1) / RANKERS, r0 = t * rchunk, r1 = min(n, r0 + rchunk);
+  if (t < RANKERS)
+    for (int f = r0; f < r1; f++) {
+      keep[f] = -1;
+      if (nobs[f] >= 4) hb[start[f] * 8 + (nobs[f] - 4)][t]++;
+    }
+  __syncthreads();
+  if (t < FT_BINS) {
+    int run = 0;
+    for (int k = 0; k < RANKERS; k++) { const int cth = hb[t][k]; hb[t][k] = (unsigned short)run; run += cth; }
   }
+  __syncthreads();
+  if (t < RANKERS)
+    for (int f = r0; f < r1; f++)
+      if (nobs[f] >= 4) { const int bin = start[f] * 8 + (nobs[f] - 4); keep[f] = lay[LAY_BIN + bin] + hb[bin][t]++; }
+  __threadfence_block();
+  __syncthreads();
   const int lm_off = lay[0];
   for (int f = f0; f < f1; f++) {
     if (nobs[f] < 4) continue;
@@ -489,22 +512,57 @@ gfbe_status ft_alloc(gfbe_ctx *c, gfbe_ftab *t, T **p, size_t n) {
   *p = (T *)q;
   return GFBE_OK;
 }
-// small host argument -> device copy that lives until the stream has been synchronised by the caller
+// Host arguments of one table operation -> the table's staging chunk (one pinned host mirror, ONE host-to-device copy before
+// the launch, ONE device-to-host copy of the output range after it). `need` = upper bound of the staged bytes.
 struct Staged {
   gfbe_ctx *c;
-  std::vector<void *> tmp;
-  explicit Staged(gfbe_ctx *ctx) : c(ctx) {}
-  ~Staged() { (void)hipStreamSynchronize(ctx_stream(c)); for (void *p : tmp) (void)hipFree(p); }
+  gfbe_ftab *t;
+  size_t off = 0, ulo = SIZE_MAX, uhi = 0, dlo = SIZE_MAX, dhi = 0;
+  bool ok = true;
+  struct Out { void *h; size_t off, bytes; };
+  std::vector<Out> outs;
+  Staged(gfbe_ctx *ctx, gfbe_ftab *tab, size_t need) : c(ctx), t(tab) {
+    need += 4096;
+    if (need <= t->stage_cap) return;
+    (void)hipStreamSynchronize(ctx_stream(c));
+    if (t->stage_d) (void)hipFree(t->stage_d);
+    if (t->stage_h) (void)hipHostFree(t->stage_h);
+    t->stage_d = t->stage_h = nullptr; t->stage_cap = 0;
+    const size_t cap = std::max<size_t>(2 * need, (size_t)1 << 20);
+    if (hipMalloc((void **)&t->stage_d, cap) != hipSuccess || hipHostMalloc((void **)&t->stage_h, cap) != hipSuccess) { ok = false; return; }
+    t->stage_cap = cap;
+  }
+  ~Staged() { finish(); }
   template <typename T>
   T *up(const T *h, size_t n) {
-    void *q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-    tmp.push_back(q);
-    if (h && n) (void)hipMemcpyAsync(q, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_stream(c));
-    return (T *)q;
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (!ok || off + bytes > t->stage_cap) { ok = false; return nullptr; }
+    if (h && n) { std::memcpy(t->stage_h + off, h, n * sizeof(T)); ulo = std::min(ulo, off); uhi = std::max(uhi, off + n * sizeof(T)); }
+    T *p = (T *)(t->stage_d + off);
+    off += bytes;
+    return p;
+  }
+  void flush() {   // before the launch
+    if (ok && uhi > ulo) (void)hipMemcpyAsync(t->stage_d + ulo, t->stage_h + ulo, uhi - ulo, hipMemcpyHostToDevice, ctx_stream(c));
   }
   template <typename T>
-  void down(T *h, const T *dptr, size_t n) { if (h && n) (void)hipMemcpyAsync(h, dptr, n * sizeof(T), hipMemcpyDeviceToHost, ctx_stream(c)); }
+  void down(T *h, const T *dptr, size_t n) {
+    if (!h || !n || !ok) return;
+    const char *p = (const char *)dptr;
+    if (p >= t->stage_d && p < t->stage_d + t->stage_cap) {
+      const size_t o = (size_t)(p - t->stage_d);
+      outs.push_back({h, o, n * sizeof(T)});
+      dlo = std::min(dlo, o); dhi = std::max(dhi, o + n * sizeof(T));
+    } else {
+      (void)hipMemcpyAsync(h, dptr, n * sizeof(T), hipMemcpyDeviceToHost, ctx_stream(c));
+    }
+  }
+  void finish() {
+    if (dhi > dlo) (void)hipMemcpyAsync(t->stage_h + dlo, t->stage_d + dlo, dhi - dlo, hipMemcpyDeviceToHost, ctx_stream(c));
+    (void)hipStreamSynchronize(ctx_stream(c));
+    for (const Out &o : outs) std::memcpy(o.h, t->stage_h + o.off, o.bytes);
+    outs.clear(); dlo = SIZE_MAX; dhi = 0;
+  }
 };
 gfbe_status ft_ready(gfbe_ctx *c, gfbe_ftab *t) {
   if (!c || !t) return GFBE_BAD_INPUT;
@@ -554,11 +612,13 @@ gfbe_status gfbe_ftab_create(gfbe_ctx *c, int32_t n_tables, int32_t cap, const g
   gfbe_status st;
 #define FA(p, n) if ((st = ft_alloc(c, t, &p, n)) != GFBE_OK) return st
   FA(d.count, n_tables); FA(d.err, n_tables); FA(d.keep, N); FA(d.ndepth, N); FA(d.ids_scratch, N); FA(d.cnt_scratch, n_tables);
+  FA(d.hist, (size_t)n_tables * (FT_BINS + 2)); FA(d.layout, (size_t)n_tables * FT_LAY_STRIDE);
   for (int b = 0; b < 2; b++) {
     FA(d.id[b], N); FA(d.start[b], N); FA(d.nobs[b], N); FA(d.eflag[b], N); FA(d.sflag[b], N);
     FA(d.depth[b], N); FA(d.obs[b], N * NOBS * OW); FA(d.td[b], N * NOBS);
   }
 #undef FA
+  { Staged warm(c, t, (size_t)n_tables * cap * 8); }   // staging sized for the largest result (every id flagged) up front
   FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
   return GFBE_OK;
 }
@@ -567,6 +627,8 @@ void gfbe_ftab_destroy(gfbe_ctx *c, gfbe_ftab *t) {
   if (!t) return;
   if (c && ctx_device(c) >= 0) (void)hipStreamSynchronize(ctx_stream(c));
   for (void *p : t->allocs) (void)hipFree(p);
+  if (t->stage_d) (void)hipFree(t->stage_d);
+  if (t->stage_h) (void)hipHostFree(t->stage_h);
   delete t;
 }
 
@@ -580,11 +642,17 @@ gfbe_status gfbe_ftab_add_frame(gfbe_ctx *c, gfbe_ftab *t, const int32_t *frame_
     for (int k = offset[w] + 1; k < offset[w + 1]; k++)
       if (feature_id[k] <= feature_id[k - 1]) { ctx_set_error(c, "gfbe_ftab_add_frame: feature ids of a table must be strictly ascending"); return GFBE_BAD_INPUT; }
   {
-    Staged s(c);
-    int *dfc = s.up(frame_count, W), *doff = s.up(offset, W + 1), *dfid = s.up(feature_id, M), *dmatch = s.up<int>(nullptr, M);
+    Staged s(c, t, (size_t)M * (OW * 8 + 8) + (size_t)W * 64 + 16 * 256);
+    int *dfc = s.up(frame_count, W), *doff = s.up(offset, W + 1), *dfid = s.up(feature_id, M);
     double *dobs = s.up(obs8, (size_t)M * OW), *dtd = s.up(td, W);
+    int *dmatch = s.up<int>(nullptr, M);
     int *dkf = s.up<int>(nullptr, W), *dcnt = s.up<int>(nullptr, 3 * W);
     double *davg = s.up<double>(nullptr, W);
+    if (!s.ok) { ctx_set_error(c, "gfbe_ftab_add_frame: staging allocation failed"); return GFBE_DEVICE_ERROR; }
+    s.flush();
+    int mmax = 1;
+    for (int w = 0; w < W; w++) mmax = std::max(mmax, offset[w + 1] - offset[w]);
+    hipLaunchKernelGGL(k_ftab_match, dim3((mmax + 63) / 64, W), dim3(64), 0, ctx_stream(c), t->d, t->cur, doff, dfid, dmatch);
     hipLaunchKernelGGL(k_ftab_add, dim3(W), dim3(FT_THREADS), 0, ctx_stream(c), t->d, t->cur, dfc, doff, dfid, dobs, dtd, dmatch, dkf, dcnt, davg);
     s.down(keyframe, dkf, W); s.down(counters, dcnt, 3 * (size_t)W); s.down(avg_parallax, davg, W);
   }
@@ -596,10 +664,13 @@ static gfbe_status ft_erase(gfbe_ctx *c, gfbe_ftab *t, int op, const double *a, 
   if (st != GFBE_OK) return st;
   const int W = t->d.W;
   {
-    Staged s(c);
+    Staged s(c, t, (size_t)W * 256 + (off ? (size_t)off[W] * 4 : 0) + 8 * 256);
     double *da = a ? s.up(a, 12 * (size_t)W) : nullptr, *db = b ? s.up(b, 12 * (size_t)W) : nullptr;
     int *di = iarg ? s.up(iarg, W) : nullptr, *doff = off ? s.up(off, W + 1) : nullptr, *dids = off ? s.up(ids, off[W]) : nullptr;
+    if (!s.ok) { ctx_set_error(c, "feature table operation: staging allocation failed"); return GFBE_DEVICE_ERROR; }
+    s.flush();
     hipLaunchKernelGGL(k_ftab_erase, dim3(W), dim3(FT_THREADS), 0, ctx_stream(c), t->d, t->cur, op, da, db, di, doff, dids);
+    hipLaunchKernelGGL(k_ftab_erase_copy, dim3((unsigned)(((size_t)t->d.F * NOBS + 255) / 256), W), dim3(256), 0, ctx_stream(c), t->d, t->cur);
   }
   t->cur = 1 - t->cur;
   return ft_finish(c, t);
@@ -625,9 +696,12 @@ static gfbe_status ft_depth(gfbe_ctx *c, gfbe_ftab *t, int mode, const int32_t *
   const int W = t->d.W;
   if (mode != 0 && (!offset || !x_io)) return GFBE_BAD_INPUT;
   {
-    Staged s(c);
-    int *doff = offset ? s.up(offset, W + 1) : nullptr, *dcnt = s.up<int>(nullptr, W);
+    Staged s(c, t, (size_t)W * 16 + (offset ? (size_t)offset[W] * 8 : 0) + 8 * 256);
+    int *doff = offset ? s.up(offset, W + 1) : nullptr;
     double *dx = offset ? s.up(mode == 1 ? x_io : nullptr, offset[W]) : nullptr;
+    int *dcnt = s.up<int>(nullptr, W);
+    if (!s.ok) { ctx_set_error(c, "feature table operation: staging allocation failed"); return GFBE_DEVICE_ERROR; }
+    s.flush();
     hipLaunchKernelGGL(k_ftab_depth, dim3(W), dim3(FT_THREADS), 0, ctx_stream(c), t->d, t->cur, mode, doff, dx, dcnt);
     if (mode == 2) s.down(x_io, dx, offset[W]);
     s.down(count, dcnt, W);
@@ -644,8 +718,10 @@ gfbe_status gfbe_ftab_triangulate(gfbe_ctx *c, gfbe_ftab *t, const double *poses
   if (!poses || !tic_ric) return GFBE_BAD_INPUT;
   const int W = t->d.W;
   {
-    Staged s(c);
+    Staged s(c, t, (size_t)W * 144 * 8 + 8 * 256);
     double *dp = s.up(poses, 132 * (size_t)W), *de = s.up(tic_ric, 12 * (size_t)W);
+    if (!s.ok) { ctx_set_error(c, "feature table operation: staging allocation failed"); return GFBE_DEVICE_ERROR; }
+    s.flush();
     hipLaunchKernelGGL(k_ftab_triangulate, dim3((t->d.F + 255) / 256, W), dim3(256), 0, ctx_stream(c), t->d, t->cur, dp, de, with_depth);
   }
   return ft_finish(c, t);
@@ -658,22 +734,28 @@ gfbe_status gfbe_ftab_check_outliers(gfbe_ctx *c, gfbe_ftab *t, const double *po
   if (!poses || !tic_ric || !offset || !ids_out || !count_out) return GFBE_BAD_INPUT;
   const int W = t->d.W;
   {
-    Staged s(c);
+    Staged s(c, t, (size_t)W * 144 * 8 + (size_t)W * 4 + 8 * 256);
     double *dp = s.up(poses, 132 * (size_t)W), *de = s.up(tic_ric, 12 * (size_t)W);
+    if (!s.ok) { ctx_set_error(c, "feature table operation: staging allocation failed"); return GFBE_DEVICE_ERROR; }
+    int *dcnt = s.up<int>(nullptr, W);      // counts come back through the pinned mirror (a pageable 1 KB copy took 21 ms here)
+    if (!s.ok) { ctx_set_error(c, "feature table operation: staging allocation failed"); return GFBE_DEVICE_ERROR; }
+    s.flush();
     hipLaunchKernelGGL(k_ftab_outliers, dim3(W), dim3(FT_THREADS), sizeof(int) * (size_t)t->d.F, ctx_stream(c), t->d, t->cur, dp, de, mode,
-                       t->d.ids_scratch, t->d.cnt_scratch);
-    hipLaunchKernelGGL(k_ftab_pack, dim3(1), dim3(FT_THREADS), 0, ctx_stream(c), W, t->d.F, t->d.cnt_scratch, t->d.ids_scratch, t->d.keep);
-    s.down(count_out, t->d.cnt_scratch, W);
+                       t->d.ids_scratch, dcnt);
+    hipLaunchKernelGGL(k_ftab_pack, dim3(1), dim3(FT_THREADS), 0, ctx_stream(c), W, t->d.F, dcnt, t->d.ids_scratch, t->d.keep);
+    s.down(count_out, dcnt, W);
   }
   size_t total = 0;
   for (int w = 0; w < W; w++) total += count_out[w];
-  if (total) {   // the host copy moves exactly the flagged ids (a pageable device-to-host copy runs at a few 100 MB/s)
-    std::vector<int32_t> tmp(total);
-    FT_CHECK(c, hipMemcpyAsync(tmp.data(), t->d.keep, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx_stream(c)));
+  if (total) {   // the host copy moves exactly the flagged ids, through the pinned staging mirror (a pageable copy runs at a few 100 MB/s)
+    Staged s2(c, t, sizeof(int32_t) * total);
+    if (!s2.ok) { ctx_set_error(c, "gfbe_ftab_check_outliers: staging allocation failed"); return GFBE_DEVICE_ERROR; }
+    FT_CHECK(c, hipMemcpyAsync(t->stage_h, t->d.keep, sizeof(int32_t) * total, hipMemcpyDeviceToHost, ctx_stream(c)));
     FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
+    const int32_t *tmp = (const int32_t *)t->stage_h;
     size_t run = 0;
     for (int w = 0; w < W; w++) {
-      std::memcpy(ids_out + offset[w], tmp.data() + run, sizeof(int32_t) * std::min<size_t>(offset[w + 1] - offset[w], count_out[w]));
+      std::memcpy(ids_out + offset[w], tmp + run, sizeof(int32_t) * std::min<size_t>(offset[w + 1] - offset[w], count_out[w]));
       run += count_out[w];
     }
   }

@@ -50,6 +50,9 @@ struct gfbe_ctx {
   // Device memory of freed batches, kept for the next upload: one window per camera frame is the reference's call
   // pattern, and ~70 hipMalloc / hipFree pairs per call cost more than its solve (3.6 ms of 4.1 ms measured).
   std::vector<std::pair<void *, size_t>> slab_cache;
+  // grow-only device scratch of the short host-buffer calls (pre-integration): no hipMalloc / hipFree per call
+  char *scratch = nullptr;
+  size_t scratch_cap = 0;
 };
 enum : size_t { SLAB_CACHE_ENTRIES = 4, SLAB_CACHE_MAX_BYTES = (size_t)512 << 20 };
 
@@ -151,6 +154,7 @@ void gfbe_destroy(gfbe_ctx *c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (auto &sl : c->slab_cache) (void)hipFree(sl.first);
+  if (c->scratch) (void)hipFree(c->scratch);
   delete c;
 }
 
@@ -356,13 +360,11 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<int> tcounts, tlayout;     // table source: per window [L, K, bins], layout table for the pack kernel
   if (tabs) {
     if (tab0 < 0 || tab0 + B > tabs->d.W) { c->err = "gfbe_batch_upload_tables: more windows than tables"; return GFBE_BAD_INPUT; }
-    int *dcounts = nullptr;
-    HIPCHK(c, hipMalloc((void **)&dcounts, sizeof(int) * (size_t)B * (FT_BINS + 2)));
+    int *dcounts = tabs->d.hist + (size_t)tab0 * (FT_BINS + 2);
     launch_ftab_count(tabs->d, tabs->cur, tab0, B, dcounts, c->stream);
     tcounts.resize((size_t)B * (FT_BINS + 2));
     HIPCHK(c, hipMemcpyAsync(tcounts.data(), dcounts, sizeof(int) * tcounts.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(dcounts);
     tlayout.assign((size_t)B * FT_LAY_STRIDE, 0);
   }
   for (int w = 0; w < B; w++) {
@@ -616,16 +618,14 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
 #undef AL
   }
   if (tabs) {   // landmark arrays straight from the device-resident tables; the slot of every landmark comes back for the download
-    int *dlay = nullptr, *dslot = nullptr;
-    HIPCHK(c, hipMalloc((void **)&dlay, sizeof(int) * tlayout.size()));
-    HIPCHK(c, hipMalloc((void **)&dslot, sizeof(int) * (size_t)B * tabs->d.F));
+    // (layout table and slot map live in the tables' own scratch: no allocation on this path)
+    int *dlay = tabs->d.layout + (size_t)tab0 * FT_LAY_STRIDE, *dslot = tabs->d.ids_scratch + (size_t)tab0 * tabs->d.F;
     HIPCHK(c, hipMemcpyAsync(dlay, tlayout.data(), sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, c->stream));
     launch_ftab_pack(tabs->d, tabs->cur, tab0, B, d, dlay, dslot, c->stream);
-    std::vector<int> hs((size_t)B * tabs->d.F);
-    HIPCHK(c, hipMemcpyAsync(hs.data(), dslot, sizeof(int) * hs.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(dlay); (void)hipFree(dslot);
-    for (int w = 0; w < B; w++) b->slot_of[w].assign(hs.begin() + (size_t)w * tabs->d.F, hs.begin() + (size_t)w * tabs->d.F + b->L[w]);
+    for (int w = 0; w < B; w++) {
+      b->slot_of[w].resize(b->L[w]);
+      if (b->L[w] > 0) HIPCHK(c, hipMemcpyAsync(b->slot_of[w].data(), dslot + (size_t)w * tabs->d.F, sizeof(int) * b->L[w], hipMemcpyDeviceToHost, c->stream));
+    }
   }
   const double T2 = now();
   if (dbg_t) (void)hipStreamSynchronize(c->stream);
@@ -999,13 +999,24 @@ static gfbe_status preint_common(gfbe_ctx *c, int n, const int32_t *offset, cons
   if (!c || n <= 0 || !offset || !samples || !out) return GFBE_BAD_INPUT;
   if (c->device < 0 || !c->stream) { c->err = "HIP device context required (no CPU fallback)"; return GFBE_NO_DEVICE; }
   const int tot = offset[n];
-  int *d_off = nullptr; double *d_s = nullptr, *d_f = nullptr, *d_l = nullptr, *d_n = nullptr; REC_T *d_o = nullptr;
-  HIPCHK(c, hipMalloc((void **)&d_off, sizeof(int) * (n + 1)));
-  HIPCHK(c, hipMalloc((void **)&d_s, sizeof(double) * 7 * std::max(tot, 1)));
-  HIPCHK(c, hipMalloc((void **)&d_f, sizeof(double) * 6 * n));
-  HIPCHK(c, hipMalloc((void **)&d_l, sizeof(double) * lin_w * n));
-  HIPCHK(c, hipMalloc((void **)&d_n, sizeof(double) * 4));
-  HIPCHK(c, hipMalloc((void **)&d_o, sizeof(REC_T) * n));
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_off = al(sizeof(int) * (n + 1)), b_s = al(sizeof(double) * 7 * std::max(tot, 1)), b_f = al(sizeof(double) * 6 * n),
+               b_l = al(sizeof(double) * lin_w * n), b_n = al(sizeof(double) * 4), b_o = al(sizeof(REC_T) * n);
+  const size_t need = b_off + b_s + b_f + b_l + b_n + b_o;
+  if (need > c->scratch_cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->scratch) (void)hipFree(c->scratch);
+    c->scratch = nullptr; c->scratch_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&c->scratch, 2 * need));
+    c->scratch_cap = 2 * need;
+  }
+  char *base = c->scratch;
+  int *d_off = (int *)base; base += b_off;
+  double *d_s = (double *)base; base += b_s;
+  double *d_f = (double *)base; base += b_f;
+  double *d_l = (double *)base; base += b_l;
+  double *d_n = (double *)base; base += b_n;
+  REC_T *d_o = (REC_T *)base;
   HIPCHK(c, hipMemcpyAsync(d_off, offset, sizeof(int) * (n + 1), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_s, samples, sizeof(double) * 7 * tot, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_f, first, sizeof(double) * 6 * n, hipMemcpyHostToDevice, c->stream));
@@ -1016,7 +1027,6 @@ static gfbe_status preint_common(gfbe_ctx *c, int n, const int32_t *offset, cons
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(out, d_o, sizeof(REC_T) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_off); (void)hipFree(d_s); (void)hipFree(d_f); (void)hipFree(d_l); (void)hipFree(d_n); (void)hipFree(d_o);
   return GFBE_OK;
 }
 

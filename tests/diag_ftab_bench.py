@@ -33,6 +33,7 @@ for name, T in tabs.items():
     L = int((T.download(0)["n_obs"] >= 4).sum())
     x = [1.0 / rng.uniform(0.5, 9, L)] * W
     t0 = time.perf_counter(); T.set_depth(x); t["set_depth"] = time.perf_counter() - t0
+    t0 = time.perf_counter(); T.check_outliers(poses, tic_ric, 1); t["movingConsistencyCheckW (first call)"] = time.perf_counter() - t0
     t0 = time.perf_counter(); T.check_outliers(poses, tic_ric, 1); t["movingConsistencyCheckW"] = time.perf_counter() - t0
     PR = np.tile(np.concatenate([np.zeros(3), np.eye(3).ravel()]), (W, 1))
     t0 = time.perf_counter(); T.remove_back_shift_depth(PR, PR); t["remove_back_shift_depth"] = time.perf_counter() - t0
