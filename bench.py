@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows (tiled to --batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", type=int, default=None, help="gfbe_options.split_batch: parts a batch of >= 128 windows is solved in, side by side (library default: 2)")
+    ap.add_argument("--graph", action="store_true", help="gfbe_options.use_graph: replay the launch sequence as a hipGraph")
     ap.add_argument("--shard-landmarks", action="store_true",
                     help="N > 1 only: every rank holds the SAME windows and evaluates its share of the landmark tiles; the partial "
                          "normal equations are summed with RCCL all-reduces (BASELINE configs[2]; strong scaling of one solve)")
@@ -55,7 +57,12 @@ def main():
         dist.init_process_group(os.environ.get("GFBE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    be = gf.Backend(device=local_rank)          # raises if the HIP extension / GPU is missing
+    opts = abi.default_options()
+    if args.split is not None:
+        opts.split_batch = args.split
+    if args.graph:
+        opts.use_graph = 1
+    be = gf.Backend(device=local_rank, options=opts)          # raises if the HIP extension / GPU is missing
     be.set_stream(torch.cuda.current_stream().cuda_stream)
     shard = args.shard_landmarks and world > 1
     if shard:

@@ -639,27 +639,39 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
 
 extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b);
 
-// Batches of >= BATCH_SPLIT_MIN_B windows become two halves solved side by side on two stream pairs.
+// Batches of >= BATCH_SPLIT_MIN_B windows become `split_batch` parts (default two halves) solved side by side, each on
+// its own pair of streams: a chain a -> a->second -> ...; part k + 1 runs on part k's `lane2`.
+static gfbe_status make_lane(gfbe_ctx *c, gfbe_batch *a) {
+  if (hipStreamCreateWithFlags(&a->lane2.s, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&a->lane2.aux, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&a->lane2.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&a->lane2.join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_start2, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&a->ev_done2, hipEventDisableTiming) != hipSuccess) {
+    c->err = "hipStreamCreate/hipEventCreate (part of a split batch) failed";
+    return GFBE_DEVICE_ERROR;
+  }
+  return GFBE_OK;
+}
 static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   *out = nullptr;
-  const bool split = B >= BATCH_SPLIT_MIN_B && c->world == 1 && c->opt.split_batch;
-  const int nA = split ? (B + 1) / 2 : B;
-  gfbe_status st = upload_one(c, nA, wins, out, tabs, 0);
-  if (st != GFBE_OK) { gfbe_batch_free(c, *out); *out = nullptr; return st; }
-  if (!split) return st;
-  gfbe_batch *a = *out;
-  st = upload_one(c, B - nA, wins + nA, &a->second, tabs, nA);
-  if (st == GFBE_OK && (hipStreamCreateWithFlags(&a->lane2.s, hipStreamNonBlocking) != hipSuccess ||
-                        hipStreamCreateWithFlags(&a->lane2.aux, hipStreamNonBlocking) != hipSuccess ||
-                        hipEventCreateWithFlags(&a->lane2.fork, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&a->lane2.join, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&a->ev_start2, hipEventDisableTiming) != hipSuccess ||
-                        hipEventCreateWithFlags(&a->ev_done2, hipEventDisableTiming) != hipSuccess)) {
-    c->err = "hipStreamCreate/hipEventCreate (second half of the batch) failed";
-    st = GFBE_DEVICE_ERROR;
+  int parts = 1;
+  if (B >= BATCH_SPLIT_MIN_B && c->world == 1 && c->opt.split_batch) parts = std::min(std::max(c->opt.split_batch, 2), std::max(B / DENSE_SPLIT_MIN_B, 1));
+  gfbe_batch **link = out;
+  gfbe_batch *prev = nullptr;
+  int done = 0;
+  gfbe_status st = GFBE_OK;
+  for (int p = 0; p < parts && st == GFBE_OK; p++) {
+    const int n = (B - done + (parts - p) - 1) / (parts - p);
+    st = upload_one(c, n, wins + done, link, tabs, done);
+    if (st == GFBE_OK && prev) st = make_lane(c, prev);
+    if (st != GFBE_OK) break;
+    prev = *link;
+    link = &prev->second;
+    done += n;
   }
-  if (st != GFBE_OK) { gfbe_batch_free(c, a); *out = nullptr; }
+  if (st != GFBE_OK) { gfbe_batch_free(c, *out); *out = nullptr; }
   return st;
 }
 
@@ -686,10 +698,12 @@ extern "C" gfbe_status gfbe_batch_upload_tables(gfbe_ctx *c, gfbe_ftab *t, int32
 }
 
 extern "C" int32_t gfbe_batch_feature_count(const gfbe_batch *b, int32_t w) {
-  if (!b || w < 0) return -1;
-  const int nA = (int)b->L.size();
-  if (w < nA) return b->L[w];
-  return b->second && w - nA < (int)b->second->L.size() ? b->second->L[w - nA] : -1;
+  if (w < 0) return -1;
+  for (; b; b = b->second) {
+    if (w < (int)b->L.size()) return b->L[w];
+    w -= (int)b->L.size();
+  }
+  return -1;
 }
 
 extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
@@ -796,7 +810,26 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
   const BatchDev &d = b->d;
   if (d.world > 1 && !c->allreduce) { c->err = "batch was uploaded for landmark sharding but the all-reduce hook is gone"; return GFBE_BAD_INPUT; }
   // hipGraph replay: not while profiling (per-kernel events) and not with the all-reduce hook (host callback)
+  // (not for split batches: capturing the cross-stream fork / join of the parts crashed the runtime on ROCm 7.2)
   const bool graphable = c->opt.use_graph && !c->profiling && d.world == 1 && !b->second;
+  const Lane lane1 = {c->stream, c->aux, c->ev_fork, c->ev_join};
+  // every part but the first on its own streams beside the first, joined back into the caller's stream
+  auto enqueue_all = [&]() -> gfbe_status {
+    gfbe_status st = GFBE_OK;
+    if (b->second && !c->profiling) {
+      (void)hipEventRecord(b->ev_start2, c->stream);
+      for (gfbe_batch *p = b; p->second && st == GFBE_OK; p = p->second) {
+        (void)hipStreamWaitEvent(p->lane2.s, b->ev_start2, 0);
+        st = enqueue_solve(c, p->second, p->lane2, margin_flag);
+        (void)hipEventRecord(p->ev_done2, p->lane2.s);
+      }
+      if (st == GFBE_OK) st = enqueue_solve(c, b, lane1, margin_flag);
+      for (gfbe_batch *p = b; p->second; p = p->second) (void)hipStreamWaitEvent(c->stream, p->ev_done2, 0);
+    } else {
+      for (gfbe_batch *p = b; p && st == GFBE_OK; p = p->second) st = enqueue_solve(c, p, lane1, margin_flag);
+    }
+    return st;
+  };
   if (graphable && b->graph[margin_flag]) {
     HIPCHK(c, hipGraphLaunch(b->graph[margin_flag], c->stream));
     return GFBE_OK;
@@ -804,7 +837,7 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
   if (graphable && b->calls[margin_flag]++ >= 1) {   // the first call ran eagerly (one-time attribute setup); capture now
     hipGraph_t g = nullptr;
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
-      enqueue_solve(c, b, Lane{c->stream, c->aux, c->ev_fork, c->ev_join}, margin_flag);
+      (void)enqueue_all();
       const hipError_t e = hipStreamEndCapture(c->stream, &g);
       if (e == hipSuccess && g && hipGraphInstantiate(&b->graph[margin_flag], g, nullptr, nullptr, 0) == hipSuccess) {
         (void)hipGraphDestroy(g);
@@ -817,19 +850,7 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
     }
     c->opt.use_graph = 0;   // capture not available on this stream: stay eager
   }
-  const Lane lane1 = {c->stream, c->aux, c->ev_fork, c->ev_join};
-  gfbe_status st;
-  if (b->second && !c->profiling) {   // the second half beside the first, on its own streams; joined back into the caller's stream
-    (void)hipEventRecord(b->ev_start2, c->stream);
-    (void)hipStreamWaitEvent(b->lane2.s, b->ev_start2, 0);
-    st = enqueue_solve(c, b->second, b->lane2, margin_flag);
-    (void)hipEventRecord(b->ev_done2, b->lane2.s);
-    if (st == GFBE_OK) st = enqueue_solve(c, b, lane1, margin_flag);
-    (void)hipStreamWaitEvent(c->stream, b->ev_done2, 0);
-  } else {
-    st = enqueue_solve(c, b, lane1, margin_flag);
-    if (st == GFBE_OK && b->second) st = enqueue_solve(c, b->second, lane1, margin_flag);
-  }
+  const gfbe_status st = enqueue_all();
   if (st != GFBE_OK) return st;
   HIPCHK(c, hipGetLastError());
   return GFBE_OK;
@@ -892,12 +913,16 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
 extern "C" gfbe_status gfbe_batch_download(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_state, double *const *out_feature,
                                           gfbe_prior *const *prior_out, gfbe_summary *summary) {
   if (!c || !b) return GFBE_BAD_INPUT;
-  gfbe_status st = download_one(c, b, out_state, out_feature, prior_out, summary);
-  if (!b->second || st > GFBE_NO_CONVERGENCE) return st;
-  const int nA = b->d.B;
-  const gfbe_status st2 = download_one(c, b->second, out_state ? out_state + nA : nullptr, out_feature ? out_feature + nA : nullptr,
-                                       prior_out ? prior_out + nA : nullptr, summary ? summary + nA : nullptr);
-  return st2 > st ? st2 : st;
+  gfbe_status worst = GFBE_OK;
+  int done = 0;
+  for (gfbe_batch *p = b; p; p = p->second) {
+    const gfbe_status st = download_one(c, p, out_state ? out_state + done : nullptr, out_feature ? out_feature + done : nullptr,
+                                        prior_out ? prior_out + done : nullptr, summary ? summary + done : nullptr);
+    if (st > GFBE_NO_CONVERGENCE) return st;
+    if (st > worst) worst = st;
+    done += p->d.B;
+  }
+  return worst;
 }
 
 extern "C" gfbe_status gfbe_solve_batch(gfbe_ctx *c, int32_t n, const gfbe_window *const *win, int32_t margin_flag,

@@ -185,9 +185,10 @@ typedef struct gfbe_options {
    * call eager, second captured); 0 (default): eager launches — on ROCm 7.2 / MI355X the replay measured 2.50 vs
    * 2.54 ms for one window and 3 % slower at 256 windows. Ignored while profiling / landmark sharding. */
   int32_t use_graph;
-  /* 1 (default): gfbe_batch_upload splits batches of >= 128 windows into two halves that gfbe_batch_solve runs side by
-   * side on two pairs of streams (kernels of different stages share the GPU: +13 % at 256 windows); results per
-   * window are unchanged (every window is independent). 0: one launch sequence for the whole batch. */
+  /* Parts a batch of >= 128 windows is split into by gfbe_batch_upload; gfbe_batch_solve runs the parts side by side,
+   * each on its own pair of streams (kernels of different stages share the GPU). 1 or 2 (default 1): two halves, +13 % at
+   * 256 windows; 3 / 4 parts measured slower (45.1k / 44.0k vs 49.5k solves/s at 1024 windows). Results per window are
+   * unchanged (every window is independent). 0: one launch sequence for the whole batch. */
   int32_t split_batch;
 } gfbe_options;
 
