@@ -212,6 +212,7 @@ void launch_asm_table(const BatchDev &d, hipStream_t s);
 hipStream_t ctx_stream(gfbe_ctx *c);
 int ctx_device(const gfbe_ctx *c);
 void ctx_set_error(gfbe_ctx *c, const char *msg);
+void *ctx_scratch(gfbe_ctx *c, size_t bytes);   // grow-only device scratch of the context (one caller at a time), nullptr on failure
 void launch_xchg_gram(const BatchDev &d, hipStream_t s);
 void launch_xchg_cand(const BatchDev &d, hipStream_t s);
 void launch_lam_mask(const BatchDev &d, hipStream_t s);

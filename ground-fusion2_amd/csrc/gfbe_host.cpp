@@ -95,6 +95,18 @@ namespace gfd {
 hipStream_t ctx_stream(gfbe_ctx *c) { return c->stream; }
 int ctx_device(const gfbe_ctx *c) { return c ? c->device : -1; }
 void ctx_set_error(gfbe_ctx *c, const char *msg) { if (c) c->err = msg; }
+// grow-only device scratch of the context (at least `bytes`; contents undefined); nullptr when the allocation fails
+void *ctx_scratch(gfbe_ctx *c, size_t bytes) {
+  if (bytes > c->scratch_cap) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->scratch) (void)hipFree(c->scratch);
+    c->scratch = nullptr; c->scratch_cap = 0;
+    const size_t cap = bytes + bytes / 2;
+    if (hipMalloc((void **)&c->scratch, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->scratch_cap = cap;
+  }
+  return c->scratch;
+}
 }  // namespace gfd
 
 extern "C" {
@@ -1028,13 +1040,7 @@ static gfbe_status preint_common(gfbe_ctx *c, int n, const int32_t *offset, cons
   const size_t b_off = al(sizeof(int) * (n + 1)), b_s = al(sizeof(double) * 7 * std::max(tot, 1)), b_f = al(sizeof(double) * 6 * n),
                b_l = al(sizeof(double) * lin_w * n), b_n = al(sizeof(double) * 4), b_o = al(sizeof(REC_T) * n);
   const size_t need = b_off + b_s + b_f + b_l + b_n + b_o;
-  if (need > c->scratch_cap) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->scratch) (void)hipFree(c->scratch);
-    c->scratch = nullptr; c->scratch_cap = 0;
-    HIPCHK(c, hipMalloc((void **)&c->scratch, 2 * need));
-    c->scratch_cap = 2 * need;
-  }
+  if (!ctx_scratch(c, need)) { c->err = "hipMalloc(pre-integration scratch) failed"; return GFBE_DEVICE_ERROR; }
   char *base = c->scratch;
   int *d_off = (int *)base; base += b_off;
   double *d_s = (double *)base; base += b_s;

@@ -302,10 +302,11 @@ struct PgBuffers {
   size_t cap = 0, used = 0;
   bool dry = true;
   explicit PgBuffers(gfbe_ctx *ctx) : c(ctx) {}
-  ~PgBuffers() { (void)hipStreamSynchronize(ctx_stream(c)); if (slab) (void)hipFree(slab); }
-  bool commit() {   // end of the dry run: allocate what was asked for, restart
+  ~PgBuffers() { (void)hipStreamSynchronize(ctx_stream(c)); }
+  bool commit() {   // end of the dry run: take what was asked for from the context's grow-only scratch, restart
     cap = used; used = 0; dry = false;
-    if (hipMalloc((void **)&slab, std::max<size_t>(cap, 256)) != hipSuccess) return false;
+    slab = (char *)ctx_scratch(c, std::max<size_t>(cap, 256));
+    if (!slab) return false;
     (void)hipMemsetAsync(slab, 0, std::max<size_t>(cap, 256), ctx_stream(c));
     return true;
   }
@@ -321,21 +322,58 @@ struct PgBuffers {
   }
 };
 
-// sums per-pose values in pose order on the host (fixed order -> reproducible)
-double host_sum(gfbe_ctx *c, const double *dptr, int n, std::vector<double> &tmp, bool take_max = false) {
-  tmp.resize(n);
-  (void)hipMemcpyAsync(tmp.data(), dptr, sizeof(double) * n, hipMemcpyDeviceToHost, ctx_stream(c));
+// Per-pose values -> up to three scalars on the device, 24 bytes back to the host instead of n doubles per sum. Two stages,
+// fixed order: workgroup b reduces the segment [b * PGR_SEG, (b + 1) * PGR_SEG) (coalesced loads, thread t takes t, t + 256, ...,
+// LDS tree), then one workgroup adds the segment partials in segment order. take_max: the first array is reduced with max
+// (gradient infinity norm).
+enum { PGR_SEG = 4096, PGR_MAXSEG = 1024 };
+__global__ __launch_bounds__(256) void k_pg_reduce1(int n, const double *a, const double *b, const double *c3, int take_max, double *partial) {
+  __shared__ double sh[3][256];
+  const int t = threadIdx.x, i0 = blockIdx.x * PGR_SEG, i1 = min(n, i0 + PGR_SEG);
+  double va = 0.0, vb = 0.0, vc = 0.0;
+  for (int i = i0 + t; i < i1; i += 256) {
+    va = take_max ? fmax(va, a[i]) : va + a[i];
+    if (b) vb += b[i];
+    if (c3) vc += c3[i];
+  }
+  sh[0][t] = va; sh[1][t] = vb; sh[2][t] = vc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) {
+      sh[0][t] = take_max ? fmax(sh[0][t], sh[0][t + o]) : sh[0][t] + sh[0][t + o];
+      sh[1][t] += sh[1][t + o];
+      sh[2][t] += sh[2][t + o];
+    }
+    __syncthreads();
+  }
+  if (t < 3) partial[3 * blockIdx.x + t] = sh[t][0];
+}
+__global__ __launch_bounds__(64) void k_pg_reduce2(int nseg, const double *partial, int take_max, double *out) {
+  const int t = threadIdx.x;
+  if (t >= 3) return;
+  double v = 0.0;
+  for (int q = 0; q < nseg; q++) { const double x = partial[3 * q + t]; v = (take_max && t == 0) ? fmax(v, x) : v + x; }
+  out[t] = v;
+}
+// dscratch: 3 + 3 * PGR_MAXSEG doubles
+void dev_reduce(gfbe_ctx *c, int n, const double *a, const double *b, const double *c3, bool take_max, double *dscratch, double out[3]) {
+  const int nseg = (n + PGR_SEG - 1) / PGR_SEG;
+  hipLaunchKernelGGL(k_pg_reduce1, dim3(nseg), dim3(256), 0, ctx_stream(c), n, a, b, c3, take_max ? 1 : 0, dscratch + 4);
+  hipLaunchKernelGGL(k_pg_reduce2, dim3(1), dim3(64), 0, ctx_stream(c), nseg, dscratch + 4, take_max ? 1 : 0, dscratch);
+  (void)hipMemcpyAsync(out, dscratch, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx_stream(c));
   (void)hipStreamSynchronize(ctx_stream(c));
-  double s = 0.0;
-  for (int i = 0; i < n; i++) s = take_max ? std::max(s, tmp[i]) : s + tmp[i];
-  return s;
+}
+double host_sum(gfbe_ctx *c, const double *dptr, int n, double *dscratch, bool take_max = false) {
+  double out[3];
+  dev_reduce(c, n, dptr, nullptr, nullptr, take_max, dscratch, out);
+  return out[0];
 }
 
 gfbe_status pg_prepare(gfbe_ctx *c, int n, int n_rel, const int32_t *rel_i, int n_fix, const int32_t *fix_i, const double *fix_meas,
                        std::vector<int> &rel_of, std::vector<int> &fix_begin, std::vector<double> &fix_sorted, std::vector<int> &fix_order) {
   if (!c) return GFBE_BAD_INPUT;
   if (ctx_device(c) < 0) return GFBE_NO_DEVICE;
-  if (n < 1 || n_rel < 0 || n_fix < 0) return GFBE_BAD_INPUT;
+  if (n < 1 || n_rel < 0 || n_fix < 0 || n > PGR_SEG * PGR_MAXSEG) return GFBE_BAD_INPUT;   // (4.2 M poses: the reduction scratch)
   rel_of.assign(n, -1);
   for (int k = 0; k < n_rel; k++) {
     if (rel_i[k] < 0 || rel_i[k] + 1 >= n || rel_of[rel_i[k]] >= 0) { ctx_set_error(c, "gfbe_pg: relative factors must connect distinct consecutive poses (i, i+1)"); return GFBE_BAD_INPUT; }
@@ -363,18 +401,18 @@ gfbe_status gfbe_pg_eval(gfbe_ctx *c, int32_t n, const double *pose, int32_t n_r
   if (st != GFBE_OK) return st;
   PgBuffers buf(c);
   PgDev P;
-  double *dpose, *dcost, *dr, *dJ, *dfr, *Hd, *Ho, *g;
+  double *dpose, *dcost, *dr, *dJ, *dfr, *Hd, *Ho, *g, *red3;
   for (int pass = 0; pass < 2; pass++) {
     P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
          buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
     dpose = buf.dev<double>((size_t)7 * n, pose); dcost = buf.dev<double>(n); dr = buf.dev<double>((size_t)6 * n_rel);
     dJ = buf.dev<double>((size_t)72 * n_rel); dfr = buf.dev<double>((size_t)3 * n_fix);
     Hd = buf.dev<double>((size_t)36 * n); Ho = buf.dev<double>((size_t)36 * n); g = buf.dev<double>((size_t)6 * n);
+    red3 = buf.dev<double>(4 + 3 * (size_t)PGR_MAXSEG);
     if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_eval: device allocation failed"); return GFBE_DEVICE_ERROR; }
   }
   hipLaunchKernelGGL(k_pg_lin, dim3((n + 127) / 128), dim3(128), 0, ctx_stream(c), P, dpose, dcost, Hd, Ho, g, dr, dJ, dfr);
-  std::vector<double> tmp;
-  const double total = host_sum(c, dcost, n, tmp);
+  const double total = host_sum(c, dcost, n, red3);
   if (cost) *cost = total;
   if (rel_r && n_rel) (void)hipMemcpy(rel_r, dr, sizeof(double) * 6 * n_rel, hipMemcpyDeviceToHost);
   if (rel_J && n_rel) (void)hipMemcpy(rel_J, dJ, sizeof(double) * 72 * n_rel, hipMemcpyDeviceToHost);
@@ -400,6 +438,7 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
   PgDev P;
   double *x, *cand, *per, *per2, *per3, *Hd, *Ho, *g, *scale, *diag2, *Bs, *A0, *C0, *Ab[2], *Bb[2], *Cb[2], *db[2], *d0, *y;
   int *fail;
+  double *red3;
   for (int pass = 0; pass < 2; pass++) {
     P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
          buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
@@ -414,14 +453,14 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     }
     d0 = buf.dev<double>((size_t)6 * n); y = buf.dev<double>((size_t)6 * n);
     fail = buf.dev<int>(1);
+    red3 = buf.dev<double>(4 + 3 * (size_t)PGR_MAXSEG);
     if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_solve: device allocation failed"); return GFBE_DEVICE_ERROR; }
   }
   const dim3 g128((n + 127) / 128), b128(128), g64((n + 63) / 64), b64(64);
-  std::vector<double> tmp;
   gfbe_summary sm;
   std::memset(&sm, 0, sizeof sm);
   hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, x, per, Hd, Ho, g, (double *)nullptr, (double *)nullptr, (double *)nullptr);
-  double cost = host_sum(c, per, n, tmp);
+  double cost = host_sum(c, per, n, red3);
   sm.initial_cost = cost; sm.cost_history[0] = cost; sm.status = GFBE_NO_CONVERGENCE;
   double radius = 1e4, decrease = 2.0, x_norm;
   {
@@ -438,7 +477,7 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     hipLaunchKernelGGL(k_pg_system, g128, b128, 0, s, n, Hd, Ho, g, scale, have_scale ? 0 : 1, diag2, reuse ? 1 : 0, radius, Bb[0], d0, Bs, per);
     hipLaunchKernelGGL(k_pg_system2, g128, b128, 0, s, n, Ho, scale, A0, C0);
     have_scale = true;
-    const double gmax = host_sum(c, per, n, tmp, true);
+    const double gmax = host_sum(c, per, n, red3, true);
     if (gmax <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; break; }
     if (radius < 1e-32) { sm.termination = 4; break; }
     it++;
@@ -456,7 +495,9 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     hipLaunchKernelGGL(k_pg_candidate, g128, b128, 0, s, n, Bs, A0, C0, d0, y, scale, x, cand, per, per2, per3);
     int hfail = 0;
     (void)hipMemcpyAsync(&hfail, fail, sizeof(int), hipMemcpyDeviceToHost, s);
-    const double model_change = host_sum(c, per, n, tmp);
+    double r3[3];
+    dev_reduce(c, n, per, per2, per3, false, red3, r3);      // model change, |step|^2, |candidate|^2
+    const double model_change = r3[0];
     if (hfail || !(model_change > 0.0)) {
       sm.accepted[it] = 0; sm.cost_history[it] = cost;
       if (++invalid >= 5) { sm.termination = 4; sm.status = GFBE_NUMERICAL_FAILURE; break; }
@@ -464,10 +505,10 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
       continue;
     }
     invalid = 0;
-    const double step2 = host_sum(c, per2, n, tmp), cand_x2 = host_sum(c, per3, n, tmp);
+    const double step2 = r3[1], cand_x2 = r3[2];
     hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, cand, per, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr);
-    const double cand_cost = host_sum(c, per, n, tmp);
+    const double cand_cost = host_sum(c, per, n, red3);
     sm.cost_history[it] = cost;
     if (std::sqrt(step2) <= 1e-8 * (x_norm + 1e-8)) { sm.termination = 2; sm.status = GFBE_OK; break; }
     const double change = cost - cand_cost;
