@@ -909,11 +909,16 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
 #define VB_THREADS 1024
 #define VB_GROUP 512
 #define V_LD 74
-__global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
-  const int w = blockIdx.x;
+// SPLIT (small batches): one workgroup per (start frame, window) writes its own block vis_Hs[w][i]; k_assemble adds the blocks
+// in start-frame order — the same additions in the same order as the sequential loop of the one-workgroup form (bit-identical),
+// ten workgroups beside each other instead of ten start frames one after the other on the latency path of a single window.
+template <bool SPLIT>
+__device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last) {
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
+  // (SPLIT: a start frame without landmarks leaves its block as the upload zeroed it — the structure never changes)
+  if (SPLIT && i_first != 0 && ds.sf_tile_begin[i_first] == ds.sf_tile_begin[i_first + 1]) return;
   __shared__ double V[NV * V_LD];
   __shared__ int s_tile_begin[NF + 1];
   const int t = threadIdx.x;
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
   const bool row_ok = live && la != 19, mir_ok = live && mirror && lb != 19;
   const bool uses_j = aj || bj;
   const double *vp = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VP_STRIDE + e;
-  for (int i = 0; i < NF - 1; i++) {
+  for (int i = i_first; i <= i_last; i++) {
     const int t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
     if (t0 == t1) continue;
     const int nk = NF - 1 - i;
@@ -990,7 +995,8 @@ __global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
       __syncthreads();
     }
   }
-  if (ds.lio_n > 0 && d.rank == 0 && t < 27) {   // LiDAR factors of pose lio_frame (k_lio_window): 6 x 6 block, gradient
+  const bool lead = (i_first == 0);      // (SPLIT: the start-frame-0 workgroup also carries the LiDAR block and the cost)
+  if (!SPLIT && lead && ds.lio_n > 0 && d.rank == 0 && t < 27) {   // LiDAR factors of pose lio_frame (k_lio_window): 6 x 6 block, gradient (SPLIT: k_assemble adds them)
     double v = 0.0;
     for (int q = 0; q < LIOW_WGS; q++) v += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + t];
     const int o = 6 * ds.lio_frame;
@@ -1005,10 +1011,10 @@ __global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
     }
   }
   __syncthreads();
-  double *out = d.vis_H + (size_t)w * NV * V_LD;
+  double *out = SPLIT ? d.vis_Hs + ((size_t)w * (NF - 1) + i_first) * NV * V_LD : d.vis_H + (size_t)w * NV * V_LD;
   for (int q = t; q < NV * V_LD; q += VB_THREADS) out[q] = V[q];
   // robustified visual cost of this linearisation point (this rank's tiles; lanes stride the tiles, fixed tree order)
-  if (t < 64) {
+  if (lead && t < 64) {
     double cs = 0.0;
     for (int q = t; q < ds.n_tiles; q += 64) cs += d.tile_cost[(size_t)w * d.max_tiles + q];
     cs = wave_sum(cs);
@@ -1019,6 +1025,8 @@ __global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) {
   ASTAMP(7);
 #undef ASTAMP
 }
+__global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) { visblock_body<false>(d, blockIdx.x, 0, NF - 2); }
+__global__ __launch_bounds__(VB_THREADS) void k_visblock_small(BatchDev d) { visblock_body<true>(d, blockIdx.y, blockIdx.x, blockIdx.x); }
 
 #define ASM_THREADS 256
 #define ASM_WGS 16
@@ -1041,6 +1049,10 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   const int4 *tab = (const int4 *)d.asm_tab;
   const double *imu_w = d.imu_part + (size_t)w * MAX_IMU * IMU_PART, *wheel_w = d.wheel_part + (size_t)w * MAX_WHEEL * WHEEL_PART;
   const double *prior_w = d.prior_H + (size_t)w * ND * ND, *vis_w = d.vis_H + (size_t)w * NV * V_LD;
+  const bool vsplit = d.vis_Hs != nullptr;
+  const bool lio_on = vsplit && ds.lio_n > 0 && d.rank == 0;
+  const int lio_o = 6 * ds.lio_frame;
+  const double *vis_s = vsplit ? d.vis_Hs + (size_t)w * (NF - 1) * NV * V_LD : Z;
   for (int e0 = gt; e0 < ASM_NTRI; e0 += 4 * gn) {
     int4 ent[4];
 #pragma unroll
@@ -1061,11 +1073,33 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
       p[u][3] = r1 >= 0 ? wheel_w + r1 * WHEEL_PART + ((z >> 20) & 1023) : Z;
       const int pa = on[u] && dense_here && tb.prior_n > 0 ? tb.prior_map[b] : -1, pb = on[u] && dense_here && tb.prior_n > 0 ? tb.prior_map[a] : -1;
       p[u][4] = (pa >= 0 && pb >= 0) ? prior_w + (size_t)pa * tb.prior_n + pb : Z;
-      p[u][5] = (on[u] && a < NV) ? vis_w + b * V_LD + a : Z;
+      p[u][5] = (on[u] && a < NV && !vsplit) ? vis_w + b * V_LD + a : Z;
     }
     double v[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) v[u] = *p[u][0] + *p[u][1] + *p[u][2] + *p[u][3] + *p[u][4] + *p[u][5];
+    if (vsplit) {   // small batches: the visual entry is the sum of the start-frame blocks, in start-frame order (loads in flight together)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
+        if (!(on[u] && a < NV)) continue;
+        const double *q = vis_s + b * V_LD + a;
+        double blk[NF - 1];
+#pragma unroll
+        for (int f = 0; f < NF - 1; f++) blk[f] = q[(size_t)f * NV * V_LD];
+        double sv = 0.0;
+#pragma unroll
+        for (int f = 0; f < NF - 1; f++) sv += blk[f];
+        if (lio_on && b >= lio_o && a < lio_o + 6) {   // LiDAR block of pose lio_frame: added last, as the one-workgroup form does
+          const int ra = b - lio_o, rb = a - lio_o;      // ra <= rb: packed upper triangle of k_lio_window
+          const int e = ra * 6 - ra * (ra - 1) / 2 + (rb - ra);
+          double lv = 0.0;
+          for (int q = 0; q < LIOW_WGS; q++) lv += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + e];
+          sv += lv;
+        }
+        v[u] += sv;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       if (ent[u].x < 0) continue;
@@ -1095,7 +1129,22 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   }
   for (int a = gt; a < ND; a += gn) {
     double v = 0.0;
-    if (tb.act[a]) { v = dense_here ? gather_g_dense(d, tb, Z, w, a) : 0.0; if (a < NV) v += vis_w[a * V_LD + NV]; }
+    if (tb.act[a]) {
+      v = dense_here ? gather_g_dense(d, tb, Z, w, a) : 0.0;
+      if (a < NV) {
+        if (!vsplit) v += vis_w[a * V_LD + NV];
+        else {
+          double sv = 0.0;
+          for (int f = 0; f < NF - 1; f++) sv += vis_s[(size_t)f * NV * V_LD + a * V_LD + NV];
+          if (lio_on && a >= lio_o && a < lio_o + 6) {
+            double lv = 0.0;
+            for (int q = 0; q < LIOW_WGS; q++) lv += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + 21 + a - lio_o];
+            sv += lv;
+          }
+          v += sv;
+        }
+      }
+    }
     g[a] = v;
     if (a < NV) eg[a] = tb.act[a] ? gather_E11(d, Z, w, a, NV) : 0.0;
   }
@@ -1864,7 +1913,10 @@ void launch_lio_window(const BatchDev &d, int mode, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL(k_lio_window<0>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
   else hipLaunchKernelGGL(k_lio_window<1>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
 }
-void launch_visblock(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d); }
+void launch_visblock(const BatchDev &d, hipStream_t s) {
+  if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(NF - 1, d.B), dim3(VB_THREADS), 0, s, d);
+  else hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d);
+}
 void launch_assemble(const BatchDev &d, hipStream_t s) {
   hipLaunchKernelGGL(k_assemble, dim3(ASM_WGS, d.B), dim3(ASM_THREADS), 0, s, d);
 }
