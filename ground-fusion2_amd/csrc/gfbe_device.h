@@ -33,6 +33,7 @@ enum {
   MAX_IMU = 10, MAX_WHEEL = 10,
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
+  VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)
   XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
   HC = 13                     // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
@@ -167,7 +168,7 @@ struct BatchDev {
                               //   xa: visual cost of the linearisation point; xb: landmark shares of the dogleg scalars;
                               //   xc: candidate cost / step norms
   double *vis_H;              // [B][73][74]  visual block of the normal equations + gradient column (k_visblock)
-  double *vis_Hs;             // small batches only (else nullptr): [B][NF - 1][73][74], one block per start frame, summed by k_assemble
+  double *vis_Hs;             // small batches only (else nullptr): [B][VS_BLOCKS][73][74], one block per (start frame, thread group), summed by k_assemble
   double *raw_imu, *raw_wheel; // [MAX_IMU][15 + 450][B], [MAX_WHEEL][6 + 132][B]  un-whitened residuals / Jacobians (k_dense_raw), window-minor
   int *asm_tab;               // [ND (ND + 1) / 2][4]  window-independent assembly table (k_asm_table)
   double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble

@@ -603,7 +603,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0);
   AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
   AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
-  if (B < DENSE_SPLIT_MIN_B && c->world == 1) { AL(vis_Hs, (size_t)B * (NF - 1) * NV * (NV + 1)); } else d.vis_Hs = nullptr; AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
+  if (B < DENSE_SPLIT_MIN_B && c->world == 1) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr; AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
   AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
   AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
   AL(rec, (size_t)tot_rec * REC);

@@ -909,16 +909,19 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
 #define VB_THREADS 1024
 #define VB_GROUP 512
 #define V_LD 74
-// SPLIT (small batches): one workgroup per (start frame, window) writes its own block vis_Hs[w][i]; k_assemble adds the blocks
-// in start-frame order — the same additions in the same order as the sequential loop of the one-workgroup form (bit-identical),
-// ten workgroups beside each other instead of ten start frames one after the other on the latency path of a single window.
+// SPLIT (small batches): one 512-thread workgroup per (start frame, thread group, window) writes its own block
+// vis_Hs[w][2 i + group]; k_assemble adds the 20 blocks in (start frame, group) order — exactly the additions, in exactly the
+// order, of the sequential loop of the one-workgroup form (bit-identical), twenty workgroups beside each other instead of ten
+// start frames one after the other on the latency path of a single window. sgrp: the thread group of a SPLIT workgroup.
 template <bool SPLIT>
-__device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last) {
+__device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last, const int sgrp) {
+  constexpr int NT = SPLIT ? VB_GROUP : VB_THREADS;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   // (SPLIT: a start frame without landmarks leaves its block as the upload zeroed it — the structure never changes)
-  if (SPLIT && i_first != 0 && ds.sf_tile_begin[i_first] == ds.sf_tile_begin[i_first + 1]) return;
+  const bool lead = (i_first == 0) && (!SPLIT || sgrp == 0);   // (SPLIT: this workgroup also carries the cost)
+  if (SPLIT && !lead && ds.sf_tile_begin[i_first] + sgrp >= ds.sf_tile_begin[i_first + 1]) return;
   __shared__ double V[NV * V_LD];
   __shared__ int s_tile_begin[NF + 1];
   const int t = threadIdx.x;
@@ -926,10 +929,10 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   double *stamp = d.timing + (size_t)w * 32;
 #define ASTAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   ASTAMP(6);
-  for (int e = t; e < NV * V_LD; e += VB_THREADS) V[e] = 0.0;
+  for (int e = t; e < NV * V_LD; e += NT) V[e] = 0.0;
   if (t <= NF) s_tile_begin[t] = ds.sf_tile_begin[t];
   __syncthreads();
-  const int grp = t / VB_GROUP, e = t - grp * VB_GROUP;
+  const int grp = SPLIT ? sgrp : t / VB_GROUP, e = SPLIT ? t : t - grp * VB_GROUP;
   const bool live = e < VP_STRIDE;
   // compact column pair (la, lb) of this thread's entry of a fused partial (layout of k_vis: T0 16x16, T1 16x4, T2 4x4)
   int la = 0, lb = 0; bool mirror = false;
@@ -995,7 +998,6 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
       __syncthreads();
     }
   }
-  const bool lead = (i_first == 0);      // (SPLIT: the start-frame-0 workgroup also carries the LiDAR block and the cost)
   if (!SPLIT && lead && ds.lio_n > 0 && d.rank == 0 && t < 27) {   // LiDAR factors of pose lio_frame (k_lio_window): 6 x 6 block, gradient (SPLIT: k_assemble adds them)
     double v = 0.0;
     for (int q = 0; q < LIOW_WGS; q++) v += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + t];
@@ -1011,8 +1013,8 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
     }
   }
   __syncthreads();
-  double *out = SPLIT ? d.vis_Hs + ((size_t)w * (NF - 1) + i_first) * NV * V_LD : d.vis_H + (size_t)w * NV * V_LD;
-  for (int q = t; q < NV * V_LD; q += VB_THREADS) out[q] = V[q];
+  double *out = SPLIT ? d.vis_Hs + ((size_t)w * VS_BLOCKS + 2 * i_first + sgrp) * NV * V_LD : d.vis_H + (size_t)w * NV * V_LD;
+  for (int q = t; q < NV * V_LD; q += NT) out[q] = V[q];
   // robustified visual cost of this linearisation point (this rank's tiles; lanes stride the tiles, fixed tree order)
   if (lead && t < 64) {
     double cs = 0.0;
@@ -1025,8 +1027,8 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   ASTAMP(7);
 #undef ASTAMP
 }
-__global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) { visblock_body<false>(d, blockIdx.x, 0, NF - 2); }
-__global__ __launch_bounds__(VB_THREADS) void k_visblock_small(BatchDev d) { visblock_body<true>(d, blockIdx.y, blockIdx.x, blockIdx.x); }
+__global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) { visblock_body<false>(d, blockIdx.x, 0, NF - 2, 0); }
+__global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d) { visblock_body<true>(d, blockIdx.y, blockIdx.x >> 1, blockIdx.x >> 1, blockIdx.x & 1); }
 
 #define ASM_THREADS 256
 #define ASM_WGS 16
@@ -1052,7 +1054,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   const bool vsplit = d.vis_Hs != nullptr;
   const bool lio_on = vsplit && ds.lio_n > 0 && d.rank == 0;
   const int lio_o = 6 * ds.lio_frame;
-  const double *vis_s = vsplit ? d.vis_Hs + (size_t)w * (NF - 1) * NV * V_LD : Z;
+  const double *vis_s = vsplit ? d.vis_Hs + (size_t)w * VS_BLOCKS * NV * V_LD : Z;
   for (int e0 = gt; e0 < ASM_NTRI; e0 += 4 * gn) {
     int4 ent[4];
 #pragma unroll
@@ -1084,12 +1086,12 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
         const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
         if (!(on[u] && a < NV)) continue;
         const double *q = vis_s + b * V_LD + a;
-        double blk[NF - 1];
+        double blk[VS_BLOCKS];
 #pragma unroll
-        for (int f = 0; f < NF - 1; f++) blk[f] = q[(size_t)f * NV * V_LD];
+        for (int f = 0; f < VS_BLOCKS; f++) blk[f] = q[(size_t)f * NV * V_LD];
         double sv = 0.0;
 #pragma unroll
-        for (int f = 0; f < NF - 1; f++) sv += blk[f];
+        for (int f = 0; f < VS_BLOCKS; f++) sv += blk[f];
         if (lio_on && b >= lio_o && a < lio_o + 6) {   // LiDAR block of pose lio_frame: added last, as the one-workgroup form does
           const int ra = b - lio_o, rb = a - lio_o;      // ra <= rb: packed upper triangle of k_lio_window
           const int e = ra * 6 - ra * (ra - 1) / 2 + (rb - ra);
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
         if (!vsplit) v += vis_w[a * V_LD + NV];
         else {
           double sv = 0.0;
-          for (int f = 0; f < NF - 1; f++) sv += vis_s[(size_t)f * NV * V_LD + a * V_LD + NV];
+          for (int f = 0; f < VS_BLOCKS; f++) sv += vis_s[(size_t)f * NV * V_LD + a * V_LD + NV];
           if (lio_on && a >= lio_o && a < lio_o + 6) {
             double lv = 0.0;
             for (int q = 0; q < LIOW_WGS; q++) lv += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + 21 + a - lio_o];
@@ -1914,7 +1916,7 @@ void launch_lio_window(const BatchDev &d, int mode, hipStream_t s) {
   else hipLaunchKernelGGL(k_lio_window<1>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
 }
 void launch_visblock(const BatchDev &d, hipStream_t s) {
-  if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(NF - 1, d.B), dim3(VB_THREADS), 0, s, d);
+  if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(VS_BLOCKS, d.B), dim3(VB_GROUP), 0, s, d);
   else hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d);
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
