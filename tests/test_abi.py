@@ -111,3 +111,27 @@ def test_backend_raises_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(gf.BackendError):
         gf.Backend(device=0)
+
+
+def test_every_public_struct_matches_the_c_header(tmp_path):
+    """sizeof and every field offset of the ctypes mirrors (abi.py) against what a C compiler makes of include/gfbe.h."""
+    import subprocess
+    pairs = [("gfbe_state", abi.State), ("gfbe_imu_preint", abi.ImuPreint), ("gfbe_wheel_preint", abi.WheelPreint),
+             ("gfbe_visual", abi.Visual), ("gfbe_prior", abi.Prior), ("gfbe_lio_block", abi.LioBlock), ("gfbe_window", abi.Window),
+             ("gfbe_options", abi.Options), ("gfbe_summary", abi.Summary), ("gfbe_feature_list", abi.FeatureList),
+             ("gfbe_ftab_options", abi.FtabOptions)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gfbe.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, "%s.%s" % (cname, f)
