@@ -362,7 +362,13 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<gfbe_imu_preint> imu;
   std::vector<gfbe_wheel_preint> wheel;
   std::vector<double> lio;
-  std::vector<double> pJ0((size_t)B * ND * ND, 0.0), pr0((size_t)B * ND, 0.0), px0((size_t)B * PRIOR_X0, 0.0);
+  std::vector<double> pr0((size_t)B * ND, 0.0), px0((size_t)B * PRIOR_X0, 0.0);
+  // J0 of the priors travels compactly: host rows of nmax^2 doubles (nmax = the largest prior of the batch), copied into the
+  // device slots of ND^2 doubles by one 2-D copy (a 2k-landmark window's prior is 86^2 of the 182^2 doubles of a slot)
+  int pn_max = 0;
+  for (int w = 0; w < B; w++) if (wins[w] && wins[w]->prior && wins[w]->prior->valid) pn_max = std::max(pn_max, std::min(wins[w]->prior->n, (int)ND));
+  const size_t pj_row = (size_t)std::max(pn_max, 0) * std::max(pn_max, 0);
+  std::vector<double> pJ0((size_t)B * pj_row, 0.0);
   b->slot_of.resize(B);
   b->L.resize(B);
   // first pass: sizes
@@ -557,7 +563,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
         for (int k = 0; k < blk_lsize(id); k++) ds.prior_map[blk_tan(id) + k] = pr.block_idx[q] + k;
       }
       std::memcpy(&px0[(size_t)w * PRIOR_X0], pr.x0, sizeof(double) * xo);
-      std::memcpy(&pJ0[(size_t)w * ND * ND], pr.J0, sizeof(double) * pr.n * pr.n);
+      std::memcpy(&pJ0[(size_t)w * pj_row], pr.J0, sizeof(double) * pr.n * pr.n);
       std::memcpy(&pr0[(size_t)w * ND], pr.r0, sizeof(double) * pr.n);
     }
     // reduced program: blocks touched by a residual and not constant (Ceres drops the rest)
@@ -600,7 +606,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
   d.tot_lio = (int)(lio.size() / 8);
   UP(lio, lio); AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
-  UP(prior_J0, pJ0); UP(prior_r0, pr0); UP(prior_x0, px0);
+  AL(prior_J0, (size_t)B * ND * ND); UP(prior_r0, pr0); UP(prior_x0, px0);
+  if (!b->dry && pj_row > 0)
+    HIPCHK(c, hipMemcpy2DAsync(d.prior_J0, sizeof(double) * ND * ND, pJ0.data(), sizeof(double) * pj_row, sizeof(double) * pj_row, B, hipMemcpyHostToDevice, c->stream));
   AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
   AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
   if (B < DENSE_SPLIT_MIN_B && c->world == 1) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr; AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
