@@ -351,45 +351,47 @@ struct PgBuffers {
 // LDS tree), then one workgroup adds the segment partials in segment order. take_max: the first array is reduced with max
 // (gradient infinity norm).
 enum { PGR_SEG = 4096, PGR_MAXSEG = 1024 };
-__global__ __launch_bounds__(256) void k_pg_reduce1(int n, const double *a, const double *b, const double *c3, int take_max, double *partial) {
-  __shared__ double sh[3][256];
+__global__ __launch_bounds__(256) void k_pg_reduce1(int n, const double *a, const double *b, const double *c3, const double *d4, int take_max, double *partial) {
+  __shared__ double sh[4][256];
   const int t = threadIdx.x, i0 = blockIdx.x * PGR_SEG, i1 = min(n, i0 + PGR_SEG);
-  double va = 0.0, vb = 0.0, vc = 0.0;
+  double va = 0.0, vb = 0.0, vc = 0.0, vd = 0.0;
   for (int i = i0 + t; i < i1; i += 256) {
     va = take_max ? fmax(va, a[i]) : va + a[i];
     if (b) vb += b[i];
     if (c3) vc += c3[i];
+    if (d4) vd += d4[i];
   }
-  sh[0][t] = va; sh[1][t] = vb; sh[2][t] = vc;
+  sh[0][t] = va; sh[1][t] = vb; sh[2][t] = vc; sh[3][t] = vd;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (t < o) {
       sh[0][t] = take_max ? fmax(sh[0][t], sh[0][t + o]) : sh[0][t] + sh[0][t + o];
       sh[1][t] += sh[1][t + o];
       sh[2][t] += sh[2][t + o];
+      sh[3][t] += sh[3][t + o];
     }
     __syncthreads();
   }
-  if (t < 3) partial[3 * blockIdx.x + t] = sh[t][0];
+  if (t < 4) partial[4 * blockIdx.x + t] = sh[t][0];
 }
 __global__ __launch_bounds__(64) void k_pg_reduce2(int nseg, const double *partial, int take_max, double *out) {
   const int t = threadIdx.x;
-  if (t >= 3) return;
+  if (t >= 4) return;
   double v = 0.0;
-  for (int q = 0; q < nseg; q++) { const double x = partial[3 * q + t]; v = (take_max && t == 0) ? fmax(v, x) : v + x; }
+  for (int q = 0; q < nseg; q++) { const double x = partial[4 * q + t]; v = (take_max && t == 0) ? fmax(v, x) : v + x; }
   out[t] = v;
 }
-// dscratch: 3 + 3 * PGR_MAXSEG doubles
-void dev_reduce(gfbe_ctx *c, int n, const double *a, const double *b, const double *c3, bool take_max, double *dscratch, double out[3]) {
+// dscratch: 4 + 4 * PGR_MAXSEG doubles
+void dev_reduce(gfbe_ctx *c, int n, const double *a, const double *b, const double *c3, const double *d4, bool take_max, double *dscratch, double out[4]) {
   const int nseg = (n + PGR_SEG - 1) / PGR_SEG;
-  hipLaunchKernelGGL(k_pg_reduce1, dim3(nseg), dim3(256), 0, ctx_stream(c), n, a, b, c3, take_max ? 1 : 0, dscratch + 4);
+  hipLaunchKernelGGL(k_pg_reduce1, dim3(nseg), dim3(256), 0, ctx_stream(c), n, a, b, c3, d4, take_max ? 1 : 0, dscratch + 4);
   hipLaunchKernelGGL(k_pg_reduce2, dim3(1), dim3(64), 0, ctx_stream(c), nseg, dscratch + 4, take_max ? 1 : 0, dscratch);
-  (void)hipMemcpyAsync(out, dscratch, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx_stream(c));
+  (void)hipMemcpyAsync(out, dscratch, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx_stream(c));
   (void)hipStreamSynchronize(ctx_stream(c));
 }
 double host_sum(gfbe_ctx *c, const double *dptr, int n, double *dscratch, bool take_max = false) {
-  double out[3];
-  dev_reduce(c, n, dptr, nullptr, nullptr, take_max, dscratch, out);
+  double out[4];
+  dev_reduce(c, n, dptr, nullptr, nullptr, nullptr, take_max, dscratch, out);
   return out[0];
 }
 
@@ -432,7 +434,7 @@ gfbe_status gfbe_pg_eval(gfbe_ctx *c, int32_t n, const double *pose, int32_t n_r
     dpose = buf.dev<double>((size_t)7 * n, pose); dcost = buf.dev<double>(n); dr = buf.dev<double>((size_t)6 * n_rel);
     dJ = buf.dev<double>((size_t)72 * n_rel); dfr = buf.dev<double>((size_t)3 * n_fix);
     Hd = buf.dev<double>((size_t)36 * n); Ho = buf.dev<double>((size_t)36 * n); g = buf.dev<double>((size_t)6 * n);
-    red3 = buf.dev<double>(4 + 3 * (size_t)PGR_MAXSEG);
+    red3 = buf.dev<double>(4 + 4 * (size_t)PGR_MAXSEG);
     if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_eval: device allocation failed"); return GFBE_DEVICE_ERROR; }
   }
   hipLaunchKernelGGL(k_pg_lin, dim3((n + 127) / 128), dim3(128), 0, ctx_stream(c), P, dpose, dcost, Hd, Ho, g, dr, dJ, dfr);
@@ -460,14 +462,14 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
   hipStream_t s = ctx_stream(c);
   PgBuffers buf(c);
   PgDev P;
-  double *x, *cand, *per, *per2, *per3, *Hd, *Ho, *g, *scale, *diag2, *Bs, *A0, *C0, *Ab[2], *Bb[2], *Cb[2], *db[2], *d0, *y;
+  double *x, *cand, *per, *per2, *per3, *per4, *Hd, *Ho, *g, *scale, *diag2, *Bs, *A0, *C0, *Ab[2], *Bb[2], *Cb[2], *db[2], *d0, *y;
   int *fail;
   double *red3;
   for (int pass = 0; pass < 2; pass++) {
     P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
          buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
     x = buf.dev<double>((size_t)7 * n, pose_in); cand = buf.dev<double>((size_t)7 * n);
-    per = buf.dev<double>(n); per2 = buf.dev<double>(n); per3 = buf.dev<double>(n);
+    per = buf.dev<double>(n); per2 = buf.dev<double>(n); per3 = buf.dev<double>(n); per4 = buf.dev<double>(n);
     Hd = buf.dev<double>((size_t)36 * n); Ho = buf.dev<double>((size_t)36 * n); g = buf.dev<double>((size_t)6 * n);
     scale = buf.dev<double>((size_t)6 * n); diag2 = buf.dev<double>((size_t)6 * n); Bs = buf.dev<double>((size_t)36 * n);
     A0 = buf.dev<double>((size_t)36 * n); C0 = buf.dev<double>((size_t)36 * n);
@@ -477,7 +479,7 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     }
     d0 = buf.dev<double>((size_t)6 * n); y = buf.dev<double>((size_t)6 * n);
     fail = buf.dev<int>(1);
-    red3 = buf.dev<double>(4 + 3 * (size_t)PGR_MAXSEG);
+    red3 = buf.dev<double>(4 + 4 * (size_t)PGR_MAXSEG);
     if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_solve: device allocation failed"); return GFBE_DEVICE_ERROR; }
   }
   const dim3 g128((n + 127) / 128), b128(128), g64((n + 63) / 64), b64(64);
@@ -499,13 +501,16 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     if (it >= max_it) { sm.termination = 0; break; }
     // system at the current point (B includes the LM diagonal at the current radius)
     const dim3 g6((6 * n + 191) / 192), b6(192);
-    hipLaunchKernelGGL(k_pg_system, g6, b6, 0, s, n, Hd, Ho, g, scale, have_scale ? 0 : 1, diag2, reuse ? 1 : 0, radius, Bb[0], d0, Bs, per, db[0], fail);
+    hipLaunchKernelGGL(k_pg_system, g6, b6, 0, s, n, Hd, Ho, g, scale, have_scale ? 0 : 1, diag2, reuse ? 1 : 0, radius, Bb[0], d0, Bs, per4, db[0], fail);
     hipLaunchKernelGGL(k_pg_system2, g6, b6, 0, s, n, Ho, scale, A0, C0, Ab[0], Cb[0]);
     have_scale = true;
-    const double gmax = host_sum(c, per, n, red3, true);
-    if (gmax <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; break; }
-    if (radius < 1e-32) { sm.termination = 4; break; }
-    it++;
+    // (the gradient norm of this point comes back together with the step's scalars — one host decision less per iteration;
+    //  the step that was computed meanwhile is simply dropped when the gradient test ends the solve)
+    if (radius < 1e-32) {
+      const double gm = host_sum(c, per4, n, red3, true);
+      if (gm <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; } else sm.termination = 4;
+      break;
+    }
     // parallel block cyclic reduction: log2(n) sweeps
     // (k_pg_system / k_pg_system2 also wrote the copies the reduction consumes and cleared the failure flag)
     int cur = 0;
@@ -517,9 +522,11 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     hipLaunchKernelGGL(k_pg_candidate, g128, b128, 0, s, n, Bs, A0, C0, d0, y, scale, x, cand, per, per2, per3);
     int hfail = 0;
     (void)hipMemcpyAsync(&hfail, fail, sizeof(int), hipMemcpyDeviceToHost, s);
-    double r3[3];
-    dev_reduce(c, n, per, per2, per3, false, red3, r3);      // model change, |step|^2, |candidate|^2
-    const double model_change = r3[0];
+    double r4[4];
+    dev_reduce(c, n, per4, per, per2, per3, true, red3, r4);      // max |g|, model change, |step|^2, |candidate|^2
+    if (r4[0] <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; break; }
+    it++;
+    const double model_change = r4[1];
     if (hfail || !(model_change > 0.0)) {
       sm.accepted[it] = 0; sm.cost_history[it] = cost;
       if (++invalid >= 5) { sm.termination = 4; sm.status = GFBE_NUMERICAL_FAILURE; break; }
@@ -527,7 +534,7 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
       continue;
     }
     invalid = 0;
-    const double step2 = r3[1], cand_x2 = r3[2];
+    const double step2 = r4[2], cand_x2 = r4[3];
     hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, cand, per, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr);
     const double cand_cost = host_sum(c, per, n, red3);
