@@ -1,0 +1,35 @@
+"""The drop-in boundary from plain C: examples/gfbe_minimal.c includes only include/gfbe.h, is compiled as C99 with -Wall -Wextra
+-Werror, linked against libgfbe.so and run. Without a GPU it must report GFBE_NO_DEVICE (there is no CPU fallback); on an MI355X
+it solves its hand-made window."""
+import os
+import subprocess
+
+import pytest
+
+from _gfbe_import import gf
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build(tmp_path):
+    gf.build_native()
+    exe = tmp_path / "gfbe_minimal"
+    libdir = os.path.dirname(gf.lib_path())
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "gfbe_minimal.c"),
+                    "-L", libdir, "-lgfbe", "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_c_caller_compiles_links_and_fails_loudly_without_a_gpu(tmp_path):
+    exe = build(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "GFBE_NO_DEVICE" in out.stdout or "iterations" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_caller_solves_its_window(tmp_path):
+    exe = build(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "iterations" in out.stdout and "gfbe 0.1.0" in out.stdout
