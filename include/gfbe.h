@@ -216,6 +216,8 @@ void gfbe_default_options(gfbe_options *opt);
 /* device < 0: host-only context (bookkeeping functions only; every compute entry point returns
  * GFBE_NO_DEVICE). device >= 0: HIP device ordinal; fails with GFBE_NO_DEVICE if absent. */
 gfbe_status gfbe_create(gfbe_ctx **ctx, int device, const gfbe_options *opt);
+/* Frees the context and the device memory it caches. Batches (gfbe_batch_free) and feature tables (gfbe_ftab_destroy) made with
+ * the context must be released BEFORE it. */
 void gfbe_destroy(gfbe_ctx *ctx);
 const char *gfbe_last_error(const gfbe_ctx *ctx);
 const char *gfbe_version(void);
