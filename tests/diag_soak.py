@@ -31,9 +31,22 @@ for i in range(N):
         snap["feature_const"] = fc
     if lidar:
         snap["lio"] = synth.lidar_block(scn, k0, n=int(rng.choice([50, 800, 2000])), seed=i, outliers=0.05)
+    partial = (not with_prior) and rng.random() < 0.25      # a window that is still filling up (frame_count < WINDOW_SIZE): no marginalisation
+    if partial:
+        fc = int(rng.integers(2, abi.WINDOW_SIZE))
+        keep = snap["vis_imu_j"] <= fc
+        for k in list(snap):
+            if k.startswith("vis_"):
+                snap[k] = snap[k][keep]
+        snap["frame_count"] = fc
+        snap["imu"], snap["imu_frame"] = snap["imu"][:fc], snap["imu_frame"][:fc]
+        if wheel:
+            snap["wheel"], snap["wheel_frame"] = snap["wheel"][:fc], snap["wheel_frame"][:fc]
+        if lidar:
+            snap["lio"]["frame"] = fc
     want, got = orc.solve(snap, flag), be.solve(snap, flag)
     sw, sg = want["summary"], got["summary"]
-    tag = "L=%d wheel=%d prior=%d lidar=%d rgbd=%d flag=%d" % (L, wheel, with_prior, lidar, rgbd, flag)
+    tag = "L=%d wheel=%d prior=%d lidar=%d rgbd=%d flag=%d partial=%d" % (L, wheel, with_prior, lidar, rgbd, flag, partial)
     if (sw["iterations"], sw["accepted"], sw["termination"]) != (sg["iterations"], sg["accepted"], sg["termination"]):
         bad.append((i, tag, sw["iterations"], sg["iterations"], sw["accepted"], sg["accepted"]))
         continue
