@@ -420,9 +420,9 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_landmarks(FtabDev T, int cu
   __shared__ int lds[20];
   const int *lay = layout + (size_t)wl * LAY_STRIDE;
   const int n = T.count[w];
-  const size_t base = (size_t)w * T.F, TL = d.tot_lm;
+  const size_t base = (size_t)w * T.F;
   const int *start = T.start[cur] + base, *nobs = T.nobs[cur] + base, *eflag = T.eflag[cur] + base;
-  const double *depth = T.depth[cur] + base, *obs = T.obs[cur] + base * NOBS * OW, *td = T.td[cur] + base * NOBS;
+  const double *depth = T.depth[cur] + base;
   int *keep = T.keep + base;       // scratch: slot of feature f (or -1)
   const int chunk = (n + FT_THREADS - 1) / FT_THREADS, f0 = t * chunk, f1 = min(n, f0 + chunk);
   // landmark index in list order
@@ -455,24 +455,36 @@ __global__ __launch_bounds__(FT_THREADS) void k_ftab_landmarks(FtabDev T, int cu
   __threadfence_block();
   __syncthreads();
   const int lm_off = lay[0];
-  for (int f = f0; f < f1; f++) {
+  for (int f = f0; f < f1; f++) {      // per-landmark scalars and the list-order -> slot map (the bulk goes to k_ftab_landmarks_write)
     if (nobs[f] < 4) continue;
-    const int s = start[f], m = nobs[f] - 1, rel = keep[f], slot = lm_off + rel;
+    const int s = start[f], m = nobs[f] - 1, slot = lm_off + keep[f];
     d.lm_info[slot] = s | (m << 8) | ((eflag[f] == 1 ? 1 : 0) << 16) | (1 << 24);
     d.lm_abi[slot] = lidx;
     d.lam0[slot] = 1.0 / depth[f];
     slot_of[(size_t)wl * T.F + lidx] = slot;
     lidx++;
-    const double *o0 = obs + (size_t)f * NOBS * OW;
-    d.lm_pts[0 * TL + slot] = o0[0]; d.lm_pts[1 * TL + slot] = o0[1]; d.lm_pts[2 * TL + slot] = o0[2];
-    d.lm_pts[3 * TL + slot] = o0[5]; d.lm_pts[4 * TL + slot] = o0[6]; d.lm_pts[5 * TL + slot] = td[(size_t)f * NOBS];
-    const int in_group = rel - lay[LAY_GRP + s];
-    for (int k = 0; k < m; k++) {
-      const double *oj = o0 + (size_t)(1 + k) * OW;
-      double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
-      ob[0] = oj[0]; ob[TL] = oj[1]; ob[2 * TL] = oj[5]; ob[3 * TL] = oj[6]; ob[4 * TL] = td[(size_t)f * NOBS + 1 + k];
-      d.lm_rec[(size_t)k * TL + slot] = lay[LAY_PAIR + s * NF + s + 1 + k] + in_group;   // slot order inside a pair = group order
-    }
+  }
+}
+// observations and record indices of every landmark: one thread per (feature, observation slot), any number of workgroups
+__global__ __launch_bounds__(256) void k_ftab_landmarks_write(FtabDev T, int cur, int w0, BatchDev d, const int *layout) {
+  const int wl = blockIdx.y, w = w0 + wl;
+  const int g = blockIdx.x * 256 + threadIdx.x, f = g / NOBS, q = g - f * NOBS;
+  if (f >= T.count[w]) return;
+  const size_t base = (size_t)w * T.F, TL = d.tot_lm;
+  const int n_o = T.nobs[cur][base + f];
+  if (n_o < 4 || q >= n_o) return;
+  const int *lay = layout + (size_t)wl * LAY_STRIDE;
+  const int s = T.start[cur][base + f], rel = T.keep[base + f], slot = lay[0] + rel;
+  const double *o = T.obs[cur] + ((base + f) * NOBS + q) * OW;
+  const double tdq = T.td[cur][(base + f) * NOBS + q];
+  if (q == 0) {
+    d.lm_pts[0 * TL + slot] = o[0]; d.lm_pts[1 * TL + slot] = o[1]; d.lm_pts[2 * TL + slot] = o[2];
+    d.lm_pts[3 * TL + slot] = o[5]; d.lm_pts[4 * TL + slot] = o[6]; d.lm_pts[5 * TL + slot] = tdq;
+  } else {
+    const int k = q - 1;
+    double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
+    ob[0] = o[0]; ob[TL] = o[1]; ob[2 * TL] = o[5]; ob[3 * TL] = o[6]; ob[4 * TL] = tdq;
+    d.lm_rec[(size_t)k * TL + slot] = lay[LAY_PAIR + s * NF + s + 1 + k] + (rel - lay[LAY_GRP + s]);   // slot order inside a pair = group order
   }
 }
 __global__ void k_fill(double *p, size_t n, double v) {
@@ -588,6 +600,7 @@ void launch_ftab_pack(const FtabDev &T, int cur, int w0, int n, const BatchDev &
   if (d.tot_lm > 0) hipLaunchKernelGGL(k_fill, dim3((unsigned)((d.tot_lm + 255) / 256)), dim3(256), 0, s, d.lam0, (size_t)d.tot_lm, 1.0);
   (void)hipMemsetAsync(d.lm_abi, 0xFF, sizeof(int) * (size_t)d.tot_lm, s);     // padding slots: -1
   hipLaunchKernelGGL(k_ftab_landmarks, dim3(n), dim3(FT_THREADS), 0, s, T, cur, w0, d, layout, slot_of);
+  hipLaunchKernelGGL(k_ftab_landmarks_write, dim3((unsigned)(((size_t)T.F * NOBS + 255) / 256), n), dim3(256), 0, s, T, cur, w0, d, layout);
 }
 }  // namespace gfd
 
