@@ -630,7 +630,7 @@ typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I - 1) / 2 + (J - I); }   // I <= J < 5
 
-__global__ __launch_bounds__(256) void k_schur(BatchDev d, int marg) {
+__global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   const int w = blockIdx.x, s = blockIdx.y;   // start-frame-major dispatch: the heavy start frame 0 of every window first
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
