@@ -601,7 +601,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(64, FUSED ? 1 : 2) void k_dense(BatchDev d, int mode, int debug_out) {
+__global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mode, int debug_out) {
   dense_body<FUSED>(d, mode, debug_out, blockIdx.y, blockIdx.x);
 }
 
