@@ -5,15 +5,26 @@ One *step* = one pass of the hot path over one batch of synthetic input: every r
 reset to its uploaded state and run through the whole Estimator::optimization() sequence
 (estimator.cpp:2951-3698): <= 8 dogleg iterations, double2vector re-anchoring, MARGIN_OLD
 marginalisation. Workload = BASELINE.json configs[1]: 10-keyframe VI-wheel window, 2 000 landmarks,
-with a marginalisation prior (SURVEY.md §8d generator), B independent windows per GPU resident in
-HBM. Multi-GPU: windows are independent units -> sharded over ranks, no data-path collective
-("scaling": "weak"); the barrier + max-over-ranks timing is the only communication.
+with a marginalisation prior (SURVEY.md section 8d generator), B independent windows per GPU resident in
+HBM (`value`: inputs already in HBM when the timed region starts).
+
+Next to `value` the JSON line carries `end_to_end`: the same workload with FRESH inputs every step —
+host-fed (gfbe_batch_upload from the caller's gfbe_window structures: packing + one H2D copy, solve,
+gather + one D2H copy + unpacking, two batches in flight) and table-fed (gfbe_batch_upload_tables from
+the device-resident feature tables) — plus the host-to-host latency of one gfbe_solve_window call.
+
+Multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one process per
+GPU, RCCL) when it is not already running under a launcher. Windows are independent units -> sharded
+over ranks, no data-path collective ("scaling": "weak"); `--shard-landmarks` is BASELINE configs[2]:
+every rank holds the SAME windows and evaluates its share of the landmark tiles, the partial normal
+equations are summed by RCCL all-reduces ("scaling": "strong").
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,37 +35,72 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="resident windows per GPU (throughput saturates near 1024: 39k solves/s at 256, 47k at 512, 49k at 1024 and 2048)")
+    ap.add_argument("--batch", type=int, default=1024, help="resident windows per GPU (throughput saturates near 1024)")
     ap.add_argument("--landmarks", type=int, default=2000)
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows (tiled to --batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block")
+    ap.add_argument("--e2e-batch", type=int, default=512, help="windows per batch of the end-to-end loops (two batches in flight)")
+    ap.add_argument("--e2e-steps", type=int, default=8)
+    ap.add_argument("--host-threads", type=int, default=0, help="gfbe_options.host_threads (0: library default)")
     ap.add_argument("--split", type=int, default=None, help="gfbe_options.split_batch: parts a batch of >= 128 windows is solved in, side by side (library default: 2)")
     ap.add_argument("--graph", action="store_true", help="gfbe_options.use_graph: replay the launch sequence as a hipGraph")
     ap.add_argument("--shard-landmarks", action="store_true",
                     help="N > 1 only: every rank holds the SAME windows and evaluates its share of the landmark tiles; the partial "
                          "normal equations are summed with RCCL all-reduces (BASELINE configs[2]; strong scaling of one solve)")
-    args = ap.parse_args()
+    ap.add_argument("--hook", choices=("native", "torch"), default="native",
+                    help="all-reduce hook of --shard-landmarks: libgfbe_rccl.so (ncclAllReduce on the solver stream) or the torch.distributed callback")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only exercise the N-rank launch + rendezvous + the throughput aggregation (no GPU needed with GFBE_DIST_BACKEND=gloo)")
+    ap.add_argument("--master-port", type=int, default=29511)
+    return ap.parse_args(argv)
+
+
+def relaunch_under_launcher(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one process per GPU) and hand over."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_launcher(args))
 
     import torch
     import torch.distributed as dist
-    from _gfbe_import import gf
-    abi, synth = gf.abi, gf.synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         # "nccl" is RCCL on ROCm. GFBE_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
-        # ranks (ranks then share devices): a test aid, never used by the driver.
+        # ranks (ranks then share devices) or without any (--launch-check): a test aid, never used by the driver.
         dist.init_process_group(os.environ.get("GFBE_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+
+    from _gfbe_import import gf
+    abi, synth = gf.abi, gf.synth
+
+    if args.launch_check:
+        units, elapsed = gf.dist.aggregate_throughput(100 + rank, 1.0 + 0.5 * rank, dist if world > 1 else None)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "units": units, "elapsed": elapsed}))
+        return
+
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     opts = abi.default_options()
@@ -62,11 +108,13 @@ def main():
         opts.split_batch = args.split
     if args.graph:
         opts.use_graph = 1
+    opts.host_threads = args.host_threads
     be = gf.Backend(device=local_rank, options=opts)          # raises if the HIP extension / GPU is missing
     be.set_stream(torch.cuda.current_stream().cuda_stream)
     shard = args.shard_landmarks and world > 1
+    hook_kind = None
     if shard:
-        be.set_allreduce(gf.dist.torch_allreduce_hook(), rank, world)
+        hook_kind = gf.dist.install_allreduce_hook(be, rank, world, prefer=args.hook)
 
     # ---- synthetic input (untimed). The prior of each window comes from the back end itself:
     # window k of the run is solved + marginalised (MARGIN_OLD) on the GPU, its prior and shifted
@@ -112,6 +160,8 @@ def main():
     res = batch.download()
     final_costs = [r["summary"]["final_cost"] for r in res[: args.unique]]
     iters = [r["summary"]["iterations"] for r in res[: args.unique]]
+    phase_ms = {"solve": res[0]["summary"]["ms_solve"], "marginalize": res[0]["summary"]["ms_marginalize"]}
+    io_bytes = {"uploaded_per_window": res[0]["summary"]["bytes_uploaded"], "downloaded_per_window": res[0]["summary"]["bytes_downloaded"]}
 
     out = None
     prof = None
@@ -125,12 +175,19 @@ def main():
         torch.cuda.synchronize()
         prof = {p["name"]: p for p in be.profile()}
         be.profile_enable(False)
+    batch.free()
+
+    # ---- end to end with fresh inputs every step (every rank; aggregated like `value`)
+    e2e = None
+    if not args.no_e2e and not shard:
+        e2e = end_to_end(args, be, gf, torch, dist if world > 1 else None, scns, snaps, final_costs)
+
     if rank == 0:
         tot_ms = sum(p["total_ms"] for p in prof.values())
         dom = max((p for p in prof.values()), key=lambda p: p["total_ms"])
         lin0 = prof.get("k_vis_lin_iter0", prof.get("k_vis_lin"))
         # Dominant hot-path kernel: k_vis<0> = visual evaluate + linearise with J^T J fused on the FP64
-        # matrix cores (J is never materialised). SURVEY.md §8d per-unit figures for one visual residual
+        # matrix cores (J is never materialised). SURVEY.md section 8d per-unit figures for one visual residual
         # block: 108 B of input (fused form) and 1.6 kflop of J^T J. At 14.8 flop/B the kernel sits to the
         # right of the FP64 ridge point (78.6 TF / 8 TB/s = 9.8 flop/B): the matrix-core roofline bounds it.
         lin_ms = lin0["total_ms"] / max(lin0["launches"], 1)
@@ -140,30 +197,22 @@ def main():
         algo_bytes = 108.0 * units_per_launch
         achieved_tf = algo_flops / (lin_ms * 1e-3) / 1e12
         # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
-        # passes (profiles/r1_pmc_fetch.txt / _write.txt, tests/diag_pmc.sh) hold FETCH_SIZE / WRITE_SIZE per dispatch
+        # passes (profiles/*_pmc_fetch.txt / _write.txt, tests/diag_pmc.sh) hold FETCH_SIZE / WRITE_SIZE per dispatch
         # for exactly the default workload, so they are quoted for it and left null for any other configuration.
-        traffic = None
+        traffic, traffic_src = None, None
         if args.batch == 1024 and args.landmarks == 2000 and args.unique == 8:
-            try:
-                tot = 0.0
-                for fn, key in (("r1_pmc_fetch.txt", "FETCH_SIZE"), ("r1_pmc_write.txt", "WRITE_SIZE")):
-                    lines = open(os.path.join(ROOT, "profiles", fn)).read().splitlines()
-                    i = [k for k, ln in enumerate(lines) if "k_visILi0E" in ln and "grid=(32768,36,1)" in ln][0]   # one half of the batch
-                    tot += float([ln for ln in lines[i + 1:i + 4] if key in ln][0].split()[1]) * 1024.0
-                traffic = tot
-            except Exception:
-                traffic = None
+            traffic, traffic_src = pmc_traffic()
         roofline = {"bound": "mfma", "kernel": "k_vis<0> (visual evaluate + linearise + fused J^T J; first iteration: all windows active)",
                     "achieved": achieved_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved_tf / 78.6, "traffic": traffic,
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same workload, bytes per launch: profiles/r1_pmc_fetch.txt + r1_pmc_write.txt" if traffic else None,
+                    "traffic_source": traffic_src,
                     "avg_launch_ms": lin_ms, "algorithmic_flops_per_launch": algo_flops,
                     "algorithmic_bytes_per_launch": algo_bytes, "hbm_view_GBps": algo_bytes / (lin_ms * 1e-3) / 1e9,
                     "hbm_view_frac_of_8TBps": algo_bytes / (lin_ms * 1e-3) / 8e12,
                     "dominant_by_time": dom["name"],
                     "time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}}
 
-        # ---- single-window latency (B = 1), same workload
-        single_ms = None
+        # ---- single-window latency (B = 1), same workload: resident re-solve, and host-to-host gfbe_solve_window
+        single_ms, single_host_ms = None, None
         if not shard:
             one = be.batch_upload(batch_snaps[:1])
             for _ in range(3):
@@ -175,55 +224,18 @@ def main():
             torch.cuda.synchronize()
             single_ms = (time.perf_counter() - t1) / 10 * 1e3
             one.free()
+            h = abi.WindowHolder(batch_snaps[0])
+            for _ in range(3):
+                be.solve(h, abi.MARGIN_OLD)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                be.solve_raw(h, abi.MARGIN_OLD)
+            single_host_ms = (time.perf_counter() - t1) / 10 * 1e3
 
         # ---- CPU baseline: the oracle (Ceres stand-in "port", 1 core) on the same windows, bounded sample
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib
-            orc = oracle_lib.load()
-            n_done, t_cpu = 0, 0.0
-            holders = [abi.WindowHolder(s) for s in snaps]
-            while t_cpu < args.cpu_seconds:
-                h = holders[n_done % len(holders)]
-                tc = time.perf_counter()
-                r = orc.solve(h, abi.MARGIN_OLD)
-                t_cpu += time.perf_counter() - tc
-                if n_done < len(holders):
-                    ref_cost = r["summary"]["final_cost"]
-                    assert abs(final_costs[n_done] - ref_cost) < 1e-6 * ref_cost, (final_costs[n_done], ref_cost)
-                n_done += 1
-            cpu = {"value": n_done / t_cpu, "unit": "solves/s", "cores": 1, "kind": "port",
-                   "sample": "%d full optimization() calls (solve + MARGIN_OLD) of the same %d-landmark windows in %.1f s; "
-                             "oracle/ C++ restatement, -O3 -march=native, 1 thread like the reference's ceres::Solve" %
-                             (n_done, args.landmarks, t_cpu),
-                   "ms_per_solve": 1e3 * t_cpu / n_done}
-            # the same port on every host core (one window per thread; ctypes drops the GIL): SURVEY.md §8d (b)
-            import threading
-            ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            counts = [0] * ncore
-            deadline = time.perf_counter() + min(args.cpu_seconds, 10.0)
-            import ctypes as C
-            fsolve = orc._fn("solve_window")
-            fsolve.restype = abi.c_i
-            def worker(k):   # the bare C call in the loop: no Python-side result conversion under the GIL
-                hs = [abi.WindowHolder(s) for s in snaps]
-                st, pr, sm = abi.State(), abi.PriorHolder(), abi.Summary()
-                feat = np.zeros(max(h.n_feature for h in hs))
-                i = k
-                while time.perf_counter() < deadline:
-                    fsolve(orc.head, C.byref(hs[i % len(hs)].c), int(abi.MARGIN_OLD), C.byref(st), abi._pd(feat), C.byref(pr.c), C.byref(sm))
-                    counts[k] += 1
-                    i += 1
-            t_all = time.perf_counter()
-            th = [threading.Thread(target=worker, args=(k,)) for k in range(ncore)]
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            t_all = time.perf_counter() - t_all
-            cpu["all_cores"] = {"value": sum(counts) / t_all, "unit": "solves/s", "cores": ncore,
-                                "sample": "%d solves on %d threads in %.1f s" % (sum(counts), ncore, t_all)}
+            cpu = cpu_baseline(args, abi, snaps, final_costs)
         out = {
             "metric": "sliding-window solves/sec (10-kf, 2k landmarks)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -231,22 +243,194 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 10-keyframe VI-wheel window, %d landmarks (K=%d visual factors avg), "
                                    "marginalisation prior n=%d, full optimization() = <=8 dogleg iterations + re-anchor + MARGIN_OLD" %
                                    (args.landmarks, int(np.mean(K_per)), snaps[0]["prior"]["n"]),
-                       "windows_per_gpu": args.batch, "unique_windows": args.unique, "parallelism": ("landmark tiles of every window sharded over %d ranks, RCCL all-reduce of the partial normal equations" % world) if shard
+                       "windows_per_gpu": args.batch, "unique_windows": args.unique,
+                       "parallelism": ("landmark tiles of every window sharded over %d ranks, RCCL all-reduce of the partial normal equations (%s hook)" % (world, hook_kind)) if shard
                                       else "windows sharded over %d rank(s), no collective" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "end_to_end": e2e,
             "single_window_ms": single_ms, "single_window_solves_per_s": (1e3 / single_ms) if single_ms else None,
+            "single_window_host_to_host_ms": single_host_ms,
+            "device_phase_ms_per_step": phase_ms, "pcie_bytes": io_bytes,
             "iterations": iters, "final_cost": final_costs, "setup_s": setup_s,
         }
         if cpu:
             out["speedup_vs_cpu_1core"] = value / cpu["value"]
             if single_ms:
                 out["single_window_speedup_vs_cpu_1core"] = (1e3 / single_ms) / cpu["value"]
-    batch.free()
+            if single_host_ms:
+                out["single_window_host_to_host_speedup_vs_cpu_1core"] = (1e3 / single_host_ms) / cpu["value"]
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
+
+
+def pmc_traffic():
+    """FETCH_SIZE + WRITE_SIZE (KB per dispatch) of the k_vis<0> launch over one half of the default batch, from the newest
+    committed rocprofv3 PMC passes."""
+    for tag in ("r2", "r1"):
+        try:
+            tot = 0.0
+            for fn, key in ((tag + "_pmc_fetch.txt", "FETCH_SIZE"), (tag + "_pmc_write.txt", "WRITE_SIZE")):
+                lines = open(os.path.join(ROOT, "profiles", fn)).read().splitlines()
+                i = [k for k, ln in enumerate(lines) if "k_visILi0E" in ln and "grid=(32768," in ln][0]   # one half of the batch
+                tot += float([ln for ln in lines[i + 1:i + 4] if key in ln][0].split()[1]) * 1024.0
+            return tot, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same workload, bytes per launch: "
+                         "profiles/%s_pmc_fetch.txt + %s_pmc_write.txt" % (tag, tag))
+        except Exception:
+            continue
+    return None, None
+
+
+def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
+    """Fresh inputs every step. Host-fed: gfbe_batch_upload (parallel packing into pinned memory, ONE H2D copy on the copy
+    stream) -> gfbe_batch_solve -> gfbe_batch_download (gather kernel + ONE D2H copy on the download stream, parallel
+    unpacking), two batches in flight so that batch k+1 is packed and copied while batch k solves. Table-fed: the same with
+    gfbe_batch_upload_tables reading the landmarks from device-resident feature tables."""
+    abi = gf.abi
+    B = args.e2e_batch
+    nu = len(snaps)
+    sets = [gf.WindowSet([snaps[(i + q) % nu] for i in range(B)]) for q in range(2)]   # two different host window sets, alternated
+    bufs = gf.DownloadBuffers(B, max(h.n_feature for h in sets[0].holders))
+    out = {"windows_per_batch": B, "batches_in_flight": 2, "steps": args.e2e_steps}
+
+    def pipeline(upload):
+        cur = upload(0)
+        cur.solve(abi.MARGIN_OLD)
+        t_up = t_dl = 0.0
+        t0 = None
+        n_timed = 0
+        for s in range(args.e2e_steps + 2):
+            if s == 2:            # two untimed warm-up steps (allocator, slab / pinned caches)
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                t_up = t_dl = 0.0
+            ta = time.perf_counter()
+            nxt = upload((s + 1) % 2)          # packs + enqueues the copy while `cur` solves
+            nxt.solve(abi.MARGIN_OLD)
+            tb = time.perf_counter()
+            cur.download_into(bufs)
+            tc = time.perf_counter()
+            cur.free()
+            cur = nxt
+            t_up += tb - ta
+            t_dl += tc - tb
+            if s >= 2:
+                n_timed += 1
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        cur.download_into(bufs)
+        cur.free()
+        solves, el = gf.dist.aggregate_throughput(n_timed * B, el, dist)
+        return {"value": solves / el, "unit": "solves/s", "ms_per_batch": 1e3 * el / n_timed,
+                "host_ms_in_upload_call": 1e3 * t_up / n_timed, "host_ms_in_download_call": 1e3 * t_dl / n_timed}
+
+    r = pipeline(lambda q: be.batch_upload(sets[q]))
+    costs = [bufs.sums[k].final_cost for k in range(min(nu, B))]
+    r["final_cost_matches_resident_run"] = bool(all(abs(a - b) <= 1e-9 * abs(b) for a, b in zip(costs, [ref_costs[(k + 1) % nu] for k in range(len(costs))])) or
+                                                all(abs(a - b) <= 1e-9 * abs(b) for a, b in zip(costs, ref_costs)))
+    r["pcie_MB_per_window"] = {"up": bufs.sums[0].bytes_uploaded / 1e6, "down": bufs.sums[0].bytes_downloaded / 1e6}
+    out["host_fed"] = r
+
+    # ---- table-fed: W device-resident feature tables holding the same windows' features
+    try:
+        tables, order = build_tables(gf, be, scns, B)
+        tsets = [gf.WindowSet([table_snap(gf, snaps[(i + q) % nu], order[(i + q) % nu]) for i in range(B)]) for q in range(1)]
+        tb_bufs = gf.DownloadBuffers(B, max(len(o) for o in order))
+        bufs = tb_bufs
+        r = pipeline(lambda q: be.batch_upload_tables(tables, tsets[0]))
+        costs = [bufs.sums[k].final_cost for k in range(min(nu, B))]
+        r["final_cost_matches_resident_run"] = bool(all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(costs, ref_costs)))
+        out["table_fed"] = r
+        tables.close()
+    except Exception as e:   # the table-fed leg must not take the headline down with it
+        out["table_fed"] = {"error": repr(e)}
+    return out
+
+
+def build_tables(gf, be, scns, B):
+    """B device tables holding the features of window 1 of the scenarios (tiled), inserted frame by frame through
+    gfbe_ftab_add_frame like a running front end would; returns (tables, per-scenario landmark order = table order)."""
+    abi = gf.abi
+    nu = len(scns)
+    fls = [s.feature_list(1) for s in scns]
+    per = []
+    for fl in fls:
+        start, nobs = fl["start_frame"], fl["n_obs"]
+        off = np.concatenate([[0], np.cumsum(nobs)])[:-1]
+        ids_sorted = np.argsort(start, kind="stable")          # insertion order of a table: by first frame, then id
+        fid = np.empty(len(start), np.int64)
+        fid[ids_sorted] = np.arange(len(start))
+        frames = []
+        for fc in range(abi.NFRAMES):
+            act = np.nonzero((start <= fc) & (fc < start + nobs))[0]
+            act = act[np.argsort(fid[act])]
+            rows = fl["obs"][off[act] + (fc - start[act])]
+            frames.append((fid[act].astype(np.int32), np.concatenate([rows, np.zeros((len(act), 1))], axis=1)))
+        lm = [f for f in ids_sorted if nobs[f] >= 4]
+        per.append(dict(frames=frames, lm=np.array(lm), depth=fl["estimated_depth"]))
+    cap = 1 << int(np.ceil(np.log2(max(len(fl["start_frame"]) for fl in fls) + 1)))
+    tables = abi.FeatureTables(be.lib, "gfbe_", be.ctx, B, cap)
+    for fc in range(abi.NFRAMES):
+        tables.add_frame([fc] * B, [per[w % nu]["frames"][fc][0] for w in range(B)], [per[w % nu]["frames"][fc][1] for w in range(B)], [0.0] * B)
+    tables.set_depth([1.0 / per[w % nu]["depth"][per[w % nu]["lm"]] for w in range(B)])
+    return tables, [p["lm"] for p in per]
+
+
+def table_snap(gf, snap, order):
+    return gf.strip_visual(snap)
+
+
+def cpu_baseline(args, abi, snaps, final_costs):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    orc = oracle_lib.load()
+    n_done, t_cpu = 0, 0.0
+    holders = [abi.WindowHolder(s) for s in snaps]
+    while t_cpu < args.cpu_seconds:
+        h = holders[n_done % len(holders)]
+        tc = time.perf_counter()
+        r = orc.solve(h, abi.MARGIN_OLD)
+        t_cpu += time.perf_counter() - tc
+        if n_done < len(holders):
+            ref_cost = r["summary"]["final_cost"]
+            assert abs(final_costs[n_done] - ref_cost) < 1e-6 * ref_cost, (final_costs[n_done], ref_cost)
+        n_done += 1
+    cpu = {"value": n_done / t_cpu, "unit": "solves/s", "cores": 1, "kind": "port",
+           "sample": "%d full optimization() calls (solve + MARGIN_OLD) of the same %d-landmark windows in %.1f s; "
+                     "oracle/ C++ restatement, -O3 -march=native, 1 thread like the reference's ceres::Solve" %
+                     (n_done, args.landmarks, t_cpu),
+           "ms_per_solve": 1e3 * t_cpu / n_done}
+    # the same port on every host core (one window per thread; ctypes drops the GIL): SURVEY.md section 8d (b)
+    import threading
+    import ctypes as C
+    ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    counts = [0] * ncore
+    deadline = time.perf_counter() + min(args.cpu_seconds, 10.0)
+    fsolve = orc._fn("solve_window")
+    fsolve.restype = abi.c_i
+
+    def worker(k):   # the bare C call in the loop: no Python-side result conversion under the GIL
+        hs = [abi.WindowHolder(s) for s in snaps]
+        st, pr, sm = abi.State(), abi.PriorHolder(), abi.Summary()
+        feat = np.zeros(max(h.n_feature for h in hs))
+        i = k
+        while time.perf_counter() < deadline:
+            fsolve(orc.head, C.byref(hs[i % len(hs)].c), int(abi.MARGIN_OLD), C.byref(st), abi._pd(feat), C.byref(pr.c), C.byref(sm))
+            counts[k] += 1
+            i += 1
+    t_all = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(ncore)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    t_all = time.perf_counter() - t_all
+    cpu["all_cores"] = {"value": sum(counts) / t_all, "unit": "solves/s", "cores": ncore,
+                        "sample": "%d solves on %d threads in %.1f s" % (sum(counts), ncore, t_all)}
+    return cpu
 
 
 if __name__ == "__main__":

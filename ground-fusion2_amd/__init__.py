@@ -7,6 +7,7 @@ this package is the thin ctypes binding + synthetic-input generator. There is NO
 every compute entry point raises if the HIP library or a GPU is missing.
 """
 from . import abi, synth, dist, stream  # noqa: F401
-from .backend import Backend, BackendError, lib_path, build_native  # noqa: F401
+from . import backend  # noqa: F401
+from .backend import Backend, BackendError, lib_path, build_native, WindowSet, DownloadBuffers, strip_visual  # noqa: F401
 
 __version__ = "0.1.0"

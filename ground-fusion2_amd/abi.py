@@ -107,13 +107,15 @@ class Options(C.Structure):
     _fields_ = [("max_num_iterations", c_i), ("huber_delta", c_d), ("vis_sqrt_info", c_d), ("g_norm", c_d),
                 ("initial_trust_region_radius", c_d), ("function_tolerance", c_d), ("gradient_tolerance", c_d),
                 ("parameter_tolerance", c_d), ("min_relative_decrease", c_d), ("jacobi_scaling", c_i),
-                ("marg_eps", c_d), ("marg_sqrt", c_i), ("use_graph", c_i), ("split_batch", c_i)]
+                ("marg_eps", c_d), ("marg_sqrt", c_i), ("use_graph", c_i), ("split_batch", c_i),
+                ("max_solver_time_in_seconds", c_d), ("host_threads", c_i)]
 
 
 class Summary(C.Structure):
     _fields_ = [("status", c_i), ("iterations", c_i), ("num_successful", c_i), ("termination", c_i),
                 ("initial_cost", c_d), ("final_cost", c_d), ("final_radius", c_d),
-                ("cost_history", c_d * 16), ("accepted", c_u8 * 16)]
+                ("cost_history", c_d * 16), ("accepted", c_u8 * 16),
+                ("ms_solve", c_d), ("ms_marginalize", c_d), ("bytes_uploaded", c_d), ("bytes_downloaded", c_d)]
 
 
 class FeatureList(C.Structure):
@@ -138,6 +140,8 @@ def default_options():
     o.marg_sqrt = 1
     o.use_graph = 0
     o.split_batch = 1
+    o.max_solver_time_in_seconds = 0.0
+    o.host_threads = 0
     return o
 
 
@@ -453,12 +457,26 @@ class CApi:
                     summary=summary_to_dict(sm), status=rc)
 
 
+def _solve_raw(self, wh, margin_flag=MARGIN_NONE):
+    """solve_window into outputs kept on the holder: the bare C call (latency measurements)."""
+    if not hasattr(wh, "_raw_out"):
+        wh._raw_out = (State(), np.zeros(max(wh.n_feature, 1)), PriorHolder(), Summary())
+    st, feat, pr, sm = wh._raw_out
+    f = self._fn("solve_window")
+    f.restype = c_i
+    return self.check(f(self.head, C.byref(wh.c), int(margin_flag), C.byref(st), _pd(feat), C.byref(pr.c), C.byref(sm)), "solve_window")
+
+
+CApi.solve_raw = _solve_raw
+
+
 def summary_to_dict(sm):
     n = sm.iterations + 1
     return dict(status=sm.status, iterations=sm.iterations, num_successful=sm.num_successful,
                 termination=sm.termination, initial_cost=sm.initial_cost, final_cost=sm.final_cost,
                 final_radius=sm.final_radius, cost_history=list(sm.cost_history)[:n],
-                accepted=list(sm.accepted)[:n])
+                accepted=list(sm.accepted)[:n], ms_solve=sm.ms_solve, ms_marginalize=sm.ms_marginalize,
+                bytes_uploaded=sm.bytes_uploaded, bytes_downloaded=sm.bytes_downloaded)
 
 
 # ---------------------------------------------------------------------------------------------

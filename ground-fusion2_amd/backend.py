@@ -15,7 +15,8 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libgfbe.so")
+# GFBE_LIB: an alternative build of the library (tests/diag_variants.py compares kernel variants built side by side)
+_SO = os.environ.get("GFBE_LIB") or os.path.join(_CSRC, "libgfbe.so")
 
 # Every symbol include/gfbe.h declares (checked by tests/test_abi.py on CPU).
 EXPORTS = [
@@ -47,21 +48,43 @@ def sources():
     return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp")))
 
 
-def build_native(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> csrc/libgfbe.so (cross-compiles without a GPU)."""
+def build_native(force=False, verbose=False, out=None, extra_flags=None, fp_contract="off"):
+    """hipcc --offload-arch=gfx950 -> csrc/libgfbe.so (cross-compiles without a GPU). `out` / `extra_flags` / `fp_contract`:
+    side-by-side variant builds (tests/diag_variants.py)."""
+    so = out or os.path.join(_CSRC, "libgfbe.so")
     srcs = sources()
     deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hpp"))]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "gfbe.h"))
-    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
-        return _SO
+    if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
+        return so
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
-           "-I", os.path.join(os.path.dirname(_HERE), "include"), "-o", _SO] + os.environ.get("GFBE_EXTRA_FLAGS", "").split() + srcs
+    flags = os.environ.get("GFBE_EXTRA_FLAGS", "").split() if extra_flags is None else list(extra_flags)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=" + fp_contract,
+           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-pthread",
+           "-I", os.path.join(os.path.dirname(_HERE), "include"), "-o", so] + flags + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return _SO
+    return so
+
+
+_RCCL_SO = os.path.join(_CSRC, "libgfbe_rccl.so")
+RCCL_EXPORTS = ["gfbe_rccl_unique_id", "gfbe_rccl_create", "gfbe_rccl_destroy", "gfbe_rccl_allreduce", "gfbe_rccl_last_error", "gfbe_rccl_calls"]
+
+
+def build_rccl_hook(force=False, verbose=False):
+    """csrc/rccl/gfbe_rccl_hook.cpp -> csrc/libgfbe_rccl.so (the native all-reduce hook of include/gfbe_rccl.h; links librccl)."""
+    src = os.path.join(_CSRC, "rccl", "gfbe_rccl_hook.cpp")
+    deps = [src, os.path.join(os.path.dirname(_HERE), "include", "gfbe_rccl.h")]
+    if not force and os.path.exists(_RCCL_SO) and all(os.path.getmtime(_RCCL_SO) >= os.path.getmtime(d) for d in deps):
+        return _RCCL_SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", "/opt/rocm/include",
+           "-o", _RCCL_SO, src, "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return _RCCL_SO
 
 
 class Backend(abi.CApi):
@@ -119,8 +142,11 @@ class Backend(abi.CApi):
 
     # ---- device-resident batch
     def batch_upload(self, snaps):
-        holders = [s if isinstance(s, abi.WindowHolder) else abi.WindowHolder(s) for s in snaps]
-        arr = (C.POINTER(abi.Window) * len(holders))(*[C.pointer(h.c) for h in holders])
+        if isinstance(snaps, WindowSet):      # prebuilt pointer array: no per-call Python work (the end-to-end loops of bench.py)
+            holders, arr = snaps.holders, snaps.arr
+        else:
+            holders = [s if isinstance(s, abi.WindowHolder) else abi.WindowHolder(s) for s in snaps]
+            arr = (C.POINTER(abi.Window) * len(holders))(*[C.pointer(h.c) for h in holders])
         batch = C.c_void_p()
         self.check(self.lib.gfbe_batch_upload(self.ctx, len(holders), arr, C.byref(batch)), "batch_upload")
         return Batch(self, batch, holders)
@@ -128,6 +154,11 @@ class Backend(abi.CApi):
     def batch_upload_tables(self, tables, snaps):
         """snaps: window snapshots WITHOUT visual factors (state, pre-integrations, prior, flags); the landmarks of window w
         come from table w of `tables` (abi.FeatureTables on this library) without leaving the device."""
+        if isinstance(snaps, WindowSet):
+            batch = C.c_void_p()
+            self.lib.gfbe_batch_upload_tables.restype = abi.c_i
+            self.check(self.lib.gfbe_batch_upload_tables(self.ctx, tables.h, len(snaps.holders), snaps.arr, C.byref(batch)), "batch_upload_tables")
+            return Batch(self, batch, snaps.holders)
         holders = []
         for s in snaps:
             s = dict(s)
@@ -169,11 +200,49 @@ class Backend(abi.CApi):
             out.append(dict(name=name.value.decode(), launches=launches.value, total_ms=ms.value, bytes=by.value))
         return out
 
-    # ---- multi-GPU landmark sharding: all-reduce hook (RCCL via torch.distributed in the caller)
+    # ---- multi-GPU landmark sharding: the native hook (libgfbe_rccl.so: ncclAllReduce on the solver's stream)
+    def set_allreduce_native(self, fn_ptr, user_ptr, rank, world_size):
+        """fn_ptr: address of a gfbe_allreduce_fn (e.g. gfbe_rccl_allreduce), user_ptr: its handle."""
+        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+        self._cb = C.cast(fn_ptr, CB)
+        self.check(self.lib.gfbe_set_allreduce(self.ctx, self._cb, C.c_void_p(user_ptr), int(rank), int(world_size)), "set_allreduce")
+
+    # ---- the same through a Python callable (torch.distributed in the caller; the tests' gloo flavour)
     def set_allreduce(self, fn, rank, world_size):
         CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
         self._cb = CB(lambda user, ptr, n, stream: fn(ptr, n, stream)) if fn is not None else C.cast(None, CB)
         self.check(self.lib.gfbe_set_allreduce(self.ctx, self._cb, None, int(rank), int(world_size)), "set_allreduce")
+
+
+def strip_visual(snap):
+    """Window snapshot without its visual part (what gfbe_batch_upload_tables reads from the host)."""
+    s = dict(snap)
+    for k in ("vis_feature_index", "vis_imu_i", "vis_imu_j", "vis_pts_i", "vis_pts_j", "vis_vel_i", "vis_vel_j", "vis_td_i", "vis_td_j"):
+        s[k] = np.zeros(0)
+    s["para_feature"], s["feature_const"] = np.zeros(0), np.zeros(0, np.uint8)
+    return s
+
+
+class WindowSet:
+    """A list of windows with the ctypes pointer array gfbe_batch_upload takes, built once (bench.py's end-to-end loops
+    re-upload the same host structures every step; the library re-packs and re-copies them every time)."""
+
+    def __init__(self, snaps):
+        self.holders = [s if isinstance(s, abi.WindowHolder) else abi.WindowHolder(s) for s in snaps]
+        self.arr = (C.POINTER(abi.Window) * len(self.holders))(*[C.pointer(h.c) for h in self.holders])
+
+
+class DownloadBuffers:
+    """Pre-allocated outputs of gfbe_batch_download for n windows of up to max_features landmarks."""
+
+    def __init__(self, n, max_features):
+        self.n = n
+        self.states = (abi.State * n)()
+        self.feats = np.zeros((n, max(int(max_features), 1)))
+        self.fptr = (abi.PD * n)(*[abi._pd(self.feats[k]) for k in range(n)])
+        self.priors = [abi.PriorHolder() for _ in range(n)]
+        self.pptr = (C.POINTER(abi.Prior) * n)(*[C.pointer(p.c) for p in self.priors])
+        self.sums = (abi.Summary * n)()
 
 
 class Batch:
@@ -199,6 +268,10 @@ class Batch:
                             prior=priors[k].to_dict() if priors[k].c.valid else None,
                             summary=abi.summary_to_dict(sums[k]), status=sums[k].status))
         return out
+
+    def download_into(self, bufs):
+        """gfbe_batch_download into pre-allocated buffers (no per-window Python work); returns the status."""
+        return self.be.check(self.be.lib.gfbe_batch_download(self.be.ctx, self.h, bufs.states, bufs.fptr, bufs.pptr, bufs.sums), "batch_download")
 
     def debug_timing(self, w=0):
         out = np.zeros(32)

@@ -125,6 +125,8 @@ struct WinCtl {
   double initial_cost;
   double cost_history[16];
   unsigned char accepted[16];
+  long long t_start, t_solved, t_marg;   // device wall clock (100 MHz ticks): k_reset, k_reanchor, end of the marginalisation (0: none)
+  int marg_ran, pad1;                    // the marginalisation kernels handled this window in the last solve
 };
 
 // ---- batch: all device pointers ----------------------------------------------------------------
@@ -143,6 +145,8 @@ struct BatchDev {
   double *lm_pts;             // [6][tot_lm]: pix piy piz vix viy td_i
   double *lm_obs;             // [MAXOBS][5][tot_lm]: pjx pjy vjx vjy td_j
   int *lm_rec;                // [MAXOBS][tot_lm]: record position (relative to rec_off) of factor k
+  double *fobs;               // [tot_rec][5] host upload only: pjx pjy vjx vjy td_j of every factor in record (pair-major) order; k_expand
+                              // scatters them into lm_obs / lm_rec (the ELL rows never cross PCIe: 40 B per factor instead of ~100)
   double *lam0, *lam;         // [tot_lm], [2][tot_lm]
   double *lm_Hll, *lm_gl;     // [tot_lm]
   double *lm_hC;              // [HC][tot_lm]
@@ -164,6 +168,7 @@ struct BatchDev {
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
+  int test_fail_chol_iter, pad_t;   // fault injection (GFBE_TEST_FAIL_CHOL_ITER, tests only): the first factorisation of that iteration "fails"
   double *xa, *xb, *xc;       // [B][world][XCHG] scalar exchange rows (own row written, the others zeroed, then sum all-reduce):
                               //   xa: visual cost of the linearisation point; xb: landmark shares of the dogleg scalars;
                               //   xc: candidate cost / step norms
@@ -192,12 +197,25 @@ struct BatchDev {
   int *mmeta;                 // [B][4 + 3*GFBE_MAX_PRIOR_BLOCKS]: valid, n, n_blocks, pad, ids, sizes, idx
   double *mx0;                // [B][PRIOR_X0]
   double *timing;             // [B][32] phase time stamps of k_solve (wall_clock64, 10 ns ticks; diagnostics)
+  // ---- result hand-over (k_gather): everything gfbe_batch_download returns, packed for ONE device-to-host copy
+  //   dl_fix [B][DL_FIX doubles]: WinCtl | xout | prior meta (ints) | prior x0 | prior r0     dl_feat [sum L]: para_Feature in ABI order
+  //   dl_J0: the new priors' J0, n x n each, at the host-known offsets dl_j0_off[w] (upper bounds of n from the block tables)
+  double *dl_fix, *dl_feat, *dl_J0;
+  int *dl_feat_off;           // [B + 1]
+  long long *dl_j0_off;       // [B + 1]
 };
+enum { DL_CTL = (sizeof(WinCtl) + 7) / 8, DL_META = (4 + 3 * GFBE_MAX_PRIOR_BLOCKS + 1) / 2,
+       DL_OFF_X = DL_CTL, DL_OFF_META = DL_OFF_X + NA, DL_OFF_X0 = DL_OFF_META + DL_META, DL_OFF_R0 = DL_OFF_X0 + GFBE_NFRAMES * 16 + 32,
+       DL_FIX = DL_OFF_R0 + ND };
 
 enum { PRIOR_X0 = GFBE_NFRAMES * 16 + 32 };
 
 // ---- kernel launchers (gfbe_kernels.hip / gfbe_marg.hip) -------------------------------------------
+hipError_t kernels_init_device();   // per-device kernel attributes (k_solve's dynamic LDS); called by gfbe_create
+hipError_t marg_init_device();      // same for k_marg
 void launch_prep(const BatchDev &d, hipStream_t s);
+void launch_expand(const BatchDev &d, hipStream_t s);                 // host upload: fobs -> lm_obs / lm_rec
+void launch_gather(const BatchDev &d, int margin_flag, hipStream_t s);   // results -> dl_fix / dl_feat / dl_J0
 void launch_reset(const BatchDev &d, hipStream_t s);
 // mode 0: linearise at the current parameters (writes records, landmark sums, cost partials)
 // mode 1: candidate cost only   mode 2: linearise the marginalisation set at xout (start frame 0 only)

@@ -7,7 +7,13 @@
 //   Ground-Fusion++/vins_estimator/src/estimator/estimator.cpp:2951-3698
 #include "gfbe_device.h"
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -32,6 +38,59 @@ struct ProfEntry {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+// Host threads of the upload / download packing: a fixed set of workers, one parallel-for at a time, the caller takes part.
+class HostPool {
+ public:
+  explicit HostPool(int n) { for (int i = 0; i < n; i++) th_.emplace_back([this] { loop(); }); }
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  int size() const { return (int)th_.size(); }
+  // fn(i) for i in [0, n) on `helpers` workers + the calling thread; returns when all are done
+  void run(int n, int helpers, const std::function<void(int)> &fn) {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; n_ = n; next_.store(0); active_ = std::min(helpers, (int)th_.size()); running_ = active_; gen_++;
+    }
+    cv_.notify_all();
+    for (int i; (i = next_.fetch_add(1)) < n;) fn(i);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return running_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int)> *fn;
+      int n;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        if (active_ <= 0) continue;     // more workers than this job wants
+        active_--;
+        fn = fn_; n = n_;
+      }
+      for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
+      { std::lock_guard<std::mutex> lk(m_); running_--; }
+      done_.notify_all();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *fn_ = nullptr;
+  int n_ = 0, active_ = 0, running_ = 0;
+  std::atomic<int> next_{0};
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
 struct gfbe_ctx {
   int device = -1;
   gfbe_options opt;
@@ -53,8 +112,15 @@ struct gfbe_ctx {
   // grow-only device scratch of the short host-buffer calls (pre-integration): no hipMalloc / hipFree per call
   char *scratch = nullptr;
   size_t scratch_cap = 0;
+  // host <-> device hand-over beside the solves: uploads (one H2D copy + preparation kernels) run on `copy`, downloads
+  // (gather kernel + one D2H copy) on `dl`, so that batch k + 1 is uploaded and batch k - 1 downloaded while batch k solves
+  hipStream_t copy = nullptr, dl = nullptr;
+  std::vector<std::pair<void *, size_t>> pin_cache;   // pinned host staging of freed batches
+  std::unique_ptr<HostPool> pool;                     // packing threads (gfbe_options.host_threads)
+  bool want_records = false;                          // gfbe_eval_factors: allocate the block-CSR record array
 };
-enum : size_t { SLAB_CACHE_ENTRIES = 4, SLAB_CACHE_MAX_BYTES = (size_t)512 << 20 };
+// (a 1024-window batch of 2k-landmark windows is a 7 GB slab; 288 GB of HBM leave room to keep a few)
+enum : size_t { SLAB_CACHE_ENTRIES = 6, SLAB_CACHE_MAX_BYTES = (size_t)48 << 30, PIN_CACHE_ENTRIES = 12, PIN_CACHE_MAX_BYTES = (size_t)8 << 30 };
 
 // The streams / events one (sub-)batch runs on: main stream, the aux stream of its dense factors, fork / join events.
 struct Lane { hipStream_t s, aux; hipEvent_t fork, join; };
@@ -66,8 +132,20 @@ struct gfbe_batch {
   char *slab = nullptr;
   size_t slab_bytes = 0, slab_off = 0;
   bool dry = false;
-  std::vector<std::vector<int>> slot_of;   // per window: ABI landmark -> global slot
+  std::vector<std::vector<int>> slot_of;   // per window: ABI landmark -> global slot (host-fed batches)
   std::vector<int> L;
+  // upload region [0, up_end) of the slab = the pinned mirror up_h; [up_end, zero_end) is cleared; the rest is written before read
+  char *up_h = nullptr;
+  size_t up_cap = 0, up_bytes = 0, up_end = 0, zero_end = 0;
+  // results: [dl_fix | dl_feat | dl_J0] at the end of the slab -> dl_h (pinned) in one copy
+  char *dl_h = nullptr;
+  size_t dl_cap = 0, dl_bytes = 0;
+  std::vector<int> feat_off;
+  std::vector<long long> j0_off;
+  std::vector<double> up_win_bytes;
+  hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_dl = nullptr;   // upload complete / last solve complete / results on the host
+  int last_flag = GFBE_MARGIN_NONE;
+  bool fetched = false;                    // dl_h holds the results of the last solve
   double algo_bytes_lin = 0.0;             // algorithmic bytes of one visual linearisation of the batch
   size_t slab_n = 0;                       // doubles of the [H | g | E | eg | xa] slab
   // the launch sequence of one optimization() is fixed (no host decision inside): captured once per margin flag
@@ -126,6 +204,8 @@ void gfbe_default_options(gfbe_options *o) {
   o->marg_sqrt = 1;                          // pivoted LDL^T square root (0 = eigen-decomposition as in the reference)
   o->split_batch = 1;                        // batches of >= 128 windows run as two halves on two pairs of streams
   o->use_graph = 0;                          // 1: replay the fixed launch sequence of gfbe_batch_solve as a hipGraph (measured: no gain)
+  o->max_solver_time_in_seconds = 0.0;       // no cap (the reference: SOLVER_TIME = 0.04, estimator.cpp:3369-3376)
+  o->host_threads = 0;                       // packing threads: min(hardware threads, 32)
 }
 
 const char *gfbe_version(void) { return "gfbe 0.1.0 (gfx950, HIP)"; }
@@ -149,11 +229,17 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   }
   c->own_stream = true;
   if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->dl, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     c->err = "hipStreamCreate/hipEventCreate (aux stream) failed";
     return GFBE_DEVICE_ERROR;
   }
+  // kernel attributes are per device: every context sets them for its own GPU
+  hipError_t ea = kernels_init_device();
+  if (ea == hipSuccess) ea = marg_init_device();
+  if (ea != hipSuccess) { c->err = std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
   return GFBE_OK;
 }
 
@@ -163,6 +249,9 @@ void gfbe_destroy(gfbe_ctx *c) {
   for (auto &p : c->prof) for (auto &ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+  if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
+  if (c->dl) { (void)hipStreamSynchronize(c->dl); (void)hipStreamDestroy(c->dl); }
+  for (auto &sl : c->pin_cache) (void)hipHostFree(sl.first);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (auto &sl : c->slab_cache) (void)hipFree(sl.first);
@@ -277,7 +366,10 @@ void prof_collect(gfbe_ctx *c) {
   }
 }
 
-// (the slab is zeroed once, before the second pass)
+// Two passes over one allocation sequence: the dry pass adds up the sizes, the slab comes from the context's cache (or
+// hipMalloc), the second pass hands out the pointers. The arrays the host fills come FIRST ("upload region"): they have a
+// mirror at the same offsets in one pinned host buffer, the packing threads write straight into that mirror, and the whole
+// region crosses PCIe as ONE hipMemcpyAsync. Only the arrays the kernels expect zeroed are cleared (one hipMemsetAsync).
 template <typename T>
 gfbe_status dev_alloc(gfbe_ctx *c, gfbe_batch *b, T **p, size_t n) {
   const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
@@ -287,11 +379,14 @@ gfbe_status dev_alloc(gfbe_ctx *c, gfbe_batch *b, T **p, size_t n) {
   b->slab_off += bytes;
   return GFBE_OK;
 }
+// an array of the upload region: device pointer + its pinned host mirror (valid in the second pass)
 template <typename T>
-gfbe_status dev_upload(gfbe_ctx *c, gfbe_batch *b, T **p, const std::vector<T> &h) {
-  gfbe_status st = dev_alloc(c, b, p, h.size());
-  if (st != GFBE_OK || b->dry) return st;
-  if (!h.empty()) HIPCHK(c, hipMemcpyAsync(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+gfbe_status up_alloc(gfbe_ctx *c, gfbe_batch *b, T **p, T **h, size_t n) {
+  const size_t off = b->dry ? b->slab_bytes : b->slab_off;
+  gfbe_status st = dev_alloc(c, b, p, n);
+  if (st != GFBE_OK) return st;
+  if (b->dry) { *h = nullptr; b->up_bytes = b->slab_bytes; }
+  else *h = (T *)(b->up_h + off);
   return GFBE_OK;
 }
 // the smallest cached slab that fits (and is not more than twice too large), else a new one
@@ -321,12 +416,13 @@ gfbe_status slab_acquire(gfbe_ctx *c, gfbe_batch *b) {
     if (e != hipSuccess) { (void)hipGetLastError(); c->err = std::string("hipMalloc(batch slab): ") + hipGetErrorString(e); return GFBE_DEVICE_ERROR; }
     b->slab = (char *)q;
   }
-  HIPCHK(c, hipMemsetAsync(b->slab, 0, b->slab_bytes, c->stream));
   return GFBE_OK;
 }
 void slab_release(gfbe_ctx *c, gfbe_batch *b) {
   if (!b->slab) return;
-  if (c && b->slab_bytes <= SLAB_CACHE_MAX_BYTES) {
+  size_t cached = 0;
+  if (c) for (auto &sl : c->slab_cache) cached += sl.second;
+  if (c && cached + b->slab_bytes <= SLAB_CACHE_MAX_BYTES) {
     if (c->slab_cache.size() >= SLAB_CACHE_ENTRIES) { (void)hipFree(c->slab_cache.front().first); c->slab_cache.erase(c->slab_cache.begin()); }
     c->slab_cache.emplace_back(b->slab, b->slab_bytes);
   } else {
@@ -334,14 +430,137 @@ void slab_release(gfbe_ctx *c, gfbe_batch *b) {
   }
   b->slab = nullptr;
 }
+// pinned host staging (upload mirror / download buffer): hipHostMalloc costs ~1 ms per 10 MB, so the buffers are cached too
+char *pin_acquire(gfbe_ctx *c, size_t bytes, size_t *cap_out) {
+  int best = -1;
+  for (size_t i = 0; i < c->pin_cache.size(); i++) {
+    const size_t cap = c->pin_cache[i].second;
+    if (cap >= bytes && cap <= 2 * bytes + ((size_t)1 << 20) && (best < 0 || cap < c->pin_cache[best].second)) best = (int)i;
+  }
+  if (best >= 0) {
+    char *q = (char *)c->pin_cache[best].first;
+    *cap_out = c->pin_cache[best].second;
+    c->pin_cache.erase(c->pin_cache.begin() + best);
+    return q;
+  }
+  size_t grain = (size_t)1 << 16;
+  while (grain * 8 <= bytes) grain *= 2;
+  const size_t cap = (bytes + grain - 1) / grain * grain;
+  void *q = nullptr;
+  if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  *cap_out = cap;
+  return (char *)q;
+}
+void pin_release(gfbe_ctx *c, char *p, size_t cap) {
+  if (!p) return;
+  size_t cached = 0;
+  if (c) for (auto &sl : c->pin_cache) cached += sl.second;
+  if (c && cached + cap <= PIN_CACHE_MAX_BYTES) {
+    if (c->pin_cache.size() >= PIN_CACHE_ENTRIES) { (void)hipHostFree(c->pin_cache.front().first); c->pin_cache.erase(c->pin_cache.begin()); }
+    c->pin_cache.emplace_back(p, cap);
+  } else {
+    (void)hipHostFree(p);
+  }
+}
+
+// One window per task on the context's host threads (the caller takes part); n == 1 or host_threads == 1 runs inline.
+void host_parallel(gfbe_ctx *c, int n, const std::function<void(int)> &fn) {
+  int want = c->opt.host_threads > 0 ? c->opt.host_threads : std::min<int>(32, std::max(1u, std::thread::hardware_concurrency()));
+  want = std::min(want, n);
+  if (want <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+  if (!c->pool || c->pool->size() < want - 1) c->pool.reset(new HostPool(want - 1));
+  c->pool->run(n, want - 1, fn);
+}
 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // Upload: pack windows into the device layout.
 // ---------------------------------------------------------------------------------------------
+namespace {
+// what the scan of one window's factor list leaves for the fill pass
+struct WinScan {
+  int L = 0, K = 0, slots = 0, n_tiles = 0;
+  int sf_tile_begin[NF + 1];
+  int pair_begin[NPAIR + 1];
+  std::vector<int> slot_rel;      // ABI landmark -> slot relative to the window's first slot
+  std::vector<unsigned char> lstart, lm;
+  std::string err;
+};
+
+// Validates the visual factor list of one window and lays its landmarks out: groups by start frame (tile aligned), inside a
+// group longer tracks first, ties in ABI order (a stable counting sort over (start, m) bins).
+bool scan_window(const gfbe_window &win, int w, WinScan &sc) {
+  const int L = win.n_feature, K = win.vis.n_factor;
+  sc.L = L; sc.K = K;
+  auto fail = [&](const std::string &m) { sc.err = "window " + std::to_string(w) + ": " + m; return false; };
+  if (L > 0 && !win.para_Feature) return fail("para_Feature is null");
+  if (K > 0 && (!win.vis.feature_index || !win.vis.imu_i || !win.vis.imu_j || !win.vis.pts_i || !win.vis.pts_j || !win.vis.vel_i ||
+                !win.vis.vel_j || !win.vis.td_i || !win.vis.td_j)) return fail("null visual factor array");
+  sc.lstart.assign(L, 255); sc.lm.assign(L, 0);
+  std::vector<unsigned short> mask(L, 0);
+  int pair_cnt[NPAIR];
+  for (int p = 0; p < NPAIR; p++) pair_cnt[p] = 0;
+  for (int k = 0; k < K; k++) {
+    const int l = win.vis.feature_index[k], i = win.vis.imu_i[k], j = win.vis.imu_j[k];
+    if (l < 0 || l >= L || i < 0 || j <= i || j > win.frame_count) return fail("bad visual factor " + std::to_string(k));
+    if (sc.lstart[l] == 255) sc.lstart[l] = (unsigned char)i;
+    if (sc.lstart[l] != i) return fail("visual factors of one landmark must share imu_i");
+    const unsigned short bit = (unsigned short)(1u << (j - i - 1));
+    if (mask[l] & bit) return fail("two visual factors of one landmark on the same frame");
+    mask[l] |= bit; sc.lm[l]++;
+    pair_cnt[i * NF + j]++;
+  }
+  int bin_cnt[NF][MAXOBS + 1];
+  for (int s = 0; s < NF; s++) for (int m = 0; m <= MAXOBS; m++) bin_cnt[s][m] = 0;
+  for (int l = 0; l < L; l++) {
+    if (sc.lstart[l] == 255) sc.lstart[l] = 0;
+    const int m = sc.lm[l];
+    if (m > MAXOBS) return fail("landmark with more than 10 factors");
+    if (mask[l] != (unsigned short)((1u << m) - 1)) return fail("landmark track must be contiguous from start_frame (feature_per_frame order)");
+    bin_cnt[sc.lstart[l]][m]++;
+  }
+  int bin_base[NF][MAXOBS + 1];
+  int slots = 0;
+  for (int s = 0; s < NF; s++) {
+    sc.sf_tile_begin[s] = slots / LM_TILE;
+    int in_group = 0;
+    for (int m = MAXOBS; m >= 0; m--) { bin_base[s][m] = slots + in_group; in_group += bin_cnt[s][m]; }
+    slots += (in_group + LM_TILE - 1) / LM_TILE * LM_TILE;
+  }
+  sc.sf_tile_begin[NF] = slots / LM_TILE;
+  sc.slots = slots; sc.n_tiles = slots / LM_TILE;
+  sc.slot_rel.resize(L);
+  for (int l = 0; l < L; l++) sc.slot_rel[l] = bin_base[sc.lstart[l]][sc.lm[l]]++;
+  int run = 0;
+  for (int p = 0; p < NPAIR; p++) { sc.pair_begin[p] = run; run += pair_cnt[p]; }
+  sc.pair_begin[NPAIR] = run;
+  return true;
+}
+
+// Upper bound of the tangent size of the prior a marginalisation of this window can return (MarginalizationInfo::n): the
+// blocks the marginalisation set touches (k_marg builds the same table on the device) minus the dropped ones.
+int prior_out_bound(const gfbe_window &win, const int *pair_begin, bool old) {
+  bool touched[GFBE_BLK_COUNT];
+  for (int q = 0; q < GFBE_BLK_COUNT; q++) touched[q] = false;
+  const gfbe_prior *pr = (win.prior && win.prior->valid && win.prior->n > 0) ? win.prior : nullptr;
+  if (pr) for (int q = 0; q < pr->n_blocks; q++) touched[pr->block_id[q]] = true;
+  if (!old) return pr ? pr->n : 0;
+  for (int k = 0; k < win.n_imu; k++) if (win.imu_frame[k] == 0) touched[0] = touched[GFBE_BLK_SB0] = touched[1] = touched[GFBE_BLK_SB0 + 1] = true;
+  for (int k = 0; k < win.n_wheel; k++)
+    if (win.wheel_frame[k] == 0) touched[0] = touched[1] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_SX] = touched[GFBE_BLK_SY] = touched[GFBE_BLK_SW] = touched[GFBE_BLK_TD_WHEEL] = true;
+  if (pair_begin) { for (int j = 1; j < NF; j++) if (pair_begin[j + 1] > pair_begin[j]) touched[0] = touched[j] = touched[GFBE_BLK_EX_CAM] = touched[GFBE_BLK_TD] = true; }
+  else for (int q = 0; q < NF; q++) touched[q] = touched[GFBE_BLK_EX_CAM] = touched[GFBE_BLK_TD] = true;   // (table-fed: pair counts live on the device)
+  int n = 0;
+  for (int q = 0; q < GFBE_BLK_COUNT; q++) if (touched[q] && q != 0 && q != GFBE_BLK_SB0) n += blk_lsize(q);
+  return n;
+}
+}  // namespace
+
 // tabs != nullptr: the visual factors of window w come from table tab0 + w of the device-resident feature tables
 // (wins[w]->vis, n_feature, para_Feature, feature_const are ignored); the landmark arrays are then filled on the device.
+// The call returns when the windows are packed into pinned memory and the copy + preparation kernels are enqueued on the
+// context's copy stream: the caller's buffers are free again, gfbe_batch_solve waits for the batch's `ev_up`.
 static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs = nullptr,
                               int tab0 = 0) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
@@ -350,221 +569,285 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   HIPCHK(c, hipSetDevice(c->device));
   const double T0 = now();
+  for (int w = 0; w < B; w++) {
+    const gfbe_window *win = wins[w];
+    if (!win) { c->err = "window " + std::to_string(w) + ": null pointer"; return GFBE_BAD_INPUT; }
+    if (win->frame_count < 0 || win->frame_count > GFBE_WINDOW_SIZE || win->n_imu < 0 || win->n_imu > MAX_IMU || win->n_wheel < 0 || win->n_wheel > MAX_WHEEL ||
+        (!tabs && (win->n_feature < 0 || win->vis.n_factor < 0)) || (win->n_imu > 0 && (!win->imu || !win->imu_frame)) ||
+        (win->n_wheel > 0 && (!win->wheel || !win->wheel_frame))) {
+      c->err = "window " + std::to_string(w) + ": bad sizes"; return GFBE_BAD_INPUT;
+    }
+  }
   gfbe_batch *b = new gfbe_batch();
   *out = b;
   BatchDev &d = b->d;
   std::memset(&d, 0, sizeof d);
   d.B = B;
   d.opt = c->opt;
-  std::vector<WinDesc> desc(B);
-  std::vector<int> lm_info, lm_abi, lm_rec, tile_start;
-  std::vector<double> lm_pts, lm_obs, lam0, x0((size_t)B * NA);
-  std::vector<gfbe_imu_preint> imu;
-  std::vector<gfbe_wheel_preint> wheel;
-  std::vector<double> lio;
-  std::vector<double> pr0((size_t)B * ND, 0.0), px0((size_t)B * PRIOR_X0, 0.0);
-  // J0 of the priors travels compactly: host rows of nmax^2 doubles (nmax = the largest prior of the batch), copied into the
-  // device slots of ND^2 doubles by one 2-D copy (a 2k-landmark window's prior is 86^2 of the 182^2 doubles of a slot)
-  int pn_max = 0;
-  for (int w = 0; w < B; w++) if (wins[w] && wins[w]->prior && wins[w]->prior->valid) pn_max = std::max(pn_max, std::min(wins[w]->prior->n, (int)ND));
-  const size_t pj_row = (size_t)std::max(pn_max, 0) * std::max(pn_max, 0);
-  std::vector<double> pJ0((size_t)B * pj_row, 0.0);
+  if (hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&b->ev_dl, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate (batch) failed"; return GFBE_DEVICE_ERROR; }
+  // the stream the upload runs on: host-fed batches use the copy stream (beside a solve on the main stream); the table-fed
+  // path follows the table operations on the main stream
+  hipStream_t us = tabs ? c->stream : c->copy;
   b->slot_of.resize(B);
   b->L.resize(B);
-  // first pass: sizes
-  struct LmTmp { int start, m, abi; std::vector<int> fac; };
-  std::vector<std::vector<LmTmp>> all_lms(B);
-  int tot_lm = 0, tot_rec = 0, max_tiles = 0;
+  b->up_win_bytes.assign(B, 0.0);
+  std::vector<WinScan> scan(B);
   std::vector<int> tcounts, tlayout;     // table source: per window [L, K, bins], layout table for the pack kernel
+  // ---- pass 1 (parallel over windows): validate the factor lists, lay the landmarks out
   if (tabs) {
     if (tab0 < 0 || tab0 + B > tabs->d.W) { c->err = "gfbe_batch_upload_tables: more windows than tables"; return GFBE_BAD_INPUT; }
     int *dcounts = tabs->d.hist + (size_t)tab0 * (FT_BINS + 2);
-    launch_ftab_count(tabs->d, tabs->cur, tab0, B, dcounts, c->stream);
+    launch_ftab_count(tabs->d, tabs->cur, tab0, B, dcounts, us);
     tcounts.resize((size_t)B * (FT_BINS + 2));
-    HIPCHK(c, hipMemcpyAsync(tcounts.data(), dcounts, sizeof(int) * tcounts.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(tcounts.data(), dcounts, sizeof(int) * tcounts.size(), hipMemcpyDeviceToHost, us));
+    HIPCHK(c, hipStreamSynchronize(us));
     tlayout.assign((size_t)B * FT_LAY_STRIDE, 0);
-  }
-  for (int w = 0; w < B; w++) {
-    const gfbe_window &win = *wins[w];
-    WinDesc &ds = desc[w];
-    std::memset(&ds, 0, sizeof ds);
-    const int L = tabs ? tcounts[(size_t)w * (FT_BINS + 2)] : win.n_feature, K = tabs ? tcounts[(size_t)w * (FT_BINS + 2) + 1] : win.vis.n_factor;
-    if (L < 0 || K < 0 || win.frame_count < 0 || win.frame_count > GFBE_WINDOW_SIZE || win.n_imu > MAX_IMU || win.n_wheel > MAX_WHEEL) {
-      c->err = "window " + std::to_string(w) + ": bad sizes"; return GFBE_BAD_INPUT;
-    }
-    ds.L = L; ds.K = K; ds.frame_count = win.frame_count;
-    if (tabs) {   // layout from the per-bin counts: groups by start frame (tile aligned), longer tracks first inside a group
+    for (int w = 0; w < B; w++) {   // layout from the per-bin counts: groups by start frame (tile aligned), longer tracks first inside a group
+      WinScan &sc = scan[w];
       const int *cnt = &tcounts[(size_t)w * (FT_BINS + 2) + 2];
       int *lay = &tlayout[(size_t)w * FT_LAY_STRIDE];
-      ds.lm_off = tot_lm;
-      ds.tile_off = (int)tile_start.size();
-      b->L[w] = L;
-      lay[0] = tot_lm;
+      sc.L = tcounts[(size_t)w * (FT_BINS + 2)]; sc.K = tcounts[(size_t)w * (FT_BINS + 2) + 1];
+      if (sc.L < 0 || sc.K < 0) { c->err = "window " + std::to_string(w) + ": bad sizes"; return GFBE_BAD_INPUT; }
       int slots = 0;
       for (int s = 0; s < NF; s++) {
-        ds.sf_tile_begin[s] = slots / LM_TILE;
+        sc.sf_tile_begin[s] = slots / LM_TILE;
         lay[FT_LAY_GRP + s] = slots;
         int in_group = 0;
         for (int m = MAXOBS; m >= 3; m--) { lay[FT_LAY_BIN + s * 8 + (m - 3)] = slots + in_group; in_group += cnt[s * 8 + (m - 3)]; }
-        const int padded = (in_group + LM_TILE - 1) / LM_TILE * LM_TILE;
-        for (int t = 0; t < padded / LM_TILE; t++) tile_start.push_back(s);
-        slots += padded;
+        slots += (in_group + LM_TILE - 1) / LM_TILE * LM_TILE;
       }
-      ds.sf_tile_begin[NF] = slots / LM_TILE;
-      ds.lm_slots = slots;
-      ds.n_tiles = slots / LM_TILE;
-      max_tiles = std::max(max_tiles, ds.n_tiles);
-      tot_lm += slots;
-      ds.rec_off = tot_rec;
-      tot_rec += K;
-      continue;
-    }
-    std::vector<LmTmp> &lms = all_lms[w];
-    lms.resize(L);
-    for (int l = 0; l < L; l++) { lms[l].start = -1; lms[l].m = 0; lms[l].abi = l; }
-    for (int k = 0; k < K; k++) {
-      const int l = win.vis.feature_index[k], i = win.vis.imu_i[k], j = win.vis.imu_j[k];
-      if (l < 0 || l >= L || i < 0 || j <= i || j > win.frame_count) { c->err = "window " + std::to_string(w) + ": bad visual factor " + std::to_string(k); return GFBE_BAD_INPUT; }
-      if (lms[l].start < 0) lms[l].start = i;
-      if (lms[l].start != i) { c->err = "visual factors of one landmark must share imu_i"; return GFBE_BAD_INPUT; }
-      lms[l].fac.push_back(k);
-    }
-    for (int l = 0; l < L; l++) {
-      LmTmp &lm = lms[l];
-      if (lm.start < 0) lm.start = 0;
-      std::sort(lm.fac.begin(), lm.fac.end(), [&](int a, int bb) { return win.vis.imu_j[a] < win.vis.imu_j[bb]; });
-      lm.m = (int)lm.fac.size();
-      if (lm.m > MAXOBS) { c->err = "landmark with more than 10 factors"; return GFBE_BAD_INPUT; }
-      for (int k = 0; k < lm.m; k++)
-        if (win.vis.imu_j[lm.fac[k]] != lm.start + 1 + k) { c->err = "landmark track must be contiguous from start_frame (feature_per_frame order)"; return GFBE_BAD_INPUT; }
-    }
-    // internal order: by start frame, then longer tracks first (uniform trip counts inside a wave)
-    std::vector<int> order(L);
-    for (int l = 0; l < L; l++) order[l] = l;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int bb) {
-      if (lms[a].start != lms[bb].start) return lms[a].start < lms[bb].start;
-      return lms[a].m > lms[bb].m;
-    });
-    ds.lm_off = tot_lm;
-    ds.tile_off = (int)tile_start.size();
-    b->slot_of[w].assign(L, -1);
-    b->L[w] = L;
-    int slots = 0, oi = 0;
-    for (int s = 0; s < NF; s++) {
-      ds.sf_tile_begin[s] = slots / LM_TILE;
-      int cnt = 0;
-      while (oi < L && lms[order[oi]].start == s) { b->slot_of[w][order[oi]] = tot_lm + slots + cnt; cnt++; oi++; }
-      const int padded = (cnt + LM_TILE - 1) / LM_TILE * LM_TILE;
-      for (int t = 0; t < padded / LM_TILE; t++) tile_start.push_back(s);
-      slots += padded;
-    }
-    ds.sf_tile_begin[NF] = slots / LM_TILE;
-    ds.lm_slots = slots;
-    ds.n_tiles = slots / LM_TILE;
-    max_tiles = std::max(max_tiles, ds.n_tiles);
-    tot_lm += slots;
-    ds.rec_off = tot_rec;
-    tot_rec += K;
-  }
-  d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec;
-  lm_info.assign(tot_lm, 0); lm_abi.assign(tot_lm, -1);
-  lm_pts.assign((size_t)6 * tot_lm, 0.0); lm_obs.assign((size_t)MAXOBS * 5 * tot_lm, 0.0);
-  lm_rec.assign((size_t)MAXOBS * tot_lm, 0); lam0.assign(tot_lm, 1.0);
-  const size_t TL = tot_lm;
-  double algo_bytes = 0.0;
-  for (int w = 0; w < B; w++) {
-    const gfbe_window &win = *wins[w];
-    WinDesc &ds = desc[w];
-    std::vector<LmTmp> &lms = all_lms[w];
-    // pair-major record positions, assigned in slot order
-    std::vector<int> pair_cnt(NPAIR + 1, 0);
-    if (tabs) {   // factors of pair (s, s+1+k) = landmarks of start frame s with more than k factors
-      const int *cnt = &tcounts[(size_t)w * (FT_BINS + 2) + 2];
+      sc.sf_tile_begin[NF] = slots / LM_TILE;
+      sc.slots = slots; sc.n_tiles = slots / LM_TILE;
+      // factors of pair (s, s+1+k) = landmarks of start frame s with more than k factors
+      int pair_cnt[NPAIR];
+      for (int p = 0; p < NPAIR; p++) pair_cnt[p] = 0;
       for (int s = 0; s < NF; s++)
         for (int k = 0; k < MAXOBS && s + 1 + k < NF; k++)
           for (int m = std::max(k + 1, 3); m <= MAXOBS; m++) pair_cnt[s * NF + s + 1 + k] += cnt[s * 8 + (m - 3)];
-    } else {
-      for (int k = 0; k < ds.K; k++) pair_cnt[win.vis.imu_i[k] * NF + win.vis.imu_j[k]]++;
+      int run = 0;
+      for (int p = 0; p < NPAIR; p++) { sc.pair_begin[p] = run; run += pair_cnt[p]; }
+      sc.pair_begin[NPAIR] = run;
+      std::memcpy(&lay[FT_LAY_PAIR], sc.pair_begin, sizeof(int) * (NPAIR + 1));
     }
-    int run = 0;
-    for (int p = 0; p < NPAIR; p++) { ds.pair_begin[p] = run; run += pair_cnt[p]; }
-    ds.pair_begin[NPAIR] = run;
-    if (tabs) std::memcpy(&tlayout[(size_t)w * FT_LAY_STRIDE + FT_LAY_PAIR], ds.pair_begin, sizeof(int) * (NPAIR + 1));
-    std::vector<int> fill(ds.pair_begin, ds.pair_begin + NPAIR);
-    std::vector<std::pair<int, int>> by_slot;
-    if (!tabs) for (int l = 0; l < ds.L; l++) by_slot.emplace_back(b->slot_of[w][l], l);
-    std::sort(by_slot.begin(), by_slot.end());
-    for (auto &sl : by_slot) {
-      const int slot = sl.first, l = sl.second;
-      const LmTmp &lm = lms[l];
-      const bool is_const = win.feature_const && win.feature_const[l];
-      lm_info[slot] = lm.start | (lm.m << 8) | ((is_const ? 1 : 0) << 16) | (1 << 24);
-      lm_abi[slot] = l;
-      lam0[slot] = win.para_Feature[l];
-      if (lm.m > 0) {
-        const int k0 = lm.fac[0];
-        lm_pts[0 * TL + slot] = win.vis.pts_i[3 * k0]; lm_pts[1 * TL + slot] = win.vis.pts_i[3 * k0 + 1];
-        lm_pts[2 * TL + slot] = win.vis.pts_i[3 * k0 + 2];
-        lm_pts[3 * TL + slot] = win.vis.vel_i[2 * k0]; lm_pts[4 * TL + slot] = win.vis.vel_i[2 * k0 + 1];
-        lm_pts[5 * TL + slot] = win.vis.td_i[k0];
+  } else {
+    std::atomic<int> bad(-1);
+    host_parallel(c, B, [&](int w) { if (!scan_window(*wins[w], w, scan[w])) { int e = -1; bad.compare_exchange_strong(e, w); } });
+    if (bad.load() >= 0) { c->err = scan[bad.load()].err; return GFBE_BAD_INPUT; }
+  }
+  // ---- serial: offsets of every window in the batch-wide arrays
+  std::vector<WinDesc> desc_tmp(B);   // (only the offset fields are set here; the fill pass completes the descriptors)
+  std::vector<int> tile_start;
+  std::vector<int> feat_off(B + 1, 0);
+  std::vector<long long> j0_off(B + 1, 0);
+  int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0;
+  double algo_bytes = 0.0;
+  for (int w = 0; w < B; w++) {
+    const gfbe_window &win = *wins[w];
+    const WinScan &sc = scan[w];
+    WinDesc &ds = desc_tmp[w];
+    std::memset(&ds, 0, sizeof ds);
+    ds.L = sc.L; ds.K = sc.K; ds.frame_count = win.frame_count;
+    ds.lm_off = tot_lm; ds.lm_slots = sc.slots; ds.n_tiles = sc.n_tiles; ds.tile_off = (int)tile_start.size();
+    ds.rec_off = tot_rec;
+    for (int s = 0; s < NF; s++) for (int t = sc.sf_tile_begin[s]; t < sc.sf_tile_begin[s + 1]; t++) tile_start.push_back(s);
+    if (tabs) tlayout[(size_t)w * FT_LAY_STRIDE] = tot_lm;
+    tot_lm += sc.slots; tot_rec += sc.K; max_tiles = std::max(max_tiles, sc.n_tiles);
+    ds.imu_off = n_imu_tot; ds.wheel_off = n_wheel_tot; ds.lio_off = tot_lio;
+    n_imu_tot += win.n_imu; n_wheel_tot += win.n_wheel; tot_lio += win.lio.n > 0 ? win.lio.n : 0;
+    b->L[w] = sc.L;
+    feat_off[w + 1] = feat_off[w] + sc.L;
+    if (win.prior && win.prior->valid && win.prior->n > 0) {
+      const gfbe_prior &pr = *win.prior;
+      if (pr.n > ND || pr.n_blocks < 0 || pr.n_blocks > GFBE_MAX_PRIOR_BLOCKS || !pr.J0 || !pr.r0) { c->err = "window " + std::to_string(w) + ": prior too large or without J0 / r0"; return GFBE_BAD_INPUT; }
+      bool seen[GFBE_BLK_COUNT];
+      for (int q = 0; q < GFBE_BLK_COUNT; q++) seen[q] = false;
+      int xo = 0;
+      for (int q = 0; q < pr.n_blocks; q++) {
+        const int id = pr.block_id[q];
+        if (id < 0 || id >= GFBE_BLK_COUNT || pr.block_size[q] != blk_gsize(id) || seen[id] || pr.block_idx[q] < 0 || pr.block_idx[q] + blk_lsize(id) > pr.n) {
+          c->err = "window " + std::to_string(w) + ": prior block table inconsistent (id, size, duplicate or offset out of range)"; return GFBE_BAD_INPUT;
+        }
+        seen[id] = true; xo += pr.block_size[q];
       }
-      for (int k = 0; k < lm.m; k++) {
-        const int f = lm.fac[k];
-        double *ob = &lm_obs[(size_t)k * 5 * TL + slot];
-        ob[0] = win.vis.pts_j[3 * f]; ob[TL] = win.vis.pts_j[3 * f + 1];
-        ob[2 * TL] = win.vis.vel_j[2 * f]; ob[3 * TL] = win.vis.vel_j[2 * f + 1]; ob[4 * TL] = win.vis.td_j[f];
-        lm_rec[(size_t)k * TL + slot] = fill[lm.start * NF + lm.start + 1 + k]++;
-      }
+      if (xo > (int)PRIOR_X0) { c->err = "prior x0 too large"; return GFBE_BAD_INPUT; }
+      pn_max = std::max(pn_max, pr.n);
     }
-    algo_bytes += 108.0 * ds.K;   // 12 f64 + 3 i32 per visual residual block, J never re-read by the host
+    const int nb = std::max(prior_out_bound(win, tabs ? nullptr : sc.pair_begin, true), prior_out_bound(win, nullptr, false));
+    j0_off[w + 1] = j0_off[w] + (long long)nb * nb;
+    algo_bytes += 108.0 * sc.K;   // 12 f64 + 3 i32 per visual residual block, J never re-read by the host
+  }
+  d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio;
+  d.rank = c->rank; d.world = c->world;
+  { const char *fe = getenv("GFBE_TEST_FAIL_CHOL_ITER"); d.test_fail_chol_iter = fe ? atoi(fe) : 0; }   // fault injection of the mu-retry path (tests)
+  b->algo_bytes_lin = algo_bytes;
+  const size_t TL = tot_lm;
+  const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
+  const double T1 = now();
+  // ---- allocation sequence (dry pass, then the real one)
+  gfbe_status st;
+  WinDesc *h_desc = nullptr; int *h_lm_info = nullptr, *h_lm_abi = nullptr, *h_tile_start = nullptr, *h_feat_off = nullptr;
+  long long *h_j0_off = nullptr;
+  double *h_lm_pts = nullptr, *h_lam0 = nullptr, *h_fobs = nullptr, *h_x0 = nullptr, *h_lio = nullptr, *h_pr0 = nullptr, *h_px0 = nullptr, *h_pJ0 = nullptr;
+  gfbe_imu_preint *h_imu = nullptr; gfbe_wheel_preint *h_wheel = nullptr;
+  double *d_pJ0c = nullptr;
+  const bool want_rec = c->want_records;
+  for (int pass = 0; pass < 2; pass++) {
+    b->dry = pass == 0;
+    if (pass == 1) {
+      if ((st = slab_acquire(c, b)) != GFBE_OK) return st;
+      b->up_h = pin_acquire(c, b->up_bytes, &b->up_cap);
+      if (!b->up_h) { c->err = "hipHostMalloc(upload staging) failed"; return GFBE_DEVICE_ERROR; }
+    }
+#define UP(field, host, n) if ((st = up_alloc(c, b, &d.field, &host, (size_t)(n))) != GFBE_OK) return st
+#define AL(field, n) if ((st = dev_alloc(c, b, &d.field, (size_t)(n))) != GFBE_OK) return st
+    // -- upload region
+    UP(desc, h_desc, B); UP(tile_start, h_tile_start, tile_start.size()); UP(x0, h_x0, (size_t)B * NA);
+    UP(imu, h_imu, n_imu_tot); UP(wheel, h_wheel, n_wheel_tot); UP(lio, h_lio, (size_t)tot_lio * 8);
+    UP(prior_r0, h_pr0, (size_t)B * ND); UP(prior_x0, h_px0, (size_t)B * PRIOR_X0);
+    UP(dl_feat_off, h_feat_off, B + 1); UP(dl_j0_off, h_j0_off, B + 1);
+    if ((st = up_alloc(c, b, &d_pJ0c, &h_pJ0, (size_t)B * pj_row)) != GFBE_OK) return st;
+    if (!tabs) { UP(lm_info, h_lm_info, TL); UP(lm_abi, h_lm_abi, TL); UP(lm_pts, h_lm_pts, (size_t)6 * TL); UP(lam0, h_lam0, TL); UP(fobs, h_fobs, (size_t)tot_rec * 5); }
+    const size_t up_end = b->dry ? b->slab_bytes : b->slab_off;
+    // -- arrays the kernels expect zeroed at the start (rows past a track's length, partials of absent factors, ...)
+    if (tabs) { AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lam0, TL); d.fobs = nullptr; }
+    AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);
+    AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
+    AL(prior_J0, (size_t)B * ND * ND);
+    AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
+    AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
+    if (B < DENSE_SPLIT_MIN_B && c->world == 1) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
+    AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
+    AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
+    AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
+    AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36); AL(prior_H, (size_t)B * ND * ND);
+    AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
+    AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
+    AL(prior_g, (size_t)B * (ND + 2));
+    AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
+    AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
+    // the partial reduced system [H | g | E | eg | xa] is one slab: a single all-reduce per linearisation when the
+    // landmarks are sharded over ranks
+    {
+      const size_t nH = (size_t)B * ND * ND, ng = (size_t)B * ND, nE = (size_t)B * NV * NV, ne = (size_t)B * NV, nx = (size_t)B * d.world * XCHG;
+      AL(H, nH + ng + nE + ne + nx);
+      if (!b->dry) { d.g = d.H + nH; d.E = d.g + ng; d.eg = d.E + nE; d.xa = d.eg + ne; }
+      b->slab_n = nH + ng + nE + ne + nx;
+    }
+    AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
+    AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
+    AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
+    AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
+    AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);
+    AL(timing, (size_t)B * 32); AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
+    AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));
+    const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
+    // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
+    AL(rec, want_rec ? (size_t)tot_rec * REC : 1); AL(mV, (size_t)B * ND * ND);
+    AL(dl_fix, (size_t)B * DL_FIX); AL(dl_feat, feat_off[B]); AL(dl_J0, (size_t)j0_off[B]);
+    if (!b->dry) { b->up_end = up_end; b->zero_end = zero_end; }
+#undef UP
+#undef AL
+  }
+  // download staging: [dl_fix | dl_feat | dl_J0] are contiguous at the end of the slab -> one device-to-host copy
+  b->dl_bytes = (size_t)((char *)(d.dl_J0 + j0_off[B]) - (char *)d.dl_fix);
+  b->feat_off = feat_off; b->j0_off = j0_off;
+  const double T2 = now();
+  // ---- pass 2 (parallel over windows): fill the pinned mirror of the upload region
+  std::memcpy(h_tile_start, tile_start.data(), sizeof(int) * tile_start.size());
+  std::memcpy(h_feat_off, feat_off.data(), sizeof(int) * (B + 1));
+  std::memcpy(h_j0_off, j0_off.data(), sizeof(long long) * (B + 1));
+  std::atomic<int> bad(-1);
+  std::vector<std::string> errs(B);
+  host_parallel(c, B, [&](int w) {
+    const gfbe_window &win = *wins[w];
+    const WinScan &sc = scan[w];
+    WinDesc &ds = h_desc[w];
+    ds = desc_tmp[w];
+    auto fail = [&](const char *m) { errs[w] = "window " + std::to_string(w) + ": " + m; int e = -1; bad.compare_exchange_strong(e, w); };
+    std::memcpy(ds.sf_tile_begin, sc.sf_tile_begin, sizeof ds.sf_tile_begin);
+    std::memcpy(ds.pair_begin, sc.pair_begin, sizeof ds.pair_begin);
+    double bytes = sizeof(WinDesc) + sizeof(double) * NA;
+    if (!tabs) {
+      // landmark scalars: padding slots first (valid = 0, abi -1, lambda 1), then the landmarks
+      const int o = ds.lm_off;
+      for (int q = 0; q < sc.slots; q++) { h_lm_info[o + q] = 0; h_lm_abi[o + q] = -1; h_lam0[o + q] = 1.0; }
+      for (int r = 0; r < 6; r++) std::memset(h_lm_pts + r * TL + o, 0, sizeof(double) * sc.slots);
+      for (int l = 0; l < sc.L; l++) {
+        const int slot = o + sc.slot_rel[l];
+        const bool is_const = win.feature_const && win.feature_const[l];
+        h_lm_info[slot] = sc.lstart[l] | (sc.lm[l] << 8) | ((is_const ? 1 : 0) << 16) | (1 << 24);
+        h_lm_abi[slot] = l;
+        h_lam0[slot] = win.para_Feature[l];
+      }
+      double *fo = h_fobs + (size_t)ds.rec_off * 5;
+      for (int k = 0; k < sc.K; k++) {
+        const int l = win.vis.feature_index[k], i = win.vis.imu_i[k], j = win.vis.imu_j[k];
+        const int rel = sc.slot_rel[l];
+        const int rec = sc.pair_begin[i * NF + j] + (rel - sc.sf_tile_begin[i] * LM_TILE);
+        double *f = fo + (size_t)rec * 5;
+        f[0] = win.vis.pts_j[3 * k]; f[1] = win.vis.pts_j[3 * k + 1]; f[2] = win.vis.vel_j[2 * k]; f[3] = win.vis.vel_j[2 * k + 1]; f[4] = win.vis.td_j[k];
+        if (j == i + 1) {   // the landmark's first observation travels with its first factor
+          const size_t slot = (size_t)o + rel;
+          h_lm_pts[0 * TL + slot] = win.vis.pts_i[3 * k]; h_lm_pts[1 * TL + slot] = win.vis.pts_i[3 * k + 1]; h_lm_pts[2 * TL + slot] = win.vis.pts_i[3 * k + 2];
+          h_lm_pts[3 * TL + slot] = win.vis.vel_i[2 * k]; h_lm_pts[4 * TL + slot] = win.vis.vel_i[2 * k + 1]; h_lm_pts[5 * TL + slot] = win.vis.td_i[k];
+        }
+      }
+      b->slot_of[w].resize(sc.L);
+      for (int l = 0; l < sc.L; l++) b->slot_of[w][l] = o + sc.slot_rel[l];
+      bytes += (double)sc.slots * (4 + 4 + 8 + 48) + 40.0 * sc.K;
+    }
     // dense state
-    std::memcpy(&x0[(size_t)w * NA], &win.state, sizeof(double) * NA);
+    std::memcpy(h_x0 + (size_t)w * NA, &win.state, sizeof(double) * NA);
     // inertial factors
     for (int q = 0; q < NF; q++) ds.imu_of_frame[q] = ds.wheel_of_frame[q] = -1;
-    ds.n_imu = win.n_imu; ds.imu_off = (int)imu.size();
+    ds.n_imu = win.n_imu;
     for (int k = 0; k < win.n_imu; k++) {
-      if (win.imu_frame[k] < 0 || win.imu_frame[k] >= win.frame_count) { c->err = "bad imu_frame"; return GFBE_BAD_INPUT; }
-      imu.push_back(win.imu[k]); ds.imu_frame[k] = win.imu_frame[k]; ds.imu_of_frame[win.imu_frame[k]] = k;
+      if (win.imu_frame[k] < 0 || win.imu_frame[k] >= win.frame_count) return fail("bad imu_frame");
+      h_imu[ds.imu_off + k] = win.imu[k]; ds.imu_frame[k] = win.imu_frame[k]; ds.imu_of_frame[win.imu_frame[k]] = k;
     }
-    ds.n_wheel = win.n_wheel; ds.wheel_off = (int)wheel.size();
+    ds.n_wheel = win.n_wheel;
     for (int k = 0; k < win.n_wheel; k++) {
-      if (win.wheel_frame[k] < 0 || win.wheel_frame[k] >= win.frame_count) { c->err = "bad wheel_frame"; return GFBE_BAD_INPUT; }
-      wheel.push_back(win.wheel[k]); ds.wheel_frame[k] = win.wheel_frame[k]; ds.wheel_of_frame[win.wheel_frame[k]] = k;
+      if (win.wheel_frame[k] < 0 || win.wheel_frame[k] >= win.frame_count) return fail("bad wheel_frame");
+      h_wheel[ds.wheel_off + k] = win.wheel[k]; ds.wheel_frame[k] = win.wheel_frame[k]; ds.wheel_of_frame[win.wheel_frame[k]] = k;
     }
+    bytes += sizeof(gfbe_imu_preint) * win.n_imu + sizeof(gfbe_wheel_preint) * win.n_wheel;
     // LiDAR factors on one pose
-    ds.lio_n = win.lio.n > 0 ? win.lio.n : 0; ds.lio_off = (int)(lio.size() / 8); ds.lio_frame = win.lio.frame;
+    ds.lio_n = win.lio.n > 0 ? win.lio.n : 0; ds.lio_frame = win.lio.frame;
     ds.lio_sqrt_info = win.lio.sqrt_info; ds.lio_huber = win.lio.huber_delta;
     if (ds.lio_n > 0) {
-      if (win.lio.frame < 0 || win.lio.frame > win.frame_count || !win.lio.pts || !win.lio.normals || !win.lio.offsets) { c->err = "bad lio block"; return GFBE_BAD_INPUT; }
+      if (win.lio.frame < 0 || win.lio.frame > win.frame_count || !win.lio.pts || !win.lio.normals || !win.lio.offsets) return fail("bad lio block");
+      double *lo = h_lio + (size_t)ds.lio_off * 8;
       for (int k = 0; k < ds.lio_n; k++) {
-        for (int q = 0; q < 3; q++) lio.push_back(win.lio.pts[3 * k + q]);
-        for (int q = 0; q < 3; q++) lio.push_back(win.lio.normals[3 * k + q]);
-        lio.push_back(win.lio.offsets[k]);
-        lio.push_back(win.lio.weights ? win.lio.weights[k] : 1.0);
+        for (int q = 0; q < 3; q++) { lo[8 * k + q] = win.lio.pts[3 * k + q]; lo[8 * k + 3 + q] = win.lio.normals[3 * k + q]; }
+        lo[8 * k + 6] = win.lio.offsets[k];
+        lo[8 * k + 7] = win.lio.weights ? win.lio.weights[k] : 1.0;
       }
+      bytes += 64.0 * ds.lio_n;
     }
     // prior
     bool used[GFBE_BLK_COUNT];
     for (int q = 0; q < GFBE_BLK_COUNT; q++) used[q] = false;
     if (ds.lio_n > 0) used[ds.lio_frame] = true;
     for (int q = 0; q < ND; q++) ds.prior_map[q] = -1;
+    std::memset(h_pr0 + (size_t)w * ND, 0, sizeof(double) * ND);
+    std::memset(h_px0 + (size_t)w * PRIOR_X0, 0, sizeof(double) * PRIOR_X0);
+    if (pj_row) std::memset(h_pJ0 + (size_t)w * pj_row, 0, sizeof(double) * pj_row);
     if (win.prior && win.prior->valid && win.prior->n > 0) {
-      const gfbe_prior &pr = *win.prior;
-      if (pr.n > ND || pr.n_blocks > GFBE_MAX_PRIOR_BLOCKS) { c->err = "prior too large"; return GFBE_BAD_INPUT; }
+      const gfbe_prior &pr = *win.prior;   // (validated in the serial pass)
       ds.prior_n = pr.n; ds.prior_nblk = pr.n_blocks;
       int xo = 0;
       for (int q = 0; q < pr.n_blocks; q++) {
         const int id = pr.block_id[q];
-        if (id < 0 || id >= GFBE_BLK_COUNT || pr.block_size[q] != blk_gsize(id)) { c->err = "prior block table inconsistent"; return GFBE_BAD_INPUT; }
         ds.prior_blk_id[q] = id; ds.prior_blk_size[q] = pr.block_size[q]; ds.prior_blk_idx[q] = pr.block_idx[q];
         ds.prior_x0_off[q] = xo; xo += pr.block_size[q];
         used[id] = true;
         for (int k = 0; k < blk_lsize(id); k++) ds.prior_map[blk_tan(id) + k] = pr.block_idx[q] + k;
       }
-      std::memcpy(&px0[(size_t)w * PRIOR_X0], pr.x0, sizeof(double) * xo);
-      std::memcpy(&pJ0[(size_t)w * pj_row], pr.J0, sizeof(double) * pr.n * pr.n);
-      std::memcpy(&pr0[(size_t)w * ND], pr.r0, sizeof(double) * pr.n);
+      std::memcpy(h_px0 + (size_t)w * PRIOR_X0, pr.x0, sizeof(double) * xo);
+      std::memcpy(h_pJ0 + (size_t)w * pj_row, pr.J0, sizeof(double) * pr.n * pr.n);
+      std::memcpy(h_pr0 + (size_t)w * ND, pr.r0, sizeof(double) * pr.n);
+      bytes += 8.0 * ((double)pr.n * pr.n + pr.n + xo);
     }
     // reduced program: blocks touched by a residual and not constant (Ceres drops the rest)
     for (int k = 0; k < win.n_imu; k++) { const int i = win.imu_frame[k]; used[i] = used[GFBE_BLK_SB0 + i] = used[i + 1] = used[GFBE_BLK_SB0 + i + 1] = true; }
@@ -572,7 +855,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       const int i = win.wheel_frame[k];
       used[i] = used[i + 1] = used[GFBE_BLK_EX_WHEEL] = used[GFBE_BLK_SX] = used[GFBE_BLK_SY] = used[GFBE_BLK_SW] = used[GFBE_BLK_TD_WHEEL] = true;
     }
-    for (int p = 0; p < NPAIR; p++) if (pair_cnt[p] > 0) { used[p / NF] = used[p % NF] = used[GFBE_BLK_EX_CAM] = used[GFBE_BLK_TD] = true; }
+    for (int p = 0; p < NPAIR; p++) if (sc.pair_begin[p + 1] > sc.pair_begin[p]) { used[p / NF] = used[p % NF] = used[GFBE_BLK_EX_CAM] = used[GFBE_BLK_TD] = true; }
     for (int q = 0; q < GFBE_BLK_COUNT; q++) {
       bool cst;
       if (q < GFBE_BLK_SB0) cst = win.pose_const[q] || q > win.frame_count;
@@ -587,74 +870,32 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     }
     std::memcpy(ds.ex_cam_mask, win.ex_cam_mask, 6);
     std::memcpy(ds.ex_wheel_mask, win.ex_wheel_mask, 6);
-  }
-  b->algo_bytes_lin = algo_bytes;
-  gfbe_status st;
-  const double T1 = now();
-  d.rank = c->rank; d.world = c->world;
-  for (int pass = 0; pass < 2; pass++) {
-  b->dry = pass == 0;
-  if (pass == 1 && (st = slab_acquire(c, b)) != GFBE_OK) return st;
-#define UP(field, vec) if ((st = dev_upload(c, b, &d.field, vec)) != GFBE_OK) return st
-#define AL(field, n) if ((st = dev_alloc(c, b, &d.field, (size_t)(n))) != GFBE_OK) return st
-  UP(desc, desc);
-  if (tabs) {
-    AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL); AL(lam0, TL);
-  } else {
-    UP(lm_info, lm_info); UP(lm_abi, lm_abi); UP(lm_pts, lm_pts); UP(lm_obs, lm_obs); UP(lm_rec, lm_rec); UP(lam0, lam0);
-  }
-  UP(x0, x0); UP(tile_start, tile_start); UP(imu, imu); UP(wheel, wheel);
-  d.tot_lio = (int)(lio.size() / 8);
-  UP(lio, lio); AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
-  AL(prior_J0, (size_t)B * ND * ND); UP(prior_r0, pr0); UP(prior_x0, px0);
-  if (!b->dry && pj_row > 0)
-    HIPCHK(c, hipMemcpy2DAsync(d.prior_J0, sizeof(double) * ND * ND, pJ0.data(), sizeof(double) * pj_row, sizeof(double) * pj_row, B, hipMemcpyHostToDevice, c->stream));
-  AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
-  AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
-  if (B < DENSE_SPLIT_MIN_B && c->world == 1) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr; AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2)); AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
-  AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
-  AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
-  AL(rec, (size_t)tot_rec * REC);
-  AL(imu_sqrt, imu.size() * 225); AL(wheel_sqrt, wheel.size() * 36); AL(prior_H, (size_t)B * ND * ND);
-  AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
-  AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
-  AL(prior_g, (size_t)B * (ND + 2));
-  AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
-  AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
-  // the partial reduced system [H | g | E | eg | xa] is one slab: a single all-reduce per linearisation when the
-  // landmarks are sharded over ranks
-  {
-    const size_t nH = (size_t)B * ND * ND, ng = (size_t)B * ND, nE = (size_t)B * NV * NV, ne = (size_t)B * NV, nx = (size_t)B * d.world * XCHG;
-    AL(H, nH + ng + nE + ne + nx);
-    if (!b->dry) { d.g = d.H + nH; d.E = d.g + ng; d.eg = d.E + nE; d.xa = d.eg + ne; }
-    b->slab_n = nH + ng + nE + ne + nx;
-  }
-  AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
-  AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
-  AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
-  AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
-  AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND); AL(mV, (size_t)B * ND * ND);
-  AL(timing, (size_t)B * 32); AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
-#undef UP
-#undef AL
-  }
-  if (tabs) {   // landmark arrays straight from the device-resident tables; the slot of every landmark comes back for the download
-    // (layout table and slot map live in the tables' own scratch: no allocation on this path)
-    int *dlay = tabs->d.layout + (size_t)tab0 * FT_LAY_STRIDE, *dslot = tabs->d.ids_scratch + (size_t)tab0 * tabs->d.F;
-    HIPCHK(c, hipMemcpyAsync(dlay, tlayout.data(), sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, c->stream));
-    launch_ftab_pack(tabs->d, tabs->cur, tab0, B, d, dlay, dslot, c->stream);
-    for (int w = 0; w < B; w++) {
-      b->slot_of[w].resize(b->L[w]);
-      if (b->L[w] > 0) HIPCHK(c, hipMemcpyAsync(b->slot_of[w].data(), dslot + (size_t)w * tabs->d.F, sizeof(int) * b->L[w], hipMemcpyDeviceToHost, c->stream));
-    }
-  }
-  const double T2 = now();
-  if (dbg_t) (void)hipStreamSynchronize(c->stream);
+    b->up_win_bytes[w] = bytes;
+  });
+  if (bad.load() >= 0) { c->err = errs[bad.load()]; return GFBE_BAD_INPUT; }
   const double T3 = now();
-  { Timed t(c, "k_prep", 0); launch_prep(d, c->stream); launch_asm_table(d, c->stream); }
+  // ---- enqueue: clear what must start as zero, ONE host-to-device copy, then the preparation kernels
+  if (b->zero_end > b->up_end) HIPCHK(c, hipMemsetAsync(b->slab + b->up_end, 0, b->zero_end - b->up_end, us));
+  HIPCHK(c, hipMemcpyAsync(b->slab, b->up_h, b->up_end, hipMemcpyHostToDevice, us));
+  if (pj_row > 0)
+    HIPCHK(c, hipMemcpy2DAsync(d.prior_J0, sizeof(double) * ND * ND, d_pJ0c, sizeof(double) * pj_row, sizeof(double) * pj_row, B, hipMemcpyDeviceToDevice, us));
+  if (tabs) {   // landmark arrays straight from the device-resident tables (layout table and slot map live in the tables' own scratch)
+    int *dlay = tabs->d.layout + (size_t)tab0 * FT_LAY_STRIDE, *dslot = tabs->d.ids_scratch + (size_t)tab0 * tabs->d.F;
+    HIPCHK(c, hipMemcpyAsync(dlay, tlayout.data(), sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, us));
+    launch_ftab_pack(tabs->d, tabs->cur, tab0, B, d, dlay, dslot, us);
+    HIPCHK(c, hipStreamSynchronize(us));   // tlayout dies here
+  } else {
+    launch_expand(d, us);
+  }
+  launch_prep(d, us);
+  launch_asm_table(d, us);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipStreamSynchronize(c->stream));   // host staging vectors die here
-  if (dbg_t) fprintf(stderr, "upload: host pack %.3f ms, slab+copies enqueue %.3f ms, drain %.3f ms, k_prep+table %.3f ms (slab %.1f MB)\n", T1 - T0, T2 - T1, T3 - T2, now() - T3, b->slab_bytes / 1048576.0);
+  HIPCHK(c, hipEventRecord(b->ev_up, us));
+  if (dbg_t) {
+    (void)hipStreamSynchronize(us);
+    fprintf(stderr, "upload: scan %.3f ms, layout + staging %.3f ms, fill %.3f ms, copy + prep %.3f ms (slab %.1f MB, upload %.2f MB, cleared %.1f MB)\n",
+            T1 - T0, T2 - T1, T3 - T2, now() - T3, b->slab_bytes / 1048576.0, b->up_end / 1048576.0, (b->zero_end - b->up_end) / 1048576.0);
+  }
   return GFBE_OK;
 }
 
@@ -729,7 +970,8 @@ extern "C" int32_t gfbe_batch_feature_count(const gfbe_batch *b, int32_t w) {
 
 extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
   if (!b) return;
-  if (c && c->stream) (void)hipStreamSynchronize(c->stream);
+  // wait for THIS batch's work only (upload, last solve, download): other batches of the context keep running
+  for (hipEvent_t e : {b->ev_up, b->ev_done, b->ev_dl}) if (e) (void)hipEventSynchronize(e);
   if (b->second) {
     if (b->lane2.s) (void)hipStreamSynchronize(b->lane2.s);
     gfbe_batch_free(c, b->second);
@@ -738,7 +980,10 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
     for (hipEvent_t e : {b->lane2.fork, b->lane2.join, b->ev_start2, b->ev_done2}) if (e) (void)hipEventDestroy(e);
   }
   for (auto &g : b->graph) if (g) (void)hipGraphExecDestroy(g);
+  for (hipEvent_t e : {b->ev_up, b->ev_done, b->ev_dl}) if (e) (void)hipEventDestroy(e);
   slab_release(c, b);
+  if (c) { pin_release(c, b->up_h, b->up_cap); pin_release(c, b->dl_h, b->dl_cap); }
+  else { if (b->up_h) (void)hipHostFree(b->up_h); if (b->dl_h) (void)hipHostFree(b->dl_h); }
   delete b;
 }
 
@@ -834,6 +1079,10 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
   // (not for split batches: capturing the cross-stream fork / join of the parts crashed the runtime on ROCm 7.2)
   const bool graphable = c->opt.use_graph && !c->profiling && d.world == 1 && !b->second;
   const Lane lane1 = {c->stream, c->aux, c->ev_fork, c->ev_join};
+  // the uploads ran on the copy stream: the solve starts when they have landed
+  for (gfbe_batch *p = b; p; p = p->second) { HIPCHK(c, hipStreamWaitEvent(c->stream, p->ev_up, 0)); p->last_flag = margin_flag; p->fetched = false; }
+  // (ev_done of every part is recorded on the caller's stream after the parts have joined it)
+  auto mark_done = [&]() -> gfbe_status { for (gfbe_batch *p = b; p; p = p->second) HIPCHK(c, hipEventRecord(p->ev_done, c->stream)); return GFBE_OK; };
   // every part but the first on its own streams beside the first, joined back into the caller's stream
   auto enqueue_all = [&]() -> gfbe_status {
     gfbe_status st = GFBE_OK;
@@ -853,7 +1102,7 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
   };
   if (graphable && b->graph[margin_flag]) {
     HIPCHK(c, hipGraphLaunch(b->graph[margin_flag], c->stream));
-    return GFBE_OK;
+    return mark_done();
   }
   if (graphable && b->calls[margin_flag]++ >= 1) {   // the first call ran eagerly (one-time attribute setup); capture now
     hipGraph_t g = nullptr;
@@ -863,7 +1112,7 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
       if (e == hipSuccess && g && hipGraphInstantiate(&b->graph[margin_flag], g, nullptr, nullptr, 0) == hipSuccess) {
         (void)hipGraphDestroy(g);
         HIPCHK(c, hipGraphLaunch(b->graph[margin_flag], c->stream));
-        return GFBE_OK;
+        return mark_done();
       }
       if (g) (void)hipGraphDestroy(g);
       b->graph[margin_flag] = nullptr;
@@ -874,48 +1123,62 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
   const gfbe_status st = enqueue_all();
   if (st != GFBE_OK) return st;
   HIPCHK(c, hipGetLastError());
-  return GFBE_OK;
+  return mark_done();
 }
 
+// Results of one part: the gather kernel and ONE device-to-host copy on the download stream (beside whatever the main stream
+// is solving), then the host scatter into the caller's structures on the packing threads.
+static gfbe_status fetch_one(gfbe_ctx *c, gfbe_batch *b) {
+  if (b->fetched) return GFBE_OK;
+  const BatchDev &d = b->d;
+  if (!b->dl_h) {
+    b->dl_h = pin_acquire(c, b->dl_bytes, &b->dl_cap);
+    if (!b->dl_h) { c->err = "hipHostMalloc(download staging) failed"; return GFBE_DEVICE_ERROR; }
+  }
+  HIPCHK(c, hipStreamWaitEvent(c->dl, b->ev_up, 0));
+  HIPCHK(c, hipStreamWaitEvent(c->dl, b->ev_done, 0));
+  launch_gather(d, b->last_flag, c->dl);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(b->dl_h, d.dl_fix, b->dl_bytes, hipMemcpyDeviceToHost, c->dl));
+  HIPCHK(c, hipEventRecord(b->ev_dl, c->dl));
+  return GFBE_OK;
+}
 static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_state, double *const *out_feature,
                                 gfbe_prior *const *prior_out, gfbe_summary *summary) {
-  if (!c || !b) return GFBE_BAD_INPUT;
   const BatchDev &d = b->d;
   const int B = d.B;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  std::vector<WinCtl> ctl(B);
-  HIPCHK(c, hipMemcpy(ctl.data(), d.ctl, sizeof(WinCtl) * B, hipMemcpyDeviceToHost));
-  if (out_state) HIPCHK(c, hipMemcpy(out_state, d.xout, sizeof(double) * NA * B, hipMemcpyDeviceToHost));
-  if (out_feature) {
-    std::vector<double> lam(2 * (size_t)d.tot_lm);
-    HIPCHK(c, hipMemcpy(lam.data(), d.lam, sizeof(double) * lam.size(), hipMemcpyDeviceToHost));
-    for (int w = 0; w < B; w++) {
-      if (!out_feature[w]) continue;
-      for (int l = 0; l < b->L[w]; l++) out_feature[w][l] = lam[(size_t)ctl[w].cur * d.tot_lm + b->slot_of[w][l]];
-    }
-  }
-  if (prior_out) {
-    std::vector<int> meta((size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS));
-    HIPCHK(c, hipMemcpy(meta.data(), d.mmeta, sizeof(int) * meta.size(), hipMemcpyDeviceToHost));
-    for (int w = 0; w < B; w++) {
+  HIPCHK(c, hipEventSynchronize(b->ev_dl));
+  b->fetched = true;
+  const double *fix = (const double *)b->dl_h;
+  const double *feat = fix + (size_t)B * DL_FIX;
+  const double *J0s = feat + b->feat_off[B];
+  std::vector<int> status(B);
+  host_parallel(c, B, [&](int w) {
+    const double *f = fix + (size_t)w * DL_FIX;
+    WinCtl k;
+    std::memcpy(&k, f, sizeof k);
+    status[w] = k.status;
+    const int *m = (const int *)(f + DL_OFF_META);
+    double dl_bytes = 8.0 * DL_FIX + 8.0 * b->L[w];
+    if (out_state) std::memcpy(out_state + w, f + DL_OFF_X, sizeof(double) * NA);
+    if (out_feature && out_feature[w] && b->L[w] > 0) std::memcpy(out_feature[w], feat + b->feat_off[w], sizeof(double) * b->L[w]);
+    // the prior is only touched when a marginalisation ran for this window (estimator.cpp:3391: a window that is still filling
+    // up, or MARGIN_NONE, leaves last_marginalization_info as it is)
+    if (prior_out && prior_out[w] && b->last_flag != GFBE_MARGIN_NONE && k.marg_ran) {
       gfbe_prior *p = prior_out[w];
-      if (!p) continue;
-      const int *m = &meta[(size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)];
-      p->valid = m[0]; p->n = m[1]; p->n_blocks = m[2];
-      if (!p->valid) continue;
-      int xo = 0;
-      for (int q = 0; q < p->n_blocks; q++) {
-        p->block_id[q] = m[4 + q]; p->block_size[q] = m[4 + GFBE_MAX_PRIOR_BLOCKS + q]; p->block_idx[q] = m[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q];
-        xo += p->block_size[q];
+      p->valid = m[0] == 1 ? 1 : 0; p->n = m[1]; p->n_blocks = m[2];
+      if (p->valid) {
+        int xo = 0;
+        for (int q = 0; q < p->n_blocks; q++) {
+          p->block_id[q] = m[4 + q]; p->block_size[q] = m[4 + GFBE_MAX_PRIOR_BLOCKS + q]; p->block_idx[q] = m[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q];
+          xo += p->block_size[q];
+        }
+        std::memcpy(p->x0, f + DL_OFF_X0, sizeof(double) * xo);
+        std::memcpy(p->J0, J0s + b->j0_off[w], sizeof(double) * p->n * p->n);
+        std::memcpy(p->r0, f + DL_OFF_R0, sizeof(double) * p->n);
+        dl_bytes += 8.0 * p->n * p->n;
       }
-      HIPCHK(c, hipMemcpy(p->x0, d.mx0 + (size_t)w * PRIOR_X0, sizeof(double) * xo, hipMemcpyDeviceToHost));
-      HIPCHK(c, hipMemcpy(p->J0, d.mJ0 + (size_t)w * ND * ND, sizeof(double) * p->n * p->n, hipMemcpyDeviceToHost));
-      HIPCHK(c, hipMemcpy(p->r0, d.mr0 + (size_t)w * ND, sizeof(double) * p->n, hipMemcpyDeviceToHost));
     }
-  }
-  gfbe_status worst = GFBE_OK;
-  for (int w = 0; w < B; w++) {
-    const WinCtl &k = ctl[w];
     if (summary) {
       gfbe_summary &s = summary[w];
       std::memset(&s, 0, sizeof s);
@@ -923,9 +1186,17 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
       s.initial_cost = k.initial_cost; s.final_cost = k.cost; s.final_radius = k.radius;
       std::memcpy(s.cost_history, k.cost_history, sizeof s.cost_history);
       std::memcpy(s.accepted, k.accepted, sizeof s.accepted);
+      s.ms_solve = k.t_solved > k.t_start ? (double)(k.t_solved - k.t_start) * 1e-5 : 0.0;     // 100 MHz ticks
+      s.ms_marginalize = k.t_marg > k.t_solved ? (double)(k.t_marg - k.t_solved) * 1e-5 : 0.0;
+      s.bytes_uploaded = b->up_win_bytes[w]; s.bytes_downloaded = dl_bytes;
     }
-    if (k.status == GFBE_NUMERICAL_FAILURE) worst = GFBE_NUMERICAL_FAILURE;
-    else if (k.status == GFBE_NO_CONVERGENCE && worst == GFBE_OK) worst = GFBE_NO_CONVERGENCE;
+  });
+  gfbe_status worst = GFBE_OK;
+  for (int w = 0; w < B; w++) {
+    const int m0 = ((const int *)(fix + (size_t)w * DL_FIX + DL_OFF_META))[0];
+    if (m0 == -2) { c->err = "new prior larger than its download slot"; return GFBE_DEVICE_ERROR; }
+    if (status[w] == GFBE_NUMERICAL_FAILURE) worst = GFBE_NUMERICAL_FAILURE;
+    else if (status[w] == GFBE_NO_CONVERGENCE && worst == GFBE_OK) worst = GFBE_NO_CONVERGENCE;
   }
   if (worst == GFBE_NUMERICAL_FAILURE) c->err = "linear solve failed for every mu < 1 in at least one window";
   return worst;
@@ -934,6 +1205,9 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
 extern "C" gfbe_status gfbe_batch_download(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_state, double *const *out_feature,
                                           gfbe_prior *const *prior_out, gfbe_summary *summary) {
   if (!c || !b) return GFBE_BAD_INPUT;
+  if (c->device < 0) return GFBE_NO_DEVICE;
+  // all parts' gathers and copies are enqueued first, then unpacked part by part
+  for (gfbe_batch *p = b; p; p = p->second) { const gfbe_status st = fetch_one(c, p); if (st != GFBE_OK) return st; }
   gfbe_status worst = GFBE_OK;
   int done = 0;
   for (gfbe_batch *p = b; p; p = p->second) {
@@ -977,10 +1251,13 @@ extern "C" gfbe_status gfbe_eval_factors(gfbe_ctx *c, const gfbe_window *win, in
   const gfbe_window *wins[1] = {win};
   const gfbe_options keep = c->opt;
   if (!robustify) c->opt.huber_delta = 1e150;   // rho(s) = s everywhere: the corrector becomes the identity
+  c->want_records = true;
   gfbe_status st = gfbe_batch_upload(c, 1, wins, &b);
+  c->want_records = false;
   c->opt = keep;
   if (st != GFBE_OK) { gfbe_batch_free(c, b); return st; }
   BatchDev &d = b->d;
+  HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_up, 0));
   launch_reset(d, c->stream);
   launch_vis(d, 0, c->stream, /*write_records=*/1);
   launch_dense_factors(d, 0, 1, c->stream);

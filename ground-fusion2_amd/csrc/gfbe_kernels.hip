@@ -27,6 +27,9 @@ namespace gfd {
 #ifndef GFBE_ABLATE
 #define GFBE_ABLATE 0   // timing ablations of k_vis (tests/diag_ablate.sh); 0 in every shipped build
 #endif
+#ifndef GFBE_KVIS_EARLY
+#define GFBE_KVIS_EARLY 1   // k_vis: the prefetched observation of the next step is waited for BEFORE this step's stores are issued
+#endif
 #define GF_MIN_DIAG 1e-6
 #define GF_MAX_DIAG 1e32
 #define GF_MIN_MU 1e-8
@@ -136,6 +139,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
       c.G2 = c.N2 = c.gy = c.vHv = c.vHy = c.yHy = c.alpha = c.grad_max = 0;
       c.c1 = c.c2 = c.step_norm = c.model_change = 0; c.initial_cost = 0;
       for (int i = 0; i < 16; i++) { c.cost_history[i] = 0; c.accepted[i] = 0; }
+      c.t_start = (long long)wall_clock64(); c.t_solved = 0; c.t_marg = 0; c.marg_ran = 0; c.pad1 = 0;
       d.ctl[w] = c;
     }
   }
@@ -203,7 +207,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
   }
   for (int k = 0; k < mmax; k++) {
-    double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2];
+    double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2], hp[6];
     const double pjx = nob[0], pjy = nob[1], vjx = nob[2], vjy = nob[3], tdj = nob[4];
     if (k + 1 < mmax) {
       const double *ob = d.lm_obs + (size_t)(k + 1) * 5 * TL + slot;
@@ -245,7 +249,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
         for (int q = 0; q < 6; q++) {
           hC[q] += Ji[q] * w0 + Ji[6 + q] * w1;
           hC[6 + q] += Je[q] * w0 + Je[6 + q] * w1;
-          if (GFBE_ABLATE != 3 || w0 == 1.2345) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = Jj[q] * w0 + Jj[6 + q] * w1;
+          hp[q] = Jj[q] * w0 + Jj[6 + q] * w1;
         }
         hC[12] += Jt[0] * w0 + Jt[1] * w1;
       }
@@ -253,6 +257,20 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
       for (int q = 0; q < 12; q++) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
       Jt[0] = Jt[1] = 0.0; r[0] = r[1] = 0.0;
+    }
+    if (MODE != 1) {
+#if GFBE_KVIS_EARLY
+      // vmcnt counts loads and stores in one queue: if the next step's observation (loaded at the top of this step) were first
+      // touched at the loop's back edge, the wave would sit there until this step's partial-sum stores have been acknowledged.
+      // Touching it here — after ~2000 cycles of evaluation, before any store of this step, on a path every lane takes —
+      // costs nothing and leaves the stores to drain behind the matrix-core phase.
+#pragma unroll
+      for (int q = 0; q < 5; q++) asm volatile("" : "+v"(nob[q]));
+#endif
+      if (k < m && (GFBE_ABLATE != 3 || hp[0] == 1.2345)) {   // the landmark's H_pl block of observing pose s + 1 + k
+#pragma unroll
+        for (int q = 0; q < 6; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = hp[q];
+      }
     }
     if (MODE != 1 && GFBE_ABLATE != 1) {
       // X^T X of the step's 128 x 20 panel X = [J(pose_i pose_j ex td) | r] on the FP64 matrix cores (the
@@ -1434,6 +1452,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
       if (P == 0) STAMP(19);
     }
     bool ok = (flag == 0);
+    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid) ok = false;   // fault injection: first attempt of that iteration
     STAMP(3);
     if (ok) {
       // z = L^-1 rhs sits in row n of L. Backward substitution y = L^-T z by ONE wave without block barriers (two
@@ -1687,6 +1706,8 @@ __global__ __launch_bounds__(64) void k_step(BatchDev d) {
   c.have_step = 0;
   // TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue
   const int max_it = min(d.opt.max_num_iterations, 15);
+  // Solver::Options::max_solver_time_in_seconds (estimator.cpp:3369-3376), against the device's 100 MHz wall clock
+  if (d.opt.max_solver_time_in_seconds > 0.0 && (double)((long long)wall_clock64() - c.t_start) * 1e-8 >= d.opt.max_solver_time_in_seconds) { c.done = 1; c.termination = 0; return; }
   if (c.iter >= max_it) { c.done = 1; c.termination = 0; return; }
   if (c.grad_max <= d.opt.gradient_tolerance) { c.done = 1; c.termination = 3; c.status = GFBE_OK; return; }
   if (c.radius < 1e-32) { c.done = 1; c.termination = 4; return; }
@@ -1839,7 +1860,8 @@ __global__ __launch_bounds__(64) void k_accept(BatchDev d) {
 // =============================================================================================
 __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
   const int w = blockIdx.x;
-  const WinCtl &c = d.ctl[w];
+  WinCtl &c = d.ctl[w];
+  if (threadIdx.x == 0) c.t_solved = (long long)wall_clock64();
   const double *X0 = d.x0 + (size_t)w * NA;
   const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
   double *Y = d.xout + (size_t)w * NA;
@@ -1870,10 +1892,87 @@ __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
 }
 
 // =============================================================================================
+// k_expand (host upload): the factors cross PCIe compactly — fobs[record][5], pair-major record order — and are scattered
+// here into the ELL rows lm_obs[k][.][slot] the evaluation kernels read; lm_rec[k][slot] is the record position itself:
+// inside a start-frame group the landmarks are sorted longest track first, so the factors of pair (s, s+1+k) are a prefix
+// of the group and the record of (slot, k) is pair_begin + position in the group.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_expand(BatchDev d) {
+  const int w = blockIdx.y;
+  const WinDesc &ds = d.desc[w];
+  const int rel = blockIdx.x * 256 + threadIdx.x;
+  if (rel >= ds.lm_slots) return;
+  const int slot = ds.lm_off + rel;
+  const int info = d.lm_info[slot];
+  if (!((info >> 24) & 1)) return;
+  const int s = info & 0xff, m = (info >> 8) & 0xff;
+  const int pos = rel - ds.sf_tile_begin[s] * LM_TILE;
+  const size_t TL = d.tot_lm;
+  for (int k = 0; k < m; k++) {
+    const int rec = ds.pair_begin[s * NF + s + 1 + k] + pos;
+    d.lm_rec[(size_t)k * TL + slot] = rec;
+    const double *f = d.fobs + ((size_t)ds.rec_off + rec) * 5;
+    double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
+#pragma unroll
+    for (int q = 0; q < 5; q++) ob[q * TL] = f[q];
+  }
+}
+
+// =============================================================================================
+// k_gather: everything gfbe_batch_download hands back, packed for ONE device-to-host copy:
+// WinCtl | re-anchored state | new prior's block table, x0, r0 per window at a fixed stride; para_Feature in ABI order
+// (scatter through lm_abi); the new prior's J0 (n x n) at host-known offsets.
+// =============================================================================================
+enum { GATHER_WGS = 8 };
+__global__ __launch_bounds__(256) void k_gather(BatchDev d, int margin_flag) {
+  const int w = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x, nt = GATHER_WGS * 256;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  double *fix = d.dl_fix + (size_t)w * DL_FIX;
+  const int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
+  const bool marg = margin_flag != GFBE_MARGIN_NONE && c.marg_ran;
+  {
+    const double *src = (const double *)&c;
+    for (int q = t; q < (int)(sizeof(WinCtl) / 8); q += nt) fix[q] = src[q];
+    for (int q = t; q < NA; q += nt) fix[DL_OFF_X + q] = d.xout[(size_t)w * NA + q];
+    int *mi = (int *)(fix + DL_OFF_META);
+    for (int q = t; q < 4 + 3 * GFBE_MAX_PRIOR_BLOCKS; q += nt) mi[q] = marg ? meta[q] : 0;
+    if (marg && meta[0] == 1) {
+      for (int q = t; q < PRIOR_X0; q += nt) fix[DL_OFF_X0 + q] = d.mx0[(size_t)w * PRIOR_X0 + q];
+      for (int q = t; q < meta[1]; q += nt) fix[DL_OFF_R0 + q] = d.mr0[(size_t)w * ND + q];
+    }
+  }
+  {
+    const size_t TL = d.tot_lm;
+    double *feat = d.dl_feat + d.dl_feat_off[w];
+    for (int q = t; q < ds.lm_slots; q += nt) {
+      const int slot = ds.lm_off + q, abi = d.lm_abi[slot];
+      if (abi >= 0) feat[abi] = d.lam[(size_t)c.cur * TL + slot];
+    }
+  }
+  if (marg && meta[0] == 1) {
+    const long long n2 = (long long)meta[1] * meta[1], cap = d.dl_j0_off[w + 1] - d.dl_j0_off[w];
+    if (n2 <= cap) {
+      const double *J = d.mJ0 + (size_t)w * ND * ND;
+      double *o = d.dl_J0 + d.dl_j0_off[w];
+      for (long long q = t; q < n2; q += nt) o[q] = J[q];
+    } else if (t == 0) {
+      ((int *)(fix + DL_OFF_META))[0] = -2;   // (never: the host's bound of n comes from the same block tables)
+    }
+  }
+}
+
+// =============================================================================================
 // launchers
 // =============================================================================================
 static size_t solve_smem_bytes() { const int nt = (ND + 1 + TB - 1) / TB; return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
 
+void launch_expand(const BatchDev &d, hipStream_t s) {
+  if (d.max_tiles > 0) hipLaunchKernelGGL(k_expand, dim3((d.max_tiles * LM_TILE + 255) / 256, d.B), dim3(256), 0, s, d);
+}
+void launch_gather(const BatchDev &d, int margin_flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather, dim3(GATHER_WGS, d.B), dim3(256), 0, s, d, margin_flag);
+}
 void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B, 1 + PREP_PRIOR_WGS), dim3(256), 0, s, d); }
 void launch_reset(const BatchDev &d, hipStream_t s) {
   const int slots = d.max_tiles * LM_TILE;
@@ -1922,12 +2021,12 @@ void launch_visblock(const BatchDev &d, hipStream_t s) {
 void launch_assemble(const BatchDev &d, hipStream_t s) {
   hipLaunchKernelGGL(k_assemble, dim3(ASM_WGS, d.B), dim3(ASM_THREADS), 0, s, d);
 }
+// Per-DEVICE kernel attributes (dynamic LDS above the 64 KB default): set by gfbe_create for the context's device, so that
+// contexts on several GPUs of one process all get them (a process-wide "done" flag would cover the first device only).
+hipError_t kernels_init_device() {
+  return hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem_bytes());
+}
 void launch_solve(const BatchDev &d, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem_bytes());
-    attr_set = true;
-  }
   hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d);
 }
 void launch_lm_step(const BatchDev &d, hipStream_t s) {

@@ -195,6 +195,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   double *J0 = d.mJ0 + (size_t)w * ND * ND;
   double *r0 = d.mr0 + (size_t)w * ND;
   const bool old = (flag == GFBE_MARGIN_OLD);
+  // estimator.cpp:3391 `if (frame_count < WINDOW_SIZE) return;` — a window that is still filling up is not marginalised and its
+  // caller's prior stays as it is (marg_ran = 0: gfbe_batch_download leaves prior_out untouched)
+  if (ds.frame_count < GFBE_WINDOW_SIZE) return;
+  if (t == 0) { d.ctl[w].marg_ran = 1; }
   double *stamp = d.timing + 24;
 #define MSTAMP(i) do { if (w == 0 && t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   MSTAMP(0);
@@ -241,6 +245,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     if (t == 0) {
       meta[0] = n > 0 ? 1 : 0; meta[1] = n; meta[2] = ds.prior_nblk; meta[3] = 1;
       for (int q = 0; q < ds.prior_nblk; q++) { meta[4 + q] = ds.prior_blk_id[q]; meta[4 + GFBE_MAX_PRIOR_BLOCKS + q] = ds.prior_blk_size[q]; meta[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q] = ds.prior_blk_idx[q]; }
+      d.ctl[w].t_marg = (long long)wall_clock64();
     }
     return;
   }
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
       for (int k = 0; k < blk_gsize(id); k++) d.mx0[(size_t)w * PRIOR_X0 + xo + k] = Xo[blk_amb(id) + k];
       idx += blk_lsize(id); xo += blk_gsize(id);
     }
+    d.ctl[w].t_marg = (long long)wall_clock64();
   }
 }
 
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   int rank;
   if (n <= 4 * 22) rank = ldlt_registers<4>(A, bv, J0, r0, n, d.opt.marg_eps);
   else rank = ldlt_registers<8>(A, bv, J0, r0, n, d.opt.marg_eps);
-  if (threadIdx.x == 0) { meta[3] = -rank; if (w == 0) stamp[6] = (double)wall_clock64(); }
+  if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
 }
 
 // MARGIN_OLD: the partials of the marginalisation set at the re-anchored state (visual factors of the landmarks
@@ -578,10 +584,11 @@ void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {
   else launch_dense_factors(d, 3, 0, s);
   launch_marginalize_finish(d, flag, s);
 }
+hipError_t marg_init_device() {   // per device, from gfbe_create (see kernels_init_device)
+  return hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N));
+}
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s) {
-  static bool attr_set = false;
   const size_t lds = sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
   hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(MARG_THREADS), lds, s, d, flag);
   if (d.opt.marg_sqrt == 1) hipLaunchKernelGGL(k_marg_ldlt, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
 }

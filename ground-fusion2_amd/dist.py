@@ -89,3 +89,60 @@ def torch_allreduce_hook(group=None):
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
                 t.copy_(h)
     return hook
+
+
+class RcclHook:
+    """libgfbe_rccl.so (include/gfbe_rccl.h): an ncclAllReduce on the solver's own stream, no interpreter on the path.
+    The 128-byte unique id travels from rank 0 over the caller's torch.distributed group (one broadcast at start-up)."""
+
+    def __init__(self, rank, world, device, group=None):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import backend
+        self.lib = C.CDLL(backend._RCCL_SO)          # (after `import torch`: its librccl.so.1 is the one already loaded)
+        self.lib.gfbe_rccl_unique_id.restype = C.c_int32
+        self.lib.gfbe_rccl_create.restype = C.c_int32
+        self.lib.gfbe_rccl_last_error.restype = C.c_int32
+        self.lib.gfbe_rccl_calls.restype = C.c_int64
+        idbuf = C.create_string_buffer(128)
+        if rank == 0:
+            rc = self.lib.gfbe_rccl_unique_id(idbuf)
+            if rc != 0:
+                raise RuntimeError("gfbe_rccl_unique_id failed: %d" % rc)
+        t = torch.tensor(list(idbuf.raw), dtype=torch.uint8)
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0, group=group)
+        idbuf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        self.h = C.c_void_p()
+        rc = self.lib.gfbe_rccl_create(C.byref(self.h), idbuf, int(rank), int(world), int(device))
+        if rc != 0:
+            raise RuntimeError("gfbe_rccl_create failed: %d" % rc)
+        self.fn_ptr = C.cast(self.lib.gfbe_rccl_allreduce, C.c_void_p).value
+
+    def calls(self):
+        return int(self.lib.gfbe_rccl_calls(self.h))
+
+    def last_error(self):
+        return int(self.lib.gfbe_rccl_last_error(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.gfbe_rccl_destroy(self.h)
+            self.h = None
+
+
+def install_allreduce_hook(be, rank, world, prefer="native", group=None):
+    """Landmark sharding on `be`: the native RCCL hook when asked for and usable (backend nccl, library built), else the
+    torch.distributed callback. Returns the kind installed ("native-rccl" / "torch-<backend>")."""
+    import torch.distributed as dist
+    from . import backend
+    import os
+    if prefer == "native" and dist.get_backend(group) == "nccl" and os.path.exists(backend._RCCL_SO):
+        hook = RcclHook(rank, world, be.device, group)
+        be._rccl_hook = hook                       # keep the communicator alive as long as the back end
+        be.set_allreduce_native(hook.fn_ptr, hook.h.value, rank, world)
+        return "native-rccl"
+    be.set_allreduce(torch_allreduce_hook(group), rank, world)
+    return "torch-" + dist.get_backend(group)

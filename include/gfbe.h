@@ -190,6 +190,15 @@ typedef struct gfbe_options {
    * 256 windows; 3 / 4 parts measured slower (45.1k / 44.0k vs 49.5k solves/s at 1024 windows). Results per window are
    * unchanged (every window is independent). 0: one launch sequence for the whole batch. */
   int32_t split_batch;
+  /* Solver::Options::max_solver_time_in_seconds (estimator.cpp:3369-3376: SOLVER_TIME = 0.04 s, x 4/5 before a MARGIN_OLD).
+   * Checked ON THE DEVICE at the start of every trust-region iteration against the device's wall clock (no host
+   * synchronisation inside a solve); a window over budget stops with termination 0 / GFBE_NO_CONVERGENCE like Ceres'
+   * "maximum solver time reached". 0 (default) = no cap: results then depend on the inputs only. A binding that wants the
+   * reference's behaviour sets 0.04 (or 0.032); at 2 ms per solve it never triggers. */
+  double max_solver_time_in_seconds;
+  /* Host threads gfbe_batch_upload / gfbe_batch_download pack and unpack windows with (one window per task).
+   * 0 (default) = min(hardware threads, 32); 1 = the calling thread only. */
+  int32_t host_threads;
 } gfbe_options;
 
 typedef struct gfbe_summary {
@@ -202,6 +211,12 @@ typedef struct gfbe_summary {
   double final_radius;
   double cost_history[16];   /* cost after each iteration (accepted or not), [0] = initial */
   uint8_t accepted[16];      /* accept/reject per iteration */
+  /* Phase times from the device's wall clock (100 MHz), per window: first kernel of the solve -> re-anchored state, and
+   * re-anchored state -> prior written (0 when no marginalisation ran). In a batch all windows advance together, so these
+   * are the batch's phase times as seen by this window. */
+  double ms_solve, ms_marginalize;
+  /* Host <-> device bytes of this window: packed upload (landmarks, factors, pre-integrations, prior) and result download. */
+  double bytes_uploaded, bytes_downloaded;
 } gfbe_summary;
 
 enum { GFBE_MARGIN_OLD = 0, GFBE_MARGIN_SECOND_NEW = 1, GFBE_MARGIN_NONE = 2 };

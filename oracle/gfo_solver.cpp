@@ -16,6 +16,7 @@
 #include "gfo_api.h"
 #include "gfo_factors.h"
 #include <vector>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <algorithm>
@@ -377,6 +378,11 @@ static void solve(const Problem &P, Solution &sol) {
       }
       // Gauss-Newton step with the mu-regularised Schur solve (DoglegStrategy::ComputeGaussNewtonStep)
       bool solved = false;
+      // fault injection (tests only): the first factorisation of iteration GFBE_TEST_FAIL_CHOL_ITER is declared failed,
+      // so that the mu-retry path (DoglegStrategy: mu *= 10 until the linear solver succeeds) is exercised — Gauss-Newton
+      // systems with mu >= 1e-8 practically never fail on their own
+      const char *fenv = std::getenv("GFBE_TEST_FAIL_CHOL_ITER");
+      bool inject = fenv && std::atoi(fenv) == it;
       while (mu < max_mu) {
         for (int a = 0; a < ND; a++) {
           for (int b = 0; b < ND; b++) St[(size_t)a * ND + b] = sp[a] * sp[b] * lin.H[(size_t)a * ND + b];
@@ -397,7 +403,9 @@ static void solve(const Problem &P, Solution &sol) {
             for (int q = 0; q < nz; q++) row[idx[q]] -= f * hv[q];
           }
         }
-        if (chol_solve(St, rhs, P.act, yp.data())) {
+        bool chol_ok = chol_solve(St, rhs, P.act, yp.data());
+        if (inject) { chol_ok = false; inject = false; }
+        if (chol_ok) {
           bool fin = true;
           for (int l = 0; l < L; l++) {
             if (!P.lm_free[l]) { yl[l] = 0; continue; }
@@ -690,6 +698,7 @@ void gfo_default_options(gfbe_options *o) {
   o->marg_sqrt = 0;   // the oracle always uses the reference's eigen-decomposition
   o->use_graph = 0;   // (device options; meaningless on the CPU)
   o->split_batch = 1;
+  o->max_solver_time_in_seconds = 0.0; o->host_threads = 0;
 }
 
 int32_t gfo_sqrt_info(const double *cov, double *out, int32_t n) { return sqrt_info_from_cov(cov, out, n) ? 0 : 1; }

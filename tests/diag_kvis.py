@@ -21,3 +21,15 @@ for _ in range(3): run()
 torch.cuda.synchronize()
 for p in sorted(be.profile(), key=lambda p: -p["total_ms"]):
     print("%-20s launches %4d  avg %.4f ms  total %.3f" % (p["name"], p["launches"], p["total_ms"] / max(p["launches"], 1), p["total_ms"]))
+# whole-solve throughput of this build (not profiled), and a result fingerprint
+import time
+be.profile_enable(False)
+for _ in range(2): run()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): run()
+torch.cuda.synchronize()
+print("solves_per_s %.0f" % (5 * B / (time.perf_counter() - t0)))
+try:
+    print("final_cost %.12g" % batch.download()[0]["summary"]["final_cost"])
+except Exception as e:
+    print("final_cost error", e)

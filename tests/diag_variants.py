@@ -1,0 +1,41 @@
+"""Kernel variants side by side (one gpurun call instead of one per build): `build` compiles the variants into
+ground-fusion2_amd/csrc/variants/ HERE (hipcc cross-compiles without a GPU; the .so files travel with the snapshot),
+`run` times every variant on the GPU box in its own process (GFBE_LIB selects the library).
+  python tests/diag_variants.py build [names...]      python tests/diag_variants.py run [names...]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, "ground-fusion2_amd", "csrc", "variants")
+VARIANTS = {   # name -> (extra flags, fp-contract)
+    "base": ([], "off"),
+    "noearly": (["-DGFBE_KVIS_EARLY=0"], "off"),
+    "contract": ([], "fast"),
+    "abl1_nomfma": (["-DGFBE_ABLATE=1"], "off"),
+    "abl2_nopartstore": (["-DGFBE_ABLATE=2"], "off"),
+    "abl3_nohpstore": (["-DGFBE_ABLATE=3"], "off"),
+    "abl4_noeval": (["-DGFBE_ABLATE=4"], "off"),
+}
+
+def build(names):
+    from _gfbe_import import gf
+    os.makedirs(VDIR, exist_ok=True)
+    for n in names:
+        flags, fc = VARIANTS[n]
+        print("build", n, flags, fc, flush=True)
+        gf.build_native(force=True, out=os.path.join(VDIR, "libgfbe_%s.so" % n), extra_flags=flags, fp_contract=fc)
+
+def run(names):
+    for n in names:
+        so = os.path.join(VDIR, "libgfbe_%s.so" % n)
+        if not os.path.exists(so):
+            print("== %s: not built" % n); continue
+        env = dict(os.environ, GFBE_LIB=so, B=os.environ.get("B", "1024"), SPLIT=os.environ.get("SPLIT", "1"))
+        print("== variant %s" % n, flush=True)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "diag_kvis.py")], env=env, capture_output=True, text=True, timeout=600)
+        print("\n".join(l for l in r.stdout.splitlines() if l.split() and l.split()[0] in ("k_vis_lin_iter0", "k_vis_lin", "k_schur", "k_solve", "k_assemble", "k_visblock", "solves_per_s", "final_cost")))
+        if r.returncode != 0:
+            print("rc", r.returncode, r.stderr[-600:])
+
+if __name__ == "__main__":
+    names = sys.argv[2:] or list(VARIANTS)
+    {"build": build, "run": run}[sys.argv[1]](names)

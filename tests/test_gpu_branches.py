@@ -1,0 +1,130 @@
+"""Branches of the hot path the standard windows never take ("GPU-untested branches"), each through the
+C ABI on the GPU against the CPU oracle with the tolerances of tests/test_gpu_parity.py::check_solve:
+  * every optional block free (camera extrinsic, td, wheel intrinsics, td_wheel: estimator.cpp:3024-3161) with non-zero
+    PoseSubsetParameterization masks (pose_subset_parameterization.cpp:27-64: masked in Plus only);
+  * double2vector()'s gimbal-lock branch (estimator.cpp:2523-2532): frame-0 pitch within 1 degree of 90;
+  * the mu-retry of DoglegStrategy after a failed linear solve, with the in-kernel rebuild of E (fault injection:
+    GFBE_TEST_FAIL_CHOL_ITER makes the first factorisation of one iteration "fail" in both implementations);
+  * USE_IMU = 0 (estimator.cpp:3018-3022): no IMU factors, speed-bias blocks absent, Pose[0] constant.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from _gfbe_import import gf
+from test_gpu_parity import check_solve, window_with_prior
+
+abi, synth = gf.abi, gf.synth
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    return gf.Backend(device=0)
+
+
+def all_free(snap, masks=True):
+    s = dict(snap)
+    s.update(ex_cam_const=0, ex_wheel_const=0, ix_wheel_const=0, td_const=0, td_wheel_const=0)
+    if masks:   # CameraExtrinsicAdjustType / WheelExtrinsicAdjustType style masks (1 = component held in Plus)
+        s["ex_cam_mask"] = np.array([0, 0, 1, 0, 0, 0], np.uint8)
+        s["ex_wheel_mask"] = np.array([0, 0, 1, 1, 1, 0], np.uint8)
+    s["ix_wheel"] = np.array([1.01, 0.99, 1.02])
+    s["td"], s["td_wheel"] = 0.002, -0.003
+    return s
+
+
+@pytest.mark.parametrize("flag", [abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW])
+def test_all_blocks_free_with_subset_masks(be, oracle, flag):
+    _, snap = window_with_prior(oracle, 61, 400)
+    snap = all_free(snap)
+    want, got = check_solve(be, oracle, snap, flag)
+    # the free blocks really moved, and the masked components did not (Plus zeroes them; the Jacobian still sees them)
+    assert abs(got["state"]["td"] - snap["td"]) > 1e-9 and np.abs(got["state"]["ix_wheel"] - snap["ix_wheel"]).max() > 1e-9
+    assert got["state"]["ex_pose"][2] == snap["ex_pose"][2]
+    assert got["state"]["ex_pose_wheel"][2] == snap["ex_pose_wheel"][2]
+    assert abs(got["state"]["td"] - want["state"]["td"]) < 1e-9 and abs(got["state"]["td_wheel"] - want["state"]["td_wheel"]) < 1e-9
+    pw, pg = want["prior"], got["prior"]
+    assert pg["block_id"].tolist() == pw["block_id"].tolist() and pg["block_idx"].tolist() == pw["block_idx"].tolist()
+    Aw, Ag = pw["J0"].T @ pw["J0"], pg["J0"].T @ pg["J0"]
+    assert np.abs(Ag - Aw).max() < 1e-6 * np.abs(Aw).max()
+
+
+def test_all_blocks_free_first_window_no_prior(be, oracle):
+    scn = synth.Scenario(seed=62, n_landmarks=300, use_wheel=True)
+    check_solve(be, oracle, all_free(scn.window(0), masks=False), abi.MARGIN_OLD)
+
+
+def test_reanchor_gimbal_lock_branch(be, oracle):
+    """Frame 0 pitched to 89.5 degrees: |pitch| within 1 degree of 90 switches double2vector() from the yaw difference to
+    rot_diff = R0 * R00^T (estimator.cpp:2523-2532). The window is otherwise the standard one (the factors then pull frame 0
+    back: two iterations are enough to move it, and few enough for the two implementations not to drift apart)."""
+    scn = synth.Scenario(seed=63, n_landmarks=300, use_wheel=True)
+    snap = scn.window(0)
+    R0 = synth.rz(0.3) @ synth.ry(np.deg2rad(89.5)) @ synth.rx(0.02)
+    q = synth.rot2q(R0)
+    snap["pose"] = snap["pose"].copy()
+    snap["pose"][0, 3:] = q / np.linalg.norm(q)
+    o2 = oracle.with_options(max_num_iterations=2)
+    opt = abi.default_options()
+    opt.max_num_iterations = 2
+    be2 = gf.Backend(device=0, options=opt)
+    want, got = o2.solve(snap, abi.MARGIN_NONE), be2.solve(snap, abi.MARGIN_NONE)
+    assert got["summary"]["accepted"] == want["summary"]["accepted"] and got["summary"]["iterations"] == want["summary"]["iterations"]
+    np.testing.assert_allclose(got["summary"]["cost_history"], want["summary"]["cost_history"], rtol=1e-9)
+    # the gauge fix ran in its gimbal branch on both sides: frame 0 keeps its ORIGINAL full rotation, not just the yaw
+    assert 2 * np.linalg.norm(synth.qmul(synth.qinv(snap["pose"][0, 3:]), got["state"]["pose"][0, 3:])[:3]) < 1e-9
+    assert np.abs(got["state"]["pose"][:, :3] - want["state"]["pose"][:, :3]).max() < 1e-8
+    for i in range(abi.NFRAMES):
+        dq = synth.qmul(synth.qinv(want["state"]["pose"][i, 3:]), got["state"]["pose"][i, 3:])
+        assert 2 * np.linalg.norm(dq[:3]) < 1e-9
+    assert np.abs(got["state"]["speed_bias"] - want["state"]["speed_bias"]).max() < 1e-7
+    be2.close()
+
+
+@pytest.mark.parametrize("fail_iter", [1, 3])
+def test_mu_retry_after_failed_linear_solve(be, oracle, fail_iter, monkeypatch):
+    """The first Cholesky of iteration `fail_iter` is declared failed: mu goes 1e-8 -> 1e-7, k_solve rebuilds E from the
+    landmark rows for the new mu inside the kernel and factorises again; the later iterations carry the larger mu."""
+    _, snap = window_with_prior(oracle, 64, 500)
+    plain = oracle.solve(snap, abi.MARGIN_OLD)
+    monkeypatch.setenv("GFBE_TEST_FAIL_CHOL_ITER", str(fail_iter))
+    want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD)
+    assert want["summary"]["cost_history"] != plain["summary"]["cost_history"]      # the retry changed the iteration (larger damping)
+    # a batch mixes windows: the retry of one must not leak into its neighbours' partials
+    res = be.solve_batch([snap, snap, snap], abi.MARGIN_OLD)
+    for r in res:
+        assert r["summary"]["cost_history"] == got["summary"]["cost_history"]
+
+
+def test_no_imu_pose0_constant(be, oracle):
+    """USE_IMU = 0: no IMUFactor, no speed-bias blocks in the problem, Pose[0] fixed (estimator.cpp:3018-3022); the wheel
+    odometry and the camera carry the window."""
+    scn = synth.Scenario(seed=65, n_landmarks=300, use_wheel=True)
+    snap = scn.window(0)
+    snap["imu"] = np.zeros((0, abi.IMU_DOUBLES))
+    snap["imu_frame"] = np.zeros(0, np.int32)
+    pc = np.zeros(abi.NFRAMES, np.uint8)
+    pc[0] = 1
+    snap["pose_const"] = pc
+    want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD)
+    assert np.array_equal(got["state"]["speed_bias"], snap["speed_bias"])            # untouched blocks come back as they went in
+    assert got["prior"] is not None and abi.BLK_SB0 not in got["prior"]["block_id"].tolist()
+
+
+def test_solver_time_cap_stops_on_the_device(be, oracle):
+    """gfbe_options.max_solver_time_in_seconds (Solver::Options::max_solver_time_in_seconds = SOLVER_TIME, estimator.cpp:3369-3376):
+    a cap far below one iteration stops the solve after the first step with termination 0 / NO_CONVERGENCE, no host sync
+    involved; the default 0 never stops early."""
+    scn = synth.Scenario(seed=66, n_landmarks=300, use_wheel=True)
+    snap = scn.window(0)
+    opt = abi.default_options()
+    opt.max_solver_time_in_seconds = 1e-7
+    bec = gf.Backend(device=0, options=opt)
+    capped, full = bec.solve(snap, abi.MARGIN_NONE), be.solve(snap, abi.MARGIN_NONE)
+    assert capped["summary"]["iterations"] < full["summary"]["iterations"]
+    assert capped["summary"]["termination"] == 0 and capped["status"] == abi.NO_CONVERGENCE
+    s = full["summary"]
+    assert s["ms_solve"] > 0 and s["bytes_uploaded"] > 0 and s["bytes_downloaded"] > 0
+    bec.close()
