@@ -160,8 +160,8 @@ def main():
     res = batch.download()
     final_costs = [r["summary"]["final_cost"] for r in res[: args.unique]]
     iters = [r["summary"]["iterations"] for r in res[: args.unique]]
-    phase_ms = {"solve": res[0]["summary"]["ms_solve"], "marginalize": res[0]["summary"]["ms_marginalize"]}
-    io_bytes = {"uploaded_per_window": res[0]["summary"]["bytes_uploaded"], "downloaded_per_window": res[0]["summary"]["bytes_downloaded"]}
+    phase_ms = {"solve": res[0]["perf"]["ms_solve"], "marginalize": res[0]["perf"]["ms_marginalize"]}
+    io_bytes = {"uploaded_per_window": res[0]["perf"]["bytes_uploaded"], "downloaded_per_window": res[0]["perf"]["bytes_downloaded"]}
 
     out = None
     prof = None

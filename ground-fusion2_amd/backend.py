@@ -266,7 +266,7 @@ class Batch:
         for k in range(n):
             out.append(dict(state=abi.state_to_dict(states[k]), feature=feats[k],
                             prior=priors[k].to_dict() if priors[k].c.valid else None,
-                            summary=abi.summary_to_dict(sums[k]), status=sums[k].status))
+                            summary=abi.summary_to_dict(sums[k]), perf=abi.summary_perf(sums[k]), status=sums[k].status))
         return out
 
     def download_into(self, bufs):

@@ -565,7 +565,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
                               int tab0 = 0) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   if (c->device < 0 || !c->stream) { c->err = "HIP device context required (no CPU fallback)"; return GFBE_NO_DEVICE; }
-  const bool dbg_t = getenv("GFBE_DEBUG_UPLOAD") != nullptr;   // phase times of the upload on stderr (tests/diag_e2e_latency.py)
+  const bool dbg_t = getenv("GFBE_DEBUG_UPLOAD") != nullptr && getenv("GFBE_DEBUG_UPLOAD")[0] != 0;   // phase times of the upload on stderr (tests/diag_e2e_latency.py)
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   HIPCHK(c, hipSetDevice(c->device));
   const double T0 = now();
@@ -739,7 +739,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
     AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
     AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);
-    AL(timing, (size_t)B * 32); AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
+    AL(timing, (size_t)(B + 1) * 32);   // (+ one block for the phase stamps of a diagnostics build)
+    AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
     AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
@@ -1149,9 +1150,10 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
   const int B = d.B;
   HIPCHK(c, hipEventSynchronize(b->ev_dl));
   b->fetched = true;
+  // (the three result arrays are separate 256-byte aligned allocations at the end of the slab: offsets from the device pointers)
   const double *fix = (const double *)b->dl_h;
-  const double *feat = fix + (size_t)B * DL_FIX;
-  const double *J0s = feat + b->feat_off[B];
+  const double *feat = (const double *)(b->dl_h + ((const char *)d.dl_feat - (const char *)d.dl_fix));
+  const double *J0s = (const double *)(b->dl_h + ((const char *)d.dl_J0 - (const char *)d.dl_fix));
   std::vector<int> status(B);
   host_parallel(c, B, [&](int w) {
     const double *f = fix + (size_t)w * DL_FIX;
@@ -1358,8 +1360,8 @@ extern "C" gfbe_status gfbe_preintegrate_wheel(gfbe_ctx *c, int32_t n, const int
 
 // diagnostics: copy the k_solve phase stamps of window w (32 doubles, 10 ns ticks)
 extern "C" gfbe_status gfbe_debug_timing(gfbe_ctx *c, gfbe_batch *b, int32_t w, double *out32) {
-  if (b && b->second && w >= b->d.B) return gfbe_debug_timing(c, b->second, w - b->d.B, out32);
-  if (!c || !b || !out32 || w < 0 || w >= b->d.B) return GFBE_BAD_INPUT;
+  if (b && b->second && w > b->d.B) return gfbe_debug_timing(c, b->second, w - b->d.B, out32);
+  if (!c || !b || !out32 || w < 0 || w > b->d.B) return GFBE_BAD_INPUT;   // (w == B: the extra block of the first part)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out32, b->d.timing + (size_t)w * 32, sizeof(double) * 32, hipMemcpyDeviceToHost));
   return GFBE_OK;

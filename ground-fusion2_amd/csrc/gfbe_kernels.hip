@@ -30,6 +30,9 @@ namespace gfd {
 #ifndef GFBE_KVIS_EARLY
 #define GFBE_KVIS_EARLY 1   // k_vis: the prefetched observation of the next step is waited for BEFORE this step's stores are issued
 #endif
+#ifndef GFBE_KVIS_STAMP
+#define GFBE_KVIS_STAMP 0   // diagnostics build (tests/diag_variants.py): phase time stamps of one wave of k_vis<0> into d.timing
+#endif
 #define GF_MIN_DIAG 1e-6
 #define GF_MAX_DIAG 1e32
 #define GF_MIN_MU 1e-8
@@ -170,6 +173,14 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   const double *X = (MODE == 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
   const double *lamv = d.lam + (size_t)buf * d.tot_lm;
 
+#if GFBE_KVIS_STAMP
+  double *kstamp = d.timing + (size_t)d.B * 32;      // (the extra block behind the windows' own slots)
+  const bool kst = MODE == 0 && w == d.B / 2 && tile == 0 && threadIdx.x == 0 && c.iter == 0;
+#define KSTAMP(i) do { if (kst) kstamp[i] = (double)wall_clock64(); } while (0)
+#else
+#define KSTAMP(i) do { } while (0)
+#endif
+  KSTAMP(0);
   __shared__ PoseRT sp[NF + 1];
   __shared__ PairConst pcs[NF];          // pair (sframe, j) constants, j = sframe+1 .. 10
   __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XS_LD];   // one [J | r] row of each of the wave's 64 factors
@@ -181,6 +192,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   __syncthreads();
   const double td = X[A_TD];
   const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
+  KSTAMP(1);
 
   const int slot = ds.lm_off + tile * LM_TILE + lane;
   const int info = d.lm_info[slot];
@@ -206,7 +218,9 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
     for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
   }
+  KSTAMP(2);
   for (int k = 0; k < mmax; k++) {
+    if (k < 5) KSTAMP(3 + 5 * k);
     double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2], hp[6];
     const double pjx = nob[0], pjy = nob[1], vjx = nob[2], vjy = nob[3], tdj = nob[4];
     if (k + 1 < mmax) {
@@ -258,6 +272,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       for (int q = 0; q < 12; q++) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
       Jt[0] = Jt[1] = 0.0; r[0] = r[1] = 0.0;
     }
+    if (k < 5) KSTAMP(4 + 5 * k);
     if (MODE != 1) {
 #if GFBE_KVIS_EARLY
       // vmcnt counts loads and stores in one queue: if the next step's observation (loaded at the top of this step) were first
@@ -285,8 +300,10 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       dbl4_v acc0 = {0, 0, 0, 0};
       double acc1 = 0.0, acc2 = 0.0;
       const int lr = lane & 15, lk = lane >> 4, lj = lane & 3, lb = (lane & 15) >> 2;
+      if (k < 5) KSTAMP(5 + 5 * k);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
+        if (k < 5 && h == 1) KSTAMP(6 + 5 * k);
         {
           double *xr = xs + lane * XS_LD;
 #pragma unroll
@@ -320,6 +337,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       }
       acc2 += __shfl_xor(acc2, 4, 64);
       acc2 += __shfl_xor(acc2, 8, 64);
+      if (k < 5) KSTAMP(7 + 5 * k);
       double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VP_STRIDE;
       if (GFBE_ABLATE == 2 && acc0[0] != 1.2345) continue;
 #pragma unroll
@@ -335,6 +353,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
     for (int q = 0; q < HC; q++) d.lm_hC[(size_t)q * TL + slot] = hC[q];
   }
+  KSTAMP(30);
   cost = wave_sum(cost);
   if (lane == 0) {
     if (MODE == 1) d.tile_cand[((size_t)w * d.max_tiles + tile) * 4] = cost;

@@ -39,7 +39,9 @@ def all_free(snap, masks=True):
 def test_all_blocks_free_with_subset_masks(be, oracle, flag):
     _, snap = window_with_prior(oracle, 61, 400)
     snap = all_free(snap)
-    want, got = check_solve(be, oracle, snap, flag)
+    # this window stops on rejected steps three accepted steps after a cost of 1e8 (not settled): the tolerances of a settled
+    # solve x 100
+    want, got = check_solve(be, oracle, snap, flag, loose=100.0)
     # the free blocks really moved, and the masked components did not (Plus zeroes them; the Jacobian still sees them)
     assert abs(got["state"]["td"] - snap["td"]) > 1e-9 and np.abs(got["state"]["ix_wheel"] - snap["ix_wheel"]).max() > 1e-9
     assert got["state"]["ex_pose"][2] == snap["ex_pose"][2]
@@ -125,6 +127,19 @@ def test_solver_time_cap_stops_on_the_device(be, oracle):
     capped, full = bec.solve(snap, abi.MARGIN_NONE), be.solve(snap, abi.MARGIN_NONE)
     assert capped["summary"]["iterations"] < full["summary"]["iterations"]
     assert capped["summary"]["termination"] == 0 and capped["status"] == abi.NO_CONVERGENCE
-    s = full["summary"]
+    s = full["perf"]
     assert s["ms_solve"] > 0 and s["bytes_uploaded"] > 0 and s["bytes_downloaded"] > 0
     bec.close()
+
+
+@pytest.mark.parametrize("name", ["A", "B", "cfg1", "free_masks", "retry2"])
+def test_hip_backend_reproduces_independent_trust_region_loop(be, oracle, name, monkeypatch):
+    """The HIP path against tests/golden/dogleg_np.npz — the outputs of the independent numpy trust-region loop
+    (tests/ceres_trust_region_np.py, from Ceres 1.14's published algorithm): same accept / reject sequence and termination,
+    costs and final radius to the tolerances of tests/test_oracle_numpy.py::_check_against_loop."""
+    from dogleg_cases import cases
+    from test_oracle_numpy import _check_against_loop, _dogleg_fixture
+    snap, kw = [(s, k) for n, s, k in cases(oracle) if n == name][0]
+    if kw.get("fail_chol_iter"):
+        monkeypatch.setenv("GFBE_TEST_FAIL_CHOL_ITER", str(kw["fail_chol_iter"]))
+    _check_against_loop(be.solve(snap, abi.MARGIN_NONE)["summary"], _dogleg_fixture(), name, final_rtol=1e-6 if name == "free_masks" else 1e-9)

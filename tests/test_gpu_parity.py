@@ -44,7 +44,7 @@ def test_factor_blocks_match_oracle(be, oracle, robust):
         assert abs(got["cost"] - want["cost"]) < 1e-10 * want["cost"]
 
 
-def check_solve(be, oracle, snap, flag):
+def check_solve(be, oracle, snap, flag, loose=1.0):
     """Stated FP64 tolerances of a whole optimization() call vs the oracle (measured deviations on
     MI355X are 2-4 orders of magnitude below them, see tests/diag_parity.py):
       accept/reject sequence, iteration count, termination reason : identical
@@ -59,16 +59,17 @@ def check_solve(be, oracle, snap, flag):
     assert sg["accepted"] == sw["accepted"]
     assert sg["termination"] == sw["termination"]
     np.testing.assert_allclose(sg["cost_history"], sw["cost_history"], rtol=1e-6)
-    assert abs(sg["final_cost"] - sw["final_cost"]) < 1e-9 * sw["final_cost"]
+    # (loose: a multiplier for windows that stop before they have settled, stated by the caller)
+    assert abs(sg["final_cost"] - sw["final_cost"]) < loose * 1e-9 * sw["final_cost"]
     ate = np.sqrt(((got["state"]["pose"][:, :3] - want["state"]["pose"][:, :3]) ** 2).sum(axis=1).mean())
-    assert ate < 1e-8, ate
+    assert ate < loose * 1e-8, ate
     for i in range(abi.NFRAMES):
         dq = synth.qmul(synth.qinv(want["state"]["pose"][i, 3:]), got["state"]["pose"][i, 3:])
-        assert 2 * np.linalg.norm(dq[:3]) < 1e-9
-    assert np.abs(got["state"]["speed_bias"] - want["state"]["speed_bias"]).max() < 1e-7
+        assert 2 * np.linalg.norm(dq[:3]) < loose * 1e-9
+    assert np.abs(got["state"]["speed_bias"] - want["state"]["speed_bias"]).max() < loose * 1e-7
     for k in ("ex_pose", "ex_pose_wheel", "ix_wheel"):
-        assert np.abs(got["state"][k] - want["state"][k]).max() < 1e-7, k
-    np.testing.assert_allclose(got["feature"], want["feature"], rtol=1e-7, atol=1e-12)
+        assert np.abs(got["state"][k] - want["state"][k]).max() < loose * 1e-7, k
+    np.testing.assert_allclose(got["feature"], want["feature"], rtol=loose * 1e-7, atol=1e-12)
     return want, got
 
 
