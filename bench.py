@@ -48,6 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block")
     ap.add_argument("--e2e-batch", type=int, default=512, help="windows per batch of the end-to-end loops (two batches in flight)")
     ap.add_argument("--e2e-steps", type=int, default=8)
+    ap.add_argument("--e2e-depth", type=int, default=3, help="batches in flight in the end-to-end loops")
     ap.add_argument("--host-threads", type=int, default=0, help="gfbe_options.host_threads (0: library default)")
     ap.add_argument("--split", type=int, default=None, help="gfbe_options.split_batch: parts a batch of >= 128 windows is solved in, side by side (library default: 2)")
     ap.add_argument("--graph", action="store_true", help="gfbe_options.use_graph: replay the launch sequence as a hipGraph")
@@ -292,11 +293,20 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
     nu = len(snaps)
     sets = [gf.WindowSet([snaps[(i + q) % nu] for i in range(B)]) for q in range(2)]   # two different host window sets, alternated
     bufs = gf.DownloadBuffers(B, max(h.n_feature for h in sets[0].holders))
-    out = {"windows_per_batch": B, "batches_in_flight": 2, "steps": args.e2e_steps}
+    out = {"windows_per_batch": B, "steps": args.e2e_steps}
+
+    depth = args.e2e_depth
+    out["batches_in_flight"] = depth
 
     def pipeline(upload):
-        cur = upload(0)
-        cur.solve(abi.MARGIN_OLD)
+        """`depth` batches in flight: while batch k solves, batch k+1 waits on the GPU with its inputs landed and batch k+2 is
+        being packed by the host; the oldest batch is downloaded (gather + D2H + unpack) after each new upload."""
+        from collections import deque
+        q = deque()
+        for i in range(depth - 1):
+            b = upload(i % 2)
+            b.solve(abi.MARGIN_OLD)
+            q.append(b)
         t_up = t_dl = 0.0
         t0 = None
         n_timed = 0
@@ -308,21 +318,24 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
                 t0 = time.perf_counter()
                 t_up = t_dl = 0.0
             ta = time.perf_counter()
-            nxt = upload((s + 1) % 2)          # packs + enqueues the copy while `cur` solves
+            nxt = upload((s + depth - 1) % 2)          # packs + enqueues the copy while the older batches solve
             nxt.solve(abi.MARGIN_OLD)
+            q.append(nxt)
             tb = time.perf_counter()
+            cur = q.popleft()
             cur.download_into(bufs)
             tc = time.perf_counter()
             cur.free()
-            cur = nxt
             t_up += tb - ta
             t_dl += tc - tb
             if s >= 2:
                 n_timed += 1
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        cur.download_into(bufs)
-        cur.free()
+        while q:
+            cur = q.popleft()
+            cur.download_into(bufs)
+            cur.free()
         solves, el = gf.dist.aggregate_throughput(n_timed * B, el, dist)
         return {"value": solves / el, "unit": "solves/s", "ms_per_batch": 1e3 * el / n_timed,
                 "host_ms_in_upload_call": 1e3 * t_up / n_timed, "host_ms_in_download_call": 1e3 * t_dl / n_timed}

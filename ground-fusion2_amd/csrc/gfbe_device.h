@@ -168,7 +168,8 @@ struct BatchDev {
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
-  int test_fail_chol_iter, pad_t;   // fault injection (GFBE_TEST_FAIL_CHOL_ITER, tests only): the first factorisation of that iteration "fails"
+  int test_fail_chol_iter;          // fault injection (GFBE_TEST_FAIL_CHOL_ITER, tests only): the first factorisation of that iteration "fails"
+  int vis_full;                     // some window of the batch has a free camera extrinsic or td: the visual kernels form those Jacobian blocks
   double *xa, *xb, *xc;       // [B][world][XCHG] scalar exchange rows (own row written, the others zeroed, then sum all-reduce):
                               //   xa: visual cost of the linearisation point; xb: landmark shares of the dogleg scalars;
                               //   xc: candidate cost / step norms

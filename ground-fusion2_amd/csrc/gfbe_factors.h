@@ -198,6 +198,96 @@ GF_HD void correct_cols(double *row0, double *row1, int n, double r0, double r1,
 }
 
 // ---------------------------------------------------------------------------------------------
+// visual_lin: what the linearisation kernels run per factor — residual, HuberLoss corrector and the corrected tangent
+// Jacobian in one pass (projectionTwoFrameOneCamFactor.cpp:43-151 + marginalization_factor.cpp:46-77), written for the
+// FP64 pipe of gfx950 (matrix-core and vector FP64 instructions do not overlap there, profiles/ubench/
+// mfma_valu_overlap_mi355x.txt, so every vector instruction saved is time saved):
+//   * explicit fused multiply-adds (the library is built with -ffp-contract=off: what is fused is fused HERE, identically
+//     in every kernel that inlines this function, so the small-batch and throughput kernel sets stay bit-identical);
+//   * the corrector's sqrt(rho') goes into the 2 x 3 projection derivative `reduce` BEFORE the Jacobian blocks are formed
+//     (4 multiplications instead of 42 on the finished blocks; rho' = 1 for an inlier, where this changes no bit);
+//     the rank-one term of a loss with rho'' > 0 (never HuberLoss: alpha = 0) is applied to the scaled blocks afterwards;
+//   * FULL = false: the camera extrinsic and td are constant in this window (the shipped yamls: estimate_extrinsic 0,
+//     estimate_td 0) — their Jacobian blocks are not formed, as Ceres passes jacobians[2] = jacobians[4] = nullptr
+//     for constant blocks (projectionTwoFrameOneCamFactor.cpp:122,141).
+// Returns 0.5 rho(|r|^2). JAC = false: cost only (r is the uncorrected residual).
+// ---------------------------------------------------------------------------------------------
+template <bool JAC, bool FULL>
+GF_HD double visual_lin(const PairConst &pc, double inv_dep, double td, double pix, double piy, double piz, double pjx,
+                        double pjy, double vix, double viy, double vjx, double vjy, double td_i, double td_j,
+                        double sqrt_info, double delta, double *r, double *Ji, double *Jj, double *Je, double *Jl, double *Jt) {
+  const double dti = td - td_i, dtj = td - td_j;
+  const double inv_l = 1.0 / inv_dep;
+  const double cx = __builtin_fma(-dti, vix, pix) * inv_l, cy = __builtin_fma(-dti, viy, piy) * inv_l, cz = piz * inv_l;   // P_ci
+  vec3 q;
+#pragma unroll
+  for (int a = 0; a < 3; a++) q[a] = __builtin_fma(pc.Tm(a, 0), cx, __builtin_fma(pc.Tm(a, 1), cy, pc.Tm(a, 2) * cz));
+  const double X = q[0] + pc.u[0], Y = q[1] + pc.u[1], Z = q[2] + pc.u[2];                                               // P_cj
+  const double inv_z = 1.0 / Z;
+  const double r0 = sqrt_info * __builtin_fma(X, inv_z, -__builtin_fma(-dtj, vjx, pjx));
+  const double r1 = sqrt_info * __builtin_fma(Y, inv_z, -__builtin_fma(-dtj, vjy, pjy));
+  double s1, rs, asn;
+  const double cost = corrector(__builtin_fma(r0, r0, r1 * r1), delta, &s1, &rs, &asn);
+  if (!JAC) { r[0] = r0; r[1] = r1; return cost; }
+  // reduce = sqrt(rho') sqrt_info d(pi(P))/dP
+  const double si = s1 * sqrt_info;
+  const double r00 = si * inv_z, r02 = -(r00 * X * inv_z), r12 = -(r00 * Y * inv_z);   // (r11 == r00)
+  // rotation blocks through R [v]x = [R v]x R:  d/dtheta_i = -[q + B tic]x B,  d/dtheta_j = [P_cj + ric^T tic]x ric^T
+  const double a0 = q[0] + pc.Btic[0], a1 = q[1] + pc.Btic[1], a2 = q[2] + pc.Btic[2];
+  const double b0 = X + pc.c2[0], b1 = Y + pc.c2[1], b2 = Z + pc.c2[2];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    Ji[c] = __builtin_fma(r00, pc.A(0, c), r02 * pc.A(2, c));
+    Ji[6 + c] = __builtin_fma(r00, pc.A(1, c), r12 * pc.A(2, c));
+    Jj[c] = -Ji[c];
+    Jj[6 + c] = -Ji[6 + c];
+    // -[a]x B, rows 0..2 of column c
+    const double i0 = __builtin_fma(a2, pc.B(1, c), -(a1 * pc.B(2, c))), i1 = __builtin_fma(a0, pc.B(2, c), -(a2 * pc.B(0, c))),
+                 i2 = __builtin_fma(a1, pc.B(0, c), -(a0 * pc.B(1, c)));
+    Ji[3 + c] = __builtin_fma(r00, i0, r02 * i2);
+    Ji[9 + c] = __builtin_fma(r00, i1, r12 * i2);
+    // [b]x ric^T
+    const double j0 = __builtin_fma(b1, pc.ricT(2, c), -(b2 * pc.ricT(1, c))), j1 = __builtin_fma(b2, pc.ricT(0, c), -(b0 * pc.ricT(2, c))),
+                 j2 = __builtin_fma(b0, pc.ricT(1, c), -(b1 * pc.ricT(0, c)));
+    Jj[3 + c] = __builtin_fma(r00, j0, r02 * j2);
+    Jj[9 + c] = __builtin_fma(r00, j1, r12 * j2);
+    if (FULL) {
+      Je[c] = __builtin_fma(r00, pc.jep(0, c), r02 * pc.jep(2, c));
+      Je[6 + c] = __builtin_fma(r00, pc.jep(1, c), r12 * pc.jep(2, c));
+      // [q]x (I - Tm) + [u]x
+      const double e0 = __builtin_fma(q[1], pc.ImTm(2, c), -(q[2] * pc.ImTm(1, c))) + (c == 1 ? -pc.u[2] : (c == 2 ? pc.u[1] : 0.0));
+      const double e1 = __builtin_fma(q[2], pc.ImTm(0, c), -(q[0] * pc.ImTm(2, c))) + (c == 0 ? pc.u[2] : (c == 2 ? -pc.u[0] : 0.0));
+      const double e2 = __builtin_fma(q[0], pc.ImTm(1, c), -(q[1] * pc.ImTm(0, c))) + (c == 0 ? -pc.u[1] : (c == 1 ? pc.u[0] : 0.0));
+      Je[3 + c] = __builtin_fma(r00, e0, r02 * e2);
+      Je[9 + c] = __builtin_fma(r00, e1, r12 * e2);
+    }
+  }
+  // d/d lambda = -reduce q / lambda
+  Jl[0] = -(__builtin_fma(r00, q[0], r02 * q[2]) * inv_l);
+  Jl[1] = -(__builtin_fma(r00, q[1], r12 * q[2]) * inv_l);
+  if (FULL) {   // d/d td = -reduce Tm [v_i; 0] / lambda + sqrt(rho') sqrt_info v_j
+    const double t0 = __builtin_fma(pc.Tm(0, 0), vix, pc.Tm(0, 1) * viy), t1 = __builtin_fma(pc.Tm(1, 0), vix, pc.Tm(1, 1) * viy);
+    const double t2 = __builtin_fma(pc.Tm(2, 0), vix, pc.Tm(2, 1) * viy);
+    Jt[0] = __builtin_fma(si, vjx, -(__builtin_fma(r00, t0, r02 * t2) * inv_l));
+    Jt[1] = __builtin_fma(si, vjy, -(__builtin_fma(r00, t1, r12 * t2) * inv_l));
+  }
+  if (asn != 0.0) {   // a loss with rho'' > 0: J <- J - alpha/|r|^2 r r^T J on the sqrt(rho')-scaled blocks (r still uncorrected)
+    auto fix = [&](double *row0, double *row1, int n) {
+      for (int c = 0; c < n; c++) {
+        const double rtj = __builtin_fma(r0, row0[c], r1 * row1[c]);
+        row0[c] -= asn * r0 * rtj;
+        row1[c] -= asn * r1 * rtj;
+      }
+    };
+    fix(Ji, Ji + 6, 6); fix(Jj, Jj + 6, 6); fix(Jl, Jl + 1, 1);
+    if (FULL) { fix(Je, Je + 6, 6); fix(Jt, Jt + 1, 1); }
+  }
+  r[0] = r0 * rs;
+  r[1] = r1 * rs;
+  return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
 // sqrt_info = LLT(cov^-1).matrixL()^T (imu_factor.h:73, wheel_factor.h:85): partial-pivot LU inverse
 // (Eigen's inverse() for n > 4) followed by a lower Cholesky. Single-thread, n <= 15.
 // work: 2*n*n doubles. Returns 0 on success.

@@ -681,6 +681,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   d.rank = c->rank; d.world = c->world;
   { const char *fe = getenv("GFBE_TEST_FAIL_CHOL_ITER"); d.test_fail_chol_iter = fe ? atoi(fe) : 0; }   // fault injection of the mu-retry path (tests)
   b->algo_bytes_lin = algo_bytes;
+  for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
+  if (getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics: force the 20-column panel)
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
   const double T1 = now();

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 // MODE 0: linearise at the current point; MODE 1: candidate cost; MODE 2: marginalisation set
 // (landmarks with start_frame 0, estimator.cpp:3498-3531) at the re-anchored state.
 // =============================================================================================
-template <int MODE>
+template <int MODE, bool FULL>
 __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile) {
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
@@ -208,9 +208,15 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
   const double vix = d.lm_pts[3 * TL + slot], viy = d.lm_pts[4 * TL + slot], tdi = d.lm_pts[5 * TL + slot];
   const double lam = lamv[slot];
-  double hC[HC], Hll = 0.0, gl = 0.0;
+  // landmark row of the normal equations: pose_i (6) [| extrinsic (6) | td] — the latter only when they are free somewhere
+  constexpr int NHC = FULL ? HC : 6;
+  double hC[NHC], Hll = 0.0, gl = 0.0;
 #pragma unroll
-  for (int q = 0; q < HC; q++) hC[q] = 0.0;
+  for (int q = 0; q < NHC; q++) hC[q] = 0.0;
+  if (MODE != 1 && !FULL) {   // reduced panel [Ji Jj r 0 0 0]: the three padding columns are written once
+    double *xr = xs + lane * XS_LD;
+    xr[13] = 0.0; xr[14] = 0.0; xr[15] = 0.0;
+  }
   // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length are zero in memory)
   double nob[5];
   {
@@ -221,7 +227,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   KSTAMP(2);
   for (int k = 0; k < mmax; k++) {
     if (k < 5) KSTAMP(3 + 5 * k);
-    double r[2], Ji[12], Jj[12], Je[12], Jl[2], Jt[2], hp[6];
+    double r[2], Ji[12], Jj[12], Je[FULL ? 12 : 1], Jl[2], Jt[2], hp[6];
     const double pjx = nob[0], pjy = nob[1], vjx = nob[2], vjy = nob[3], tdj = nob[4];
     if (k + 1 < mmax) {
       const double *ob = d.lm_obs + (size_t)(k + 1) * 5 * TL + slot;
@@ -231,45 +237,37 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     if (k < m) {
       if (GFBE_ABLATE == 4 && MODE == 0) {
 #pragma unroll
-        for (int q = 0; q < 12; q++) { Ji[q] = pjx + q; Jj[q] = pjy * q; Je[q] = vjx - q; }
+        for (int q = 0; q < 12; q++) { Ji[q] = pjx + q; Jj[q] = pjy * q; if (FULL) Je[q] = vjx - q; }
         Jl[0] = lam; Jl[1] = tdj; Jt[0] = vjy; Jt[1] = pix; r[0] = piy * 1e-3; r[1] = piz * 1e-3;
       } else
-      visual_eval_pc<MODE != 1>(pcs[sframe + 1 + k], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
-                                sq, r, Ji, Jj, Je, Jl, Jt);
-      double s1, rs, asn;
-      cost += corrector(r[0] * r[0] + r[1] * r[1], delta, &s1, &rs, &asn);
+      cost += visual_lin<MODE != 1, FULL>(pcs[sframe + 1 + k], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
+                                          sq, delta, r, Ji, Jj, Je, Jl, Jt);
       if (MODE != 1) {
-        correct_cols(Ji, Ji + 6, 6, r[0], r[1], s1, asn);
-        correct_cols(Jj, Jj + 6, 6, r[0], r[1], s1, asn);
-        correct_cols(Je, Je + 6, 6, r[0], r[1], s1, asn);
-        correct_cols(Jl, Jl + 1, 1, r[0], r[1], s1, asn);
-        correct_cols(Jt, Jt + 1, 1, r[0], r[1], s1, asn);
-        r[0] *= rs; r[1] *= rs;
-        if (write_records) {   // inspection path (gfbe_eval_factors): block-CSR record r(2) | row0: Ji Jj Je Jl Jt | row1
+        if (FULL && write_records) {   // inspection path (gfbe_eval_factors): block-CSR record r(2) | row0: Ji Jj Je Jl Jt | row1
           double *rb = d.rec + ((size_t)ds.rec_off + d.lm_rec[(size_t)k * TL + slot]) * REC;
           rb[0] = r[0]; rb[1] = r[1];
 #pragma unroll
           for (int q = 0; q < 6; q++) {
-            rb[2 + q] = Ji[q]; rb[8 + q] = Jj[q]; rb[14 + q] = Je[q];
-            rb[22 + q] = Ji[6 + q]; rb[28 + q] = Jj[6 + q]; rb[34 + q] = Je[6 + q];
+            rb[2 + q] = Ji[q]; rb[8 + q] = Jj[q]; rb[14 + q] = Je[FULL ? q : 0];
+            rb[22 + q] = Ji[6 + q]; rb[28 + q] = Jj[6 + q]; rb[34 + q] = Je[FULL ? 6 + q : 0];
           }
           rb[20] = Jl[0]; rb[21] = Jt[0]; rb[40] = Jl[1]; rb[41] = Jt[1];
         }
         // landmark row of the normal equations (w = Jl)
         const double w0 = (is_const && MODE == 0) ? 0.0 : Jl[0], w1 = (is_const && MODE == 0) ? 0.0 : Jl[1];
-        Hll += w0 * w0 + w1 * w1;
-        gl += w0 * r[0] + w1 * r[1];
+        Hll += __builtin_fma(w0, w0, w1 * w1);
+        gl += __builtin_fma(w0, r[0], w1 * r[1]);
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-          hC[q] += Ji[q] * w0 + Ji[6 + q] * w1;
-          hC[6 + q] += Je[q] * w0 + Je[6 + q] * w1;
-          hp[q] = Jj[q] * w0 + Jj[6 + q] * w1;
+          hC[q] += __builtin_fma(Ji[q], w0, Ji[6 + q] * w1);
+          if (FULL) hC[6 + q] += __builtin_fma(Je[q], w0, Je[6 + q] * w1);
+          hp[q] = __builtin_fma(Jj[q], w0, Jj[6 + q] * w1);
         }
-        hC[12] += Jt[0] * w0 + Jt[1] * w1;
+        if (FULL) hC[12] += __builtin_fma(Jt[0], w0, Jt[1] * w1);
       }
     } else if (MODE != 1) {
 #pragma unroll
-      for (int q = 0; q < 12; q++) { Ji[q] = 0.0; Jj[q] = 0.0; Je[q] = 0.0; }
+      for (int q = 0; q < 12; q++) { Ji[q] = 0.0; Jj[q] = 0.0; if (FULL) Je[q] = 0.0; }
       Jt[0] = Jt[1] = 0.0; r[0] = r[1] = 0.0;
     }
     if (k < 5) KSTAMP(4 + 5 * k);
@@ -277,8 +275,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #if GFBE_KVIS_EARLY
       // vmcnt counts loads and stores in one queue: if the next step's observation (loaded at the top of this step) were first
       // touched at the loop's back edge, the wave would sit there until this step's partial-sum stores have been acknowledged.
-      // Touching it here — after ~2000 cycles of evaluation, before any store of this step, on a path every lane takes —
-      // costs nothing and leaves the stores to drain behind the matrix-core phase.
+      // Touching it here — after the evaluation, before any store of this step, on a path every lane takes — costs nothing.
 #pragma unroll
       for (int q = 0; q < 5; q++) asm volatile("" : "+v"(nob[q]));
 #endif
@@ -288,14 +285,18 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       }
     }
     if (MODE != 1 && GFBE_ABLATE != 1) {
-      // X^T X of the step's 128 x 20 panel X = [J(pose_i pose_j ex td) | r] on the FP64 matrix cores (the
-      // J^T J / J^T r of this tile's factors of pose pair (sframe, sframe+1+k)); J never leaves the CU.
-      // The panel goes through LDS 64 rows at a time (row h of every lane's factor, h = 0, 1).
-      // T0 = X(:,0:16)^T X(:,0:16) with v_mfma_f64_16x16x4_f64 (64 clk / 4 rows); the thin blocks use
-      // v_mfma_f64_4x4x4_4b_f64 (18 clk, lane layout measured in profiles/ubench/mfma_f64_4x4x4_layout.hip:
-      // A_blk[i][k] at lane 16k+4blk+i, B_blk[k][j] at 16k+4blk+j, D_blk[i][j] at 16i+4blk+j):
-      //   T1 = X(:,0:16)^T X(:,16:20): block blk = rows 4blk..4blk+3 of T1, same A operand as T0
-      //   T2 = X(:,16:20)^T X(:,16:20): the four blocks take four different row quads, summed at the end
+      // X^T X of the step's 128-row panel on the FP64 matrix cores (the J^T J / J^T r of this tile's factors of pose pair
+      // (sframe, sframe+1+k)); J never leaves the CU. The panel goes through LDS 64 rows at a time (row h of every lane's
+      // factor, h = 0, 1).
+      //   FULL: X = [Ji Jj Je Jt | r], 20 columns. T0 = X(:,0:16)^T X(:,0:16) with v_mfma_f64_16x16x4_f64 (64 clk / 4 rows);
+      //     the thin blocks use v_mfma_f64_4x4x4_4b_f64 (18 clk, lane layout measured in profiles/ubench/
+      //     mfma_f64_4x4x4_layout.hip: A_blk[i][k] at lane 16k+4blk+i, B_blk[k][j] at 16k+4blk+j, D_blk[i][j] at 16i+4blk+j):
+      //     T1 = X(:,0:16)^T X(:,16:20) (block blk = rows 4blk..4blk+3, same A operand as T0), T2 = X(:,16:20)^T X(:,16:20)
+      //     (the four blocks take four different row quads, summed at the end).
+      //   reduced (extrinsic and td constant in every window of the batch): X = [Ji Jj r 0 0 0] is one 16-column tile —
+      //     16 matrix-core instructions per half instead of 36 — and the partial is written in the FULL layout's positions
+      //     (gradient column into T1(:,3), r^T r into T2(3,3)); the extrinsic / td positions keep whatever they hold
+      //     (zero, or the marginalisation pass's values): those dims are inactive and k_assemble never reads them.
       typedef double dbl4_v __attribute__((ext_vector_type(4)));
       dbl4_v acc0 = {0, 0, 0, 0};
       double acc1 = 0.0, acc2 = 0.0;
@@ -307,8 +308,9 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
         {
           double *xr = xs + lane * XS_LD;
 #pragma unroll
-          for (int q = 0; q < 6; q++) { xr[q] = Ji[6 * h + q]; xr[6 + q] = Jj[6 * h + q]; xr[12 + q] = Je[6 * h + q]; }
-          xr[18] = Jt[h]; xr[19] = r[h];
+          for (int q = 0; q < 6; q++) { xr[q] = Ji[6 * h + q]; xr[6 + q] = Jj[6 * h + q]; if (FULL) xr[12 + q] = Je[6 * h + q]; }
+          if (FULL) { xr[18] = Jt[h]; xr[19] = r[h]; }
+          else xr[12] = r[h];
         }
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();
@@ -318,15 +320,16 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             const double *rowp = xs + (4 * (8 * blk + u) + lk) * XS_LD;
-            va[u] = rowp[lr]; vb[u] = rowp[16 + lj];
+            va[u] = rowp[lr];
+            if (FULL) vb[u] = rowp[16 + lj];
           }
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(va[u], vb[u], acc1, 0, 0, 0);
+            if (FULL) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(va[u], vb[u], acc1, 0, 0, 0);
           }
         }
-        {
+        if (FULL) {
           double vc[LM_TILE / 16];
 #pragma unroll
           for (int qd = 0; qd < LM_TILE / 16; qd++) vc[qd] = xs[(16 * qd + 4 * lb + lk) * XS_LD + 16 + lj];
@@ -335,15 +338,28 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
         }
         __builtin_amdgcn_wave_barrier();
       }
-      acc2 += __shfl_xor(acc2, 4, 64);
-      acc2 += __shfl_xor(acc2, 8, 64);
+      if (FULL) {
+        acc2 += __shfl_xor(acc2, 4, 64);
+        acc2 += __shfl_xor(acc2, 8, 64);
+      }
       if (k < 5) KSTAMP(7 + 5 * k);
       double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VP_STRIDE;
       if (GFBE_ABLATE == 2 && acc0[0] != 1.2345) continue;
+      if (FULL) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) vo[(lk + 4 * q) * 16 + lr] = acc0[q];
-      vo[256 + (4 * lb + lk) * 4 + lj] = acc1;        // T1[row 4 blk + i][col j], i = lane >> 4
-      if (lb == 0) vo[320 + lk * 4 + lj] = acc2;       // T2[i][j]
+        for (int q = 0; q < 4; q++) vo[(lk + 4 * q) * 16 + lr] = acc0[q];
+        vo[256 + (4 * lb + lk) * 4 + lj] = acc1;        // T1[row 4 blk + i][col j], i = lane >> 4
+        if (lb == 0) vo[320 + lk * 4 + lj] = acc2;       // T2[i][j]
+      } else {
+        // lane holds (row lk + 4 q, column lr) of the 16 x 16 tile: rows / columns 0..11 are pose_i, pose_j; 12 is r
+#pragma unroll
+        for (int q = 0; q < 3; q++) {                    // rows 0..11
+          const int a = lk + 4 * q;
+          if (lr < 12) vo[a * 16 + lr] = acc0[q];
+          else if (lr == 12) vo[256 + a * 4 + 3] = acc0[q];     // J^T r -> column 19 of the full layout
+        }
+        if (lk == 0 && lr == 12) vo[320 + 15] = acc0[3];        // r^T r (row 12, column 12)
+      }
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -351,7 +367,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     d.lm_Hll[slot] = Hll;
     d.lm_gl[slot] = gl;
 #pragma unroll
-    for (int q = 0; q < HC; q++) d.lm_hC[(size_t)q * TL + slot] = hC[q];
+    for (int q = 0; q < NHC; q++) d.lm_hC[(size_t)q * TL + slot] = hC[q];
   }
   KSTAMP(30);
   cost = wave_sum(cost);
@@ -361,11 +377,11 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   }
 }
 
-template <int MODE>
+template <int MODE, bool FULL>
 __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_records) {
   // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
   // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
-  vis_body<MODE>(d, write_records, blockIdx.x, blockIdx.y);
+  vis_body<MODE, FULL>(d, write_records, blockIdx.x, blockIdx.y);
 }
 
 // =============================================================================================
@@ -645,10 +661,10 @@ __global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mod
 // Small batches (one window per camera frame is the reference's call pattern): the visual tiles and the inertial / wheel /
 // prior factors of a linearisation (MODE 0) or of a candidate evaluation (MODE 1) in ONE launch — the ~35 us of a single
 // lane evaluating an IMU factor hide behind the visual tiles instead of following them on the stream.
-template <int MODE>
+template <int MODE, bool FULL>
 __global__ __launch_bounds__(64, 1) void k_lin_small(BatchDev d) {
   const int w = blockIdx.x, y = blockIdx.y;
-  if (y < d.max_tiles) vis_body<MODE>(d, 0, w, y);
+  if (y < d.max_tiles) vis_body<MODE, FULL>(d, 0, w, y);
   else dense_body<true>(d, MODE, 0, w, y - d.max_tiles);
 }
 
@@ -2000,14 +2016,17 @@ void launch_reset(const BatchDev &d, hipStream_t s) {
 void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   if (d.max_tiles == 0) return;
   const dim3 g(d.B, d.max_tiles), b(LM_TILE);
-  if (mode == 0) hipLaunchKernelGGL(k_vis<0>, g, b, 0, s, d, write_records);
-  else if (mode == 1) hipLaunchKernelGGL(k_vis<1>, g, b, 0, s, d, 0);
-  else hipLaunchKernelGGL(k_vis<2>, g, b, 0, s, d, write_records);
+  // (reduced panel: only when the camera extrinsic and td are constant in EVERY window of the batch and no records are asked for)
+  if (mode == 0 && (d.vis_full || write_records)) hipLaunchKernelGGL((k_vis<0, true>), g, b, 0, s, d, write_records);
+  else if (mode == 0) hipLaunchKernelGGL((k_vis<0, false>), g, b, 0, s, d, 0);
+  else if (mode == 1) hipLaunchKernelGGL((k_vis<1, true>), g, b, 0, s, d, 0);
+  else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s) {
   const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1), b(LM_TILE);
-  if (mode == 0) hipLaunchKernelGGL(k_lin_small<0>, g, b, 0, s, d);
-  else hipLaunchKernelGGL(k_lin_small<1>, g, b, 0, s, d);
+  if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d);
+  else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d);
+  else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d);
 }
 void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
   hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);

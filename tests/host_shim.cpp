@@ -41,6 +41,36 @@ extern "C" int shim_eval_factors(const gfbe_options *opt, const gfbe_window *w, 
       correct_cols(Jt, Jt + 1, 1, r[0], r[1], s1, asn);
       r[0] *= rs; r[1] *= rs;
     }
+    {   // the fused form the linearisation kernels run (visual_lin: corrector folded into `reduce`, explicit FMAs) against the
+        // block-by-block form above, and its reduced variant (constant extrinsic / td) against the full one, bit for bit
+      double r3[2], Ji3[12], Jj3[12], Je3[12], Jl3[2], Jt3[2], r4[2], Ji4[12], Jj4[12], Je4[1], Jl4[2], Jt4[2];
+      const double delta = robust ? opt->huber_delta : 1e150;
+      const double c3 = visual_lin<true, true>(pc, w->para_Feature[v.feature_index[k]], st.para_Td, v.pts_i[3 * k], v.pts_i[3 * k + 1],
+                                               v.pts_i[3 * k + 2], v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_i[2 * k], v.vel_i[2 * k + 1],
+                                               v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_i[k], v.td_j[k], opt->vis_sqrt_info, delta, r3, Ji3, Jj3, Je3, Jl3, Jt3);
+      const double c4 = visual_lin<true, false>(pc, w->para_Feature[v.feature_index[k]], st.para_Td, v.pts_i[3 * k], v.pts_i[3 * k + 1],
+                                                v.pts_i[3 * k + 2], v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_i[2 * k], v.vel_i[2 * k + 1],
+                                                v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_i[k], v.td_j[k], opt->vis_sqrt_info, delta, r4, Ji4, Jj4, Je4, Jl4, Jt4);
+      double rc[2], cc;
+      cc = visual_lin<false, true>(pc, w->para_Feature[v.feature_index[k]], st.para_Td, v.pts_i[3 * k], v.pts_i[3 * k + 1],
+                                   v.pts_i[3 * k + 2], v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_i[2 * k], v.vel_i[2 * k + 1],
+                                   v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_i[k], v.td_j[k], opt->vis_sqrt_info, delta, rc, nullptr, nullptr, nullptr, nullptr, nullptr);
+      if (c3 != c4 || c3 != cc) return 3;                       // the candidate-cost pass sees the same cost as the linearisation
+      double scale = 1.0, err = 0.0;
+      for (int q = 0; q < 12; q++) { scale = fmax(scale, fabs(Ji[q])); scale = fmax(scale, fabs(Je[q])); }
+      for (int q = 0; q < 12; q++) {
+        err = fmax(err, fabs(Ji[q] - Ji3[q])); err = fmax(err, fabs(Jj[q] - Jj3[q])); err = fmax(err, fabs(Je[q] - Je3[q]));
+        if (Ji3[q] != Ji4[q] || Jj3[q] != Jj4[q]) return 4;
+      }
+      for (int q = 0; q < 2; q++) {
+        err = fmax(err, fabs(Jl[q] - Jl3[q]) / fmax(1.0, fabs(Jl[q]))); err = fmax(err, fabs(Jt[q] - Jt3[q])); err = fmax(err, fabs(r[q] - r3[q]));
+        if (Jl3[q] != Jl4[q] || r3[q] != r4[q]) return 4;
+      }
+      if (err > 1e-11 * scale) return 5;
+      // what leaves the shim is the kernels' form
+      for (int q = 0; q < 12; q++) { Ji[q] = Ji3[q]; Jj[q] = Jj3[q]; Je[q] = Je3[q]; }
+      for (int q = 0; q < 2; q++) { Jl[q] = Jl3[q]; Jt[q] = Jt3[q]; r[q] = r3[q]; }
+    }
     vis_r[2 * k] = r[0]; vis_r[2 * k + 1] = r[1];
     double *J = vis_J + 40 * (size_t)k;
     for (int row = 0; row < 2; row++) {
