@@ -36,7 +36,8 @@ enum {
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)
   XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
-  HC = 13                     // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
+  HC = 13,                    // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
+  PAIR_CONST_DOUBLES = 63     // sizeof(PairConst) / 8 (gfbe_factors.h; static_assert in gfbe_kernels.hip)
 };
 
 // tangent offsets (same convention as the ABI's block order)
@@ -139,6 +140,10 @@ struct BatchDev {
   gfbe_options opt;
   // dense parameters: x0 = uploaded state, x[2] = current/candidate, xout = re-anchored result
   double *x0, *x, *xout;      // [B][NA], [B][2][NA], [B][NA]
+  // pose-pair constants of the visual factors (PairConst, gfbe_factors.h) of the three states a window can be evaluated at:
+  // [B][3][NPAIR][PC_DOUBLES] — slot 0 / 1 follow x[0] / x[1], slot 2 the re-anchored state xout. Written by the single-wave
+  // kernels that produce those states (k_reset, k_candidate, k_reanchor); every visual tile then just loads its <= 10 records.
+  double *pc;
   // landmarks (internal order: sorted by start frame, tile aligned). SoA over tot_lm slots.
   int *lm_info;               // start | m << 8 | const << 16 | valid << 24
   int *lm_abi;                // ABI feature_index of the slot (-1 for padding)

@@ -88,10 +88,15 @@ GF_HD void visual_eval(const PoseRT &Fi, const PoseRT &Fj, const PoseRT &Ex, dou
 //   d/dtheta_j :  ric^T [P_bj]x    =  [P_cj + ric^T tic]x ric^T
 //   d/dtheta_ex: -Tm [P_ci]x + [Tm P_ci]x + [u]x = [Tm P_ci]x (I - Tm) + [u]x
 // ---------------------------------------------------------------------------------------------
-struct PairConst {
-  mat3 A, B, Tm, ricT, ImTm, jep;   // jep = B - ric^T  (translation block of the extrinsic)
+// (the members a window with constant extrinsic / td needs come first: the reduced kernels stage only that prefix in LDS)
+struct PairConstR {
+  mat3 A, B, Tm, ricT;
   vec3 u, Btic, c2;                 // c2 = ric^T tic
 };
+struct PairConst : PairConstR {
+  mat3 ImTm, jep;                   // jep = B - ric^T  (translation block of the extrinsic)
+};
+enum { PC_DOUBLES = sizeof(PairConst) / sizeof(double), PCR_DOUBLES = sizeof(PairConstR) / sizeof(double) };
 GF_HD PairConst make_pair_const(const PoseRT &Fi, const PoseRT &Fj, const PoseRT &Ex) {
   PairConst p;
   p.ricT = transp(Ex.R);
@@ -212,8 +217,8 @@ GF_HD void correct_cols(double *row0, double *row1, int n, double r0, double r1,
 //     for constant blocks (projectionTwoFrameOneCamFactor.cpp:122,141).
 // Returns 0.5 rho(|r|^2). JAC = false: cost only (r is the uncorrected residual).
 // ---------------------------------------------------------------------------------------------
-template <bool JAC, bool FULL>
-GF_HD double visual_lin(const PairConst &pc, double inv_dep, double td, double pix, double piy, double piz, double pjx,
+template <bool JAC, bool FULL, typename PC>
+GF_HD double visual_lin(const PC &pc, double inv_dep, double td, double pix, double piy, double piz, double pjx,
                         double pjy, double vix, double viy, double vjx, double vjy, double td_i, double td_j,
                         double sqrt_info, double delta, double *r, double *Ji, double *Jj, double *Je, double *Jl, double *Jt) {
   const double dti = td - td_i, dtj = td - td_j;
@@ -251,7 +256,7 @@ GF_HD double visual_lin(const PairConst &pc, double inv_dep, double td, double p
                  j2 = __builtin_fma(b0, pc.ricT(1, c), -(b1 * pc.ricT(0, c)));
     Jj[3 + c] = __builtin_fma(r00, j0, r02 * j2);
     Jj[9 + c] = __builtin_fma(r00, j1, r12 * j2);
-    if (FULL) {
+    if constexpr (FULL) {
       Je[c] = __builtin_fma(r00, pc.jep(0, c), r02 * pc.jep(2, c));
       Je[6 + c] = __builtin_fma(r00, pc.jep(1, c), r12 * pc.jep(2, c));
       // [q]x (I - Tm) + [u]x
@@ -265,7 +270,7 @@ GF_HD double visual_lin(const PairConst &pc, double inv_dep, double td, double p
   // d/d lambda = -reduce q / lambda
   Jl[0] = -(__builtin_fma(r00, q[0], r02 * q[2]) * inv_l);
   Jl[1] = -(__builtin_fma(r00, q[1], r12 * q[2]) * inv_l);
-  if (FULL) {   // d/d td = -reduce Tm [v_i; 0] / lambda + sqrt(rho') sqrt_info v_j
+  if constexpr (FULL) {   // d/d td = -reduce Tm [v_i; 0] / lambda + sqrt(rho') sqrt_info v_j
     const double t0 = __builtin_fma(pc.Tm(0, 0), vix, pc.Tm(0, 1) * viy), t1 = __builtin_fma(pc.Tm(1, 0), vix, pc.Tm(1, 1) * viy);
     const double t2 = __builtin_fma(pc.Tm(2, 0), vix, pc.Tm(2, 1) * viy);
     Jt[0] = __builtin_fma(si, vjx, -(__builtin_fma(r00, t0, r02 * t2) * inv_l));
@@ -280,7 +285,7 @@ GF_HD double visual_lin(const PairConst &pc, double inv_dep, double td, double p
       }
     };
     fix(Ji, Ji + 6, 6); fix(Jj, Jj + 6, 6); fix(Jl, Jl + 1, 1);
-    if (FULL) { fix(Je, Je + 6, 6); fix(Jt, Jt + 1, 1); }
+    if constexpr (FULL) { fix(Je, Je + 6, 6); fix(Jt, Jt + 1, 1); }
   }
   r[0] = r0 * rs;
   r[1] = r1 * rs;

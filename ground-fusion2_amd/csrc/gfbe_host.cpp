@@ -720,6 +720,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
     if (B < DENSE_SPLIT_MIN_B && c->world == 1) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
     AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
+    AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
     AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
     AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36); AL(prior_H, (size_t)B * ND * ND);

@@ -21,6 +21,7 @@
 //   k_reanchor     Estimator::double2vector gauge fix (estimator/estimator.cpp:2501-2555)
 #include "gfbe_device.h"
 #include "gfbe_factors.h"
+#include <type_traits>
 
 namespace gfd {
 
@@ -119,6 +120,26 @@ __global__ __launch_bounds__(256) void k_prep(BatchDev d) {
   }
 }
 
+// Pose-pair constants of the visual factors at state X (gfbe_state layout) for all 55 pairs i < j: ONE wave (lanes 0..63 of the
+// calling workgroup; `sp` = 12 PoseRT of LDS), one pair per lane. Called by the kernels that produce a state; the visual
+// tiles (36 workgroups per window and pass) load the records instead of rebuilding them from the poses each.
+static_assert(PC_DOUBLES == PAIR_CONST_DOUBLES, "PairConst layout");
+__device__ __forceinline__ void pair_consts_of_state(const double *X, double *pc_out, PoseRT *sp, int lane) {
+  if (lane < NF) sp[lane] = make_pose(X + A_POSE(lane));
+  if (lane == NF) sp[NF] = make_pose(X + A_EX);
+  __syncthreads();
+  if (lane < NF * (NF - 1) / 2) {
+    int i = 0, rem = lane;
+    while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
+    const int j = i + 1 + rem;
+    const PairConst p = make_pair_const(sp[i], sp[j], sp[NF]);
+    double *o = pc_out + (size_t)(i * NF + j) * PC_DOUBLES;
+    const double *src = (const double *)&p;
+#pragma unroll
+    for (int q = 0; q < PC_DOUBLES; q++) o[q] = src[q];
+  }
+}
+
 // =============================================================================================
 // k_reset: start of every solve — restore the uploaded state, reset the trust-region bookkeeping.
 // =============================================================================================
@@ -126,7 +147,9 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
   const int w = blockIdx.y;
   const WinDesc &ds = d.desc[w];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ PoseRT sp_reset[NF + 1];
   if (blockIdx.x == 0) {
+    pair_consts_of_state(d.x0 + (size_t)w * NA, d.pc + (size_t)w * 3 * NPAIR * PC_DOUBLES, sp_reset, threadIdx.x);   // (block-uniform branch: the barrier inside is safe)
     if (threadIdx.x < NA) {
       const double v = d.x0[(size_t)w * NA + threadIdx.x];
       d.x[((size_t)w * 2) * NA + threadIdx.x] = v;
@@ -181,14 +204,19 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #define KSTAMP(i) do { } while (0)
 #endif
   KSTAMP(0);
-  __shared__ PoseRT sp[NF + 1];
-  __shared__ PairConst pcs[NF];          // pair (sframe, j) constants, j = sframe+1 .. 10
-  __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XS_LD];   // one [J | r] row of each of the wave's 64 factors
+  // pair (sframe, j) constants, j = sframe+1 .. 10, from the records the state's producer left (k_reset / k_candidate /
+  // k_reanchor): one coalesced load instead of 12 quaternion -> matrix conversions, 10 triple products and two barriers per
+  // tile. A window with constant extrinsic and td stages only the members its Jacobian blocks need (PairConstR).
+  typedef typename std::conditional<FULL, PairConst, PairConstR>::type PCT;
+  constexpr int PCW = sizeof(PCT) / sizeof(double), XLD = FULL ? XS_LD : 17;
+  __shared__ PCT pcs[NF];
+  __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XLD];   // one [J | r] row of each of the wave's 64 factors
   const int lane = threadIdx.x;
-  if (lane < NF) sp[lane] = make_pose(X + A_POSE(lane));
-  if (lane == NF) sp[NF] = make_pose(X + A_EX);
-  __syncthreads();
-  if (lane > sframe && lane < NF) pcs[lane] = make_pair_const(sp[sframe], sp[lane], sp[NF]);
+  {
+    const double *src = d.pc + (((size_t)w * 3 + (MODE == 2 ? 2 : buf)) * NPAIR + sframe * NF) * PC_DOUBLES;
+    for (int j = sframe + 1; j < NF; j++)
+      if (lane < PCW) ((double *)&pcs[j])[lane] = src[(size_t)j * PC_DOUBLES + lane];
+  }
   __syncthreads();
   const double td = X[A_TD];
   const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
@@ -214,7 +242,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
   for (int q = 0; q < NHC; q++) hC[q] = 0.0;
   if (MODE != 1 && !FULL) {   // reduced panel [Ji Jj r 0 0 0]: the three padding columns are written once
-    double *xr = xs + lane * XS_LD;
+    double *xr = xs + lane * XLD;
     xr[13] = 0.0; xr[14] = 0.0; xr[15] = 0.0;
   }
   // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length are zero in memory)
@@ -306,7 +334,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       for (int h = 0; h < 2; h++) {
         if (k < 5 && h == 1) KSTAMP(6 + 5 * k);
         {
-          double *xr = xs + lane * XS_LD;
+          double *xr = xs + lane * XLD;
 #pragma unroll
           for (int q = 0; q < 6; q++) { xr[q] = Ji[6 * h + q]; xr[6 + q] = Jj[6 * h + q]; if (FULL) xr[12 + q] = Je[6 * h + q]; }
           if (FULL) { xr[18] = Jt[h]; xr[19] = r[h]; }
@@ -319,7 +347,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
           double va[8], vb[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            const double *rowp = xs + (4 * (8 * blk + u) + lk) * XS_LD;
+            const double *rowp = xs + (4 * (8 * blk + u) + lk) * XLD;
             va[u] = rowp[lr];
             if (FULL) vb[u] = rowp[16 + lj];
           }
@@ -332,7 +360,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
         if (FULL) {
           double vc[LM_TILE / 16];
 #pragma unroll
-          for (int qd = 0; qd < LM_TILE / 16; qd++) vc[qd] = xs[(16 * qd + 4 * lb + lk) * XS_LD + 16 + lj];
+          for (int qd = 0; qd < LM_TILE / 16; qd++) vc[qd] = xs[(16 * qd + 4 * lb + lk) * XLD + 16 + lj];
 #pragma unroll
           for (int qd = 0; qd < LM_TILE / 16; qd++) acc2 = __builtin_amdgcn_mfma_f64_4x4x4f64(vc[qd], vc[qd], acc2, 0, 0, 0);
         }
@@ -1832,6 +1860,11 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
     }
     d2 = wave_sum(d2); n2 = wave_sum(n2);
     if (t == 0) { d.dense_cand[(size_t)w * 4 + 1] = d2; d.dense_cand[(size_t)w * 4 + 2] = n2; }
+    // the candidate's pose-pair constants, for its cost evaluation and — if it is accepted — the next linearisation
+    __shared__ PoseRT sp_cand[NF + 1];
+    __threadfence_block();
+    __syncthreads();
+    pair_consts_of_state(Y, d.pc + ((size_t)w * 3 + (1 - c.cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
   }
 }
 
@@ -1924,6 +1957,11 @@ __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
     const quat q = rot2quat(qrot(qnormalize(ldq(X + A_EXW + 3))));
     Y[A_EXW + 3] = q.x; Y[A_EXW + 4] = q.y; Y[A_EXW + 5] = q.z; Y[A_EXW + 6] = q.w;
   }
+  // pose-pair constants of the re-anchored state: the marginalisation linearises its visual factors there
+  __shared__ PoseRT sp_anch[NF + 1];
+  __threadfence_block();
+  __syncthreads();
+  pair_consts_of_state(Y, d.pc + ((size_t)w * 3 + 2) * NPAIR * PC_DOUBLES, sp_anch, t);
 }
 
 // =============================================================================================
