@@ -31,6 +31,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# eight hardware queues instead of the HIP runtime's default four (before the runtime starts): the upload / download streams then
+# do not share a queue with a solve (gfbe_create sets the same default for callers that have not initialised HIP yet)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 
@@ -46,9 +49,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block")
-    ap.add_argument("--e2e-batch", type=int, default=512, help="windows per batch of the end-to-end loops (two batches in flight)")
+    ap.add_argument("--e2e-batch", type=int, default=1024, help="windows per batch of the end-to-end loops")
     ap.add_argument("--e2e-steps", type=int, default=8)
-    ap.add_argument("--e2e-depth", type=int, default=3, help="batches in flight in the end-to-end loops")
+    ap.add_argument("--e2e-depth", type=int, default=2, help="batches in flight in the end-to-end loops")
     ap.add_argument("--host-threads", type=int, default=0, help="gfbe_options.host_threads (0: library default)")
     ap.add_argument("--split", type=int, default=None, help="gfbe_options.split_batch: parts a batch of >= 128 windows is solved in, side by side (library default: 2)")
     ap.add_argument("--graph", action="store_true", help="gfbe_options.use_graph: replay the launch sequence as a hipGraph")

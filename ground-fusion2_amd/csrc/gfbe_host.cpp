@@ -118,6 +118,10 @@ struct gfbe_ctx {
   std::vector<std::pair<void *, size_t>> pin_cache;   // pinned host staging of freed batches
   std::unique_ptr<HostPool> pool;                     // packing threads (gfbe_options.host_threads)
   bool want_records = false;                          // gfbe_eval_factors: allocate the block-CSR record array
+  // streams / events of the extra parts of split batches, recycled (creating and destroying two streams and four events
+  // per uploaded batch cost ~2 ms of host time and synchronised with the device)
+  struct LaneSet { hipStream_t s, aux; hipEvent_t fork, join, start2, done2; };
+  std::vector<LaneSet> lane_pool;
 };
 // (a 1024-window batch of 2k-landmark windows is a 7 GB slab; 288 GB of HBM leave room to keep a few)
 enum : size_t { SLAB_CACHE_ENTRIES = 6, SLAB_CACHE_MAX_BYTES = (size_t)48 << 30, PIN_CACHE_ENTRIES = 12, PIN_CACHE_MAX_BYTES = (size_t)8 << 30 };
@@ -218,6 +222,11 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   c->device = device;
   *out = c;
   if (device < 0) return GFBE_OK;   // host-only context: bookkeeping entry points only
+  // A context drives up to eight streams (two parts x (main + dense-factor stream), upload, download, the caller's): with the
+  // HIP runtime's default of four hardware queues they share queues and an upload queues up behind a whole solve. Only
+  // effective when the runtime has not been initialised yet in this process (a caller that initialises HIP first sets it
+  // itself: INTEGRATION.md); never overrides the caller's own setting.
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= device) {
     c->err = "no HIP device " + std::to_string(device) + " visible (the HIP back end has no CPU fallback)";
@@ -252,6 +261,10 @@ void gfbe_destroy(gfbe_ctx *c) {
   if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
   if (c->dl) { (void)hipStreamSynchronize(c->dl); (void)hipStreamDestroy(c->dl); }
   for (auto &sl : c->pin_cache) (void)hipHostFree(sl.first);
+  for (auto &l : c->lane_pool) {
+    (void)hipStreamDestroy(l.s); (void)hipStreamDestroy(l.aux);
+    for (hipEvent_t e : {l.fork, l.join, l.start2, l.done2}) (void)hipEventDestroy(e);
+  }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (auto &sl : c->slab_cache) (void)hipFree(sl.first);
@@ -908,6 +921,12 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b);
 // Batches of >= BATCH_SPLIT_MIN_B windows become `split_batch` parts (default two halves) solved side by side, each on
 // its own pair of streams: a chain a -> a->second -> ...; part k + 1 runs on part k's `lane2`.
 static gfbe_status make_lane(gfbe_ctx *c, gfbe_batch *a) {
+  if (!c->lane_pool.empty()) {
+    const gfbe_ctx::LaneSet l = c->lane_pool.back();
+    c->lane_pool.pop_back();
+    a->lane2 = {l.s, l.aux, l.fork, l.join}; a->ev_start2 = l.start2; a->ev_done2 = l.done2;
+    return GFBE_OK;
+  }
   if (hipStreamCreateWithFlags(&a->lane2.s, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&a->lane2.aux, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&a->lane2.fork, hipEventDisableTiming) != hipSuccess ||
@@ -977,11 +996,15 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
   // wait for THIS batch's work only (upload, last solve, download): other batches of the context keep running
   for (hipEvent_t e : {b->ev_up, b->ev_done, b->ev_dl}) if (e) (void)hipEventSynchronize(e);
   if (b->second) {
-    if (b->lane2.s) (void)hipStreamSynchronize(b->lane2.s);
+    // (the part's own events are waited for in the recursive call; its streams are pooled and may already serve a newer batch)
     gfbe_batch_free(c, b->second);
-    if (b->lane2.s) (void)hipStreamDestroy(b->lane2.s);
-    if (b->lane2.aux) (void)hipStreamDestroy(b->lane2.aux);
-    for (hipEvent_t e : {b->lane2.fork, b->lane2.join, b->ev_start2, b->ev_done2}) if (e) (void)hipEventDestroy(e);
+    if (c && b->lane2.s && b->lane2.aux && b->lane2.fork && b->lane2.join && b->ev_start2 && b->ev_done2 && c->lane_pool.size() < 16) {
+      c->lane_pool.push_back({b->lane2.s, b->lane2.aux, b->lane2.fork, b->lane2.join, b->ev_start2, b->ev_done2});   // (idle: the part's events were waited for)
+    } else {
+      if (b->lane2.s) (void)hipStreamDestroy(b->lane2.s);
+      if (b->lane2.aux) (void)hipStreamDestroy(b->lane2.aux);
+      for (hipEvent_t e : {b->lane2.fork, b->lane2.join, b->ev_start2, b->ev_done2}) if (e) (void)hipEventDestroy(e);
+    }
   }
   for (auto &g : b->graph) if (g) (void)hipGraphExecDestroy(g);
   for (hipEvent_t e : {b->ev_up, b->ev_done, b->ev_dl}) if (e) (void)hipEventDestroy(e);
