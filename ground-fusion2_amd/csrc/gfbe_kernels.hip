@@ -1302,12 +1302,18 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {   // src is wa
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-// In-place lower Cholesky of one 16 x 16 LDS tile by a single wave: lane i < 16 keeps row i in
-// registers, column entries travel through v_readlane. On exit the diagonal holds 1 / L[k][k]
-// (the panel solve and the substitutions multiply by it). Returns false on a bad pivot.
-__device__ __noinline__ bool chol_tile16(double *T, int lane) {
+// Lower Cholesky of one 16 x 16 LDS tile by a single wave, replaced IN PLACE by the inverse of its factor, W = L^-1
+// (lower triangular, the upper triangle written as zeros). With W the panel step X L^T = A becomes the matrix-core product
+// X = A W^T (no 16-step substitution per row any more) and the back-substitution a 16 x 16 matrix-vector product per panel.
+//   phase 1: lane i < 16 keeps row i in registers, column entries travel through v_readlane (diagonal kept as 1 / L[k][k]);
+//   phase 2: L goes through the tile, lane j computes column j of W by forward substitution (broadcast LDS reads).
+// Returns false on a bad pivot.
+// zrow >= 0: row `zrow` of L (the right-hand side row of the LAST diagonal tile: z of the last partial panel) is saved to zout
+// before the tile is overwritten.
+__device__ __noinline__ bool chol_inv_tile16(double *T, int lane, int zrow, double *zout, double *stamp = nullptr) {
   double row[TB];
   const int li = lane & 15;
+  if (stamp && lane == 0) stamp[21] = (double)wall_clock64();
 #pragma unroll
   for (int q = 0; q < TB; q++) row[q] = T[tsw(li, q)];
   bool ok = true;
@@ -1327,7 +1333,35 @@ __device__ __noinline__ bool chol_tile16(double *T, int lane) {
   if (lane < TB) {
 #pragma unroll
     for (int q = 0; q < TB; q++) T[tsw(li, q)] = row[q];
+    if (lane == zrow) {
+#pragma unroll
+      for (int q = 0; q < TB; q++) zout[q] = row[q];
+    }
   }
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  if (stamp && lane == 0) stamp[22] = (double)wall_clock64();
+  // W[j][j] = 1 / L[j][j];  W[i][j] = -(1 / L[i][i]) sum_{k < i} L[i][k] W[k][j]   (W[k][j] = 0 for k < j)
+  double wc[TB];
+  if (lane < TB) {
+#pragma unroll
+    for (int i = 0; i < TB; i++) {
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < i; k++) {
+        const double l = T[tsw(i, k)];
+        if (k & 1) acc1 = __builtin_fma(l, wc[k], acc1); else acc0 = __builtin_fma(l, wc[k], acc0);
+      }
+      const double dinv = T[tsw(i, i)];
+      wc[i] = (i < li) ? 0.0 : ((i == li) ? dinv : -((acc0 + acc1) * dinv));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();            // every read of L is done before the tile is overwritten
+  if (lane < TB) {
+#pragma unroll
+    for (int i = 0; i < TB; i++) T[tsw(i, li)] = wc[i];
+  }
+  if (stamp && lane == 0) stamp[23] = (double)wall_clock64();
   return ok;
 }
 
@@ -1337,8 +1371,9 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ int perm[ND + TB];
+  __shared__ short perm[ND + TB];     // (16-bit: the 160 KB of LDS are full — 78 tiles of 2 KB for a fully active window)
   __shared__ double red[16], ys[2 * ND + TB];
+  __shared__ double s_zz, s_vSv, zlast[TB];
   __shared__ int flag, s_nact;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
@@ -1415,18 +1450,23 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     //      [ rhs' big ]
     const int ntile_all = nt * (nt + 1) / 2;
     // scaling and right-hand side staged in LDS (ys is free until the back-substitution)
-    for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0); }
+    // scaling and the Cauchy direction v staged in LDS (ys is free until the back-substitution; the right-hand side row
+    // gt - s eg is read where it is placed: one tile row)
+    for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = gvp[a]; }
     __syncthreads();
+    double vsv = 0.0;      // v^T S v, summed over the tile entries as they are built (off-diagonal tiles stand for both triangles)
     for (int te0 = t >> 8; te0 < ntile_all; te0 += BUILD_UNROLL * (SOLVE_THREADS >> 8)) {   // BUILD_UNROLL tiles per thread group in flight
       const int r = (t & 255) >> 4, cc = t & 15;
       double hv[BUILD_UNROLL], ev[BUILD_UNROLL];
       int aa[BUILD_UNROLL], bb[BUILD_UNROLL], kind[BUILD_UNROLL];
+      bool offdiag[BUILD_UNROLL];
 #pragma unroll
       for (int u = 0; u < BUILD_UNROLL; u++) {
         const int te = te0 + u * (SOLVE_THREADS >> 8);
         int I = 0, J = te;
         while (J > I) { J -= I + 1; I++; }
         const int ia = I * TB + r, ib = J * TB + cc;
+        offdiag[u] = I != J;
         kind[u] = 0; aa[u] = 0; bb[u] = 0; hv[u] = 0.0; ev[u] = 0.0;
         if (te < ntile_all) {
           if (ia < n && ib < n) {
@@ -1449,53 +1489,54 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
           if (aa[u] < NV && bb[u] < NV) v -= ev[u];
           v *= ys[aa[u]] * ys[bb[u]];
           if (aa[u] == bb[u]) { const double dp = gDp[aa[u]]; v += mu * dp * dp; }
-        } else if (kind[u] == 2) v = ys[ND + bb[u]];
+          vsv = __builtin_fma(v * ys[ND + aa[u]], ys[ND + bb[u]] * (offdiag[u] ? 2.0 : 1.0), vsv);
+        } else if (kind[u] == 2) v = ggts[bb[u]] - (bb[u] < NV ? gsp[bb[u]] * eg[bb[u]] : 0.0);
         else v = kind[u] == 4 ? 1e200 : (kind[u] == 3 ? 1.0 : 0.0);
         smem[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
       }
     }
-    if (t == 0) flag = 0;
+    vsv = block_sum(vsv, red);
+    if (t == 0) { flag = 0; s_vSv = vsv; }
     __syncthreads();
     STAMP(2);
-    // ---- blocked right-looking Cholesky: diagonal tile (1 wave) -> panel solve (thread per row) ->
-    //      trailing update on the FP64 matrix cores (v_mfma_f64_16x16x4_f64)
-    // The diagonal tile of panel P + 1 is factorised by the wave that has just updated it (wave 0 takes it first
-    // in the trailing update), while the other waves are still updating: only panel 0 pays for its own diagonal tile.
-    if (wave == 0) { if (!chol_tile16(smem + (size_t)tile_idx(0, 0) * (TB * TB), lane) && lane == 0) flag = 1; }
+    // ---- blocked right-looking Cholesky on the FP64 matrix cores. Per panel P:
+    //        W_P = L_PP^-1 in place of the diagonal tile (one wave, chol_inv_tile16)
+    //        L_IP = A_IP W_P^T for every tile below it (one v_mfma_f64_16x16x4_f64 chain per tile; the right-hand side row is one
+    //        of them: forward substitution for free)
+    //        trailing tiles (I, J) -= L_IP L_JP^T; the wave that updates tile (P+1, P+1) first factorises and inverts it right
+    //        away, while the other waves are still updating: only panel 0 pays for its own diagonal tile.
+    //      Two block barriers per panel.
+    if (wave == 0) { if (!chol_inv_tile16(smem + (size_t)tile_idx(0, 0) * (TB * TB), lane, nt == 1 ? n % TB : -1, zlast) && lane == 0) flag = 1; }
     __syncthreads();
+    const int lr = lane & 15, lk = lane >> 4;
     for (int P = 0; P < nt; P++) {
-      double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+      const double *Wp = smem + (size_t)tile_idx(P, P) * (TB * TB);
       if (P == 0) STAMP(17);
       if (flag) break;
-      const int rows = (nt - 1 - P) * TB;
-      if (t < rows) {
-        const int I = P + 1 + (t >> 4), r = t & 15;
+      for (int I = P + 1 + wave; I < nt; I += (SOLVE_THREADS >> 6)) {
         double *tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
-        double x[TB];
+        dbl4 acc = {0.0, 0.0, 0.0, 0.0};
+        double va[4], vb[4];
 #pragma unroll
-        for (int q = 0; q < TB; q++) x[q] = tip[tsw(r, q)];
+        for (int q = 0; q < 4; q++) { va[q] = tip[tsw(lr, q * 4 + lk)]; vb[q] = Wp[tsw(lr, q * 4 + lk)]; }
 #pragma unroll
-        for (int cidx = 0; cidx < TB; cidx++) {
-          double acc = x[cidx];
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
 #pragma unroll
-          for (int k = 0; k < cidx; k++) acc -= x[k] * Tpp[tsw(cidx, k)];
-          x[cidx] = acc * Tpp[tsw(cidx, cidx)];   // diagonal holds 1 / L[c][c]
-        }
-#pragma unroll
-        for (int q = 0; q < TB; q++) tip[tsw(r, q)] = x[q];
+        for (int q = 0; q < 4; q++) tip[tsw(lk + 4 * q, lr)] = acc[q];
       }
       __syncthreads();
       if (P == 0) STAMP(18);
       // trailing tiles (I, J), P < J <= I, round-robin over the waves
       const int nrem = nt - 1 - P;
       const int ntr = nrem * (nrem + 1) / 2;
-      for (int e = wave; e < ntr; e += (SOLVE_THREADS >> 6)) {
+      // (wave 0 takes tile (P+1, P+1) and its factor-and-invert — the critical chain — and nothing else; the other tiles go
+      // round-robin over waves 1..15)
+      for (int e = (wave == 0 ? 0 : wave); e < ntr; e += (wave == 0 ? ntr : (SOLVE_THREADS >> 6) - 1)) {
         int ii = 0, rr = e;
         while (rr > ii) { rr -= ii + 1; ii++; }
         const int I = P + 1 + ii, J = P + 1 + rr;
         const double *LI = smem + (size_t)tile_idx(I, P) * (TB * TB), *LJ = smem + (size_t)tile_idx(J, P) * (TB * TB);
         double *C = smem + (size_t)tile_idx(I, J) * (TB * TB);
-        const int lr = lane & 15, lk = lane >> 4;
         dbl4 acc;
         double va[4], vb[4];
 #pragma unroll
@@ -1504,10 +1545,10 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
         for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; q++) C[tsw(lk + 4 * q, lr)] = acc[q];
-        if (e == 0) {   // tile (P+1, P+1) is final now: factorise it here (wave 0), ahead of the block barrier
+        if (e == 0) {   // tile (P+1, P+1) is final now: factorise and invert it here (wave 0), ahead of the block barrier
           __threadfence_block();
           __builtin_amdgcn_wave_barrier();
-          if (!chol_tile16(C, lane) && lane == 0) flag = 1;
+          if (!chol_inv_tile16(C, lane, P + 2 == nt ? n % TB : -1, zlast, P == 0 ? stamp : nullptr) && lane == 0) flag = 1;
         }
       }
       if (P == 0) STAMP(20);
@@ -1518,47 +1559,49 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid) ok = false;   // fault injection: first attempt of that iteration
     STAMP(3);
     if (ok) {
-      // z = L^-1 rhs sits in row n of L. Backward substitution y = L^-T z by ONE wave without block barriers (two
-      // 1024-thread barriers per panel cost more than the arithmetic): for panel P, lane (c, part) gathers
-      // sum_{I > P, I = P + 1 + part mod 4} L(I,P)^T y_I for column c, the four parts meet through two shuffles, then
-      // the 16 x 16 triangular solve runs in registers (lane i keeps y_i and column i of L_PP).
-      for (int i = t; i < n; i += blockDim.x)
-        ys[i] = smem[(size_t)tile_idx(n / TB, i / TB) * (TB * TB) + tsw(n % TB, i % TB)];
+      // z = L^-1 rhs sits in row n of the factor; y^T S y = |z|^2. Backward substitution y = L^-T z by ONE wave without
+      // block barriers: for panel P, lane (c, part) gathers sum_{I > P} L(I,P)^T y_I for column c over its four rows of every
+      // tile, the four parts meet through two shuffles, and y_P = W_P^T (z_P - sum) is a 16 x 16 matrix-vector product.
+      double zz = 0.0;
+      for (int i = t; i < n + TB; i += blockDim.x) {
+        // (the entries of the last diagonal tile were saved before the tile became its own inverse)
+        const double z = i < n ? (i / TB == n / TB ? zlast[i % TB] : smem[(size_t)tile_idx(n / TB, i / TB) * (TB * TB) + tsw(n % TB, i % TB)]) : 0.0;
+        ys[i] = z;                                   // (zeros behind n: the rows of the last tile past the system)
+        zz += z * z;
+      }
+      zz = block_sum(zz, red);
+      if (t == 0) s_zz = zz;
       __syncthreads();
       if (wave == 0) {
-        const int li = lane & 15, part = lane >> 4;
+        const int cI = lane & 15, part = lane >> 4;
         const int np = (n - 1) / TB;
         for (int P = np; P >= 0; P--) {
-          const double *Tpp = smem + (size_t)tile_idx(P, P) * (TB * TB);
-          const int r0 = P * TB, cnt = min(TB, n - r0);
-          double sacc = 0.0;
-          for (int I = P + 1 + part; I <= np; I += 4) {
+          const double *Wt = smem + (size_t)tile_idx(P, P) * (TB * TB);
+          const int r0 = P * TB;
+          double s0 = 0.0, s1 = 0.0;
+          for (int I = P + 1; I <= np; I++) {
             const double *Tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
-            const int rI = I * TB, cI = min(TB, n - rI);
-#pragma unroll
-            for (int h = 0; h < TB; h += 8) {
-              double lv[8], yv[8];
-#pragma unroll
-              for (int k = 0; k < 8; k++) { lv[k] = Tip[tsw(h + k, li)]; yv[k] = ys[rI + h + k]; }   // (ys has TB slack behind n)
-#pragma unroll
-              for (int k = 0; k < 8; k++) if (h + k < cI) sacc += lv[k] * yv[k];
-            }
+            const int rI = I * TB + 4 * part;
+            s0 = __builtin_fma(Tip[tsw(4 * part, cI)], ys[rI], s0);
+            s1 = __builtin_fma(Tip[tsw(4 * part + 1, cI)], ys[rI + 1], s1);
+            s0 = __builtin_fma(Tip[tsw(4 * part + 2, cI)], ys[rI + 2], s0);
+            s1 = __builtin_fma(Tip[tsw(4 * part + 3, cI)], ys[rI + 3], s1);
           }
+          double sacc = s0 + s1;
           sacc += __shfl_xor(sacc, 16, 64);
           sacc += __shfl_xor(sacc, 32, 64);
-          double colv[TB];
+          const double tc = ys[r0 + cI] - sacc;       // (entries past n: 0 - 0)
+          // y_j = sum_i W[i][j] t_i: lane (j, part) takes rows i = 4 part .. 4 part + 3; t_i comes from lane i
+          double yj = 0.0;
 #pragma unroll
-          for (int k = 0; k < TB; k++) colv[k] = Tpp[tsw(k, li)];     // L[k][i]; [k][k] is 1 / L[k][k]
-          double yi = (li < cnt) ? ys[r0 + li] - sacc : 0.0;
-#pragma unroll
-          for (int k = TB - 1; k >= 0; k--) {
-            if (k < cnt) {
-              const double yk = lane_bcast(yi, k) * lane_bcast(colv[k], k);
-              if (li == k) yi = yk;
-              else if (li < k) yi -= colv[k] * yk;
-            }
+          for (int h = 0; h < 4; h++) {
+            const int i = 4 * part + h;
+            yj = __builtin_fma(Wt[tsw(i, cI)], __shfl(tc, i, 64), yj);
           }
-          if (lane < cnt) ys[r0 + lane] = yi;
+          yj += __shfl_xor(yj, 16, 64);
+          yj += __shfl_xor(yj, 32, 64);
+          __builtin_amdgcn_wave_barrier();
+          if (lane < TB && r0 + lane < n) ys[r0 + lane] = yj;
           __threadfence_block();
           __builtin_amdgcn_wave_barrier();
         }
@@ -1584,41 +1627,39 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     return;
   }
   STAMP(4);
-  // dense shares of the dogleg scalars: v^T Ht v, y^T Ht v, y^T Ht y with Ht = s H s, as double sums over the lower
-  // triangle (a, b <= a): wave `wave` takes rows a = wave, wave + 16, ...; lane l the columns l, l + 64, l + 128
-  // (coalesced row reads; rows / columns of constant dims are zero in H). One block reduction at the end, fixed order.
-  double n2 = 0.0, gyv = 0.0, vhv = 0.0, vhy = 0.0, yhy = 0.0;
-  for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }
+  // dense shares of the dogleg scalars v^T Ht v, v^T Ht y, y^T Ht y with Ht = s H s (the landmark shares come from k_lm_step).
+  // The factorised system is S = Ht + mu D^2 - Et (Et = s E s) and S y = rhs, y^T S y = |z|^2, so
+  //   y^T Ht y = |z|^2   - mu y^T D^2 y + y^T Et y        v^T Ht y = v^T rhs - mu v^T D^2 y + v^T Et y
+  //   v^T Ht v = v^T S v - mu v^T D^2 v + v^T Et v        (v^T S v: summed while the tiles were built)
+  // — one pass over the 73 x 73 block E instead of a second pass over the 182 x 182 block H.
+  double n2 = 0.0, gyv = 0.0, vrhs = 0.0, vDv = 0.0, vDy = 0.0, vEv = 0.0, vEy = 0.0, yEy = 0.0;
+  for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }   // s v, s y (original dims)
   __syncthreads();
-  {
-    double svb[3], syb[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) { const int b = lane + 64 * q; svb[q] = b < ND ? ys[b] : 0.0; syb[q] = b < ND ? ys[ND + b] : 0.0; }
-    for (int a = wave; a < ND; a += SOLVE_THREADS >> 6) {
-      // row a of the lower triangle: sum_{b<a} H_ab (.)_b counts twice (symmetry), the diagonal once
-      const double *Ha = H + (size_t)a * ND;
-      double hv = 0.0, hy = 0.0, dg = 0.0;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int b = lane + 64 * q;
-        const double h = b <= a ? Ha[b] : 0.0;
-        if (b == a) dg = h;
-        else { hv += h * svb[q]; hy += h * syb[q]; }
-      }
-      const double sva = ys[a], sya = ys[ND + a];
-      vhv += 2.0 * sva * hv + dg * sva * sva;
-      vhy += sya * hv + sva * hy + dg * sya * sva;
-      yhy += 2.0 * sya * hy + dg * sya * sya;
-    }
-  }
   for (int a = t; a < ND; a += blockDim.x) {
-    n2 += gDp[a] * gDp[a] * gyp[a] * gyp[a];
-    gyv += ggts[a] * gyp[a];
+    const double d2 = gDp[a] * gDp[a], y = gyp[a], v = gvp[a];
+    n2 += d2 * y * y;
+    gyv += ggts[a] * y;
+    vDv += d2 * v * v;
+    vDy += d2 * v * y;
+    vrhs += v * (ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0));
   }
-  n2 = block_sum(n2, red); gyv = block_sum(gyv, red); vhv = block_sum(vhv, red); vhy = block_sum(vhy, red); yhy = block_sum(yhy, red);
+  for (int e = t; e < NV * NV; e += blockDim.x) {
+    const int a = e / NV, b = e - a * NV;
+    const double ev = E[e];                       // (rows / columns of inactive dims are zero in E)
+    vEv = __builtin_fma(ev * ys[a], ys[b], vEv);
+    vEy = __builtin_fma(ev * ys[a], ys[ND + b], vEy);
+    yEy = __builtin_fma(ev * ys[ND + a], ys[ND + b], yEy);
+  }
+  n2 = block_sum(n2, red); gyv = block_sum(gyv, red); vrhs = block_sum(vrhs, red); vDv = block_sum(vDv, red); vDy = block_sum(vDy, red);
+  vEv = block_sum(vEv, red); vEy = block_sum(vEy, red); yEy = block_sum(yEy, red);
   if (t == 0) {
+    const double zz = s_zz, vSv = s_vSv;
     c.mu = mu;
-    c.G2 = g2; c.N2 = n2; c.gy = gyv; c.vHv = vhv; c.vHy = vhy; c.yHy = yhy; c.grad_max = gmax;
+    c.G2 = g2; c.N2 = n2; c.gy = gyv;
+    c.vHv = vSv - mu * vDv + vEv;
+    c.vHy = vrhs - mu * vDy + vEy;
+    c.yHy = zz - mu * n2 + yEy;
+    c.grad_max = gmax;
     c.x_norm = xn2;        // dense share; k_step adds the landmarks and takes the square root
     c.have_step = 2;       // "fresh linearisation" marker consumed by k_step
   }

@@ -15,8 +15,8 @@ names = ["perm+scale+reduce", "tile build", "cholesky", "backsub", "gram+store"]
 for i, n in enumerate(names):
     print("%-20s %8.2f us" % (n, (t[i + 1] - t[i]) * 0.01))
 print("total %.2f us" % ((t[5] - t[0]) * 0.01))
-print("panel 0: diag tile %.2f us, panel solve %.2f us, trailing update %.2f us" % ((t[17]-t[16])*0.01, (t[18]-t[17])*0.01, (t[19]-t[18])*0.01))
-print("   wave 0 own trailing work %.2f us" % ((t[20]-t[18])*0.01))
+print("panel 0: panel multiply (incl. barrier) %.2f us, trailing update %.2f us; wave 0: own trailing tiles + factor-and-invert of tile (1,1) %.2f us" % ((t[18]-t[17])*0.01, (t[19]-t[18])*0.01, (t[20]-t[18])*0.01))
+print("   chol_inv_tile16 of tile (1,1): factor %.2f us, inverse %.2f us" % ((t[22]-t[21])*0.01, (t[23]-t[22])*0.01))
 
 print("k_schur WG(0,0): first prefetch %.2f us, first LDS stage %.2f us, all %d tiles %.2f us" % ((t[9]-t[8])*0.01, (t[10]-t[9])*0.01, int(t[12]), (t[11]-t[8])*0.01))
 print("k_schur WG(0,0) shader clock during the kernel: %.0f MHz" % ((t[14]-t[13]) / ((t[11]-t[8])*0.01)))
