@@ -72,6 +72,29 @@ __device__ __forceinline__ double block_max(double v, double *scratch) {
   return r;
 }
 
+// NQ quantities per thread reduced over the block with ONE pair of barriers (bit q of maxmask: maximum instead of sum): wave
+// sums by the shuffle tree, then thread q adds the <= 16 wave values in wave order — the same order as block_sum / block_max,
+// so the results are bit-identical to NQ separate calls. scratch: (16 + 1) * NQ doubles; results in scratch[16 * NQ + q] for
+// every thread after the call.
+template <int NQ>
+__device__ __forceinline__ void block_reduce_multi(const double (&v)[NQ], unsigned maxmask, double *scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const double r = ((maxmask >> q) & 1) ? wave_max(v[q]) : wave_sum(v[q]);
+    if (lane == 0) scratch[q * 16 + wid] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    const int q = threadIdx.x;
+    double r = 0.0;
+    for (int i = 0; i < nw; i++) r = ((maxmask >> q) & 1) ? fmax(r, scratch[q * 16 + i]) : r + scratch[q * 16 + i];
+    scratch[16 * NQ + q] = r;
+  }
+  __syncthreads();
+}
+
 // landmark sharding: tile t of a window is evaluated by rank t % world (gfbe_set_allreduce)
 #define TILE_OWNED(d, tile) ((d).world == 1 || (tile) % (d).world == (d).rank)
 
@@ -1244,7 +1267,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 #ifndef SOLVE_WAVES_PER_EU
 #define SOLVE_WAVES_PER_EU 4
 #endif
-#define BUILD_UNROLL 4
+#define BUILD_UNROLL 6
 #define TB 16                          // tile edge of the blocked Cholesky
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
@@ -1294,8 +1317,9 @@ __device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu
 // 1/sqrt(d) from v_rsq_f64 + two Newton steps (full FP64 accuracy without the long IEEE sqrt/div sequences).
 __device__ __forceinline__ double rsqrt_refined(double d) {
   double r = __builtin_amdgcn_rsq(d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  r = r * (1.5 - 0.5 * d * r * r);
+  const double hd = 0.5 * d;
+  r = r * __builtin_fma(-hd * r, r, 1.5);
+  r = r * __builtin_fma(-hd * r, r, 1.5);
   return r;
 }
 __device__ __forceinline__ double lane_bcast(double v, int src) {   // src is wave-uniform
@@ -1310,7 +1334,11 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {   // src is wa
 // Returns false on a bad pivot.
 // zrow >= 0: row `zrow` of L (the right-hand side row of the LAST diagonal tile: z of the last partial panel) is saved to zout
 // before the tile is overwritten.
-__device__ __noinline__ bool chol_inv_tile16(double *T, int lane, int zrow, double *zout, double *stamp = nullptr) {
+// (out of line — inlined, its 64 live registers push the 128-VGPR kernel into scratch — with LDS-typed pointers: a generic
+// pointer would turn every tile access into a FLAT instruction; the products are explicit FMAs: the library is built with
+// -ffp-contract=off)
+typedef __attribute__((address_space(3))) double lds_double;
+__device__ __noinline__ bool chol_inv_tile16(lds_double *T, int lane, int zrow, lds_double *zout, double *stamp = nullptr) {
   double row[TB];
   const int li = lane & 15;
   if (stamp && lane == 0) stamp[21] = (double)wall_clock64();
@@ -1327,7 +1355,7 @@ __device__ __noinline__ bool chol_inv_tile16(double *T, int lane, int zrow, doub
 #pragma unroll
     for (int j = k + 1; j < TB; j++) {
       const double ljk = lane_bcast(lik, j);
-      row[j] -= lik * ljk;                    // only meaningful for i >= j; the upper part is never read
+      row[j] = __builtin_fma(-lik, ljk, row[j]);   // only meaningful for i >= j; the upper part is never read
     }
   }
   if (lane < TB) {
@@ -1428,9 +1456,11 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     for (int b = t; b < GFBE_BLK_COUNT; b += blockDim.x)
       if (ds.blk_free[b]) for (int k = 0; k < blk_gsize(b); k++) { const double v = X[blk_amb(b) + k]; xn2 += v * v; }
   }
-  g2 = block_sum(g2, red);
-  gmax = block_max(gmax, red);
-  xn2 = block_sum(xn2, red);
+  {   // (the tile area is free until the build: scratch of the combined reduction)
+    const double pv[3] = {g2, gmax, xn2};
+    block_reduce_multi<3>(pv, 0x2u, smem);
+    g2 = smem[48]; gmax = smem[49]; xn2 = smem[50];
+  }
   __syncthreads();
   STAMP(1);
   const int n = s_nact;                 // active dims
@@ -1463,8 +1493,8 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 #pragma unroll
       for (int u = 0; u < BUILD_UNROLL; u++) {
         const int te = te0 + u * (SOLVE_THREADS >> 8);
-        int I = 0, J = te;
-        while (J > I) { J -= I + 1; I++; }
+        int I, J;
+        tri_decode(te, I, J);
         const int ia = I * TB + r, ib = J * TB + cc;
         offdiag[u] = I != J;
         kind[u] = 0; aa[u] = 0; bb[u] = 0; hv[u] = 0.0; ev[u] = 0.0;
@@ -1506,49 +1536,52 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     //        trailing tiles (I, J) -= L_IP L_JP^T; the wave that updates tile (P+1, P+1) first factorises and inverts it right
     //        away, while the other waves are still updating: only panel 0 pays for its own diagonal tile.
     //      Two block barriers per panel.
-    if (wave == 0) { if (!chol_inv_tile16(smem + (size_t)tile_idx(0, 0) * (TB * TB), lane, nt == 1 ? n % TB : -1, zlast) && lane == 0) flag = 1; }
-    __syncthreads();
+    // (the loop starts at P = -1 — no panel yet, wave 0 factorises tile (0, 0) — so that chol_inv_tile16 is inlined once:
+    // two copies of its 64 live registers do not fit the 128-VGPR budget of a 1024-thread workgroup)
     const int lr = lane & 15, lk = lane >> 4;
-    for (int P = 0; P < nt; P++) {
-      const double *Wp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+    for (int P = -1; P < nt; P++) {
       if (P == 0) STAMP(17);
       if (flag) break;
-      for (int I = P + 1 + wave; I < nt; I += (SOLVE_THREADS >> 6)) {
-        double *tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
-        dbl4 acc = {0.0, 0.0, 0.0, 0.0};
-        double va[4], vb[4];
+      if (P >= 0) {
+        const double *Wp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+        for (int I = P + 1 + wave; I < nt; I += (SOLVE_THREADS >> 6)) {
+          double *tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
+          dbl4 acc = {0.0, 0.0, 0.0, 0.0};
+          double va[4], vb[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { va[q] = tip[tsw(lr, q * 4 + lk)]; vb[q] = Wp[tsw(lr, q * 4 + lk)]; }
+          for (int q = 0; q < 4; q++) { va[q] = tip[tsw(lr, q * 4 + lk)]; vb[q] = Wp[tsw(lr, q * 4 + lk)]; }
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
+          for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; q++) tip[tsw(lk + 4 * q, lr)] = acc[q];
+          for (int q = 0; q < 4; q++) tip[tsw(lk + 4 * q, lr)] = acc[q];
+        }
+        __syncthreads();
       }
-      __syncthreads();
       if (P == 0) STAMP(18);
-      // trailing tiles (I, J), P < J <= I, round-robin over the waves
+      // trailing tiles (I, J), P < J <= I. Wave 0 takes tile (P+1, P+1) and its factor-and-invert — the critical chain — and
+      // nothing else; the other tiles go round-robin over waves 1..15.
       const int nrem = nt - 1 - P;
-      const int ntr = nrem * (nrem + 1) / 2;
-      // (wave 0 takes tile (P+1, P+1) and its factor-and-invert — the critical chain — and nothing else; the other tiles go
-      // round-robin over waves 1..15)
+      const int ntr = P < 0 ? 1 : nrem * (nrem + 1) / 2;
       for (int e = (wave == 0 ? 0 : wave); e < ntr; e += (wave == 0 ? ntr : (SOLVE_THREADS >> 6) - 1)) {
         int ii = 0, rr = e;
         while (rr > ii) { rr -= ii + 1; ii++; }
         const int I = P + 1 + ii, J = P + 1 + rr;
-        const double *LI = smem + (size_t)tile_idx(I, P) * (TB * TB), *LJ = smem + (size_t)tile_idx(J, P) * (TB * TB);
         double *C = smem + (size_t)tile_idx(I, J) * (TB * TB);
-        dbl4 acc;
-        double va[4], vb[4];
+        if (P >= 0) {
+          const double *LI = smem + (size_t)tile_idx(I, P) * (TB * TB), *LJ = smem + (size_t)tile_idx(J, P) * (TB * TB);
+          dbl4 acc;
+          double va[4], vb[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { acc[q] = C[tsw(lk + 4 * q, lr)]; va[q] = -LI[tsw(lr, q * 4 + lk)]; vb[q] = LJ[tsw(lr, q * 4 + lk)]; }
+          for (int q = 0; q < 4; q++) { acc[q] = C[tsw(lk + 4 * q, lr)]; va[q] = -LI[tsw(lr, q * 4 + lk)]; vb[q] = LJ[tsw(lr, q * 4 + lk)]; }
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
+          for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; q++) C[tsw(lk + 4 * q, lr)] = acc[q];
-        if (e == 0) {   // tile (P+1, P+1) is final now: factorise and invert it here (wave 0), ahead of the block barrier
+          for (int q = 0; q < 4; q++) C[tsw(lk + 4 * q, lr)] = acc[q];
+        }
+        if (e == 0 && P + 1 < nt) {   // tile (P+1, P+1) is final now: factorise and invert it here (wave 0), ahead of the block barrier
           __threadfence_block();
           __builtin_amdgcn_wave_barrier();
-          if (!chol_inv_tile16(C, lane, P + 2 == nt ? n % TB : -1, zlast, P == 0 ? stamp : nullptr) && lane == 0) flag = 1;
+          if (!chol_inv_tile16((lds_double *)C, lane, P + 2 == nt ? n % TB : -1, (lds_double *)zlast, P == 0 ? stamp : nullptr) && lane == 0) flag = 1;
         }
       }
       if (P == 0) STAMP(20);
@@ -1607,12 +1640,10 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
         }
       }
       __syncthreads();
-      for (int a = t; a < ND; a += blockDim.x) gyp[a] = 0.0;
-      __syncthreads();
-      for (int i = t; i < n; i += blockDim.x) gyp[perm[i]] = ys[i];
-      __syncthreads();
+      // y back to the tangent dims: inactive dims get 0 (written by the threads of the padding entries of perm), every dim once
       int bad = 0;
-      for (int a = t; a < ND; a += blockDim.x) { if (!ds.act[a]) gyp[a] = 0.0; else if (!isfinite(gyp[a])) bad = 1; }
+      for (int i = t; i < n; i += blockDim.x) { const double y = ys[i]; gyp[perm[i]] = y; if (!isfinite(y)) bad = 1; }
+      for (int a = t; a < ND; a += blockDim.x) if (!ds.act[a]) gyp[a] = 0.0;
       if (bad) flag = 1;
       __syncthreads();
       ok = (flag == 0);
@@ -1650,8 +1681,11 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     vEy = __builtin_fma(ev * ys[a], ys[ND + b], vEy);
     yEy = __builtin_fma(ev * ys[ND + a], ys[ND + b], yEy);
   }
-  n2 = block_sum(n2, red); gyv = block_sum(gyv, red); vrhs = block_sum(vrhs, red); vDv = block_sum(vDv, red); vDy = block_sum(vDy, red);
-  vEv = block_sum(vEv, red); vEy = block_sum(vEy, red); yEy = block_sum(yEy, red);
+  {   // (the tiles are dead after the back-substitution: scratch of the combined reduction)
+    const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
+    block_reduce_multi<8>(gv, 0u, smem);
+    n2 = smem[128]; gyv = smem[129]; vrhs = smem[130]; vDv = smem[131]; vDy = smem[132]; vEv = smem[133]; vEy = smem[134]; yEy = smem[135];
+  }
   if (t == 0) {
     const double zz = s_zz, vSv = s_vSv;
     c.mu = mu;
