@@ -119,7 +119,7 @@ struct WinCtl {
   int have_step;             // k_step produced a valid candidate this iteration
   int num_successful, termination, status, invalid_steps, lin_fail;
   int n_clamped;
-  int pad0;
+  int lin_retry;             // landmark sharding: the factorisation failed at the previous mu; the retry pass factorises with c.mu and the rebuilt, all-reduced E
   double radius, mu, cost, cand_cost, x_norm, cand_norm2, step_amb2;
   double G2, N2, gy, vHv, vHy, yHy, alpha, grad_max;
   double c1, c2, step_norm, model_change;
@@ -193,6 +193,8 @@ struct BatchDev {
   // assembled system
   double *H, *g;              // [B][ND*ND], [B][ND]  unscaled J^T J, J^T r of the dense block
   double *E, *eg;             // [B][NV*NV], [B][NV]  sum_l w_l h_l h_l^T, sum_l w_l h_l gl  (unscaled h)
+  double *Er;                 // landmark sharding only: [B][NV*NV + NV] E | eg rebuilt for a larger mu by every rank from its own tiles
+                              // (zeros for the windows that do not retry), summed by one all-reduce before the retry pass of k_solve
   double *sp, *Dp, *gts, *vp, *yp, *step;   // [B][ND] each
   // debug / inspection outputs (gfbe_eval_factors)
   double *dbg_imu, *dbg_wheel, *dbg_prior;  // [B][MAX_IMU][15*31], [B][MAX_WHEEL][6*23], [B][ND]
@@ -244,7 +246,8 @@ void launch_xchg_cand(const BatchDev &d, hipStream_t s);
 void launch_lam_mask(const BatchDev &d, hipStream_t s);
 void launch_marginalize_partials(const BatchDev &d, hipStream_t s);
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s);
-void launch_solve(const BatchDev &d, hipStream_t s);
+void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass = 0);
+void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s);
 void launch_lm_step(const BatchDev &d, hipStream_t s);
 void launch_step(const BatchDev &d, hipStream_t s);
 void launch_candidate(const BatchDev &d, hipStream_t s);

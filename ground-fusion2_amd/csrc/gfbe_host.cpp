@@ -751,6 +751,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       b->slab_n = nH + ng + nE + ne + nx;
     }
     AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
+    if (d.world > 1) { AL(Er, (size_t)B * (NV * NV + NV)); } else d.Er = nullptr;
     AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
     AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
     AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
@@ -1040,6 +1041,14 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   { Timed t(c, "k_assemble", 0); launch_assemble(d, ln.s); }
   if (d.world > 1) { Timed t(c, "allreduce_system", 0); c->allreduce(c->allreduce_user, d.H, (int64_t)b->slab_n, ln.s); }
   { Timed t(c, "k_solve", 0); launch_solve(d, ln.s); }
+  if (d.world > 1) {
+    // the mu retry of DoglegStrategy when the landmarks are sharded: a window whose factorisation failed gets E rebuilt for the
+    // larger mu from every rank's own tiles, one more all-reduce (E | eg only), and a second factorisation
+    Timed t(c, "mu_retry_sharded", 0);
+    launch_rebuild_E_shard(d, ln.s);
+    c->allreduce(c->allreduce_user, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);
+    launch_solve(d, ln.s, 1);
+  }
   { Timed t(c, "k_lm_step", 0); launch_lm_step(d, ln.s); }
   if (d.world > 1) {
     Timed t(c, "allreduce_scalars", 0);

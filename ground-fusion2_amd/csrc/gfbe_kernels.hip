@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
       WinCtl c;
       c.cur = 0; c.iter = 0; c.done = 0; c.reuse = 0; c.have_step = 0;
       c.num_successful = 0; c.termination = 0; c.status = GFBE_NO_CONVERGENCE; c.invalid_steps = 0; c.lin_fail = 0;
-      c.n_clamped = 0; c.pad0 = 0;
+      c.n_clamped = 0; c.lin_retry = 0;
       c.radius = d.opt.initial_trust_region_radius; c.mu = GF_MIN_MU; c.cost = 0; c.cand_cost = 0; c.x_norm = 0;
       c.cand_norm2 = 0; c.step_amb2 = 0;
       c.G2 = c.N2 = c.gy = c.vHv = c.vHy = c.yHy = c.alpha = c.grad_max = 0;
@@ -1277,9 +1277,9 @@ __device__ __forceinline__ int tile_idx(int I, int J) { return I * (I + 1) / 2 +
 // instead of two (a row stride of 16 doubles = 32 dwords is the worst case for the 64-bank LDS).
 __device__ __forceinline__ int tsw(int r, int c) { return r * TB + (c ^ r); }
 
-// Rebuild E for a new mu directly from the landmark rows (slow path: only after a failed Cholesky).
-__device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu) {
-  double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
+// Rebuild E for a new mu directly from the landmark rows (slow path: only after a failed Cholesky). own_only: the tiles of this
+// rank (landmark sharding; the ranks' parts are summed by an all-reduce).
+__device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu, double *E, double *eg, bool own_only) {
   const size_t TL = d.tot_lm;
   for (int e = threadIdx.x; e < NV * NV + NV; e += blockDim.x) {
     const bool isg = e >= NV * NV;
@@ -1289,6 +1289,7 @@ __device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu
       for (int tile = 0; tile < ds.n_tiles; tile++) {
         const int s = d.tile_start[ds.tile_off + tile];
         if (6 * s > a) break;   // tiles are ordered by start frame
+        if (own_only && !TILE_OWNED(d, tile)) continue;
         for (int l = 0; l < LM_TILE; l++) {
           const int slot = ds.lm_off + tile * LM_TILE + l;
           const int info = d.lm_info[slot];
@@ -1312,6 +1313,14 @@ __device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu
     else if (a <= b) { E[a * NV + b] = acc; E[b * NV + a] = acc; }
   }
   __syncthreads();
+}
+// landmark sharding: this rank's part of E | eg at the retry's mu for the windows that retry, zeros for the others
+__global__ __launch_bounds__(1024) void k_rebuild_E_shard(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinCtl &c = d.ctl[w];
+  double *Er = d.Er + (size_t)w * (NV * NV + NV);
+  if (c.done || !c.lin_retry) { for (int e = threadIdx.x; e < NV * NV + NV; e += blockDim.x) Er[e] = 0.0; return; }
+  rebuild_E(d, d.desc[w], w, c.mu, Er, Er + NV * NV, true);
 }
 
 // 1/sqrt(d) from v_rsq_f64 + two Newton steps (full FP64 accuracy without the long IEEE sqrt/div sequences).
@@ -1393,11 +1402,12 @@ __device__ __noinline__ bool chol_inv_tile16(lds_double *T, int lane, int zrow, 
   return ok;
 }
 
-__global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(BatchDev d) {
+__global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(BatchDev d, int retry_pass) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
+  if (retry_pass && !c.lin_retry) return;       // (landmark sharding: second factorisation of the windows whose first one failed)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ short perm[ND + TB];     // (16-bit: the 160 KB of LDS are full — 78 tiles of 2 KB for a fully active window)
   __shared__ double red[16], ys[2 * ND + TB];
@@ -1466,14 +1476,20 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   const int n = s_nact;                 // active dims
   const int na = n + 1;                 // + the right-hand side as an extra row (forward substitution for free)
   const int nt = (na + TB - 1) / TB;    // tiles per side
-  const double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
+  const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
+  const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
 
   double mu = c.mu;
   bool solved = false, e_valid = true;
   while (mu < GF_MAX_MU) {
     if (!e_valid) {
-      if (d.world > 1) break;   // landmark sharding: E would need another all-reduce; reported as a failed linear solve
-      rebuild_E(d, ds, w, mu);
+      if (d.world > 1) {
+        // landmark sharding: E for the larger mu needs every rank's landmarks — hand the window to the retry pass (rebuild on
+        // all ranks, one all-reduce, k_solve again); a second failure is a failed linear solve
+        if (!retry_pass) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }
+        break;
+      }
+      rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
     }
     // ---- augmented, scaled, regularised, Schur-reduced system in 16x16 LDS tiles (lower triangle of tiles)
     //      [ S    rhs ]   S = s H s + mu D^2 - s E s   rhs = gt - s eg
@@ -1589,7 +1605,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
       if (P == 0) STAMP(19);
     }
     bool ok = (flag == 0);
-    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid) ok = false;   // fault injection: first attempt of that iteration
+    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;   // fault injection: first attempt of that iteration
     STAMP(3);
     if (ok) {
       // z = L^-1 rhs sits in row n of the factor; y^T S y = |z|^2. Backward substitution y = L^-T z by ONE wave without
@@ -1696,6 +1712,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     c.grad_max = gmax;
     c.x_norm = xn2;        // dense share; k_step adds the landmarks and takes the square root
     c.have_step = 2;       // "fresh linearisation" marker consumed by k_step
+    c.lin_retry = 0;
   }
   STAMP(5);
 #undef STAMP
@@ -2177,9 +2194,10 @@ void launch_assemble(const BatchDev &d, hipStream_t s) {
 hipError_t kernels_init_device() {
   return hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem_bytes());
 }
-void launch_solve(const BatchDev &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d);
+void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass) {
+  hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d, retry_pass);
 }
+void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_rebuild_E_shard, dim3(d.B), dim3(1024), 0, s, d); }
 void launch_lm_step(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles == 0) return;
   hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);

@@ -22,11 +22,16 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,L", [(2, 2000), (3, 500)])
-def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L):
+@pytest.mark.parametrize("world,L,fail_iter", [(2, 2000, 0), (3, 500, 0), (2, 500, 2)])
+def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter):
+    """fail_iter > 0: the first factorisation of that iteration is declared failed on every rank (and in the unsharded
+    reference): the sharded mu retry — E rebuilt from every rank's own tiles at the larger mu, one more all-reduce, second
+    factorisation — must give what the in-kernel retry of the unsharded solve gives."""
     port = free_port()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if fail_iter:
+        env["GFBE_TEST_FAIL_CHOL_ITER"] = str(fail_iter)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(r), str(world), str(port), str(L), outs[r]],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
