@@ -10,7 +10,7 @@ import numpy as np
 
 WINDOW_SIZE = 10
 NFRAMES = 11
-DENSE_DIM = 182
+DENSE_DIM = 187
 MAX_PRIOR_BLOCKS = 32
 PRIOR_X0_CAP = NFRAMES * 16 + 32
 
@@ -18,7 +18,7 @@ OK, NO_CONVERGENCE, NUMERICAL_FAILURE, BAD_INPUT, DEVICE_ERROR, NO_DEVICE = rang
 MARGIN_OLD, MARGIN_SECOND_NEW, MARGIN_NONE = 0, 1, 2
 
 BLK_POSE0, BLK_SB0, BLK_EX_CAM, BLK_EX_WHEEL = 0, 11, 22, 23
-BLK_SX, BLK_SY, BLK_SW, BLK_TD, BLK_TD_WHEEL, BLK_COUNT = 24, 25, 26, 27, 28, 29
+BLK_SX, BLK_SY, BLK_SW, BLK_TD, BLK_TD_WHEEL, BLK_PLANE_R, BLK_PLANE_Z, BLK_COUNT = 24, 25, 26, 27, 28, 29, 30, 31
 
 c_d = C.c_double
 c_i = C.c_int32
@@ -35,6 +35,8 @@ def block_global_size(bid):
         return 9
     if bid in (BLK_EX_CAM, BLK_EX_WHEEL):
         return 7
+    if bid == BLK_PLANE_R:
+        return 4
     return 1
 
 
@@ -50,7 +52,9 @@ class State(C.Structure):
                 ("para_Ex_Pose_wheel", c_d * 7),
                 ("para_Ix_wheel", c_d * 3),
                 ("para_Td", c_d),
-                ("para_Td_wheel", c_d)]
+                ("para_Td_wheel", c_d),
+                ("para_plane_R", c_d * 4),
+                ("para_plane_Z", c_d)]
 
 
 class ImuPreint(C.Structure):
@@ -95,12 +99,14 @@ class Window(C.Structure):
                 ("pose_const", c_u8 * NFRAMES), ("sb_const", c_u8 * NFRAMES),
                 ("ex_cam_const", c_u8), ("ex_wheel_const", c_u8), ("ix_wheel_const", c_u8),
                 ("td_const", c_u8), ("td_wheel_const", c_u8),
-                ("ex_cam_mask", c_u8 * 6), ("ex_wheel_mask", c_u8 * 6), ("_pad", c_u8 * 3),
+                ("ex_cam_mask", c_u8 * 6), ("ex_wheel_mask", c_u8 * 6),
+                ("use_plane", c_u8), ("plane_const", c_u8), ("use_anchor", c_u8),
                 ("n_imu", c_i), ("imu_frame", PI), ("imu", C.POINTER(ImuPreint)),
                 ("n_wheel", c_i), ("wheel_frame", PI), ("wheel", C.POINTER(WheelPreint)),
                 ("vis", Visual),
                 ("prior", C.POINTER(Prior)),
-                ("lio", LioBlock)]
+                ("lio", LioBlock),
+                ("plane_noise_inv", c_d * 3), ("anchor_pose", c_d * 7), ("anchor_sqrt_info", c_d)]
 
 
 class Options(C.Structure):
@@ -177,6 +183,8 @@ def state_from_snapshot(snap, st=None):
     st.para_Ix_wheel[:] = _f64(snap["ix_wheel"]).tolist()
     st.para_Td = float(snap["td"])
     st.para_Td_wheel = float(snap["td_wheel"])
+    st.para_plane_R[:] = _f64(snap.get("plane_R", [0.0, 0.0, 0.0, 1.0])).tolist()
+    st.para_plane_Z = float(snap.get("plane_Z", 0.0))
     return st
 
 
@@ -189,6 +197,8 @@ def state_to_dict(st):
         "ix_wheel": np.array(list(st.para_Ix_wheel)),
         "td": float(st.para_Td),
         "td_wheel": float(st.para_Td_wheel),
+        "plane_R": np.array(list(st.para_plane_R)),
+        "plane_Z": float(st.para_plane_Z),
     }
 
 
@@ -256,6 +266,15 @@ class WindowHolder:
         w.td_wheel_const = int(snap.get("td_wheel_const", 1))
         w.ex_cam_mask[:] = _u8(snap.get("ex_cam_mask", np.zeros(6))).tolist()
         w.ex_wheel_mask[:] = _u8(snap.get("ex_wheel_mask", np.zeros(6))).tolist()
+        # optional in-window factors: snap["plane"] = dict(noise_inv=[pitch, roll, zpw], const=0/1); snap["anchor"] = dict(pose=[7], sqrt_info=120)
+        pl, an = snap.get("plane"), snap.get("anchor")
+        if pl is not None:
+            w.use_plane, w.plane_const = 1, int(pl.get("const", 0))
+            w.plane_noise_inv[:] = _f64(pl["noise_inv"]).tolist()
+        if an is not None:
+            w.use_anchor = 1
+            w.anchor_pose[:] = _f64(an["pose"]).tolist()
+            w.anchor_sqrt_info = float(an.get("sqrt_info", 120.0))
         # IMU / wheel
         self.imu = _f64(snap.get("imu", np.zeros((0, IMU_DOUBLES)))).reshape(-1, IMU_DOUBLES)
         self.imu_frame = _i32(snap.get("imu_frame", np.zeros(0)))

@@ -15,9 +15,9 @@ namespace gfd {
 // ---- dimensions -----------------------------------------------------------------------------
 enum {
   NF = GFBE_NFRAMES,          // 11 frames
-  ND = GFBE_DENSE_DIM,        // 182 tangent dims of the dense (pose/IMU/extrinsic) block
+  ND = GFBE_DENSE_DIM,        // 187 tangent dims of the dense (pose / IMU / extrinsic / ground plane) block
   NV = 73,                    // leading dims visual factors touch: 11 poses * 6 + ex_cam 6 + td 1
-  NA = 195,                   // ambient doubles of gfbe_state
+  NA = 200,                   // ambient doubles of gfbe_state
   MAXOBS = 10,                // factors per landmark (n_obs - 1)
   REC = 42,                   // doubles per visual block-CSR record: r(2) + J(2 x 20)   = 336 B
   NPAIR = NF * NF,            // (imu_i, imu_j) pair slots, index i * 11 + j
@@ -30,7 +30,9 @@ enum {
   SCHUR_CHUNK = 64,           // landmarks per Schur work item
   IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost
   WHEEL_PART = 22 * 22 + 22 + 2,
-  MAX_IMU = 10, MAX_WHEEL = 10,
+  MAX_IMU = 10, MAX_WHEEL = 10, MAX_PLANE = 10,
+  PLANE_PART = 16 * 16 + 16 + 2,    // J^T J, J^T r, cost, candidate cost of one PlaneFactor (columns pose_i 6, ex_wheel 6, plane_R 3, plane_Z 1)
+  ANCHOR_PART = 6 * 6 + 6 + 2,
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
@@ -42,12 +44,14 @@ enum {
 
 // tangent offsets (same convention as the ABI's block order)
 __host__ __device__ inline int T_POSE(int k) { return 6 * k; }
-enum { T_EX = 66, T_TD = 72, T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181 };
+enum { T_EX = 66, T_TD = 72, T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181,
+       T_PLR = 182,          // para_plane_R: three tangent dims + the quaternion's 4th slot (185), which only ever exists in the prior
+       T_PLZ = 186 };
 __host__ __device__ inline int T_SB(int k) { return 73 + 9 * k; }
 // ambient offsets inside gfbe_state (195 doubles)
 __host__ __device__ inline int A_POSE(int k) { return 7 * k; }
 __host__ __device__ inline int A_SB(int k) { return 77 + 9 * k; }
-enum { A_EX = 176, A_EXW = 183, A_IX = 190, A_TD = 193, A_TDW = 194 };
+enum { A_EX = 176, A_EXW = 183, A_IX = 190, A_TD = 193, A_TDW = 194, A_PLR = 195, A_PLZ = 199 };
 
 __host__ __device__ inline int blk_tan(int id) {
   if (id < GFBE_BLK_SB0) return T_POSE(id);
@@ -59,6 +63,8 @@ __host__ __device__ inline int blk_tan(int id) {
     case GFBE_BLK_SY: return T_SY;
     case GFBE_BLK_SW: return T_SW;
     case GFBE_BLK_TD: return T_TD;
+    case GFBE_BLK_PLANE_R: return T_PLR;
+    case GFBE_BLK_PLANE_Z: return T_PLZ;
     default: return T_TDW;
   }
 }
@@ -72,6 +78,8 @@ __host__ __device__ inline int blk_amb(int id) {
     case GFBE_BLK_SY: return A_IX + 1;
     case GFBE_BLK_SW: return A_IX + 2;
     case GFBE_BLK_TD: return A_TD;
+    case GFBE_BLK_PLANE_R: return A_PLR;
+    case GFBE_BLK_PLANE_Z: return A_PLZ;
     default: return A_TDW;
   }
 }
@@ -79,8 +87,11 @@ __host__ __device__ inline int blk_gsize(int id) {
   if (id < GFBE_BLK_SB0) return 7;
   if (id < GFBE_BLK_EX_CAM) return 9;
   if (id == GFBE_BLK_EX_CAM || id == GFBE_BLK_EX_WHEEL) return 7;
+  if (id == GFBE_BLK_PLANE_R) return 4;
   return 1;
 }
+// (para_plane_R: local size 4 like MarginalizationInfo::localSize gives every block that is not 7 wide — the solve keeps its
+//  4th tangent slot inactive, the prior carries a column for it)
 __host__ __device__ inline int blk_lsize(int id) { const int g = blk_gsize(id); return g == 7 ? 6 : g; }
 
 // ---- per-window descriptor (constant during a solve) ----------------------------------------
@@ -108,6 +119,8 @@ struct WinDesc {
   unsigned char pad_[3];
   int lio_n, lio_off, lio_frame, lio_pad;   // LiDAR point-to-plane factors on pose lio_frame (gfbe_lio_block)
   double lio_sqrt_info, lio_huber;
+  int n_plane, use_anchor;                  // PlaneFactors on poses 0 .. n_plane - 1 (0: none); PoseAnchorFactor on pose 0
+  double plane_noise_inv[3], anchor_pose[7], anchor_sqrt_info;
 };
 
 // ---- per-window solver state (mutated by kernels; mirrors TrustRegionMinimizer + DoglegStrategy)
@@ -170,6 +183,8 @@ struct BatchDev {
   double *vis_part;           // [B][max_tiles][MAXOBS][VP_STRIDE]  X^T X of the 64 factors of one tile at one step, X = [J | r]
   double *schur_part;         // [B][NF][SCHUR_STRIDE]  sum over the landmarks of one start frame
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
+  double *plane_part, *anchor_part;  // [B][MAX_PLANE][PLANE_PART], [B][ANCHOR_PART]   (only read for windows with n_plane / use_anchor)
+  int any_plane;                     // some window of the batch has plane or anchor factors (else their workgroups are not launched)
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;

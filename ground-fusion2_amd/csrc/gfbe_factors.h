@@ -499,4 +499,53 @@ GF_HD void pose_plus(const double *x, const double *d6, const unsigned char *mas
   y[3] = q.x; y[4] = q.y; y[5] = q.z; y[6] = q.w;
 }
 
+// OrientationSubsetParameterization::Plus (orientation_subset_parameterization.cpp:27-45): para_plane_R uses constant = {2}.
+GF_HD void orientation_plus(const double *q4, const double *d3, const unsigned char *constant3, double *y4) {
+  const vec3 dv = mk3(constant3[0] ? 0.0 : d3[0], constant3[1] ? 0.0 : d3[1], constant3[2] ? 0.0 : d3[2]);
+  const quat q = qnormalize(qmul(ldq(q4), small_rot(dv)));
+  y4[0] = q.x; y4[1] = q.y; y4[2] = q.z; y4[3] = q.w;
+}
+
+// PlaneFactor::Evaluate (plane_factor.h:25-122): r[3]; J[3][16] tangent columns pose_i (6) ex_wheel (6) plane_R (3) plane_Z (1),
+// J may be null. (Roll / pitch of the ground normal seen from the wheel odometer frame, height of the odometer over the plane.)
+GF_HD void plane_eval(const double *pose, const double *ex, const double *plane_q, double plane_z, const double *ninv, double *r, double *J) {
+  const vec3 tio = ld3(ex), Pi = ld3(pose);
+  const mat3 Rio = qrot(ldq(ex + 3)), Rpw = qrot(ldq(plane_q)), Ri = qrot(ldq(pose + 3));
+  const vec3 up_p = tmv(Rpw, mk3(0, 0, 1)), up_b = tmv(Ri, up_p), up_o = tmv(Rio, up_b);
+  const vec3 lever = add(Pi, mv(Ri, tio));
+  r[0] = ninv[0] * up_o[0]; r[1] = ninv[1] * up_o[1]; r[2] = ninv[2] * (plane_z + mv(Rpw, lever)[2]);
+  if (!J) return;
+  for (int i = 0; i < 48; i++) J[i] = 0.0;
+  const mat3 A = tmul(Rio, hat(up_b)), Bm = hat(up_o), Cq = tmul(Rio, tmul(Ri, hat(up_p)));
+  const mat3 RpwRi = mul(Rpw, Ri), D = mul(RpwRi, hat(tio)), E = mul(Rpw, hat(lever));
+  for (int row = 0; row < 2; row++)
+    for (int j = 0; j < 3; j++) {
+      J[row * 16 + 3 + j] = ninv[row] * A(row, j);
+      J[row * 16 + 9 + j] = ninv[row] * Bm(row, j);
+      J[row * 16 + 12 + j] = ninv[row] * Cq(row, j);
+    }
+  for (int j = 0; j < 3; j++) {
+    J[32 + j] = ninv[2] * Rpw(2, j);
+    J[32 + 3 + j] = -ninv[2] * D(2, j);
+    J[32 + 6 + j] = ninv[2] * RpwRi(2, j);
+    J[32 + 12 + j] = -ninv[2] * E(2, j);
+  }
+  J[32 + 15] = ninv[2];
+}
+
+// PoseAnchorFactor::Evaluate (pose_anchor_factor.cpp:8-32): r[6]; J[6][6] (may be null). The reference scales the WHOLE Jacobian by
+// 2 sqrt_info (:29) — the position block is twice the derivative of its own residual — and builds the rotation block from the
+// anchor alone: reproduced as it is.
+GF_HD void anchor_eval(const double *x, const double *a, double sqrt_info, double *r, double *J) {
+  const quat qa_inv = qinv(ldq(a + 3));
+  const vec3 dv = qvec(qmul(ldq(x + 3), qa_inv));
+  for (int i = 0; i < 3; i++) { r[i] = sqrt_info * (x[i] - a[i]); r[3 + i] = sqrt_info * 2.0 * dv[i]; }
+  if (!J) return;
+  for (int i = 0; i < 36; i++) J[i] = 0.0;
+  const double s = 2.0 * sqrt_info;
+  for (int i = 0; i < 3; i++) J[i * 6 + i] = s;
+  const mat3 Jq = qright3(qa_inv);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[(3 + i) * 6 + 3 + j] = s * Jq(i, j);
+}
+
 }  // namespace gfd

@@ -562,6 +562,7 @@ int prior_out_bound(const gfbe_window &win, const int *pair_begin, bool old) {
   for (int k = 0; k < win.n_imu; k++) if (win.imu_frame[k] == 0) touched[0] = touched[GFBE_BLK_SB0] = touched[1] = touched[GFBE_BLK_SB0 + 1] = true;
   for (int k = 0; k < win.n_wheel; k++)
     if (win.wheel_frame[k] == 0) touched[0] = touched[1] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_SX] = touched[GFBE_BLK_SY] = touched[GFBE_BLK_SW] = touched[GFBE_BLK_TD_WHEEL] = true;
+  if (win.use_plane && win.frame_count > 0) touched[0] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_PLANE_R] = touched[GFBE_BLK_PLANE_Z] = true;
   if (pair_begin) { for (int j = 1; j < NF; j++) if (pair_begin[j + 1] > pair_begin[j]) touched[0] = touched[j] = touched[GFBE_BLK_EX_CAM] = touched[GFBE_BLK_TD] = true; }
   else for (int q = 0; q < NF; q++) touched[q] = touched[GFBE_BLK_EX_CAM] = touched[GFBE_BLK_TD] = true;   // (table-fed: pair counts live on the device)
   int n = 0;
@@ -695,6 +696,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   { const char *fe = getenv("GFBE_TEST_FAIL_CHOL_ITER"); d.test_fail_chol_iter = fe ? atoi(fe) : 0; }   // fault injection of the mu-retry path (tests)
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
+  for (int w = 0; w < B; w++) if (wins[w]->use_plane || wins[w]->use_anchor) d.any_plane = 1;
   if (getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics: force the 20-column panel)
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
@@ -739,6 +741,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36); AL(prior_H, (size_t)B * ND * ND);
     AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
     AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
+    AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
     AL(prior_g, (size_t)B * (ND + 2));
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
     AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
@@ -874,6 +877,15 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       used[i] = used[i + 1] = used[GFBE_BLK_EX_WHEEL] = used[GFBE_BLK_SX] = used[GFBE_BLK_SY] = used[GFBE_BLK_SW] = used[GFBE_BLK_TD_WHEEL] = true;
     }
     for (int p = 0; p < NPAIR; p++) if (sc.pair_begin[p + 1] > sc.pair_begin[p]) { used[p / NF] = used[p % NF] = used[GFBE_BLK_EX_CAM] = used[GFBE_BLK_TD] = true; }
+    // optional in-window factors: PlaneFactor on every pose i < frame_count (estimator.cpp:3214-3220), PoseAnchorFactor on Pose[0]
+    ds.n_plane = win.use_plane ? std::min(win.frame_count, (int)MAX_PLANE) : 0;
+    ds.use_anchor = win.use_anchor ? 1 : 0;
+    for (int q = 0; q < 3; q++) ds.plane_noise_inv[q] = win.plane_noise_inv[q];
+    for (int q = 0; q < 7; q++) ds.anchor_pose[q] = win.anchor_pose[q];
+    ds.anchor_sqrt_info = win.anchor_sqrt_info;
+    for (int i = 0; i < ds.n_plane; i++) used[i] = true;
+    if (ds.n_plane > 0) used[GFBE_BLK_EX_WHEEL] = used[GFBE_BLK_PLANE_R] = used[GFBE_BLK_PLANE_Z] = true;
+    if (ds.use_anchor) used[0] = true;
     for (int q = 0; q < GFBE_BLK_COUNT; q++) {
       bool cst;
       if (q < GFBE_BLK_SB0) cst = win.pose_const[q] || q > win.frame_count;
@@ -882,10 +894,12 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       else if (q == GFBE_BLK_EX_WHEEL) cst = win.ex_wheel_const;
       else if (q == GFBE_BLK_TD) cst = win.td_const;
       else if (q == GFBE_BLK_TD_WHEEL) cst = win.td_wheel_const;
+      else if (q == GFBE_BLK_PLANE_R || q == GFBE_BLK_PLANE_Z) cst = win.plane_const;
       else cst = win.ix_wheel_const;
       ds.blk_free[q] = used[q] && !cst;
       if (ds.blk_free[q]) for (int k = 0; k < blk_lsize(q); k++) ds.act[blk_tan(q) + k] = 1;
     }
+    ds.act[T_PLR + 3] = 0;   // the plane quaternion's 4th slot only exists in the prior (three tangent dims in the solve)
     std::memcpy(ds.ex_cam_mask, win.ex_cam_mask, 6);
     std::memcpy(ds.ex_wheel_mask, win.ex_wheel_mask, 6);
     b->up_win_bytes[w] = bytes;
@@ -1344,6 +1358,13 @@ extern "C" gfbe_status gfbe_eval_factors(gfbe_ctx *c, const gfbe_window *win, in
     for (int q = 0; q < win->n_imu; q++) total += ip[(size_t)q * IMU_PART + IMU_PART - 2];
     for (int q = 0; q < win->n_wheel; q++) total += wp[(size_t)q * WHEEL_PART + WHEEL_PART - 2];
     total += pg[ND];
+    if (d.any_plane) {   // PlaneFactors and the PoseAnchorFactor (use_plane / use_anchor)
+      std::vector<double> pp((size_t)MAX_PLANE * PLANE_PART), ap(ANCHOR_PART);
+      HIPCHK(c, hipMemcpy(pp.data(), d.plane_part, sizeof(double) * pp.size(), hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(ap.data(), d.anchor_part, sizeof(double) * ap.size(), hipMemcpyDeviceToHost));
+      for (int q = 0; q < ds[0].n_plane; q++) total += pp[(size_t)q * PLANE_PART + PLANE_PART - 2];
+      if (ds[0].use_anchor) total += ap[ANCHOR_PART - 2];
+    }
     *cost = total;
   }
   gfbe_batch_free(c, b);

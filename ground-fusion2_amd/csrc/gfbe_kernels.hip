@@ -673,6 +673,41 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
       for (int q = t; q < 132; q += 64) dbg[6 + q] = Jw[q];
       if (t < 6) dbg[t] = rw[t];
     }
+  } else if (f > MAX_IMU + MAX_WHEEL && f <= MAX_IMU + MAX_WHEEL + MAX_PLANE) {
+    // PlaneFactor of pose i (estimator.cpp:3214-3220; plane_factor.h:25-122): J^T J (16 x 16: pose_i, ex_wheel, plane_R, plane_Z),
+    // J^T r, cost. mode 2: the one of frame 0 joins the MARGIN_OLD set (estimator.cpp:3441-3448).
+    const int i = f - (MAX_IMU + MAX_WHEEL + 1);
+    double *part = d.plane_part + ((size_t)w * MAX_PLANE + i) * PLANE_PART;
+    if (i >= ds.n_plane) return;
+    if (mode >= 2 && !(mode == 2 && i == 0)) { if (t == 0) part[PLANE_PART - 2] = -1.0; return; }
+    if (t == 0) plane_eval(X + A_POSE(i), X + A_EXW, X + A_PLR, X[A_PLZ], ds.plane_noise_inv, raw, mode == 1 ? nullptr : Jraw);
+    __syncthreads();
+    double cst = 0.0;
+    if (t == 0) for (int a = 0; a < 3; a++) cst += 0.5 * raw[a] * raw[a];
+    if (mode == 1) { if (t == 0) part[PLANE_PART - 1] = cst; return; }
+    for (int e = t; e < 272; e += 64) {
+      double s = 0.0;
+      if (e < 256) { const int a = e >> 4, b = e & 15; for (int r = 0; r < 3; r++) s += Jraw[r * 16 + a] * Jraw[r * 16 + b]; }
+      else { const int a = e - 256; for (int r = 0; r < 3; r++) s += Jraw[r * 16 + a] * raw[r]; }
+      part[e] = s;
+    }
+    if (t == 0) part[PLANE_PART - 2] = cst;
+  } else if (f == MAX_IMU + MAX_WHEEL + MAX_PLANE + 1) {
+    // PoseAnchorFactor on Pose[0] (estimator.cpp:3004-3012; pose_anchor_factor.cpp:8-32)
+    double *part = d.anchor_part + (size_t)w * ANCHOR_PART;
+    if (!ds.use_anchor || mode >= 2) return;
+    if (t == 0) anchor_eval(X + A_POSE(0), ds.anchor_pose, ds.anchor_sqrt_info, raw, mode == 1 ? nullptr : Jraw);
+    __syncthreads();
+    double cst = 0.0;
+    if (t == 0) for (int a = 0; a < 6; a++) cst += 0.5 * raw[a] * raw[a];
+    if (mode == 1) { if (t == 0) part[ANCHOR_PART - 1] = cst; return; }
+    if (t < 42) {
+      double s = 0.0;
+      if (t < 36) { const int a = t / 6, b = t % 6; for (int r = 0; r < 6; r++) s += Jraw[r * 6 + a] * Jraw[r * 6 + b]; }
+      else { const int a = t - 36; for (int r = 0; r < 6; r++) s += Jraw[r * 6 + a] * raw[r]; }
+      part[t] = s;
+    }
+    if (t == 0) part[ANCHOR_PART - 2] = cst;
   } else {
     // prior: r = r0 + J0 dx ; g = J0^T r   (marginalization_factor.cpp:375-389)
     double *pg = d.prior_g + (size_t)w * (ND + 2);
@@ -889,6 +924,31 @@ __device__ __forceinline__ int wheel_loc(int a, int i) {
   return -1;
 }
 
+__device__ __forceinline__ int plane_loc(int a, int i) {         // column of dim a in the PlaneFactor of pose i
+  if (a < 66) { const int f = a / 6; return f == i ? a - 6 * f : -1; }
+  if (a >= T_EXW && a < T_EXW + 6) return 6 + (a - T_EXW);
+  if (a >= T_PLR && a < T_PLR + 3) return 12 + (a - T_PLR);
+  if (a == T_PLZ) return 15;
+  return -1;
+}
+// PlaneFactors' and the PoseAnchorFactor's share of H(a, b) (b == -1: of the gradient g(a)), fixed order
+__device__ __forceinline__ double plane_anchor_term(const BatchDev &d, int w, int n_plane, int use_anchor, int a, int b) {
+  double s = 0.0;
+  if (n_plane > 0) {
+    const int fa = a < 66 ? a / 6 : -1, fb = (b >= 0 && b < 66) ? b / 6 : -1;
+    if (!(fa >= 0 && fb >= 0 && fa != fb)) {
+      const int only = fa >= 0 ? fa : fb;       // a pose dim pins the factor; otherwise every factor touches the entry
+      const int i0 = only >= 0 ? only : 0, i1 = only >= 0 ? only : n_plane - 1;
+      for (int i = i0; i <= i1 && i < n_plane; i++) {
+        const int la = plane_loc(a, i), lb = b >= 0 ? plane_loc(b, i) : 0;
+        if (la >= 0 && lb >= 0) s += d.plane_part[((size_t)w * MAX_PLANE + i) * PLANE_PART + (b >= 0 ? la * 16 + lb : 256 + la)];
+      }
+    }
+  }
+  if (use_anchor && a < 6 && b < 6) s += d.anchor_part[(size_t)w * ANCHOR_PART + (b >= 0 ? a * 6 + b : 36 + a)];
+  return s;
+}
+
 __device__ __forceinline__ int vp_off(int a, int b) {   // entry (a <= b) of the 20-column X^T X inside a fused visual partial
   if (a > b) { const int t = a; a = b; b = t; }
   if (b < 16) return a * 16 + b;
@@ -920,7 +980,7 @@ __device__ double gather_eg(const BatchDev &d, const WinDesc &ds, int w, int a, 
 struct AsmTab {
   int prior_map[ND];
   int imu_of_frame[NF], wheel_of_frame[NF];
-  int prior_n, n_wheel;
+  int prior_n, n_wheel, n_plane, use_anchor;
   unsigned char act[ND + 2];
 };
 
@@ -984,6 +1044,7 @@ __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab
     }
   }
   if (tb.prior_n > 0 && tb.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + tb.prior_map[a]];
+  if (tb.n_plane > 0 || tb.use_anchor) s += plane_anchor_term(d, w, tb.n_plane, tb.use_anchor, a, -1);
   return s;
 }
 // E(a,b), a <= b < NVP (b = 73: the gradient column): the 11 start-frame Schur partials, loads unconditional in flight
@@ -1146,7 +1207,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   const double *Z = d.zero;
   for (int a = t; a < ND; a += ASM_THREADS) { tb.prior_map[a] = ds.prior_map[a]; tb.act[a] = ds.act[a]; }
   if (t < NF) { tb.imu_of_frame[t] = ds.imu_of_frame[t]; tb.wheel_of_frame[t] = ds.wheel_of_frame[t]; }
-  if (t == 0) { tb.prior_n = ds.prior_n; tb.n_wheel = ds.n_wheel; }
+  if (t == 0) { tb.prior_n = ds.prior_n; tb.n_wheel = ds.n_wheel; tb.n_plane = ds.n_plane; tb.use_anchor = ds.use_anchor; }
   __syncthreads();
   const int gt = blockIdx.x * ASM_THREADS + t, gn = ASM_WGS * ASM_THREADS;
   const bool dense_here = (d.rank == 0);   // landmark sharding: the inertial / wheel / prior factors are added once (rank 0)
@@ -1211,7 +1272,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
       if (ent[u].x < 0) continue;
       const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
       double x = v[u];
-      if (b >= T_EXW && on[u] && dense_here && tb.n_wheel > 0) {
+      if (b >= T_EXW && a <= T_TDW && on[u] && dense_here && tb.n_wheel > 0) {
         // wheel extrinsic / intrinsic / td_wheel block: every wheel factor contributes (10 loads in flight)
         const int off = wheel_loc(b, 0) * 22 + wheel_loc(a, 0);   // global dims: the column does not depend on the factor
         double ws = 0.0;
@@ -1222,6 +1283,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
         }
         x += ws;
       }
+      if ((tb.n_plane > 0 || tb.use_anchor) && on[u] && dense_here) x += plane_anchor_term(d, w, tb.n_plane, tb.use_anchor, a, b);
       H[(size_t)a * ND + b] = x;   // lower triangle only (b <= a): k_solve never reads the mirror
     }
   }
@@ -1444,6 +1506,8 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
     for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
     cost += d.prior_g[(size_t)w * (ND + 2) + ND];
+    for (int q = 0; q < ds.n_plane; q++) cost += d.plane_part[((size_t)w * MAX_PLANE + q) * PLANE_PART + PLANE_PART - 2];
+    if (ds.use_anchor) cost += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
     c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
   }
   // Jacobi scaling (iteration 0 only), D = sqrt(clamp(diag)), scaled gradient, Cauchy direction
@@ -1942,6 +2006,9 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
         if (gs == 7) {
           const unsigned char *mask = (b == GFBE_BLK_EX_CAM) ? ds.ex_cam_mask : (b == GFBE_BLK_EX_WHEEL ? ds.ex_wheel_mask : nullptr);
           pose_plus(X + am, dl, mask, Y + am);
+        } else if (gs == 4) {   // para_plane_R: OrientationSubsetParameterization({2}) (estimator.cpp:3122)
+          const unsigned char constant[3] = {0, 0, 1};
+          orientation_plus(X + am, dl, constant, Y + am);
         } else {
           for (int k = 0; k < gs; k++) Y[am + k] = X[am + k] + dl[k];
         }
@@ -1980,6 +2047,8 @@ __global__ __launch_bounds__(64) void k_accept(BatchDev d) {
   if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 1];
   if (lane == 32) { cand += d.prior_g[(size_t)w * (ND + 2) + ND + 1]; d2 += d.dense_cand[(size_t)w * 4 + 1]; n2 += d.dense_cand[(size_t)w * 4 + 2]; }
   if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 28];
+  if (lane >= 48 && lane - 48 < ds.n_plane) cand += d.plane_part[((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - 1];
+  if (lane == 58 && ds.use_anchor) cand += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 1];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o, 64); d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
   if (lane != 0) return;
@@ -2153,7 +2222,7 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s) {
-  const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1), b(LM_TILE);
+  const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LM_TILE);
   if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d);
   else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d);
   else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d);
@@ -2162,12 +2231,13 @@ void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
   hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);
 }
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s) {
+  const int nf = MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0);   // (+ PlaneFactors and the PoseAnchorFactor)
   if (d.B < DENSE_SPLIT_MIN_B) {
-    hipLaunchKernelGGL(k_dense<true>, dim3(MAX_IMU + MAX_WHEEL + 1, d.B), dim3(64), 0, s, d, mode, debug_out);
+    hipLaunchKernelGGL(k_dense<true>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out);
     return;
   }
   if (mode != 3) hipLaunchKernelGGL(k_dense_raw, dim3(MAX_IMU + MAX_WHEEL, (d.B + 63) / 64), dim3(64), 0, s, d, mode);
-  hipLaunchKernelGGL(k_dense<false>, dim3(MAX_IMU + MAX_WHEEL + 1, d.B), dim3(64), 0, s, d, mode, debug_out);
+  hipLaunchKernelGGL(k_dense<false>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out);
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
   if (d.max_tiles == 0) return;

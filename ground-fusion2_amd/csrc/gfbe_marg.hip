@@ -43,6 +43,14 @@ __device__ __forceinline__ int m_wheel_loc(int a) {        // wheel factor (0, 1
   return -1;
 }
 
+__device__ __forceinline__ int m_plane_loc(int a) {        // PlaneFactor of pose 0
+  if (a < 6) return a;
+  if (a >= T_EXW && a < T_EXW + 6) return 6 + (a - T_EXW);
+  if (a >= T_PLR && a < T_PLR + 3) return 12 + (a - T_PLR);
+  if (a == T_PLZ) return 15;
+  return -1;
+}
+
 __device__ __forceinline__ int m_schur_off(int a, int b) {   // a <= b: offset inside a start-frame partial
   const int I = a >> 4, J = b >> 4;
   return (I * 5 - I * (I - 1) / 2 + (J - I)) * 256 + (a & 15) * 16 + (b & 15);
@@ -61,7 +69,7 @@ struct MargShared {
   int n_keep, n, m;
   int drop_dim[16];       // tangent dims being eliminated densely (15 for OLD, 6 for SECOND_NEW)
   int keep_dim[ND];       // tangent dim of kept column k
-  int use_imu, use_wheel;
+  int use_imu, use_wheel, use_plane;
   int passthrough;
   int sweeps;
 };
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   if (t == 0) {
     for (int q = 0; q < GFBE_BLK_COUNT; q++) sh.touched[q] = 0;
     for (int q = 0; q < ds.prior_nblk; q++) sh.touched[ds.prior_blk_id[q]] = 1;
-    sh.use_imu = sh.use_wheel = 0; sh.passthrough = 0;
+    sh.use_imu = sh.use_wheel = sh.use_plane = 0; sh.passthrough = 0;
     if (old) {
       for (int q = 0; q < ds.n_imu; q++) if (d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2] >= 0.0 && ds.imu_frame[q] == 0) sh.use_imu = 1 + q;
       for (int q = 0; q < ds.n_wheel; q++) if (d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2] >= 0.0 && ds.wheel_frame[q] == 0) sh.use_wheel = 1 + q;
@@ -214,6 +222,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
       if (sh.use_wheel) sh.touched[0] = sh.touched[1] = sh.touched[GFBE_BLK_EX_WHEEL] = sh.touched[GFBE_BLK_SX] = sh.touched[GFBE_BLK_SY] = sh.touched[GFBE_BLK_SW] = sh.touched[GFBE_BLK_TD_WHEEL] = 1;
       for (int j = 1; j < NF; j++)
         if (ds.pair_begin[j + 1] > ds.pair_begin[j]) sh.touched[0] = sh.touched[j] = sh.touched[GFBE_BLK_EX_CAM] = sh.touched[GFBE_BLK_TD] = 1;
+      if (ds.n_plane > 0 && d.plane_part[(size_t)w * MAX_PLANE * PLANE_PART + PLANE_PART - 2] >= 0.0) {   // estimator.cpp:3441-3448
+        sh.use_plane = 1;
+        sh.touched[0] = sh.touched[GFBE_BLK_EX_WHEEL] = sh.touched[GFBE_BLK_PLANE_R] = sh.touched[GFBE_BLK_PLANE_Z] = 1;
+      }
     }
     int m = 0;
     if (old) {
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE;   // start frame 0 partial (15 dense 16x16 tiles)
   const double *ipart = sh.use_imu ? d.imu_part + ((size_t)w * MAX_IMU + sh.use_imu - 1) * IMU_PART : nullptr;
   const double *wpart = sh.use_wheel ? d.wheel_part + ((size_t)w * MAX_WHEEL + sh.use_wheel - 1) * WHEEL_PART : nullptr;
+  const double *ppart = sh.use_plane ? d.plane_part + (size_t)w * MAX_PLANE * PLANE_PART : nullptr;
   // only the dims of the marginalisation (dropped + kept, nn <= 101 of 182) are ever read back: pairs (ia >= ib) of that list
   const int nn = n + m;
   for (int e = t; e < nn * (nn + 1) / 2; e += blockDim.x) {
@@ -279,6 +292,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     }
     if (ipart) { const int la = m_imu_loc(a), lb = m_imu_loc(b); if (la >= 0 && lb >= 0) s += ipart[la * 30 + lb]; }
     if (wpart) { const int la = m_wheel_loc(a), lb = m_wheel_loc(b); if (la >= 0 && lb >= 0) s += wpart[la * 22 + lb]; }
+    if (ppart) { const int la = m_plane_loc(a), lb = m_plane_loc(b); if (la >= 0 && lb >= 0) s += ppart[la * 16 + lb]; }
     if (ds.prior_n > 0) { const int pa = ds.prior_map[a], pb = ds.prior_map[b]; if (pa >= 0 && pb >= 0) s += d.prior_H[(size_t)w * ND * ND + (size_t)pa * ds.prior_n + pb]; }
     A[(size_t)a * ND + b] = s; A[(size_t)b * ND + a] = s;
   }
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     }
     if (ipart) { const int la = m_imu_loc(a); if (la >= 0) s += ipart[900 + la]; }
     if (wpart) { const int la = m_wheel_loc(a); if (la >= 0) s += wpart[484 + la]; }
+    if (ppart) { const int la = m_plane_loc(a); if (la >= 0) s += ppart[256 + la]; }
     if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
     bv[a] = s;
   }

@@ -4,15 +4,15 @@
 //   PoseAnchorFactor::Evaluate   factor/pose_anchor_factor.cpp:8-32   (6-D, pins para_Pose[0] when GNSS starts)
 //   OrientationSubsetParameterization::Plus   factor/orientation_subset_parameterization.cpp:27-45 (host)
 // One thread per factor; tangent-space Jacobians (the leading 6 / 3 columns of every block, as the [I; 0] ComputeJacobian
-// of the parameterizations gives). The factors are not wired into gfbe_solve_window (all shipped yamls leave plane: 0 and
-// gnss_enable: 0): a caller can evaluate them in batches of any size.
+// of the parameterizations gives). Stand-alone evaluation in batches of any size; the same device functions (plane_eval,
+// anchor_eval in gfbe_factors.h) run inside the window solve when gfbe_window.use_plane / use_anchor are set.
 #include <hip/hip_runtime.h>
 
 #include <string>
 #include <vector>
 
 #include "gfbe_device.h"
-#include "gfbe_math.h"
+#include "gfbe_factors.h"
 
 using namespace gfd;
 
@@ -23,34 +23,13 @@ struct PlaneConst { double ex[7], q[4], z, ninv[3]; };
 __global__ __launch_bounds__(256) void k_plane(int n, const double *pose, PlaneConst pc, double *r, double *J, double *cost_part) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) {
-    const vec3 tio = ld3(pc.ex), Pi = ld3(pose + 7 * (size_t)k);
-    const mat3 Rio = qrot(ldq(pc.ex + 3)), Rpw = qrot(ldq(pc.q)), Ri = qrot(ldq(pose + 7 * (size_t)k + 3));
-    const vec3 up_p = tmv(Rpw, mk3(0, 0, 1)), up_b = tmv(Ri, up_p), up_o = tmv(Rio, up_b);
-    const vec3 lever = add(Pi, mv(Ri, tio));
-    const double res[3] = {pc.ninv[0] * up_o[0], pc.ninv[1] * up_o[1], pc.ninv[2] * (pc.z + mv(Rpw, lever)[2])};
+    double res[3], Jl[48];
+    plane_eval(pose + 7 * (size_t)k, pc.ex, pc.q, pc.z, pc.ninv, res, J ? Jl : nullptr);
     double c = 0.5 * res[0] * res[0];
     c += 0.5 * res[1] * res[1];
     c += 0.5 * res[2] * res[2];
     if (r) for (int i = 0; i < 3; i++) r[3 * (size_t)k + i] = res[i];
-    if (J) {
-      double *Jk = J + (size_t)k * 48;
-      for (int i = 0; i < 48; i++) Jk[i] = 0.0;
-      const mat3 A = tmul(Rio, hat(up_b)), Bm = hat(up_o), Cq = tmul(Rio, tmul(Ri, hat(up_p)));
-      const mat3 RpwRi = mul(Rpw, Ri), D = mul(RpwRi, hat(tio)), E = mul(Rpw, hat(lever));
-      for (int row = 0; row < 2; row++)
-        for (int j = 0; j < 3; j++) {
-          Jk[row * 16 + 3 + j] = pc.ninv[row] * A(row, j);
-          Jk[row * 16 + 9 + j] = pc.ninv[row] * Bm(row, j);
-          Jk[row * 16 + 12 + j] = pc.ninv[row] * Cq(row, j);
-        }
-      for (int j = 0; j < 3; j++) {
-        Jk[32 + j] = pc.ninv[2] * Rpw(2, j);
-        Jk[32 + 3 + j] = -pc.ninv[2] * D(2, j);
-        Jk[32 + 6 + j] = pc.ninv[2] * RpwRi(2, j);
-        Jk[32 + 12 + j] = -pc.ninv[2] * E(2, j);
-      }
-      Jk[32 + 15] = pc.ninv[2];
-    }
+    if (J) for (int i = 0; i < 48; i++) J[(size_t)k * 48 + i] = Jl[i];
     cost_part[k] = c;       // summed in factor order on the host
   }
 }
@@ -59,22 +38,12 @@ __global__ __launch_bounds__(256) void k_anchor(int n, const double *pose, const
                                                 double *cost_part) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const double *x = pose + 7 * (size_t)k, *a = anchor + 7 * (size_t)k;
-  const quat qa_inv = qinv(ldq(a + 3));
-  const vec3 dv = qvec(qmul(ldq(x + 3), qa_inv));
-  double res[6];
-  for (int i = 0; i < 3; i++) { res[i] = sqrt_info * (x[i] - a[i]); res[3 + i] = sqrt_info * 2.0 * dv[i]; }
+  double res[6], Jl[36];
+  anchor_eval(pose + 7 * (size_t)k, anchor + 7 * (size_t)k, sqrt_info, res, J ? Jl : nullptr);
   double c = 0.0;
   for (int i = 0; i < 6; i++) c += 0.5 * res[i] * res[i];
   if (r) for (int i = 0; i < 6; i++) r[6 * (size_t)k + i] = res[i];
-  if (J) {
-    double *Jk = J + (size_t)k * 36;
-    for (int i = 0; i < 36; i++) Jk[i] = 0.0;
-    const double s = 2.0 * sqrt_info;          // the reference scales the whole Jacobian by 2 sqrt_info (pose_anchor_factor.cpp:29)
-    for (int i = 0; i < 3; i++) Jk[i * 6 + i] = s;
-    const mat3 Jq = qright3(qa_inv);
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jk[(3 + i) * 6 + 3 + j] = s * Jq(i, j);
-  }
+  if (J) for (int i = 0; i < 36; i++) J[(size_t)k * 36 + i] = Jl[i];
   cost_part[k] = c;
 }
 

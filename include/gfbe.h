@@ -29,7 +29,8 @@ extern "C" {
 #define GFBE_WINDOW_SIZE 10 /* parameters.h:24 */
 #define GFBE_NFRAMES 11     /* WINDOW_SIZE + 1 */
 #define GFBE_MAX_OBS 11     /* a landmark has at most one observation per frame */
-#define GFBE_DENSE_DIM 182  /* 11*6 + 11*9 + 6 + 6 + 3 + 1 + 1 tangent dims */
+#define GFBE_DENSE_DIM 187  /* 11*6 + 11*9 + 6 + 6 + 3 + 1 + 1 tangent dims + 4 + 1 of the ground plane (para_plane_R is
+                               marginalised as a 4-D block without a manifold, marginalization_factor.cpp:140-143: four prior columns) */
 #define GFBE_MAX_PRIOR_BLOCKS 32
 
 typedef enum gfbe_status {
@@ -51,7 +52,9 @@ enum {
   GFBE_BLK_SX = 24, GFBE_BLK_SY = 25, GFBE_BLK_SW = 26, /* para_Ix_s{x,y,w}_wheel size 1 */
   GFBE_BLK_TD = 27,     /* para_Td       size 1 */
   GFBE_BLK_TD_WHEEL = 28, /* para_Td_wheel size 1 */
-  GFBE_BLK_COUNT = 29
+  GFBE_BLK_PLANE_R = 29,  /* para_plane_R  size 4 (quaternion x y z w, OrientationSubsetParameterization({2}): estimator.cpp:3120-3123) */
+  GFBE_BLK_PLANE_Z = 30,  /* para_plane_Z  size 1 */
+  GFBE_BLK_COUNT = 31
 };
 
 /* The dense ("camera side") parameter blocks of one window — what vector2double() fills
@@ -64,7 +67,9 @@ typedef struct gfbe_state {
   double para_Ix_wheel[3];       /* sx, sy, sw */
   double para_Td;
   double para_Td_wheel;
-} gfbe_state; /* 195 doubles */
+  double para_plane_R[4];        /* ground plane in the world: rotation (x y z w) and height (estimator.h:233-236); used with use_plane */
+  double para_plane_Z;
+} gfbe_state; /* 200 doubles */
 
 /* What IMUFactor reads from IntegrationBase (imu_factor.h:69-90, integration_base.h:169-195). */
 typedef struct gfbe_imu_preint {
@@ -151,7 +156,13 @@ typedef struct gfbe_window {
   /* PoseSubsetParameterization constancy masks (pose_subset_parameterization.cpp:11-45): tangent
    * components zeroed in Plus only (the Jacobian stays unmasked — reference quirk, reproduced). */
   uint8_t ex_cam_mask[6], ex_wheel_mask[6];
-  uint8_t _pad[3];
+  /* Optional in-window factors (estimator.cpp:3120-3136, 3214-3228, 3004-3012; all shipped yamls: plane 0, gnss_enable 0):
+   *   use_plane   one PlaneFactor (plane_factor.h:25-122) per window pose i < frame_count on {Pose[i], Ex_Pose_wheel, plane_R,
+   *               plane_Z}; the MARGIN_OLD set takes the one of frame 0 (estimator.cpp:3441-3448). plane_const = the
+   *               SetParameterBlockConstant decision of :3126-3135.
+   *   use_anchor  one PoseAnchorFactor (pose_anchor_factor.cpp:8-32) on Pose[0] (the `first_optimization && GNSS_ENABLE`
+   *               block, :3004-3012). */
+  uint8_t use_plane, plane_const, use_anchor;
   int32_t n_imu;                /* IMU factors; factor k links frames imu_frame[k], imu_frame[k]+1 */
   const int32_t *imu_frame;
   const gfbe_imu_preint *imu;
@@ -161,6 +172,9 @@ typedef struct gfbe_window {
   gfbe_visual vis;
   const gfbe_prior *prior;      /* NULL or !valid => no MarginalizationFactor */
   gfbe_lio_block lio;           /* optional LiDAR factors on one pose (n = 0: none) */
+  double plane_noise_inv[3];    /* PITCH_N_INV, ROLL_N_INV, ZPW_N_INV (parameters.cpp:340-345) */
+  double anchor_pose[7];        /* PoseAnchorFactor's anchor_value (para_Pose[0] at the first optimisation) */
+  double anchor_sqrt_info;      /* 120 in the reference (pose_anchor_factor.h:19) */
 } gfbe_window;
 
 typedef struct gfbe_options {

@@ -19,6 +19,8 @@ const double *block_ptr(const gfbe_state &st, int id) {
     case GFBE_BLK_SW: return &st.para_Ix_wheel[2];
     case GFBE_BLK_TD: return &st.para_Td;
     case GFBE_BLK_TD_WHEEL: return &st.para_Td_wheel;
+    case GFBE_BLK_PLANE_R: return st.para_plane_R;
+    case GFBE_BLK_PLANE_Z: return &st.para_plane_Z;
   }
   return nullptr;
 }
@@ -27,6 +29,8 @@ int block_global_size(int id) {
   if (id < GFBE_BLK_SB0) return 7;
   if (id < GFBE_BLK_EX_CAM) return 9;
   if (id == GFBE_BLK_EX_CAM || id == GFBE_BLK_EX_WHEEL) return 7;
+  if (id == GFBE_BLK_PLANE_R) return 4;   // (local size 4 as well: MarginalizationInfo::localSize only knows size-7 manifolds,
+                                          //  marginalization_factor.cpp:140-143; the solve leaves the 4th tangent slot inactive)
   return 1;
 }
 int block_local_size(int id) { int g = block_global_size(id); return g == 7 ? 6 : g; }

@@ -22,6 +22,13 @@
 #include <algorithm>
 #include <limits>
 
+// the optional in-window factors (gfo_optional.cpp)
+extern "C" int32_t gfo_plane_eval(void *, int32_t n, const double *pose, const double *ex_wheel, const double *plane_R, double plane_Z,
+                                  const double *noise_inv, double *r, double *J, double *cost);
+extern "C" int32_t gfo_anchor_eval(void *, int32_t n, const double *pose, const double *anchor, double sqrt_info, double *r, double *J,
+                                   double *cost);
+extern "C" void gfo_orientation_subset_plus(const double *q, const double *delta, const uint8_t *constant, double *out);
+
 namespace gfo {
 
 // ---- tangent layout of the dense block (oracle's own; the product documents its layout in DESIGN.md)
@@ -29,7 +36,7 @@ enum { NV = 73, ND = GFBE_DENSE_DIM };
 static inline int T_POSE(int k) { return 6 * k; }
 enum { T_EX = 66, T_TD = 72 };
 static inline int T_SB(int k) { return 73 + 9 * k; }
-enum { T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181 };
+enum { T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181, T_PLR = 182, T_PLZ = 186 };
 
 static int tan_off(int id) {
   if (id < GFBE_BLK_SB0) return T_POSE(id);
@@ -42,6 +49,8 @@ static int tan_off(int id) {
     case GFBE_BLK_SW: return T_SW;
     case GFBE_BLK_TD: return T_TD;
     case GFBE_BLK_TD_WHEEL: return T_TDW;
+    case GFBE_BLK_PLANE_R: return T_PLR;
+    case GFBE_BLK_PLANE_Z: return T_PLZ;
   }
   return -1;
 }
@@ -113,6 +122,11 @@ static bool setup(Problem &P, const gfbe_window *win, const gfbe_options *opt) {
     if (win->lio.frame < 0 || win->lio.frame > win->frame_count) return false;
     P.blk_used[GFBE_BLK_POSE0 + win->lio.frame] = true;
   }
+  if (win->use_plane) {       // one PlaneFactor per pose i < frame_count (estimator.cpp:3214-3220)
+    for (int i = 0; i < win->frame_count; i++) P.blk_used[GFBE_BLK_POSE0 + i] = true;
+    if (win->frame_count > 0) P.blk_used[GFBE_BLK_EX_WHEEL] = P.blk_used[GFBE_BLK_PLANE_R] = P.blk_used[GFBE_BLK_PLANE_Z] = true;
+  }
+  if (win->use_anchor) P.blk_used[GFBE_BLK_POSE0] = true;
   for (int b = 0; b < GFBE_BLK_COUNT; b++) {
     bool c;
     if (b < GFBE_BLK_SB0) c = win->pose_const[b] || b > win->frame_count;
@@ -121,12 +135,14 @@ static bool setup(Problem &P, const gfbe_window *win, const gfbe_options *opt) {
     else if (b == GFBE_BLK_EX_WHEEL) c = win->ex_wheel_const;
     else if (b == GFBE_BLK_TD) c = win->td_const;
     else if (b == GFBE_BLK_TD_WHEEL) c = win->td_wheel_const;
+    else if (b == GFBE_BLK_PLANE_R || b == GFBE_BLK_PLANE_Z) c = win->plane_const;
     else c = win->ix_wheel_const;
     P.blk_free[b] = P.blk_used[b] && !c;
   }
   for (int d = 0; d < ND; d++) P.act[d] = false;
   for (int b = 0; b < GFBE_BLK_COUNT; b++)
     if (P.blk_free[b]) for (int k = 0; k < block_local_size(b); k++) P.act[tan_off(b) + k] = true;
+  P.act[T_PLR + 3] = false;   // the quaternion's 4th slot exists in the prior only (OrientationSubsetParameterization: 3 tangent dims)
   return P.ok;
 }
 
@@ -240,6 +256,32 @@ static double evaluate(const Problem &P, const gfbe_state &st, const double *lam
       accum(*lin, r, J, 1, 6, map);
     }
   }
+  // --- PlaneFactor per pose i < frame_count (estimator.cpp:3214-3220; plane_factor.h:25-122), no loss
+  if (w.use_plane) {
+    for (int i = 0; i < w.frame_count; i++) {
+      double r[3], J[48];
+      gfo_plane_eval(nullptr, 1, st.para_Pose[i], st.para_Ex_Pose_wheel, st.para_plane_R, st.para_plane_Z, w.plane_noise_inv, r, lin ? J : nullptr, nullptr);
+      for (int q = 0; q < 3; q++) cost += 0.5 * r[q] * r[q];
+      if (lin) {
+        int map[16];
+        for (int q = 0; q < 6; q++) { map[q] = T_POSE(i) + q; map[6 + q] = T_EXW + q; }
+        for (int q = 0; q < 3; q++) map[12 + q] = T_PLR + q;
+        map[15] = T_PLZ;
+        accum(*lin, r, J, 3, 16, map);
+      }
+    }
+  }
+  // --- PoseAnchorFactor on Pose[0] (estimator.cpp:3004-3012; pose_anchor_factor.cpp:8-32), no loss
+  if (w.use_anchor) {
+    double r[6], J[36];
+    gfo_anchor_eval(nullptr, 1, st.para_Pose[0], w.anchor_pose, w.anchor_sqrt_info, r, lin ? J : nullptr, nullptr);
+    for (int q = 0; q < 6; q++) cost += 0.5 * r[q] * r[q];
+    if (lin) {
+      int map[6];
+      for (int q = 0; q < 6; q++) map[q] = T_POSE(0) + q;
+      accum(*lin, r, J, 6, 6, map);
+    }
+  }
   if (lin) {
     // Remove constant / unused dims from the reduced program.
     for (int a = 0; a < ND; a++)
@@ -274,6 +316,9 @@ static void plus(const Problem &P, const gfbe_state &x, const double *lam, const
       for (int k = 0; k < 3; k++) yb[k] = xb[k] + d[k];
       Q4 q = normalized(q4(xb + 3) * deltaQ(v3(d + 3)));
       yb[3] = q.x; yb[4] = q.y; yb[5] = q.z; yb[6] = q.w;
+    } else if (gs == 4) {   // para_plane_R: OrientationSubsetParameterization({2}) (estimator.cpp:3122; .cpp:27-45)
+      const uint8_t constant[3] = {0, 0, 1};
+      gfo_orientation_subset_plus(xb, dp + off, constant, yb);
     } else {
       for (int k = 0; k < gs; k++) yb[k] = xb[k] + dp[off + k];
     }
@@ -549,6 +594,8 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
     for (int k = 0; k < w.n_wheel; k++) if (w.wheel_frame[k] == 0 && w.wheel[k].sum_dt < 10.0) { use_wheel0 = true; wheel0 = k; }
     if (use_imu0) touched[GFBE_BLK_POSE0] = touched[GFBE_BLK_SB0] = touched[GFBE_BLK_POSE0 + 1] = touched[GFBE_BLK_SB0 + 1] = true;
     if (use_wheel0) touched[GFBE_BLK_POSE0] = touched[GFBE_BLK_POSE0 + 1] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_SX] = touched[GFBE_BLK_SY] = touched[GFBE_BLK_SW] = touched[GFBE_BLK_TD_WHEEL] = true;
+    if (w.use_plane && w.frame_count > 0)     // estimator.cpp:3441-3448: the PlaneFactor of frame 0, drop set {Pose[0]}
+      touched[GFBE_BLK_POSE0] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_PLANE_R] = touched[GFBE_BLK_PLANE_Z] = true;
     std::vector<uint8_t> seen(P.L, 0);
     for (int k = 0; k < w.vis.n_factor; k++) {
       if (w.vis.imu_i[k] != 0) continue;
@@ -613,6 +660,14 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
     for (int q = 0; q < 6; q++) { map[q] = idx_of[GFBE_BLK_POSE0] + q; map[6 + q] = idx_of[GFBE_BLK_POSE0 + 1] + q; map[12 + q] = idx_of[GFBE_BLK_EX_WHEEL] + q; }
     map[18] = idx_of[GFBE_BLK_SX]; map[19] = idx_of[GFBE_BLK_SY]; map[20] = idx_of[GFBE_BLK_SW]; map[21] = idx_of[GFBE_BLK_TD_WHEEL];
     add(r, J, 6, 22, map);
+  }
+  if (flag == GFBE_MARGIN_OLD && w.use_plane && w.frame_count > 0) {
+    double r[3], J[48]; int map[16];
+    gfo_plane_eval(nullptr, 1, st.para_Pose[0], st.para_Ex_Pose_wheel, st.para_plane_R, st.para_plane_Z, w.plane_noise_inv, r, J, nullptr);
+    for (int q = 0; q < 6; q++) { map[q] = idx_of[GFBE_BLK_POSE0] + q; map[6 + q] = idx_of[GFBE_BLK_EX_WHEEL] + q; }
+    for (int q = 0; q < 3; q++) map[12 + q] = idx_of[GFBE_BLK_PLANE_R] + q;     // (the factor's 3 x 4 block has a zero 4th column)
+    map[15] = idx_of[GFBE_BLK_PLANE_Z];
+    add(r, J, 3, 16, map);
   }
   if (flag == GFBE_MARGIN_OLD) {
     const gfbe_visual &v = w.vis;

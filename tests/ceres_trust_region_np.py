@@ -57,6 +57,10 @@ def _block_table(snap):
         touched |= {("pose", int(f)), ("pose", int(f) + 1), ("exw", 0), ("sx", 0), ("sy", 0), ("sw", 0), ("tdw", 0)}
     for k in range(K):
         touched |= {("pose", int(snap["vis_imu_i"][k])), ("pose", int(snap["vis_imu_j"][k])), ("exc", 0), ("td", 0)}
+    if snap.get("plane") is not None and fc > 0:      # PlaneFactor on every pose i < frame_count (estimator.cpp:3214-3220)
+        touched |= {("pose", i) for i in range(fc)} | {("exw", 0), ("plr", 0), ("plz", 0)}
+    if snap.get("anchor") is not None:
+        touched.add(("pose", 0))
     if prior is not None:
         for bid in prior["block_id"]:
             touched.add(_block_of_id(int(bid)))
@@ -76,9 +80,13 @@ def _block_table(snap):
         const.add(("tdw", 0))
     if int(snap.get("ix_wheel_const", 1)):
         const |= {("sx", 0), ("sy", 0), ("sw", 0)}
-    order = [("exc", 0), ("td", 0)] + [("sb", i) for i in range(abi.NFRAMES)] + [("tdw", 0), ("sw", 0), ("sy", 0), ("sx", 0), ("exw", 0)] + \
-            [("pose", i) for i in range(abi.NFRAMES)][::-1]
-    sizes = {"pose": (7, 6), "sb": (9, 9), "exc": (7, 6), "exw": (7, 6), "td": (1, 1), "tdw": (1, 1), "sx": (1, 1), "sy": (1, 1), "sw": (1, 1)}
+    if snap.get("plane") is not None and int(snap["plane"].get("const", 0)):
+        const |= {("plr", 0), ("plz", 0)}
+    order = [("plz", 0), ("exc", 0), ("td", 0)] + [("sb", i) for i in range(abi.NFRAMES)] + [("tdw", 0), ("sw", 0), ("sy", 0), ("sx", 0), ("exw", 0)] + \
+            [("pose", i) for i in range(abi.NFRAMES)][::-1] + [("plr", 0)]
+    # (global size, tangent size in the solve). para_plane_R: a quaternion on OrientationSubsetParameterization — 3 tangent dims
+    sizes = {"pose": (7, 6), "sb": (9, 9), "exc": (7, 6), "exw": (7, 6), "td": (1, 1), "tdw": (1, 1), "sx": (1, 1), "sy": (1, 1), "sw": (1, 1),
+             "plr": (4, 3), "plz": (1, 1)}
     free = [b for b in order if b in touched and b not in const]
     off, table = 0, {}
     for b in free:
@@ -93,7 +101,8 @@ def _block_of_id(bid):
     if bid < abi.BLK_EX_CAM:
         return ("sb", bid - abi.BLK_SB0)
     return {abi.BLK_EX_CAM: ("exc", 0), abi.BLK_EX_WHEEL: ("exw", 0), abi.BLK_SX: ("sx", 0), abi.BLK_SY: ("sy", 0),
-            abi.BLK_SW: ("sw", 0), abi.BLK_TD: ("td", 0), abi.BLK_TD_WHEEL: ("tdw", 0)}[bid]
+            abi.BLK_SW: ("sw", 0), abi.BLK_TD: ("td", 0), abi.BLK_TD_WHEEL: ("tdw", 0), abi.BLK_PLANE_R: ("plr", 0),
+            abi.BLK_PLANE_Z: ("plz", 0)}[bid]
 
 
 class Problem:
@@ -115,10 +124,27 @@ class Problem:
         o = self.table.get(b)
         return None if o is None else np.arange(o, o + self.sizes[b[0]][1])
 
+    def _optional(self, snap):
+        """Plane / anchor factors through the stand-alone evaluators (pinned on their own in tests/test_optional_oracle.py)."""
+        out = []
+        fc = int(snap.get("frame_count", abi.WINDOW_SIZE))
+        if snap.get("plane") is not None and fc > 0:
+            e = abi.plane_eval(self.api.lib, self.api.prefix, None, np.asarray(snap["pose"])[:fc], snap["ex_pose_wheel"],
+                               snap.get("plane_R", [0, 0, 0, 1.0]), float(snap.get("plane_Z", 0.0)), snap["plane"]["noise_inv"])
+            for i in range(fc):
+                out.append((e["r"][i], e["J"][i], [(("pose", i), 6), (("exw", 0), 6), (("plr", 0), 3), (("plz", 0), 1)]))
+        if snap.get("anchor") is not None:
+            e = abi.anchor_eval(self.api.lib, self.api.prefix, None, np.asarray(snap["pose"])[:1], np.asarray(snap["anchor"]["pose"])[None],
+                                float(snap["anchor"].get("sqrt_info", 120.0)))
+            out.append((e["r"][0], e["J"][0], [(("pose", 0), 6)]))
+        return out
+
     def evaluate(self, snap, want_jacobian=True):
         ev = self.api.eval_factors(snap, robustify=True)
+        opt = self._optional(snap)
+        cost = ev["cost"]      # (the whole objective: eval_factors counts the optional factors' cost too)
         if not want_jacobian:
-            return ev["cost"], None, None
+            return cost, None, None
         rows_r, rows_J = [], []
 
         def add(r, Jb, blocks):
@@ -127,7 +153,7 @@ class Problem:
             for b, w in blocks:
                 cols = b if isinstance(b, np.ndarray) else self._cols(b)
                 if cols is not None and len(cols):
-                    Jrow[:, cols] = Jb[:, c0:c0 + w]
+                    Jrow[:, cols] = Jb[:, c0:c0 + len(cols)]
                 c0 += w
             rows_r.append(r)
             rows_J.append(Jrow)
@@ -152,9 +178,14 @@ class Problem:
                 b = _block_of_id(int(pr["block_id"][q]))
                 blocks.append((b, self.sizes[b[0]][1]))
             # J0's columns are laid out by block_idx: reorder to the sorted-by-offset sequence used above
-            perm = np.concatenate([np.arange(int(pr["block_idx"][q]), int(pr["block_idx"][q]) + self.sizes[_block_of_id(int(pr["block_id"][q]))[0]][1]) for q in order])
+            # (a 4-wide prior block of the plane quaternion carries 4 columns; the solve's tangent Jacobian is the first three —
+            #  OrientationSubsetParameterization::ComputeJacobian = [I3; 0] — and the residual uses all four differences)
+            blocks = [(b, w) if b[0] != "plr" else (b, 4) for b, w in blocks]
+            perm = np.concatenate([np.arange(int(pr["block_idx"][q]), int(pr["block_idx"][q]) + (4 if _block_of_id(int(pr["block_id"][q]))[0] == "plr" else self.sizes[_block_of_id(int(pr["block_id"][q]))[0]][1])) for q in order])
             add(ev["prior_r"], J0[:, perm], blocks)
-        return ev["cost"], np.concatenate(rows_r), np.vstack(rows_J)
+        for r_, J_, blocks in opt:
+            add(r_, J_, blocks)
+        return cost, np.concatenate(rows_r), np.vstack(rows_J)
 
     # ---- manifold
     def plus(self, snap, delta):
@@ -188,6 +219,12 @@ class Problem:
                 s["td"] = float(snap["td"]) + d[0]
             elif b[0] == "tdw":
                 s["td_wheel"] = float(snap["td_wheel"]) + d[0]
+            elif b[0] == "plr":      # OrientationSubsetParameterization({2}): component 2 held in Plus
+                dq = np.array([0.5 * d[0], 0.5 * d[1], 0.0, 1.0])
+                q = synth.qmul(np.asarray(snap.get("plane_R", [0, 0, 0, 1.0]), float), dq)
+                s["plane_R"] = q / np.linalg.norm(q)
+            elif b[0] == "plz":
+                s["plane_Z"] = float(snap.get("plane_Z", 0.0)) + d[0]
             else:
                 s["ix_wheel"][{"sx": 0, "sy": 1, "sw": 2}[b[0]]] += d[0]
         s["para_feature"][self.lm_free] += delta[self.nd:]
@@ -209,6 +246,10 @@ class Problem:
                 parts.append([float(snap["td"])])
             elif b[0] == "tdw":
                 parts.append([float(snap["td_wheel"])])
+            elif b[0] == "plr":
+                parts.append(np.asarray(snap.get("plane_R", [0, 0, 0, 1.0]), float))
+            elif b[0] == "plz":
+                parts.append([float(snap.get("plane_Z", 0.0))])
             else:
                 parts.append([np.asarray(snap["ix_wheel"])[{"sx": 0, "sy": 1, "sw": 2}[b[0]]]])
         parts.append(np.asarray(snap["para_feature"])[self.lm_free])

@@ -34,7 +34,7 @@ class Oracle(abi.CApi):
     def linearize(self, snap):
         wh = snap if isinstance(snap, abi.WindowHolder) else abi.WindowHolder(snap)
         L = wh.n_feature
-        H, g = np.zeros((182, 182)), np.zeros(182)
+        H, g = np.zeros((abi.DENSE_DIM, abi.DENSE_DIM)), np.zeros(abi.DENSE_DIM)
         Hll, gl, Hpl = np.zeros(L), np.zeros(L), np.zeros((L, 73))
         cost = C.c_double(0)
         rc = self.lib.gfo_linearize(self.head, C.byref(wh.c), abi._pd(H), abi._pd(g), abi._pd(Hll), abi._pd(gl),
@@ -50,7 +50,7 @@ class Oracle(abi.CApi):
     def marginalize(self, snap, flag):
         wh = snap if isinstance(snap, abi.WindowHolder) else abi.WindowHolder(snap)
         pr = abi.PriorHolder()
-        A, b = np.zeros(182 * 182), np.zeros(182)
+        A, b = np.zeros(abi.DENSE_DIM * abi.DENSE_DIM), np.zeros(abi.DENSE_DIM)
         rc = self.lib.gfo_marginalize(self.head, C.byref(wh.c), int(flag), C.byref(pr.c), abi._pd(A), abi._pd(b))
         if rc != 0 or not pr.c.valid:
             return None, None, None, rc

@@ -30,7 +30,7 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_struct_layouts_match_header(lib):
-    assert C.sizeof(abi.State) == 195 * 8
+    assert C.sizeof(abi.State) == 200 * 8
     assert C.sizeof(abi.ImuPreint) == 467 * 8
     assert C.sizeof(abi.WheelPreint) == 78 * 8
     o = abi.Options()

@@ -1,0 +1,56 @@
+"""PlaneFactor / PoseAnchorFactor inside the window solve and the marginalisation on the GPU (gfbe_window.use_plane / use_anchor;
+estimator.cpp:3120-3136, 3214-3228, 3441-3448, 3004-3012) against the CPU oracle, with the tolerances of check_solve."""
+import numpy as np
+import pytest
+
+from _gfbe_import import gf
+from plane_cases import next_plane_window, plane_window
+from test_gpu_parity import check_solve
+
+abi, synth = gf.abi, gf.synth
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    return gf.Backend(device=0)
+
+
+def check_prior(pw, pg):
+    assert pg["block_id"].tolist() == pw["block_id"].tolist() and pg["block_size"].tolist() == pw["block_size"].tolist()
+    assert pg["block_idx"].tolist() == pw["block_idx"].tolist() and pg["n"] == pw["n"]
+    np.testing.assert_allclose(pg["x0"], pw["x0"], rtol=0, atol=1e-6)
+    Aw, Ag = pw["J0"].T @ pw["J0"], pg["J0"].T @ pg["J0"]
+    assert np.abs(Ag - Aw).max() < 1e-7 * np.abs(Aw).max()
+    bw, bg = pw["J0"].T @ pw["r0"], pg["J0"].T @ pg["r0"]
+    assert np.abs(bg - bw).max() < 1e-6 * max(np.abs(bw).max(), 1.0)
+
+
+@pytest.mark.parametrize("anchor", [True, False])
+def test_plane_in_solve_and_marginalisation(be, oracle, anchor):
+    scn, snap = plane_window(anchor=anchor)
+    want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD)
+    assert np.abs(got["state"]["plane_R"] - want["state"]["plane_R"]).max() < 1e-9 and abs(got["state"]["plane_Z"] - want["state"]["plane_Z"]) < 1e-8
+    assert abi.BLK_PLANE_R in got["prior"]["block_id"].tolist()
+    check_prior(want["prior"], got["prior"])
+    # the next window: the prior carries the 4-wide plane block; rejected steps make it an unsettled run (tolerances x 100)
+    snap2 = next_plane_window(scn, snap, want)
+    for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
+        want2, got2 = check_solve(be, oracle, snap2, flag, loose=100.0)
+        check_prior(want2["prior"], got2["prior"])
+
+
+def test_plane_constant_and_mixed_batch(be, oracle):
+    """SetParameterBlockConstant(para_plane_R / para_plane_Z) (estimator.cpp:3126-3135), and a batch that mixes windows with and
+    without the optional factors (bit-identical to their single solves)."""
+    scn, snap_c = plane_window(anchor=False, const=1)
+    want, got = check_solve(be, oracle, snap_c, abi.MARGIN_OLD)
+    assert np.array_equal(got["state"]["plane_R"], snap_c["plane_R"]) and got["state"]["plane_Z"] == snap_c["plane_Z"]
+    check_prior(want["prior"], got["prior"])
+    _, snap_p = plane_window(seed=72)
+    plain = synth.Scenario(seed=73, n_landmarks=150, use_wheel=True).window(0)
+    singles = [be.solve(s, abi.MARGIN_OLD) for s in (snap_p, plain, snap_c)]
+    batch = be.solve_batch([snap_p, plain, snap_c], abi.MARGIN_OLD)
+    for a, b in zip(singles, batch):
+        assert a["summary"] == b["summary"]
+        assert np.array_equal(a["state"]["pose"], b["state"]["pose"]) and np.array_equal(a["prior"]["J0"], b["prior"]["J0"])

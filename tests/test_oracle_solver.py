@@ -16,7 +16,7 @@ T_EXW, T_SX, T_SY, T_SW, T_TDW = 172, 178, 179, 180, 181
 
 def numpy_normal_equations(snap, ev):
     """H = sum J'J, g = sum J'r from the block-CSR factor outputs (robustified)."""
-    H, g = np.zeros((182, 182)), np.zeros(182)
+    H, g = np.zeros((abi.DENSE_DIM, abi.DENSE_DIM)), np.zeros(abi.DENSE_DIM)
     L = len(snap["para_feature"])
     Hll, gl, Hpl = np.zeros(L), np.zeros(L), np.zeros((L, 73))
     for k in range(len(snap["vis_imu_i"])):
