@@ -752,3 +752,54 @@ def orientation_subset_plus(lib, prefix, q, delta, constant=(0, 0, 1)):
     f.argtypes = [PD, PD, PU8, PD]
     f(_pd(q), _pd(d), m.ctypes.data_as(PU8), _pd(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# f2: GNSS factors, evaluation only (gfbe_gnss_eval)
+# ---------------------------------------------------------------------------------------------
+class GnssObs(C.Structure):
+    _fields_ = [("sv_pos", c_d * 3), ("sv_vel", c_d * 3), ("svdt", c_d), ("svddt", c_d), ("tgd", c_d), ("pr_uura", c_d), ("dp_uura", c_d),
+                ("psr", c_d), ("dopp", c_d), ("wavelength", c_d), ("ratio", c_d), ("doy", c_d), ("tow", c_d),
+                ("frame", c_i), ("lower_idx", c_i), ("sys_idx", c_i), ("_pad", c_i)]
+
+
+class GnssState(C.Structure):
+    _fields_ = [("rcv_dt", (c_d * 4) * NFRAMES), ("rcv_ddt", c_d * NFRAMES), ("yaw_enu_local", c_d), ("anc_ecef", c_d * 3)]
+
+
+GNSS_OBS_KEYS = ("svdt", "svddt", "tgd", "pr_uura", "dp_uura", "psr", "dopp", "wavelength", "ratio", "doy", "tow", "frame", "lower_idx", "sys_idx")
+
+
+def gnss_eval(lib, prefix, ctx, obs, iono, pose, speed_bias, rcv_dt, rcv_ddt, yaw_enu_local, anc_ecef, frame_dt, ddt_weight, want_J=True):
+    """obs: list of dicts with sv_pos, sv_vel and GNSS_OBS_KEYS. pose [11][7], speed_bias [11][9] (the window state's blocks)."""
+    n = len(obs)
+    arr = (GnssObs * max(n, 1))()
+    for k, o in enumerate(obs):
+        arr[k].sv_pos[:] = [float(x) for x in o["sv_pos"]]
+        arr[k].sv_vel[:] = [float(x) for x in o["sv_vel"]]
+        for key in GNSS_OBS_KEYS:
+            setattr(arr[k], key, o[key])
+    st = State()
+    p, sb = _f64(pose).reshape(NFRAMES, 7), _f64(speed_bias).reshape(NFRAMES, 9)
+    for i in range(NFRAMES):
+        st.para_Pose[i][:] = p[i].tolist()
+        st.para_SpeedBias[i][:] = sb[i].tolist()
+    g = GnssState()
+    rd = _f64(rcv_dt).reshape(NFRAMES, 4)
+    for i in range(NFRAMES):
+        g.rcv_dt[i][:] = rd[i].tolist()
+    g.rcv_ddt[:] = _f64(rcv_ddt).tolist()
+    g.yaw_enu_local = float(yaw_enu_local)
+    g.anc_ecef[:] = _f64(anc_ecef).tolist()
+    fdt = _f64(frame_dt)
+    assert fdt.shape == (WINDOW_SIZE,)
+    io = _f64(iono) if iono is not None else None
+    r, J, rc_, rs, cost = np.zeros((n, 2)), np.zeros((n, 2, 18)), np.zeros((4, WINDOW_SIZE)), np.zeros(WINDOW_SIZE), np.zeros(1)
+    f = getattr(lib, prefix + "gnss_eval")
+    f.restype = c_i
+    f.argtypes = [C.c_void_p, c_i, C.POINTER(GnssObs), PD, C.POINTER(State), C.POINTER(GnssState), PD, c_d, PD, PD, PD, PD, PD]
+    rc = f(ctx, n, arr, _pd(io) if io is not None else None, C.byref(st), C.byref(g), _pd(fdt), float(ddt_weight), _pd(r),
+           _pd(J) if want_J else None, _pd(rc_), _pd(rs), _pd(cost))
+    if rc != OK:
+        raise RuntimeError("%sgnss_eval failed with status %d" % (prefix, rc))
+    return dict(r=r, J=J if want_J else None, r_dt_ddt=rc_, r_smooth=rs, cost=float(cost[0]))

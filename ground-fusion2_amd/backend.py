@@ -32,7 +32,7 @@ EXPORTS = [
     "gfbe_ftab_remove_failures", "gfbe_ftab_clear_depth", "gfbe_ftab_set_depth", "gfbe_ftab_get_depth_vector",
     "gfbe_ftab_triangulate", "gfbe_ftab_check_outliers", "gfbe_ftab_size", "gfbe_ftab_download", "gfbe_slide_window_state",
     "gfbe_pg_eval", "gfbe_pg_solve", "gfbe_lio_linearize", "gfbe_batch_upload_tables", "gfbe_batch_feature_count",
-    "gfbe_plane_eval", "gfbe_anchor_eval", "gfbe_orientation_subset_plus",
+    "gfbe_plane_eval", "gfbe_anchor_eval", "gfbe_orientation_subset_plus", "gfbe_gnss_eval",
 ]
 
 

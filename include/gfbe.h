@@ -410,9 +410,12 @@ gfbe_status gfbe_lio_linearize(gfbe_ctx *ctx, int32_t ct, int32_t n, const doubl
                                double *g, double *cost);
 
 /* ------------------------------------------------------------------------------------------
- * f2  Optional in-window factors, EVALUATION ONLY — they are not wired into
- *     gfbe_solve_window (every shipped yaml has plane: 0 and gnss_enable: 0); the GNSS pseudo-range / Doppler factors
- *     are not provided (they need gnss_comm's ephemeris / atmosphere models, which the reference does not vendor).
+ * f2  Optional in-window factors. PlaneFactor and PoseAnchorFactor run INSIDE
+ *     gfbe_solve_window / gfbe_marginalize when gfbe_window.use_plane / use_anchor are set (see gfbe_window); the
+ *     functions below evaluate them stand-alone. The GNSS factors are evaluation only: with gnss_enable the reference's
+ *     problem grows by rcv_dt[11][4], rcv_ddt[11], yaw_enu_local and anc_ecef (59 more dimensions), which the
+ *     LDS-resident dense solve of this library (187 dimensions, one workgroup's 160 KB) does not hold; every shipped
+ *     yaml sets gnss_enable: 0.
  *       PlaneFactor::Evaluate        factor/plane_factor.h:25-122  — n factors sharing ex_wheel [p | q(x,y,z,w)],
  *           plane_R [q(x,y,z,w)] and plane_Z (estimator.cpp:3214-3220: one factor per window pose);
  *           noise_inv = {PITCH_N_INV, ROLL_N_INV, ZPW_N_INV} (parameters.cpp:340-345).
@@ -432,6 +435,50 @@ gfbe_status gfbe_anchor_eval(gfbe_ctx *ctx, int32_t n, const double *pose /*[n][
                              double sqrt_info, double *r, double *J, double *cost);
 void gfbe_orientation_subset_plus(const double *q /*[4] x y z w*/, const double *delta /*[3]*/,
                                   const uint8_t *constant /*[3]*/, double *out /*[4]*/);
+
+/* ------------------------------------------------------------------------------------------
+ * f2  GNSS factors of the window (estimator.cpp:3239-3291), evaluated on the device:
+ *       GnssPsrDoppFactor::Evaluate   factor/gnss_psr_dopp_factor.cpp:50-208   (2 rows: pseudo-range, Doppler)
+ *       DtDdtFactor::Evaluate         factor/gnss_dt_ddt_factor.cpp:3-34       (receiver clock bias / drift chain)
+ *       DdtSmoothFactor::Evaluate     factor/gnss_ddt_smooth_factor.cpp:3-22
+ *     together with the gnss_comm functions the pseudo-range factor calls per evaluation (gnss_comm/src/gnss_utility.cpp:
+ *     ecef2geo :347, ecef2rotation :757, sat_azel :762, calculate_trop_delay :841 — Saastamoinen + Niell mapping,
+ *     calculate_ion_delay :865 — Klobuchar). What the factor's CONSTRUCTOR derives from the observation and the
+ *     broadcast ephemeris (gnss_psr_dopp_factor.cpp:3-47: eph2pos / geph2pos / eph2svdt at the transmission time, the
+ *     group delay, the URA scalings) is front-end work and crosses the boundary precomputed in gfbe_gnss_obs.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct gfbe_gnss_obs {
+  double sv_pos[3], sv_vel[3];   /* satellite ECEF position / velocity at transmission time (:20-35) */
+  double svdt, svddt, tgd;       /* satellite clock bias (s), drift (s/s), group delay (s) */
+  double pr_uura, dp_uura;       /* pseudo-range / Doppler deviation scalings (:24-26, :38-40) */
+  double psr, dopp;              /* obs->psr[freq_idx] (m), obs->dopp[freq_idx] (Hz) */
+  double wavelength;             /* LIGHT_SPEED / freq (m) */
+  double ratio;                  /* ts_ratio (estimator.cpp:3262): weight of frame lower_idx against lower_idx + 1 */
+  double doy, tow;               /* time2doy(obs->time), time2gpst(obs->time): the atmosphere models' time arguments */
+  int32_t frame;                 /* i of gnss_meas_buf[i]: uses rcv_dt[i][sys_idx] and rcv_ddt[i] */
+  int32_t lower_idx;             /* the factor connects Pose / SpeedBias lower_idx and lower_idx + 1 */
+  int32_t sys_idx;               /* gnss_comm::sys2idx: 0 GPS, 1 GLO, 2 GAL, 3 BDS */
+  int32_t _pad;
+} gfbe_gnss_obs;
+
+typedef struct gfbe_gnss_state {   /* estimator.h: para_rcv_dt, para_rcv_ddt, para_yaw_enu_local, para_anc_ecef */
+  double rcv_dt[GFBE_WINDOW_SIZE + 1][4];
+  double rcv_ddt[GFBE_WINDOW_SIZE + 1];
+  double yaw_enu_local;
+  double anc_ecef[3];
+} gfbe_gnss_state;
+
+/* One thread per factor. iono: the 8 Klobuchar parameters (latest_gnss_iono_params) or NULL (no ionosphere term).
+ * frame_dt[i] = Headers[i+1] - Headers[i]. Outputs (any may be NULL):
+ *   r_obs [n_obs][2]; J_obs [n_obs][2][18] with columns P_lower(3) V_lower(3) P_upper(3) V_upper(3) rcv_dt rcv_ddt yaw_enu_local
+ *   anc_ecef(3) — the non-zero parts of the reference's 2 x {7, 9, 7, 9, 1, 1, 1, 3} blocks; like the reference the Jacobian leaves
+ *   out the atmosphere and Sagnac derivatives and approximates d/d anc_ecef;
+ *   r_dt_ddt [4][GFBE_WINDOW_SIZE] (k-major, the reference's insertion order; Jacobian = {-50, 50, -25 dt, -25 dt});
+ *   r_smooth [GFBE_WINDOW_SIZE] (Jacobian = {w, -w});
+ *   cost = 1/2 sum r^2 over the three families, summed in the reference's insertion order. */
+gfbe_status gfbe_gnss_eval(gfbe_ctx *ctx, int32_t n_obs, const gfbe_gnss_obs *obs, const double *iono /*[8] or NULL*/,
+                           const gfbe_state *state, const gfbe_gnss_state *gnss, const double *frame_dt /*[WINDOW_SIZE]*/,
+                           double ddt_weight, double *r_obs, double *J_obs, double *r_dt_ddt, double *r_smooth, double *cost);
 
 /* ------------------------------------------------------------------------------------------
  * a4/a5/a7/a9/a10  Factor evaluation on the device, block-CSR output (parity / inspection API).

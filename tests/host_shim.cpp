@@ -106,3 +106,20 @@ extern "C" int shim_eval_factors(const gfbe_options *opt, const gfbe_window *w, 
   (void)prior_r;
   return 0;
 }
+
+// the GNSS factor arithmetic of csrc/gfbe_gnss.h, the loop k_gnss runs one thread per factor
+#include "../ground-fusion2_amd/csrc/gfbe_gnss.h"
+extern "C" int shim_gnss_eval(int n_obs, const gfbe_gnss_obs *obs, const double *iono, const gfbe_state *st, const gfbe_gnss_state *g,
+                              const double *frame_dt, double ddt_weight, double *r_obs, double *J_obs, double *r_dt_ddt, double *r_smooth) {
+  for (int k = 0; k < n_obs; k++) {
+    const gfbe_gnss_obs &o = obs[k];
+    gnss_psr_dopp_eval(o, iono, st->para_Pose[o.lower_idx], st->para_SpeedBias[o.lower_idx], st->para_Pose[o.lower_idx + 1],
+                       st->para_SpeedBias[o.lower_idx + 1], g->rcv_dt[o.frame][o.sys_idx], g->rcv_ddt[o.frame], g->yaw_enu_local, g->anc_ecef,
+                       r_obs + 2 * k, J_obs + 36 * k);
+  }
+  for (int sys = 0; sys < 4; sys++)
+    for (int i = 0; i < GFBE_WINDOW_SIZE; i++)
+      r_dt_ddt[sys * GFBE_WINDOW_SIZE + i] = gnss_dt_ddt_res(g->rcv_dt[i][sys], g->rcv_dt[i + 1][sys], g->rcv_ddt[i], g->rcv_ddt[i + 1], frame_dt[i]);
+  for (int i = 0; i < GFBE_WINDOW_SIZE; i++) r_smooth[i] = gnss_ddt_smooth_res(g->rcv_ddt[i], g->rcv_ddt[i + 1], ddt_weight);
+  return 0;
+}

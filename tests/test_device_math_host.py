@@ -22,7 +22,7 @@ def shim():
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "tests", "host_shim.cpp")
     deps = [src, os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_factors.h"),
-            os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_math.h")]
+            os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_math.h"), os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_gnss.h")]
     if not os.path.exists(SHIM) or any(os.path.getmtime(d) > os.path.getmtime(SHIM) for d in deps):
         os.makedirs(os.path.dirname(SHIM), exist_ok=True)
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -58,3 +58,38 @@ def test_device_factor_math_matches_oracle(shim, oracle, robust):
     for k in ("imu_r", "imu_J"):
         sc = max(1.0, np.abs(want[k]).max())
         assert np.abs(got[k] - want[k]).max() < 1e-9 * sc, k
+
+
+def test_device_gnss_math_matches_oracle(shim, oracle):
+    """csrc/gfbe_gnss.h on the host against oracle/gfo_gnss.cpp: pseudo-ranges of 2.5e7 m in doubles, weights up to 250."""
+    import gnss_cases as gc
+
+    class Shim:      # abi.gnss_eval drives any library exporting <prefix>gnss_eval with the C ABI's argument list
+        def __init__(self, lib):
+            self.lib = lib
+
+        def __getattr__(self, name):
+            assert name == "shim_gnss_eval"
+            f = self.lib.shim_gnss_eval
+
+            def call(ctx, n, arr, io, st, g, fdt, w, r, J, rc, rs, cost):
+                return f(n, arr, io, st, g, fdt, C.c_double(w), r, J, rc, rs)
+            return _Holder(call)
+
+    class _Holder:
+        def __init__(self, fn):
+            self.fn, self.restype, self.argtypes = fn, None, None
+
+        def __call__(self, *a):
+            return self.fn(*a)
+
+    for seed, lat in [(11, 22.3), (12, -50.0), (13, 80.0)]:
+        c = gc.gnss_case(seed, lat=lat)
+        want = gc.eval_case(abi, oracle.lib, "gfo_", None, c)
+        got = gc.eval_case(abi, Shim(shim), "shim_", None, c)
+        assert np.abs(got["r"] - want["r"]).max() < 1e-5               # 4e-9 m resolution x weight 250 x a few operations
+        assert np.abs(got["J"] - want["J"]).max() < 1e-9 * np.abs(want["J"]).max()
+        np.testing.assert_allclose(got["r_dt_ddt"], want["r_dt_ddt"], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(got["r_smooth"], want["r_smooth"], rtol=0, atol=1e-12)
+        noi = gc.eval_case(abi, Shim(shim), "shim_", None, c, iono=None)
+        assert np.abs(noi["r"] - gc.eval_case(abi, oracle.lib, "gfo_", None, c, iono=None)["r"]).max() < 1e-5
