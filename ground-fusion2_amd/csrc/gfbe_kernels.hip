@@ -1330,6 +1330,9 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 #define SOLVE_WAVES_PER_EU 4
 #endif
 #define BUILD_UNROLL 6
+#ifndef GFBE_SOLVE_ESYM
+#define GFBE_SOLVE_ESYM 1
+#endif
 #define TB 16                          // tile edge of the blocked Cholesky
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
@@ -1400,68 +1403,190 @@ __device__ __forceinline__ double lane_bcast(double v, int src) {   // src is wa
 // Lower Cholesky of one 16 x 16 LDS tile by a single wave, replaced IN PLACE by the inverse of its factor, W = L^-1
 // (lower triangular, the upper triangle written as zeros). With W the panel step X L^T = A becomes the matrix-core product
 // X = A W^T (no 16-step substitution per row any more) and the back-substitution a 16 x 16 matrix-vector product per panel.
-//   phase 1: lane i < 16 keeps row i in registers, column entries travel through v_readlane (diagonal kept as 1 / L[k][k]);
-//   phase 2: L goes through the tile, lane j computes column j of W by forward substitution (broadcast LDS reads).
-// Returns false on a bad pivot.
-// zrow >= 0: row `zrow` of L (the right-hand side row of the LAST diagonal tile: z of the last partial panel) is saved to zout
-// before the tile is overwritten.
-// (out of line — inlined, its 64 live registers push the 128-VGPR kernel into scratch — with LDS-typed pointers: a generic
-// pointer would turn every tile access into a FLAT instruction; the products are explicit FMAs: the library is built with
-// -ffp-contract=off)
+//   A single wave issues one instruction every ~5 cycles, so the tile step is bound by its instruction count, not by latencies.
+//   Lane i (of every 16-lane row of the wave) keeps row i of the FULL symmetric tile (the tiles are built and updated symmetric)
+//   and row i of the inverse being formed in registers. At step k the pivot row travels by DPP: `row_newbcast:k` hands lane
+//   k's register to its whole row inside the FMA itself (64-bit DPP; no v_readlane, no SGPR round trip):
+//       d = a_kk (v_mov_b64_dpp), inv = 1/sqrt(d), t_i = a_ik / d
+//       a_ij -= t_i a_kj  (j > k)        u_ic -= t_i u_kc  (c <= k)       one v_fmac_f64_dpp each
+//   where u = diag(L) W is the unscaled inverse (u starts as the identity); lane i scales its row by 1/L_ii at the end.
+//   Column k of the tile dies at step k and column k of u is born there: 17 live doubles per lane throughout.
+// Returns false on a bad pivot (not positive or not finite).
+// zrow >= 0: row `zrow` of L (the right-hand side row of the LAST diagonal tile: z of the last partial panel) is written to zout
+// as it is formed (entries q < zrow are meaningful).
+// (out of line — inlined, its live registers push the 128-VGPR kernel into scratch — with LDS-typed pointers: a generic
+// pointer would turn every tile access into a FLAT instruction. A VALU result needs two wait states before a DPP instruction
+// reads it; the compiler's hazard recogniser does not look into inline assembly, hence the s_nop in front of the pivot move:
+// everything else a DPP operand reads was written at least one pivot chain earlier.)
 typedef __attribute__((address_space(3))) double lds_double;
-__device__ __noinline__ bool chol_inv_tile16(lds_double *T, int lane, int zrow, lds_double *zout, double *stamp = nullptr) {
-  double row[TB];
+typedef __attribute__((address_space(3))) int lds_int;
+template <int KK>
+__device__ __forceinline__ void dpp_fmac(double &acc, double m) {   // acc += m * (lane KK of the 16-lane row)'s acc
+  asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(KK));
+}
+// Pivot step K. (Measured, profiles/ubench/dp_issue_rate_mi355x.txt: a lone wave issues one FP64 instruction every ~5.4 cycles,
+// a dependent one every 9, v_rsq_f64 26: the step is bound by its ~33 instructions; weaving the updates of step K-1 into the
+// rsq / Newton chain of step K by hand — every instruction a volatile asm — came out slower than the compiler's schedule.)
+template <int K>
+__device__ __forceinline__ void chol_inv_step(double (&row)[TB], double (&u)[TB], int li, double &myinv, int zrow, lds_double *zout) {
+  double dkk;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(dkk) : "v"(row[K]), "n"(K));
+  const double inv = rsqrt_refined(dkk);
+  const double lik = row[K] * inv;          // L[i][k] for i > k
+  double m = (li > K) ? -(lik * inv) : 0.0; // -a_ik / d for the rows below the pivot; rows <= k are final
+  myinv = (li == K) ? inv : myinv;
+  u[K] = (li == K) ? 1.0 : 0.0;             // (column K of the unscaled inverse starts here: rows above K never touch it)
+  asm volatile("" : "+v"(u[K]), "+v"(m));   // materialised HERE: a VALU write needs two wait states before a DPP instruction reads
+                                            // the register, and the compiler's hazard recogniser does not look into inline assembly
+  // (the last diagonal tile only — a scalar branch — and every lane stores the same value: a lane-masked store would rewrite
+  // EXEC in every step, and a DPP instruction needs five wait states after an EXEC write)
+  if (zrow >= 0) zout[K] = lane_bcast(lik, zrow);
+#pragma unroll
+  for (int j = K + 1; j < TB; j++) dpp_fmac<K>(row[j], m);
+#pragma unroll
+  for (int c = 0; c <= K; c++) dpp_fmac<K>(u[c], m);
+}
+__device__ __forceinline__ bool chol_inv_tile16(lds_double *T, int lane, int zrow, lds_double *zout, double *stamp = nullptr) {
+  double row[TB], u[TB];
   const int li = lane & 15;
   if (stamp && lane == 0) stamp[21] = (double)wall_clock64();
+  int lio = li;
+  asm volatile("" : "+v"(lio));               // (opaque: 16 loop-invariant tile addresses hoisted out of the panel loop would be spilled)
 #pragma unroll
-  for (int q = 0; q < TB; q++) row[q] = T[tsw(li, q)];
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < TB; k++) {
-    const double dkk = lane_bcast(row[k], k);
-    if (!(dkk > 0.0) || !isfinite(dkk)) ok = false;
-    const double inv = rsqrt_refined(dkk);
-    const double lik = row[k] * inv;          // L[i][k] for i > k
-    row[k] = (li == k) ? inv : lik;
-#pragma unroll
-    for (int j = k + 1; j < TB; j++) {
-      const double ljk = lane_bcast(lik, j);
-      row[j] = __builtin_fma(-lik, ljk, row[j]);   // only meaningful for i >= j; the upper part is never read
-    }
-  }
-  if (lane < TB) {
-#pragma unroll
-    for (int q = 0; q < TB; q++) T[tsw(li, q)] = row[q];
-    if (lane == zrow) {
-#pragma unroll
-      for (int q = 0; q < TB; q++) zout[q] = row[q];
-    }
-  }
-  __threadfence_block();
-  __builtin_amdgcn_wave_barrier();
+  for (int q = 0; q < TB; q++) row[q] = T[tsw(lio, q)];
+  double myinv = 0.0;
+  chol_inv_step<0>(row, u, li, myinv, zrow, zout);   chol_inv_step<1>(row, u, li, myinv, zrow, zout);
+  chol_inv_step<2>(row, u, li, myinv, zrow, zout);   chol_inv_step<3>(row, u, li, myinv, zrow, zout);
+  chol_inv_step<4>(row, u, li, myinv, zrow, zout);   chol_inv_step<5>(row, u, li, myinv, zrow, zout);
+  chol_inv_step<6>(row, u, li, myinv, zrow, zout);   chol_inv_step<7>(row, u, li, myinv, zrow, zout);
+  chol_inv_step<8>(row, u, li, myinv, zrow, zout);   chol_inv_step<9>(row, u, li, myinv, zrow, zout);
+  chol_inv_step<10>(row, u, li, myinv, zrow, zout); chol_inv_step<11>(row, u, li, myinv, zrow, zout);
+  chol_inv_step<12>(row, u, li, myinv, zrow, zout); chol_inv_step<13>(row, u, li, myinv, zrow, zout);
+  chol_inv_step<14>(row, u, li, myinv, zrow, zout); chol_inv_step<15>(row, u, li, myinv, zrow, zout);
   if (stamp && lane == 0) stamp[22] = (double)wall_clock64();
-  // W[j][j] = 1 / L[j][j];  W[i][j] = -(1 / L[i][i]) sum_{k < i} L[i][k] W[k][j]   (W[k][j] = 0 for k < j)
-  double wc[TB];
   if (lane < TB) {
 #pragma unroll
-    for (int i = 0; i < TB; i++) {
-      double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-      for (int k = 0; k < i; k++) {
-        const double l = T[tsw(i, k)];
-        if (k & 1) acc1 = __builtin_fma(l, wc[k], acc1); else acc0 = __builtin_fma(l, wc[k], acc0);
-      }
-      const double dinv = T[tsw(i, i)];
-      wc[i] = (i < li) ? 0.0 : ((i == li) ? dinv : -((acc0 + acc1) * dinv));
-    }
-  }
-  __builtin_amdgcn_wave_barrier();            // every read of L is done before the tile is overwritten
-  if (lane < TB) {
-#pragma unroll
-    for (int i = 0; i < TB; i++) T[tsw(i, li)] = wc[i];
+    for (int q = 0; q < TB; q++) T[tsw(lio, q)] = u[q] * myinv;     // (u[q] is an exact zero for q > i: column q starts as e_q and rows < q never touch it)
   }
   if (stamp && lane == 0) stamp[23] = (double)wall_clock64();
-  return ok;
+  // a pivot that is not positive and finite turns its 1/sqrt into inf or NaN (and everything after it into NaN): one test of
+  // every lane's own 1 / L_ii at the end instead of a test per pivot inside the chain
+  return __ballot(!((myinv > 0.0) && (myinv < 1.0e300))) == 0ull;
+}
+
+// The tile build of k_solve, out of line (its own register allocation: six tiles in flight per thread group). Returns this
+// thread's share of v^T S v.
+// (address-space-typed pointers: through generic ones every load here would be a FLAT instruction)
+typedef __attribute__((address_space(3))) short lds_short;
+typedef __attribute__((address_space(1))) double glb_double;
+__device__ __noinline__ double solve_build_tiles(lds_double *smem, const lds_short *perm, const lds_double *ys, const glb_double *H, const glb_double *E,
+                                                 const glb_double *eg, const glb_double *gsp, const glb_double *gDp, const glb_double *ggts, double mu,
+                                                 int n, int ntile_all, int t) {
+  double vsv = 0.0;      // v^T S v, summed over the tile entries as they are built (off-diagonal tiles stand for both triangles)
+  for (int te0 = t >> 8; te0 < ntile_all; te0 += BUILD_UNROLL * (SOLVE_THREADS >> 8)) {   // BUILD_UNROLL tiles per thread group in flight
+    const int r = (t & 255) >> 4, cc = t & 15;
+    double hv[BUILD_UNROLL], ev[BUILD_UNROLL];
+    int aa[BUILD_UNROLL], bb[BUILD_UNROLL], kind[BUILD_UNROLL];
+    bool offdiag[BUILD_UNROLL];
+#pragma unroll
+    for (int u = 0; u < BUILD_UNROLL; u++) {
+      const int te = te0 + u * (SOLVE_THREADS >> 8);
+      int I, J;
+      tri_decode(te, I, J);
+      const int ia = I * TB + r, ib = J * TB + cc;
+      offdiag[u] = I != J;
+      kind[u] = 0; aa[u] = 0; bb[u] = 0; hv[u] = 0.0; ev[u] = 0.0;
+      if (te < ntile_all) {
+        if (ia < n && ib < n) {
+          const int a = perm[ia], b = perm[ib];
+          aa[u] = a; bb[u] = b; kind[u] = 1;
+          hv[u] = H[(size_t)max(a, b) * ND + min(a, b)];   // H holds its lower triangle
+#if GFBE_SOLVE_ESYM
+          if (a < NV && b < NV) ev[u] = E[max(a, b) * NV + min(a, b)];   // (lower triangle, like H: the diagonal tiles come out exactly symmetric)
+#else
+          if (a < NV && b < NV) ev[u] = E[a * NV + b];
+#endif
+        } else if (ia == n && ib < n) { bb[u] = perm[ib]; kind[u] = 2; }
+        else if (ib == n && ia < n) { bb[u] = perm[ia]; kind[u] = 2; }
+        else kind[u] = (ia == ib) ? (ia == n ? 4 : 3) : 5;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BUILD_UNROLL; u++) {
+      const int te = te0 + u * (SOLVE_THREADS >> 8);
+      if (te >= ntile_all) continue;
+      double v;
+      if (kind[u] == 1) {
+        v = hv[u];
+        if (aa[u] < NV && bb[u] < NV) v -= ev[u];
+        v *= ys[aa[u]] * ys[bb[u]];
+        if (aa[u] == bb[u]) { const double dp = gDp[aa[u]]; v += mu * dp * dp; }
+        vsv = __builtin_fma(v * ys[ND + aa[u]], ys[ND + bb[u]] * (offdiag[u] ? 2.0 : 1.0), vsv);
+      } else if (kind[u] == 2) v = ggts[bb[u]] - (bb[u] < NV ? gsp[bb[u]] * eg[bb[u]] : 0.0);
+      else v = kind[u] == 4 ? 1e200 : (kind[u] == 3 ? 1.0 : 0.0);
+      smem[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
+    }
+  }
+  return vsv;
+}
+
+// The factorisation loop of k_solve, out of line: inside this function the only live state is a handful of indices, so the
+// register-resident tile step (chol_inv_tile16: 64 VGPRs of tile and inverse rows) is inlined without spilling and without a
+// call per panel; the kernel around it saves its own registers once.
+__device__ __noinline__ void chol_factor_all(lds_double *smem, int nt, int n, int t, lds_double *zlast, lds_int *flag, double *stamp) {
+  const int lane = t & 63, wave = t >> 6;
+#define CF_STAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int P = -1; P < nt; P++) {
+    if (P == 0) CF_STAMP(17);
+    if (*flag) break;
+    if (P >= 0) {
+      const lds_double *Wp = smem + (size_t)tile_idx(P, P) * (TB * TB);
+      for (int I = P + 1 + wave; I < nt; I += (SOLVE_THREADS >> 6)) {
+        lds_double *tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
+        dbl4 acc = {0.0, 0.0, 0.0, 0.0};
+        double va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { va[q] = tip[tsw(lr, q * 4 + lk)]; vb[q] = Wp[tsw(lr, q * 4 + lk)]; }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) tip[tsw(lk + 4 * q, lr)] = acc[q];
+      }
+      __syncthreads();
+    }
+    if (P == 0) CF_STAMP(18);
+    // trailing tiles (I, J), P < J <= I. Wave 0 takes tile (P+1, P+1) and its factor-and-invert — the critical chain — and
+    // nothing else; the other tiles go round-robin over waves 1..15.
+    const int nrem = nt - 1 - P;
+    const int ntr = P < 0 ? 1 : nrem * (nrem + 1) / 2;
+    for (int e = (wave == 0 ? 0 : wave); e < ntr; e += (wave == 0 ? ntr : (SOLVE_THREADS >> 6) - 1)) {
+      int ii = 0, rr = e;
+      while (rr > ii) { rr -= ii + 1; ii++; }
+      const int I = P + 1 + ii, J = P + 1 + rr;
+      lds_double *C = smem + (size_t)tile_idx(I, J) * (TB * TB);
+      if (P >= 0) {
+        const lds_double *LI = smem + (size_t)tile_idx(I, P) * (TB * TB), *LJ = smem + (size_t)tile_idx(J, P) * (TB * TB);
+        dbl4 acc;
+        double va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { acc[q] = C[tsw(lk + 4 * q, lr)]; va[q] = -LI[tsw(lr, q * 4 + lk)]; vb[q] = LJ[tsw(lr, q * 4 + lk)]; }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) C[tsw(lk + 4 * q, lr)] = acc[q];
+      }
+      if (e == 0 && P + 1 < nt) {   // tile (P+1, P+1) is final now: factorise and invert it here (wave 0), ahead of the block barrier
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        if (!chol_inv_tile16(C, lane, P + 2 == nt ? n % TB : -1, zlast, P == 0 ? stamp : nullptr) && lane == 0) *flag = 1;
+      }
+    }
+    if (P == 0) CF_STAMP(20);
+    __syncthreads();
+    if (P == 0) CF_STAMP(19);
+  }
+#undef CF_STAMP
 }
 
 __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(BatchDev d, int retry_pass) {
@@ -1564,47 +1689,8 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     // gt - s eg is read where it is placed: one tile row)
     for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = gvp[a]; }
     __syncthreads();
-    double vsv = 0.0;      // v^T S v, summed over the tile entries as they are built (off-diagonal tiles stand for both triangles)
-    for (int te0 = t >> 8; te0 < ntile_all; te0 += BUILD_UNROLL * (SOLVE_THREADS >> 8)) {   // BUILD_UNROLL tiles per thread group in flight
-      const int r = (t & 255) >> 4, cc = t & 15;
-      double hv[BUILD_UNROLL], ev[BUILD_UNROLL];
-      int aa[BUILD_UNROLL], bb[BUILD_UNROLL], kind[BUILD_UNROLL];
-      bool offdiag[BUILD_UNROLL];
-#pragma unroll
-      for (int u = 0; u < BUILD_UNROLL; u++) {
-        const int te = te0 + u * (SOLVE_THREADS >> 8);
-        int I, J;
-        tri_decode(te, I, J);
-        const int ia = I * TB + r, ib = J * TB + cc;
-        offdiag[u] = I != J;
-        kind[u] = 0; aa[u] = 0; bb[u] = 0; hv[u] = 0.0; ev[u] = 0.0;
-        if (te < ntile_all) {
-          if (ia < n && ib < n) {
-            const int a = perm[ia], b = perm[ib];
-            aa[u] = a; bb[u] = b; kind[u] = 1;
-            hv[u] = H[(size_t)max(a, b) * ND + min(a, b)];   // H holds its lower triangle
-            if (a < NV && b < NV) ev[u] = E[a * NV + b];
-          } else if (ia == n && ib < n) { bb[u] = perm[ib]; kind[u] = 2; }
-          else if (ib == n && ia < n) { bb[u] = perm[ia]; kind[u] = 2; }
-          else kind[u] = (ia == ib) ? (ia == n ? 4 : 3) : 5;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < BUILD_UNROLL; u++) {
-        const int te = te0 + u * (SOLVE_THREADS >> 8);
-        if (te >= ntile_all) continue;
-        double v;
-        if (kind[u] == 1) {
-          v = hv[u];
-          if (aa[u] < NV && bb[u] < NV) v -= ev[u];
-          v *= ys[aa[u]] * ys[bb[u]];
-          if (aa[u] == bb[u]) { const double dp = gDp[aa[u]]; v += mu * dp * dp; }
-          vsv = __builtin_fma(v * ys[ND + aa[u]], ys[ND + bb[u]] * (offdiag[u] ? 2.0 : 1.0), vsv);
-        } else if (kind[u] == 2) v = ggts[bb[u]] - (bb[u] < NV ? gsp[bb[u]] * eg[bb[u]] : 0.0);
-        else v = kind[u] == 4 ? 1e200 : (kind[u] == 3 ? 1.0 : 0.0);
-        smem[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
-      }
-    }
+    double vsv = solve_build_tiles((lds_double *)smem, (const lds_short *)perm, (const lds_double *)ys, (const glb_double *)H, (const glb_double *)E,
+                                   (const glb_double *)eg, (const glb_double *)gsp, (const glb_double *)gDp, (const glb_double *)ggts, mu, n, ntile_all, t);
     vsv = block_sum(vsv, red);
     if (t == 0) { flag = 0; s_vSv = vsv; }
     __syncthreads();
@@ -1618,56 +1704,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     //      Two block barriers per panel.
     // (the loop starts at P = -1 — no panel yet, wave 0 factorises tile (0, 0) — so that chol_inv_tile16 is inlined once:
     // two copies of its 64 live registers do not fit the 128-VGPR budget of a 1024-thread workgroup)
-    const int lr = lane & 15, lk = lane >> 4;
-    for (int P = -1; P < nt; P++) {
-      if (P == 0) STAMP(17);
-      if (flag) break;
-      if (P >= 0) {
-        const double *Wp = smem + (size_t)tile_idx(P, P) * (TB * TB);
-        for (int I = P + 1 + wave; I < nt; I += (SOLVE_THREADS >> 6)) {
-          double *tip = smem + (size_t)tile_idx(I, P) * (TB * TB);
-          dbl4 acc = {0.0, 0.0, 0.0, 0.0};
-          double va[4], vb[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) { va[q] = tip[tsw(lr, q * 4 + lk)]; vb[q] = Wp[tsw(lr, q * 4 + lk)]; }
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; q++) tip[tsw(lk + 4 * q, lr)] = acc[q];
-        }
-        __syncthreads();
-      }
-      if (P == 0) STAMP(18);
-      // trailing tiles (I, J), P < J <= I. Wave 0 takes tile (P+1, P+1) and its factor-and-invert — the critical chain — and
-      // nothing else; the other tiles go round-robin over waves 1..15.
-      const int nrem = nt - 1 - P;
-      const int ntr = P < 0 ? 1 : nrem * (nrem + 1) / 2;
-      for (int e = (wave == 0 ? 0 : wave); e < ntr; e += (wave == 0 ? ntr : (SOLVE_THREADS >> 6) - 1)) {
-        int ii = 0, rr = e;
-        while (rr > ii) { rr -= ii + 1; ii++; }
-        const int I = P + 1 + ii, J = P + 1 + rr;
-        double *C = smem + (size_t)tile_idx(I, J) * (TB * TB);
-        if (P >= 0) {
-          const double *LI = smem + (size_t)tile_idx(I, P) * (TB * TB), *LJ = smem + (size_t)tile_idx(J, P) * (TB * TB);
-          dbl4 acc;
-          double va[4], vb[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) { acc[q] = C[tsw(lk + 4 * q, lr)]; va[q] = -LI[tsw(lr, q * 4 + lk)]; vb[q] = LJ[tsw(lr, q * 4 + lk)]; }
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; q++) C[tsw(lk + 4 * q, lr)] = acc[q];
-        }
-        if (e == 0 && P + 1 < nt) {   // tile (P+1, P+1) is final now: factorise and invert it here (wave 0), ahead of the block barrier
-          __threadfence_block();
-          __builtin_amdgcn_wave_barrier();
-          if (!chol_inv_tile16((lds_double *)C, lane, P + 2 == nt ? n % TB : -1, (lds_double *)zlast, P == 0 ? stamp : nullptr) && lane == 0) flag = 1;
-        }
-      }
-      if (P == 0) STAMP(20);
-      __syncthreads();
-      if (P == 0) STAMP(19);
-    }
+    chol_factor_all((lds_double *)smem, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
     bool ok = (flag == 0);
     if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;   // fault injection: first attempt of that iteration
     STAMP(3);

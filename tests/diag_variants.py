@@ -11,6 +11,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "noearly": (["-DGFBE_KVIS_EARLY=0"], "off"),
     "contract": ([], "fast"),
     "stamp": (["-DGFBE_KVIS_STAMP=1"], "off"),
+    "noesym": (["-DGFBE_SOLVE_ESYM=0"], "off"),
     "abl1_nomfma": (["-DGFBE_ABLATE=1"], "off"),
     "abl2_nopartstore": (["-DGFBE_ABLATE=2"], "off"),
     "abl3_nohpstore": (["-DGFBE_ABLATE=3"], "off"),
