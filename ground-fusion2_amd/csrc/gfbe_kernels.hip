@@ -1330,6 +1330,9 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 #define SOLVE_WAVES_PER_EU 4
 #endif
 #define BUILD_UNROLL 6
+#ifndef GFBE_CHOL_STAMP
+#define GFBE_CHOL_STAMP 0   // diagnostics: per-panel time stamps into the NEXT window's timing slots (single-window runs only)
+#endif
 #ifndef GFBE_SOLVE_ESYM
 #define GFBE_SOLVE_ESYM 1
 #endif
@@ -1585,6 +1588,9 @@ __device__ __noinline__ void chol_factor_all(lds_double *smem, int nt, int n, in
     if (P == 0) CF_STAMP(20);
     __syncthreads();
     if (P == 0) CF_STAMP(19);
+#if GFBE_CHOL_STAMP
+    if (P >= 0 && P < 12) { if (t == 0) stamp[32 + P] = (double)wall_clock64(); if (t == 0 && P == 0) stamp[31] = stamp[17]; }
+#endif
   }
 #undef CF_STAMP
 }

@@ -12,6 +12,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "contract": ([], "fast"),
     "stamp": (["-DGFBE_KVIS_STAMP=1"], "off"),
     "noesym": (["-DGFBE_SOLVE_ESYM=0"], "off"),
+    "cholstamp": (["-DGFBE_CHOL_STAMP=1"], "off"),
     "abl1_nomfma": (["-DGFBE_ABLATE=1"], "off"),
     "abl2_nopartstore": (["-DGFBE_ABLATE=2"], "off"),
     "abl3_nohpstore": (["-DGFBE_ABLATE=3"], "off"),
