@@ -10,17 +10,25 @@
 
 namespace gfd {
 
+// Which of the 17 distinct 3 x 3 blocks sits at block (row / 3, column / 3) of F (5 x 5) and V (5 x 6); -1: zero.
+#define IMU_NSRC 17
+__constant__ signed char IMU_FMAP[25] = {0, 1, 2, 3, 4,   -1, 5, -1, -1, 6,   -1, 7, 0, 8, 9,   -1, -1, -1, 0, -1,   -1, -1, -1, -1, 0};
+__constant__ signed char IMU_VMAP[30] = {10, 11, 12, 11, -1, -1,   -1, 13, -1, 13, -1, -1,   14, 15, 16, 15, -1, -1,   -1, -1, -1, -1, 2, -1,   -1, -1, -1, -1, -1, 2};
+
 __global__ __launch_bounds__(64) void k_preint_imu(int n, const int *off, const double *samples, const double *first,
                                                   const double *lin, const double *noise, gfbe_imu_preint *out) {
   const int iv = blockIdx.x, t = threadIdx.x;
   if (iv >= n) return;
-  __shared__ double F[225], V[15 * 18], Jm[225], P[225], T1[225], T2[225], N[18];
+  __shared__ double F[225], V[15 * 18], Jm[225], P[225], T1[225], T2[225], N[18], src[IMU_NSRC * 9];
+  __shared__ signed char fmap[25], vmap[30];
   vec3 acc_0 = ld3(first + 6 * iv), gyr_0 = ld3(first + 6 * iv + 3);
   const vec3 ba = ld3(lin + 6 * iv), bg = ld3(lin + 6 * iv + 3);
   vec3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
   quat dq; dq.x = dq.y = dq.z = 0.0; dq.w = 1.0;
   double sum_dt = 0.0;
   for (int e = t; e < 225; e += 64) { Jm[e] = (e / 15 == e % 15) ? 1.0 : 0.0; P[e] = 0.0; }
+  if (t < 25) fmap[t] = IMU_FMAP[t];
+  if (t < 30) vmap[t] = IMU_VMAP[t];
   if (t < 18) {
     const int g = t / 3;   // ACC_N GYR_N ACC_N GYR_N ACC_W GYR_W  (integration_base.h:30-36)
     const double sdev = (g == 0 || g == 2) ? noise[0] : (g == 1 || g == 3) ? noise[1] : (g == 4 ? noise[2] : noise[3]);
@@ -41,38 +49,43 @@ __global__ __launch_bounds__(64) void k_preint_imu(int n, const int *off, const 
     const vec3 un_acc = scl(0.5, add(un_acc_0, un_acc_1));
     const vec3 rp = add(add(dp, scl(dt, dv)), scl(0.5 * dt * dt, un_acc));
     const vec3 rv = add(dv, scl(dt, un_acc));
-    if (t == 0) {   // F (15x15) and V (15x18), integration_base.h:83-129
-      for (int e = 0; e < 225; e++) F[e] = 0.0;
-      for (int e = 0; e < 270; e++) V[e] = 0.0;
+    {   // F (15x15) and V (15x18), integration_base.h:83-129: the 17 distinct 3 x 3 blocks are formed by every lane (same
+        // instructions, no extra time), lanes 0..8 publish one entry of each, then all lanes fill F and V through the block maps
       const mat3 Rw = hat(un_gyr), Ra0 = hat(sub(acc_0, ba)), Ra1 = hat(sub(acc_1, ba)), I = ident3();
       const mat3 ImW = msub(I, mscl(dt, Rw));
       const mat3 RrA1 = mul(Rr, Ra1);
-      put3(F, 15, 0, 0, I);
-      put3(F, 15, 0, 3, madd(mscl(-0.25 * dt * dt, mul(Rd, Ra0)), mscl(-0.25 * dt * dt, mul(RrA1, ImW))));
-      put3(F, 15, 0, 6, mscl(dt, I));
-      put3(F, 15, 0, 9, mscl(-0.25 * dt * dt, madd(Rd, Rr)));
-      put3(F, 15, 0, 12, mscl(-0.25 * dt * dt * -dt, RrA1));
-      put3(F, 15, 3, 3, ImW);
-      put3(F, 15, 3, 12, mscl(-dt, I));
-      put3(F, 15, 6, 3, madd(mscl(-0.5 * dt, mul(Rd, Ra0)), mscl(-0.5 * dt, mul(RrA1, ImW))));
-      put3(F, 15, 6, 6, I);
-      put3(F, 15, 6, 9, mscl(-0.5 * dt, madd(Rd, Rr)));
-      put3(F, 15, 6, 12, mscl(-0.5 * dt * -dt, RrA1));
-      put3(F, 15, 9, 9, I);
-      put3(F, 15, 12, 12, I);
       const mat3 v03 = mscl(0.25 * dt * dt * 0.5 * dt, mneg(RrA1)), v63 = mscl(0.5 * dt * 0.5 * dt, mneg(RrA1));
-      put3(V, 18, 0, 0, mscl(0.25 * dt * dt, Rd));
-      put3(V, 18, 0, 3, v03);
-      put3(V, 18, 0, 6, mscl(0.25 * dt * dt, Rr));
-      put3(V, 18, 0, 9, v03);
-      put3(V, 18, 3, 3, mscl(0.5 * dt, I));
-      put3(V, 18, 3, 9, mscl(0.5 * dt, I));
-      put3(V, 18, 6, 0, mscl(0.5 * dt, Rd));
-      put3(V, 18, 6, 3, v63);
-      put3(V, 18, 6, 6, mscl(0.5 * dt, Rr));
-      put3(V, 18, 6, 9, v63);
-      put3(V, 18, 9, 12, mscl(dt, I));
-      put3(V, 18, 12, 15, mscl(dt, I));
+      const mat3 blk[IMU_NSRC] = {
+          I,                                                                                                   //  0
+          madd(mscl(-0.25 * dt * dt, mul(Rd, Ra0)), mscl(-0.25 * dt * dt, mul(RrA1, ImW))),                    //  1  F(0,3)
+          mscl(dt, I),                                                                                         //  2
+          mscl(-0.25 * dt * dt, madd(Rd, Rr)),                                                                 //  3  F(0,9)
+          mscl(-0.25 * dt * dt * -dt, RrA1),                                                                   //  4  F(0,12)
+          ImW,                                                                                                 //  5  F(3,3)
+          mscl(-dt, I),                                                                                        //  6  F(3,12)
+          madd(mscl(-0.5 * dt, mul(Rd, Ra0)), mscl(-0.5 * dt, mul(RrA1, ImW))),                                //  7  F(6,3)
+          mscl(-0.5 * dt, madd(Rd, Rr)),                                                                       //  8  F(6,9)
+          mscl(-0.5 * dt * -dt, RrA1),                                                                         //  9  F(6,12)
+          mscl(0.25 * dt * dt, Rd), v03, mscl(0.25 * dt * dt, Rr),                                             // 10 11 12  V row 0
+          mscl(0.5 * dt, I),                                                                                   // 13
+          mscl(0.5 * dt, Rd), v63, mscl(0.5 * dt, Rr)};                                                        // 14 15 16  V row 6
+      if (t < 9) {
+#pragma unroll
+        for (int m = 0; m < IMU_NSRC; m++) {
+          double v = blk[m].m[0];
+#pragma unroll
+          for (int k = 1; k < 9; k++) v = (t == k) ? blk[m].m[k] : v;
+          src[m * 9 + t] = v;
+        }
+      }
+      __syncthreads();
+      for (int e = t; e < 225 + 270; e += 64) {
+        const bool isF = e < 225;
+        const int q = isF ? e : e - 225, ld = isF ? 15 : 18, r = q / ld, c = q - r * ld;
+        const int m = isF ? fmap[(r / 3) * 5 + c / 3] : vmap[(r / 3) * 6 + c / 3];
+        const double v = m >= 0 ? src[m * 9 + (r % 3) * 3 + c % 3] : 0.0;
+        if (isF) F[q] = v; else V[q] = v;
+      }
     }
     __syncthreads();
     for (int e = t; e < 225; e += 64) {     // T1 = F * jacobian, T2 = F * cov
