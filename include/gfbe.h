@@ -411,7 +411,7 @@ gfbe_status gfbe_lio_linearize(gfbe_ctx *ctx, int32_t ct, int32_t n, const doubl
 
 /* ------------------------------------------------------------------------------------------
  * f2  Optional in-window factors. PlaneFactor and PoseAnchorFactor run INSIDE
- *     gfbe_solve_window / gfbe_marginalize when gfbe_window.use_plane / use_anchor are set (see gfbe_window); the
+ *     gfbe_solve_window / gfbe_batch_solve when gfbe_window.use_plane / use_anchor are set (see gfbe_window); the
  *     functions below evaluate them stand-alone. The GNSS factors are evaluation only: with gnss_enable the reference's
  *     problem grows by rcv_dt[11][4], rcv_ddt[11], yaw_enu_local and anc_ecef (59 more dimensions), which the
  *     LDS-resident dense solve of this library (187 dimensions, one workgroup's 160 KB) does not hold; every shipped
