@@ -12,3 +12,7 @@ head -8 $R/gpurun_out/r2_pmc_fetch.txt; head -8 $R/gpurun_out/r2_pmc_write.txt
 rm -rf /tmp/prof_single; N=30 rocprofv3 --kernel-trace --stats -d /tmp/prof_single -- python $R/tests/diag_single.py > $R/gpurun_out/r2_single.log 2>&1
 python $R/profiles/summarize_rocpd.py /tmp/prof_single/*/*_results.db $R/gpurun_out/r2_single_trace.txt | head -30
 python $R/tests/diag_single.py 2>&1 | tail -3
+cd $R
+NEW=250 python tests/diag_stream_frame_time.py > gpurun_out/r2_stream_frame_time.txt 2>&1; tail -22 gpurun_out/r2_stream_frame_time.txt
+python tests/diag_handoff_bench.py > gpurun_out/r2_handoff.txt 2>&1; tail -6 gpurun_out/r2_handoff.txt
+python bench.py > gpurun_out/r2_bench_default.json 2> gpurun_out/r2_bench_default.err; head -c 400 gpurun_out/r2_bench_default.json
