@@ -1323,13 +1323,27 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 // mu-regularised reduced system, packed Cholesky in LDS, Gauss-Newton step y_p, dense shares of
 // the dogleg scalars. (Ceres 1.14 DoglegStrategy::ComputeStep / ComputeGaussNewtonStep.)
 // =============================================================================================
+// 768 threads = 12 waves = 3 per SIMD: 170 VGPRs per lane instead of the 128 of a 1024-thread workgroup. Measured on one box
+// (tests/diag_variants.py, one window / 1024 resident windows): 1024 threads 83.6 us / 48.6k solves/s, 512 threads 83.2 /
+// 49.2-49.6k (faster under load: less scratch traffic from the out-of-line phases, but the tile build takes 21 instead of 15 us),
+// 768 threads 77.8 / 50.4-50.7k. Inlining the phases back is slower at every size (the back-substitution alone 9 -> 17 us).
 #ifndef SOLVE_THREADS
-#define SOLVE_THREADS 1024
+#define SOLVE_THREADS 768
 #endif
 #ifndef SOLVE_WAVES_PER_EU
-#define SOLVE_WAVES_PER_EU 4
+#define SOLVE_WAVES_PER_EU 3
 #endif
+#ifndef BUILD_UNROLL
 #define BUILD_UNROLL 6
+#endif
+#ifndef GFBE_SOLVE_INLINE
+#define GFBE_SOLVE_INLINE 0
+#endif
+#if GFBE_SOLVE_INLINE
+#define GFBE_SOLVE_FN __forceinline__
+#else
+#define GFBE_SOLVE_FN __noinline__
+#endif
 #ifndef GFBE_CHOL_STAMP
 #define GFBE_CHOL_STAMP 0   // diagnostics: per-panel time stamps into the NEXT window's timing slots (single-window runs only)
 #endif
@@ -1482,7 +1496,7 @@ __device__ __forceinline__ bool chol_inv_tile16(lds_double *T, int lane, int zro
 // (address-space-typed pointers: through generic ones every load here would be a FLAT instruction)
 typedef __attribute__((address_space(3))) short lds_short;
 typedef __attribute__((address_space(1))) double glb_double;
-__device__ __noinline__ double solve_build_tiles(lds_double *smem, const lds_short *perm, const lds_double *ys, const glb_double *H, const glb_double *E,
+__device__ GFBE_SOLVE_FN double solve_build_tiles(lds_double *smem, const lds_short *perm, const lds_double *ys, const glb_double *H, const glb_double *E,
                                                  const glb_double *eg, const glb_double *gsp, const glb_double *gDp, const glb_double *ggts, double mu,
                                                  int n, int ntile_all, int t) {
   double vsv = 0.0;      // v^T S v, summed over the tile entries as they are built (off-diagonal tiles stand for both triangles)
@@ -1536,7 +1550,7 @@ __device__ __noinline__ double solve_build_tiles(lds_double *smem, const lds_sho
 // The factorisation loop of k_solve, out of line: inside this function the only live state is a handful of indices, so the
 // register-resident tile step (chol_inv_tile16: 64 VGPRs of tile and inverse rows) is inlined without spilling and without a
 // call per panel; the kernel around it saves its own registers once.
-__device__ __noinline__ void chol_factor_all(lds_double *smem, int nt, int n, int t, lds_double *zlast, lds_int *flag, double *stamp) {
+__device__ GFBE_SOLVE_FN void chol_factor_all(lds_double *smem, int nt, int n, int t, lds_double *zlast, lds_int *flag, double *stamp) {
   const int lane = t & 63, wave = t >> 6;
 #define CF_STAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   const int lr = lane & 15, lk = lane >> 4;

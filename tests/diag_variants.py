@@ -13,6 +13,13 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "stamp": (["-DGFBE_KVIS_STAMP=1"], "off"),
     "noesym": (["-DGFBE_SOLVE_ESYM=0"], "off"),
     "cholstamp": (["-DGFBE_CHOL_STAMP=1"], "off"),
+    "s512": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2"], "off"),
+    "s512u10": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DBUILD_UNROLL=10"], "off"),
+    "s512u13": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DBUILD_UNROLL=13"], "off"),
+    "s768": (["-DSOLVE_THREADS=768", "-DSOLVE_WAVES_PER_EU=3", "-DBUILD_UNROLL=9"], "off"),
+    "s768i": (["-DSOLVE_THREADS=768", "-DSOLVE_WAVES_PER_EU=3", "-DBUILD_UNROLL=9", "-DGFBE_SOLVE_INLINE=1"], "off"),
+    "s768u6": (["-DSOLVE_THREADS=768", "-DSOLVE_WAVES_PER_EU=3", "-DBUILD_UNROLL=6"], "off"),
+    "s512i": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DGFBE_SOLVE_INLINE=1"], "off"),
     "abl1_nomfma": (["-DGFBE_ABLATE=1"], "off"),
     "abl2_nopartstore": (["-DGFBE_ABLATE=2"], "off"),
     "abl3_nohpstore": (["-DGFBE_ABLATE=3"], "off"),
