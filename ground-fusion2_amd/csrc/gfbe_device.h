@@ -34,6 +34,7 @@ enum {
   PLANE_PART = 16 * 16 + 16 + 2,    // J^T J, J^T r, cost, candidate cost of one PlaneFactor (columns pose_i 6, ex_wheel 6, plane_R 3, plane_Z 1)
   ANCHOR_PART = 6 * 6 + 6 + 2,
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
+  LIN_SMALL_KS = 4,           // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)
@@ -199,6 +200,8 @@ struct BatchDev {
   int *asm_tab;               // [ND (ND + 1) / 2][4]  window-independent assembly table (k_asm_table)
   double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble
   double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
+  double *vis_contrib;        // [B][max_tiles][MAXOBS][16][64] small batches: per-step contributions to Hll, gl, hC, cost (k_lin_small)
+  int *tile_cnt;              // [B][max_tiles]   arrival counter of the tile's LIN_SMALL_KS workgroups (zero between launches)
   double *tile_cand;          // [B][max_tiles][4] candidate: cost, |x-xc|^2, |xc|^2, pad
   double *tile_gram;          // [B][max_tiles][8] landmark parts of G2 N2 gy vHv vHy yHy gradmax
   double *dense_cand;         // [B][4] dense-factor candidate cost, |x-xc|^2, |xc|^2

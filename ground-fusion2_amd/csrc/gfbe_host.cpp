@@ -744,6 +744,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
     AL(prior_g, (size_t)B * (ND + 2));
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
+    AL(tile_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) : 1);
     AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
     // the partial reduced system [H | g | E | eg | xa] is one slab: a single all-reduce per linearisation when the
     // landmarks are sharded over ranks
@@ -765,6 +766,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(rec, want_rec ? (size_t)tot_rec * REC : 1); AL(mV, (size_t)B * ND * ND);
+    AL(vis_contrib, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) * MAXOBS * 16 * LM_TILE : 1);
     AL(dl_fix, (size_t)B * DL_FIX); AL(dl_feat, feat_off[B]); AL(dl_J0, (size_t)j0_off[B]);
     if (!b->dry) { b->up_end = up_end; b->zero_end = zero_end; }
 #undef UP

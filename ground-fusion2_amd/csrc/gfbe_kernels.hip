@@ -206,8 +206,14 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 // MODE 0: linearise at the current point; MODE 1: candidate cost; MODE 2: marginalisation set
 // (landmarks with start_frame 0, estimator.cpp:3498-3531) at the re-anchored state.
 // =============================================================================================
-template <int MODE, bool FULL>
-__device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile) {
+// KS > 1 (small batches, k_lin_small): the observation steps of a tile are independent pose pairs — their partials, their
+// H_pl blocks — except for three per-landmark running sums (Hll, gl, hC) and the cost. KS workgroups share a tile, workgroup
+// kq takes the steps k = kq, kq + KS, ..., every step's CONTRIBUTION to the running sums goes to a scratch array, and the
+// workgroup that arrives last (an atomic counter per tile; nobody waits for anybody) adds them up in step order: the same
+// additions in the same order as the one-wave loop of the throughput path, so the results stay bit-identical to it.
+#define VC_STRIDE 16      // doubles per (step, lane) in vis_contrib: Hll, gl, hC[<= 13], cost
+template <int MODE, bool FULL, int KS = 1>
+__device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile, const int kq = 0) {
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
@@ -271,17 +277,18 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length are zero in memory)
   double nob[5];
   {
-    const double *ob = d.lm_obs + slot;
+    const double *ob = d.lm_obs + (size_t)kq * 5 * TL + slot;
 #pragma unroll
-    for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
+    for (int q = 0; q < 5; q++) nob[q] = (kq < mmax) ? ob[q * TL] : 0.0;
   }
   KSTAMP(2);
-  for (int k = 0; k < mmax; k++) {
+  double *contrib = KS > 1 ? d.vis_contrib + (((size_t)w * d.max_tiles + tile) * MAXOBS) * (VC_STRIDE * LM_TILE) + lane : nullptr;
+  for (int k = kq; k < mmax; k += KS) {
     if (k < 5) KSTAMP(3 + 5 * k);
     double r[2], Ji[12], Jj[12], Je[FULL ? 12 : 1], Jl[2], Jt[2], hp[6];
     const double pjx = nob[0], pjy = nob[1], vjx = nob[2], vjy = nob[3], tdj = nob[4];
-    if (k + 1 < mmax) {
-      const double *ob = d.lm_obs + (size_t)(k + 1) * 5 * TL + slot;
+    if (k + KS < mmax) {
+      const double *ob = d.lm_obs + (size_t)(k + KS) * 5 * TL + slot;
 #pragma unroll
       for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
     }
@@ -291,8 +298,11 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
         for (int q = 0; q < 12; q++) { Ji[q] = pjx + q; Jj[q] = pjy * q; if (FULL) Je[q] = vjx - q; }
         Jl[0] = lam; Jl[1] = tdj; Jt[0] = vjy; Jt[1] = pix; r[0] = piy * 1e-3; r[1] = piz * 1e-3;
       } else
-      cost += visual_lin<MODE != 1, FULL>(pcs[sframe + 1 + k], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
-                                          sq, delta, r, Ji, Jj, Je, Jl, Jt);
+      {
+        const double ck = visual_lin<MODE != 1, FULL>(pcs[sframe + 1 + k], lam, td, pix, piy, piz, pjx, pjy, vix, viy, vjx, vjy, tdi, tdj,
+                                                      sq, delta, r, Ji, Jj, Je, Jl, Jt);
+        if (KS > 1) contrib[((size_t)k * VC_STRIDE + 15) * LM_TILE] = ck; else cost += ck;
+      }
       if (MODE != 1) {
         if (FULL && write_records) {   // inspection path (gfbe_eval_factors): block-CSR record r(2) | row0: Ji Jj Je Jl Jt | row1
           double *rb = d.rec + ((size_t)ds.rec_off + d.lm_rec[(size_t)k * TL + slot]) * REC;
@@ -306,6 +316,18 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
         }
         // landmark row of the normal equations (w = Jl)
         const double w0 = (is_const && MODE == 0) ? 0.0 : Jl[0], w1 = (is_const && MODE == 0) ? 0.0 : Jl[1];
+        if (KS > 1) {
+          double *cb = contrib + (size_t)k * VC_STRIDE * LM_TILE;
+          cb[0] = __builtin_fma(w0, w0, w1 * w1);
+          cb[LM_TILE] = __builtin_fma(w0, r[0], w1 * r[1]);
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+            cb[(2 + q) * LM_TILE] = __builtin_fma(Ji[q], w0, Ji[6 + q] * w1);
+            if (FULL) cb[(8 + q) * LM_TILE] = __builtin_fma(Je[q], w0, Je[6 + q] * w1);
+            hp[q] = __builtin_fma(Jj[q], w0, Jj[6 + q] * w1);
+          }
+          if (FULL) cb[14 * LM_TILE] = __builtin_fma(Jt[0], w0, Jt[1] * w1);
+        } else {
         Hll += __builtin_fma(w0, w0, w1 * w1);
         gl += __builtin_fma(w0, r[0], w1 * r[1]);
 #pragma unroll
@@ -315,6 +337,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
           hp[q] = __builtin_fma(Jj[q], w0, Jj[6 + q] * w1);
         }
         if (FULL) hC[12] += __builtin_fma(Jt[0], w0, Jt[1] * w1);
+        }
       }
     } else if (MODE != 1) {
 #pragma unroll
@@ -412,6 +435,31 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
         if (lk == 0 && lr == 12) vo[320 + 15] = acc0[3];        // r^T r (row 12, column 12)
       }
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (KS > 1) {
+    // the last of the tile's KS workgroups to get here adds the steps' contributions up, in step order
+    __threadfence();
+    int last = 0;
+    int *cnt = d.tile_cnt + (size_t)w * d.max_tiles + tile;
+    if (lane == 0) last = atomicAdd(cnt, 1) == KS - 1;
+    last = __shfl(last, 0, 64);
+    if (!last) return;
+    __threadfence();
+    if (lane == 0) *cnt = 0;     // (ready for the next launch)
+    const double *cr = d.vis_contrib + (((size_t)w * d.max_tiles + tile) * MAXOBS) * (VC_STRIDE * LM_TILE) + lane;
+    for (int k = 0; k < m; k++) {
+      const double *cb = cr + (size_t)k * VC_STRIDE * LM_TILE;
+#define VC_LD(i) __hip_atomic_load(cb + (i) * LM_TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+      cost += VC_LD(15);
+      if (MODE != 1) {
+        Hll += VC_LD(0);
+        gl += VC_LD(1);
+#pragma unroll
+        for (int q = 0; q < 6; q++) { hC[q] += VC_LD(2 + q); if (FULL) hC[6 + q] += VC_LD(8 + q); }
+        if (FULL) hC[12] += VC_LD(14);
+      }
+#undef VC_LD
     }
   }
   if (MODE != 1 && valid) {
@@ -750,8 +798,9 @@ __global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mod
 template <int MODE, bool FULL>
 __global__ __launch_bounds__(64, 1) void k_lin_small(BatchDev d) {
   const int w = blockIdx.x, y = blockIdx.y;
-  if (y < d.max_tiles) vis_body<MODE, FULL>(d, 0, w, y);
-  else dense_body<true>(d, MODE, 0, w, y - d.max_tiles);
+  constexpr int KS = MODE == 0 ? LIN_SMALL_KS : 1;      // (the cost-only pass is too short to gain: 9 -> 12 us when split)
+  if (y < d.max_tiles * KS) vis_body<MODE, FULL, KS>(d, 0, w, y / KS, y % KS);
+  else dense_body<true>(d, MODE, 0, w, y - d.max_tiles * KS);
 }
 
 // =============================================================================================
@@ -2279,7 +2328,7 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s) {
-  const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LM_TILE);
+  const dim3 g(d.B, d.max_tiles * (mode == 0 ? LIN_SMALL_KS : 1) + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LM_TILE);
   if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d);
   else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d);
   else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d);
