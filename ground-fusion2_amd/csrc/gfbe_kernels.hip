@@ -490,6 +490,12 @@ __global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_record
 // the workgroup reduces in a fixed order and writes one partial. MODE 0: linearise; MODE 1: candidate cost.
 // k_visblock adds the partials into the pose block / gradient / cost of the visual part; k_accept adds the candidate cost.
 // =============================================================================================
+// small batches: LIN_SMALL_KS workgroups per tile (see vis_body)
+template <int MODE, bool FULL>
+__global__ __launch_bounds__(LM_TILE, 1) void k_vis_split(BatchDev d, int write_records) {
+  vis_body<MODE, FULL, LIN_SMALL_KS>(d, write_records, blockIdx.x, blockIdx.y / LIN_SMALL_KS, blockIdx.y % LIN_SMALL_KS);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_lio_window(BatchDev d) {
   const int w = blockIdx.y, wg = blockIdx.x, t = threadIdx.x;
@@ -2325,6 +2331,7 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   if (mode == 0 && (d.vis_full || write_records)) hipLaunchKernelGGL((k_vis<0, true>), g, b, 0, s, d, write_records);
   else if (mode == 0) hipLaunchKernelGGL((k_vis<0, false>), g, b, 0, s, d, 0);
   else if (mode == 1) hipLaunchKernelGGL((k_vis<1, true>), g, b, 0, s, d, 0);
+  else if (d.B < DENSE_SPLIT_MIN_B) hipLaunchKernelGGL((k_vis_split<2, true>), dim3(d.B, d.max_tiles * LIN_SMALL_KS), b, 0, s, d, write_records);
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s) {
