@@ -104,41 +104,140 @@ __device__ __forceinline__ double clamp_diag(double x) { return fmin(fmax(x, GF_
 // k_prep: once per upload. sqrt_info of every IMU / wheel factor (imu_factor.h:73, wheel_factor.h:85,
 // hoisted out of Evaluate: SURVEY App. A.5) and H_prior = J0^T J0.
 // =============================================================================================
-// Grid (B, 1 + PREP_PRIOR_WGS): y = 0 factorises the covariances (one lane per factor), the others share H_prior.
-enum { PREP_PRIOR_WGS = 8 };
+// Grid (B, PREP_FACT_WGS + PREP_PRIOR_WGS): the first workgroups factorise the covariances (one WAVE per factor: the 20
+// waves take the <= 10 inertial and <= 10 wheel factors of a window side by side), the others share H_prior.
+//
+// sqrt_info_from_cov (gfbe_factors.h: inverse by partially pivoted LU, then a lower Cholesky of the inverse, written transposed)
+// by the 64 lanes of one wave. Every entry goes through exactly the operations, in exactly the order, of the one-thread form
+// (row updates of an elimination step are independent of each other; a column of the inverse is one lane's own substitution;
+// a column of the Cholesky factor is a dot product per row): the results are bit-identical to it (tests/test_gpu_parity.py
+// compares them with the host build of the one-thread form through the oracle), at ~10 us instead of ~150 us per factor — the
+// one-lane version was the longest kernel on the upload path of a single window.
+// lu, inv, U: n * n doubles of LDS each, private to the wave. Returns 0 on success (wave-uniform).
+#define PREP_WSYNC() do { __threadfence_block(); __builtin_amdgcn_wave_barrier(); } while (0)
+template <int n>
+__device__ __forceinline__ int sqrt_info_from_cov_wave(const double *cov, double *lu, double *inv, double *U, const int lane) {
+  for (int e = lane; e < n * n; e += 64) { lu[e] = cov[e]; U[e] = 0.0; }
+  int perm = lane;                       // lane i < n holds perm[i]
+  PREP_WSYNC();
+  for (int k = 0; k < n; k++) {
+    // the FIRST row of maximal |lu[i][k]|, i >= k (the scan of the one-thread form replaces the pivot on a strictly larger value)
+    const bool cand = lane >= k && lane < n;
+    const double a = cand ? fabs(lu[lane * n + k]) : -1.0;
+    double best = a;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o, 64));
+    if (best == 0.0) return 1;
+    const int piv = __ffsll((long long)__ballot(cand && a == best)) - 1;
+    if (piv != k) {
+      if (lane < n) { const double t = lu[k * n + lane]; lu[k * n + lane] = lu[piv * n + lane]; lu[piv * n + lane] = t; }
+      const int pk = __shfl(perm, k, 64), pp = __shfl(perm, piv, 64);
+      if (lane == k) perm = pp;
+      if (lane == piv) perm = pk;
+      PREP_WSYNC();
+    }
+    if (lane > k && lane < n) lu[lane * n + k] = lu[lane * n + k] / lu[k * n + k];
+    PREP_WSYNC();
+    const int m = n - k - 1;
+    for (int e = lane; e < m * m; e += 64) {
+      const int i = k + 1 + e / m, j = k + 1 + e % m;
+      const double f = lu[i * n + k];
+      lu[i * n + j] -= f * lu[k * n + j];
+    }
+    PREP_WSYNC();
+  }
+  if (lane < n) {                        // column `lane` of the inverse
+    const int c = lane;
+    double y[n], x[n];                   // (n is a compile-time constant and the loops are unrolled: registers, not scratch)
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      double sum = (__shfl(perm, i, 64) == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < i; j++) sum -= lu[i * n + j] * y[j];
+      y[i] = sum;
+    }
+#pragma unroll
+    for (int i = n - 1; i >= 0; i--) {
+      double sum = y[i];
+#pragma unroll
+      for (int j = i + 1; j < n; j++) sum -= lu[i * n + j] * x[j];
+      x[i] = sum / lu[i * n + i];
+      inv[i * n + c] = x[i];
+    }
+  }
+  PREP_WSYNC();
+  for (int j = 0; j < n; j++) {          // lower Cholesky of inv, written transposed (upper) into U
+    double dd = inv[j * n + j];
+    for (int k = 0; k < j; k++) dd -= U[k * n + j] * U[k * n + j];
+    if (!(dd > 0.0)) return 2;
+    dd = sqrt(dd);
+    if (lane == j) U[j * n + j] = dd;
+    if (lane > j && lane < n) {
+      double sum = inv[lane * n + j];
+      for (int k = 0; k < j; k++) sum -= U[k * n + lane] * U[k * n + j];
+      U[j * n + lane] = sum / dd;        // L(i,j) stored at U(j,i)
+    }
+    PREP_WSYNC();
+  }
+  return 0;
+}
+enum { PREP_FACT_WGS = 5, PREP_PRIOR_WGS = 8, PREP_ROWS = 16 };
+__device__ __forceinline__ void tri_decode(int e, int &a, int &b);
 __global__ __launch_bounds__(256) void k_prep(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
-  __shared__ double work[MAX_IMU][450];
-  __shared__ double wwork[MAX_WHEEL][72];
+  __shared__ double work[4][3 * 225];
   const int t = threadIdx.x;
-  if (blockIdx.y == 0) {
-    if (t < ds.n_imu) {
-      double *out = d.imu_sqrt + (size_t)(ds.imu_off + t) * 225;
-      double tmp[225];
-      const int rc = sqrt_info_from_cov(d.imu[ds.imu_off + t].covariance, 15, tmp, work[t]);
-      for (int i = 0; i < 225; i++) out[i] = rc ? nan("") : tmp[i];
-    } else if (t >= 64 && t < 64 + ds.n_wheel) {
-      const int k = t - 64;
-      double *out = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
-      double tmp[36];
-      const int rc = sqrt_info_from_cov(d.wheel[ds.wheel_off + k].covariance, 6, tmp, wwork[k]);
-      for (int i = 0; i < 36; i++) out[i] = rc ? nan("") : tmp[i];
+  if (blockIdx.y < PREP_FACT_WGS) {
+    const int lane = t & 63, wave = t >> 6;
+    double *lu = work[wave], *inv = lu + 225, *U = inv + 225;
+    for (int f = blockIdx.y * 4 + wave; f < ds.n_imu + ds.n_wheel; f += 4 * PREP_FACT_WGS) {      // wave-uniform
+      const bool imu = f < ds.n_imu;
+      const int k = imu ? f : f - ds.n_imu, n = imu ? 15 : 6;
+      const double *cov = imu ? d.imu[ds.imu_off + k].covariance : d.wheel[ds.wheel_off + k].covariance;
+      double *out = imu ? d.imu_sqrt + (size_t)(ds.imu_off + k) * 225 : d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
+      const int rc = imu ? sqrt_info_from_cov_wave<15>(cov, lu, inv, U, lane) : sqrt_info_from_cov_wave<6>(cov, lu, inv, U, lane);
+      for (int e = lane; e < n * n; e += 64) out[e] = rc ? nan("") : U[e];
+      PREP_WSYNC();
     }
     return;
   }
+  // H_prior = J0^T J0, lower triangle mirrored. J0 goes through LDS sixteen rows at a time (coalesced loads, every row read once
+  // per workgroup); a thread keeps its <= 9 entries in registers across the row panels and adds the products in row order —
+  // the same sums as the entry-by-entry loop over global memory this replaces (130 us of strided, dependent loads).
   const int n = ds.prior_n;
   if (n > 0) {
     const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
     double *Hp = d.prior_H + (size_t)w * ND * ND;
-    // lower triangle (i >= j), mirrored: consecutive lanes read consecutive columns j of every row r
-    for (int e = (blockIdx.y - 1) * blockDim.x + t; e < n * n; e += PREP_PRIOR_WGS * blockDim.x) {
-      const int i = e / n, j = e % n;
-      if (j > i) continue;
-      double s = 0.0;
-      for (int r = 0; r < n; r++) s += J0[(size_t)r * n + i] * J0[(size_t)r * n + j];
-      Hp[(size_t)i * n + j] = s;
-      Hp[(size_t)j * n + i] = s;
+    __shared__ double panel[PREP_ROWS * ND];
+    const int ntri = n * (n + 1) / 2, stride = PREP_PRIOR_WGS * 256, first = (blockIdx.y - PREP_FACT_WGS) * 256 + t;
+    constexpr int MAXE = (ND * (ND + 1) / 2 + PREP_PRIOR_WGS * 256 - 1) / (PREP_PRIOR_WGS * 256);
+    double acc[MAXE];
+    int ei[MAXE], ej[MAXE];
+#pragma unroll
+    for (int q = 0; q < MAXE; q++) {
+      acc[q] = 0.0; ei[q] = -1; ej[q] = 0;
+      const int e = first + q * stride;
+      if (e < ntri) tri_decode(e, ei[q], ej[q]);       // ej <= ei
+    }
+    for (int r0 = 0; r0 < n; r0 += PREP_ROWS) {
+      const int nr = min(PREP_ROWS, n - r0);
+      __syncthreads();
+      for (int e = t; e < nr * n; e += 256) panel[e] = J0[(size_t)r0 * n + e];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < MAXE; q++) {
+        if (ei[q] < 0) continue;
+        double sacc = acc[q];
+        for (int rr = 0; rr < nr; rr++) sacc += panel[rr * n + ei[q]] * panel[rr * n + ej[q]];
+        acc[q] = sacc;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXE; q++) {
+      if (ei[q] < 0) continue;
+      Hp[(size_t)ei[q] * n + ej[q]] = acc[q];
+      Hp[(size_t)ej[q] * n + ei[q]] = acc[q];
     }
   }
 }
@@ -2319,7 +2418,7 @@ void launch_expand(const BatchDev &d, hipStream_t s) {
 void launch_gather(const BatchDev &d, int margin_flag, hipStream_t s) {
   hipLaunchKernelGGL(k_gather, dim3(GATHER_WGS, d.B), dim3(256), 0, s, d, margin_flag);
 }
-void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B, 1 + PREP_PRIOR_WGS), dim3(256), 0, s, d); }
+void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B, PREP_FACT_WGS + PREP_PRIOR_WGS), dim3(256), 0, s, d); }
 void launch_reset(const BatchDev &d, hipStream_t s) {
   const int slots = d.max_tiles * LM_TILE;
   hipLaunchKernelGGL(k_reset, dim3((slots + 255) / 256 > 0 ? (slots + 255) / 256 : 1, d.B), dim3(256), 0, s, d);
