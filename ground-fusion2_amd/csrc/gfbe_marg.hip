@@ -514,11 +514,29 @@ __device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, cons
 #pragma unroll
       for (int q = 0; q < 3; q++)
         if (alive[q] && (bi < 0 || dg[q] > best)) { best = dg[q]; bi = lane + 64 * q; }
+      // arg-max over the wave (largest value, smallest index among equals: any reduction order gives the same answer): inside a
+      // 16-lane row by DPP rotations instead of dependent ds_bpermute rounds, then the four row results through v_readlane
+#define LDLT_TAKE(ob, oi) do { if ((oi) >= 0 && (bi < 0 || (ob) > best || ((ob) == best && (oi) < bi))) { best = (ob); bi = (oi); } } while (0)
+#define LDLT_ROR(N) do {                                                                                              \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(best), 0x120 + (N), 0xf, 0xf, false);            \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(best), 0x120 + (N), 0xf, 0xf, false);            \
+        const int oi_ = __builtin_amdgcn_update_dpp(0, bi, 0x120 + (N), 0xf, 0xf, false);                              \
+        const double ob_ = __hiloint2double(hi_, lo_);                                                                 \
+        LDLT_TAKE(ob_, oi_);                                                                                           \
+      } while (0)
+      LDLT_ROR(8); LDLT_ROR(4); LDLT_ROR(2); LDLT_ROR(1);
+      {
+        double rb[4]; int ri[4];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-        if (oi >= 0 && (bi < 0 || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+        for (int q = 0; q < 4; q++) {
+          rb[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 16 * q), __builtin_amdgcn_readlane(__double2loint(best), 16 * q));
+          ri[q] = __builtin_amdgcn_readlane(bi, 16 * q);
+        }
+        best = rb[0]; bi = ri[0];
+        LDLT_TAKE(rb[1], ri[1]); LDLT_TAKE(rb[2], ri[2]); LDLT_TAKE(rb[3], ri[3]);
       }
+#undef LDLT_ROR
+#undef LDLT_TAKE
       if (!(best > eps)) { rank = k; break; }     // identical in every wave
       const int pv = bi, pq = pv >> 6, pl = pv & 63;
       const double piv = best, inv = 1.0 / piv;
