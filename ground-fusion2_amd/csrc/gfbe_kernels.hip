@@ -1252,7 +1252,10 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   if (t <= NF) s_tile_begin[t] = ds.sf_tile_begin[t];
   __syncthreads();
   const int grp = SPLIT ? sgrp : t / VB_GROUP, e = SPLIT ? t : t - grp * VB_GROUP;
-  const bool live = e < VP_STRIDE;
+  // reduced panel (extrinsic and td constant in every window of the batch): k_vis fills only the pose block, the gradient
+  // column and r^T r of a partial — 157 of its 336 entries; the others belong to inactive dims and are not fetched
+  const bool need = d.vis_full || (e < 256 ? ((e >> 4) < 12 && (e & 15) < 12) : (e < 320 ? (((e - 256) & 3) == 3 && ((e - 256) >> 2) < 12) : e == 335));
+  const bool live = e < VP_STRIDE && need;
   // compact column pair (la, lb) of this thread's entry of a fused partial (layout of k_vis: T0 16x16, T1 16x4, T2 4x4)
   int la = 0, lb = 0; bool mirror = false;
   if (e < 256) { la = e >> 4; lb = e & 15; }
