@@ -119,7 +119,7 @@ def test_every_public_struct_matches_the_c_header(tmp_path):
     pairs = [("gfbe_state", abi.State), ("gfbe_imu_preint", abi.ImuPreint), ("gfbe_wheel_preint", abi.WheelPreint),
              ("gfbe_visual", abi.Visual), ("gfbe_prior", abi.Prior), ("gfbe_lio_block", abi.LioBlock), ("gfbe_window", abi.Window),
              ("gfbe_options", abi.Options), ("gfbe_summary", abi.Summary), ("gfbe_feature_list", abi.FeatureList),
-             ("gfbe_ftab_options", abi.FtabOptions)]
+             ("gfbe_ftab_options", abi.FtabOptions), ("gfbe_gnss_obs", abi.GnssObs), ("gfbe_gnss_state", abi.GnssState)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gfbe.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
