@@ -18,6 +18,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 @pytest.fixture(scope="module")
 def shim():
+    return build_shim()
+
+
+def build_shim():
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "tests", "host_shim.cpp")

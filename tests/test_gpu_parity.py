@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP back end through the C ABI vs the CPU oracle on the same seeded
 inputs. FP64 everywhere; tolerances are written next to each assertion (north_star: "results match
 the reference solve on the same window to a stated float tolerance; bit-exact index bookkeeping")."""
+import os
+
 import numpy as np
 import pytest
 
@@ -325,3 +327,18 @@ def test_invariants_over_a_chain_of_windows_at_bench_size(be):
         assert again["summary"]["initial_cost"] - again["summary"]["final_cost"] < 1e-2 * sm["final_cost"]
         st = synth.shift_state_for_next_window(scn, res["state"], k + 1)
         prior = pr
+
+
+def test_whitened_inertial_factors_bit_identical_to_host_build(be):
+    """k_prep forms the square-root information matrices with one wave per factor (64 lanes sharing the LU inverse and the
+    Cholesky of the inverse); every entry goes through the operations of the one-thread sqrt_info_from_cov in the same order,
+    so the whitened IMU / wheel residuals and Jacobians of the device equal, bit for bit, those of the same header compiled for
+    the host (tests/host_shim.cpp; no fused multiply-add in either build)."""
+    import test_device_math_host as tdm
+    shim = tdm.build_shim()          # (skips without hipcc)
+    for seed in (41, 42):
+        scn = synth.Scenario(seed=seed, n_landmarks=120, use_wheel=True)
+        snap = scn.window(0)
+        got, want = be.eval_factors(snap, robustify=False), tdm.shim_eval(shim, snap, False)
+        for k in ("imu_r", "imu_J", "wheel_r", "wheel_J"):
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
