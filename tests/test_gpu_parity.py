@@ -329,7 +329,7 @@ def test_invariants_over_a_chain_of_windows_at_bench_size(be):
         prior = pr
 
 
-def test_whitened_inertial_factors_bit_identical_to_host_build(be):
+def test_factor_blocks_bit_identical_to_host_build(be):
     """k_prep forms the square-root information matrices with one wave per factor (64 lanes sharing the LU inverse and the
     Cholesky of the inverse); every entry goes through the operations of the one-thread sqrt_info_from_cov in the same order,
     so the whitened IMU / wheel residuals and Jacobians of the device equal, bit for bit, those of the same header compiled for
@@ -339,6 +339,9 @@ def test_whitened_inertial_factors_bit_identical_to_host_build(be):
     for seed in (41, 42):
         scn = synth.Scenario(seed=seed, n_landmarks=120, use_wheel=True)
         snap = scn.window(0)
-        got, want = be.eval_factors(snap, robustify=False), tdm.shim_eval(shim, snap, False)
-        for k in ("imu_r", "imu_J", "wheel_r", "wheel_J"):
-            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
+        for rob in (False, True):
+            got, want = be.eval_factors(snap, robustify=rob), tdm.shim_eval(shim, snap, rob)
+            # ... and so do the visual blocks (the fused evaluation + Huber corrector of the linearisation kernels): what the CPU
+            # suite pins against the oracle (tests/test_device_math_host.py) IS what the GPU computes
+            for k in ("imu_r", "imu_J", "wheel_r", "wheel_J", "vis_r", "vis_J"):
+                assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
