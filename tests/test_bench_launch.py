@@ -63,3 +63,10 @@ def test_rccl_hook_library_contract():
         assert not h.value
     assert lib.gfbe_rccl_last_error(None) == -1
     lib.gfbe_rccl_allreduce(None, None, 0, None)                             # null handle: ignored
+
+
+def test_public_headers_are_strict_c99(tmp_path):
+    """include/gfbe.h and include/gfbe_rccl.h together, as a C caller sees them."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "gfbe.h"\n#include "gfbe_rccl.h"\nint main(void) { return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-fsyntax-only", str(src)], check=True)
