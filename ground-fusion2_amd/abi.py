@@ -114,7 +114,8 @@ class Options(C.Structure):
                 ("initial_trust_region_radius", c_d), ("function_tolerance", c_d), ("gradient_tolerance", c_d),
                 ("parameter_tolerance", c_d), ("min_relative_decrease", c_d), ("jacobi_scaling", c_i),
                 ("marg_eps", c_d), ("marg_sqrt", c_i), ("use_graph", c_i), ("split_batch", c_i),
-                ("max_solver_time_in_seconds", c_d), ("host_threads", c_i)]
+                ("max_solver_time_in_seconds", c_d), ("host_threads", c_i), ("solve_kernel", c_i),
+                ("test_fail_chol_iter", c_i)]
 
 
 class Summary(C.Structure):
@@ -148,6 +149,8 @@ def default_options():
     o.split_batch = 1
     o.max_solver_time_in_seconds = 0.0
     o.host_threads = 0
+    o.solve_kernel = 0
+    o.test_fail_chol_iter = 0
     return o
 
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "gfbe_solve_window", "gfbe_solve_batch",
     "gfbe_batch_upload", "gfbe_batch_solve", "gfbe_batch_download", "gfbe_batch_free",
     "gfbe_profile_enable", "gfbe_profile_count", "gfbe_profile_get", "gfbe_profile_reset",
-    "gfbe_set_allreduce", "gfbe_debug_timing",
+    "gfbe_set_allreduce", "gfbe_debug_timing", "gfbe_debug_vector",
     "gfbe_ftab_default_options", "gfbe_ftab_create", "gfbe_ftab_destroy", "gfbe_ftab_add_frame",
     "gfbe_ftab_remove_back_shift_depth", "gfbe_ftab_remove_back", "gfbe_ftab_remove_front", "gfbe_ftab_remove_outlier",
     "gfbe_ftab_remove_failures", "gfbe_ftab_clear_depth", "gfbe_ftab_set_depth", "gfbe_ftab_get_depth_vector",
@@ -49,22 +49,43 @@ def sources():
 
 
 def build_native(force=False, verbose=False, out=None, extra_flags=None, fp_contract="off"):
-    """hipcc --offload-arch=gfx950 -> csrc/libgfbe.so (cross-compiles without a GPU). `out` / `extra_flags` / `fp_contract`:
-    side-by-side variant builds (tests/diag_variants.py)."""
+    """hipcc --offload-arch=gfx950 -> csrc/libgfbe.so (cross-compiles without a GPU). Every source is compiled to its own
+    object (in parallel, only when it is older than the source or a header) and the objects are linked: a one-file change
+    rebuilds in seconds. `out` / `extra_flags` / `fp_contract`: side-by-side variant builds (tests/diag_variants.py)."""
+    from concurrent.futures import ThreadPoolExecutor
     so = out or os.path.join(_CSRC, "libgfbe.so")
     srcs = sources()
-    deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hpp"))]
-    deps.append(os.path.join(os.path.dirname(_HERE), "include", "gfbe.h"))
-    if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
-        return so
+    hdrs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hpp"))]
+    hdrs.append(os.path.join(os.path.dirname(_HERE), "include", "gfbe.h"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = os.environ.get("GFBE_EXTRA_FLAGS", "").split() if extra_flags is None else list(extra_flags)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=" + fp_contract,
-           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-pthread",
-           "-I", os.path.join(os.path.dirname(_HERE), "include"), "-o", so] + flags + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    cflags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=" + fp_contract, "-munsafe-fp-atomics",
+              "-Wall", "-Wno-unused-function", "-pthread", "-I", os.path.join(os.path.dirname(_HERE), "include")] + flags
+    tag = "default" if (out is None and not flags and fp_contract == "off") else os.path.splitext(os.path.basename(so))[0]
+    odir = os.path.join(_CSRC, "build", tag)
+    os.makedirs(odir, exist_ok=True)
+    stamp = os.path.join(odir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(cflags):
+        force = True
+    hnew = max(os.path.getmtime(h) for h in hdrs)
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(odir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hnew):
+            jobs.append([hipcc] + cflags + ["-c", src, "-o", obj])
+    if not jobs and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(o) for o in objs):
+        return so
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", so] + objs)
+    with open(stamp, "w") as f:
+        f.write(" ".join(cflags))
     return so
 
 
@@ -276,6 +297,11 @@ class Batch:
     def debug_timing(self, w=0):
         out = np.zeros(32)
         self.be.lib.gfbe_debug_timing(self.be.ctx, self.h, int(w), abi._pd(out))
+        return out
+
+    def debug_vector(self, which, w=0):
+        out = np.zeros(abi.DENSE_DIM)
+        self.be.check(self.be.lib.gfbe_debug_vector(self.be.ctx, self.h, int(w), int(which), abi._pd(out)), "debug_vector")
         return out
 
     def free(self):

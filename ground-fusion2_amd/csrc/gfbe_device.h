@@ -189,7 +189,7 @@ struct BatchDev {
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
-  int test_fail_chol_iter;          // fault injection (GFBE_TEST_FAIL_CHOL_ITER, tests only): the first factorisation of that iteration "fails"
+  int test_fail_chol_iter;          // gfbe_options.test_fail_chol_iter (test hook): the first factorisation of that iteration "fails"
   int vis_full;                     // some window of the batch has a free camera extrinsic or td: the visual kernels form those Jacobian blocks
   double *xa, *xb, *xc;       // [B][world][XCHG] scalar exchange rows (own row written, the others zeroed, then sum all-reduce):
                               //   xa: visual cost of the linearisation point; xb: landmark shares of the dogleg scalars;
@@ -214,6 +214,10 @@ struct BatchDev {
   double *Er;                 // landmark sharding only: [B][NV*NV + NV] E | eg rebuilt for a larger mu by every rank from its own tiles
                               // (zeros for the windows that do not retry), summed by one all-reduce before the retry pass of k_solve
   double *sp, *Dp, *gts, *vp, *yp, *step;   // [B][ND] each
+  // k_solve_chain (gfbe_solve.hip): the speed-bias blocks are eliminated before the dense factorisation
+  double *solveY;             // [B][99][96]  Yr rows of the chain (written by the elimination, read back by the back-substitution)
+  int solve_ntile;            // dense tiles (16 x 16, lower triangle incl. the right-hand side row) of the largest window: sizes the dynamic LDS
+  int solve_mono;             // some window's prior couples a speed-bias block other than SpeedBias[0]: the whole batch takes the monolithic k_solve
   // debug / inspection outputs (gfbe_eval_factors)
   double *dbg_imu, *dbg_wheel, *dbg_prior;  // [B][MAX_IMU][15*31], [B][MAX_WHEEL][6*23], [B][ND]
   // marginalisation
@@ -265,6 +269,7 @@ void launch_lam_mask(const BatchDev &d, hipStream_t s);
 void launch_marginalize_partials(const BatchDev &d, hipStream_t s);
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s);
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass = 0);
+int solve_chain_tiles(const unsigned char *act);   // dense 16 x 16 tiles k_solve_chain needs for a window with these active dims
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s);
 void launch_lm_step(const BatchDev &d, hipStream_t s);
 void launch_step(const BatchDev &d, hipStream_t s);

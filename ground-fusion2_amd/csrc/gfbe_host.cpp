@@ -210,6 +210,8 @@ void gfbe_default_options(gfbe_options *o) {
   o->use_graph = 0;                          // 1: replay the fixed launch sequence of gfbe_batch_solve as a hipGraph (measured: no gain)
   o->max_solver_time_in_seconds = 0.0;       // no cap (the reference: SOLVER_TIME = 0.04, estimator.cpp:3369-3376)
   o->host_threads = 0;                       // packing threads: min(hardware threads, 32)
+  o->solve_kernel = 0;                       // chain-eliminated factorisation of the reduced system (k_solve_chain)
+  o->test_fail_chol_iter = 0;
 }
 
 const char *gfbe_version(void) { return "gfbe 0.1.0 (gfx950, HIP)"; }
@@ -693,7 +695,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   }
   d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio;
   d.rank = c->rank; d.world = c->world;
-  { const char *fe = getenv("GFBE_TEST_FAIL_CHOL_ITER"); d.test_fail_chol_iter = fe ? atoi(fe) : 0; }   // fault injection of the mu-retry path (tests)
+  d.test_fail_chol_iter = c->opt.test_fail_chol_iter;   // (test hook of the mu-retry path, 0 in production: gfbe_options)
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
   for (int w = 0; w < B; w++) if (wins[w]->use_plane || wins[w]->use_anchor) d.any_plane = 1;
@@ -767,6 +769,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(rec, want_rec ? (size_t)tot_rec * REC : 1); AL(mV, (size_t)B * ND * ND);
     AL(vis_contrib, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) * MAXOBS * 16 * LM_TILE : 1);
+    AL(solveY, (size_t)B * 99 * 96);
     AL(dl_fix, (size_t)B * DL_FIX); AL(dl_feat, feat_off[B]); AL(dl_J0, (size_t)j0_off[B]);
     if (!b->dry) { b->up_end = up_end; b->zero_end = zero_end; }
 #undef UP
@@ -907,6 +910,18 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     b->up_win_bytes[w] = bytes;
   });
   if (bad.load() >= 0) { c->err = errs[bad.load()]; return GFBE_BAD_INPUT; }
+  // k_solve_chain eliminates the speed-bias blocks as a chain: IMUFactor couples SpeedBias[k] with its neighbours only, and the
+  // priors the reference builds keep SpeedBias[0] alone (estimator.cpp:3400-3433, 3600-3632). A prior with any other speed-bias
+  // block breaks that structure: such a batch takes the monolithic factorisation (gfbe_options.solve_kernel = 1 forces it).
+  {
+    int ntile = 1, mono = c->opt.solve_kernel == 1;
+    for (int w = 0; w < B; w++) {
+      const WinDesc &ds = h_desc[w];
+      ntile = std::max(ntile, solve_chain_tiles(ds.act));
+      for (int q = 0; q < ds.prior_nblk; q++) if (ds.prior_blk_id[q] > GFBE_BLK_SB0 && ds.prior_blk_id[q] < GFBE_BLK_EX_CAM) mono = 1;
+    }
+    d.solve_ntile = ntile; d.solve_mono = mono;
+  }
   const double T3 = now();
   // ---- enqueue: clear what must start as zero, ONE host-to-device copy, then the preparation kernels
   if (b->zero_end > b->up_end) HIPCHK(c, hipMemsetAsync(b->slab + b->up_end, 0, b->zero_end - b->up_end, us));
@@ -1422,6 +1437,17 @@ extern "C" gfbe_status gfbe_debug_timing(gfbe_ctx *c, gfbe_batch *b, int32_t w, 
   if (!c || !b || !out32 || w < 0 || w > b->d.B) return GFBE_BAD_INPUT;   // (w == B: the extra block of the first part)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out32, b->d.timing + (size_t)w * 32, sizeof(double) * 32, hipMemcpyDeviceToHost));
+  return GFBE_OK;
+}
+extern "C" gfbe_status gfbe_debug_vector(gfbe_ctx *c, gfbe_batch *b, int32_t w, int32_t which, double *out) {
+  if (!c || !b || !out || which < 0 || which > 3) return GFBE_BAD_INPUT;
+  int off = w;
+  gfbe_batch *p = b;
+  while (p && off >= p->d.B) { off -= p->d.B; p = p->second; }
+  if (!p || off < 0) return GFBE_BAD_INPUT;
+  const double *src = which == 0 ? p->d.yp : which == 1 ? p->d.vp : which == 2 ? p->d.sp : p->d.g;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, src + (size_t)off * ND, sizeof(double) * ND, hipMemcpyDeviceToHost));
   return GFBE_OK;
 }
 

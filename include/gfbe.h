@@ -213,6 +213,16 @@ typedef struct gfbe_options {
   /* Host threads gfbe_batch_upload / gfbe_batch_download pack and unpack windows with (one window per task).
    * 0 (default) = min(hardware threads, 32); 1 = the calling thread only. */
   int32_t host_threads;
+  /* Factorisation of the reduced system (the DENSE_SCHUR linear solve of estimator.cpp:3364-3379 after the landmark elimination):
+   *   0 (default)  the speed-bias blocks are eliminated as a chain of 9 x 9 blocks before the dense pose / extrinsic part is
+   *                factorised (~70 KB of LDS, two workgroups per CU). Needs the structure every factor of the reference has:
+   *                a prior that keeps a speed-bias block other than SpeedBias[0] switches its batch to 1 by itself.
+   *   1            one blocked factorisation of the whole reduced system (160 KB of LDS). Same step to rounding. */
+  int32_t solve_kernel;
+  /* TEST HOOK (0 = off, the default; never set it in production): the first factorisation of trust-region iteration
+   * `test_fail_chol_iter` is declared failed, so that DoglegStrategy's mu retry — which well-posed windows never take —
+   * can be exercised (tests/test_gpu_branches.py). */
+  int32_t test_fail_chol_iter;
 } gfbe_options;
 
 typedef struct gfbe_summary {
@@ -567,6 +577,10 @@ void gfbe_profile_reset(gfbe_ctx *ctx);
 
 /* Diagnostics: phase time stamps (10 ns ticks) of the dense solve kernel for window w of a batch. */
 gfbe_status gfbe_debug_timing(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, double *out32);
+/* Diagnostics: a per-window vector of the LAST linearisation of a solved batch (GFBE_DENSE_DIM doubles each; waits for the solve):
+ * which = 0 Gauss-Newton step y of the dense block (Jacobi-scaled), 1 Cauchy direction v, 2 Jacobi scaling s, 3 gradient g.
+ * Lets a test compare the two factorisations of gfbe_options.solve_kernel entry by entry. */
+gfbe_status gfbe_debug_vector(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, int32_t which, double *out);
 
 /* Multi-GPU landmark sharding: when set, the library calls
  * fn(user, device_ptr, n_doubles, hip_stream) once per linearisation on the packed partial reduced

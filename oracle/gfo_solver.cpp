@@ -423,11 +423,10 @@ static void solve(const Problem &P, Solution &sol) {
       }
       // Gauss-Newton step with the mu-regularised Schur solve (DoglegStrategy::ComputeGaussNewtonStep)
       bool solved = false;
-      // fault injection (tests only): the first factorisation of iteration GFBE_TEST_FAIL_CHOL_ITER is declared failed,
+      // fault injection (tests only): the first factorisation of iteration gfbe_options.test_fail_chol_iter is declared failed,
       // so that the mu-retry path (DoglegStrategy: mu *= 10 until the linear solver succeeds) is exercised — Gauss-Newton
       // systems with mu >= 1e-8 practically never fail on their own
-      const char *fenv = std::getenv("GFBE_TEST_FAIL_CHOL_ITER");
-      bool inject = fenv && std::atoi(fenv) == it;
+      bool inject = o.test_fail_chol_iter > 0 && o.test_fail_chol_iter == it;
       while (mu < max_mu) {
         for (int a = 0; a < ND; a++) {
           for (int b = 0; b < ND; b++) St[(size_t)a * ND + b] = sp[a] * sp[b] * lin.H[(size_t)a * ND + b];
@@ -754,6 +753,7 @@ void gfo_default_options(gfbe_options *o) {
   o->use_graph = 0;   // (device options; meaningless on the CPU)
   o->split_batch = 1;
   o->max_solver_time_in_seconds = 0.0; o->host_threads = 0;
+  o->solve_kernel = 0; o->test_fail_chol_iter = 0;
 }
 
 int32_t gfo_sqrt_info(const double *cov, double *out, int32_t n) { return sqrt_info_from_cov(cov, out, n) ? 0 : 1; }

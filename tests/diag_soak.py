@@ -64,11 +64,14 @@ for i in range(N):
         pc[0] = 1
         snap["pose_const"] = pc
     retry = int(rng.integers(1, 5)) if rng.random() < 0.15 else 0
-    if retry:
-        os.environ["GFBE_TEST_FAIL_CHOL_ITER"] = str(retry)
+    if retry:      # gfbe_options.test_fail_chol_iter (test hook) on both sides
+        oo = abi.default_options()
+        oo.test_fail_chol_iter = retry
+        ber = gf.Backend(device=0, options=oo)
+        want, got = orc.with_options(test_fail_chol_iter=retry).solve(snap, flag), ber.solve(snap, flag)
+        ber.close()
     else:
-        os.environ.pop("GFBE_TEST_FAIL_CHOL_ITER", None)
-    want, got = orc.solve(snap, flag), be.solve(snap, flag)
+        want, got = orc.solve(snap, flag), be.solve(snap, flag)
     sw, sg = want["summary"], got["summary"]
     tag = "L=%d wheel=%d prior=%d lidar=%d rgbd=%d flag=%d partial=%d free=%d gimbal=%d noimu=%d retry=%d" % (
         L, wheel, with_prior, lidar, rgbd, flag, partial, free_all, gimbal, no_imu, retry)

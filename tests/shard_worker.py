@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     rank, world, port, L, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    fail_iter = int(sys.argv[6]) if len(sys.argv) > 6 else 0      # gfbe_options.test_fail_chol_iter (test hook of the mu retry)
     import torch
     import torch.distributed as dist
     from _gfbe_import import gf
@@ -20,8 +21,11 @@ def main():
     plain = gf.Backend(device=0)
     first = plain.solve(scn.window(0), abi.MARGIN_OLD)
     snap = scn.window(1, state=synth.shift_state_for_next_window(scn, first["state"], 1), prior=first["prior"])
-    ref = plain.solve(snap, abi.MARGIN_OLD)
-    be = gf.Backend(device=0)
+    opt = abi.default_options()
+    opt.test_fail_chol_iter = fail_iter
+    failing = gf.Backend(device=0, options=opt)
+    ref = failing.solve(snap, abi.MARGIN_OLD)
+    be = gf.Backend(device=0, options=opt)
     be.set_allreduce(gf.dist.torch_allreduce_hook(), rank, world)
     got = be.solve(snap, abi.MARGIN_OLD)
     again = be.solve(snap, abi.MARGIN_OLD)

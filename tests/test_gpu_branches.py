@@ -4,7 +4,7 @@ C ABI on the GPU against the CPU oracle with the tolerances of tests/test_gpu_pa
     PoseSubsetParameterization masks (pose_subset_parameterization.cpp:27-64: masked in Plus only);
   * double2vector()'s gimbal-lock branch (estimator.cpp:2523-2532): frame-0 pitch within 1 degree of 90;
   * the mu-retry of DoglegStrategy after a failed linear solve, with the in-kernel rebuild of E (fault injection:
-    GFBE_TEST_FAIL_CHOL_ITER makes the first factorisation of one iteration "fail" in both implementations);
+    gfbe_options.test_fail_chol_iter makes the first factorisation of one iteration "fail" in both implementations);
   * USE_IMU = 0 (estimator.cpp:3018-3022): no IMU factors, speed-bias blocks absent, Pose[0] constant.
 """
 import os
@@ -85,19 +85,27 @@ def test_reanchor_gimbal_lock_branch(be, oracle):
     be2.close()
 
 
+def _failing(oracle, fail_iter):
+    """A backend and an oracle whose options carry the test hook gfbe_options.test_fail_chol_iter."""
+    opt = abi.default_options()
+    opt.test_fail_chol_iter = fail_iter
+    return gf.Backend(device=0, options=opt), oracle.with_options(test_fail_chol_iter=fail_iter)
+
+
 @pytest.mark.parametrize("fail_iter", [1, 3])
-def test_mu_retry_after_failed_linear_solve(be, oracle, fail_iter, monkeypatch):
+def test_mu_retry_after_failed_linear_solve(be, oracle, fail_iter):
     """The first Cholesky of iteration `fail_iter` is declared failed: mu goes 1e-8 -> 1e-7, k_solve rebuilds E from the
     landmark rows for the new mu inside the kernel and factorises again; the later iterations carry the larger mu."""
     _, snap = window_with_prior(oracle, 64, 500)
     plain = oracle.solve(snap, abi.MARGIN_OLD)
-    monkeypatch.setenv("GFBE_TEST_FAIL_CHOL_ITER", str(fail_iter))
-    want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD)
+    bef, orf = _failing(oracle, fail_iter)
+    want, got = check_solve(bef, orf, snap, abi.MARGIN_OLD)
     assert want["summary"]["cost_history"] != plain["summary"]["cost_history"]      # the retry changed the iteration (larger damping)
     # a batch mixes windows: the retry of one must not leak into its neighbours' partials
-    res = be.solve_batch([snap, snap, snap], abi.MARGIN_OLD)
+    res = bef.solve_batch([snap, snap, snap], abi.MARGIN_OLD)
     for r in res:
         assert r["summary"]["cost_history"] == got["summary"]["cost_history"]
+    bef.close()
 
 
 def test_no_imu_pose0_constant(be, oracle):
@@ -133,13 +141,14 @@ def test_solver_time_cap_stops_on_the_device(be, oracle):
 
 
 @pytest.mark.parametrize("name", ["A", "B", "cfg1", "free_masks", "retry2"])
-def test_hip_backend_reproduces_independent_trust_region_loop(be, oracle, name, monkeypatch):
+def test_hip_backend_reproduces_independent_trust_region_loop(be, oracle, name):
     """The HIP path against tests/golden/dogleg_np.npz — the outputs of the independent numpy trust-region loop
     (tests/ceres_trust_region_np.py, from Ceres 1.14's published algorithm): same accept / reject sequence and termination,
     costs and final radius to the tolerances of tests/test_oracle_numpy.py::_check_against_loop."""
     from dogleg_cases import cases
     from test_oracle_numpy import _check_against_loop, _dogleg_fixture
     snap, kw = [(s, k) for n, s, k in cases(oracle) if n == name][0]
-    if kw.get("fail_chol_iter"):
-        monkeypatch.setenv("GFBE_TEST_FAIL_CHOL_ITER", str(kw["fail_chol_iter"]))
-    _check_against_loop(be.solve(snap, abi.MARGIN_NONE)["summary"], _dogleg_fixture(), name, final_rtol=1e-6 if name == "free_masks" else 1e-9)
+    bex = _failing(oracle, kw["fail_chol_iter"])[0] if kw.get("fail_chol_iter") else be
+    _check_against_loop(bex.solve(snap, abi.MARGIN_NONE)["summary"], _dogleg_fixture(), name, final_rtol=1e-6 if name == "free_masks" else 1e-9)
+    if bex is not be:
+        bex.close()

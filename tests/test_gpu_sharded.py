@@ -30,9 +30,7 @@ def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter)
     port = free_port()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if fail_iter:
-        env["GFBE_TEST_FAIL_CHOL_ITER"] = str(fail_iter)
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(r), str(world), str(port), str(L), outs[r]],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(r), str(world), str(port), str(L), outs[r], str(fail_iter)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     for p in procs:

@@ -171,13 +171,12 @@ def _check_against_loop(summary, ref, name, final_rtol=1e-9):
 
 
 @pytest.mark.parametrize("name", ["A", "B", "cfg1", "free_masks", "retry2"])
-def test_dogleg_loop_oracle_reproduces_independent_numpy_loop(oracle, name, monkeypatch):
+def test_dogleg_loop_oracle_reproduces_independent_numpy_loop(oracle, name):
     from dogleg_cases import cases
     ref = _dogleg_fixture()
     snap, kw = [(s, k) for n, s, k in cases(oracle) if n == name][0]
-    if kw.get("fail_chol_iter"):
-        monkeypatch.setenv("GFBE_TEST_FAIL_CHOL_ITER", str(kw["fail_chol_iter"]))
-    _check_against_loop(oracle.solve(snap, abi.MARGIN_NONE)["summary"], ref, name, final_rtol=1e-6 if name == "free_masks" else 1e-9)
+    orc = oracle.with_options(test_fail_chol_iter=kw["fail_chol_iter"]) if kw.get("fail_chol_iter") else oracle
+    _check_against_loop(orc.solve(snap, abi.MARGIN_NONE)["summary"], ref, name, final_rtol=1e-6 if name == "free_masks" else 1e-9)
 
 
 @pytest.mark.parametrize("name", ["B", "free_masks"])
