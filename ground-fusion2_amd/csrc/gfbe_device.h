@@ -215,7 +215,7 @@ struct BatchDev {
                               // (zeros for the windows that do not retry), summed by one all-reduce before the retry pass of k_solve
   double *sp, *Dp, *gts, *vp, *yp, *step;   // [B][ND] each
   // k_solve_chain (gfbe_solve.hip): the speed-bias blocks are eliminated before the dense factorisation
-  double *solveY;             // [B][99][96]  Yr rows of the chain (written by the elimination, read back by the back-substitution)
+  double *solveY;             // [B][96][104]  Yr rows of the chain, transposed (written by the elimination, read back by the back-substitution)
   int solve_ntile;            // dense tiles (16 x 16, lower triangle incl. the right-hand side row) of the largest window: sizes the dynamic LDS
   int solve_mono;             // some window's prior couples a speed-bias block other than SpeedBias[0]: the whole batch takes the monolithic k_solve
   // debug / inspection outputs (gfbe_eval_factors)
@@ -269,7 +269,8 @@ void launch_lam_mask(const BatchDev &d, hipStream_t s);
 void launch_marginalize_partials(const BatchDev &d, hipStream_t s);
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s);
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass = 0);
-int solve_chain_tiles(const unsigned char *act);   // dense 16 x 16 tiles k_solve_chain needs for a window with these active dims
+int solve_chain_tiles(const unsigned char *act);
+size_t solve_chain_scratch_doubles();              // doubles of BatchDev::solveY per window   // dense 16 x 16 tiles k_solve_chain needs for a window with these active dims
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s);
 void launch_lm_step(const BatchDev &d, hipStream_t s);
 void launch_step(const BatchDev &d, hipStream_t s);

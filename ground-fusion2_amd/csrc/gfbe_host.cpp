@@ -769,7 +769,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(rec, want_rec ? (size_t)tot_rec * REC : 1); AL(mV, (size_t)B * ND * ND);
     AL(vis_contrib, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) * MAXOBS * 16 * LM_TILE : 1);
-    AL(solveY, (size_t)B * 99 * 96);
+    AL(solveY, (size_t)B * solve_chain_scratch_doubles());
     AL(dl_fix, (size_t)B * DL_FIX); AL(dl_feat, feat_off[B]); AL(dl_J0, (size_t)j0_off[B]);
     if (!b->dry) { b->up_end = up_end; b->zero_end = zero_end; }
 #undef UP

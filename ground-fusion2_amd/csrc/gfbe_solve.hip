@@ -538,289 +538,349 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 // other structure to the monolithic k_solve). k_solve factorises all of S as 12 x 12 tiles: twelve 16-pivot tile steps on one
 // wave's critical chain, 78 tiles = the whole 160 KB of a CU's LDS. Here, with the variable order [SB_10, SB_9, ..., SB_0, dense]:
 //
-//   chain, block k = 10 .. 0 (ONE wave, 9 pivots per block, all in registers through 64-bit DPP row broadcasts):
+//   chain, block k = 10 .. 0 (wave 0, 9 pivots per block, in registers through 64-bit DPP row broadcasts — chain_block):
 //       W_k = chol(A_k)^-1                    A_k: the block's 9 x 9 diagonal block (already downdated by block k + 1)
 //       Yc_k = W_k C_k                        C_k = S(SB_k, SB_k-1): the row operations of the factorisation applied to C_k's
 //       A_k-1 -= Yc_k^T Yc_k                                         columns as well, like the identity that becomes W_k
-//   wide rows (two waves behind it, one LANE per column of the dense part + the right-hand side; lane-local recurrence):
-//       R_k' = R_k - Yc_k+1^T Yr_k+1          R_k = S(SB_k, dense | rhs)
-//       Yr_k = W_k R_k'                       (column nd of Yr_k = z_k, the forward-substituted right-hand side of the block)
-//   dense update (five waves behind those, FP64 matrix cores, accumulators in registers over all blocks):
-//       D -= sum_k Yr_k^T Yr_k                (augmented with the right-hand side row, like k_solve's tiles)
+//   wide rows (waves 1..3 one step behind, FP64 matrix cores, 16 dense columns per tile; wide_role):
+//       R_k' = R_k - Yc_k+1^T Yr_k+1          R_k = S(SB_k, dense | rhs)     [one 16x16x4 chain: A = -Yc^T, B = Yr_k+1, C = R_k]
+//       Yr_k = W_k R_k'                       (column nd of Yr_k = z_k)      [one more: A = W_k, B = R_k' — the accumulator
+//                                                                             layout of the first IS the B layout of the second]
+//   dense update (the same waves, one more step behind; accumulators in registers over all blocks):
+//       D -= sum_k Yr_k^T Yr_k                (augmented with the right-hand side row, like k_solve's tiles; the wave that forms
+//                                              a column tile of Yr_k holds the operand of its tile row in registers)
 //   then the blocked Cholesky of k_solve on the 5 x 5 tiles of D (chol_factor_all), its back-substitution, and the chain's:
-//       x_k = W_k^T (z_k - Yr_k x_dense - Yc_k x_k-1),  k = 0 .. 10.
+//       x_k = W_k^T (z_k - Yr_k x_dense) - G_k x_k-1,  k = 0 .. 10,   G_k = W_k^T Yc_k formed inside the pipeline,
+//   i.e. one 9 x 9 matrix-vector product per block on the sequential path (DPP row broadcasts, no LDS round trip).
 //
-// The three stages run as a pipeline, one block barrier per chain block. Fill stays inside the structure: Yr_k only reaches the
-// poses of frames >= k - 1 (lo_k) besides the extrinsic / intrinsic columns, which the column lanes and the tile products skip.
-// 15 tiles + chain blocks + a two-block ring of Yr = ~67 KB of LDS: two workgroups per CU; the Yr rows (76 KB per window)
-// go to HBM / L2 for the back-substitution. Inactive speed-bias dims (constant block, window still filling up, USE_IMU = 0)
+// One block barrier per chain block. Fill stays inside the structure: Yr_k only reaches the poses of frames >= k - 1 (lo_k)
+// besides the extrinsic / intrinsic columns; column tiles and tile products below lo_k are skipped. 15 tiles + chain blocks +
+// a two-block ring of Yr = ~67 KB of LDS and 4 waves: two workgroups per CU; the Yr rows (80 KB per window, transposed) go
+// to HBM / L2 for the back-substitution. Inactive speed-bias dims (constant block, window still filling up, USE_IMU = 0)
 // are identity rows of their block.
 // =============================================================================================
-#define S2_THREADS 512
+#define S2_THREADS 256
+#ifndef GFBE_ROLE_INLINE
+#define GFBE_ROLE_INLINE 0
+#endif
+#if GFBE_ROLE_INLINE
+#define GFBE_ROLE_FN __forceinline__
+#else
+#define GFBE_ROLE_FN __noinline__
+#endif
 #define S2_WAVES (S2_THREADS >> 6)
-#define S2_COL_WAVES 2                       // waves 1..2: the wide-row recurrence (lane = dense column)
-enum { CH_NB = 9, CH_NC = NF, CH_ROWS = CH_NB * CH_NC, CH_RW = 96, CH_BLK = CH_NB * CH_NB, RING_ROWS = 12, RING_LD = 112,
-       S2_MAX_NT = 6, S2_MAX_TILES = S2_MAX_NT * (S2_MAX_NT + 1) / 2 };
+enum { CH_NB = 9, CH_NC = NF, CH_ROWS = CH_NB * CH_NC, CH_BLK = CH_NB * CH_NB, RING_ROWS = 12,
+       S2_MAX_NT = 6, S2_MAX_TILES = S2_MAX_NT * (S2_MAX_NT + 1) / 2, GYT_LD = 104, GYT_COLS = TB * S2_MAX_NT };
+// row stride of the Yr ring: >= 16 x tile columns and = 16 (mod 32) doubles, so that the two row groups a half-wave reads as a
+// matrix-core operand fall into disjoint LDS banks (five tile columns -> 80, six -> 112)
+__host__ __device__ inline int chain_ring_ld(int ntile) { return ntile <= 15 ? 80 : 112; }
 __host__ __device__ inline bool dim_in_chain(int a) { return a >= T_SB(0) && a < T_SB(0) + CH_ROWS; }
+typedef __attribute__((address_space(3))) unsigned char lds_uchar;
 
 template <int KK>
 __device__ __forceinline__ void dpp_fmac2(double &acc, double bc, double m) {   // acc += m * (lane KK of the 16-lane row)'s bc
   asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(bc), "v"(m), "n"(KK));
 }
-// Pivot K of a chain block: chol_inv_step with CH_NB columns and the block's coupling row cr riding along (see chol_inv_step for
-// the hazards handled by hand).
+// One block of the chain by one wave. Lane (g, i) — 16-lane row g of the wave, lane i of the row — owns row i of the block:
+// every row group keeps the 9 entries of the diagonal block A_k (the pivot column must be in every group), and the 18
+// "passive" columns that only ride along — the identity that becomes W_k and the coupling block C_k that becomes Yc_k — are
+// dealt over the four groups: register q of group g holds passive column 4 q + g (columns 0..8: W, 9..17: Yc). A pivot is then
+// ~14 instructions of the 1/sqrt chain + (8 - K) + 5 row updates (v_fmac_f64_dpp, the pivot row travels inside the FMA) instead
+// of (8 - K) + 18. The downdate of A_k-1 is dealt the same way: group g forms the columns of A_k-1 whose Yc columns it holds.
+// Hazards the compiler does not see inside inline assembly: chol_inv_step.
+//   A: in A_k (downdated), out W_k = L_k^-1 (lower triangular, zeros above the diagonal)     Cb: in C_k, out Yc_k (has_next)
+//   An: A_k-1, downdated in place (has_next). Returns false on a pivot that is not positive and finite.
+#define CH_NP 5          // passive registers per lane: ceil(18 / 4)
 template <int K>
-__device__ __forceinline__ void chain_pivot(double (&row)[CH_NB], double (&u)[CH_NB], double (&cr)[CH_NB], int li, double &myinv) {
+__device__ __forceinline__ void chain_pivot(double (&row)[CH_NB], double (&p)[CH_NP], int li, double &myinv) {
   double dkk;
   asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(dkk) : "v"(row[K]), "n"(K));
   const double inv = rsqrt_refined(dkk);
   const double lik = row[K] * inv;
   double m = (li > K) ? -(lik * inv) : 0.0;
   myinv = (li == K) ? inv : myinv;
-  u[K] = (li == K) ? 1.0 : 0.0;
-  asm volatile("" : "+v"(u[K]), "+v"(m));
+  asm volatile("" : "+v"(m));
 #pragma unroll
   for (int j = K + 1; j < CH_NB; j++) dpp_fmac<K>(row[j], m);
 #pragma unroll
-  for (int c = 0; c <= K; c++) dpp_fmac<K>(u[c], m);
-#pragma unroll
-  for (int j = 0; j < CH_NB; j++) dpp_fmac<K>(cr[j], m);
+  for (int q = 0; q < CH_NP; q++) dpp_fmac<K>(p[q], m);
 }
 template <int K> struct ChainPivots {
-  static __device__ __forceinline__ void run(double (&row)[CH_NB], double (&u)[CH_NB], double (&cr)[CH_NB], int li, double &myinv) {
-    chain_pivot<K>(row, u, cr, li, myinv);
-    if constexpr (K + 1 < CH_NB) ChainPivots<K + 1>::run(row, u, cr, li, myinv);
+  static __device__ __forceinline__ void run(double (&row)[CH_NB], double (&p)[CH_NP], int li, double &myinv) {
+    chain_pivot<K>(row, p, li, myinv);
+    if constexpr (K + 1 < CH_NB) ChainPivots<K + 1>::run(row, p, li, myinv);
   }
 };
-template <int M> struct ChainDowndate {   // arow -= Yc^T Yc, one row m of Yc at a time: arow[j] -= Yc[m][i] * Yc[m][j]
-  static __device__ __forceinline__ void run(double (&arow)[CH_NB], const double (&ycs)[CH_NB], const double (&nyc)[CH_NB]) {
+template <int M> struct ChainDowndate {   // a[q] -= Yc[m][i] * Yc[m][j_q], one row m of Yc at a time (q = 2..4: the Yc columns of this group)
+  static __device__ __forceinline__ void run(double (&a)[3], const double (&p)[CH_NP], const double (&nyc)[CH_NB]) {
 #pragma unroll
-    for (int j = 0; j < CH_NB; j++) dpp_fmac2<M>(arow[j], ycs[j], nyc[M]);
-    if constexpr (M + 1 < CH_NB) ChainDowndate<M + 1>::run(arow, ycs, nyc);
+    for (int q = 0; q < 3; q++) dpp_fmac2<M>(a[q], p[2 + q], nyc[M]);
+    if constexpr (M + 1 < CH_NB) ChainDowndate<M + 1>::run(a, p, nyc);
   }
 };
-// One block of the chain by one wave (every 16-lane row of the wave does the same work; lane i < 9 of a row owns row i).
-//   A: the block's diagonal block (in: downdated A_k; out: W_k = L_k^-1, lower triangular)     Cb: C_k in, Yc_k out (k > 0)
-//   An: A_k-1, downdated in place (k > 0)
-// Returns false on a pivot that is not positive and finite.
 __device__ __forceinline__ bool chain_block(lds_double *A, lds_double *Cb, lds_double *An, int lane, int has_next) {
-  const int li = lane & 15;
-  int lio = li < CH_NB ? li : 0;
-  asm volatile("" : "+v"(lio));
-  double row[CH_NB], u[CH_NB], cr[CH_NB];
+  const int li = lane & 15, g = lane >> 4;
   const bool mine = li < CH_NB;
+  int lio = mine ? li : 0;
+  asm volatile("" : "+v"(lio));
+  double row[CH_NB], p[CH_NP];
 #pragma unroll
-  for (int q = 0; q < CH_NB; q++) {
-    const double a = A[lio * CH_NB + q], cc = has_next ? Cb[lio * CH_NB + q] : 0.0;
-    row[q] = mine ? a : 0.0; cr[q] = mine ? cc : 0.0; u[q] = 0.0;
+  for (int q = 0; q < CH_NB; q++) { const double a = A[lio * CH_NB + q]; row[q] = mine ? a : 0.0; }
+#pragma unroll
+  for (int q = 0; q < CH_NP; q++) {
+    const int idx = 4 * q + g;                                         // passive column of this register
+    double v = (idx == li) ? 1.0 : 0.0;                                // columns 0..8: the identity
+    if (idx >= CH_NB) { const double cv = (has_next && idx < 2 * CH_NB) ? Cb[lio * CH_NB + min(idx, 2 * CH_NB - 1) - CH_NB] : 0.0; v = cv; }
+    p[q] = mine ? v : 0.0;
   }
   double myinv = 0.0;
-  // (definitions pinned here: a VALU write needs two wait states before a DPP instruction reads the register and the compiler
-  //  does not look into inline assembly — it could otherwise sink a definition next to its first DPP use; EXEC may have been
-  //  rewritten by masked code: five wait states before the first DPP instruction)
+  // (definitions pinned: a VALU write needs two wait states before a DPP instruction reads the register and the compiler does not
+  //  look into inline assembly; EXEC may have been rewritten by masked code: five wait states before the first DPP instruction)
 #pragma unroll
-  for (int q = 0; q < CH_NB; q++) asm volatile("" : "+v"(row[q]), "+v"(cr[q]));
+  for (int q = 0; q < CH_NB; q++) asm volatile("" : "+v"(row[q]));
+#pragma unroll
+  for (int q = 0; q < CH_NP; q++) asm volatile("" : "+v"(p[q]));
   asm volatile("s_nop 4" ::: "memory");
-  ChainPivots<0>::run(row, u, cr, li, myinv);
-  double ycs[CH_NB];
+  ChainPivots<0>::run(row, p, li, myinv);
 #pragma unroll
-  for (int q = 0; q < CH_NB; q++) { u[q] *= myinv; ycs[q] = cr[q] * myinv; }
-  if (lane < CH_NB) {
+  for (int q = 0; q < CH_NP; q++) p[q] *= myinv;
 #pragma unroll
-    for (int q = 0; q < CH_NB; q++) { A[lio * CH_NB + q] = u[q]; if (has_next) Cb[lio * CH_NB + q] = ycs[q]; }
+  for (int q = 0; q < CH_NP; q++) {
+    const int idx = 4 * q + g;
+    lds_double *dst = idx < CH_NB ? A + lio * CH_NB + idx : Cb + lio * CH_NB + (idx - CH_NB);
+    if (mine && (idx < CH_NB || (has_next && idx < 2 * CH_NB))) *dst = p[q];
   }
   const bool ok = __ballot(mine && !((myinv > 0.0) && (myinv < 1.0e300))) == 0ull;
   if (has_next) {
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    double arow[CH_NB], nyc[CH_NB];
+    double a[3], nyc[CH_NB];
+    int jq[3];
 #pragma unroll
-    for (int q = 0; q < CH_NB; q++) { arow[q] = An[lio * CH_NB + q]; nyc[q] = -Cb[q * CH_NB + lio]; }   // row i of A_k-1, column i of Yc_k
+    for (int q = 0; q < 3; q++) { jq[q] = 4 * (2 + q) + g - CH_NB; const bool on = jq[q] >= 0 && jq[q] < CH_NB; a[q] = on ? An[lio * CH_NB + (on ? jq[q] : 0)] : 0.0; }
 #pragma unroll
-    for (int q = 0; q < CH_NB; q++) asm volatile("" : "+v"(ycs[q]), "+v"(nyc[q]), "+v"(arow[q]));
+    for (int q = 0; q < CH_NB; q++) nyc[q] = -Cb[q * CH_NB + lio];       // column i of Yc_k
+#pragma unroll
+    for (int q = 0; q < 3; q++) asm volatile("" : "+v"(a[q]));
+#pragma unroll
+    for (int q = 0; q < CH_NB; q++) asm volatile("" : "+v"(nyc[q]));
+#pragma unroll
+    for (int q = 0; q < CH_NP; q++) asm volatile("" : "+v"(p[q]));
     asm volatile("s_nop 4" ::: "memory");
-    ChainDowndate<0>::run(arow, ycs, nyc);
-    if (lane < CH_NB) {
+    ChainDowndate<0>::run(a, p, nyc);
 #pragma unroll
-      for (int q = 0; q < CH_NB; q++) An[lio * CH_NB + q] = arow[q];
-    }
+    for (int q = 0; q < 3; q++) if (mine && jq[q] >= 0 && jq[q] < CH_NB) An[lio * CH_NB + jq[q]] = a[q];
   }
   __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
   return ok;
 }
 
-typedef __attribute__((address_space(3))) unsigned char lds_uchar;
-// ---- the three roles of the chain pipeline (k_solve_chain). Each is out of line — its own register allocation: the chain wave
-// keeps ~45 doubles of block rows, a column lane its recurrence state, the matrix-core waves their accumulators — and each
-// passes exactly CH_NC + 2 block barriers.
-__device__ __noinline__ void chain_role(lds_double *Ach, lds_double *Cch, lds_int *flag, int lane) {
+// Block barrier of the pipeline: LDS traffic only. __syncthreads() also drains the vector-memory counter — every step would wait
+// for its Yr stores to reach L2 and for the NEXT block's prefetched coupling rows (~2 us per step measured).
+#ifndef GFBE_CHAIN_STAMP
+#define GFBE_CHAIN_STAMP 0      // diagnostics build (tests/diag_chain.py): per-step time stamps of the pipeline roles into the NEXT window's timing slots
+#endif
+#if GFBE_CHAIN_STAMP
+#define RSTAMP(cond, i) do { if (cond) rstamp[i] = (double)wall_clock64(); } while (0)
+#else
+#define RSTAMP(cond, i) do { } while (0)
+#endif
+#define CH_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// ---- the roles of the chain pipeline (k_solve_chain). Each is out of line — its own register allocation — and each passes
+// exactly CH_NC + 2 block barriers.
+__device__ GFBE_ROLE_FN void chain_role(lds_double *Ach, lds_double *Cch, lds_int *flag, int lane, double *rstamp) {
   for (int s = 0; s <= CH_NC + 1; s++) {
     const int k = CH_NC - 1 - s;
+    RSTAMP(lane == 0, 32 + s);
     if (k >= 0) {
       if (!chain_block(Ach + k * CH_BLK, Cch + k * CH_BLK, Ach + (k > 0 ? k - 1 : 0) * CH_BLK, lane, k > 0) && lane == 0) *flag = 1;
     }
-    __syncthreads();
+    RSTAMP(lane == 0 && s < 6, 46 + s);
+    CH_LDS_BARRIER();
   }
 }
-// Wide rows: lane j owns column j of the dense part (j == n: the right-hand side). Returns the lane's share of v^T S v over the
-// coupling entries it loads; the right-hand side lane leaves |z_chain|^2 in *zzc_out.
-__device__ __noinline__ double column_role(const lds_double *Ach, const lds_double *Cch, lds_double *ring, const lds_double *ys, const lds_short *perm,
-                                           const lds_int *s_lo, const lds_uchar *chact, lds_double *zzc_out, const glb_double *H, const glb_double *ggts,
-                                           glb_double *gY, int n, int j) {
-  const int na = n + 1;
-  const bool col_on = j < na;
-  const int bj = col_on && j < n ? perm[j] : 0;          // tangent dim of the column
-  const double sbj = col_on && j < n ? ys[bj] : 0.0, vbj = col_on && j < n ? ys[ND + bj] : 0.0;
-  double yprev[CH_NB], rpre[CH_NB], zzc = 0.0, vsv = 0.0;
+// Wide rows and the dense update, waves 1..3 (wv = 0..2): wave wv forms the column tiles wv and wv + 3 of Yr (16 dense columns each,
+// the right-hand side is column n) and adds every third tile of the dense update D -= sum_k Yr_k^T Yr_k one step later, both
+// operands from the two-block ring of Yr in LDS. Lane (lr, lk) holds rows lk, lk + 4, lk + 8 of column 16 c + lr — the operand
+// layout of v_mfma_f64_16x16x4_f64 for every product here and the layout of its result, so Yr_k+1 never leaves the registers.
+// A lone wave issues ONE instruction every ~5.4 cycles whatever it is (profiles/ubench/dp_issue_rate_mi355x.txt), so the loop is
+// written for instruction count and without divergent branches: pointers into H, into the chain blocks and into the transposed
+// Yr rows advance by a per-lane constant per block; lanes outside a 9 x 9 block read a zero slot of LDS (stride 0) and write to a
+// dump slot. (Inactive speed-bias dims: H holds exact zeros there.)
+// Returns the lane's share of v^T S v over the coupling entries it loads; |z_chain|^2 goes to *zzc_out.
+#define S2_WIDE_WAVES (S2_WAVES - 1)
+#define S2_TPW ((S2_MAX_TILES + S2_WIDE_WAVES - 1) / S2_WIDE_WAVES)
+enum { CH_ZERO = 96 };     // doubles behind the chain blocks: a zero slot (first half: parked operand reads reach 36 doubles in) and a dump slot
+__device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds_double *Cch, lds_double *ring, lds_double *zslot, const lds_double *sS,
+                                         const lds_double *vS, const lds_double *rS, const lds_short *perm, const lds_int *s_lo, lds_double *zzc_out,
+                                         const glb_double *H, glb_double *gYT, int n_, int nt_, int ring_ld_, int wv_, int lane, double *rstamp) {
+  // (wave-uniform values in scalar registers: the compiler cannot see that they are uniform — they come from LDS / the thread
+  //  index — and would turn every branch on them into an EXEC-masked region)
+  const int n = __builtin_amdgcn_readfirstlane(n_), nt = __builtin_amdgcn_readfirstlane(nt_);
+  const int ring_ld = __builtin_amdgcn_readfirstlane(ring_ld_), wv = __builtin_amdgcn_readfirstlane(wv_);
+  const int lr = lane & 15, lk = lane >> 4, na = n + 1;
+  const bool in01 = lr < CH_NB, in2 = lr < CH_NB && lk == 0;
+  // ---- per-lane state of the two column tiles
+  bool on[2];
+  int jc[2];
+  double sbj[2], vbj2[2], mrhs[2];
+  const glb_double *pH[2];        // S-source entry (SB_k row lk, column): H[a * ND + b] for b below the speed-bias dims, H[b * ND + a] above
+  long dH[2];
+  glb_double *pY[2], *pY8[2];     // transposed Yr rows: rows lk, lk + 4 | row 8 (lk == 0) — or the dump column
+  lds_double *pR[2];              // ring slot (row lk, column 16 c + lr)
 #pragma unroll
-  for (int i = 0; i < CH_NB; i++) { yprev[i] = 0.0; rpre[i] = 0.0; }
-  // R_k[i][j] = S(SB_k dim i, column j): scaled H entry (the speed-bias rows lie outside E), or the scaled gradient for j == n
-  auto load_R = [&](int k, double (&r)[CH_NB]) {
-    const bool reach = col_on && j >= s_lo[k];
+  for (int u = 0; u < 2; u++) {
+    const int c = wv + S2_WIDE_WAVES * u;
+    on[u] = c < nt;
+    jc[u] = TB * c + lr;
+    const bool col_on = on[u] && jc[u] < na, dense_col = on[u] && jc[u] < n;
+    const int bj = dense_col ? perm[jc[u]] : 0;
+    sbj[u] = dense_col ? sS[bj] : 0.0; vbj2[u] = dense_col ? 2.0 * vS[bj] : 0.0;
+    mrhs[u] = (on[u] && jc[u] == n) ? 1.0 : 0.0;
+    const int a0 = T_SB(CH_NC - 1) + lk;
+    dH[u] = bj < T_SB(0) ? ND : 1;
+    pH[u] = H + (bj < T_SB(0) ? (size_t)a0 * ND + bj : (size_t)bj * ND + a0);
+    glb_double *col = gYT + (size_t)(col_on ? jc[u] : GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB;    // (column 95 is never a system column: the dump)
+    pY[u] = col + lk;
+    pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB + 8;
+    pR[u] = ring + lk * ring_ld + min(TB * c, ring_ld - TB) + lr;
+  }
+  double yv[2][3], rpre[2][3], vsv = 0.0, zzc = 0.0;
 #pragma unroll
-    for (int i = 0; i < CH_NB; i++) {
-      const int a = T_SB(k) + i;
-      double v = 0.0;
-      if (reach && chact[a - T_SB(0)]) v = (j < n) ? H[(size_t)max(a, bj) * ND + min(a, bj)] * ys[a] * sbj : ggts[a];
-      r[i] = v;
-    }
+  for (int u = 0; u < 2; u++)
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; }
+  // rows lk, lk + 4, lk + 8 of block k (the third only counts for lk == 0: the others read into the next block and are masked)
+  auto load_R = [&](int u, double (&r)[3]) {
+    r[0] = pH[u][0]; r[1] = pH[u][4 * dH[u]]; r[2] = pH[u][8 * dH[u]];
+    pH[u] -= CH_NB * dH[u];
   };
-  load_R(CH_NC - 1, rpre);
+#pragma unroll
+  for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rpre[u]);
+  // operand pointers into the chain blocks (block CH_NC - 1 first; per-lane stride, 0 for the lanes parked on the zero slot)
+  //   a2[kk] = W_k[lr][4 kk + lk]        a1[kk] = -Yc_k+1[4 kk + lk][lr]      (G: W_kG[4 kk + lk][lr], Yc_kG[4 kk + lk][lr])
+  const int sW01 = in01 ? CH_BLK : 0, sW2 = in2 ? CH_BLK : 0;
+  const lds_double *pW01 = in01 ? Ach + (CH_NC - 1) * CH_BLK + lr * CH_NB + lk : zslot;
+  const lds_double *pW2 = in2 ? Ach + (CH_NC - 1) * CH_BLK + lr * CH_NB + 8 : zslot;
+  const lds_double *pC01 = in01 ? Cch + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot;      // (block k + 1 = CH_NC - 1 is first used at the second step)
+  const lds_double *pC2 = in2 ? Cch + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
+  const lds_double *pT01 = in01 ? Ach + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot;      // W transposed access for G (block kG)
+  const lds_double *pT2 = in2 ? Ach + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
+  lds_double *pG01 = in01 ? Cch + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot + CH_ZERO / 2;   // G output (block kG), or the dump half of the slot
+  lds_double *pG2 = in2 ? Cch + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot + CH_ZERO / 2;
+  const double m2 = lk == 0 ? 1.0 : 0.0;     // (row 8 + lk exists for lk == 0 only)
+  // ---- dense update: tiles e = wv, wv + 3, ... of the lower triangle
+  dbl4 acc[S2_TPW];
+  int oI[S2_TPW], oJ[S2_TPW], tJ1[S2_TPW];
+#pragma unroll
+  for (int q = 0; q < S2_TPW; q++) {
+    acc[q] = dbl4{0.0, 0.0, 0.0, 0.0};
+    const int e = wv + S2_WIDE_WAVES * q;
+    int I = 0, J = 0;
+    const bool v = e < nt * (nt + 1) / 2;
+    if (v) tri_decode(e, I, J);
+    oI[q] = TB * I; oJ[q] = TB * J; tJ1[q] = v ? TB * (J + 1) : 0;     // (tJ1 = 0: never above lo_k >= 0 -> skipped)
+  }
+  const int ro = lk * ring_ld + lr, rblk = RING_ROWS * ring_ld;
   for (int s = 0; s <= CH_NC + 1; s++) {
+    // (1) dense update with Yr of block kg (in the ring since the previous step)
+    const int kg = CH_NC + 1 - s;
+    if (kg >= 0 && kg < CH_NC) {
+      const lds_double *rg = ring + (kg & 1) * rblk + ro;
+      const int lo = __builtin_amdgcn_readfirstlane(s_lo[kg]);
+#pragma unroll
+      for (int q = 0; q < S2_TPW; q++) {
+        if (tJ1[q] <= lo) continue;                               // (columns below lo_kg are zero in Yr_kg; wave-uniform)
+        double a[3], b[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) { a[kk] = rg[4 * kk * ring_ld + oI[q]]; b[kk] = rg[4 * kk * ring_ld + oJ[q]]; }
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc[q], 0, 0, 0);
+      }
+    }
+    // (2) Yr of block k: R' = R_k - Yc_k+1^T Yr_k+1, Yr_k = W_k R'
     const int k = CH_NC - s;
     if (k >= 0 && k < CH_NC) {
-      double r[CH_NB], y[CH_NB];
+      const int lo = __builtin_amdgcn_readfirstlane(s_lo[k]);
+      double a1[3], a2[3];
+      a2[0] = pW01[0]; a2[1] = pW01[4]; a2[2] = pW2[0];
+      if (k + 1 < CH_NC) { a1[0] = -pC01[0]; a1[1] = -pC01[4 * CH_NB]; a1[2] = -pC2[0]; pC01 -= sW01; pC2 -= sW2; }
+      else { a1[0] = 0.0; a1[1] = 0.0; a1[2] = 0.0; }
+      pW01 -= sW01; pW2 -= sW2;
+      double sk[3], vk[3], rk[3];
 #pragma unroll
-      for (int i = 0; i < CH_NB; i++) r[i] = rpre[i];
-      if (k > 0) load_R(k - 1, rpre);                     // (in flight during this block's arithmetic)
-      if (j < n) {
+      for (int kk = 0; kk < 3; kk++) { const int a = T_SB(k) + min(lk + 4 * kk, CH_NB - 1); sk[kk] = sS[a]; vk[kk] = vS[a]; rk[kk] = rS[a]; }
+      sk[2] *= m2; rk[2] *= m2;
 #pragma unroll
-        for (int i = 0; i < CH_NB; i++) vsv = __builtin_fma(r[i] * ys[ND + T_SB(k) + i], 2.0 * vbj, vsv);
-      }
-      if (k + 1 < CH_NC) {
-        const lds_double *Yc = Cch + (k + 1) * CH_BLK;    // Yc_k+1[m][i]
+      for (int u = 0; u < 2; u++) {
+        if (!on[u]) continue;                                      // (wave-uniform)
+        const bool zero_tile = TB * (wv + S2_WIDE_WAVES * u + 1) <= lo;      // (below the reach of block k: Yr_k is zero here; wave-uniform)
+        const double reach = (jc[u] >= lo && jc[u] < na) ? 1.0 : 0.0;
+        const double m1 = reach * sbj[u], mr = reach * mrhs[u];
+        double r[3];
 #pragma unroll
-        for (int m = 0; m < CH_NB; m++)
+        for (int kk = 0; kk < 3; kk++) r[kk] = __builtin_fma(rpre[u][kk] * sk[kk], m1, mr * rk[kk]);
+        load_R(u, rpre[u]);                                        // (block k - 1; in flight during this block's products. The loads of
+                                                                   //  the step after block 0 read valid, unused rows of H)
+        if (!zero_tile) {
 #pragma unroll
-          for (int i = 0; i < CH_NB; i++) r[i] = __builtin_fma(-Yc[m * CH_NB + i], yprev[m], r[i]);
-      }
-      const lds_double *Wk = Ach + k * CH_BLK;
+          for (int kk = 0; kk < 3; kk++) vsv = __builtin_fma(r[kk] * vk[kk], vbj2[u], vsv);
+          dbl4 rp = {r[0], r[1], r[2], 0.0};
 #pragma unroll
-      for (int i = 0; i < CH_NB; i++) {
-        double sacc = 0.0;
+          for (int kk = 0; kk < 3; kk++) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], yv[u][kk], rp, 0, 0, 0);
+          dbl4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int m = 0; m <= i; m++) sacc = __builtin_fma(Wk[i * CH_NB + m], r[m], sacc);
-        y[i] = sacc;
-      }
-      if (col_on) {
-        lds_double *rg = ring + (size_t)(k & 1) * RING_ROWS * RING_LD + j;
+          for (int kk = 0; kk < 3; kk++) y = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kk], rp[kk], y, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < CH_NB; i++) { rg[i * RING_LD] = y[i]; gY[(size_t)(k * CH_NB + i) * CH_RW + j] = y[i]; yprev[i] = y[i]; }
-        if (j == n) {
+          for (int kk = 0; kk < 3; kk++) yv[u][kk] = y[kk];
+          lds_double *rgw = pR[u] + (k & 1) * rblk;
 #pragma unroll
-          for (int i = 0; i < CH_NB; i++) zzc = __builtin_fma(y[i], y[i], zzc);
+          for (int kk = 0; kk < 3; kk++) rgw[4 * kk * ring_ld] = yv[u][kk];
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) zzc = __builtin_fma(yv[u][kk] * mrhs[u], yv[u][kk], zzc);
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) yv[u][kk] = 0.0;
         }
+        pY[u][0] = yv[u][0]; pY[u][4] = yv[u][1]; pY8[u][0] = yv[u][2];
+        pY[u] -= CH_NB; pY8[u] -= CH_NB;
       }
     }
-    __syncthreads();
-  }
-  if (col_on && j == n) *zzc_out = zzc;
-  return vsv;
-}
-// Dense update D -= sum_k Yr_k^T Yr_k: wave gw takes the tiles e = gw, gw + 5, ... of the lower triangle (<= 5 of the 21 tiles of a
-// 6 x 6 grid), accumulators in registers over all blocks, the blocks' Yr rows from the ring.
-#define S2_UPD_WAVES (S2_WAVES - 1 - S2_COL_WAVES)
-#define S2_UPD_TPW ((S2_MAX_TILES + S2_UPD_WAVES - 1) / S2_UPD_WAVES)
-__device__ __noinline__ void gemm_role(lds_double *tiles, const lds_double *ring, const lds_int *s_lo, int ntile_all, int gw, int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  dbl4 acc[S2_UPD_TPW];
-  int tI[S2_UPD_TPW], tJ[S2_UPD_TPW];
-#pragma unroll
-  for (int q = 0; q < S2_UPD_TPW; q++) {
-    acc[q] = dbl4{0.0, 0.0, 0.0, 0.0};
-    const int e = gw + S2_UPD_WAVES * q;
-    tI[q] = -1; tJ[q] = 0;
-    if (e < ntile_all) tri_decode(e, tI[q], tJ[q]);
-  }
-  for (int s = 0; s <= CH_NC + 1; s++) {
-    const int k = CH_NC + 1 - s;
-    if (k >= 0 && k < CH_NC) {
-      const lds_double *rg = ring + (size_t)(k & 1) * RING_ROWS * RING_LD;
-      const int lo = s_lo[k];
-#pragma unroll
-      for (int q = 0; q < S2_UPD_TPW; q++) {
-        if (tI[q] < 0 || TB * (tJ[q] + 1) <= lo) continue;   // (columns below lo_k are zero in Yr_k)
-        double va[3], vb[3];
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) { va[kk] = rg[(4 * kk + lk) * RING_LD + TB * tI[q] + lr]; vb[kk] = rg[(4 * kk + lk) * RING_LD + TB * tJ[q] + lr]; }
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], acc[q], 0, 0, 0);
-      }
+    // (3) G_kG = W_kG^T Yc_kG in place of Yc_kG, one step after its last reader (the wide rows of block kG - 1): the chain's
+    //     back-substitution then needs one matrix-vector product per block
+    const int kG = CH_NC - s + 2;
+    if (wv == S2_WIDE_WAVES - 1 && kG >= 1 && kG < CH_NC) {
+      const int off = (kG - (CH_NC - 1));                          // (<= 0) blocks below the first one
+      const lds_double *t01 = pT01 + off * sW01, *t2 = pT2 + off * sW2, *c01 = pG01 + off * sW01, *c2 = pG2 + off * sW2;
+      const double ag0 = t01[0], ag1 = t01[4 * CH_NB], ag2 = t2[0], bg0 = c01[0], bg1 = c01[4 * CH_NB], bg2 = c2[0];
+      dbl4 gq = {0.0, 0.0, 0.0, 0.0};
+      gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag0, in01 ? bg0 : 0.0, gq, 0, 0, 0);
+      gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag1, in01 ? bg1 : 0.0, gq, 0, 0, 0);
+      gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag2, in2 ? bg2 : 0.0, gq, 0, 0, 0);
+      lds_double *g01 = pG01 + off * sW01, *g2 = pG2 + off * sW2;
+      g01[0] = gq[0]; g01[4 * CH_NB] = gq[1]; g2[0] = gq[2];
     }
-    __syncthreads();
+    RSTAMP(wv == 1 && lane == 0 && s < 12, 52 + s);
+    CH_LDS_BARRIER();
   }
+  // dense tiles -= the accumulated products
 #pragma unroll
-  for (int q = 0; q < S2_UPD_TPW; q++) {
-    if (tI[q] < 0) continue;
-    lds_double *C = tiles + (size_t)tile_idx(tI[q], tJ[q]) * (TB * TB);
+  for (int q = 0; q < S2_TPW; q++) {
+    if (tJ1[q] == 0) continue;
+    lds_double *C = tiles + (size_t)tile_idx(oI[q] / TB, oJ[q] / TB) * (TB * TB);
 #pragma unroll
     for (int r = 0; r < 4; r++) C[tsw(lk + 4 * r, lr)] -= acc[q][r];
   }
-}
-
-// Dense tiles of the chain solve: entry (r, cc) of tile te of the augmented, scaled, regularised, Schur-reduced dense part
-// (the k_solve tile layout with perm = the dense dims only). tb / nth: index and number of the building threads.
-// Returns the thread's share of v^T S v over these entries.
-__device__ __forceinline__ double chain_build_dense(double *tiles, const short *perm, const double *ys, const double *H, const double *E,
-                                                    const double *eg, const double *gsp, const double *gDp, const double *ggts, double mu,
-                                                    int n, int ntile_all, int tb, int nth) {
-  double vsv = 0.0;
-  constexpr int U = 4;
-  for (int i0 = tb; i0 < ntile_all * (TB * TB); i0 += U * nth) {
-    double hv[U], ev[U];
-    int aa[U], bb[U], kind[U];
-    bool offd[U];
+  // |z_chain|^2: the four lanes (lk = 0..3) of the right-hand side column
+  zzc += __shfl_xor(zzc, 16, 64);
+  zzc += __shfl_xor(zzc, 32, 64);
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int idx = i0 + u * nth;
-      kind[u] = -1; aa[u] = 0; bb[u] = 0; hv[u] = 0.0; ev[u] = 0.0; offd[u] = false;
-      if (idx >= ntile_all * (TB * TB)) continue;
-      const int te = idx >> 8, r = (idx >> 4) & 15, cc = idx & 15;
-      int I, J;
-      tri_decode(te, I, J);
-      const int ia = I * TB + r, ib = J * TB + cc;
-      offd[u] = I != J;
-      kind[u] = 0;
-      if (ia < n && ib < n) {
-        const int a = perm[ia], b = perm[ib];
-        aa[u] = a; bb[u] = b; kind[u] = 1;
-        hv[u] = H[(size_t)max(a, b) * ND + min(a, b)];
-        if (a < NV && b < NV) ev[u] = E[max(a, b) * NV + min(a, b)];
-      } else if (ia == n && ib < n) { bb[u] = perm[ib]; kind[u] = 2; }
-      else if (ib == n && ia < n) { bb[u] = perm[ia]; kind[u] = 2; }
-      else kind[u] = (ia == ib) ? (ia == n ? 4 : 3) : 5;
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (kind[u] < 0) continue;
-      const int idx = i0 + u * nth;
-      const int te = idx >> 8, r = (idx >> 4) & 15, cc = idx & 15;
-      double v;
-      if (kind[u] == 1) {
-        v = hv[u];
-        if (aa[u] < NV && bb[u] < NV) v -= ev[u];
-        v *= ys[aa[u]] * ys[bb[u]];
-        if (aa[u] == bb[u]) { const double dp = gDp[aa[u]]; v += mu * dp * dp; }
-        vsv = __builtin_fma(v * ys[ND + aa[u]], ys[ND + bb[u]] * (offd[u] ? 2.0 : 1.0), vsv);
-      } else if (kind[u] == 2) v = ggts[bb[u]] - (bb[u] < NV ? gsp[bb[u]] * eg[bb[u]] : 0.0);
-      else v = kind[u] == 4 ? 1e200 : (kind[u] == 3 ? 1.0 : 0.0);
-      tiles[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
-    }
-  }
+  for (int u = 0; u < 2; u++) if (mrhs[u] != 0.0 && lk == 0) *zzc_out = zzc;
   return vsv;
 }
 
-__global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int retry_pass) {
+__global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int retry_pass) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
@@ -828,24 +888,29 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
   if (retry_pass && !c.lin_retry) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ short perm[ND + TB];
-  __shared__ double red[16], ys[2 * ND + TB];
-  __shared__ double s_zz, s_zzc, s_vSv, zlast[TB], xs[CH_ROWS], tch[CH_ROWS + 16];
+  __shared__ double red[16], ys[ND + TB];                        // ys: the solution of the dense part (tile order)
+  __shared__ double sS[ND], vS[ND], dS[ND], gS[ND], rS[ND], yT[ND];   // per tangent dim: Jacobi scale, Cauchy direction, D, scaled gradient, right-hand side, GN step
+  __shared__ double s_zz, s_zzc, s_vSv, zlast[TB], xs[CH_ROWS + 16], tch[CH_ROWS + 16], cterm[64];
+  __shared__ double s_keep[4];
   __shared__ int flag, s_nact, s_nch, s_lo[CH_NC + 1];
+  __shared__ unsigned long long s_mask0;
   __shared__ unsigned char chact[CH_ROWS + 1];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
   double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
-  double *gY = d.solveY + (size_t)w * CH_ROWS * CH_RW;
+  double *gYT = d.solveY + (size_t)w * GYT_COLS * GYT_LD;
   const bool first = (c.iter == 0);
   double *stamp = d.timing + (size_t)w * 32;
 #define STAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   STAMP(0);
-  // LDS carve-up: dense tiles | chain diagonal blocks (A_k -> W_k) | chain couplings (C_k -> Yc_k) | two-block ring of Yr
+  // LDS carve-up: dense tiles | chain diagonal blocks (A_k -> W_k) | chain couplings (C_k -> Yc_k -> G_k) | zero / dump slot | two-block ring of Yr
   double *tiles = smem;
   double *Ach = smem + (size_t)d.solve_ntile * (TB * TB);
   double *Cch = Ach + CH_NC * CH_BLK;
-  double *ring = Cch + CH_NC * CH_BLK;
+  double *zslot = Cch + CH_NC * CH_BLK;
+  double *ring = zslot + CH_ZERO;
+  if (t < CH_ZERO) zslot[t] = 0.0;
 
   // dense dims (active, not in the chain) by a wave-level prefix count (dims 0..191 live in waves 0..2); chain activity flags
   __shared__ int wcount[4];
@@ -855,35 +920,42 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
     const unsigned long long m = __ballot(on);
     const unsigned long long mc = __ballot(act_t && dim_in_chain(t));
     if (t < 192 && lane == 0) wcount[wave] = __popcll(m);
+    if (t == 0) { s_nch = 0; s_mask0 = m; }
     if (t < ND && dim_in_chain(t)) chact[t - T_SB(0)] = act_t ? 1 : 0;
-    if (t == 0) s_nch = 0;
     __syncthreads();
     if (t < 192) {
       int base = 0;
       for (int q = 0; q < wave; q++) base += wcount[q];
       if (on) perm[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
-      if (t == 0) s_nact = wcount[0] + wcount[1] + wcount[2];
       if (lane == 0 && mc) atomicAdd(&s_nch, __popcll(mc));
     }
-    __syncthreads();
-    for (int a = s_nact + t; a < ND + TB; a += blockDim.x) perm[a] = -1;
-    // lo_k: first dense column the wide row of block k can reach — the poses of frames >= k - 1 (perm is ascending)
-    if (t <= CH_NC) {
-      int lo = 0;
-      if (t >= 2 && t < CH_NC) { const int lim = 6 * (t - 1); for (int q = 0; q < s_nact && perm[q] < lim; q++) lo++; }
-      s_lo[t] = (t == CH_NC) ? 0 : lo;
+    const int nact = wcount[0] + wcount[1] + wcount[2];
+    if (t == 0) s_nact = nact;
+    for (int a = nact + t; a < ND + TB; a += blockDim.x) perm[a] = -1;
+    // lo_k: first dense column the wide row of block k can reach — the poses of frames >= k - 1 (pose dims are 0..65: wave 0's mask)
+    if (t <= CH_NC) s_lo[t] = (t >= 2 && t < CH_NC) ? __popcll(s_mask0 & ((1ull << (6 * (t - 1))) - 1ull)) : 0;
+  }
+  if (first && wave == 3) {   // total cost of the first linearisation point: the terms side by side, summed in lane order
+    double term = 0.0;
+    if (lane < ds.n_imu) term = d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 2];
+    else if (lane >= 16 && lane - 16 < ds.n_wheel) term = d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 2];
+    else if (lane == 32) term = d.prior_g[(size_t)w * (ND + 2) + ND];
+    else if (lane >= 33 && lane - 33 < d.world && lane < 44) term = d.xa[((size_t)w * d.world + lane - 33) * XCHG];
+    else if (lane >= 44 && lane - 44 < ds.n_plane) term = d.plane_part[((size_t)w * MAX_PLANE + lane - 44) * PLANE_PART + PLANE_PART - 2];
+    else if (lane == 58 && ds.use_anchor) term = d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
+    cterm[lane] = term;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      double cost = 0.0;
+      for (int q = 33; q < 44; q++) cost += cterm[q];      // visual cost (k_visblock; the ranks' shares)
+      for (int q = 0; q < 33; q++) cost += cterm[q];
+      for (int q = 44; q < 64; q++) cost += cterm[q];
+      c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
     }
   }
-  if (first && t == 0) {   // total cost of the first linearisation point (fixed order)
-    double cost = 0.0;
-    for (int r = 0; r < d.world; r++) cost += d.xa[((size_t)w * d.world + r) * XCHG];
-    for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
-    for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
-    cost += d.prior_g[(size_t)w * (ND + 2) + ND];
-    for (int q = 0; q < ds.n_plane; q++) cost += d.plane_part[((size_t)w * MAX_PLANE + q) * PLANE_PART + PLANE_PART - 2];
-    if (ds.use_anchor) cost += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
-    c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
-  }
+  const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
+  const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
   // Jacobi scaling (iteration 0 only), D = sqrt(clamp(diag)), scaled gradient, Cauchy direction
   double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
   for (int a = t; a < ND; a += blockDim.x) {
@@ -898,7 +970,8 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
     }
     if (first) gsp[a] = s;
     gDp[a] = dp; ggts[a] = gt; gvp[a] = v;
-    ys[a] = s; ys[ND + a] = v;            // staged for the builds (ys is free until the back-substitution)
+    sS[a] = s; vS[a] = v; dS[a] = dp; gS[a] = gt;      // staged in LDS: the builds and the dogleg sums never wait for HBM
+    rS[a] = gt - (a < NV ? s * eg[a] : 0.0);           // right-hand side of the reduced system
   }
   {
     const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
@@ -908,17 +981,15 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
   {
     const double pv[3] = {g2, gmax, xn2};
     block_reduce_multi<3>(pv, 0x2u, smem);
-    g2 = smem[48]; gmax = smem[49]; xn2 = smem[50];
+    if (t == 0) { s_keep[0] = smem[48]; s_keep[1] = smem[49]; s_keep[2] = smem[50]; }   // (needed at the very end: parked in LDS, not in registers)
   }
   __syncthreads();
   STAMP(1);
-  const int n = s_nact;                 // dense dims
+  const int n = __builtin_amdgcn_readfirstlane(s_nact);                 // dense dims (wave-uniform: kept in scalar registers)
   const int na = n + 1;                 // + the right-hand side row / column
   const int nt = (na + TB - 1) / TB;
   const int ntile_all = nt * (nt + 1) / 2;
-  const bool chain_on = s_nch > 0;
-  const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
-  const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
+  const bool chain_on = __builtin_amdgcn_readfirstlane(s_nch) > 0;
 
   double mu = c.mu;
   bool solved = false, e_valid = true;
@@ -929,52 +1000,114 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
         break;
       }
       rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
-      for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = gvp[a]; }   // (ys held the previous attempt's solution)
+      for (int a = t; a < ND; a += blockDim.x) rS[a] = gS[a] - (a < NV ? sS[a] * eg[a] : 0.0);   // (eg was rebuilt with E)
       __syncthreads();
     }
-    // ---- build: chain blocks (identity rows for inactive dims), dense tiles, the ring's padding rows
+    // ---- build: every global load of the thread's entries first (one round trip), then the arithmetic and the LDS stores.
+    //      Threads 0..255: entry (r, cc) = (t / 16, t % 16) of EVERY dense tile — the tangent dims of the thread's row r and column
+    //      cc of each tile row / column and their scale / direction entries are looked up once. Waves 4..5: the chain blocks.
     double vsv = 0.0;
-    if (chain_on) {
-      for (int e = t; e < 2 * CH_NC * CH_BLK; e += S2_THREADS) {
-        const bool isC = e >= CH_NC * CH_BLK;
-        const int ee = isC ? e - CH_NC * CH_BLK : e;
-        const int k = ee / CH_BLK, i = (ee % CH_BLK) / CH_NB, j = ee % CH_NB;
-        double v = 0.0;
-        if (!isC) {
-          const int a = T_SB(k) + i, b = T_SB(k) + j;
-          if (chact[a - T_SB(0)] && chact[b - T_SB(0)]) {
-            v = H[(size_t)max(a, b) * ND + min(a, b)] * ys[a] * ys[b];
-            if (i == j) { const double dp = gDp[a]; v += mu * dp * dp; }
-            vsv = __builtin_fma(v * ys[ND + a], ys[ND + b], vsv);
-          } else if (i == j) v = 1.0;
-          Ach[ee] = v;
-        } else {
-          if (k > 0) {
-            const int a = T_SB(k) + i, b = T_SB(k - 1) + j;      // a > b: lower triangle of H
-            if (chact[a - T_SB(0)] && chact[b - T_SB(0)]) {
-              v = H[(size_t)a * ND + b] * ys[a] * ys[b];
-              vsv = __builtin_fma(v * ys[ND + a], 2.0 * ys[ND + b], vsv);
+    {
+      int tt = t;
+      asm volatile("" : "+v"(tt));     // (opaque: the entry addresses are invariant in the mu-retry loop — hoisted out of it they are all spilled)
+      if (tt < TB * TB) {
+        const int r = tt >> 4, cc = tt & 15;
+        const int nm1 = max(n - 1, 0);
+        int ar[S2_MAX_NT], bc[S2_MAX_NT];
+        double sa[S2_MAX_NT], va[S2_MAX_NT], sb[S2_MAX_NT], vb[S2_MAX_NT], dd[S2_MAX_NT];
+#pragma unroll
+        for (int I = 0; I < S2_MAX_NT; I++) {
+          ar[I] = max((int)perm[min(I * TB + r, nm1)], 0); bc[I] = max((int)perm[min(I * TB + cc, nm1)], 0);
+          sa[I] = sS[ar[I]]; va[I] = vS[ar[I]]; sb[I] = sS[bc[I]]; vb[I] = vS[bc[I]]; dd[I] = dS[ar[I]];
+        }
+        // (loads unconditional, through clamped indices, selected afterwards: straight-line code, every load in flight at once)
+        double hv[S2_MAX_TILES], ev[S2_MAX_TILES];
+        {
+          int I = 0, J = 0;
+#pragma unroll
+          for (int te = 0; te < S2_MAX_TILES; te++) {
+            hv[te] = 0.0; ev[te] = 0.0;
+            if (te < ntile_all) {                                   // (wave-uniform)
+              const int hi = max(ar[I], bc[J]), lo = min(ar[I], bc[J]);
+              hv[te] = H[(size_t)hi * ND + lo];
+              ev[te] = E[min(hi, NV - 1) * NV + min(lo, NV - 1)];
             }
+            if (++J > I) { J = 0; I++; }
           }
-          Cch[ee] = v;
+        }
+#if GFBE_CHAIN_STAMP
+        if (t == 0) stamp[8] = (double)wall_clock64();
+#endif
+        {
+          int I = 0, J = 0;
+#pragma unroll
+          for (int te = 0; te < S2_MAX_TILES; te++) {
+            if (te < ntile_all) {
+              const int a = ar[I], b = bc[J];
+              double v = (hv[te] - ((a < NV && b < NV) ? ev[te] : 0.0)) * (sa[I] * sb[J]);
+              if (I == J && r == cc) v = __builtin_fma(mu * dd[I], dd[I], v);          // (a == b: the diagonal)
+              double q = v * va[I] * (vb[J] * (I != J ? 2.0 : 1.0));
+              if (I == nt - 1) {       // (wave-uniform: the last tile row holds the right-hand side row and the padding)
+                const int ia = I * TB + r, ib = J * TB + cc;
+                if (ia >= n || ib >= n) {
+                  q = 0.0;
+                  if (ia == n && ib < n) v = rS[b];
+                  else if (ib == n && ia < n) v = rS[a];
+                  else v = (ia == ib) ? (ia == n ? 1e200 : 1.0) : 0.0;
+                }
+              }
+              vsv += q;
+              tiles[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
+            }
+            if (++J > I) { J = 0; I++; }
+          }
         }
       }
-      for (int e = t; e < 2 * RING_ROWS * RING_LD; e += S2_THREADS) ring[e] = 0.0;
+      if (chain_on && tt < 3 * CH_BLK) {
+        // chain blocks: the 22 blocks A_0..A_10, C_1..C_10 (C_k = S(SB_k, SB_k-1); slot 0 of the couplings is unused) are dealt over
+        // three thread groups of 81 — a thread keeps its entry (i, j) and takes every third block (inactive dims: H holds exact
+        // zeros there, the diagonal becomes 1)
+        const int grp = tt / CH_BLK, e81 = tt - CH_BLK * grp, ei = e81 / CH_NB, ej = e81 - CH_NB * ei;
+        constexpr int NQ = (2 * CH_NC + 2) / 3;
+        double hc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int kb = grp + 3 * q;                     // block slot: 0..10 diagonal blocks, 11..21 couplings
+          const bool isC = kb >= CH_NC;
+          const int k = isC ? kb - CH_NC : kb;
+          const int a = T_SB(min(k, CH_NC - 1)) + ei, b = (isC ? T_SB(k > 0 ? min(k, CH_NC - 1) - 1 : 0) : T_SB(min(k, CH_NC - 1))) + ej;
+          hc[q] = H[(size_t)max(a, b) * ND + min(a, b)];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int kb = grp + 3 * q;
+          if (kb >= 2 * CH_NC) continue;
+          const bool isC = kb >= CH_NC;
+          const int k = isC ? kb - CH_NC : kb;
+          const int a = T_SB(k) + ei, b = (isC ? T_SB(k > 0 ? k - 1 : 0) : T_SB(k)) + ej;
+          double v = hc[q] * sS[a] * sS[b];
+          if (isC) { if (k == 0) v = 0.0; }
+          else if (ei == ej) v = chact[a - T_SB(0)] ? __builtin_fma(mu * dS[a], dS[a], v) : 1.0;
+          vsv = __builtin_fma(v * vS[a], vS[b] * (isC ? 2.0 : 1.0), vsv);
+          (isC ? Cch : Ach)[k * CH_BLK + e81] = v;
+        }
+      }
     }
-    vsv += chain_build_dense(tiles, perm, ys, H, E, eg, gsp, gDp, ggts, mu, n, ntile_all, t, S2_THREADS);
     if (t == 0) { flag = 0; s_zzc = 0.0; }
+#if GFBE_CHAIN_STAMP
+    if (t == 0) stamp[11] = (double)wall_clock64();
+#endif
     __syncthreads();
     STAMP(2);
     if (chain_on) {
-      // ---- the three-stage pipeline over the chain blocks, one block barrier per block (the roles are separate functions with
-      //      their own register allocation; every role passes the same CH_NC + 2 barriers):
-      //   step s: wave 0 factorises block NC-1-s | waves 1..2 form Yr of block NC-s | waves 3..7 add Yr^T Yr of block NC+1-s
-      if (wave == 0) chain_role((lds_double *)Ach, (lds_double *)Cch, (lds_int *)&flag, lane);
-      else if (wave <= S2_COL_WAVES)
-        vsv += column_role((const lds_double *)Ach, (const lds_double *)Cch, (lds_double *)ring, (const lds_double *)ys, (const lds_short *)perm,
-                           (const lds_int *)s_lo, (const lds_uchar *)chact, (lds_double *)&s_zzc, (const glb_double *)H, (const glb_double *)ggts,
-                           (glb_double *)gY, n, t - 64);
-      else gemm_role((lds_double *)tiles, (const lds_double *)ring, (const lds_int *)s_lo, ntile_all, wave - 1 - S2_COL_WAVES, lane);
+      // ---- the pipeline over the chain blocks, one block barrier per block (the roles are separate functions with their own
+      //      register allocation; every role passes the same CH_NC + 2 barriers):
+      //   step s: wave 0 factorises block NC-1-s | waves 1..3 form Yr of block NC-s and add Yr^T Yr of block NC+1-s
+      if (wave == 0) chain_role((lds_double *)Ach, (lds_double *)Cch, (lds_int *)&flag, lane, stamp);
+      else
+        vsv += wide_role((lds_double *)tiles, (lds_double *)Ach, (lds_double *)Cch, (lds_double *)ring, (lds_double *)zslot, (const lds_double *)sS,
+                         (const lds_double *)vS, (const lds_double *)rS, (const lds_short *)perm, (const lds_int *)s_lo, (lds_double *)&s_zzc,
+                         (const glb_double *)H, (glb_double *)gYT, n, nt, chain_ring_ld(d.solve_ntile), wave - 1, lane, stamp);
     }
     vsv = block_sum(vsv, red);
     if (t == 0) s_vSv = vsv;
@@ -1028,55 +1161,68 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
         }
       }
       __syncthreads();
-      // ---- the chain's back-substitution: tch = z_k - Yr_k x_dense for all 99 rows (every wave a share of the rows, the Yr
-      //      rows read back from HBM / L2), then x_k = W_k^T (tch_k - Yc_k x_k-1) block by block on one wave
+      STAMP(16);
+      // ---- the chain's back-substitution: t_r = z_r - (Yr x_dense)_r for the 99 chain rows (lane = row, the transposed Yr rows
+      //      read back coalesced from HBM / L2, all loads in flight), a_k = W_k^T t_k, then x_k = a_k - G_k x_k-1 on one wave
       if (chain_on) {
-        constexpr int RPW = (CH_ROWS + S2_WAVES - 1) / S2_WAVES;   // rows per wave
-        double part[RPW];
-        const double x0 = lane < n ? ys[lane] : 0.0, x1 = lane + 64 < n ? ys[lane + 64] : 0.0;
+        if (t < 128) {
+          const int r = t < CH_ROWS ? t : CH_ROWS - 1;
+          const double *col = gYT + r;
+          double s0 = 0.0, s1 = 0.0;
+          int j = 0;
+          for (; j + 8 <= n; j += 8) {
+            double v[8];
 #pragma unroll
-        for (int q = 0; q < RPW; q++) {
-          const int r = wave * RPW + q;
-          part[q] = 0.0;
-          if (r < CH_ROWS) {
-            const double *yr = gY + (size_t)r * CH_RW;
-            const double a0 = lane < n ? yr[lane] : 0.0, a1 = lane + 64 < n ? yr[lane + 64] : 0.0;
-            part[q] = __builtin_fma(a0, x0, a1 * x1);
+            for (int q = 0; q < 8; q++) v[q] = col[(size_t)(j + q) * GYT_LD];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) { s0 = __builtin_fma(v[q], ys[j + q], s0); s1 = __builtin_fma(v[q + 1], ys[j + q + 1], s1); }
           }
+          for (; j < n; j++) s0 = __builtin_fma(col[(size_t)j * GYT_LD], ys[j], s0);
+          if (t < CH_ROWS) tch[t] = col[(size_t)n * GYT_LD] - (s0 + s1);
         }
+        __syncthreads();
+        if (t < CH_ROWS) {
+          const int k = t / CH_NB, i = t % CH_NB;
+          double a = 0.0;
 #pragma unroll
-        for (int q = 0; q < RPW; q++) {
-          const int r = wave * RPW + q;
-          const double sacc = wave_sum(part[q]);
-          if (lane == 0 && r < CH_ROWS) tch[r] = gY[(size_t)r * CH_RW + n] - sacc;
+          for (int m = 0; m < CH_NB; m++) a = __builtin_fma(Ach[k * CH_BLK + m * CH_NB + i], tch[k * CH_NB + m], a);
+          xs[t] = a;
         }
         __syncthreads();
         if (wave == 0) {
-          const int i = lane < CH_NB ? lane : 0;
-          for (int k = 0; k < CH_NC; k++) {
-            double uu = tch[k * CH_NB + i];
-            if (k > 0) {
-              const double *Yc = Cch + k * CH_BLK;
+          const int li = lane & 15;
+          const int lio = li < CH_NB ? li : 0;
+          double x = xs[lio];
+          double gn[CH_NB], gc[CH_NB];
 #pragma unroll
-              for (int m = 0; m < CH_NB; m++) uu = __builtin_fma(-Yc[i * CH_NB + m], xs[(k - 1) * CH_NB + m], uu);
+          for (int m = 0; m < CH_NB; m++) gn[m] = -Cch[1 * CH_BLK + lio * CH_NB + m];
+          for (int k = 1; k < CH_NC; k++) {
+            double acc = xs[k * CH_NB + lio];
+#pragma unroll
+            for (int m = 0; m < CH_NB; m++) gc[m] = gn[m];
+            if (k + 1 < CH_NC) {
+#pragma unroll
+              for (int m = 0; m < CH_NB; m++) gn[m] = -Cch[(k + 1) * CH_BLK + lio * CH_NB + m];
             }
-            const double *Wk = Ach + k * CH_BLK;
-            double xv = 0.0;
 #pragma unroll
-            for (int m = 0; m < CH_NB; m++) xv = __builtin_fma(Wk[m * CH_NB + i], __shfl(uu, m, 64), xv);   // (W_k is lower triangular: the entries above the diagonal are stored zeros)
-            if (lane < CH_NB) xs[k * CH_NB + lane] = xv;
-            __threadfence_block();
-            __builtin_amdgcn_wave_barrier();
+            for (int m = 0; m < CH_NB; m++) asm volatile("" : "+v"(gc[m]));
+            asm volatile("" : "+v"(x), "+v"(acc));
+            asm volatile("s_nop 4" ::: "memory");
+            dpp_fmac2<0>(acc, x, gc[0]); dpp_fmac2<1>(acc, x, gc[1]); dpp_fmac2<2>(acc, x, gc[2]);
+            dpp_fmac2<3>(acc, x, gc[3]); dpp_fmac2<4>(acc, x, gc[4]); dpp_fmac2<5>(acc, x, gc[5]);
+            dpp_fmac2<6>(acc, x, gc[6]); dpp_fmac2<7>(acc, x, gc[7]); dpp_fmac2<8>(acc, x, gc[8]);
+            x = acc;
+            if (lane < CH_NB) xs[k * CH_NB + lane] = x;
           }
         }
         __syncthreads();
       }
       // y back to the tangent dims: inactive dims get 0, every dim written once
       int bad = 0;
-      for (int i = t; i < n; i += blockDim.x) { const double y = ys[i]; gyp[perm[i]] = y; if (!isfinite(y)) bad = 1; }
+      for (int i = t; i < n; i += blockDim.x) { const double y = ys[i]; const int a = perm[i]; gyp[a] = y; yT[a] = y; if (!isfinite(y)) bad = 1; }
       for (int a = t; a < ND; a += blockDim.x) {
-        if (dim_in_chain(a)) { const double y = chain_on ? xs[a - T_SB(0)] : 0.0; gyp[a] = y; if (!isfinite(y)) bad = 1; }
-        else if (!ds.act[a]) gyp[a] = 0.0;
+        if (dim_in_chain(a)) { const double y = chain_on ? xs[a - T_SB(0)] : 0.0; gyp[a] = y; yT[a] = y; if (!isfinite(y)) bad = 1; }
+        else if (!ds.act[a]) { gyp[a] = 0.0; yT[a] = 0.0; }
       }
       if (bad) flag = 1;
       __syncthreads();
@@ -1092,24 +1238,29 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
     return;
   }
   STAMP(4);
-  // dense shares of the dogleg scalars (see k_solve)
+  // dense shares of the dogleg scalars (see k_solve), from the LDS copies of the vectors; E: three threads per row, the row's 25
+  // entries of a thread in flight at once
   double n2 = 0.0, gyv = 0.0, vrhs = 0.0, vDv = 0.0, vDy = 0.0, vEv = 0.0, vEy = 0.0, yEy = 0.0;
-  for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }
+  for (int a = t; a < NV; a += blockDim.x) { ys[a] = sS[a] * vS[a]; ys[NVP + a] = sS[a] * yT[a]; }   // s v, s y of the visual dims
   __syncthreads();
   for (int a = t; a < ND; a += blockDim.x) {
-    const double d2 = gDp[a] * gDp[a], y = gyp[a], v = gvp[a];
+    const double d2 = dS[a] * dS[a], y = yT[a], v = vS[a];
     n2 += d2 * y * y;
-    gyv += ggts[a] * y;
+    gyv += gS[a] * y;
     vDv += d2 * v * v;
     vDy += d2 * v * y;
-    vrhs += v * (ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0));
+    vrhs += v * rS[a];
   }
-  for (int e = t; e < NV * NV; e += blockDim.x) {
-    const int a = e / NV, b = e - a * NV;
-    const double ev = E[e];
-    vEv = __builtin_fma(ev * ys[a], ys[b], vEv);
-    vEy = __builtin_fma(ev * ys[a], ys[ND + b], vEy);
-    yEy = __builtin_fma(ev * ys[ND + a], ys[ND + b], yEy);
+  if (t < 3 * NV) {
+    const int a = t / 3, b0 = t - 3 * a;
+    constexpr int NE = (NV + 2) / 3;
+    double ev[NE];
+#pragma unroll
+    for (int q = 0; q < NE; q++) { const int b = b0 + 3 * q; ev[q] = b < NV ? E[a * NV + b] : 0.0; }   // (rows / columns of inactive dims are zero in E)
+    double Ev = 0.0, Ey = 0.0;
+#pragma unroll
+    for (int q = 0; q < NE; q++) { const int b = min(b0 + 3 * q, NV - 1); Ev = __builtin_fma(ev[q], ys[b], Ev); Ey = __builtin_fma(ev[q], ys[NVP + b], Ey); }
+    vEv = ys[a] * Ev; vEy = ys[a] * Ey; yEy = ys[NVP + a] * Ey;
   }
   {
     const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
@@ -1119,12 +1270,12 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
   if (t == 0) {
     const double zz = s_zz, vSv = s_vSv;
     c.mu = mu;
-    c.G2 = g2; c.N2 = n2; c.gy = gyv;
+    c.G2 = s_keep[0]; c.N2 = n2; c.gy = gyv;
     c.vHv = vSv - mu * vDv + vEv;
     c.vHy = vrhs - mu * vDy + vEy;
     c.yHy = zz - mu * n2 + yEy;
-    c.grad_max = gmax;
-    c.x_norm = xn2;
+    c.grad_max = s_keep[1];
+    c.x_norm = s_keep[2];
     c.have_step = 2;
     c.lin_retry = 0;
   }
@@ -1132,8 +1283,10 @@ __global__ __launch_bounds__(S2_THREADS, 4) void k_solve_chain(BatchDev d, int r
 #undef STAMP
 }
 
+
 static size_t solve_smem_bytes() { const int nt = (ND + 1 + TB - 1) / TB; return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
-static size_t chain_smem_bytes(int ntile) { return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + 2 * RING_ROWS * RING_LD); }
+static size_t chain_smem_bytes(int ntile) { return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + 2 * RING_ROWS * chain_ring_ld(ntile)); }
+size_t solve_chain_scratch_doubles() { return (size_t)GYT_COLS * GYT_LD; }
 // dense tiles a window with these active dims needs in k_solve_chain (host side of the kernel's own count)
 int solve_chain_tiles(const unsigned char *act) {
   int n = 0;

@@ -77,5 +77,11 @@ for kern in (1, 0):
             print("   %-10s %7.2f us" % ("backsub", (t[4] - t[3]) * 0.01))
             print("   %-10s %7.2f us" % ("gram", (t[5] - t[4]) * 0.01))
             print("   total %.2f us" % ((t[5] - t[0]) * 0.01))
+            if os.environ.get("GFBE_LIB", "").endswith("chainstamp.so"):
+                print("   build: loads issued %.2f | +chain loads %.2f | tile stores %.2f | chain stores %.2f | barrier %.2f" % tuple((t[i] - t[j]) * 0.01 for i, j in ((8, 1), (9, 8), (10, 9), (11, 10), (2, 11))))
+                u = b.debug_timing(1)
+                print("   chain wave: step starts (us from pipeline start):", " ".join("%.2f" % ((u[s] - t[2]) * 0.01) for s in range(0, 14)))
+                print("   chain wave: work done at                        :", " ".join("%.2f" % ((u[14 + s] - t[2]) * 0.01) for s in range(0, 6)))
+                print("   wide wave 2: work done at                       :", " ".join("%.2f" % ((u[20 + s] - t[2]) * 0.01) for s in range(0, 12)))
         b.free()
     be.close()

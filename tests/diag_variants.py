@@ -13,6 +13,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "stamp": (["-DGFBE_KVIS_STAMP=1"], "off"),
     "noesym": (["-DGFBE_SOLVE_ESYM=0"], "off"),
     "cholstamp": (["-DGFBE_CHOL_STAMP=1"], "off"),
+    "chainstamp": (["-DGFBE_CHAIN_STAMP=1"], "off"),
     "s512": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2"], "off"),
     "s512u10": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DBUILD_UNROLL=10"], "off"),
     "s512u13": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DBUILD_UNROLL=13"], "off"),
