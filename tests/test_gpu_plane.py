@@ -26,6 +26,21 @@ def check_prior(pw, pg, loose=1.0):
     assert np.abs(bg - bw).max() < loose * 1e-6 * max(np.abs(bw).max(), 1.0)
 
 
+def test_plane_window_both_factorisations_hold_the_plain_tolerances(oracle):
+    """The plane + anchor window settles (function tolerance at iteration 6): the plain tolerances of check_solve hold for the
+    chain-eliminated and for the monolithic factorisation of gfbe_options.solve_kernel. (The window with the plane blocks
+    constant creeps — the cost still falls by 4 % between iterations 8 and 15 — and is compared on a stated multiple below.)"""
+    for kernel in (0, 1):
+        o = abi.default_options()
+        o.solve_kernel = kernel
+        bes = gf.Backend(device=0, options=o)
+        _, snap = plane_window(anchor=True)
+        want, got = check_solve(bes, oracle, snap, abi.MARGIN_OLD)
+        assert want["summary"]["termination"] == 1          # (function tolerance, not the iteration cap)
+        check_prior(want["prior"], got["prior"])
+        bes.close()
+
+
 @pytest.mark.parametrize("anchor", [True, False])
 def test_plane_in_solve_and_marginalisation(be, oracle, anchor):
     scn, snap = plane_window(anchor=anchor)
@@ -46,7 +61,9 @@ def test_plane_constant_and_mixed_batch(be, oracle):
     """SetParameterBlockConstant(para_plane_R / para_plane_Z) (estimator.cpp:3126-3135), and a batch that mixes windows with and
     without the optional factors (bit-identical to their single solves)."""
     scn, snap_c = plane_window(anchor=False, const=1)
-    want, got = check_solve(be, oracle, snap_c, abi.MARGIN_OLD)
+    # (an unsettled run: it stops on the iteration cap while the cost still moves — the two orders of elimination of
+    #  gfbe_options.solve_kernel end 1.4e-9 apart in the final cost; the settled variant below holds the plain tolerances)
+    want, got = check_solve(be, oracle, snap_c, abi.MARGIN_OLD, loose=5.0)
     assert np.array_equal(got["state"]["plane_R"], snap_c["plane_R"]) and got["state"]["plane_Z"] == snap_c["plane_Z"]
     check_prior(want["prior"], got["prior"])
     _, snap_p = plane_window(seed=72)
