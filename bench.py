@@ -158,6 +158,10 @@ def main():
     solves, elapsed = gf.dist.aggregate_throughput(args.batch * args.steps, elapsed, dist if world > 1 else None)
     if shard:
         solves //= world          # every rank worked on the same windows
+        hook = getattr(be, "_rccl_hook", None)
+        if hook is not None:      # the number below is only reported if every all-reduce of the timed steps was enqueued and succeeded
+            assert hook.last_error() == 0, "RCCL all-reduce failed: %d" % hook.last_error()
+            assert hook.calls() > 0, "the native all-reduce hook was never called"
     value = solves / elapsed
 
     # ---- correctness of what was timed (cheap): every window converged to the same cost as window 0 of its kind

@@ -148,6 +148,10 @@ class Backend(abi.CApi):
         if self.ctx:
             self.lib.gfbe_destroy(self.ctx)
             self.ctx = C.c_void_p()
+        hook = getattr(self, "_rccl_hook", None)      # (the native all-reduce hook's communicator lives as long as the context)
+        if hook is not None:
+            hook.close()
+            self._rccl_hook = None
 
     def __del__(self):
         try:
@@ -224,14 +228,23 @@ class Backend(abi.CApi):
     # ---- multi-GPU landmark sharding: the native hook (libgfbe_rccl.so: ncclAllReduce on the solver's stream)
     def set_allreduce_native(self, fn_ptr, user_ptr, rank, world_size):
         """fn_ptr: address of a gfbe_allreduce_fn (e.g. gfbe_rccl_allreduce), user_ptr: its handle."""
-        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+        CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
         self._cb = C.cast(fn_ptr, CB)
         self.check(self.lib.gfbe_set_allreduce(self.ctx, self._cb, C.c_void_p(user_ptr), int(rank), int(world_size)), "set_allreduce")
 
     # ---- the same through a Python callable (torch.distributed in the caller; the tests' gloo flavour)
     def set_allreduce(self, fn, rank, world_size):
-        CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
-        self._cb = CB(lambda user, ptr, n, stream: fn(ptr, n, stream)) if fn is not None else C.cast(None, CB)
+        CB = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+        def call(user, ptr, n, stream):      # (0, or 1 when the Python hook raised: the solve then returns GFBE_DEVICE_ERROR)
+            try:
+                fn(ptr, n, stream)
+                return 0
+            except Exception:                # noqa: BLE001 — an exception must not unwind through the C library
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = CB(call) if fn is not None else C.cast(None, CB)
         self.check(self.lib.gfbe_set_allreduce(self.ctx, self._cb, None, int(rank), int(world_size)), "set_allreduce")
 
 

@@ -189,6 +189,7 @@ struct BatchDev {
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
+  int sharded;                      // an all-reduce hook is installed (gfbe_set_allreduce): the launch sequence with the exchange blocks, also for world == 1
   int test_fail_chol_iter;          // gfbe_options.test_fail_chol_iter (test hook): the first factorisation of that iteration "fails"
   int vis_full;                     // some window of the batch has a free camera extrinsic or td: the visual kernels form those Jacobian blocks
   double *xa, *xb, *xc;       // [B][world][XCHG] scalar exchange rows (own row written, the others zeroed, then sum all-reduce):

@@ -105,6 +105,7 @@ struct gfbe_ctx {
   std::vector<hipEvent_t> event_pool;
   gfbe_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
+  int allreduce_rc = 0;                               // first non-zero return of the hook during the current gfbe_batch_solve
   int rank = 0, world = 1;
   // Device memory of freed batches, kept for the next upload: one window per camera frame is the reference's call
   // pattern, and ~70 hipMalloc / hipFree pairs per call cost more than its solve (3.6 ms of 4.1 ms measured).
@@ -594,6 +595,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       c->err = "window " + std::to_string(w) + ": bad sizes"; return GFBE_BAD_INPUT;
     }
   }
+  if (c->allreduce && c->opt.max_solver_time_in_seconds > 0.0) {
+    // (every rank would stop on its own clock: the replicated dense state would diverge between the ranks)
+    c->err = "max_solver_time_in_seconds is not available with landmark sharding (gfbe_set_allreduce)"; return GFBE_BAD_INPUT;
+  }
   gfbe_batch *b = new gfbe_batch();
   *out = b;
   BatchDev &d = b->d;
@@ -694,7 +699,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     algo_bytes += 108.0 * sc.K;   // 12 f64 + 3 i32 per visual residual block, J never re-read by the host
   }
   d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio;
-  d.rank = c->rank; d.world = c->world;
+  d.rank = c->rank; d.world = c->world; d.sharded = c->allreduce ? 1 : 0;
   d.test_fail_chol_iter = c->opt.test_fail_chol_iter;   // (test hook of the mu-retry path, 0 in production: gfbe_options)
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
@@ -735,7 +740,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(prior_J0, (size_t)B * ND * ND);
     AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
     AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
-    if (B < DENSE_SPLIT_MIN_B && c->world == 1) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
+    if (B < DENSE_SPLIT_MIN_B && !c->allreduce) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
     AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
     AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
@@ -757,7 +762,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       b->slab_n = nH + ng + nE + ne + nx;
     }
     AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
-    if (d.world > 1) { AL(Er, (size_t)B * (NV * NV + NV)); } else d.Er = nullptr;
+    if (d.sharded) { AL(Er, (size_t)B * (NV * NV + NV)); } else d.Er = nullptr;
     AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
     AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
     AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
@@ -974,7 +979,7 @@ static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *cons
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   *out = nullptr;
   int parts = 1;
-  if (B >= BATCH_SPLIT_MIN_B && c->world == 1 && c->opt.split_batch) parts = std::min(std::max(c->opt.split_batch, 2), std::max(B / DENSE_SPLIT_MIN_B, 1));
+  if (B >= BATCH_SPLIT_MIN_B && !c->allreduce && c->opt.split_batch) parts = std::min(std::max(c->opt.split_batch, 2), std::max(B / DENSE_SPLIT_MIN_B, 1));
   gfbe_batch **link = out;
   gfbe_batch *prev = nullptr;
   int done = 0;
@@ -1010,7 +1015,7 @@ extern "C" gfbe_status gfbe_batch_upload(gfbe_ctx *c, int32_t B, const gfbe_wind
 // Same as gfbe_batch_upload, with the visual factors of window w taken from table w of `t` on the device.
 extern "C" gfbe_status gfbe_batch_upload_tables(gfbe_ctx *c, gfbe_ftab *t, int32_t B, const gfbe_window *const *wins, gfbe_batch **out) {
   if (!c || !t || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
-  if (c->world > 1) { c->err = "gfbe_batch_upload_tables: not available with landmark sharding"; return GFBE_BAD_INPUT; }
+  if (c->allreduce) { c->err = "gfbe_batch_upload_tables: not available with landmark sharding"; return GFBE_BAD_INPUT; }
   return upload_guarded(c, B, wins, out, t);
 }
 
@@ -1046,6 +1051,12 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
   delete b;
 }
 
+// The all-reduce hook of the landmark-sharded solve; the first failure is kept for gfbe_batch_solve's status.
+static void run_allreduce(gfbe_ctx *c, double *ptr, int64_t n, hipStream_t s) {
+  const int32_t rc = c->allreduce(c->allreduce_user, ptr, n, s);
+  if (rc != 0 && c->allreduce_rc == 0) c->allreduce_rc = rc;
+}
+
 // One linearisation of the whole batch at the current parameters (skipped on device for windows
 // that only need a new radius).
 static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool first) {
@@ -1070,21 +1081,21 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   { Timed t(c, "k_visblock", 0); launch_visblock(d, ln.s); }
   if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);   // join
   { Timed t(c, "k_assemble", 0); launch_assemble(d, ln.s); }
-  if (d.world > 1) { Timed t(c, "allreduce_system", 0); c->allreduce(c->allreduce_user, d.H, (int64_t)b->slab_n, ln.s); }
+  if (d.sharded) { Timed t(c, "allreduce_system", 0); run_allreduce(c, d.H, (int64_t)b->slab_n, ln.s); }
   { Timed t(c, "k_solve", 0); launch_solve(d, ln.s); }
-  if (d.world > 1) {
+  if (d.sharded) {
     // the mu retry of DoglegStrategy when the landmarks are sharded: a window whose factorisation failed gets E rebuilt for the
     // larger mu from every rank's own tiles, one more all-reduce (E | eg only), and a second factorisation
     Timed t(c, "mu_retry_sharded", 0);
     launch_rebuild_E_shard(d, ln.s);
-    c->allreduce(c->allreduce_user, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);
+    run_allreduce(c, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);
     launch_solve(d, ln.s, 1);
   }
   { Timed t(c, "k_lm_step", 0); launch_lm_step(d, ln.s); }
-  if (d.world > 1) {
+  if (d.sharded) {
     Timed t(c, "allreduce_scalars", 0);
     launch_xchg_gram(d, ln.s);
-    c->allreduce(c->allreduce_user, d.xb, (int64_t)d.B * d.world * XCHG, ln.s);
+    run_allreduce(c, d.xb, (int64_t)d.B * d.world * XCHG, ln.s);
   }
 }
 
@@ -1109,29 +1120,29 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
     if (!small && !overlap) { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, ln.s); }
     else if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);
-    if (d.world > 1) {
+    if (d.sharded) {
       Timed t(c, "allreduce_scalars", 0);
       launch_xchg_cand(d, ln.s);
-      c->allreduce(c->allreduce_user, d.xc, (int64_t)d.B * d.world * XCHG, ln.s);
+      run_allreduce(c, d.xc, (int64_t)d.B * d.world * XCHG, ln.s);
     }
     { Timed t(c, "k_accept", 0); launch_accept(d, ln.s); }
   }
   { Timed t(c, "k_reanchor", 0); launch_reanchor(d, ln.s); }
   if (margin_flag != GFBE_MARGIN_NONE) {
     Timed t(c, "marginalize", 0);
-    if (d.world > 1 && margin_flag == GFBE_MARGIN_OLD) {
+    if (d.sharded && margin_flag == GFBE_MARGIN_OLD) {
       // the partials of the landmarks that start in frame 0 are summed over the ranks before k_marg reads them
       launch_marginalize_partials(d, ln.s);
-      c->allreduce(c->allreduce_user, d.pair_part, (int64_t)d.B * NPAIR * VP_STRIDE, ln.s);
-      c->allreduce(c->allreduce_user, d.schur_part, (int64_t)d.B * NF * SCHUR_STRIDE, ln.s);
+      run_allreduce(c, d.pair_part, (int64_t)d.B * NPAIR * VP_STRIDE, ln.s);
+      run_allreduce(c, d.schur_part, (int64_t)d.B * NF * SCHUR_STRIDE, ln.s);
       launch_marginalize_finish(d, margin_flag, ln.s);
     } else {
       launch_marginalize(d, margin_flag, ln.s);
     }
   }
-  if (d.world > 1) {   // every rank ends with all inverse depths: owners contribute theirs, the others zeros
+  if (d.sharded) {   // every rank ends with all inverse depths: owners contribute theirs, the others zeros
     launch_lam_mask(d, ln.s);
-    c->allreduce(c->allreduce_user, d.lam, (int64_t)2 * d.tot_lm, ln.s);
+    run_allreduce(c, d.lam, (int64_t)2 * d.tot_lm, ln.s);
   }
   return GFBE_OK;
 }
@@ -1141,10 +1152,10 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
   if (c->device < 0) return GFBE_NO_DEVICE;
   if (margin_flag < 0 || margin_flag > 2) return GFBE_BAD_INPUT;
   const BatchDev &d = b->d;
-  if (d.world > 1 && !c->allreduce) { c->err = "batch was uploaded for landmark sharding but the all-reduce hook is gone"; return GFBE_BAD_INPUT; }
+  if (d.sharded && !c->allreduce) { c->err = "batch was uploaded for landmark sharding but the all-reduce hook is gone"; return GFBE_BAD_INPUT; }
   // hipGraph replay: not while profiling (per-kernel events) and not with the all-reduce hook (host callback)
   // (not for split batches: capturing the cross-stream fork / join of the parts crashed the runtime on ROCm 7.2)
-  const bool graphable = c->opt.use_graph && !c->profiling && d.world == 1 && !b->second;
+  const bool graphable = c->opt.use_graph && !c->profiling && !d.sharded && !b->second;
   const Lane lane1 = {c->stream, c->aux, c->ev_fork, c->ev_join};
   // the uploads ran on the copy stream: the solve starts when they have landed
   for (gfbe_batch *p = b; p; p = p->second) { HIPCHK(c, hipStreamWaitEvent(c->stream, p->ev_up, 0)); p->last_flag = margin_flag; p->fetched = false; }
@@ -1187,9 +1198,15 @@ extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t marg
     }
     c->opt.use_graph = 0;   // capture not available on this stream: stay eager
   }
+  c->allreduce_rc = 0;
   const gfbe_status st = enqueue_all();
   if (st != GFBE_OK) return st;
   HIPCHK(c, hipGetLastError());
+  if (c->allreduce_rc != 0) {   // (the partial sums of this solve were not all reduced: no result is handed back)
+    c->err = "all-reduce hook failed with code " + std::to_string(c->allreduce_rc) + " during gfbe_batch_solve";
+    (void)mark_done();
+    return GFBE_DEVICE_ERROR;
+  }
   return mark_done();
 }
 

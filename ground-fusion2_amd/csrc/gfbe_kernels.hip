@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(64) void k_step(BatchDev d) {
   if (c.done) return;
   if (c.have_step == 2) {   // fresh linearisation: fold in the landmark shares (lanes stride the tiles; fixed tree order)
     double p[8];
-    if (d.world == 1) tile_gram_sum(d, ds, w, lane, p);
+    if (!d.sharded) tile_gram_sum(d, ds, w, lane, p);
     else {   // landmark sharding: the ranks' shares (k_xchg_gram + all-reduce), combined in rank order
 #pragma unroll
       for (int k = 0; k < 8; k++) p[k] = 0.0;
@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(64) void k_accept(BatchDev d) {
   WinCtl &c = d.ctl[w];
   if (c.done || !c.have_step) return;
   double cand = 0.0, d2 = 0.0, n2 = 0.0;
-  if (d.world == 1) tile_cand_sum(d, ds, w, lane, cand, d2, n2);
+  if (!d.sharded) tile_cand_sum(d, ds, w, lane, cand, d2, n2);
   else if (lane < d.world) {   // landmark sharding: the ranks' sums (k_xchg_cand + all-reduce)
     const double *xr = d.xc + ((size_t)w * d.world + lane) * XCHG;
     cand = xr[0]; d2 = xr[1]; n2 = xr[2];

@@ -380,7 +380,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   bool solved = false, e_valid = true;
   while (mu < GF_MAX_MU) {
     if (!e_valid) {
-      if (d.world > 1) {
+      if (d.sharded) {
         // landmark sharding: E for the larger mu needs every rank's landmarks — hand the window to the retry pass (rebuild on
         // all ranks, one all-reduce, k_solve again); a second failure is a failed linear solve
         if (!retry_pass) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
   bool solved = false, e_valid = true;
   while (mu < GF_MAX_MU) {
     if (!e_valid) {
-      if (d.world > 1) {
+      if (d.sharded) {
         if (!retry_pass) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }
         break;
       }

@@ -51,12 +51,13 @@ void gfbe_rccl_destroy(gfbe_rccl *h) {
   delete h;
 }
 
-void gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream) {
+int32_t gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream) {
   gfbe_rccl *h = (gfbe_rccl *)user;
-  if (!h || !h->comm || !device_ptr || n_doubles <= 0) { if (h) h->err = -1; return; }
+  if (!h || !h->comm || !device_ptr || n_doubles <= 0) { if (h && h->err == 0) h->err = -1; return -1; }
   const ncclResult_t r = ncclAllReduce(device_ptr, device_ptr, (size_t)n_doubles, ncclDouble, ncclSum, h->comm, (hipStream_t)hip_stream);
   if (r != ncclSuccess && h->err == 0) h->err = (int32_t)r;
   h->calls++;
+  return r == ncclSuccess ? 0 : (int32_t)r;
 }
 
 int32_t gfbe_rccl_last_error(const gfbe_rccl *h) { return h ? h->err : -1; }

@@ -8,7 +8,8 @@ Secondary mode — *landmark sharding of one window* (BASELINE.json configs[2]):
 same window, evaluates the landmark tiles t with t % world == rank, eliminates them locally and
 contributes partial normal equations; libgfbe calls the hook installed with gfbe_set_allreduce to sum
 them in place: one all-reduce of [H | g | E | eg | cost] (~38.7k doubles per window) per linearisation
-plus two 8-doubles-per-rank scalar exchanges per trust-region iteration. The dense solve is then
+plus two 8-doubles-per-rank scalar exchanges per trust-region iteration. The hook returns a status: a failed
+all-reduce makes the solve return GFBE_DEVICE_ERROR instead of un-reduced sums. The dense solve is then
 redundant (and bit-identical) on every rank. `torch_allreduce_hook` is that hook over torch.distributed.
 """
 import numpy as np
@@ -97,10 +98,17 @@ class RcclHook:
 
     def __init__(self, rank, world, device, group=None):
         import ctypes as C
+        import os
         import torch
         import torch.distributed as dist
         from . import backend
-        self.lib = C.CDLL(backend._RCCL_SO)          # (after `import torch`: its librccl.so.1 is the one already loaded)
+        # One ROCm runtime per process: inside a Python process torch's bundled librccl.so.1 / libamdhip64 / libhsa-runtime64 are the
+        # ones in use. Loaded here first (same SONAME as /opt/rocm's), it is the copy libgfbe_rccl.so's NEEDED entry resolves to —
+        # /opt/rocm's RCCL would dlopen a second, uninitialised HSA runtime ("pfn_hsa_system_get_info failed", measured on the test box).
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(tl):
+            self._rccl = C.CDLL(tl, mode=C.RTLD_GLOBAL)
+        self.lib = C.CDLL(backend._RCCL_SO)
         self.lib.gfbe_rccl_unique_id.restype = C.c_int32
         self.lib.gfbe_rccl_create.restype = C.c_int32
         self.lib.gfbe_rccl_last_error.restype = C.c_int32
@@ -110,11 +118,12 @@ class RcclHook:
             rc = self.lib.gfbe_rccl_unique_id(idbuf)
             if rc != 0:
                 raise RuntimeError("gfbe_rccl_unique_id failed: %d" % rc)
-        t = torch.tensor(list(idbuf.raw), dtype=torch.uint8)
-        if dist.get_backend(group) == "nccl":
-            t = t.cuda()
-        dist.broadcast(t, src=0, group=group)
-        idbuf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+        if world > 1 or dist.is_initialized():       # (a one-rank communicator needs no rendezvous)
+            t = torch.tensor(list(idbuf.raw), dtype=torch.uint8)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            idbuf = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
         self.h = C.c_void_p()
         rc = self.lib.gfbe_rccl_create(C.byref(self.h), idbuf, int(rank), int(world), int(device))
         if rc != 0:
@@ -139,7 +148,8 @@ def install_allreduce_hook(be, rank, world, prefer="native", group=None):
     import torch.distributed as dist
     from . import backend
     import os
-    if prefer == "native" and dist.get_backend(group) == "nccl" and os.path.exists(backend._RCCL_SO):
+    solo = world == 1 and not dist.is_initialized()        # one rank, no process group: the native hook over a one-rank communicator
+    if prefer == "native" and (solo or dist.get_backend(group) == "nccl") and os.path.exists(backend._RCCL_SO):
         hook = RcclHook(rank, world, be.device, group)
         be._rccl_hook = hook                       # keep the communicator alive as long as the back end
         be.set_allreduce_native(hook.fn_ptr, hook.h.value, rank, world)

@@ -540,8 +540,12 @@ gfbe_status gfbe_preintegrate_wheel(gfbe_ctx *ctx, int32_t n_interval, const int
  *                                                                      marginalization_factor.cpp:119-330
  * out_state / out_feature receive the re-anchored parameter blocks (what a second vector2double()
  * would produce, estimator.cpp:3398) — outputs are untouched when status is an error.
- * prior_out (may be NULL when margin_flag == GFBE_MARGIN_NONE) receives the new prior with block
- * ids already shifted (slot i -> i-1 for MARGIN_OLD; slot 10 -> 9 for SECOND_NEW).
+ * prior_out (may be NULL when margin_flag == GFBE_MARGIN_NONE) is IN/OUT like last_marginalization_info: when a marginalisation
+ * ran — margin_flag != GFBE_MARGIN_NONE and the window is full (frame_count == GFBE_WINDOW_SIZE, estimator.cpp:3391) — it
+ * receives the new prior with block ids already shifted (slot i -> i-1 for MARGIN_OLD; slot 10 -> 9 for SECOND_NEW), `valid`
+ * = 0 if the marginalisation produced none (marginalization_factor.cpp:205-210). When NO marginalisation ran (a window that is
+ * still filling up) it is left exactly as the caller passed it: pass the previous prior, or a structure whose `valid` the
+ * caller has set to 0 — an uninitialised gfbe_prior stays uninitialised.
  * ------------------------------------------------------------------------------------------ */
 gfbe_status gfbe_solve_window(gfbe_ctx *ctx, const gfbe_window *win, int32_t margin_flag,
                               gfbe_state *out_state, double *out_feature,
@@ -553,10 +557,15 @@ gfbe_status gfbe_solve_batch(gfbe_ctx *ctx, int32_t n_window, const gfbe_window 
                              gfbe_prior *const *prior_out, gfbe_summary *summary);
 
 /* Device-resident form used for throughput measurement: upload once, (re)solve many times.
- *   gfbe_batch_upload   packs the windows into the device layout
+ *   gfbe_batch_upload   packs the windows into pinned staging memory and ENQUEUES one host-to-device copy plus the
+ *                       preparation kernels on the context's private copy stream. It returns when the
+ *                       caller's gfbe_window structures have been read — they may be reused at once — but the copy may still
+ *                       be in flight: gfbe_batch_solve waits for it on the device (an event), never on the host
  *   gfbe_batch_solve    resets every window to its uploaded state, then runs the full
  *                       optimization() sequence on the ctx stream; asynchronous, no host sync
- *   gfbe_batch_download copies results back (synchronises)
+ *   gfbe_batch_download runs the gather kernel and ONE device-to-host copy on the context's private download stream
+ *                       (after the solve's event), waits for that copy only, and unpacks. prior_out: in/out as described
+ *                       above (untouched for windows whose marginalisation did not run)
  * ------------------------------------------------------------------------------------------ */
 typedef struct gfbe_batch gfbe_batch;
 gfbe_status gfbe_batch_upload(gfbe_ctx *ctx, int32_t n_window, const gfbe_window *const *win,
@@ -584,8 +593,12 @@ gfbe_status gfbe_debug_vector(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, int32
 
 /* Multi-GPU landmark sharding: when set, the library calls
  * fn(user, device_ptr, n_doubles, hip_stream) once per linearisation on the packed partial reduced
- * system [S | g | cost ...]; the callee performs an in-place sum all-reduce (RCCL) on that stream. */
-typedef void (*gfbe_allreduce_fn)(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);
+ * system [S | g | cost ...] (and on a few small exchange blocks per iteration); the callee performs an in-place sum
+ * all-reduce (RCCL) on that stream and returns 0, or a non-zero code: the solve that enqueued the call then returns
+ * GFBE_DEVICE_ERROR with the code in gfbe_last_error — un-reduced partial sums are never handed back as a result.
+ * A hook installed with world_size 1 still runs the sharded launch sequence (every all-reduce is then the identity): that is
+ * how a single-GPU box exercises the whole path. fn == NULL switches the sharding off. */
+typedef int32_t (*gfbe_allreduce_fn)(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);
 gfbe_status gfbe_set_allreduce(gfbe_ctx *ctx, gfbe_allreduce_fn fn, void *user, int32_t rank,
                                int32_t world_size);
 

@@ -26,8 +26,9 @@ typedef struct gfbe_rccl gfbe_rccl;
 int32_t gfbe_rccl_unique_id(char id[GFBE_RCCL_ID_BYTES]);
 int32_t gfbe_rccl_create(gfbe_rccl **out, const char id[GFBE_RCCL_ID_BYTES], int32_t rank, int32_t world_size, int32_t device);
 void gfbe_rccl_destroy(gfbe_rccl *h);
-/* Signature of gfbe_allreduce_fn: user = the gfbe_rccl handle. Errors are sticky and read with gfbe_rccl_last_error. */
-void gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);
+/* Signature of gfbe_allreduce_fn: user = the gfbe_rccl handle. Returns 0 or the ncclResult_t (negative: bad argument) — libgfbe turns
+ * a non-zero return into GFBE_DEVICE_ERROR of the solve; the first error also stays readable with gfbe_rccl_last_error. */
+int32_t gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);
 int32_t gfbe_rccl_last_error(const gfbe_rccl *h);
 int64_t gfbe_rccl_calls(const gfbe_rccl *h);
 #ifdef __cplusplus

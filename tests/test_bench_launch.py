@@ -50,9 +50,10 @@ def test_rccl_hook_library_contract():
     assert declared == set(gf.backend.RCCL_EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    # the hook has the signature of gfbe_allreduce_fn (include/gfbe.h): (user, device_ptr, n_doubles, hip_stream) -> void
+    # the hook has the signature of gfbe_allreduce_fn (include/gfbe.h): (user, device_ptr, n_doubles, hip_stream) -> status
     hdr = open(os.path.join(ROOT, "include", "gfbe_rccl.h")).read()
-    assert "void gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);" in hdr
+    assert "int32_t gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);" in hdr
+    assert "typedef int32_t (*gfbe_allreduce_fn)(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);" in open(os.path.join(ROOT, "include", "gfbe.h")).read()
     lib.gfbe_rccl_create.restype = C.c_int32
     lib.gfbe_rccl_last_error.restype = C.c_int32
     h, idb = C.c_void_p(), C.create_string_buffer(128)
@@ -62,7 +63,8 @@ def test_rccl_hook_library_contract():
         assert lib.gfbe_rccl_create(C.byref(h), idb, 0, 1, 0) == -2        # no GPU: refused, no crash, no handle
         assert not h.value
     assert lib.gfbe_rccl_last_error(None) == -1
-    lib.gfbe_rccl_allreduce(None, None, 0, None)                             # null handle: ignored
+    lib.gfbe_rccl_allreduce.restype = C.c_int32
+    assert lib.gfbe_rccl_allreduce(None, None, 0, None) == -1               # null handle: refused with a status, no crash
 
 
 def test_public_headers_are_strict_c99(tmp_path):
