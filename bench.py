@@ -191,33 +191,7 @@ def main():
         e2e = end_to_end(args, be, gf, torch, dist if world > 1 else None, scns, snaps, final_costs)
 
     if rank == 0:
-        tot_ms = sum(p["total_ms"] for p in prof.values())
-        dom = max((p for p in prof.values()), key=lambda p: p["total_ms"])
-        lin0 = prof.get("k_vis_lin_iter0", prof.get("k_vis_lin"))
-        # Dominant hot-path kernel: k_vis<0> = visual evaluate + linearise with J^T J fused on the FP64
-        # matrix cores (J is never materialised). SURVEY.md section 8d per-unit figures for one visual residual
-        # block: 108 B of input (fused form) and 1.6 kflop of J^T J. At 14.8 flop/B the kernel sits to the
-        # right of the FP64 ridge point (78.6 TF / 8 TB/s = 9.8 flop/B): the matrix-core roofline bounds it.
-        lin_ms = lin0["total_ms"] / max(lin0["launches"], 1)
-        # (batches >= 128 windows run as two halves: a launch then covers half of the resident windows)
-        units_per_launch = K_batch * nprof / max(lin0["launches"], 1)
-        algo_flops = 1600.0 * units_per_launch
-        algo_bytes = 108.0 * units_per_launch
-        achieved_tf = algo_flops / (lin_ms * 1e-3) / 1e12
-        # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the committed rocprofv3
-        # passes (profiles/*_pmc_fetch.txt / _write.txt, tests/diag_pmc.sh) hold FETCH_SIZE / WRITE_SIZE per dispatch
-        # for exactly the default workload, so they are quoted for it and left null for any other configuration.
-        traffic, traffic_src = None, None
-        if args.batch == 1024 and args.landmarks == 2000 and args.unique == 8:
-            traffic, traffic_src = pmc_traffic()
-        roofline = {"bound": "mfma", "kernel": "k_vis<0> (visual evaluate + linearise + fused J^T J; first iteration: all windows active)",
-                    "achieved": achieved_tf, "peak": 78.6, "unit": "TFLOP/s", "frac": achieved_tf / 78.6, "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "avg_launch_ms": lin_ms, "algorithmic_flops_per_launch": algo_flops,
-                    "algorithmic_bytes_per_launch": algo_bytes, "hbm_view_GBps": algo_bytes / (lin_ms * 1e-3) / 1e9,
-                    "hbm_view_frac_of_8TBps": algo_bytes / (lin_ms * 1e-3) / 8e12,
-                    "dominant_by_time": dom["name"],
-                    "time_share": {k: round(v["total_ms"] / tot_ms, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}}
+        roofline = roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters)
 
         # ---- single-window latency (B = 1), same workload: resident re-solve, and host-to-host gfbe_solve_window
         single_ms, single_host_ms = None, None
@@ -273,21 +247,120 @@ def main():
         print(json.dumps(out))
 
 
-def pmc_traffic():
-    """FETCH_SIZE + WRITE_SIZE (KB per dispatch) of the k_vis<0> launch over one half of the default batch, from the newest
-    committed rocprofv3 PMC passes."""
-    for tag in ("r2", "r1"):
+PEAK_F64_TF = 78.6     # dense FP64 matrix-core peak of one MI355X, TFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_HBM_TBS = 8.0     # HBM3E, TB/s
+
+
+def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
+    """`roofline` of the JSON line. The dominant kernel family by arithmetic is k_vis<0> (visual evaluate + linearise with the
+    J^T J of the step's 64 factors on the FP64 matrix cores; J is never materialised). What is credited is what the kernel RUNS:
+      reduced panel (camera extrinsic and td constant in every window — the shipped configuration and this workload):
+        X = [J_i J_j r] is 13 columns padded to ONE 16 x 16 x 4 tile, 32 matrix-core instructions per 64 factors
+        -> 1024 flop ISSUED per factor, 2 * 2 * 13 * 13 = 676 of them useful;
+      full 20-column panel (extrinsic or td free somewhere in the batch): SURVEY.md section 8d's 1.6 kflop per factor.
+    `achieved` / `frac` are the ISSUED matrix-core flops over the kernel's own launch time (what SQ_VALU_MFMA_BUSY_CYCLES sees);
+    `useful_frac` counts the 676. All times are the library's own hipEvents around the launches of the FIRST iteration (every
+    window active), on the launch stream; in profiling mode the two halves of a batch run one after the other, so a launch covers
+    windows_per_launch windows. `kernels` is the same for the other kernels of an iteration, `whole_solve` SURVEY section 8d's
+    ~32 Mflop per linearisation over the measured solves/s."""
+    tot_ms = sum(p["total_ms"] for p in prof.values())
+    fam = {}                                                                # kernel families (first-iteration launches are profiled under their own name)
+    for k, p in prof.items():
+        fam[k.replace("_iter0", "")] = fam.get(k.replace("_iter0", ""), 0.0) + p["total_ms"]
+    dom = max(fam, key=fam.get)
+    lin0 = prof.get("k_vis_lin_iter0", prof.get("k_vis_lin"))
+    lin_ms = lin0["total_ms"] / max(lin0["launches"], 1)
+    units_per_launch = K_batch * nprof / max(lin0["launches"], 1)          # visual factors one launch evaluates
+    windows_per_launch = args.batch * nprof / max(lin0["launches"], 1)
+    full_panel = any((not s.get("ex_cam_const", 1)) or (not s.get("td_const", 1)) for s in batch_snaps[: args.unique])
+    issued, useful = (1600.0, 1600.0) if full_panel else (1024.0, 676.0)
+    achieved_tf = issued * units_per_launch / (lin_ms * 1e-3) / 1e12
+    pmc = pmc_summary() if (args.batch == 1024 and args.landmarks == 2000 and args.unique == 8) else {}
+    kv = pmc.get("k_vis", {})
+    # ---- the other kernels of a linearisation: algorithmic work of ONE launch over windows_per_launch windows
+    L = float(np.mean([len(s["para_feature"]) for s in batch_snaps[: args.unique]]))
+    n_obs = np.concatenate([np.bincount(np.asarray(s["vis_feature_index"]), minlength=len(s["para_feature"])) for s in batch_snaps[: args.unique]])
+    K1 = float(K_batch) / args.batch
+    tiles = L / 64.0 * 1.15                                                   # landmark tiles per window incl. the start-frame padding
+    n_act = 175.0                                                             # active tangent dims of this workload (76 dense + 99 speed-bias)
+    pn = float(batch_snaps[0]["prior"]["n"]) if batch_snaps[0].get("prior") else 0.0
+    work = {
+        # k_schur: sum_l w_l h_l h_l^T over the landmark's (6 (m + 1) + 7 + 1)-wide row, symmetric half
+        "k_schur": ("mfma", float(np.mean((6.0 * (n_obs + 1) + 8.0) ** 2)) * L),
+        # k_solve: Cholesky of the reduced system + the two triangular solves
+        "k_solve": ("mfma", n_act ** 3 / 3.0 + 2.0 * n_act ** 2),
+        # k_visblock: reads the filled entries of the tiles' X^T X partials, writes the 73 x 74 visual block
+        "k_visblock": ("hbm", 8.0 * (tiles * 10 * (336 if full_panel else 157) * 0.5 + 73 * 74)),
+        # k_assemble: reads inertial / wheel / prior / visual / Schur partials, writes H (lower), g, E, eg
+        "k_assemble": ("hbm", 8.0 * (10 * 932 + 10 * 508 + pn * pn + 73 * 74 + 11 * 15 * 256 + 187 * 188 / 2 + 187 + 73 * 73 + 73)),
+        # k_lm_step: per landmark its H_pl row, Hll, gl, scale, lambda in; y_l, v_l out
+        "k_lm_step": ("hbm", 8.0 * (L * (13 + 5) + 6.0 * K1 + 2 * L)),
+    }
+    kernels = {}
+    for name, (bound, per_window) in work.items():
+        p = prof.get(name + "_iter0")
+        if not p or not p["launches"]:
+            continue
+        us = 1e3 * p["total_ms"] / p["launches"]
+        tot = per_window * windows_per_launch
+        ach = tot / (us * 1e-6) / 1e12
+        peak = PEAK_F64_TF if bound == "mfma" else PEAK_HBM_TBS
+        kernels[name] = {"bound": bound, "algorithmic_%s_per_launch" % ("flops" if bound == "mfma" else "bytes"): tot, "avg_launch_us": us,
+                         "achieved": ach, "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": ach / peak}
+        if name in pmc and "mfma_busy" in pmc[name]:
+            kernels[name]["mfma_busy_pmc"] = pmc[name]["mfma_busy"]
+    lin_per_solve = float(np.mean(iters)) + 1.0
+    whole_tf = 32e6 * (K1 / 9457.0) * lin_per_solve * value / 1e12
+    return {"bound": "mfma", "kernel": "k_vis<0, %s> (visual evaluate + linearise + fused X^T X; first iteration: all windows active)" % ("full 20-column panel" if full_panel else "reduced 13-column panel"),
+            "achieved": achieved_tf, "peak": PEAK_F64_TF, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F64_TF,
+            "flops_per_factor": {"issued": issued, "useful": useful, "survey_8d_full_panel": 1600.0},
+            "useful_frac": achieved_tf / PEAK_F64_TF * useful / issued,
+            "mfma_busy_pmc": kv.get("mfma_busy"), "traffic": kv.get("traffic"), "traffic_source": pmc.get("source"),
+            "avg_launch_ms": lin_ms, "factors_per_launch": units_per_launch, "windows_per_launch": windows_per_launch,
+            "algorithmic_bytes_per_launch": 108.0 * units_per_launch,
+            "hbm_view_GBps": (kv["traffic"] / (lin_ms * 1e-3) / 1e9) if kv.get("traffic") else None,
+            "kernels": kernels,
+            "whole_solve": {"flops_per_linearisation": 32e6 * (K1 / 9457.0), "linearisations_per_solve": lin_per_solve,
+                            "achieved": whole_tf, "unit": "TFLOP/s", "frac": whole_tf / PEAK_F64_TF},
+            "dominant_by_time": dom,
+            "time_share": {k: round(v / tot_ms, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}}
+
+
+def pmc_summary():
+    """Counter values of the newest committed rocprofv3 PMC passes of the DEFAULT workload (profiles/rN_pmc_*.txt; PMC counters
+    cannot be read from inside this process): HBM bytes per launch of k_vis<0> (FETCH_SIZE + WRITE_SIZE, KB per dispatch, separate
+    passes) and the matrix-core busy fraction of the MFMA kernels — SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x launch cycles at
+    2.4 GHz."""
+    pat = {"k_vis": "k_visILi0E", "k_schur": "k_schurE", "k_solve": "k_solve"}
+    for tag in ("r3", "r2"):
         try:
+            out = {"source": "rocprofv3 --pmc (separate passes) of the same workload: profiles/%s_pmc_fetch.txt, %s_pmc_write.txt, %s_pmc_sq1.txt" % (tag, tag, tag)}
+
+            def blocks(fn):
+                lines = open(os.path.join(ROOT, "profiles", fn)).read().splitlines()
+                res, cur = [], None
+                for ln in lines:
+                    if not ln.startswith(" "):
+                        cur = {"head": ln, "c": {}}
+                        res.append(cur)
+                    elif cur is not None and len(ln.split()) >= 2:
+                        cur["c"][ln.split()[0]] = float(ln.split()[1])
+                return res
             tot = 0.0
             for fn, key in ((tag + "_pmc_fetch.txt", "FETCH_SIZE"), (tag + "_pmc_write.txt", "WRITE_SIZE")):
-                lines = open(os.path.join(ROOT, "profiles", fn)).read().splitlines()
-                i = [k for k, ln in enumerate(lines) if "k_visILi0E" in ln and "grid=(32768," in ln][0]   # one half of the batch
-                tot += float([ln for ln in lines[i + 1:i + 4] if key in ln][0].split()[1]) * 1024.0
-            return tot, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same workload, bytes per launch: "
-                         "profiles/%s_pmc_fetch.txt + %s_pmc_write.txt" % (tag, tag))
+                b = [x for x in blocks(fn) if pat["k_vis"] in x["head"] and "grid=(32768," in x["head"]][0]     # one half of the batch
+                tot += b["c"][key] * 1024.0
+            out["k_vis"] = {"traffic": tot}
+            for name, sub in pat.items():
+                bs = [x for x in blocks(tag + "_pmc_sq1.txt") if sub in x["head"] and "SQ_VALU_MFMA_BUSY_CYCLES" in x["c"]]
+                if bs:
+                    b = max(bs, key=lambda x: float(x["head"].split("avg_us=")[1]))
+                    us = float(b["head"].split("avg_us=")[1])
+                    out.setdefault(name, {})["mfma_busy"] = b["c"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * 2400.0)
+            return out
         except Exception:
             continue
-    return None, None
+    return {}
 
 
 def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):

@@ -25,7 +25,8 @@ enum {
   XS_LD = 21,                 // LDS row stride of the [J | r] panel (20 + 1)
   NVP = 80,                   // NV padded to 5 tiles of 16; column 73 carries the landmark gradient
   SCHUR_TILES = 15,           // upper-triangular 16x16 tile pairs of the 80 x 80 block
-  SCHUR_STRIDE = SCHUR_TILES * 256, // one partial per (window, start frame): 15 dense tiles
+  SCHUR_STRIDE = SCHUR_TILES * 256, // one partial per (window, group of start frames): 15 dense tiles
+  SCHUR_GROUPS = 3,           // throughput batches: start frames {0, 1}, {2, 3, 4}, {5 .. 10}: one k_schur workgroup and one partial each
   LM_TILE = 64,               // landmarks per workgroup in the landmark kernels
   SCHUR_CHUNK = 64,           // landmarks per Schur work item
   IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost
@@ -182,7 +183,8 @@ struct BatchDev {
   // partial results
   double *pair_part;          // [B][NPAIR][VP_STRIDE]   X^T X per pose pair (sum of vis_part over the tiles of the start frame)
   double *vis_part;           // [B][max_tiles][MAXOBS][VP_STRIDE]  X^T X of the 64 factors of one tile at one step, X = [J | r]
-  double *schur_part;         // [B][NF][SCHUR_STRIDE]  sum over the landmarks of one start frame
+  double *schur_part;         // [B][NF][SCHUR_STRIDE]  sum over the landmarks of one group of start frames (schur_groups slots in use)
+  int schur_groups;           // SCHUR_GROUPS for throughput batches, NF (one group per start frame) for small ones
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *plane_part, *anchor_part;  // [B][MAX_PLANE][PLANE_PART], [B][ANCHOR_PART]   (only read for windows with n_plane / use_anchor)
   int any_plane;                     // some window of the batch has plane or anchor factors (else their workgroups are not launched)

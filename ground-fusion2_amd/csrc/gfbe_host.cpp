@@ -700,6 +700,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   }
   d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio;
   d.rank = c->rank; d.world = c->world; d.sharded = c->allreduce ? 1 : 0;
+  d.schur_groups = B >= DENSE_SPLIT_MIN_B ? SCHUR_GROUPS : NF;
   d.test_fail_chol_iter = c->opt.test_fail_chol_iter;   // (test hook of the mu-retry path, 0 in production: gfbe_options)
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
@@ -737,15 +738,13 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     if (tabs) { AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lam0, TL); d.fobs = nullptr; }
     AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);
     AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
-    AL(prior_J0, (size_t)B * ND * ND);
     AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
     AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
     if (B < DENSE_SPLIT_MIN_B && !c->allreduce) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
-    AL(ctl, B); AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);
-    AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);
+    AL(ctl, B);
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
     AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
-    AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36); AL(prior_H, (size_t)B * ND * ND);
+    AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36);
     AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
     AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
     AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
@@ -753,6 +752,21 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
     AL(tile_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) : 1);
     AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
+    AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
+    if (d.sharded) { AL(Er, (size_t)B * (NV * NV + NV)); } else d.Er = nullptr;
+    AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
+    AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
+    AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);
+    AL(timing, (size_t)(B + 1) * 32);   // (+ one block for the phase stamps of a diagnostics build)
+    AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
+    AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));
+    const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
+    // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
+    AL(prior_J0, (size_t)B * ND * ND);     // (the n x n prior block arrives by copy; nothing reads past it)
+    AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)
+    AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);                   // (written by the kernels that produce a state)
+    AL(prior_H, (size_t)B * ND * ND);      // (k_prep writes the n x n block k_assemble reads)
+    // (k_assemble writes every entry of H (lower triangle), g, E, eg it owns, k_visblock the exchange row: no clearing)
     // the partial reduced system [H | g | E | eg | xa] is one slab: a single all-reduce per linearisation when the
     // landmarks are sharded over ranks
     {
@@ -761,17 +775,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       if (!b->dry) { d.g = d.H + nH; d.E = d.g + ng; d.eg = d.E + nE; d.xa = d.eg + ne; }
       b->slab_n = nH + ng + nE + ne + nx;
     }
-    AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
-    if (d.sharded) { AL(Er, (size_t)B * (NV * NV + NV)); } else d.Er = nullptr;
-    AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
-    AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
     AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
-    AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);
-    AL(timing, (size_t)(B + 1) * 32);   // (+ one block for the phase stamps of a diagnostics build)
-    AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
-    AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));
-    const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
-    // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(rec, want_rec ? (size_t)tot_rec * REC : 1); AL(mV, (size_t)B * ND * ND);
     AL(vis_contrib, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) * MAXOBS * 16 * LM_TILE : 1);
     AL(solveY, (size_t)B * solve_chain_scratch_doubles());
@@ -1077,12 +1081,12 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
   }
   if (d.tot_lio > 0) { Timed t(c, "k_lio_window", 0); launch_lio_window(d, 0, ln.s); }
-  { Timed t(c, "k_schur", 0); launch_schur(d, 0, ln.s); }
-  { Timed t(c, "k_visblock", 0); launch_visblock(d, ln.s); }
+  { Timed t(c, first ? "k_schur_iter0" : "k_schur", 0); launch_schur(d, 0, ln.s); }
+  { Timed t(c, first ? "k_visblock_iter0" : "k_visblock", 0); launch_visblock(d, ln.s); }
   if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);   // join
-  { Timed t(c, "k_assemble", 0); launch_assemble(d, ln.s); }
+  { Timed t(c, first ? "k_assemble_iter0" : "k_assemble", 0); launch_assemble(d, ln.s); }
   if (d.sharded) { Timed t(c, "allreduce_system", 0); run_allreduce(c, d.H, (int64_t)b->slab_n, ln.s); }
-  { Timed t(c, "k_solve", 0); launch_solve(d, ln.s); }
+  { Timed t(c, first ? "k_solve_iter0" : "k_solve", 0); launch_solve(d, ln.s); }
   if (d.sharded) {
     // the mu retry of DoglegStrategy when the landmarks are sharded: a window whose factorisation failed gets E rebuilt for the
     // larger mu from every rank's own tiles, one more all-reduce (E | eg only), and a second factorisation
@@ -1091,7 +1095,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     run_allreduce(c, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);
     launch_solve(d, ln.s, 1);
   }
-  { Timed t(c, "k_lm_step", 0); launch_lm_step(d, ln.s); }
+  { Timed t(c, first ? "k_lm_step_iter0" : "k_lm_step", 0); launch_lm_step(d, ln.s); }
   if (d.sharded) {
     Timed t(c, "allreduce_scalars", 0);
     launch_xchg_gram(d, ln.s);

@@ -857,20 +857,34 @@ typedef double dbl4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I - 1) / 2 + (J - I); }   // I <= J < 5
 
+// One workgroup per (window, GROUP of start frames). Throughput batches (>= 32 windows): the landmark tiles of start frames {0, 1},
+// {2, 3, 4}, {5 .. 10} go through the same accumulators one after the other (a window's tiles are sorted by start frame: a group is
+// a contiguous range of tiles), so that a window leaves THREE partials instead of eleven — k_assemble's gather of E reads 3 instead
+// of 11 values per entry and two thirds of the partial stores are gone. Small batches keep one group per start frame: eleven
+// workgroups side by side are what a single window's latency wants. The marginalisation pass (start frame 0 alone) uses slot 0.
+__device__ __forceinline__ int schur_group_first(int g, int ng) { return ng == NF ? g : (g == 0 ? 0 : (g == 1 ? 2 : 5)); }
 __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
-  const int w = blockIdx.x, s = blockIdx.y;   // start-frame-major dispatch: the heavy start frame 0 of every window first
+  const int w = blockIdx.x, grp = blockIdx.y;   // group-major dispatch: the heavy first group of every window first
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (!marg && (c.done || c.reuse)) return;
-  if (marg && s != 0) return;
-  const int tb = ds.sf_tile_begin[s], te = ds.sf_tile_begin[s + 1];
-  if (tb == te) return;   // partial stays zero (zeroed at upload; the structure never changes)
+  if (marg && grp != 0) return;
+  const int ng = d.schur_groups;
+  const int s_first = schur_group_first(grp, ng), s_end = marg ? 1 : (grp == ng - 1 ? NF : schur_group_first(grp + 1, ng));
+  const int tb = ds.sf_tile_begin[s_first], te = ds.sf_tile_begin[s_end];
+  const int tfirst = tb + ((d.rank - tb) % d.world + d.world) % d.world;   // first tile of this rank (world 1: tb)
+  if (tfirst >= te) {
+    // solve: the partial stays zero (zeroed at upload; the structure never changes). Marginalisation: slot 0 may hold the solve's
+    // partial of the group {0, 1} — no landmark (of this rank) starts in frame 0, so its Schur term is zero
+    if (marg) for (int q = threadIdx.x; q < SCHUR_STRIDE; q += 256) d.schur_part[((size_t)w * NF) * SCHUR_STRIDE + q] = 0.0;
+    return;
+  }
   __shared__ double hs[LM_TILE * HS_LD];
   const size_t TL = d.tot_lm;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool first = (c.iter == 0);   // Jacobi scaling is fixed at iteration 0 (TrustRegionMinimizer::IterationZero)
-  // output tiles of this start frame: tile rows/cols >= I0, upper pairs, round-robin over the 4 waves
-  const int I0 = (6 * s) / 16;
+  // output tiles of this group: tile rows/cols >= I0 (of its first start frame), upper pairs, round-robin over the 4 waves
+  const int I0 = (6 * s_first) / 16;
   // slot q of this wave owns the (4 q + wave)-th upper tile pair (I, J), I0 <= I <= J < 5 — all wave-uniform
   // scalars, and the four accumulators are separate named registers (no dynamic indexing of AGPRs).
   const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -889,12 +903,13 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   // are issued together (rows beyond a track's length are zero in memory) and the NEXT tile's loads are
   // in flight while the matrix cores work on the current one.
   const int l = t & 63, part = t >> 6;
-  const int kmax = NF - 1 - s;          // observing poses s+1 .. 10
   double pre[24];
   double pHll = 0.0, psl = 1.0;
-  int pinfo = 0;
+  int pinfo = 0, ps = 0;                // (ps: start frame of the prefetched tile)
   auto prefetch = [&](int tile) {
     const int slot = ds.lm_off + tile * LM_TILE + l;
+    ps = d.tile_start[ds.tile_off + tile];
+    const int kmax = NF - 1 - ps;       // observing poses ps+1 .. 10
     pinfo = d.lm_info[slot];
     pHll = d.lm_Hll[slot];
     psl = first ? 1.0 : d.lm_sl[slot];
@@ -911,17 +926,16 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
       }
     }
   };
-  const bool stamp_wg = (w == 0 && s == 0 && t == 0 && !marg);
+  const bool stamp_wg = (w == 0 && grp == 0 && t == 0 && !marg);
   double *stamp = d.timing + 8;
   if (stamp_wg) { stamp[0] = (double)wall_clock64(); stamp[5] = (double)clock64(); }
   const int tstep = d.world;
-  const int tfirst = tb + ((d.rank - tb) % d.world + d.world) % d.world;   // first tile of this rank (world 1: tb)
-  if (tfirst >= te) return;
   prefetch(tfirst);
   for (int tile = tfirst; tile < te; tile += tstep) {
     __syncthreads();
     if (stamp_wg && tile == tfirst) stamp[1] = (double)wall_clock64();
     {
+      const int s = ps, kmax = NF - 1 - s;          // this tile's start frame
       const int slot = ds.lm_off + tile * LM_TILE + l;
       const bool valid = (pinfo >> 24) & 1;
       const int m = (pinfo >> 8) & 0xff;
@@ -978,7 +992,7 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
 #undef SCHUR_SLOT
   }
   if (stamp_wg) { stamp[3] = (double)wall_clock64(); stamp[4] = (double)(te - tb); stamp[6] = (double)clock64(); }
-  double *out = d.schur_part + ((size_t)w * NF + s) * SCHUR_STRIDE;
+  double *out = d.schur_part + ((size_t)w * NF + grp) * SCHUR_STRIDE;
 #define SCHUR_OUT(Q, ACC)                                                         \
   if (pI[Q] >= 0) {                                                               \
     double *o = out + (size_t)schur_pair(pI[Q], pJ[Q]) * 256;                     \
@@ -1050,20 +1064,6 @@ __device__ __forceinline__ int dim_frame(int a) {
   return -1;
 }
 
-// E(a,b), a <= b < NVP: sum over the start frames s with 6 s <= a (fixed order)
-__device__ double gather_E(const BatchDev &d, const WinDesc &ds, int w, int a, int b, bool marg) {
-  if (a > b) { const int t = a; a = b; b = t; }
-  const int off = schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);
-  const int smax = marg ? 0 : min(a / 6, NF - 1);
-  const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE;
-  double s = 0.0;
-  for (int f = 0; f <= smax; f++) s += sp[(size_t)f * SCHUR_STRIDE + off];
-  return s;
-}
-__device__ double gather_eg(const BatchDev &d, const WinDesc &ds, int w, int a, bool marg) {
-  return gather_E(d, ds, w, a, NV, marg);   // column 73 of the padded block carries sum_l w_l h_l g_l
-}
-
 // Tables of the window descriptor the assembly consults per entry, staged in LDS once per workgroup.
 struct AsmTab {
   int prior_map[ND];
@@ -1129,14 +1129,24 @@ __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab
   if (tb.n_plane > 0 || tb.use_anchor) s += plane_anchor_term(d, w, tb.n_plane, tb.use_anchor, a, -1);
   return s;
 }
-// E(a,b), a <= b < NVP (b = 73: the gradient column): the 11 start-frame Schur partials, loads unconditional in flight
+// E(a,b), a <= b < NVP (b = 73: the gradient column): the Schur partials of the start-frame groups that reach dim a (a group
+// reaches the dims from its first start frame's pose on), loads unconditional in flight
 __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z, int w, int a, int b) {
   const int off = schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);
-  const int smax = min(a / 6, NF - 1);
   const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE + off;
+  const int ng = d.schur_groups;
+  if (ng == SCHUR_GROUPS) {
+    double v[SCHUR_GROUPS];
+#pragma unroll
+    for (int f = 0; f < SCHUR_GROUPS; f++) v[f] = *(6 * schur_group_first(f, SCHUR_GROUPS) <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
+    double s = 0.0;
+#pragma unroll
+    for (int f = 0; f < SCHUR_GROUPS; f++) s += v[f];
+    return s;
+  }
   double v[NF];
 #pragma unroll
-  for (int f = 0; f < NF; f++) v[f] = *(f <= smax ? sp + (size_t)f * SCHUR_STRIDE : Z);
+  for (int f = 0; f < NF; f++) v[f] = *(6 * f <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
   double s = 0.0;
 #pragma unroll
   for (int f = 0; f < NF; f++) s += v[f];
@@ -1862,7 +1872,7 @@ void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
   if (d.max_tiles == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(d.B, marg ? 1 : NF), dim3(256), 0, s, d, marg);
+  hipLaunchKernelGGL(k_schur, dim3(d.B, marg ? 1 : d.schur_groups), dim3(256), 0, s, d, marg);
 }
 void launch_xchg_gram(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_gram, dim3(d.B), dim3(64), 0, s, d); }
 void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_cand, dim3(d.B), dim3(64), 0, s, d); }
