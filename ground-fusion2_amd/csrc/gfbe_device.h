@@ -26,7 +26,7 @@ enum {
   NVP = 80,                   // NV padded to 5 tiles of 16; column 73 carries the landmark gradient
   SCHUR_TILES = 15,           // upper-triangular 16x16 tile pairs of the 80 x 80 block
   SCHUR_STRIDE = SCHUR_TILES * 256, // one partial per (window, group of start frames): 15 dense tiles
-  SCHUR_GROUPS = 3,           // throughput batches: start frames {0, 1}, {2, 3, 4}, {5 .. 10}: one k_schur workgroup and one partial each
+  SCHUR_GROUPS = 4,           // throughput batches: start frames {0, 1}, {2}, {3, 4, 5}, {6 .. 10}: one k_schur workgroup and one partial each
   LM_TILE = 64,               // landmarks per workgroup in the landmark kernels
   SCHUR_CHUNK = 64,           // landmarks per Schur work item
   IMU_PART = 30 * 30 + 30 + 2,      // J^T J, J^T r, cost

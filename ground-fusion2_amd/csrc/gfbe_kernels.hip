@@ -858,11 +858,13 @@ typedef double dbl4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I - 1) / 2 + (J - I); }   // I <= J < 5
 
 // One workgroup per (window, GROUP of start frames). Throughput batches (>= 32 windows): the landmark tiles of start frames {0, 1},
-// {2, 3, 4}, {5 .. 10} go through the same accumulators one after the other (a window's tiles are sorted by start frame: a group is
-// a contiguous range of tiles), so that a window leaves THREE partials instead of eleven — k_assemble's gather of E reads 3 instead
-// of 11 values per entry and two thirds of the partial stores are gone. Small batches keep one group per start frame: eleven
+// {2}, {3, 4, 5}, {6 .. 10} go through the same accumulators one after the other (a window's tiles are sorted by start frame: a
+// group is a contiguous range of tiles), so that a window leaves FOUR partials instead of eleven — k_assemble's gather of E reads 4
+// instead of 11 values per entry and two thirds of the partial stores are gone. Small batches keep one group per start frame: eleven
 // workgroups side by side are what a single window's latency wants. The marginalisation pass (start frame 0 alone) uses slot 0.
-__device__ __forceinline__ int schur_group_first(int g, int ng) { return ng == NF ? g : (g == 0 ? 0 : (g == 1 ? 2 : 5)); }
+// (the groups follow the tile rows a start frame's landmarks can reach — I0 = 6 s / 16 steps at s = 3 and s = 6 — so that no group
+//  multiplies tile pairs its later start frames do not touch; work ~ tiles x pairs: {0,1} 30, {2} 15, {3,4,5} 30, {6..10} 12)
+__device__ __forceinline__ int schur_group_first(int g, int ng) { return ng == NF ? g : (g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 6))); }
 __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   const int w = blockIdx.x, grp = blockIdx.y;   // group-major dispatch: the heavy first group of every window first
   const WinDesc &ds = d.desc[w];
