@@ -139,6 +139,7 @@ struct gfbe_batch {
   bool dry = false;
   std::vector<std::vector<int>> slot_of;   // per window: ABI landmark -> global slot (host-fed batches)
   std::vector<int> L;
+  std::vector<unsigned char> anchor_only;      // window: MARGIN_SECOND_NEW meets an invalid prior that lists Pose[WINDOW_SIZE-1] (estimator.cpp:3622-3632)
   // upload region [0, up_end) of the slab = the pinned mirror up_h; [up_end, zero_end) is cleared; the rest is written before read
   char *up_h = nullptr;
   size_t up_cap = 0, up_bytes = 0, up_end = 0, zero_end = 0;
@@ -612,6 +613,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   hipStream_t us = tabs ? c->stream : c->copy;
   b->slot_of.resize(B);
   b->L.resize(B);
+  b->anchor_only.assign(B, 0);
   b->up_win_bytes.assign(B, 0.0);
   std::vector<WinScan> scan(B);
   std::vector<int> tcounts, tlayout;     // table source: per window [L, K, bins], layout table for the pack kernel
@@ -678,6 +680,11 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     n_imu_tot += win.n_imu; n_wheel_tot += win.n_wheel; tot_lio += win.lio.n > 0 ? win.lio.n : 0;
     b->L[w] = sc.L;
     feat_off[w + 1] = feat_off[w] + sc.L;
+    // MARGIN_SECOND_NEW with an INVALID last_marginalization_info that still lists Pose[WINDOW_SIZE-1] (estimator.cpp:3600, 3622-3632):
+    // the reference marginalises a PoseAnchorFactor on Pose[0] with drop set {Pose[0]} — six dims dropped, nothing kept — and ends
+    // with a valid, empty MarginalizationInfo. Nothing to compute: gfbe_batch_download hands back exactly that.
+    if (win.prior && !win.prior->valid && win.frame_count == GFBE_WINDOW_SIZE && win.prior->n_blocks > 0 && win.prior->n_blocks <= GFBE_MAX_PRIOR_BLOCKS)
+      for (int q = 0; q < win.prior->n_blocks; q++) if (win.prior->block_id[q] == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1) b->anchor_only[w] = 1;
     if (win.prior && win.prior->valid && win.prior->n > 0) {
       const gfbe_prior &pr = *win.prior;
       if (pr.n > ND || pr.n_blocks < 0 || pr.n_blocks > GFBE_MAX_PRIOR_BLOCKS || !pr.J0 || !pr.r0) { c->err = "window " + std::to_string(w) + ": prior too large or without J0 / r0"; return GFBE_BAD_INPUT; }
@@ -1259,7 +1266,10 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
     if (out_feature && out_feature[w] && b->L[w] > 0) std::memcpy(out_feature[w], feat + b->feat_off[w], sizeof(double) * b->L[w]);
     // the prior is only touched when a marginalisation ran for this window (estimator.cpp:3391: a window that is still filling
     // up, or MARGIN_NONE, leaves last_marginalization_info as it is)
-    if (prior_out && prior_out[w] && b->last_flag != GFBE_MARGIN_NONE && k.marg_ran) {
+    if (prior_out && prior_out[w] && b->last_flag == GFBE_MARGIN_SECOND_NEW && b->anchor_only[w]) {
+      // estimator.cpp:3622-3632 (see upload_one): the invalid prior is replaced by a valid, empty one
+      prior_out[w]->valid = 1; prior_out[w]->n = 0; prior_out[w]->n_blocks = 0;
+    } else if (prior_out && prior_out[w] && b->last_flag != GFBE_MARGIN_NONE && k.marg_ran) {
       gfbe_prior *p = prior_out[w];
       p->valid = m[0] == 1 ? 1 : 0; p->n = m[1]; p->n_blocks = m[2];
       if (p->valid) {

@@ -609,6 +609,15 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
     for (int l : lm0) drop.push_back(GFBE_BLK_COUNT + l);
   } else {
     // MARGIN_SECOND_NEW: only when the prior touches Pose[WINDOW_SIZE-1] (estimator.cpp:3600-3601)
+    if (!has_prior && w.prior && !w.prior->valid) {
+      // estimator.cpp:3622-3632: last_marginalization_info exists but is NOT valid (a marginalisation with nothing to drop,
+      // marginalization_factor.cpp:204-210, still lists its parameter blocks) and lists Pose[WINDOW_SIZE-1]: the only residual is a
+      // PoseAnchorFactor on Pose[0] anchored at Pose[0] itself, drop set {Pose[0]} — m = 6, nothing kept: the new info is VALID
+      // and empty (no blocks, n = 0), i.e. the invalid prior is replaced by no prior at all
+      bool lists = false;
+      for (int b = 0; b < w.prior->n_blocks; b++) lists |= w.prior->block_id[b] == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1;
+      if (lists) { out->valid = 1; out->n = 0; out->n_blocks = 0; return 0; }
+    }
     if (!has_prior || !touched[GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1]) return 1;   // nothing to do: keep old prior
     drop.push_back(GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1);
   }

@@ -152,3 +152,31 @@ def test_hip_backend_reproduces_independent_trust_region_loop(be, oracle, name):
     _check_against_loop(bex.solve(snap, abi.MARGIN_NONE)["summary"], _dogleg_fixture(), name, final_rtol=1e-6 if name == "free_masks" else 1e-9)
     if bex is not be:
         bex.close()
+
+
+def test_second_new_with_an_invalid_prior_that_lists_the_second_newest_pose(be, oracle):
+    """estimator.cpp:3622-3632 (the PoseAnchorFactor else-branch of MARGIN_SECOND_NEW): an invalid last_marginalization_info that
+    still lists Pose[WINDOW_SIZE - 1] is replaced by a valid, empty one; the solve runs without a prior factor. Same outcome as
+    the oracle, alone and inside a batch next to a window with an ordinary prior."""
+    import ctypes as C
+    scn, snap = window_with_prior(oracle, 67, 300)
+    bad = dict(snap["prior"], valid=0)
+    odd = dict(snap, prior=bad)
+    outs = []
+    for lib, head, pre in ((be.lib, be.head, "gfbe_"), (oracle.lib, oracle.head, "gfo_")):
+        wh = abi.WindowHolder(odd)
+        pr = abi.PriorHolder()
+        pr.c.valid, pr.c.n, pr.c.n_blocks = 7, 7, 7
+        st, feat, sm = abi.State(), np.zeros(wh.n_feature), abi.Summary()
+        f = getattr(lib, pre + "solve_window")
+        f.restype = abi.c_i
+        rc = f(head, C.byref(wh.c), abi.MARGIN_SECOND_NEW, C.byref(st), abi._pd(feat), C.byref(pr.c), C.byref(sm))
+        assert rc in (abi.OK, abi.NO_CONVERGENCE)
+        outs.append(((pr.c.valid, pr.c.n, pr.c.n_blocks), abi.summary_to_dict(sm)))
+    assert outs[0][0] == outs[1][0] == (1, 0, 0)
+    assert outs[0][1]["accepted"] == outs[1][1]["accepted"]
+    assert abs(outs[0][1]["final_cost"] - outs[1][1]["final_cost"]) < 1e-9 * outs[1][1]["final_cost"]
+    # in a batch: the ordinary window still gets its SECOND_NEW prior
+    res = be.solve_batch([snap, odd], abi.MARGIN_SECOND_NEW)
+    assert res[0]["prior"] is not None and res[0]["prior"]["n"] > 0
+    assert res[1]["prior"] is not None and res[1]["prior"]["n"] == 0 and len(res[1]["prior"]["block_id"]) == 0

@@ -268,3 +268,26 @@ def test_feature_bookkeeping_bit_exact(oracle):
     long = np.where(fl["n_obs"] >= 4)[0]
     assert flag[long[3]] == 2 and (flag[long[:3]] == 1).all() and (flag[fl["n_obs"] < 4] == 0).all()
     np.testing.assert_array_equal(est[long], 1.0 / lam)
+
+
+def test_second_new_with_an_invalid_prior_that_lists_the_second_newest_pose(oracle):
+    """estimator.cpp:3600, 3622-3632: last_marginalization_info exists, is NOT valid (a marginalisation that had nothing to drop
+    keeps its block list, marginalization_factor.cpp:204-210, 310-330) and lists Pose[WINDOW_SIZE - 1]: the else-branch marginalises
+    a PoseAnchorFactor on Pose[0] with drop set {Pose[0]} — nothing is kept, the new info is valid and EMPTY. Without
+    Pose[WINDOW_SIZE - 1] in the list the old (invalid) info simply stays."""
+    scn = synth.Scenario(seed=31, n_landmarks=120, use_wheel=True)
+    r0 = oracle.solve(scn.window(0), abi.MARGIN_OLD)
+    snap = scn.window(1, state=synth.shift_state_for_next_window(scn, r0["state"], 1), prior=r0["prior"])
+    bad = dict(r0["prior"], valid=0)
+    assert abi.BLK_POSE0 + abi.WINDOW_SIZE - 1 in bad["block_id"].tolist()
+    wh = abi.WindowHolder(dict(snap, prior=bad))
+    pr = abi.PriorHolder()
+    pr.c.valid, pr.c.n, pr.c.n_blocks = 7, 7, 7          # (whatever the caller left there)
+    st, feat, sm = abi.State(), np.zeros(wh.n_feature), abi.Summary()
+    import ctypes as C
+    rc = oracle.lib.gfo_solve_window(oracle.head, C.byref(wh.c), abi.MARGIN_SECOND_NEW, C.byref(st), abi._pd(feat), C.byref(pr.c), C.byref(sm))
+    assert rc in (abi.OK, abi.NO_CONVERGENCE)
+    assert (pr.c.valid, pr.c.n, pr.c.n_blocks) == (1, 0, 0)
+    # the solve itself ran without a prior factor (estimator.cpp:3004: only a valid info is added)
+    plain = oracle.solve(dict(snap, prior=None), abi.MARGIN_NONE)
+    assert abi.summary_to_dict(sm)["cost_history"] == plain["summary"]["cost_history"]
