@@ -54,7 +54,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block")
     ap.add_argument("--e2e-batch", type=int, default=1024, help="windows per batch of the end-to-end loops")
     ap.add_argument("--e2e-steps", type=int, default=8)
-    ap.add_argument("--e2e-depth", type=int, default=2, help="batches in flight in the end-to-end loops")
+    ap.add_argument("--e2e-depth", type=int, default=3, help="batches in flight in the end-to-end loops")
+    ap.add_argument("--e2e-split", type=int, default=2,
+                    help="gfbe_options.split_batch of the end-to-end loops: with several batches in flight two parts per batch measured best "
+                         "(1024 windows per batch, three in flight: 45.4k solves/s host-fed; four parts per batch: 32-36k)")
     ap.add_argument("--host-threads", type=int, default=0, help="gfbe_options.host_threads (0: library default)")
     ap.add_argument("--split", type=int, default=None, help="gfbe_options.split_batch: parts a batch of >= 128 windows is solved in, side by side (library default: 2)")
     ap.add_argument("--graph", action="store_true", help="gfbe_options.use_graph: replay the launch sequence as a hipGraph")
@@ -167,22 +170,6 @@ def main():
             assert hook.calls() > 0, "the native all-reduce hook was never called"
     value = solves / elapsed
 
-    # ---- the same with the 1024 resident windows rounds 1 and 2 were quoted on (continuity of the series; not `value`)
-    resident_1024 = None
-    if args.batch != 1024 and not shard:
-        b1k = be.batch_upload(batch_snaps[:1024] if args.batch >= 1024 else [snaps[i % args.unique] for i in range(1024)])
-        for _ in range(2):
-            b1k.solve(abi.MARGIN_OLD)
-        sync()
-        t1k = time.perf_counter()
-        n1k = max(args.steps // 2, 5)
-        for _ in range(n1k):
-            b1k.solve(abi.MARGIN_OLD)
-        sync()
-        s1k, e1k = gf.dist.aggregate_throughput(1024 * n1k, time.perf_counter() - t1k, dist if world > 1 else None)
-        resident_1024 = {"value": s1k / e1k, "unit": "solves/s", "windows_per_gpu": 1024, "steps": n1k}
-        b1k.free()
-
     # ---- correctness of what was timed (cheap): every window converged to the same cost as window 0 of its kind
     res = batch.download()
     final_costs = [r["summary"]["final_cost"] for r in res[: args.unique]]
@@ -204,10 +191,32 @@ def main():
         be.profile_enable(False)
     batch.free()
 
+    # ---- the same with the 1024 resident windows rounds 1 and 2 were quoted on (continuity of the series; not `value`)
+    # (after the main batch has been freed: its four pairs of streams go back to the pool and are the ones this batch runs on)
+    resident_1024 = None
+    if args.batch != 1024 and not shard:
+        b1k = be.batch_upload(batch_snaps[:1024] if args.batch >= 1024 else [snaps[i % args.unique] for i in range(1024)])
+        for _ in range(2):
+            b1k.solve(abi.MARGIN_OLD)
+        sync()
+        t1k = time.perf_counter()
+        n1k = max(args.steps // 2, 5)
+        for _ in range(n1k):
+            b1k.solve(abi.MARGIN_OLD)
+        sync()
+        s1k, e1k = gf.dist.aggregate_throughput(1024 * n1k, time.perf_counter() - t1k, dist if world > 1 else None)
+        resident_1024 = {"value": s1k / e1k, "unit": "solves/s", "windows_per_gpu": 1024, "steps": n1k}
+        b1k.free()
+
     # ---- end to end with fresh inputs every step (every rank; aggregated like `value`)
     e2e = None
     if not args.no_e2e and not shard:
-        e2e = end_to_end(args, be, gf, torch, dist if world > 1 else None, scns, snaps, final_costs)
+        o2 = abi.default_options()
+        o2.split_batch, o2.host_threads = args.e2e_split, args.host_threads
+        be2 = gf.Backend(device=local_rank, options=o2)          # (its own context: the parts a batch is solved in are a context option)
+        be2.set_stream(torch.cuda.current_stream().cuda_stream)
+        e2e = end_to_end(args, be2, gf, torch, dist if world > 1 else None, scns, snaps, final_costs)
+        be2.close()
 
     if rank == 0:
         roofline = roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters)
@@ -396,6 +405,7 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
 
     depth = args.e2e_depth
     out["batches_in_flight"] = depth
+    out["parts_per_batch"] = args.e2e_split
 
     def pipeline(upload):
         """`depth` batches in flight: while batch k solves, batch k+1 waits on the GPU with its inputs landed and batch k+2 is
