@@ -707,7 +707,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   }
   d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio;
   d.rank = c->rank; d.world = c->world; d.sharded = c->allreduce ? 1 : 0;
-  d.schur_groups = B >= DENSE_SPLIT_MIN_B ? SCHUR_GROUPS : NF;
+  d.schur_groups = B >= DENSE_SPLIT_MIN_B ? SCHUR_GROUPS : (c->allreduce ? NF : 2 * NF);
   d.test_fail_chol_iter = c->opt.test_fail_chol_iter;   // (test hook of the mu-retry path, 0 in production: gfbe_options)
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
@@ -752,7 +752,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
     AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
     AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36);
-    AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * NF * SCHUR_STRIDE);
+    AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * 2 * NF * SCHUR_STRIDE);
     AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
     AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
     AL(prior_g, (size_t)B * (ND + 2));
@@ -1151,7 +1151,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       // the partials of the landmarks that start in frame 0 are summed over the ranks before k_marg reads them
       launch_marginalize_partials(d, ln.s);
       run_allreduce(c, d.pair_part, (int64_t)d.B * NPAIR * VP_STRIDE, ln.s);
-      run_allreduce(c, d.schur_part, (int64_t)d.B * NF * SCHUR_STRIDE, ln.s);
+      run_allreduce(c, d.schur_part, (int64_t)d.B * 2 * NF * SCHUR_STRIDE, ln.s);
       launch_marginalize_finish(d, margin_flag, ln.s);
     } else {
       launch_marginalize(d, margin_flag, ln.s);

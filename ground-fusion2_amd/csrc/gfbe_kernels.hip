@@ -860,25 +860,28 @@ __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I 
 // One workgroup per (window, GROUP of start frames). Throughput batches (>= 32 windows): the landmark tiles of start frames {0, 1},
 // {2}, {3, 4, 5}, {6 .. 10} go through the same accumulators one after the other (a window's tiles are sorted by start frame: a
 // group is a contiguous range of tiles), so that a window leaves FOUR partials instead of eleven — k_assemble's gather of E reads 4
-// instead of 11 values per entry and two thirds of the partial stores are gone. Small batches keep one group per start frame: eleven
-// workgroups side by side are what a single window's latency wants. The marginalisation pass (start frame 0 alone) uses slot 0.
+// instead of 11 values per entry and two thirds of the partial stores are gone. Small batches keep one group per start frame and deal
+// its tiles over TWO workgroups (22 partials): a start frame of a 2k-landmark window has 4-5 tiles of ~3.5 us each, and a single
+// window's latency wants them side by side. The marginalisation pass (start frame 0 alone, one workgroup) uses slot 0.
 // (the groups follow the tile rows a start frame's landmarks can reach — I0 = 6 s / 16 steps at s = 3 and s = 6 — so that no group
 //  multiplies tile pairs its later start frames do not touch; work ~ tiles x pairs: {0,1} 30, {2} 15, {3,4,5} 30, {6..10} 12)
-__device__ __forceinline__ int schur_group_first(int g, int ng) { return ng == NF ? g : (g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 6))); }
+__device__ __forceinline__ int schur_group_first(int g, int ng) { return ng >= NF ? g : (g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 6))); }
 __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   const int w = blockIdx.x, grp = blockIdx.y;   // group-major dispatch: the heavy first group of every window first
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (!marg && (c.done || c.reuse)) return;
   if (marg && grp != 0) return;
-  const int ng = d.schur_groups;
-  const int s_first = schur_group_first(grp, ng), s_end = marg ? 1 : (grp == ng - 1 ? NF : schur_group_first(grp + 1, ng));
+  const int sub = (!marg && d.schur_groups == 2 * NF) ? 2 : 1;        // workgroups per start-frame group (small batches: two, tiles dealt alternately)
+  const int ng = marg ? NF : d.schur_groups / sub, half = grp % sub;
+  const int gi = grp / sub;
+  const int s_first = schur_group_first(gi, ng), s_end = marg ? 1 : (gi == ng - 1 ? NF : schur_group_first(gi + 1, ng));
   const int tb = ds.sf_tile_begin[s_first], te = ds.sf_tile_begin[s_end];
-  const int tfirst = tb + ((d.rank - tb) % d.world + d.world) % d.world;   // first tile of this rank (world 1: tb)
+  const int tfirst = sub == 2 ? tb + half : tb + ((d.rank - tb) % d.world + d.world) % d.world;   // first tile of this workgroup / rank (world 1: tb)
   if (tfirst >= te) {
     // solve: the partial stays zero (zeroed at upload; the structure never changes). Marginalisation: slot 0 may hold the solve's
     // partial of the group {0, 1} — no landmark (of this rank) starts in frame 0, so its Schur term is zero
-    if (marg) for (int q = threadIdx.x; q < SCHUR_STRIDE; q += 256) d.schur_part[((size_t)w * NF) * SCHUR_STRIDE + q] = 0.0;
+    if (marg) for (int q = threadIdx.x; q < SCHUR_STRIDE; q += 256) d.schur_part[((size_t)w * 2 * NF) * SCHUR_STRIDE + q] = 0.0;
     return;
   }
   __shared__ double hs[LM_TILE * HS_LD];
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   const bool stamp_wg = (w == 0 && grp == 0 && t == 0 && !marg);
   double *stamp = d.timing + 8;
   if (stamp_wg) { stamp[0] = (double)wall_clock64(); stamp[5] = (double)clock64(); }
-  const int tstep = d.world;
+  const int tstep = sub == 2 ? 2 : d.world;
   prefetch(tfirst);
   for (int tile = tfirst; tile < te; tile += tstep) {
     __syncthreads();
@@ -994,7 +997,7 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
 #undef SCHUR_SLOT
   }
   if (stamp_wg) { stamp[3] = (double)wall_clock64(); stamp[4] = (double)(te - tb); stamp[6] = (double)clock64(); }
-  double *out = d.schur_part + ((size_t)w * NF + grp) * SCHUR_STRIDE;
+  double *out = d.schur_part + ((size_t)w * 2 * NF + grp) * SCHUR_STRIDE;
 #define SCHUR_OUT(Q, ACC)                                                         \
   if (pI[Q] >= 0) {                                                               \
     double *o = out + (size_t)schur_pair(pI[Q], pJ[Q]) * 256;                     \
@@ -1135,7 +1138,7 @@ __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab
 // reaches the dims from its first start frame's pose on), loads unconditional in flight
 __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z, int w, int a, int b) {
   const int off = schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);
-  const double *sp = d.schur_part + (size_t)w * NF * SCHUR_STRIDE + off;
+  const double *sp = d.schur_part + (size_t)w * 2 * NF * SCHUR_STRIDE + off;
   const int ng = d.schur_groups;
   if (ng == SCHUR_GROUPS) {
     double v[SCHUR_GROUPS];
@@ -1146,12 +1149,21 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
     for (int f = 0; f < SCHUR_GROUPS; f++) s += v[f];
     return s;
   }
-  double v[NF];
+  if (ng == NF) {
+    double v[NF];
 #pragma unroll
-  for (int f = 0; f < NF; f++) v[f] = *(6 * f <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
+    for (int f = 0; f < NF; f++) v[f] = *(6 * f <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
+    double s = 0.0;
+#pragma unroll
+    for (int f = 0; f < NF; f++) s += v[f];
+    return s;
+  }
+  double v[2 * NF];           // small batches: two partials per start frame
+#pragma unroll
+  for (int f = 0; f < 2 * NF; f++) v[f] = *(6 * (f >> 1) <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
   double s = 0.0;
 #pragma unroll
-  for (int f = 0; f < NF; f++) s += v[f];
+  for (int f = 0; f < 2 * NF; f++) s += v[f];
   return s;
 }
 
