@@ -36,6 +36,7 @@ enum {
   ANCHOR_PART = 6 * 6 + 6 + 2,
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   LIN_SMALL_KS = 4,           // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
+  LIN_SMALL_THREADS = 256,    // k_lin_small: threads per workgroup (one wave per visual tile item, four for an inertial / wheel / prior item)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)

@@ -359,8 +359,11 @@ GF_HD mat3 get3(const double *A, int lda, int r0, int c0) {
 // IMU factor, un-whitened: raw[15] and (if Jraw) Jraw[15][30] (caller zero-fills), columns
 // pose_i(6) sb_i(9) pose_j(6) sb_j(9). Whitening by sqrt_info is done by the caller (in parallel).
 // ---------------------------------------------------------------------------------------------
+// part / nparts: the 18 non-zero 3 x 3 blocks of the Jacobian are dealt over `nparts` callers (block b belongs to part b % nparts;
+// part 0 also writes the residual): a small batch lets the four waves of a workgroup take a quarter of the blocks each — same
+// expressions per block, so the values do not depend on the split.
 GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose_i, const double *sb_i,
-                   const double *pose_j, const double *sb_j, double *raw, double *Jraw, size_t es = 1) {
+                   const double *pose_j, const double *sb_j, double *raw, double *Jraw, size_t es = 1, int part = 0, int nparts = 1) {
   const vec3 Pi = ld3(pose_i), Pj = ld3(pose_j);
   const quat Qi = ldq(pose_i + 3), Qj = ldq(pose_j + 3);
   const vec3 Vi = ld3(sb_i), Bai = ld3(sb_i + 3), Bgi = ld3(sb_i + 6);
@@ -382,30 +385,31 @@ GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose
   const vec3 rp = sub(a_p, cp);
   const vec3 rq = scl(2.0, qvec(qmul(qinv(cq), qmul(Qi_inv, Qj))));
   const vec3 rv = sub(a_v, cv);
-  for (int k = 0; k < 3; k++) {
-    raw[k * es] = rp[k]; raw[(3 + k) * es] = rq[k]; raw[(6 + k) * es] = rv[k];
-    raw[(9 + k) * es] = Baj[k] - Bai[k]; raw[(12 + k) * es] = Bgj[k] - Bgi[k];
-  }
+  if (part == 0)
+    for (int k = 0; k < 3; k++) {
+      raw[k * es] = rp[k]; raw[(3 + k) * es] = rq[k]; raw[(6 + k) * es] = rv[k];
+      raw[(9 + k) * es] = Baj[k] - Bai[k]; raw[(12 + k) * es] = Bgj[k] - Bgi[k];
+    }
   if (!Jraw) return;
   const mat3 I = ident3();
-  put3(Jraw, 30, 0, 0, mneg(RiT), es);                                                  // imu_factor.h:107
-  put3(Jraw, 30, 0, 3, hat(a_p), es);                                                   // :108
-  put3(Jraw, 30, 3, 3, mneg(qleft_qright3(qmul(qinv(Qj), Qi), cq)), es);                // :113-114
-  put3(Jraw, 30, 6, 3, hat(a_v), es);                                                   // :117
-  put3(Jraw, 30, 0, 6, mscl(-dt, RiT), es);                                             // :133
-  put3(Jraw, 30, 0, 9, mneg(dp_dba), es);
-  put3(Jraw, 30, 0, 12, mneg(dp_dbg), es);
-  put3(Jraw, 30, 3, 12, mneg(mul(qleft3(qmul(qmul(qinv(Qj), Qi), dq)), dq_dbg)), es);   // :142 (uncorrected delta_q)
-  put3(Jraw, 30, 6, 6, mneg(RiT), es);
-  put3(Jraw, 30, 6, 9, mneg(dv_dba), es);
-  put3(Jraw, 30, 6, 12, mneg(dv_dbg), es);
-  put3(Jraw, 30, 9, 9, mneg(I), es);
-  put3(Jraw, 30, 12, 12, mneg(I), es);
-  put3(Jraw, 30, 0, 15, RiT, es);                                                       // :162
-  put3(Jraw, 30, 3, 18, qleft3(qmul(qmul(qinv(cq), Qi_inv), Qj)), es);                  // :168
-  put3(Jraw, 30, 6, 21, RiT, es);                                                       // :179
-  put3(Jraw, 30, 9, 24, I, es);
-  put3(Jraw, 30, 12, 27, I, es);
+  if (0 % nparts == part) put3(Jraw, 30, 0, 0, mneg(RiT), es);                                                  // imu_factor.h:107
+  if (1 % nparts == part) put3(Jraw, 30, 0, 3, hat(a_p), es);                                                   // :108
+  if (2 % nparts == part) put3(Jraw, 30, 3, 3, mneg(qleft_qright3(qmul(qinv(Qj), Qi), cq)), es);                // :113-114
+  if (3 % nparts == part) put3(Jraw, 30, 6, 3, hat(a_v), es);                                                   // :117
+  if (4 % nparts == part) put3(Jraw, 30, 0, 6, mscl(-dt, RiT), es);                                             // :133
+  if (5 % nparts == part) put3(Jraw, 30, 0, 9, mneg(dp_dba), es);
+  if (6 % nparts == part) put3(Jraw, 30, 0, 12, mneg(dp_dbg), es);
+  if (7 % nparts == part) put3(Jraw, 30, 3, 12, mneg(mul(qleft3(qmul(qmul(qinv(Qj), Qi), dq)), dq_dbg)), es);   // :142 (uncorrected delta_q)
+  if (8 % nparts == part) put3(Jraw, 30, 6, 6, mneg(RiT), es);
+  if (9 % nparts == part) put3(Jraw, 30, 6, 9, mneg(dv_dba), es);
+  if (10 % nparts == part) put3(Jraw, 30, 6, 12, mneg(dv_dbg), es);
+  if (11 % nparts == part) put3(Jraw, 30, 9, 9, mneg(I), es);
+  if (12 % nparts == part) put3(Jraw, 30, 12, 12, mneg(I), es);
+  if (13 % nparts == part) put3(Jraw, 30, 0, 15, RiT, es);                                                       // :162
+  if (14 % nparts == part) put3(Jraw, 30, 3, 18, qleft3(qmul(qmul(qinv(cq), Qi_inv), Qj)), es);                  // :168
+  if (15 % nparts == part) put3(Jraw, 30, 6, 21, RiT, es);                                                       // :179
+  if (16 % nparts == part) put3(Jraw, 30, 9, 24, I, es);
+  if (17 % nparts == part) put3(Jraw, 30, 12, 27, I, es);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -675,7 +675,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
   if (mode == 1 && (c.done || !c.have_step)) return;
   const int buf = (mode == 1) ? 1 - c.cur : c.cur;
   const double *X = (mode >= 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, nthr = blockDim.x;      // (64 threads; 256 in k_lin_small: four waves share an inertial factor)
   __shared__ double raw[16], rw[16], Jraw[15 * 30], Jw[15 * 30], red[16];
   __shared__ double dx[ND], rp[ND];
 
@@ -685,16 +685,17 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     const int fi = ds.imu_frame[f];
     if (mode >= 2 && !(mode == 2 && fi == 0 && d.imu[ds.imu_off + f].sum_dt < 10.0)) { if (t == 0) part[IMU_PART - 2] = -1.0; return; }
     if (FUSED) {
-      for (int q = t; q < 450; q += 64) Jraw[q] = 0.0;
+      for (int q = t; q < 450; q += nthr) Jraw[q] = 0.0;
       __syncthreads();
-      if (t == 0)
+      // the scalar quaternion algebra of the factor: lane 0 of EVERY wave takes its share of the 18 Jacobian blocks
+      if ((t & 63) == 0 && (mode != 1 || t == 0))
         imu_raw(&d.imu[ds.imu_off + f], d.opt.g_norm, X + A_POSE(fi), X + A_SB(fi), X + A_POSE(fi + 1), X + A_SB(fi + 1), raw,
-                mode == 1 ? nullptr : Jraw);
+                mode == 1 ? nullptr : Jraw, 1, t >> 6, nthr >> 6);
     } else {   // raw residual / Jacobian of this factor from k_dense_raw (window-minor layout)
       const double *in = d.raw_imu + (size_t)f * RAW_IMU * d.B + w;
       if (t < 15) raw[t] = in[(size_t)t * d.B];
       if (mode != 1)
-        for (int q = t; q < 450; q += 64) Jraw[q] = imu_nz(q / 30, q % 30) ? in[(size_t)(15 + q) * d.B] : 0.0;
+        for (int q = t; q < 450; q += nthr) Jraw[q] = imu_nz(q / 30, q % 30) ? in[(size_t)(15 + q) * d.B] : 0.0;
     }
     __syncthreads();
     const double *S = d.imu_sqrt + (size_t)(ds.imu_off + f) * 225;   // upper triangular
@@ -707,7 +708,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     double cst = 0.0;
     if (t == 0) for (int a = 0; a < 15; a++) cst += 0.5 * rw[a] * rw[a];
     if (mode == 1) { if (t == 0) part[IMU_PART - 1] = cst; return; }
-    for (int e = t; e < 930; e += 64) {
+    for (int e = t; e < 930; e += nthr) {
       double s = 0.0;
       if (e < 900) { const int a = e / 30, b = e % 30; for (int r = 0; r < 15; r++) s += Jw[r * 30 + a] * Jw[r * 30 + b]; }
       else { const int a = e - 900; for (int r = 0; r < 15; r++) s += Jw[r * 30 + a] * rw[r]; }
@@ -716,7 +717,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     if (t == 0) part[IMU_PART - 2] = cst;
     if (debug_out) {
       double *dbg = d.dbg_imu + ((size_t)w * MAX_IMU + f) * (15 * 31);
-      for (int q = t; q < 450; q += 64) dbg[15 + q] = Jw[q];
+      for (int q = t; q < 450; q += nthr) dbg[15 + q] = Jw[q];
       if (t < 15) dbg[t] = rw[t];
     }
   } else if (f < MAX_IMU + MAX_WHEEL) {
@@ -726,7 +727,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     const int fi = ds.wheel_frame[k];
     if (mode >= 2 && !(mode == 2 && fi == 0 && d.wheel[ds.wheel_off + k].sum_dt < 10.0)) { if (t == 0) part[WHEEL_PART - 2] = -1.0; return; }
     if (FUSED) {
-      for (int q = t; q < 132; q += 64) Jraw[q] = 0.0;
+      for (int q = t; q < 132; q += nthr) Jraw[q] = 0.0;
       __syncthreads();
       if (t == 0)
         wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
@@ -735,7 +736,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
       const double *in = d.raw_wheel + (size_t)k * RAW_WHEEL * d.B + w;
       if (t < 6) raw[t] = in[(size_t)t * d.B];
       if (mode != 1)
-        for (int q = t; q < 132; q += 64) Jraw[q] = wheel_nz(q / 22, q % 22) ? in[(size_t)(6 + q) * d.B] : 0.0;
+        for (int q = t; q < 132; q += nthr) Jraw[q] = wheel_nz(q / 22, q % 22) ? in[(size_t)(6 + q) * d.B] : 0.0;
     }
     __syncthreads();
     const double *S = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
@@ -748,7 +749,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     double cst = 0.0;
     if (t == 0) for (int a = 0; a < 6; a++) cst += 0.5 * rw[a] * rw[a];
     if (mode == 1) { if (t == 0) part[WHEEL_PART - 1] = cst; return; }
-    for (int e = t; e < 506; e += 64) {
+    for (int e = t; e < 506; e += nthr) {
       double s = 0.0;
       if (e < 484) { const int a = e / 22, b = e % 22; for (int r = 0; r < 6; r++) s += Jw[r * 22 + a] * Jw[r * 22 + b]; }
       else { const int a = e - 484; for (int r = 0; r < 6; r++) s += Jw[r * 22 + a] * rw[r]; }
@@ -757,7 +758,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     if (t == 0) part[WHEEL_PART - 2] = cst;
     if (debug_out) {
       double *dbg = d.dbg_wheel + ((size_t)w * MAX_WHEEL + k) * (6 * 23);
-      for (int q = t; q < 132; q += 64) dbg[6 + q] = Jw[q];
+      for (int q = t; q < 132; q += nthr) dbg[6 + q] = Jw[q];
       if (t < 6) dbg[t] = rw[t];
     }
   } else if (f > MAX_IMU + MAX_WHEEL && f <= MAX_IMU + MAX_WHEEL + MAX_PLANE) {
@@ -772,7 +773,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     double cst = 0.0;
     if (t == 0) for (int a = 0; a < 3; a++) cst += 0.5 * raw[a] * raw[a];
     if (mode == 1) { if (t == 0) part[PLANE_PART - 1] = cst; return; }
-    for (int e = t; e < 272; e += 64) {
+    for (int e = t; e < 272; e += nthr) {
       double s = 0.0;
       if (e < 256) { const int a = e >> 4, b = e & 15; for (int r = 0; r < 3; r++) s += Jraw[r * 16 + a] * Jraw[r * 16 + b]; }
       else { const int a = e - 256; for (int r = 0; r < 3; r++) s += Jraw[r * 16 + a] * raw[r]; }
@@ -807,7 +808,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
     const double *r0 = d.prior_r0 + (size_t)w * ND;
     double cst = 0.0;
-    for (int i = t; i < n; i += 64) {
+    for (int i = t; i < n; i += nthr) {
       double s = r0[i];
       for (int k = 0; k < n; k++) s += J0[(size_t)i * n + k] * dx[k];
       rp[i] = s;
@@ -816,13 +817,13 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     cst = block_sum(cst, red);
     if (mode == 1) { if (t == 0) pg[ND + 1] = cst; return; }
     __syncthreads();
-    for (int k = t; k < n; k += 64) {
+    for (int k = t; k < n; k += nthr) {
       double s = 0.0;
       for (int i = 0; i < n; i++) s += J0[(size_t)i * n + k] * rp[i];
       pg[k] = s;
     }
     if (t == 0) pg[ND] = cst;
-    if (debug_out) for (int i = t; i < n; i += 64) d.dbg_prior[(size_t)w * ND + i] = rp[i];
+    if (debug_out) for (int i = t; i < n; i += nthr) d.dbg_prior[(size_t)w * ND + i] = rp[i];
   }
 }
 
@@ -835,10 +836,12 @@ __global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mod
 // prior factors of a linearisation (MODE 0) or of a candidate evaluation (MODE 1) in ONE launch — the ~35 us of a single
 // lane evaluating an IMU factor hide behind the visual tiles instead of following them on the stream.
 template <int MODE, bool FULL>
-__global__ __launch_bounds__(64, 1) void k_lin_small(BatchDev d) {
+__global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d) {
   const int w = blockIdx.x, y = blockIdx.y;
   constexpr int KS = MODE == 0 ? LIN_SMALL_KS : 1;      // (the cost-only pass is too short to gain: 9 -> 12 us when split)
-  if (y < d.max_tiles * KS) vis_body<MODE, FULL, KS>(d, 0, w, y / KS, y % KS);
+  // four waves per workgroup: a visual tile is one wave's work (the others leave at once); the inertial / wheel / prior items use
+  // all four — the single lane that evaluated an IMU factor was the longest chain of the launch
+  if (y < d.max_tiles * KS) { if (threadIdx.x < LM_TILE) vis_body<MODE, FULL, KS>(d, 0, w, y / KS, y % KS); }
   else dense_body<true>(d, MODE, 0, w, y - d.max_tiles * KS);
 }
 
@@ -1430,20 +1433,9 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 // =============================================================================================
 // k_lm_step: back-substitution of the eliminated landmarks and their share of the dogleg scalars.
 // =============================================================================================
-__global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
-  const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
-  const WinDesc &ds = d.desc[w];
-  if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
-  const WinCtl &c = d.ctl[w];
-  if (c.done || c.reuse) return;
-  __shared__ double sy[NV], sv[NV];
-  const int t = threadIdx.x;
-  for (int a = t; a < NV; a += LM_TILE) {
-    const double s = d.sp[(size_t)w * ND + a];
-    sy[a] = s * d.yp[(size_t)w * ND + a];
-    sv[a] = s * d.vp[(size_t)w * ND + a];
-  }
-  __syncthreads();
+// One landmark tile (64 lanes): sy / sv = the scaled Gauss-Newton step and Cauchy direction of the visual dims, staged by the caller.
+__device__ __forceinline__ void lm_step_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t,
+                                             const double *sy, const double *sv) {
   const int s0 = d.tile_start[ds.tile_off + tile];
   const int slot = ds.lm_off + tile * LM_TILE + t;
   const int info = d.lm_info[slot];
@@ -1485,6 +1477,22 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
     const double r = (q == 6) ? wave_max(p[q]) : wave_sum(p[q]);
     if (t == 0) out[q] = r;
   }
+}
+__global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
+  const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
+  const WinDesc &ds = d.desc[w];
+  if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
+  const WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  __shared__ double sy[NV], sv[NV];
+  const int t = threadIdx.x;
+  for (int a = t; a < NV; a += LM_TILE) {
+    const double s = d.sp[(size_t)w * ND + a];
+    sy[a] = s * d.yp[(size_t)w * ND + a];
+    sv[a] = s * d.vp[(size_t)w * ND + a];
+  }
+  __syncthreads();
+  lm_step_tile(d, ds, c, w, tile, t, sy, sv);
 }
 
 // =============================================================================================
@@ -1541,10 +1549,7 @@ __global__ __launch_bounds__(LM_TILE) void k_lam_mask(BatchDev d) {
   d.lam[(size_t)d.tot_lm + slot] = 0.0;
 }
 
-__global__ __launch_bounds__(64) void k_step(BatchDev d) {
-  const int w = blockIdx.x, lane = threadIdx.x;
-  const WinDesc &ds = d.desc[w];
-  WinCtl &c = d.ctl[w];
+__device__ __forceinline__ void step_body(const BatchDev &d, const WinDesc &ds, WinCtl &c, const int w, const int lane) {
   if (c.done) return;
   if (c.have_step == 2) {   // fresh linearisation: fold in the landmark shares (lanes stride the tiles; fixed tree order)
     double p[8];
@@ -1603,41 +1608,43 @@ __global__ __launch_bounds__(64) void k_step(BatchDev d) {
   c.invalid_steps = 0;
   c.have_step = 1;
 }
+__global__ __launch_bounds__(64) void k_step(BatchDev d) {
+  const int w = blockIdx.x;
+  step_body(d, d.desc[w], d.ctl[w], w, threadIdx.x);
+}
 
 // =============================================================================================
 // k_candidate: x_cand = x (+) s * (c1 v + c2 y). Blocks [0, max_tiles) landmarks, block max_tiles
 // the dense parameter blocks.
 // =============================================================================================
-__global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
-  const int w = blockIdx.y;
-  const WinDesc &ds = d.desc[w];
-  const WinCtl &c = d.ctl[w];
-  if (c.done || !c.have_step) return;
-  const int t = threadIdx.x;
+// landmark tile `tile` (64 lanes)
+__device__ __forceinline__ void candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t) {
   const size_t TL = d.tot_lm;
-  if ((int)blockIdx.x < d.max_tiles) {
-    const int tile = blockIdx.x;
-    if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
-    const int slot = ds.lm_off + tile * LM_TILE + t;
-    const int info = d.lm_info[slot];
-    const bool valid = (info >> 24) & 1;
-    const bool free_lm = valid && !((info >> 16) & 1) && ((info >> 8) & 0xff) > 0;
-    const double lam = d.lam[(size_t)c.cur * TL + slot];
-    double lc = lam, d2 = 0.0, n2 = 0.0;
-    if (free_lm) {
-      lc = lam + d.lm_sl[slot] * (c.c1 * d.lm_vl[slot] + c.c2 * d.lm_yl[slot]);
-      d2 = (lam - lc) * (lam - lc);
-      n2 = lc * lc;
-    }
-    d.lam[(size_t)(1 - c.cur) * TL + slot] = lc;
-    d2 = wave_sum(d2); n2 = wave_sum(n2);
-    if (t == 0) {
-      double *o = d.tile_cand + ((size_t)w * d.max_tiles + tile) * 4;
-      o[1] = d2; o[2] = n2;
-    }
-  } else {
-    const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
-    double *Y = d.x + ((size_t)w * 2 + 1 - c.cur) * NA;
+  const int slot = ds.lm_off + tile * LM_TILE + t;
+  const int info = d.lm_info[slot];
+  const bool valid = (info >> 24) & 1;
+  const bool free_lm = valid && !((info >> 16) & 1) && ((info >> 8) & 0xff) > 0;
+  const double lam = d.lam[(size_t)c.cur * TL + slot];
+  double lc = lam, d2 = 0.0, n2 = 0.0;
+  if (free_lm) {
+    lc = lam + d.lm_sl[slot] * (c.c1 * d.lm_vl[slot] + c.c2 * d.lm_yl[slot]);
+    d2 = (lam - lc) * (lam - lc);
+    n2 = lc * lc;
+  }
+  d.lam[(size_t)(1 - c.cur) * TL + slot] = lc;
+  d2 = wave_sum(d2); n2 = wave_sum(n2);
+  if (t == 0) {
+    double *o = d.tile_cand + ((size_t)w * d.max_tiles + tile) * 4;
+    o[1] = d2; o[2] = n2;
+  }
+}
+// the dense parameter blocks (one wave; sp_cand: NF + 1 PoseRT of LDS; contains a block barrier: call it from every thread of the
+// workgroup or from a one-wave workgroup)
+__device__ __forceinline__ void candidate_dense(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int t, PoseRT *sp_cand,
+                                                const bool my_wave) {
+  const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
+  double *Y = d.x + ((size_t)w * 2 + 1 - c.cur) * NA;
+  if (my_wave) {
     double d2 = 0.0, n2 = 0.0;
     if (t < GFBE_BLK_COUNT) {
       const int b = t, off = blk_tan(b), am = blk_amb(b), gs = blk_gsize(b);
@@ -1664,11 +1671,25 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
     }
     d2 = wave_sum(d2); n2 = wave_sum(n2);
     if (t == 0) { d.dense_cand[(size_t)w * 4 + 1] = d2; d.dense_cand[(size_t)w * 4 + 2] = n2; }
-    // the candidate's pose-pair constants, for its cost evaluation and — if it is accepted — the next linearisation
-    __shared__ PoseRT sp_cand[NF + 1];
     __threadfence_block();
-    __syncthreads();
-    pair_consts_of_state(Y, d.pc + ((size_t)w * 3 + (1 - c.cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
+  }
+  // the candidate's pose-pair constants, for its cost evaluation and — if it is accepted — the next linearisation
+  __syncthreads();
+  if (my_wave) pair_consts_of_state(Y, d.pc + ((size_t)w * 3 + (1 - c.cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
+}
+__global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
+  const int w = blockIdx.y;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (c.done || !c.have_step) return;
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x < d.max_tiles) {
+    const int tile = blockIdx.x;
+    if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
+    candidate_tile(d, ds, c, w, tile, t);
+  } else {
+    __shared__ PoseRT sp_cand[NF + 1];
+    candidate_dense(d, ds, c, w, t, sp_cand, true);
   }
 }
 
@@ -1867,7 +1888,7 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s) {
-  const dim3 g(d.B, d.max_tiles * (mode == 0 ? LIN_SMALL_KS : 1) + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LM_TILE);
+  const dim3 g(d.B, d.max_tiles * (mode == 0 ? LIN_SMALL_KS : 1) + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LIN_SMALL_THREADS);
   if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d);
   else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d);
   else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d);
