@@ -10,7 +10,8 @@ import numpy as np
 
 WINDOW_SIZE = 10
 NFRAMES = 11
-DENSE_DIM = 187
+DENSE_DIM = 246
+CORE_DIM = 187      # the tangent dims without the GNSS blocks
 MAX_PRIOR_BLOCKS = 32
 PRIOR_X0_CAP = NFRAMES * 16 + 32
 
@@ -18,7 +19,8 @@ OK, NO_CONVERGENCE, NUMERICAL_FAILURE, BAD_INPUT, DEVICE_ERROR, NO_DEVICE = rang
 MARGIN_OLD, MARGIN_SECOND_NEW, MARGIN_NONE = 0, 1, 2
 
 BLK_POSE0, BLK_SB0, BLK_EX_CAM, BLK_EX_WHEEL = 0, 11, 22, 23
-BLK_SX, BLK_SY, BLK_SW, BLK_TD, BLK_TD_WHEEL, BLK_PLANE_R, BLK_PLANE_Z, BLK_COUNT = 24, 25, 26, 27, 28, 29, 30, 31
+BLK_SX, BLK_SY, BLK_SW, BLK_TD, BLK_TD_WHEEL, BLK_PLANE_R, BLK_PLANE_Z = 24, 25, 26, 27, 28, 29, 30
+BLK_ANC_ECEF, BLK_YAW_ENU, BLK_RCV_DT0, BLK_RCV_DDT0, BLK_COUNT = 31, 32, 33, 77, 88     # GNSS blocks (rcv_dt: + 4 frame + constellation)
 
 c_d = C.c_double
 c_i = C.c_int32
@@ -37,12 +39,38 @@ def block_global_size(bid):
         return 7
     if bid == BLK_PLANE_R:
         return 4
+    if bid == BLK_ANC_ECEF:
+        return 3
     return 1
+
+
+def block_tangent_offset(bid):
+    """First tangent dim of block `bid` in the DENSE_DIM-wide layout of the solver."""
+    if bid < BLK_SB0:
+        return 6 * bid
+    if bid < BLK_EX_CAM:
+        return 73 + 9 * (bid - BLK_SB0)
+    if bid >= BLK_RCV_DDT0:
+        return 235 + (bid - BLK_RCV_DDT0)
+    if bid >= BLK_RCV_DT0:
+        return 191 + (bid - BLK_RCV_DT0)
+    return {BLK_EX_CAM: 66, BLK_TD: 72, BLK_EX_WHEEL: 172, BLK_SX: 178, BLK_SY: 179, BLK_SW: 180, BLK_TD_WHEEL: 181, BLK_PLANE_R: 182,
+            BLK_PLANE_Z: 186, BLK_ANC_ECEF: 187, BLK_YAW_ENU: 190}[bid]
 
 
 def block_local_size(bid):
     g = block_global_size(bid)
     return 6 if g == 7 else g
+
+
+class GnssObs(C.Structure):
+    _fields_ = [("sv_pos", c_d * 3), ("sv_vel", c_d * 3), ("svdt", c_d), ("svddt", c_d), ("tgd", c_d), ("pr_uura", c_d), ("dp_uura", c_d),
+                ("psr", c_d), ("dopp", c_d), ("wavelength", c_d), ("ratio", c_d), ("doy", c_d), ("tow", c_d),
+                ("frame", c_i), ("lower_idx", c_i), ("sys_idx", c_i), ("_pad", c_i)]
+
+
+class GnssState(C.Structure):
+    _fields_ = [("rcv_dt", (c_d * 4) * NFRAMES), ("rcv_ddt", c_d * NFRAMES), ("yaw_enu_local", c_d), ("anc_ecef", c_d * 3)]
 
 
 class State(C.Structure):
@@ -54,7 +82,8 @@ class State(C.Structure):
                 ("para_Td", c_d),
                 ("para_Td_wheel", c_d),
                 ("para_plane_R", c_d * 4),
-                ("para_plane_Z", c_d)]
+                ("para_plane_Z", c_d),
+                ("gnss", GnssState)]
 
 
 class ImuPreint(C.Structure):
@@ -106,7 +135,9 @@ class Window(C.Structure):
                 ("vis", Visual),
                 ("prior", C.POINTER(Prior)),
                 ("lio", LioBlock),
-                ("plane_noise_inv", c_d * 3), ("anchor_pose", c_d * 7), ("anchor_sqrt_info", c_d)]
+                ("plane_noise_inv", c_d * 3), ("anchor_pose", c_d * 7), ("anchor_sqrt_info", c_d),
+                ("gnss_ready", c_i), ("n_gnss", c_i), ("gnss_obs", C.POINTER(GnssObs)), ("gnss_iono", PD),
+                ("gnss_frame_dt", c_d * WINDOW_SIZE), ("gnss_ddt_weight", c_d)]
 
 
 class Options(C.Structure):
@@ -188,6 +219,14 @@ def state_from_snapshot(snap, st=None):
     st.para_Td_wheel = float(snap["td_wheel"])
     st.para_plane_R[:] = _f64(snap.get("plane_R", [0.0, 0.0, 0.0, 1.0])).tolist()
     st.para_plane_Z = float(snap.get("plane_Z", 0.0))
+    g = snap.get("gnss_state")
+    if g is not None:
+        rd = _f64(g["rcv_dt"]).reshape(NFRAMES, 4)
+        for i in range(NFRAMES):
+            st.gnss.rcv_dt[i][:] = rd[i].tolist()
+        st.gnss.rcv_ddt[:] = _f64(g["rcv_ddt"]).tolist()
+        st.gnss.yaw_enu_local = float(g["yaw_enu_local"])
+        st.gnss.anc_ecef[:] = _f64(g["anc_ecef"]).tolist()
     return st
 
 
@@ -202,6 +241,8 @@ def state_to_dict(st):
         "td_wheel": float(st.para_Td_wheel),
         "plane_R": np.array(list(st.para_plane_R)),
         "plane_Z": float(st.para_plane_Z),
+        "gnss_state": {"rcv_dt": np.array([list(st.gnss.rcv_dt[i]) for i in range(NFRAMES)]), "rcv_ddt": np.array(list(st.gnss.rcv_ddt)),
+                       "yaw_enu_local": float(st.gnss.yaw_enu_local), "anc_ecef": np.array(list(st.gnss.anc_ecef))},
     }
 
 
@@ -278,6 +319,18 @@ class WindowHolder:
             w.use_anchor = 1
             w.anchor_pose[:] = _f64(an["pose"]).tolist()
             w.anchor_sqrt_info = float(an.get("sqrt_info", 120.0))
+        # GNSS inside the window: snap["gnss"] = dict(obs=[dicts as for gnss_eval], iono=[8] or None, frame_dt=[10], ddt_weight, ready=1);
+        # the GNSS state blocks travel in snap["gnss_state"]
+        gn = snap.get("gnss")
+        if gn is not None:
+            self.gnss_obs = gnss_obs_array(gn["obs"])
+            self.gnss_iono = _f64(gn["iono"]) if gn.get("iono") is not None else None
+            w.gnss_ready, w.n_gnss = int(gn.get("ready", 1)), len(gn["obs"])
+            w.gnss_obs = self.gnss_obs
+            if self.gnss_iono is not None:
+                w.gnss_iono = _pd(self.gnss_iono)
+            w.gnss_frame_dt[:] = _f64(gn["frame_dt"]).tolist()
+            w.gnss_ddt_weight = float(gn["ddt_weight"])
         # IMU / wheel
         self.imu = _f64(snap.get("imu", np.zeros((0, IMU_DOUBLES)))).reshape(-1, IMU_DOUBLES)
         self.imu_frame = _i32(snap.get("imu_frame", np.zeros(0)))
@@ -760,28 +813,24 @@ def orientation_subset_plus(lib, prefix, q, delta, constant=(0, 0, 1)):
 # ---------------------------------------------------------------------------------------------
 # f2: GNSS factors, evaluation only (gfbe_gnss_eval)
 # ---------------------------------------------------------------------------------------------
-class GnssObs(C.Structure):
-    _fields_ = [("sv_pos", c_d * 3), ("sv_vel", c_d * 3), ("svdt", c_d), ("svddt", c_d), ("tgd", c_d), ("pr_uura", c_d), ("dp_uura", c_d),
-                ("psr", c_d), ("dopp", c_d), ("wavelength", c_d), ("ratio", c_d), ("doy", c_d), ("tow", c_d),
-                ("frame", c_i), ("lower_idx", c_i), ("sys_idx", c_i), ("_pad", c_i)]
-
-
-class GnssState(C.Structure):
-    _fields_ = [("rcv_dt", (c_d * 4) * NFRAMES), ("rcv_ddt", c_d * NFRAMES), ("yaw_enu_local", c_d), ("anc_ecef", c_d * 3)]
-
-
 GNSS_OBS_KEYS = ("svdt", "svddt", "tgd", "pr_uura", "dp_uura", "psr", "dopp", "wavelength", "ratio", "doy", "tow", "frame", "lower_idx", "sys_idx")
 
 
-def gnss_eval(lib, prefix, ctx, obs, iono, pose, speed_bias, rcv_dt, rcv_ddt, yaw_enu_local, anc_ecef, frame_dt, ddt_weight, want_J=True):
-    """obs: list of dicts with sv_pos, sv_vel and GNSS_OBS_KEYS. pose [11][7], speed_bias [11][9] (the window state's blocks)."""
-    n = len(obs)
-    arr = (GnssObs * max(n, 1))()
+def gnss_obs_array(obs):
+    """list of dicts with sv_pos, sv_vel and GNSS_OBS_KEYS -> ctypes array of gfbe_gnss_obs"""
+    arr = (GnssObs * max(len(obs), 1))()
     for k, o in enumerate(obs):
         arr[k].sv_pos[:] = [float(x) for x in o["sv_pos"]]
         arr[k].sv_vel[:] = [float(x) for x in o["sv_vel"]]
         for key in GNSS_OBS_KEYS:
             setattr(arr[k], key, o[key])
+    return arr
+
+
+def gnss_eval(lib, prefix, ctx, obs, iono, pose, speed_bias, rcv_dt, rcv_ddt, yaw_enu_local, anc_ecef, frame_dt, ddt_weight, want_J=True):
+    """obs: list of dicts with sv_pos, sv_vel and GNSS_OBS_KEYS. pose [11][7], speed_bias [11][9] (the window state's blocks)."""
+    n = len(obs)
+    arr = gnss_obs_array(obs)
     st = State()
     p, sb = _f64(pose).reshape(NFRAMES, 7), _f64(speed_bias).reshape(NFRAMES, 9)
     for i in range(NFRAMES):

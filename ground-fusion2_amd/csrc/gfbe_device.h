@@ -15,9 +15,10 @@ namespace gfd {
 // ---- dimensions -----------------------------------------------------------------------------
 enum {
   NF = GFBE_NFRAMES,          // 11 frames
-  ND = GFBE_DENSE_DIM,        // 187 tangent dims of the dense (pose / IMU / extrinsic / ground plane) block
+  ND = GFBE_DENSE_DIM,        // 246 tangent dims of the dense (pose / IMU / extrinsic / ground plane / GNSS) blocks: every row stride
+  NC = GFBE_CORE_DIM,         // 187 of them without the GNSS blocks: BatchDev::nu is NC for a batch without GNSS windows, ND with
   NV = 73,                    // leading dims visual factors touch: 11 poses * 6 + ex_cam 6 + td 1
-  NA = 200,                   // ambient doubles of gfbe_state
+  NA = 259,                   // ambient doubles of gfbe_state
   MAXOBS = 10,                // factors per landmark (n_obs - 1)
   REC = 42,                   // doubles per visual block-CSR record: r(2) + J(2 x 20)   = 336 B
   NPAIR = NF * NF,            // (imu_i, imu_j) pair slots, index i * 11 + j
@@ -49,17 +50,25 @@ enum {
 __host__ __device__ inline int T_POSE(int k) { return 6 * k; }
 enum { T_EX = 66, T_TD = 72, T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181,
        T_PLR = 182,          // para_plane_R: three tangent dims + the quaternion's 4th slot (185), which only ever exists in the prior
-       T_PLZ = 186 };
+       T_PLZ = 186,
+       T_ANC = 187, T_YAW = 190 };   // para_anc_ecef (3), para_yaw_enu_local; then rcv_dt[11][4] and rcv_ddt[11]
+__host__ __device__ inline int T_DT(int i, int k) { return 191 + 4 * i + k; }
+__host__ __device__ inline int T_DDT(int i) { return 235 + i; }
 __host__ __device__ inline int T_SB(int k) { return 73 + 9 * k; }
 // ambient offsets inside gfbe_state (195 doubles)
 __host__ __device__ inline int A_POSE(int k) { return 7 * k; }
 __host__ __device__ inline int A_SB(int k) { return 77 + 9 * k; }
-enum { A_EX = 176, A_EXW = 183, A_IX = 190, A_TD = 193, A_TDW = 194, A_PLR = 195, A_PLZ = 199 };
+enum { A_EX = 176, A_EXW = 183, A_IX = 190, A_TD = 193, A_TDW = 194, A_PLR = 195, A_PLZ = 199,
+       A_DT = 200, A_DDT = 244, A_YAW = 255, A_ANC = 256 };   // gfbe_state::gnss: rcv_dt[11][4], rcv_ddt[11], yaw_enu_local, anc_ecef[3]
 
 __host__ __device__ inline int blk_tan(int id) {
   if (id < GFBE_BLK_SB0) return T_POSE(id);
   if (id < GFBE_BLK_EX_CAM) return T_SB(id - GFBE_BLK_SB0);
+  if (id >= GFBE_BLK_RCV_DDT0) return T_DDT(id - GFBE_BLK_RCV_DDT0);
+  if (id >= GFBE_BLK_RCV_DT0) return T_DT(0, id - GFBE_BLK_RCV_DT0);
   switch (id) {
+    case GFBE_BLK_ANC_ECEF: return T_ANC;
+    case GFBE_BLK_YAW_ENU: return T_YAW;
     case GFBE_BLK_EX_CAM: return T_EX;
     case GFBE_BLK_EX_WHEEL: return T_EXW;
     case GFBE_BLK_SX: return T_SX;
@@ -74,7 +83,11 @@ __host__ __device__ inline int blk_tan(int id) {
 __host__ __device__ inline int blk_amb(int id) {
   if (id < GFBE_BLK_SB0) return A_POSE(id);
   if (id < GFBE_BLK_EX_CAM) return A_SB(id - GFBE_BLK_SB0);
+  if (id >= GFBE_BLK_RCV_DDT0) return A_DDT + (id - GFBE_BLK_RCV_DDT0);
+  if (id >= GFBE_BLK_RCV_DT0) return A_DT + (id - GFBE_BLK_RCV_DT0);
   switch (id) {
+    case GFBE_BLK_ANC_ECEF: return A_ANC;
+    case GFBE_BLK_YAW_ENU: return A_YAW;
     case GFBE_BLK_EX_CAM: return A_EX;
     case GFBE_BLK_EX_WHEEL: return A_EXW;
     case GFBE_BLK_SX: return A_IX;
@@ -91,6 +104,7 @@ __host__ __device__ inline int blk_gsize(int id) {
   if (id < GFBE_BLK_EX_CAM) return 9;
   if (id == GFBE_BLK_EX_CAM || id == GFBE_BLK_EX_WHEEL) return 7;
   if (id == GFBE_BLK_PLANE_R) return 4;
+  if (id == GFBE_BLK_ANC_ECEF) return 3;
   return 1;
 }
 // (para_plane_R: local size 4 like MarginalizationInfo::localSize gives every block that is not 7 wide — the solve keeps its

@@ -206,10 +206,10 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
   __shared__ PoseRT sp_reset[NF + 1];
   if (blockIdx.x == 0) {
     pair_consts_of_state(d.x0 + (size_t)w * NA, d.pc + (size_t)w * 3 * NPAIR * PC_DOUBLES, sp_reset, threadIdx.x);   // (block-uniform branch: the barrier inside is safe)
-    if (threadIdx.x < NA) {
-      const double v = d.x0[(size_t)w * NA + threadIdx.x];
-      d.x[((size_t)w * 2) * NA + threadIdx.x] = v;
-      d.x[((size_t)w * 2 + 1) * NA + threadIdx.x] = v;
+    for (int q = threadIdx.x; q < NA; q += blockDim.x) {
+      const double v = d.x0[(size_t)w * NA + q];
+      d.x[((size_t)w * 2) * NA + q] = v;
+      d.x[((size_t)w * 2 + 1) * NA + q] = v;
     }
     if (threadIdx.x == 0) {
       WinCtl c;

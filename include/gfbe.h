@@ -29,8 +29,10 @@ extern "C" {
 #define GFBE_WINDOW_SIZE 10 /* parameters.h:24 */
 #define GFBE_NFRAMES 11     /* WINDOW_SIZE + 1 */
 #define GFBE_MAX_OBS 11     /* a landmark has at most one observation per frame */
-#define GFBE_DENSE_DIM 187  /* 11*6 + 11*9 + 6 + 6 + 3 + 1 + 1 tangent dims + 4 + 1 of the ground plane (para_plane_R is
-                               marginalised as a 4-D block without a manifold, marginalization_factor.cpp:140-143: four prior columns) */
+#define GFBE_DENSE_DIM 246  /* tangent dims of the non-landmark blocks: 11*6 + 11*9 + 6 + 6 + 3 + 1 + 1 + 4 + 1 of the ground
+                               plane (para_plane_R is marginalised as a 4-D block without a manifold, marginalization_factor.cpp:140-143:
+                               four prior columns) = 187, + 3 + 1 + 44 + 11 of the GNSS blocks (anc_ecef, yaw_enu_local, rcv_dt, rcv_ddt) */
+#define GFBE_CORE_DIM 187   /* the tangent dims without the GNSS blocks */
 #define GFBE_MAX_PRIOR_BLOCKS 32
 
 typedef enum gfbe_status {
@@ -54,8 +56,35 @@ enum {
   GFBE_BLK_TD_WHEEL = 28, /* para_Td_wheel size 1 */
   GFBE_BLK_PLANE_R = 29,  /* para_plane_R  size 4 (quaternion x y z w, OrientationSubsetParameterization({2}): estimator.cpp:3120-3123) */
   GFBE_BLK_PLANE_Z = 30,  /* para_plane_Z  size 1 */
-  GFBE_BLK_COUNT = 31
+  /* GNSS blocks (estimator.h:306-309, estimator.cpp:2965-3002; only in the problem when gfbe_window.gnss_ready) */
+  GFBE_BLK_ANC_ECEF = 31, /* para_anc_ecef       size 3 */
+  GFBE_BLK_YAW_ENU = 32,  /* para_yaw_enu_local  size 1 — always SetParameterBlockConstant (estimator.cpp:2991) */
+  GFBE_BLK_RCV_DT0 = 33,  /* .. +43: para_rcv_dt + 4 i + k (frame i, constellation k)  size 1 */
+  GFBE_BLK_RCV_DDT0 = 77, /* .. +10: para_rcv_ddt + i                                  size 1 */
+  GFBE_BLK_COUNT = 88
 };
+
+/* One GNSS observation of the window with everything GnssPsrDoppFactor's constructor derives from it (see f2 below). */
+typedef struct gfbe_gnss_obs {
+  double sv_pos[3], sv_vel[3];   /* satellite ECEF position / velocity at transmission time (:20-35) */
+  double svdt, svddt, tgd;       /* satellite clock bias (s), drift (s/s), group delay (s) */
+  double pr_uura, dp_uura;       /* pseudo-range / Doppler deviation scalings (:24-26, :38-40) */
+  double psr, dopp;              /* obs->psr[freq_idx] (m), obs->dopp[freq_idx] (Hz) */
+  double wavelength;             /* LIGHT_SPEED / freq (m) */
+  double ratio;                  /* ts_ratio (estimator.cpp:3262): weight of frame lower_idx against lower_idx + 1 */
+  double doy, tow;               /* time2doy(obs->time), time2gpst(obs->time): the atmosphere models' time arguments */
+  int32_t frame;                 /* i of gnss_meas_buf[i]: uses rcv_dt[i][sys_idx] and rcv_ddt[i] */
+  int32_t lower_idx;             /* the factor connects Pose / SpeedBias lower_idx and lower_idx + 1 */
+  int32_t sys_idx;               /* gnss_comm::sys2idx: 0 GPS, 1 GLO, 2 GAL, 3 BDS */
+  int32_t _pad;
+} gfbe_gnss_obs;
+
+typedef struct gfbe_gnss_state {   /* estimator.h: para_rcv_dt, para_rcv_ddt, para_yaw_enu_local, para_anc_ecef */
+  double rcv_dt[GFBE_WINDOW_SIZE + 1][4];
+  double rcv_ddt[GFBE_WINDOW_SIZE + 1];
+  double yaw_enu_local;
+  double anc_ecef[3];
+} gfbe_gnss_state;
 
 /* The dense ("camera side") parameter blocks of one window — what vector2double() fills
  * (estimator.cpp:2337-2414) and double2vector() reads back (estimator.cpp:2501-2630). */
@@ -69,7 +98,8 @@ typedef struct gfbe_state {
   double para_Td_wheel;
   double para_plane_R[4];        /* ground plane in the world: rotation (x y z w) and height (estimator.h:233-236); used with use_plane */
   double para_plane_Z;
-} gfbe_state; /* 200 doubles */
+  gfbe_gnss_state gnss;          /* para_rcv_dt, para_rcv_ddt, para_yaw_enu_local, para_anc_ecef; used with gnss_ready */
+} gfbe_state; /* 259 doubles */
 
 /* What IMUFactor reads from IntegrationBase (imu_factor.h:69-90, integration_base.h:169-195). */
 typedef struct gfbe_imu_preint {
@@ -175,6 +205,22 @@ typedef struct gfbe_window {
   double plane_noise_inv[3];    /* PITCH_N_INV, ROLL_N_INV, ZPW_N_INV (parameters.cpp:340-345) */
   double anchor_pose[7];        /* PoseAnchorFactor's anchor_value (para_Pose[0] at the first optimisation) */
   double anchor_sqrt_info;      /* 120 in the reference (pose_anchor_factor.h:19) */
+  /* GNSS inside the window (estimator.cpp:2965-3002, 3239-3291, 3462-3496; gnss_enable: 0 in every shipped yaml).
+   *   gnss_ready  the blocks para_yaw_enu_local (held constant, :2991), para_anc_ecef, para_rcv_dt[11][4], para_rcv_ddt[11] join the
+   *               problem. Unless the window moves too slowly — mean |Vs[i].xy| over the window below 0.3 m/s at the start of the
+   *               call, `lowspeed`, :2969-2984, computed by the library from `state` — one GnssPsrDoppFactor per observation, one
+   *               DtDdtFactor per constellation and frame interval and one DdtSmoothFactor per interval are added (:3239-3291).
+   *               MARGIN_OLD takes the factors of frame 0 with the drop sets of :3462-3496 whether the window is slow or not.
+   *   gnss_obs    the n_gnss observations of gnss_meas_buf[0 .. WINDOW_SIZE] in the reference's insertion order (frame-major);
+   *               `frame`, `lower_idx`, `ratio`, `sys_idx` as :3250-3263 computes them (frame 0 always has lower_idx 0).
+   *   gnss_iono   latest_gnss_iono_params (8 Klobuchar parameters) or NULL; gnss_frame_dt[i] = Headers[i + 1] - Headers[i];
+   *               gnss_ddt_weight = GNSS_DDT_WEIGHT. The GNSS state travels in `state.gnss` and comes back in out_state->gnss. */
+  int32_t gnss_ready;
+  int32_t n_gnss;
+  const gfbe_gnss_obs *gnss_obs;
+  const double *gnss_iono;
+  double gnss_frame_dt[GFBE_WINDOW_SIZE];
+  double gnss_ddt_weight;
 } gfbe_window;
 
 typedef struct gfbe_options {
@@ -458,26 +504,7 @@ void gfbe_orientation_subset_plus(const double *q /*[4] x y z w*/, const double 
  *     broadcast ephemeris (gnss_psr_dopp_factor.cpp:3-47: eph2pos / geph2pos / eph2svdt at the transmission time, the
  *     group delay, the URA scalings) is front-end work and crosses the boundary precomputed in gfbe_gnss_obs.
  * ------------------------------------------------------------------------------------------ */
-typedef struct gfbe_gnss_obs {
-  double sv_pos[3], sv_vel[3];   /* satellite ECEF position / velocity at transmission time (:20-35) */
-  double svdt, svddt, tgd;       /* satellite clock bias (s), drift (s/s), group delay (s) */
-  double pr_uura, dp_uura;       /* pseudo-range / Doppler deviation scalings (:24-26, :38-40) */
-  double psr, dopp;              /* obs->psr[freq_idx] (m), obs->dopp[freq_idx] (Hz) */
-  double wavelength;             /* LIGHT_SPEED / freq (m) */
-  double ratio;                  /* ts_ratio (estimator.cpp:3262): weight of frame lower_idx against lower_idx + 1 */
-  double doy, tow;               /* time2doy(obs->time), time2gpst(obs->time): the atmosphere models' time arguments */
-  int32_t frame;                 /* i of gnss_meas_buf[i]: uses rcv_dt[i][sys_idx] and rcv_ddt[i] */
-  int32_t lower_idx;             /* the factor connects Pose / SpeedBias lower_idx and lower_idx + 1 */
-  int32_t sys_idx;               /* gnss_comm::sys2idx: 0 GPS, 1 GLO, 2 GAL, 3 BDS */
-  int32_t _pad;
-} gfbe_gnss_obs;
-
-typedef struct gfbe_gnss_state {   /* estimator.h: para_rcv_dt, para_rcv_ddt, para_yaw_enu_local, para_anc_ecef */
-  double rcv_dt[GFBE_WINDOW_SIZE + 1][4];
-  double rcv_ddt[GFBE_WINDOW_SIZE + 1];
-  double yaw_enu_local;
-  double anc_ecef[3];
-} gfbe_gnss_state;
+/* (gfbe_gnss_obs and gfbe_gnss_state are defined with gfbe_state near the top of this header) */
 
 /* One thread per factor. iono: the 8 Klobuchar parameters (latest_gnss_iono_params) or NULL (no ionosphere term).
  * frame_dt[i] = Headers[i+1] - Headers[i]. Outputs (any may be NULL):

@@ -21,7 +21,11 @@ const double *block_ptr(const gfbe_state &st, int id) {
     case GFBE_BLK_TD_WHEEL: return &st.para_Td_wheel;
     case GFBE_BLK_PLANE_R: return st.para_plane_R;
     case GFBE_BLK_PLANE_Z: return &st.para_plane_Z;
+    case GFBE_BLK_ANC_ECEF: return st.gnss.anc_ecef;
+    case GFBE_BLK_YAW_ENU: return &st.gnss.yaw_enu_local;
   }
+  if (id >= GFBE_BLK_RCV_DT0 && id < GFBE_BLK_RCV_DDT0) return &st.gnss.rcv_dt[0][0] + (id - GFBE_BLK_RCV_DT0);
+  if (id >= GFBE_BLK_RCV_DDT0 && id < GFBE_BLK_COUNT) return &st.gnss.rcv_ddt[id - GFBE_BLK_RCV_DDT0];
   return nullptr;
 }
 double *block_ptr(gfbe_state &st, int id) { return const_cast<double *>(block_ptr(const_cast<const gfbe_state &>(st), id)); }
@@ -31,6 +35,7 @@ int block_global_size(int id) {
   if (id == GFBE_BLK_EX_CAM || id == GFBE_BLK_EX_WHEEL) return 7;
   if (id == GFBE_BLK_PLANE_R) return 4;   // (local size 4 as well: MarginalizationInfo::localSize only knows size-7 manifolds,
                                           //  marginalization_factor.cpp:140-143; the solve leaves the 4th tangent slot inactive)
+  if (id == GFBE_BLK_ANC_ECEF) return 3;
   return 1;
 }
 int block_local_size(int id) { int g = block_global_size(id); return g == 7 ? 6 : g; }

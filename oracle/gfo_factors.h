@@ -42,4 +42,9 @@ double *block_ptr(gfbe_state &st, int id);
 int block_global_size(int id);
 int block_local_size(int id);
 
+// GnssPsrDoppFactor::Evaluate for one observation (gfo_gnss.cpp). r[2]; J[2][18] or null: columns P_i(3) V_i(3) P_j(3) V_j(3)
+// rcv_dt rcv_ddt yaw_enu_local anc_ecef(3).
+void eval_gnss_psr_dopp(const gfbe_gnss_obs &o, const double *iono, const double *pi, const double *vi, const double *pj, const double *vj,
+                        double rcv_dt, double rcv_ddt, double yaw, const double *anc, double *r, double *J);
+
 }  // namespace gfo

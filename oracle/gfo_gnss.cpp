@@ -106,6 +106,58 @@ double ion_delay(double tow, const double *ion, V3 lla, const double *azel) {   
 
 }  // namespace
 
+// GnssPsrDoppFactor::Evaluate (gnss_psr_dopp_factor.cpp:50-208) for one observation. r[2]; J[2][18] or null, columns
+// P_i(3) V_i(3) P_j(3) V_j(3) rcv_dt rcv_ddt yaw_enu_local anc_ecef(3): the non-zero parts of the reference's 2 x {7, 9, 7, 9, 1, 1, 1, 3}.
+namespace gfo {
+void eval_gnss_psr_dopp(const gfbe_gnss_obs &o, const double *iono, const double *pi, const double *vi, const double *pj, const double *vj,
+                        double rcv_dt, double rcv_ddt, double yaw, const double *anc, double *r, double *J) {
+  const V3 Pi = v3(pi), Vi = v3(vi), Pj = v3(pj), Vj = v3(vj);
+  const double ratio = o.ratio;
+  const V3 ref = v3(anc), sv_pos = v3(o.sv_pos), sv_vel = v3(o.sv_vel);
+  const V3 local_pos = ratio * Pi + (1.0 - ratio) * Pj, local_vel = ratio * Vi + (1.0 - ratio) * Vj;
+  const double sy = std::sin(yaw), cy = std::cos(yaw);
+  const M3 R_enu_local = {{{cy, -sy, 0}, {sy, cy, 0}, {0, 0, 1}}};
+  const M3 R_ecef_enu = geo2rotation(ecef2geo(ref)), R_ecef_local = R_ecef_enu * R_enu_local;
+  const V3 P_ecef = R_ecef_local * local_pos + ref, V_ecef = R_ecef_local * local_vel;
+  double ion = 0, tro = 0, azel[2] = {0, M_PI / 2.0};
+  if (norm(P_ecef) > 0) {
+    sat_azel(P_ecef, sv_pos, azel);
+    const V3 lla = ecef2geo(P_ecef);
+    tro = trop_delay(o.doy, lla, azel);
+    ion = iono ? ion_delay(o.tow, iono, lla, azel) : 0.0;
+  }
+  const double sin_el = std::sin(azel[1]), sin_el_2 = sin_el * sin_el;
+  const double pr_weight = sin_el_2 / o.pr_uura * 10.0, dp_weight = sin_el_2 / o.dp_uura * 10.0 * 5.0;
+  const V3 rcv2sat = sv_pos - P_ecef, unit = (1.0 / norm(rcv2sat)) * rcv2sat;
+  const double psr_sagnac = kOmega * (sv_pos.x * P_ecef.y - sv_pos.y * P_ecef.x) / kC;
+  const double psr_est = norm(rcv2sat) + psr_sagnac + rcv_dt - o.svdt * kC + ion + tro + o.tgd * kC;
+  const double dopp_sagnac = kOmega / kC * (sv_vel.x * P_ecef.y + sv_pos.x * V_ecef.y - sv_vel.y * P_ecef.x - sv_pos.y * V_ecef.x);
+  const double dopp_est = dot(sv_vel - V_ecef, unit) + dopp_sagnac + rcv_ddt - o.svddt * kC;
+  const double r0 = (psr_est - o.psr) * pr_weight, r1 = (dopp_est + o.dopp * o.wavelength) * dp_weight;
+  r[0] = r0; r[1] = r1;
+  if (!J) return;
+  std::memset(J, 0, sizeof(double) * 36);
+  const double n2 = norm2(rcv2sat), n3 = std::pow(norm(rcv2sat), 3);
+  M3 unit2rcv;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) unit2rcv.m[i][j] = -(i == j ? (n2 - get(rcv2sat, i) * get(rcv2sat, i)) / n3 : (-get(rcv2sat, i) * get(rcv2sat, j)) / n3);
+  const V3 uR = T(R_ecef_local) * unit;                              // (unit^T R)^T
+  const V3 wR = T(R_ecef_local) * (T(unit2rcv) * (sv_vel - V_ecef));  // ((sv_vel - V)^T unit2rcv R)^T
+  for (int j = 0; j < 3; j++) {
+    J[j] = -get(uR, j) * pr_weight * ratio;            J[18 + j] = get(wR, j) * dp_weight * ratio;
+    J[18 + 3 + j] = -get(uR, j) * dp_weight * ratio;
+    J[6 + j] = -get(uR, j) * pr_weight * (1.0 - ratio); J[18 + 6 + j] = get(wR, j) * dp_weight * (1.0 - ratio);
+    J[18 + 9 + j] = -get(uR, j) * dp_weight * (1.0 - ratio);
+    J[15 + j] = -get(unit, j) * pr_weight;
+  }
+  J[12] = pr_weight;
+  J[18 + 13] = dp_weight;
+  const M3 d_yaw = {{{-sy, -cy, 0}, {cy, -sy, 0}, {0, 0, 0}}};
+  J[14] = -dot(unit, R_ecef_enu * (d_yaw * local_pos)) * pr_weight;
+  J[18 + 14] = -dot(unit, R_ecef_enu * (d_yaw * local_vel)) * dp_weight;
+}
+}  // namespace gfo
+
 extern "C" int32_t gfo_gnss_eval(void *, int32_t n_obs, const gfbe_gnss_obs *obs, const double *iono, const gfbe_state *st, const gfbe_gnss_state *g,
                                  const double *frame_dt, double ddt_weight, double *r_obs, double *J_obs, double *r_dt_ddt, double *r_smooth,
                                  double *cost) {
@@ -113,53 +165,12 @@ extern "C" int32_t gfo_gnss_eval(void *, int32_t n_obs, const gfbe_gnss_obs *obs
   double c = 0.0;
   for (int k = 0; k < n_obs; k++) {
     const gfbe_gnss_obs &o = obs[k];
-    const V3 Pi = v3(st->para_Pose[o.lower_idx]), Vi = v3(st->para_SpeedBias[o.lower_idx]), Pj = v3(st->para_Pose[o.lower_idx + 1]),
-             Vj = v3(st->para_SpeedBias[o.lower_idx + 1]);
-    const double rcv_dt = g->rcv_dt[o.frame][o.sys_idx], rcv_ddt = g->rcv_ddt[o.frame], yaw = g->yaw_enu_local, ratio = o.ratio;
-    const V3 ref = v3(g->anc_ecef), sv_pos = v3(o.sv_pos), sv_vel = v3(o.sv_vel);
-    const V3 local_pos = ratio * Pi + (1.0 - ratio) * Pj, local_vel = ratio * Vi + (1.0 - ratio) * Vj;
-    const double sy = std::sin(yaw), cy = std::cos(yaw);
-    const M3 R_enu_local = {{{cy, -sy, 0}, {sy, cy, 0}, {0, 0, 1}}};
-    const M3 R_ecef_enu = geo2rotation(ecef2geo(ref)), R_ecef_local = R_ecef_enu * R_enu_local;
-    const V3 P_ecef = R_ecef_local * local_pos + ref, V_ecef = R_ecef_local * local_vel;
-    double ion = 0, tro = 0, azel[2] = {0, M_PI / 2.0};
-    if (norm(P_ecef) > 0) {
-      sat_azel(P_ecef, sv_pos, azel);
-      const V3 lla = ecef2geo(P_ecef);
-      tro = trop_delay(o.doy, lla, azel);
-      ion = iono ? ion_delay(o.tow, iono, lla, azel) : 0.0;
-    }
-    const double sin_el = std::sin(azel[1]), sin_el_2 = sin_el * sin_el;
-    const double pr_weight = sin_el_2 / o.pr_uura * 10.0, dp_weight = sin_el_2 / o.dp_uura * 10.0 * 5.0;
-    const V3 rcv2sat = sv_pos - P_ecef, unit = (1.0 / norm(rcv2sat)) * rcv2sat;
-    const double psr_sagnac = kOmega * (sv_pos.x * P_ecef.y - sv_pos.y * P_ecef.x) / kC;
-    const double psr_est = norm(rcv2sat) + psr_sagnac + rcv_dt - o.svdt * kC + ion + tro + o.tgd * kC;
-    const double dopp_sagnac = kOmega / kC * (sv_vel.x * P_ecef.y + sv_pos.x * V_ecef.y - sv_vel.y * P_ecef.x - sv_pos.y * V_ecef.x);
-    const double dopp_est = dot(sv_vel - V_ecef, unit) + dopp_sagnac + rcv_ddt - o.svddt * kC;
-    const double r0 = (psr_est - o.psr) * pr_weight, r1 = (dopp_est + o.dopp * o.wavelength) * dp_weight;
-    c += 0.5 * r0 * r0 + 0.5 * r1 * r1;
-    if (r_obs) { r_obs[2 * k] = r0; r_obs[2 * k + 1] = r1; }
-    if (!J_obs) continue;
-    double *J = J_obs + (size_t)36 * k;
-    std::memset(J, 0, sizeof(double) * 36);
-    const double n2 = norm2(rcv2sat), n3 = std::pow(norm(rcv2sat), 3);
-    M3 unit2rcv;
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) unit2rcv.m[i][j] = -(i == j ? (n2 - get(rcv2sat, i) * get(rcv2sat, i)) / n3 : (-get(rcv2sat, i) * get(rcv2sat, j)) / n3);
-    const V3 uR = T(R_ecef_local) * unit;                              // (unit^T R)^T
-    const V3 wR = T(R_ecef_local) * (T(unit2rcv) * (sv_vel - V_ecef));  // ((sv_vel - V)^T unit2rcv R)^T
-    for (int j = 0; j < 3; j++) {
-      J[j] = -get(uR, j) * pr_weight * ratio;            J[18 + j] = get(wR, j) * dp_weight * ratio;
-      J[18 + 3 + j] = -get(uR, j) * dp_weight * ratio;
-      J[6 + j] = -get(uR, j) * pr_weight * (1.0 - ratio); J[18 + 6 + j] = get(wR, j) * dp_weight * (1.0 - ratio);
-      J[18 + 9 + j] = -get(uR, j) * dp_weight * (1.0 - ratio);
-      J[15 + j] = -get(unit, j) * pr_weight;
-    }
-    J[12] = pr_weight;
-    J[18 + 13] = dp_weight;
-    const M3 d_yaw = {{{-sy, -cy, 0}, {cy, -sy, 0}, {0, 0, 0}}};
-    J[14] = -dot(unit, R_ecef_enu * (d_yaw * local_pos)) * pr_weight;
-    J[18 + 14] = -dot(unit, R_ecef_enu * (d_yaw * local_vel)) * dp_weight;
+    double r[2];
+    gfo::eval_gnss_psr_dopp(o, iono, st->para_Pose[o.lower_idx], st->para_SpeedBias[o.lower_idx], st->para_Pose[o.lower_idx + 1],
+                            st->para_SpeedBias[o.lower_idx + 1], g->rcv_dt[o.frame][o.sys_idx], g->rcv_ddt[o.frame], g->yaw_enu_local,
+                            g->anc_ecef, r, J_obs ? J_obs + (size_t)36 * k : nullptr);
+    c += 0.5 * r[0] * r[0] + 0.5 * r[1] * r[1];
+    if (r_obs) { r_obs[2 * k] = r[0]; r_obs[2 * k + 1] = r[1]; }
   }
   for (int sys = 0; sys < 4; sys++)
     for (int i = 0; i < W; i++) {

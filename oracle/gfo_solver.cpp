@@ -36,7 +36,9 @@ enum { NV = 73, ND = GFBE_DENSE_DIM };
 static inline int T_POSE(int k) { return 6 * k; }
 enum { T_EX = 66, T_TD = 72 };
 static inline int T_SB(int k) { return 73 + 9 * k; }
-enum { T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181, T_PLR = 182, T_PLZ = 186 };
+enum { T_EXW = 172, T_SX = 178, T_SY = 179, T_SW = 180, T_TDW = 181, T_PLR = 182, T_PLZ = 186, T_ANC = 187, T_YAW = 190 };
+static inline int T_DT(int i, int k) { return 191 + 4 * i + k; }    // para_rcv_dt + 4 i + k
+static inline int T_DDT(int i) { return 235 + i; }                  // para_rcv_ddt + i
 
 static int tan_off(int id) {
   if (id < GFBE_BLK_SB0) return T_POSE(id);
@@ -51,7 +53,11 @@ static int tan_off(int id) {
     case GFBE_BLK_TD_WHEEL: return T_TDW;
     case GFBE_BLK_PLANE_R: return T_PLR;
     case GFBE_BLK_PLANE_Z: return T_PLZ;
+    case GFBE_BLK_ANC_ECEF: return T_ANC;
+    case GFBE_BLK_YAW_ENU: return T_YAW;
   }
+  if (id >= GFBE_BLK_RCV_DT0 && id < GFBE_BLK_RCV_DDT0) return T_DT(0, id - GFBE_BLK_RCV_DT0);
+  if (id >= GFBE_BLK_RCV_DDT0 && id < GFBE_BLK_COUNT) return T_DDT(id - GFBE_BLK_RCV_DDT0);
   return -1;
 }
 
@@ -63,6 +69,7 @@ struct Problem {
   std::vector<double> wheel_sqrt;  // n_wheel * 36
   std::vector<double> Hprior;      // n*n  J0'J0 (constant over the solve)
   bool has_prior;
+  bool gnss_factors;               // gnss_ready && !lowspeed (estimator.cpp:3239): the GNSS residual blocks are in the problem
   bool blk_used[GFBE_BLK_COUNT];
   bool blk_free[GFBE_BLK_COUNT];   // in the reduced program (not constant, touched by a factor)
   bool act[ND];                    // per tangent dim
@@ -127,6 +134,30 @@ static bool setup(Problem &P, const gfbe_window *win, const gfbe_options *opt) {
     if (win->frame_count > 0) P.blk_used[GFBE_BLK_EX_WHEEL] = P.blk_used[GFBE_BLK_PLANE_R] = P.blk_used[GFBE_BLK_PLANE_Z] = true;
   }
   if (win->use_anchor) P.blk_used[GFBE_BLK_POSE0] = true;
+  // GNSS (estimator.cpp:2965-3002, 3239-3291): lowspeed from the window's velocities, then the blocks the factors touch
+  P.gnss_factors = false;
+  if (win->gnss_ready) {
+    double ax = 0.0, ay = 0.0;
+    for (int i = 0; i <= GFBE_WINDOW_SIZE; i++) { ax += std::fabs(win->state.para_SpeedBias[i][0]); ay += std::fabs(win->state.para_SpeedBias[i][1]); }
+    ax /= GFBE_WINDOW_SIZE + 1; ay /= GFBE_WINDOW_SIZE + 1;
+    P.gnss_factors = !(std::sqrt(ax * ax + ay * ay) < 0.3);
+    if (win->n_gnss < 0 || (win->n_gnss > 0 && !win->gnss_obs)) return false;
+    for (int k = 0; k < win->n_gnss; k++) {
+      const gfbe_gnss_obs &ob = win->gnss_obs[k];
+      if (ob.frame < 0 || ob.frame > GFBE_WINDOW_SIZE || ob.lower_idx < 0 || ob.lower_idx >= GFBE_WINDOW_SIZE || ob.sys_idx < 0 || ob.sys_idx > 3 ||
+          !(ob.pr_uura > 0.0) || !(ob.dp_uura > 0.0)) return false;
+    }
+  }
+  if (P.gnss_factors) {
+    for (int k = 0; k < win->n_gnss; k++) {
+      const gfbe_gnss_obs &ob = win->gnss_obs[k];
+      P.blk_used[GFBE_BLK_POSE0 + ob.lower_idx] = P.blk_used[GFBE_BLK_SB0 + ob.lower_idx] = true;
+      P.blk_used[GFBE_BLK_POSE0 + ob.lower_idx + 1] = P.blk_used[GFBE_BLK_SB0 + ob.lower_idx + 1] = true;
+      P.blk_used[GFBE_BLK_RCV_DT0 + 4 * ob.frame + ob.sys_idx] = P.blk_used[GFBE_BLK_RCV_DDT0 + ob.frame] = true;
+      P.blk_used[GFBE_BLK_YAW_ENU] = P.blk_used[GFBE_BLK_ANC_ECEF] = true;
+    }
+    for (int b = GFBE_BLK_RCV_DT0; b < GFBE_BLK_COUNT; b++) P.blk_used[b] = true;     // DtDdtFactor / DdtSmoothFactor chains
+  }
   for (int b = 0; b < GFBE_BLK_COUNT; b++) {
     bool c;
     if (b < GFBE_BLK_SB0) c = win->pose_const[b] || b > win->frame_count;
@@ -136,6 +167,8 @@ static bool setup(Problem &P, const gfbe_window *win, const gfbe_options *opt) {
     else if (b == GFBE_BLK_TD) c = win->td_const;
     else if (b == GFBE_BLK_TD_WHEEL) c = win->td_wheel_const;
     else if (b == GFBE_BLK_PLANE_R || b == GFBE_BLK_PLANE_Z) c = win->plane_const;
+    else if (b == GFBE_BLK_YAW_ENU) c = win->gnss_ready != 0;          // estimator.cpp:2991
+    else if (b == GFBE_BLK_ANC_ECEF || b >= GFBE_BLK_RCV_DT0) c = false;
     else c = win->ix_wheel_const;
     P.blk_free[b] = P.blk_used[b] && !c;
   }
@@ -161,6 +194,40 @@ static void accum(Lin &lin, const double *r, const double *J, int nr, int nc, co
       for (int i = 0; i < nr; i++) s += J[i * nc + a] * J[i * nc + b];
       lin.H[(size_t)ga * ND + gb] += s;
     }
+  }
+}
+
+// The GNSS residual blocks (estimator.cpp:3239-3291; only_frame0: the marginalisation set of :3462-3496). `emit` receives every
+// block as (r, J, rows, cols, tangent dim of each column).
+template <class Emit>
+static void gnss_blocks(const gfbe_window &w, const gfbe_state &st, bool with_jac, bool only_frame0, Emit emit) {
+  const gfbe_gnss_state &g = st.gnss;
+  for (int k = 0; k < w.n_gnss; k++) {
+    const gfbe_gnss_obs &ob = w.gnss_obs[k];
+    if (only_frame0 && ob.frame != 0) continue;
+    const int lo = only_frame0 ? 0 : ob.lower_idx;
+    double r[2], J[36];
+    eval_gnss_psr_dopp(ob, w.gnss_iono, st.para_Pose[lo], st.para_SpeedBias[lo], st.para_Pose[lo + 1], st.para_SpeedBias[lo + 1],
+                       g.rcv_dt[ob.frame][ob.sys_idx], g.rcv_ddt[ob.frame], g.yaw_enu_local, g.anc_ecef, r, with_jac ? J : nullptr);
+    int map[18];
+    for (int q = 0; q < 3; q++) { map[q] = T_POSE(lo) + q; map[3 + q] = T_SB(lo) + q; map[6 + q] = T_POSE(lo + 1) + q; map[9 + q] = T_SB(lo + 1) + q; map[15 + q] = T_ANC + q; }
+    map[12] = T_DT(ob.frame, ob.sys_idx); map[13] = T_DDT(ob.frame); map[14] = T_YAW;
+    emit(r, J, 2, 18, map);
+  }
+  const int ni = only_frame0 ? 1 : GFBE_WINDOW_SIZE;
+  for (int k = 0; k < 4; k++)                      // DtDdtFactor (gnss_dt_ddt_factor.cpp:3-34), dt_info_coeff = 50
+    for (int i = 0; i < ni; i++) {
+      const double dt = w.gnss_frame_dt[i];
+      double r[1] = {(g.rcv_dt[i + 1][k] - g.rcv_dt[i][k] - 0.5 * (g.rcv_ddt[i] + g.rcv_ddt[i + 1]) * dt) * 50.0};
+      double J[4] = {-50.0, 50.0, -0.5 * dt * 50.0, -0.5 * dt * 50.0};
+      int map[4] = {T_DT(i, k), T_DT(i + 1, k), T_DDT(i), T_DDT(i + 1)};
+      emit(r, J, 1, 4, map);
+    }
+  for (int i = 0; i < ni; i++) {                   // DdtSmoothFactor (gnss_ddt_smooth_factor.cpp:3-22)
+    double r[1] = {(g.rcv_ddt[i] - g.rcv_ddt[i + 1]) * w.gnss_ddt_weight};
+    double J[2] = {w.gnss_ddt_weight, -w.gnss_ddt_weight};
+    int map[2] = {T_DDT(i), T_DDT(i + 1)};
+    emit(r, J, 1, 2, map);
   }
 }
 
@@ -282,6 +349,12 @@ static double evaluate(const Problem &P, const gfbe_state &st, const double *lam
       accum(*lin, r, J, 6, 6, map);
     }
   }
+  // --- GNSS: GnssPsrDoppFactor per observation, DtDdtFactor / DdtSmoothFactor chains (estimator.cpp:3239-3291), no loss
+  if (P.gnss_factors)
+    gnss_blocks(w, st, lin != nullptr, false, [&](const double *r, const double *J, int nr, int nc, const int *map) {
+      for (int q = 0; q < nr; q++) cost += 0.5 * r[q] * r[q];
+      if (lin) accum(*lin, r, J, nr, nc, map);
+    });
   if (lin) {
     // Remove constant / unused dims from the reduced program.
     for (int a = 0; a < ND; a++)
@@ -338,28 +411,31 @@ static double ambient_norm2_diff(const Problem &P, const gfbe_state &a, const do
   return s;
 }
 
-// Dense Cholesky solve S y = rhs on the active dims (inactive rows are identity). false on failure.
+// Dense Cholesky solve S y = rhs on the active dims (compacted: the inactive rows would be identity rows that touch nothing).
+// false on failure.
 static bool chol_solve(std::vector<double> &S, const std::vector<double> &rhs, const bool *act, double *y) {
-  const int n = ND;
-  for (int a = 0; a < n; a++) if (!act[a]) { for (int b = 0; b < n; b++) S[(size_t)a * n + b] = S[(size_t)b * n + a] = 0; S[(size_t)a * n + a] = 1.0; }
+  int idx[ND], n = 0;
+  for (int a = 0; a < ND; a++) { y[a] = 0.0; if (act[a]) idx[n++] = a; }
+  std::vector<double> C((size_t)n * n), z(n), yc(n);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < n; j++) C[(size_t)i * n + j] = S[(size_t)idx[i] * ND + idx[j]];
   // in-place lower Cholesky (Eigen::LLT as used by Ceres 1.14 DenseSchurComplementSolver)
   for (int j = 0; j < n; j++) {
-    double d = S[(size_t)j * n + j];
-    for (int k = 0; k < j; k++) d -= S[(size_t)j * n + k] * S[(size_t)j * n + k];
+    double d = C[(size_t)j * n + j];
+    for (int k = 0; k < j; k++) d -= C[(size_t)j * n + k] * C[(size_t)j * n + k];
     if (!(d > 0.0) || !std::isfinite(d)) return false;
     d = std::sqrt(d);
-    S[(size_t)j * n + j] = d;
+    C[(size_t)j * n + j] = d;
     for (int i = j + 1; i < n; i++) {
-      double s = S[(size_t)i * n + j];
-      const double *Li = &S[(size_t)i * n], *Lj = &S[(size_t)j * n];
+      double s = C[(size_t)i * n + j];
+      const double *Li = &C[(size_t)i * n], *Lj = &C[(size_t)j * n];
       for (int k = 0; k < j; k++) s -= Li[k] * Lj[k];
-      S[(size_t)i * n + j] = s / d;
+      C[(size_t)i * n + j] = s / d;
     }
   }
-  std::vector<double> z(n);
-  for (int i = 0; i < n; i++) { double s = act[i] ? rhs[i] : 0.0; for (int k = 0; k < i; k++) s -= S[(size_t)i * n + k] * z[k]; z[i] = s / S[(size_t)i * n + i]; }
-  for (int i = n - 1; i >= 0; i--) { double s = z[i]; for (int k = i + 1; k < n; k++) s -= S[(size_t)k * n + i] * y[k]; y[i] = s / S[(size_t)i * n + i]; }
-  for (int i = 0; i < n; i++) if (!std::isfinite(y[i])) return false;
+  for (int i = 0; i < n; i++) { double s = rhs[idx[i]]; for (int k = 0; k < i; k++) s -= C[(size_t)i * n + k] * z[k]; z[i] = s / C[(size_t)i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double s = z[i]; for (int k = i + 1; k < n; k++) s -= C[(size_t)k * n + i] * yc[k]; yc[i] = s / C[(size_t)i * n + i]; }
+  for (int i = 0; i < n; i++) { if (!std::isfinite(yc[i])) return false; y[idx[i]] = yc[i]; }
   return true;
 }
 
@@ -595,6 +671,15 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
     if (use_wheel0) touched[GFBE_BLK_POSE0] = touched[GFBE_BLK_POSE0 + 1] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_SX] = touched[GFBE_BLK_SY] = touched[GFBE_BLK_SW] = touched[GFBE_BLK_TD_WHEEL] = true;
     if (w.use_plane && w.frame_count > 0)     // estimator.cpp:3441-3448: the PlaneFactor of frame 0, drop set {Pose[0]}
       touched[GFBE_BLK_POSE0] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_PLANE_R] = touched[GFBE_BLK_PLANE_Z] = true;
+    if (w.gnss_ready) {                          // estimator.cpp:3459-3496: the GNSS factors of frame 0
+      for (int k = 0; k < w.n_gnss; k++) {
+        if (w.gnss_obs[k].frame != 0) continue;
+        touched[GFBE_BLK_POSE0] = touched[GFBE_BLK_SB0] = touched[GFBE_BLK_POSE0 + 1] = touched[GFBE_BLK_SB0 + 1] = true;
+        touched[GFBE_BLK_RCV_DT0 + w.gnss_obs[k].sys_idx] = touched[GFBE_BLK_RCV_DDT0] = touched[GFBE_BLK_YAW_ENU] = touched[GFBE_BLK_ANC_ECEF] = true;
+      }
+      for (int k = 0; k < 4; k++) touched[GFBE_BLK_RCV_DT0 + k] = touched[GFBE_BLK_RCV_DT0 + 4 + k] = true;
+      touched[GFBE_BLK_RCV_DDT0] = touched[GFBE_BLK_RCV_DDT0 + 1] = true;
+    }
     std::vector<uint8_t> seen(P.L, 0);
     for (int k = 0; k < w.vis.n_factor; k++) {
       if (w.vis.imu_i[k] != 0) continue;
@@ -606,6 +691,10 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
     // drop set: Pose[0], SpeedBias[0] (prior: estimator.cpp:3405-3407; IMU {0,1}: :3421; wheel {0}: :3434; visual {0,3}: :3526)
     if (touched[GFBE_BLK_POSE0]) drop.push_back(GFBE_BLK_POSE0);
     if (touched[GFBE_BLK_SB0]) drop.push_back(GFBE_BLK_SB0);
+    if (w.gnss_ready) {                          // drop sets {0, 1, 4, 5}, {0, 2}, {0} (:3477, :3487, :3494): rcv_dt[0][k], rcv_ddt[0]
+      for (int k = 0; k < 4; k++) drop.push_back(GFBE_BLK_RCV_DT0 + k);
+      drop.push_back(GFBE_BLK_RCV_DDT0);
+    }
     for (int l : lm0) drop.push_back(GFBE_BLK_COUNT + l);
   } else {
     // MARGIN_SECOND_NEW: only when the prior touches Pose[WINDOW_SIZE-1] (estimator.cpp:3600-3601)
@@ -677,6 +766,16 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
     map[15] = idx_of[GFBE_BLK_PLANE_Z];
     add(r, J, 3, 16, map);
   }
+  if (flag == GFBE_MARGIN_OLD && w.gnss_ready)
+    gnss_blocks(w, st, true, true, [&](const double *r, const double *J, int nr, int nc, const int *tmap) {
+      int map[18];
+      for (int a = 0; a < nc; a++) {     // tangent dim -> (block, offset) -> position in the marginalisation's ordering
+        map[a] = -1;
+        for (int b2 = 0; b2 < GFBE_BLK_COUNT && map[a] < 0; b2++)
+          if (tmap[a] >= tan_off(b2) && tmap[a] < tan_off(b2) + block_local_size(b2)) map[a] = idx_of[b2] + (tmap[a] - tan_off(b2));
+      }
+      add(r, J, nr, nc, map);
+    });
   if (flag == GFBE_MARGIN_OLD) {
     const gfbe_visual &v = w.vis;
     for (int k = 0; k < v.n_factor; k++) {
@@ -737,8 +836,14 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
   for (size_t q = 0; q < keep.size(); q++) {
     const int id = keep[q];
     int nid = id;
-    if (flag == GFBE_MARGIN_OLD) { if (id < GFBE_BLK_EX_CAM) nid = id - 1; }           // slot i -> i-1 (pose and speed-bias)
-    else { if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE) nid = id - 1; if (id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE) nid = id - 1; }
+    const bool is_dt = id >= GFBE_BLK_RCV_DT0 && id < GFBE_BLK_RCV_DDT0, is_ddt = id >= GFBE_BLK_RCV_DDT0;
+    if (flag == GFBE_MARGIN_OLD) {                                                      // slot i -> i-1 (pose, speed-bias, receiver clock)
+      if (id < GFBE_BLK_EX_CAM || is_ddt) nid = id - 1;
+      if (is_dt) nid = id - 4;
+    } else {
+      if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_RCV_DDT0 + GFBE_WINDOW_SIZE) nid = id - 1;
+      if (is_dt && id >= GFBE_BLK_RCV_DT0 + 4 * GFBE_WINDOW_SIZE) nid = id - 4;
+    }
     out->block_id[q] = nid;
     out->block_size[q] = block_global_size(id);
     out->block_idx[q] = idx_of[id] - m;
@@ -844,6 +949,8 @@ int32_t gfo_solve_window(const gfbe_options *opt, const gfbe_window *w, int32_t 
   Solution sol;
   solve(P, sol);
   if (sol.sum.status == GFBE_NUMERICAL_FAILURE) { if (summary) *summary = sol.sum; return GFBE_NUMERICAL_FAILURE; }
+  while (sol.x.gnss.yaw_enu_local > M_PI) sol.x.gnss.yaw_enu_local -= 2.0 * M_PI;      // estimator.cpp:3383-3386
+  while (sol.x.gnss.yaw_enu_local < -M_PI) sol.x.gnss.yaw_enu_local += 2.0 * M_PI;
   gfbe_state anchored;
   reanchor(w->state, sol.x, w->frame_count, anchored);
   if (margin_flag != GFBE_MARGIN_NONE && prior_out && w->frame_count == GFBE_WINDOW_SIZE) {

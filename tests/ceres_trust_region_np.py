@@ -61,6 +61,12 @@ def _block_table(snap):
         touched |= {("pose", i) for i in range(fc)} | {("exw", 0), ("plr", 0), ("plz", 0)}
     if snap.get("anchor") is not None:
         touched.add(("pose", 0))
+    if gnss_factors_on(snap):            # estimator.cpp:3239-3291
+        for o in snap["gnss"]["obs"]:
+            lo = int(o["lower_idx"])
+            touched |= {("pose", lo), ("sb", lo), ("pose", lo + 1), ("sb", lo + 1), ("dt", 4 * int(o["frame"]) + int(o["sys_idx"])), ("ddt", int(o["frame"])),
+                        ("yaw", 0), ("anc", 0)}
+        touched |= {("dt", q) for q in range(4 * abi.NFRAMES)} | {("ddt", i) for i in range(abi.NFRAMES)}
     if prior is not None:
         for bid in prior["block_id"]:
             touched.add(_block_of_id(int(bid)))
@@ -82,11 +88,14 @@ def _block_table(snap):
         const |= {("sx", 0), ("sy", 0), ("sw", 0)}
     if snap.get("plane") is not None and int(snap["plane"].get("const", 0)):
         const |= {("plr", 0), ("plz", 0)}
-    order = [("plz", 0), ("exc", 0), ("td", 0)] + [("sb", i) for i in range(abi.NFRAMES)] + [("tdw", 0), ("sw", 0), ("sy", 0), ("sx", 0), ("exw", 0)] + \
+    if snap.get("gnss") is not None and int(snap["gnss"].get("ready", 1)):
+        const.add(("yaw", 0))            # estimator.cpp:2991
+    order = [("ddt", i) for i in range(abi.NFRAMES)][::-1] + [("anc", 0)] + [("dt", q) for q in range(4 * abi.NFRAMES)] + [("yaw", 0)] + \
+            [("plz", 0), ("exc", 0), ("td", 0)] + [("sb", i) for i in range(abi.NFRAMES)] + [("tdw", 0), ("sw", 0), ("sy", 0), ("sx", 0), ("exw", 0)] + \
             [("pose", i) for i in range(abi.NFRAMES)][::-1] + [("plr", 0)]
     # (global size, tangent size in the solve). para_plane_R: a quaternion on OrientationSubsetParameterization — 3 tangent dims
     sizes = {"pose": (7, 6), "sb": (9, 9), "exc": (7, 6), "exw": (7, 6), "td": (1, 1), "tdw": (1, 1), "sx": (1, 1), "sy": (1, 1), "sw": (1, 1),
-             "plr": (4, 3), "plz": (1, 1)}
+             "plr": (4, 3), "plz": (1, 1), "anc": (3, 3), "yaw": (1, 1), "dt": (1, 1), "ddt": (1, 1)}
     free = [b for b in order if b in touched and b not in const]
     off, table = 0, {}
     for b in free:
@@ -95,7 +104,22 @@ def _block_table(snap):
     return free, table, off, sizes
 
 
+def gnss_factors_on(snap):
+    """gnss_ready && !lowspeed (estimator.cpp:2965-2984, 3239): the mean absolute horizontal velocity over the window, as a vector."""
+    gn = snap.get("gnss")
+    if gn is None or not int(gn.get("ready", 1)):
+        return False
+    v = np.abs(np.asarray(snap["speed_bias"], float)[:, :2]).sum(axis=0) / abi.NFRAMES
+    return not np.linalg.norm(v) < 0.3
+
+
 def _block_of_id(bid):
+    if bid >= abi.BLK_RCV_DDT0:
+        return ("ddt", bid - abi.BLK_RCV_DDT0)
+    if bid >= abi.BLK_RCV_DT0:
+        return ("dt", bid - abi.BLK_RCV_DT0)
+    if bid in (abi.BLK_ANC_ECEF, abi.BLK_YAW_ENU):
+        return ("anc", 0) if bid == abi.BLK_ANC_ECEF else ("yaw", 0)
     if bid < abi.BLK_SB0:
         return ("pose", bid)
     if bid < abi.BLK_EX_CAM:
@@ -137,6 +161,26 @@ class Problem:
             e = abi.anchor_eval(self.api.lib, self.api.prefix, None, np.asarray(snap["pose"])[:1], np.asarray(snap["anchor"]["pose"])[None],
                                 float(snap["anchor"].get("sqrt_info", 120.0)))
             out.append((e["r"][0], e["J"][0], [(("pose", 0), 6)]))
+        if gnss_factors_on(snap):       # through the stand-alone evaluator (pinned on its own in tests/test_gnss_oracle.py)
+            gn, gs = snap["gnss"], snap["gnss_state"]
+            e = abi.gnss_eval(self.api.lib, self.api.prefix, None, gn["obs"], gn.get("iono"), snap["pose"], snap["speed_bias"], gs["rcv_dt"], gs["rcv_ddt"],
+                              gs["yaw_enu_local"], gs["anc_ecef"], gn["frame_dt"], gn["ddt_weight"])
+            for k, o in enumerate(gn["obs"]):
+                lo, fr = int(o["lower_idx"]), int(o["frame"])
+                # the evaluator's 18 columns: P_i V_i P_j V_j (3 each: the leading columns of the pose / speed-bias blocks) dt ddt yaw anc
+                Jb = np.zeros((2, 6 + 9 + 6 + 9 + 1 + 1 + 1 + 3))
+                J = e["J"][k]
+                Jb[:, 0:3], Jb[:, 6:9], Jb[:, 15:18], Jb[:, 21:24], Jb[:, 30:36] = J[:, 0:3], J[:, 3:6], J[:, 6:9], J[:, 9:12], J[:, 12:18]
+                out.append((e["r"][k], Jb, [(("pose", lo), 6), (("sb", lo), 9), (("pose", lo + 1), 6), (("sb", lo + 1), 9), (("dt", 4 * fr + int(o["sys_idx"])), 1),
+                                            (("ddt", fr), 1), (("yaw", 0), 1), (("anc", 0), 3)]))
+            fdt = np.asarray(gn["frame_dt"], float)
+            for k in range(4):
+                for i in range(abi.WINDOW_SIZE):
+                    out.append((e["r_dt_ddt"][k, i:i + 1], np.array([[-50.0, 50.0, -25.0 * fdt[i], -25.0 * fdt[i]]]),
+                                [(("dt", 4 * i + k), 1), (("dt", 4 * (i + 1) + k), 1), (("ddt", i), 1), (("ddt", i + 1), 1)]))
+            wgt = float(gn["ddt_weight"])
+            for i in range(abi.WINDOW_SIZE):
+                out.append((e["r_smooth"][i:i + 1], np.array([[wgt, -wgt]]), [(("ddt", i), 1), (("ddt", i + 1), 1)]))
         return out
 
     def evaluate(self, snap, want_jacobian=True):
@@ -181,6 +225,7 @@ class Problem:
             # (a 4-wide prior block of the plane quaternion carries 4 columns; the solve's tangent Jacobian is the first three —
             #  OrientationSubsetParameterization::ComputeJacobian = [I3; 0] — and the residual uses all four differences)
             blocks = [(b, w) if b[0] != "plr" else (b, 4) for b, w in blocks]
+            # (a constant block — the yaw, a constant extrinsic — keeps its columns out of J but its difference in the residual)
             perm = np.concatenate([np.arange(int(pr["block_idx"][q]), int(pr["block_idx"][q]) + (4 if _block_of_id(int(pr["block_id"][q]))[0] == "plr" else self.sizes[_block_of_id(int(pr["block_id"][q]))[0]][1])) for q in order])
             add(ev["prior_r"], J0[:, perm], blocks)
         for r_, J_, blocks in opt:
@@ -196,6 +241,8 @@ class Problem:
         s["ex_pose_wheel"] = np.array(snap["ex_pose_wheel"], float).copy()
         s["ix_wheel"] = np.array(snap["ix_wheel"], float).copy()
         s["para_feature"] = np.array(snap["para_feature"], float).copy()
+        if snap.get("gnss_state") is not None:
+            s["gnss_state"] = {k: np.array(v, float).copy() for k, v in snap["gnss_state"].items()}
 
         def pose_plus(x, d, mask=None):
             d = np.array(d, float)
@@ -225,6 +272,14 @@ class Problem:
                 s["plane_R"] = q / np.linalg.norm(q)
             elif b[0] == "plz":
                 s["plane_Z"] = float(snap.get("plane_Z", 0.0)) + d[0]
+            elif b[0] == "anc":
+                s["gnss_state"]["anc_ecef"] += d
+            elif b[0] == "yaw":
+                s["gnss_state"]["yaw_enu_local"] += d[0]
+            elif b[0] == "dt":
+                s["gnss_state"]["rcv_dt"].reshape(-1)[b[1]] += d[0]
+            elif b[0] == "ddt":
+                s["gnss_state"]["rcv_ddt"][b[1]] += d[0]
             else:
                 s["ix_wheel"][{"sx": 0, "sy": 1, "sw": 2}[b[0]]] += d[0]
         s["para_feature"][self.lm_free] += delta[self.nd:]
@@ -250,6 +305,14 @@ class Problem:
                 parts.append(np.asarray(snap.get("plane_R", [0, 0, 0, 1.0]), float))
             elif b[0] == "plz":
                 parts.append([float(snap.get("plane_Z", 0.0))])
+            elif b[0] == "anc":
+                parts.append(np.asarray(snap["gnss_state"]["anc_ecef"], float))
+            elif b[0] == "yaw":
+                parts.append([float(snap["gnss_state"]["yaw_enu_local"])])
+            elif b[0] == "dt":
+                parts.append([np.asarray(snap["gnss_state"]["rcv_dt"], float).reshape(-1)[b[1]]])
+            elif b[0] == "ddt":
+                parts.append([np.asarray(snap["gnss_state"]["rcv_ddt"], float)[b[1]]])
             else:
                 parts.append([np.asarray(snap["ix_wheel"])[{"sx": 0, "sy": 1, "sw": 2}[b[0]]]])
         parts.append(np.asarray(snap["para_feature"])[self.lm_free])

@@ -30,7 +30,8 @@ def test_header_symbols_all_exported(lib):
 
 
 def test_struct_layouts_match_header(lib):
-    assert C.sizeof(abi.State) == 200 * 8
+    assert C.sizeof(abi.State) == 259 * 8
+    assert C.sizeof(abi.GnssObs) == 19 * 8 and C.sizeof(abi.Window) == 2536
     assert C.sizeof(abi.ImuPreint) == 467 * 8
     assert C.sizeof(abi.WheelPreint) == 78 * 8
     o = abi.Options()

@@ -26,7 +26,8 @@ def build_shim():
         pytest.skip("hipcc not available")
     src = os.path.join(ROOT, "tests", "host_shim.cpp")
     deps = [src, os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_factors.h"),
-            os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_math.h"), os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_gnss.h")]
+            os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_math.h"), os.path.join(ROOT, "ground-fusion2_amd", "csrc", "gfbe_gnss.h"),
+            os.path.join(ROOT, "include", "gfbe.h")]
     if not os.path.exists(SHIM) or any(os.path.getmtime(d) > os.path.getmtime(SHIM) for d in deps):
         os.makedirs(os.path.dirname(SHIM), exist_ok=True)
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
