@@ -43,7 +43,13 @@ enum {
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)
   XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
   HC = 13,                    // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
-  PAIR_CONST_DOUBLES = 63     // sizeof(PairConst) / 8 (gfbe_factors.h; static_assert in gfbe_kernels.hip)
+  PAIR_CONST_DOUBLES = 63,    // sizeof(PairConst) / 8 (gfbe_factors.h; static_assert in gfbe_kernels.hip)
+  // GNSS inside the window (gfbe_gnss_solve.hip)
+  GN_C = 124,                 // compact list of the tangent dims the GNSS factors reach in the solve: position of the 11 poses (33), velocity of
+                              // the 11 speed-bias blocks (33), rcv_dt (44), rcv_ddt (11), anc_ecef (3); the yaw is constant there
+  GN_M = 26,                  // local dims of the marginalisation set: P0 V0 P1 V1 (3 each) rcv_dt[0][4] rcv_ddt[0] rcv_dt[1][4] rcv_ddt[1] yaw anc(3)
+  GN_MPART = GN_M * GN_M + GN_M + 2,   // J^T J, J^T r, cost of the frame-0 GNSS factors at the re-anchored state
+  BIG_LD = 256                // k_solve_big: row stride of the factor in its global scratch (n + 1 <= 247 rows)
 };
 
 // tangent offsets (same convention as the ABI's block order)
@@ -138,6 +144,11 @@ struct WinDesc {
   double lio_sqrt_info, lio_huber;
   int n_plane, use_anchor;                  // PlaneFactors on poses 0 .. n_plane - 1 (0: none); PoseAnchorFactor on pose 0
   double plane_noise_inv[3], anchor_pose[7], anchor_sqrt_info;
+  // GNSS (gfbe_window.gnss_*): gnss_factors = gnss_ready && !lowspeed (estimator.cpp:2969-2984, 3239)
+  int gnss_ready, gnss_factors, n_gnss, gnss_off;   // observations [gnss_off, gnss_off + n_gnss) of BatchDev::gnss_obs, sorted by frame
+  int gnss_frame_begin[NF + 1];                     // observations of frame i: [gnss_frame_begin[i], gnss_frame_begin[i + 1]) relative to gnss_off
+  int gnss_has_iono, gnss_pad;
+  double gnss_iono[8], gnss_frame_dt[GFBE_WINDOW_SIZE], gnss_ddt_weight;
 };
 
 // ---- per-window solver state (mutated by kernels; mirrors TrustRegionMinimizer + DoglegStrategy)
@@ -227,6 +238,15 @@ struct BatchDev {
   double *lio;                // [tot_lio][8]  p(3) n(3) offset weight
   double *lio_part;           // [B][LIOW_WGS][LIOW_PART]
   // assembled system
+  // GNSS inside the solve (gfbe_gnss_solve.hip): observations, their residuals / Jacobians at the current linearisation, costs
+  int any_gnss, tot_gnss;           // some window has gnss_ready; observations of the whole batch
+  gfbe_gnss_obs *gnss_obs;          // [tot_gnss]
+  double *gnss_J, *gnss_r;          // [tot_gnss][36], [tot_gnss][2]
+  double *gnss_cost;                // [B][2]  cost of the GNSS factors at the linearisation point / at the candidate
+  double *gnss_marg;                // [B][GN_MPART]  the frame-0 GNSS factors of MARGIN_OLD at the re-anchored state (cost < 0: none)
+  int solve_big;                    // some window has active GNSS dims: the batch takes k_solve_big (factor in global memory, n <= 246)
+  double *solveS;                   // k_solve_big: [B][BIG_LD * BIG_LD] scaled system / its factor
+  int nu;                     // tangent dims in use: NC (no window of the batch has GNSS blocks) or ND
   double *H, *g;              // [B][ND*ND], [B][ND]  unscaled J^T J, J^T r of the dense block
   double *E, *eg;             // [B][NV*NV], [B][NV]  sum_l w_l h_l h_l^T, sum_l w_l h_l gl  (unscaled h)
   double *Er;                 // landmark sharding only: [B][NV*NV + NV] E | eg rebuilt for a larger mu by every rank from its own tiles
@@ -296,6 +316,9 @@ void launch_candidate(const BatchDev &d, hipStream_t s);
 void launch_accept(const BatchDev &d, hipStream_t s);
 void launch_reanchor(const BatchDev &d, hipStream_t s);
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s);
+// mode 0: GNSS factors at the current parameters, added to H / g (after launch_assemble); 1: candidate cost; 2: the frame-0 factors at
+// the re-anchored state for MARGIN_OLD
+void launch_gnss(const BatchDev &d, int mode, hipStream_t s);
 
 // ---- device-resident feature tables (gfbe_ftab.hip; shared with the batch upload that reads them)
 enum { FT_NOBS = GFBE_WINDOW_SIZE + 1, FT_OW = 8, FT_BINS = NF * 8,

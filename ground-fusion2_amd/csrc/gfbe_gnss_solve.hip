@@ -1,0 +1,179 @@
+// gfbe_gnss_solve.hip — the GNSS factors inside the window solve and the marginalisation.
+//   problem set-up        Ground-Fusion++/vins_estimator/src/estimator/estimator.cpp:2965-3002 (blocks, the lowspeed gate)
+//   residual blocks       estimator.cpp:3239-3291 (GnssPsrDoppFactor per observation, DtDdtFactor / DdtSmoothFactor chains)
+//   marginalisation set   estimator.cpp:3459-3496 (the factors of frame 0, drop sets {0, 1, 4, 5}, {0, 2}, {0})
+// One workgroup per window. The observations are evaluated one per thread (the arithmetic is gfbe_gnss.h, shared with
+// gfbe_gnss_eval); their 2 x 18 Jacobians stay in L2 and every entry of the normal equations the GNSS factors reach is then
+// summed by ONE thread over the observations of the frames that can touch it, in observation order: no atomics, the same bits
+// on every run. The clock factors are linear with constant Jacobians and are added in closed form.
+#include "gfbe_devutil.h"
+#include "gfbe_gnss.h"
+
+namespace gfd {
+
+// ---- compact list of the tangent dims the GNSS factors reach in the solve (GN_C = 124; the yaw is constant there)
+__device__ __forceinline__ int gn_tan(int c) {
+  if (c < 33) return T_POSE(c / 3) + c % 3;                      // position of pose c / 3
+  if (c < 66) return T_SB((c - 33) / 3) + (c - 33) % 3;          // velocity of speed-bias (c - 33) / 3
+  if (c < 110) return T_DT(0, c - 66);
+  if (c < 121) return T_DDT(c - 110);
+  return T_ANC + (c - 121);
+}
+// frames whose observations can reach compact dim c (an observation of frame i interpolates between poses lower_idx and
+// lower_idx + 1 with lower_idx in {i - 1, i}: estimator.cpp:3253-3259)
+__device__ __forceinline__ void gn_frames(int c, int &lo, int &hi) {
+  if (c < 66) { const int f = (c < 33 ? c : c - 33) / 3; lo = max(f - 1, 0); hi = min(f + 1, NF - 1); }
+  else if (c < 110) lo = hi = (c - 66) / 4;
+  else if (c < 121) lo = hi = c - 110;
+  else { lo = 0; hi = NF - 1; }
+}
+// column of compact dim c in the 2 x 18 Jacobian of an observation (frame fr, lower_idx lw, constellation sys), or -1
+__device__ __forceinline__ int gn_col(int c, int fr, int lw, int sys) {
+  if (c < 33) { const int f = c / 3, q = c % 3; return f == lw ? q : (f == lw + 1 ? 6 + q : -1); }
+  if (c < 66) { const int f = (c - 33) / 3, q = (c - 33) % 3; return f == lw ? 3 + q : (f == lw + 1 ? 9 + q : -1); }
+  if (c < 110) return (c - 66) == 4 * fr + sys ? 12 : -1;
+  if (c < 121) return (c - 110) == fr ? 13 : -1;
+  return 15 + (c - 121);
+}
+// coefficient of compact dim c (a clock dim, 66 <= c < 121) in DtDdtFactor (i, k): [-50, 50, -25 dt, -25 dt] over
+// rcv_dt[i][k], rcv_dt[i + 1][k], rcv_ddt[i], rcv_ddt[i + 1] (gnss_dt_ddt_factor.cpp:3-34)
+__device__ __forceinline__ double gn_dtddt_coef(int c, int i, int k, double dt) {
+  if (c < 110) { const int f = (c - 66) >> 2, kk = (c - 66) & 3; return kk != k ? 0.0 : (f == i ? -50.0 : (f == i + 1 ? 50.0 : 0.0)); }
+  const int f = c - 110;
+  return (f == i || f == i + 1) ? -25.0 * dt : 0.0;
+}
+// ... and in DdtSmoothFactor (i): [w, -w] over rcv_ddt[i], rcv_ddt[i + 1] (gnss_ddt_smooth_factor.cpp:3-22)
+__device__ __forceinline__ double gn_smooth_coef(int c, int i, double wgt) {
+  if (c < 110) return 0.0;
+  const int f = c - 110;
+  return f == i ? wgt : (f == i + 1 ? -wgt : 0.0);
+}
+
+// ---- the marginalisation set's local dims (GN_M = 26): P0 V0 P1 V1 | rcv_dt[0][4] rcv_ddt[0] | rcv_dt[1][4] rcv_ddt[1] | yaw | anc
+__device__ __forceinline__ int gm_col(int la, int sys) {       // column in the Jacobian of a frame-0 observation (lower_idx 0), or -1
+  if (la < 12) return la;
+  if (la < 16) return (la - 12) == sys ? 12 : -1;
+  if (la == 16) return 13;
+  if (la < 22) return -1;
+  if (la == 22) return 14;
+  return 15 + (la - 23);
+}
+__device__ __forceinline__ double gm_dtddt_coef(int la, int k, double dt) {
+  if (la >= 12 && la < 16) return (la - 12) == k ? -50.0 : 0.0;
+  if (la >= 17 && la < 21) return (la - 17) == k ? 50.0 : 0.0;
+  return (la == 16 || la == 21) ? -25.0 * dt : 0.0;
+}
+__device__ __forceinline__ double gm_smooth_coef(int la, double wgt) { return la == 16 ? wgt : (la == 21 ? -wgt : 0.0); }
+
+#define GN_THREADS 256
+enum { GN_NCLK = 5 * GFBE_WINDOW_SIZE };   // 40 DtDdtFactors (constellation-major, the reference's insertion order) + 10 DdtSmoothFactors
+
+__global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
+  const int w = blockIdx.x, t = threadIdx.x;
+  const WinDesc &ds = d.desc[w];
+  if (!ds.gnss_ready) return;
+  const WinCtl &c = d.ctl[w];
+  if (mode == 0 && (!ds.gnss_factors || c.done || c.reuse)) return;
+  if (mode == 1 && (!ds.gnss_factors || c.done || !c.have_step)) return;
+  if (mode == 2 && ds.frame_count < GFBE_WINDOW_SIZE) return;
+  const double *X = mode == 2 ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + (mode == 1 ? 1 - c.cur : c.cur)) * NA;
+  __shared__ double red[16], clk_r[GN_NCLK];
+  const gfbe_gnss_obs *obs = d.gnss_obs + ds.gnss_off;
+  double *Jw = d.gnss_J + (size_t)ds.gnss_off * 36, *rw = d.gnss_r + (size_t)ds.gnss_off * 2;
+  // MARGIN_OLD takes the observations of frame 0 (first in the frame-sorted list) between poses 0 and 1, and the clock factors of
+  // the first interval
+  const int n_obs = mode == 2 ? ds.gnss_frame_begin[1] : ds.n_gnss, n_int = mode == 2 ? 1 : GFBE_WINDOW_SIZE;
+  double cost = 0.0;
+  for (int k = t; k < n_obs; k += GN_THREADS) {
+    const gfbe_gnss_obs o = obs[k];
+    const int lw = mode == 2 ? 0 : o.lower_idx;
+    double r[2], J[36];
+    gnss_psr_dopp_eval(o, ds.gnss_has_iono ? ds.gnss_iono : nullptr, X + A_POSE(lw), X + A_SB(lw), X + A_POSE(lw + 1), X + A_SB(lw + 1),
+                       X[A_DT + 4 * o.frame + o.sys_idx], X[A_DDT + o.frame], X[A_YAW], X + A_ANC, r, mode == 1 ? nullptr : J);
+    cost += 0.5 * r[0] * r[0] + 0.5 * r[1] * r[1];
+    if (mode != 1) {
+      rw[2 * k] = r[0]; rw[2 * k + 1] = r[1];
+      for (int q = 0; q < 36; q++) Jw[(size_t)36 * k + q] = J[q];
+    }
+  }
+  if (t < GN_NCLK) {
+    double r = 0.0;
+    if (t < 4 * GFBE_WINDOW_SIZE) {
+      const int k = t / GFBE_WINDOW_SIZE, i = t % GFBE_WINDOW_SIZE;
+      if (i < n_int) r = gnss_dt_ddt_res(X[A_DT + 4 * i + k], X[A_DT + 4 * (i + 1) + k], X[A_DDT + i], X[A_DDT + i + 1], ds.gnss_frame_dt[i]);
+    } else {
+      const int i = t - 4 * GFBE_WINDOW_SIZE;
+      if (i < n_int) r = gnss_ddt_smooth_res(X[A_DDT + i], X[A_DDT + i + 1], ds.gnss_ddt_weight);
+    }
+    clk_r[t] = r;
+    cost += 0.5 * r * r;
+  }
+  cost = block_sum(cost, red);      // (two block barriers: clk_r and this workgroup's Jw / rw are visible to every thread afterwards)
+  if (mode == 1) { if (t == 0) d.gnss_cost[(size_t)w * 2 + 1] = cost; return; }
+  const double wgt = ds.gnss_ddt_weight;
+  if (mode == 2) {
+    double *part = d.gnss_marg + (size_t)w * GN_MPART;
+    for (int e = t; e < GN_M * GN_M + GN_M; e += GN_THREADS) {
+      const bool isg = e >= GN_M * GN_M;
+      const int la = isg ? e - GN_M * GN_M : e / GN_M, lb = isg ? 0 : e % GN_M;
+      double s = 0.0;
+      for (int k = 0; k < n_obs; k++) {
+        const int sys = obs[k].sys_idx, ca = gm_col(la, sys), cb = isg ? 0 : gm_col(lb, sys);
+        if (ca < 0 || cb < 0) continue;
+        const double *J = Jw + (size_t)36 * k;
+        s += isg ? J[ca] * rw[2 * k] + J[18 + ca] * rw[2 * k + 1] : J[ca] * J[cb] + J[18 + ca] * J[18 + cb];
+      }
+      for (int k = 0; k < 4; k++) {
+        const double a = gm_dtddt_coef(la, k, ds.gnss_frame_dt[0]);
+        s += a * (isg ? clk_r[k * GFBE_WINDOW_SIZE] : gm_dtddt_coef(lb, k, ds.gnss_frame_dt[0]));
+      }
+      s += gm_smooth_coef(la, wgt) * (isg ? clk_r[4 * GFBE_WINDOW_SIZE] : gm_smooth_coef(lb, wgt));
+      part[e] = s;
+    }
+    if (t == 0) part[GN_MPART - 2] = cost;
+    return;
+  }
+  if (t == 0) d.gnss_cost[(size_t)w * 2] = cost;
+  if (d.rank != 0) return;      // landmark sharding: like the inertial / wheel / prior factors, added once
+  double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
+  for (int e = t; e < GN_C * (GN_C + 1) / 2 + GN_C; e += GN_THREADS) {
+    const bool isg = e >= GN_C * (GN_C + 1) / 2;
+    int ca, cb;
+    if (isg) { ca = e - GN_C * (GN_C + 1) / 2; cb = ca; } else tri_decode(e, ca, cb);
+    const int ta = gn_tan(ca), tb = gn_tan(cb);
+    if (!ds.act[ta] || !ds.act[tb]) continue;
+    int fa0, fa1, fb0, fb1;
+    gn_frames(ca, fa0, fa1);
+    gn_frames(cb, fb0, fb1);
+    const int f0 = max(fa0, fb0), f1 = min(fa1, fb1);
+    double s = 0.0;
+    if (f0 <= f1)
+      for (int k = ds.gnss_frame_begin[f0]; k < ds.gnss_frame_begin[f1 + 1]; k++) {
+        const gfbe_gnss_obs &o = obs[k];
+        const int ja = gn_col(ca, o.frame, o.lower_idx, o.sys_idx), jb = isg ? 0 : gn_col(cb, o.frame, o.lower_idx, o.sys_idx);
+        if (ja < 0 || jb < 0) continue;
+        const double *J = Jw + (size_t)36 * k;
+        s += isg ? J[ja] * rw[2 * k] + J[18 + ja] * rw[2 * k + 1] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
+      }
+    if (ca >= 66 && ca < 121 && cb >= 66 && cb < 121) {
+      for (int q = 0; q < 4 * GFBE_WINDOW_SIZE; q++) {
+        const int k = q / GFBE_WINDOW_SIZE, i = q % GFBE_WINDOW_SIZE;
+        const double a = gn_dtddt_coef(ca, i, k, ds.gnss_frame_dt[i]);
+        if (a != 0.0) s += a * (isg ? clk_r[q] : gn_dtddt_coef(cb, i, k, ds.gnss_frame_dt[i]));
+      }
+      for (int i = 0; i < GFBE_WINDOW_SIZE; i++) {
+        const double a = gn_smooth_coef(ca, i, wgt);
+        if (a != 0.0) s += a * (isg ? clk_r[4 * GFBE_WINDOW_SIZE + i] : gn_smooth_coef(cb, i, wgt));
+      }
+    }
+    if (isg) g[ta] += s;
+    else H[(size_t)max(ta, tb) * ND + min(ta, tb)] += s;      // (H holds its lower triangle; every entry has one owner thread)
+  }
+}
+
+void launch_gnss(const BatchDev &d, int mode, hipStream_t s) {
+  if (!d.any_gnss) return;
+  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), 0, s, d, mode);
+}
+
+}  // namespace gfd

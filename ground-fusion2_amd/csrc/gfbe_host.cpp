@@ -22,6 +22,8 @@
 #include <vector>
 
 using namespace gfd;
+static_assert(sizeof(gfbe_state) == sizeof(double) * NA, "gfbe_state layout: NA doubles");
+
 
 namespace gfd {
 void launch_preint_imu(int n, const int *d_off, const double *d_samples, const double *d_first, const double *d_lin,
@@ -567,11 +569,16 @@ int prior_out_bound(const gfbe_window &win, const int *pair_begin, bool old) {
   for (int k = 0; k < win.n_wheel; k++)
     if (win.wheel_frame[k] == 0) touched[0] = touched[1] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_SX] = touched[GFBE_BLK_SY] = touched[GFBE_BLK_SW] = touched[GFBE_BLK_TD_WHEEL] = true;
   if (win.use_plane && win.frame_count > 0) touched[0] = touched[GFBE_BLK_EX_WHEEL] = touched[GFBE_BLK_PLANE_R] = touched[GFBE_BLK_PLANE_Z] = true;
+  if (win.gnss_ready) {
+    touched[0] = touched[GFBE_BLK_SB0] = touched[1] = touched[GFBE_BLK_SB0 + 1] = touched[GFBE_BLK_YAW_ENU] = touched[GFBE_BLK_ANC_ECEF] = true;
+    for (int k = 0; k < 4; k++) touched[GFBE_BLK_RCV_DT0 + 4 + k] = true;
+    touched[GFBE_BLK_RCV_DDT0 + 1] = true;
+  }
   if (pair_begin) { for (int j = 1; j < NF; j++) if (pair_begin[j + 1] > pair_begin[j]) touched[0] = touched[j] = touched[GFBE_BLK_EX_CAM] = touched[GFBE_BLK_TD] = true; }
   else for (int q = 0; q < NF; q++) touched[q] = touched[GFBE_BLK_EX_CAM] = touched[GFBE_BLK_TD] = true;   // (table-fed: pair counts live on the device)
   int n = 0;
   for (int q = 0; q < GFBE_BLK_COUNT; q++) if (touched[q] && q != 0 && q != GFBE_BLK_SB0) n += blk_lsize(q);
-  return n;
+  return std::min(n, (int)ND);
 }
 }  // namespace
 
@@ -663,7 +670,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<int> tile_start;
   std::vector<int> feat_off(B + 1, 0);
   std::vector<long long> j0_off(B + 1, 0);
-  int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0;
+  int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0, tot_gnss = 0, any_gnss = 0, gnss_dims = 0;
   double algo_bytes = 0.0;
   for (int w = 0; w < B; w++) {
     const gfbe_window &win = *wins[w];
@@ -678,6 +685,18 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     tot_lm += sc.slots; tot_rec += sc.K; max_tiles = std::max(max_tiles, sc.n_tiles);
     ds.imu_off = n_imu_tot; ds.wheel_off = n_wheel_tot; ds.lio_off = tot_lio;
     n_imu_tot += win.n_imu; n_wheel_tot += win.n_wheel; tot_lio += win.lio.n > 0 ? win.lio.n : 0;
+    if (win.gnss_ready) {
+      if (win.n_gnss < 0 || (win.n_gnss > 0 && !win.gnss_obs)) { c->err = "window " + std::to_string(w) + ": gnss_ready without observations array"; return GFBE_BAD_INPUT; }
+      for (int k = 0; k < win.n_gnss; k++) {
+        const gfbe_gnss_obs &o = win.gnss_obs[k];
+        if (o.frame < 0 || o.frame > GFBE_WINDOW_SIZE || o.lower_idx < 0 || o.lower_idx >= GFBE_WINDOW_SIZE || (o.lower_idx != o.frame && o.lower_idx != o.frame - 1) ||
+            o.sys_idx < 0 || o.sys_idx > 3 || !(o.pr_uura > 0.0) || !(o.dp_uura > 0.0)) {
+          c->err = "window " + std::to_string(w) + ": GNSS observation " + std::to_string(k) + " has an index or a deviation out of range"; return GFBE_BAD_INPUT;
+        }
+      }
+      ds.gnss_ready = 1; ds.n_gnss = win.n_gnss; ds.gnss_off = tot_gnss;
+      tot_gnss += win.n_gnss; any_gnss = 1;
+    }
     b->L[w] = sc.L;
     feat_off[w + 1] = feat_off[w] + sc.L;
     // MARGIN_SECOND_NEW with an INVALID last_marginalization_info that still lists Pose[WINDOW_SIZE-1] (estimator.cpp:3600, 3622-3632):
@@ -697,6 +716,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
           c->err = "window " + std::to_string(w) + ": prior block table inconsistent (id, size, duplicate or offset out of range)"; return GFBE_BAD_INPUT;
         }
         seen[id] = true; xo += pr.block_size[q];
+        if (id >= GFBE_BLK_ANC_ECEF) gnss_dims = 1;
       }
       if (xo > (int)PRIOR_X0) { c->err = "prior x0 too large"; return GFBE_BAD_INPUT; }
       pn_max = std::max(pn_max, pr.n);
@@ -712,6 +732,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
   for (int w = 0; w < B; w++) if (wins[w]->use_plane || wins[w]->use_anchor) d.any_plane = 1;
+  d.any_gnss = any_gnss; d.tot_gnss = tot_gnss;
+  d.nu = (any_gnss || gnss_dims) ? (int)ND : (int)NC;       // a batch without GNSS blocks never touches the last 59 tangent dims
+  d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
   if (getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics: force the 20-column panel)
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
@@ -722,6 +745,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   long long *h_j0_off = nullptr;
   double *h_lm_pts = nullptr, *h_lam0 = nullptr, *h_fobs = nullptr, *h_x0 = nullptr, *h_lio = nullptr, *h_pr0 = nullptr, *h_px0 = nullptr, *h_pJ0 = nullptr;
   gfbe_imu_preint *h_imu = nullptr; gfbe_wheel_preint *h_wheel = nullptr;
+  gfbe_gnss_obs *h_gnss = nullptr;
   double *d_pJ0c = nullptr;
   const bool want_rec = c->want_records;
   for (int pass = 0; pass < 2; pass++) {
@@ -738,6 +762,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     UP(imu, h_imu, n_imu_tot); UP(wheel, h_wheel, n_wheel_tot); UP(lio, h_lio, (size_t)tot_lio * 8);
     UP(prior_r0, h_pr0, (size_t)B * ND); UP(prior_x0, h_px0, (size_t)B * PRIOR_X0);
     UP(dl_feat_off, h_feat_off, B + 1); UP(dl_j0_off, h_j0_off, B + 1);
+    UP(gnss_obs, h_gnss, std::max(tot_gnss, 1));
     if ((st = up_alloc(c, b, &d_pJ0c, &h_pJ0, (size_t)B * pj_row)) != GFBE_OK) return st;
     if (!tabs) { UP(lm_info, h_lm_info, TL); UP(lm_abi, h_lm_abi, TL); UP(lm_pts, h_lm_pts, (size_t)6 * TL); UP(lam0, h_lam0, TL); UP(fobs, h_fobs, (size_t)tot_rec * 5); }
     const size_t up_end = b->dry ? b->slab_bytes : b->slab_off;
@@ -785,7 +810,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
     AL(rec, want_rec ? (size_t)tot_rec * REC : 1); AL(mV, (size_t)B * ND * ND);
     AL(vis_contrib, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) * MAXOBS * 16 * LM_TILE : 1);
-    AL(solveY, (size_t)B * solve_chain_scratch_doubles());
+    AL(solveY, d.solve_big ? 1 : (size_t)B * solve_chain_scratch_doubles());
+    AL(solveS, d.solve_big ? (size_t)B * BIG_LD * BIG_LD : 1);
+    AL(gnss_J, (size_t)std::max(tot_gnss, 1) * 36); AL(gnss_r, (size_t)std::max(tot_gnss, 1) * 2);
+    AL(gnss_cost, (size_t)B * 2); AL(gnss_marg, any_gnss ? (size_t)B * GN_MPART : 1);
     AL(dl_fix, (size_t)B * DL_FIX); AL(dl_feat, feat_off[B]); AL(dl_J0, (size_t)j0_off[B]);
     if (!b->dry) { b->up_end = up_end; b->zero_end = zero_end; }
 #undef UP
@@ -907,6 +935,33 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     for (int i = 0; i < ds.n_plane; i++) used[i] = true;
     if (ds.n_plane > 0) used[GFBE_BLK_EX_WHEEL] = used[GFBE_BLK_PLANE_R] = used[GFBE_BLK_PLANE_Z] = true;
     if (ds.use_anchor) used[0] = true;
+    // GNSS (estimator.cpp:2965-3002, 3239-3291): the observations sorted by frame (stable: the reference's insertion order is
+    // frame-major already), the lowspeed gate from the window's velocities, the blocks the factors touch
+    if (ds.gnss_ready) {
+      int cnt[NF + 1];
+      for (int q = 0; q <= NF; q++) cnt[q] = 0;
+      for (int k = 0; k < win.n_gnss; k++) cnt[win.gnss_obs[k].frame + 1]++;
+      for (int q = 0; q < NF; q++) cnt[q + 1] += cnt[q];
+      for (int q = 0; q <= NF; q++) ds.gnss_frame_begin[q] = cnt[q];
+      for (int k = 0; k < win.n_gnss; k++) h_gnss[ds.gnss_off + cnt[win.gnss_obs[k].frame]++] = win.gnss_obs[k];
+      ds.gnss_has_iono = win.gnss_iono ? 1 : 0;
+      for (int q = 0; q < 8; q++) ds.gnss_iono[q] = win.gnss_iono ? win.gnss_iono[q] : 0.0;
+      for (int q = 0; q < GFBE_WINDOW_SIZE; q++) ds.gnss_frame_dt[q] = win.gnss_frame_dt[q];
+      ds.gnss_ddt_weight = win.gnss_ddt_weight;
+      double ax = 0.0, ay = 0.0;
+      for (int i = 0; i <= GFBE_WINDOW_SIZE; i++) { ax += std::fabs(win.state.para_SpeedBias[i][0]); ay += std::fabs(win.state.para_SpeedBias[i][1]); }
+      ax /= GFBE_WINDOW_SIZE + 1; ay /= GFBE_WINDOW_SIZE + 1;
+      ds.gnss_factors = !(std::sqrt(ax * ax + ay * ay) < 0.3);
+      if (ds.gnss_factors) {
+        for (int k = 0; k < win.n_gnss; k++) {
+          const gfbe_gnss_obs &o = win.gnss_obs[k];
+          used[o.lower_idx] = used[GFBE_BLK_SB0 + o.lower_idx] = used[o.lower_idx + 1] = used[GFBE_BLK_SB0 + o.lower_idx + 1] = true;
+          used[GFBE_BLK_YAW_ENU] = used[GFBE_BLK_ANC_ECEF] = true;
+        }
+        for (int q = GFBE_BLK_RCV_DT0; q < GFBE_BLK_COUNT; q++) used[q] = true;     // DtDdtFactor / DdtSmoothFactor chains
+      }
+      bytes += sizeof(gfbe_gnss_obs) * win.n_gnss;
+    }
     for (int q = 0; q < GFBE_BLK_COUNT; q++) {
       bool cst;
       if (q < GFBE_BLK_SB0) cst = win.pose_const[q] || q > win.frame_count;
@@ -916,6 +971,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       else if (q == GFBE_BLK_TD) cst = win.td_const;
       else if (q == GFBE_BLK_TD_WHEEL) cst = win.td_wheel_const;
       else if (q == GFBE_BLK_PLANE_R || q == GFBE_BLK_PLANE_Z) cst = win.plane_const;
+      else if (q == GFBE_BLK_YAW_ENU) cst = win.gnss_ready != 0;         // estimator.cpp:2991
+      else if (q == GFBE_BLK_ANC_ECEF || q >= GFBE_BLK_RCV_DT0) cst = false;
       else cst = win.ix_wheel_const;
       ds.blk_free[q] = used[q] && !cst;
       if (ds.blk_free[q]) for (int k = 0; k < blk_lsize(q); k++) ds.act[blk_tan(q) + k] = 1;
@@ -1098,6 +1155,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   { Timed t(c, first ? "k_visblock_iter0" : "k_visblock", 0); launch_visblock(d, ln.s); }
   if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);   // join
   { Timed t(c, first ? "k_assemble_iter0" : "k_assemble", 0); launch_assemble(d, ln.s); }
+  if (d.any_gnss) { Timed t(c, "k_gnss", 0); launch_gnss(d, 0, ln.s); }
   if (d.sharded) { Timed t(c, "allreduce_system", 0); run_allreduce(c, d.H, (int64_t)b->slab_n, ln.s); }
   { Timed t(c, first ? "k_solve_iter0" : "k_solve", 0); launch_solve(d, ln.s); }
   if (d.sharded) {
@@ -1135,6 +1193,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     if (small) launch_lin_small(d, 1, ln.s);
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
+    if (d.any_gnss) { Timed t(c, "k_gnss_cost", 0); launch_gnss(d, 1, ln.s); }
     if (!small && !overlap) { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, ln.s); }
     else if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);
     if (d.sharded) {
@@ -1366,6 +1425,7 @@ extern "C" gfbe_status gfbe_eval_factors(gfbe_ctx *c, const gfbe_window *win, in
   launch_reset(d, c->stream);
   launch_vis(d, 0, c->stream, /*write_records=*/1);
   launch_dense_factors(d, 0, 1, c->stream);
+  launch_gnss(d, 0, c->stream);       // (its cost; the normal-equation entries it adds to are not read here)
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int K = win->vis.n_factor;
@@ -1418,6 +1478,11 @@ extern "C" gfbe_status gfbe_eval_factors(gfbe_ctx *c, const gfbe_window *win, in
       HIPCHK(c, hipMemcpy(ap.data(), d.anchor_part, sizeof(double) * ap.size(), hipMemcpyDeviceToHost));
       for (int q = 0; q < ds[0].n_plane; q++) total += pp[(size_t)q * PLANE_PART + PLANE_PART - 2];
       if (ds[0].use_anchor) total += ap[ANCHOR_PART - 2];
+    }
+    if (ds[0].gnss_factors) {           // GNSS factors inside the window (gnss_ready and not lowspeed)
+      double gc[2];
+      HIPCHK(c, hipMemcpy(gc, d.gnss_cost, sizeof gc, hipMemcpyDeviceToHost));
+      total += gc[0];
     }
     *cost = total;
   }

@@ -1332,10 +1332,11 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
   const bool lio_on = vsplit && ds.lio_n > 0 && d.rank == 0;
   const int lio_o = 6 * ds.lio_frame;
   const double *vis_s = vsplit ? d.vis_Hs + (size_t)w * VS_BLOCKS * NV * V_LD : Z;
-  for (int e0 = gt; e0 < ASM_NTRI; e0 += 4 * gn) {
+  const int ntri = d.nu * (d.nu + 1) / 2;      // the table is ordered by the larger dim: a batch without GNSS windows stops after the 187 core dims
+  for (int e0 = gt; e0 < ntri; e0 += 4 * gn) {
     int4 ent[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const int e = e0 + u * gn; ent[u] = e < ASM_NTRI ? tab[e] : make_int4(-1, 0, 0, 0); }
+    for (int u = 0; u < 4; u++) { const int e = e0 + u * gn; ent[u] = e < ntri ? tab[e] : make_int4(-1, 0, 0, 0); }
     const double *p[4][6];
     bool on[4];
 #pragma unroll
@@ -1646,8 +1647,8 @@ __device__ __forceinline__ void candidate_dense(const BatchDev &d, const WinDesc
   double *Y = d.x + ((size_t)w * 2 + 1 - c.cur) * NA;
   if (my_wave) {
     double d2 = 0.0, n2 = 0.0;
-    if (t < GFBE_BLK_COUNT) {
-      const int b = t, off = blk_tan(b), am = blk_amb(b), gs = blk_gsize(b);
+    for (int b = t; b < GFBE_BLK_COUNT; b += 64) {
+      const int off = blk_tan(b), am = blk_amb(b), gs = blk_gsize(b);
       if (ds.blk_free[b]) {
         double dl[9];
         for (int k = 0; k < blk_lsize(b); k++) {
@@ -1715,6 +1716,7 @@ __global__ __launch_bounds__(64) void k_accept(BatchDev d) {
   if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 28];
   if (lane >= 48 && lane - 48 < ds.n_plane) cand += d.plane_part[((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - 1];
   if (lane == 58 && ds.use_anchor) cand += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 1];
+  if (lane == 59 && ds.gnss_factors) cand += d.gnss_cost[(size_t)w * 2 + 1];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o, 64); d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
   if (lane != 0) return;
@@ -1783,6 +1785,13 @@ __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
   } else if (t == NF + 1) {
     const quat q = rot2quat(qrot(qnormalize(ldq(X + A_EXW + 3))));
     Y[A_EXW + 3] = q.x; Y[A_EXW + 4] = q.y; Y[A_EXW + 5] = q.z; Y[A_EXW + 6] = q.w;
+  } else if (t == NF + 2) {   // estimator.cpp:3383-3386: para_yaw_enu_local back into (-pi, pi]
+    double yaw = X[A_YAW];
+    if (isfinite(yaw)) {
+      while (yaw > 3.14159265358979323846) yaw -= 2.0 * 3.14159265358979323846;
+      while (yaw < -3.14159265358979323846) yaw += 2.0 * 3.14159265358979323846;
+    }
+    Y[A_YAW] = yaw;
   }
   // pose-pair constants of the re-anchored state: the marginalisation linearises its visual factors there
   __shared__ PoseRT sp_anch[NF + 1];

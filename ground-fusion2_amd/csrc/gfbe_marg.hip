@@ -51,6 +51,20 @@ __device__ __forceinline__ int m_plane_loc(int a) {        // PlaneFactor of pos
   return -1;
 }
 
+__device__ __forceinline__ int m_gnss_loc(int a) {         // the frame-0 GNSS factors (k_gnss mode 2: P0 V0 P1 V1 | dt0 ddt0 | dt1 ddt1 | yaw | anc)
+  if (a < 3) return a;
+  if (a >= T_SB(0) && a < T_SB(0) + 3) return 3 + (a - T_SB(0));
+  if (a >= T_POSE(1) && a < T_POSE(1) + 3) return 6 + (a - T_POSE(1));
+  if (a >= T_SB(1) && a < T_SB(1) + 3) return 9 + (a - T_SB(1));
+  if (a >= T_DT(0, 0) && a < T_DT(0, 0) + 4) return 12 + (a - T_DT(0, 0));
+  if (a == T_DDT(0)) return 16;
+  if (a >= T_DT(1, 0) && a < T_DT(1, 0) + 4) return 17 + (a - T_DT(1, 0));
+  if (a == T_DDT(1)) return 21;
+  if (a == T_YAW) return 22;
+  if (a >= T_ANC && a < T_ANC + 3) return 23 + (a - T_ANC);
+  return -1;
+}
+
 __device__ __forceinline__ int m_schur_off(int a, int b) {   // a <= b: offset inside a start-frame partial
   const int I = a >> 4, J = b >> 4;
   return (I * 5 - I * (I - 1) / 2 + (J - I)) * 256 + (a & 15) * 16 + (b & 15);
@@ -67,9 +81,9 @@ struct MargShared {
   int touched[GFBE_BLK_COUNT];
   int keep_id[GFBE_MAX_PRIOR_BLOCKS];
   int n_keep, n, m;
-  int drop_dim[16];       // tangent dims being eliminated densely (15 for OLD, 6 for SECOND_NEW)
+  int drop_dim[32];       // tangent dims being eliminated densely (15 for OLD, + 5 receiver clock dims with GNSS; 6 for SECOND_NEW)
   int keep_dim[ND];       // tangent dim of kept column k
-  int use_imu, use_wheel, use_plane;
+  int use_imu, use_wheel, use_plane, use_gnss;
   int passthrough;
   int sweeps;
 };
@@ -194,7 +208,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const WinDesc &ds = d.desc[w];
   const int t = threadIdx.x;
   __shared__ MargShared sh;
-  __shared__ double Pm[16 * 16], Pv[16 * 16], Pw[16 * 16], Pl[16], Pinv[16 * 16], bm[16];
+  __shared__ double Pm[16 * 16], Pv[16 * 16], Pw[16 * 16], Pl[16], Pinv16[16 * 16], bm[32];
+  extern __shared__ __attribute__((aligned(16))) double marg_lds[];
   __shared__ int cflag;
   int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
   const double *Xo = d.xout + (size_t)w * NA;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   if (t == 0) {
     for (int q = 0; q < GFBE_BLK_COUNT; q++) sh.touched[q] = 0;
     for (int q = 0; q < ds.prior_nblk; q++) sh.touched[ds.prior_blk_id[q]] = 1;
-    sh.use_imu = sh.use_wheel = sh.use_plane = 0; sh.passthrough = 0;
+    sh.use_imu = sh.use_wheel = sh.use_plane = sh.use_gnss = 0; sh.passthrough = 0;
     if (old) {
       for (int q = 0; q < ds.n_imu; q++) if (d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2] >= 0.0 && ds.imu_frame[q] == 0) sh.use_imu = 1 + q;
       for (int q = 0; q < ds.n_wheel; q++) if (d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2] >= 0.0 && ds.wheel_frame[q] == 0) sh.use_wheel = 1 + q;
@@ -226,11 +241,22 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
         sh.use_plane = 1;
         sh.touched[0] = sh.touched[GFBE_BLK_EX_WHEEL] = sh.touched[GFBE_BLK_PLANE_R] = sh.touched[GFBE_BLK_PLANE_Z] = 1;
       }
+      if (ds.gnss_ready) {   // estimator.cpp:3459-3496: the GNSS factors of frame 0 (k_gnss mode 2), whether the window was slow or not
+        sh.use_gnss = 1;
+        if (ds.gnss_frame_begin[1] > 0)
+          sh.touched[0] = sh.touched[GFBE_BLK_SB0] = sh.touched[1] = sh.touched[GFBE_BLK_SB0 + 1] = sh.touched[GFBE_BLK_YAW_ENU] = sh.touched[GFBE_BLK_ANC_ECEF] = 1;
+        for (int k = 0; k < 4; k++) sh.touched[GFBE_BLK_RCV_DT0 + k] = sh.touched[GFBE_BLK_RCV_DT0 + 4 + k] = 1;
+        sh.touched[GFBE_BLK_RCV_DDT0] = sh.touched[GFBE_BLK_RCV_DDT0 + 1] = 1;
+      }
     }
     int m = 0;
     if (old) {
       if (sh.touched[0]) for (int k = 0; k < 6; k++) sh.drop_dim[m++] = k;
       if (sh.touched[GFBE_BLK_SB0]) for (int k = 0; k < 9; k++) sh.drop_dim[m++] = T_SB(0) + k;
+      if (sh.use_gnss) {   // drop sets {0, 1, 4, 5}, {0, 2}, {0}: rcv_dt[0][k], rcv_ddt[0]
+        for (int k = 0; k < 4; k++) sh.drop_dim[m++] = T_DT(0, k);
+        sh.drop_dim[m++] = T_DDT(0);
+      }
     } else {
       const int pb = GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1;
       if (ds.prior_n > 0 && sh.touched[pb]) for (int k = 0; k < 6; k++) sh.drop_dim[m++] = T_POSE(GFBE_WINDOW_SIZE - 1) + k;
@@ -240,7 +266,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     int nk = 0, n = 0;
     for (int q = 0; q < GFBE_BLK_COUNT; q++) {
       if (!sh.touched[q]) continue;
-      bool dropped = old ? (q == 0 || q == GFBE_BLK_SB0) : (q == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1);
+      bool dropped = old ? (q == 0 || q == GFBE_BLK_SB0 || (sh.use_gnss && ((q >= GFBE_BLK_RCV_DT0 && q < GFBE_BLK_RCV_DT0 + 4) || q == GFBE_BLK_RCV_DDT0)))
+                         : (q == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1);
       if (dropped) continue;
       sh.keep_id[nk++] = q;
       for (int k = 0; k < blk_lsize(q); k++) sh.keep_dim[n++] = blk_tan(q) + k;
@@ -273,6 +300,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const double *ipart = sh.use_imu ? d.imu_part + ((size_t)w * MAX_IMU + sh.use_imu - 1) * IMU_PART : nullptr;
   const double *wpart = sh.use_wheel ? d.wheel_part + ((size_t)w * MAX_WHEEL + sh.use_wheel - 1) * WHEEL_PART : nullptr;
   const double *ppart = sh.use_plane ? d.plane_part + (size_t)w * MAX_PLANE * PLANE_PART : nullptr;
+  const double *gpart = sh.use_gnss ? d.gnss_marg + (size_t)w * GN_MPART : nullptr;
   // only the dims of the marginalisation (dropped + kept, nn <= 101 of 182) are ever read back: pairs (ia >= ib) of that list
   const int nn = n + m;
   for (int e = t; e < nn * (nn + 1) / 2; e += blockDim.x) {
@@ -293,6 +321,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     if (ipart) { const int la = m_imu_loc(a), lb = m_imu_loc(b); if (la >= 0 && lb >= 0) s += ipart[la * 30 + lb]; }
     if (wpart) { const int la = m_wheel_loc(a), lb = m_wheel_loc(b); if (la >= 0 && lb >= 0) s += wpart[la * 22 + lb]; }
     if (ppart) { const int la = m_plane_loc(a), lb = m_plane_loc(b); if (la >= 0 && lb >= 0) s += ppart[la * 16 + lb]; }
+    if (gpart) { const int la = m_gnss_loc(a), lb = m_gnss_loc(b); if (la >= 0 && lb >= 0) s += gpart[la * GN_M + lb]; }
     if (ds.prior_n > 0) { const int pa = ds.prior_map[a], pb = ds.prior_map[b]; if (pa >= 0 && pb >= 0) s += d.prior_H[(size_t)w * ND * ND + (size_t)pa * ds.prior_n + pb]; }
     A[(size_t)a * ND + b] = s; A[(size_t)b * ND + a] = s;
   }
@@ -308,17 +337,38 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     if (ipart) { const int la = m_imu_loc(a); if (la >= 0) s += ipart[900 + la]; }
     if (wpart) { const int la = m_wheel_loc(a); if (la >= 0) s += wpart[484 + la]; }
     if (ppart) { const int la = m_plane_loc(a); if (la >= 0) s += ppart[256 + la]; }
+    if (gpart) { const int la = m_gnss_loc(a); if (la >= 0) s += gpart[GN_M * GN_M + la]; }
     if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
     bv[a] = s;
   }
   __syncthreads();
   MSTAMP(2);
   // ---- dense elimination of the m dropped dims: Amm = V diag(l) V^T, pinv with eps
+  // (m <= 16: the one-wave path below; the 20 dims of a GNSS window: the workgroup-wide Jacobi on a 32-stride block of the dynamic
+  //  LDS, which is free until A' is eigen-decomposed — the reference's construction without a shortcut)
+  const int ms = m > 16 ? 32 : 16;
+  double *Pinv = m > 16 ? marg_lds + 2 * 32 * 32 : Pinv16;
+  if (t < m) bm[t] = bv[sh.drop_dim[t]];
+  if (m > 16) {
+    double *G32 = marg_lds, *V32 = marg_lds + 32 * 32, *lam32 = marg_lds + 3 * 32 * 32;
+    for (int e = t; e < m * m; e += blockDim.x) {
+      const int i = e / m, j = e % m;
+      G32[j * 32 + i] = 0.5 * (A[(size_t)sh.drop_dim[i] * ND + sh.drop_dim[j]] + A[(size_t)sh.drop_dim[j] * ND + sh.drop_dim[i]]);
+    }
+    __syncthreads();
+    jacobi_eig(G32, V32, m, 32, lam32, &cflag, nullptr);
+    for (int e = t; e < m * m; e += blockDim.x) {
+      const int i = e / m, j = e % m;
+      double s = 0.0;
+      for (int k = 0; k < m; k++) if (lam32[k] > d.opt.marg_eps) s += V32[k * 32 + i] * V32[k * 32 + j] / lam32[k];
+      Pinv[i * 32 + j] = s;
+    }
+    __syncthreads();
+  } else {
   for (int e = t; e < m * m; e += blockDim.x) {
     const int i = e / m, j = e % m;
     Pm[j * 16 + i] = 0.5 * (A[(size_t)sh.drop_dim[i] * ND + sh.drop_dim[j]] + A[(size_t)sh.drop_dim[j] * ND + sh.drop_dim[i]]);
   }
-  if (t < m) bm[t] = bv[sh.drop_dim[t]];
   __syncthreads();
   // Fast path: when every eigenvalue of Amm is safely above eps the thresholded pseudo-inverse IS the inverse. One wave
   // takes the Cholesky factor L (lane = row), the lanes invert it column by column, Pinv = L^-T L^-1, and
@@ -385,26 +435,27 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     }
     __syncthreads();
   }
+  }
   MSTAMP(3);
   // T = A_rm * Pinv (n x m) kept in J0's storage; then A' and b' (compact, n x n) into r0/J0 staging
-  double *T = J0;   // n x 16
+  double *T = J0;   // n x ms
   for (int e = t; e < n * m; e += blockDim.x) {
     const int i = e / m, j = e % m;
     double s = 0.0;
-    for (int k = 0; k < m; k++) s += A[(size_t)sh.keep_dim[i] * ND + sh.drop_dim[k]] * Pinv[k * 16 + j];
-    T[i * 16 + j] = s;
+    for (int k = 0; k < m; k++) s += A[(size_t)sh.keep_dim[i] * ND + sh.drop_dim[k]] * Pinv[k * ms + j];
+    T[i * ms + j] = s;
   }
   __syncthreads();
-  double *Ap = J0 + (size_t)ND * 16;   // compact A' (n x n, ld = n) — fits: 16*ND + n*n <= ND*ND for n <= 166
+  double *Ap = J0 + (size_t)ND * ms;   // compact A' (n x n, ld = n) — fits: 32 ND + n^2 <= ND^2 for n <= 229
   for (int e = t; e < n * n; e += blockDim.x) {
     const int i = e / n, j = e % n;
     double s = A[(size_t)sh.keep_dim[i] * ND + sh.keep_dim[j]];
-    for (int k = 0; k < m; k++) s -= T[i * 16 + k] * A[(size_t)sh.drop_dim[k] * ND + sh.keep_dim[j]];
+    for (int k = 0; k < m; k++) s -= T[i * ms + k] * A[(size_t)sh.drop_dim[k] * ND + sh.keep_dim[j]];
     Ap[(size_t)i * n + j] = s;
   }
   for (int i = t; i < n; i += blockDim.x) {
     double s = bv[sh.keep_dim[i]];
-    for (int k = 0; k < m; k++) s -= T[i * 16 + k] * bm[k];
+    for (int k = 0; k < m; k++) s -= T[i * ms + k] * bm[k];
     r0[i] = s;           // b' staged in r0
   }
   __syncthreads();
@@ -416,7 +467,6 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   for (int i = t; i < n; i += blockDim.x) bv[i] = r0[i];
   __syncthreads();
   MSTAMP(4);
-  extern __shared__ __attribute__((aligned(16))) double marg_lds[];
   __shared__ int order[ND];
   if (d.opt.marg_sqrt == 1) {
     // the square root itself is taken by k_marg_ldlt (own kernel: the matrix is register-resident there)
@@ -462,8 +512,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     for (int q = 0; q < sh.n_keep; q++) {
       const int id = sh.keep_id[q];
       int nid = id;
-      if (old) { if (id < GFBE_BLK_EX_CAM) nid = id - 1; }
-      else if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE) nid = id - 1;
+      const bool is_dt = id >= GFBE_BLK_RCV_DT0 && id < GFBE_BLK_RCV_DDT0, is_ddt = id >= GFBE_BLK_RCV_DDT0;
+      if (old) { if (id < GFBE_BLK_EX_CAM || is_ddt) nid = id - 1; else if (is_dt) nid = id - 4; }   // slot i -> i - 1: pose, speed-bias, receiver clock
+      else if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_RCV_DDT0 + GFBE_WINDOW_SIZE) nid = id - 1;
+      else if (is_dt && id >= GFBE_BLK_RCV_DT0 + 4 * GFBE_WINDOW_SIZE) nid = id - 4;
       meta[4 + q] = nid; meta[4 + GFBE_MAX_PRIOR_BLOCKS + q] = blk_gsize(id); meta[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q] = idx;
       for (int k = 0; k < blk_gsize(id); k++) d.mx0[(size_t)w * PRIOR_X0 + xo + k] = Xo[blk_amb(id) + k];
       idx += blk_lsize(id); xo += blk_gsize(id);
@@ -610,6 +662,7 @@ void launch_marginalize_partials(const BatchDev &d, hipStream_t s) {
   launch_vis(d, 2, s);
   launch_pair(d, 1, s);
   launch_dense_factors(d, 2, 0, s);
+  launch_gnss(d, 2, s);
   launch_schur(d, 1, s);
 }
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {

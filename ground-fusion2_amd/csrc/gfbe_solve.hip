@@ -1284,7 +1284,251 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
 }
 
 
-static size_t solve_smem_bytes() { const int nt = (ND + 1 + TB - 1) / TB; return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
+
+// =============================================================================================
+// k_solve_big: the same step as k_solve for windows whose reduced system does not fit a CU's LDS — the GNSS blocks (anchor,
+// 44 receiver clock biases, 11 drifts) bring the dense part to as many as 246 dims: 136 tiles of 2 KB. The scaled, regularised,
+// Schur-reduced system and its factor live in global memory (BatchDev::solveS, 512 KB per window, L2 resident for a handful of
+// windows); the factorisation is left-looking over 16-column panels:
+//     panel j (rows 16 j .. of the lower triangle) is loaded into LDS, downdated by the earlier panels k < j staged through LDS
+//     one at a time (P -= L(., k) L(j, k)^T), its diagonal tile is factorised and inverted by one wave (chol_inv_tile16, the
+//     register-resident step of k_solve), the rows below become L = P W^T, and the panel goes back to global memory with W in
+//     place of the diagonal tile.
+// The right-hand side is row n of the matrix (forward substitution for free), the back-substitution runs panel by panel from
+// the last. GNSS is an optional path of the reference (gnss_enable: 0 in every shipped yaml): this kernel favours plain,
+// structure-agnostic code — any set of active dims, any prior — over the last microsecond (k_solve / k_solve_chain keep the
+// batches without GNSS dims).
+// =============================================================================================
+#define BIG_THREADS 512
+enum { BIG_PLD = 17, BIG_ROWS = BIG_LD };
+static size_t big_smem_bytes() { return sizeof(double) * (2 * (size_t)BIG_ROWS * BIG_PLD + TB * TB); }
+
+__global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry_pass) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  if (retry_pass && !c.lin_retry) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double *Pn = smem, *Q = smem + BIG_ROWS * BIG_PLD, *Dg = smem + 2 * BIG_ROWS * BIG_PLD;
+  __shared__ short perm[ND + TB];
+  __shared__ double red[16], ys[2 * ND + TB], zlast[TB];
+  __shared__ double s_zz, s_vSv;
+  __shared__ int flag, s_nact, wcount[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
+  double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
+  double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
+  double *S = d.solveS + (size_t)w * BIG_LD * BIG_LD;
+  const bool first = (c.iter == 0);
+  // active-dim list by a wave-level prefix count (dims 0..255 live in waves 0..3)
+  {
+    const bool on = (t < ND) && ds.act[t];
+    const unsigned long long m = __ballot(on);
+    if (t < 256 && lane == 0) wcount[wave] = __popcll(m);
+    __syncthreads();
+    if (t < 256) {
+      int base = 0;
+      for (int q = 0; q < wave; q++) base += wcount[q];
+      if (on) perm[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+      if (t == 0) s_nact = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    }
+    __syncthreads();
+    for (int a = s_nact + t; a < ND + TB; a += blockDim.x) perm[a] = -1;
+  }
+  if (first && t == 0) {   // total cost of the first linearisation point (fixed order)
+    double cost = 0.0;
+    for (int r = 0; r < d.world; r++) cost += d.xa[((size_t)w * d.world + r) * XCHG];
+    for (int q = 0; q < ds.n_imu; q++) cost += d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2];
+    for (int q = 0; q < ds.n_wheel; q++) cost += d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2];
+    cost += d.prior_g[(size_t)w * (ND + 2) + ND];
+    for (int q = 0; q < ds.n_plane; q++) cost += d.plane_part[((size_t)w * MAX_PLANE + q) * PLANE_PART + PLANE_PART - 2];
+    if (ds.use_anchor) cost += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
+    if (ds.gnss_factors) cost += d.gnss_cost[(size_t)w * 2];
+    c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
+  }
+  // Jacobi scaling (iteration 0 only), D = sqrt(clamp(diag)), scaled gradient, Cauchy direction
+  double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
+  for (int a = t; a < ND; a += blockDim.x) {
+    double s = 1.0, dp = 1.0, gt = 0.0, v = 0.0;
+    if (ds.act[a]) {
+      const double haa = H[(size_t)a * ND + a];
+      s = first ? (d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(haa)) : 1.0) : gsp[a];
+      const double d2 = clamp_diag(s * s * haa);
+      dp = sqrt(d2); gt = s * g[a]; v = gt / d2;
+      g2 += gt * gt / d2;
+      gmax = fmax(gmax, fabs(g[a]));
+    }
+    if (first) gsp[a] = s;
+    gDp[a] = dp; ggts[a] = gt; gvp[a] = v;
+  }
+  {
+    const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
+    for (int b = t; b < GFBE_BLK_COUNT; b += blockDim.x)
+      if (ds.blk_free[b]) for (int k = 0; k < blk_gsize(b); k++) { const double v = X[blk_amb(b) + k]; xn2 += v * v; }
+  }
+  {
+    const double pv[3] = {g2, gmax, xn2};
+    block_reduce_multi<3>(pv, 0x2u, smem);
+    g2 = smem[48]; gmax = smem[49]; xn2 = smem[50];
+  }
+  __syncthreads();
+  const int n = s_nact, na = n + 1, nt = (na + TB - 1) / TB, npad = nt * TB;
+  const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
+  const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
+  double mu = c.mu;
+  bool solved = false, e_valid = true;
+  while (mu < GF_MAX_MU) {
+    if (!e_valid) {
+      if (d.sharded) {
+        if (!retry_pass) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }
+        break;
+      }
+      rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
+    }
+    for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = gvp[a]; }
+    __syncthreads();
+    // ---- [ S rhs ; rhs' big ], S = s H s + mu D^2 - s E s, rhs = gt - s eg: lower triangle, diagonal tiles in full
+    double vsv = 0.0;
+    for (int e = t; e < npad * npad; e += blockDim.x) {
+      const int ia = e / npad, ib = e - ia * npad;
+      if (ib > ia && (ib >> 4) != (ia >> 4)) continue;
+      double v;
+      if (ia < n && ib < n) {
+        const int a = perm[ia], b = perm[ib], hi = max(a, b), lo = min(a, b);
+        v = H[(size_t)hi * ND + lo];
+        if (hi < NV) v -= E[hi * NV + lo];
+        v *= ys[a] * ys[b];
+        if (a == b) { const double dp = gDp[a]; v += mu * dp * dp; }
+        if (ib <= ia) vsv = __builtin_fma(v * ys[ND + a], ys[ND + b] * (ia != ib ? 2.0 : 1.0), vsv);
+      } else if ((ia == n && ib < n) || (ib == n && ia < n)) {
+        const int b = perm[min(ia, ib)];
+        v = ggts[b] - (b < NV ? gsp[b] * eg[b] : 0.0);
+      } else v = ia == ib ? (ia == n ? 1e200 : 1.0) : 0.0;
+      S[(size_t)ia * BIG_LD + ib] = v;
+    }
+    vsv = block_sum(vsv, red);
+    if (t == 0) { flag = 0; s_vSv = vsv; }
+    __syncthreads();
+    // ---- left-looking blocked Cholesky
+    for (int j = 0; j < nt; j++) {
+      const int R = npad - TB * j, r0 = TB * j;
+      for (int e = t; e < R * TB; e += blockDim.x) { const int r = e >> 4, cc = e & 15; Pn[r * BIG_PLD + cc] = S[(size_t)(r0 + r) * BIG_LD + r0 + cc]; }
+      for (int k = 0; k < j; k++) {
+        __syncthreads();
+        for (int e = t; e < R * TB; e += blockDim.x) { const int r = e >> 4, cc = e & 15; Q[r * BIG_PLD + cc] = S[(size_t)(r0 + r) * BIG_LD + TB * k + cc]; }
+        __syncthreads();
+        for (int e = t; e < R * TB; e += blockDim.x) {
+          const int r = e >> 4, cc = e & 15;
+          double acc = Pn[r * BIG_PLD + cc];
+#pragma unroll
+          for (int m = 0; m < TB; m++) acc = __builtin_fma(-Q[r * BIG_PLD + m], Q[cc * BIG_PLD + m], acc);
+          Pn[r * BIG_PLD + cc] = acc;
+        }
+      }
+      __syncthreads();
+      if (t < TB * TB) { const int r = t >> 4, cc = t & 15; Dg[tsw(r, cc)] = Pn[r * BIG_PLD + cc]; }
+      __syncthreads();
+      if (wave == 0 && !chol_inv_tile16((lds_double *)Dg, lane, j == nt - 1 ? n % TB : -1, (lds_double *)zlast) && lane == 0) flag = 1;
+      __syncthreads();
+      if (flag) break;
+      for (int e = t; e < (R - TB) * TB; e += blockDim.x) {      // rows below the diagonal tile: L = P W^T
+        const int r = TB + (e >> 4), cc = e & 15;
+        double s = 0.0;
+        for (int m = 0; m <= cc; m++) s = __builtin_fma(Pn[r * BIG_PLD + m], Dg[tsw(cc, m)], s);
+        Q[r * BIG_PLD + cc] = s;
+      }
+      __syncthreads();
+      for (int e = t; e < R * TB; e += blockDim.x) {
+        const int r = e >> 4, cc = e & 15;
+        S[(size_t)(r0 + r) * BIG_LD + r0 + cc] = r < TB ? Dg[tsw(r, cc)] : Q[r * BIG_PLD + cc];
+      }
+      __syncthreads();
+    }
+    bool ok = (flag == 0);
+    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;   // fault injection: first attempt of that iteration
+    if (ok) {
+      // z = L^-1 rhs is row n of the factor (its last partial panel was saved before the tile became its own inverse); y = L^-T z
+      double zz = 0.0;
+      for (int i = t; i < npad; i += blockDim.x) {
+        const double z = i < n ? (i / TB == n / TB ? zlast[i % TB] : S[(size_t)n * BIG_LD + i]) : 0.0;
+        ys[i] = z;
+        zz += z * z;
+      }
+      zz = block_sum(zz, red);
+      if (t == 0) s_zz = zz;
+      __syncthreads();
+      for (int P = (n - 1) / TB; P >= 0; P--) {
+        const int p0 = TB * P;
+        if (wave == 0) {      // y_P = W_P^T t_P: lane j < 16 sums its column
+          double yj = 0.0;
+          if (lane < TB) for (int i = lane; i < TB; i++) yj = __builtin_fma(S[(size_t)(p0 + i) * BIG_LD + p0 + lane], ys[p0 + i], yj);
+          __builtin_amdgcn_wave_barrier();
+          if (lane < TB) ys[p0 + lane] = p0 + lane < n ? yj : 0.0;
+        }
+        __syncthreads();
+        for (int r = t; r < p0; r += blockDim.x) {                 // z_r -= sum_c L(p0 + c, r) y_(p0 + c) for the rows above
+          double s = ys[r];
+#pragma unroll
+          for (int cc = 0; cc < TB; cc++) s = __builtin_fma(-S[(size_t)(p0 + cc) * BIG_LD + r], ys[p0 + cc], s);
+          ys[r] = s;
+        }
+        __syncthreads();
+      }
+      int bad = 0;
+      for (int i = t; i < n; i += blockDim.x) { const double y = ys[i]; gyp[perm[i]] = y; if (!isfinite(y)) bad = 1; }
+      for (int a = t; a < ND; a += blockDim.x) if (!ds.act[a]) gyp[a] = 0.0;
+      if (bad) flag = 1;
+      __syncthreads();
+      ok = (flag == 0);
+    }
+    __syncthreads();
+    if (ok) { solved = true; break; }
+    mu *= GF_MU_INC;
+    e_valid = false;
+  }
+  if (!solved) {
+    if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
+    return;
+  }
+  // dense shares of the dogleg scalars (the identities of k_solve: one pass over E instead of a second pass over H)
+  double n2 = 0.0, gyv = 0.0, vrhs = 0.0, vDv = 0.0, vDy = 0.0, vEv = 0.0, vEy = 0.0, yEy = 0.0;
+  for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }
+  __syncthreads();
+  for (int a = t; a < ND; a += blockDim.x) {
+    const double d2 = gDp[a] * gDp[a], y = gyp[a], v = gvp[a];
+    n2 += d2 * y * y;
+    gyv += ggts[a] * y;
+    vDv += d2 * v * v;
+    vDy += d2 * v * y;
+    vrhs += v * (ggts[a] - (a < NV ? gsp[a] * eg[a] : 0.0));
+  }
+  for (int e = t; e < NV * NV; e += blockDim.x) {
+    const int a = e / NV, b = e - a * NV;
+    const double ev = E[e];
+    vEv = __builtin_fma(ev * ys[a], ys[b], vEv);
+    vEy = __builtin_fma(ev * ys[a], ys[ND + b], vEy);
+    yEy = __builtin_fma(ev * ys[ND + a], ys[ND + b], yEy);
+  }
+  {
+    const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
+    block_reduce_multi<8>(gv, 0u, smem);
+    n2 = smem[128]; gyv = smem[129]; vrhs = smem[130]; vDv = smem[131]; vDy = smem[132]; vEv = smem[133]; vEy = smem[134]; yEy = smem[135];
+  }
+  if (t == 0) {
+    c.mu = mu;
+    c.G2 = g2; c.N2 = n2; c.gy = gyv;
+    c.vHv = s_vSv - mu * vDv + vEv;
+    c.vHy = vrhs - mu * vDy + vEy;
+    c.yHy = s_zz - mu * n2 + yEy;
+    c.grad_max = gmax;
+    c.x_norm = xn2;
+    c.have_step = 2;
+    c.lin_retry = 0;
+  }
+}
+
+static size_t solve_smem_bytes() { const int nt = (NC + 1 + TB - 1) / TB;   /* (k_solve never sees the GNSS dims: those batches take k_solve_big) */ return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
 static size_t chain_smem_bytes(int ntile) { return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + 2 * RING_ROWS * chain_ring_ld(ntile)); }
 size_t solve_chain_scratch_doubles() { return (size_t)GYT_COLS * GYT_LD; }
 // dense tiles a window with these active dims needs in k_solve_chain (host side of the kernel's own count)
@@ -1299,10 +1543,13 @@ int solve_chain_tiles(const unsigned char *act) {
 hipError_t kernels_init_device() {
   const hipError_t e = hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem_bytes());
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)k_solve_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_MAX_TILES));
+  const hipError_t e2 = hipFuncSetAttribute((const void *)k_solve_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_MAX_TILES));
+  if (e2 != hipSuccess) return e2;
+  return hipFuncSetAttribute((const void *)k_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_smem_bytes());
 }
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass) {
-  if (d.solve_mono) hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d, retry_pass);
+  if (d.solve_big) hipLaunchKernelGGL(k_solve_big, dim3(d.B), dim3(BIG_THREADS), big_smem_bytes(), s, d, retry_pass);
+  else if (d.solve_mono) hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d, retry_pass);
   else hipLaunchKernelGGL(k_solve_chain, dim3(d.B), dim3(S2_THREADS), chain_smem_bytes(d.solve_ntile), s, d, retry_pass);
 }
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_rebuild_E_shard, dim3(d.B), dim3(1024), 0, s, d); }

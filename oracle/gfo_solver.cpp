@@ -949,8 +949,10 @@ int32_t gfo_solve_window(const gfbe_options *opt, const gfbe_window *w, int32_t 
   Solution sol;
   solve(P, sol);
   if (sol.sum.status == GFBE_NUMERICAL_FAILURE) { if (summary) *summary = sol.sum; return GFBE_NUMERICAL_FAILURE; }
-  while (sol.x.gnss.yaw_enu_local > M_PI) sol.x.gnss.yaw_enu_local -= 2.0 * M_PI;      // estimator.cpp:3383-3386
-  while (sol.x.gnss.yaw_enu_local < -M_PI) sol.x.gnss.yaw_enu_local += 2.0 * M_PI;
+  if (std::isfinite(sol.x.gnss.yaw_enu_local)) {                                         // estimator.cpp:3383-3386
+    while (sol.x.gnss.yaw_enu_local > M_PI) sol.x.gnss.yaw_enu_local -= 2.0 * M_PI;
+    while (sol.x.gnss.yaw_enu_local < -M_PI) sol.x.gnss.yaw_enu_local += 2.0 * M_PI;
+  }
   gfbe_state anchored;
   reanchor(w->state, sol.x, w->frame_count, anchored);
   if (margin_flag != GFBE_MARGIN_NONE && prior_out && w->frame_count == GFBE_WINDOW_SIZE) {

@@ -1,0 +1,101 @@
+"""GNSS inside the window solve and the marginalisation on the GPU (gfbe_window.gnss_ready; estimator.cpp:2965-3002, 3239-3291,
+3459-3496, 3561-3590) against the CPU oracle, through the C ABI.
+
+Tolerances. A pseudo-range is ~2.5e7 m in a double (4e-9 m resolution) and is weighted by up to 50, the device's sin / cos /
+atan2 differ from the host's in the last bit: a GNSS residual agrees with the oracle's to ~1e-6 absolute (tests/test_gpu_gnss.py
+states 1e-5), so a cost of ~3e3 made of ~100 such residuals agrees to ~1e-7 relative instead of the 1e-9 of a window without
+GNSS: check_solve's bounds are taken times GNSS_LOOSE = 100 here. The receiver clock biases are metres (1e5 m in size), the anchor is ECEF metres."""
+import numpy as np
+import pytest
+
+from _gfbe_import import gf
+import gnss_window_cases as gw
+from test_gpu_parity import check_solve
+from test_gpu_plane import check_prior
+
+abi, synth = gf.abi, gf.synth
+pytestmark = pytest.mark.gpu
+GNSS_LOOSE = 100.0
+
+
+@pytest.fixture(scope="module")
+def be():
+    return gf.Backend(device=0)
+
+
+def check_gnss_state(want, got, loose=1.0):
+    a, b = want["state"]["gnss_state"], got["state"]["gnss_state"]
+    assert np.abs(b["rcv_dt"] - a["rcv_dt"]).max() < loose * 1e-6          # metres
+    assert np.abs(b["rcv_ddt"] - a["rcv_ddt"]).max() < loose * 1e-7         # metres / second
+    assert np.abs(b["anc_ecef"] - a["anc_ecef"]).max() < loose * 1e-6       # metres, on 6.4e6
+    assert b["yaw_enu_local"] == a["yaw_enu_local"]                         # constant in the solve, wrapped the same way
+
+
+def test_gnss_factor_cost_and_first_linearisation(be, oracle):
+    _, _, snap = gw.gnss_window(seed=83, L=60, n_per_frame=5)
+    want, got = oracle.eval_factors(snap, robustify=True), be.eval_factors(snap, robustify=True)
+    assert abs(got["cost"] - want["cost"]) < 1e-9 * want["cost"]
+    base = dict(snap)
+    base.pop("gnss")
+    assert want["cost"] - oracle.eval_factors(base, robustify=True)["cost"] > 1.0          # (the GNSS factors are in the objective)
+
+
+@pytest.mark.parametrize("seed,anchor,n_per_frame", [(81, False, 8), (85, True, 3)])
+def test_gnss_window_solve_and_both_marginalisations(be, oracle, seed, anchor, n_per_frame):
+    scn, tru, snap = gw.gnss_window(seed=seed, L=150, n_per_frame=n_per_frame, anchor=anchor)
+    want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD, loose=GNSS_LOOSE)
+    check_gnss_state(want, got)
+    assert want["summary"]["iterations"] >= 3 and want["summary"]["final_cost"] < 1e-3 * want["summary"]["initial_cost"]
+    ids = got["prior"]["block_id"].tolist()
+    for bid in [abi.BLK_RCV_DT0 + k for k in range(4)] + [abi.BLK_RCV_DDT0, abi.BLK_YAW_ENU, abi.BLK_ANC_ECEF]:
+        assert bid in ids                                   # rcv_dt[1] -> rcv_dt[0], rcv_ddt[1] -> rcv_ddt[0], yaw and anchor kept
+    check_prior(want["prior"], got["prior"], loose=GNSS_LOOSE)
+    # the next window carries that prior: both marginalisation flavours
+    nxt = gw.next_gnss_window(scn, tru, want, seed=seed)
+    for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
+        want2, got2 = check_solve(be, oracle, nxt, flag, loose=GNSS_LOOSE)
+        check_gnss_state(want2, got2)
+        check_prior(want2["prior"], got2["prior"], loose=GNSS_LOOSE)
+    assert abi.BLK_POSE0 + 9 not in got2["prior"]["block_id"].tolist() and abi.BLK_RCV_DT0 in got2["prior"]["block_id"].tolist()
+
+
+def test_slow_window_and_prior_without_gnss_ready(be, oracle):
+    # lowspeed (estimator.cpp:2973-2981): no GNSS residual blocks in the solve, the frame-0 factors still marginalised
+    _, _, snap = gw.gnss_window(seed=86, L=100, n_per_frame=4)
+    slow = dict(snap)
+    slow["speed_bias"] = np.array(snap["speed_bias"], float).copy()
+    slow["speed_bias"][:, :2] *= 0.2
+    want, got = check_solve(be, oracle, slow, abi.MARGIN_OLD)
+    assert got["state"]["gnss_state"]["rcv_dt"].tolist() == np.asarray(snap["gnss_state"]["rcv_dt"]).tolist()
+    check_prior(want["prior"], got["prior"], loose=GNSS_LOOSE)
+    assert abi.BLK_ANC_ECEF in got["prior"]["block_id"].tolist()
+    # a prior with GNSS blocks in a window that is not gnss_ready: the blocks are free parameters of the prior factor alone
+    scn, tru, snap = gw.gnss_window(seed=89, L=100, n_per_frame=4)
+    res = oracle.solve(snap, abi.MARGIN_OLD)
+    nxt = gw.next_gnss_window(scn, tru, res, seed=89)
+    nxt.pop("gnss")
+    want, got = check_solve(be, oracle, nxt, abi.MARGIN_SECOND_NEW, loose=GNSS_LOOSE)
+    check_gnss_state(want, got)
+
+
+def test_gnss_windows_in_a_batch(be, oracle):
+    """A GNSS window, a plain window and a second GNSS window in one batch: every window as the oracle solves it alone, and the
+    batch bit-identical from run to run (no atomics in the GNSS sums)."""
+    snaps = [gw.gnss_window(seed=91, L=120, n_per_frame=6)[2], synth.Scenario(seed=92, n_landmarks=150, use_wheel=True).window(0),
+             gw.gnss_window(seed=93, L=90, n_per_frame=10, anchor=True)[2]]
+    runs = []
+    for _ in range(2):
+        batch = be.batch_upload(snaps)
+        batch.solve(abi.MARGIN_OLD)
+        runs.append(batch.download())
+        batch.free()
+    for k, snap in enumerate(snaps):
+        want = oracle.solve(snap, abi.MARGIN_OLD)
+        got = runs[0][k]
+        loose = GNSS_LOOSE if "gnss" in snap else 1.0
+        assert got["summary"]["accepted"] == want["summary"]["accepted"]
+        np.testing.assert_allclose(got["summary"]["cost_history"], want["summary"]["cost_history"], rtol=loose * 1e-6)
+        assert np.abs(got["state"]["pose"] - want["state"]["pose"]).max() < loose * 1e-8
+        check_prior(want["prior"], got["prior"], loose=loose)
+        assert got["summary"]["cost_history"] == runs[1][k]["summary"]["cost_history"]
+        assert np.array_equal(got["state"]["pose"], runs[1][k]["state"]["pose"]) and np.array_equal(got["prior"]["J0"], runs[1][k]["prior"]["J0"])
