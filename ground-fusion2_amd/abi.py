@@ -246,6 +246,14 @@ def state_to_dict(st):
     }
 
 
+def flat_state(d):
+    """A state dict with the GNSS blocks lifted to the top level (gnss_rcv_dt, ...): every value an array or a scalar."""
+    out = {k: v for k, v in d.items() if k != "gnss_state"}
+    for k, v in (d.get("gnss_state") or {}).items():
+        out["gnss_" + k] = v
+    return out
+
+
 class PriorHolder:
     """Owns J0/r0 storage for a gfbe_prior (capacity DENSE_DIM) and converts to/from dicts."""
 

@@ -225,7 +225,7 @@ __device__ GFBE_SOLVE_FN double solve_build_tiles(lds_double *smem, const lds_sh
         if (aa[u] < NV && bb[u] < NV) v -= ev[u];
         v *= ys[aa[u]] * ys[bb[u]];
         if (aa[u] == bb[u]) { const double dp = gDp[aa[u]]; v += mu * dp * dp; }
-        vsv = __builtin_fma(v * ys[ND + aa[u]], ys[ND + bb[u]] * (offdiag[u] ? 2.0 : 1.0), vsv);
+        vsv = __builtin_fma(v * ys[NC + aa[u]], ys[NC + bb[u]] * (offdiag[u] ? 2.0 : 1.0), vsv);
       } else if (kind[u] == 2) v = ggts[bb[u]] - (bb[u] < NV ? gsp[bb[u]] * eg[bb[u]] : 0.0);
       else v = kind[u] == 4 ? 1e200 : (kind[u] == 3 ? 1.0 : 0.0);
       smem[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
@@ -304,8 +304,9 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   if (c.done || c.reuse) return;
   if (retry_pass && !c.lin_retry) return;       // (landmark sharding: second factorisation of the windows whose first one failed)
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ short perm[ND + TB];     // (16-bit: the 160 KB of LDS are full — 78 tiles of 2 KB for a fully active window)
-  __shared__ double red[16], ys[2 * ND + TB];
+  __shared__ short perm[NC + TB];     // (16-bit: the 160 KB of LDS are full — 78 tiles of 2 KB for a fully active window)
+  __shared__ double red[16], ys[2 * NC + TB];   // (NC: this kernel only ever sees batches without GNSS dims, d.nu == NC — with ND the
+                                                // static LDS would push the 78 tiles past the CU's 160 KB)
   __shared__ double s_zz, s_vSv, zlast[TB];
   __shared__ int flag, s_nact;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   // active-dim list by a wave-level prefix count (dims 0..191 live in waves 0..2)
   __shared__ int wcount[4];
   {
-    const bool on = (t < ND) && ds.act[t];
+    const bool on = (t < NC) && ds.act[t];
     const unsigned long long m = __ballot(on);
     if (t < 192 && lane == 0) wcount[wave] = __popcll(m);
     __syncthreads();
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
       if (t == 0) s_nact = wcount[0] + wcount[1] + wcount[2];
     }
     __syncthreads();
-    for (int a = s_nact + t; a < ND + TB; a += blockDim.x) perm[a] = -1;
+    for (int a = s_nact + t; a < NC + TB; a += blockDim.x) perm[a] = -1;
   }
   if (first && t == 0) {   // total cost of the first linearisation point (fixed order)
     double cost = 0.0;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   }
   // Jacobi scaling (iteration 0 only), D = sqrt(clamp(diag)), scaled gradient, Cauchy direction
   double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
-  for (int a = t; a < ND; a += blockDim.x) {
+  for (int a = t; a < NC; a += blockDim.x) {
     double s = 1.0, dp = 1.0, gt = 0.0, v = 0.0;
     if (ds.act[a]) {
       const double haa = H[(size_t)a * ND + a];
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     // scaling and right-hand side staged in LDS (ys is free until the back-substitution)
     // scaling and the Cauchy direction v staged in LDS (ys is free until the back-substitution; the right-hand side row
     // gt - s eg is read where it is placed: one tile row)
-    for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a]; ys[ND + a] = gvp[a]; }
+    for (int a = t; a < NC; a += blockDim.x) { ys[a] = gsp[a]; ys[NC + a] = gvp[a]; }
     __syncthreads();
     double vsv = solve_build_tiles((lds_double *)smem, (const lds_short *)perm, (const lds_double *)ys, (const glb_double *)H, (const glb_double *)E,
                                    (const glb_double *)eg, (const glb_double *)gsp, (const glb_double *)gDp, (const glb_double *)ggts, mu, n, ntile_all, t);
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
       // y back to the tangent dims: inactive dims get 0 (written by the threads of the padding entries of perm), every dim once
       int bad = 0;
       for (int i = t; i < n; i += blockDim.x) { const double y = ys[i]; gyp[perm[i]] = y; if (!isfinite(y)) bad = 1; }
-      for (int a = t; a < ND; a += blockDim.x) if (!ds.act[a]) gyp[a] = 0.0;
+      for (int a = t; a < NC; a += blockDim.x) if (!ds.act[a]) gyp[a] = 0.0;
       if (bad) flag = 1;
       __syncthreads();
       ok = (flag == 0);
@@ -489,9 +490,9 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   //   v^T Ht v = v^T S v - mu v^T D^2 v + v^T Et v        (v^T S v: summed while the tiles were built)
   // — one pass over the 73 x 73 block E instead of a second pass over the 182 x 182 block H.
   double n2 = 0.0, gyv = 0.0, vrhs = 0.0, vDv = 0.0, vDy = 0.0, vEv = 0.0, vEy = 0.0, yEy = 0.0;
-  for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }   // s v, s y (original dims)
+  for (int a = t; a < NC; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[NC + a] = gsp[a] * gyp[a]; }   // s v, s y (original dims)
   __syncthreads();
-  for (int a = t; a < ND; a += blockDim.x) {
+  for (int a = t; a < NC; a += blockDim.x) {
     const double d2 = gDp[a] * gDp[a], y = gyp[a], v = gvp[a];
     n2 += d2 * y * y;
     gyv += ggts[a] * y;
@@ -503,8 +504,8 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     const int a = e / NV, b = e - a * NV;
     const double ev = E[e];                       // (rows / columns of inactive dims are zero in E)
     vEv = __builtin_fma(ev * ys[a], ys[b], vEv);
-    vEy = __builtin_fma(ev * ys[a], ys[ND + b], vEy);
-    yEy = __builtin_fma(ev * ys[ND + a], ys[ND + b], yEy);
+    vEy = __builtin_fma(ev * ys[a], ys[NC + b], vEy);
+    yEy = __builtin_fma(ev * ys[NC + a], ys[NC + b], yEy);
   }
   {   // (the tiles are dead after the back-substitution: scratch of the combined reduction)
     const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};

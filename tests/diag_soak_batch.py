@@ -25,8 +25,9 @@ for i in range(N):
 def same(a, b):
     if a["summary"] != b["summary"] or not np.array_equal(a["feature"], b["feature"]):
         return False
-    for k in a["state"]:
-        if not np.array_equal(np.asarray(a["state"][k]), np.asarray(b["state"][k])):
+    fa, fb = abi.flat_state(a["state"]), abi.flat_state(b["state"])
+    for k in fa:
+        if not np.array_equal(np.asarray(fa[k]), np.asarray(fb[k])):
             return False
     if (a["prior"] is None) != (b["prior"] is None):
         return False

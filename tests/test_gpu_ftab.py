@@ -175,8 +175,9 @@ def test_table_fed_batch_equals_host_upload(be):
             assert x["status"] == y["status"]
             assert x["summary"] == y["summary"]
             np.testing.assert_array_equal(x["feature"], y["feature"])
-            for k in x["state"]:
-                np.testing.assert_array_equal(np.asarray(x["state"][k]), np.asarray(y["state"][k]))
+            fx, fy = abi.flat_state(x["state"]), abi.flat_state(y["state"])
+            for k in fx:
+                np.testing.assert_array_equal(np.asarray(fx[k]), np.asarray(fy[k]))
             assert (x["prior"] is None) == (y["prior"] is None) == (flag == abi.MARGIN_SECOND_NEW)   # no previous prior: nothing to carry
             for k in ("J0", "r0", "x0", "block_id", "block_idx") if x["prior"] else ():
                 np.testing.assert_array_equal(x["prior"][k], y["prior"][k])

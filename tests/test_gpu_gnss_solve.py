@@ -4,7 +4,9 @@
 Tolerances. A pseudo-range is ~2.5e7 m in a double (4e-9 m resolution) and is weighted by up to 50, the device's sin / cos /
 atan2 differ from the host's in the last bit: a GNSS residual agrees with the oracle's to ~1e-6 absolute (tests/test_gpu_gnss.py
 states 1e-5), so a cost of ~3e3 made of ~100 such residuals agrees to ~1e-7 relative instead of the 1e-9 of a window without
-GNSS: check_solve's bounds are taken times GNSS_LOOSE = 100 here. The receiver clock biases are metres (1e5 m in size), the anchor is ECEF metres."""
+GNSS: check_solve's bounds are taken times GNSS_LOOSE = 10 here (measured on MI355X, scratch/gnss_diag.py: cost history 1.3e-9
+relative, final cost 5e-11, poses 1e-11 m, clock biases 5e-9 m, anchor 4e-9 m: inside the plain bounds already); the priors'
+normal equations are compared on PRIOR_LOOSE = 100 (A' 1.3e-9 relative measured; b' cancels numbers of the information's size). The receiver clock biases are metres (1e5 m in size), the anchor is ECEF metres."""
 import numpy as np
 import pytest
 
@@ -15,7 +17,7 @@ from test_gpu_plane import check_prior
 
 abi, synth = gf.abi, gf.synth
 pytestmark = pytest.mark.gpu
-GNSS_LOOSE = 100.0
+GNSS_LOOSE, PRIOR_LOOSE = 10.0, 100.0
 
 
 @pytest.fixture(scope="module")
@@ -23,8 +25,11 @@ def be():
     return gf.Backend(device=0)
 
 
-def check_gnss_state(want, got, loose=1.0):
+def check_gnss_state(want, got, loose=1.0, yaw_free=False):
     a, b = want["state"]["gnss_state"], got["state"]["gnss_state"]
+    if yaw_free:      # (a window that is not gnss_ready does not hold the yaw constant)
+        assert abs(b["yaw_enu_local"] - a["yaw_enu_local"]) < loose * 1e-10
+        b = dict(b, yaw_enu_local=a["yaw_enu_local"])
     assert np.abs(b["rcv_dt"] - a["rcv_dt"]).max() < loose * 1e-6          # metres
     assert np.abs(b["rcv_ddt"] - a["rcv_ddt"]).max() < loose * 1e-7         # metres / second
     assert np.abs(b["anc_ecef"] - a["anc_ecef"]).max() < loose * 1e-6       # metres, on 6.4e6
@@ -49,13 +54,13 @@ def test_gnss_window_solve_and_both_marginalisations(be, oracle, seed, anchor, n
     ids = got["prior"]["block_id"].tolist()
     for bid in [abi.BLK_RCV_DT0 + k for k in range(4)] + [abi.BLK_RCV_DDT0, abi.BLK_YAW_ENU, abi.BLK_ANC_ECEF]:
         assert bid in ids                                   # rcv_dt[1] -> rcv_dt[0], rcv_ddt[1] -> rcv_ddt[0], yaw and anchor kept
-    check_prior(want["prior"], got["prior"], loose=GNSS_LOOSE)
+    check_prior(want["prior"], got["prior"], loose=PRIOR_LOOSE)
     # the next window carries that prior: both marginalisation flavours
     nxt = gw.next_gnss_window(scn, tru, want, seed=seed)
     for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
         want2, got2 = check_solve(be, oracle, nxt, flag, loose=GNSS_LOOSE)
         check_gnss_state(want2, got2)
-        check_prior(want2["prior"], got2["prior"], loose=GNSS_LOOSE)
+        check_prior(want2["prior"], got2["prior"], loose=PRIOR_LOOSE)
     assert abi.BLK_POSE0 + 9 not in got2["prior"]["block_id"].tolist() and abi.BLK_RCV_DT0 in got2["prior"]["block_id"].tolist()
 
 
@@ -67,7 +72,7 @@ def test_slow_window_and_prior_without_gnss_ready(be, oracle):
     slow["speed_bias"][:, :2] *= 0.2
     want, got = check_solve(be, oracle, slow, abi.MARGIN_OLD)
     assert got["state"]["gnss_state"]["rcv_dt"].tolist() == np.asarray(snap["gnss_state"]["rcv_dt"]).tolist()
-    check_prior(want["prior"], got["prior"], loose=GNSS_LOOSE)
+    check_prior(want["prior"], got["prior"], loose=PRIOR_LOOSE)
     assert abi.BLK_ANC_ECEF in got["prior"]["block_id"].tolist()
     # a prior with GNSS blocks in a window that is not gnss_ready: the blocks are free parameters of the prior factor alone
     scn, tru, snap = gw.gnss_window(seed=89, L=100, n_per_frame=4)
@@ -75,7 +80,8 @@ def test_slow_window_and_prior_without_gnss_ready(be, oracle):
     nxt = gw.next_gnss_window(scn, tru, res, seed=89)
     nxt.pop("gnss")
     want, got = check_solve(be, oracle, nxt, abi.MARGIN_SECOND_NEW, loose=GNSS_LOOSE)
-    check_gnss_state(want, got)
+    check_gnss_state(want, got, yaw_free=True)
+    assert got["state"]["gnss_state"]["yaw_enu_local"] != nxt["gnss_state"]["yaw_enu_local"]
 
 
 def test_gnss_windows_in_a_batch(be, oracle):
@@ -96,6 +102,6 @@ def test_gnss_windows_in_a_batch(be, oracle):
         assert got["summary"]["accepted"] == want["summary"]["accepted"]
         np.testing.assert_allclose(got["summary"]["cost_history"], want["summary"]["cost_history"], rtol=loose * 1e-6)
         assert np.abs(got["state"]["pose"] - want["state"]["pose"]).max() < loose * 1e-8
-        check_prior(want["prior"], got["prior"], loose=loose)
+        check_prior(want["prior"], got["prior"], loose=PRIOR_LOOSE if "gnss" in snap else 1.0)
         assert got["summary"]["cost_history"] == runs[1][k]["summary"]["cost_history"]
         assert np.array_equal(got["state"]["pose"], runs[1][k]["state"]["pose"]) and np.array_equal(got["prior"]["J0"], runs[1][k]["prior"]["J0"])
