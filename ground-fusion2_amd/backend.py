@@ -114,6 +114,9 @@ class Backend(abi.CApi):
     def __init__(self, device=0, options=None):
         if not os.path.exists(_SO):
             raise BackendError("HIP extension %s is missing: run __graft_entry__.build() (no CPU fallback)" % _SO)
+        # the solver drives up to eight streams: the HIP runtime's hardware-queue count is the CALLER's to set, before HIP
+        # initialises in this process; a value the embedding application already chose is left alone
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         self.lib = abi.bind(C.CDLL(_SO), "gfbe_")
         self.opt = options or abi.default_options()
         self.ctx = C.c_void_p()
@@ -124,6 +127,7 @@ class Backend(abi.CApi):
         rc = self.lib.gfbe_create(C.byref(self.ctx), int(device), C.byref(self.opt))
         if rc != abi.OK:
             raise BackendError("gfbe_create(device=%d) failed with status %d (%s)" % (device, rc, self._err()))
+        self.create_note = self._err()      # (a note, not an error: e.g. fewer than eight hardware queues configured)
         self.head = self.ctx
         self.device = device
         for name in ("batch_upload", "batch_solve", "batch_download", "solve_batch", "profile_enable",

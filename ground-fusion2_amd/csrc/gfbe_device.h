@@ -239,7 +239,7 @@ struct BatchDev {
   double *lio_part;           // [B][LIOW_WGS][LIOW_PART]
   // assembled system
   // GNSS inside the solve (gfbe_gnss_solve.hip): observations, their residuals / Jacobians at the current linearisation, costs
-  int any_gnss, tot_gnss;           // some window has gnss_ready; observations of the whole batch
+  int any_gnss, tot_gnss, gnss_max_obs;   // some window has gnss_ready; observations of the whole batch / of its largest window
   gfbe_gnss_obs *gnss_obs;          // [tot_gnss]
   double *gnss_J, *gnss_r;          // [tot_gnss][36], [tot_gnss][2]
   double *gnss_cost;                // [B][2]  cost of the GNSS factors at the linearisation point / at the candidate
@@ -281,6 +281,7 @@ enum { PRIOR_X0 = GFBE_NFRAMES * 16 + 32 };
 // ---- kernel launchers (gfbe_kernels.hip / gfbe_marg.hip) -------------------------------------------
 hipError_t kernels_init_device();   // per-device kernel attributes (k_solve's dynamic LDS); called by gfbe_create
 hipError_t marg_init_device();      // same for k_marg
+hipError_t gnss_init_device();      // same for k_gnss
 void launch_prep(const BatchDev &d, hipStream_t s);
 void launch_expand(const BatchDev &d, hipStream_t s);                 // host upload: fobs -> lm_obs / lm_rec
 void launch_gather(const BatchDev &d, int margin_flag, hipStream_t s);   // results -> dl_fix / dl_feat / dl_J0

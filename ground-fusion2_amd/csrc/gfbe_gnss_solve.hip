@@ -7,6 +7,8 @@
 // summed by ONE thread over the observations of the frames that can touch it, in observation order: no atomics, the same bits
 // on every run. The clock factors are linear with constant Jacobians and are added in closed form.
 #include "gfbe_devutil.h"
+#include <algorithm>
+
 #include "gfbe_gnss.h"
 
 namespace gfd {
@@ -65,10 +67,14 @@ __device__ __forceinline__ double gm_dtddt_coef(int la, int k, double dt) {
 }
 __device__ __forceinline__ double gm_smooth_coef(int la, double wgt) { return la == 16 ? wgt : (la == 21 ? -wgt : 0.0); }
 
-#define GN_THREADS 256
-enum { GN_NCLK = 5 * GFBE_WINDOW_SIZE };   // 40 DtDdtFactors (constellation-major, the reference's insertion order) + 10 DdtSmoothFactors
+// 512 threads: the sums below are issue-bound integer / LDS work (a lone wave issues one instruction every ~5 cycles), two waves
+// per SIMD halve that; the per-observation evaluation keeps its 256 VGPRs.
+#define GN_THREADS 512
+enum { GN_NCLK = 5 * GFBE_WINDOW_SIZE,     // 40 DtDdtFactors (constellation-major, the reference's insertion order) + 10 DdtSmoothFactors
+       GN_ROW = 38,                        // doubles per staged observation: J (2 x 18) | r (2)
+       GN_LDS_OBS = 384 };                 // observations a window can stage in LDS (114 KB); a larger window sums from the global copy (L2)
 
-__global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
+__global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsigned lds_obs) {
   const int w = blockIdx.x, t = threadIdx.x;
   const WinDesc &ds = d.desc[w];
   if (!ds.gnss_ready) return;
@@ -78,6 +84,16 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
   if (mode == 2 && ds.frame_count < GFBE_WINDOW_SIZE) return;
   const double *X = mode == 2 ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + (mode == 1 ? 1 - c.cur : c.cur)) * NA;
   __shared__ double red[16], clk_r[GN_NCLK];
+  double *stamp = d.timing + (size_t)d.B * 32 + 8 * mode;     // phase stamps of window 0 (diagnostics: gfbe_debug_timing(batch, B))
+#define GSTAMP(i) do { if (w == 0 && t == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  GSTAMP(0);
+  // staged copy of the Jacobians / residuals and of (frame, lower_idx, constellation) per observation: the sums below walk them
+  // once per entry, and a single window has no other wave to hide a global load behind (measured on one window: 400 us per
+  // launch from L2)
+  extern __shared__ __attribute__((aligned(16))) double gn_lds[];
+  const bool staged = ds.n_gnss <= (int)lds_obs;
+  double *sJ = gn_lds;
+  int *sMeta = (int *)(gn_lds + (size_t)lds_obs * GN_ROW);
   const gfbe_gnss_obs *obs = d.gnss_obs + ds.gnss_off;
   double *Jw = d.gnss_J + (size_t)ds.gnss_off * 36, *rw = d.gnss_r + (size_t)ds.gnss_off * 2;
   // MARGIN_OLD takes the observations of frame 0 (first in the frame-sorted list) between poses 0 and 1, and the clock factors of
@@ -94,6 +110,11 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
     if (mode != 1) {
       rw[2 * k] = r[0]; rw[2 * k + 1] = r[1];
       for (int q = 0; q < 36; q++) Jw[(size_t)36 * k + q] = J[q];
+      if (staged) {
+        for (int q = 0; q < 36; q++) sJ[k * GN_ROW + q] = J[q];
+        sJ[k * GN_ROW + 36] = r[0]; sJ[k * GN_ROW + 37] = r[1];
+        sMeta[k] = o.frame | (lw << 8) | (o.sys_idx << 16);
+      }
     }
   }
   if (t < GN_NCLK) {
@@ -108,6 +129,7 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
     clk_r[t] = r;
     cost += 0.5 * r * r;
   }
+  GSTAMP(1);
   cost = block_sum(cost, red);      // (two block barriers: clk_r and this workgroup's Jw / rw are visible to every thread afterwards)
   if (mode == 1) { if (t == 0) d.gnss_cost[(size_t)w * 2 + 1] = cost; return; }
   const double wgt = ds.gnss_ddt_weight;
@@ -118,10 +140,15 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
       const int la = isg ? e - GN_M * GN_M : e / GN_M, lb = isg ? 0 : e % GN_M;
       double s = 0.0;
       for (int k = 0; k < n_obs; k++) {
-        const int sys = obs[k].sys_idx, ca = gm_col(la, sys), cb = isg ? 0 : gm_col(lb, sys);
+        const int sys = staged ? (sMeta[k] >> 16) : obs[k].sys_idx, ca = gm_col(la, sys), cb = isg ? 0 : gm_col(lb, sys);
         if (ca < 0 || cb < 0) continue;
-        const double *J = Jw + (size_t)36 * k;
-        s += isg ? J[ca] * rw[2 * k] + J[18 + ca] * rw[2 * k + 1] : J[ca] * J[cb] + J[18 + ca] * J[18 + cb];
+        if (staged) {
+          const double *J = sJ + k * GN_ROW;
+          s += isg ? J[ca] * J[36] + J[18 + ca] * J[37] : J[ca] * J[cb] + J[18 + ca] * J[18 + cb];
+        } else {
+          const double *J = Jw + (size_t)36 * k;
+          s += isg ? J[ca] * rw[2 * k] + J[18 + ca] * rw[2 * k + 1] : J[ca] * J[cb] + J[18 + ca] * J[18 + cb];
+        }
       }
       for (int k = 0; k < 4; k++) {
         const double a = gm_dtddt_coef(la, k, ds.gnss_frame_dt[0]);
@@ -149,11 +176,19 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
     double s = 0.0;
     if (f0 <= f1)
       for (int k = ds.gnss_frame_begin[f0]; k < ds.gnss_frame_begin[f1 + 1]; k++) {
-        const gfbe_gnss_obs &o = obs[k];
-        const int ja = gn_col(ca, o.frame, o.lower_idx, o.sys_idx), jb = isg ? 0 : gn_col(cb, o.frame, o.lower_idx, o.sys_idx);
-        if (ja < 0 || jb < 0) continue;
-        const double *J = Jw + (size_t)36 * k;
-        s += isg ? J[ja] * rw[2 * k] + J[18 + ja] * rw[2 * k + 1] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
+        if (staged) {
+          const int mt = sMeta[k], fr = mt & 255, lw = (mt >> 8) & 255, sys = mt >> 16;
+          const int ja = gn_col(ca, fr, lw, sys), jb = isg ? 0 : gn_col(cb, fr, lw, sys);
+          if (ja < 0 || jb < 0) continue;
+          const double *J = sJ + k * GN_ROW;
+          s += isg ? J[ja] * J[36] + J[18 + ja] * J[37] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
+        } else {
+          const gfbe_gnss_obs &o = obs[k];
+          const int ja = gn_col(ca, o.frame, o.lower_idx, o.sys_idx), jb = isg ? 0 : gn_col(cb, o.frame, o.lower_idx, o.sys_idx);
+          if (ja < 0 || jb < 0) continue;
+          const double *J = Jw + (size_t)36 * k;
+          s += isg ? J[ja] * rw[2 * k] + J[18 + ja] * rw[2 * k + 1] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
+        }
       }
     if (ca >= 66 && ca < 121 && cb >= 66 && cb < 121) {
       for (int q = 0; q < 4 * GFBE_WINDOW_SIZE; q++) {
@@ -169,11 +204,19 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode) {
     if (isg) g[ta] += s;
     else H[(size_t)max(ta, tb) * ND + min(ta, tb)] += s;      // (H holds its lower triangle; every entry has one owner thread)
   }
+  GSTAMP(2);
+#undef GSTAMP
 }
 
+static size_t gnss_lds_bytes(unsigned n_obs) { return sizeof(double) * (size_t)n_obs * GN_ROW + sizeof(int) * (size_t)n_obs; }
+hipError_t gnss_init_device() {   // per device, from gfbe_create (see kernels_init_device)
+  return hipFuncSetAttribute((const void *)k_gnss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnss_lds_bytes(GN_LDS_OBS));
+}
 void launch_gnss(const BatchDev &d, int mode, hipStream_t s) {
   if (!d.any_gnss) return;
-  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), 0, s, d, mode);
+  // LDS for the batch's largest window (mode 1, the candidate cost, stages nothing)
+  const unsigned n = mode == 1 ? 0u : (unsigned)std::min(d.gnss_max_obs, (int)GN_LDS_OBS);
+  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), gnss_lds_bytes(n), s, d, mode, n);
 }
 
 }  // namespace gfd

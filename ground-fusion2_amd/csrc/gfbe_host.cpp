@@ -229,10 +229,13 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   *out = c;
   if (device < 0) return GFBE_OK;   // host-only context: bookkeeping entry points only
   // A context drives up to eight streams (two parts x (main + dense-factor stream), upload, download, the caller's): with the
-  // HIP runtime's default of four hardware queues they share queues and an upload queues up behind a whole solve. Only
-  // effective when the runtime has not been initialised yet in this process (a caller that initialises HIP first sets it
-  // itself: INTEGRATION.md); never overrides the caller's own setting.
-  setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // HIP runtime's default of four hardware queues they share queues and an upload queues up behind a whole solve. The queue
+  // count is a process-wide setting read when the runtime initialises, so it belongs to the caller (the Python
+  // host layer and bench.py set GPU_MAX_HW_QUEUES=8 before they load HIP): the library only says so when it finds less.
+  {
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    if (!q || atoi(q) < 8) c->err = "note: GPU_MAX_HW_QUEUES is unset or below 8 — uploads and downloads will share hardware queues with the solver streams (set it before HIP initialises)";
+  }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= device) {
     c->err = "no HIP device " + std::to_string(device) + " visible (the HIP back end has no CPU fallback)";
@@ -254,6 +257,7 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   // kernel attributes are per device: every context sets them for its own GPU
   hipError_t ea = kernels_init_device();
   if (ea == hipSuccess) ea = marg_init_device();
+  if (ea == hipSuccess) ea = gnss_init_device();
   if (ea != hipSuccess) { c->err = std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
   return GFBE_OK;
 }
@@ -670,7 +674,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<int> tile_start;
   std::vector<int> feat_off(B + 1, 0);
   std::vector<long long> j0_off(B + 1, 0);
-  int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0, tot_gnss = 0, any_gnss = 0, gnss_dims = 0;
+  int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0, tot_gnss = 0, any_gnss = 0, gnss_dims = 0, gnss_max = 0;
   double algo_bytes = 0.0;
   for (int w = 0; w < B; w++) {
     const gfbe_window &win = *wins[w];
@@ -695,7 +699,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
         }
       }
       ds.gnss_ready = 1; ds.n_gnss = win.n_gnss; ds.gnss_off = tot_gnss;
-      tot_gnss += win.n_gnss; any_gnss = 1;
+      tot_gnss += win.n_gnss; any_gnss = 1; gnss_max = std::max(gnss_max, win.n_gnss);
     }
     b->L[w] = sc.L;
     feat_off[w + 1] = feat_off[w] + sc.L;
@@ -732,7 +736,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
   for (int w = 0; w < B; w++) if (wins[w]->use_plane || wins[w]->use_anchor) d.any_plane = 1;
-  d.any_gnss = any_gnss; d.tot_gnss = tot_gnss;
+  d.any_gnss = any_gnss; d.tot_gnss = tot_gnss; d.gnss_max_obs = gnss_max;
   d.nu = (any_gnss || gnss_dims) ? (int)ND : (int)NC;       // a batch without GNSS blocks never touches the last 59 tangent dims
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
   if (getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics: force the 20-column panel)

@@ -1301,8 +1301,93 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
 // batches without GNSS dims).
 // =============================================================================================
 #define BIG_THREADS 512
-enum { BIG_PLD = 17, BIG_ROWS = BIG_LD };
-static size_t big_smem_bytes() { return sizeof(double) * (2 * (size_t)BIG_ROWS * BIG_PLD + TB * TB); }
+enum { BIG_WAVES = BIG_THREADS / 64 };
+static size_t big_smem_bytes() { return sizeof(double) * (size_t)(BIG_WAVES + 1) * TB * TB; }   // a tile per wave (layout changes, reductions) + the diagonal tile
+
+// The factorisation loop of k_solve_big, out of line (its own register allocation: two accumulator tiles, four k-steps of operands
+// in flight and — at another time — the 64 registers of the tile step).
+//   Left-looking blocked Cholesky on the FP64 matrix cores, operands straight from global memory (L2): for panel j every wave takes
+//   the tiles (I, j), I = j + wave, j + wave + 8 and subtracts sum_k L(I, k) L(j, k)^T — 16x16x4 chains, no barrier and no LDS
+//   inside the k loop; the operands of four k-steps are loaded together (a lone workgroup has nothing else to hide an L2 round
+//   trip behind: one trip per four steps instead of one per step). Wave 0's first tile is the diagonal one, which it factorises
+//   and inverts in LDS (chol_inv_tile16); after one block barrier every wave turns its tiles into L(I, j) = P W^T and stores them.
+//   Two block barriers per panel. Tw: a tile of the calling wave's own, for the accumulator -> A-operand layout change.
+enum { BIG_KCH = 4 };
+__device__ __noinline__ void big_factor(double *S, int nt, int n, int lane, int wave, lds_double *Dgl, lds_double *Tw, lds_double *zlast, lds_int *flag) {
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int j = 0; j < nt; j++) {
+    const int I0 = j + wave, I1 = j + wave + BIG_WAVES;
+    dbl4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    if (I0 < nt) {
+      const double *Sc0 = S + (size_t)(TB * I0 + lk) * BIG_LD + TB * j + lr;    // accumulator layout: row lk + 4 q, column lr
+      const double *Sc1 = S + (size_t)(TB * min(I1, nt - 1) + lk) * BIG_LD + TB * j + lr;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { acc0[q] = Sc0[(size_t)4 * q * BIG_LD]; acc1[q] = Sc1[(size_t)4 * q * BIG_LD]; }
+      const double *Sj = S + (size_t)(TB * j + lr) * BIG_LD + lk;                // B operand: tile row j
+      const double *Sa0 = S + (size_t)(TB * I0 + lr) * BIG_LD + lk, *Sa1 = S + (size_t)(TB * min(I1, nt - 1) + lr) * BIG_LD + lk;
+      const bool two = I1 < nt;
+      for (int k0 = 0; k0 < j; k0 += BIG_KCH) {
+        double va[BIG_KCH][4], vb[BIG_KCH][4], vc[BIG_KCH][4];
+#pragma unroll
+        for (int u = 0; u < BIG_KCH; u++) {
+          const int k = min(k0 + u, j - 1);        // (clamped: the steps past the panel re-load the last one and are not multiplied)
+#pragma unroll
+          for (int q = 0; q < 4; q++) { vb[u][q] = Sj[TB * k + 4 * q]; va[u][q] = -Sa0[TB * k + 4 * q]; vc[u][q] = -Sa1[TB * k + 4 * q]; }
+        }
+#pragma unroll
+        for (int u = 0; u < BIG_KCH; u++) {
+          if (k0 + u < j) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u][kk], vb[u][kk], acc0, 0, 0, 0);
+            if (two) {
+#pragma unroll
+              for (int kk = 0; kk < 4; kk++) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[u][kk], vb[u][kk], acc1, 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    if (wave == 0) {     // I0 == j: the diagonal tile
+#pragma unroll
+      for (int q = 0; q < 4; q++) Dgl[tsw(lk + 4 * q, lr)] = acc0[q];
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+      if (!chol_inv_tile16(Dgl, lane, j == nt - 1 ? n % TB : -1, zlast) && lane == 0) *flag = 1;
+    }
+    __syncthreads();
+    if (*flag) break;
+    // L(I, j) = P(I, j) W^T: the accumulator goes through the wave's LDS tile into the A-operand layout, B = W^T
+    double wb[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) wb[q] = Dgl[tsw(lr, q * 4 + lk)];
+    if (wave == 0) {     // W in place of the diagonal tile (zeros above the diagonal)
+#pragma unroll
+      for (int q = 0; q < 4; q++) S[(size_t)(TB * j + lk + 4 * q) * BIG_LD + TB * j + lr] = Dgl[tsw(lk + 4 * q, lr)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int I = u == 0 ? I0 : I1;
+      if (I < nt && I != j) {
+        const dbl4 pacc = u == 0 ? acc0 : acc1;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; q++) Tw[tsw(lk + 4 * q, lr)] = pacc[q];
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        double pa[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) pa[q] = Tw[tsw(lr, q * 4 + lk)];
+        dbl4 out = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) out = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], wb[kk], out, 0, 0, 0);
+        double *So = S + (size_t)(TB * I + lk) * BIG_LD + TB * j + lr;
+#pragma unroll
+        for (int q = 0; q < 4; q++) So[(size_t)4 * q * BIG_LD] = out[q];
+      }
+    }
+    __syncthreads();
+  }
+}
 
 __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry_pass) {
   const int w = blockIdx.x;
@@ -1311,7 +1396,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
   if (c.done || c.reuse) return;
   if (retry_pass && !c.lin_retry) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double *Pn = smem, *Q = smem + BIG_ROWS * BIG_PLD, *Dg = smem + 2 * BIG_ROWS * BIG_PLD;
+  double *Pn = smem, *Dg = smem + BIG_WAVES * TB * TB;
   __shared__ short perm[ND + TB];
   __shared__ double red[16], ys[2 * ND + TB], zlast[TB];
   __shared__ double s_zz, s_vSv;
@@ -1322,6 +1407,9 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
   double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
   double *S = d.solveS + (size_t)w * BIG_LD * BIG_LD;
   const bool first = (c.iter == 0);
+  double *stamp = d.timing + (size_t)w * 32;       // phase stamps (diagnostics: gfbe_debug_timing)
+#define BSTAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  BSTAMP(0);
   // active-dim list by a wave-level prefix count (dims 0..255 live in waves 0..3)
   {
     const bool on = (t < ND) && ds.act[t];
@@ -1374,6 +1462,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
     g2 = smem[48]; gmax = smem[49]; xn2 = smem[50];
   }
   __syncthreads();
+  BSTAMP(1);
   const int n = s_nact, na = n + 1, nt = (na + TB - 1) / TB, npad = nt * TB;
   const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
   const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
@@ -1391,61 +1480,44 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
     __syncthreads();
     // ---- [ S rhs ; rhs' big ], S = s H s + mu D^2 - s E s, rhs = gt - s eg: lower triangle, diagonal tiles in full
     double vsv = 0.0;
-    for (int e = t; e < npad * npad; e += blockDim.x) {
-      const int ia = e / npad, ib = e - ia * npad;
-      if (ib > ia && (ib >> 4) != (ia >> 4)) continue;
-      double v;
-      if (ia < n && ib < n) {
-        const int a = perm[ia], b = perm[ib], hi = max(a, b), lo = min(a, b);
-        v = H[(size_t)hi * ND + lo];
-        if (hi < NV) v -= E[hi * NV + lo];
-        v *= ys[a] * ys[b];
-        if (a == b) { const double dp = gDp[a]; v += mu * dp * dp; }
-        if (ib <= ia) vsv = __builtin_fma(v * ys[ND + a], ys[ND + b] * (ia != ib ? 2.0 : 1.0), vsv);
-      } else if ((ia == n && ib < n) || (ib == n && ia < n)) {
-        const int b = perm[min(ia, ib)];
-        v = ggts[b] - (b < NV ? gsp[b] * eg[b] : 0.0);
-      } else v = ia == ib ? (ia == n ? 1e200 : 1.0) : 0.0;
-      S[(size_t)ia * BIG_LD + ib] = v;
+    for (int te = wave; te < nt * (nt + 1) / 2; te += BIG_WAVES) {     // a tile per wave and pass, four entries per lane in flight
+      int I, J;
+      tri_decode(te, I, J);
+      const int ib = J * TB + (lane & 15);
+      double hv[4], ev[4];
+      int aa[4], kind[4];
+      const int b = ib < n ? perm[ib] : -1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int ia = I * TB + (lane >> 4) + 4 * q;
+        kind[q] = 0; aa[q] = 0; hv[q] = 0.0; ev[q] = 0.0;
+        if (ia < n && ib < n) {
+          const int a = perm[ia], hi = max(a, b), lo = min(a, b);
+          aa[q] = a; kind[q] = 1;
+          hv[q] = H[(size_t)hi * ND + lo];
+          if (hi < NV) ev[q] = E[hi * NV + lo];
+        } else if ((ia == n && ib < n) || (ib == n && ia < n)) { aa[q] = perm[min(ia, ib)]; kind[q] = 2; }
+        else kind[q] = ia == ib ? (ia == n ? 4 : 3) : 5;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int ia = I * TB + (lane >> 4) + 4 * q;
+        double v;
+        if (kind[q] == 1) {
+          v = (hv[q] - ev[q]) * (ys[aa[q]] * ys[b]);
+          if (aa[q] == b) { const double dp = gDp[b]; v += mu * dp * dp; }
+          if (ib <= ia) vsv = __builtin_fma(v * ys[ND + aa[q]], ys[ND + b] * (ia != ib ? 2.0 : 1.0), vsv);
+        } else if (kind[q] == 2) v = ggts[aa[q]] - (aa[q] < NV ? gsp[aa[q]] * eg[aa[q]] : 0.0);
+        else v = kind[q] == 4 ? 1e200 : (kind[q] == 3 ? 1.0 : 0.0);
+        S[(size_t)ia * BIG_LD + ib] = v;
+      }
     }
     vsv = block_sum(vsv, red);
     if (t == 0) { flag = 0; s_vSv = vsv; }
     __syncthreads();
-    // ---- left-looking blocked Cholesky
-    for (int j = 0; j < nt; j++) {
-      const int R = npad - TB * j, r0 = TB * j;
-      for (int e = t; e < R * TB; e += blockDim.x) { const int r = e >> 4, cc = e & 15; Pn[r * BIG_PLD + cc] = S[(size_t)(r0 + r) * BIG_LD + r0 + cc]; }
-      for (int k = 0; k < j; k++) {
-        __syncthreads();
-        for (int e = t; e < R * TB; e += blockDim.x) { const int r = e >> 4, cc = e & 15; Q[r * BIG_PLD + cc] = S[(size_t)(r0 + r) * BIG_LD + TB * k + cc]; }
-        __syncthreads();
-        for (int e = t; e < R * TB; e += blockDim.x) {
-          const int r = e >> 4, cc = e & 15;
-          double acc = Pn[r * BIG_PLD + cc];
-#pragma unroll
-          for (int m = 0; m < TB; m++) acc = __builtin_fma(-Q[r * BIG_PLD + m], Q[cc * BIG_PLD + m], acc);
-          Pn[r * BIG_PLD + cc] = acc;
-        }
-      }
-      __syncthreads();
-      if (t < TB * TB) { const int r = t >> 4, cc = t & 15; Dg[tsw(r, cc)] = Pn[r * BIG_PLD + cc]; }
-      __syncthreads();
-      if (wave == 0 && !chol_inv_tile16((lds_double *)Dg, lane, j == nt - 1 ? n % TB : -1, (lds_double *)zlast) && lane == 0) flag = 1;
-      __syncthreads();
-      if (flag) break;
-      for (int e = t; e < (R - TB) * TB; e += blockDim.x) {      // rows below the diagonal tile: L = P W^T
-        const int r = TB + (e >> 4), cc = e & 15;
-        double s = 0.0;
-        for (int m = 0; m <= cc; m++) s = __builtin_fma(Pn[r * BIG_PLD + m], Dg[tsw(cc, m)], s);
-        Q[r * BIG_PLD + cc] = s;
-      }
-      __syncthreads();
-      for (int e = t; e < R * TB; e += blockDim.x) {
-        const int r = e >> 4, cc = e & 15;
-        S[(size_t)(r0 + r) * BIG_LD + r0 + cc] = r < TB ? Dg[tsw(r, cc)] : Q[r * BIG_PLD + cc];
-      }
-      __syncthreads();
-    }
+    BSTAMP(2);
+    big_factor(S, nt, n, lane, wave, (lds_double *)Dg, (lds_double *)(Pn + wave * TB * TB), (lds_double *)zlast, (lds_int *)&flag);
+    BSTAMP(3);
     bool ok = (flag == 0);
     if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;   // fault injection: first attempt of that iteration
     if (ok) {
@@ -1492,6 +1564,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
     if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
     return;
   }
+  BSTAMP(4);
   // dense shares of the dogleg scalars (the identities of k_solve: one pass over E instead of a second pass over H)
   double n2 = 0.0, gyv = 0.0, vrhs = 0.0, vDv = 0.0, vDy = 0.0, vEv = 0.0, vEy = 0.0, yEy = 0.0;
   for (int a = t; a < ND; a += blockDim.x) { ys[a] = gsp[a] * gvp[a]; ys[ND + a] = gsp[a] * gyp[a]; }
@@ -1527,6 +1600,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
     c.have_step = 2;
     c.lin_retry = 0;
   }
+  BSTAMP(5);
+#undef BSTAMP
 }
 
 static size_t solve_smem_bytes() { const int nt = (NC + 1 + TB - 1) / TB;   /* (k_solve never sees the GNSS dims: those batches take k_solve_big) */ return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }

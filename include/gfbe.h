@@ -300,7 +300,11 @@ typedef struct gfbe_ctx gfbe_ctx;
 void gfbe_default_options(gfbe_options *opt);
 
 /* device < 0: host-only context (bookkeeping functions only; every compute entry point returns
- * GFBE_NO_DEVICE). device >= 0: HIP device ordinal; fails with GFBE_NO_DEVICE if absent. */
+ * GFBE_NO_DEVICE). device >= 0: HIP device ordinal; fails with GFBE_NO_DEVICE if absent.
+ * The solver drives up to eight HIP streams (two solver lanes with a side stream each, upload, download, the caller's): set
+ * GPU_MAX_HW_QUEUES=8 in the process environment before HIP initialises — the runtime's default of four makes uploads queue
+ * behind solves. The library does not touch the environment; gfbe_create returns GFBE_OK and leaves a note in gfbe_last_error
+ * when the variable is unset or below 8. */
 gfbe_status gfbe_create(gfbe_ctx **ctx, int device, const gfbe_options *opt);
 /* Frees the context and the device memory it caches. Batches (gfbe_batch_free) and feature tables (gfbe_ftab_destroy) made with
  * the context must be released BEFORE it. */
@@ -469,10 +473,10 @@ gfbe_status gfbe_lio_linearize(gfbe_ctx *ctx, int32_t ct, int32_t n, const doubl
 /* ------------------------------------------------------------------------------------------
  * f2  Optional in-window factors. PlaneFactor and PoseAnchorFactor run INSIDE
  *     gfbe_solve_window / gfbe_batch_solve when gfbe_window.use_plane / use_anchor are set (see gfbe_window); the
- *     functions below evaluate them stand-alone. The GNSS factors are evaluation only: with gnss_enable the reference's
- *     problem grows by rcv_dt[11][4], rcv_ddt[11], yaw_enu_local and anc_ecef (59 more dimensions), which the
- *     LDS-resident dense solve of this library (187 dimensions, one workgroup's 160 KB) does not hold; every shipped
- *     yaml sets gnss_enable: 0.
+ *     functions below evaluate them stand-alone. The GNSS factors run inside the solve and MARGIN_OLD as well when
+ *     gfbe_window.gnss_ready is set: the problem then grows by rcv_dt[11][4], rcv_ddt[11], yaw_enu_local and anc_ecef
+ *     (59 more tangent dimensions, GFBE_DENSE_DIM = 246); such batches factorise their reduced system from global memory
+ *     (k_solve_big) instead of the LDS-resident kernels. Every shipped yaml sets gnss_enable: 0.
  *       PlaneFactor::Evaluate        factor/plane_factor.h:25-122  — n factors sharing ex_wheel [p | q(x,y,z,w)],
  *           plane_R [q(x,y,z,w)] and plane_Z (estimator.cpp:3214-3220: one factor per window pose);
  *           noise_inv = {PITCH_N_INV, ROLL_N_INV, ZPW_N_INV} (parameters.cpp:340-345).
@@ -494,7 +498,8 @@ void gfbe_orientation_subset_plus(const double *q /*[4] x y z w*/, const double 
                                   const uint8_t *constant /*[3]*/, double *out /*[4]*/);
 
 /* ------------------------------------------------------------------------------------------
- * f2  GNSS factors of the window (estimator.cpp:3239-3291), evaluated on the device:
+ * f2  GNSS factors of the window (estimator.cpp:3239-3291), evaluated stand-alone on the device (inspection / parity API; inside
+ *     the solve they are driven by gfbe_window.gnss_*):
  *       GnssPsrDoppFactor::Evaluate   factor/gnss_psr_dopp_factor.cpp:50-208   (2 rows: pseudo-range, Doppler)
  *       DtDdtFactor::Evaluate         factor/gnss_dt_ddt_factor.cpp:3-34       (receiver clock bias / drift chain)
  *       DdtSmoothFactor::Evaluate     factor/gnss_ddt_smooth_factor.cpp:3-22
