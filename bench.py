@@ -317,10 +317,10 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
         "k_schur": ("mfma", float(np.mean((6.0 * (n_obs + 1) + 8.0) ** 2)) * L),
         # k_solve: Cholesky of the reduced system + the two triangular solves
         "k_solve": ("mfma", n_act ** 3 / 3.0 + 2.0 * n_act ** 2),
-        # k_visblock: reads the filled entries of the tiles' X^T X partials, writes the 73 x 74 visual block
-        "k_visblock": ("hbm", 8.0 * (tiles * 10 * (336 if full_panel else 157) * 0.5 + 73 * 74)),
-        # k_assemble: reads inertial / wheel / prior / visual / Schur partials, writes H (lower), g, E, eg
-        "k_assemble": ("hbm", 8.0 * (10 * 932 + 10 * 508 + pn * pn + 73 * 74 + 11 * 15 * 256 + 187 * 188 / 2 + 187 + 73 * 73 + 73)),
+        # k_visasm (the profile name stays k_assemble; k_visblock is part of it since round 3): reads the filled entries of the tiles'
+        # X^T X partials into the 73 x 74 visual block (LDS), the inertial / wheel / prior partials and the four start-frame-group
+        # Schur partials; writes H (lower), g, E, eg
+        "k_assemble": ("hbm", 8.0 * (tiles * 10 * (336 if full_panel else 157) * 0.5 + 10 * 932 + 10 * 508 + pn * pn + 4 * 15 * 256 + 187 * 188 / 2 + 187 + 73 * 73 + 73)),
         # k_lm_step: per landmark its H_pl row, Hll, gl, scale, lambda in; y_l, v_l out
         "k_lm_step": ("hbm", 8.0 * (L * (13 + 5) + 6.0 * K1 + 2 * L)),
     }

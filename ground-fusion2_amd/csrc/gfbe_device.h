@@ -10,6 +10,13 @@
 
 #include "../../include/gfbe.h"
 
+#ifndef GFBE_LIN_SMALL_KS
+#define GFBE_LIN_SMALL_KS 4
+#endif
+#ifndef GFBE_ASM_WGS_SMALL
+#define GFBE_ASM_WGS_SMALL 64   // k_assemble, small batches: workgroups per window (16 -> 64: 1.518 -> 1.497 ms per single-window solve)
+#endif
+
 namespace gfd {
 
 // ---- dimensions -----------------------------------------------------------------------------
@@ -36,7 +43,7 @@ enum {
   PLANE_PART = 16 * 16 + 16 + 2,    // J^T J, J^T r, cost, candidate cost of one PlaneFactor (columns pose_i 6, ex_wheel 6, plane_R 3, plane_Z 1)
   ANCHOR_PART = 6 * 6 + 6 + 2,
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
-  LIN_SMALL_KS = 4,           // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
+  LIN_SMALL_KS = GFBE_LIN_SMALL_KS,   // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
   LIN_SMALL_THREADS = 256,    // k_lin_small: threads per workgroup (one wave per visual tile item, four for an inertial / wheel / prior item)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)

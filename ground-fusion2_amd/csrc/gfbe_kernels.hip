@@ -1187,8 +1187,9 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
 // vis_Hs[w][2 i + group]; k_assemble adds the 20 blocks in (start frame, group) order — exactly the additions, in exactly the
 // order, of the sequential loop of the one-workgroup form (bit-identical), twenty workgroups beside each other instead of ten
 // start frames one after the other on the latency path of a single window. sgrp: the thread group of a SPLIT workgroup.
-template <bool SPLIT>
-__device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last, const int sgrp) {
+// KEEP: the block stays in the caller's LDS array V (k_visasm assembles from there) instead of going to vis_H.
+template <bool SPLIT, bool KEEP>
+__device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last, const int sgrp, double *V) {
   constexpr int NT = SPLIT ? VB_GROUP : VB_THREADS;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
@@ -1196,7 +1197,6 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   // (SPLIT: a start frame without landmarks leaves its block as the upload zeroed it — the structure never changes)
   const bool lead = (i_first == 0) && (!SPLIT || sgrp == 0);   // (SPLIT: this workgroup also carries the cost)
   if (SPLIT && !lead && ds.sf_tile_begin[i_first] + sgrp >= ds.sf_tile_begin[i_first + 1]) return;
-  __shared__ double V[NV * V_LD];
   __shared__ int s_tile_begin[NF + 1];
   const int t = threadIdx.x;
   const double *Z = d.zero;
@@ -1290,8 +1290,10 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
     }
   }
   __syncthreads();
-  double *out = SPLIT ? d.vis_Hs + ((size_t)w * VS_BLOCKS + 2 * i_first + sgrp) * NV * V_LD : d.vis_H + (size_t)w * NV * V_LD;
-  for (int q = t; q < NV * V_LD; q += NT) out[q] = V[q];
+  if (!KEEP) {
+    double *out = SPLIT ? d.vis_Hs + ((size_t)w * VS_BLOCKS + 2 * i_first + sgrp) * NV * V_LD : d.vis_H + (size_t)w * NV * V_LD;
+    for (int q = t; q < NV * V_LD; q += NT) out[q] = V[q];
+  }
   // robustified visual cost of this linearisation point (this rank's tiles; lanes stride the tiles, fixed tree order)
   if (lead && t < 64) {
     double cs = 0.0;
@@ -1304,30 +1306,30 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   ASTAMP(7);
 #undef ASTAMP
 }
-__global__ __launch_bounds__(VB_THREADS) void k_visblock(BatchDev d) { visblock_body<false>(d, blockIdx.x, 0, NF - 2, 0); }
-__global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d) { visblock_body<true>(d, blockIdx.y, blockIdx.x >> 1, blockIdx.x >> 1, blockIdx.x & 1); }
+__global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d) {
+  __shared__ double V[NV * V_LD];
+  visblock_body<true, false>(d, blockIdx.y, blockIdx.x >> 1, blockIdx.x >> 1, blockIdx.x & 1, V);
+}
 
+#ifndef ASM_THREADS
 #define ASM_THREADS 256
-#define ASM_WGS 16
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
-  const int w = blockIdx.y;
+#endif
+// The assembly of window w by the threads gt, gt + gn, ... of its workgroup(s). vis_w: the visual block [73][74] (vis_H in global
+// memory, or the LDS array k_visasm built it in — a generic pointer either way); tb: an LDS table of the calling kernel.
+__device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, const double *vis_w, AsmTab &tb, const int gt, const int gn) {
   const WinDesc &ds = d.desc[w];
-  const WinCtl &c = d.ctl[w];
-  if (c.done || c.reuse) return;
-  __shared__ AsmTab tb;
   const int t = threadIdx.x;
   const double *Z = d.zero;
-  for (int a = t; a < ND; a += ASM_THREADS) { tb.prior_map[a] = ds.prior_map[a]; tb.act[a] = ds.act[a]; }
+  for (int a = t; a < ND; a += blockDim.x) { tb.prior_map[a] = ds.prior_map[a]; tb.act[a] = ds.act[a]; }
   if (t < NF) { tb.imu_of_frame[t] = ds.imu_of_frame[t]; tb.wheel_of_frame[t] = ds.wheel_of_frame[t]; }
   if (t == 0) { tb.prior_n = ds.prior_n; tb.n_wheel = ds.n_wheel; tb.n_plane = ds.n_plane; tb.use_anchor = ds.use_anchor; }
   __syncthreads();
-  const int gt = blockIdx.x * ASM_THREADS + t, gn = ASM_WGS * ASM_THREADS;
   const bool dense_here = (d.rank == 0);   // landmark sharding: the inertial / wheel / prior factors are added once (rank 0)
   double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
   const int4 *tab = (const int4 *)d.asm_tab;
   const double *imu_w = d.imu_part + (size_t)w * MAX_IMU * IMU_PART, *wheel_w = d.wheel_part + (size_t)w * MAX_WHEEL * WHEEL_PART;
-  const double *prior_w = d.prior_H + (size_t)w * ND * ND, *vis_w = d.vis_H + (size_t)w * NV * V_LD;
+  const double *prior_w = d.prior_H + (size_t)w * ND * ND;
   const bool vsplit = d.vis_Hs != nullptr;
   const bool lio_on = vsplit && ds.lio_n > 0 && d.rank == 0;
   const int lio_o = 6 * ds.lio_frame;
@@ -1429,6 +1431,29 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
     g[a] = v;
     if (a < NV) eg[a] = tb.act[a] ? gather_E11(d, Z, w, a, NV) : 0.0;
   }
+}
+// small batches: GFBE_ASM_WGS_SMALL workgroups per window (a single window's latency wants them side by side), the visual blocks
+// from k_visblock_small
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
+  const int w = blockIdx.y;
+  const WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  __shared__ AsmTab tb;
+  assemble_body(d, w, d.vis_H + (size_t)w * NV * V_LD, tb, blockIdx.x * ASM_THREADS + threadIdx.x, gridDim.x * ASM_THREADS);
+}
+// throughput batches: ONE workgroup per window builds the visual block in LDS and assembles from there. (Measured, 1024 windows:
+// 16 workgroups of 256 threads per window took 313 us per launch with the SIMDs half empty — the kernel was bound by the
+// dispatch and the table staging of its 16384 short workgroups; 2 workgroups 200 us, one 192 us; fused with k_visblock the
+// 43 KB block per window neither goes to HBM nor comes back.)
+__global__ __launch_bounds__(VB_THREADS) void k_visasm(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinCtl &c = d.ctl[w];
+  if (c.done || c.reuse) return;
+  __shared__ double V[NV * V_LD];
+  __shared__ AsmTab tb;
+  visblock_body<false, true>(d, w, 0, NF - 2, 0, V);
+  __syncthreads();
+  assemble_body(d, w, V, tb, threadIdx.x, VB_THREADS);
 }
 
 // =============================================================================================
@@ -1927,12 +1952,12 @@ void launch_lio_window(const BatchDev &d, int mode, hipStream_t s) {
   if (mode == 0) hipLaunchKernelGGL(k_lio_window<0>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
   else hipLaunchKernelGGL(k_lio_window<1>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
 }
-void launch_visblock(const BatchDev &d, hipStream_t s) {
+void launch_visblock(const BatchDev &d, hipStream_t s) {       // (throughput batches: part of k_visasm, launch_assemble)
   if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(VS_BLOCKS, d.B), dim3(VB_GROUP), 0, s, d);
-  else hipLaunchKernelGGL(k_visblock, dim3(d.B), dim3(VB_THREADS), 0, s, d);
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_assemble, dim3(ASM_WGS, d.B), dim3(ASM_THREADS), 0, s, d);
+  if (d.vis_Hs) hipLaunchKernelGGL(k_assemble, dim3(GFBE_ASM_WGS_SMALL, d.B), dim3(ASM_THREADS), 0, s, d);
+  else hipLaunchKernelGGL(k_visasm, dim3(d.B), dim3(VB_THREADS), 0, s, d);
 }
 void launch_lm_step(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles == 0) return;
