@@ -55,11 +55,11 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-batch", type=int, default=1024, help="windows per batch of the end-to-end loops")
     ap.add_argument("--e2e-steps", type=int, default=8)
     ap.add_argument("--e2e-depth", type=int, default=3, help="batches in flight in the end-to-end loops")
-    ap.add_argument("--e2e-split", type=int, default=2,
-                    help="gfbe_options.split_batch of the end-to-end loops: with several batches in flight two parts per batch measured best "
-                         "(1024 windows per batch, three in flight: 45.4k solves/s host-fed; four parts per batch: 32-36k)")
+    ap.add_argument("--e2e-split", type=int, default=0,
+                    help="gfbe_options.split_batch of the end-to-end loops: the batches in flight already overlap each other, every batch as ONE "
+                         "part measured best (1024 windows per batch, three in flight: 48.8k solves/s host-fed; two parts 42.6k, four 33.0k)")
     ap.add_argument("--host-threads", type=int, default=0, help="gfbe_options.host_threads (0: library default)")
-    ap.add_argument("--split", type=int, default=None, help="gfbe_options.split_batch: parts a batch of >= 128 windows is solved in, side by side (library default: 2)")
+    ap.add_argument("--split", type=int, default=None, help="gfbe_options.split_batch: parts a batch of >= 128 windows is solved in, side by side (library default 1: four parts from 2048 windows on, one below)")
     ap.add_argument("--graph", action="store_true", help="gfbe_options.use_graph: replay the launch sequence as a hipGraph")
     ap.add_argument("--shard-landmarks", action="store_true",
                     help="N > 1 only: every rank holds the SAME windows and evaluates its share of the landmark tiles; the partial "
@@ -405,7 +405,7 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
 
     depth = args.e2e_depth
     out["batches_in_flight"] = depth
-    out["parts_per_batch"] = args.e2e_split
+    out["parts_per_batch"] = max(args.e2e_split, 1)
 
     def pipeline(upload):
         """`depth` batches in flight: while batch k solves, batch k+1 waits on the GPU with its inputs landed and batch k+2 is

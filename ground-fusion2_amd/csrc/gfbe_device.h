@@ -216,7 +216,7 @@ struct BatchDev {
   // partial results
   double *pair_part;          // [B][NPAIR][VP_STRIDE]   X^T X per pose pair (sum of vis_part over the tiles of the start frame)
   double *vis_part;           // [B][max_tiles][MAXOBS][VP_STRIDE]  X^T X of the 64 factors of one tile at one step, X = [J | r]
-  double *schur_part;         // [B][2 NF][SCHUR_STRIDE]  sum over the landmarks of one group of start frames (schur_groups slots in use)
+  double *schur_part;         // [B][schur_groups][SCHUR_STRIDE]  sum over the landmarks of one group of start frames
   int schur_groups;           // SCHUR_GROUPS for throughput batches; small batches: 2 NF (two workgroups per start frame), NF when sharded
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *plane_part, *anchor_part;  // [B][MAX_PLANE][PLANE_PART], [B][ANCHOR_PART]   (only read for windows with n_plane / use_anchor)

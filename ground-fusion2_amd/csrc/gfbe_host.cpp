@@ -781,7 +781,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
     AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
     AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36);
-    AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * 2 * NF * SCHUR_STRIDE);
+    AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * d.schur_groups * SCHUR_STRIDE);
     AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
     AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
     AL(prior_g, (size_t)B * (ND + 2));
@@ -792,13 +792,13 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     if (d.sharded) { AL(Er, (size_t)B * (NV * NV + NV)); } else d.Er = nullptr;
     AL(sp, (size_t)B * ND); AL(Dp, (size_t)B * ND); AL(gts, (size_t)B * ND); AL(vp, (size_t)B * ND);
     AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
-    AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);
     AL(timing, (size_t)(B + 1) * 32);   // (+ one block for the phase stamps of a diagnostics build)
     AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
     AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(prior_J0, (size_t)B * ND * ND);     // (the n x n prior block arrives by copy; nothing reads past it)
+    AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);   // (k_marg / k_marg_ldlt write what they and k_gather read)
     AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)
     AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);                   // (written by the kernels that produce a state)
     AL(prior_H, (size_t)B * ND * ND);      // (k_prep writes the n x n block k_assemble reads)
@@ -1050,12 +1050,14 @@ static gfbe_status make_lane(gfbe_ctx *c, gfbe_batch *a) {
 static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   *out = nullptr;
-  // parts of a throughput batch, solved side by side (gfbe_options.split_batch): 1 = the measured default — parts of >= 256
-  // windows, at most four (1024 windows: 4 x 256 measured 59.3k solves/s against 54.2k as two halves and 55.4k as three parts;
-  // six or eight parts 44k / 36k; 4096 windows: 64.6k as 4 x 1024) — an explicit count >= 2 is taken as it is
+  // parts of a throughput batch, solved side by side (gfbe_options.split_batch): 1 = the measured default — four parts for
+  // batches of >= 2048 windows, none below (with k_visasm and two k_solve_chain workgroups per CU a single part fills the GPU:
+  // 1024 windows 62.7k solves/s whole against 61.2k as 4 x 256 and 56.7k as two halves; 512 windows 59.2k against 50.7k / 52.0k;
+  // 2048: 65.3k as four parts against 64.3k whole; 4096: 67.2k against 65.0k, 64.1k as two and 62.5k as eight parts) — an
+  // explicit count >= 2 is taken as it is
   int parts = 1;
   if (B >= BATCH_SPLIT_MIN_B && !c->allreduce && c->opt.split_batch) {
-    parts = c->opt.split_batch == 1 ? std::min(std::max(B / 256, 2), 4) : c->opt.split_batch;
+    parts = c->opt.split_batch == 1 ? (B >= 2048 ? 4 : 1) : c->opt.split_batch;
     parts = std::min(parts, std::max(B / DENSE_SPLIT_MIN_B, 1));
   }
   gfbe_batch **link = out;
@@ -1214,7 +1216,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       // the partials of the landmarks that start in frame 0 are summed over the ranks before k_marg reads them
       launch_marginalize_partials(d, ln.s);
       run_allreduce(c, d.pair_part, (int64_t)d.B * NPAIR * VP_STRIDE, ln.s);
-      run_allreduce(c, d.schur_part, (int64_t)d.B * 2 * NF * SCHUR_STRIDE, ln.s);
+      run_allreduce(c, d.schur_part, (int64_t)d.B * d.schur_groups * SCHUR_STRIDE, ln.s);
       launch_marginalize_finish(d, margin_flag, ln.s);
     } else {
       launch_marginalize(d, margin_flag, ln.s);

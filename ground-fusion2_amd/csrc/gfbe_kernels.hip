@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   if (tfirst >= te) {
     // solve: the partial stays zero (zeroed at upload; the structure never changes). Marginalisation: slot 0 may hold the solve's
     // partial of the group {0, 1} — no landmark (of this rank) starts in frame 0, so its Schur term is zero
-    if (marg) for (int q = threadIdx.x; q < SCHUR_STRIDE; q += 256) d.schur_part[((size_t)w * 2 * NF) * SCHUR_STRIDE + q] = 0.0;
+    if (marg) for (int q = threadIdx.x; q < SCHUR_STRIDE; q += 256) d.schur_part[((size_t)w * d.schur_groups) * SCHUR_STRIDE + q] = 0.0;
     return;
   }
   __shared__ double hs[LM_TILE * HS_LD];
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
 #undef SCHUR_SLOT
   }
   if (stamp_wg) { stamp[3] = (double)wall_clock64(); stamp[4] = (double)(te - tb); stamp[6] = (double)clock64(); }
-  double *out = d.schur_part + ((size_t)w * 2 * NF + grp) * SCHUR_STRIDE;
+  double *out = d.schur_part + ((size_t)w * d.schur_groups + grp) * SCHUR_STRIDE;
 #define SCHUR_OUT(Q, ACC)                                                         \
   if (pI[Q] >= 0) {                                                               \
     double *o = out + (size_t)schur_pair(pI[Q], pJ[Q]) * 256;                     \
@@ -1141,7 +1141,7 @@ __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab
 // reaches the dims from its first start frame's pose on), loads unconditional in flight
 __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z, int w, int a, int b) {
   const int off = schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);
-  const double *sp = d.schur_part + (size_t)w * 2 * NF * SCHUR_STRIDE + off;
+  const double *sp = d.schur_part + (size_t)w * d.schur_groups * SCHUR_STRIDE + off;
   const int ng = d.schur_groups;
   if (ng == SCHUR_GROUPS) {
     double v[SCHUR_GROUPS];

@@ -246,9 +246,9 @@ typedef struct gfbe_options {
    * 2.54 ms for one window and 3 % slower at 256 windows. Ignored while profiling / landmark sharding. */
   int32_t use_graph;
   /* Parts a batch of >= 128 windows is split into by gfbe_batch_upload; gfbe_batch_solve runs the parts side by side,
-   * each on its own pair of streams (kernels of different stages share the GPU). 1 (default): parts of >= 256 windows, two
-   * to four of them (measured round 3, 1024 windows: 54.2k / 55.4k / 59.3k solves/s as 2 / 3 / 4 parts, 44k as six);
-   * n >= 2: exactly n parts. Results per window are unchanged (every window is independent). 0: one launch sequence for the
+   * each on its own pair of streams (kernels of different stages share the GPU). 1 (default): four parts for batches of
+   * >= 2048 windows, one below (measured round 3: 1024 windows 62.7k solves/s whole, 61.2k as four parts, 56.7k as two;
+   * 4096 windows 67.2k as four parts, 65.0k whole); n >= 2: exactly n parts. Results per window are unchanged (every window is independent). 0: one launch sequence for the
    * whole batch. */
   int32_t split_batch;
   /* Solver::Options::max_solver_time_in_seconds (estimator.cpp:3369-3376: SOLVER_TIME = 0.04 s, x 4/5 before a MARGIN_OLD).
