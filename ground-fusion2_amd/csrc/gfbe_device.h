@@ -270,6 +270,7 @@ struct BatchDev {
   double *mJ0, *mr0;          // [B][ND*ND], [B][ND]
   double *mV;                 // [B][ND*ND] eigenvectors scratch
   int *mmeta;                 // [B][4 + 3*GFBE_MAX_PRIOR_BLOCKS]: valid, n, n_blocks, pad, ids, sizes, idx
+  int marg_nmax;              // host-known upper bound of the new priors' size over the batch
   double *mx0;                // [B][PRIOR_X0]
   double *timing;             // [B][32] phase time stamps of k_solve (wall_clock64, 10 ns ticks; diagnostics)
   // ---- result hand-over (k_gather): everything gfbe_batch_download returns, packed for ONE device-to-host copy

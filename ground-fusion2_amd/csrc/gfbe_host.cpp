@@ -674,7 +674,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<int> tile_start;
   std::vector<int> feat_off(B + 1, 0);
   std::vector<long long> j0_off(B + 1, 0);
-  int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0, tot_gnss = 0, any_gnss = 0, gnss_dims = 0, gnss_max = 0;
+  int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0, tot_gnss = 0, any_gnss = 0, gnss_dims = 0, gnss_max = 0, marg_nmax = 0;
   double algo_bytes = 0.0;
   for (int w = 0; w < B; w++) {
     const gfbe_window &win = *wins[w];
@@ -727,6 +727,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     }
     const int nb = std::max(prior_out_bound(win, tabs ? nullptr : sc.pair_begin, true), prior_out_bound(win, nullptr, false));
     j0_off[w + 1] = j0_off[w] + (long long)nb * nb;
+    marg_nmax = std::max(marg_nmax, nb);
     algo_bytes += 108.0 * sc.K;   // 12 f64 + 3 i32 per visual residual block, J never re-read by the host
   }
   d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio;
@@ -736,7 +737,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
   for (int w = 0; w < B; w++) if (wins[w]->use_plane || wins[w]->use_anchor) d.any_plane = 1;
-  d.any_gnss = any_gnss; d.tot_gnss = tot_gnss; d.gnss_max_obs = gnss_max;
+  d.any_gnss = any_gnss; d.tot_gnss = tot_gnss; d.gnss_max_obs = gnss_max; d.marg_nmax = marg_nmax;
   d.nu = (any_gnss || gnss_dims) ? (int)ND : (int)NC;       // a batch without GNSS blocks never touches the last 59 tangent dims
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
   if (getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics: force the 20-column panel)

@@ -39,8 +39,8 @@ namespace gfd {
 // k_prep: once per upload. sqrt_info of every IMU / wheel factor (imu_factor.h:73, wheel_factor.h:85,
 // hoisted out of Evaluate: SURVEY App. A.5) and H_prior = J0^T J0.
 // =============================================================================================
-// Grid (B, PREP_FACT_WGS + PREP_PRIOR_WGS): the first workgroups factorise the covariances (one WAVE per factor: the 20
-// waves take the <= 10 inertial and <= 10 wheel factors of a window side by side), the others share H_prior.
+// k_prep, grid (B, PREP_FACT_WGS): the workgroups factorise the covariances (one WAVE per factor: the 20 waves take the <= 10
+// inertial and <= 10 wheel factors of a window side by side); k_prep_prior, grid (B, PREP_PRIOR_WGS), shares H_prior.
 //
 // sqrt_info_from_cov (gfbe_factors.h: inverse by partially pivoted LU, then a lower Cholesky of the inverse, written transposed)
 // by the 64 lanes of one wave. Every entry goes through exactly the operations, in exactly the order, of the one-thread form
@@ -122,45 +122,51 @@ __global__ __launch_bounds__(256) void k_prep(BatchDev d) {
   const WinDesc &ds = d.desc[w];
   __shared__ double work[4][3 * 225];
   const int t = threadIdx.x;
-  if (blockIdx.y < PREP_FACT_WGS) {
-    const int lane = t & 63, wave = t >> 6;
-    double *lu = work[wave], *inv = lu + 225, *U = inv + 225;
-    for (int f = blockIdx.y * 4 + wave; f < ds.n_imu + ds.n_wheel; f += 4 * PREP_FACT_WGS) {      // wave-uniform
-      const bool imu = f < ds.n_imu;
-      const int k = imu ? f : f - ds.n_imu, n = imu ? 15 : 6;
-      const double *cov = imu ? d.imu[ds.imu_off + k].covariance : d.wheel[ds.wheel_off + k].covariance;
-      double *out = imu ? d.imu_sqrt + (size_t)(ds.imu_off + k) * 225 : d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
-      const int rc = imu ? sqrt_info_from_cov_wave<15>(cov, lu, inv, U, lane) : sqrt_info_from_cov_wave<6>(cov, lu, inv, U, lane);
-      for (int e = lane; e < n * n; e += 64) out[e] = rc ? nan("") : U[e];
-      PREP_WSYNC();
-    }
-    return;
+  const int lane = t & 63, wave = t >> 6;
+  double *lu = work[wave], *inv = lu + 225, *U = inv + 225;
+  for (int f = blockIdx.y * 4 + wave; f < ds.n_imu + ds.n_wheel; f += 4 * PREP_FACT_WGS) {      // wave-uniform
+    const bool imu = f < ds.n_imu;
+    const int k = imu ? f : f - ds.n_imu, n = imu ? 15 : 6;
+    const double *cov = imu ? d.imu[ds.imu_off + k].covariance : d.wheel[ds.wheel_off + k].covariance;
+    double *out = imu ? d.imu_sqrt + (size_t)(ds.imu_off + k) * 225 : d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
+    const int rc = imu ? sqrt_info_from_cov_wave<15>(cov, lu, inv, U, lane) : sqrt_info_from_cov_wave<6>(cov, lu, inv, U, lane);
+    for (int e = lane; e < n * n; e += 64) out[e] = rc ? nan("") : U[e];
+    PREP_WSYNC();
   }
-  // H_prior = J0^T J0, lower triangle mirrored. J0 goes through LDS sixteen rows at a time (coalesced loads, every row read once
-  // per workgroup); a thread keeps its <= 9 entries in registers across the row panels and adds the products in row order —
-  // the same sums as the entry-by-entry loop over global memory this replaces (130 us of strided, dependent loads).
+}
+// H_prior = J0^T J0, lower triangle mirrored (PREP_PRIOR_WGS workgroups per window; its own kernel: the factorisations above take
+// 256 VGPRs, this one a fraction — eight workgroups per CU instead of one). J0 goes through LDS sixteen rows at a time (coalesced
+// loads, every row read once per pass); a thread keeps PREP_MAXE entries in registers across the row panels and adds the products
+// in row order — the same sums as an entry-by-entry loop over global memory. A prior larger than 8 x 256 x PREP_MAXE entries of
+// the triangle (n > 127) takes more than one pass over J0.
+enum { PREP_MAXE = 4 };
+__global__ __launch_bounds__(256) void k_prep_prior(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  const int t = threadIdx.x;
   const int n = ds.prior_n;
-  if (n > 0) {
-    const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
-    double *Hp = d.prior_H + (size_t)w * ND * ND;
-    __shared__ double panel[PREP_ROWS * ND];
-    const int ntri = n * (n + 1) / 2, stride = PREP_PRIOR_WGS * 256, first = (blockIdx.y - PREP_FACT_WGS) * 256 + t;
-    constexpr int MAXE = (ND * (ND + 1) / 2 + PREP_PRIOR_WGS * 256 - 1) / (PREP_PRIOR_WGS * 256);
-    double acc[MAXE];
-    int ei[MAXE], ej[MAXE];
+  if (n == 0) return;
+  const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
+  double *Hp = d.prior_H + (size_t)w * ND * ND;
+  __shared__ double panel[PREP_ROWS * ND];
+  const int ntri = n * (n + 1) / 2, stride = PREP_PRIOR_WGS * 256;
+  for (int pass0 = 0; pass0 < ntri; pass0 += PREP_MAXE * stride) {     // (uniform trip count: barriers inside)
+    const int base = pass0 + blockIdx.y * 256 + t;
+    double acc[PREP_MAXE];
+    int ei[PREP_MAXE], ej[PREP_MAXE];
 #pragma unroll
-    for (int q = 0; q < MAXE; q++) {
+    for (int q = 0; q < PREP_MAXE; q++) {
       acc[q] = 0.0; ei[q] = -1; ej[q] = 0;
-      const int e = first + q * stride;
+      const int e = base + q * stride;
       if (e < ntri) tri_decode(e, ei[q], ej[q]);       // ej <= ei
     }
     for (int r0 = 0; r0 < n; r0 += PREP_ROWS) {
-      const int nr = min(PREP_ROWS, n - r0);
+      const int nr = min((int)PREP_ROWS, n - r0);
       __syncthreads();
       for (int e = t; e < nr * n; e += 256) panel[e] = J0[(size_t)r0 * n + e];
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < MAXE; q++) {
+      for (int q = 0; q < PREP_MAXE; q++) {
         if (ei[q] < 0) continue;
         double sacc = acc[q];
         for (int rr = 0; rr < nr; rr++) sacc += panel[rr * n + ei[q]] * panel[rr * n + ej[q]];
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(256) void k_prep(BatchDev d) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < MAXE; q++) {
+    for (int q = 0; q < PREP_MAXE; q++) {
       if (ei[q] < 0) continue;
       Hp[(size_t)ei[q] * n + ej[q]] = acc[q];
       Hp[(size_t)ej[q] * n + ei[q]] = acc[q];
@@ -1906,7 +1912,10 @@ void launch_expand(const BatchDev &d, hipStream_t s) {
 void launch_gather(const BatchDev &d, int margin_flag, hipStream_t s) {
   hipLaunchKernelGGL(k_gather, dim3(GATHER_WGS, d.B), dim3(256), 0, s, d, margin_flag);
 }
-void launch_prep(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(d.B, PREP_FACT_WGS + PREP_PRIOR_WGS), dim3(256), 0, s, d); }
+void launch_prep(const BatchDev &d, hipStream_t s) {
+  hipLaunchKernelGGL(k_prep, dim3(d.B, PREP_FACT_WGS), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_prep_prior, dim3(d.B, PREP_PRIOR_WGS), dim3(256), 0, s, d);
+}
 void launch_reset(const BatchDev &d, hipStream_t s) {
   const int slots = d.max_tiles * LM_TILE;
   hipLaunchKernelGGL(k_reset, dim3((slots + 255) / 256 > 0 ? (slots + 255) / 256 : 1, d.B), dim3(256), 0, s, d);

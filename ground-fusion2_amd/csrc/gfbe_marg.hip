@@ -199,7 +199,9 @@ __device__ void jacobi_eig_wave16(double *G, double *V, int n, double *lam, int 
   if (lane < n) { double sum = 0.0; for (int i = 0; i < n; i++) sum += V[lane * 16 + i] * G[lane * 16 + i]; lam[lane] = sum; }
 }
 
+#ifndef MARG_THREADS
 #define MARG_THREADS 1024
+#endif
 #define MARG_SQRT_PENDING (-1000000)
 #define MARG_LDS_N 94   // A' up to this size is eigen-decomposed entirely inside LDS (2 n^2 doubles)
 
@@ -640,19 +642,21 @@ __device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, cons
     return rank;
 }
 
+// R = 4: priors of up to 88 dims (the 86 of the shipped configuration: 16 matrix registers per thread, two workgroups per CU);
+// R = 8: larger ones (up to 176). Both are launched when a batch may hold both kinds; a workgroup leaves the other kind alone.
+template <int R>
 __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   const int w = blockIdx.x;
   int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
   if (meta[0] != 1 || meta[3] != MARG_SQRT_PENDING) return;
   const int n = meta[1];
+  if ((n <= 4 * 22) != (R == 4)) return;
   const double *A = d.mA + (size_t)w * ND * ND;
   const double *bv = d.mb + (size_t)w * ND;
   double *J0 = d.mJ0 + (size_t)w * ND * ND;
   double *r0 = d.mr0 + (size_t)w * ND;
   double *stamp = d.timing + 24;
-  int rank;
-  if (n <= 4 * 22) rank = ldlt_registers<4>(A, bv, J0, r0, n, d.opt.marg_eps);
-  else rank = ldlt_registers<8>(A, bv, J0, r0, n, d.opt.marg_eps);
+  const int rank = ldlt_registers<R>(A, bv, J0, r0, n, d.opt.marg_eps);
   if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
 }
 
@@ -674,9 +678,16 @@ hipError_t marg_init_device() {   // per device, from gfbe_create (see kernels_i
   return hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N));
 }
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s) {
-  const size_t lds = sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N;
-  hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(MARG_THREADS), lds, s, d, flag);
-  if (d.opt.marg_sqrt == 1) hipLaunchKernelGGL(k_marg_ldlt, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
+  // dynamic LDS: the eigen-decomposition of A' (marg_sqrt = 0) wants G and V resident; with the LDL^T square root only the
+  // 20-dim dense elimination of a GNSS window uses it (four 32 x 32 blocks)
+  const size_t lds = sizeof(double) * (d.opt.marg_sqrt == 1 ? 4 * 32 * 32 : 2 * MARG_LDS_N * MARG_LDS_N);
+  // (throughput batches: 512-thread workgroups, two per CU, overlap each other's barrier stalls — 1.04 -> 0.92 ms for the whole
+  //  marginalisation of 1024 windows; a single window keeps the 1024 threads of its one workgroup)
+  hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(d.B >= DENSE_SPLIT_MIN_B ? MARG_THREADS / 2 : MARG_THREADS), lds, s, d, flag);
+  if (d.opt.marg_sqrt == 1) {
+    hipLaunchKernelGGL(k_marg_ldlt<4>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
+    if (d.marg_nmax > 4 * 22) hipLaunchKernelGGL(k_marg_ldlt<8>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
+  }
 }
 
 }  // namespace gfd
