@@ -1194,9 +1194,11 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
 // order, of the sequential loop of the one-workgroup form (bit-identical), twenty workgroups beside each other instead of ten
 // start frames one after the other on the latency path of a single window. sgrp: the thread group of a SPLIT workgroup.
 // KEEP: the block stays in the caller's LDS array V (k_visasm assembles from there) instead of going to vis_H.
-template <bool SPLIT, bool KEEP>
+// DUAL: ONE thread group of 512 takes the tiles of both groups, one group after the other — the same sums added in the same order
+// by half the threads (k_visasm: two 512-thread workgroups per CU overlap each other's gather latencies).
+template <bool SPLIT, bool KEEP, bool DUAL>
 __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last, const int sgrp, double *V) {
-  constexpr int NT = SPLIT ? VB_GROUP : VB_THREADS;
+  constexpr int NT = (SPLIT || DUAL) ? VB_GROUP : VB_THREADS;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
@@ -1212,7 +1214,7 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   for (int e = t; e < NV * V_LD; e += NT) V[e] = 0.0;
   if (t <= NF) s_tile_begin[t] = ds.sf_tile_begin[t];
   __syncthreads();
-  const int grp = SPLIT ? sgrp : t / VB_GROUP, e = SPLIT ? t : t - grp * VB_GROUP;
+  const int grp = SPLIT ? sgrp : (DUAL ? 0 : t / VB_GROUP), e = (SPLIT || DUAL) ? t : t - grp * VB_GROUP;
   // reduced panel (extrinsic and td constant in every window of the batch): k_vis fills only the pose block, the gradient
   // column and r^T r of a partial — 157 of its 336 entries; the others belong to inactive dims and are not fetched
   const bool need = d.vis_full || (e < 256 ? ((e >> 4) < 12 && (e & 15) < 12) : (e < 320 ? (((e - 256) & 3) == 3 && ((e - 256) >> 2) < 12) : e == 335));
@@ -1235,28 +1237,29 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
     const int t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
     if (t0 == t1) continue;
     const int nk = NF - 1 - i;
-    double s[MAXOBS];
-#pragma unroll
-    for (int k = 0; k < MAXOBS; k++) s[k] = 0.0;
-    if (live) {
-      for (int tt = t0 + grp; tt < t1; tt += 4) {
-        const double *q0 = vp + (size_t)tt * MAXOBS * VP_STRIDE, *q1 = q0 + (size_t)2 * MAXOBS * VP_STRIDE;
-        const bool two = tt + 2 < t1;
-        double v0[MAXOBS], v1[MAXOBS];
-#pragma unroll
-        for (int k = 0; k < MAXOBS; k++) {   // steps a tile never runs stay zero in vis_part
-          v0[k] = *(k < nk ? q0 + k * VP_STRIDE : Z);
-          v1[k] = *((two && k < nk) ? q1 + k * VP_STRIDE : Z);
-        }
-#pragma unroll
-        for (int k = 0; k < MAXOBS; k++) { s[k] += v0[k]; s[k] += v1[k]; }
-      }
-    }
     const int da0 = a_0 + a_i * i, db0 = b_0 + b_i * i;
     const int i0 = da0 * V_LD + db0, i1 = db0 * V_LD + da0;
+    // thread group g sums its tiles (g, g + 2, g + 4, ...: two in flight) and adds them into V; group 1 after group 0
     for (int gsel = 0; gsel < 2; gsel++) {
       if (gsel >= t1 - t0) break;
-      if (grp == gsel) {
+      if (DUAL || grp == gsel) {
+        double s[MAXOBS];
+#pragma unroll
+        for (int k = 0; k < MAXOBS; k++) s[k] = 0.0;
+        if (live) {
+          for (int tt = t0 + gsel; tt < t1; tt += 4) {
+            const double *q0 = vp + (size_t)tt * MAXOBS * VP_STRIDE, *q1 = q0 + (size_t)2 * MAXOBS * VP_STRIDE;
+            const bool two = tt + 2 < t1;
+            double v0[MAXOBS], v1[MAXOBS];
+#pragma unroll
+            for (int k = 0; k < MAXOBS; k++) {   // steps a tile never runs stay zero in vis_part
+              v0[k] = *(k < nk ? q0 + k * VP_STRIDE : Z);
+              v1[k] = *((two && k < nk) ? q1 + k * VP_STRIDE : Z);
+            }
+#pragma unroll
+            for (int k = 0; k < MAXOBS; k++) { s[k] += v0[k]; s[k] += v1[k]; }
+          }
+        }
         if (!uses_j) {
           double tot = 0.0;
 #pragma unroll
@@ -1278,7 +1281,7 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
           }
         }
       }
-      __syncthreads();
+      if (!DUAL || gsel == 1 || t1 - t0 == 1) __syncthreads();    // (DUAL: both groups are this thread's own additions; one barrier per start frame)
     }
   }
   if (!SPLIT && lead && ds.lio_n > 0 && d.rank == 0 && t < 27) {   // LiDAR factors of pose lio_frame (k_lio_window): 6 x 6 block, gradient (SPLIT: k_assemble adds them)
@@ -1314,7 +1317,7 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
 }
 __global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d) {
   __shared__ double V[NV * V_LD];
-  visblock_body<true, false>(d, blockIdx.y, blockIdx.x >> 1, blockIdx.x >> 1, blockIdx.x & 1, V);
+  visblock_body<true, false, false>(d, blockIdx.y, blockIdx.x >> 1, blockIdx.x >> 1, blockIdx.x & 1, V);
 }
 
 #ifndef ASM_THREADS
@@ -1451,15 +1454,15 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
 // 16 workgroups of 256 threads per window took 313 us per launch with the SIMDs half empty — the kernel was bound by the
 // dispatch and the table staging of its 16384 short workgroups; 2 workgroups 200 us, one 192 us; fused with k_visblock the
 // 43 KB block per window neither goes to HBM nor comes back.)
-__global__ __launch_bounds__(VB_THREADS) void k_visasm(BatchDev d) {
+__global__ __launch_bounds__(VB_GROUP, 4) void k_visasm(BatchDev d) {
   const int w = blockIdx.x;
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   __shared__ double V[NV * V_LD];
   __shared__ AsmTab tb;
-  visblock_body<false, true>(d, w, 0, NF - 2, 0, V);
+  visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
   __syncthreads();
-  assemble_body(d, w, V, tb, threadIdx.x, VB_THREADS);
+  assemble_body(d, w, V, tb, threadIdx.x, VB_GROUP);
 }
 
 // =============================================================================================
@@ -1966,7 +1969,7 @@ void launch_visblock(const BatchDev &d, hipStream_t s) {       // (throughput ba
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
   if (d.vis_Hs) hipLaunchKernelGGL(k_assemble, dim3(GFBE_ASM_WGS_SMALL, d.B), dim3(ASM_THREADS), 0, s, d);
-  else hipLaunchKernelGGL(k_visasm, dim3(d.B), dim3(VB_THREADS), 0, s, d);
+  else hipLaunchKernelGGL(k_visasm, dim3(d.B), dim3(VB_GROUP), 0, s, d);
 }
 void launch_lm_step(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles == 0) return;
