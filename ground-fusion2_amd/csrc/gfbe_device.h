@@ -256,6 +256,7 @@ struct BatchDev {
   int nu;                     // tangent dims in use: NC (no window of the batch has GNSS blocks) or ND
   double *H, *g;              // [B][ND*ND], [B][ND]  unscaled J^T J, J^T r of the dense block
   double *E, *eg;             // [B][NV*NV], [B][NV]  sum_l w_l h_l h_l^T, sum_l w_l h_l gl  (unscaled h)
+  double *sys_pack;           // landmark sharding only: [B][sys_pack_doubles] the packed partial system the all-reduce sums (k_sys_pack)
   double *Er;                 // landmark sharding only: [B][NV*NV + NV] E | eg rebuilt for a larger mu by every rank from its own tiles
                               // (zeros for the windows that do not retry), summed by one all-reduce before the retry pass of k_solve
   double *sp, *Dp, *gts, *vp, *yp, *step;   // [B][ND] each
@@ -319,6 +320,8 @@ void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass = 0);
 int solve_chain_tiles(const unsigned char *act);
 size_t solve_chain_scratch_doubles();              // doubles of BatchDev::solveY per window   // dense 16 x 16 tiles k_solve_chain needs for a window with these active dims
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s);
+void launch_sys_pack(const BatchDev &d, int dir, hipStream_t s);   // landmark sharding: pack (0) / unpack (1) the partial system around its all-reduce
+size_t sys_pack_doubles_host(int nu, int world);
 void launch_lm_step(const BatchDev &d, hipStream_t s);
 void launch_step(const BatchDev &d, hipStream_t s);
 void launch_candidate(const BatchDev &d, hipStream_t s);

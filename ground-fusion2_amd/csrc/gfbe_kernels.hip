@@ -1971,6 +1971,31 @@ void launch_assemble(const BatchDev &d, hipStream_t s) {
   if (d.vis_Hs) hipLaunchKernelGGL(k_assemble, dim3(GFBE_ASM_WGS_SMALL, d.B), dim3(ASM_THREADS), 0, s, d);
   else hipLaunchKernelGGL(k_visasm, dim3(d.B), dim3(VB_GROUP), 0, s, d);
 }
+// Landmark sharding: the partial reduced system of a window, packed for the all-reduce — the lower triangle of H over the dims
+// in use, g, the lower triangle of E, eg and the ranks' cost rows: sys_pack_doubles() per window (20.6k doubles = 164 KB for a
+// batch without GNSS blocks, against 60.5k + 5.4k for the square arrays). dir 0: gather into sys_pack; 1: scatter the sums back
+// (E into both triangles: the solve kernels read it as a full matrix).
+__host__ __device__ inline int sys_pack_doubles(int nu, int world) { return nu * (nu + 1) / 2 + nu + NV * (NV + 1) / 2 + NV + world * XCHG; }
+__global__ __launch_bounds__(256) void k_sys_pack(BatchDev d, int dir) {
+  const int w = blockIdx.y, nthr = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+  const int nu = d.nu, T = nu * (nu + 1) / 2, TE = NV * (NV + 1) / 2, nx = d.world * XCHG;
+  double *P = d.sys_pack + (size_t)w * sys_pack_doubles(nu, d.world);
+  double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND, *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
+  double *xa = d.xa + (size_t)w * nx;
+  for (int e = t0; e < T + nu + TE + NV + nx; e += nthr) {
+    double *src;
+    double *mirror = nullptr;
+    if (e < T) { int a, b; tri_decode(e, a, b); src = H + (size_t)a * ND + b; }
+    else if (e < T + nu) src = g + (e - T);
+    else if (e < T + nu + TE) { int a, b; tri_decode(e - T - nu, a, b); src = E + a * NV + b; mirror = E + b * NV + a; }
+    else if (e < T + nu + TE + NV) src = eg + (e - T - nu - TE);
+    else src = xa + (e - T - nu - TE - NV);
+    if (dir == 0) P[e] = *src;
+    else { const double v = P[e]; *src = v; if (mirror) *mirror = v; }
+  }
+}
+void launch_sys_pack(const BatchDev &d, int dir, hipStream_t s) { hipLaunchKernelGGL(k_sys_pack, dim3(8, d.B), dim3(256), 0, s, d, dir); }
+size_t sys_pack_doubles_host(int nu, int world) { return (size_t)sys_pack_doubles(nu, world); }
 void launch_lm_step(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles == 0) return;
   hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
