@@ -43,10 +43,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096,
-                    help="resident windows per GPU, solved as four parts side by side (measured round 3: 57.7k / 62.3k / 64.4k solves/s at "
-                         "1024 / 2048 / 4096 windows; a 2k-landmark window takes ~12 MB of the 288 GB). `resident_1024` in the JSON line "
-                         "is the same measurement at the 1024 windows of rounds 1-2")
+    ap.add_argument("--batch", type=int, default=8192,
+                    help="resident windows per GPU, solved as four parts side by side (measured round 3, final build: 62.7k / 65.3k / 67.2k / "
+                         "70.7k / 71.1k solves/s at 1024 / 2048 / 4096 / 8192 / 16384 windows; a 2k-landmark window takes ~8 MB of the 288 GB). "
+                         "`resident_1024` in the JSON line is the same measurement at the 1024 windows of rounds 1-2")
     ap.add_argument("--landmarks", type=int, default=2000)
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic windows (tiled to --batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
