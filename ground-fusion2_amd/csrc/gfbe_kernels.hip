@@ -919,10 +919,11 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   const int l = t & 63, part = t >> 6;
   double pre[24];
   double pHll = 0.0, psl = 1.0;
-  int pinfo = 0, ps = 0;                // (ps: start frame of the prefetched tile)
+  int pinfo = 0, ps = 0, pm0 = 0;       // (ps: start frame of the prefetched tile; pm0: lm_info of its first, longest track)
   auto prefetch = [&](int tile) {
     const int slot = ds.lm_off + tile * LM_TILE + l;
     ps = d.tile_start[ds.tile_off + tile];
+    pm0 = d.lm_info[ds.lm_off + tile * LM_TILE];
     const int kmax = NF - 1 - ps;       // observing poses ps+1 .. 10
     pinfo = d.lm_info[slot];
     pHll = d.lm_Hll[slot];
@@ -948,6 +949,10 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   for (int tile = tfirst; tile < te; tile += tstep) {
     __syncthreads();
     if (stamp_wg && tile == tfirst) stamp[1] = (double)wall_clock64();
+    // The tracks of a tile are sorted longest first: its rows are zero beyond the pose columns of the first track's last observer,
+    // jl = the last 16-column block they reach (block 4 holds the extrinsic / td / gradient columns of every row). Tile pairs
+    // outside are products of zeros: skipped (the accumulators keep their bits: + 0.0).
+    const int jl = __builtin_amdgcn_readfirstlane((6 * (ps + ((pm0 >> 8) & 0xff) + 1) - 1) >> 4);
     {
       const int s = ps, kmax = NF - 1 - s;          // this tile's start frame
       const int slot = ds.lm_off + tile * LM_TILE + l;
@@ -993,7 +998,7 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
     if (stamp_wg && tile == tfirst) stamp[2] = (double)wall_clock64();
     if (tile + tstep < te) prefetch(tile + tstep);
 #define SCHUR_SLOT(Q, ACC)                                                                          \
-    if (pI[Q] >= 0) {                                                                               \
+    if (pI[Q] >= 0 && (pI[Q] <= jl || pI[Q] == 4) && (pJ[Q] <= jl || pJ[Q] == 4)) {                 \
       const double *pa = hs + 16 * pI[Q] + lr + lk * HS_LD, *pb = hs + 16 * pJ[Q] + lr + lk * HS_LD; \
       double va[LM_TILE / 4], vb[LM_TILE / 4];                                                      \
       _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 4; kk++) { va[kk] = pa[4 * kk * HS_LD]; vb[kk] = pb[4 * kk * HS_LD]; } \
