@@ -1715,7 +1715,8 @@ __device__ __forceinline__ void candidate_dense(const BatchDev &d, const WinDesc
   }
   // the candidate's pose-pair constants, for its cost evaluation and — if it is accepted — the next linearisation
   __syncthreads();
-  if (my_wave) pair_consts_of_state(Y, d.pc + ((size_t)w * 3 + (1 - c.cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
+  // (every thread of the workgroup passes the barrier inside; the lanes of the other waves have no pair to form)
+  pair_consts_of_state(Y, d.pc + ((size_t)w * 3 + (1 - c.cur)) * NPAIR * PC_DOUBLES, sp_cand, my_wave ? t : NPAIR);
 }
 __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
   const int w = blockIdx.y;
@@ -1731,6 +1732,22 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
     __shared__ PoseRT sp_cand[NF + 1];
     candidate_dense(d, ds, c, w, t, sp_cand, true);
   }
+}
+
+// Throughput batches: ONE workgroup per window — wave 0 takes the dense blocks, then all four waves walk the landmark tiles
+// (a wave per tile, the per-tile sums by the same 64 lanes as in k_candidate: the same bits). The tiles + 1 single-wave workgroups
+// per window of k_candidate are 37 k dispatches of a few hundred nanoseconds of work each per launch of 1024 windows.
+#define CAND_THREADS 256
+__global__ __launch_bounds__(CAND_THREADS) void k_candidate_window(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (c.done || !c.have_step) return;
+  const int t = threadIdx.x, wave = t >> 6;
+  __shared__ PoseRT sp_cand[NF + 1];
+  for (int tile = wave; tile < ds.n_tiles; tile += CAND_THREADS / 64)
+    if (TILE_OWNED(d, tile)) candidate_tile(d, ds, c, w, tile, t & 63);
+  candidate_dense(d, ds, c, w, t, sp_cand, wave == 0);
 }
 
 // =============================================================================================
@@ -2007,7 +2024,8 @@ void launch_lm_step(const BatchDev &d, hipStream_t s) {
 }
 void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
 void launch_candidate(const BatchDev &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_candidate, dim3(d.max_tiles + 1, d.B), dim3(LM_TILE), 0, s, d);
+  if (d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_candidate_window, dim3(d.B), dim3(CAND_THREADS), 0, s, d);
+  else hipLaunchKernelGGL(k_candidate, dim3(d.max_tiles + 1, d.B), dim3(LM_TILE), 0, s, d);
 }
 void launch_accept(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_accept, dim3(d.B), dim3(64), 0, s, d); }
 void launch_reanchor(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_reanchor, dim3(d.B), dim3(64), 0, s, d); }
