@@ -67,12 +67,33 @@ __device__ __forceinline__ double gm_dtddt_coef(int la, int k, double dt) {
 }
 __device__ __forceinline__ double gm_smooth_coef(int la, double wgt) { return la == 16 ? wgt : (la == 21 ? -wgt : 0.0); }
 
+// ---- cells: the observations of frame fr that interpolate between poses lw and lw + 1, lw in {fr - 1, fr}: cell 2 fr + (lw == fr).
+//      All observations of a cell reach the same GN_CL = 20 dims: P_lw V_lw P_lw+1 V_lw+1 (3 each) | rcv_dt[fr][0..3] | rcv_ddt[fr] | anc
+enum { GN_CELLS = 2 * NF, GN_CL = 20, GN_CITEMS = GN_CL * (GN_CL + 1) / 2 + GN_CL, GN_CLD = 232 };   // 210 lower pairs + 20 gradient entries per cell
+__device__ __forceinline__ int gc_col(int la, int sys) {        // column of local dim la in the Jacobian of an observation of constellation sys
+  if (la < 12) return la;
+  if (la < 16) return (la - 12) == sys ? 12 : -1;
+  if (la == 16) return 13;
+  return 15 + (la - 17);
+}
+__device__ __forceinline__ int gc_loc(int c, int ce) {          // local index of compact dim c in cell ce, or -1
+  const int fr = ce >> 1, lw = fr - 1 + (ce & 1);
+  if (c < 66) {
+    const int cc = c < 33 ? c : c - 33, f = cc / 3, q = cc - 3 * f, o = c < 33 ? 0 : 3;
+    return f == lw ? o + q : (f == lw + 1 ? 6 + o + q : -1);
+  }
+  if (c < 110) return ((c - 66) >> 2) == fr ? 12 + ((c - 66) & 3) : -1;
+  if (c < 121) return (c - 110) == fr ? 16 : -1;
+  return 17 + (c - 121);
+}
+
 // 512 threads: the sums below are issue-bound integer / LDS work (a lone wave issues one instruction every ~5 cycles), two waves
 // per SIMD halve that; the per-observation evaluation keeps its 256 VGPRs.
 #define GN_THREADS 512
 enum { GN_NCLK = 5 * GFBE_WINDOW_SIZE,     // 40 DtDdtFactors (constellation-major, the reference's insertion order) + 10 DdtSmoothFactors
        GN_ROW = 38,                        // doubles per staged observation: J (2 x 18) | r (2)
-       GN_LDS_OBS = 384 };                 // observations a window can stage in LDS (114 KB); a larger window sums from the global copy (L2)
+       GN_LDS_OBS = 320 };                 // observations a window can stage in LDS (95 KB, beside 40 KB of cell partials); a larger window
+                                           // sums from the global copy (L2), entry by entry
 
 __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsigned lds_obs) {
   const int w = blockIdx.x, t = threadIdx.x;
@@ -83,7 +104,12 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsig
   if (mode == 1 && (!ds.gnss_factors || c.done || !c.have_step)) return;
   if (mode == 2 && ds.frame_count < GFBE_WINDOW_SIZE) return;
   const double *X = mode == 2 ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + (mode == 1 ? 1 - c.cur : c.cur)) * NA;
-  __shared__ double red[16], clk_r[GN_NCLK];
+  __shared__ double red[16], clk_r[GN_NCLK], s_dt[GFBE_WINDOW_SIZE];
+  __shared__ int s_fb[NF + 1];
+  __shared__ unsigned char s_act[GN_C];      // (the descriptor lives in global memory: what the sums below consult per entry is staged once)
+  if (t < GFBE_WINDOW_SIZE) s_dt[t] = ds.gnss_frame_dt[t];
+  if (t <= NF) s_fb[t] = ds.gnss_frame_begin[t];
+  if (t < GN_C) s_act[t] = ds.act[gn_tan(t)];
   double *stamp = d.timing + (size_t)d.B * 32 + 8 * mode;     // phase stamps of window 0 (diagnostics: gfbe_debug_timing(batch, B))
 #define GSTAMP(i) do { if (w == 0 && t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   GSTAMP(0);
@@ -92,8 +118,8 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsig
   // launch from L2)
   extern __shared__ __attribute__((aligned(16))) double gn_lds[];
   const bool staged = ds.n_gnss <= (int)lds_obs;
-  double *sJ = gn_lds;
-  int *sMeta = (int *)(gn_lds + (size_t)lds_obs * GN_ROW);
+  double *cellP = gn_lds, *sJ = gn_lds + GN_CELLS * GN_CLD;
+  int *sMeta = (int *)(sJ + (size_t)lds_obs * GN_ROW);
   const gfbe_gnss_obs *obs = d.gnss_obs + ds.gnss_off;
   double *Jw = d.gnss_J + (size_t)ds.gnss_off * 36, *rw = d.gnss_r + (size_t)ds.gnss_off * 2;
   // MARGIN_OLD takes the observations of frame 0 (first in the frame-sorted list) between poses 0 and 1, and the clock factors of
@@ -163,26 +189,63 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsig
   if (t == 0) d.gnss_cost[(size_t)w * 2] = cost;
   if (d.rank != 0) return;      // landmark sharding: like the inertial / wheel / prior factors, added once
   double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
+  if (staged) {
+    // cell partials: a wave per cell, its lanes own the 230 items (four each), the observations of the cell's frame walked by the
+    // whole wave together (LDS broadcasts, no divergence), in observation order
+    const int lane = t & 63;
+    for (int ce = t >> 6; ce < GN_CELLS; ce += GN_THREADS / 64) {
+      const int fr = ce >> 1, lw = fr - 1 + (ce & 1);
+      int la[4], lb[4];
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int it = lane + 64 * j;
+        la[j] = -1; lb[j] = -1;
+        if (it < GN_CL * (GN_CL + 1) / 2) tri_decode(it, la[j], lb[j]);
+        else if (it < GN_CITEMS) { la[j] = it - GN_CL * (GN_CL + 1) / 2; lb[j] = GN_CL; }     // lb == GN_CL: the gradient entry of la
+      }
+      if (lw >= 0 && lw < GFBE_WINDOW_SIZE)
+        for (int k = s_fb[fr]; k < s_fb[fr + 1]; k++) {
+          const int mt = sMeta[k];
+          if (((mt >> 8) & 255) != lw) continue;        // (wave-uniform)
+          const int sys = mt >> 16;
+          const double *J = sJ + k * GN_ROW;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (la[j] < 0) continue;
+            const int ja = gc_col(la[j], sys), jb = lb[j] == GN_CL ? 36 : gc_col(lb[j], sys);
+            if (ja < 0 || jb < 0) continue;
+            acc[j] += lb[j] == GN_CL ? J[ja] * J[36] + J[18 + ja] * J[37] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (lane + 64 * j < GN_CITEMS) cellP[ce * GN_CLD + lane + 64 * j] = acc[j];
+    }
+    __syncthreads();
+  }
+  GSTAMP(3);
   for (int e = t; e < GN_C * (GN_C + 1) / 2 + GN_C; e += GN_THREADS) {
     const bool isg = e >= GN_C * (GN_C + 1) / 2;
     int ca, cb;
     if (isg) { ca = e - GN_C * (GN_C + 1) / 2; cb = ca; } else tri_decode(e, ca, cb);
+    if (!s_act[ca] || !s_act[cb]) continue;
     const int ta = gn_tan(ca), tb = gn_tan(cb);
-    if (!ds.act[ta] || !ds.act[tb]) continue;
     int fa0, fa1, fb0, fb1;
     gn_frames(ca, fa0, fa1);
     gn_frames(cb, fb0, fb1);
     const int f0 = max(fa0, fb0), f1 = min(fa1, fb1);
     double s = 0.0;
-    if (f0 <= f1)
-      for (int k = ds.gnss_frame_begin[f0]; k < ds.gnss_frame_begin[f1 + 1]; k++) {
-        if (staged) {
-          const int mt = sMeta[k], fr = mt & 255, lw = (mt >> 8) & 255, sys = mt >> 16;
-          const int ja = gn_col(ca, fr, lw, sys), jb = isg ? 0 : gn_col(cb, fr, lw, sys);
-          if (ja < 0 || jb < 0) continue;
-          const double *J = sJ + k * GN_ROW;
-          s += isg ? J[ja] * J[36] + J[18 + ja] * J[37] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
-        } else {
+    if (f0 <= f1 && staged) {
+      // the cells of frames f0 .. f1 that hold both dims, in cell order
+      for (int ce = max(2 * f0, 1); ce <= min(2 * f1 + 1, GN_CELLS - 2); ce++) {
+        const int la = gc_loc(ca, ce), lb = isg ? 0 : gc_loc(cb, ce);
+        if (la < 0 || lb < 0) continue;
+        const int hi = max(la, lb), lo = min(la, lb);
+        s += cellP[ce * GN_CLD + (isg ? GN_CL * (GN_CL + 1) / 2 + la : hi * (hi + 1) / 2 + lo)];
+      }
+    } else if (f0 <= f1)
+      for (int k = s_fb[f0]; k < s_fb[f1 + 1]; k++) {
+        {
           const gfbe_gnss_obs &o = obs[k];
           const int ja = gn_col(ca, o.frame, o.lower_idx, o.sys_idx), jb = isg ? 0 : gn_col(cb, o.frame, o.lower_idx, o.sys_idx);
           if (ja < 0 || jb < 0) continue;
@@ -191,12 +254,16 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsig
         }
       }
     if (ca >= 66 && ca < 121 && cb >= 66 && cb < 121) {
-      for (int q = 0; q < 4 * GFBE_WINDOW_SIZE; q++) {
-        const int k = q / GFBE_WINDOW_SIZE, i = q % GFBE_WINDOW_SIZE;
-        const double a = gn_dtddt_coef(ca, i, k, ds.gnss_frame_dt[i]);
-        if (a != 0.0) s += a * (isg ? clk_r[q] : gn_dtddt_coef(cb, i, k, ds.gnss_frame_dt[i]));
-      }
-      for (int i = 0; i < GFBE_WINDOW_SIZE; i++) {
+      // clock factors: interval i couples frames i and i + 1 — only i in [max(fa, fb) - 1, min(fa, fb)] can hold both dims;
+      // constellation-major, then interval order, like the reference inserts them
+      const int fca = ca < 110 ? (ca - 66) >> 2 : ca - 110, fcb = cb < 110 ? (cb - 66) >> 2 : cb - 110;
+      const int i0 = max(max(fca, fcb) - 1, 0), i1 = min(min(fca, fcb), GFBE_WINDOW_SIZE - 1);
+      for (int k = 0; k < 4; k++)
+        for (int i = i0; i <= i1; i++) {
+          const double a = gn_dtddt_coef(ca, i, k, s_dt[i]);
+          if (a != 0.0) s += a * (isg ? clk_r[k * GFBE_WINDOW_SIZE + i] : gn_dtddt_coef(cb, i, k, s_dt[i]));
+        }
+      for (int i = i0; i <= i1; i++) {
         const double a = gn_smooth_coef(ca, i, wgt);
         if (a != 0.0) s += a * (isg ? clk_r[4 * GFBE_WINDOW_SIZE + i] : gn_smooth_coef(cb, i, wgt));
       }
@@ -208,7 +275,7 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsig
 #undef GSTAMP
 }
 
-static size_t gnss_lds_bytes(unsigned n_obs) { return sizeof(double) * (size_t)n_obs * GN_ROW + sizeof(int) * (size_t)n_obs; }
+static size_t gnss_lds_bytes(unsigned n_obs) { return sizeof(double) * ((size_t)GN_CELLS * GN_CLD + (size_t)n_obs * GN_ROW) + sizeof(int) * (size_t)n_obs; }
 hipError_t gnss_init_device() {   // per device, from gfbe_create (see kernels_init_device)
   return hipFuncSetAttribute((const void *)k_gnss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnss_lds_bytes(GN_LDS_OBS));
 }
@@ -216,7 +283,7 @@ void launch_gnss(const BatchDev &d, int mode, hipStream_t s) {
   if (!d.any_gnss) return;
   // LDS for the batch's largest window (mode 1, the candidate cost, stages nothing)
   const unsigned n = mode == 1 ? 0u : (unsigned)std::min(d.gnss_max_obs, (int)GN_LDS_OBS);
-  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), gnss_lds_bytes(n), s, d, mode, n);
+  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), mode == 1 ? 0 : gnss_lds_bytes(n), s, d, mode, n);
 }
 
 }  // namespace gfd

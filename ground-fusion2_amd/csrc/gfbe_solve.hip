@@ -1301,8 +1301,8 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
 // batches without GNSS dims).
 // =============================================================================================
 #define BIG_THREADS 512
-enum { BIG_WAVES = BIG_THREADS / 64 };
-static size_t big_smem_bytes() { return sizeof(double) * (size_t)(BIG_WAVES + 1) * TB * TB; }   // a tile per wave (layout changes, reductions) + the diagonal tile
+enum { BIG_WAVES = BIG_THREADS / 64, BIG_BLD = 244 };    // BIG_BLD: LDS row stride of the staged tile row (up to 15 tiles of 16 columns)
+static size_t big_smem_bytes() { return sizeof(double) * ((size_t)(BIG_WAVES + 1) * TB * TB + TB * BIG_BLD); }   // a tile per wave (layout changes, reductions) + the diagonal tile + a tile row
 
 // The factorisation loop of k_solve_big, out of line (its own register allocation: two accumulator tiles, four k-steps of operands
 // in flight and — at another time — the 64 registers of the tile step).
@@ -1313,40 +1313,70 @@ static size_t big_smem_bytes() { return sizeof(double) * (size_t)(BIG_WAVES + 1)
 //   and inverts in LDS (chol_inv_tile16); after one block barrier every wave turns its tiles into L(I, j) = P W^T and stores them.
 //   Two block barriers per panel. Tw: a tile of the calling wave's own, for the accumulator -> A-operand layout change.
 enum { BIG_KCH = 4 };
-__device__ __noinline__ void big_factor(double *S, int nt, int n, int lane, int wave, lds_double *Dgl, lds_double *Tw, lds_double *zlast, lds_int *flag) {
-  const int lr = lane & 15, lk = lane >> 4;
-  for (int j = 0; j < nt; j++) {
-    const int I0 = j + wave, I1 = j + wave + BIG_WAVES;
-    dbl4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    if (I0 < nt) {
-      const double *Sc0 = S + (size_t)(TB * I0 + lk) * BIG_LD + TB * j + lr;    // accumulator layout: row lk + 4 q, column lr
-      const double *Sc1 = S + (size_t)(TB * min(I1, nt - 1) + lk) * BIG_LD + TB * j + lr;
+#ifndef GFBE_BIG_STAMP
+#define GFBE_BIG_STAMP 0    // diagnostics: phase stamps of panel 10 into the window's timing slots 8..13
+#endif
+// the k loop of one panel for a wave with one (TWO = false) or two tiles; B operands from the staged tile row in LDS
+template <bool TWO>
+__device__ __forceinline__ void big_kloop(const glb_double *Sa0, const glb_double *Sa1, const lds_double *Bj, int j, dbl4 &acc0, dbl4 &acc1) {
+  for (int k0 = 0; k0 < j; k0 += BIG_KCH) {
+    double va[BIG_KCH][4], vb[BIG_KCH][4], vc[BIG_KCH][4];
 #pragma unroll
-      for (int q = 0; q < 4; q++) { acc0[q] = Sc0[(size_t)4 * q * BIG_LD]; acc1[q] = Sc1[(size_t)4 * q * BIG_LD]; }
-      const double *Sj = S + (size_t)(TB * j + lr) * BIG_LD + lk;                // B operand: tile row j
-      const double *Sa0 = S + (size_t)(TB * I0 + lr) * BIG_LD + lk, *Sa1 = S + (size_t)(TB * min(I1, nt - 1) + lr) * BIG_LD + lk;
-      const bool two = I1 < nt;
-      for (int k0 = 0; k0 < j; k0 += BIG_KCH) {
-        double va[BIG_KCH][4], vb[BIG_KCH][4], vc[BIG_KCH][4];
+    for (int u = 0; u < BIG_KCH; u++) {
+      const int k = min(k0 + u, j - 1);        // (clamped: the steps past the panel re-load the last one and are not multiplied)
 #pragma unroll
-        for (int u = 0; u < BIG_KCH; u++) {
-          const int k = min(k0 + u, j - 1);        // (clamped: the steps past the panel re-load the last one and are not multiplied)
+      for (int q = 0; q < 4; q++) {
+        va[u][q] = -Sa0[TB * k + q];
+        vc[u][q] = TWO ? -Sa1[TB * k + q] : 0.0;
+        vb[u][q] = Bj[TB * k + q];
+      }
+    }
 #pragma unroll
-          for (int q = 0; q < 4; q++) { vb[u][q] = Sj[TB * k + 4 * q]; va[u][q] = -Sa0[TB * k + 4 * q]; vc[u][q] = -Sa1[TB * k + 4 * q]; }
-        }
+    for (int u = 0; u < BIG_KCH; u++) {
+      if (k0 + u < j) {
 #pragma unroll
-        for (int u = 0; u < BIG_KCH; u++) {
-          if (k0 + u < j) {
+        for (int kk = 0; kk < 4; kk++) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u][kk], vb[u][kk], acc0, 0, 0, 0);
+        if (TWO) {
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u][kk], vb[u][kk], acc0, 0, 0, 0);
-            if (two) {
-#pragma unroll
-              for (int kk = 0; kk < 4; kk++) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[u][kk], vb[u][kk], acc1, 0, 0, 0);
-            }
-          }
+          for (int kk = 0; kk < 4; kk++) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[u][kk], vb[u][kk], acc1, 0, 0, 0);
         }
       }
     }
+  }
+}
+// Brow: [16][BIG_BLD] LDS copy of tile row j (columns 0 .. 16 j - 1), shared by all waves
+__device__ __noinline__ void big_factor(glb_double *S, int nt, int n, int lane, int wave, lds_double *Dgl, lds_double *Tw, lds_double *Brow, lds_double *zlast,
+                                        lds_int *flag, double *stamp) {
+  const int lr = lane & 15, lk = lane >> 4, t = wave * 64 + lane;
+#define FSTAMP(i) do { if (GFBE_BIG_STAMP && j == 10 && wave == 0 && lane == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  for (int j = 0; j < nt; j++) {
+    FSTAMP(8);
+    const int I0 = j + wave, I1 = j + wave + BIG_WAVES;
+    dbl4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // tile row j is the B operand of every product of the panel: staged once (coalesced), read from LDS by all waves
+    for (int e = t; e < TB * TB * j; e += BIG_THREADS) {
+      const int r = e / (TB * j), cc = e - r * (TB * j);
+      Brow[r * BIG_BLD + cc] = S[(size_t)(TB * j + r) * BIG_LD + cc];
+    }
+    if (I0 < nt) {
+      const glb_double *Sc0 = S + (size_t)(TB * I0 + lk) * BIG_LD + TB * j + lr;    // accumulator layout: row lk + 4 q, column lr
+      const glb_double *Sc1 = S + (size_t)(TB * min(I1, nt - 1) + lk) * BIG_LD + TB * j + lr;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { acc0[q] = Sc0[(size_t)4 * q * BIG_LD]; acc1[q] = Sc1[(size_t)4 * q * BIG_LD]; }
+    }
+    __syncthreads();
+    if (I0 < nt) {
+      // operands: lane (lr, lk) takes the FOUR CONSECUTIVE entries 4 lk .. 4 lk + 3 of its row of a 16 x 16 tile — one 32-byte load —
+      // and feeds entry kk to the kk-th 16x16x4 instruction: the k index of a product runs 4 lk + kk instead of 4 kk + lk, the
+      // same permutation for both operands, so the sum over the sixteen k's is the same sum in another order. (With the
+      // natural 4 kk + lk mapping every 8-byte load picked 32 bytes out of sixteen different 128-byte lines, four times over:
+      // the k loop was bound by the vector L1's line rate, 6.6 us per four-step chunk with all eight waves loading.)
+      const glb_double *Sa0 = S + (size_t)(TB * I0 + lr) * BIG_LD + 4 * lk, *Sa1 = S + (size_t)(TB * min(I1, nt - 1) + lr) * BIG_LD + 4 * lk;
+      const lds_double *Bj = Brow + lr * BIG_BLD + 4 * lk;
+      if (I1 < nt) big_kloop<true>(Sa0, Sa1, Bj, j, acc0, acc1);
+      else big_kloop<false>(Sa0, Sa1, Bj, j, acc0, acc1);
+    }
+    FSTAMP(9);
     if (wave == 0) {     // I0 == j: the diagonal tile
 #pragma unroll
       for (int q = 0; q < 4; q++) Dgl[tsw(lk + 4 * q, lr)] = acc0[q];
@@ -1354,7 +1384,9 @@ __device__ __noinline__ void big_factor(double *S, int nt, int n, int lane, int 
       __builtin_amdgcn_wave_barrier();
       if (!chol_inv_tile16(Dgl, lane, j == nt - 1 ? n % TB : -1, zlast) && lane == 0) *flag = 1;
     }
+    FSTAMP(10);
     __syncthreads();
+    FSTAMP(11);
     if (*flag) break;
     // L(I, j) = P(I, j) W^T: the accumulator goes through the wave's LDS tile into the A-operand layout, B = W^T
     double wb[4];
@@ -1380,13 +1412,16 @@ __device__ __noinline__ void big_factor(double *S, int nt, int n, int lane, int 
         dbl4 out = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) out = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], wb[kk], out, 0, 0, 0);
-        double *So = S + (size_t)(TB * I + lk) * BIG_LD + TB * j + lr;
+        glb_double *So = S + (size_t)(TB * I + lk) * BIG_LD + TB * j + lr;
 #pragma unroll
         for (int q = 0; q < 4; q++) So[(size_t)4 * q * BIG_LD] = out[q];
       }
     }
+    FSTAMP(12);
     __syncthreads();
+    FSTAMP(13);
   }
+#undef FSTAMP
 }
 
 __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry_pass) {
@@ -1516,7 +1551,8 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
     if (t == 0) { flag = 0; s_vSv = vsv; }
     __syncthreads();
     BSTAMP(2);
-    big_factor(S, nt, n, lane, wave, (lds_double *)Dg, (lds_double *)(Pn + wave * TB * TB), (lds_double *)zlast, (lds_int *)&flag);
+    big_factor((glb_double *)S, nt, n, lane, wave, (lds_double *)Dg, (lds_double *)(Pn + wave * TB * TB), (lds_double *)(Dg + TB * TB), (lds_double *)zlast,
+               (lds_int *)&flag, stamp);
     BSTAMP(3);
     bool ok = (flag == 0);
     if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;   // fault injection: first attempt of that iteration
@@ -1604,6 +1640,12 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
 #undef BSTAMP
 }
 
+// k_solve's LDS budget: 78 tiles of 2 KB + its static arrays must fit the 160 KB of a CU (it did by 200 bytes in round 2 and
+// stopped fitting when the GNSS blocks widened ND: the static arrays are sized by the core dims since). The sum below mirrors the
+// __shared__ declarations of the kernel; hipFuncSetAttribute fails at gfbe_create if the real figure exceeds the limit.
+static_assert(((NC + 1 + TB - 1) / TB) * (((NC + 1 + TB - 1) / TB) + 1) / 2 * TB * TB * sizeof(double)      // dynamic: the tiles
+              + sizeof(short) * (NC + TB) + sizeof(double) * (16 + 2 * NC + TB + 2 + TB) + sizeof(int) * 6      // perm, red, ys, s_zz, s_vSv, zlast, flags
+              + 128 /* alignment padding */ <= 160 * 1024, "k_solve: tiles + static LDS exceed a CU's 160 KB");
 static size_t solve_smem_bytes() { const int nt = (NC + 1 + TB - 1) / TB;   /* (k_solve never sees the GNSS dims: those batches take k_solve_big) */ return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
 static size_t chain_smem_bytes(int ntile) { return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + 2 * RING_ROWS * chain_ring_ld(ntile)); }
 size_t solve_chain_scratch_doubles() { return (size_t)GYT_COLS * GYT_LD; }

@@ -14,6 +14,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "noesym": (["-DGFBE_SOLVE_ESYM=0"], "off"),
     "cholstamp": (["-DGFBE_CHOL_STAMP=1"], "off"),
     "chainstamp": (["-DGFBE_CHAIN_STAMP=1"], "off"),
+    "bigstamp": (["-DGFBE_BIG_STAMP=1"], "off"),
     "marg512": (["-DMARG_THREADS=512"], "off"),
     "marg256": (["-DMARG_THREADS=256"], "off"),
     "asmw1": (["-DASM_WGS=1"], "off"),
