@@ -16,11 +16,19 @@ def main():
     abi, synth = gf.abi, gf.synth
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    scn = synth.Scenario(seed=20250710 + L, n_landmarks=L, use_wheel=True)
-    # window 0 (no prior) solved + marginalised unsharded -> prior and shifted state of window 1 (same on every rank)
+    gnss = len(sys.argv) > 7 and sys.argv[7] == "gnss"
     plain = gf.Backend(device=0)
-    first = plain.solve(scn.window(0), abi.MARGIN_OLD)
-    snap = scn.window(1, state=synth.shift_state_for_next_window(scn, first["state"], 1), prior=first["prior"])
+    if gnss:      # a window with GNSS inside the solve (the 246-dim layout, k_solve_big, the GNSS factors added by rank 0) and its prior
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import gnss_window_cases as gw
+        scn, tru, snap0 = gw.gnss_window(seed=20250710 + L, L=L, n_per_frame=6)
+        first = plain.solve(snap0, abi.MARGIN_OLD)
+        snap = gw.next_gnss_window(scn, tru, first, seed=20250710 + L)
+    else:
+        scn = synth.Scenario(seed=20250710 + L, n_landmarks=L, use_wheel=True)
+        # window 0 (no prior) solved + marginalised unsharded -> prior and shifted state of window 1 (same on every rank)
+        first = plain.solve(scn.window(0), abi.MARGIN_OLD)
+        snap = scn.window(1, state=synth.shift_state_for_next_window(scn, first["state"], 1), prior=first["prior"])
     opt = abi.default_options()
     opt.test_fail_chol_iter = fail_iter
     failing = gf.Backend(device=0, options=opt)

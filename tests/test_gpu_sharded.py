@@ -22,15 +22,16 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,L,fail_iter", [(2, 2000, 0), (3, 500, 0), (2, 500, 2)])
-def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter):
+@pytest.mark.parametrize("world,L,fail_iter,kind", [(2, 2000, 0, "plain"), (3, 500, 0, "plain"), (2, 500, 2, "plain"), (2, 300, 0, "gnss")])
+def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter, kind):
     """fail_iter > 0: the first factorisation of that iteration is declared failed on every rank (and in the unsharded
     reference): the sharded mu retry — E rebuilt from every rank's own tiles at the larger mu, one more all-reduce, second
-    factorisation — must give what the in-kernel retry of the unsharded solve gives."""
+    factorisation — must give what the in-kernel retry of the unsharded solve gives. kind "gnss": a window with GNSS blocks and a GNSS
+    prior (k_solve_big, the packed 246-dim system in the all-reduce, the GNSS factors added by rank 0 only)."""
     port = free_port()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(r), str(world), str(port), str(L), outs[r], str(fail_iter)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), str(r), str(world), str(port), str(L), outs[r], str(fail_iter), kind],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     logs = []
     for p in procs:
@@ -54,13 +55,16 @@ def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter)
     assert int(r0["got_iterations"]) == int(r0["ref_iterations"])
     assert r0["got_accepted"].tolist() == r0["ref_accepted"].tolist()
     # transient iterations drop the cost by 1e5: 1e-6 relative there (as in test_gpu_parity.py), 1e-11 at convergence
+    # (a GNSS window stops on the parameter tolerance before it has settled — DESIGN.md section 6 — and carries 1e5..1e7-sized
+    #  clock / anchor blocks: two summation orders end 1e-10 apart in the cost; bounds x 100)
+    lo = 100.0 if kind == "gnss" else 1.0
     np.testing.assert_allclose(r0["got_cost_history"], r0["ref_cost_history"], rtol=1e-6)
-    assert abs(float(r0["got_final_cost"]) - float(r0["ref_final_cost"])) < 1e-11 * float(r0["ref_final_cost"])
-    assert np.abs(r0["got_pose"] - r0["ref_pose"]).max() < 1e-10
-    assert np.abs(r0["got_sb"] - r0["ref_sb"]).max() < 1e-9
-    np.testing.assert_allclose(r0["got_feature"], r0["ref_feature"], rtol=1e-9, atol=1e-13)
+    assert abs(float(r0["got_final_cost"]) - float(r0["ref_final_cost"])) < lo * 1e-11 * float(r0["ref_final_cost"])
+    assert np.abs(r0["got_pose"] - r0["ref_pose"]).max() < lo * 1e-10
+    assert np.abs(r0["got_sb"] - r0["ref_sb"]).max() < lo * 1e-9
+    np.testing.assert_allclose(r0["got_feature"], r0["ref_feature"], rtol=lo * 1e-9, atol=1e-13)
     Ag, Ar = r0["got_J0"].T @ r0["got_J0"], r0["ref_J0"].T @ r0["ref_J0"]
-    assert np.abs(Ag - Ar).max() < 1e-9 * np.abs(Ar).max()
+    assert np.abs(Ag - Ar).max() < lo * 1e-9 * np.abs(Ar).max()
     bg, br = r0["got_J0"].T @ r0["got_r0"], r0["ref_J0"].T @ r0["ref_r0"]
     # b' = b_r - A_rm A_mm^-1 b_m cancels ~1e10-sized inertial terms: 1e-6 relative, as in test_gpu_parity.py
-    assert np.abs(bg - br).max() < 1e-6 * max(np.abs(br).max(), 1.0)
+    assert np.abs(bg - br).max() < lo * 1e-6 * max(np.abs(br).max(), 1.0)
