@@ -3,9 +3,12 @@
 //   residual blocks       estimator.cpp:3239-3291 (GnssPsrDoppFactor per observation, DtDdtFactor / DdtSmoothFactor chains)
 //   marginalisation set   estimator.cpp:3459-3496 (the factors of frame 0, drop sets {0, 1, 4, 5}, {0, 2}, {0})
 // One workgroup per window. The observations are evaluated one per thread (the arithmetic is gfbe_gnss.h, shared with
-// gfbe_gnss_eval); their 2 x 18 Jacobians stay in L2 and every entry of the normal equations the GNSS factors reach is then
-// summed by ONE thread over the observations of the frames that can touch it, in observation order: no atomics, the same bits
-// on every run. The clock factors are linear with constant Jacobians and are added in closed form.
+// gfbe_gnss_eval) and their 2 x 18 Jacobians staged in LDS. The observations of frame fr that interpolate between poses lw and
+// lw + 1 form a CELL (lw in {fr - 1, fr}: 20 cells), all of whose observations reach the same 20 dims: a wave per cell sums the
+// cell's 20 x 20 block and gradient over its observations in observation order (LDS broadcasts, no divergence); every entry of
+// the normal equations the GNSS factors reach is then summed by ONE owner thread over the cells that hold both dims, in cell
+// order: no atomics, the same bits on every run. The clock factors are linear with constant Jacobians and are added in closed
+// form. (A window with more observations than fit in LDS sums entry by entry from the global copy of the Jacobians.)
 #include "gfbe_devutil.h"
 #include <algorithm>
 
