@@ -228,21 +228,35 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
 #define MSTAMP(i) do { if (w == 0 && t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   MSTAMP(0);
 
-  if (t == 0) {
-    for (int q = 0; q < GFBE_BLK_COUNT; q++) sh.touched[q] = 0;
-    for (int q = 0; q < ds.prior_nblk; q++) sh.touched[ds.prior_blk_id[q]] = 1;
-    sh.use_imu = sh.use_wheel = sh.use_plane = sh.use_gnss = 0; sh.passthrough = 0;
-    if (old) {
-      for (int q = 0; q < ds.n_imu; q++) if (d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2] >= 0.0 && ds.imu_frame[q] == 0) sh.use_imu = 1 + q;
-      for (int q = 0; q < ds.n_wheel; q++) if (d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2] >= 0.0 && ds.wheel_frame[q] == 0) sh.use_wheel = 1 + q;
-      if (sh.use_imu) sh.touched[0] = sh.touched[GFBE_BLK_SB0] = sh.touched[1] = sh.touched[GFBE_BLK_SB0 + 1] = 1;
-      if (sh.use_wheel) sh.touched[0] = sh.touched[1] = sh.touched[GFBE_BLK_EX_WHEEL] = sh.touched[GFBE_BLK_SX] = sh.touched[GFBE_BLK_SY] = sh.touched[GFBE_BLK_SW] = sh.touched[GFBE_BLK_TD_WHEEL] = 1;
-      for (int j = 1; j < NF; j++)
-        if (ds.pair_begin[j + 1] > ds.pair_begin[j]) sh.touched[0] = sh.touched[j] = sh.touched[GFBE_BLK_EX_CAM] = sh.touched[GFBE_BLK_TD] = 1;
+  // which blocks do the factors of the marginalisation set touch? The look-ups (descriptor fields and cost slots in global memory:
+  // a microsecond of latency each) by different threads side by side — on one lane they were 20 us of a single window's solve; every
+  // flag is written with the same value by whoever finds it
+  if (t < GFBE_BLK_COUNT) sh.touched[t] = 0;
+  if (t == 0) { sh.use_imu = sh.use_wheel = sh.use_plane = sh.use_gnss = 0; sh.passthrough = 0; }
+  __syncthreads();
+  if (t < ds.prior_nblk) sh.touched[ds.prior_blk_id[t]] = 1;
+  if (old) {
+    if (t >= 64 && t < 64 + ds.n_imu) {            // (one factor at most starts at frame 0)
+      const int q = t - 64;
+      if (d.imu_part[((size_t)w * MAX_IMU + q) * IMU_PART + IMU_PART - 2] >= 0.0 && ds.imu_frame[q] == 0) {
+        sh.use_imu = 1 + q;
+        sh.touched[0] = sh.touched[GFBE_BLK_SB0] = sh.touched[1] = sh.touched[GFBE_BLK_SB0 + 1] = 1;
+      }
+    } else if (t >= 128 && t < 128 + ds.n_wheel) {
+      const int q = t - 128;
+      if (d.wheel_part[((size_t)w * MAX_WHEEL + q) * WHEEL_PART + WHEEL_PART - 2] >= 0.0 && ds.wheel_frame[q] == 0) {
+        sh.use_wheel = 1 + q;
+        sh.touched[0] = sh.touched[1] = sh.touched[GFBE_BLK_EX_WHEEL] = sh.touched[GFBE_BLK_SX] = sh.touched[GFBE_BLK_SY] = sh.touched[GFBE_BLK_SW] = sh.touched[GFBE_BLK_TD_WHEEL] = 1;
+      }
+    } else if (t >= 192 && t < 192 + NF - 1) {
+      const int j = t - 191;
+      if (ds.pair_begin[j + 1] > ds.pair_begin[j]) sh.touched[0] = sh.touched[j] = sh.touched[GFBE_BLK_EX_CAM] = sh.touched[GFBE_BLK_TD] = 1;
+    } else if (t == 224) {
       if (ds.n_plane > 0 && d.plane_part[(size_t)w * MAX_PLANE * PLANE_PART + PLANE_PART - 2] >= 0.0) {   // estimator.cpp:3441-3448
         sh.use_plane = 1;
         sh.touched[0] = sh.touched[GFBE_BLK_EX_WHEEL] = sh.touched[GFBE_BLK_PLANE_R] = sh.touched[GFBE_BLK_PLANE_Z] = 1;
       }
+    } else if (t == 225) {
       if (ds.gnss_ready) {   // estimator.cpp:3459-3496: the GNSS factors of frame 0 (k_gnss mode 2), whether the window was slow or not
         sh.use_gnss = 1;
         if (ds.gnss_frame_begin[1] > 0)
@@ -251,6 +265,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
         sh.touched[GFBE_BLK_RCV_DDT0] = sh.touched[GFBE_BLK_RCV_DDT0 + 1] = 1;
       }
     }
+  }
+  __syncthreads();
+  if (t == 0) {
     int m = 0;
     if (old) {
       if (sh.touched[0]) for (int k = 0; k < 6; k++) sh.drop_dim[m++] = k;
@@ -440,7 +457,13 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
   MSTAMP(3);
   // T = A_rm * Pinv (n x m) kept in J0's storage; then A' and b' (compact, n x n) into r0/J0 staging
-  double *T = J0;   // n x ms
+  // T and the dropped rows of A through LDS when they fit the block that is free until A' is square-rooted (the 86-dim prior:
+  // 2.7k doubles): A' = A_rr - T A_mr then reads its 2 m operands per entry from LDS instead of L2 (33 -> ~12 us for one window;
+  // the same products in the same order)
+  const bool tl = m <= 16 && n <= 128;
+  double *T = tl ? marg_lds : J0;   // n x ms
+  double *Amr = marg_lds + 128 * 16;   // [m][n] (tl only)
+  if (tl) for (int e = t; e < m * n; e += blockDim.x) { const int k = e / n, j = e - k * n; Amr[e] = A[(size_t)sh.drop_dim[k] * ND + sh.keep_dim[j]]; }
   for (int e = t; e < n * m; e += blockDim.x) {
     const int i = e / m, j = e % m;
     double s = 0.0;
@@ -452,7 +475,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   for (int e = t; e < n * n; e += blockDim.x) {
     const int i = e / n, j = e % n;
     double s = A[(size_t)sh.keep_dim[i] * ND + sh.keep_dim[j]];
-    for (int k = 0; k < m; k++) s -= T[i * ms + k] * A[(size_t)sh.drop_dim[k] * ND + sh.keep_dim[j]];
+    if (tl) { for (int k = 0; k < m; k++) s -= T[i * ms + k] * Amr[k * n + j]; }
+    else for (int k = 0; k < m; k++) s -= T[i * ms + k] * A[(size_t)sh.drop_dim[k] * ND + sh.keep_dim[j]];
     Ap[(size_t)i * n + j] = s;
   }
   for (int i = t; i < n; i += blockDim.x) {
