@@ -63,6 +63,17 @@ for i in range(N):
         pc = np.zeros(abi.NFRAMES, np.uint8)
         pc[0] = 1
         snap["pose_const"] = pc
+    # GNSS inside the window (round 3): observations of 3..12 satellites per frame from the scenario's true trajectory; one in five of
+    # those windows too slow for the GNSS residual blocks (the lowspeed gate), whose frame-0 factors are still marginalised
+    gnss = wheel and (not partial) and (not gimbal) and rng.random() < 0.25
+    slow = gnss and rng.random() < 0.2
+    if gnss:
+        import gnss_window_cases as gw
+        tru = gw.GnssTruth(scn, 1000 + i, n_per_frame=int(rng.integers(3, 13)), lat=float(rng.uniform(-60, 60)), lon=float(rng.uniform(-180, 180)))
+        snap["gnss"], snap["gnss_state"] = tru.block(k0), tru.state(k0, 1000 + i)
+        if slow:
+            snap["speed_bias"] = np.array(snap["speed_bias"], float).copy()
+            snap["speed_bias"][:, :2] *= 0.2
     retry = int(rng.integers(1, 5)) if rng.random() < 0.15 else 0
     if retry:      # gfbe_options.test_fail_chol_iter (test hook) on both sides
         oo = abi.default_options()
@@ -73,10 +84,11 @@ for i in range(N):
     else:
         want, got = orc.solve(snap, flag), be.solve(snap, flag)
     sw, sg = want["summary"], got["summary"]
-    tag = "L=%d wheel=%d prior=%d lidar=%d rgbd=%d flag=%d partial=%d free=%d gimbal=%d noimu=%d retry=%d" % (
-        L, wheel, with_prior, lidar, rgbd, flag, partial, free_all, gimbal, no_imu, retry)
-    counts = globals().setdefault("counts", dict(free=0, gimbal=0, noimu=0, retry=0))
+    tag = "L=%d wheel=%d prior=%d lidar=%d rgbd=%d flag=%d partial=%d free=%d gimbal=%d noimu=%d retry=%d gnss=%d slow=%d" % (
+        L, wheel, with_prior, lidar, rgbd, flag, partial, free_all, gimbal, no_imu, retry, gnss, slow)
+    counts = globals().setdefault("counts", dict(free=0, gimbal=0, noimu=0, retry=0, gnss=0, gnss_slow=0))
     counts["free"] += free_all; counts["gimbal"] += gimbal; counts["noimu"] += no_imu; counts["retry"] += retry > 0
+    counts["gnss"] += gnss; counts["gnss_slow"] += slow
     if (sw["iterations"], sw["accepted"], sw["termination"]) != (sg["iterations"], sg["accepted"], sg["termination"]):
         bad.append((i, tag, sw["iterations"], sg["iterations"], sw["accepted"], sg["accepted"]))
         continue
@@ -91,8 +103,8 @@ for i in range(N):
     if dev > 1e-6:
         print("  window %d: final cost %.3e rel off (%s; iterations %d, accepted %s, termination %d)" % (i, dev, tag, sw["iterations"], sw["accepted"], sw["termination"]))
     rare = free_all or gimbal or no_imu or retry
-    key = "rare" if rare else "std"
-    wr = globals().setdefault("worst_by", dict(rare=0.0, std=0.0))
+    key = "gnss" if gnss else ("rare" if rare else "std")
+    wr = globals().setdefault("worst_by", dict(rare=0.0, std=0.0, gnss=0.0))
     wr[key] = max(wr[key], dev)
     worst["cost"] = max(worst["cost"], dev)
     worst["ate"] = max(worst["ate"], np.sqrt(((got["state"]["pose"][:, :3] - want["state"]["pose"][:, :3]) ** 2).sum(axis=1).mean()))
@@ -105,7 +117,7 @@ for i in range(N):
         A, Ag = want["prior"]["J0"].T @ want["prior"]["J0"], got["prior"]["J0"].T @ got["prior"]["J0"]
         worst["prior"] = max(worst["prior"], np.abs(A - Ag).max() / np.abs(A).max())
 print("%d random windows in %.0f s; discrete outcome differs in %d" % (N, time.time() - t0, len(bad)))
-print("rare branches drawn:", counts, "; largest final-cost deviation: standard windows %.2e, rare-branch windows %.2e" % (worst_by["std"], worst_by["rare"]))
+print("rare branches drawn:", counts, "; largest final-cost deviation: standard windows %.2e, rare-branch windows %.2e, GNSS windows %.2e" % (worst_by["std"], worst_by["rare"], worst_by["gnss"]))
 for b in bad:
     print("  DIFFERS:", b)
 if "worst_gimbal" in globals():

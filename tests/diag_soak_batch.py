@@ -1,5 +1,6 @@
-"""Soak of the batch paths: N random windows (as in diag_soak.py) solved (a) one by one, (b) in one batch of N (two halves,
-second-stream dense factors, one-workgroup k_visblock) and (c) in batches of 7 — every output must be bit-identical."""
+"""Soak of the batch paths: N random windows (as in diag_soak.py) solved (a) one by one, (b) in batches of 7, (c) in one batch of N
+and (d) in batches of 40: (a) == (b) and (c) == (d) bit for bit; (a) vs (c) — the small-batch and the throughput kernel set — at
+tolerance with identical discrete outcomes."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
@@ -32,32 +33,27 @@ def same(a, b):
     if (a["prior"] is None) != (b["prior"] is None):
         return False
     return a["prior"] is None or all(np.array_equal(a["prior"][k], b["prior"][k]) for k in ("J0", "r0", "x0", "block_id"))
+def deviation(a, b):
+    sa, sb = a["summary"], b["summary"]
+    if (sa["iterations"], sa["accepted"], sa["termination"]) != (sb["iterations"], sb["accepted"], sb["termination"]):
+        return None
+    return max(abs(sb["final_cost"] / sa["final_cost"] - 1), np.abs(a["state"]["pose"] - b["state"]["pose"]).max())
+# The guarantees since round 3: a window is bit-reproducible and independent of its neighbours inside each
+# kernel set — small batches (< 32 windows: single solves == batches of 7) and throughput batches (one batch of N == batches of 40) —
+# and the two sets agree at tolerance (k_schur sums a window's landmark tiles in 4 start-frame groups instead of 22).
 for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
     t0 = time.time()
     single = [be.solve(s, flag) for s in snaps]
     big = be.solve_batch(snaps, flag)
-    small = []
+    small, mid = [], []
     for k in range(0, N, 7):
         small += be.solve_batch(snaps[k:k + 7], flag)
-    bad_big = [i for i in range(N) if not same(single[i], big[i])]
+    for k in range(0, N, 40):
+        chunk = snaps[k:k + 40]
+        mid += be.solve_batch(chunk, flag) if len(chunk) >= 32 else [None] * len(chunk)
     bad_small = [i for i in range(N) if not same(single[i], small[i])]
-    print("flag %d: %d windows, %.0f s: batch of %d differs from single solves in %d windows, batches of 7 in %d" % (flag, N, time.time() - t0, N, len(bad_big), len(bad_small)), bad_big[:5], bad_small[:5])
-
-# ---- which windows differ, and by how much
-flag = abi.MARGIN_OLD
-single = [be.solve(s, flag) for s in snaps]
-for B in (40,):
-    got = []
-    for k in range(0, N, B):
-        got += be.solve_batch(snaps[k:k + B], flag) if len(snaps[k:k + B]) >= 32 else [None] * len(snaps[k:k + B])
-    rows = []
-    for i in range(N):
-        if got[i] is None:
-            continue
-        d = not same(single[i], got[i])
-        s = snaps[i]
-        rows.append((d, len(s.get("wheel", [])) > 0, s.get("prior") is not None, "lio" in s, "feature_const" in s,
-                     np.abs(single[i]["state"]["pose"] - got[i]["state"]["pose"]).max()))
-    rows = np.array(rows, dtype=float)
-    print("batches of %d: %d of %d differ; among differing: wheel %.2f prior %.2f lio %.2f const %.2f; among identical: wheel %.2f prior %.2f lio %.2f const %.2f; max |dpose| %.1e"
-          % (B, int(rows[:, 0].sum()), len(rows), *rows[rows[:, 0] == 1][:, 1:5].mean(axis=0), *rows[rows[:, 0] == 0][:, 1:5].mean(axis=0), rows[:, 5].max()))
+    bad_mid = [i for i in range(N) if mid[i] is not None and not same(big[i], mid[i])]
+    devs = [deviation(single[i], big[i]) for i in range(N)]
+    print("flag %d: %d windows, %.0f s: batches of 7 differ from single solves in %d windows; batches of 40 differ from the batch of %d in %d windows; "
+          "single vs throughput kernel set: discrete outcome differs in %d, largest deviation (final cost rel / pose abs) %.2e"
+          % (flag, N, time.time() - t0, len(bad_small), N, len(bad_mid), sum(d is None for d in devs), max(d for d in devs if d is not None)), bad_small[:5], bad_mid[:5])
