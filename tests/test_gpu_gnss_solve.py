@@ -105,3 +105,29 @@ def test_gnss_windows_in_a_batch(be, oracle):
         check_prior(want["prior"], got["prior"], loose=PRIOR_LOOSE if "gnss" in snap else 1.0)
         assert got["summary"]["cost_history"] == runs[1][k]["summary"]["cost_history"]
         assert np.array_equal(got["state"]["pose"], runs[1][k]["state"]["pose"]) and np.array_equal(got["prior"]["J0"], runs[1][k]["prior"]["J0"])
+
+
+def test_gnss_windows_in_a_throughput_batch(be, oracle):
+    """34 windows (>= 32: the throughput kernel set — k_visasm, k_candidate_window, the dense factors on the side stream) of which
+    every third carries GNSS: each window as the small-batch path solves it alone (tolerance: the two kernel sets sum the Schur
+    partials in different groups), the GNSS state included, and the batch bit-identical from run to run."""
+    kinds = [gw.gnss_window(seed=95, L=100, n_per_frame=5)[2], synth.Scenario(seed=96, n_landmarks=120, use_wheel=True).window(0),
+             gw.gnss_window(seed=97, L=80, n_per_frame=9, anchor=True)[2]]
+    snaps = [kinds[i % 3] for i in range(34)]
+    runs = []
+    for _ in range(2):
+        batch = be.batch_upload(snaps)
+        batch.solve(abi.MARGIN_OLD)
+        runs.append(batch.download())
+        batch.free()
+    alone = [be.solve(k, abi.MARGIN_OLD) for k in kinds]
+    for i, got in enumerate(runs[0]):
+        want = alone[i % 3]
+        assert got["summary"]["accepted"] == want["summary"]["accepted"] and got["summary"]["iterations"] == want["summary"]["iterations"]
+        np.testing.assert_allclose(got["summary"]["cost_history"], want["summary"]["cost_history"], rtol=1e-7)
+        assert np.abs(got["state"]["pose"] - want["state"]["pose"]).max() < 1e-8
+        if "gnss" in snaps[i]:
+            check_gnss_state(want, got)
+        assert got["prior"]["block_id"].tolist() == want["prior"]["block_id"].tolist()
+        assert got["summary"]["cost_history"] == runs[1][i]["summary"]["cost_history"] and np.array_equal(got["prior"]["J0"], runs[1][i]["prior"]["J0"])
+        assert got["summary"]["cost_history"] == runs[0][i % 3]["summary"]["cost_history"]        # (independent of the slot inside the batch)
