@@ -630,7 +630,10 @@ gfbe_status gfbe_debug_vector(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, int32
  * all-reduce (RCCL) on that stream and returns 0, or a non-zero code: the solve that enqueued the call then returns
  * GFBE_DEVICE_ERROR with the code in gfbe_last_error — un-reduced partial sums are never handed back as a result.
  * A hook installed with world_size 1 still runs the sharded launch sequence (every all-reduce is then the identity): that is
- * how a single-GPU box exercises the whole path. fn == NULL switches the sharding off. */
+ * how a single-GPU box exercises the whole path. fn == NULL switches the sharding off.
+ * Limits of the sharded mode: no solver time cap (max_solver_time_in_seconds is refused: the ranks' clocks would stop them at
+ * different iterations), no device-resident feature tables, and ONE mu retry per linearisation — a factorisation that fails
+ * again at the larger mu ends the window with GFBE_NUMERICAL_FAILURE, where the unsharded solve keeps raising mu up to max_mu. */
 typedef int32_t (*gfbe_allreduce_fn)(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);
 gfbe_status gfbe_set_allreduce(gfbe_ctx *ctx, gfbe_allreduce_fn fn, void *user, int32_t rank,
                                int32_t world_size);

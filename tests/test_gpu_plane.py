@@ -49,11 +49,13 @@ def test_plane_in_solve_and_marginalisation(be, oracle, anchor):
     assert abi.BLK_PLANE_R in got["prior"]["block_id"].tolist()
     check_prior(want["prior"], got["prior"])
     # the next window: the prior carries the 4-wide plane block; rejected steps make it an unsettled run that stops on the
-    # iteration cap while the cost still moves in its seventh digit: two factorisations that differ in the last bit (the
-    # register-resident tile step vs the earlier LDS one: 1.9e-5 and 2.7e-5 from the oracle) end 1e-7 apart (tolerances x 300)
+    # iteration cap while the cost still moves (193.69 -> 193.28 in its last iteration, still creeping after 15): measured
+    # against the oracle with the round-3 kernels 1.9e-8 relative in the final cost and 1.6e-8 m in the poses (6e-9 / 1.5e-8
+    # with 12 or 15 iterations, scratch/plane_settle.py) — tolerances x 50 (x 300 in round 2); the accept / reject sequence,
+    # which check_solve compares exactly, and the settled first window at the plain tolerances are the tighter gates
     snap2 = next_plane_window(scn, snap, want)
     for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
-        want2, got2 = check_solve(be, oracle, snap2, flag, loose=300.0)
+        want2, got2 = check_solve(be, oracle, snap2, flag, loose=50.0)
         check_prior(want2["prior"], got2["prior"], loose=10.0)     # (linearised at states 1e-7 apart)
 
 
