@@ -215,7 +215,7 @@ struct BatchDev {
   double *imu_sqrt, *wheel_sqrt;     // [n][225], [n][36]
   double *prior_J0, *prior_r0, *prior_x0, *prior_H;   // [B][ND*ND], [B][ND], [B][PRIOR_X0], [B][ND*ND]
   // partial results
-  double *pair_part;          // [B][NPAIR][VP_STRIDE]   X^T X per pose pair (sum of vis_part over the tiles of the start frame)
+  double *pair_part;          // [B][NF][VP_STRIDE]   marginalisation: X^T X of the pose pairs (0, j), slot j (sum of vis_part over the tiles of start frame 0)
   double *vis_part;           // [B][max_tiles][MAXOBS][VP_STRIDE]  X^T X of the 64 factors of one tile at one step, X = [J | r]
   double *schur_part;         // [B][schur_groups][SCHUR_STRIDE]  sum over the landmarks of one group of start frames
   int schur_groups;           // SCHUR_GROUPS for throughput batches; small batches: 2 NF (two workgroups per start frame), NF when sharded

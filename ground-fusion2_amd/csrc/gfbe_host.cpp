@@ -782,7 +782,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
     AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
     AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36);
-    AL(pair_part, (size_t)B * NPAIR * VP_STRIDE); AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); AL(schur_part, (size_t)B * d.schur_groups * SCHUR_STRIDE);
+    AL(pair_part, (size_t)B * NF * VP_STRIDE); AL(schur_part, (size_t)B * d.schur_groups * SCHUR_STRIDE);
     AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
     AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
     AL(prior_g, (size_t)B * (ND + 2));
@@ -799,6 +799,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(prior_J0, (size_t)B * ND * ND);     // (the n x n prior block arrives by copy; nothing reads past it)
+    AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE);   // (a tile's steps below its longest track are written by k_vis, the others never read)
     AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);   // (k_marg / k_marg_ldlt write what they and k_gather read)
     AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)
     AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);                   // (written by the kernels that produce a state)
@@ -1221,7 +1222,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     if (d.sharded && margin_flag == GFBE_MARGIN_OLD) {
       // the partials of the landmarks that start in frame 0 are summed over the ranks before k_marg reads them
       launch_marginalize_partials(d, ln.s);
-      run_allreduce(c, d.pair_part, (int64_t)d.B * NPAIR * VP_STRIDE, ln.s);
+      run_allreduce(c, d.pair_part, (int64_t)d.B * NF * VP_STRIDE, ln.s);
       run_allreduce(c, d.schur_part, (int64_t)d.B * d.schur_groups * SCHUR_STRIDE, ln.s);
       launch_marginalize_finish(d, margin_flag, ln.s);
     } else {

@@ -612,8 +612,11 @@ __global__ __launch_bounds__(VP_STRIDE) void k_pairsum(BatchDev d, int marg) {
   if (ds.pair_begin[p + 1] == ds.pair_begin[p]) return;   // no factor on this pose pair: block stays zero
   const double *vp = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VP_STRIDE + (size_t)(j - i - 1) * VP_STRIDE + threadIdx.x;
   double s = 0.0;
-  for (int t = ds.sf_tile_begin[i]; t < ds.sf_tile_begin[i + 1]; t++) s += vp[(size_t)t * MAXOBS * VP_STRIDE];
-  d.pair_part[((size_t)w * NPAIR + p) * VP_STRIDE + threadIdx.x] = s;
+  for (int t = ds.sf_tile_begin[i]; t < ds.sf_tile_begin[i + 1]; t++) {
+    if (((d.lm_info[ds.lm_off + t * LM_TILE] >> 8) & 0xff) <= j - i - 1) break;   // tiles are sorted longest first: the others never ran this step (vis_part is not cleared)
+    if (TILE_OWNED(d, t)) s += vp[(size_t)t * MAXOBS * VP_STRIDE];                // (landmark sharding: this rank's tiles)
+  }
+  if (marg) d.pair_part[((size_t)w * NF + j) * VP_STRIDE + threadIdx.x] = s;     // (only the marginalisation keeps per-pair sums: pairs (0, j), slot j)
 }
 
 // =============================================================================================
@@ -1255,11 +1258,16 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
           for (int tt = t0 + gsel; tt < t1; tt += 4) {
             const double *q0 = vp + (size_t)tt * MAXOBS * VP_STRIDE, *q1 = q0 + (size_t)2 * MAXOBS * VP_STRIDE;
             const bool two = tt + 2 < t1;
+            // k_vis runs (and writes) the steps below the tile's longest track — its first landmark: a start-frame group is sorted
+            // longest first — and nothing else of vis_part is ever read: the array is not cleared at upload
+            // (landmark sharding: the tiles of the other ranks were not evaluated here)
+            const int m0 = TILE_OWNED(d, tt) ? (d.lm_info[ds.lm_off + tt * LM_TILE] >> 8) & 0xff : 0;
+            const int m1 = (two && TILE_OWNED(d, tt + 2)) ? (d.lm_info[ds.lm_off + (tt + 2) * LM_TILE] >> 8) & 0xff : 0;
             double v0[MAXOBS], v1[MAXOBS];
 #pragma unroll
-            for (int k = 0; k < MAXOBS; k++) {   // steps a tile never runs stay zero in vis_part
-              v0[k] = *(k < nk ? q0 + k * VP_STRIDE : Z);
-              v1[k] = *((two && k < nk) ? q1 + k * VP_STRIDE : Z);
+            for (int k = 0; k < MAXOBS; k++) {
+              v0[k] = *(k < m0 ? q0 + k * VP_STRIDE : Z);
+              v1[k] = *(k < m1 ? q1 + k * VP_STRIDE : Z);
             }
 #pragma unroll
             for (int k = 0; k < MAXOBS; k++) { s[k] += v0[k]; s[k] += v1[k]; }

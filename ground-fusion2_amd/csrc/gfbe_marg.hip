@@ -314,7 +314,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const int n = sh.n, m = sh.m;
   MSTAMP(1);
   // ---- full A (ND x ND, landmark block already eliminated) and b over all tangent dims
-  const double *pp = d.pair_part + (size_t)w * NPAIR * VP_STRIDE;   // pairs (0, j): index j
+  const double *pp = d.pair_part + (size_t)w * NF * VP_STRIDE;   // pairs (0, j): index j
   const double *sp = d.schur_part + (size_t)w * d.schur_groups * SCHUR_STRIDE;   // start frame 0 partial (slot 0: 15 dense 16x16 tiles)
   const double *ipart = sh.use_imu ? d.imu_part + ((size_t)w * MAX_IMU + sh.use_imu - 1) * IMU_PART : nullptr;
   const double *wpart = sh.use_wheel ? d.wheel_part + ((size_t)w * MAX_WHEEL + sh.use_wheel - 1) * WHEEL_PART : nullptr;
