@@ -15,15 +15,6 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "cholstamp": (["-DGFBE_CHOL_STAMP=1"], "off"),
     "chainstamp": (["-DGFBE_CHAIN_STAMP=1"], "off"),
     "bigstamp": (["-DGFBE_BIG_STAMP=1"], "off"),
-    "marg512": (["-DMARG_THREADS=512"], "off"),
-    "marg256": (["-DMARG_THREADS=256"], "off"),
-    "asmw1": (["-DASM_WGS=1"], "off"),
-    "asmw1t512": (["-DASM_WGS=1", "-DASM_THREADS=512"], "off"),
-    "asmw1t1024": (["-DASM_WGS=1", "-DASM_THREADS=1024"], "off"),
-    "asmw2t512": (["-DASM_WGS=2", "-DASM_THREADS=512"], "off"),
-    "asmw2": (["-DASM_WGS=2"], "off"),
-    "asmw4": (["-DASM_WGS=4"], "off"),
-    "asmw8": (["-DASM_WGS=8"], "off"),
     "ks5": (["-DGFBE_LIN_SMALL_KS=5"], "off"),
     "ks10": (["-DGFBE_LIN_SMALL_KS=10"], "off"),
     "asm32": (["-DGFBE_ASM_WGS_SMALL=32"], "off"),
