@@ -1851,7 +1851,7 @@ __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
     Y[A_EXW + 3] = q.x; Y[A_EXW + 4] = q.y; Y[A_EXW + 5] = q.z; Y[A_EXW + 6] = q.w;
   } else if (t == NF + 2) {   // estimator.cpp:3383-3386: para_yaw_enu_local back into (-pi, pi]
     double yaw = X[A_YAW];
-    if (isfinite(yaw)) {
+    if (isfinite(yaw) && fabs(yaw) < 1e6) {   // (the reference's loops would not terminate on a non-finite or absurd value: left alone)
       while (yaw > 3.14159265358979323846) yaw -= 2.0 * 3.14159265358979323846;
       while (yaw < -3.14159265358979323846) yaw += 2.0 * 3.14159265358979323846;
     }

@@ -949,7 +949,7 @@ int32_t gfo_solve_window(const gfbe_options *opt, const gfbe_window *w, int32_t 
   Solution sol;
   solve(P, sol);
   if (sol.sum.status == GFBE_NUMERICAL_FAILURE) { if (summary) *summary = sol.sum; return GFBE_NUMERICAL_FAILURE; }
-  if (std::isfinite(sol.x.gnss.yaw_enu_local)) {                                         // estimator.cpp:3383-3386
+  if (std::isfinite(sol.x.gnss.yaw_enu_local) && std::fabs(sol.x.gnss.yaw_enu_local) < 1e6) {   // estimator.cpp:3383-3386 (absurd values left alone)
     while (sol.x.gnss.yaw_enu_local > M_PI) sol.x.gnss.yaw_enu_local -= 2.0 * M_PI;
     while (sol.x.gnss.yaw_enu_local < -M_PI) sol.x.gnss.yaw_enu_local += 2.0 * M_PI;
   }
