@@ -17,6 +17,14 @@
 #define GFBE_ASM_WGS_SMALL 64   // k_assemble, small batches: workgroups per window (16 -> 64: 1.518 -> 1.497 ms per single-window solve)
 #endif
 
+// Small batches (< 32 windows, no landmark sharding): launches of one iteration merged on a single window's latency path. Bit 0:
+// k_schur + k_visblock_small in one launch; bit 1: k_step and the dense half of k_candidate by the workgroup of k_lm_step that
+// finishes last, the landmark half of k_candidate by k_lin_small<1>'s tile workgroups; bit 2: k_accept by the workgroup of
+// k_lin_small<1> that finishes last. Same code, same order of every sum: the results do not change by a bit.
+#ifndef GFBE_FUSE_SMALL
+#define GFBE_FUSE_SMALL 7
+#endif
+
 namespace gfd {
 
 // ---- dimensions -----------------------------------------------------------------------------
@@ -239,6 +247,7 @@ struct BatchDev {
   double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
   double *vis_contrib;        // [B][max_tiles][MAXOBS][16][64] small batches: per-step contributions to Hll, gl, hC, cost (k_lin_small)
   int *tile_cnt;              // [B][max_tiles]   arrival counter of the tile's LIN_SMALL_KS workgroups (zero between launches)
+  int *win_cnt;               // [B][2]           arrival counters of a window's k_lm_step / k_lin_small<1> workgroups (GFBE_FUSE_SMALL; zero between launches)
   double *tile_cand;          // [B][max_tiles][4] candidate: cost, |x-xc|^2, |xc|^2, pad
   double *tile_gram;          // [B][max_tiles][8] landmark parts of G2 N2 gy vHv vHy yHy gradmax
   double *dense_cand;         // [B][4] dense-factor candidate cost, |x-xc|^2, |xc|^2
@@ -300,9 +309,9 @@ void launch_reset(const BatchDev &d, hipStream_t s);
 // mode 1: candidate cost only   mode 2: linearise the marginalisation set at xout (start frame 0 only)
 void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records = 0);
 void launch_pair(const BatchDev &d, int marg, hipStream_t s);
-void launch_lin_small(const BatchDev &d, int mode, hipStream_t s);
+void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse = 0);   // fuse (mode 1): bit 1 candidate tiles first, bit 2 k_accept last
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
-void launch_schur(const BatchDev &d, int marg, hipStream_t s);
+void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock = 0);   // with_visblock: k_schur_visblock_small
 void launch_visblock(const BatchDev &d, hipStream_t s);
 void launch_lio_window(const BatchDev &d, int mode, hipStream_t s);
 void launch_assemble(const BatchDev &d, hipStream_t s);
@@ -323,7 +332,7 @@ size_t solve_chain_scratch_doubles();              // doubles of BatchDev::solve
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s);
 void launch_sys_pack(const BatchDev &d, int dir, hipStream_t s);   // landmark sharding: pack (0) / unpack (1) the partial system around its all-reduce
 size_t sys_pack_doubles_host(int nu, int world);
-void launch_lm_step(const BatchDev &d, hipStream_t s);
+void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse = 0);   // fuse: k_step + the dense blocks of k_candidate by the last workgroup of a window
 void launch_step(const BatchDev &d, hipStream_t s);
 void launch_candidate(const BatchDev &d, hipStream_t s);
 void launch_accept(const BatchDev &d, hipStream_t s);

@@ -788,6 +788,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(prior_g, (size_t)B * (ND + 2));
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
     AL(tile_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) : 1);
+    AL(win_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * 2 : 1);
     AL(tile_gram, (size_t)B * std::max(max_tiles, 1) * 8); AL(dense_cand, (size_t)B * 4);
     AL(xb, (size_t)B * d.world * XCHG); AL(xc, (size_t)B * d.world * XCHG);
     if (d.sharded) { AL(Er, (size_t)B * (NV * NV + NV)); AL(sys_pack, (size_t)B * sys_pack_doubles_host(d.nu, d.world)); } else { d.Er = nullptr; d.sys_pack = nullptr; }
@@ -1139,6 +1140,15 @@ static void run_allreduce(gfbe_ctx *c, double *ptr, int64_t n, hipStream_t s) {
   if (rc != 0 && c->allreduce_rc == 0) c->allreduce_rc = rc;
 }
 
+// GFBE_FUSE_SMALL (gfbe_device.h): which launches of an iteration are merged for this batch. Small batches on the latency path only:
+// not while profiling (per-kernel events), not with an all-reduce hook, not without landmarks (k_lm_step is not launched then).
+static int small_fuse(const gfbe_ctx *c, const BatchDev &d) {
+  if (c->profiling || d.B >= DENSE_SPLIT_MIN_B || !d.vis_Hs || d.sharded || d.max_tiles == 0) return 0;
+  int f = GFBE_FUSE_SMALL;
+  if (d.any_gnss || d.tot_lio > 0) f &= ~4;     // (their candidate costs are launches of their own between k_lin_small<1> and k_accept)
+  return f;
+}
+
 // One linearisation of the whole batch at the current parameters (skipped on device for windows
 // that only need a new radius).
 static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool first) {
@@ -1159,8 +1169,9 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
   }
   if (d.tot_lio > 0) { Timed t(c, "k_lio_window", 0); launch_lio_window(d, 0, ln.s); }
-  { Timed t(c, first ? "k_schur_iter0" : "k_schur", 0); launch_schur(d, 0, ln.s); }
-  if (d.vis_Hs) { Timed t(c, first ? "k_visblock_iter0" : "k_visblock", 0); launch_visblock(d, ln.s); }   // (throughput batches: inside k_visasm, below)
+  const int fuse = small_fuse(c, d);
+  { Timed t(c, first ? "k_schur_iter0" : "k_schur", 0); launch_schur(d, 0, ln.s, fuse & 1); }
+  if (d.vis_Hs && !(fuse & 1)) { Timed t(c, first ? "k_visblock_iter0" : "k_visblock", 0); launch_visblock(d, ln.s); }   // (throughput batches: inside k_visasm, below)
   if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);   // join
   { Timed t(c, first ? "k_assemble_iter0" : "k_assemble", 0); launch_assemble(d, ln.s); }
   if (d.any_gnss) { Timed t(c, "k_gnss", 0); launch_gnss(d, 0, ln.s); }
@@ -1179,7 +1190,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     run_allreduce(c, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);
     launch_solve(d, ln.s, 1);
   }
-  { Timed t(c, first ? "k_lm_step_iter0" : "k_lm_step", 0); launch_lm_step(d, ln.s); }
+  { Timed t(c, first ? "k_lm_step_iter0" : "k_lm_step", 0); launch_lm_step(d, ln.s, fuse & 2); }
   if (d.sharded) {
     Timed t(c, "allreduce_scalars", 0);
     launch_xchg_gram(d, ln.s);
@@ -1193,8 +1204,11 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
   const int iters = std::min(c->opt.max_num_iterations, 15);
   for (int it = 0; it < iters; it++) {
     enqueue_linearize(c, b, ln, it == 0);
-    { Timed t(c, "k_step", 0); launch_step(d, ln.s); }
-    { Timed t(c, "k_candidate", 0); launch_candidate(d, ln.s); }
+    const int fuse = small_fuse(c, d);
+    if (!(fuse & 2)) {
+      { Timed t(c, "k_step", 0); launch_step(d, ln.s); }
+      { Timed t(c, "k_candidate", 0); launch_candidate(d, ln.s); }
+    }
     const bool overlap = !c->profiling && ln.aux && d.B >= DENSE_SPLIT_MIN_B;
     if (overlap) {
       (void)hipEventRecord(ln.fork, ln.s);
@@ -1203,7 +1217,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       (void)hipEventRecord(ln.join, ln.aux);
     }
     const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;
-    if (small) launch_lin_small(d, 1, ln.s);
+    if (small) launch_lin_small(d, 1, ln.s, fuse);
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
     if (d.any_gnss) { Timed t(c, "k_gnss_cost", 0); launch_gnss(d, 1, ln.s); }
@@ -1214,7 +1228,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       launch_xchg_cand(d, ln.s);
       run_allreduce(c, d.xc, (int64_t)d.B * d.world * XCHG, ln.s);
     }
-    { Timed t(c, "k_accept", 0); launch_accept(d, ln.s); }
+    if (!(fuse & 4)) { Timed t(c, "k_accept", 0); launch_accept(d, ln.s); }
   }
   { Timed t(c, "k_reanchor", 0); launch_reanchor(d, ln.s); }
   if (margin_flag != GFBE_MARGIN_NONE) {

@@ -844,14 +844,36 @@ __global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mod
 // Small batches (one window per camera frame is the reference's call pattern): the visual tiles and the inertial / wheel /
 // prior factors of a linearisation (MODE 0) or of a candidate evaluation (MODE 1) in ONE launch — the ~35 us of a single
 // lane evaluating an IMU factor hide behind the visual tiles instead of following them on the stream.
+__device__ __forceinline__ void candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
+__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane);
+__device__ __forceinline__ bool arrive_last(int *cnt, const int expected, const int lane);
+// fuse (MODE 1, GFBE_FUSE_SMALL): bit 1 — a tile workgroup first forms the candidate inverse depths of its tile (the landmark half of
+// k_candidate; the dense half ran at the tail of k_lm_step_fused); bit 2 — the workgroup of a window that finishes last goes on with
+// k_accept.
 template <int MODE, bool FULL>
-__global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d) {
+__global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, int fuse) {
   const int w = blockIdx.x, y = blockIdx.y;
   constexpr int KS = MODE == 0 ? LIN_SMALL_KS : 1;      // (the cost-only pass is too short to gain: 9 -> 12 us when split)
   // four waves per workgroup: a visual tile is one wave's work (the others leave at once); the inertial / wheel / prior items use
   // all four — the single lane that evaluated an IMU factor was the longest chain of the launch
-  if (y < d.max_tiles * KS) { if (threadIdx.x < LM_TILE) vis_body<MODE, FULL, KS>(d, 0, w, y / KS, y % KS); }
-  else dense_body<true>(d, MODE, 0, w, y - d.max_tiles * KS);
+  const bool tile_wg = y < d.max_tiles * KS;
+  if (tile_wg) {
+    if (threadIdx.x >= LM_TILE) return;
+    if (MODE == 1 && (fuse & 2)) {
+      const WinDesc &ds = d.desc[w];
+      const WinCtl &c = d.ctl[w];
+      if (y < ds.n_tiles && TILE_OWNED(d, y) && !c.done && c.have_step) candidate_tile(d, ds, c, w, y, threadIdx.x);
+    }
+    vis_body<MODE, FULL, KS>(d, 0, w, y / KS, y % KS);
+  } else {
+    dense_body<true>(d, MODE, 0, w, y - d.max_tiles * KS);
+  }
+  if (MODE == 1 && (fuse & 4)) {
+    // (a factor's four waves are done with their stores before the workgroup arrives — dense_body leaves workgroup-uniformly —; its first wave goes on)
+    if (!tile_wg) { __syncthreads(); if (threadIdx.x >= 64) return; }
+    if (!arrive_last(d.win_cnt + 2 * w + 1, gridDim.y, threadIdx.x)) return;
+    accept_body(d, w, threadIdx.x);
+  }
 }
 
 // =============================================================================================
@@ -878,8 +900,7 @@ __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I 
 // (the groups follow the tile rows a start frame's landmarks can reach — I0 = 6 s / 16 steps at s = 3 and s = 6 — so that no group
 //  multiplies tile pairs its later start frames do not touch; work ~ tiles x pairs: {0,1} 30, {2} 15, {3,4,5} 30, {6..10} 12)
 __device__ __forceinline__ int schur_group_first(int g, int ng) { return ng >= NF ? g : (g == 0 ? 0 : (g == 1 ? 2 : (g == 2 ? 3 : 6))); }
-__global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
-  const int w = blockIdx.x, grp = blockIdx.y;   // group-major dispatch: the heavy first group of every window first
+__device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, const int w, const int grp) {
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (!marg && (c.done || c.reuse)) return;
@@ -1025,6 +1046,9 @@ __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   SCHUR_OUT(2, acc2)
   SCHUR_OUT(3, acc3)
 #undef SCHUR_OUT
+}
+__global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
+  schur_body(d, marg, blockIdx.x, blockIdx.y);   // group-major dispatch: the heavy first group of every window first
 }
 
 // =============================================================================================
@@ -1331,6 +1355,20 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
 __global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d) {
   __shared__ double V[NV * V_LD];
   visblock_body<true, false, false>(d, blockIdx.y, blockIdx.x >> 1, blockIdx.x >> 1, blockIdx.x & 1, V);
+}
+// Small batches, one launch for both: the Schur partials (k_schur's workgroups: the first four waves of a 512-thread workgroup, the
+// others leave at once — s_barrier waits for the surviving waves only) and the start-frame blocks of the visual Hessian read different
+// outputs of the linearisation and nothing of each other: side by side instead of one after the other on a single window's
+// latency path (k_visblock_small was 6.9 us of a 154 us iteration). Same code, same bits as the two launches.
+__global__ __launch_bounds__(VB_GROUP) void k_schur_visblock_small(BatchDev d) {
+  const int w = blockIdx.x, y = blockIdx.y;
+  if (y < d.schur_groups) {
+    if (threadIdx.x < 256) schur_body(d, 0, w, y);
+  } else {
+    __shared__ double V[NV * V_LD];
+    const int v = y - d.schur_groups;
+    visblock_body<true, false, false>(d, w, v >> 1, v >> 1, v & 1, V);
+  }
 }
 
 #ifndef ASM_THREADS
@@ -1758,13 +1796,50 @@ __global__ __launch_bounds__(CAND_THREADS) void k_candidate_window(BatchDev d) {
   candidate_dense(d, ds, c, w, t, sp_cand, wave == 0);
 }
 
+// Small batches (GFBE_FUSE_SMALL bit 1): k_lm_step whose last workgroup of a window to finish (an arrival counter per window; nobody
+// waits for anybody) goes on with k_step's scalar logic and the dense parameter blocks of k_candidate — two dependent launches
+// less per iteration on a single window's latency path. The landmark half of k_candidate runs at the head of k_lin_small<1>'s tile
+// workgroups. A window that re-uses its linearisation (or is done) has nothing to back-substitute: its workgroups only arrive.
+// Returns true in the workgroup that arrived last, after an acquire fence (the others' stores are visible to it).
+__device__ __forceinline__ bool arrive_last(int *cnt, const int expected, const int lane) {
+  __threadfence();
+  int last = 0;
+  if (lane == 0) last = atomicAdd(cnt, 1) == expected - 1;
+  last = __shfl(last, 0, 64);
+  if (!last) return false;
+  __threadfence();
+  if (lane == 0) *cnt = 0;     // (ready for the next launch)
+  return true;
+}
+__global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d) {
+  const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
+  const WinDesc &ds = d.desc[w];
+  WinCtl &c = d.ctl[w];
+  const int t = threadIdx.x;
+  __shared__ double sy[NV], sv[NV];
+  __shared__ PoseRT sp_cand[NF + 1];
+  if (tile < ds.n_tiles && !(c.done || c.reuse)) {
+    for (int a = t; a < NV; a += LM_TILE) {
+      const double s = d.sp[(size_t)w * ND + a];
+      sy[a] = s * d.yp[(size_t)w * ND + a];
+      sv[a] = s * d.vp[(size_t)w * ND + a];
+    }
+    __syncthreads();
+    lm_step_tile(d, ds, c, w, tile, t, sy, sv);
+  }
+  if (!arrive_last(d.win_cnt + 2 * w, gridDim.y, t)) return;
+  step_body(d, ds, c, w, t);
+  __threadfence();      // (lane 0 wrote c1, c2, have_step: every lane reads them below)
+  if (c.done || !c.have_step) return;
+  candidate_dense(d, ds, c, w, t, sp_cand, true);
+}
+
 // =============================================================================================
 // k_accept: candidate cost, tolerances, step acceptance, radius / mu update
 // (TrustRegionMinimizer::{ParameterToleranceReached,FunctionToleranceReached,IsStepSuccessful,
 //  HandleSuccessfulStep,HandleUnsuccessfulStep}, DoglegStrategy::{StepAccepted,StepRejected}).
 // =============================================================================================
-__global__ __launch_bounds__(64) void k_accept(BatchDev d) {
-  const int w = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane) {
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   if (c.done || !c.have_step) return;
@@ -1814,6 +1889,7 @@ __global__ __launch_bounds__(64) void k_accept(BatchDev d) {
   }
   c.have_step = 0;
 }
+__global__ __launch_bounds__(64) void k_accept(BatchDev d) { accept_body(d, blockIdx.x, threadIdx.x); }
 
 // =============================================================================================
 // k_reanchor: double2vector()'s yaw / position gauge fix followed by vector2double()
@@ -1963,11 +2039,11 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   else if (d.B < DENSE_SPLIT_MIN_B) hipLaunchKernelGGL((k_vis_split<2, true>), dim3(d.B, d.max_tiles * LIN_SMALL_KS), b, 0, s, d, write_records);
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
-void launch_lin_small(const BatchDev &d, int mode, hipStream_t s) {
+void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse) {
   const dim3 g(d.B, d.max_tiles * (mode == 0 ? LIN_SMALL_KS : 1) + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LIN_SMALL_THREADS);
-  if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d);
-  else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d);
-  else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d);
+  if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d, 0);
+  else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d, 0);
+  else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d, fuse);
 }
 void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
   hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);
@@ -1981,9 +2057,10 @@ void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_
   if (mode != 3) hipLaunchKernelGGL(k_dense_raw, dim3(MAX_IMU + MAX_WHEEL, (d.B + 63) / 64), dim3(64), 0, s, d, mode);
   hipLaunchKernelGGL(k_dense<false>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out);
 }
-void launch_schur(const BatchDev &d, int marg, hipStream_t s) {
+void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock) {
   if (d.max_tiles == 0) return;
-  hipLaunchKernelGGL(k_schur, dim3(d.B, marg ? 1 : d.schur_groups), dim3(256), 0, s, d, marg);
+  if (with_visblock && !marg && d.vis_Hs) hipLaunchKernelGGL(k_schur_visblock_small, dim3(d.B, d.schur_groups + VS_BLOCKS), dim3(VB_GROUP), 0, s, d);
+  else hipLaunchKernelGGL(k_schur, dim3(d.B, marg ? 1 : d.schur_groups), dim3(256), 0, s, d, marg);
 }
 void launch_xchg_gram(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_gram, dim3(d.B), dim3(64), 0, s, d); }
 void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_cand, dim3(d.B), dim3(64), 0, s, d); }
@@ -2026,9 +2103,10 @@ __global__ __launch_bounds__(256) void k_sys_pack(BatchDev d, int dir) {
 }
 void launch_sys_pack(const BatchDev &d, int dir, hipStream_t s) { hipLaunchKernelGGL(k_sys_pack, dim3(8, d.B), dim3(256), 0, s, d, dir); }
 size_t sys_pack_doubles_host(int nu, int world) { return (size_t)sys_pack_doubles(nu, world); }
-void launch_lm_step(const BatchDev &d, hipStream_t s) {
+void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse) {
   if (d.max_tiles == 0) return;
-  hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
+  if (fuse) hipLaunchKernelGGL(k_lm_step_fused, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
+  else hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
 }
 void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
 void launch_candidate(const BatchDev &d, hipStream_t s) {

@@ -15,6 +15,10 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "cholstamp": (["-DGFBE_CHOL_STAMP=1"], "off"),
     "chainstamp": (["-DGFBE_CHAIN_STAMP=1"], "off"),
     "bigstamp": (["-DGFBE_BIG_STAMP=1"], "off"),
+    "fuse0": (["-DGFBE_FUSE_SMALL=0"], "off"),
+    "fuse1": (["-DGFBE_FUSE_SMALL=1"], "off"),
+    "fuse3": (["-DGFBE_FUSE_SMALL=3"], "off"),
+    "fuse5": (["-DGFBE_FUSE_SMALL=5"], "off"),
     "ks5": (["-DGFBE_LIN_SMALL_KS=5"], "off"),
     "ks10": (["-DGFBE_LIN_SMALL_KS=10"], "off"),
     "asm32": (["-DGFBE_ASM_WGS_SMALL=32"], "off"),
