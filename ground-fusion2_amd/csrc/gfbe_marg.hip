@@ -532,6 +532,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
   MSTAMP(5);
   // ---- getParameterBlocks + addr_shift (estimator.cpp:3561-3590, 3644-3687)
+  // (the kept blocks' values at the re-anchored state: every thread one double — a single lane's load -> store chain over the
+  //  ~130 doubles of 16 blocks was a third of the kernel for one window)
+  __shared__ int s_xo[GFBE_MAX_PRIOR_BLOCKS];
   if (t == 0) {
     meta[0] = 1; meta[1] = n; meta[2] = sh.n_keep; meta[3] = sh.sweeps;   // [3]: Jacobi sweeps (diagnostic)
     int idx = 0, xo = 0;
@@ -543,9 +546,16 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
       else if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_RCV_DDT0 + GFBE_WINDOW_SIZE) nid = id - 1;
       else if (is_dt && id >= GFBE_BLK_RCV_DT0 + 4 * GFBE_WINDOW_SIZE) nid = id - 4;
       meta[4 + q] = nid; meta[4 + GFBE_MAX_PRIOR_BLOCKS + q] = blk_gsize(id); meta[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q] = idx;
-      for (int k = 0; k < blk_gsize(id); k++) d.mx0[(size_t)w * PRIOR_X0 + xo + k] = Xo[blk_amb(id) + k];
+      s_xo[q] = xo;
       idx += blk_lsize(id); xo += blk_gsize(id);
     }
+  }
+  __syncthreads();
+  for (int e = t; e < sh.n_keep * 16; e += blockDim.x) {
+    const int q = e >> 4, k = e & 15, id = sh.keep_id[q];
+    if (k < blk_gsize(id)) d.mx0[(size_t)w * PRIOR_X0 + s_xo[q] + k] = Xo[blk_amb(id) + k];
+  }
+  if (t == 0) {
     d.ctl[w].t_marg = (long long)wall_clock64();
   }
 }
@@ -554,10 +564,36 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
 // ---- diagonally pivoted LDL^T of A' with pivots > eps:  A' ~= P L D+ L^T P^T,
 //      J0 = D+^(1/2) L^T P^T,  r0 = D+^(-1/2) L^-1 P^T b'   (forward substitution folded in)
 #define LDLT_THREADS 512
+// maximum / minimum of a 32-bit value over the wave, as a scalar: four DPP rotations inside the 16-lane rows, the rows' results
+// through v_readlane
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define ROR_MAX(N) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + (N), 0xf, 0xf, false))
+  ROR_MAX(8); ROR_MAX(4); ROR_MAX(2); ROR_MAX(1);
+#undef ROR_MAX
+  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define ROR_MIN(N) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x120 + (N), 0xf, 0xf, false))
+  ROR_MIN(8); ROR_MIN(4); ROR_MIN(2); ROR_MIN(1);
+#undef ROR_MIN
+  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+#ifndef GFBE_LDLT_STAMP
+#define GFBE_LDLT_STAMP 0      // diagnostics build: time stamps inside the first steps of the pivot loop (scratch/marg_stamps.py)
+#endif
 template <int R>
 __device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, const double *__restrict__ bv, double *__restrict__ J0,
-                                              double *__restrict__ r0, const int n, const double eps) {
+                                              double *__restrict__ r0, const int n, const double eps, double *lstamp) {
   const int t = threadIdx.x;
+#if GFBE_LDLT_STAMP
+#define LSTAMP(i) do { if (t == 0 && k >= 8 && k < 12) lstamp[(k - 8) * 8 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#endif
     // The matrix lives in REGISTERS: thread (ti, tj) of a G x G grid (G = ceil(n / R)) owns the R x R tile
     // A'(R ti .. R ti + R - 1, R tj .. R tj + R - 1). Step k: every wave finds the largest remaining diagonal entry p_k
     // from its own register copy of the diagonal (no cross-wave reduction), the owners of row p_k publish it
@@ -588,34 +624,30 @@ __device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, cons
     }
     int rank = n;
     for (int k = 0; k < n; k++) {
-      double best = -1e300; int bi = -1;
+      LSTAMP(0);
+      // arg-max of the remaining diagonal over the wave (largest value, smallest index among equals — every wave finds the same one
+      // from its own copy). A positive double orders like its bit pattern: the high words' maximum, then the low words' among the
+      // lanes that hold it, then the smallest index among those that hold both — three 32-bit reductions (DPP rotations inside the
+      // 16-lane rows, the four row results through v_readlane into scalar max / min) instead of one on (double, index) pairs whose
+      // compare-and-select chains were 0.6 us of a 1.3 us step. Entries that are not positive cannot be pivots: key 0.
+      unsigned khi = 0, klo = 0;
 #pragma unroll
-      for (int q = 0; q < 3; q++)
-        if (alive[q] && (bi < 0 || dg[q] > best)) { best = dg[q]; bi = lane + 64 * q; }
-      // arg-max over the wave (largest value, smallest index among equals: any reduction order gives the same answer): inside a
-      // 16-lane row by DPP rotations instead of dependent ds_bpermute rounds, then the four row results through v_readlane
-#define LDLT_TAKE(ob, oi) do { if ((oi) >= 0 && (bi < 0 || (ob) > best || ((ob) == best && (oi) < bi))) { best = (ob); bi = (oi); } } while (0)
-#define LDLT_ROR(N) do {                                                                                              \
-        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(best), 0x120 + (N), 0xf, 0xf, false);            \
-        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(best), 0x120 + (N), 0xf, 0xf, false);            \
-        const int oi_ = __builtin_amdgcn_update_dpp(0, bi, 0x120 + (N), 0xf, 0xf, false);                              \
-        const double ob_ = __hiloint2double(hi_, lo_);                                                                 \
-        LDLT_TAKE(ob_, oi_);                                                                                           \
-      } while (0)
-      LDLT_ROR(8); LDLT_ROR(4); LDLT_ROR(2); LDLT_ROR(1);
-      {
-        double rb[4]; int ri[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          rb[q] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(best), 16 * q), __builtin_amdgcn_readlane(__double2loint(best), 16 * q));
-          ri[q] = __builtin_amdgcn_readlane(bi, 16 * q);
-        }
-        best = rb[0]; bi = ri[0];
-        LDLT_TAKE(rb[1], ri[1]); LDLT_TAKE(rb[2], ri[2]); LDLT_TAKE(rb[3], ri[3]);
+      for (int q = 0; q < 3; q++) {
+        const unsigned h = (unsigned)__double2hiint(dg[q]), l = (unsigned)__double2loint(dg[q]);
+        const bool cand = alive[q] && !(h >> 31);
+        const bool gt = cand && (h > khi || (h == khi && l > klo));
+        khi = gt ? h : khi; klo = gt ? l : klo;
       }
-#undef LDLT_ROR
-#undef LDLT_TAKE
-      if (!(best > eps)) { rank = k; break; }     // identical in every wave
+      const unsigned mh = wave_max_u32(khi);
+      const unsigned ml = wave_max_u32(khi == mh ? klo : 0u);
+      unsigned ci = 0xffffffffu;
+#pragma unroll
+      for (int q = 2; q >= 0; q--)
+        if (alive[q] && (unsigned)__double2hiint(dg[q]) == mh && (unsigned)__double2loint(dg[q]) == ml) ci = (unsigned)(lane + 64 * q);
+      const int bi = (int)wave_min_u32(ci);
+      const double best = __hiloint2double((int)mh, (int)ml);
+      LSTAMP(1);
+      if (!(best > eps) || (mh | ml) == 0u) { rank = k; break; }     // identical in every wave
       const int pv = bi, pq = pv >> 6, pl = pv & 63;
       const double piv = best, inv = 1.0 / piv;
       const double zsel = pq == 0 ? bzr[0] : (pq == 1 ? bzr[1] : bzr[2]);
@@ -631,7 +663,10 @@ __device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, cons
           cb[tj * R + c] = v;
         }
       }
-      __syncthreads();
+      // (LDS traffic only: __syncthreads() also drains the vector-memory counter — the J0 row the previous step streamed out)
+      LSTAMP(2);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      LSTAMP(3);
       double cx[3];
 #pragma unroll
       for (int q = 0; q < 3; q++) cx[q] = cb[lane + 64 * q];
@@ -651,6 +686,7 @@ __device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, cons
         bzr[q] -= li * zk;
         if (lane + 64 * q == pv) alive[q] = false;
       }
+      LSTAMP(4);
       if (owner_active) {
         double ci[R], cj[R];
 #pragma unroll
@@ -660,7 +696,9 @@ __device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, cons
 #pragma unroll
           for (int c = 0; c < R; c++) a[r][c] -= ci[r] * cj[c];
       }
+      LSTAMP(5);
     }
+#undef LSTAMP
     for (int e = t + rank * n; e < n * n; e += blockDim.x) J0[e] = 0.0;
     for (int k = t + rank; k < n; k += blockDim.x) r0[k] = 0.0;
     return rank;
@@ -680,7 +718,7 @@ __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   double *J0 = d.mJ0 + (size_t)w * ND * ND;
   double *r0 = d.mr0 + (size_t)w * ND;
   double *stamp = d.timing + 24;
-  const int rank = ldlt_registers<R>(A, bv, J0, r0, n, d.opt.marg_eps);
+  const int rank = ldlt_registers<R>(A, bv, J0, r0, n, d.opt.marg_eps, d.timing + (size_t)d.B * 32);
   if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
 }
 

@@ -15,6 +15,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "cholstamp": (["-DGFBE_CHOL_STAMP=1"], "off"),
     "chainstamp": (["-DGFBE_CHAIN_STAMP=1"], "off"),
     "bigstamp": (["-DGFBE_BIG_STAMP=1"], "off"),
+    "ldltstamp": (["-DGFBE_LDLT_STAMP=1"], "off"),
     "fuse0": (["-DGFBE_FUSE_SMALL=0"], "off"),
     "fuse1": (["-DGFBE_FUSE_SMALL=1"], "off"),
     "fuse3": (["-DGFBE_FUSE_SMALL=3"], "off"),
