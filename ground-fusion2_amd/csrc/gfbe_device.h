@@ -20,9 +20,10 @@
 // Small batches (< 32 windows, no landmark sharding): launches of one iteration merged on a single window's latency path. Bit 0:
 // k_schur + k_visblock_small in one launch; bit 1: k_step and the dense half of k_candidate by the workgroup of k_lm_step that
 // finishes last, the landmark half of k_candidate by k_lin_small<1>'s tile workgroups; bit 2: k_accept by the workgroup of
-// k_lin_small<1> that finishes last. Same code, same order of every sum: the results do not change by a bit.
+// k_lin_small<1> that finishes last; bit 3: the marginalisation's linearisation (k_vis_split<2> + k_dense) in one launch, its pair sums
+// and its Schur partial in another. Same code, same order of every sum: the results do not change by a bit.
 #ifndef GFBE_FUSE_SMALL
-#define GFBE_FUSE_SMALL 7
+#define GFBE_FUSE_SMALL 15
 #endif
 
 namespace gfd {
@@ -309,6 +310,7 @@ void launch_reset(const BatchDev &d, hipStream_t s);
 // mode 1: candidate cost only   mode 2: linearise the marginalisation set at xout (start frame 0 only)
 void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records = 0);
 void launch_pair(const BatchDev &d, int marg, hipStream_t s);
+void launch_pair_schur_marg(const BatchDev &d, hipStream_t s);   // small batches: k_pairsum (marg) + k_schur (marg) in one launch
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse = 0);   // fuse (mode 1): bit 1 candidate tiles first, bit 2 k_accept last
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock = 0);   // with_visblock: k_schur_visblock_small

@@ -599,12 +599,11 @@ __global__ __launch_bounds__(256) void k_lio_window(BatchDev d) {
 //   pair_part[w][(i,j)][:] = sum_{tiles t of start frame i} vis_part[w][t][j-i-1][:]
 // Used by the marginalisation (pairs (0, j)); the solve loop sums the tiles inside k_assemble.
 // =============================================================================================
-__global__ __launch_bounds__(VP_STRIDE) void k_pairsum(BatchDev d, int marg) {
-  const int w = blockIdx.y;
+__device__ __forceinline__ void pairsum_body(const BatchDev &d, const int marg, const int w, const int pair) {
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   if (!marg && (c.done || c.reuse)) return;
-  int i = 0, rem = blockIdx.x;
+  int i = 0, rem = pair;
   while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
   const int j = i + 1 + rem;
   if (marg && i != 0) return;
@@ -618,6 +617,7 @@ __global__ __launch_bounds__(VP_STRIDE) void k_pairsum(BatchDev d, int marg) {
   }
   if (marg) d.pair_part[((size_t)w * NF + j) * VP_STRIDE + threadIdx.x] = s;     // (only the marginalisation keeps per-pair sums: pairs (0, j), slot j)
 }
+__global__ __launch_bounds__(VP_STRIDE) void k_pairsum(BatchDev d, int marg) { pairsum_body(d, marg, blockIdx.y, blockIdx.x); }
 
 // =============================================================================================
 // k_dense: blocks 0..9 IMU factors, 10..19 wheel factors, 20 the prior. 64 threads each.
@@ -853,7 +853,7 @@ __device__ __forceinline__ bool arrive_last(int *cnt, const int expected, const 
 template <int MODE, bool FULL>
 __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, int fuse) {
   const int w = blockIdx.x, y = blockIdx.y;
-  constexpr int KS = MODE == 0 ? LIN_SMALL_KS : 1;      // (the cost-only pass is too short to gain: 9 -> 12 us when split)
+  constexpr int KS = MODE != 1 ? LIN_SMALL_KS : 1;      // (the cost-only pass is too short to gain: 9 -> 12 us when split)
   // four waves per workgroup: a visual tile is one wave's work (the others leave at once); the inertial / wheel / prior items use
   // all four — the single lane that evaluated an IMU factor was the longest chain of the launch
   const bool tile_wg = y < d.max_tiles * KS;
@@ -1049,6 +1049,13 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
 }
 __global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
   schur_body(d, marg, blockIdx.x, blockIdx.y);   // group-major dispatch: the heavy first group of every window first
+}
+// Small batches, marginalisation: the pair sums (0, j) and the Schur partial of start frame 0 both read what the linearisation of the
+// marginalisation set left and nothing of each other: one launch (GFBE_FUSE_SMALL bit 3).
+__global__ __launch_bounds__(VP_STRIDE) void k_pairsum_schur_marg(BatchDev d) {
+  const int w = blockIdx.x, y = blockIdx.y;
+  if (y < NF - 1) pairsum_body(d, 1, w, y);
+  else if (threadIdx.x < 256) schur_body(d, 1, w, 0);
 }
 
 // =============================================================================================
@@ -2040,10 +2047,15 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse) {
-  const dim3 g(d.B, d.max_tiles * (mode == 0 ? LIN_SMALL_KS : 1) + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LIN_SMALL_THREADS);
-  if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d, 0);
+  const dim3 g(d.B, d.max_tiles * (mode != 1 ? LIN_SMALL_KS : 1) + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LIN_SMALL_THREADS);
+  if (mode == 2) hipLaunchKernelGGL((k_lin_small<2, true>), g, b, 0, s, d, 0);   // (the marginalisation set: k_vis_split<2> + k_dense mode 2 in one launch)
+  else if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d, 0);
   else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d, 0);
   else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d, fuse);
+}
+void launch_pair_schur_marg(const BatchDev &d, hipStream_t s) {
+  if (d.max_tiles == 0) { launch_pair(d, 1, s); return; }
+  hipLaunchKernelGGL(k_pairsum_schur_marg, dim3(d.B, NF), dim3(VP_STRIDE), 0, s, d);
 }
 void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
   hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);

@@ -199,6 +199,151 @@ __device__ void jacobi_eig_wave16(double *G, double *V, int n, double *lam, int 
   if (lane < n) { double sum = 0.0; for (int i = 0; i < n; i++) sum += V[lane * 16 + i] * G[lane * 16 + i]; lam[lane] = sum; }
 }
 
+// ---- diagonally pivoted LDL^T of A' with pivots > eps:  A' ~= P L D+ L^T P^T,
+//      J0 = D+^(1/2) L^T P^T,  r0 = D+^(-1/2) L^-1 P^T b'   (forward substitution folded in)
+#define LDLT_THREADS 512
+// maximum / minimum of a 32-bit value over the wave, as a scalar: four DPP rotations inside the 16-lane rows, the rows' results
+// through v_readlane
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define ROR_MAX(N) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + (N), 0xf, 0xf, false))
+  ROR_MAX(8); ROR_MAX(4); ROR_MAX(2); ROR_MAX(1);
+#undef ROR_MAX
+  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#define ROR_MIN(N) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x120 + (N), 0xf, 0xf, false))
+  ROR_MIN(8); ROR_MIN(4); ROR_MIN(2); ROR_MIN(1);
+#undef ROR_MIN
+  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return min(min(r0, r1), min(r2, r3));
+}
+#ifndef GFBE_LDLT_STAMP
+#define GFBE_LDLT_STAMP 0      // diagnostics build: time stamps inside the first steps of the pivot loop (scratch/marg_stamps.py)
+#endif
+// loadA(i, j): entry (i, j) of A'; loadB(i): entry i of b' — from the compact arrays k_marg left (k_marg_ldlt), or formed on the fly
+// from the Schur operands in LDS (the LDL^T at the tail of k_marg itself).
+template <int R, class LoadA, class LoadB>
+__device__ __forceinline__ int ldlt_registers(LoadA loadA, LoadB loadB, double *__restrict__ J0,
+                                              double *__restrict__ r0, const int n, const double eps, double *lstamp) {
+  const int t = threadIdx.x;
+#if GFBE_LDLT_STAMP
+#define LSTAMP(i) do { if (t == 0 && k >= 8 && k < 12) lstamp[(k - 8) * 8 + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#endif
+    // The matrix lives in REGISTERS: thread (ti, tj) of a G x G grid (G = ceil(n / R)) owns the R x R tile
+    // A'(R ti .. R ti + R - 1, R tj .. R tj + R - 1). Step k: every wave finds the largest remaining diagonal entry p_k
+    // from its own register copy of the diagonal (no cross-wave reduction), the owners of row p_k publish it
+    // through a double-buffered LDS vector, one block barrier, and every thread subtracts the rank-1 term
+    // from its tile. Nothing is moved: eliminated rows / columns simply stay behind (masked on output), and
+    // row k of J0 = sqrt(d_k) L(:,k)^T is streamed to HBM from the published vector as it is produced.
+    __shared__ double colbuf[2][192];
+    const int G = (n + R - 1) / R;
+    const int ti = t / G, tj = t - ti * G;
+    const bool owner_active = t < G * G;
+    const int lane = t & 63, wv = t >> 6;
+    double a[R][R];
+#pragma unroll
+    for (int r = 0; r < R; r++)
+#pragma unroll
+      for (int c = 0; c < R; c++) {
+        const int i = ti * R + r, j = tj * R + c;
+        a[r][c] = (owner_active && i < n && j < n) ? loadA(i, j) : 0.0;
+      }
+    double dg[3], bzr[3];
+    bool alive[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int i = lane + 64 * q;
+      alive[q] = i < n;
+      dg[q] = alive[q] ? loadA(i, i) : 0.0;
+      bzr[q] = alive[q] ? loadB(i) : 0.0;
+    }
+    int rank = n;
+    for (int k = 0; k < n; k++) {
+      LSTAMP(0);
+      // arg-max of the remaining diagonal over the wave (largest value, smallest index among equals — every wave finds the same one
+      // from its own copy). A positive double orders like its bit pattern: the high words' maximum, then the low words' among the
+      // lanes that hold it, then the smallest index among those that hold both — three 32-bit reductions (DPP rotations inside the
+      // 16-lane rows, the four row results through v_readlane into scalar max / min) instead of one on (double, index) pairs whose
+      // compare-and-select chains were 0.6 us of a 1.3 us step. Entries that are not positive cannot be pivots: key 0.
+      unsigned khi = 0, klo = 0;
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const unsigned h = (unsigned)__double2hiint(dg[q]), l = (unsigned)__double2loint(dg[q]);
+        const bool cand = alive[q] && !(h >> 31);
+        const bool gt = cand && (h > khi || (h == khi && l > klo));
+        khi = gt ? h : khi; klo = gt ? l : klo;
+      }
+      const unsigned mh = wave_max_u32(khi);
+      const unsigned ml = wave_max_u32(khi == mh ? klo : 0u);
+      unsigned ci = 0xffffffffu;
+#pragma unroll
+      for (int q = 2; q >= 0; q--)
+        if (alive[q] && (unsigned)__double2hiint(dg[q]) == mh && (unsigned)__double2loint(dg[q]) == ml) ci = (unsigned)(lane + 64 * q);
+      const int bi = (int)wave_min_u32(ci);
+      const double best = __hiloint2double((int)mh, (int)ml);
+      LSTAMP(1);
+      if (!(best > eps) || (mh | ml) == 0u) { rank = k; break; }     // identical in every wave
+      const int pv = bi, pq = pv >> 6, pl = pv & 63;
+      const double piv = best, inv = 1.0 / piv;
+      const double zsel = pq == 0 ? bzr[0] : (pq == 1 ? bzr[1] : bzr[2]);
+      const double zk = __shfl(zsel, pl, 64);
+      double *cb = colbuf[k & 1];
+      const int pr = pv / R, pc = pv - pr * R;
+      if (owner_active && ti == pr) {                         // symmetric: row p_k == column p_k
+#pragma unroll
+        for (int c = 0; c < R; c++) {
+          double v = a[0][c];
+#pragma unroll
+          for (int r = 1; r < R; r++) v = pc == r ? a[r][c] : v;
+          cb[tj * R + c] = v;
+        }
+      }
+      // (LDS traffic only: __syncthreads() also drains the vector-memory counter — the J0 row the previous step streamed out)
+      LSTAMP(2);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      LSTAMP(3);
+      double cx[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) cx[q] = cb[lane + 64 * q];
+      if (wv == (k & (LDLT_THREADS / 64 - 1))) {                                   // row k of J0, r0[k]
+        const double rs = 1.0 / sqrt(piv);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const int i = lane + 64 * q;
+          if (i < n) J0[(size_t)k * n + i] = i == pv ? sqrt(piv) : (alive[q] ? cx[q] * rs : 0.0);
+        }
+        if (lane == 0) r0[k] = zk * rs;
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const double li = cx[q] * inv;
+        dg[q] -= li * cx[q];
+        bzr[q] -= li * zk;
+        if (lane + 64 * q == pv) alive[q] = false;
+      }
+      LSTAMP(4);
+      if (owner_active) {
+        double ci[R], cj[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { ci[r] = cb[ti * R + r] * inv; cj[r] = cb[tj * R + r]; }
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+          for (int c = 0; c < R; c++) a[r][c] -= ci[r] * cj[c];
+      }
+      LSTAMP(5);
+    }
+#undef LSTAMP
+    for (int e = t + rank * n; e < n * n; e += LDLT_THREADS) J0[e] = 0.0;      // (LDLT_THREADS threads run this function, whatever the workgroup's size)
+    for (int k = t + rank; k < n; k += LDLT_THREADS) r0[k] = 0.0;
+    return rank;
+}
+
 #ifndef MARG_THREADS
 #define MARG_THREADS 1024
 #endif
@@ -231,6 +376,8 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   // which blocks do the factors of the marginalisation set touch? The look-ups (descriptor fields and cost slots in global memory:
   // a microsecond of latency each) by different threads side by side — on one lane they were 20 us of a single window's solve; every
   // flag is written with the same value by whoever finds it
+  __shared__ int s_pmap[ND];       // prior column of a tangent dim (-1: not in the prior): read per entry of the assembly below
+  for (int a = t; a < ND; a += blockDim.x) s_pmap[a] = ds.prior_map[a];
   if (t < GFBE_BLK_COUNT) sh.touched[t] = 0;
   if (t == 0) { sh.use_imu = sh.use_wheel = sh.use_plane = sh.use_gnss = 0; sh.passthrough = 0; }
   __syncthreads();
@@ -267,7 +414,9 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     }
   }
   __syncthreads();
-  if (t == 0) {
+  // the dropped dims by one lane, the kept blocks and their tangent dims by a wave next to it (two blocks per lane, positions by
+  // prefix sums over the lanes: 88 blocks one after the other on one lane were ~4 us of a single window's marginalisation)
+  if (t == 64) {
     int m = 0;
     if (old) {
       if (sh.touched[0]) for (int k = 0; k < 6; k++) sh.drop_dim[m++] = k;
@@ -282,16 +431,33 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
       else sh.passthrough = 1;                      // estimator.cpp:3600-3601: prior does not touch Pose[9]
     }
     sh.m = m;
-    int nk = 0, n = 0;
-    for (int q = 0; q < GFBE_BLK_COUNT; q++) {
-      if (!sh.touched[q]) continue;
-      bool dropped = old ? (q == 0 || q == GFBE_BLK_SB0 || (sh.use_gnss && ((q >= GFBE_BLK_RCV_DT0 && q < GFBE_BLK_RCV_DT0 + 4) || q == GFBE_BLK_RCV_DDT0)))
-                         : (q == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1);
-      if (dropped) continue;
-      sh.keep_id[nk++] = q;
-      for (int k = 0; k < blk_lsize(q); k++) sh.keep_dim[n++] = blk_tan(q) + k;
+  }
+  if (t < 64) {
+    static_assert(GFBE_BLK_COUNT <= 128, "two blocks per lane");
+    int base_k = 0, base_n = 0;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int q = t + 64 * u;
+      bool kept = q < GFBE_BLK_COUNT && sh.touched[min(q, GFBE_BLK_COUNT - 1)];
+      if (kept) {
+        const bool dropped = old ? (q == 0 || q == GFBE_BLK_SB0 || (sh.use_gnss && ((q >= GFBE_BLK_RCV_DT0 && q < GFBE_BLK_RCV_DT0 + 4) || q == GFBE_BLK_RCV_DDT0)))
+                                 : (q == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE - 1);
+        kept = !dropped;
+      }
+      const int ls = kept ? blk_lsize(q) : 0;
+      int ck = kept ? 1 : 0, cn = ls;          // inclusive prefix sums over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int ok = __shfl_up(ck, o, 64), on = __shfl_up(cn, o, 64);
+        if (t >= o) { ck += ok; cn += on; }
+      }
+      if (kept) {
+        sh.keep_id[base_k + ck - 1] = q;
+        for (int k = 0; k < ls; k++) sh.keep_dim[base_n + cn - ls + k] = blk_tan(q) + k;
+      }
+      base_k += __shfl(ck, 63, 64); base_n += __shfl(cn, 63, 64);
     }
-    sh.n_keep = nk; sh.n = n;
+    if (t == 0) { sh.n_keep = base_k; sh.n = base_n; }
   }
   __syncthreads();
   if (sh.passthrough) {
@@ -321,19 +487,28 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const double *ppart = sh.use_plane ? d.plane_part + (size_t)w * MAX_PLANE * PLANE_PART : nullptr;
   const double *gpart = sh.use_gnss ? d.gnss_marg + (size_t)w * GN_MPART : nullptr;
   // only the dims of the marginalisation (dropped + kept, nn <= 101 of 182) are ever read back: pairs (ia >= ib) of that list
-  const int nn = n + m;
-  for (int e = t; e < nn * (nn + 1) / 2; e += blockDim.x) {
+  const int nn = n + m, ntri = nn * (nn + 1) / 2;
+  // entry e of the lower triangle over the marginalisation's dims: the sum of its terms in the fixed order pairs (0, 1..10), Schur,
+  // IMU, wheel, plane, GNSS, prior. Two entries per thread and pass: the loads of both are in flight together (five dependent passes
+  // of ~3 us each were the longest phase of the kernel for one window).
+  auto entry_sum = [&](const int e, int &a, int &b) -> double {
     int ia = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
     while ((ia + 1) * (ia + 2) / 2 <= e) ia++;
     while (ia * (ia + 1) / 2 > e) ia--;
     const int ib = e - ia * (ia + 1) / 2;
     const int da = ia < m ? sh.drop_dim[ia] : sh.keep_dim[ia - m], db = ib < m ? sh.drop_dim[ib] : sh.keep_dim[ib - m];
-    const int a = max(da, db), b = min(da, db);
+    a = max(da, db); b = min(da, db);
     double s = 0.0;
     if (old && a < NV) {
-      for (int j = 1; j < NF; j++) {
-        const int la = m_vis_loc(a, j), lb = m_vis_loc(b, j);
-        if (la >= 0 && lb >= 0) s += pp[(size_t)j * VP_STRIDE + m_vp_off(la, lb)];
+      // pairs (0, j) whose factors reach both dims: every j when neither is a pose dim of a frame > 0 (pose 0, extrinsic, td: the
+      // column inside the pair's block does not depend on j), the one j of that frame otherwise (none for two different frames)
+      const int fa = a < 66 ? a / 6 : 0, fb = b < 66 ? b / 6 : 0;
+      if (fa == 0 && fb == 0) {
+        const int off = m_vp_off(m_vis_loc(a, 1), m_vis_loc(b, 1));
+        for (int j = 1; j < NF; j++) s += pp[(size_t)j * VP_STRIDE + off];
+      } else if (fa == 0 || fb == 0 || fa == fb) {
+        const int j = max(fa, fb);
+        s += pp[(size_t)j * VP_STRIDE + m_vp_off(m_vis_loc(a, j), m_vis_loc(b, j))];
       }
       s -= sp[m_schur_off(b, a)];                         // b <= a
     }
@@ -341,8 +516,16 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     if (wpart) { const int la = m_wheel_loc(a), lb = m_wheel_loc(b); if (la >= 0 && lb >= 0) s += wpart[la * 22 + lb]; }
     if (ppart) { const int la = m_plane_loc(a), lb = m_plane_loc(b); if (la >= 0 && lb >= 0) s += ppart[la * 16 + lb]; }
     if (gpart) { const int la = m_gnss_loc(a), lb = m_gnss_loc(b); if (la >= 0 && lb >= 0) s += gpart[la * GN_M + lb]; }
-    if (ds.prior_n > 0) { const int pa = ds.prior_map[a], pb = ds.prior_map[b]; if (pa >= 0 && pb >= 0) s += d.prior_H[(size_t)w * ND * ND + (size_t)pa * ds.prior_n + pb]; }
-    A[(size_t)a * ND + b] = s; A[(size_t)b * ND + a] = s;
+    if (ds.prior_n > 0) { const int pa = s_pmap[a], pb = s_pmap[b]; if (pa >= 0 && pb >= 0) s += d.prior_H[(size_t)w * ND * ND + (size_t)pa * ds.prior_n + pb]; }
+    return s;
+  };
+  for (int e = t; e < ntri; e += 2 * blockDim.x) {
+    int a0, b0, a1 = 0, b1 = 0;
+    const int e1 = e + blockDim.x;
+    const double s0 = entry_sum(e, a0, b0);
+    const double s1 = e1 < ntri ? entry_sum(e1, a1, b1) : 0.0;
+    A[(size_t)a0 * ND + b0] = s0; A[(size_t)b0 * ND + a0] = s0;
+    if (e1 < ntri) { A[(size_t)a1 * ND + b1] = s1; A[(size_t)b1 * ND + a1] = s1; }
   }
   for (int a = t; a < ND; a += blockDim.x) {
     double s = 0.0;
@@ -357,7 +540,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     if (wpart) { const int la = m_wheel_loc(a); if (la >= 0) s += wpart[484 + la]; }
     if (ppart) { const int la = m_plane_loc(a); if (la >= 0) s += ppart[256 + la]; }
     if (gpart) { const int la = m_gnss_loc(a); if (la >= 0) s += gpart[GN_M * GN_M + la]; }
-    if (ds.prior_n > 0 && ds.prior_map[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + ds.prior_map[a]];
+    if (ds.prior_n > 0 && s_pmap[a] >= 0) s += d.prior_g[(size_t)w * (ND + 2) + s_pmap[a]];
     bv[a] = s;
   }
   __syncthreads();
@@ -471,6 +654,32 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
     T[i * ms + j] = s;
   }
   __syncthreads();
+  __shared__ int s_xo[GFBE_MAX_PRIOR_BLOCKS];
+  auto write_blocks = [&](const int sweeps_code) {      // (every thread of the workgroup calls it: one block barrier inside)
+  // ---- getParameterBlocks + addr_shift (estimator.cpp:3561-3590, 3644-3687)
+  // (the kept blocks' values at the re-anchored state: every thread one double — a single lane's load -> store chain over the
+  //  ~130 doubles of 16 blocks was a third of the kernel for one window)
+  if (t == 0) {
+    meta[0] = 1; meta[1] = n; meta[2] = sh.n_keep; meta[3] = sweeps_code;   // [3]: Jacobi sweeps (diagnostic)
+    int idx = 0, xo = 0;
+    for (int q = 0; q < sh.n_keep; q++) {
+      const int id = sh.keep_id[q];
+      int nid = id;
+      const bool is_dt = id >= GFBE_BLK_RCV_DT0 && id < GFBE_BLK_RCV_DDT0, is_ddt = id >= GFBE_BLK_RCV_DDT0;
+      if (old) { if (id < GFBE_BLK_EX_CAM || is_ddt) nid = id - 1; else if (is_dt) nid = id - 4; }   // slot i -> i - 1: pose, speed-bias, receiver clock
+      else if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_RCV_DDT0 + GFBE_WINDOW_SIZE) nid = id - 1;
+      else if (is_dt && id >= GFBE_BLK_RCV_DT0 + 4 * GFBE_WINDOW_SIZE) nid = id - 4;
+      meta[4 + q] = nid; meta[4 + GFBE_MAX_PRIOR_BLOCKS + q] = blk_gsize(id); meta[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q] = idx;
+      s_xo[q] = xo;
+      idx += blk_lsize(id); xo += blk_gsize(id);
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < sh.n_keep * 16; e += blockDim.x) {
+    const int q = e >> 4, k = e & 15, id = sh.keep_id[q];
+    if (k < blk_gsize(id)) d.mx0[(size_t)w * PRIOR_X0 + s_xo[q] + k] = Xo[blk_amb(id) + k];
+  }
+    };
   double *Ap = J0 + (size_t)ND * ms;   // compact A' (n x n, ld = n) — fits: 32 ND + n^2 <= ND^2 for n <= 229
   for (int e = t; e < n * n; e += blockDim.x) {
     const int i = e / n, j = e % n;
@@ -531,178 +740,10 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   }
   }
   MSTAMP(5);
-  // ---- getParameterBlocks + addr_shift (estimator.cpp:3561-3590, 3644-3687)
-  // (the kept blocks' values at the re-anchored state: every thread one double — a single lane's load -> store chain over the
-  //  ~130 doubles of 16 blocks was a third of the kernel for one window)
-  __shared__ int s_xo[GFBE_MAX_PRIOR_BLOCKS];
-  if (t == 0) {
-    meta[0] = 1; meta[1] = n; meta[2] = sh.n_keep; meta[3] = sh.sweeps;   // [3]: Jacobi sweeps (diagnostic)
-    int idx = 0, xo = 0;
-    for (int q = 0; q < sh.n_keep; q++) {
-      const int id = sh.keep_id[q];
-      int nid = id;
-      const bool is_dt = id >= GFBE_BLK_RCV_DT0 && id < GFBE_BLK_RCV_DDT0, is_ddt = id >= GFBE_BLK_RCV_DDT0;
-      if (old) { if (id < GFBE_BLK_EX_CAM || is_ddt) nid = id - 1; else if (is_dt) nid = id - 4; }   // slot i -> i - 1: pose, speed-bias, receiver clock
-      else if (id == GFBE_BLK_POSE0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_SB0 + GFBE_WINDOW_SIZE || id == GFBE_BLK_RCV_DDT0 + GFBE_WINDOW_SIZE) nid = id - 1;
-      else if (is_dt && id >= GFBE_BLK_RCV_DT0 + 4 * GFBE_WINDOW_SIZE) nid = id - 4;
-      meta[4 + q] = nid; meta[4 + GFBE_MAX_PRIOR_BLOCKS + q] = blk_gsize(id); meta[4 + 2 * GFBE_MAX_PRIOR_BLOCKS + q] = idx;
-      s_xo[q] = xo;
-      idx += blk_lsize(id); xo += blk_gsize(id);
-    }
-  }
-  __syncthreads();
-  for (int e = t; e < sh.n_keep * 16; e += blockDim.x) {
-    const int q = e >> 4, k = e & 15, id = sh.keep_id[q];
-    if (k < blk_gsize(id)) d.mx0[(size_t)w * PRIOR_X0 + s_xo[q] + k] = Xo[blk_amb(id) + k];
-  }
-  if (t == 0) {
-    d.ctl[w].t_marg = (long long)wall_clock64();
-  }
+  write_blocks(sh.sweeps);
+  if (t == 0) d.ctl[w].t_marg = (long long)wall_clock64();
 }
 
-
-// ---- diagonally pivoted LDL^T of A' with pivots > eps:  A' ~= P L D+ L^T P^T,
-//      J0 = D+^(1/2) L^T P^T,  r0 = D+^(-1/2) L^-1 P^T b'   (forward substitution folded in)
-#define LDLT_THREADS 512
-// maximum / minimum of a 32-bit value over the wave, as a scalar: four DPP rotations inside the 16-lane rows, the rows' results
-// through v_readlane
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#define ROR_MAX(N) v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + (N), 0xf, 0xf, false))
-  ROR_MAX(8); ROR_MAX(4); ROR_MAX(2); ROR_MAX(1);
-#undef ROR_MAX
-  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
-  const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
-  return max(max(r0, r1), max(r2, r3));
-}
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#define ROR_MIN(N) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x120 + (N), 0xf, 0xf, false))
-  ROR_MIN(8); ROR_MIN(4); ROR_MIN(2); ROR_MIN(1);
-#undef ROR_MIN
-  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
-  const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
-  return min(min(r0, r1), min(r2, r3));
-}
-#ifndef GFBE_LDLT_STAMP
-#define GFBE_LDLT_STAMP 0      // diagnostics build: time stamps inside the first steps of the pivot loop (scratch/marg_stamps.py)
-#endif
-template <int R>
-__device__ __forceinline__ int ldlt_registers(const double *__restrict__ A, const double *__restrict__ bv, double *__restrict__ J0,
-                                              double *__restrict__ r0, const int n, const double eps, double *lstamp) {
-  const int t = threadIdx.x;
-#if GFBE_LDLT_STAMP
-#define LSTAMP(i) do { if (t == 0 && k >= 8 && k < 12) lstamp[(k - 8) * 8 + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define LSTAMP(i) do { } while (0)
-#endif
-    // The matrix lives in REGISTERS: thread (ti, tj) of a G x G grid (G = ceil(n / R)) owns the R x R tile
-    // A'(R ti .. R ti + R - 1, R tj .. R tj + R - 1). Step k: every wave finds the largest remaining diagonal entry p_k
-    // from its own register copy of the diagonal (no cross-wave reduction), the owners of row p_k publish it
-    // through a double-buffered LDS vector, one block barrier, and every thread subtracts the rank-1 term
-    // from its tile. Nothing is moved: eliminated rows / columns simply stay behind (masked on output), and
-    // row k of J0 = sqrt(d_k) L(:,k)^T is streamed to HBM from the published vector as it is produced.
-    __shared__ double colbuf[2][192];
-    const int G = (n + R - 1) / R;
-    const int ti = t / G, tj = t - ti * G;
-    const bool owner_active = t < G * G;
-    const int lane = t & 63, wv = t >> 6;
-    double a[R][R];
-#pragma unroll
-    for (int r = 0; r < R; r++)
-#pragma unroll
-      for (int c = 0; c < R; c++) {
-        const int i = ti * R + r, j = tj * R + c;
-        a[r][c] = (owner_active && i < n && j < n) ? A[(size_t)i * n + j] : 0.0;
-      }
-    double dg[3], bzr[3];
-    bool alive[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int i = lane + 64 * q;
-      alive[q] = i < n;
-      dg[q] = alive[q] ? A[(size_t)i * n + i] : 0.0;
-      bzr[q] = alive[q] ? bv[i] : 0.0;
-    }
-    int rank = n;
-    for (int k = 0; k < n; k++) {
-      LSTAMP(0);
-      // arg-max of the remaining diagonal over the wave (largest value, smallest index among equals — every wave finds the same one
-      // from its own copy). A positive double orders like its bit pattern: the high words' maximum, then the low words' among the
-      // lanes that hold it, then the smallest index among those that hold both — three 32-bit reductions (DPP rotations inside the
-      // 16-lane rows, the four row results through v_readlane into scalar max / min) instead of one on (double, index) pairs whose
-      // compare-and-select chains were 0.6 us of a 1.3 us step. Entries that are not positive cannot be pivots: key 0.
-      unsigned khi = 0, klo = 0;
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const unsigned h = (unsigned)__double2hiint(dg[q]), l = (unsigned)__double2loint(dg[q]);
-        const bool cand = alive[q] && !(h >> 31);
-        const bool gt = cand && (h > khi || (h == khi && l > klo));
-        khi = gt ? h : khi; klo = gt ? l : klo;
-      }
-      const unsigned mh = wave_max_u32(khi);
-      const unsigned ml = wave_max_u32(khi == mh ? klo : 0u);
-      unsigned ci = 0xffffffffu;
-#pragma unroll
-      for (int q = 2; q >= 0; q--)
-        if (alive[q] && (unsigned)__double2hiint(dg[q]) == mh && (unsigned)__double2loint(dg[q]) == ml) ci = (unsigned)(lane + 64 * q);
-      const int bi = (int)wave_min_u32(ci);
-      const double best = __hiloint2double((int)mh, (int)ml);
-      LSTAMP(1);
-      if (!(best > eps) || (mh | ml) == 0u) { rank = k; break; }     // identical in every wave
-      const int pv = bi, pq = pv >> 6, pl = pv & 63;
-      const double piv = best, inv = 1.0 / piv;
-      const double zsel = pq == 0 ? bzr[0] : (pq == 1 ? bzr[1] : bzr[2]);
-      const double zk = __shfl(zsel, pl, 64);
-      double *cb = colbuf[k & 1];
-      const int pr = pv / R, pc = pv - pr * R;
-      if (owner_active && ti == pr) {                         // symmetric: row p_k == column p_k
-#pragma unroll
-        for (int c = 0; c < R; c++) {
-          double v = a[0][c];
-#pragma unroll
-          for (int r = 1; r < R; r++) v = pc == r ? a[r][c] : v;
-          cb[tj * R + c] = v;
-        }
-      }
-      // (LDS traffic only: __syncthreads() also drains the vector-memory counter — the J0 row the previous step streamed out)
-      LSTAMP(2);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      LSTAMP(3);
-      double cx[3];
-#pragma unroll
-      for (int q = 0; q < 3; q++) cx[q] = cb[lane + 64 * q];
-      if (wv == (k & (LDLT_THREADS / 64 - 1))) {                                   // row k of J0, r0[k]
-        const double rs = 1.0 / sqrt(piv);
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const int i = lane + 64 * q;
-          if (i < n) J0[(size_t)k * n + i] = i == pv ? sqrt(piv) : (alive[q] ? cx[q] * rs : 0.0);
-        }
-        if (lane == 0) r0[k] = zk * rs;
-      }
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const double li = cx[q] * inv;
-        dg[q] -= li * cx[q];
-        bzr[q] -= li * zk;
-        if (lane + 64 * q == pv) alive[q] = false;
-      }
-      LSTAMP(4);
-      if (owner_active) {
-        double ci[R], cj[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) { ci[r] = cb[ti * R + r] * inv; cj[r] = cb[tj * R + r]; }
-#pragma unroll
-        for (int r = 0; r < R; r++)
-#pragma unroll
-          for (int c = 0; c < R; c++) a[r][c] -= ci[r] * cj[c];
-      }
-      LSTAMP(5);
-    }
-#undef LSTAMP
-    for (int e = t + rank * n; e < n * n; e += blockDim.x) J0[e] = 0.0;
-    for (int k = t + rank; k < n; k += blockDim.x) r0[k] = 0.0;
-    return rank;
-}
 
 // R = 4: priors of up to 88 dims (the 86 of the shipped configuration: 16 matrix registers per thread, two workgroups per CU);
 // R = 8: larger ones (up to 176). Both are launched when a batch may hold both kinds; a workgroup leaves the other kind alone.
@@ -718,13 +759,20 @@ __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   double *J0 = d.mJ0 + (size_t)w * ND * ND;
   double *r0 = d.mr0 + (size_t)w * ND;
   double *stamp = d.timing + 24;
-  const int rank = ldlt_registers<R>(A, bv, J0, r0, n, d.opt.marg_eps, d.timing + (size_t)d.B * 32);
+  const int rank = ldlt_registers<R>([&](int i, int j) { return A[(size_t)i * n + j]; }, [&](int i) { return bv[i]; }, J0, r0, n, d.opt.marg_eps,
+                                     d.timing + (size_t)d.B * 32);
   if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
 }
 
 // MARGIN_OLD: the partials of the marginalisation set at the re-anchored state (visual factors of the landmarks
 // starting in frame 0, the inertial / wheel factor of frame 0, their Schur partial)
 void launch_marginalize_partials(const BatchDev &d, hipStream_t s) {
+  if ((GFBE_FUSE_SMALL & 8) && d.B < DENSE_SPLIT_MIN_B && d.vis_Hs && !d.sharded && d.max_tiles > 0) {   // (small batches: two launches instead of four)
+    launch_lin_small(d, 2, s);
+    launch_pair_schur_marg(d, s);
+    launch_gnss(d, 2, s);
+    return;
+  }
   launch_vis(d, 2, s);
   launch_pair(d, 1, s);
   launch_dense_factors(d, 2, 0, s);
