@@ -13,9 +13,6 @@
 #ifndef GFBE_LIN_SMALL_KS
 #define GFBE_LIN_SMALL_KS 4
 #endif
-#ifndef GFBE_ASM_WGS_SMALL
-#define GFBE_ASM_WGS_SMALL 64   // k_assemble, small batches: workgroups per window (16 -> 64: 1.518 -> 1.497 ms per single-window solve)
-#endif
 
 // Small batches (< 32 windows, no landmark sharding): launches of one iteration merged on a single window's latency path. Bit 0:
 // k_schur + k_visblock_small in one launch; bit 1: k_step and the dense half of k_candidate by the workgroup of k_lm_step that

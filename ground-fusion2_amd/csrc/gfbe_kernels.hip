@@ -258,7 +258,11 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   const WinCtl &c = d.ctl[w];
   if (MODE == 0 && (c.done || c.reuse)) return;
   if (MODE == 1 && (c.done || !c.have_step)) return;
-  const int sframe = d.tile_start[ds.tile_off + tile];
+  // start frame of the tile from the descriptor's own table (scalar loads next to n_tiles) instead of tile_start[]: one dependent
+  // memory round trip less before the pair constants can be fetched
+  int sframe = 0;
+#pragma unroll
+  for (int q = 1; q < NF; q++) sframe += (tile >= ds.sf_tile_begin[q]) ? 1 : 0;
   if (MODE == 2 && sframe != 0) return;
   const int buf = (MODE == 1) ? 1 - c.cur : c.cur;
   const double *X = (MODE == 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
@@ -948,7 +952,6 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
     const int slot = ds.lm_off + tile * LM_TILE + l;
     ps = d.tile_start[ds.tile_off + tile];
     pm0 = d.lm_info[ds.lm_off + tile * LM_TILE];
-    const int kmax = NF - 1 - ps;       // observing poses ps+1 .. 10
     pinfo = d.lm_info[slot];
     pHll = d.lm_Hll[slot];
     psl = first ? 1.0 : d.lm_sl[slot];
@@ -961,7 +964,7 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
       for (int u = 0; u < 4; u++) {
         const int k = part - 1 + 3 * u;
 #pragma unroll
-        for (int q = 0; q < 6; q++) pre[u * 6 + q] = (k < kmax) ? d.lm_hP[((size_t)k * 6 + q) * TL + slot] : 0.0;
+        for (int q = 0; q < 6; q++) pre[u * 6 + q] = (k < MAXOBS) ? d.lm_hP[((size_t)k * 6 + q) * TL + slot] : 0.0;   // (rows past a track's length — past kmax — are zero in memory, and not staged below: the loads do not wait for the tile's start frame)
       }
     }
   };
@@ -1383,33 +1386,58 @@ __global__ __launch_bounds__(VB_GROUP) void k_schur_visblock_small(BatchDev d) {
 #endif
 // The assembly of window w by the threads gt, gt + gn, ... of its workgroup(s). vis_w: the visual block [73][74] (vis_H in global
 // memory, or the LDS array k_visasm built it in — a generic pointer either way); tb: an LDS table of the calling kernel.
-__device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, const double *vis_w, AsmTab &tb, const int gt, const int gn) {
+struct AsmCommon {
+  bool dense_here, vsplit, lio_on;
+  int lio_o, ntri;
+  double *H, *g, *E, *eg;
+  const int4 *tab;
+  const double *imu_w, *wheel_w, *prior_w, *vis_s, *Z;
+};
+__device__ __forceinline__ void asm_stage_tables(const BatchDev &d, const int w, AsmTab &tb) {     // (the caller's block barrier follows)
   const WinDesc &ds = d.desc[w];
   const int t = threadIdx.x;
-  const double *Z = d.zero;
   for (int a = t; a < ND; a += blockDim.x) { tb.prior_map[a] = ds.prior_map[a]; tb.act[a] = ds.act[a]; }
   if (t < NF) { tb.imu_of_frame[t] = ds.imu_of_frame[t]; tb.wheel_of_frame[t] = ds.wheel_of_frame[t]; }
   if (t == 0) { tb.prior_n = ds.prior_n; tb.n_wheel = ds.n_wheel; tb.n_plane = ds.n_plane; tb.use_anchor = ds.use_anchor; }
-  __syncthreads();
-  const bool dense_here = (d.rank == 0);   // landmark sharding: the inertial / wheel / prior factors are added once (rank 0)
-  double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
-  double *E = d.E + (size_t)w * NV * NV, *eg = d.eg + (size_t)w * NV;
-  const int4 *tab = (const int4 *)d.asm_tab;
-  const double *imu_w = d.imu_part + (size_t)w * MAX_IMU * IMU_PART, *wheel_w = d.wheel_part + (size_t)w * MAX_WHEEL * WHEEL_PART;
-  const double *prior_w = d.prior_H + (size_t)w * ND * ND;
-  const bool vsplit = d.vis_Hs != nullptr;
-  const bool lio_on = vsplit && ds.lio_n > 0 && d.rank == 0;
-  const int lio_o = 6 * ds.lio_frame;
-  const double *vis_s = vsplit ? d.vis_Hs + (size_t)w * VS_BLOCKS * NV * V_LD : Z;
-  const int ntri = d.nu * (d.nu + 1) / 2;      // the table is ordered by the larger dim: a batch without GNSS windows stops after the 187 core dims
-  for (int e0 = gt; e0 < ntri; e0 += 4 * gn) {
-    int4 ent[4];
+}
+__device__ __forceinline__ AsmCommon asm_common(const BatchDev &d, const int w) {
+  const WinDesc &ds = d.desc[w];
+  AsmCommon c;
+  c.Z = d.zero;
+  c.dense_here = (d.rank == 0);   // landmark sharding: the inertial / wheel / prior factors are added once (rank 0)
+  c.H = d.H + (size_t)w * ND * ND; c.g = d.g + (size_t)w * ND;
+  c.E = d.E + (size_t)w * NV * NV; c.eg = d.eg + (size_t)w * NV;
+  c.tab = (const int4 *)d.asm_tab;
+  c.imu_w = d.imu_part + (size_t)w * MAX_IMU * IMU_PART; c.wheel_w = d.wheel_part + (size_t)w * MAX_WHEEL * WHEEL_PART;
+  c.prior_w = d.prior_H + (size_t)w * ND * ND;
+  c.vsplit = d.vis_Hs != nullptr;
+  c.lio_on = c.vsplit && ds.lio_n > 0 && d.rank == 0;
+  c.lio_o = 6 * ds.lio_frame;
+  c.vis_s = c.vsplit ? d.vis_Hs + (size_t)w * VS_BLOCKS * NV * V_LD : c.Z;
+  c.ntri = d.nu * (d.nu + 1) / 2;      // the table is ordered by the larger dim: a batch without GNSS windows stops after the 187 core dims
+  return c;
+}
+#define ASM_UNPACK(c)                                                                                                              \
+  const bool dense_here = (c).dense_here, vsplit = (c).vsplit, lio_on = (c).lio_on; const int lio_o = (c).lio_o, ntri = (c).ntri;   \
+  double *H = (c).H, *g = (c).g, *E = (c).E, *eg = (c).eg; const int4 *tab = (c).tab; const double *Z = (c).Z;                    \
+  const double *imu_w = (c).imu_w, *wheel_w = (c).wheel_w, *prior_w = (c).prior_w, *vis_s = (c).vis_s;                            \
+  (void)dense_here; (void)vsplit; (void)lio_on; (void)lio_o; (void)ntri; (void)H; (void)g; (void)E; (void)eg; (void)tab; (void)Z;  \
+  (void)imu_w; (void)wheel_w; (void)prior_w; (void)vis_s
+// H: the lower triangle, entries gt, gt + gn, ... of the table (pre: the first pass's four table entries, fetched by the caller
+// before the tables were staged — or nullptr)
+// U: entries per thread and pass; VSPLIT: the visual entry is the sum of k_visblock_small's start-frame blocks (small batches)
+template <int U, bool VSPLIT>
+__device__ __forceinline__ void asm_H(const BatchDev &d, const int w, const double *vis_w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn,
+                                      const int4 *pre) {
+  ASM_UNPACK(cm);
+  for (int e0 = gt; e0 < ntri; e0 += U * gn) {
+    int4 ent[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const int e = e0 + u * gn; ent[u] = e < ntri ? tab[e] : make_int4(-1, 0, 0, 0); }
-    const double *p[4][6];
-    bool on[4];
+    for (int u = 0; u < U; u++) { const int e = e0 + u * gn; ent[u] = (pre && e0 == gt) ? pre[u] : (e < ntri ? tab[e] : make_int4(-1, 0, 0, 0)); }
+    const double *p[U][6];
+    bool on[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
       on[u] = ent[u].x >= 0 && tb.act[a] && tb.act[b];
       const int y = (on[u] && dense_here) ? ent[u].y : 0, z = (on[u] && dense_here && tb.n_wheel > 0) ? ent[u].z : 0;
@@ -1422,23 +1450,34 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
       p[u][3] = r1 >= 0 ? wheel_w + r1 * WHEEL_PART + ((z >> 20) & 1023) : Z;
       const int pa = on[u] && dense_here && tb.prior_n > 0 ? tb.prior_map[b] : -1, pb = on[u] && dense_here && tb.prior_n > 0 ? tb.prior_map[a] : -1;
       p[u][4] = (pa >= 0 && pb >= 0) ? prior_w + (size_t)pa * tb.prior_n + pb : Z;
-      p[u][5] = (on[u] && a < NV && !vsplit) ? vis_w + b * V_LD + a : Z;
+      p[u][5] = (on[u] && a < NV && !VSPLIT) ? vis_w + b * V_LD + a : Z;
     }
-    double v[4];
+    // small batches: the visual entry is the sum of the start-frame blocks, in start-frame order. Their loads are issued with the
+    // factors' (unconditionally: a zero slot with stride 0 where the entry has no visual part), the sums follow below
+    double blk[VSPLIT ? U : 1][VS_BLOCKS];
+    bool vs[U];
+    if (VSPLIT) {
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = *p[u][0] + *p[u][1] + *p[u][2] + *p[u][3] + *p[u][4] + *p[u][5];
-    if (vsplit) {   // small batches: the visual entry is the sum of the start-frame blocks, in start-frame order (loads in flight together)
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < U; u++) {
         const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
-        if (!(on[u] && a < NV)) continue;
-        const double *q = vis_s + b * V_LD + a;
-        double blk[VS_BLOCKS];
+        vs[u] = on[u] && a < NV;
+        const double *q = vs[u] ? vis_s + b * V_LD + a : Z;
+        const size_t st = vs[u] ? (size_t)NV * V_LD : 0;
 #pragma unroll
-        for (int f = 0; f < VS_BLOCKS; f++) blk[f] = q[(size_t)f * NV * V_LD];
+        for (int f = 0; f < VS_BLOCKS; f++) blk[VSPLIT ? u : 0][f] = q[f * st];
+      }
+    }
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = *p[u][0] + *p[u][1] + *p[u][2] + *p[u][3] + *p[u][4] + *p[u][5];
+    if (VSPLIT) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
+        if (!vs[u]) continue;
         double sv = 0.0;
 #pragma unroll
-        for (int f = 0; f < VS_BLOCKS; f++) sv += blk[f];
+        for (int f = 0; f < VS_BLOCKS; f++) sv += blk[VSPLIT ? u : 0][f];
         if (lio_on && b >= lio_o && a < lio_o + 6) {   // LiDAR block of pose lio_frame: added last, as the one-workgroup form does
           const int ra = b - lio_o, rb = a - lio_o;      // ra <= rb: packed upper triangle of k_lio_window
           const int e = ra * 6 - ra * (ra - 1) / 2 + (rb - ra);
@@ -1450,7 +1489,7 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       if (ent[u].x < 0) continue;
       const int a = ent[u].x & 255, b = (ent[u].x >> 8) & 255;
       double x = v[u];
@@ -1469,7 +1508,10 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
       H[(size_t)a * ND + b] = x;   // lower triangle only (b <= a): k_solve never reads the mirror
     }
   }
-  // E (73 x 73, symmetric), eg
+}
+// E (73 x 73, symmetric): entries gt, gt + gn, ... of its triangle
+__device__ __forceinline__ void asm_E(const BatchDev &d, const int w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
+  ASM_UNPACK(cm);
   for (int e = gt; e < NV * (NV + 1) / 2; e += gn) {
     int a, b;
     tri_decode(e, a, b);
@@ -1477,6 +1519,10 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
     E[a * NV + b] = ev;
     E[b * NV + a] = ev;
   }
+}
+// g and eg: dims gt, gt + gn, ...
+__device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const double *vis_w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
+  ASM_UNPACK(cm);
   for (int a = gt; a < ND; a += gn) {
     double v = 0.0;
     if (tb.act[a]) {
@@ -1499,14 +1545,37 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
     if (a < NV) eg[a] = tb.act[a] ? gather_E11(d, Z, w, a, NV) : 0.0;
   }
 }
-// small batches: GFBE_ASM_WGS_SMALL workgroups per window (a single window's latency wants them side by side), the visual blocks
-// from k_visblock_small
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d) {
-  const int w = blockIdx.y;
+__device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, const double *vis_w, AsmTab &tb, const int gt, const int gn) {
+  asm_stage_tables(d, w, tb);
+  __syncthreads();
+  const AsmCommon cm = asm_common(d, w);
+  asm_H<4, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);     // (k_visasm: throughput batches, the visual block in the caller's LDS)
+  asm_E(d, w, tb, cm, gt, gn);
+  asm_g(d, w, vis_w, tb, cm, gt, gn);
+}
+// small batches (a single window's latency): the visual blocks come from k_visblock_small, and every thread has ONE item — the
+// workgroups [0, nH) take an entry of H each (the table entry is fetched before the descriptor tables are staged), the next
+// ASM_E_WGS an entry of E, the last one g and eg — instead of an H entry, then an E entry, then a gradient entry one after the other:
+// the dependent memory round trips of the three parts side by side (14.1 -> ~11 us per launch for one window).
+#define ASM_E_WGS ((NV * (NV + 1) / 2 + ASM_THREADS - 1) / ASM_THREADS)
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d, int nH) {
+  const int w = blockIdx.y, bx = blockIdx.x;
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   __shared__ AsmTab tb;
-  assemble_body(d, w, d.vis_H + (size_t)w * NV * V_LD, tb, blockIdx.x * ASM_THREADS + threadIdx.x, gridDim.x * ASM_THREADS);
+  const int gtH = bx * ASM_THREADS + threadIdx.x, gnH = nH * ASM_THREADS;
+  int4 pre[1] = {make_int4(-1, 0, 0, 0)};
+  if (bx < nH) {
+    const int ntri = d.nu * (d.nu + 1) / 2;
+    if (gtH < ntri) pre[0] = ((const int4 *)d.asm_tab)[gtH];
+  }
+  asm_stage_tables(d, w, tb);
+  __syncthreads();
+  const AsmCommon cm = asm_common(d, w);
+  const double *vis_w = d.vis_H + (size_t)w * NV * V_LD;
+  if (bx < nH) asm_H<1, true>(d, w, vis_w, tb, cm, gtH, gnH, pre);
+  else if (bx < nH + ASM_E_WGS) asm_E(d, w, tb, cm, (bx - nH) * ASM_THREADS + threadIdx.x, ASM_E_WGS * ASM_THREADS);
+  else asm_g(d, w, vis_w, tb, cm, threadIdx.x, ASM_THREADS);
 }
 // throughput batches: ONE workgroup per window builds the visual block in LDS and assembles from there. (Measured, 1024 windows:
 // 16 workgroups of 256 threads per window took 313 us per launch with the SIMDs half empty — the kernel was bound by the
@@ -2087,7 +2156,10 @@ void launch_visblock(const BatchDev &d, hipStream_t s) {       // (throughput ba
   if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(VS_BLOCKS, d.B), dim3(VB_GROUP), 0, s, d);
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
-  if (d.vis_Hs) hipLaunchKernelGGL(k_assemble, dim3(GFBE_ASM_WGS_SMALL, d.B), dim3(ASM_THREADS), 0, s, d);
+  if (d.vis_Hs) {
+    const int nH = (d.nu * (d.nu + 1) / 2 + ASM_THREADS - 1) / ASM_THREADS;      // one entry of H per thread
+    hipLaunchKernelGGL(k_assemble, dim3(nH + ASM_E_WGS + 1, d.B), dim3(ASM_THREADS), 0, s, d, nH);
+  }
   else hipLaunchKernelGGL(k_visasm, dim3(d.B), dim3(VB_GROUP), 0, s, d);
 }
 // Landmark sharding: the partial reduced system of a window, packed for the all-reduce — the lower triangle of H over the dims
