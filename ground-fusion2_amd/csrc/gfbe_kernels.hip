@@ -186,6 +186,19 @@ __global__ __launch_bounds__(256) void k_prep_prior(BatchDev d) {
 // calling workgroup; `sp` = 12 PoseRT of LDS), one pair per lane. Called by the kernels that produce a state; the visual
 // tiles (36 workgroups per window and pass) load the records instead of rebuilding them from the poses each.
 static_assert(PC_DOUBLES == PAIR_CONST_DOUBLES, "PairConst layout");
+// (second half of pair_consts_of_state: the NF + 1 poses are staged in sp, the caller's barrier has passed)
+__device__ __forceinline__ void pair_consts_from_staged(double *pc_out, const PoseRT *sp, int lane) {
+  if (lane < NF * (NF - 1) / 2) {
+    int i = 0, rem = lane;
+    while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
+    const int j = i + 1 + rem;
+    const PairConst p = make_pair_const(sp[i], sp[j], sp[NF]);
+    double *o = pc_out + (size_t)(i * NF + j) * PC_DOUBLES;
+    const double *src = (const double *)&p;
+#pragma unroll
+    for (int q = 0; q < PC_DOUBLES; q++) o[q] = src[q];
+  }
+}
 __device__ __forceinline__ void pair_consts_of_state(const double *X, double *pc_out, PoseRT *sp, int lane) {
   if (lane < NF) sp[lane] = make_pose(X + A_POSE(lane));
   if (lane == NF) sp[NF] = make_pose(X + A_EX);
@@ -1711,7 +1724,15 @@ __global__ __launch_bounds__(LM_TILE) void k_lam_mask(BatchDev d) {
   d.lam[(size_t)d.tot_lm + slot] = 0.0;
 }
 
-__device__ __forceinline__ void step_body(const BatchDev &d, const WinDesc &ds, WinCtl &c, const int w, const int lane) {
+// c: the scalars of the window's trust-region state — WinCtl itself, or a register copy of them (StepLocal: k_lm_step_fused loads it
+// before its workgroup arrives); cg: WinCtl in memory, for the per-iteration records (stores only).
+struct StepLocal {
+  int done, have_step, reuse, iter, termination, status, invalid_steps;
+  double G2, N2, gy, vHv, vHy, yHy, grad_max, x_norm, alpha, radius, c1, c2, step_norm, model_change, cost, mu;
+  long long t_start;
+};
+template <class CT>
+__device__ __forceinline__ void step_body(const BatchDev &d, const WinDesc &ds, CT &c, WinCtl &cg, const int w, const int lane) {
   if (c.done) return;
   if (c.have_step == 2) {   // fresh linearisation: fold in the landmark shares (lanes stride the tiles; fixed tree order)
     double p[8];
@@ -1762,7 +1783,7 @@ __device__ __forceinline__ void step_body(const BatchDev &d, const WinDesc &ds, 
   const double model_change = -(c1 * c.G2 + c2 * c.gy) - 0.5 * (c1 * c1 * c.vHv + 2.0 * c1 * c2 * c.vHy + c2 * c2 * c.yHy);
   c.c1 = c1; c.c2 = c2; c.step_norm = step_norm; c.model_change = model_change;
   if (!(model_change > 0.0)) {   // TrustRegionMinimizer::HandleInvalidStep
-    c.accepted[it] = 0; c.cost_history[it] = c.cost;
+    cg.accepted[it] = 0; cg.cost_history[it] = c.cost;
     if (++c.invalid_steps >= 5) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; return; }
     c.mu *= GF_MU_INC; c.reuse = 0;
     return;
@@ -1772,7 +1793,7 @@ __device__ __forceinline__ void step_body(const BatchDev &d, const WinDesc &ds, 
 }
 __global__ __launch_bounds__(64) void k_step(BatchDev d) {
   const int w = blockIdx.x;
-  step_body(d, d.desc[w], d.ctl[w], w, threadIdx.x);
+  step_body(d, d.desc[w], d.ctl[w], d.ctl[w], w, threadIdx.x);
 }
 
 // =============================================================================================
@@ -1887,13 +1908,73 @@ __device__ __forceinline__ bool arrive_last(int *cnt, const int expected, const 
   if (lane == 0) *cnt = 0;     // (ready for the next launch)
   return true;
 }
+// What the tail needs and no workgroup of this launch writes — the trust-region scalars, this lane's parameter blocks with their scale
+// / Cauchy / Gauss-Newton entries — is loaded BEFORE the workgroup arrives (by every workgroup: any of them may be the last), so
+// that after the arrival only the tiles' dogleg shares are fetched: the tail was five dependent memory round trips longer without.
+// The arithmetic is step_body's and candidate_dense's, operand for operand.
+struct BlockPre {       // one parameter block of a lane
+  int off, am, gs, ls;
+  bool on, is_free;
+  double sp[9], vp[9], yp[9], X[9];
+  unsigned char mask[6];
+  bool has_mask;
+};
+template <int MAXS>
+__device__ __forceinline__ void block_preload(const BatchDev &d, const WinDesc &ds, const int w, const double *X, const int b, BlockPre &q) {
+  q.on = b < GFBE_BLK_COUNT;
+  const int bb = q.on ? b : 0;
+  q.off = blk_tan(bb); q.am = blk_amb(bb); q.gs = q.on ? blk_gsize(bb) : 0; q.ls = q.on ? blk_lsize(bb) : 0;
+  q.is_free = q.on && ds.blk_free[bb];
+  q.has_mask = (bb == GFBE_BLK_EX_CAM || bb == GFBE_BLK_EX_WHEEL);
+#pragma unroll
+  for (int k = 0; k < 6; k++) q.mask[k] = q.has_mask ? (bb == GFBE_BLK_EX_CAM ? ds.ex_cam_mask[k] : ds.ex_wheel_mask[k]) : 0;
+#pragma unroll
+  for (int k = 0; k < MAXS; k++) {
+    const size_t a = (size_t)w * ND + q.off + min(k, max(q.ls - 1, 0));
+    const bool in = q.is_free && k < q.ls;
+    q.sp[k] = in ? d.sp[a] : 0.0; q.vp[k] = in ? d.vp[a] : 0.0; q.yp[k] = in ? d.yp[a] : 0.0;
+    q.X[k] = k < q.gs ? X[q.am + k] : 0.0;
+  }
+}
+// x_cand of one block from its preloaded entries (candidate_dense's loop body); Yl: the candidate block
+template <int MAXS>
+__device__ __forceinline__ void block_candidate(const BatchDev &d, const int w, const BlockPre &q, const double c1, const double c2, double *Y, double (&Yl)[9],
+                                                double &d2, double &n2) {
+  if (!q.on) return;
+  if (q.is_free) {
+    double dl[9];
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) {
+      dl[k] = q.sp[k] * (c1 * q.vp[k] + c2 * q.yp[k]);
+      if (k < q.ls) d.step[(size_t)w * ND + q.off + k] = dl[k];
+    }
+    if (MAXS >= 7 && q.gs == 7) {
+      pose_plus(q.X, dl, q.has_mask ? q.mask : nullptr, Yl);
+    } else if (MAXS >= 4 && q.gs == 4) {   // para_plane_R: OrientationSubsetParameterization({2}) (estimator.cpp:3122)
+      const unsigned char constant[3] = {0, 0, 1};
+      orientation_plus(q.X, dl, constant, Yl);
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAXS; k++) Yl[k] = q.X[k] + dl[k];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) if (k < q.gs) { const double df = q.X[k] - Yl[k]; d2 += df * df; n2 += Yl[k] * Yl[k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < MAXS; k++) Yl[k] = q.X[k];
+  }
+#pragma unroll
+  for (int k = 0; k < MAXS; k++) if (k < q.gs) Y[q.am + k] = Yl[k];
+}
 __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d) {
+  static_assert(GFBE_BLK_COUNT <= 128 && GFBE_BLK_RCV_DT0 <= 64, "two blocks per lane, the second one a scalar block");
   const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   const int t = threadIdx.x;
   __shared__ double sy[NV], sv[NV];
   __shared__ PoseRT sp_cand[NF + 1];
+  const int cur = c.cur;
   if (tile < ds.n_tiles && !(c.done || c.reuse)) {
     for (int a = t; a < NV; a += LM_TILE) {
       const double s = d.sp[(size_t)w * ND + a];
@@ -1903,11 +1984,41 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d) {
     __syncthreads();
     lm_step_tile(d, ds, c, w, tile, t, sy, sv);
   }
+  // ---- preloads of the tail
+  StepLocal lc;
+  lc.done = c.done; lc.have_step = c.have_step; lc.reuse = c.reuse; lc.iter = c.iter; lc.termination = c.termination; lc.status = c.status;
+  lc.invalid_steps = c.invalid_steps;
+  lc.G2 = c.G2; lc.N2 = c.N2; lc.gy = c.gy; lc.vHv = c.vHv; lc.vHy = c.vHy; lc.yHy = c.yHy; lc.grad_max = c.grad_max; lc.x_norm = c.x_norm;
+  lc.alpha = c.alpha; lc.radius = c.radius; lc.c1 = c.c1; lc.c2 = c.c2; lc.step_norm = c.step_norm; lc.model_change = c.model_change;
+  lc.cost = c.cost; lc.mu = c.mu; lc.t_start = c.t_start;
+  const double *X = d.x + ((size_t)w * 2 + cur) * NA;
+  double *Y = d.x + ((size_t)w * 2 + 1 - cur) * NA;
+  BlockPre q0, q1;
+  block_preload<9>(d, ds, w, X, t, q0);
+  block_preload<1>(d, ds, w, X, t + 64, q1);
   if (!arrive_last(d.win_cnt + 2 * w, gridDim.y, t)) return;
-  step_body(d, ds, c, w, t);
-  __threadfence();      // (lane 0 wrote c1, c2, have_step: every lane reads them below)
-  if (c.done || !c.have_step) return;
-  candidate_dense(d, ds, c, w, t, sp_cand, true);
+  // ---- k_step
+  step_body(d, ds, lc, c, w, t);
+  if (t == 0) {
+    c.done = lc.done; c.have_step = lc.have_step; c.reuse = lc.reuse; c.iter = lc.iter; c.termination = lc.termination; c.status = lc.status;
+    c.invalid_steps = lc.invalid_steps;
+    c.G2 = lc.G2; c.N2 = lc.N2; c.gy = lc.gy; c.vHv = lc.vHv; c.vHy = lc.vHy; c.yHy = lc.yHy; c.grad_max = lc.grad_max; c.x_norm = lc.x_norm;
+    c.alpha = lc.alpha; c.c1 = lc.c1; c.c2 = lc.c2; c.step_norm = lc.step_norm; c.model_change = lc.model_change; c.mu = lc.mu;
+  }
+  const int go = __shfl((lc.done || !lc.have_step) ? 0 : 1, 0, 64);       // (lane 0 ran the scalar logic)
+  if (!go) return;
+  const double c1 = __shfl(lc.c1, 0, 64), c2 = __shfl(lc.c2, 0, 64);
+  // ---- the dense parameter blocks of k_candidate
+  double d2 = 0.0, n2 = 0.0, Yl0[9], Yl1[9];
+  block_candidate<9>(d, w, q0, c1, c2, Y, Yl0, d2, n2);
+  block_candidate<1>(d, w, q1, c1, c2, Y, Yl1, d2, n2);
+  d2 = wave_sum(d2); n2 = wave_sum(n2);
+  if (t == 0) { d.dense_cand[(size_t)w * 4 + 1] = d2; d.dense_cand[(size_t)w * 4 + 2] = n2; }
+  // the candidate's pose-pair constants: the poses straight from the lanes that formed them (block id = lane: Pose[t]; the camera extrinsic)
+  if (t < NF) sp_cand[t] = make_pose(Yl0);
+  if (t == GFBE_BLK_EX_CAM) sp_cand[NF] = make_pose(Yl0);
+  __syncthreads();
+  pair_consts_from_staged(d.pc + ((size_t)w * 3 + (1 - cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
 }
 
 // =============================================================================================
