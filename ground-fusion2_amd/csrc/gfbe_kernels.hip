@@ -862,7 +862,12 @@ __global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mod
 // prior factors of a linearisation (MODE 0) or of a candidate evaluation (MODE 1) in ONE launch — the ~35 us of a single
 // lane evaluating an IMU factor hide behind the visual tiles instead of following them on the stream.
 __device__ __forceinline__ void candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
-__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane);
+struct AcceptLocal {
+  int done, have_step, iter, cur, num_successful, termination, status, reuse;
+  double cost, x_norm, model_change, radius, step_norm, mu, cand_cost;
+};
+template <class CT>
+__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane, CT &c, WinCtl &cg);
 __device__ __forceinline__ bool arrive_last(int *cnt, const int expected, const int lane);
 // fuse (MODE 1, GFBE_FUSE_SMALL): bit 1 — a tile workgroup first forms the candidate inverse depths of its tile (the landmark half of
 // k_candidate; the dense half ran at the tail of k_lm_step_fused); bit 2 — the workgroup of a window that finishes last goes on with
@@ -888,8 +893,19 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, 
   if (MODE == 1 && (fuse & 4)) {
     // (a factor's four waves are done with their stores before the workgroup arrives — dense_body leaves workgroup-uniformly —; its first wave goes on)
     if (!tile_wg) { __syncthreads(); if (threadIdx.x >= 64) return; }
+    // (the scalars k_accept reads are this launch's inputs: loaded before the arrival, by every workgroup — any may be the last)
+    WinCtl &c = d.ctl[w];
+    AcceptLocal la;
+    la.done = c.done; la.have_step = c.have_step; la.iter = c.iter; la.cur = c.cur; la.num_successful = c.num_successful;
+    la.termination = c.termination; la.status = c.status; la.reuse = c.reuse;
+    la.cost = c.cost; la.x_norm = c.x_norm; la.model_change = c.model_change; la.radius = c.radius; la.step_norm = c.step_norm; la.mu = c.mu;
+    la.cand_cost = c.cand_cost;
     if (!arrive_last(d.win_cnt + 2 * w + 1, gridDim.y, threadIdx.x)) return;
-    accept_body(d, w, threadIdx.x);
+    accept_body(d, w, threadIdx.x, la, c);
+    if (threadIdx.x == 0) {
+      c.done = la.done; c.have_step = la.have_step; c.cur = la.cur; c.num_successful = la.num_successful; c.termination = la.termination;
+      c.status = la.status; c.reuse = la.reuse; c.cost = la.cost; c.x_norm = la.x_norm; c.radius = la.radius; c.mu = la.mu; c.cand_cost = la.cand_cost;
+    }
   }
 }
 
@@ -2026,9 +2042,11 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d) {
 // (TrustRegionMinimizer::{ParameterToleranceReached,FunctionToleranceReached,IsStepSuccessful,
 //  HandleSuccessfulStep,HandleUnsuccessfulStep}, DoglegStrategy::{StepAccepted,StepRejected}).
 // =============================================================================================
-__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane) {
+// c: the window's trust-region scalars — WinCtl itself or a register copy (AcceptLocal: the fused tail of k_lin_small<1> loads it
+// before its workgroup arrives); cg: WinCtl in memory, for the per-iteration records (stores only).
+template <class CT>
+__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane, CT &c, WinCtl &cg) {
   const WinDesc &ds = d.desc[w];
-  WinCtl &c = d.ctl[w];
   if (c.done || !c.have_step) return;
   double cand = 0.0, d2 = 0.0, n2 = 0.0;
   if (!d.sharded) tile_cand_sum(d, ds, w, lane, cand, d2, n2);
@@ -2049,7 +2067,7 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
   if (!isfinite(cand)) cand = 1.7976931348623157e308;
   const int it = c.iter;
   c.cand_cost = cand;
-  c.cost_history[it] = c.cost;
+  cg.cost_history[it] = c.cost;
   const double step_amb = sqrt(d2);
   if (step_amb <= d.opt.parameter_tolerance * (c.x_norm + d.opt.parameter_tolerance)) {
     c.done = 1; c.termination = 2; c.status = GFBE_OK; c.have_step = 0; return;
@@ -2063,20 +2081,20 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
     c.cur = 1 - c.cur;
     c.cost = cand;
     c.x_norm = sqrt(n2);
-    c.accepted[it] = 1; c.num_successful++;
-    c.cost_history[it] = cand;
+    cg.accepted[it] = 1; c.num_successful++;
+    cg.cost_history[it] = cand;
     if (quality < 0.25) c.radius *= 0.5;
     if (quality > 0.75) c.radius = fmax(c.radius, 3.0 * c.step_norm);
     c.mu = fmax(GF_MIN_MU, 2.0 * c.mu / GF_MU_INC);
     c.reuse = 0;
   } else {
-    c.accepted[it] = 0;
+    cg.accepted[it] = 0;
     c.radius *= 0.5;
     c.reuse = 1;
   }
   c.have_step = 0;
 }
-__global__ __launch_bounds__(64) void k_accept(BatchDev d) { accept_body(d, blockIdx.x, threadIdx.x); }
+__global__ __launch_bounds__(64) void k_accept(BatchDev d) { accept_body(d, blockIdx.x, threadIdx.x, d.ctl[blockIdx.x], d.ctl[blockIdx.x]); }
 
 // =============================================================================================
 // k_reanchor: double2vector()'s yaw / position gauge fix followed by vector2double()
