@@ -10,8 +10,11 @@
 
 #include "../../include/gfbe.h"
 
+#ifndef GFBE_LIN_SMALL_THREADS
+#define GFBE_LIN_SMALL_THREADS 256
+#endif
 #ifndef GFBE_LIN_SMALL_KS
-#define GFBE_LIN_SMALL_KS 4
+#define GFBE_LIN_SMALL_KS 5     // (4 -> 5 once the wheel factor and the tails were out of the way: 1.244 -> 1.227 ms per single-window solve; 10: 1.316)
 #endif
 
 // Small batches (< 32 windows, no landmark sharding): launches of one iteration merged on a single window's latency path. Bit 0:
@@ -50,7 +53,7 @@ enum {
   ANCHOR_PART = 6 * 6 + 6 + 2,
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   LIN_SMALL_KS = GFBE_LIN_SMALL_KS,   // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
-  LIN_SMALL_THREADS = 256,    // k_lin_small: threads per workgroup (one wave per visual tile item, four for an inertial / wheel / prior item)
+  LIN_SMALL_THREADS = GFBE_LIN_SMALL_THREADS,    // k_lin_small: threads per workgroup (one wave per visual tile item, four for an inertial / wheel / prior item)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)

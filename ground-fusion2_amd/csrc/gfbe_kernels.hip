@@ -263,6 +263,9 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 // kq takes the steps k = kq, kq + KS, ..., every step's CONTRIBUTION to the running sums goes to a scratch array, and the
 // workgroup that arrives last (an atomic counter per tile; nobody waits for anybody) adds them up in step order: the same
 // additions in the same order as the one-wave loop of the throughput path, so the results stay bit-identical to it.
+#ifndef GFBE_LIN_STAMP
+#define GFBE_LIN_STAMP 0
+#endif
 #define VC_STRIDE 16      // doubles per (step, lane) in vis_contrib: Hll, gl, hC[<= 13], cost
 template <int MODE, bool FULL, int KS = 1>
 __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile, const int kq = 0) {
@@ -879,6 +882,14 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, 
   // four waves per workgroup: a visual tile is one wave's work (the others leave at once); the inertial / wheel / prior items use
   // all four — the single lane that evaluated an IMU factor was the longest chain of the launch
   const bool tile_wg = y < d.max_tiles * KS;
+#if GFBE_LIN_STAMP
+  // diagnostics build (scratch/lin_stamps.py): start of workgroup 0 and the latest end per kind of item, of the LAST launch of MODE 0
+  unsigned long long *ls = (unsigned long long *)(d.timing + (size_t)d.B * 32);
+  if (MODE == 0 && y == 0 && threadIdx.x == 0) ls[0] = wall_clock64();
+  if (MODE == 0 && y == d.max_tiles * KS && threadIdx.x == 0) ls[8] = wall_clock64();                 // first inertial item starts
+  if (MODE == 0 && y == d.max_tiles * KS + MAX_IMU && threadIdx.x == 0) ls[9] = wall_clock64();       // first wheel item starts
+  if (MODE == 0 && y == d.max_tiles * KS + MAX_IMU + MAX_WHEEL && threadIdx.x == 0) ls[10] = wall_clock64();   // the prior starts
+#endif
   if (tile_wg) {
     if (threadIdx.x >= LM_TILE) return;
     if (MODE == 1 && (fuse & 2)) {
@@ -890,6 +901,16 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, 
   } else {
     dense_body<true>(d, MODE, 0, w, y - d.max_tiles * KS);
   }
+#if GFBE_LIN_STAMP
+  if (MODE == 0 && (threadIdx.x & 63) == 0) {
+    const int f = y - d.max_tiles * KS;
+    const int kind = tile_wg ? 1 : (f < MAX_IMU ? 2 : (f < MAX_IMU + MAX_WHEEL ? 3 : (f == MAX_IMU + MAX_WHEEL ? 4 : 5)));
+    atomicMax(ls + kind, (unsigned long long)wall_clock64());
+    if (tile_wg && y == 0) ls[6] = wall_clock64();
+    if (tile_wg && y == d.max_tiles * KS - 1) ls[7] = wall_clock64();
+    if (threadIdx.x == 0 && f == MAX_IMU) ls[11] = wall_clock64();                                      // first wheel item ends
+  }
+#endif
   if (MODE == 1 && (fuse & 4)) {
     // (a factor's four waves are done with their stores before the workgroup arrives — dense_body leaves workgroup-uniformly —; its first wave goes on)
     if (!tile_wg) { __syncthreads(); if (threadIdx.x >= 64) return; }
@@ -981,6 +1002,7 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
     const int slot = ds.lm_off + tile * LM_TILE + l;
     ps = d.tile_start[ds.tile_off + tile];
     pm0 = d.lm_info[ds.lm_off + tile * LM_TILE];
+    const int kmax = NF - 1 - ps;       // observing poses ps+1 .. 10
     pinfo = d.lm_info[slot];
     pHll = d.lm_Hll[slot];
     psl = first ? 1.0 : d.lm_sl[slot];
@@ -993,7 +1015,7 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
       for (int u = 0; u < 4; u++) {
         const int k = part - 1 + 3 * u;
 #pragma unroll
-        for (int q = 0; q < 6; q++) pre[u * 6 + q] = (k < MAXOBS) ? d.lm_hP[((size_t)k * 6 + q) * TL + slot] : 0.0;   // (rows past a track's length — past kmax — are zero in memory, and not staged below: the loads do not wait for the tile's start frame)
+        for (int q = 0; q < 6; q++) pre[u * 6 + q] = (k < kmax) ? d.lm_hP[((size_t)k * 6 + q) * TL + slot] : 0.0;
       }
     }
   };

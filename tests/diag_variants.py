@@ -16,6 +16,10 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "chainstamp": (["-DGFBE_CHAIN_STAMP=1"], "off"),
     "bigstamp": (["-DGFBE_BIG_STAMP=1"], "off"),
     "ldltstamp": (["-DGFBE_LDLT_STAMP=1"], "off"),
+    "linstamp": (["-DGFBE_LIN_STAMP=1"], "off"),
+    "lin512": (["-DGFBE_LIN_SMALL_THREADS=512"], "off"),
+    "lin1024": (["-DGFBE_LIN_SMALL_THREADS=1024"], "off"),
+    "lin512ks5": (["-DGFBE_LIN_SMALL_THREADS=512", "-DGFBE_LIN_SMALL_KS=5"], "off"),
     "fuse0": (["-DGFBE_FUSE_SMALL=0"], "off"),
     "fuse1": (["-DGFBE_FUSE_SMALL=1"], "off"),
     "fuse3": (["-DGFBE_FUSE_SMALL=3"], "off"),
