@@ -773,7 +773,6 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     const size_t up_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- arrays the kernels expect zeroed at the start (rows past a track's length, partials of absent factors, ...)
     if (tabs) { AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lam0, TL); d.fobs = nullptr; }
-    AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);
     AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
     AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
     AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
@@ -800,6 +799,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(prior_J0, (size_t)B * ND * ND);     // (the n x n prior block arrives by copy; nothing reads past it)
+    AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);   // (k_expand / k_ftab_pack write the rows of a track; the evaluation uses a row only below the track's length: 0.9 of the 2.8 MB per window that used to be cleared)
     AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE);   // (a tile's steps below its longest track are written by k_vis, the others never read)
     AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);   // (k_marg / k_marg_ldlt write what they and k_gather read)
     AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)

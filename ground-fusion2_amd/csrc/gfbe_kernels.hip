@@ -333,7 +333,8 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     double *xr = xs + lane * XLD;
     xr[13] = 0.0; xr[14] = 0.0; xr[15] = 0.0;
   }
-  // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length are zero in memory)
+  // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length hold whatever the memory held —
+  // lm_obs is not cleared at upload — and are used below the track's length only)
   double nob[5];
   {
     const double *ob = d.lm_obs + (size_t)kq * 5 * TL + slot;
