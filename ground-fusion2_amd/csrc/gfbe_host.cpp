@@ -6,6 +6,9 @@
 // Reference being replaced: Estimator::optimization()
 //   Ground-Fusion++/vins_estimator/src/estimator/estimator.cpp:2951-3698
 #include "gfbe_device.h"
+#ifndef GFBE_CLEAR_LM
+#define GFBE_CLEAR_LM 0
+#endif
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -145,6 +148,8 @@ struct gfbe_batch {
   // upload region [0, up_end) of the slab = the pinned mirror up_h; [up_end, zero_end) is cleared; the rest is written before read
   char *up_h = nullptr;
   size_t up_cap = 0, up_bytes = 0, up_end = 0, zero_end = 0;
+  struct PoisonEntry { const char *name; size_t off, bytes; };
+  std::vector<PoisonEntry> poison_list;     // (GFBE_POISON_UNCLEARED test hook: the slab's arrays by name)
   // results: [dl_fix | dl_feat | dl_J0] at the end of the slab -> dl_h (pinned) in one copy
   char *dl_h = nullptr;
   size_t dl_cap = 0, dl_bytes = 0;
@@ -753,6 +758,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   gfbe_gnss_obs *h_gnss = nullptr;
   double *d_pJ0c = nullptr;
   const bool want_rec = c->want_records;
+  const char *poison_env = getenv("GFBE_POISON_UNCLEARED");   // (test hook, see the enqueue below; read per upload)
   for (int pass = 0; pass < 2; pass++) {
     b->dry = pass == 0;
     if (pass == 1) {
@@ -761,7 +767,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       if (!b->up_h) { c->err = "hipHostMalloc(upload staging) failed"; return GFBE_DEVICE_ERROR; }
     }
 #define UP(field, host, n) if ((st = up_alloc(c, b, &d.field, &host, (size_t)(n))) != GFBE_OK) return st
-#define AL(field, n) if ((st = dev_alloc(c, b, &d.field, (size_t)(n))) != GFBE_OK) return st
+#define AL(field, n) do { const size_t o_ = b->slab_off; if ((st = dev_alloc(c, b, &d.field, (size_t)(n))) != GFBE_OK) return st; \
+                          if (!b->dry && poison_env) b->poison_list.push_back({#field, o_, b->slab_off - o_}); } while (0)
     // -- upload region
     UP(desc, h_desc, B); UP(tile_start, h_tile_start, tile_start.size()); UP(x0, h_x0, (size_t)B * NA);
     UP(imu, h_imu, n_imu_tot); UP(wheel, h_wheel, n_wheel_tot); UP(lio, h_lio, (size_t)tot_lio * 8);
@@ -773,12 +780,15 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     const size_t up_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- arrays the kernels expect zeroed at the start (rows past a track's length, partials of absent factors, ...)
     if (tabs) { AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lam0, TL); d.fobs = nullptr; }
+#if GFBE_CLEAR_LM      // (diagnostics: the landmark rows back in the cleared region)
+    AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
+#endif
     AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
     AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
     AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
     if (B < DENSE_SPLIT_MIN_B && !c->allreduce) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
     AL(ctl, B);
-    AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
+    AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL);
     AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
     AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36);
     AL(pair_part, (size_t)B * NF * VP_STRIDE); AL(schur_part, (size_t)B * d.schur_groups * SCHUR_STRIDE);
@@ -799,7 +809,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(prior_J0, (size_t)B * ND * ND);     // (the n x n prior block arrives by copy; nothing reads past it)
+#if !GFBE_CLEAR_LM
     AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);   // (k_expand / k_ftab_pack write the rows of a track; the evaluation uses a row only below the track's length: 0.9 of the 2.8 MB per window that used to be cleared)
+    AL(lm_hP, (size_t)MAXOBS * 6 * TL);    // (k_vis writes the rows below a tile's longest track — zeros past a track's own end —, k_schur masks the others: 1.0 MB per window)
+#endif
     AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE);   // (a tile's steps below its longest track are written by k_vis, the others never read)
     AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);   // (k_marg / k_marg_ldlt write what they and k_gather read)
     AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)
@@ -1005,6 +1018,13 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   const double T3 = now();
   // ---- enqueue: clear what must start as zero, ONE host-to-device copy, then the preparation kernels
   if (b->zero_end > b->up_end) HIPCHK(c, hipMemsetAsync(b->slab + b->up_end, 0, b->zero_end - b->up_end, us));
+  // (test hook, tests/test_gpu_uncleared.py: the part of the slab that is NOT cleared filled with NaN bit patterns — a kernel that
+  //  uses what nobody wrote poisons its results instead of finding the previous batch's numbers there)
+  //  GFBE_POISON_UNCLEARED=1: all of it; =<array name>: that array alone)
+  if (poison_env)
+    for (const auto &pl : b->poison_list)
+      if (pl.off >= b->zero_end && (!strcmp(poison_env, "1") || !strcmp(poison_env, "clean") || !strcmp(poison_env, pl.name)))
+        HIPCHK(c, hipMemsetAsync(b->slab + pl.off, strcmp(poison_env, "clean") ? 0xFF : 0, pl.bytes, us));   // ("clean": zeros, for a scan that poisons one array at a time)
   HIPCHK(c, hipMemcpyAsync(b->slab, b->up_h, b->up_end, hipMemcpyHostToDevice, us));
   if (pj_row > 0)
     HIPCHK(c, hipMemcpy2DAsync(d.prior_J0, sizeof(double) * ND * ND, d_pJ0c, sizeof(double) * pj_row, sizeof(double) * pj_row, B, hipMemcpyDeviceToDevice, us));

@@ -753,8 +753,11 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
 #pragma unroll
     for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; }
   // rows lk, lk + 4, lk + 8 of block k (the third only counts for lk == 0: the others read into the next block and are masked)
+  // (row 8 + lk exists for lk == 0 only: the other lanes' third load lands in the next block or above the diagonal, on entries nobody
+  //  writes — H is not cleared at upload — and is replaced by zero, not multiplied by it)
   auto load_R = [&](int u, double (&r)[3]) {
-    r[0] = pH[u][0]; r[1] = pH[u][4 * dH[u]]; r[2] = pH[u][8 * dH[u]];
+    const double r2 = pH[u][8 * dH[u]];
+    r[0] = pH[u][0]; r[1] = pH[u][4 * dH[u]]; r[2] = lk == 0 ? r2 : 0.0;
     pH[u] -= CH_NB * dH[u];
   };
 #pragma unroll

@@ -16,6 +16,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "chainstamp": (["-DGFBE_CHAIN_STAMP=1"], "off"),
     "bigstamp": (["-DGFBE_BIG_STAMP=1"], "off"),
     "ldltstamp": (["-DGFBE_LDLT_STAMP=1"], "off"),
+    "clearlm": (["-DGFBE_CLEAR_LM=1"], "off"),
     "linstamp": (["-DGFBE_LIN_STAMP=1"], "off"),
     "lin512": (["-DGFBE_LIN_SMALL_THREADS=512"], "off"),
     "lin1024": (["-DGFBE_LIN_SMALL_THREADS=1024"], "off"),

@@ -1,0 +1,50 @@
+"""Nothing reads what nobody wrote. A batch's slab is cleared only where the kernels expect zeros (gfbe_batch_upload: 1 of its ~8 MB
+per 2k-landmark window); everything else — the assembled system, the landmark rows past a track's length, the marginalisation's
+work matrices, the download staging ... — must be written before it is read, and a value that is loaded speculatively must be
+replaced, not multiplied by zero. The test hook GFBE_POISON_UNCLEARED=1 fills the not-cleared part with NaN bit patterns at every
+upload: the results must not change by a bit. (It found k_solve_chain's wide rows multiplying unwritten entries of H by a zero mask:
+harmless while the slab's previous contents are finite, a spurious "linear solve failed" when they are not.)"""
+import os
+
+import numpy as np
+import pytest
+
+from _gfbe_import import gf
+import gnss_window_cases as gw
+
+abi, synth = gf.abi, gf.synth
+pytestmark = pytest.mark.gpu
+
+
+def _digest(results):
+    out = []
+    for r in results:
+        s = r["summary"]
+        out.append((s["iterations"], s["termination"], tuple(s["cost_history"]), r["state"]["pose"].tobytes(), r["feature"].tobytes(),
+                    None if r["prior"] is None else (r["prior"]["J0"].tobytes(), r["prior"]["r0"].tobytes(), tuple(r["prior"]["block_id"].tolist()))))
+    return out
+
+
+def test_results_do_not_depend_on_the_not_cleared_part_of_the_slab():
+    be = gf.Backend(device=0)
+    scn = synth.Scenario(seed=11, n_landmarks=300, use_wheel=True)
+    r0 = be.solve(scn.window(0), abi.MARGIN_OLD)
+    snap = scn.window(1, state=synth.shift_state_for_next_window(scn, r0["state"], 1), prior=r0["prior"])
+    cases = {"one window with prior": [snap],
+             "throughput batch (40 windows, with and without prior)": [snap if i % 2 else scn.window(0) for i in range(40)],
+             "GNSS window": [gw.gnss_window(seed=81, L=150, n_per_frame=8)[2]],
+             "window without landmarks": [synth.Scenario(seed=12, n_landmarks=0, use_wheel=True).window(0)],
+             "ragged tracks, constant landmarks": [dict(synth.Scenario(seed=13, n_landmarks=700, use_wheel=False).window(0),
+                                                        feature_const=(np.arange(700) % 3 == 0).astype(np.uint8))]}
+    old = os.environ.pop("GFBE_POISON_UNCLEARED", None)
+    try:
+        for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
+            want = {k: _digest(be.solve_batch(v, flag)) for k, v in cases.items()}
+            os.environ["GFBE_POISON_UNCLEARED"] = "1"
+            for k, v in cases.items():
+                assert _digest(be.solve_batch(v, flag)) == want[k], (k, flag)
+            os.environ.pop("GFBE_POISON_UNCLEARED")
+    finally:
+        os.environ.pop("GFBE_POISON_UNCLEARED", None)
+        if old is not None:
+            os.environ["GFBE_POISON_UNCLEARED"] = old
