@@ -303,6 +303,7 @@ hipError_t kernels_init_device();   // per-device kernel attributes (k_solve's d
 hipError_t marg_init_device();      // same for k_marg
 hipError_t gnss_init_device();      // same for k_gnss
 void launch_prep(const BatchDev &d, hipStream_t s);
+void launch_upload_small(const BatchDev &d, int with_expand, hipStream_t s);   // small batches: k_expand + k_prep + k_prep_prior + k_asm_table in one launch
 void launch_expand(const BatchDev &d, hipStream_t s);                 // host upload: fobs -> lm_obs / lm_rec
 void launch_gather(const BatchDev &d, int margin_flag, hipStream_t s);   // results -> dl_fix / dl_feat / dl_J0
 void launch_reset(const BatchDev &d, hipStream_t s);

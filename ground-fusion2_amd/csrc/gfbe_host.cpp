@@ -805,10 +805,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(yp, (size_t)B * ND); AL(step, (size_t)B * ND);
     AL(timing, (size_t)(B + 1) * 32);   // (+ one block for the phase stamps of a diagnostics build)
     AL(mmeta, (size_t)B * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS)); AL(mx0, (size_t)B * PRIOR_X0);
-    AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(prior_J0, (size_t)B * ND * ND);     // (the n x n prior block arrives by copy; nothing reads past it)
+    AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));   // (k_asm_table writes every entry)
 #if !GFBE_CLEAR_LM
     AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);   // (k_expand / k_ftab_pack write the rows of a track; the evaluation uses a row only below the track's length: 0.9 of the 2.8 MB per window that used to be cleared)
     AL(lm_hP, (size_t)MAXOBS * 6 * TL);    // (k_vis writes the rows below a tile's longest track — zeros past a track's own end —, k_schur masks the others: 1.0 MB per window)
@@ -1033,11 +1033,11 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     HIPCHK(c, hipMemcpyAsync(dlay, tlayout.data(), sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, us));
     launch_ftab_pack(tabs->d, tabs->cur, tab0, B, d, dlay, dslot, us);
     HIPCHK(c, hipStreamSynchronize(us));   // tlayout dies here
-  } else {
+  } else if (B >= DENSE_SPLIT_MIN_B) {
     launch_expand(d, us);
   }
-  launch_prep(d, us);
-  launch_asm_table(d, us);
+  if (B < DENSE_SPLIT_MIN_B) launch_upload_small(d, tabs ? 0 : 1, us);    // (one launch: gfbe_kernels.hip)
+  else { launch_prep(d, us); launch_asm_table(d, us); }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(b->ev_up, us));
   if (dbg_t) {

@@ -117,14 +117,13 @@ __device__ __forceinline__ int sqrt_info_from_cov_wave(const double *cov, double
   return 0;
 }
 enum { PREP_FACT_WGS = 5, PREP_PRIOR_WGS = 8, PREP_ROWS = 16 };
-__global__ __launch_bounds__(256) void k_prep(BatchDev d) {
-  const int w = blockIdx.x;
+__device__ __forceinline__ void prep_body(const BatchDev &d, const int w, const int by) {
   const WinDesc &ds = d.desc[w];
   __shared__ double work[4][3 * 225];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   double *lu = work[wave], *inv = lu + 225, *U = inv + 225;
-  for (int f = blockIdx.y * 4 + wave; f < ds.n_imu + ds.n_wheel; f += 4 * PREP_FACT_WGS) {      // wave-uniform
+  for (int f = by * 4 + wave; f < ds.n_imu + ds.n_wheel; f += 4 * PREP_FACT_WGS) {      // wave-uniform
     const bool imu = f < ds.n_imu;
     const int k = imu ? f : f - ds.n_imu, n = imu ? 15 : 6;
     const double *cov = imu ? d.imu[ds.imu_off + k].covariance : d.wheel[ds.wheel_off + k].covariance;
@@ -134,14 +133,14 @@ __global__ __launch_bounds__(256) void k_prep(BatchDev d) {
     PREP_WSYNC();
   }
 }
+__global__ __launch_bounds__(256) void k_prep(BatchDev d) { prep_body(d, blockIdx.x, blockIdx.y); }
 // H_prior = J0^T J0, lower triangle mirrored (PREP_PRIOR_WGS workgroups per window; its own kernel: the factorisations above take
 // 256 VGPRs, this one a fraction — eight workgroups per CU instead of one). J0 goes through LDS sixteen rows at a time (coalesced
 // loads, every row read once per pass); a thread keeps PREP_MAXE entries in registers across the row panels and adds the products
 // in row order — the same sums as an entry-by-entry loop over global memory. A prior larger than 8 x 256 x PREP_MAXE entries of
 // the triangle (n > 127) takes more than one pass over J0.
 enum { PREP_MAXE = 4 };
-__global__ __launch_bounds__(256) void k_prep_prior(BatchDev d) {
-  const int w = blockIdx.x;
+__device__ __forceinline__ void prep_prior_body(const BatchDev &d, const int w, const int by) {
   const WinDesc &ds = d.desc[w];
   const int t = threadIdx.x;
   const int n = ds.prior_n;
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(256) void k_prep_prior(BatchDev d) {
   __shared__ double panel[PREP_ROWS * ND];
   const int ntri = n * (n + 1) / 2, stride = PREP_PRIOR_WGS * 256;
   for (int pass0 = 0; pass0 < ntri; pass0 += PREP_MAXE * stride) {     // (uniform trip count: barriers inside)
-    const int base = pass0 + blockIdx.y * 256 + t;
+    const int base = pass0 + by * 256 + t;
     double acc[PREP_MAXE];
     int ei[PREP_MAXE], ej[PREP_MAXE];
 #pragma unroll
@@ -181,6 +180,7 @@ __global__ __launch_bounds__(256) void k_prep_prior(BatchDev d) {
     }
   }
 }
+__global__ __launch_bounds__(256) void k_prep_prior(BatchDev d) { prep_prior_body(d, blockIdx.x, blockIdx.y); }
 
 // Pose-pair constants of the visual factors at state X (gfbe_state layout) for all 55 pairs i < j: ONE wave (lanes 0..63 of the
 // calling workgroup; `sp` = 12 PoseRT of LDS), one pair per lane. Called by the kernels that produce a state; the visual
@@ -203,16 +203,7 @@ __device__ __forceinline__ void pair_consts_of_state(const double *X, double *pc
   if (lane < NF) sp[lane] = make_pose(X + A_POSE(lane));
   if (lane == NF) sp[NF] = make_pose(X + A_EX);
   __syncthreads();
-  if (lane < NF * (NF - 1) / 2) {
-    int i = 0, rem = lane;
-    while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
-    const int j = i + 1 + rem;
-    const PairConst p = make_pair_const(sp[i], sp[j], sp[NF]);
-    double *o = pc_out + (size_t)(i * NF + j) * PC_DOUBLES;
-    const double *src = (const double *)&p;
-#pragma unroll
-    for (int q = 0; q < PC_DOUBLES; q++) o[q] = src[q];
-  }
+  pair_consts_from_staged(pc_out, sp, lane);
 }
 
 // =============================================================================================
@@ -1192,8 +1183,8 @@ struct AsmTab {
 //   y = IMU:   slot0 = (i0 + 1) | off0 << 4 (bits 0..13), slot1 the same in bits 16..29; i + 1 == 0: none
 //   z = wheel: same packing (the wheel-global x wheel-global block is handled separately)
 #define ASM_NTRI (ND * (ND + 1) / 2)
-__global__ __launch_bounds__(256) void k_asm_table(int4 *tab) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void asm_table_body(int4 *tab, const int bx) {
+  const int e = bx * 256 + threadIdx.x;
   if (e >= ASM_NTRI) return;
   int hi, lo_;
   tri_decode(e, hi, lo_);
@@ -1217,6 +1208,7 @@ __global__ __launch_bounds__(256) void k_asm_table(int4 *tab) {
   }
   tab[e] = r;
 }
+__global__ __launch_bounds__(256) void k_asm_table(int4 *tab) { asm_table_body(tab, blockIdx.x); }
 void launch_asm_table(const BatchDev &d, hipStream_t s) {
   hipLaunchKernelGGL(k_asm_table, dim3((ASM_NTRI + 255) / 256), dim3(256), 0, s, (int4 *)d.asm_tab);
 }
@@ -2179,10 +2171,9 @@ __global__ __launch_bounds__(64) void k_reanchor(BatchDev d) {
 // inside a start-frame group the landmarks are sorted longest track first, so the factors of pair (s, s+1+k) are a prefix
 // of the group and the record of (slot, k) is pair_begin + position in the group.
 // =============================================================================================
-__global__ __launch_bounds__(256) void k_expand(BatchDev d) {
-  const int w = blockIdx.y;
+__device__ __forceinline__ void expand_body(const BatchDev &d, const int w, const int bx) {
   const WinDesc &ds = d.desc[w];
-  const int rel = blockIdx.x * 256 + threadIdx.x;
+  const int rel = bx * 256 + threadIdx.x;
   if (rel >= ds.lm_slots) return;
   const int slot = ds.lm_off + rel;
   const int info = d.lm_info[slot];
@@ -2198,6 +2189,26 @@ __global__ __launch_bounds__(256) void k_expand(BatchDev d) {
 #pragma unroll
     for (int q = 0; q < 5; q++) ob[q * TL] = f[q];
   }
+}
+__global__ __launch_bounds__(256) void k_expand(BatchDev d) { expand_body(d, blockIdx.y, blockIdx.x); }
+// Small batches (one window per call is the reference's pattern): the four preparation steps of an upload are independent of each
+// other — the landmark rows, the factors' square-root informations, the prior's J0^T J0, the assembly table — and run as ONE launch
+// (workgroup ranges), not four one after the other on the latency path of gfbe_solve_window. (Throughput batches keep them apart:
+// the factorisations' 256 VGPRs would cap the occupancy of the others.)
+__global__ __launch_bounds__(256) void k_upload_small(BatchDev d, int n_expand) {
+  int bx = blockIdx.x;
+  const int ne = d.B * n_expand, nf = d.B * PREP_FACT_WGS, np = d.B * PREP_PRIOR_WGS;
+  if (bx < ne) { expand_body(d, bx / n_expand, bx % n_expand); return; }
+  bx -= ne;
+  if (bx < nf) { prep_body(d, bx / PREP_FACT_WGS, bx % PREP_FACT_WGS); return; }
+  bx -= nf;
+  if (bx < np) { prep_prior_body(d, bx / PREP_PRIOR_WGS, bx % PREP_PRIOR_WGS); return; }
+  asm_table_body((int4 *)d.asm_tab, bx - np);
+}
+void launch_upload_small(const BatchDev &d, int with_expand, hipStream_t s) {
+  const int n_expand = (with_expand && d.max_tiles > 0) ? (d.max_tiles * LM_TILE + 255) / 256 : 0;
+  const int total = d.B * (n_expand + PREP_FACT_WGS + PREP_PRIOR_WGS) + (ASM_NTRI + 255) / 256;
+  hipLaunchKernelGGL(k_upload_small, dim3(total), dim3(256), 0, s, d, n_expand);
 }
 
 // =============================================================================================
