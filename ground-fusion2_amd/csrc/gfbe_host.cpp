@@ -811,7 +811,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));   // (k_asm_table writes every entry)
 #if !GFBE_CLEAR_LM
     AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);   // (k_expand / k_ftab_pack write the rows of a track; the evaluation uses a row only below the track's length: 0.9 of the 2.8 MB per window that used to be cleared)
-    AL(lm_hP, (size_t)MAXOBS * 6 * TL);    // (k_vis writes the rows below a tile's longest track — zeros past a track's own end —, k_schur masks the others: 1.0 MB per window)
+    AL(lm_hP, (size_t)MAXOBS * 6 * TL);    // (k_vis writes the rows below a track's length, k_schur masks the others per landmark: 1.0 MB per window)
 #endif
     AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE);   // (a tile's steps below its longest track are written by k_vis, the others never read)
     AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);   // (k_marg / k_marg_ldlt write what they and k_gather read)

@@ -404,12 +404,11 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
       for (int q = 0; q < 5; q++) asm volatile("" : "+v"(nob[q]));
 #endif
-      if (GFBE_ABLATE != 3 || hp[0] == 1.2345) {   // the landmark's H_pl block of observing pose s + 1 + k
-        // (every lane stores: a zero row where the track — or the slot — has ended below the tile's longest track. lm_hP is not
-        //  cleared at upload; k_schur masks the rows from the longest track on, nobody else reads past a track's length)
-        const bool live = k < m;
+      if (k < m && (GFBE_ABLATE != 3 || hp[0] == 1.2345)) {   // the landmark's H_pl block of observing pose s + 1 + k
+        // (lm_hP is not cleared at upload: rows from a track's length on hold whatever the memory held; k_schur masks them per
+        //  landmark, nobody else reads past a track's length)
 #pragma unroll
-        for (int q = 0; q < 6; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = live ? hp[q] : 0.0;
+        for (int q = 0; q < 6; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = hp[q];
       }
     }
     if (MODE != 1 && GFBE_ABLATE != 1) {
@@ -1061,8 +1060,8 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
         for (int u = 0; u < 4; u++) {
           const int k = part - 1 + 3 * u;
           if (k < kmax) {
-            // (rows from the tile's longest track on were never written — lm_hP is not cleared at upload: zeros, not products)
-            const bool written = k < ((pm0 >> 8) & 0xff);
+            // (rows from the landmark's track length on were never written — lm_hP is not cleared at upload: zeros, not products)
+            const bool written = valid && k < m;
 #pragma unroll
             for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = written ? sw * pre[u * 6 + q] : 0.0;
           }
