@@ -21,7 +21,7 @@ cd $R
 python tests/diag_single.py 2>&1 | tail -3
 GFBE_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_chainstamp.so python tests/diag_chain.py 2>&1 | grep -v "worst dims" > gpurun_out/r3_solve_chain_phases.txt; tail -14 gpurun_out/r3_solve_chain_phases.txt
 # one GNSS window and the same window without GNSS through the library's per-kernel events; phase stamps of k_solve_big / k_gnss
-python scratch/gnss_prof.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r3_gnss_window_profile.txt; python scratch/gnss_stamps.py 2>&1 | grep -v amdgpu.ids | tail -2 >> gpurun_out/r3_gnss_window_profile.txt; head -3 gpurun_out/r3_gnss_window_profile.txt
+python tests/diag_scripts/gnss_prof.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r3_gnss_window_profile.txt; python tests/diag_scripts/gnss_stamps.py 2>&1 | grep -v amdgpu.ids | tail -2 >> gpurun_out/r3_gnss_window_profile.txt; head -3 gpurun_out/r3_gnss_window_profile.txt
 # the end-to-end loop alone under the kernel tracer
 cd /tmp; rm -rf /tmp/pe; B=1024 DEPTH=3 STEPS=10 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/pe -- python $R/tests/diag_e2e.py > /tmp/pe.log 2>&1; tail -1 /tmp/pe.log > $R/gpurun_out/r3_e2e.log
 python $R/profiles/summarize_rocpd.py /tmp/pe/*/*_results.db $R/gpurun_out/r3_e2e_trace.txt | head -12; cat $R/gpurun_out/r3_e2e.log

@@ -48,3 +48,26 @@ def test_results_do_not_depend_on_the_not_cleared_part_of_the_slab():
         os.environ.pop("GFBE_POISON_UNCLEARED", None)
         if old is not None:
             os.environ["GFBE_POISON_UNCLEARED"] = old
+
+
+def test_merged_launches_equal_the_one_kernel_per_launch_sequence():
+    """A small batch runs an iteration in six launches (k_schur + k_visblock_small in one launch, k_step / k_candidate
+    at the tail of k_lm_step, k_accept at the tail of k_lin_small<1>, the marginalisation's four linearisation launches in two);
+    with the library's per-kernel profiling on, every kernel is a launch of its own again. Same code, same order of every sum:
+    the same bits — with and without landmarks, GNSS, LiDAR-free; for one window and for a batch of seven."""
+    be = gf.Backend(device=0)
+    scn = synth.Scenario(seed=21, n_landmarks=500, use_wheel=True)
+    r0 = be.solve(scn.window(0), abi.MARGIN_OLD)
+    snap = scn.window(1, state=synth.shift_state_for_next_window(scn, r0["state"], 1), prior=r0["prior"])
+    cases = {"one window": [snap], "seven windows": [snap if i % 2 else scn.window(0) for i in range(7)],
+             "GNSS window": [gw.gnss_window(seed=85, L=120, n_per_frame=4, anchor=True)[2]],
+             "no landmarks": [synth.Scenario(seed=22, n_landmarks=0, use_wheel=True).window(0)]}
+    for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):
+        merged = {k: _digest(be.solve_batch(v, flag)) for k, v in cases.items()}
+        be.profile_enable(True)
+        try:
+            for k, v in cases.items():
+                assert _digest(be.solve_batch(v, flag)) == merged[k], (k, flag)
+        finally:
+            be.profile_enable(False)
+            be.profile_reset()
