@@ -27,6 +27,9 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "fuse5": (["-DGFBE_FUSE_SMALL=5"], "off"),
     "ks5": (["-DGFBE_LIN_SMALL_KS=5"], "off"),
     "ks10": (["-DGFBE_LIN_SMALL_KS=10"], "off"),
+    "ks4": (["-DGFBE_LIN_SMALL_KS=4"], "off"),
+    "ks6": (["-DGFBE_LIN_SMALL_KS=6"], "off"),
+    "ks7": (["-DGFBE_LIN_SMALL_KS=7"], "off"),
     "s512": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2"], "off"),
     "s512u10": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DBUILD_UNROLL=10"], "off"),
     "s512u13": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DBUILD_UNROLL=13"], "off"),
