@@ -20,7 +20,7 @@ _SO = os.environ.get("GFBE_LIB") or os.path.join(_CSRC, "libgfbe.so")
 
 # Every symbol include/gfbe.h declares (checked by tests/test_abi.py on CPU).
 EXPORTS = [
-    "gfbe_default_options", "gfbe_create", "gfbe_destroy", "gfbe_last_error", "gfbe_version", "gfbe_set_stream",
+    "gfbe_default_options", "gfbe_create", "gfbe_destroy", "gfbe_last_error", "gfbe_create_note", "gfbe_version", "gfbe_set_stream",
     "gfbe_feature_count", "gfbe_visual_factor_count", "gfbe_build_visual_factors", "gfbe_set_depth",
     "gfbe_eval_factors", "gfbe_preintegrate_imu", "gfbe_preintegrate_wheel",
     "gfbe_solve_window", "gfbe_solve_batch",
@@ -127,7 +127,9 @@ class Backend(abi.CApi):
         rc = self.lib.gfbe_create(C.byref(self.ctx), int(device), C.byref(self.opt))
         if rc != abi.OK:
             raise BackendError("gfbe_create(device=%d) failed with status %d (%s)" % (device, rc, self._err()))
-        self.create_note = self._err()      # (a note, not an error: e.g. fewer than eight hardware queues configured)
+        self.lib.gfbe_create_note.restype = C.c_char_p
+        self.lib.gfbe_create_note.argtypes = [C.c_void_p]
+        self.create_note = (self.lib.gfbe_create_note(self.ctx) or b"").decode()   # (a remark, not an error: e.g. fewer than eight hardware queues configured)
         self.head = self.ctx
         self.device = device
         for name in ("batch_upload", "batch_solve", "batch_download", "solve_batch", "profile_enable",

@@ -51,6 +51,7 @@ enum {
   MAX_IMU = 10, MAX_WHEEL = 10, MAX_PLANE = 10,
   PLANE_PART = 16 * 16 + 16 + 2,    // J^T J, J^T r, cost, candidate cost of one PlaneFactor (columns pose_i 6, ex_wheel 6, plane_R 3, plane_Z 1)
   ANCHOR_PART = 6 * 6 + 6 + 2,
+  MAX_BATCH_PARTS = 16,       // upper bound of gfbe_options.split_batch (every part beyond the first owns a pair of streams)
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   LIN_SMALL_KS = GFBE_LIN_SMALL_KS,   // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
   LIN_SMALL_THREADS = GFBE_LIN_SMALL_THREADS,    // k_lin_small: threads per workgroup (one wave per visual tile item, four for an inertial / wheel / prior item)

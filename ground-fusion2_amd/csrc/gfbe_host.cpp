@@ -105,6 +105,7 @@ struct gfbe_ctx {
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
+  std::string note;                                   // set by gfbe_create (never an error): gfbe_create_note
   bool profiling = false;
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> event_pool;
@@ -225,6 +226,7 @@ void gfbe_default_options(gfbe_options *o) {
 
 const char *gfbe_version(void) { return "gfbe 0.1.0 (gfx950, HIP)"; }
 const char *gfbe_last_error(const gfbe_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+const char *gfbe_create_note(const gfbe_ctx *ctx) { return ctx ? ctx->note.c_str() : ""; }
 
 gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   if (!out) return GFBE_BAD_INPUT;
@@ -239,7 +241,7 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   // host layer and bench.py set GPU_MAX_HW_QUEUES=8 before they load HIP): the library only says so when it finds less.
   {
     const char *q = getenv("GPU_MAX_HW_QUEUES");
-    if (!q || atoi(q) < 8) c->err = "note: GPU_MAX_HW_QUEUES is unset or below 8 — uploads and downloads will share hardware queues with the solver streams (set it before HIP initialises)";
+    if (!q || atoi(q) < 8) c->note = "GPU_MAX_HW_QUEUES is unset or below 8 — uploads and downloads will share hardware queues with the solver streams (set it before HIP initialises)";
   }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= device) {
@@ -1080,8 +1082,9 @@ static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *cons
   // explicit count >= 2 is taken as it is
   int parts = 1;
   if (B >= BATCH_SPLIT_MIN_B && !c->allreduce && c->opt.split_batch) {
+    if (c->opt.split_batch < 0) { c->err = "gfbe_options.split_batch must be >= 0"; return GFBE_BAD_INPUT; }
     parts = c->opt.split_batch == 1 ? (B >= 2048 ? 4 : 1) : c->opt.split_batch;
-    parts = std::min(parts, std::max(B / DENSE_SPLIT_MIN_B, 1));
+    parts = std::max(1, std::min(std::min(parts, (int)MAX_BATCH_PARTS), std::max(B / DENSE_SPLIT_MIN_B, 1)));   // (every part beyond the first owns a pair of streams)
   }
   gfbe_batch **link = out;
   gfbe_batch *prev = nullptr;
@@ -1273,7 +1276,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
 extern "C" gfbe_status gfbe_batch_solve(gfbe_ctx *c, gfbe_batch *b, int32_t margin_flag) {
   if (!c || !b) return GFBE_BAD_INPUT;
   if (c->device < 0) return GFBE_NO_DEVICE;
-  if (margin_flag < 0 || margin_flag > 2) return GFBE_BAD_INPUT;
+  if (margin_flag < 0 || margin_flag > 2) { c->err = "gfbe_batch_solve: margin_flag out of range"; return GFBE_BAD_INPUT; }
   const BatchDev &d = b->d;
   if (d.sharded && !c->allreduce) { c->err = "batch was uploaded for landmark sharding but the all-reduce hook is gone"; return GFBE_BAD_INPUT; }
   // hipGraph replay: not while profiling (per-kernel events) and not with the all-reduce hook (host callback)

@@ -202,6 +202,12 @@ __device__ void jacobi_eig_wave16(double *G, double *V, int n, double *lam, int 
 // ---- diagonally pivoted LDL^T of A' with pivots > eps:  A' ~= P L D+ L^T P^T,
 //      J0 = D+^(1/2) L^T P^T,  r0 = D+^(-1/2) L^-1 P^T b'   (forward substitution folded in)
 #define LDLT_THREADS 512
+// Largest A' the register-resident LDL^T holds: an R = 8 tile per thread of a 22 x 22 thread grid (22^2 <= LDLT_THREADS), the
+// published column in colbuf[2][192], the diagonal in three registers per lane of a wave. A new prior beyond it (reachable through
+// the ABI only — the priors the reference builds stay near 100 dims, a GNSS window near 150) takes the eigen-decomposition path
+// whatever gfbe_options.marg_sqrt says.
+#define LDLT_MAX_N 176
+static_assert(LDLT_MAX_N == 8 * 22 && 22 * 22 <= LDLT_THREADS && LDLT_MAX_N <= 192 && LDLT_MAX_N <= 3 * 64, "k_marg_ldlt<8>: thread grid / colbuf / diagonal registers");
 // maximum / minimum of a 32-bit value over the wave, as a scalar: four DPP rotations inside the 16-lane rows, the rows' results
 // through v_readlane
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
@@ -703,7 +709,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   __syncthreads();
   MSTAMP(4);
   __shared__ int order[ND];
-  if (d.opt.marg_sqrt == 1) {
+  if (d.opt.marg_sqrt == 1 && n <= LDLT_MAX_N) {
     // the square root itself is taken by k_marg_ldlt (own kernel: the matrix is register-resident there)
     if (t == 0) sh.sweeps = MARG_SQRT_PENDING;
   } else {

@@ -944,7 +944,9 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
     if (lane < ds.n_imu) term = d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 2];
     else if (lane >= 16 && lane - 16 < ds.n_wheel) term = d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 2];
     else if (lane == 32) term = d.prior_g[(size_t)w * (ND + 2) + ND];
-    else if (lane >= 33 && lane - 33 < d.world && lane < 44) term = d.xa[((size_t)w * d.world + lane - 33) * XCHG];
+    else if (lane == 33) {   // the ranks' visual-cost shares, in rank order (any world size gfbe_set_allreduce accepts: k_solve / k_solve_big loop the same way)
+      for (int r = 0; r < d.world; r++) term += d.xa[((size_t)w * d.world + r) * XCHG];
+    }
     else if (lane >= 44 && lane - 44 < ds.n_plane) term = d.plane_part[((size_t)w * MAX_PLANE + lane - 44) * PLANE_PART + PLANE_PART - 2];
     else if (lane == 58 && ds.use_anchor) term = d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
     cterm[lane] = term;

@@ -303,13 +303,15 @@ void gfbe_default_options(gfbe_options *opt);
  * GFBE_NO_DEVICE). device >= 0: HIP device ordinal; fails with GFBE_NO_DEVICE if absent.
  * The solver drives up to eight HIP streams (two solver lanes with a side stream each, upload, download, the caller's): set
  * GPU_MAX_HW_QUEUES=8 in the process environment before HIP initialises — the runtime's default of four makes uploads queue
- * behind solves. The library does not touch the environment; gfbe_create returns GFBE_OK and leaves a note in gfbe_last_error
- * when the variable is unset or below 8. */
+ * behind solves. The library does not touch the environment; gfbe_create returns GFBE_OK and leaves a note in gfbe_create_note
+ * (never in gfbe_last_error, which only ever holds the cause of a failing call) when the variable is unset or below 8. */
 gfbe_status gfbe_create(gfbe_ctx **ctx, int device, const gfbe_options *opt);
 /* Frees the context and the device memory it caches. Batches (gfbe_batch_free) and feature tables (gfbe_ftab_destroy) made with
  * the context must be released BEFORE it. */
 void gfbe_destroy(gfbe_ctx *ctx);
 const char *gfbe_last_error(const gfbe_ctx *ctx);
+/* Informational remarks of gfbe_create ("" when there are none); the reference has no counterpart (ROS_WARN at start-up). */
+const char *gfbe_create_note(const gfbe_ctx *ctx);
 const char *gfbe_version(void);
 /* Launch kernels on this hipStream_t (e.g. torch's current stream). NULL = the ctx's own stream. */
 gfbe_status gfbe_set_stream(gfbe_ctx *ctx, void *hip_stream);

@@ -131,3 +131,18 @@ def test_gnss_windows_in_a_throughput_batch(be, oracle):
         assert got["prior"]["block_id"].tolist() == want["prior"]["block_id"].tolist()
         assert got["summary"]["cost_history"] == runs[1][i]["summary"]["cost_history"] and np.array_equal(got["prior"]["J0"], runs[1][i]["prior"]["J0"])
         assert got["summary"]["cost_history"] == runs[0][i % 3]["summary"]["cost_history"]        # (independent of the slot inside the batch)
+
+
+def test_gnss_window_beyond_the_lds_staging_limit(be, oracle):
+    """Four constellations, 32 satellites per frame: 352 observations > GN_LDS_OBS = 320 (gfbe_gnss_solve.hip), so k_gnss takes the
+    path that sums entry by entry from the global J / r copy — in the solve (mode 0) and in MARGIN_OLD (mode 2). ADVICE round 3."""
+    scn, tru, snap = gw.gnss_window(seed=87, L=150, n_per_frame=32)
+    assert len(snap["gnss"]["obs"]) > 320
+    want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD, loose=GNSS_LOOSE)
+    check_gnss_state(want, got)
+    check_prior(want["prior"], got["prior"], loose=PRIOR_LOOSE)
+    # the same window inside a batch whose other window stages in LDS (the launch sizes the LDS for the batch's largest window, capped)
+    _, _, small = gw.gnss_window(seed=81, L=150, n_per_frame=8)
+    both = be.solve_batch([small, snap], abi.MARGIN_OLD)
+    assert both[1]["summary"]["final_cost"] == got["summary"]["final_cost"]
+    assert np.array_equal(both[1]["state"]["pose"], got["state"]["pose"])
