@@ -15,7 +15,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-# GFBE_LIB: an alternative build of the library (tests/diag_variants.py compares kernel variants built side by side)
+# GFBE_LIB: an alternative build of the library (tools/diag_variants.py compares kernel variants built side by side)
 _SO = os.environ.get("GFBE_LIB") or os.path.join(_CSRC, "libgfbe.so")
 
 # Every symbol include/gfbe.h declares (checked by tests/test_abi.py on CPU).
@@ -48,11 +48,17 @@ def sources():
     return sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp")))
 
 
-def build_native(force=False, verbose=False, out=None, extra_flags=None, fp_contract="off"):
+DIAG_SO = os.path.join(_CSRC, "libgfbe_diag.so")
+
+
+def build_native(force=False, verbose=False, out=None, extra_flags=None, fp_contract="off", diag=False):
     """hipcc --offload-arch=gfx950 -> csrc/libgfbe.so (cross-compiles without a GPU). Every source is compiled to its own
     object (in parallel, only when it is older than the source or a header) and the objects are linked: a one-file change
-    rebuilds in seconds. `out` / `extra_flags` / `fp_contract`: side-by-side variant builds (tests/diag_variants.py)."""
+    rebuilds in seconds. `out` / `extra_flags` / `fp_contract`: side-by-side variant builds (tools/diag_variants.py)."""
     from concurrent.futures import ThreadPoolExecutor
+    if diag:
+        out = out or DIAG_SO
+        extra_flags = list(extra_flags or []) + ["-DGFBE_DIAG=1"]
     so = out or os.path.join(_CSRC, "libgfbe.so")
     srcs = sources()
     hdrs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".h", ".hpp"))]
@@ -111,7 +117,8 @@ def build_rccl_hook(force=False, verbose=False):
 class Backend(abi.CApi):
     prefix = "gfbe_"
 
-    def __init__(self, device=0, options=None):
+    def __init__(self, device=0, options=None, so=None):
+        _SO = so or globals()["_SO"]          # (so: another build of the library, e.g. DIAG_SO)
         if not os.path.exists(_SO):
             raise BackendError("HIP extension %s is missing: run __graft_entry__.build() (no CPU fallback)" % _SO)
         # the solver drives up to eight streams: the HIP runtime's hardware-queue count is the CALLER's to set, before HIP

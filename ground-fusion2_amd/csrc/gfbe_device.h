@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -26,7 +27,25 @@
 #define GFBE_FUSE_SMALL 15
 #endif
 
+// GFBE_DIAG = 1: the diagnostics build (libgfbe_diag.so; backend.build_native(diag=True)). Only that build reads the environment
+// hooks of the measurement / test scripts (GFBE_POISON_UNCLEARED, GFBE_VIS_FULL, GFBE_DEBUG_UPLOAD) and accepts the kernel
+// time-stamp / ablation macros (GFBE_ABLATE, GFBE_*_STAMP). The shipped library has none of them: no environment variable can
+// change what it computes or writes.
+#ifndef GFBE_DIAG
+#define GFBE_DIAG 0
+#endif
+#if !GFBE_DIAG && (defined(GFBE_ABLATE) || defined(GFBE_KVIS_STAMP) || defined(GFBE_LIN_STAMP) || defined(GFBE_CHOL_STAMP) || \
+                   defined(GFBE_CHAIN_STAMP) || defined(GFBE_BIG_STAMP) || defined(GFBE_LDLT_STAMP))
+#error "kernel time stamps / ablations are diagnostics: build with -DGFBE_DIAG=1"
+#endif
+
 namespace gfd {
+
+#if GFBE_DIAG
+inline const char *diag_getenv(const char *name) { return getenv(name); }
+#else
+inline const char *diag_getenv(const char *) { return nullptr; }
+#endif
 
 // ---- dimensions -----------------------------------------------------------------------------
 enum {

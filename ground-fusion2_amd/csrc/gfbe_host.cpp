@@ -601,7 +601,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
                               int tab0 = 0) {
   if (!c || !wins || !out || B <= 0) return GFBE_BAD_INPUT;
   if (c->device < 0 || !c->stream) { c->err = "HIP device context required (no CPU fallback)"; return GFBE_NO_DEVICE; }
-  const bool dbg_t = getenv("GFBE_DEBUG_UPLOAD") != nullptr && getenv("GFBE_DEBUG_UPLOAD")[0] != 0;   // phase times of the upload on stderr (tests/diag_e2e_latency.py)
+  const bool dbg_t = diag_getenv("GFBE_DEBUG_UPLOAD") != nullptr && diag_getenv("GFBE_DEBUG_UPLOAD")[0] != 0;   // phase times of the upload on stderr (tools/diag_e2e_latency.py)
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   HIPCHK(c, hipSetDevice(c->device));
   const double T0 = now();
@@ -747,7 +747,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   d.any_gnss = any_gnss; d.tot_gnss = tot_gnss; d.gnss_max_obs = gnss_max; d.marg_nmax = marg_nmax;
   d.nu = (any_gnss || gnss_dims) ? (int)ND : (int)NC;       // a batch without GNSS blocks never touches the last 59 tangent dims
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
-  if (getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics: force the 20-column panel)
+  if (diag_getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics build only: force the 20-column panel)
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
   const double T1 = now();
@@ -760,7 +760,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   gfbe_gnss_obs *h_gnss = nullptr;
   double *d_pJ0c = nullptr;
   const bool want_rec = c->want_records;
-  const char *poison_env = getenv("GFBE_POISON_UNCLEARED");   // (test hook, see the enqueue below; read per upload)
+  const char *poison_env = diag_getenv("GFBE_POISON_UNCLEARED");   // (test hook of the diagnostics build, see the enqueue below; read per upload)
   for (int pass = 0; pass < 2; pass++) {
     b->dry = pass == 0;
     if (pass == 1) {

@@ -26,13 +26,13 @@
 namespace gfd {
 
 #ifndef GFBE_ABLATE
-#define GFBE_ABLATE 0   // timing ablations of k_vis (tests/diag_ablate.sh); 0 in every shipped build
+#define GFBE_ABLATE 0   // timing ablations of k_vis (tools/diag_ablate.sh); 0 in every shipped build
 #endif
 #ifndef GFBE_KVIS_EARLY
 #define GFBE_KVIS_EARLY 1   // k_vis: the prefetched observation of the next step is waited for BEFORE this step's stores are issued
 #endif
 #ifndef GFBE_KVIS_STAMP
-#define GFBE_KVIS_STAMP 0   // diagnostics build (tests/diag_variants.py): phase time stamps of one wave of k_vis<0> into d.timing
+#define GFBE_KVIS_STAMP 0   // diagnostics build (tools/diag_variants.py): phase time stamps of one wave of k_vis<0> into d.timing
 #endif
 
 // =============================================================================================
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, 
   // all four — the single lane that evaluated an IMU factor was the longest chain of the launch
   const bool tile_wg = y < d.max_tiles * KS;
 #if GFBE_LIN_STAMP
-  // diagnostics build (tests/diag_scripts/lin_stamps.py): start of workgroup 0 and the latest end per kind of item, of the LAST launch of MODE 0
+  // diagnostics build (tools/diag_scripts/lin_stamps.py): start of workgroup 0 and the latest end per kind of item, of the LAST launch of MODE 0
   unsigned long long *ls = (unsigned long long *)(d.timing + (size_t)d.B * 32);
   if (MODE == 0 && y == 0 && threadIdx.x == 0) ls[0] = wall_clock64();
   if (MODE == 0 && y == d.max_tiles * KS && threadIdx.x == 0) ls[8] = wall_clock64();                 // first inertial item starts

@@ -227,7 +227,7 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return min(min(r0, r1), min(r2, r3));
 }
 #ifndef GFBE_LDLT_STAMP
-#define GFBE_LDLT_STAMP 0      // diagnostics build: time stamps inside the first steps of the pivot loop (tests/diag_scripts/marg_stamps.py)
+#define GFBE_LDLT_STAMP 0      // diagnostics build: time stamps inside the first steps of the pivot loop (tools/diag_scripts/marg_stamps.py)
 #endif
 // loadA(i, j): entry (i, j) of A'; loadB(i): entry i of b' — from the compact arrays k_marg left (k_marg_ldlt), or formed on the fly
 // from the Schur operands in LDS (the LDL^T at the tail of k_marg itself).

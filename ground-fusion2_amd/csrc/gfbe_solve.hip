@@ -11,7 +11,7 @@ namespace gfd {
 // the dogleg scalars. (Ceres 1.14 DoglegStrategy::ComputeStep / ComputeGaussNewtonStep.)
 // =============================================================================================
 // 768 threads = 12 waves = 3 per SIMD: 170 VGPRs per lane instead of the 128 of a 1024-thread workgroup. Measured on one box
-// (tests/diag_variants.py, one window / 1024 resident windows): 1024 threads 83.6 us / 48.6k solves/s, 512 threads 83.2 /
+// (tools/diag_variants.py, one window / 1024 resident windows): 1024 threads 83.6 us / 48.6k solves/s, 512 threads 83.2 /
 // 49.2-49.6k (faster under load: less scratch traffic from the out-of-line phases, but the tile build takes 21 instead of 15 us),
 // 768 threads 77.8 / 50.4-50.7k. Inlining the phases back is slower at every size (the back-substitution alone 9 -> 17 us).
 #ifndef SOLVE_THREADS
@@ -680,7 +680,7 @@ __device__ __forceinline__ bool chain_block(lds_double *A, lds_double *Cb, lds_d
 // Block barrier of the pipeline: LDS traffic only. __syncthreads() also drains the vector-memory counter — every step would wait
 // for its Yr stores to reach L2 and for the NEXT block's prefetched coupling rows (~2 us per step measured).
 #ifndef GFBE_CHAIN_STAMP
-#define GFBE_CHAIN_STAMP 0      // diagnostics build (tests/diag_chain.py): per-step time stamps of the pipeline roles into the NEXT window's timing slots
+#define GFBE_CHAIN_STAMP 0      // diagnostics build (tools/diag_chain.py): per-step time stamps of the pipeline roles into the NEXT window's timing slots
 #endif
 #if GFBE_CHAIN_STAMP
 #define RSTAMP(cond, i) do { if (cond) rstamp[i] = (double)wall_clock64(); } while (0)

@@ -15,14 +15,14 @@ head -6 $R/gpurun_out/r3_pmc_fetch.txt; head -6 $R/gpurun_out/r3_pmc_write.txt
 # the bench line last: its roofline block reads the PMC summaries of THIS build from profiles/ (traffic, matrix-core busy fraction)
 cp $R/gpurun_out/r3_pmc_sq1.txt $R/gpurun_out/r3_pmc_sq2.txt $R/gpurun_out/r3_pmc_fetch.txt $R/gpurun_out/r3_pmc_write.txt $R/profiles/
 (cd $R && python bench.py > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err; head -c 600 gpurun_out/r3_bench_default.json; echo)
-rm -rf /tmp/prof_single; N=30 rocprofv3 --kernel-trace --stats -d /tmp/prof_single -- python $R/tests/diag_single.py > $R/gpurun_out/r3_single.log 2>&1
+rm -rf /tmp/prof_single; N=30 rocprofv3 --kernel-trace --stats -d /tmp/prof_single -- python $R/tools/diag_single.py > $R/gpurun_out/r3_single.log 2>&1
 python $R/profiles/summarize_rocpd.py /tmp/prof_single/*/*_results.db $R/gpurun_out/r3_single_trace.txt | head -24
 cd $R
-python tests/diag_single.py 2>&1 | tail -3
-GFBE_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_chainstamp.so python tests/diag_chain.py 2>&1 | grep -v "worst dims" > gpurun_out/r3_solve_chain_phases.txt; tail -14 gpurun_out/r3_solve_chain_phases.txt
+python tools/diag_single.py 2>&1 | tail -3
+GFBE_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_chainstamp.so python tools/diag_chain.py 2>&1 | grep -v "worst dims" > gpurun_out/r3_solve_chain_phases.txt; tail -14 gpurun_out/r3_solve_chain_phases.txt
 # one GNSS window and the same window without GNSS through the library's per-kernel events; phase stamps of k_solve_big / k_gnss
-python tests/diag_scripts/gnss_prof.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r3_gnss_window_profile.txt; python tests/diag_scripts/gnss_stamps.py 2>&1 | grep -v amdgpu.ids | tail -2 >> gpurun_out/r3_gnss_window_profile.txt; head -3 gpurun_out/r3_gnss_window_profile.txt
+python tools/diag_scripts/gnss_prof.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r3_gnss_window_profile.txt; python tools/diag_scripts/gnss_stamps.py 2>&1 | grep -v amdgpu.ids | tail -2 >> gpurun_out/r3_gnss_window_profile.txt; head -3 gpurun_out/r3_gnss_window_profile.txt
 # the end-to-end loop alone under the kernel tracer
-cd /tmp; rm -rf /tmp/pe; B=1024 DEPTH=3 STEPS=10 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/pe -- python $R/tests/diag_e2e.py > /tmp/pe.log 2>&1; tail -1 /tmp/pe.log > $R/gpurun_out/r3_e2e.log
+cd /tmp; rm -rf /tmp/pe; B=1024 DEPTH=3 STEPS=10 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/pe -- python $R/tools/diag_e2e.py > /tmp/pe.log 2>&1; tail -1 /tmp/pe.log > $R/gpurun_out/r3_e2e.log
 python $R/profiles/summarize_rocpd.py /tmp/pe/*/*_results.db $R/gpurun_out/r3_e2e_trace.txt | head -12; cat $R/gpurun_out/r3_e2e.log
 cd $R; python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1

@@ -4,7 +4,7 @@
 Tolerances. A pseudo-range is ~2.5e7 m in a double (4e-9 m resolution) and is weighted by up to 50, the device's sin / cos /
 atan2 differ from the host's in the last bit: a GNSS residual agrees with the oracle's to ~1e-6 absolute (tests/test_gpu_gnss.py
 states 1e-5), so a cost of ~3e3 made of ~100 such residuals agrees to ~1e-7 relative instead of the 1e-9 of a window without
-GNSS: check_solve's bounds are taken times GNSS_LOOSE = 10 here (measured on MI355X, tests/diag_scripts/gnss_diag.py: cost history 1.3e-9
+GNSS: check_solve's bounds are taken times GNSS_LOOSE = 10 here (measured on MI355X, tools/diag_scripts/gnss_diag.py: cost history 1.3e-9
 relative, final cost 5e-11, poses 1e-11 m, clock biases 5e-9 m, anchor 4e-9 m: inside the plain bounds already); the priors'
 normal equations are compared on PRIOR_LOOSE = 100 (A' 1.3e-9 relative measured; b' cancels numbers of the information's size). The receiver clock biases are metres (1e5 m in size), the anchor is ECEF metres."""
 import numpy as np

@@ -48,7 +48,7 @@ def test_factor_blocks_match_oracle(be, oracle, robust):
 
 def check_solve(be, oracle, snap, flag, loose=1.0):
     """Stated FP64 tolerances of a whole optimization() call vs the oracle (measured deviations on
-    MI355X are 2-4 orders of magnitude below them, see tests/diag_parity.py):
+    MI355X are 2-4 orders of magnitude below them, see tools/diag_parity.py):
       accept/reject sequence, iteration count, termination reason : identical
       cost after every iteration : 1e-6 relative (the transient iterations drop the cost by 1e4)
       final cost                 : 1e-9 relative

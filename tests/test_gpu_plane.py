@@ -51,7 +51,7 @@ def test_plane_in_solve_and_marginalisation(be, oracle, anchor):
     # the next window: the prior carries the 4-wide plane block; rejected steps make it an unsettled run that stops on the
     # iteration cap while the cost still moves (193.69 -> 193.28 in its last iteration, still creeping after 15): measured
     # against the oracle with the round-3 kernels 1.9e-8 relative in the final cost and 1.6e-8 m in the poses (6e-9 / 1.5e-8
-    # with 12 or 15 iterations, tests/diag_scripts/plane_settle.py) — tolerances x 50 (x 300 in round 2); the accept / reject sequence,
+    # with 12 or 15 iterations, tools/diag_scripts/plane_settle.py) — tolerances x 50 (x 300 in round 2); the accept / reject sequence,
     # which check_solve compares exactly, and the settled first window at the plain tolerances are the tighter gates
     snap2 = next_plane_window(scn, snap, want)
     for flag in (abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW):

@@ -1,7 +1,7 @@
 """Nothing reads what nobody wrote. A batch's slab is cleared only where the kernels expect zeros (gfbe_batch_upload: 1 of its ~8 MB
 per 2k-landmark window); everything else — the assembled system, the landmark rows past a track's length, the marginalisation's
 work matrices, the download staging ... — must be written before it is read, and a value that is loaded speculatively must be
-replaced, not multiplied by zero. The test hook GFBE_POISON_UNCLEARED=1 fills the not-cleared part with NaN bit patterns at every
+replaced, not multiplied by zero. The test hook GFBE_POISON_UNCLEARED=1 (diagnostics build of the library only) fills the not-cleared part with NaN bit patterns at every
 upload: the results must not change by a bit. (It found k_solve_chain's wide rows multiplying unwritten entries of H by a zero mask:
 harmless while the slab's previous contents are finite, a spurious "linear solve failed" when they are not.)"""
 import os
@@ -26,7 +26,9 @@ def _digest(results):
 
 
 def test_results_do_not_depend_on_the_not_cleared_part_of_the_slab():
-    be = gf.Backend(device=0)
+    # the hook exists in the diagnostics build only (libgfbe_diag.so, -DGFBE_DIAG=1: the same sources, the environment hooks compiled in)
+    assert os.path.exists(gf.backend.DIAG_SO), "run __graft_entry__.build()"
+    be = gf.Backend(device=0, so=gf.backend.DIAG_SO)
     scn = synth.Scenario(seed=11, n_landmarks=300, use_wheel=True)
     r0 = be.solve(scn.window(0), abi.MARGIN_OLD)
     snap = scn.window(1, state=synth.shift_state_for_next_window(scn, r0["state"], 1), prior=r0["prior"])
