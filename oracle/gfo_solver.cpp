@@ -18,6 +18,7 @@
 #include <vector>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <cmath>
 #include <algorithm>
 #include <limits>
@@ -451,6 +452,7 @@ static void solve(const Problem &P, Solution &sol) {
   const int L = P.L;
   gfbe_summary &S = sol.sum;
   std::memset(&S, 0, sizeof S);
+  const auto t_begin = std::chrono::steady_clock::now();      // (Ceres' clock starts before the first evaluation)
   sol.x = w.state;
   sol.lam.assign(w.para_Feature, w.para_Feature + L);
   Lin lin;
@@ -480,6 +482,10 @@ static void solve(const Problem &P, Solution &sol) {
   while (true) {
     // FinalizeIterationAndCheckIfMinimizerCanContinue
     if (it >= std::min(o.max_num_iterations, 15)) { S.termination = 0; break; }   // summary arrays hold 16 entries
+    // Solver::Options::max_solver_time_in_seconds (estimator.cpp:3369-3376: SOLVER_TIME): checked between iterations like
+    // TrustRegionMinimizer does; termination NO_CONVERGENCE. 0 = no cap (the deterministic setting every parity test uses)
+    if (o.max_solver_time_in_seconds > 0.0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() >= o.max_solver_time_in_seconds) { S.termination = 0; break; }
     if (grad_max() <= o.gradient_tolerance) { S.termination = 3; S.status = GFBE_OK; break; }
     if (radius < 1e-32) { S.termination = 4; break; }
     it++;
@@ -713,7 +719,7 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
   std::vector<int> idx_of(GFBE_BLK_COUNT + P.L, -1);
   int pos = 0;
   for (int id : drop) { idx_of[id] = pos; pos += (id < GFBE_BLK_COUNT) ? block_local_size(id) : 1; }
-  const int m = pos;
+  int m = pos;
   for (int b = 0; b < GFBE_BLK_COUNT; b++)
     if (touched[b] && idx_of[b] < 0) { keep.push_back(b); idx_of[b] = pos; pos += block_local_size(b); }
   const int n = pos - m;
@@ -790,6 +796,34 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
       add(r, J, 2, 20, map);
     }
   }
+  if (o.marg_sqrt == 1 && !lm0.empty()) {
+    // NOT the reference's construction (its Amm is eigen-decomposed whole, below): the product's order of elimination (DESIGN.md
+    // section 6, always on in the product; here tied to marg_sqrt = 1 = "the product's algorithm", for bench.py's like-for-like CPU
+    // leg). The landmarks of the drop set are 1-D blocks coupled to the dense dims only: eliminate each with lambda > eps by its own
+    // rank-1 term (a landmark with lambda <= eps is dropped, as the thresholded pseudo-inverse would), then hand the (m - L0 + n)
+    // system to the code below. The same Schur complement whenever every eigenvalue of Amm exceeds eps.
+    const int nl = (int)lm0.size(), md = m - nl, pr = md + n;
+    std::vector<int> nz;
+    for (int k = 0; k < nl; k++) {
+      const int q = md + k;
+      const double lq = A[(size_t)q * pos + q];
+      if (!(lq > o.marg_eps)) continue;
+      nz.clear();
+      for (int i = 0; i < pos; i++) if ((i < md || i >= m) && (A[(size_t)q * pos + i] != 0.0 || A[(size_t)i * pos + q] != 0.0)) nz.push_back(i);
+      for (int i : nz) {
+        const double f = A[(size_t)i * pos + q] / lq;
+        b[i] -= f * b[q];
+        for (int j : nz) A[(size_t)i * pos + j] -= f * A[(size_t)q * pos + j];
+      }
+    }
+    std::vector<double> A2((size_t)pr * pr), b2(pr);
+    auto src = [&](int i) { return i < md ? i : i + nl; };
+    for (int i = 0; i < pr; i++) { b2[i] = b[src(i)]; for (int j = 0; j < pr; j++) A2[(size_t)i * pr + j] = A[(size_t)src(i) * pos + src(j)]; }
+    A.swap(A2); b.swap(b2);
+    // (from here on the landmarks are gone: m, pos and the kept blocks' offsets shrink by L0)
+    for (size_t q = 0; q < idx_of.size(); q++) if (idx_of[q] >= m) idx_of[q] -= nl;
+    m = md; pos = pr;
+  }
   // marginalization_factor.cpp:278-292
   std::vector<double> Amm((size_t)m * m), wv(m), V((size_t)m * m), Amm_inv((size_t)m * m, 0.0);
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Amm[(size_t)i * m + j] = 0.5 * (A[(size_t)i * pos + j] + A[(size_t)j * pos + i]);
@@ -819,6 +853,36 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
   }
   if (A_out) std::memcpy(A_out, Ap.data(), sizeof(double) * n * n);
   if (b_out) std::memcpy(b_out, bp.data(), sizeof(double) * n);
+  if (o.marg_sqrt == 1) {
+    // NOT the reference's construction: the product's default square root (gfbe_options.marg_sqrt = 1), restated
+    // here so that bench.py can time both legs of its CPU / GPU ratio on the SAME algorithm. Diagonally pivoted LDL^T of
+    // the symmetrised A' with pivots > eps:  A' ~= sum_k d_k l_k l_k^T (l_k = column p_k of the remaining matrix / d_k),
+    // J0 row k = sqrt(d_k) l_k^T,  r0[k] = beta_k / sqrt(d_k) with beta_k the p_k-th entry of the right-hand side after the
+    // same eliminations (forward substitution folded in): J0^T J0 = A'+, J0^T r0 = b'+ like the eigen form. Rows past the rank: 0.
+    std::vector<double> M((size_t)n * n), rhs(bp);
+    std::vector<char> gone(n, 0);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) M[(size_t)i * n + j] = 0.5 * (Ap[(size_t)i * n + j] + Ap[(size_t)j * n + i]);
+    for (size_t e = 0; e < (size_t)n * n; e++) out->J0[e] = 0.0;
+    for (int k = 0; k < n; k++) out->r0[k] = 0.0;
+    for (int k = 0; k < n; k++) {
+      int p = -1;
+      for (int i = 0; i < n; i++) if (!gone[i] && (p < 0 || M[(size_t)i * n + i] > M[(size_t)p * n + p])) p = i;   // (first of equal maxima)
+      if (p < 0 || !(M[(size_t)p * n + p] > o.marg_eps)) break;
+      const double dk = M[(size_t)p * n + p], sd = std::sqrt(dk);
+      std::vector<double> l(n, 0.0);
+      for (int i = 0; i < n; i++) if (!gone[i]) l[i] = M[(size_t)i * n + p] / dk;
+      l[p] = 1.0;
+      const double beta = rhs[p];
+      for (int i = 0; i < n; i++) {
+        if (gone[i] || i == p) continue;
+        rhs[i] -= l[i] * beta;
+        for (int j = 0; j < n; j++) if (!gone[j] && j != p) M[(size_t)i * n + j] -= l[i] * dk * l[j];
+      }
+      for (int i = 0; i < n; i++) out->J0[(size_t)k * n + i] = sd * l[i];
+      out->r0[k] = beta / sd;
+      gone[p] = 1;
+    }
+  } else {
   // :294-302  J0 = diag(sqrt(S)) V^T, r0 = diag(1/sqrt(S)) V^T b
   std::vector<double> w2(n), V2((size_t)n * n);
   sym_eig(Ap.data(), n, w2.data(), V2.data());
@@ -829,6 +893,7 @@ static int marginalize(const Problem &P, const gfbe_state &st, const double *lam
     double vb = 0;
     for (int i = 0; i < n; i++) { out->J0[(size_t)k * n + i] = ss * V2[(size_t)i * n + k]; vb += V2[(size_t)i * n + k] * bp[i]; }
     out->r0[k] = si * vb;
+  }
   }
   // getParameterBlocks + addr_shift (estimator.cpp:3561-3590 / 3644-3687)
   out->valid = 1; out->n = n; out->n_blocks = (int)keep.size();
@@ -863,7 +928,7 @@ void gfo_default_options(gfbe_options *o) {
   o->max_num_iterations = 8; o->huber_delta = 1.0; o->vis_sqrt_info = 600.0 / 1.5; o->g_norm = 9.7944;
   o->initial_trust_region_radius = 1e4; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8; o->min_relative_decrease = 1e-3; o->jacobi_scaling = 1; o->marg_eps = 1e-8;
-  o->marg_sqrt = 0;   // the oracle always uses the reference's eigen-decomposition
+  o->marg_sqrt = 0;   // the reference's eigen-decomposition square root (1: the product's pivoted LDL^T, for bench.py's like-for-like CPU leg)
   o->use_graph = 0;   // (device options; meaningless on the CPU)
   o->split_batch = 1;
   o->max_solver_time_in_seconds = 0.0; o->host_threads = 0;

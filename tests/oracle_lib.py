@@ -17,16 +17,25 @@ def build():
     return SO
 
 
+def oracle_options():
+    """The oracle's defaults (gfo_default_options): the product's, except that the square root of the new prior is the reference's
+    eigen-decomposition (marg_sqrt = 0, marginalization_factor.cpp:294-302) unless a test or the like-for-like CPU baseline of
+    bench.py asks for the pivoted LDL^T (marg_sqrt = 1)."""
+    o = abi.default_options()
+    o.marg_sqrt = 0
+    return o
+
+
 class Oracle(abi.CApi):
     prefix = "gfo_"
 
     def __init__(self, lib, opt=None):
         self.lib = abi.bind(lib, "gfo_")
-        self.opt = opt or abi.default_options()
+        self.opt = opt or oracle_options()
         self.head = C.byref(self.opt)
 
     def with_options(self, **kw):
-        o = abi.default_options()
+        o = oracle_options()
         for k, v in kw.items():
             setattr(o, k, v)
         return Oracle(self.lib, o)

@@ -224,6 +224,61 @@ def test_marginalize_old_against_numpy_schur(oracle):
         off += size
 
 
+def numpy_pivoted_ldlt_sqrt(Ap, bp, eps=1e-8):
+    """Independent statement of the product's default square root: diagonally pivoted LDL^T with pivots > eps,
+    written as successive Schur complements on index sets (no in-place elimination loops like the C++ ones)."""
+    n = len(bp)
+    M, rhs = 0.5 * (Ap + Ap.T), bp.copy()
+    left = list(range(n))
+    J0, r0 = np.zeros((n, n)), np.zeros(n)
+    for k in range(n):
+        dg = np.array([M[i, i] for i in left])
+        p = left[int(np.argmax(dg))]
+        if not M[p, p] > eps:
+            break
+        d = M[p, p]
+        col = np.zeros(n)
+        col[left] = M[left, p] / d
+        J0[k] = np.sqrt(d) * col
+        r0[k] = rhs[p] / np.sqrt(d)
+        left.remove(p)
+        M[np.ix_(left, left)] -= d * np.outer(col[left], col[left])
+        rhs[left] -= col[left] * (r0[k] * np.sqrt(d))
+    return J0, r0
+
+
+def test_ldlt_square_root_mode_of_the_oracle(oracle):
+    """gfo_options.marg_sqrt = 1 (the product's default, NOT the reference's construction; used by bench.py's like-for-like CPU leg):
+    the same information as the eigen form, and row for row the numpy statement above."""
+    scn = synth.Scenario(seed=36, n_landmarks=80, use_wheel=True)
+    snap = scn.window(0)
+    pe, A, b, rc = oracle.marginalize(snap, abi.MARGIN_OLD)
+    pl, A1, b1, rc1 = oracle.with_options(marg_sqrt=1).marginalize(snap, abi.MARGIN_OLD)
+    assert rc == 0 and rc1 == 0
+    assert pl["block_id"].tolist() == pe["block_id"].tolist() and np.array_equal(pl["x0"], pe["x0"]) and pl["block_idx"].tolist() == pe["block_idx"].tolist()
+    sc = np.abs(A).max()
+    # marg_sqrt = 1 is "the product's algorithm": the frame-0 landmarks (diagonal block) eliminated first, then the 15 dense dims —
+    # the same Schur complement as the reference's whole-Amm pseudo-inverse (every eigenvalue of Amm exceeds eps here)
+    # (A' cancels numbers of the un-reduced information's size — the inertial factor's ~1e10 —: roundoff is relative to that, as above)
+    _, _, _, a_scale, b_scale = numpy_marginalize_old(snap, oracle.eval_factors(snap, robustify=True))
+    assert np.abs(A1 - A).max() < 1e-11 * a_scale and np.abs(b1 - b).max() < 1e-11 * max(b_scale, 1e-2 * a_scale)
+    A, b = A1, b1
+    assert np.abs(pl["J0"].T @ pl["J0"] - pe["J0"].T @ pe["J0"]).max() < 1e-11 * a_scale
+    assert np.abs(pl["J0"].T @ pl["r0"] - pe["J0"].T @ pe["r0"]).max() < 1e-11 * max(b_scale, 1e-2 * a_scale)
+    J0n, r0n = numpy_pivoted_ldlt_sqrt(A, b)
+    rank = int((np.abs(J0n).sum(axis=1) > 0).sum())
+    assert rank == int((np.abs(pl["J0"]).sum(axis=1) > 0).sum()) and 70 <= rank <= 86
+    # the trailing pivots are Schur complements that have cancelled eight or more digits of A': their rows agree to what is left
+    np.testing.assert_allclose(pl["J0"][:60], J0n[:60], rtol=1e-7, atol=1e-9 * np.sqrt(sc))
+    np.testing.assert_allclose(pl["r0"][:60], r0n[:60], rtol=1e-6, atol=1e-7 * np.abs(r0n).max())
+    # and a whole solve that carries the LDL^T prior forward ends where the eigen one does
+    r0_ = oracle.solve(snap, abi.MARGIN_OLD)
+    r1_ = oracle.with_options(marg_sqrt=1).solve(snap, abi.MARGIN_OLD)
+    nxt = [scn.window(1, state=synth.shift_state_for_next_window(scn, r["state"], 1), prior=r["prior"]) for r in (r0_, r1_)]
+    c0, c1 = oracle.solve(nxt[0], abi.MARGIN_NONE)["summary"], oracle.solve(nxt[1], abi.MARGIN_NONE)["summary"]
+    assert c0["accepted"] == c1["accepted"] and abs(c0["final_cost"] - c1["final_cost"]) < 1e-7 * c0["final_cost"]
+
+
 def test_prior_chain_old_then_second_new(oracle):
     scn = synth.Scenario(seed=37, n_landmarks=300, use_wheel=True)   # enough tracks from frame 0 to reach frame 10
     resA = oracle.solve(scn.window(0), abi.MARGIN_OLD)
