@@ -79,7 +79,9 @@ enum {
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)
   XCHG = 8,                   // doubles per (window, rank) row of a scalar exchange block
   HC = 13,                    // common part of a landmark's H_pl row: pose_i(6) ex(6) td(1)
-  PAIR_CONST_DOUBLES = 63,    // sizeof(PairConst) / 8 (gfbe_factors.h; static_assert in gfbe_kernels.hip)
+  PAIR_CONST_DOUBLES = 75,    // sizeof(PairConst) / 8 (gfbe_factors.h; static_assert in gfbe_kernels.hip)
+  VPY = 28,                   // fused visual partial of a window with constant extrinsic / td: upper triangle of the 7 x 7 [Y r]^T [Y r] (visual_lin_y)
+  VPY_STRIDE = 32,            // doubles per (tile, observation step) slot of vis_part in that layout
   // GNSS inside the window (gfbe_gnss_solve.hip)
   GN_C = 124,                 // compact list of the tangent dims the GNSS factors reach in the solve: position of the 11 poses (33), velocity of
                               // the 11 speed-bias blocks (33), rcv_dt (44), rcv_ddt (11), anc_ecef (3); the yaw is constant there

@@ -88,17 +88,41 @@ GF_HD void visual_eval(const PoseRT &Fi, const PoseRT &Fj, const PoseRT &Ex, dou
 //   d/dtheta_j :  ric^T [P_bj]x    =  [P_cj + ric^T tic]x ric^T
 //   d/dtheta_ex: -Tm [P_ci]x + [Tm P_ci]x + [u]x = [Tm P_ci]x (I - Tm) + [u]x
 // ---------------------------------------------------------------------------------------------
-// (the members a window with constant extrinsic / td needs come first: the reduced kernels stage only that prefix in LDS)
-struct PairConstR {
-  mat3 A, B, Tm, ricT;
-  vec3 u, Btic, c2;                 // c2 = ric^T tic
+// (the members the kernels need come in the order of their prefixes: the cost pass stages Tm and u, the linearisation of a window
+//  with constant extrinsic / td — visual_lin_y below — the 33 doubles of PairConstY, the marginalisation's 13-column panel
+//  PairConstR; only a free extrinsic or td needs the whole record)
+struct PairConstY {
+  mat3 Tm; vec3 u;                  // P_cj = Tm P_ci + u
+  mat3 A;                           // ric^T Rj^T: the world-to-camera-j rotation (dr/dP_w = reduce A)
+  mat3 Rj; vec3 dP;                 // rotation of pose j; ti - tj
+};
+struct PairConstR : PairConstY {
+  mat3 B, ricT;
+  vec3 Btic, c2;                    // c2 = ric^T tic
 };
 struct PairConst : PairConstR {
   mat3 ImTm, jep;                   // jep = B - ric^T  (translation block of the extrinsic)
 };
-enum { PC_DOUBLES = sizeof(PairConst) / sizeof(double), PCR_DOUBLES = sizeof(PairConstR) / sizeof(double) };
+// Per-frame constants of the start frame of a landmark tile (slot (i, i) of the pair table): a landmark's world-frame vectors
+//   f = W p_ci (from the camera centre of frame i), e = f + wt (from the body origin of frame i), W = Ri ric, wt = Ri tic
+//   dPc = P_i - P_0: the landmark seen from the window's origin (frame 0), P_w - P_0 = e + dPc (the panel's second half, below)
+struct FrameConst {
+  mat3 W; vec3 wt; mat3 R; vec3 dPc;
+};
+enum { PC_DOUBLES = sizeof(PairConst) / sizeof(double), PCR_DOUBLES = sizeof(PairConstR) / sizeof(double),
+       PCY_DOUBLES = sizeof(PairConstY) / sizeof(double), FC_DOUBLES = sizeof(FrameConst) / sizeof(double) };
+GF_HD FrameConst make_frame_const(const PoseRT &Fi, const PoseRT &Ex, const PoseRT &F0) {
+  FrameConst f;
+  f.W = mul(Fi.R, Ex.R);
+  f.wt = mv(Fi.R, Ex.t);
+  f.R = Fi.R;
+  f.dPc = sub(Fi.t, F0.t);
+  return f;
+}
 GF_HD PairConst make_pair_const(const PoseRT &Fi, const PoseRT &Fj, const PoseRT &Ex) {
   PairConst p;
+  p.Rj = Fj.R;
+  p.dP = sub(Fi.t, Fj.t);
   p.ricT = transp(Ex.R);
   p.A = tmul(Ex.R, transp(Fj.R));
   p.B = mul(p.A, Fi.R);
@@ -290,6 +314,66 @@ GF_HD double visual_lin(const PC &pc, double inv_dep, double td, double pix, dou
   r[0] = r0 * rs;
   r[1] = r1 * rs;
   return cost;
+}
+
+// ---------------------------------------------------------------------------------------------
+// visual_lin_y: the linearisation of a window with constant extrinsic and td in the form the throughput kernels sum
+// (round 4). Every Jacobian block of the factor is the 2 x 3 derivative of the residual with respect to the landmark's WORLD
+// position, G = reduce ric^T Rj^T (reduce: projectionTwoFrameOneCamFactor.cpp:97-100, times the corrector's sqrt(rho')),
+// times something that is constant over the factors of a pose pair or a 3-vector of the landmark — with e = P_w - P_i:
+//   d/dP_i = G                       d/dtheta_i = -G [e]x Ri                      (:106-110;  Ri [P_bi]x = [e]x Ri)
+//   d/dP_j = -G                      d/dtheta_j =  G [e + P_i - P_j]x Rj          (:118-122;  ric^T [P_bj]x = ric^T Rj^T [P_w - P_j]x Rj)
+//   d/dlambda = -G f / lambda        f = Ri ric P_ci = e - Ri tic                 (:139)
+// With the landmark taken from a point c common to the window (c = P_0; x = P_w - c = e + P_i - c) and
+//   Y = [G | G [x]x]  (2 x 6 per factor; the rows of G [x]x are g x x),   T_f = [ I  [P_f - c]x R_f ;  0  -R_f ]  (6 x 6, per FRAME)
+// this is  J_i = Y T_i,  J_j = -Y T_j:  the block of the pose pair in sum J^T J is -T_i^T (sum Y^T Y) T_j, a frame's diagonal
+// block T_f^T (sum of Y^T Y over every factor that touches the frame) T_f.
+// The kernels therefore sum the 7 x 7 matrix [Y r]^T [Y r] over the factors of a pair — ONE 16-wide matrix-core tile holds
+// both rows of a factor — and apply the T_f once per frame (k_visasm), instead of summing the 13 x 13 one of [J_i J_j r]; and
+// the per-factor work is G, two cross products and the landmark row below instead of four 3 x 3 products. (c inside the
+// window keeps |x| at the size of the scene: G [x]x - G [P_i - c]x cancels nothing a landmark's own distance does not.)
+// Landmark row (w = d/dlambda, d = G^T w): H_ll += w.w, g_l += w.r; the H_pl blocks of the two poses are
+//   pose i: [ d ; Ri^T (e x d) ]  (summed over the landmark's factors: [ D ; Ri^T (e x D) ], D = sum d)
+//   pose j: [ -d ; Rj^T (d x (e + P_i - P_j)) ].
+// Out: r (corrected), g0 / g1 (rows of G), Jl. Returns 0.5 rho(|r|^2). cx, cy, cz = P_ci (the caller's, per landmark).
+// ---------------------------------------------------------------------------------------------
+template <typename PC>
+GF_HD double visual_lin_y(const PC &pc, double cx, double cy, double cz, const vec3 &f, double inv_l, double td, double pjx, double pjy,
+                          double vjx, double vjy, double td_j, double sqrt_info, double delta, double *r, double *g0, double *g1, double *Jl) {
+  const double dtj = td - td_j;
+  vec3 q;
+#pragma unroll
+  for (int a = 0; a < 3; a++) q[a] = __builtin_fma(pc.Tm(a, 0), cx, __builtin_fma(pc.Tm(a, 1), cy, pc.Tm(a, 2) * cz));
+  const double X = q[0] + pc.u[0], Y = q[1] + pc.u[1], Z = q[2] + pc.u[2];                                               // P_cj
+  const double inv_z = 1.0 / Z;
+  const double r0 = sqrt_info * __builtin_fma(X, inv_z, -__builtin_fma(-dtj, vjx, pjx));
+  const double r1 = sqrt_info * __builtin_fma(Y, inv_z, -__builtin_fma(-dtj, vjy, pjy));
+  double s1, rs, asn;
+  const double cost = corrector(__builtin_fma(r0, r0, r1 * r1), delta, &s1, &rs, &asn);
+  const double si = s1 * sqrt_info;
+  const double r00 = si * inv_z, r02 = -(r00 * X * inv_z), r12 = -(r00 * Y * inv_z);   // (r11 == r00)
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    g0[c] = __builtin_fma(r00, pc.A(0, c), r02 * pc.A(2, c));
+    g1[c] = __builtin_fma(r00, pc.A(1, c), r12 * pc.A(2, c));
+  }
+  if (asn != 0.0) {   // a loss with rho'' > 0 (never HuberLoss): J <- J - alpha/|r|^2 r r^T J — on G, which every block is a multiple of
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const double rtj = __builtin_fma(r0, g0[c], r1 * g1[c]);
+      g0[c] -= asn * r0 * rtj;
+      g1[c] -= asn * r1 * rtj;
+    }
+  }
+  Jl[0] = -(__builtin_fma(g0[0], f[0], __builtin_fma(g0[1], f[1], g0[2] * f[2])) * inv_l);
+  Jl[1] = -(__builtin_fma(g1[0], f[0], __builtin_fma(g1[1], f[1], g1[2] * f[2])) * inv_l);
+  r[0] = r0 * rs;
+  r[1] = r1 * rs;
+  return cost;
+}
+// a x b
+GF_HD vec3 cross3(const vec3 &a, const vec3 &b) {
+  return mk3(__builtin_fma(a[1], b[2], -(a[2] * b[1])), __builtin_fma(a[2], b[0], -(a[0] * b[2])), __builtin_fma(a[0], b[1], -(a[1] * b[0])));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1592,13 +1592,22 @@ extern "C" gfbe_status gfbe_debug_timing(gfbe_ctx *c, gfbe_batch *b, int32_t w, 
   return GFBE_OK;
 }
 extern "C" gfbe_status gfbe_debug_vector(gfbe_ctx *c, gfbe_batch *b, int32_t w, int32_t which, double *out) {
-  if (!c || !b || !out || which < 0 || which > 3) return GFBE_BAD_INPUT;
+  if (!c || !b || !out || which < 0 || (which > 3 && !(which >= 1000 && which < 1000 + ND) && !(which >= 2000 && which <= 2000 + NV))) return GFBE_BAD_INPUT;
   int off = w;
   gfbe_batch *p = b;
   while (p && off >= p->d.B) { off -= p->d.B; p = p->second; }
   if (!p || off < 0) return GFBE_BAD_INPUT;
-  const double *src = which == 0 ? p->d.yp : which == 1 ? p->d.vp : which == 2 ? p->d.sp : p->d.g;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (which >= 1000 && which < 1000 + ND) {           // row (which - 1000) of the assembled H (lower triangle valid)
+    HIPCHK(c, hipMemcpy(out, p->d.H + (size_t)off * ND * ND + (size_t)(which - 1000) * ND, sizeof(double) * ND, hipMemcpyDeviceToHost));
+    return GFBE_OK;
+  }
+  if (which >= 2000 && which < 2000 + NV + 1) {       // row (which - 2000) of E (NV entries; row NV: eg)
+    const double *srcE = which == 2000 + NV ? p->d.eg + (size_t)off * NV : p->d.E + (size_t)off * NV * NV + (size_t)(which - 2000) * NV;
+    HIPCHK(c, hipMemcpy(out, srcE, sizeof(double) * NV, hipMemcpyDeviceToHost));
+    return GFBE_OK;
+  }
+  const double *src = which == 0 ? p->d.yp : which == 1 ? p->d.vp : which == 2 ? p->d.sp : p->d.g;
   HIPCHK(c, hipMemcpy(out, src + (size_t)off * ND, sizeof(double) * ND, hipMemcpyDeviceToHost));
   return GFBE_OK;
 }

@@ -188,6 +188,13 @@ __global__ __launch_bounds__(256) void k_prep_prior(BatchDev d) { prep_prior_bod
 static_assert(PC_DOUBLES == PAIR_CONST_DOUBLES, "PairConst layout");
 // (second half of pair_consts_of_state: the NF + 1 poses are staged in sp, the caller's barrier has passed)
 __device__ __forceinline__ void pair_consts_from_staged(double *pc_out, const PoseRT *sp, int lane) {
+  if (lane < NF) {     // the per-frame constants of visual_lin_y in the (unused) diagonal slot (i, i)
+    const FrameConst f = make_frame_const(sp[lane], sp[NF], sp[0]);
+    double *o = pc_out + (size_t)(lane * NF + lane) * PC_DOUBLES;
+    const double *src = (const double *)&f;
+#pragma unroll
+    for (int q = 0; q < FC_DOUBLES; q++) o[q] = src[q];
+  }
   if (lane < NF * (NF - 1) / 2) {
     int i = 0, rem = lane;
     while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
@@ -286,15 +293,23 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   // pair (sframe, j) constants, j = sframe+1 .. 10, from the records the state's producer left (k_reset / k_candidate /
   // k_reanchor): one coalesced load instead of 12 quaternion -> matrix conversions, 10 triple products and two barriers per
   // tile. A window with constant extrinsic and td stages only the members its Jacobian blocks need (PairConstR).
-  typedef typename std::conditional<FULL, PairConst, PairConstR>::type PCT;
-  constexpr int PCW = sizeof(PCT) / sizeof(double), XLD = FULL ? XS_LD : 17;
+  // YM (round 4): the linearisation of a window with constant extrinsic and td sums [Y r]^T [Y r] (7 x 7; visual_lin_y in
+  // gfbe_factors.h) instead of [J_i J_j r]^T [J_i J_j r] (13 x 13): both rows of a factor fit ONE 16-wide matrix-core tile (16
+  // instructions per step instead of 32), the per-factor work is G and two cross products instead of four 3 x 3 products, and a
+  // (tile, step) partial is 28 doubles instead of 157; k_visasm applies the pair's 6 x 12 transform T once per pair. The
+  // marginalisation set (MODE 2) keeps the 13-column panel: k_marg reads its pair sums in the full layout.
+  constexpr bool YM = (MODE == 0 && !FULL);
+  typedef typename std::conditional<FULL, PairConst, typename std::conditional<MODE == 2, PairConstR, PairConstY>::type>::type PCT;
+  constexpr int PCW = (MODE == 1) ? 12 : sizeof(PCT) / sizeof(double), XLD = FULL ? XS_LD : 17;   // (the cost pass uses Tm and u: the first twelve doubles)
   __shared__ PCT pcs[NF];
-  __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XLD];   // one [J | r] row of each of the wave's 64 factors
+  __shared__ FrameConst fcs;
+  __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XLD];   // one [J | r] row of each of the wave's 64 factors (YM: both [Y r] rows)
   const int lane = threadIdx.x;
   {
     const double *src = d.pc + (((size_t)w * 3 + (MODE == 2 ? 2 : buf)) * NPAIR + sframe * NF) * PC_DOUBLES;
     for (int j = sframe + 1; j < NF; j++)
-      if (lane < PCW) ((double *)&pcs[j])[lane] = src[(size_t)j * PC_DOUBLES + lane];
+      for (int q = lane; q < PCW; q += LM_TILE) ((double *)&pcs[j])[q] = src[(size_t)j * PC_DOUBLES + q];     // (the whole record is 75 doubles: two rounds)
+    if (YM && lane < FC_DOUBLES) ((double *)&fcs)[lane] = src[(size_t)sframe * PC_DOUBLES + lane];
   }
   __syncthreads();
   const double td = X[A_TD];
@@ -320,9 +335,26 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   double hC[NHC], Hll = 0.0, gl = 0.0;
 #pragma unroll
   for (int q = 0; q < NHC; q++) hC[q] = 0.0;
-  if (MODE != 1 && !FULL) {   // reduced panel [Ji Jj r 0 0 0]: the three padding columns are written once
+  if (MODE != 1 && !FULL && !YM) {   // reduced panel [Ji Jj r 0 0 0]: the three padding columns are written once
     double *xr = xs + lane * XLD;
     xr[13] = 0.0; xr[14] = 0.0; xr[15] = 0.0;
+  }
+  // YM: the landmark's camera-frame point P_ci and its world-frame vectors (f: from the camera centre of frame i, e: from its
+  // body origin, x: from the window's origin P_0) are the same for all of its factors
+  double ycx = 0.0, ycy = 0.0, ycz = 0.0, yinv_l = 0.0, Dsum[3] = {0.0, 0.0, 0.0};
+  vec3 yf = mk3(0.0, 0.0, 0.0), ye = yf, yx = yf;
+  if (YM) {
+    const double dti = td - tdi;
+    yinv_l = 1.0 / lam;
+    ycx = __builtin_fma(-dti, vix, pix) * yinv_l; ycy = __builtin_fma(-dti, viy, piy) * yinv_l; ycz = piz * yinv_l;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      yf[a] = __builtin_fma(fcs.W(a, 0), ycx, __builtin_fma(fcs.W(a, 1), ycy, fcs.W(a, 2) * ycz));
+      ye[a] = yf[a] + fcs.wt[a];
+      yx[a] = ye[a] + fcs.dPc[a];      // from the window's origin P_0
+    }
+    double *xr = xs + lane * XLD;      // panel row [g0 y0 r0 0 | g1 y1 r1 0]: the two padding columns are written once
+    xr[7] = 0.0; xr[15] = 0.0;
   }
   // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length hold whatever the memory held —
   // lm_obs is not cleared at upload — and are used below the track's length only)
@@ -343,6 +375,80 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
       for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
     }
+    if constexpr (YM) {
+      double *xr = xs + lane * XLD;
+      if (k < m) {
+        const PCT &pc = pcs[sframe + 1 + k];
+        double g0[3], g1[3];
+        const double ck = visual_lin_y(pc, ycx, ycy, ycz, yf, yinv_l, td, pjx, pjy, vjx, vjy, tdj, sq, delta, r, g0, g1, Jl);
+        if (KS > 1) contrib[((size_t)k * VC_STRIDE + 15) * LM_TILE] = ck; else cost += ck;
+        const vec3 y0 = cross3(mk3(g0[0], g0[1], g0[2]), yx), y1 = cross3(mk3(g1[0], g1[1], g1[2]), yx);   // rows of G [x]x
+        // landmark row of the normal equations (w = d/dlambda; a constant landmark has none)
+        const double w0 = is_const ? 0.0 : Jl[0], w1 = is_const ? 0.0 : Jl[1];
+        vec3 dv;
+#pragma unroll
+        for (int q = 0; q < 3; q++) dv[q] = __builtin_fma(g0[q], w0, g1[q] * w1);                         // d = G^T w
+        if (KS > 1) {
+          double *cb = contrib + (size_t)k * VC_STRIDE * LM_TILE;
+          cb[0] = __builtin_fma(w0, w0, w1 * w1);
+          cb[LM_TILE] = __builtin_fma(w0, r[0], w1 * r[1]);
+#pragma unroll
+          for (int q = 0; q < 3; q++) cb[(2 + q) * LM_TILE] = dv[q];
+        } else {
+          Hll += __builtin_fma(w0, w0, w1 * w1);
+          gl += __builtin_fma(w0, r[0], w1 * r[1]);
+#pragma unroll
+          for (int q = 0; q < 3; q++) Dsum[q] += dv[q];
+        }
+        // H_pl block of the observing pose j = s + 1 + k: [ -d ; Rj^T (d x (e + P_i - P_j)) ]
+        const vec3 tj = cross3(dv, add(ye, pc.dP));
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          hp[q] = -dv[q];
+          hp[3 + q] = __builtin_fma(pc.Rj(0, q), tj[0], __builtin_fma(pc.Rj(1, q), tj[1], pc.Rj(2, q) * tj[2]));
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) { xr[q] = g0[q]; xr[3 + q] = y0[q]; xr[8 + q] = g1[q]; xr[11 + q] = y1[q]; }
+        xr[6] = r[0]; xr[14] = r[1];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 7; q++) { xr[q] = 0.0; xr[8 + q] = 0.0; }
+      }
+#if GFBE_KVIS_EARLY
+#pragma unroll
+      for (int q = 0; q < 5; q++) asm volatile("" : "+v"(nob[q]));      // (see the 13-column path below)
+#endif
+      if (k < m) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = hp[q];
+      }
+      // [Y r]^T [Y r] of the step's 64 factors: lane's LDS row holds BOTH residual rows of its factor, eight columns each, so the
+      // 16 x 16 product has the two 8 x 8 blocks wanted on its diagonal (the off-diagonal blocks mix the rows: dropped)
+      typedef double dbl4_y __attribute__((ext_vector_type(4)));
+      dbl4_y acc0 = {0, 0, 0, 0};
+      const int lr = lane & 15, lk = lane >> 4;
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int blk = 0; blk < LM_TILE / 4 / 8; blk++) {
+        double va[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) va[u] = xs[(4 * (8 * blk + u) + lk) * XLD + lr];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc0, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // lane (lk, lr): acc0[q] = entry (lk + 4 q, lr). Rows 0..7 x columns 0..7 (first residual row) live in q = 0, 1 of the lanes
+      // lr < 8; rows 8..15 x columns 8..15 (second row) in q = 2, 3 of the lanes lr >= 8: folded onto the lanes lr < 8
+      const double s0 = acc0[0] + __shfl_down(acc0[2], 8, 64), s1 = acc0[1] + __shfl_down(acc0[3], 8, 64);
+      double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VPY_STRIDE;
+      if (lr < 7) {      // upper triangle of the 7 x 7 sum, row-major packed: (a, b), a <= b, at 7 a - a (a - 1) / 2 + b - a
+        { const int a = lk; if (a <= lr) vo[7 * a - a * (a - 1) / 2 + lr - a] = s0; }
+        { const int a = lk + 4; if (a <= lr) vo[7 * a - a * (a - 1) / 2 + lr - a] = s1; }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (!YM) {
     if (k < m) {
       if (GFBE_ABLATE == 4 && MODE == 0) {
 #pragma unroll
@@ -489,6 +595,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       }
       __builtin_amdgcn_wave_barrier();
     }
+    }   // (!YM)
   }
   if (KS > 1) {
     // the last of the tile's KS workgroups to get here adds the steps' contributions up, in step order
@@ -508,11 +615,24 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       if (MODE != 1) {
         Hll += VC_LD(0);
         gl += VC_LD(1);
+        if (YM) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) { hC[q] += VC_LD(2 + q); if (FULL) hC[6 + q] += VC_LD(8 + q); }
-        if (FULL) hC[12] += VC_LD(14);
+          for (int q = 0; q < 3; q++) Dsum[q] += VC_LD(2 + q);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 6; q++) { hC[q] += VC_LD(2 + q); if (FULL) hC[6 + q] += VC_LD(8 + q); }
+          if (FULL) hC[12] += VC_LD(14);
+        }
       }
 #undef VC_LD
+    }
+  }
+  if (YM) {      // H_pl block of the start pose: [ D ; Ri^T (e x D) ], D = the sum of the factors' d
+    const vec3 ti = cross3(ye, mk3(Dsum[0], Dsum[1], Dsum[2]));
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      hC[q] = Dsum[q];
+      hC[3 + q] = __builtin_fma(fcs.R(0, q), ti[0], __builtin_fma(fcs.R(1, q), ti[1], fcs.R(2, q) * ti[2]));
     }
   }
   if (MODE != 1 && valid) {
@@ -1294,6 +1414,7 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   if (c.done || c.reuse) return;
   // (SPLIT: a start frame without landmarks leaves its block as the upload zeroed it — the structure never changes)
   const bool lead = (i_first == 0) && (!SPLIT || sgrp == 0);   // (SPLIT: this workgroup also carries the cost)
+  if (SPLIT && !d.vis_full && !lead) return;                   // (7 x 7 partials: the lead workgroup builds the whole block, see below)
   if (SPLIT && !lead && ds.sf_tile_begin[i_first] + sgrp >= ds.sf_tile_begin[i_first + 1]) return;
   __shared__ int s_tile_begin[NF + 1];
   const int t = threadIdx.x;
@@ -1323,6 +1444,97 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   const bool row_ok = live && la != 19, mir_ok = live && mirror && lb != 19;
   const bool uses_j = aj || bj;
   const double *vp = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VP_STRIDE + e;
+  if (!d.vis_full) {
+    // ---- constant extrinsic and td in every window of the batch (k_vis<0, false>, visual_lin_y): a (tile, step) partial is the upper
+    // triangle of M = sum [Y r]^T [Y r] (7 x 7, VPY doubles), Y = [G | G [P_w - c]x] with the landmark's world position taken from
+    // the window's origin c = P_0. With T_f = [ I  [P_f - c]x R_f ; 0  -R_f ] (6 x 6, one per FRAME):  J_i = Y T_i,  J_j = -Y T_j, so
+    //   H(i, j) = -T_i^T M(i, j) T_j,   H(f, f) = T_f^T (sum of M over every pair frame f is part of) T_f,
+    //   g(f) = T_f^T (sum of M's r-column over the pairs (f, j) - over the pairs (i, f)).
+    // (1) every pair's M summed over the tiles of its start frame, in tile order, by one owner thread per entry — all loads of
+    //     the window in flight at once; (2) the per-frame sums S_f from LDS; (3) owner-computes over the 66 x 67 entries of the
+    //     pose block: no read-modify-write, no loop over start frames, three block barriers per window.
+    // Small batches (SPLIT): the lead workgroup builds the whole block (vis_Hs block 0, the other blocks stay zero) — the same
+    // sums in the same order as the one-workgroup form.
+    __shared__ double sM[NF * (NF - 1) / 2][VPY];          // pair (i, j) at i (21 - i) / 2 + j - i - 1
+    __shared__ double sS[NF][VPY + 1];                     // per frame: sum of M (entries 0..27), entry 28..: unused
+    __shared__ double sTf[NF][18];                         // per frame: [P_f - c]x R_f (9) | -R_f (9)
+    {
+      const double *pcw = d.pc + ((size_t)w * 3 + c.cur) * NPAIR * PC_DOUBLES;
+      const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
+      for (int q = t; q < NF * 18; q += NT) {
+        const int f = q / 18, en = q - 18 * f;
+        const double *R = pcw + (size_t)(f * NF + f) * PC_DOUBLES + 12;     // FrameConst::R
+        double val;
+        if (en >= 9) val = -R[en - 9];
+        else {        // ([tf]x R)(p, cc) = tf x (column cc of R), component p;  tf = P_f - P_0
+          const int pp = en / 3, cc = en - 3 * pp, p1 = (pp + 1) % 3, p2 = (pp + 2) % 3;
+          const double d1 = X[A_POSE(f) + p1] - X[A_POSE(0) + p1], d2 = X[A_POSE(f) + p2] - X[A_POSE(0) + p2];
+          val = __builtin_fma(d1, R[3 * p2 + cc], -(d2 * R[3 * p1 + cc]));
+        }
+        sTf[f][en] = val;
+      }
+      const double *vpy = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VPY_STRIDE;
+      for (int q = t; q < NF * (NF - 1) / 2 * VPY; q += NT) {
+        const int pr = q / VPY, en = q - pr * VPY;
+        int i = 0, rem = pr;
+        while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
+        const int k = rem, t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
+        double sum = 0.0;
+        for (int tt = t0; tt < t1; tt += 4) {          // (tiles sorted longest first: a tile ran step k iff its first track reaches it)
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const bool on = tt + u < t1 && TILE_OWNED(d, tt + u) && k < ((d.lm_info[ds.lm_off + (tt + u) * LM_TILE] >> 8) & 0xff);
+            v[u] = *(on ? vpy + ((size_t)(tt + u) * MAXOBS + k) * VPY_STRIDE + en : Z);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) sum += v[u];
+        }
+        sM[pr][en] = sum;
+      }
+    }
+    __syncthreads();
+    // S_f: entries of the 6 x 6 block summed over both roles of the frame; the r-column (packed entries (p, 6)) with the sign of the role
+    for (int q = t; q < NF * VPY; q += NT) {
+      const int f = q / VPY, en = q - f * VPY;
+      const bool rcol = en == 6 || en == 12 || en == 17 || en == 21 || en == 24 || en == 26;     // (p, 6), p = 0..5
+      double sum = 0.0;
+      for (int j = f + 1; j < NF; j++) sum += sM[f * (2 * NF - 1 - f) / 2 + j - f - 1][en];
+      for (int i = 0; i < f; i++) { const double v = sM[i * (2 * NF - 1 - i) / 2 + f - i - 1][en]; sum += rcol ? -v : v; }
+      sS[f][en] = sum;
+    }
+    __syncthreads();
+    // T_f(p, a): a < 3: delta(p, a); a >= 3: sTf[f][3 p + a - 3] (p < 3), sTf[f][9 + 3 (p - 3) + a - 3] (p >= 3)
+    auto Mat = [](const double *M, int pp, int qq) { const int lo = min(pp, qq), hi = max(pp, qq); return M[7 * lo - lo * (lo - 1) / 2 + hi - lo]; };
+    for (int q = t; q < (NF * 6) * (NF * 6 + 1); q += NT) {
+      const int a = q / (NF * 6 + 1), b = q - a * (NF * 6 + 1);     // b == 66: the gradient column
+      const int fa = a / 6, la = a - 6 * fa;
+      double z = 0.0;
+      if (b == NF * 6) {
+        const double *M = sS[fa];
+        if (la < 3) z = Mat(M, la, 6);
+        else for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, 6), z);
+        V[a * V_LD + NV] = z;
+        continue;
+      }
+      const int fb = b / 6, lb = b - 6 * fb;
+      const double *M = fa == fb ? sS[fa] : sM[min(fa, fb) * (2 * NF - 1 - min(fa, fb)) / 2 + max(fa, fb) - min(fa, fb) - 1];
+      // row index of M goes with the EARLIER frame of the pair (its Y^T), column with the later one: entry (a, b) = T_fa(:, la)^T M T_fb(:, lb),
+      // M symmetric — the order of the two frames does not matter for the value, only the sign (-1 between different frames)
+      if (la < 3 && lb < 3) z = Mat(M, la, lb);
+      else if (la < 3) { for (int qq = 0; qq < 6; qq++) z = __builtin_fma(Mat(M, la, qq), sTf[fb][3 * qq + lb - 3], z); }
+      else if (lb < 3) { for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, lb), z); }
+      else {
+        for (int pp = 0; pp < 6; pp++) {
+          double row = 0.0;
+          for (int qq = 0; qq < 6; qq++) row = __builtin_fma(Mat(M, pp, qq), sTf[fb][3 * qq + lb - 3], row);
+          z = __builtin_fma(sTf[fa][3 * pp + la - 3], row, z);
+        }
+      }
+      V[a * V_LD + b] = fa == fb ? z : -z;
+    }
+    __syncthreads();
+  } else
   for (int i = i_first; i <= i_last; i++) {
     const int t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
     if (t0 == t1) continue;
@@ -1504,6 +1716,7 @@ __device__ __forceinline__ void asm_H(const BatchDev &d, const int w, const doub
     // factors' (unconditionally: a zero slot with stride 0 where the entry has no visual part), the sums follow below
     double blk[VSPLIT ? U : 1][VS_BLOCKS];
     bool vs[U];
+    const int nvb = d.vis_full ? (int)VS_BLOCKS : 1;
     if (VSPLIT) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -1512,7 +1725,7 @@ __device__ __forceinline__ void asm_H(const BatchDev &d, const int w, const doub
         const double *q = vs[u] ? vis_s + b * V_LD + a : Z;
         const size_t st = vs[u] ? (size_t)NV * V_LD : 0;
 #pragma unroll
-        for (int f = 0; f < VS_BLOCKS; f++) blk[VSPLIT ? u : 0][f] = q[f * st];
+        for (int f = 0; f < VS_BLOCKS; f++) blk[VSPLIT ? u : 0][f] = *(f < nvb ? q + f * st : Z);     // (7 x 7 partials: block 0 holds the whole visual block)
       }
     }
     double v[U];
@@ -1579,7 +1792,7 @@ __device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const doub
         if (!vsplit) v += vis_w[a * V_LD + NV];
         else {
           double sv = 0.0;
-          for (int f = 0; f < VS_BLOCKS; f++) sv += vis_s[(size_t)f * NV * V_LD + a * V_LD + NV];
+          for (int f = 0; f < (d.vis_full ? (int)VS_BLOCKS : 1); f++) sv += vis_s[(size_t)f * NV * V_LD + a * V_LD + NV];
           if (lio_on && a >= lio_o && a < lio_o + 6) {
             double lv = 0.0;
             for (int q = 0; q < LIOW_WGS; q++) lv += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + 21 + a - lio_o];

@@ -623,7 +623,8 @@ void gfbe_profile_reset(gfbe_ctx *ctx);
 gfbe_status gfbe_debug_timing(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, double *out32);
 /* Diagnostics: a per-window vector of the LAST linearisation of a solved batch (GFBE_DENSE_DIM doubles each; waits for the solve):
  * which = 0 Gauss-Newton step y of the dense block (Jacobi-scaled), 1 Cauchy direction v, 2 Jacobi scaling s, 3 gradient g.
- * Lets a test compare the two factorisations of gfbe_options.solve_kernel entry by entry. */
+ * Lets a test compare the two factorisations of gfbe_options.solve_kernel entry by entry. which = 1000 + r: row r of the assembled
+ * normal equations H (lower triangle valid); 2000 + r: row r of the Schur term E (73 entries; r = 73: its gradient share). */
 gfbe_status gfbe_debug_vector(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, int32_t which, double *out);
 
 /* Multi-GPU landmark sharding: when set, the library calls

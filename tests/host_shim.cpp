@@ -67,6 +67,53 @@ extern "C" int shim_eval_factors(const gfbe_options *opt, const gfbe_window *w, 
         if (Jl3[q] != Jl4[q] || r3[q] != r4[q]) return 4;
       }
       if (err > 1e-11 * scale) return 5;
+      {   // the form the throughput kernels sum for a window with constant extrinsic and td (round 4: visual_lin_y) — every Jacobian
+          // block as G times a pair / landmark constant: [J_i J_j] = [G | G [e]x] T, the landmark row from d = G^T w
+        const PoseRT F0 = make_pose(st.para_Pose[0]);
+        const FrameConst fc = make_frame_const(Fi, Ex, F0);
+        const double lamv = w->para_Feature[v.feature_index[k]], inv_l = 1.0 / lamv, dti = st.para_Td - v.td_i[k];
+        const double cx = __builtin_fma(-dti, v.vel_i[2 * k], v.pts_i[3 * k]) * inv_l, cy = __builtin_fma(-dti, v.vel_i[2 * k + 1], v.pts_i[3 * k + 1]) * inv_l,
+                     cz = v.pts_i[3 * k + 2] * inv_l;
+        vec3 f, e;
+        for (int a = 0; a < 3; a++) { f[a] = __builtin_fma(fc.W(a, 0), cx, __builtin_fma(fc.W(a, 1), cy, fc.W(a, 2) * cz)); e[a] = f[a] + fc.wt[a]; }
+        double r5[2], g0[3], g1[3], Jl5[2];
+        const double c5 = visual_lin_y(pc, cx, cy, cz, f, inv_l, st.para_Td, v.pts_j[3 * k], v.pts_j[3 * k + 1], v.vel_j[2 * k], v.vel_j[2 * k + 1], v.td_j[k],
+                                       opt->vis_sqrt_info, delta, r5, g0, g1, Jl5);
+        if (c5 != c3 || r5[0] != r3[0] || r5[1] != r3[1]) return 6;          // the same cost and residual, bit for bit
+        // Y = [G | G [x]x], x = P_w - P_0;  J_i = Y T_i, J_j = -Y T_j with T_f = [ I  [P_f - P_0]x R_f ; 0  -R_f ]
+        const vec3 x = add(e, fc.dPc);
+        const vec3 y0 = cross3(mk3(g0[0], g0[1], g0[2]), x), y1 = cross3(mk3(g1[0], g1[1], g1[2]), x);
+        const mat3 DRi = hat_mul(fc.dPc, fc.R), DRj = hat_mul(sub(Fj.t, F0.t), pc.Rj);
+        double e2 = 0.0;
+        for (int c = 0; c < 3; c++) {
+          const double gi[2] = {g0[c], g1[c]};
+          for (int h = 0; h < 2; h++) {
+            const vec3 &yh = h ? y1 : y0;
+            const double *gh = h ? g1 : g0;
+            e2 = fmax(e2, fabs(gi[h] - Ji3[6 * h + c]));                                                   // d/dP_i = G
+            e2 = fmax(e2, fabs(-gi[h] - Jj3[6 * h + c]));                                                  // d/dP_j = -G
+            const double ji = gh[0] * DRi(0, c) + gh[1] * DRi(1, c) + gh[2] * DRi(2, c) - (yh[0] * fc.R(0, c) + yh[1] * fc.R(1, c) + yh[2] * fc.R(2, c));
+            const double jj = -(gh[0] * DRj(0, c) + gh[1] * DRj(1, c) + gh[2] * DRj(2, c)) + yh[0] * pc.Rj(0, c) + yh[1] * pc.Rj(1, c) + yh[2] * pc.Rj(2, c);
+            e2 = fmax(e2, fabs(ji - Ji3[6 * h + 3 + c]));
+            e2 = fmax(e2, fabs(jj - Jj3[6 * h + 3 + c]));
+          }
+        }
+        for (int q = 0; q < 2; q++) e2 = fmax(e2, fabs(Jl5[q] - Jl3[q]) / fmax(1.0, fabs(Jl3[q])) * scale);
+        // landmark row: pose i [ d ; Ri^T (e x d) ], pose j [ -d ; Rj^T (d x (e + P_i - P_j)) ] against J^T w of the blocks
+        vec3 dv;
+        for (int q = 0; q < 3; q++) dv[q] = __builtin_fma(g0[q], Jl5[0], g1[q] * Jl5[1]);
+        const vec3 ti = cross3(e, dv), tj = cross3(dv, add(e, pc.dP));
+        double hscale = 1.0;
+        for (int q = 0; q < 6; q++) hscale = fmax(hscale, fmax(fabs(Ji3[q] * Jl3[0] + Ji3[6 + q] * Jl3[1]), fabs(Jj3[q] * Jl3[0] + Jj3[6 + q] * Jl3[1])));
+        for (int q = 0; q < 3; q++) {
+          const double hci = fc.R(0, q) * ti[0] + fc.R(1, q) * ti[1] + fc.R(2, q) * ti[2], hpj = pc.Rj(0, q) * tj[0] + pc.Rj(1, q) * tj[1] + pc.Rj(2, q) * tj[2];
+          if (fabs(dv[q] - (Ji3[q] * Jl3[0] + Ji3[6 + q] * Jl3[1])) > 1e-10 * hscale) return 7;
+          if (fabs(hci - (Ji3[3 + q] * Jl3[0] + Ji3[9 + q] * Jl3[1])) > 1e-10 * hscale) return 7;
+          if (fabs(-dv[q] - (Jj3[q] * Jl3[0] + Jj3[6 + q] * Jl3[1])) > 1e-10 * hscale) return 7;
+          if (fabs(hpj - (Jj3[3 + q] * Jl3[0] + Jj3[9 + q] * Jl3[1])) > 1e-10 * hscale) return 7;
+        }
+        if (e2 > 1e-10 * scale) return 8;
+      }
       // what leaves the shim is the kernels' form
       for (int q = 0; q < 12; q++) { Ji[q] = Ji3[q]; Jj[q] = Jj3[q]; Je[q] = Je3[q]; }
       for (int q = 0; q < 2; q++) { Jl[q] = Jl3[q]; Jt[q] = Jt3[q]; r[q] = r3[q]; }
