@@ -1406,6 +1406,104 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
 // KEEP: the block stays in the caller's LDS array V (k_visasm assembles from there) instead of going to vis_H.
 // DUAL: ONE thread group of 512 takes the tiles of both groups, one group after the other — the same sums added in the same order
 // by half the threads (k_visasm: two 512-thread workgroups per CU overlap each other's gather latencies).
+// ---- The visual block of a window whose batch has constant extrinsic and td everywhere (k_vis<0, false>, visual_lin_y): a (tile,
+// step) partial is the upper triangle of M = sum [Y r]^T [Y r] (7 x 7, VPY doubles), Y = [G | G [P_w - c]x] with the landmark's world
+// position taken from the window's origin c = P_0. With T_f = [ I  [P_f - c]x R_f ; 0  -R_f ] (6 x 6, one per FRAME):
+//   J_i = Y T_i,  J_j = -Y T_j   =>   H(i, j) = -T_i^T M(i, j) T_j,   H(f, f) = T_f^T (sum of M over every pair with frame f) T_f,
+//   g(f) = T_f^T (sum of M's r-column over the pairs (f, j) - over the pairs (i, f)).
+// (1) every pair's M summed over the tiles of its start frame, in tile order, by one owner thread per entry — all loads in flight at
+//     once; (2) the per-frame sums S_f from LDS; (3) owner-computes over the entries of the pose block: no read-modify-write, no loop
+//     over start frames, two block barriers.
+// ROW = false (k_visasm: one workgroup per window): all frames, into the LDS block `out` (row stride ld).
+// ROW = true (small batches: one workgroup per frame, side by side on a single window's latency path): the six rows of frame
+//     `frow` — the pairs that frame is part of — straight into vis_Hs block 0 in global memory. The same sums in the same order.
+template <int NT, bool ROW>
+__device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int frow, const int *s_tile_begin,
+                                           double *out, const int ld) {
+  __shared__ double sM[NF * (NF - 1) / 2][VPY];          // pair (i, j) at i (21 - i) / 2 + j - i - 1
+  __shared__ double sS[NF][VPY];                         // per frame: the sum of M over its pairs (r-column: signed by the role)
+  __shared__ double sTf[NF][18];                         // per frame: [P_f - c]x R_f (9) | -R_f (9)
+  const int t = threadIdx.x;
+  const double *Z = d.zero;
+  {
+    const double *pcw = d.pc + ((size_t)w * 3 + c.cur) * NPAIR * PC_DOUBLES;
+    const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
+    for (int q = t; q < NF * 18; q += NT) {
+      const int f = q / 18, en = q - 18 * f;
+      const double *R = pcw + (size_t)(f * NF + f) * PC_DOUBLES + 12;     // FrameConst::R
+      double val;
+      if (en >= 9) val = -R[en - 9];
+      else {        // ([tf]x R)(p, cc) = tf x (column cc of R), component p;  tf = P_f - P_0
+        const int pp = en / 3, cc = en - 3 * pp, p1 = (pp + 1) % 3, p2 = (pp + 2) % 3;
+        const double d1 = X[A_POSE(f) + p1] - X[A_POSE(0) + p1], d2 = X[A_POSE(f) + p2] - X[A_POSE(0) + p2];
+        val = __builtin_fma(d1, R[3 * p2 + cc], -(d2 * R[3 * p1 + cc]));
+      }
+      sTf[f][en] = val;
+    }
+    const double *vpy = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VPY_STRIDE;
+    const int npair = ROW ? NF - 1 : NF * (NF - 1) / 2;
+    for (int q = t; q < npair * VPY; q += NT) {
+      const int pq = q / VPY, en = q - pq * VPY;
+      int i, k;
+      if (ROW) { const int o = pq < frow ? pq : pq + 1; i = min(frow, o); k = max(frow, o) - i - 1; }
+      else { i = 0; int rem = pq; while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; } k = rem; }
+      const int t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
+      double sum = 0.0;
+      for (int tt = t0; tt < t1; tt += 4) {          // (tiles sorted longest first: a tile ran step k iff its first track reaches it)
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool on = tt + u < t1 && TILE_OWNED(d, tt + u) && k < ((d.lm_info[ds.lm_off + (tt + u) * LM_TILE] >> 8) & 0xff);
+          v[u] = *(on ? vpy + ((size_t)(tt + u) * MAXOBS + k) * VPY_STRIDE + en : Z);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) sum += v[u];
+      }
+      sM[i * (2 * NF - 1 - i) / 2 + k][en] = sum;
+    }
+  }
+  __syncthreads();
+  // S_f: entries of the 6 x 6 block summed over both roles of the frame; the r-column (packed entries (p, 6)) with the sign of the role
+  for (int q = t; q < (ROW ? 1 : NF) * VPY; q += NT) {
+    const int f = ROW ? frow : q / VPY, en = ROW ? q : q - f * VPY;
+    const bool rcol = en == 6 || en == 12 || en == 17 || en == 21 || en == 24 || en == 26;     // (p, 6), p = 0..5
+    double sum = 0.0;
+    for (int j = f + 1; j < NF; j++) sum += sM[f * (2 * NF - 1 - f) / 2 + j - f - 1][en];
+    for (int i = 0; i < f; i++) { const double v = sM[i * (2 * NF - 1 - i) / 2 + f - i - 1][en]; sum += rcol ? -v : v; }
+    sS[f][en] = sum;
+  }
+  __syncthreads();
+  // T_f(p, a): a < 3: delta(p, a); a >= 3: sTf[f][3 p + a - 3]
+  auto Mat = [](const double *M, int pp, int qq) { const int lo = min(pp, qq), hi = max(pp, qq); return M[7 * lo - lo * (lo - 1) / 2 + hi - lo]; };
+  constexpr int NC66 = NF * 6;
+  for (int q = t; q < (ROW ? 6 : NC66) * (NC66 + 1); q += NT) {
+    const int ar = q / (NC66 + 1), b = q - ar * (NC66 + 1), a = ROW ? 6 * frow + ar : ar;     // b == 66: the gradient column
+    const int fa = a / 6, la = a - 6 * fa;
+    double z = 0.0;
+    if (b == NC66) {
+      const double *M = sS[fa];
+      if (la < 3) z = Mat(M, la, 6);
+      else for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, 6), z);
+      out[a * ld + NV] = z;
+      continue;
+    }
+    const int fb = b / 6, lb = b - 6 * fb;
+    const double *M = fa == fb ? sS[fa] : sM[min(fa, fb) * (2 * NF - 1 - min(fa, fb)) / 2 + max(fa, fb) - min(fa, fb) - 1];
+    // entry (a, b) = +-T_fa(:, la)^T M T_fb(:, lb); M is symmetric, so the order of the two frames only decides the sign
+    if (la < 3 && lb < 3) z = Mat(M, la, lb);
+    else if (la < 3) { for (int qq = 0; qq < 6; qq++) z = __builtin_fma(Mat(M, la, qq), sTf[fb][3 * qq + lb - 3], z); }
+    else if (lb < 3) { for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, lb), z); }
+    else {
+      for (int pp = 0; pp < 6; pp++) {
+        double row = 0.0;
+        for (int qq = 0; qq < 6; qq++) row = __builtin_fma(Mat(M, pp, qq), sTf[fb][3 * qq + lb - 3], row);
+        z = __builtin_fma(sTf[fa][3 * pp + la - 3], row, z);
+      }
+    }
+    out[a * ld + b] = fa == fb ? z : -z;
+  }
+}
+
 template <bool SPLIT, bool KEEP, bool DUAL>
 __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last, const int sgrp, double *V) {
   constexpr int NT = (SPLIT || DUAL) ? VB_GROUP : VB_THREADS;
@@ -1414,10 +1512,27 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   if (c.done || c.reuse) return;
   // (SPLIT: a start frame without landmarks leaves its block as the upload zeroed it — the structure never changes)
   const bool lead = (i_first == 0) && (!SPLIT || sgrp == 0);   // (SPLIT: this workgroup also carries the cost)
-  if (SPLIT && !d.vis_full && !lead) return;                   // (7 x 7 partials: the lead workgroup builds the whole block, see below)
-  if (SPLIT && !lead && ds.sf_tile_begin[i_first] + sgrp >= ds.sf_tile_begin[i_first + 1]) return;
   __shared__ int s_tile_begin[NF + 1];
   const int t = threadIdx.x;
+  if (SPLIT && !d.vis_full) {
+    // 7 x 7 partials (visblock_y): workgroup v = 2 i_first + sgrp < NF builds the six rows of FRAME v of the visual block, straight into
+    // vis_Hs block 0 (the other blocks, and the rows / columns of the inactive extrinsic and td dims, stay as the upload zeroed them)
+    const int v = 2 * i_first + sgrp;
+    if (v >= NF) return;
+    if (t <= NF) s_tile_begin[t] = ds.sf_tile_begin[t];
+    __syncthreads();
+    visblock_y<NT, true>(d, ds, c, w, v, s_tile_begin, d.vis_Hs + (size_t)w * VS_BLOCKS * NV * V_LD, V_LD);
+    if (lead && t < 64) {      // robustified visual cost of this linearisation point (as below)
+      double cs = 0.0;
+      for (int q = t; q < ds.n_tiles; q += 64) cs += d.tile_cost[(size_t)w * d.max_tiles + q];
+      cs = wave_sum(cs);
+      if (ds.lio_n > 0 && d.rank == 0) for (int q = 0; q < LIOW_WGS; q++) cs += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + 27];
+      for (int r = 0; r < d.world; r++)
+        if (t < XCHG) d.xa[((size_t)w * d.world + r) * XCHG + t] = (r == d.rank && t == 0) ? cs : 0.0;
+    }
+    return;
+  }
+  if (SPLIT && !lead && ds.sf_tile_begin[i_first] + sgrp >= ds.sf_tile_begin[i_first + 1]) return;
   const double *Z = d.zero;
   double *stamp = d.timing + (size_t)w * 32;
 #define ASTAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
@@ -1445,94 +1560,7 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   const bool uses_j = aj || bj;
   const double *vp = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VP_STRIDE + e;
   if (!d.vis_full) {
-    // ---- constant extrinsic and td in every window of the batch (k_vis<0, false>, visual_lin_y): a (tile, step) partial is the upper
-    // triangle of M = sum [Y r]^T [Y r] (7 x 7, VPY doubles), Y = [G | G [P_w - c]x] with the landmark's world position taken from
-    // the window's origin c = P_0. With T_f = [ I  [P_f - c]x R_f ; 0  -R_f ] (6 x 6, one per FRAME):  J_i = Y T_i,  J_j = -Y T_j, so
-    //   H(i, j) = -T_i^T M(i, j) T_j,   H(f, f) = T_f^T (sum of M over every pair frame f is part of) T_f,
-    //   g(f) = T_f^T (sum of M's r-column over the pairs (f, j) - over the pairs (i, f)).
-    // (1) every pair's M summed over the tiles of its start frame, in tile order, by one owner thread per entry — all loads of
-    //     the window in flight at once; (2) the per-frame sums S_f from LDS; (3) owner-computes over the 66 x 67 entries of the
-    //     pose block: no read-modify-write, no loop over start frames, three block barriers per window.
-    // Small batches (SPLIT): the lead workgroup builds the whole block (vis_Hs block 0, the other blocks stay zero) — the same
-    // sums in the same order as the one-workgroup form.
-    __shared__ double sM[NF * (NF - 1) / 2][VPY];          // pair (i, j) at i (21 - i) / 2 + j - i - 1
-    __shared__ double sS[NF][VPY + 1];                     // per frame: sum of M (entries 0..27), entry 28..: unused
-    __shared__ double sTf[NF][18];                         // per frame: [P_f - c]x R_f (9) | -R_f (9)
-    {
-      const double *pcw = d.pc + ((size_t)w * 3 + c.cur) * NPAIR * PC_DOUBLES;
-      const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
-      for (int q = t; q < NF * 18; q += NT) {
-        const int f = q / 18, en = q - 18 * f;
-        const double *R = pcw + (size_t)(f * NF + f) * PC_DOUBLES + 12;     // FrameConst::R
-        double val;
-        if (en >= 9) val = -R[en - 9];
-        else {        // ([tf]x R)(p, cc) = tf x (column cc of R), component p;  tf = P_f - P_0
-          const int pp = en / 3, cc = en - 3 * pp, p1 = (pp + 1) % 3, p2 = (pp + 2) % 3;
-          const double d1 = X[A_POSE(f) + p1] - X[A_POSE(0) + p1], d2 = X[A_POSE(f) + p2] - X[A_POSE(0) + p2];
-          val = __builtin_fma(d1, R[3 * p2 + cc], -(d2 * R[3 * p1 + cc]));
-        }
-        sTf[f][en] = val;
-      }
-      const double *vpy = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VPY_STRIDE;
-      for (int q = t; q < NF * (NF - 1) / 2 * VPY; q += NT) {
-        const int pr = q / VPY, en = q - pr * VPY;
-        int i = 0, rem = pr;
-        while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; }
-        const int k = rem, t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
-        double sum = 0.0;
-        for (int tt = t0; tt < t1; tt += 4) {          // (tiles sorted longest first: a tile ran step k iff its first track reaches it)
-          double v[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const bool on = tt + u < t1 && TILE_OWNED(d, tt + u) && k < ((d.lm_info[ds.lm_off + (tt + u) * LM_TILE] >> 8) & 0xff);
-            v[u] = *(on ? vpy + ((size_t)(tt + u) * MAXOBS + k) * VPY_STRIDE + en : Z);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; u++) sum += v[u];
-        }
-        sM[pr][en] = sum;
-      }
-    }
-    __syncthreads();
-    // S_f: entries of the 6 x 6 block summed over both roles of the frame; the r-column (packed entries (p, 6)) with the sign of the role
-    for (int q = t; q < NF * VPY; q += NT) {
-      const int f = q / VPY, en = q - f * VPY;
-      const bool rcol = en == 6 || en == 12 || en == 17 || en == 21 || en == 24 || en == 26;     // (p, 6), p = 0..5
-      double sum = 0.0;
-      for (int j = f + 1; j < NF; j++) sum += sM[f * (2 * NF - 1 - f) / 2 + j - f - 1][en];
-      for (int i = 0; i < f; i++) { const double v = sM[i * (2 * NF - 1 - i) / 2 + f - i - 1][en]; sum += rcol ? -v : v; }
-      sS[f][en] = sum;
-    }
-    __syncthreads();
-    // T_f(p, a): a < 3: delta(p, a); a >= 3: sTf[f][3 p + a - 3] (p < 3), sTf[f][9 + 3 (p - 3) + a - 3] (p >= 3)
-    auto Mat = [](const double *M, int pp, int qq) { const int lo = min(pp, qq), hi = max(pp, qq); return M[7 * lo - lo * (lo - 1) / 2 + hi - lo]; };
-    for (int q = t; q < (NF * 6) * (NF * 6 + 1); q += NT) {
-      const int a = q / (NF * 6 + 1), b = q - a * (NF * 6 + 1);     // b == 66: the gradient column
-      const int fa = a / 6, la = a - 6 * fa;
-      double z = 0.0;
-      if (b == NF * 6) {
-        const double *M = sS[fa];
-        if (la < 3) z = Mat(M, la, 6);
-        else for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, 6), z);
-        V[a * V_LD + NV] = z;
-        continue;
-      }
-      const int fb = b / 6, lb = b - 6 * fb;
-      const double *M = fa == fb ? sS[fa] : sM[min(fa, fb) * (2 * NF - 1 - min(fa, fb)) / 2 + max(fa, fb) - min(fa, fb) - 1];
-      // row index of M goes with the EARLIER frame of the pair (its Y^T), column with the later one: entry (a, b) = T_fa(:, la)^T M T_fb(:, lb),
-      // M symmetric — the order of the two frames does not matter for the value, only the sign (-1 between different frames)
-      if (la < 3 && lb < 3) z = Mat(M, la, lb);
-      else if (la < 3) { for (int qq = 0; qq < 6; qq++) z = __builtin_fma(Mat(M, la, qq), sTf[fb][3 * qq + lb - 3], z); }
-      else if (lb < 3) { for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, lb), z); }
-      else {
-        for (int pp = 0; pp < 6; pp++) {
-          double row = 0.0;
-          for (int qq = 0; qq < 6; qq++) row = __builtin_fma(Mat(M, pp, qq), sTf[fb][3 * qq + lb - 3], row);
-          z = __builtin_fma(sTf[fa][3 * pp + la - 3], row, z);
-        }
-      }
-      V[a * V_LD + b] = fa == fb ? z : -z;
-    }
+    visblock_y<NT, false>(d, ds, c, w, 0, s_tile_begin, V, V_LD);
     __syncthreads();
   } else
   for (int i = i_first; i <= i_last; i++) {

@@ -6,7 +6,9 @@ atan2 differ from the host's in the last bit: a GNSS residual agrees with the or
 states 1e-5), so a cost of ~3e3 made of ~100 such residuals agrees to ~1e-7 relative instead of the 1e-9 of a window without
 GNSS: check_solve's bounds are taken times GNSS_LOOSE = 10 here (measured on MI355X, tools/diag_scripts/gnss_diag.py: cost history 1.3e-9
 relative, final cost 5e-11, poses 1e-11 m, clock biases 5e-9 m, anchor 4e-9 m: inside the plain bounds already); the priors'
-normal equations are compared on PRIOR_LOOSE = 100 (A' 1.3e-9 relative measured; b' cancels numbers of the information's size). The receiver clock biases are metres (1e5 m in size), the anchor is ECEF metres."""
+normal equations are compared on PRIOR_LOOSE = 300 (A' 1.3e-9 relative measured; b' — the marginal cost's gradient at a state the
+solve left before it had settled, cancelling numbers of the information's size — 1.5e-4 of its largest entry, plus what the difference of the
+linearisation points explains: check_prior). The receiver clock biases are metres (1e5 m in size), the anchor is ECEF metres."""
 import numpy as np
 import pytest
 
@@ -17,7 +19,7 @@ from test_gpu_plane import check_prior
 
 abi, synth = gf.abi, gf.synth
 pytestmark = pytest.mark.gpu
-GNSS_LOOSE, PRIOR_LOOSE = 10.0, 100.0
+GNSS_LOOSE, PRIOR_LOOSE = 10.0, 300.0      # (PRIOR_LOOSE 100 until round 3; the 7 x 7 panel sums of round 4 end the early-stopping GNSS windows 1.5e-4 of |b'| apart)
 
 
 @pytest.fixture(scope="module")
