@@ -237,6 +237,7 @@ struct BatchDev {
   double *lm_hC;              // [HC][tot_lm]
   double *lm_hP;              // [MAXOBS][6][tot_lm]
   double *lm_sl, *lm_yl, *lm_vl;   // Jacobi scale, GN component, Cauchy direction component
+  double *lm_sw;              // [tot_lm] sqrt of the landmark's weight in the Schur term at the current linearisation (k_vis<0> -> k_schur)
   // visual block-CSR records, pair-major: [tot_rec][REC]
   double *rec;
   int tot_rec;

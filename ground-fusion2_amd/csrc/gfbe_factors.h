@@ -371,6 +371,22 @@ GF_HD double visual_lin_y(const PC &pc, double cx, double cy, double cz, const v
   r[1] = r1 * rs;
   return cost;
 }
+// The candidate-cost pass: 0.5 rho(|r|^2) of one factor from the landmark's camera-frame point (cx, cy, cz — per landmark, not per
+// factor: one division by lambda per landmark) — the same operations in the same order as visual_lin / visual_lin_y: the same bits.
+template <typename PC>
+GF_HD double visual_cost_y(const PC &pc, double cx, double cy, double cz, double td, double pjx, double pjy, double vjx, double vjy, double td_j,
+                           double sqrt_info, double delta) {
+  const double dtj = td - td_j;
+  vec3 q;
+#pragma unroll
+  for (int a = 0; a < 3; a++) q[a] = __builtin_fma(pc.Tm(a, 0), cx, __builtin_fma(pc.Tm(a, 1), cy, pc.Tm(a, 2) * cz));
+  const double X = q[0] + pc.u[0], Y = q[1] + pc.u[1], Z = q[2] + pc.u[2];
+  const double inv_z = 1.0 / Z;
+  const double r0 = sqrt_info * __builtin_fma(X, inv_z, -__builtin_fma(-dtj, vjx, pjx));
+  const double r1 = sqrt_info * __builtin_fma(Y, inv_z, -__builtin_fma(-dtj, vjy, pjy));
+  double s1, rs, asn;
+  return corrector(__builtin_fma(r0, r0, r1 * r1), delta, &s1, &rs, &asn);
+}
 // a x b
 GF_HD vec3 cross3(const vec3 &a, const vec3 &b) {
   return mk3(__builtin_fma(a[1], b[2], -(a[2] * b[1])), __builtin_fma(a[2], b[0], -(a[0] * b[2])), __builtin_fma(a[0], b[1], -(a[1] * b[0])));

@@ -791,7 +791,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     if (B < DENSE_SPLIT_MIN_B && !c->allreduce) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
     AL(ctl, B);
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL);
-    AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL);
+    AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL); AL(lm_sw, TL);
     AL(imu_sqrt, (size_t)n_imu_tot * 225); AL(wheel_sqrt, (size_t)n_wheel_tot * 36);
     AL(pair_part, (size_t)B * NF * VP_STRIDE); AL(schur_part, (size_t)B * d.schur_groups * SCHUR_STRIDE);
     AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);

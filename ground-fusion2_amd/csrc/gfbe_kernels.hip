@@ -343,18 +343,20 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   // body origin, x: from the window's origin P_0) are the same for all of its factors
   double ycx = 0.0, ycy = 0.0, ycz = 0.0, yinv_l = 0.0, Dsum[3] = {0.0, 0.0, 0.0};
   vec3 yf = mk3(0.0, 0.0, 0.0), ye = yf, yx = yf;
-  if (YM) {
+  if (YM || MODE == 1) {
     const double dti = td - tdi;
     yinv_l = 1.0 / lam;
     ycx = __builtin_fma(-dti, vix, pix) * yinv_l; ycy = __builtin_fma(-dti, viy, piy) * yinv_l; ycz = piz * yinv_l;
+    if (YM) {
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-      yf[a] = __builtin_fma(fcs.W(a, 0), ycx, __builtin_fma(fcs.W(a, 1), ycy, fcs.W(a, 2) * ycz));
-      ye[a] = yf[a] + fcs.wt[a];
-      yx[a] = ye[a] + fcs.dPc[a];      // from the window's origin P_0
+      for (int a = 0; a < 3; a++) {
+        yf[a] = __builtin_fma(fcs.W(a, 0), ycx, __builtin_fma(fcs.W(a, 1), ycy, fcs.W(a, 2) * ycz));
+        ye[a] = yf[a] + fcs.wt[a];
+        yx[a] = ye[a] + fcs.dPc[a];      // from the window's origin P_0
+      }
+      double *xr = xs + lane * XLD;      // panel row [g0 y0 r0 0 | g1 y1 r1 0]: the two padding columns are written once
+      xr[7] = 0.0; xr[15] = 0.0;
     }
-    double *xr = xs + lane * XLD;      // panel row [g0 y0 r0 0 | g1 y1 r1 0]: the two padding columns are written once
-    xr[7] = 0.0; xr[15] = 0.0;
   }
   // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length hold whatever the memory held —
   // lm_obs is not cleared at upload — and are used below the track's length only)
@@ -448,7 +450,10 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       }
       __builtin_amdgcn_wave_barrier();
     }
-    if constexpr (!YM) {
+    if constexpr (MODE == 1) {
+      if (k < m) cost += visual_cost_y(pcs[sframe + 1 + k], ycx, ycy, ycz, td, pjx, pjy, vjx, vjy, tdj, sq, delta);
+    }
+    if constexpr (!YM && MODE != 1) {
     if (k < m) {
       if (GFBE_ABLATE == 4 && MODE == 0) {
 #pragma unroll
@@ -634,6 +639,21 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       hC[q] = Dsum[q];
       hC[3 + q] = __builtin_fma(fcs.R(0, q), ti[0], __builtin_fma(fcs.R(1, q), ti[1], fcs.R(2, q) * ti[2]));
     }
+  }
+  if (MODE == 0 && valid) {
+    // the landmark's weight in the Schur term, w_l = s_l^2 / (s_l^2 Hll + mu clamp(s_l^2 Hll)) (Jacobi-scaled, mu-regularised), once
+    // per landmark here instead of once per wave that stages it in k_schur; the Jacobi scale s_l is fixed at iteration 0
+    // (TrustRegionMinimizer::IterationZero). A constant landmark has none.
+    const bool first = c.iter == 0;
+    double sl = 1.0, sw = 0.0;
+    if (m > 0 && !is_const) {
+      sl = first ? (d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hll)) : 1.0) : d.lm_sl[slot];      // (loaded here, not ahead of the loop: two registers over
+                                                                                                 //  the 128 that four waves per SIMD allow cost the kernel 6 %)
+      const double hs2 = sl * sl * Hll;
+      sw = sqrt(sl * sl / (hs2 + c.mu * clamp_diag(hs2)));
+    }
+    if (first) d.lm_sl[slot] = sl;
+    d.lm_sw[slot] = sw;
   }
   if (MODE != 1 && valid) {
     d.lm_Hll[slot] = Hll;
@@ -1055,7 +1075,10 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, 
 //   marg :  w_l = 1 / Hll                                         (marginalization_factor.cpp:286-292)
 // =============================================================================================
 typedef double dbl4_t __attribute__((ext_vector_type(4)));
-#define HS_LD 82   // LDS row stride of the landmark panel (80 + 2: spreads the 16-row groups over banks)
+#ifndef GFBE_SCHUR_COMPACT
+#define GFBE_SCHUR_COMPACT 1      // 0 (diagnostics build): the absolute column layout of rounds 1-3 in the solve's Schur panels as well
+#endif
+#define HS_LD 83   // LDS row stride of the landmark panel (odd: the 64 lanes that stage one column spread over 32 bank pairs, two-way instead of four-way)
 
 __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I - 1) / 2 + (J - I); }   // I <= J < 5
 
@@ -1090,17 +1113,28 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool first = (c.iter == 0);   // Jacobi scaling is fixed at iteration 0 (TrustRegionMinimizer::IterationZero)
   // output tiles of this group: tile rows/cols >= I0 (of its first start frame), upper pairs, round-robin over the 4 waves
-  const int I0 = (6 * s_first) / 16;
-  // slot q of this wave owns the (4 q + wave)-th upper tile pair (I, J), I0 <= I <= J < 5 — all wave-uniform
+  // COMPACT panel (the solve; round 4): the columns of a group's panel are taken relative to its first start frame, the gradient
+  // column first — column 0 = sqrt(w) g_l, dim a at 1 + a - 6 s_first — so that a tile's non-zero columns are [0, 6 (s - s_first + m0
+  // + 1)] whatever the group: the 16-column blocks it multiplies are 0 .. jl, (jl + 1)(jl + 2) / 2 pairs, against the absolute columns'
+  // blocks of [6 s, 6 (s + m0 + 1)) plus the block of column 73 (counted on the 2k-landmark windows of the bench: 219 instead of 326
+  // tile pairs per window and linearisation). Pairs are numbered column-major — (I, J) at J (J + 1) / 2 + I — so the active ones of
+  // any tile are a prefix dealt evenly over the four waves. The marginalisation pass keeps the absolute layout k_marg reads.
+  const bool compact = GFBE_SCHUR_COMPACT && !marg;
+  const int coff = compact ? 1 - 6 * s_first : 0;                     // column of dim a: a + coff
+  const int I0 = compact ? 0 : (6 * s_first) / 16;
+  // slot q of this wave owns the (4 q + wave)-th upper tile pair (I, J), I <= J — all wave-uniform
   // scalars, and the four accumulators are separate named registers (no dynamic indexing of AGPRs).
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const int nside = 5 - I0, npairs = nside * (nside + 1) / 2;
+  const int nside = compact ? (1 + 6 * (NF - s_first) + (d.vis_full ? 7 : 0) + 15) / 16 : 5 - I0, npairs = nside * (nside + 1) / 2;
   int pI[4], pJ[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     int idx = 4 * q + wv, I = I0;
     pI[q] = -1; pJ[q] = -1;
-    if (idx < npairs) { while (idx >= 5 - I) { idx -= 5 - I; I++; } pI[q] = I; pJ[q] = I + idx; }
+    if (idx < npairs) {
+      if (compact) { int J = 0; while ((J + 1) * (J + 2) / 2 <= idx) J++; pJ[q] = J; pI[q] = idx - J * (J + 1) / 2; }
+      else { while (idx >= 5 - I) { idx -= 5 - I; I++; } pI[q] = I; pJ[q] = I + idx; }
+    }
   }
   dbl4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   const int lr = lane & 15, lk = lane >> 4;
@@ -1109,106 +1143,128 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   // are issued together (rows beyond a track's length are zero in memory) and the NEXT tile's loads are
   // in flight while the matrix cores work on the current one.
   const int l = t & 63, part = t >> 6;
-  double pre[24];
-  double pHll = 0.0, psl = 1.0;
-  int pinfo = 0, ps = 0, pm0 = 0;       // (ps: start frame of the prefetched tile; pm0: lm_info of its first, longest track)
-  auto prefetch = [&](int tile) {
-    const int slot = ds.lm_off + tile * LM_TILE + l;
-    ps = d.tile_start[ds.tile_off + tile];
-    pm0 = d.lm_info[ds.lm_off + tile * LM_TILE];
-    const int kmax = NF - 1 - ps;       // observing poses ps+1 .. 10
-    pinfo = d.lm_info[slot];
-    pHll = d.lm_Hll[slot];
-    psl = first ? 1.0 : d.lm_sl[slot];
-    if (part == 0) {
-#pragma unroll
-      for (int q = 0; q < HC; q++) pre[q] = d.lm_hC[(size_t)q * TL + slot];
-      pre[HC] = d.lm_gl[slot];
-    } else {
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int k = part - 1 + 3 * u;
-#pragma unroll
-        for (int q = 0; q < 6; q++) pre[u * 6 + q] = (k < kmax) ? d.lm_hP[((size_t)k * 6 + q) * TL + slot] : 0.0;
-      }
-    }
-  };
+  const bool hc_full = marg || d.vis_full;      // the linearisation of a batch with constant extrinsic / td everywhere leaves rows 6..12 of lm_hC alone
+  // What a thread holds of one landmark tile between its loads and its staging. DEEP (throughput batches): the tiles t + 1 AND t + 2
+  // are in flight while the matrix cores work on tile t — with one tile ahead a light tile (a few tile pairs) took a whole
+  // memory round trip under load, ~5 us, whatever its arithmetic; two register sets, two workgroups per CU instead of three.
+  // (the two register sets are plain local arrays and the tile body a macro over their names: a struct passed to a lambda by
+  //  reference left part of it in scratch memory)
+  // start frame of a tile from the descriptor's table (scalar loads): no dependent load before the rows can be fetched
+  // (the table staged in LDS once and the trust-region scalar read once: a vector-memory load inside the tile loop would make every
+  //  staging wait for ALL loads in flight — the counter is in order — and undo the two-deep prefetch)
+  __shared__ int s_sf[NF + 1];
+  if (t <= NF) s_sf[t] = ds.sf_tile_begin[t];
+  const int lm_off_c = ds.lm_off;
+  __syncthreads();
+  auto sframe_of = [&](int tile) __attribute__((always_inline)) { int sf = s_first; for (int q = s_first + 1; q < s_end; q++) sf += (tile >= s_sf[q]) ? 1 : 0; return sf; };
+  // Thread (l, part): landmark l of the tile; part 0 holds the common columns (start pose 6, extrinsic 6, td, gradient) and the tenth
+  // observing pose (k = 9: start frame 0 only), parts 1..3 the observing poses k = part - 1, part + 2, part + 5: 20 doubles each.
+  // Branch-free and always the same number of vector-memory operations (22 loads per thread, whatever its part and the tile): the
+  // compiler's wait-count insertion can then let the younger set's loads stay in flight while the older set is staged
+  // (s_waitcnt vmcnt(23+) instead of vmcnt(0)); rows a thread does not need are loaded from a neighbouring valid row and ignored.
+#define SCHUR_PV 20
+#define SCHUR_PREFETCH(PV, PHLL, PINFO, PS, TILE)                                                                   \
+  {                                                                                                                      \
+    const int tile_ = min((TILE), te - 1);                                                                               \
+    const int slot_ = lm_off_c + tile_ * LM_TILE + l;                                                                    \
+    PS = sframe_of(tile_);                                                                                               \
+    const int klast_ = max(NF - 2 - PS, 0);       /* last observing pose index of the tile's start frame */              \
+    PINFO = d.lm_info[slot_];                                                                                            \
+    PHLL = (marg ? d.lm_Hll : d.lm_sw)[slot_];      /* solve: sqrt(w_l), left by the linearisation */                    \
+    const double *gl_ = d.lm_gl + slot_;                                                                                 \
+    _Pragma("unroll") for (int idx_ = 0; idx_ < SCHUR_PV; idx_++) {                                                      \
+      const int u_ = idx_ / 6, q_ = idx_ - 6 * u_;                                                                       \
+      const int kk_ = min(part - 1 + 3 * u_, klast_), k9_ = min(9, klast_);                                              \
+      const double *src_ = part == 0 ? (idx_ < HC ? d.lm_hC + (size_t)((idx_ < 6 || hc_full) ? idx_ : 5) * TL + slot_   \
+                                                  : (idx_ == HC ? gl_ : d.lm_hP + ((size_t)k9_ * 6 + (idx_ - HC - 1)) * TL + slot_)) \
+                                     : d.lm_hP + ((size_t)kk_ * 6 + q_) * TL + slot_;                                    \
+      PV[idx_] = *src_;                                                                                                  \
+    }                                                                                                                    \
+  }
   const bool stamp_wg = (w == 0 && grp == 0 && t == 0 && !marg);
   double *stamp = d.timing + 8;
   if (stamp_wg) { stamp[0] = (double)wall_clock64(); stamp[5] = (double)clock64(); }
   const int tstep = sub == 2 ? 2 : d.world;
-  prefetch(tfirst);
-  for (int tile = tfirst; tile < te; tile += tstep) {
-    __syncthreads();
-    if (stamp_wg && tile == tfirst) stamp[1] = (double)wall_clock64();
-    // The tracks of a tile are sorted longest first: its rows are zero beyond the pose columns of the first track's last observer,
-    // jl = the last 16-column block they reach (block 4 holds the extrinsic / td / gradient columns of every row). Tile pairs
-    // outside are products of zeros: skipped (the accumulators keep their bits: + 0.0).
-    const int jl = __builtin_amdgcn_readfirstlane((6 * (ps + ((pm0 >> 8) & 0xff) + 1) - 1) >> 4);
-    {
-      const int s = ps, kmax = NF - 1 - s;          // this tile's start frame
-      const int slot = ds.lm_off + tile * LM_TILE + l;
-      const bool valid = (pinfo >> 24) & 1;
-      const int m = (pinfo >> 8) & 0xff;
-      const bool is_const = (pinfo >> 16) & 1;
-      double sw = 0.0;
-      if (valid && m > 0 && (marg || !is_const)) {
-        double wl;
-        if (marg) {
-          wl = (pHll > d.opt.marg_eps) ? 1.0 / pHll : 0.0;
-        } else {
-          double sl = psl;
-          if (first) { sl = d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(pHll)) : 1.0; if (part == 0) d.lm_sl[slot] = sl; }
-          const double hs2 = sl * sl * pHll;
-          wl = sl * sl / (hs2 + c.mu * clamp_diag(hs2));
-        }
-        sw = sqrt(wl);
-      } else if (!marg && first && valid && part == 0) {
-        d.lm_sl[slot] = 1.0;
-      }
-      double *row = hs + l * HS_LD;
-      if (part == 0) {
-        for (int q = 16 * I0; q < 6 * s; q++) row[q] = 0.0;
-#pragma unroll
-        for (int q = 0; q < 6; q++) { row[6 * s + q] = sw * pre[q]; row[T_EX + q] = sw * pre[6 + q]; }
-        row[T_TD] = sw * pre[12];
-        row[NV] = sw * pre[HC];
-#pragma unroll
-        for (int q = NV + 1; q < NVP; q++) row[q] = 0.0;
-      } else {
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int k = part - 1 + 3 * u;
-          if (k < kmax) {
-            // (rows from the landmark's track length on were never written — lm_hP is not cleared at upload: zeros, not products)
-            const bool written = valid && k < m;
-#pragma unroll
-            for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = written ? sw * pre[u * 6 + q] : 0.0;
-          }
-        }
-      }
-    }
-    __syncthreads();
-    if (stamp_wg && tile == tfirst) stamp[2] = (double)wall_clock64();
-    if (tile + tstep < te) prefetch(tile + tstep);
 #define SCHUR_SLOT(Q, ACC)                                                                          \
-    if (pI[Q] >= 0 && (pI[Q] <= jl || pI[Q] == 4) && (pJ[Q] <= jl || pJ[Q] == 4)) {                 \
+    if (pI[Q] >= 0 && (compact ? pJ[Q] <= jl : ((pI[Q] <= jl || pI[Q] == 4) && (pJ[Q] <= jl || pJ[Q] == 4)))) {   \
       const double *pa = hs + 16 * pI[Q] + lr + lk * HS_LD, *pb = hs + 16 * pJ[Q] + lr + lk * HS_LD; \
-      double va[LM_TILE / 4], vb[LM_TILE / 4];                                                      \
-      _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 4; kk++) { va[kk] = pa[4 * kk * HS_LD]; vb[kk] = pb[4 * kk * HS_LD]; } \
-      _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 4; kk++) ACC = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], ACC, 0, 0, 0); \
+      _Pragma("unroll") for (int hf = 0; hf < 2; hf++) {      /* (operands eight k-steps at a time: 32 instead of 64 registers) */ \
+        double va[LM_TILE / 8], vb[LM_TILE / 8];                                                    \
+        _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 8; kk++) { va[kk] = pa[4 * (8 * hf + kk) * HS_LD]; vb[kk] = pb[4 * (8 * hf + kk) * HS_LD]; } \
+        _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 8; kk++) ACC = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], ACC, 0, 0, 0); \
+      }                                                                                             \
     }
-    SCHUR_SLOT(0, acc0)
-    SCHUR_SLOT(1, acc1)
-    SCHUR_SLOT(2, acc2)
-    SCHUR_SLOT(3, acc3)
-#undef SCHUR_SLOT
+  // one tile: stage the register set into the LDS panel, refill the set with tile REFILL (if < te), multiply.
+  // The tracks of a tile are sorted longest first (pm0: its first landmark, lane 0 of every wave): its rows are zero beyond the pose
+  // columns of the first track's last observer, jl = the last 16-column block they reach (absolute layout: block 4 holds the
+  // extrinsic / td / gradient columns of every row). Tile pairs outside are products of zeros: skipped (the accumulators keep their bits).
+#define SCHUR_RUN_TILE(PV, PHLL, PINFO, PS, TILE, REFILL)                                                           \
+  {                                                                                                                      \
+    __syncthreads();                                                                                                     \
+    if (stamp_wg && (TILE) == tfirst) stamp[1] = (double)wall_clock64();                                                 \
+    const int ps = PS, pm0 = __builtin_amdgcn_readfirstlane(PINFO);                                                      \
+    const int jl = __builtin_amdgcn_readfirstlane(compact ? (d.vis_full ? nside - 1 : (6 * (ps - s_first + ((pm0 >> 8) & 0xff) + 1)) >> 4) \
+                                                          : (6 * (ps + ((pm0 >> 8) & 0xff) + 1) - 1) >> 4);              \
+    {                                                                                                                    \
+      const int s = ps, kmax = NF - 1 - s;          /* this tile's start frame */                                        \
+      const int slot = lm_off_c + (TILE) * LM_TILE + l;                                                                  \
+      const bool valid = (PINFO >> 24) & 1;                                                                              \
+      const int m = (PINFO >> 8) & 0xff;                                                                                 \
+      const bool is_const = (PINFO >> 16) & 1;                                                                           \
+      double sw = 0.0;                                                                                                   \
+      if (valid && m > 0 && (marg || !is_const))                                                                         \
+        sw = marg ? sqrt((PHLL > d.opt.marg_eps) ? 1.0 / PHLL : 0.0) : PHLL;                                             \
+      double *row = hs + l * HS_LD + coff;                                                                               \
+      if (part == 0) {                                                                                                   \
+        for (int q = compact ? 6 * s_first : 16 * I0; q < 6 * s; q++) row[q] = 0.0;                                      \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) { row[6 * s + q] = sw * PV[q]; row[T_EX + q] = hc_full ? sw * PV[6 + q] : 0.0; } \
+        row[T_TD] = hc_full ? sw * PV[12] : 0.0;                                                                         \
+        if (compact) {                                                                                                   \
+          row[-coff] = sw * PV[HC];                                     /* column 0: the gradient */                     \
+          for (int q = NV + coff; q < 16 * nside; q++) row[q - coff] = 0.0;     /* behind td, up to the last block any tile of the group multiplies */ \
+        } else {                                                                                                         \
+          row[NV] = sw * PV[HC];                                                                                         \
+          _Pragma("unroll") for (int q = NV + 1; q < NVP; q++) row[q] = 0.0;                                             \
+        }                                                                                                                \
+        if (9 < kmax) {                                                  /* the tenth observing pose (start frame 0) */  \
+          const bool written = valid && 9 < m;                                                                           \
+          _Pragma("unroll") for (int q = 0; q < 6; q++) row[6 * (s + 10) + q] = written ? sw * PV[HC + 1 + q] : 0.0;     \
+        }                                                                                                                \
+      } else {                                                                                                           \
+        _Pragma("unroll") for (int u = 0; u < 3; u++) {                                                                  \
+          const int k = part - 1 + 3 * u;                                                                                \
+          if (k < kmax) {                                                                                                \
+            /* (rows from the landmark's track length on were never written — lm_hP is not cleared at upload: zeros, not products) */ \
+            const bool written = valid && k < m;                                                                         \
+            _Pragma("unroll") for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = written ? sw * PV[u * 6 + q] : 0.0;   \
+          }                                                                                                              \
+        }                                                                                                                \
+      }                                                                                                                  \
+    }                                                                                                                    \
+    __syncthreads();                                                                                                     \
+    if (stamp_wg && (TILE) == tfirst) stamp[2] = (double)wall_clock64();                                                 \
+    SCHUR_PREFETCH(PV, PHLL, PINFO, PS, (REFILL))          /* (past the last tile: a repeat of it, never staged) */ \
+    SCHUR_SLOT(0, acc0)                                                                                                  \
+    SCHUR_SLOT(1, acc1)                                                                                                  \
+    SCHUR_SLOT(2, acc2)                                                                                                  \
+    SCHUR_SLOT(3, acc3)                                                                                                  \
   }
+  double preA[SCHUR_PV], aHll = 0.0;
+  int aInfo = 0, aS = 0;
+  SCHUR_PREFETCH(preA, aHll, aInfo, aS, tfirst)
+  // (measured, round 4: TWO tiles ahead — a second register set, the compiler's wait counts letting the younger set stay in flight —
+  //  was slower at two and at three workgroups per CU, 183-198 against 169-175 us per 512 windows: the kernel is not bound by the
+  //  latency of its loads)
+  for (int tile = tfirst; tile < te; tile += tstep) SCHUR_RUN_TILE(preA, aHll, aInfo, aS, tile, tile + tstep)
+#undef SCHUR_RUN_TILE
+#undef SCHUR_SLOT
+#undef SCHUR_PREFETCH
+#undef SCHUR_PV
   if (stamp_wg) { stamp[3] = (double)wall_clock64(); stamp[4] = (double)(te - tb); stamp[6] = (double)clock64(); }
   double *out = d.schur_part + ((size_t)w * d.schur_groups + grp) * SCHUR_STRIDE;
 #define SCHUR_OUT(Q, ACC)                                                         \
   if (pI[Q] >= 0) {                                                               \
-    double *o = out + (size_t)schur_pair(pI[Q], pJ[Q]) * 256;                     \
+    double *o = out + (size_t)(compact ? pJ[Q] * (pJ[Q] + 1) / 2 + pI[Q] : schur_pair(pI[Q], pJ[Q])) * 256; \
     _Pragma("unroll") for (int r = 0; r < 4; r++) o[(lk + 4 * r) * 16 + lr] = ACC[r]; \
   }
   SCHUR_OUT(0, acc0)
@@ -1356,34 +1412,44 @@ __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab
 // E(a,b), a <= b < NVP (b = 73: the gradient column): the Schur partials of the start-frame groups that reach dim a (a group
 // reaches the dims from its first start frame's pose on), loads unconditional in flight
 __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z, int w, int a, int b) {
-  const int off = schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);
-  const double *sp = d.schur_part + (size_t)w * d.schur_groups * SCHUR_STRIDE + off;
+  // compact panels (schur_body): in the partial of a group whose first start frame is s, dim x sits in column 1 + x - 6 s and the
+  // gradient in column 0; entry (r, c), r <= c, of the panel product at tile pair (r >> 4, c >> 4) = slot J (J + 1) / 2 + I
+  const double *sp = d.schur_part + (size_t)w * d.schur_groups * SCHUR_STRIDE;
+  auto off_of = [&](int s) {
+    if (!GFBE_SCHUR_COMPACT) return schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);      // (diagnostics: the absolute layout of rounds 1-3)
+    const int ca = 1 + a - 6 * s, r = b == NV ? 0 : ca, cc = b == NV ? ca : 1 + b - 6 * s;
+    const int I = r >> 4, J = cc >> 4;
+    return (J * (J + 1) / 2 + I) * 256 + (r & 15) * 16 + (cc & 15);
+  };
   const int ng = d.schur_groups;
   if (ng == SCHUR_GROUPS) {
     double v[SCHUR_GROUPS];
 #pragma unroll
-    for (int f = 0; f < SCHUR_GROUPS; f++) v[f] = *(6 * schur_group_first(f, SCHUR_GROUPS) <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
-    double s = 0.0;
+    for (int f = 0; f < SCHUR_GROUPS; f++) {
+      const int s = schur_group_first(f, SCHUR_GROUPS);
+      v[f] = *(6 * s <= a ? sp + (size_t)f * SCHUR_STRIDE + off_of(s) : Z);
+    }
+    double sum = 0.0;
 #pragma unroll
-    for (int f = 0; f < SCHUR_GROUPS; f++) s += v[f];
-    return s;
+    for (int f = 0; f < SCHUR_GROUPS; f++) sum += v[f];
+    return sum;
   }
   if (ng == NF) {
     double v[NF];
 #pragma unroll
-    for (int f = 0; f < NF; f++) v[f] = *(6 * f <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
-    double s = 0.0;
+    for (int f = 0; f < NF; f++) v[f] = *(6 * f <= a ? sp + (size_t)f * SCHUR_STRIDE + off_of(f) : Z);
+    double sum = 0.0;
 #pragma unroll
-    for (int f = 0; f < NF; f++) s += v[f];
-    return s;
+    for (int f = 0; f < NF; f++) sum += v[f];
+    return sum;
   }
   double v[2 * NF];           // small batches: two partials per start frame
 #pragma unroll
-  for (int f = 0; f < 2 * NF; f++) v[f] = *(6 * (f >> 1) <= a ? sp + (size_t)f * SCHUR_STRIDE : Z);
-  double s = 0.0;
+  for (int f = 0; f < 2 * NF; f++) v[f] = *(6 * (f >> 1) <= a ? sp + (size_t)f * SCHUR_STRIDE + off_of(f >> 1) : Z);
+  double sum = 0.0;
 #pragma unroll
-  for (int f = 0; f < 2 * NF; f++) s += v[f];
-  return s;
+  for (int f = 0; f < 2 * NF; f++) sum += v[f];
+  return sum;
 }
 
 // k_visblock (one workgroup per window): the visual block of the normal equations.
@@ -1896,12 +1962,21 @@ __device__ __forceinline__ void lm_step_tile(const BatchDev &d, const WinDesc &d
   double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (free_lm) {
     double hy = 0.0, hv = 0.0;
-    for (int q = 0; q < 6; q++) {
-      const double hi = d.lm_hC[(size_t)q * TL + slot], he = d.lm_hC[(size_t)(6 + q) * TL + slot];
-      hy += hi * sy[6 * s0 + q] + he * sy[T_EX + q];
-      hv += hi * sv[6 * s0 + q] + he * sv[T_EX + q];
+    if (d.vis_full) {
+      for (int q = 0; q < 6; q++) {
+        const double hi = d.lm_hC[(size_t)q * TL + slot], he = d.lm_hC[(size_t)(6 + q) * TL + slot];
+        hy += hi * sy[6 * s0 + q] + he * sy[T_EX + q];
+        hv += hi * sv[6 * s0 + q] + he * sv[T_EX + q];
+      }
+      { const double ht = d.lm_hC[(size_t)12 * TL + slot]; hy += ht * sy[T_TD]; hv += ht * sv[T_TD]; }
+    } else {      // constant extrinsic and td in every window of the batch: their rows of lm_hC are not written and their step is zero —
+                  // the sums below add the same terms in the same order (x + 0 * 0 = x) without the seven loads
+      for (int q = 0; q < 6; q++) {
+        const double hi = d.lm_hC[(size_t)q * TL + slot];
+        hy += hi * sy[6 * s0 + q] + 0.0;
+        hv += hi * sv[6 * s0 + q] + 0.0;
+      }
     }
-    { const double ht = d.lm_hC[(size_t)12 * TL + slot]; hy += ht * sy[T_TD]; hv += ht * sv[T_TD]; }
     for (int k = 0; k < m; k++)
       for (int q = 0; q < 6; q++) {
         const double h = d.lm_hP[((size_t)k * 6 + q) * TL + slot];

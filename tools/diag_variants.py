@@ -13,6 +13,8 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "ground-fusion2_amd", "csrc", "variants")
 VARIANTS = {   # name -> (extra flags, fp-contract)
     "base": ([], "off"),
+    "schurabs": (["-DGFBE_SCHUR_COMPACT=0"], "off"),
+    "schur1deep": (["-DGFBE_SCHUR_DEEP=0"], "off"),
     "noearly": (["-DGFBE_KVIS_EARLY=0"], "off"),
     "contract": ([], "fast"),
     "stamp": (["-DGFBE_KVIS_STAMP=1"], "off"),
