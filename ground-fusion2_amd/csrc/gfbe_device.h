@@ -264,7 +264,8 @@ struct BatchDev {
                               //   xa: visual cost of the linearisation point; xb: landmark shares of the dogleg scalars;
                               //   xc: candidate cost / step norms
   double *vis_H;              // [B][73][74]  visual block of the normal equations + gradient column (k_visblock)
-  double *vis_Hs;             // small batches only (else nullptr): [B][VS_BLOCKS][73][74], one block per (start frame, thread group), summed by k_assemble
+  double *vis_Hs;             // small batches only (else nullptr): [B][vs_blocks][73][74], one block per (start frame, thread group), summed by k_assemble
+  int vs_blocks;              // VS_BLOCKS when some window has a free extrinsic / td (13/20-column partials); 1 otherwise: block 0 is the whole visual block (visblock_y)
   double *raw_imu, *raw_wheel; // [MAX_IMU][15 + 450][B], [MAX_WHEEL][6 + 132][B]  un-whitened residuals / Jacobians (k_dense_raw), window-minor
   int *asm_tab;               // [ND (ND + 1) / 2][4]  window-independent assembly table (k_asm_table)
   double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble

@@ -109,6 +109,8 @@ struct gfbe_ctx {
   bool profiling = false;
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> event_pool;
+  std::vector<hipEvent_t> sync_event_pool;            // hipEventDisableTiming events of freed batches (three per batch: created and destroyed per
+                                                      // gfbe_solve_window call they cost ~50 us of its 1.45 ms)
   gfbe_allreduce_fn allreduce = nullptr;
   void *allreduce_user = nullptr;
   int allreduce_rc = 0;                               // first non-zero return of the hook during the current gfbe_batch_solve
@@ -272,6 +274,7 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
 void gfbe_destroy(gfbe_ctx *c) {
   if (!c) return;
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  for (auto e : c->sync_event_pool) (void)hipEventDestroy(e);
   for (auto &p : c->prof) for (auto &ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
@@ -624,8 +627,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::memset(&d, 0, sizeof d);
   d.B = B;
   d.opt = c->opt;
-  if (hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&b->ev_dl, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate (batch) failed"; return GFBE_DEVICE_ERROR; }
+  for (hipEvent_t *e : {&b->ev_up, &b->ev_done, &b->ev_dl}) {
+    if (!c->sync_event_pool.empty()) { *e = c->sync_event_pool.back(); c->sync_event_pool.pop_back(); }
+    else if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate (batch) failed"; return GFBE_DEVICE_ERROR; }
+  }
   // the stream the upload runs on: host-fed batches use the copy stream (beside a solve on the main stream); the table-fed
   // path follows the table operations on the main stream
   hipStream_t us = tabs ? c->stream : c->copy;
@@ -788,7 +793,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
     AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
     AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
-    if (B < DENSE_SPLIT_MIN_B && !c->allreduce) { AL(vis_Hs, (size_t)B * VS_BLOCKS * NV * (NV + 1)); } else d.vis_Hs = nullptr;
+    d.vs_blocks = d.vis_full ? (int)VS_BLOCKS : 1;
+    if (B < DENSE_SPLIT_MIN_B && !c->allreduce) { AL(vis_Hs, (size_t)B * d.vs_blocks * NV * (NV + 1)); } else d.vis_Hs = nullptr;
     AL(ctl, B);
     AL(lam, 2 * TL); AL(lm_Hll, TL); AL(lm_gl, TL); AL(lm_hC, (size_t)HC * TL);
     AL(lm_sl, TL); AL(lm_yl, TL); AL(lm_vl, TL); AL(lm_sw, TL);
@@ -1150,7 +1156,7 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
     }
   }
   for (auto &g : b->graph) if (g) (void)hipGraphExecDestroy(g);
-  for (hipEvent_t e : {b->ev_up, b->ev_done, b->ev_dl}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {b->ev_up, b->ev_done, b->ev_dl}) if (e) { if (c && c->sync_event_pool.size() < 64) c->sync_event_pool.push_back(e); else (void)hipEventDestroy(e); }
   slab_release(c, b);
   if (c) { pin_release(c, b->up_h, b->up_cap); pin_release(c, b->dl_h, b->dl_cap); }
   else { if (b->up_h) (void)hipHostFree(b->up_h); if (b->dl_h) (void)hipHostFree(b->dl_h); }
@@ -1345,12 +1351,17 @@ static gfbe_status fetch_one(gfbe_ctx *c, gfbe_batch *b) {
     b->dl_h = pin_acquire(c, b->dl_bytes, &b->dl_cap);
     if (!b->dl_h) { c->err = "hipHostMalloc(download staging) failed"; return GFBE_DEVICE_ERROR; }
   }
-  HIPCHK(c, hipStreamWaitEvent(c->dl, b->ev_up, 0));
-  HIPCHK(c, hipStreamWaitEvent(c->dl, b->ev_done, 0));
-  launch_gather(d, b->last_flag, c->dl);
+  // A small batch (a single window's latency path) gathers and copies on the solver's own stream, behind the solve: no event to wait
+  // for across streams (~15 us of a 1.45 ms call); throughput batches use the download stream, beside whatever the solver runs next.
+  hipStream_t ds = d.B < DENSE_SPLIT_MIN_B ? c->stream : c->dl;
+  if (ds != c->stream) {
+    HIPCHK(c, hipStreamWaitEvent(ds, b->ev_up, 0));
+    HIPCHK(c, hipStreamWaitEvent(ds, b->ev_done, 0));
+  }
+  launch_gather(d, b->last_flag, ds);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(b->dl_h, d.dl_fix, b->dl_bytes, hipMemcpyDeviceToHost, c->dl));
-  HIPCHK(c, hipEventRecord(b->ev_dl, c->dl));
+  HIPCHK(c, hipMemcpyAsync(b->dl_h, d.dl_fix, b->dl_bytes, hipMemcpyDeviceToHost, ds));
+  HIPCHK(c, hipEventRecord(b->ev_dl, ds));
   return GFBE_OK;
 }
 static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_state, double *const *out_feature,

@@ -1587,7 +1587,7 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
     if (v >= NF) return;
     if (t <= NF) s_tile_begin[t] = ds.sf_tile_begin[t];
     __syncthreads();
-    visblock_y<NT, true>(d, ds, c, w, v, s_tile_begin, d.vis_Hs + (size_t)w * VS_BLOCKS * NV * V_LD, V_LD);
+    visblock_y<NT, true>(d, ds, c, w, v, s_tile_begin, d.vis_Hs + (size_t)w * d.vs_blocks * NV * V_LD, V_LD);
     if (lead && t < 64) {      // robustified visual cost of this linearisation point (as below)
       double cs = 0.0;
       for (int q = t; q < ds.n_tiles; q += 64) cs += d.tile_cost[(size_t)w * d.max_tiles + q];
@@ -1701,7 +1701,7 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   }
   __syncthreads();
   if (!KEEP) {
-    double *out = SPLIT ? d.vis_Hs + ((size_t)w * VS_BLOCKS + 2 * i_first + sgrp) * NV * V_LD : d.vis_H + (size_t)w * NV * V_LD;
+    double *out = SPLIT ? d.vis_Hs + ((size_t)w * d.vs_blocks + 2 * i_first + sgrp) * NV * V_LD : d.vis_H + (size_t)w * NV * V_LD;
     for (int q = t; q < NV * V_LD; q += NT) out[q] = V[q];
   }
   // robustified visual cost of this linearisation point (this rank's tiles; lanes stride the tiles, fixed tree order)
@@ -1767,7 +1767,7 @@ __device__ __forceinline__ AsmCommon asm_common(const BatchDev &d, const int w) 
   c.vsplit = d.vis_Hs != nullptr;
   c.lio_on = c.vsplit && ds.lio_n > 0 && d.rank == 0;
   c.lio_o = 6 * ds.lio_frame;
-  c.vis_s = c.vsplit ? d.vis_Hs + (size_t)w * VS_BLOCKS * NV * V_LD : c.Z;
+  c.vis_s = c.vsplit ? d.vis_Hs + (size_t)w * d.vs_blocks * NV * V_LD : c.Z;
   c.ntri = d.nu * (d.nu + 1) / 2;      // the table is ordered by the larger dim: a batch without GNSS windows stops after the 187 core dims
   return c;
 }
@@ -1810,7 +1810,7 @@ __device__ __forceinline__ void asm_H(const BatchDev &d, const int w, const doub
     // factors' (unconditionally: a zero slot with stride 0 where the entry has no visual part), the sums follow below
     double blk[VSPLIT ? U : 1][VS_BLOCKS];
     bool vs[U];
-    const int nvb = d.vis_full ? (int)VS_BLOCKS : 1;
+    const int nvb = d.vs_blocks;
     if (VSPLIT) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
@@ -1886,7 +1886,7 @@ __device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const doub
         if (!vsplit) v += vis_w[a * V_LD + NV];
         else {
           double sv = 0.0;
-          for (int f = 0; f < (d.vis_full ? (int)VS_BLOCKS : 1); f++) sv += vis_s[(size_t)f * NV * V_LD + a * V_LD + NV];
+          for (int f = 0; f < d.vs_blocks; f++) sv += vis_s[(size_t)f * NV * V_LD + a * V_LD + NV];
           if (lio_on && a >= lio_o && a < lio_o + 6) {
             double lv = 0.0;
             for (int q = 0; q < LIOW_WGS; q++) lv += d.lio_part[((size_t)w * LIOW_WGS + q) * LIOW_PART + 21 + a - lio_o];
@@ -2623,7 +2623,7 @@ void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock) {
   if (d.max_tiles == 0) return;
-  if (with_visblock && !marg && d.vis_Hs) hipLaunchKernelGGL(k_schur_visblock_small, dim3(d.B, d.schur_groups + VS_BLOCKS), dim3(VB_GROUP), 0, s, d);
+  if (with_visblock && !marg && d.vis_Hs) hipLaunchKernelGGL(k_schur_visblock_small, dim3(d.B, d.schur_groups + (d.vis_full ? (int)VS_BLOCKS : (int)NF)), dim3(VB_GROUP), 0, s, d);
   else hipLaunchKernelGGL(k_schur, dim3(d.B, marg ? 1 : d.schur_groups), dim3(256), 0, s, d, marg);
 }
 void launch_xchg_gram(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_gram, dim3(d.B), dim3(64), 0, s, d); }
@@ -2636,7 +2636,7 @@ void launch_lio_window(const BatchDev &d, int mode, hipStream_t s) {
   else hipLaunchKernelGGL(k_lio_window<1>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
 }
 void launch_visblock(const BatchDev &d, hipStream_t s) {       // (throughput batches: part of k_visasm, launch_assemble)
-  if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(VS_BLOCKS, d.B), dim3(VB_GROUP), 0, s, d);
+  if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(d.vis_full ? (int)VS_BLOCKS : (int)NF, d.B), dim3(VB_GROUP), 0, s, d);
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
   if (d.vis_Hs) {
