@@ -96,7 +96,8 @@ def build_native(force=False, verbose=False, out=None, extra_flags=None, fp_cont
 
 
 _RCCL_SO = os.path.join(_CSRC, "libgfbe_rccl.so")
-RCCL_EXPORTS = ["gfbe_rccl_unique_id", "gfbe_rccl_create", "gfbe_rccl_destroy", "gfbe_rccl_allreduce", "gfbe_rccl_last_error", "gfbe_rccl_calls"]
+RCCL_EXPORTS = ["gfbe_rccl_unique_id", "gfbe_rccl_create", "gfbe_rccl_destroy", "gfbe_rccl_allreduce", "gfbe_rccl_last_error", "gfbe_rccl_calls",
+                "gfbe_rccl_bytes", "gfbe_rccl_comm_count"]
 
 
 def build_rccl_hook(force=False, verbose=False):

@@ -223,7 +223,8 @@ void gfbe_default_options(gfbe_options *o) {
   o->max_solver_time_in_seconds = 0.0;       // no cap (the reference: SOLVER_TIME = 0.04, estimator.cpp:3369-3376)
   o->host_threads = 0;                       // packing threads: min(hardware threads, 32)
   o->solve_kernel = 0;                       // chain-eliminated factorisation of the reduced system (k_solve_chain)
-  o->test_fail_chol_iter = 0;
+  o->test_fail_chol_iter = 0; o->test_fail_chol_count = 1;
+  o->sharded_mu_retries = 1;                 // (8 = DoglegStrategy's whole mu ladder; every retry is three more launches per linearisation)
 }
 
 const char *gfbe_version(void) { return "gfbe 0.1.0 (gfx950, HIP)"; }
@@ -1213,11 +1214,16 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   { Timed t(c, first ? "k_solve_iter0" : "k_solve", 0); launch_solve(d, ln.s); }
   if (d.sharded) {
     // the mu retry of DoglegStrategy when the landmarks are sharded: a window whose factorisation failed gets E rebuilt for the
-    // larger mu from every rank's own tiles, one more all-reduce (E | eg only), and a second factorisation
+    // larger mu from every rank's own tiles, one more all-reduce (E | eg only), and another factorisation — up to
+    // gfbe_options.sharded_mu_retries times (pass k of the solve kernel hands a window that fails again on to pass k + 1 with
+    // mu x 10; the last pass gives up like DoglegStrategy at max_mu)
     Timed t(c, "mu_retry_sharded", 0);
-    launch_rebuild_E_shard(d, ln.s);
-    run_allreduce(c, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);
-    launch_solve(d, ln.s, 1);
+    const int passes = std::max(1, std::min(c->opt.sharded_mu_retries, 8));
+    for (int k = 1; k <= passes; k++) {
+      launch_rebuild_E_shard(d, ln.s);
+      run_allreduce(c, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);
+      launch_solve(d, ln.s, k);
+    }
   }
   { Timed t(c, first ? "k_lm_step_iter0" : "k_lm_step", 0); launch_lm_step(d, ln.s, fuse & 2); }
   if (d.sharded) {

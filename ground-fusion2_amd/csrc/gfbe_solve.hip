@@ -379,12 +379,13 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 
   double mu = c.mu;
   bool solved = false, e_valid = true;
+  int att = 0;      // factorisation attempts of this linearisation so far (landmark sharding: the pass index counts them)
   while (mu < GF_MAX_MU) {
     if (!e_valid) {
       if (d.sharded) {
         // landmark sharding: E for the larger mu needs every rank's landmarks — hand the window to the retry pass (rebuild on
         // all ranks, one all-reduce, k_solve again); a second failure is a failed linear solve
-        if (!retry_pass) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }
+        if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
         break;
       }
       rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     // two copies of its 64 live registers do not fit the 128-VGPR budget of a 1024-thread workgroup)
     chol_factor_all<(SOLVE_THREADS >> 6)>((lds_double *)smem, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
     bool ok = (flag == 0);
-    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;   // fault injection: first attempt of that iteration
+    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && (d.sharded ? retry_pass : att) < max(d.opt.test_fail_chol_count, 1)) ok = false;   // fault injection: first attempt of that iteration
     STAMP(3);
     if (ok) {
       // z = L^-1 rhs sits in row n of the factor; y^T S y = |z|^2. Backward substitution y = L^-T z by ONE wave without
@@ -478,6 +479,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
     if (ok) { solved = true; break; }
     mu *= GF_MU_INC;
     e_valid = false;
+    att++;
   }
   if (!solved) {
     if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
@@ -999,10 +1001,11 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
 
   double mu = c.mu;
   bool solved = false, e_valid = true;
+  int att = 0;      // factorisation attempts of this linearisation so far (landmark sharding: the pass index counts them)
   while (mu < GF_MAX_MU) {
     if (!e_valid) {
       if (d.sharded) {
-        if (!retry_pass) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }
+        if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
         break;
       }
       rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
@@ -1121,7 +1124,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
     STAMP(15);
     chol_factor_all<S2_WAVES>((lds_double *)tiles, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
     bool ok = (flag == 0);
-    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;
+    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && (d.sharded ? retry_pass : att) < max(d.opt.test_fail_chol_count, 1)) ok = false;
     STAMP(3);
     if (ok) {
       double zz = 0.0;
@@ -1238,6 +1241,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
     if (ok) { solved = true; break; }
     mu *= GF_MU_INC;
     e_valid = false;
+    att++;
   }
   if (!solved) {
     if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
@@ -1508,10 +1512,11 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
   const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
   double mu = c.mu;
   bool solved = false, e_valid = true;
+  int att = 0;      // factorisation attempts of this linearisation so far (landmark sharding: the pass index counts them)
   while (mu < GF_MAX_MU) {
     if (!e_valid) {
       if (d.sharded) {
-        if (!retry_pass) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }
+        if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
         break;
       }
       rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
@@ -1560,7 +1565,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
                (lds_int *)&flag, stamp);
     BSTAMP(3);
     bool ok = (flag == 0);
-    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && e_valid && !retry_pass) ok = false;   // fault injection: first attempt of that iteration
+    if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && (d.sharded ? retry_pass : att) < max(d.opt.test_fail_chol_count, 1)) ok = false;   // fault injection: first attempt of that iteration
     if (ok) {
       // z = L^-1 rhs is row n of the factor (its last partial panel was saved before the tile became its own inverse); y = L^-T z
       double zz = 0.0;
@@ -1600,6 +1605,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
     if (ok) { solved = true; break; }
     mu *= GF_MU_INC;
     e_valid = false;
+    att++;
   }
   if (!solved) {
     if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }

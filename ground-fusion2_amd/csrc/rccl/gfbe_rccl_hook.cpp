@@ -13,7 +13,7 @@ struct gfbe_rccl {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   int32_t err = 0;
-  int64_t calls = 0;
+  int64_t calls = 0, bytes = 0;
 };
 
 extern "C" {
@@ -57,10 +57,17 @@ int32_t gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, voi
   const ncclResult_t r = ncclAllReduce(device_ptr, device_ptr, (size_t)n_doubles, ncclDouble, ncclSum, h->comm, (hipStream_t)hip_stream);
   if (r != ncclSuccess && h->err == 0) h->err = (int32_t)r;
   h->calls++;
+  h->bytes += 8 * n_doubles;
   return r == ncclSuccess ? 0 : (int32_t)r;
 }
 
 int32_t gfbe_rccl_last_error(const gfbe_rccl *h) { return h ? h->err : -1; }
 int64_t gfbe_rccl_calls(const gfbe_rccl *h) { return h ? h->calls : 0; }
+int64_t gfbe_rccl_bytes(const gfbe_rccl *h) { return h ? h->bytes : 0; }
+int32_t gfbe_rccl_comm_count(const gfbe_rccl *h) {
+  int n = -1;
+  if (!h || !h->comm || ncclCommCount(h->comm, &n) != ncclSuccess) return -1;
+  return n;
+}
 
 }  // extern "C"

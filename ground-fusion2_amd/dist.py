@@ -113,6 +113,8 @@ class RcclHook:
         self.lib.gfbe_rccl_create.restype = C.c_int32
         self.lib.gfbe_rccl_last_error.restype = C.c_int32
         self.lib.gfbe_rccl_calls.restype = C.c_int64
+        self.lib.gfbe_rccl_bytes.restype = C.c_int64
+        self.lib.gfbe_rccl_comm_count.restype = C.c_int32
         idbuf = C.create_string_buffer(128)
         if rank == 0:
             rc = self.lib.gfbe_rccl_unique_id(idbuf)
@@ -132,6 +134,12 @@ class RcclHook:
 
     def calls(self):
         return int(self.lib.gfbe_rccl_calls(self.h))
+
+    def bytes(self):
+        return int(self.lib.gfbe_rccl_bytes(self.h))
+
+    def comm_count(self):
+        return int(self.lib.gfbe_rccl_comm_count(self.h))
 
     def last_error(self):
         return int(self.lib.gfbe_rccl_last_error(self.h))

@@ -270,6 +270,13 @@ typedef struct gfbe_options {
    * `test_fail_chol_iter` is declared failed, so that DoglegStrategy's mu retry — which well-posed windows never take —
    * can be exercised (tests/test_gpu_branches.py). */
   int32_t test_fail_chol_iter;
+  /* TEST HOOK: how many consecutive factorisation attempts of that iteration fail (default 1; 0 is taken as 1). */
+  int32_t test_fail_chol_count;
+  /* Landmark sharding (gfbe_set_allreduce) only: how many times a window whose reduced system failed to factorise is retried with
+   * mu x 10 (DoglegStrategy::ComputeGaussNewtonStep retries up to max_mu = 1, i.e. 8 times from min_mu = 1e-8; the unsharded kernels
+   * do so inside the solve kernel). Every retry is one more [E rebuild | all-reduce | factorisation] triple in the FIXED launch
+   * sequence of every linearisation, taken or not: default 1 (well-posed windows never take even that one); 8 reproduces Ceres. */
+  int32_t sharded_mu_retries;
 } gfbe_options;
 
 typedef struct gfbe_summary {

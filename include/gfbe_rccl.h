@@ -31,6 +31,9 @@ void gfbe_rccl_destroy(gfbe_rccl *h);
 int32_t gfbe_rccl_allreduce(void *user, void *device_ptr, int64_t n_doubles, void *hip_stream);
 int32_t gfbe_rccl_last_error(const gfbe_rccl *h);
 int64_t gfbe_rccl_calls(const gfbe_rccl *h);
+/* Bytes handed to ncclAllReduce so far; ncclCommCount of the communicator (-1 without one): what a bench line reports beside its rate. */
+int64_t gfbe_rccl_bytes(const gfbe_rccl *h);
+int32_t gfbe_rccl_comm_count(const gfbe_rccl *h);
 #ifdef __cplusplus
 }
 #endif

@@ -508,7 +508,7 @@ static void solve(const Problem &P, Solution &sol) {
       // fault injection (tests only): the first factorisation of iteration gfbe_options.test_fail_chol_iter is declared failed,
       // so that the mu-retry path (DoglegStrategy: mu *= 10 until the linear solver succeeds) is exercised — Gauss-Newton
       // systems with mu >= 1e-8 practically never fail on their own
-      bool inject = o.test_fail_chol_iter > 0 && o.test_fail_chol_iter == it;
+      int inject = (o.test_fail_chol_iter > 0 && o.test_fail_chol_iter == it) ? std::max(o.test_fail_chol_count, 1) : 0;   // consecutive failing attempts
       while (mu < max_mu) {
         for (int a = 0; a < ND; a++) {
           for (int b = 0; b < ND; b++) St[(size_t)a * ND + b] = sp[a] * sp[b] * lin.H[(size_t)a * ND + b];
@@ -530,7 +530,7 @@ static void solve(const Problem &P, Solution &sol) {
           }
         }
         bool chol_ok = chol_solve(St, rhs, P.act, yp.data());
-        if (inject) { chol_ok = false; inject = false; }
+        if (inject > 0) { chol_ok = false; inject--; }
         if (chol_ok) {
           bool fin = true;
           for (int l = 0; l < L; l++) {
@@ -932,7 +932,7 @@ void gfo_default_options(gfbe_options *o) {
   o->use_graph = 0;   // (device options; meaningless on the CPU)
   o->split_batch = 1;
   o->max_solver_time_in_seconds = 0.0; o->host_threads = 0;
-  o->solve_kernel = 0; o->test_fail_chol_iter = 0;
+  o->solve_kernel = 0; o->test_fail_chol_iter = 0; o->test_fail_chol_count = 1; o->sharded_mu_retries = 1;
 }
 
 int32_t gfo_sqrt_info(const double *cov, double *out, int32_t n) { return sqrt_info_from_cov(cov, out, n) ? 0 : 1; }

@@ -31,6 +31,9 @@ def main():
         snap = scn.window(1, state=synth.shift_state_for_next_window(scn, first["state"], 1), prior=first["prior"])
     opt = abi.default_options()
     opt.test_fail_chol_iter = fail_iter
+    if len(sys.argv) > 7 and sys.argv[7] == "retry3":      # three consecutive failures of that iteration's factorisation: mu x 1000, the whole ladder allowed
+        opt.test_fail_chol_count = 3
+        opt.sharded_mu_retries = 8
     failing = gf.Backend(device=0, options=opt)
     ref = failing.solve(snap, abi.MARGIN_OLD)
     be = gf.Backend(device=0, options=opt)

@@ -39,6 +39,7 @@ def test_one_rank_rccl_all_reduce_on_the_solver_stream(oracle):
     res = be.solve_batch([snap, snap], abi.MARGIN_NONE)
     assert res[0]["summary"] == res[1]["summary"]
     assert hook.calls() > n_calls and hook.last_error() == 0
+    assert hook.comm_count() == 1 and hook.bytes() >= 8 * (hook.calls() - n_calls)        # (ncclCommCount of the communicator; what bench.py --shard-landmarks reports)
     be.close()                       # destroys the context, then the communicator
     assert be._rccl_hook is None
     plain.close()

@@ -22,12 +22,14 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,L,fail_iter,kind", [(2, 2000, 0, "plain"), (3, 500, 0, "plain"), (2, 500, 2, "plain"), (2, 300, 0, "gnss")])
+@pytest.mark.parametrize("world,L,fail_iter,kind", [(2, 2000, 0, "plain"), (3, 500, 0, "plain"), (2, 500, 2, "plain"), (2, 300, 0, "gnss"), (2, 500, 2, "retry3")])
 def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter, kind):
     """fail_iter > 0: the first factorisation of that iteration is declared failed on every rank (and in the unsharded
     reference): the sharded mu retry — E rebuilt from every rank's own tiles at the larger mu, one more all-reduce, second
     factorisation — must give what the in-kernel retry of the unsharded solve gives. kind "gnss": a window with GNSS blocks and a GNSS
-    prior (k_solve_big, the packed 246-dim system in the all-reduce, the GNSS factors added by rank 0 only)."""
+    prior (k_solve_big, the packed 246-dim system in the all-reduce, the GNSS factors added by rank 0 only). kind "retry3": the
+    factorisation of iteration fail_iter fails THREE times in a row (gfbe_options.test_fail_chol_count) with gfbe_options.sharded_mu_retries
+    = 8: three [rebuild | all-reduce | factorise] passes, mu x 1000, as the unsharded kernel's in-kernel ladder does."""
     port = free_port()
     outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
