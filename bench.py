@@ -321,17 +321,18 @@ PEAK_HBM_TBS = 8.0     # HBM3E, TB/s
 
 
 def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
-    """`roofline` of the JSON line. The dominant kernel family by arithmetic is k_vis<0> (visual evaluate + linearise with the
-    J^T J of the step's 64 factors on the FP64 matrix cores; J is never materialised). What is credited is what the kernel RUNS:
-      reduced panel (camera extrinsic and td constant in every window — the shipped configuration and this workload):
-        X = [J_i J_j r] is 13 columns padded to ONE 16 x 16 x 4 tile, 32 matrix-core instructions per 64 factors
-        -> 1024 flop ISSUED per factor, 2 * 2 * 13 * 13 = 676 of them useful;
-      full 20-column panel (extrinsic or td free somewhere in the batch): SURVEY.md section 8d's 1.6 kflop per factor.
-    `achieved` / `frac` are the ISSUED matrix-core flops over the kernel's own launch time (what SQ_VALU_MFMA_BUSY_CYCLES sees);
-    `useful_frac` counts the 676. All times are the library's own hipEvents around the launches of the FIRST iteration (every
-    window active), on the launch stream; in profiling mode the two halves of a batch run one after the other, so a launch covers
-    windows_per_launch windows. `kernels` is the same for the other kernels of an iteration, `whole_solve` SURVEY section 8d's
-    ~32 Mflop per linearisation over the measured solves/s."""
+    """`roofline` of the JSON line, for k_vis<0> (visual evaluate + linearise + the fused panel product on the FP64 matrix cores; J is
+    never materialised) — the kernel with the largest share of an iteration.
+    Round 4: for a batch with constant extrinsic and td (the shipped configuration and this workload) the kernel sums the 7 x 7
+    [Y r]^T [Y r] instead of the 13 x 13 [J_i J_j r]^T [J_i J_j r]: 16 matrix-core instructions per 64 factors instead
+    of 32 (512 flop issued per factor, 196 of them the 2 x 7 x 7 x 2 wanted) and 293 instead of 494 vector instructions per step. What
+    bounds it now is nearer HBM: `bound` = "hbm", `achieved` = SURVEY.md section 8d's ALGORITHMIC bytes (108 B per factor, the fused form)
+    over the kernel's own launch time; `moved_*` = what the kernel moves by construction (the landmark rows it leaves for k_schur /
+    k_lm_step included), `traffic` = the PMC counters' FETCH_SIZE + WRITE_SIZE of the newest committed passes, `mfma_view` the matrix-core
+    side (issued / useful flops, SQ_VALU_MFMA_BUSY_CYCLES). All times are the library's own hipEvents around the launches of the FIRST
+    iteration (every window active), on the launch stream; in profiling mode the parts of a batch run one after the other, so a
+    launch covers windows_per_launch windows. `kernels` is the same for the other kernels of an iteration, `whole_solve` SURVEY
+    section 8d's ~32 Mflop per linearisation over the measured solves/s."""
     tot_ms = sum(p["total_ms"] for p in prof.values())
     fam = {}                                                                # kernel families (first-iteration launches are profiled under their own name)
     for k, p in prof.items():
@@ -342,10 +343,17 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
     units_per_launch = K_batch * nprof / max(lin0["launches"], 1)          # visual factors one launch evaluates
     windows_per_launch = args.batch * nprof / max(lin0["launches"], 1)
     full_panel = any((not s.get("ex_cam_const", 1)) or (not s.get("td_const", 1)) for s in batch_snaps[: args.unique])
-    issued, useful = (1600.0, 1600.0) if full_panel else (1024.0, 676.0)
+    # matrix-core flops per factor: the 7 x 7 panel of round 4 (both rows of a factor in ONE 16-wide tile: 16 instructions of 2048 flop per
+    # 64 factors) or the 20-column panel of a batch with a free extrinsic / td
+    issued, useful = (1600.0, 1600.0) if full_panel else (512.0, 196.0)
     achieved_tf = issued * units_per_launch / (lin_ms * 1e-3) / 1e12
     pmc = pmc_summary(int(windows_per_launch)) if (args.landmarks == 2000 and args.unique == 8) else {}
     kv = pmc.get("k_vis", {})
+    # what the kernel moves, by construction: per factor the observation (5 doubles) in and the landmark's H_pl block of the observing
+    # pose (6 doubles) out; per landmark slot 8 doubles in (point, velocity, td_i, inverse depth, Jacobi scale) and 9 out (H_ll, g_l, the
+    # start pose's block, sqrt(w_l)); per (tile, step) the 28-double partial
+    slots = float(sum(((len(sn["para_feature"]) + 63) // 64 + 4) * 64 for sn in batch_snaps[: args.unique])) / args.unique * windows_per_launch
+    moved = 88.0 * units_per_launch + 136.0 * slots + 224.0 * units_per_launch / 64.0 * 1.35
     # ---- the other kernels of a linearisation: algorithmic work of ONE launch over windows_per_launch windows
     L = float(np.mean([len(s["para_feature"]) for s in batch_snaps[: args.unique]]))
     n_obs = np.concatenate([np.bincount(np.asarray(s["vis_feature_index"]), minlength=len(s["para_feature"])) for s in batch_snaps[: args.unique]])
@@ -378,15 +386,27 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
                          "achieved": ach, "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": ach / peak}
         if name in pmc and "mfma_busy" in pmc[name]:
             kernels[name]["mfma_busy_pmc"] = pmc[name]["mfma_busy"]
+        if name == "k_schur":      # issued: the 16 x 16 x 64 tile pairs the compact panels multiply (counted on these windows' track histogram)
+            issued_pairs = schur_tile_pairs(batch_snaps[: args.unique]) * windows_per_launch
+            kernels[name]["issued_flops_per_launch"] = issued_pairs * 16 * 2048.0
+            kernels[name]["frac_issued"] = issued_pairs * 16 * 2048.0 / (us * 1e-6) / 1e12 / PEAK_F64_TF
     lin_per_solve = float(np.mean(iters)) + 1.0
     whole_tf = 32e6 * (K1 / 9457.0) * lin_per_solve * value / 1e12
-    return {"bound": "mfma", "kernel": "k_vis<0, %s> (visual evaluate + linearise + fused X^T X; first iteration: all windows active)" % ("full 20-column panel" if full_panel else "reduced 13-column panel"),
-            "achieved": achieved_tf, "peak": PEAK_F64_TF, "unit": "TFLOP/s", "frac": achieved_tf / PEAK_F64_TF,
-            "flops_per_factor": {"issued": issued, "useful": useful, "survey_8d_full_panel": 1600.0},
-            "useful_frac": achieved_tf / PEAK_F64_TF * useful / issued,
-            "mfma_busy_pmc": kv.get("mfma_busy"), "traffic": kv.get("traffic"), "traffic_source": pmc.get("source"),
+    alg_bytes = 108.0 * units_per_launch                                   # the fused form's 12 f64 + 3 i32 per factor
+    hbm_tbs = alg_bytes / (lin_ms * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": "k_vis<0, %s> (visual evaluate + linearise + fused [Y r]^T [Y r]; first iteration: all windows active)" % ("full 20-column panel" if full_panel else "7 x 7 panel, both rows of a factor in one 16-wide tile"),
+            "achieved": hbm_tbs, "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": hbm_tbs / PEAK_HBM_TBS,
+            "why_hbm": "round 4 halved the kernel's matrix-core work and cut its vector instructions by 40 %: its own traffic (moved_bytes_by_construction, "
+                       "~126 B per factor, against SURVEY 8d's algorithmic 108 B) over its launch time is now nearer the HBM roof than its matrix-core "
+                       "flops are to theirs (mfma_view)",
+            "moved_bytes_by_construction": moved, "moved_TBps": moved / (lin_ms * 1e-3) / 1e12, "moved_frac_of_hbm_peak": moved / (lin_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+            "mfma_view": {"achieved_issued": achieved_tf, "peak": PEAK_F64_TF, "unit": "TFLOP/s", "frac_issued": achieved_tf / PEAK_F64_TF,
+                          "frac_useful": achieved_tf / PEAK_F64_TF * useful / issued,
+                          "flops_per_factor": {"issued": issued, "useful": useful, "round3_13_column_panel_issued": 1024.0, "survey_8d_full_panel": 1600.0},
+                          "mfma_busy_pmc": kv.get("mfma_busy")},
+            "traffic": kv.get("traffic"), "traffic_source": pmc.get("source"),
             "avg_launch_ms": lin_ms, "factors_per_launch": units_per_launch, "windows_per_launch": windows_per_launch,
-            "algorithmic_bytes_per_launch": 108.0 * units_per_launch,
+            "algorithmic_bytes_per_launch": alg_bytes,
             "hbm_view_GBps": (kv["traffic"] / (lin_ms * 1e-3) / 1e9) if kv.get("traffic") else None,
             "kernels": kernels,
             "whole_solve": {"flops_per_linearisation": 32e6 * (K1 / 9457.0), "linearisations_per_solve": lin_per_solve,
@@ -395,13 +415,33 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
             "time_share": {k: round(v / tot_ms, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])}}
 
 
+def schur_tile_pairs(snaps):
+    """Mean number of 16 x 16 tile pairs k_schur multiplies per window and linearisation: landmarks grouped by start frame (tile aligned,
+    longest tracks first), start-frame groups {0,1} {2} {3,4,5} {6..10}, compact columns [gradient | poses from the group's first frame]."""
+    first = {0: 0, 1: 0, 2: 2, 3: 3, 4: 3, 5: 3, 6: 6, 7: 6, 8: 6, 9: 6, 10: 6}
+    tot = 0
+    for sn in snaps:
+        fi = np.asarray(sn["vis_feature_index"])
+        ii = np.asarray(sn["vis_imu_i"])
+        L = len(sn["para_feature"])
+        m = np.bincount(fi, minlength=L)
+        start = np.zeros(L, int)
+        start[fi] = ii
+        for s0 in range(11):
+            ms = np.sort(m[(start == s0) & (m > 0)])[::-1]
+            for t0 in range(0, len(ms), 64):
+                jl = (6 * (s0 - first[s0] + int(ms[t0]) + 1)) >> 4
+                tot += (jl + 1) * (jl + 2) // 2
+    return tot / float(len(snaps))
+
+
 def pmc_summary(windows_per_launch):
     """Counter values of the newest committed rocprofv3 PMC passes of the DEFAULT workload (profiles/rN_pmc_*.txt; PMC counters
     cannot be read from inside this process): HBM bytes per launch of k_vis<0> (FETCH_SIZE + WRITE_SIZE, KB per dispatch, separate
     passes) and the matrix-core busy fraction of the MFMA kernels — SQ_VALU_MFMA_BUSY_CYCLES over 1024 SIMDs x launch cycles at
     2.4 GHz."""
     pat = {"k_vis": "k_visILi0E", "k_schur": "k_schurE", "k_solve": "k_solve"}
-    for tag in ("r3", "r2"):
+    for tag in ("r4", "r3", "r2"):
         try:
             out = {"source": "rocprofv3 --pmc (separate passes) of the same workload: profiles/%s_pmc_fetch.txt, %s_pmc_write.txt, %s_pmc_sq1.txt" % (tag, tag, tag)}
 
