@@ -71,6 +71,35 @@ __device__ __forceinline__ void block_reduce_multi(const double (&v)[NQ], unsign
 
 __device__ __forceinline__ double clamp_diag(double x) { return fmin(fmax(x, GF_MIN_DIAG), GF_MAX_DIAG); }
 
+// ---- Landmark rows of the normal equations as k_vis<0, false> leaves them (round 4; a batch with constant extrinsic and td):
+//   per factor   d = G^T w (3 doubles: lm_hP[k][0..2])        per landmark   D = sum of its d, x = P_w - P_0 (lm_hC[0..2], [3..5])
+// instead of the 6 + 6 tangent entries. With the frame constants Rt = [ R_f (row-major, 9) | t_f = P_f - P_0 (3) ] (FrameConst, slot (f, f)
+// of the pair table) the H_pl blocks are
+//   start pose i:       [ D ; R_i^T ((x - t_i) x D) ]         observing pose j:   [ -d ; R_j^T (d x (x - t_j)) ]
+// and a landmark row times a step of the poses needs no block at all: with u_f = R_f dtheta_f (the frame's rotation step in the world)
+//   h_l . delta = D . v_i(x) - sum_k d_k . v_jk(x),    v_f(x) = dp_f + u_f x (x - t_f)   (the displacement of the point with frame f).
+#define LM_RT_OFF 12          // doubles before R inside a FrameConst record (W 9, wt 3)
+__device__ __forceinline__ void lm_row_block(const double *Rt, const double *dv, const double *x, const bool start, double *out) {
+  const double e0 = x[0] - Rt[9], e1 = x[1] - Rt[10], e2 = x[2] - Rt[11];
+  double c0, c1, c2;
+  if (start) { c0 = __builtin_fma(e1, dv[2], -(e2 * dv[1])); c1 = __builtin_fma(e2, dv[0], -(e0 * dv[2])); c2 = __builtin_fma(e0, dv[1], -(e1 * dv[0])); }
+  else { c0 = __builtin_fma(dv[1], e2, -(dv[2] * e1)); c1 = __builtin_fma(dv[2], e0, -(dv[0] * e2)); c2 = __builtin_fma(dv[0], e1, -(dv[1] * e0)); }
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    out[q] = start ? dv[q] : -dv[q];
+    out[3 + q] = __builtin_fma(Rt[q], c0, __builtin_fma(Rt[3 + q], c1, Rt[6 + q] * c2));
+  }
+}
+// v_f(x) . dvec for the two steps a back-substitution needs (Gauss-Newton y and Cauchy v), fs = [ dp_y (3) | u_y (3) | dp_v (3) | u_v (3) | t (3) ]
+__device__ __forceinline__ void lm_row_dot2(const double *fs, const double *dv, const double *x, double &oy, double &ov) {
+  const double e0 = x[0] - fs[12], e1 = x[1] - fs[13], e2 = x[2] - fs[14];
+  const double y0 = fs[0] + __builtin_fma(fs[4], e2, -(fs[5] * e1)), y1 = fs[1] + __builtin_fma(fs[5], e0, -(fs[3] * e2)), y2 = fs[2] + __builtin_fma(fs[3], e1, -(fs[4] * e0));
+  const double v0 = fs[6] + __builtin_fma(fs[10], e2, -(fs[11] * e1)), v1 = fs[7] + __builtin_fma(fs[11], e0, -(fs[9] * e2)), v2 = fs[8] + __builtin_fma(fs[9], e1, -(fs[10] * e0));
+  oy = __builtin_fma(dv[0], y0, __builtin_fma(dv[1], y1, dv[2] * y2));
+  ov = __builtin_fma(dv[0], v0, __builtin_fma(dv[1], v1, dv[2] * v2));
+}
+enum { LM_FS = 15 };      // doubles per frame of the staged steps above
+
 __device__ __forceinline__ void tri_decode(int e, int &a, int &b) {
   a = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
   while ((a + 1) * (a + 2) / 2 <= e) a++;

@@ -31,6 +31,10 @@ namespace gfd {
 #ifndef GFBE_KVIS_EARLY
 #define GFBE_KVIS_EARLY 1   // k_vis: the prefetched observation of the next step is waited for BEFORE this step's stores are issued
 #endif
+#ifndef GFBE_KVIS_WAVES
+#define GFBE_KVIS_WAVES 3   // k_vis<0, false>: waves per SIMD the register allocation aims at (measured: 4 — 128 VGPRs, a 12-byte spill — 152 us per
+                            // 512 windows against 149 at 3: the kernel waits for memory, not for a free wave slot; -ffp-contract=fast: no difference either)
+#endif
 #ifndef GFBE_KVIS_STAMP
 #define GFBE_KVIS_STAMP 0   // diagnostics build (tools/diag_variants.py): phase time stamps of one wave of k_vis<0> into d.timing
 #endif
@@ -402,13 +406,10 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
           for (int q = 0; q < 3; q++) Dsum[q] += dv[q];
         }
-        // H_pl block of the observing pose j = s + 1 + k: [ -d ; Rj^T (d x (e + P_i - P_j)) ]
-        const vec3 tj = cross3(dv, add(ye, pc.dP));
+        // what k_schur / k_lm_step need of this factor is d alone (24 instead of 48 bytes): the H_pl block of the observing pose
+        // j = s + 1 + k is [ -d ; Rj^T (d x (x - t_j)) ] with the landmark's x and the frame's constants (lm_row_* in gfbe_devutil.h)
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          hp[q] = -dv[q];
-          hp[3 + q] = __builtin_fma(pc.Rj(0, q), tj[0], __builtin_fma(pc.Rj(1, q), tj[1], pc.Rj(2, q) * tj[2]));
-        }
+        for (int q = 0; q < 3; q++) hp[q] = dv[q];
 #pragma unroll
         for (int q = 0; q < 3; q++) { xr[q] = g0[q]; xr[3 + q] = y0[q]; xr[8 + q] = g1[q]; xr[11 + q] = y1[q]; }
         xr[6] = r[0]; xr[14] = r[1];
@@ -422,7 +423,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #endif
       if (k < m) {
 #pragma unroll
-        for (int q = 0; q < 6; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = hp[q];
+        for (int q = 0; q < 3; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = hp[q];
       }
       // [Y r]^T [Y r] of the step's 64 factors: lane's LDS row holds BOTH residual rows of its factor, eight columns each, so the
       // 16 x 16 product has the two 8 x 8 blocks wanted on its diagonal (the off-diagonal blocks mix the rows: dropped)
@@ -632,13 +633,10 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #undef VC_LD
     }
   }
-  if (YM) {      // H_pl block of the start pose: [ D ; Ri^T (e x D) ], D = the sum of the factors' d
-    const vec3 ti = cross3(ye, mk3(Dsum[0], Dsum[1], Dsum[2]));
+  if (YM) {      // the landmark's own part: D = the sum of its factors' d, and x, its position from the window's origin — the H_pl block
+                 // of the start pose is [ D ; Ri^T ((x - t_i) x D) ] (lm_row_* in gfbe_devutil.h)
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      hC[q] = Dsum[q];
-      hC[3 + q] = __builtin_fma(fcs.R(0, q), ti[0], __builtin_fma(fcs.R(1, q), ti[1], fcs.R(2, q) * ti[2]));
-    }
+    for (int q = 0; q < 3; q++) { hC[q] = Dsum[q]; hC[3 + q] = yx[q]; }
   }
   if (MODE == 0 && valid) {
     // the landmark's weight in the Schur term, w_l = s_l^2 / (s_l^2 Hll + mu clamp(s_l^2 Hll)) (Jacobi-scaled, mu-regularised), once
@@ -670,7 +668,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 }
 
 template <int MODE, bool FULL>
-__global__ __launch_bounds__(LM_TILE, 2) void k_vis(BatchDev d, int write_records) {
+__global__ __launch_bounds__(LM_TILE, (MODE == 0 && !FULL) ? GFBE_KVIS_WAVES : 2) void k_vis(BatchDev d, int write_records) {
   // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
   // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
   vis_body<MODE, FULL>(d, write_records, blockIdx.x, blockIdx.y);
@@ -1153,7 +1151,10 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   // (the table staged in LDS once and the trust-region scalar read once: a vector-memory load inside the tile loop would make every
   //  staging wait for ALL loads in flight — the counter is in order — and undo the two-deep prefetch)
   __shared__ int s_sf[NF + 1];
+  __shared__ double s_rt[NF][12];       // yrows: R_f | t_f = P_f - P_0 of the linearisation point (FrameConst of the pair table)
+  const bool yrows = !marg && !d.vis_full;      // the rows are in the compressed form of k_vis<0, false> (gfbe_devutil.h)
   if (t <= NF) s_sf[t] = ds.sf_tile_begin[t];
+  if (yrows && t < NF * 12) s_rt[t / 12][t % 12] = d.pc[(((size_t)w * 3 + c.cur) * NPAIR + (t / 12) * (NF + 1)) * PC_DOUBLES + LM_RT_OFF + t % 12];
   const int lm_off_c = ds.lm_off;
   __syncthreads();
   auto sframe_of = [&](int tile) __attribute__((always_inline)) { int sf = s_first; for (int q = s_first + 1; q < s_end; q++) sf += (tile >= s_sf[q]) ? 1 : 0; return sf; };
@@ -1175,9 +1176,12 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
     _Pragma("unroll") for (int idx_ = 0; idx_ < SCHUR_PV; idx_++) {                                                      \
       const int u_ = idx_ / 6, q_ = idx_ - 6 * u_;                                                                       \
       const int kk_ = min(part - 1 + 3 * u_, klast_), k9_ = min(9, klast_);                                              \
+      /* (yrows: a factor's entry is d (3 doubles); the other three slots of its block take the landmark's x = lm_hC rows 3..5) */ \
+      const int q9_ = idx_ - HC - 1;                                                                                     \
       const double *src_ = part == 0 ? (idx_ < HC ? d.lm_hC + (size_t)((idx_ < 6 || hc_full) ? idx_ : 5) * TL + slot_   \
-                                                  : (idx_ == HC ? gl_ : d.lm_hP + ((size_t)k9_ * 6 + (idx_ - HC - 1)) * TL + slot_)) \
-                                     : d.lm_hP + ((size_t)kk_ * 6 + q_) * TL + slot_;                                    \
+                                                  : (idx_ == HC ? gl_ : ((yrows && q9_ >= 3) ? d.lm_hC + (size_t)q9_ * TL + slot_ \
+                                                                                             : d.lm_hP + ((size_t)k9_ * 6 + q9_) * TL + slot_))) \
+                                     : ((yrows && q_ >= 3) ? d.lm_hC + (size_t)q_ * TL + slot_ : d.lm_hP + ((size_t)kk_ * 6 + q_) * TL + slot_); \
       PV[idx_] = *src_;                                                                                                  \
     }                                                                                                                    \
   }
@@ -1217,7 +1221,10 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
       double *row = hs + l * HS_LD + coff;                                                                               \
       if (part == 0) {                                                                                                   \
         for (int q = compact ? 6 * s_first : 16 * I0; q < 6 * s; q++) row[q] = 0.0;                                      \
-        _Pragma("unroll") for (int q = 0; q < 6; q++) { row[6 * s + q] = sw * PV[q]; row[T_EX + q] = hc_full ? sw * PV[6 + q] : 0.0; } \
+        double blk0[6];                                                                                                  \
+        if (yrows) lm_row_block(s_rt[s], PV, PV + 3, true, blk0);                     /* [ D ; Ri^T ((x - t_i) x D) ] */ \
+        else { _Pragma("unroll") for (int q = 0; q < 6; q++) blk0[q] = PV[q]; }                                          \
+        _Pragma("unroll") for (int q = 0; q < 6; q++) { row[6 * s + q] = sw * blk0[q]; row[T_EX + q] = hc_full ? sw * PV[6 + q] : 0.0; } \
         row[T_TD] = hc_full ? sw * PV[12] : 0.0;                                                                         \
         if (compact) {                                                                                                   \
           row[-coff] = sw * PV[HC];                                     /* column 0: the gradient */                     \
@@ -1228,7 +1235,10 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
         }                                                                                                                \
         if (9 < kmax) {                                                  /* the tenth observing pose (start frame 0) */  \
           const bool written = valid && 9 < m;                                                                           \
-          _Pragma("unroll") for (int q = 0; q < 6; q++) row[6 * (s + 10) + q] = written ? sw * PV[HC + 1 + q] : 0.0;     \
+          double blk9[6];                                                                                                \
+          if (yrows) lm_row_block(s_rt[min(s + 10, NF - 1)], PV + HC + 1, PV + 3, false, blk9);                          \
+          else { _Pragma("unroll") for (int q = 0; q < 6; q++) blk9[q] = PV[HC + 1 + q]; }                               \
+          _Pragma("unroll") for (int q = 0; q < 6; q++) row[6 * (s + 10) + q] = written ? sw * blk9[q] : 0.0;            \
         }                                                                                                                \
       } else {                                                                                                           \
         _Pragma("unroll") for (int u = 0; u < 3; u++) {                                                                  \
@@ -1236,7 +1246,10 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
           if (k < kmax) {                                                                                                \
             /* (rows from the landmark's track length on were never written — lm_hP is not cleared at upload: zeros, not products) */ \
             const bool written = valid && k < m;                                                                         \
-            _Pragma("unroll") for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = written ? sw * PV[u * 6 + q] : 0.0;   \
+            double blkk[6];                                                                                              \
+            if (yrows) lm_row_block(s_rt[s + 1 + k], PV + u * 6, PV + u * 6 + 3, false, blkk);    /* [ -d ; Rj^T (d x (x - t_j)) ] */ \
+            else { _Pragma("unroll") for (int q = 0; q < 6; q++) blkk[q] = PV[u * 6 + q]; }                              \
+            _Pragma("unroll") for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = written ? sw * blkk[q] : 0.0;       \
           }                                                                                                              \
         }                                                                                                                \
       }                                                                                                                  \
@@ -1951,8 +1964,22 @@ __global__ __launch_bounds__(VB_GROUP, 4) void k_visasm(BatchDev d) {
 // k_lm_step: back-substitution of the eliminated landmarks and their share of the dogleg scalars.
 // =============================================================================================
 // One landmark tile (64 lanes): sy / sv = the scaled Gauss-Newton step and Cauchy direction of the visual dims, staged by the caller.
+// Per frame f: [ dp_y | u_y = R_f dtheta_y | dp_v | u_v | t_f ] from the scaled steps sy / sv (LDS, already staged; the caller's barrier
+// lies between) and the frame constants of the linearisation point — threads 0 .. NF - 1 of the workgroup.
+__device__ __forceinline__ void stage_frame_steps(const BatchDev &d, const WinCtl &c, const int w, const int t, const double *sy, const double *sv, double *fs) {
+  if (t >= NF) return;
+  const double *Rt = d.pc + (((size_t)w * 3 + c.cur) * NPAIR + t * (NF + 1)) * PC_DOUBLES + LM_RT_OFF;
+  double *o = fs + t * LM_FS;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    o[q] = sy[6 * t + q]; o[6 + q] = sv[6 * t + q]; o[12 + q] = Rt[9 + q];
+    o[3 + q] = __builtin_fma(Rt[3 * q], sy[6 * t + 3], __builtin_fma(Rt[3 * q + 1], sy[6 * t + 4], Rt[3 * q + 2] * sy[6 * t + 5]));
+    o[9 + q] = __builtin_fma(Rt[3 * q], sv[6 * t + 3], __builtin_fma(Rt[3 * q + 1], sv[6 * t + 4], Rt[3 * q + 2] * sv[6 * t + 5]));
+  }
+}
+// fs: the frames' steps in the form of lm_row_dot2 (stage_frame_steps below) when the rows are compressed, else nullptr
 __device__ __forceinline__ void lm_step_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t,
-                                             const double *sy, const double *sv) {
+                                             const double *sy, const double *sv, const double *fs) {
   const int s0 = d.tile_start[ds.tile_off + tile];
   const int slot = ds.lm_off + tile * LM_TILE + t;
   const int info = d.lm_info[slot];
@@ -1962,7 +1989,19 @@ __device__ __forceinline__ void lm_step_tile(const BatchDev &d, const WinDesc &d
   double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (free_lm) {
     double hy = 0.0, hv = 0.0;
-    if (d.vis_full) {
+    if (fs) {      // compressed rows (k_vis<0, false>): h_l . delta = D . v_i(x) - sum_k d_k . v_jk(x)  (gfbe_devutil.h)
+      double Dx[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) Dx[q] = d.lm_hC[(size_t)q * TL + slot];
+      lm_row_dot2(fs + s0 * LM_FS, Dx, Dx + 3, hy, hv);
+      for (int k = 0; k < m; k++) {
+        double dk[3], oy, ov;
+#pragma unroll
+        for (int q = 0; q < 3; q++) dk[q] = d.lm_hP[((size_t)k * 6 + q) * TL + slot];
+        lm_row_dot2(fs + (s0 + 1 + k) * LM_FS, dk, Dx + 3, oy, ov);
+        hy -= oy; hv -= ov;
+      }
+    } else if (d.vis_full) {
       for (int q = 0; q < 6; q++) {
         const double hi = d.lm_hC[(size_t)q * TL + slot], he = d.lm_hC[(size_t)(6 + q) * TL + slot];
         hy += hi * sy[6 * s0 + q] + he * sy[T_EX + q];
@@ -1977,6 +2016,7 @@ __device__ __forceinline__ void lm_step_tile(const BatchDev &d, const WinDesc &d
         hv += hi * sv[6 * s0 + q] + 0.0;
       }
     }
+    if (!fs)
     for (int k = 0; k < m; k++)
       for (int q = 0; q < 6; q++) {
         const double h = d.lm_hP[((size_t)k * 6 + q) * TL + slot];
@@ -2018,7 +2058,10 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
     sv[a] = s * d.vp[(size_t)w * ND + a];
   }
   __syncthreads();
-  lm_step_tile(d, ds, c, w, tile, t, sy, sv);
+  __shared__ double fsteps[NF * LM_FS];
+  const bool comp = !d.vis_full;      // the rows are in the compressed form of k_vis<0, false>
+  if (comp) { stage_frame_steps(d, c, w, t, sy, sv, fsteps); __syncthreads(); }
+  lm_step_tile(d, ds, c, w, tile, t, sy, sv, comp ? fsteps : nullptr);
 }
 
 // =============================================================================================
@@ -2333,7 +2376,10 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d) {
       sv[a] = s * d.vp[(size_t)w * ND + a];
     }
     __syncthreads();
-    lm_step_tile(d, ds, c, w, tile, t, sy, sv);
+    __shared__ double fsteps[NF * LM_FS];
+    const bool comp = !d.vis_full;      // (workgroup-uniform: the barrier below is safe)
+    if (comp) { stage_frame_steps(d, c, w, t, sy, sv, fsteps); __syncthreads(); }
+    lm_step_tile(d, ds, c, w, tile, t, sy, sv, comp ? fsteps : nullptr);
   }
   // ---- preloads of the tail
   StepLocal lc;

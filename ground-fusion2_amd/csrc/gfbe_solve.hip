@@ -67,12 +67,19 @@ __device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu
           const double sl = d.lm_sl[slot], hs2 = sl * sl * d.lm_Hll[slot];
           const double wl = sl * sl / (hs2 + mu * clamp_diag(hs2));
           auto hval = [&](int x) -> double {
-            if (x >= T_EX) return d.lm_hC[(size_t)(x == T_TD ? 12 : 6 + x - T_EX) * TL + slot];
+            if (x >= T_EX) return d.vis_full ? d.lm_hC[(size_t)(x == T_TD ? 12 : 6 + x - T_EX) * TL + slot] : 0.0;
             const int f = x / 6, q = x % 6;
-            if (f == s) return d.lm_hC[(size_t)q * TL + slot];
             const int k = f - s - 1;
-            if (k < 0 || k >= m) return 0.0;
-            return d.lm_hP[((size_t)k * 6 + q) * TL + slot];
+            if (f != s && (k < 0 || k >= m)) return 0.0;
+            if (d.vis_full) return f == s ? d.lm_hC[(size_t)q * TL + slot] : d.lm_hP[((size_t)k * 6 + q) * TL + slot];
+            // compressed rows (k_vis<0, false>): the block of frame f from d (or D), x and the frame's constants (gfbe_devutil.h)
+            double dv[3], xl[3], blk[6];
+            for (int u = 0; u < 3; u++) {
+              dv[u] = f == s ? d.lm_hC[(size_t)u * TL + slot] : d.lm_hP[((size_t)k * 6 + u) * TL + slot];
+              xl[u] = d.lm_hC[(size_t)(3 + u) * TL + slot];
+            }
+            lm_row_block(d.pc + (((size_t)w * 3 + d.ctl[w].cur) * NPAIR + f * (NF + 1)) * PAIR_CONST_DOUBLES + LM_RT_OFF, dv, xl, f == s, blk);
+            return blk[q];
           };
           acc += wl * hval(a) * (isg ? d.lm_gl[slot] : hval(b));
         }

@@ -59,7 +59,8 @@ def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter,
     # transient iterations drop the cost by 1e5: 1e-6 relative there (as in test_gpu_parity.py), 1e-11 at convergence
     # (a GNSS window stops on the parameter tolerance before it has settled — DESIGN.md section 6 — and carries 1e5..1e7-sized
     #  clock / anchor blocks: two summation orders end 1e-10 apart in the cost; bounds x 100)
-    lo = 100.0 if kind == "gnss" else 1.0
+    # (retry3: an iteration taken with mu x 1000 is a heavily damped step; the run ends 1.3e-11 apart in the cost: bounds x 10)
+    lo = 100.0 if kind == "gnss" else (10.0 if kind == "retry3" else 1.0)
     np.testing.assert_allclose(r0["got_cost_history"], r0["ref_cost_history"], rtol=1e-6)
     assert abs(float(r0["got_final_cost"]) - float(r0["ref_final_cost"])) < lo * 1e-11 * float(r0["ref_final_cost"])
     assert np.abs(r0["got_pose"] - r0["ref_pose"]).max() < lo * 1e-10

@@ -14,7 +14,7 @@ VDIR = os.path.join(ROOT, "ground-fusion2_amd", "csrc", "variants")
 VARIANTS = {   # name -> (extra flags, fp-contract)
     "base": ([], "off"),
     "schurabs": (["-DGFBE_SCHUR_COMPACT=0"], "off"),
-    "schur1deep": (["-DGFBE_SCHUR_DEEP=0"], "off"),
+    "kvis3": (["-DGFBE_KVIS_WAVES=3"], "off"),
     "noearly": (["-DGFBE_KVIS_EARLY=0"], "off"),
     "contract": ([], "fast"),
     "stamp": (["-DGFBE_KVIS_STAMP=1"], "off"),
