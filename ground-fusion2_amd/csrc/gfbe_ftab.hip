@@ -476,14 +476,21 @@ __global__ __launch_bounds__(256) void k_ftab_landmarks_write(FtabDev T, int cur
   const int *lay = layout + (size_t)wl * LAY_STRIDE;
   const int s = T.start[cur][base + f], rel = T.keep[base + f], slot = lay[0] + rel;
   const double *o = T.obs[cur] + ((base + f) * NOBS + q) * OW;
-  const double tdq = T.td[cur][(base + f) * NOBS + q];
+  double tdq = T.td[cur][(base + f) * NOBS + q];
+  // a batch whose windows all hold td constant stores the observation already shifted to the window's td (what every factor evaluation
+  // would compute, projectionTwoFrameOneCamFactor.cpp:60-61) and td in place of the observation's own: see expand_body (gfbe_kernels.hip)
+  double ox = o[0], oy = o[1];
+  if (!d.vis_full) {
+    const double tdw = d.x0[(size_t)wl * NA + A_TD], dt = tdw - tdq;
+    ox = __builtin_fma(-dt, o[5], ox); oy = __builtin_fma(-dt, o[6], oy); tdq = tdw;
+  }
   if (q == 0) {
-    d.lm_pts[0 * TL + slot] = o[0]; d.lm_pts[1 * TL + slot] = o[1]; d.lm_pts[2 * TL + slot] = o[2];
+    d.lm_pts[0 * TL + slot] = ox; d.lm_pts[1 * TL + slot] = oy; d.lm_pts[2 * TL + slot] = o[2];
     d.lm_pts[3 * TL + slot] = o[5]; d.lm_pts[4 * TL + slot] = o[6]; d.lm_pts[5 * TL + slot] = tdq;
   } else {
     const int k = q - 1;
     double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
-    ob[0] = o[0]; ob[TL] = o[1]; ob[2 * TL] = o[5]; ob[3 * TL] = o[6]; ob[4 * TL] = tdq;
+    ob[0] = ox; ob[TL] = oy; ob[2 * TL] = o[5]; ob[3 * TL] = o[6]; ob[4 * TL] = tdq;
     d.lm_rec[(size_t)k * TL + slot] = lay[LAY_PAIR + s * NF + s + 1 + k] + (rel - lay[LAY_GRP + s]);   // slot order inside a pair = group order
   }
 }

@@ -332,7 +332,12 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
   double cost = 0.0;
   const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
-  const double vix = d.lm_pts[3 * TL + slot], viy = d.lm_pts[4 * TL + slot], tdi = d.lm_pts[5 * TL + slot];
+  // (tdc: the observations of this batch are stored shifted to the windows' constant td — expand_body — and need neither their
+  //  velocities nor their own td here; compile-time for the 7 x 7 linearisation, a launch-uniform flag for the cost pass)
+  const bool tdc = YM || (MODE == 1 && !d.vis_full);
+  const int nobq = tdc ? 2 : 5;
+  double vix = 0.0, viy = 0.0, tdi = 0.0;
+  if (!tdc) { vix = d.lm_pts[3 * TL + slot]; viy = d.lm_pts[4 * TL + slot]; tdi = d.lm_pts[5 * TL + slot]; }
   const double lam = lamv[slot];
   // landmark row of the normal equations: pose_i (6) [| extrinsic (6) | td] — the latter only when they are free somewhere
   constexpr int NHC = FULL ? HC : 6;
@@ -348,9 +353,9 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   double ycx = 0.0, ycy = 0.0, ycz = 0.0, yinv_l = 0.0, Dsum[3] = {0.0, 0.0, 0.0};
   vec3 yf = mk3(0.0, 0.0, 0.0), ye = yf, yx = yf;
   if (YM || MODE == 1) {
-    const double dti = td - tdi;
+    const double dti = tdc ? 0.0 : td - tdi;
     yinv_l = 1.0 / lam;
-    ycx = __builtin_fma(-dti, vix, pix) * yinv_l; ycy = __builtin_fma(-dti, viy, piy) * yinv_l; ycz = piz * yinv_l;
+    ycx = (tdc ? pix : __builtin_fma(-dti, vix, pix)) * yinv_l; ycy = (tdc ? piy : __builtin_fma(-dti, viy, piy)) * yinv_l; ycz = piz * yinv_l;
     if (YM) {
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -364,11 +369,11 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   }
   // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length hold whatever the memory held —
   // lm_obs is not cleared at upload — and are used below the track's length only)
-  double nob[5];
+  double nob[5] = {0.0, 0.0, 0.0, 0.0, td};      // (tdc: rows 2..4 are not loaded — zero velocity, the window's td: the shift is an exact zero)
   {
     const double *ob = d.lm_obs + (size_t)kq * 5 * TL + slot;
 #pragma unroll
-    for (int q = 0; q < 5; q++) nob[q] = (kq < mmax) ? ob[q * TL] : 0.0;
+    for (int q = 0; q < 5; q++) if (q < nobq) nob[q] = (kq < mmax) ? ob[q * TL] : 0.0;
   }
   KSTAMP(2);
   double *contrib = KS > 1 ? d.vis_contrib + (((size_t)w * d.max_tiles + tile) * MAXOBS) * (VC_STRIDE * LM_TILE) + lane : nullptr;
@@ -379,7 +384,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     if (k + KS < mmax) {
       const double *ob = d.lm_obs + (size_t)(k + KS) * 5 * TL + slot;
 #pragma unroll
-      for (int q = 0; q < 5; q++) nob[q] = ob[q * TL];
+      for (int q = 0; q < 5; q++) if (q < nobq) nob[q] = ob[q * TL];
     }
     if constexpr (YM) {
       double *xr = xs + lane * XLD;
@@ -419,7 +424,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       }
 #if GFBE_KVIS_EARLY
 #pragma unroll
-      for (int q = 0; q < 5; q++) asm volatile("" : "+v"(nob[q]));      // (see the 13-column path below)
+      for (int q = 0; q < 2; q++) asm volatile("" : "+v"(nob[q]));      // (see the 13-column path below)
 #endif
       if (k < m) {
 #pragma unroll
@@ -2542,13 +2547,29 @@ __device__ __forceinline__ void expand_body(const BatchDev &d, const int w, cons
   const int s = info & 0xff, m = (info >> 8) & 0xff;
   const int pos = rel - ds.sf_tile_begin[s] * LM_TILE;
   const size_t TL = d.tot_lm;
+  // A batch whose windows ALL hold td constant (and the camera extrinsic: !vis_full) stores every observation already shifted to the
+  // window's td — p' = p - (td - td_obs) v, what each factor evaluation would compute (projectionTwoFrameOneCamFactor.cpp:60-61), the
+  // same fused multiply-add — and td in place of the observation's own td, so that the kernels that still apply the shift (the
+  // marginalisation's 20-column panel, gfbe_eval_factors) subtract an exact zero: the linearisation and the candidate-cost pass then
+  // read two of an observation's five doubles and three of a landmark's six (k_vis<0, false>, k_vis<1>: both wait for memory).
+  const bool shift = !d.vis_full;
+  const double tdw = d.x0[(size_t)w * NA + A_TD];
+  if (shift) {
+    const double dti = tdw - d.lm_pts[5 * TL + slot];
+    d.lm_pts[0 * TL + slot] = __builtin_fma(-dti, d.lm_pts[3 * TL + slot], d.lm_pts[0 * TL + slot]);
+    d.lm_pts[1 * TL + slot] = __builtin_fma(-dti, d.lm_pts[4 * TL + slot], d.lm_pts[1 * TL + slot]);
+    d.lm_pts[5 * TL + slot] = tdw;
+  }
   for (int k = 0; k < m; k++) {
     const int rec = ds.pair_begin[s * NF + s + 1 + k] + pos;
     d.lm_rec[(size_t)k * TL + slot] = rec;
     const double *f = d.fobs + ((size_t)ds.rec_off + rec) * 5;
     double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
-#pragma unroll
-    for (int q = 0; q < 5; q++) ob[q * TL] = f[q];
+    const double dtj = shift ? tdw - f[4] : 0.0;
+    ob[0] = shift ? __builtin_fma(-dtj, f[2], f[0]) : f[0];
+    ob[TL] = shift ? __builtin_fma(-dtj, f[3], f[1]) : f[1];
+    ob[2 * TL] = f[2]; ob[3 * TL] = f[3];
+    ob[4 * TL] = shift ? tdw : f[4];
   }
 }
 __global__ __launch_bounds__(256) void k_expand(BatchDev d) { expand_body(d, blockIdx.y, blockIdx.x); }
