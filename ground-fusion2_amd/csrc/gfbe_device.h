@@ -267,7 +267,11 @@ struct BatchDev {
   double *vis_Hs;             // small batches only (else nullptr): [B][vs_blocks][73][74], one block per (start frame, thread group), summed by k_assemble
   int vs_blocks;              // VS_BLOCKS when some window has a free extrinsic / td (13/20-column partials); 1 otherwise: block 0 is the whole visual block (visblock_y)
   double *raw_imu, *raw_wheel; // [MAX_IMU][15 + 450][B], [MAX_WHEEL][6 + 132][B]  un-whitened residuals / Jacobians (k_dense_raw), window-minor
-  int *asm_tab;               // [ND (ND + 1) / 2][4]  window-independent assembly table (k_asm_table)
+  int *asm_tab;               // [asm_n][4]  window-independent assembly table, owned by the context (asm_tables_build): every entry of the lower
+                              // triangle over the dims in use, or — a batch without GNSS blocks whose priors hold no speed-bias block
+                              // but SpeedBias[0] — only the entries some factor of such a window can reach (~43 %: the others of H stay
+                              // the zeros of the upload)
+  int asm_n;
   double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble
   double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
   double *vis_contrib;        // [B][max_tiles][MAXOBS][16][64] small batches: per-step contributions to Hll, gl, hC, cost (k_lin_small)
@@ -342,7 +346,8 @@ void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock 
 void launch_visblock(const BatchDev &d, hipStream_t s);
 void launch_lio_window(const BatchDev &d, int mode, hipStream_t s);
 void launch_assemble(const BatchDev &d, hipStream_t s);
-void launch_asm_table(const BatchDev &d, hipStream_t s);
+// the context's assembly tables (built once per context): full[ND (ND + 1) / 2] and compact[*n_compact], both ordered by the larger dim
+hipError_t asm_tables_build(int **full, int **compact, int *n_compact, hipStream_t s);
 // context accessors for the translation units that do not see the gfbe_ctx definition (gfbe_host.cpp)
 hipStream_t ctx_stream(gfbe_ctx *c);
 int ctx_device(const gfbe_ctx *c);

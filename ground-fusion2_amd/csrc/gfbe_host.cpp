@@ -109,6 +109,8 @@ struct gfbe_ctx {
   bool profiling = false;
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> event_pool;
+  int *asm_full = nullptr, *asm_compact = nullptr;    // the window-independent assembly tables (asm_tables_build, once per context)
+  int asm_compact_n = 0;
   std::vector<hipEvent_t> sync_event_pool;            // hipEventDisableTiming events of freed batches (three per batch: created and destroyed per
                                                       // gfbe_solve_window call they cost ~50 us of its 1.45 ms)
   gfbe_allreduce_fn allreduce = nullptr;
@@ -268,6 +270,7 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   hipError_t ea = kernels_init_device();
   if (ea == hipSuccess) ea = marg_init_device();
   if (ea == hipSuccess) ea = gnss_init_device();
+  if (ea == hipSuccess) ea = asm_tables_build(&c->asm_full, &c->asm_compact, &c->asm_compact_n, c->stream);
   if (ea != hipSuccess) { c->err = std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
   return GFBE_OK;
 }
@@ -276,6 +279,8 @@ void gfbe_destroy(gfbe_ctx *c) {
   if (!c) return;
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   for (auto e : c->sync_event_pool) (void)hipEventDestroy(e);
+  if (c->asm_full) (void)hipFree(c->asm_full);
+  if (c->asm_compact) (void)hipFree(c->asm_compact);
   for (auto &p : c->prof) for (auto &ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
@@ -817,7 +822,6 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     const size_t zero_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- written before they are read: no clearing (block-CSR records only exist for the inspection API)
     AL(prior_J0, (size_t)B * ND * ND);     // (the n x n prior block arrives by copy; nothing reads past it)
-    AL(asm_tab, (size_t)4 * (ND * (ND + 1) / 2));   // (k_asm_table writes every entry)
 #if !GFBE_CLEAR_LM
     AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL);   // (k_expand / k_ftab_pack write the rows of a track; the evaluation uses a row only below the track's length: 0.9 of the 2.8 MB per window that used to be cleared)
     AL(lm_hP, (size_t)MAXOBS * 6 * TL);    // (k_vis writes the rows below a track's length, k_schur masks the others per landmark: 1.0 MB per window)
@@ -827,7 +831,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)
     AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);                   // (written by the kernels that produce a state)
     AL(prior_H, (size_t)B * ND * ND);      // (k_prep writes the n x n block k_assemble reads)
-    // (k_assemble writes every entry of H (lower triangle), g, E, eg it owns, k_visblock the exchange row: no clearing)
+    // (k_assemble writes every entry of H (lower triangle) its table lists, g, E, eg it owns, k_visblock the exchange row: no clearing
+    //  here — a batch on the compact table clears H once at upload, below)
     // the partial reduced system [H | g | E | eg | xa] is one slab: a single all-reduce per linearisation when the
     // landmarks are sharded over ranks
     {
@@ -1023,6 +1028,14 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       for (int q = 0; q < ds.prior_nblk; q++) if (ds.prior_blk_id[q] > GFBE_BLK_SB0 && ds.prior_blk_id[q] < GFBE_BLK_EX_CAM) mono = 1;
     }
     d.solve_ntile = ntile; d.solve_mono = mono;
+    // the assembly table of the context: the compact one unless a prior couples a speed-bias block other than SpeedBias[0] (entries
+    // outside the set it lists) or the batch carries GNSS dims
+    bool prior_sb = false;
+    for (int w = 0; w < B && !prior_sb; w++)
+      for (int q = 0; q < h_desc[w].prior_nblk; q++) if (h_desc[w].prior_blk_id[q] > GFBE_BLK_SB0 && h_desc[w].prior_blk_id[q] < GFBE_BLK_EX_CAM) prior_sb = true;
+    const bool compact = !prior_sb && d.nu == NC && c->asm_compact_n > 0;
+    d.asm_tab = compact ? c->asm_compact : c->asm_full;
+    d.asm_n = compact ? c->asm_compact_n : d.nu * (d.nu + 1) / 2;
   }
   const double T3 = now();
   // ---- enqueue: clear what must start as zero, ONE host-to-device copy, then the preparation kernels
@@ -1034,6 +1047,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     for (const auto &pl : b->poison_list)
       if (pl.off >= b->zero_end && (!strcmp(poison_env, "1") || !strcmp(poison_env, "clean") || !strcmp(poison_env, pl.name)))
         HIPCHK(c, hipMemsetAsync(b->slab + pl.off, strcmp(poison_env, "clean") ? 0xFF : 0, pl.bytes, us));   // ("clean": zeros, for a scan that poisons one array at a time)
+  // the compact assembly table writes only the entries of H some factor can reach: the others are read (as the zeros they are) by
+  // the solve kernels and must start as zeros — H is not part of the cleared region (the full table writes every entry)
+  if (d.asm_tab == c->asm_compact) HIPCHK(c, hipMemsetAsync(d.H, 0, sizeof(double) * (size_t)B * ND * ND, us));
   HIPCHK(c, hipMemcpyAsync(b->slab, b->up_h, b->up_end, hipMemcpyHostToDevice, us));
   if (pj_row > 0)
     HIPCHK(c, hipMemcpy2DAsync(d.prior_J0, sizeof(double) * ND * ND, d_pJ0c, sizeof(double) * pj_row, sizeof(double) * pj_row, B, hipMemcpyDeviceToDevice, us));
@@ -1046,7 +1062,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     launch_expand(d, us);
   }
   if (B < DENSE_SPLIT_MIN_B) launch_upload_small(d, tabs ? 0 : 1, us);    // (one launch: gfbe_kernels.hip)
-  else { launch_prep(d, us); launch_asm_table(d, us); }
+  else launch_prep(d, us);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(b->ev_up, us));
   if (dbg_t) {

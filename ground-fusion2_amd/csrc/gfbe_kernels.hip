@@ -1402,8 +1402,51 @@ __device__ __forceinline__ void asm_table_body(int4 *tab, const int bx) {
   tab[e] = r;
 }
 __global__ __launch_bounds__(256) void k_asm_table(int4 *tab) { asm_table_body(tab, blockIdx.x); }
-void launch_asm_table(const BatchDev &d, hipStream_t s) {
-  hipLaunchKernelGGL(k_asm_table, dim3((ASM_NTRI + 255) / 256), dim3(256), 0, s, (int4 *)d.asm_tab);
+// The compact table: the entries of the core dims (the first NC (NC + 1) / 2 of the full table) that some factor of a window can reach
+// when its prior holds no speed-bias block but SpeedBias[0] — both dims among the 73 visual ones, an inertial or wheel slot, the wheel's
+// global block, or both dims in the set a reference-structured prior (and the plane / anchor factors) can couple: the poses, SpeedBias[0],
+// the camera extrinsic and td, the wheel extrinsic / intrinsics / td, the plane blocks. One workgroup, order kept (block scans).
+__device__ __forceinline__ bool asm_prior_dim(int x) { return x < NV || (x >= T_SB(0) && x < T_SB(1)) || (x >= T_EXW && x < NC); }
+__global__ __launch_bounds__(1024) void k_asm_compact(const int4 *full, int4 *compact, int *n_out) {
+  __shared__ int wcnt[16], base;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  if (t == 0) base = 0;
+  __syncthreads();
+  const int ntri = NC * (NC + 1) / 2;
+  for (int e0 = 0; e0 < ntri; e0 += 1024) {
+    const int e = e0 + t;
+    int4 r = make_int4(0, 0, 0, 0);
+    bool live = false;
+    if (e < ntri) {
+      r = full[e];
+      const int hi = r.x & 255, lo = (r.x >> 8) & 255;
+      live = hi < NV || r.y != 0 || r.z != 0 || (lo >= T_EXW && hi <= T_TDW) || (asm_prior_dim(hi) && asm_prior_dim(lo));
+    }
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int q = 0; q < wv; q++) off += wcnt[q];
+    if (live) compact[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    __syncthreads();
+    if (t == 0) { int s2 = 0; for (int q = 0; q < 16; q++) s2 += wcnt[q]; base += s2; }
+    __syncthreads();
+  }
+  if (t == 0) *n_out = base;
+}
+hipError_t asm_tables_build(int **full, int **compact, int *n_compact, hipStream_t s) {
+  int *f = nullptr, *cmp = nullptr, *dn = nullptr;
+  hipError_t e = hipMalloc(&f, sizeof(int4) * ASM_NTRI);
+  if (e == hipSuccess) e = hipMalloc(&cmp, sizeof(int4) * (NC * (NC + 1) / 2));
+  if (e == hipSuccess) e = hipMalloc(&dn, sizeof(int));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_asm_table, dim3((ASM_NTRI + 255) / 256), dim3(256), 0, s, (int4 *)f);
+  hipLaunchKernelGGL(k_asm_compact, dim3(1), dim3(1024), 0, s, (const int4 *)f, (int4 *)cmp, dn);
+  e = hipMemcpyAsync(n_compact, dn, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(dn);
+  *full = f; *compact = cmp;
+  return e;
 }
 
 __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab &tb, const double *Z, int w, int a) {
@@ -1786,7 +1829,7 @@ __device__ __forceinline__ AsmCommon asm_common(const BatchDev &d, const int w) 
   c.lio_on = c.vsplit && ds.lio_n > 0 && d.rank == 0;
   c.lio_o = 6 * ds.lio_frame;
   c.vis_s = c.vsplit ? d.vis_Hs + (size_t)w * d.vs_blocks * NV * V_LD : c.Z;
-  c.ntri = d.nu * (d.nu + 1) / 2;      // the table is ordered by the larger dim: a batch without GNSS windows stops after the 187 core dims
+  c.ntri = d.asm_n;      // (the full table is ordered by the larger dim: a batch without GNSS windows stops after the 187 core dims; or the compact one)
   return c;
 }
 #define ASM_UNPACK(c)                                                                                                              \
@@ -1939,7 +1982,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d, int nH) {
   const int gtH = bx * ASM_THREADS + threadIdx.x, gnH = nH * ASM_THREADS;
   int4 pre[1] = {make_int4(-1, 0, 0, 0)};
   if (bx < nH) {
-    const int ntri = d.nu * (d.nu + 1) / 2;
+    const int ntri = d.asm_n;
     if (gtH < ntri) pre[0] = ((const int4 *)d.asm_tab)[gtH];
   }
   asm_stage_tables(d, w, tb);
@@ -2584,12 +2627,11 @@ __global__ __launch_bounds__(256) void k_upload_small(BatchDev d, int n_expand) 
   bx -= ne;
   if (bx < nf) { prep_body(d, bx / PREP_FACT_WGS, bx % PREP_FACT_WGS); return; }
   bx -= nf;
-  if (bx < np) { prep_prior_body(d, bx / PREP_PRIOR_WGS, bx % PREP_PRIOR_WGS); return; }
-  asm_table_body((int4 *)d.asm_tab, bx - np);
+  if (bx < np) prep_prior_body(d, bx / PREP_PRIOR_WGS, bx % PREP_PRIOR_WGS);
 }
 void launch_upload_small(const BatchDev &d, int with_expand, hipStream_t s) {
   const int n_expand = (with_expand && d.max_tiles > 0) ? (d.max_tiles * LM_TILE + 255) / 256 : 0;
-  const int total = d.B * (n_expand + PREP_FACT_WGS + PREP_PRIOR_WGS) + (ASM_NTRI + 255) / 256;
+  const int total = d.B * (n_expand + PREP_FACT_WGS + PREP_PRIOR_WGS);
   hipLaunchKernelGGL(k_upload_small, dim3(total), dim3(256), 0, s, d, n_expand);
 }
 
@@ -2707,7 +2749,7 @@ void launch_visblock(const BatchDev &d, hipStream_t s) {       // (throughput ba
 }
 void launch_assemble(const BatchDev &d, hipStream_t s) {
   if (d.vis_Hs) {
-    const int nH = (d.nu * (d.nu + 1) / 2 + ASM_THREADS - 1) / ASM_THREADS;      // one entry of H per thread
+    const int nH = (d.asm_n + ASM_THREADS - 1) / ASM_THREADS;      // one entry of H per thread
     hipLaunchKernelGGL(k_assemble, dim3(nH + ASM_E_WGS + 1, d.B), dim3(ASM_THREADS), 0, s, d, nH);
   }
   else hipLaunchKernelGGL(k_visasm, dim3(d.B), dim3(VB_GROUP), 0, s, d);
