@@ -1081,7 +1081,12 @@ typedef double dbl4_t __attribute__((ext_vector_type(4)));
 #ifndef GFBE_SCHUR_COMPACT
 #define GFBE_SCHUR_COMPACT 1      // 0 (diagnostics build): the absolute column layout of rounds 1-3 in the solve's Schur panels as well
 #endif
-#define HS_LD 83   // LDS row stride of the landmark panel (odd: the 64 lanes that stage one column spread over 32 bank pairs, two-way instead of four-way)
+#ifndef HS_LD
+#define HS_LD 75   // LDS row stride of the landmark panel: odd (the 64 lanes that stage one column spread over 32 bank pairs, two-way instead of
+                   // four-way) and just wide enough for the 74 columns in use — the matrix-core operand loads of the last 16-column block run
+                   // into the next row's first columns: products that only reach output columns >= 75, which nobody reads (38.4 KB: four
+                   // workgroups per CU)
+#endif
 
 __device__ __forceinline__ int schur_pair(int I, int J) { return I * 5 - I * (I - 1) / 2 + (J - I); }   // I <= J < 5
 
@@ -1111,7 +1116,7 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
     if (marg) for (int q = threadIdx.x; q < SCHUR_STRIDE; q += 256) d.schur_part[((size_t)w * d.schur_groups) * SCHUR_STRIDE + q] = 0.0;
     return;
   }
-  __shared__ double hs[LM_TILE * HS_LD];
+  __shared__ double hs[LM_TILE * HS_LD + 8];      // (+ the overrun of the last row's last block)
   const size_t TL = d.tot_lm;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const bool first = (c.iter == 0);   // Jacobi scaling is fixed at iteration 0 (TrustRegionMinimizer::IterationZero)
@@ -1233,10 +1238,10 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
         row[T_TD] = hc_full ? sw * PV[12] : 0.0;                                                                         \
         if (compact) {                                                                                                   \
           row[-coff] = sw * PV[HC];                                     /* column 0: the gradient */                     \
-          for (int q = NV + coff; q < 16 * nside; q++) row[q - coff] = 0.0;     /* behind td, up to the last block any tile of the group multiplies */ \
+          for (int q = NV + coff; q < min(16 * nside, (int)HS_LD); q++) row[q - coff] = 0.0;     /* behind td, up to the last block any tile of the group multiplies */ \
         } else {                                                                                                         \
           row[NV] = sw * PV[HC];                                                                                         \
-          _Pragma("unroll") for (int q = NV + 1; q < NVP; q++) row[q] = 0.0;                                             \
+          _Pragma("unroll") for (int q = NV + 1; q < HS_LD; q++) row[q] = 0.0;                                           \
         }                                                                                                                \
         if (9 < kmax) {                                                  /* the tenth observing pose (start frame 0) */  \
           const bool written = valid && 9 < m;                                                                           \
@@ -1291,7 +1296,10 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   SCHUR_OUT(3, acc3)
 #undef SCHUR_OUT
 }
-__global__ __launch_bounds__(256, 3) void k_schur(BatchDev d, int marg) {
+#ifndef GFBE_SCHUR_WGS
+#define GFBE_SCHUR_WGS 4
+#endif
+__global__ __launch_bounds__(256, GFBE_SCHUR_WGS) void k_schur(BatchDev d, int marg) {
   schur_body(d, marg, blockIdx.x, blockIdx.y);   // group-major dispatch: the heavy first group of every window first
 }
 // Small batches, marginalisation: the pair sums (0, j) and the Schur partial of start frame 0 both read what the linearisation of the
