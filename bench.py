@@ -56,6 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--mixed-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end_to_end block")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-window latency legs (profile runs: their eigen-mode k_marg launches would lead the kernel statistics)")
     ap.add_argument("--e2e-batch", type=int, default=1024, help="windows per batch of the end-to-end loops")
     ap.add_argument("--e2e-steps", type=int, default=8)
     ap.add_argument("--e2e-depth", type=int, default=3, help="batches in flight in the end-to-end loops")
@@ -263,7 +264,7 @@ def main():
         cpu, accuracy = None, None
         if not args.no_cpu_baseline and world == 1:
             cpu, accuracy = cpu_baseline(args, abi, synth, snaps, res[: args.unique])
-        lat = single_window_latencies(args, gf, torch, be, batch_snaps[0], local_rank) if not shard else None
+        lat = single_window_latencies(args, gf, torch, be, batch_snaps[0], local_rank) if not (shard or args.no_single) else None
         out = {
             "metric": "sliding-window solves/sec (10-kf, 2k landmarks)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

@@ -4,9 +4,9 @@
 # the GNSS window profile, the end-to-end loop under the tracer, the one-robot frame loop, the parity soak.
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
 cd /tmp
-rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats -d /tmp/ks -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --mixed 0 > $R/gpurun_out/r4_bench_under_rocprof.json 2> /tmp/ks.err
+rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats -d /tmp/ks -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-single --mixed 0 > $R/gpurun_out/r4_bench_under_rocprof.json 2> /tmp/ks.err
 python $R/profiles/summarize_rocpd.py /tmp/ks/*/*_results.db $R/gpurun_out/r4_kernel_stats_b8192.txt | head -14
-run() { name=$1; shift; rm -rf /tmp/pmc_$name; rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmc_$name -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --mixed 0 > /tmp/pmc_$name.json 2> $R/gpurun_out/pmc_$name.err; python $R/profiles/summarize_pmc.py /tmp/pmc_$name/*/*_results.db $R/gpurun_out/r4_pmc_$name.txt > /dev/null; }
+run() { name=$1; shift; rm -rf /tmp/pmc_$name; rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmc_$name -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-single --mixed 0 > /tmp/pmc_$name.json 2> $R/gpurun_out/pmc_$name.err; python $R/profiles/summarize_pmc.py /tmp/pmc_$name/*/*_results.db $R/gpurun_out/r4_pmc_$name.txt > /dev/null; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES
 run sq2 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VMEM SQ_WAVES
 run fetch FETCH_SIZE
