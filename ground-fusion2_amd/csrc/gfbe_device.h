@@ -406,4 +406,11 @@ struct gfbe_ftab {
   // hipMalloc / hipFree pair per argument cost more than the kernels: 0.4 ms per call measured)
   char *stage_d = nullptr, *stage_h = nullptr;
   size_t stage_cap = 0;
+  // the operations that return nothing (triangulate, setDepth, the erasing ones) do not wait for the device: their arguments go
+  // through a ring of small staging slots, a slot is reused when the event recorded behind its operation has passed
+  enum { RING = 8, RING_SLOT = 64 << 10 };
+  char *ring_d = nullptr, *ring_h = nullptr;
+  hipEvent_t ring_ev[RING] = {};
+  bool ring_used[RING] = {};
+  int ring_next = 0;
 };

@@ -141,16 +141,24 @@ __global__ __launch_bounds__(256) void k_ftab_erase_copy(FtabDev T, int cur) {
 }
 
 // ---- addFeatureCheckParallax ------------------------------------------------------------------------------
-// find_if over the list for every incoming feature (ids are unique inside a table): one thread per incoming feature, any
-// number of workgroups
+// find_if over the list for every incoming feature (feature_manager.cpp:70-74). Ids are unique inside a table (a feature is
+// appended only when the search fails), so at most one list entry matches: workgroup (x, y) compares 64 incoming ids with a
+// tile of FT_MATCH_TILE list ids staged in LDS and the one hit, if any, writes the entry (match[] starts at -1). One thread
+// scanning the whole list (3 500 dependent global loads) took ~0.3 ms per frame of one robot.
+#define FT_MATCH_TILE 1024
 __global__ __launch_bounds__(64) void k_ftab_match(FtabDev T, int cur, const int *offset, const int *fid, int *match) {
-  const int w = blockIdx.y, j0 = offset[w], m = offset[w + 1] - j0, a = blockIdx.x * 64 + threadIdx.x;
+  const int w = blockIdx.z, j0 = offset[w], m = offset[w + 1] - j0, a = blockIdx.x * 64 + threadIdx.x;
+  const int n = T.count[w], f0 = blockIdx.y * FT_MATCH_TILE, nt = min(n - f0, FT_MATCH_TILE);
+  if ((int)blockIdx.x * 64 >= m || nt <= 0) return;       // (workgroup-uniform)
+  __shared__ int s_id[FT_MATCH_TILE];
+  const int *id = T.id[cur] + (size_t)w * T.F + f0;
+  for (int f = threadIdx.x; f < nt; f += 64) s_id[f] = id[f];
+  __syncthreads();
   if (a >= m) return;
-  const int n = T.count[w], want = fid[j0 + a];
-  const int *id = T.id[cur] + (size_t)w * T.F;
+  const int want = fid[j0 + a];
   int hit = -1;
-  for (int f = 0; f < n; f++) if (id[f] == want) { hit = f; break; }
-  match[j0 + a] = hit;
+  for (int f = nt - 1; f >= 0; f--) hit = s_id[f] == want ? f : hit;     // (the first entry of the tile that matches)
+  if (hit >= 0) match[j0 + a] = f0 + hit;
 }
 __global__ __launch_bounds__(FT_THREADS) void k_ftab_add(FtabDev T, int cur, const int *frame_count, const int *offset, const int *fid,
                                                          const double *obs8, const double *tdv, int *match, int *keyframe,
@@ -532,44 +540,58 @@ gfbe_status ft_alloc(gfbe_ctx *c, gfbe_ftab *t, T **p, size_t n) {
   return GFBE_OK;
 }
 // Host arguments of one table operation -> the table's staging chunk (one pinned host mirror, ONE host-to-device copy before
-// the launch, ONE device-to-host copy of the output range after it). `need` = upper bound of the staged bytes.
+// the launch, ONE device-to-host copy of the output range after it, one wait). `need` = upper bound of the staged bytes.
+// `defer`: an operation without outputs — its arguments go through a slot of the table's ring and nobody waits; every
+// operation runs on the context's stream, so whoever reads a result later (add_frame, check_outliers, size, the solver's
+// hand-over) sees the tables after it.
 struct Staged {
   gfbe_ctx *c;
   gfbe_ftab *t;
-  size_t off = 0, ulo = SIZE_MAX, uhi = 0, dlo = SIZE_MAX, dhi = 0;
+  char *bh = nullptr, *bd = nullptr;
+  size_t cap = 0, off = 0, ulo = SIZE_MAX, uhi = 0, dlo = SIZE_MAX, dhi = 0;
+  int slot = -1;
   bool ok = true;
   struct Out { void *h; size_t off, bytes; };
   std::vector<Out> outs;
-  Staged(gfbe_ctx *ctx, gfbe_ftab *tab, size_t need) : c(ctx), t(tab) {
+  Staged(gfbe_ctx *ctx, gfbe_ftab *tab, size_t need, bool defer = false) : c(ctx), t(tab) {
     need += 4096;
-    if (need <= t->stage_cap) return;
-    (void)hipStreamSynchronize(ctx_stream(c));
-    if (t->stage_d) (void)hipFree(t->stage_d);
-    if (t->stage_h) (void)hipHostFree(t->stage_h);
-    t->stage_d = t->stage_h = nullptr; t->stage_cap = 0;
-    const size_t cap = std::max<size_t>(2 * need, (size_t)1 << 20);
-    if (hipMalloc((void **)&t->stage_d, cap) != hipSuccess || hipHostMalloc((void **)&t->stage_h, cap) != hipSuccess) { ok = false; return; }
-    t->stage_cap = cap;
+    if (defer && t->ring_d && need <= (size_t)gfbe_ftab::RING_SLOT) {
+      slot = t->ring_next;
+      t->ring_next = (slot + 1) % gfbe_ftab::RING;
+      if (t->ring_used[slot]) (void)hipEventSynchronize(t->ring_ev[slot]);
+      bh = t->ring_h + (size_t)slot * gfbe_ftab::RING_SLOT; bd = t->ring_d + (size_t)slot * gfbe_ftab::RING_SLOT; cap = gfbe_ftab::RING_SLOT;
+      return;
+    }
+    if (need > t->stage_cap) {
+      (void)hipStreamSynchronize(ctx_stream(c));
+      if (t->stage_d) (void)hipFree(t->stage_d);
+      if (t->stage_h) (void)hipHostFree(t->stage_h);
+      t->stage_d = t->stage_h = nullptr; t->stage_cap = 0;
+      const size_t ncap = std::max<size_t>(2 * need, (size_t)1 << 20);
+      if (hipMalloc((void **)&t->stage_d, ncap) != hipSuccess || hipHostMalloc((void **)&t->stage_h, ncap) != hipSuccess) { ok = false; return; }
+      t->stage_cap = ncap;
+    }
+    bh = t->stage_h; bd = t->stage_d; cap = t->stage_cap;
   }
   ~Staged() { finish(); }
   template <typename T>
   T *up(const T *h, size_t n) {
     const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
-    if (!ok || off + bytes > t->stage_cap) { ok = false; return nullptr; }
-    if (h && n) { std::memcpy(t->stage_h + off, h, n * sizeof(T)); ulo = std::min(ulo, off); uhi = std::max(uhi, off + n * sizeof(T)); }
-    T *p = (T *)(t->stage_d + off);
+    if (!ok || off + bytes > cap) { ok = false; return nullptr; }
+    if (h && n) { std::memcpy(bh + off, h, n * sizeof(T)); ulo = std::min(ulo, off); uhi = std::max(uhi, off + n * sizeof(T)); }
+    T *p = (T *)(bd + off);
     off += bytes;
     return p;
   }
   void flush() {   // before the launch
-    if (ok && uhi > ulo) (void)hipMemcpyAsync(t->stage_d + ulo, t->stage_h + ulo, uhi - ulo, hipMemcpyHostToDevice, ctx_stream(c));
+    if (ok && uhi > ulo) (void)hipMemcpyAsync(bd + ulo, bh + ulo, uhi - ulo, hipMemcpyHostToDevice, ctx_stream(c));
   }
   template <typename T>
-  void down(T *h, const T *dptr, size_t n) {
-    if (!h || !n || !ok) return;
+  void down(T *h, const T *dptr, size_t n) {     // (operations with outputs are never deferred)
+    if (!h || !n || !ok || slot >= 0) return;
     const char *p = (const char *)dptr;
-    if (p >= t->stage_d && p < t->stage_d + t->stage_cap) {
-      const size_t o = (size_t)(p - t->stage_d);
+    if (p >= bd && p < bd + cap) {
+      const size_t o = (size_t)(p - bd);
       outs.push_back({h, o, n * sizeof(T)});
       dlo = std::min(dlo, o); dhi = std::max(dhi, o + n * sizeof(T));
     } else {
@@ -577,9 +599,16 @@ struct Staged {
     }
   }
   void finish() {
-    if (dhi > dlo) (void)hipMemcpyAsync(t->stage_h + dlo, t->stage_d + dlo, dhi - dlo, hipMemcpyDeviceToHost, ctx_stream(c));
+    if (slot >= 0) {     // deferred: mark the slot busy until the stream has passed this point
+      (void)hipEventRecord(t->ring_ev[slot], ctx_stream(c));
+      t->ring_used[slot] = true;
+      slot = -2;
+      return;
+    }
+    if (slot == -2 || !bh) return;
+    if (dhi > dlo) (void)hipMemcpyAsync(bh + dlo, bd + dlo, dhi - dlo, hipMemcpyDeviceToHost, ctx_stream(c));
     (void)hipStreamSynchronize(ctx_stream(c));
-    for (const Out &o : outs) std::memcpy(o.h, t->stage_h + o.off, o.bytes);
+    for (const Out &o : outs) std::memcpy(o.h, bh + o.off, o.bytes);
     outs.clear(); dlo = SIZE_MAX; dhi = 0;
   }
 };
@@ -588,13 +617,10 @@ gfbe_status ft_ready(gfbe_ctx *c, gfbe_ftab *t) {
   if (ctx_device(c) < 0) return GFBE_NO_DEVICE;
   return GFBE_OK;
 }
-gfbe_status ft_finish(gfbe_ctx *c, gfbe_ftab *t) {
+// launch errors of the operation (the sticky table errors — capacity, observation count — are raised by k_ftab_add alone and
+// come back with gfbe_ftab_add_frame's own results)
+gfbe_status ft_finish(gfbe_ctx *c, gfbe_ftab *) {
   FT_CHECK(c, hipGetLastError());
-  std::vector<int> err(t->d.W);
-  FT_CHECK(c, hipMemcpyAsync(err.data(), t->d.err, sizeof(int) * t->d.W, hipMemcpyDeviceToHost, ctx_stream(c)));
-  FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
-  for (int w = 0; w < t->d.W; w++)
-    if (err[w]) { ctx_set_error(c, err[w] & 1 ? "feature table capacity exceeded" : "a feature received more than WINDOW_SIZE + 1 observations"); return GFBE_BAD_INPUT; }
   return GFBE_OK;
 }
 }  // namespace
@@ -639,6 +665,9 @@ gfbe_status gfbe_ftab_create(gfbe_ctx *c, int32_t n_tables, int32_t cap, const g
   }
 #undef FA
   { Staged warm(c, t, (size_t)n_tables * cap * 8); }   // staging sized for the largest result (every id flagged) up front
+  FT_CHECK(c, hipMalloc((void **)&t->ring_d, (size_t)gfbe_ftab::RING * gfbe_ftab::RING_SLOT));
+  FT_CHECK(c, hipHostMalloc((void **)&t->ring_h, (size_t)gfbe_ftab::RING * gfbe_ftab::RING_SLOT));
+  for (int k = 0; k < gfbe_ftab::RING; k++) FT_CHECK(c, hipEventCreateWithFlags(&t->ring_ev[k], hipEventDisableTiming));
   FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
   return GFBE_OK;
 }
@@ -649,6 +678,9 @@ void gfbe_ftab_destroy(gfbe_ctx *c, gfbe_ftab *t) {
   for (void *p : t->allocs) (void)hipFree(p);
   if (t->stage_d) (void)hipFree(t->stage_d);
   if (t->stage_h) (void)hipHostFree(t->stage_h);
+  if (t->ring_d) (void)hipFree(t->ring_d);
+  if (t->ring_h) (void)hipHostFree(t->ring_h);
+  for (hipEvent_t e : t->ring_ev) if (e) (void)hipEventDestroy(e);
   delete t;
 }
 
@@ -661,6 +693,7 @@ gfbe_status gfbe_ftab_add_frame(gfbe_ctx *c, gfbe_ftab *t, const int32_t *frame_
   for (int w = 0; w < W; w++)
     for (int k = offset[w] + 1; k < offset[w + 1]; k++)
       if (feature_id[k] <= feature_id[k - 1]) { ctx_set_error(c, "gfbe_ftab_add_frame: feature ids of a table must be strictly ascending"); return GFBE_BAD_INPUT; }
+  std::vector<int> err(W, 0);
   {
     Staged s(c, t, (size_t)M * (OW * 8 + 8) + (size_t)W * 64 + 16 * 256);
     int *dfc = s.up(frame_count, W), *doff = s.up(offset, W + 1), *dfid = s.up(feature_id, M);
@@ -668,14 +701,20 @@ gfbe_status gfbe_ftab_add_frame(gfbe_ctx *c, gfbe_ftab *t, const int32_t *frame_
     int *dmatch = s.up<int>(nullptr, M);
     int *dkf = s.up<int>(nullptr, W), *dcnt = s.up<int>(nullptr, 3 * W);
     double *davg = s.up<double>(nullptr, W);
+    int *derr = s.up<int>(nullptr, W);
     if (!s.ok) { ctx_set_error(c, "gfbe_ftab_add_frame: staging allocation failed"); return GFBE_DEVICE_ERROR; }
     s.flush();
     int mmax = 1;
     for (int w = 0; w < W; w++) mmax = std::max(mmax, offset[w + 1] - offset[w]);
-    hipLaunchKernelGGL(k_ftab_match, dim3((mmax + 63) / 64, W), dim3(64), 0, ctx_stream(c), t->d, t->cur, doff, dfid, dmatch);
+    (void)hipMemsetAsync(dmatch, 0xFF, sizeof(int) * (size_t)std::max(M, 1), ctx_stream(c));     // -1: not in the list
+    hipLaunchKernelGGL(k_ftab_match, dim3((mmax + 63) / 64, (t->d.F + FT_MATCH_TILE - 1) / FT_MATCH_TILE, W), dim3(64), 0, ctx_stream(c), t->d, t->cur, doff, dfid, dmatch);
     hipLaunchKernelGGL(k_ftab_add, dim3(W), dim3(FT_THREADS), 0, ctx_stream(c), t->d, t->cur, dfc, doff, dfid, dobs, dtd, dmatch, dkf, dcnt, davg);
-    s.down(keyframe, dkf, W); s.down(counters, dcnt, 3 * (size_t)W); s.down(avg_parallax, davg, W);
+    // the tables' sticky error flags (only this operation raises them) travel back with the results: one copy, one wait
+    (void)hipMemcpyAsync(derr, t->d.err, sizeof(int) * W, hipMemcpyDeviceToDevice, ctx_stream(c));
+    s.down(keyframe, dkf, W); s.down(counters, dcnt, 3 * (size_t)W); s.down(avg_parallax, davg, W); s.down(err.data(), derr, W);
   }
+  for (int w = 0; w < W; w++)
+    if (err[w]) { ctx_set_error(c, err[w] & 1 ? "feature table capacity exceeded" : "a feature received more than WINDOW_SIZE + 1 observations"); return GFBE_BAD_INPUT; }
   return ft_finish(c, t);
 }
 
@@ -684,7 +723,7 @@ static gfbe_status ft_erase(gfbe_ctx *c, gfbe_ftab *t, int op, const double *a, 
   if (st != GFBE_OK) return st;
   const int W = t->d.W;
   {
-    Staged s(c, t, (size_t)W * 256 + (off ? (size_t)off[W] * 4 : 0) + 8 * 256);
+    Staged s(c, t, (size_t)W * 256 + (off ? (size_t)off[W] * 4 : 0) + 8 * 256, /*defer=*/true);
     double *da = a ? s.up(a, 12 * (size_t)W) : nullptr, *db = b ? s.up(b, 12 * (size_t)W) : nullptr;
     int *di = iarg ? s.up(iarg, W) : nullptr, *doff = off ? s.up(off, W + 1) : nullptr, *dids = off ? s.up(ids, off[W]) : nullptr;
     if (!s.ok) { ctx_set_error(c, "feature table operation: staging allocation failed"); return GFBE_DEVICE_ERROR; }
@@ -716,7 +755,7 @@ static gfbe_status ft_depth(gfbe_ctx *c, gfbe_ftab *t, int mode, const int32_t *
   const int W = t->d.W;
   if (mode != 0 && (!offset || !x_io)) return GFBE_BAD_INPUT;
   {
-    Staged s(c, t, (size_t)W * 16 + (offset ? (size_t)offset[W] * 8 : 0) + 8 * 256);
+    Staged s(c, t, (size_t)W * 16 + (offset ? (size_t)offset[W] * 8 : 0) + 8 * 256, /*defer=*/mode != 2 && !count);
     int *doff = offset ? s.up(offset, W + 1) : nullptr;
     double *dx = offset ? s.up(mode == 1 ? x_io : nullptr, offset[W]) : nullptr;
     int *dcnt = s.up<int>(nullptr, W);
@@ -738,7 +777,7 @@ gfbe_status gfbe_ftab_triangulate(gfbe_ctx *c, gfbe_ftab *t, const double *poses
   if (!poses || !tic_ric) return GFBE_BAD_INPUT;
   const int W = t->d.W;
   {
-    Staged s(c, t, (size_t)W * 144 * 8 + 8 * 256);
+    Staged s(c, t, (size_t)W * 144 * 8 + 8 * 256, /*defer=*/true);
     double *dp = s.up(poses, 132 * (size_t)W), *de = s.up(tic_ric, 12 * (size_t)W);
     if (!s.ok) { ctx_set_error(c, "feature table operation: staging allocation failed"); return GFBE_DEVICE_ERROR; }
     s.flush();
@@ -785,8 +824,10 @@ gfbe_status gfbe_ftab_check_outliers(gfbe_ctx *c, gfbe_ftab *t, const double *po
 gfbe_status gfbe_ftab_size(gfbe_ctx *c, gfbe_ftab *t, int32_t *n) {
   gfbe_status st = ft_ready(c, t);
   if (st != GFBE_OK) return st;
-  FT_CHECK(c, hipMemcpyAsync(n, t->d.count, sizeof(int) * t->d.W, hipMemcpyDeviceToHost, ctx_stream(c)));
+  if (!n) return GFBE_BAD_INPUT;
+  FT_CHECK(c, hipMemcpyAsync(t->stage_h, t->d.count, sizeof(int) * t->d.W, hipMemcpyDeviceToHost, ctx_stream(c)));   // (through the pinned mirror)
   FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
+  std::memcpy(n, t->stage_h, sizeof(int) * t->d.W);
   return GFBE_OK;
 }
 

@@ -123,6 +123,8 @@ struct gfbe_ctx {
   // grow-only device scratch of the short host-buffer calls (pre-integration): no hipMalloc / hipFree per call
   char *scratch = nullptr;
   size_t scratch_cap = 0;
+  char *scratch_pin = nullptr;                        // pinned host mirror for the pre-integration calls (their own, smaller, size)
+  size_t scratch_pin_cap = 0;
   // host <-> device hand-over beside the solves: uploads (one H2D copy + preparation kernels) run on `copy`, downloads
   // (gather kernel + one D2H copy) on `dl`, so that batch k + 1 is uploaded and batch k - 1 downloaded while batch k solves
   hipStream_t copy = nullptr, dl = nullptr;
@@ -295,6 +297,7 @@ void gfbe_destroy(gfbe_ctx *c) {
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (auto &sl : c->slab_cache) (void)hipFree(sl.first);
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->scratch_pin) (void)hipHostFree(c->scratch_pin);
   delete c;
 }
 
@@ -652,8 +655,11 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     int *dcounts = tabs->d.hist + (size_t)tab0 * (FT_BINS + 2);
     launch_ftab_count(tabs->d, tabs->cur, tab0, B, dcounts, us);
     tcounts.resize((size_t)B * (FT_BINS + 2));
-    HIPCHK(c, hipMemcpyAsync(tcounts.data(), dcounts, sizeof(int) * tcounts.size(), hipMemcpyDeviceToHost, us));
+    // (through the tables' pinned staging mirror when it is large enough: a pageable device-to-host copy is staged by the runtime)
+    const bool pinned = tabs->stage_h && sizeof(int) * tcounts.size() <= tabs->stage_cap;
+    HIPCHK(c, hipMemcpyAsync(pinned ? (void *)tabs->stage_h : (void *)tcounts.data(), dcounts, sizeof(int) * tcounts.size(), hipMemcpyDeviceToHost, us));
     HIPCHK(c, hipStreamSynchronize(us));
+    if (pinned) std::memcpy(tcounts.data(), tabs->stage_h, sizeof(int) * tcounts.size());
     tlayout.assign((size_t)B * FT_LAY_STRIDE, 0);
     for (int w = 0; w < B; w++) {   // layout from the per-bin counts: groups by start frame (tile aligned), longer tracks first inside a group
       WinScan &sc = scan[w];
@@ -1587,23 +1593,32 @@ static gfbe_status preint_common(gfbe_ctx *c, int n, const int32_t *offset, cons
                b_l = al(sizeof(double) * lin_w * n), b_n = al(sizeof(double) * 4), b_o = al(sizeof(REC_T) * n);
   const size_t need = b_off + b_s + b_f + b_l + b_n + b_o;
   if (!ctx_scratch(c, need)) { c->err = "hipMalloc(pre-integration scratch) failed"; return GFBE_DEVICE_ERROR; }
-  char *base = c->scratch;
-  int *d_off = (int *)base; base += b_off;
-  double *d_s = (double *)base; base += b_s;
-  double *d_f = (double *)base; base += b_f;
-  double *d_l = (double *)base; base += b_l;
-  double *d_n = (double *)base; base += b_n;
-  REC_T *d_o = (REC_T *)base;
-  HIPCHK(c, hipMemcpyAsync(d_off, offset, sizeof(int) * (n + 1), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_s, samples, sizeof(double) * 7 * tot, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_f, first, sizeof(double) * 6 * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_l, lin, sizeof(double) * lin_w * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_n, noise, sizeof(double) * n_noise, hipMemcpyHostToDevice, c->stream));
+  if (need > c->scratch_pin_cap) {
+    if (c->scratch_pin) (void)hipHostFree(c->scratch_pin);
+    c->scratch_pin = nullptr; c->scratch_pin_cap = 0;
+    const size_t cap = std::max<size_t>(need + need / 2, (size_t)64 << 10);
+    if (hipHostMalloc((void **)&c->scratch_pin, cap) != hipSuccess) { (void)hipGetLastError(); c->err = "hipHostMalloc(pre-integration staging) failed"; return GFBE_DEVICE_ERROR; }
+    c->scratch_pin_cap = cap;
+  }
+  // arguments packed into the pinned mirror of the scratch: ONE host-to-device copy, the kernel, ONE copy back (five pageable
+  // copies up and one down cost more than the integration of one interval)
+  char *base = c->scratch, *pin = c->scratch_pin;
+  const size_t o_off = 0, o_s = o_off + b_off, o_f = o_s + b_s, o_l = o_f + b_f, o_n = o_l + b_l, o_o = o_n + b_n;
+  std::memcpy(pin + o_off, offset, sizeof(int) * (n + 1));
+  std::memcpy(pin + o_s, samples, sizeof(double) * 7 * tot);
+  if (first) std::memcpy(pin + o_f, first, sizeof(double) * 6 * n);
+  if (lin) std::memcpy(pin + o_l, lin, sizeof(double) * lin_w * n);
+  if (noise) std::memcpy(pin + o_n, noise, sizeof(double) * n_noise);
+  int *d_off = (int *)(base + o_off);
+  double *d_s = (double *)(base + o_s), *d_f = (double *)(base + o_f), *d_l = (double *)(base + o_l), *d_n = (double *)(base + o_n);
+  REC_T *d_o = (REC_T *)(base + o_o);
+  HIPCHK(c, hipMemcpyAsync(base, pin, o_o, hipMemcpyHostToDevice, c->stream));
   if (imu) launch_preint_imu(n, d_off, d_s, d_f, d_l, d_n, (gfbe_imu_preint *)d_o, c->stream);
   else launch_preint_wheel(n, d_off, d_s, d_f, d_l, d_n, (gfbe_wheel_preint *)d_o, c->stream);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(out, d_o, sizeof(REC_T) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(pin + o_o, d_o, sizeof(REC_T) * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out, pin + o_o, sizeof(REC_T) * n);
   return GFBE_OK;
 }
 

@@ -7,6 +7,8 @@ test (tests/test_gpu_stream.py); nothing here is part of the product's C ABI.
 Not modelled (out of scope): the front end (tracks come from projecting a synthetic world), the
 initialisation phase (the first 11 frames start from truth + noise), failure detection, re-propagation of
 pre-integrations after large bias changes."""
+import time
+
 import numpy as np
 
 from . import abi, synth
@@ -98,7 +100,24 @@ def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True, devic
     def merged(slot):
         return (np.concatenate([s for s, _ in slot]), slot[0][1])
 
+    # pre_integrations[i] persist from frame to frame in the reference (processIMU pushes the samples of the incoming interval,
+    # slideWindow merges the two newest on MARGIN_SECOND_NEW, estimator.cpp:3790-3806): only intervals whose sample set changed
+    # are integrated again
+    cache_imu, cache_wheel = {}, {}
+
+    def preintegrated(cache, slots, fn):
+        keys = [tuple(id(s) for s, _ in slot) for slot in slots]
+        todo = [i for i, key in enumerate(keys) if key not in cache]
+        if todo:
+            for i, row in zip(todo, fn([merged(slots[i]) for i in todo])):
+                cache[keys[i]] = row.copy()
+        for key in [key for key in cache if key not in keys]:
+            del cache[key]
+        return np.stack([cache[key] for key in keys])
+
+    out["frame_s"] = []        # wall time of every frame of the loop (the first ones include one-time allocations)
     for k in range(W, stream.n_kf):
+        t_frame = time.perf_counter()
         ids, obs = stream.frames[k]
         kf, _, par = tables.add_frame([W], [ids], [obs], [0.0])
         out["parallax"].append(float(par[0]))
@@ -111,12 +130,12 @@ def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True, devic
         snap["frame_count"] = W
         if not device_handoff:
             snap.update(engine.build_visual_factors(abi.ftab_to_feature_list(tables.download(0))))
-        snap["imu"] = engine.preintegrate_imu([merged(s) for s in imu_slots], scn.ba_est, scn.bg_est,
-                                              (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W))
+        snap["imu"] = preintegrated(cache_imu, imu_slots, lambda iv: engine.preintegrate_imu(
+            iv, scn.ba_est, scn.bg_est, (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)))
         snap["imu_frame"] = np.arange(W, dtype=np.int32)
         if wheel_slots is not None:
-            snap["wheel"] = engine.preintegrate_wheel([merged(s) for s in wheel_slots], [1.0, 1.0, 1.0, 0.0],
-                                                      (synth.VEL_N_WHEEL, synth.GYR_N_WHEEL))
+            snap["wheel"] = preintegrated(cache_wheel, wheel_slots, lambda iv: engine.preintegrate_wheel(
+                iv, [1.0, 1.0, 1.0, 0.0], (synth.VEL_N_WHEEL, synth.GYR_N_WHEEL)))
             snap["wheel_frame"] = np.arange(W, dtype=np.int32)
         snap.update(ex_cam_const=1, ex_wheel_const=1, ix_wheel_const=1, td_const=1, td_wheel_const=1, prior=prior)
         if device_handoff:
@@ -161,6 +180,7 @@ def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True, devic
             tables.remove_front([W])
         tables.remove_failures()
         out["n_features"].append(int(tables.size()[0]))
+        out["frame_s"].append(time.perf_counter() - t_frame)
         # ---- the next image: dead-reckon the newest frame through the incoming interval (processIMU)
         if k < stream.n_kf - 1:
             samples, first = scn.imu_raw[k]
