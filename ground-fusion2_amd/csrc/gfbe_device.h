@@ -254,6 +254,7 @@ struct BatchDev {
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *plane_part, *anchor_part;  // [B][MAX_PLANE][PLANE_PART], [B][ANCHOR_PART]   (only read for windows with n_plane / use_anchor)
   int any_plane;                     // some window of the batch has plane or anchor factors (else their workgroups are not launched)
+  int prior_n_max;                   // largest prior dimension of the batch (k_prior_tp stages J0 in LDS when it fits)
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
@@ -330,6 +331,7 @@ enum { PRIOR_X0 = GFBE_NFRAMES * 16 + 32 };
 hipError_t kernels_init_device();   // per-device kernel attributes (k_solve's dynamic LDS); called by gfbe_create
 hipError_t marg_init_device();      // same for k_marg
 hipError_t gnss_init_device();      // same for k_gnss
+hipError_t dense_init_device();     // same for k_prior_tp
 void launch_prep(const BatchDev &d, hipStream_t s);
 void launch_upload_small(const BatchDev &d, int with_expand, hipStream_t s);   // small batches: k_expand + k_prep + k_prep_prior + k_asm_table in one launch
 void launch_expand(const BatchDev &d, hipStream_t s);                 // host upload: fobs -> lm_obs / lm_rec

@@ -272,6 +272,7 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   hipError_t ea = kernels_init_device();
   if (ea == hipSuccess) ea = marg_init_device();
   if (ea == hipSuccess) ea = gnss_init_device();
+  if (ea == hipSuccess) ea = dense_init_device();
   if (ea == hipSuccess) ea = asm_tables_build(&c->asm_full, &c->asm_compact, &c->asm_compact_n, c->stream);
   if (ea != hipSuccess) { c->err = std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
   return GFBE_OK;
@@ -761,6 +762,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
   for (int w = 0; w < B; w++) if (wins[w]->use_plane || wins[w]->use_anchor) d.any_plane = 1;
+  for (int w = 0; w < B; w++) if (wins[w]->prior && wins[w]->prior->valid) d.prior_n_max = std::max(d.prior_n_max, (int)wins[w]->prior->n);
   d.any_gnss = any_gnss; d.tot_gnss = tot_gnss; d.gnss_max_obs = gnss_max; d.marg_nmax = marg_nmax;
   d.nu = (any_gnss || gnss_dims) ? (int)ND : (int)NC;       // a batch without GNSS blocks never touches the last 59 tangent dims
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
@@ -803,7 +805,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
 #endif
     AL(lio_part, (size_t)B * LIOW_WGS * LIOW_PART);
-    AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * B); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * B);
+    AL(raw_imu, (size_t)MAX_IMU * (15 + 450) * 4 * ((B + 3) / 4)); AL(raw_wheel, (size_t)MAX_WHEEL * (6 + 132) * 4 * ((B + 3) / 4));   // [factor][window / 4][value][window % 4]
     AL(zero, 16); AL(vis_H, (size_t)B * NV * (NV + 1));
     d.vs_blocks = d.vis_full ? (int)VS_BLOCKS : 1;
     if (B < DENSE_SPLIT_MIN_B && !c->allreduce) { AL(vis_Hs, (size_t)B * d.vs_blocks * NV * (NV + 1)); } else d.vis_Hs = nullptr;

@@ -31,6 +31,9 @@ namespace gfd {
 #ifndef GFBE_KVIS_EARLY
 #define GFBE_KVIS_EARLY 1   // k_vis: the prefetched observation of the next step is waited for BEFORE this step's stores are issued
 #endif
+#ifndef GFBE_DENSE_TP
+#define GFBE_DENSE_TP 1    // throughput batches: k_dense_tp (matrix-core whitening / J^T J, four windows per workgroup) instead of k_dense<false>
+#endif
 #ifndef GFBE_KVIS_WAVES
 #define GFBE_KVIS_WAVES 3   // k_vis<0, false>: waves per SIMD the register allocation aims at (measured: 4 — 128 VGPRs, a 12-byte spill — 152 us per
                             // 512 windows against 149 at 3: the kernel waits for memory, not for a free wave slot; -ffp-contract=fast: no difference either)
@@ -800,6 +803,9 @@ __device__ __forceinline__ bool dense_pass_active(const WinCtl &c, int mode) {
 }
 #define RAW_IMU (15 + 15 * 30)
 #define RAW_WHEEL (6 + 6 * 22)
+// raw values of factor slot f: [f][window / 4][value q][window % 4] — k_dense_raw (lane = window) stores 32-byte pieces, a workgroup
+// of k_dense_tp reads the RAW x 4 doubles of its four windows as one contiguous block; value q of window w is raw_of(...)[4 q]
+__device__ __forceinline__ size_t raw_of(int f, int w, int B, int raw_len) { return ((size_t)f * ((B + 3) >> 2) + (w >> 2)) * raw_len * 4 + (w & 3); }
 // k_dense_raw: the SE(3) / quaternion algebra of the inertial and wheel factors (imu_factor.h:69-190,
 // wheel_factor.h:80-243) is scalar code; here one LANE = one window (factor f of 64 windows per wave), so the 64
 // lanes of the wave are all busy. Output: raw residual + raw Jacobian non-zeros, window-minor
@@ -817,17 +823,17 @@ __global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode) {
     if (f >= ds.n_imu) return;
     const int fi = ds.imu_frame[f];
     if (mode >= 2 && !(mode == 2 && fi == 0 && d.imu[ds.imu_off + f].sum_dt < 10.0)) return;
-    double *out = d.raw_imu + (size_t)f * RAW_IMU * B + w;
+    double *out = d.raw_imu + raw_of(f, w, (int)B, RAW_IMU);
     imu_raw(&d.imu[ds.imu_off + f], d.opt.g_norm, X + A_POSE(fi), X + A_SB(fi), X + A_POSE(fi + 1), X + A_SB(fi + 1), out,
-            mode == 1 ? nullptr : out + 15 * B, B);
+            mode == 1 ? nullptr : out + 15 * 4, 4);
   } else {
     const int k = f - MAX_IMU;
     if (k >= ds.n_wheel) return;
     const int fi = ds.wheel_frame[k];
     if (mode >= 2 && !(mode == 2 && fi == 0 && d.wheel[ds.wheel_off + k].sum_dt < 10.0)) return;
-    double *out = d.raw_wheel + (size_t)k * RAW_WHEEL * B + w;
+    double *out = d.raw_wheel + raw_of(k, w, (int)B, RAW_WHEEL);
     wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
-              X[A_TDW], out, mode == 1 ? nullptr : out + 6 * B, B);
+              X[A_TDW], out, mode == 1 ? nullptr : out + 6 * 4, 4);
   }
 }
 
@@ -858,10 +864,10 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
         imu_raw(&d.imu[ds.imu_off + f], d.opt.g_norm, X + A_POSE(fi), X + A_SB(fi), X + A_POSE(fi + 1), X + A_SB(fi + 1), raw,
                 mode == 1 ? nullptr : Jraw, 1, t >> 6, nthr >> 6);
     } else {   // raw residual / Jacobian of this factor from k_dense_raw (window-minor layout)
-      const double *in = d.raw_imu + (size_t)f * RAW_IMU * d.B + w;
-      if (t < 15) raw[t] = in[(size_t)t * d.B];
+      const double *in = d.raw_imu + raw_of(f, w, d.B, RAW_IMU);
+      if (t < 15) raw[t] = in[4 * t];
       if (mode != 1)
-        for (int q = t; q < 450; q += nthr) Jraw[q] = imu_nz(q / 30, q % 30) ? in[(size_t)(15 + q) * d.B] : 0.0;
+        for (int q = t; q < 450; q += nthr) Jraw[q] = imu_nz(q / 30, q % 30) ? in[4 * (15 + q)] : 0.0;
     }
     __syncthreads();
     const double *S = d.imu_sqrt + (size_t)(ds.imu_off + f) * 225;   // upper triangular
@@ -899,10 +905,10 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
         wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
                   X[A_TDW], raw, mode == 1 ? nullptr : Jraw);
     } else {
-      const double *in = d.raw_wheel + (size_t)k * RAW_WHEEL * d.B + w;
-      if (t < 6) raw[t] = in[(size_t)t * d.B];
+      const double *in = d.raw_wheel + raw_of(k, w, d.B, RAW_WHEEL);
+      if (t < 6) raw[t] = in[4 * t];
       if (mode != 1)
-        for (int q = t; q < 132; q += nthr) Jraw[q] = wheel_nz(q / 22, q % 22) ? in[(size_t)(6 + q) * d.B] : 0.0;
+        for (int q = t; q < 132; q += nthr) Jraw[q] = wheel_nz(q / 22, q % 22) ? in[4 * (6 + q)] : 0.0;
     }
     __syncthreads();
     const double *S = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
@@ -994,8 +1000,206 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mode, int debug_out) {
-  dense_body<FUSED>(d, mode, debug_out, blockIdx.y, blockIdx.x);
+__global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mode, int debug_out, int f0) {
+  dense_body<FUSED>(d, mode, debug_out, blockIdx.y, blockIdx.x + f0);
+}
+
+// ---- k_dense_tp: the inertial / wheel factors and the prior of throughput batches (B >= DENSE_SPLIT_MIN_B), modes 0 and 1.
+// k_dense gives every factor a 64-thread workgroup whose lanes walk short serial loops (43 000 workgroups per 2048 windows, the raw
+// values fetched one 32-byte sector per double from the window-minor arrays of k_dense_raw). Here
+//   slots 0 .. 19   a workgroup = factor slot f of FOUR consecutive windows, one wave per window. The raw residual / Jacobian
+//                   values of the four windows share their sectors (thread -> (value q, window)); the whitening S [J | r] and
+//                   [Jw | rw]^T [Jw | rw] run on the FP64 matrix cores: with X = [J | r] as two 16-column tiles, Y_t = S X_t comes
+//                   out of v_mfma_f64_16x16x4_f64 in exactly the operand layout of the next product (lane (lr, lk), entry q =
+//                   Y[4 q + lk][16 t + lr]), so G_00 = Y_0^T Y_0, G_10 = Y_1^T Y_0, G_11 = Y_1^T Y_1 follow without a trip through
+//                   LDS: 8 + 12 instructions per inertial factor (15 x 30), 4 + 6 per wheel factor (6 x 22); J^T r is row C of G;
+//   (the priors: k_prior_tp below, a launch of its own because of its LDS.)
+// The cost of a factor is summed from the whitened residual in the same order in both modes. Sums differ from k_dense's in their
+// association only (the small-batch kernel set keeps k_dense; the tests compare the two sets on a tolerance).
+template <bool IMU> struct DenseKind;
+template <> struct DenseKind<true> { enum { R = 15, C = 30, NK = 4, PART = IMU_PART, RAW = RAW_IMU }; };
+template <> struct DenseKind<false> { enum { R = 6, C = 22, NK = 2, PART = WHEEL_PART, RAW = RAW_WHEEL }; };
+enum { DTP_X = 4 * 512, DTP_S = 4 * 256, DTP_LDS = DTP_X + DTP_S, DTP_PRIOR0 = MAX_IMU + MAX_WHEEL };
+
+template <bool IMU>
+__device__ __forceinline__ void dense_tp_factor(const BatchDev &d, int mode, int f, int w0, double *X, double *St, int *s_act) {
+  typedef DenseKind<IMU> K;
+  constexpr int R = K::R, C = K::C, NK = K::NK;
+  typedef double dbl4_d __attribute__((ext_vector_type(4)));
+  const int t = threadIdx.x, wv = t >> 6, lane = t & 63, lr = lane & 15, lk = lane >> 4;
+  const int B = d.B;
+  if (t < 4) {
+    const int w = w0 + t;
+    int act = 0;
+    if (w < B && dense_pass_active(d.ctl[w], mode)) act = f < (IMU ? d.desc[w].n_imu : d.desc[w].n_wheel) ? 1 : 2;   // 2: no such factor
+    s_act[t] = act;
+  }
+  for (int e = t; e < DTP_LDS; e += 256) X[e] = 0.0;      // (X and St are one array: pads and structural zeros)
+  __syncthreads();
+  {   // raw values of the four windows: one contiguous block [value q][window % 4] (raw_of), thread -> (q, window)
+    const int wi = t & 3, qq = t >> 2;
+    if (s_act[wi] == 1) {
+      const double *in = (IMU ? d.raw_imu : d.raw_wheel) + raw_of(f, w0, B, K::RAW) + wi;
+      const int nq = mode == 1 ? R : R + R * C;
+      for (int q = qq; q < nq; q += 64) {
+        int r = q, c = C;
+        bool nz = true;
+        if (q >= R) { const int e = q - R; r = e / C; c = e - r * C; nz = IMU ? imu_nz(r, c) : wheel_nz(r, c); }
+        if (nz) X[((wi * 2 + (c >> 4)) * 16 + r) * 16 + (c & 15)] = in[4 * q];
+      }
+    }
+  }
+  if (s_act[wv] == 1) {   // S of the wave's window, transposed (St[k][i] = S[i][k]; S is upper triangular)
+    const WinDesc &ds = d.desc[w0 + wv];
+    const double *S = IMU ? d.imu_sqrt + (size_t)(ds.imu_off + f) * (R * R) : d.wheel_sqrt + (size_t)(ds.wheel_off + f) * (R * R);
+    for (int e = lane; e < R * R; e += 64) { const int a = e / R, b = e - a * R; if (b >= a) St[(wv * 16 + b) * 16 + a] = S[e]; }
+  }
+  __syncthreads();
+  const int act = s_act[wv], w = w0 + wv;       // (wave-uniform from here on; no block barrier below)
+  if (act == 0) return;
+  double *part = IMU ? d.imu_part + ((size_t)w * MAX_IMU + f) * IMU_PART : d.wheel_part + ((size_t)w * MAX_WHEEL + f) * WHEEL_PART;
+  if (act == 2) { if (mode == 1 && lane == 0) part[K::PART - 1] = 0.0; return; }
+  const double *Xw = X + wv * 512, *Sw = St + wv * 256;
+  double sa[NK], xb[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; kk++) { sa[kk] = Sw[(4 * kk + lk) * 16 + lr]; xb[kk] = Xw[256 + (4 * kk + lk) * 16 + lr]; }
+  dbl4_d Y1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NK; kk++) Y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], xb[kk], Y1, 0, 0, 0);
+  // cost: column C - 16 of tile 1 is the whitened residual — lane (lr = C - 16, lk), entry q = rw[4 q + lk] (rows >= R are zero)
+  double sq = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) sq += Y1[q] * Y1[q];
+  const double s0 = __shfl(sq, C - 16, 64), s1 = __shfl(sq, C, 64), s2 = __shfl(sq, C + 16, 64), s3 = __shfl(sq, C + 32, 64);
+  const double cst = 0.5 * (((s0 + s1) + s2) + s3);
+  if (mode == 1) { if (lane == 0) part[K::PART - 1] = cst; return; }
+#pragma unroll
+  for (int kk = 0; kk < NK; kk++) xb[kk] = Xw[(4 * kk + lk) * 16 + lr];
+  dbl4_d Y0 = {0.0, 0.0, 0.0, 0.0}, G00 = {0.0, 0.0, 0.0, 0.0}, G10 = {0.0, 0.0, 0.0, 0.0}, G11 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kk = 0; kk < NK; kk++) Y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(sa[kk], xb[kk], Y0, 0, 0, 0);
+#pragma unroll
+  for (int kk = 0; kk < NK; kk++) {      // (rows >= 4 NK of Y are zero)
+    G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y0[kk], Y0[kk], G00, 0, 0, 0);
+    G10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y1[kk], Y0[kk], G10, 0, 0, 0);
+    G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y1[kk], Y1[kk], G11, 0, 0, 0);
+  }
+  // entry q of a tile's result: G[4 q + lk][lr]; J^T J (C x C, both triangles), J^T r = row C
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int i = 4 * q + lk, gi = 16 + i, gj = 16 + lr;
+    if (i >= lr) part[i * C + lr] = G00[q];                 // (the lower triangle: what the assembly tables read, part_lower())
+    if (gi < C) { part[gi * C + lr] = G10[q]; if (gj <= gi) part[gi * C + gj] = G11[q]; }
+    else if (gi == C) { part[C * C + lr] = G10[q]; if (gj < C) part[C * C + gj] = G11[q]; }
+  }
+  if (lane == 0) part[K::PART - 2] = cst;
+}
+
+// The prior of one window on 256 threads: r = r0 + J0 dx, g = J0^T r, cost (marginalization_factor.cpp:359-389). J0 (n x n,
+// 59 KB for the usual n = 86) is read ONCE: every thread issues its share of the loads at the start (up to PRIOR_REGS in flight per
+// thread; the dependent descriptor / state loads of the dx computation run behind them), the copy lands in LDS and both products
+// read it there. Measured before (a wave per row, four rows = eight loads in flight, then J0^T r from global memory again): 27 +
+// 23 us of load latency per launch over 512 windows. A batch whose largest prior does not fit (n > PRIOR_LDS_N) takes the
+// global-memory path (lds_n = 0).
+enum { PRIOR_REGS = 32, PRIOR_LDS_N = 90 };      // 256 threads x 32 values >= 90 x 90; 90 x 90 x 8 B = 63 KB of LDS
+static_assert(256 * PRIOR_REGS >= PRIOR_LDS_N * PRIOR_LDS_N, "k_prior_tp: a thread's share of J0");
+__global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_n) {
+  extern __shared__ __attribute__((aligned(16))) double psm[];      // dx[ND] | r[ND] | partial sums [4][ND] | J0 [lds_n x lds_n]
+  __shared__ double red[16];
+  const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (!dense_pass_active(c, mode)) return;
+  double *pg = d.prior_g + (size_t)w * (ND + 2);
+  const int n = ds.prior_n;
+  if (n == 0) { if (t == 0) { pg[ND] = 0.0; pg[ND + 1] = 0.0; } return; }
+  double *dx = psm, *rp = psm + ND, *pp = psm + 2 * ND, *sJ = psm + 6 * ND;
+  const double *J0 = d.prior_J0 + (size_t)w * ND * ND, *r0 = d.prior_r0 + (size_t)w * ND;
+  const bool staged = n <= lds_n;
+  double v[PRIOR_REGS];
+  if (staged) {
+#pragma unroll
+    for (int j = 0; j < PRIOR_REGS; j++) { const int e = t + 256 * j; v[j] = e < n * n ? J0[e] : 0.0; }
+  }
+  const double r0t = t < n ? r0[t] : 0.0;
+  const double *X = d.x + ((size_t)w * 2 + (mode == 1 ? 1 - c.cur : c.cur)) * NA;
+  if (t < ds.prior_nblk)
+    prior_block_dx(X + blk_amb(ds.prior_blk_id[t]), d.prior_x0 + (size_t)w * PRIOR_X0 + ds.prior_x0_off[t], ds.prior_blk_size[t],
+                   dx + ds.prior_blk_idx[t]);
+  if (staged) {
+#pragma unroll
+    for (int j = 0; j < PRIOR_REGS; j++) { const int e = t + 256 * j; if (e < n * n) sJ[e] = v[j]; }
+  }
+  for (int e = t; e < 4 * ND; e += 256) pp[e] = 0.0;
+  __syncthreads();
+  // r = r0 + J0 dx: thread (h, i) sums its quarter (h of ng) of row i; the partial sums are added in the order of h
+  const int ng = min(4, 256 / n), hh = t / n, ii = t - hh * n;      // (n <= 256: GFBE_DENSE_DIM = 246)
+  if (staged) {
+    if (hh < ng) {
+      const int k0 = hh * n / ng, k1 = (hh + 1) * n / ng;
+      double sacc = 0.0;
+      for (int k = k0; k < k1; k++) sacc += sJ[ii * n + k] * dx[k];
+      pp[hh * ND + ii] = sacc;
+    }
+    __syncthreads();
+    if (t < n) rp[t] = r0t + (((pp[t] + pp[ND + t]) + pp[2 * ND + t]) + pp[3 * ND + t]);
+  } else {
+    for (int i0 = 4 * wv; i0 < n; i0 += 16) {      // a wave per row, lanes along the row, four rows in flight
+      double sr[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int k = lane; k < n; k += 64) {
+        const double x = dx[k];
+#pragma unroll
+        for (int u = 0; u < 4; u++) sr[u] += (i0 + u < n ? J0[(size_t)(i0 + u) * n + k] : 0.0) * x;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) sr[u] = wave_sum(sr[u]);
+      if (lane == 0)
+        for (int u = 0; u < 4; u++) if (i0 + u < n) rp[i0 + u] = r0[i0 + u] + sr[u];
+    }
+  }
+  __syncthreads();
+  double cst = 0.0;
+  for (int i = t; i < n; i += 256) cst += 0.5 * rp[i] * rp[i];
+  cst = block_sum(cst, red);
+  if (mode == 1) { if (t == 0) pg[ND + 1] = cst; return; }
+  // g = J0^T r: thread (h, k) sums its quarter of column k
+  if (staged) {
+    if (hh < ng) {
+      const int i0 = hh * n / ng, i1 = (hh + 1) * n / ng;
+      double sacc = 0.0;
+      for (int i = i0; i < i1; i++) sacc += sJ[i * n + ii] * rp[i];
+      pp[hh * ND + ii] = sacc;
+    }
+  } else {
+    constexpr int NG = (ND + 63) / 64;
+    double ag[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) ag[g] = 0.0;
+#pragma unroll 4
+    for (int i = wv; i < n; i += 4) {      // wave wv: rows wv, wv + 4, ...; lanes along the columns
+      const double r = rp[i];
+      const double *row = J0 + (size_t)i * n;
+#pragma unroll
+      for (int g = 0; g < NG; g++) if (lane + 64 * g < n) ag[g] += row[lane + 64 * g] * r;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; g++) if (lane + 64 * g < ND) pp[wv * ND + lane + 64 * g] = ag[g];
+  }
+  __syncthreads();
+  for (int k = t; k < n; k += 256) pg[k] = ((pp[k] + pp[ND + k]) + pp[2 * ND + k]) + pp[3 * ND + k];
+  if (t == 0) pg[ND] = cst;
+}
+
+__global__ __launch_bounds__(256) void k_dense_tp(BatchDev d, int mode) {
+  __shared__ double sm[DTP_LDS];
+  __shared__ int s_act[4];
+  const int slot = blockIdx.x, w0 = blockIdx.y * 4;
+  if (slot < MAX_IMU) dense_tp_factor<true>(d, mode, slot, w0, sm, sm + DTP_X, s_act);
+  else dense_tp_factor<false>(d, mode, slot - MAX_IMU, w0, sm, sm + DTP_X, s_act);
+}
+static size_t prior_tp_lds(int lds_n) { return sizeof(double) * (6 * (size_t)ND + (size_t)lds_n * lds_n); }
+hipError_t dense_init_device() {   // per device, from gfbe_create (see kernels_init_device)
+  return hipFuncSetAttribute((const void *)k_prior_tp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prior_tp_lds(PRIOR_LDS_N));
 }
 
 // Small batches (one window per camera frame is the reference's call pattern): the visual tiles and the inertial / wheel /
@@ -1319,6 +1523,8 @@ __device__ __forceinline__ int vis_loc(int a, int i, int j) {   // compact colum
   if (a < 72) return 12 + (a - 66);
   return 18;
 }
+// entry (la, lb) of a factor's J^T J (symmetric, row stride C) in its lower triangle: k_dense_tp writes only that half
+__device__ __forceinline__ int part_lower(int la, int lb, int C) { return max(la, lb) * C + min(la, lb); }
 __device__ __forceinline__ int imu_loc(int a, int i) {          // column of dim a in the IMU factor (i, i+1)
   if (a < 66) { const int f = a / 6; if (f == i) return a - 6 * f; if (f == i + 1) return 15 + a - 6 * f; return -1; }
   if (a >= 73 && a < 172) { const int f = (a - 73) / 9; if (f == i) return 6 + (a - 73 - 9 * f); if (f == i + 1) return 21 + (a - 73 - 9 * f); }
@@ -1395,8 +1601,8 @@ __device__ __forceinline__ void asm_table_body(int4 *tab, const int bx) {
   if (fa >= 0 && fb >= 0 && abs(fa - fb) <= 1) {   // IMU factors (lo-1, lo) and (lo, lo+1)
     const int lo = min(fa, fb);
     const int i0 = (fa == fb) ? lo - 1 : -1, i1 = lo;
-    if (i0 >= 0) { const int la = imu_loc(a, i0), lb = imu_loc(b, i0); if (la >= 0 && lb >= 0) r.y |= (i0 + 1) | ((la * 30 + lb) << 4); }
-    if (i1 <= NF - 2) { const int la = imu_loc(a, i1), lb = imu_loc(b, i1); if (la >= 0 && lb >= 0) r.y |= ((i1 + 1) | ((la * 30 + lb) << 4)) << 16; }
+    if (i0 >= 0) { const int la = imu_loc(a, i0), lb = imu_loc(b, i0); if (la >= 0 && lb >= 0) r.y |= (i0 + 1) | (part_lower(la, lb, 30) << 4); }
+    if (i1 <= NF - 2) { const int la = imu_loc(a, i1), lb = imu_loc(b, i1); if (la >= 0 && lb >= 0) r.y |= ((i1 + 1) | (part_lower(la, lb, 30) << 4)) << 16; }
   }
   {
     const bool ga = (a >= T_EXW), gb = (b >= T_EXW);            // wheel extrinsic / intrinsics / td_wheel
@@ -1404,8 +1610,8 @@ __device__ __forceinline__ void asm_table_body(int4 *tab, const int bx) {
     int i0 = -1, i1 = -1;
     if (wa >= 0 && wb >= 0) { if (abs(wa - wb) <= 1) { const int lo = min(wa, wb); i0 = (wa == wb) ? lo - 1 : -1; i1 = lo; } }
     else if ((wa >= 0 && gb) || (wb >= 0 && ga)) { const int f = max(wa, wb); i0 = f - 1; i1 = f; }
-    if (i0 >= 0 && i0 <= NF - 2) { const int la = wheel_loc(a, i0), lb = wheel_loc(b, i0); if (la >= 0 && lb >= 0) r.z |= (i0 + 1) | ((la * 22 + lb) << 4); }
-    if (i1 >= 0 && i1 <= NF - 2) { const int la = wheel_loc(a, i1), lb = wheel_loc(b, i1); if (la >= 0 && lb >= 0) r.z |= ((i1 + 1) | ((la * 22 + lb) << 4)) << 16; }
+    if (i0 >= 0 && i0 <= NF - 2) { const int la = wheel_loc(a, i0), lb = wheel_loc(b, i0); if (la >= 0 && lb >= 0) r.z |= (i0 + 1) | (part_lower(la, lb, 22) << 4); }
+    if (i1 >= 0 && i1 <= NF - 2) { const int la = wheel_loc(a, i1), lb = wheel_loc(b, i1); if (la >= 0 && lb >= 0) r.z |= ((i1 + 1) | (part_lower(la, lb, 22) << 4)) << 16; }
   }
   tab[e] = r;
 }
@@ -1919,7 +2125,7 @@ __device__ __forceinline__ void asm_H(const BatchDev &d, const int w, const doub
       double x = v[u];
       if (b >= T_EXW && a <= T_TDW && on[u] && dense_here && tb.n_wheel > 0) {
         // wheel extrinsic / intrinsic / td_wheel block: every wheel factor contributes (10 loads in flight)
-        const int off = wheel_loc(b, 0) * 22 + wheel_loc(a, 0);   // global dims: the column does not depend on the factor
+        const int off = part_lower(wheel_loc(b, 0), wheel_loc(a, 0), 22);   // global dims: the column does not depend on the factor
         double ws = 0.0;
 #pragma unroll
         for (int i = 0; i <= NF - 2; i++) {
@@ -2732,11 +2938,19 @@ void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s) {
   const int nf = MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0);   // (+ PlaneFactors and the PoseAnchorFactor)
   if (d.B < DENSE_SPLIT_MIN_B) {
-    hipLaunchKernelGGL(k_dense<true>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out);
+    hipLaunchKernelGGL(k_dense<true>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out, 0);
     return;
   }
   if (mode != 3) hipLaunchKernelGGL(k_dense_raw, dim3(MAX_IMU + MAX_WHEEL, (d.B + 63) / 64), dim3(64), 0, s, d, mode);
-  hipLaunchKernelGGL(k_dense<false>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out);
+  if (GFBE_DENSE_TP && mode <= 1 && !debug_out) {
+    // the linearisation and the candidate cost of a throughput batch: factor slots of four windows per workgroup + the priors
+    hipLaunchKernelGGL(k_dense_tp, dim3(DTP_PRIOR0, (d.B + 3) / 4), dim3(256), 0, s, d, mode);
+    const int lds_n = d.prior_n_max <= PRIOR_LDS_N ? d.prior_n_max : 0;
+    hipLaunchKernelGGL(k_prior_tp, dim3(d.B), dim3(256), prior_tp_lds(lds_n), s, d, mode, lds_n);
+    if (d.any_plane) hipLaunchKernelGGL(k_dense<false>, dim3(MAX_PLANE + 1, d.B), dim3(64), 0, s, d, mode, 0, DTP_PRIOR0 + 1);   // PlaneFactors, PoseAnchorFactor
+    return;
+  }
+  hipLaunchKernelGGL(k_dense<false>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out, 0);
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock) {
   if (d.max_tiles == 0) return;

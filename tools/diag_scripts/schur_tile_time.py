@@ -20,10 +20,11 @@ b.solve(abi.MARGIN_OLD); b.solve(abi.MARGIN_OLD)
 t = b.debug_timing(0)
 print("B=%d k_schur WG(0,0): first prefetch %.2f us, first LDS stage %.2f us, all %d tiles %.2f us (%.2f us per tile), shader clock %.0f MHz" %
       (B, (t[9] - t[8]) * 0.01, (t[10] - t[9]) * 0.01, int(t[12]), (t[11] - t[8]) * 0.01, (t[11] - t[8]) * 0.01 / max(t[12], 1), (t[14] - t[13]) / ((t[11] - t[8]) * 0.01)))
+te = [0.0] * 32
 be.profile_enable(True); be.profile_reset()
 for _ in range(3):
     b.solve(abi.MARGIN_OLD)
 torch.cuda.synchronize()
 for p in be.profile():
-    if p["launches"] and p["name"] in ("k_schur_iter0", "k_schur", "k_vis_lin_iter0", "k_assemble_iter0", "k_lm_step_iter0", "k_vis_cost", "k_solve_iter0"):
+    if p["launches"] and p["name"] in ("k_schur_iter0", "k_schur", "k_vis_lin_iter0", "k_assemble_iter0", "k_lm_step_iter0", "k_vis_cost", "k_solve_iter0", "k_dense", "k_dense_iter0", "k_dense_cost", "k_candidate", "marginalize"):
         print("  %-18s %8.1f us per launch" % (p["name"], 1e3 * p["total_ms"] / p["launches"]))
