@@ -2536,7 +2536,9 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
 // Throughput batches: ONE workgroup per window — wave 0 takes the dense blocks, then all four waves walk the landmark tiles
 // (a wave per tile, the per-tile sums by the same 64 lanes as in k_candidate: the same bits). The tiles + 1 single-wave workgroups
 // per window of k_candidate are 37 k dispatches of a few hundred nanoseconds of work each per launch of 1024 windows.
+#ifndef CAND_THREADS
 #define CAND_THREADS 256
+#endif
 __global__ __launch_bounds__(CAND_THREADS) void k_candidate_window(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];

@@ -384,7 +384,11 @@ typedef struct gfbe_ftab_options {
   double depth_threshold;  /* triangulateWithDepth: RGB-D depths in [0.1, depth_threshold] are trusted (parameters.cpp:178; yaml) */
 } gfbe_ftab_options;
 void gfbe_ftab_default_options(gfbe_ftab_options *opt);
-/* feature_capacity <= 16384 features per table. */
+/* feature_capacity <= 16384 features per table.
+ * Every table operation runs in order on the context's stream. The ones without outputs (triangulate, set_depth, clear_depth,
+ * remove_*) copy their arguments and return without waiting for the device; the ones that hand something back (add_frame,
+ * check_outliers, get_depth_vector, size, download, gfbe_batch_upload_tables) wait for what was enqueued before them. Capacity /
+ * observation-count overflow is raised by gfbe_ftab_add_frame (GFBE_BAD_INPUT, sticky). */
 gfbe_status gfbe_ftab_create(gfbe_ctx *ctx, int32_t n_tables, int32_t feature_capacity,
                              const gfbe_ftab_options *opt, gfbe_ftab **out);
 void gfbe_ftab_destroy(gfbe_ctx *ctx, gfbe_ftab *t);

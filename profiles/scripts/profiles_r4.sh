@@ -24,6 +24,7 @@ cd /tmp; rm -rf /tmp/pe; B=1024 DEPTH=3 STEPS=10 rocprofv3 --kernel-trace --memo
 python $R/profiles/summarize_rocpd.py /tmp/pe/*/*_results.db $R/gpurun_out/r4_e2e_trace.txt | head -8; cat $R/gpurun_out/r4_e2e.log
 cd $R
 NEW=250 python tools/diag_stream_frame_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4_stream_frame_time.txt; tail -12 gpurun_out/r4_stream_frame_time.txt
+python tools/dump_stream.py /tmp/stream.bin 3 36 250 > /dev/null && g++ -O2 -std=c++17 -I include examples/stream_loop.cpp -L ground-fusion2_amd/csrc -lgfbe -Wl,-rpath,$PWD/ground-fusion2_amd/csrc -o /tmp/stream_loop && (/tmp/stream_loop /tmp/stream.bin /tmp/traj.bin; /tmp/stream_loop /tmp/stream.bin /tmp/traj.bin) | tee gpurun_out/r4_stream_loop_cpp.txt
 N=${SOAK_N:-200} python tools/diag_soak.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4_soak.txt; tail -6 gpurun_out/r4_soak.txt
 python tools/diag_soak_batch.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4_soak_batch.txt; tail -5 gpurun_out/r4_soak_batch.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1

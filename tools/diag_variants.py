@@ -16,6 +16,8 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "schurabs": (["-DGFBE_SCHUR_COMPACT=0"], "off"),
     "kvis3": (["-DGFBE_KVIS_WAVES=3"], "off"),
     "densetp0": (["-DGFBE_DENSE_TP=0"], "off"),
+    "cand512": (["-DCAND_THREADS=512"], "off"),
+    "cand1024": (["-DCAND_THREADS=1024"], "off"),
     "schur3": (["-DGFBE_SCHUR_WGS=3", "-DHS_LD=83"], "off"),
     "noearly": (["-DGFBE_KVIS_EARLY=0"], "off"),
     "contract": ([], "fast"),
