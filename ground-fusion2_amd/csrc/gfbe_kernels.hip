@@ -2537,7 +2537,9 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
 // (a wave per tile, the per-tile sums by the same 64 lanes as in k_candidate: the same bits). The tiles + 1 single-wave workgroups
 // per window of k_candidate are 37 k dispatches of a few hundred nanoseconds of work each per launch of 1024 windows.
 #ifndef CAND_THREADS
-#define CAND_THREADS 256
+#ifndef CAND_THREADS
+#define CAND_THREADS 256   // (512 / 1024 measured: 36 / 49 us per launch over 512 windows against 41, throughput -1 % / -4 %)
+#endif
 #endif
 __global__ __launch_bounds__(CAND_THREADS) void k_candidate_window(BatchDev d) {
   const int w = blockIdx.x;
