@@ -148,3 +148,31 @@ def test_gnss_window_beyond_the_lds_staging_limit(be, oracle):
     both = be.solve_batch([small, snap], abi.MARGIN_OLD)
     assert both[1]["summary"]["final_cost"] == got["summary"]["final_cost"]
     assert np.array_equal(both[1]["state"]["pose"], got["state"]["pose"])
+
+
+def test_throughput_batch_with_priors_beyond_the_lds_staging_limit(be, oracle):
+    """k_prior_tp stages J0 in LDS up to n = 90; a prior that carries GNSS blocks (clock biases, yaw, anchor) is larger, and a batch
+    that holds one takes the global-memory path for ALL its priors. 33 windows (the throughput kernel set): second GNSS windows with
+    the carried prior next to a plain window with its 86-dim prior, each as the small-batch path solves it alone."""
+    scn, tru, snap = gw.gnss_window(seed=81, L=120, n_per_frame=6)
+    first = oracle.solve(snap, abi.MARGIN_OLD)
+    big = gw.next_gnss_window(scn, tru, first, seed=81)
+    assert big["prior"]["n"] > 90
+    ps = synth.Scenario(seed=98, n_landmarks=140, use_wheel=True)
+    r0 = be.solve(ps.window(0), abi.MARGIN_OLD)
+    plain = ps.window(1, state=synth.shift_state_for_next_window(ps, r0["state"], 1), prior=r0["prior"])
+    assert 0 < plain["prior"]["n"] <= 90
+    kinds = [big, plain]
+    alone = [be.solve(k, abi.MARGIN_OLD) for k in kinds]
+    batch = be.solve_batch([kinds[i % 2] for i in range(33)], abi.MARGIN_OLD)
+    for i, got in enumerate(batch):
+        want = alone[i % 2]
+        assert got["summary"]["accepted"] == want["summary"]["accepted"] and got["summary"]["iterations"] == want["summary"]["iterations"]
+        np.testing.assert_allclose(got["summary"]["cost_history"], want["summary"]["cost_history"], rtol=1e-7)
+        assert np.abs(got["state"]["pose"] - want["state"]["pose"]).max() < 1e-8
+        assert got["prior"]["block_id"].tolist() == want["prior"]["block_id"].tolist()
+        assert got["summary"]["cost_history"] == batch[i % 2]["summary"]["cost_history"]
+    # the same plain window in a batch of its own (its prior staged in LDS): the tolerances of the two kernel sets again
+    staged = be.solve_batch([plain] * 32, abi.MARGIN_OLD)[5]
+    np.testing.assert_allclose(staged["summary"]["cost_history"], alone[1]["summary"]["cost_history"], rtol=1e-7)
+    assert np.abs(staged["state"]["pose"] - alone[1]["state"]["pose"]).max() < 1e-8
