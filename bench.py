@@ -381,10 +381,10 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
             continue
         us = 1e3 * p["total_ms"] / p["launches"]
         tot = per_window * windows_per_launch
-        ach = tot / (us * 1e-6) / 1e12
-        peak = PEAK_F64_TF if bound == "mfma" else PEAK_HBM_TBS
+        ach = tot / (us * 1e-6) / (1e12 if bound == "mfma" else 1e9)       # TFLOP/s or GB/s (the units the bench contract names)
+        peak = PEAK_F64_TF if bound == "mfma" else PEAK_HBM_TBS * 1e3
         kernels[name] = {"bound": bound, "algorithmic_%s_per_launch" % ("flops" if bound == "mfma" else "bytes"): tot, "avg_launch_us": us,
-                         "achieved": ach, "unit": "TFLOP/s" if bound == "mfma" else "TB/s", "frac": ach / peak}
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": ach / peak}
         if name in pmc and "mfma_busy" in pmc[name]:
             kernels[name]["mfma_busy_pmc"] = pmc[name]["mfma_busy"]
         if name == "k_schur":      # issued: the 16 x 16 x 64 tile pairs the compact panels multiply (counted on these windows' track histogram)
@@ -396,11 +396,11 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
     alg_bytes = 108.0 * units_per_launch                                   # the fused form's 12 f64 + 3 i32 per factor
     hbm_tbs = alg_bytes / (lin_ms * 1e-3) / 1e12
     return {"bound": "hbm", "kernel": "k_vis<0, %s> (visual evaluate + linearise + fused [Y r]^T [Y r]; first iteration: all windows active)" % ("full 20-column panel" if full_panel else "7 x 7 panel, both rows of a factor in one 16-wide tile"),
-            "achieved": hbm_tbs, "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": hbm_tbs / PEAK_HBM_TBS,
+            "achieved": hbm_tbs * 1e3, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": hbm_tbs / PEAK_HBM_TBS,
             "why_hbm": "round 4 halved the kernel's matrix-core work and cut its vector instructions by 40 %: its own traffic (moved_bytes_by_construction, "
                        "~126 B per factor, against SURVEY 8d's algorithmic 108 B) over its launch time is now nearer the HBM roof than its matrix-core "
                        "flops are to theirs (mfma_view)",
-            "moved_bytes_by_construction": moved, "moved_TBps": moved / (lin_ms * 1e-3) / 1e12, "moved_frac_of_hbm_peak": moved / (lin_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+            "moved_bytes_by_construction": moved, "moved_GBps": moved / (lin_ms * 1e-3) / 1e9, "moved_frac_of_hbm_peak": moved / (lin_ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
             "mfma_view": {"achieved_issued": achieved_tf, "peak": PEAK_F64_TF, "unit": "TFLOP/s", "frac_issued": achieved_tf / PEAK_F64_TF,
                           "frac_useful": achieved_tf / PEAK_F64_TF * useful / issued,
                           "flops_per_factor": {"issued": issued, "useful": useful, "round3_13_column_panel_issued": 1024.0, "survey_8d_full_panel": 1600.0},
