@@ -370,9 +370,13 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
         # k_visasm (the profile name stays k_assemble; k_visblock is part of it since round 3): reads the filled entries of the tiles'
         # X^T X partials into the 73 x 74 visual block (LDS), the inertial / wheel / prior partials and the four start-frame-group
         # Schur partials; writes H (lower), g, E, eg
-        "k_assemble": ("hbm", 8.0 * (tiles * 10 * (336 if full_panel else 157) * 0.5 + 10 * 932 + 10 * 508 + pn * pn + 4 * 15 * 256 + 187 * 188 / 2 + 187 + 73 * 73 + 73)),
-        # k_lm_step: per landmark its H_pl row, Hll, gl, scale, lambda in; y_l, v_l out
-        "k_lm_step": ("hbm", 8.0 * (L * (13 + 5) + 6.0 * K1 + 2 * L)),
+        # (round 4, constant extrinsic / td: 28-double [Y r]^T [Y r] partials, the lower triangles of the factors' J^T J, the 7.6k entries of
+        #  H the compact assembly table reaches instead of the 17.6k of the lower triangle)
+        "k_assemble": ("hbm", 8.0 * ((tiles * 10 * 336 * 0.5 + 10 * 932 + 10 * 508 + pn * pn + 4 * 15 * 256 + 187 * 188 / 2 + 187 + 73 * 73 + 73) if full_panel else
+                                     (tiles * 10 * 28 * 0.5 + 10 * 497 + 10 * 277 + pn * pn + 4 * 15 * 256 + 7600 + 187 + 73 * 73 + 73))),
+        # k_lm_step: per landmark its row ([D | x] of the compressed rows, or the 13-wide block), Hll, gl, scale, lambda in, per factor d
+        # (3 doubles; 6 with the full panel); y_l, v_l out
+        "k_lm_step": ("hbm", 8.0 * ((L * (13 + 5) + 6.0 * K1 + 2 * L) if full_panel else (L * (6 + 5) + 3.0 * K1 + 2 * L))),
     }
     kernels = {}
     for name, (bound, per_window) in work.items():
