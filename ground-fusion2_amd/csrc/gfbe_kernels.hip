@@ -31,6 +31,9 @@ namespace gfd {
 #ifndef GFBE_KVIS_EARLY
 #define GFBE_KVIS_EARLY 1   // k_vis: the prefetched observation of the next step is waited for BEFORE this step's stores are issued
 #endif
+#ifndef GFBE_ASM_U
+#define GFBE_ASM_U 4       // k_visasm: entries of H a thread has in flight
+#endif
 #ifndef GFBE_DENSE_TP
 #define GFBE_DENSE_TP 1    // throughput batches: k_dense_tp (matrix-core whitening / J^T J, four windows per workgroup) instead of k_dense<false>
 #endif
@@ -1817,6 +1820,60 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
   // T_f(p, a): a < 3: delta(p, a); a >= 3: sTf[f][3 p + a - 3]
   auto Mat = [](const double *M, int pp, int qq) { const int lo = min(pp, qq), hi = max(pp, qq); return M[7 * lo - lo * (lo - 1) / 2 + hi - lo]; };
   constexpr int NC66 = NF * 6;
+  if (!ROW) {
+    // One workgroup for the whole block (k_visasm): a thread per COLUMN of a 6 x 6 block instead of a thread per entry. The entry-wise
+    // loop below evaluated sum_pp T_a(pp) (sum_qq M(pp, qq) T_b(qq)) from scratch for every entry, four kinds of entries side by side in
+    // a wave and the packed index of M computed per access: ~3 800 vector instructions per wave, which is what bounded the kernel
+    // (PMC: 62 M per launch of 2048 windows, no matrix-core work, the memory pipes idle half of the time). Here M's 21 entries
+    // sit in registers, P = M T_b(:, lb) is formed once per column (36 multiply-adds) and its six rows finished from it (18): the
+    // same products added in the same order, entry for entry — bit-identical to the loop below, which the small batches keep.
+    for (int pass = 0; pass < 2; pass++) {          // pass 0: the columns lb = 3..5 (through T_b), pass 1: lb = 0..2 (T_b = identity there)
+      for (int u = t; u < NF * NF * 3; u += NT) {
+        const int blk = u / 3, jc = u - 3 * blk, fa = blk / NF, fb = blk - NF * fa;
+        const double *M = fa == fb ? sS[fa] : sM[min(fa, fb) * (2 * NF - 1 - min(fa, fb)) / 2 + max(fa, fb) - min(fa, fb) - 1];
+        double P[6];
+        if (pass == 0) {
+          double m[6][6], tb[6];
+#pragma unroll
+          for (int pp = 0; pp < 6; pp++) {
+            tb[pp] = sTf[fb][3 * pp + jc];
+#pragma unroll
+            for (int qq = pp; qq < 6; qq++) { m[pp][qq] = M[7 * pp - pp * (pp - 1) / 2 + qq - pp]; m[qq][pp] = m[pp][qq]; }
+          }
+#pragma unroll
+          for (int pp = 0; pp < 6; pp++) {
+            double row = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < 6; qq++) row = __builtin_fma(m[pp][qq], tb[qq], row);
+            P[pp] = row;
+          }
+        } else {
+#pragma unroll
+          for (int pp = 0; pp < 6; pp++) P[pp] = Mat(M, pp, jc);
+        }
+        const int b = 6 * fb + (pass == 0 ? 3 : 0) + jc;
+        const bool neg = fa != fb;
+#pragma unroll
+        for (int la = 0; la < 3; la++) out[(6 * fa + la) * ld + b] = neg ? -P[la] : P[la];
+#pragma unroll
+        for (int la = 3; la < 6; la++) {
+          double z = 0.0;
+#pragma unroll
+          for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], P[pp], z);
+          out[(6 * fa + la) * ld + b] = neg ? -z : z;
+        }
+      }
+    }
+    for (int a = t; a < NC66; a += NT) {          // the gradient column
+      const int fa = a / 6, la = a - 6 * fa;
+      const double *M = sS[fa];
+      double z = 0.0;
+      if (la < 3) z = Mat(M, la, 6);
+      else for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, 6), z);
+      out[a * ld + NV] = z;
+    }
+    return;
+  }
   for (int q = t; q < (ROW ? 6 : NC66) * (NC66 + 1); q += NT) {
     const int ar = q / (NC66 + 1), b = q - ar * (NC66 + 1), a = ROW ? 6 * frow + ar : ar;     // b == 66: the gradient column
     const int fa = a / 6, la = a - 6 * fa;
@@ -2179,7 +2236,7 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
   asm_stage_tables(d, w, tb);
   __syncthreads();
   const AsmCommon cm = asm_common(d, w);
-  asm_H<4, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);     // (k_visasm: throughput batches, the visual block in the caller's LDS)
+  asm_H<GFBE_ASM_U, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);     // (k_visasm: throughput batches, the visual block in the caller's LDS)
   asm_E(d, w, tb, cm, gt, gn);
   asm_g(d, w, vis_w, tb, cm, gt, gn);
 }

@@ -16,6 +16,9 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "schurabs": (["-DGFBE_SCHUR_COMPACT=0"], "off"),
     "kvis3": (["-DGFBE_KVIS_WAVES=3"], "off"),
     "densetp0": (["-DGFBE_DENSE_TP=0"], "off"),
+    "asmu6": (["-DGFBE_ASM_U=6"], "off"),
+    "asmu8": (["-DGFBE_ASM_U=8"], "off"),
+    "asmu2": (["-DGFBE_ASM_U=2"], "off"),
     "cand512": (["-DCAND_THREADS=512"], "off"),
     "cand1024": (["-DCAND_THREADS=1024"], "off"),
     "schur3": (["-DGFBE_SCHUR_WGS=3", "-DHS_LD=83"], "off"),
