@@ -1769,6 +1769,13 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
   __shared__ double sTf[NF][18];                         // per frame: [P_f - c]x R_f (9) | -R_f (9)
   const int t = threadIdx.x;
   const double *Z = d.zero;
+#if GFBE_DIAG
+  double *vstamp = d.timing + (size_t)d.B * 32 + 24;     // phase stamps of window 0 in k_visasm (gfbe_debug_timing(batch, B): slots 24..31)
+#define VSTAMP(i) do { if (!ROW && w == 0 && t == 0) vstamp[i] = (double)wall_clock64(); } while (0)
+#else
+#define VSTAMP(i) do { } while (0)
+#endif
+  VSTAMP(0);
   {
     const double *pcw = d.pc + ((size_t)w * 3 + c.cur) * NPAIR * PC_DOUBLES;
     const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
@@ -1786,6 +1793,14 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
     }
     const double *vpy = d.vis_part + (size_t)w * d.max_tiles * MAXOBS * VPY_STRIDE;
     const int npair = ROW ? NF - 1 : NF * (NF - 1) / 2;
+    // (one workgroup per window: the tiles' longest tracks — which steps a tile ran — staged once instead of a dependent load in
+    //  front of every round of partials; a window with more tiles than the table holds keeps the direct loads)
+    __shared__ unsigned char s_tile_m[ROW ? 1 : 256];
+    const bool staged_m = !ROW && ds.n_tiles <= 256;
+    if (staged_m) {
+      for (int tt = t; tt < ds.n_tiles; tt += NT) s_tile_m[tt] = TILE_OWNED(d, tt) ? (unsigned char)((d.lm_info[ds.lm_off + tt * LM_TILE] >> 8) & 0xff) : 0;
+      __syncthreads();
+    }
     for (int q = t; q < npair * VPY; q += NT) {
       const int pq = q / VPY, en = q - pq * VPY;
       int i, k;
@@ -1797,7 +1812,8 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
         double v[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const bool on = tt + u < t1 && TILE_OWNED(d, tt + u) && k < ((d.lm_info[ds.lm_off + (tt + u) * LM_TILE] >> 8) & 0xff);
+          const bool on = tt + u < t1 && (staged_m ? k < (int)s_tile_m[min(tt + u, 255)]
+                                                        : TILE_OWNED(d, tt + u) && k < ((d.lm_info[ds.lm_off + (tt + u) * LM_TILE] >> 8) & 0xff));
           v[u] = *(on ? vpy + ((size_t)(tt + u) * MAXOBS + k) * VPY_STRIDE + en : Z);
         }
 #pragma unroll
@@ -1807,6 +1823,7 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
     }
   }
   __syncthreads();
+  VSTAMP(1);
   // S_f: entries of the 6 x 6 block summed over both roles of the frame; the r-column (packed entries (p, 6)) with the sign of the role
   for (int q = t; q < (ROW ? 1 : NF) * VPY; q += NT) {
     const int f = ROW ? frow : q / VPY, en = ROW ? q : q - f * VPY;
@@ -1817,6 +1834,7 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
     sS[f][en] = sum;
   }
   __syncthreads();
+  VSTAMP(2);
   // T_f(p, a): a < 3: delta(p, a); a >= 3: sTf[f][3 p + a - 3]
   auto Mat = [](const double *M, int pp, int qq) { const int lo = min(pp, qq), hi = max(pp, qq); return M[7 * lo - lo * (lo - 1) / 2 + hi - lo]; };
   constexpr int NC66 = NF * 6;
@@ -1872,6 +1890,7 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
       else for (int pp = 0; pp < 6; pp++) z = __builtin_fma(sTf[fa][3 * pp + la - 3], Mat(M, pp, 6), z);
       out[a * ld + NV] = z;
     }
+    VSTAMP(3);
     return;
   }
   for (int q = t; q < (ROW ? 6 : NC66) * (NC66 + 1); q += NT) {
@@ -1901,6 +1920,7 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
     out[a * ld + b] = fa == fb ? z : -z;
   }
 }
+#undef VSTAMP
 
 template <bool SPLIT, bool KEEP, bool DUAL>
 __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, const int i_first, const int i_last, const int sgrp, double *V) {
@@ -2199,12 +2219,18 @@ __device__ __forceinline__ void asm_H(const BatchDev &d, const int w, const doub
 // E (73 x 73, symmetric): entries gt, gt + gn, ... of its triangle
 __device__ __forceinline__ void asm_E(const BatchDev &d, const int w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
   ASM_UNPACK(cm);
-  for (int e = gt; e < NV * (NV + 1) / 2; e += gn) {
-    int a, b;
-    tri_decode(e, a, b);
-    const double ev = (tb.act[a] && tb.act[b]) ? gather_E11(d, Z, w, b, a) : 0.0;
-    E[a * NV + b] = ev;
-    E[b * NV + a] = ev;
+  // (two entries per round: eight loads of the Schur partials in flight; a thread of k_visasm has five or six entries)
+  constexpr int NE = NV * (NV + 1) / 2;
+  for (int e = gt; e < NE; e += 2 * gn) {
+    int a0, b0, a1 = 0, b1 = 0;
+    tri_decode(e, a0, b0);
+    const bool two = e + gn < NE;
+    if (two) tri_decode(e + gn, a1, b1);
+    const double g0 = gather_E11(d, Z, w, b0, a0), g1 = gather_E11(d, Z, w, b1, a1);      // (unconditional: selected below)
+    const double ev0 = (tb.act[a0] && tb.act[b0]) ? g0 : 0.0, ev1 = (two && tb.act[a1] && tb.act[b1]) ? g1 : 0.0;
+    E[a0 * NV + b0] = ev0;
+    E[b0 * NV + a0] = ev0;
+    if (two) { E[a1 * NV + b1] = ev1; E[b1 * NV + a1] = ev1; }
   }
 }
 // g and eg: dims gt, gt + gn, ...
@@ -2233,12 +2259,23 @@ __device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const doub
   }
 }
 __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, const double *vis_w, AsmTab &tb, const int gt, const int gn) {
+#if GFBE_DIAG
+  double *astamp = d.timing + (size_t)d.B * 32 + 24;
+#define ASTAMP(i) do { if (w == 0 && gt == 0) astamp[i] = (double)wall_clock64(); } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
   asm_stage_tables(d, w, tb);
   __syncthreads();
+  ASTAMP(4);
   const AsmCommon cm = asm_common(d, w);
   asm_H<GFBE_ASM_U, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);     // (k_visasm: throughput batches, the visual block in the caller's LDS)
+  ASTAMP(5);
   asm_E(d, w, tb, cm, gt, gn);
+  ASTAMP(6);
   asm_g(d, w, vis_w, tb, cm, gt, gn);
+  ASTAMP(7);
+#undef ASTAMP
 }
 // small batches (a single window's latency): the visual blocks come from k_visblock_small, and every thread has ONE item — the
 // workgroups [0, nH) take an entry of H each (the table entry is fetched before the descriptor tables are staged), the next

@@ -20,7 +20,8 @@ b.solve(abi.MARGIN_OLD); b.solve(abi.MARGIN_OLD)
 t = b.debug_timing(0)
 print("B=%d k_schur WG(0,0): first prefetch %.2f us, first LDS stage %.2f us, all %d tiles %.2f us (%.2f us per tile), shader clock %.0f MHz" %
       (B, (t[9] - t[8]) * 0.01, (t[10] - t[9]) * 0.01, int(t[12]), (t[11] - t[8]) * 0.01, (t[11] - t[8]) * 0.01 / max(t[12], 1), (t[14] - t[13]) / ((t[11] - t[8]) * 0.01)))
-te = [0.0] * 32
+te = b.debug_timing(B)
+print("k_visasm, window 0 (thread 0): gather partials %.2f us, S_f %.2f, T^T M T %.2f, (barrier +) stage tables %.2f, H entries %.2f, E %.2f, g %.2f; total %.2f us" % tuple([(te[24 + i + 1] - te[24 + i]) * 0.01 for i in range(7)] + [(te[31] - te[24]) * 0.01]))
 be.profile_enable(True); be.profile_reset()
 for _ in range(3):
     b.solve(abi.MARGIN_OLD)
