@@ -20,7 +20,7 @@ python $R/profiles/summarize_rocpd.py /tmp/prof_single/*/*_results.db $R/gpurun_
 cd $R
 python tools/diag_single.py 2>&1 | tail -3 | tee -a gpurun_out/r4_single.log
 python tools/diag_scripts/gnss_prof.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4_gnss_window_profile.txt; head -3 gpurun_out/r4_gnss_window_profile.txt
-cd /tmp; rm -rf /tmp/pe; B=1024 DEPTH=3 STEPS=10 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/pe -- python $R/tools/diag_e2e.py > /tmp/pe.log 2>&1; grep -v "rocprofv3\|amdgpu.ids" /tmp/pe.log | tail -1 > $R/gpurun_out/r4_e2e.log
+cd /tmp; rm -rf /tmp/pe; B=1024 DEPTH=3 STEPS=10 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/pe -- python $R/tools/diag_e2e.py > /tmp/pe.log 2>&1; grep "e2e host-fed" /tmp/pe.log > $R/gpurun_out/r4_e2e.log
 python $R/profiles/summarize_rocpd.py /tmp/pe/*/*_results.db $R/gpurun_out/r4_e2e_trace.txt | head -8; cat $R/gpurun_out/r4_e2e.log
 cd $R
 NEW=250 python tools/diag_stream_frame_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r4_stream_frame_time.txt; tail -12 gpurun_out/r4_stream_frame_time.txt
