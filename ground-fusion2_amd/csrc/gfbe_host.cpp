@@ -176,6 +176,9 @@ struct gfbe_batch {
   // the first, so that kernels of different stages (e.g. the 1-workgroup-per-CU k_solve of one half and the visual
   // kernels of the other) share the GPU. Measured +13 % at 256 windows; four groups are host-launch-bound.
   gfbe_batch *second = nullptr;
+  // (head of a split batch only) the parts hold the windows sorted by size, see upload_halves: order[k] = the caller's index of the
+  // window at position k of the chain of parts, place[i] = the position of the caller's window i; empty: identity
+  std::vector<int> order, place;
   Lane lane2 = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_start2 = nullptr, ev_done2 = nullptr;
 };
@@ -1115,7 +1118,28 @@ static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *cons
   if (B >= BATCH_SPLIT_MIN_B && !c->allreduce && c->opt.split_batch) {
     if (c->opt.split_batch < 0) { c->err = "gfbe_options.split_batch must be >= 0"; return GFBE_BAD_INPUT; }
     parts = c->opt.split_batch == 1 ? (B >= 2048 ? 4 : 1) : c->opt.split_batch;
+    // (measured: a heterogeneous batch of 256 windows as four size classes of 64: 30.1k solves/s against 60.9k whole — parts that small
+    //  do not fill the GPU; from 2048 windows on the parts exist anyway and are made size classes below)
     parts = std::max(1, std::min(std::min(parts, (int)MAX_BATCH_PARTS), std::max(B / DENSE_SPLIT_MIN_B, 1)));   // (every part beyond the first owns a pair of streams)
+  }
+  // A part's kernels are launched for its LARGEST window (landmark tiles per window: the grids of k_vis / k_lm_step / k_schur), and
+  // the parts run side by side: with the windows of a heterogeneous batch sorted by their number of visual factors, every part's
+  // grid fits its own windows instead of the batch's largest one. A window's result does not depend on its place or its
+  // neighbours (tests/test_gpu_parity.py::test_large_batch_throughput_path), so the order is the library's to choose; results go
+  // back to the caller's places (download_one). Host-fed batches only (a table-fed window is tied to its table's index).
+  std::vector<int> order;
+  std::vector<const gfbe_window *> sorted;
+  if (parts > 1 && !tabs) {
+    int kmin = INT32_MAX, kmax = 0;
+    for (int w = 0; w < B; w++) { if (!wins[w]) { kmin = kmax = 0; break; } kmin = std::min(kmin, (int)wins[w]->vis.n_factor); kmax = std::max(kmax, (int)wins[w]->vis.n_factor); }
+    if (kmax > kmin + kmin / 8) {       // (a homogeneous batch stays as it is)
+      order.resize(B);
+      for (int w = 0; w < B; w++) order[w] = w;
+      std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return wins[a]->vis.n_factor > wins[b]->vis.n_factor; });
+      sorted.resize(B);
+      for (int k = 0; k < B; k++) sorted[k] = wins[order[k]];
+      wins = sorted.data();
+    }
   }
   gfbe_batch **link = out;
   gfbe_batch *prev = nullptr;
@@ -1130,7 +1154,12 @@ static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *cons
     link = &prev->second;
     done += n;
   }
-  if (st != GFBE_OK) { gfbe_batch_free(c, *out); *out = nullptr; }
+  if (st != GFBE_OK) { gfbe_batch_free(c, *out); *out = nullptr; return st; }
+  if (!order.empty()) {
+    (*out)->place.resize(B);
+    for (int k = 0; k < B; k++) (*out)->place[order[k]] = k;
+    (*out)->order = std::move(order);
+  }
   return st;
 }
 
@@ -1158,6 +1187,7 @@ extern "C" gfbe_status gfbe_batch_upload_tables(gfbe_ctx *c, gfbe_ftab *t, int32
 
 extern "C" int32_t gfbe_batch_feature_count(const gfbe_batch *b, int32_t w) {
   if (w < 0) return -1;
+  if (b && !b->place.empty()) { if (w >= (int)b->place.size()) return -1; w = b->place[w]; }
   for (; b; b = b->second) {
     if (w < (int)b->L.size()) return b->L[w];
     w -= (int)b->L.size();
@@ -1394,8 +1424,9 @@ static gfbe_status fetch_one(gfbe_ctx *c, gfbe_batch *b) {
   HIPCHK(c, hipEventRecord(b->ev_dl, ds));
   return GFBE_OK;
 }
+// out_* are the caller's arrays; window w of this part is the caller's window order[first + w] (or first + w)
 static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_state, double *const *out_feature,
-                                gfbe_prior *const *prior_out, gfbe_summary *summary) {
+                                gfbe_prior *const *prior_out, gfbe_summary *summary, const int first, const int *order) {
   const BatchDev &d = b->d;
   const int B = d.B;
   HIPCHK(c, hipEventSynchronize(b->ev_dl));
@@ -1412,15 +1443,16 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
     status[w] = k.status;
     const int *m = (const int *)(f + DL_OFF_META);
     double dl_bytes = 8.0 * DL_FIX + 8.0 * b->L[w];
-    if (out_state) std::memcpy(out_state + w, f + DL_OFF_X, sizeof(double) * NA);
-    if (out_feature && out_feature[w] && b->L[w] > 0) std::memcpy(out_feature[w], feat + b->feat_off[w], sizeof(double) * b->L[w]);
+    const int cw = order ? order[first + w] : first + w;      // the caller's index
+    if (out_state) std::memcpy(out_state + cw, f + DL_OFF_X, sizeof(double) * NA);
+    if (out_feature && out_feature[cw] && b->L[w] > 0) std::memcpy(out_feature[cw], feat + b->feat_off[w], sizeof(double) * b->L[w]);
     // the prior is only touched when a marginalisation ran for this window (estimator.cpp:3391: a window that is still filling
     // up, or MARGIN_NONE, leaves last_marginalization_info as it is)
-    if (prior_out && prior_out[w] && b->last_flag == GFBE_MARGIN_SECOND_NEW && b->anchor_only[w]) {
+    if (prior_out && prior_out[cw] && b->last_flag == GFBE_MARGIN_SECOND_NEW && b->anchor_only[w]) {
       // estimator.cpp:3622-3632 (see upload_one): the invalid prior is replaced by a valid, empty one
-      prior_out[w]->valid = 1; prior_out[w]->n = 0; prior_out[w]->n_blocks = 0;
-    } else if (prior_out && prior_out[w] && b->last_flag != GFBE_MARGIN_NONE && k.marg_ran) {
-      gfbe_prior *p = prior_out[w];
+      prior_out[cw]->valid = 1; prior_out[cw]->n = 0; prior_out[cw]->n_blocks = 0;
+    } else if (prior_out && prior_out[cw] && b->last_flag != GFBE_MARGIN_NONE && k.marg_ran) {
+      gfbe_prior *p = prior_out[cw];
       p->valid = m[0] == 1 ? 1 : 0; p->n = m[1]; p->n_blocks = m[2];
       if (p->valid) {
         int xo = 0;
@@ -1435,7 +1467,7 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
       }
     }
     if (summary) {
-      gfbe_summary &s = summary[w];
+      gfbe_summary &s = summary[cw];
       std::memset(&s, 0, sizeof s);
       s.status = k.status; s.iterations = k.iter; s.num_successful = k.num_successful; s.termination = k.termination;
       s.initial_cost = k.initial_cost; s.final_cost = k.cost; s.final_radius = k.radius;
@@ -1466,8 +1498,7 @@ extern "C" gfbe_status gfbe_batch_download(gfbe_ctx *c, gfbe_batch *b, gfbe_stat
   gfbe_status worst = GFBE_OK;
   int done = 0;
   for (gfbe_batch *p = b; p; p = p->second) {
-    const gfbe_status st = download_one(c, p, out_state ? out_state + done : nullptr, out_feature ? out_feature + done : nullptr,
-                                        prior_out ? prior_out + done : nullptr, summary ? summary + done : nullptr);
+    const gfbe_status st = download_one(c, p, out_state, out_feature, prior_out, summary, done, b->order.empty() ? nullptr : b->order.data());
     if (st > GFBE_NO_CONVERGENCE) return st;
     if (st > worst) worst = st;
     done += p->d.B;
@@ -1635,6 +1666,7 @@ extern "C" gfbe_status gfbe_preintegrate_wheel(gfbe_ctx *c, int32_t n, const int
 
 // diagnostics: copy the k_solve phase stamps of window w (32 doubles, 10 ns ticks)
 extern "C" gfbe_status gfbe_debug_timing(gfbe_ctx *c, gfbe_batch *b, int32_t w, double *out32) {
+  if (b && !b->place.empty() && w >= 0 && w < (int)b->place.size()) w = b->place[w];      // (a split batch holds its windows sorted by size)
   if (b && b->second && w > b->d.B) return gfbe_debug_timing(c, b->second, w - b->d.B, out32);
   if (!c || !b || !out32 || w < 0 || w > b->d.B) return GFBE_BAD_INPUT;   // (w == B: the extra block of the first part)
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1643,7 +1675,7 @@ extern "C" gfbe_status gfbe_debug_timing(gfbe_ctx *c, gfbe_batch *b, int32_t w, 
 }
 extern "C" gfbe_status gfbe_debug_vector(gfbe_ctx *c, gfbe_batch *b, int32_t w, int32_t which, double *out) {
   if (!c || !b || !out || which < 0 || (which > 3 && !(which >= 1000 && which < 1000 + ND) && !(which >= 2000 && which <= 2000 + NV))) return GFBE_BAD_INPUT;
-  int off = w;
+  int off = (!b->place.empty() && w >= 0 && w < (int)b->place.size()) ? b->place[w] : w;
   gfbe_batch *p = b;
   while (p && off >= p->d.B) { off -= p->d.B; p = p->second; }
   if (!p || off < 0) return GFBE_BAD_INPUT;

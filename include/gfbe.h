@@ -603,6 +603,8 @@ gfbe_status gfbe_solve_batch(gfbe_ctx *ctx, int32_t n_window, const gfbe_window 
                              gfbe_prior *const *prior_out, gfbe_summary *summary);
 
 /* Device-resident form used for throughput measurement: upload once, (re)solve many times.
+ *   (Window order: outputs and gfbe_batch_feature_count always use the caller's indices; inside, a batch that is solved in parts
+ *   holds its windows sorted by size — a window's result does not depend on its place.)
  *   gfbe_batch_upload   packs the windows into pinned staging memory and ENQUEUES one host-to-device copy plus the
  *                       preparation kernels on the context's private copy stream. It returns when the
  *                       caller's gfbe_window structures have been read — they may be reused at once — but the copy may still

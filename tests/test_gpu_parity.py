@@ -357,3 +357,33 @@ def test_factor_blocks_bit_identical_to_host_build(be):
             # suite pins against the oracle (tests/test_device_math_host.py) IS what the GPU computes
             for k in ("imu_r", "imu_J", "wheel_r", "wheel_J", "vis_r", "vis_J"):
                 assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), k
+
+
+def test_split_batch_sorts_its_windows_by_size_and_returns_them_in_place(oracle):
+    """A batch that is solved as several parts side by side holds its windows sorted by their number of visual factors (every
+    part's grids then fit its own windows, gfbe_host.cpp::upload_halves); results, landmark counts and priors come back at the
+    caller's places: 160 windows of five sizes in a shuffled order, four parts, against the same batch solved as ONE part — the
+    same kernels, so bit for bit."""
+    rng = np.random.default_rng(5)
+    kinds = [synth.Scenario(seed=170 + k, n_landmarks=60 + 70 * k, use_wheel=bool(k % 2)).window(0) for k in range(5)]
+    pick = rng.integers(0, 5, 160)
+    snaps = [kinds[int(i)] for i in pick]
+    o1, o4 = abi.default_options(), abi.default_options()
+    o1.split_batch, o4.split_batch = 0, 4
+    one, four = gf.Backend(device=0, options=o1), gf.Backend(device=0, options=o4)
+    want = one.solve_batch(snaps, abi.MARGIN_OLD)
+    batch = four.batch_upload(snaps)
+    batch.solve(abi.MARGIN_OLD)
+    got = batch.download()
+    for i in range(len(snaps)):
+        assert four.lib.gfbe_batch_feature_count(batch.h, i) == len(snaps[i]["para_feature"])
+    batch.free()
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert len(b["feature"]) == len(snaps[i]["para_feature"])
+        assert a["summary"] == b["summary"]
+        np.testing.assert_array_equal(a["state"]["pose"], b["state"]["pose"])
+        np.testing.assert_array_equal(a["state"]["speed_bias"], b["state"]["speed_bias"])
+        np.testing.assert_array_equal(a["feature"], b["feature"])
+        np.testing.assert_array_equal(a["prior"]["J0"], b["prior"]["J0"])
+        assert a["prior"]["block_id"].tolist() == b["prior"]["block_id"].tolist()
+    one.close(); four.close()
