@@ -31,6 +31,9 @@ namespace gfd {
 #ifndef GFBE_KVIS_EARLY
 #define GFBE_KVIS_EARLY 1   // k_vis: the prefetched observation of the next step is waited for BEFORE this step's stores are issued
 #endif
+#ifndef GFBE_FUSE_CAND
+#define GFBE_FUSE_CAND 1   // throughput batches: the landmark half of k_candidate at the head of the cost pass (k_vis<1>)
+#endif
 #ifndef GFBE_ASM_U
 #define GFBE_ASM_U 4       // k_visasm: entries of H a thread has in flight
 #endif
@@ -678,11 +681,21 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   }
 }
 
+__device__ __forceinline__ void candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
 template <int MODE, bool FULL>
 __global__ __launch_bounds__(LM_TILE, (MODE == 0 && !FULL) ? GFBE_KVIS_WAVES : 2) void k_vis(BatchDev d, int write_records) {
   // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
   // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
-  vis_body<MODE, FULL>(d, write_records, blockIdx.x, blockIdx.y);
+  if (MODE == 1 && write_records) {
+    // (the cost pass of a throughput batch, write_records = 1: the tile first forms the candidate inverse depths of its landmarks —
+    //  the landmark half of k_candidate, the same 64 lanes and the same sums; k_candidate_dense has formed the candidate's dense
+    //  blocks and pair constants before. A launch of its own walked a window's tiles four at a time: 115 us per 2048 windows.)
+    const int w = blockIdx.x, tile = blockIdx.y;
+    const WinDesc &ds = d.desc[w];
+    const WinCtl &c = d.ctl[w];
+    if (tile < ds.n_tiles && TILE_OWNED(d, tile) && !c.done && c.have_step) candidate_tile(d, ds, c, w, tile, threadIdx.x);
+  }
+  vis_body<MODE, FULL>(d, MODE == 1 ? 0 : write_records, blockIdx.x, blockIdx.y);
 }
 
 // =============================================================================================
@@ -2631,10 +2644,17 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
 // (a wave per tile, the per-tile sums by the same 64 lanes as in k_candidate: the same bits). The tiles + 1 single-wave workgroups
 // per window of k_candidate are 37 k dispatches of a few hundred nanoseconds of work each per launch of 1024 windows.
 #ifndef CAND_THREADS
-#ifndef CAND_THREADS
 #define CAND_THREADS 256   // (512 / 1024 measured: 36 / 49 us per launch over 512 windows against 41, throughput -1 % / -4 %)
 #endif
-#endif
+// the dense half alone (throughput batches, GFBE_FUSE_CAND: the landmark half runs at the head of the cost pass, k_vis<1>)
+__global__ __launch_bounds__(LM_TILE) void k_candidate_dense(BatchDev d) {
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  const WinCtl &c = d.ctl[w];
+  if (c.done || !c.have_step) return;
+  __shared__ PoseRT sp_cand[NF + 1];
+  candidate_dense(d, ds, c, w, threadIdx.x, sp_cand, true);
+}
 __global__ __launch_bounds__(CAND_THREADS) void k_candidate_window(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
@@ -3015,7 +3035,7 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
   // (reduced panel: only when the camera extrinsic and td are constant in EVERY window of the batch and no records are asked for)
   if (mode == 0 && (d.vis_full || write_records)) hipLaunchKernelGGL((k_vis<0, true>), g, b, 0, s, d, write_records);
   else if (mode == 0) hipLaunchKernelGGL((k_vis<0, false>), g, b, 0, s, d, 0);
-  else if (mode == 1) hipLaunchKernelGGL((k_vis<1, true>), g, b, 0, s, d, 0);
+  else if (mode == 1) hipLaunchKernelGGL((k_vis<1, true>), g, b, 0, s, d, (d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND) ? 1 : 0);   // (1: the tiles form their candidate inverse depths first)
   else if (d.B < DENSE_SPLIT_MIN_B) hipLaunchKernelGGL((k_vis_split<2, true>), dim3(d.B, d.max_tiles * LIN_SMALL_KS), b, 0, s, d, write_records);
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
@@ -3106,7 +3126,8 @@ void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse) {
 }
 void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
 void launch_candidate(const BatchDev &d, hipStream_t s) {
-  if (d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_candidate_window, dim3(d.B), dim3(CAND_THREADS), 0, s, d);
+  if (d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND && d.max_tiles > 0) hipLaunchKernelGGL(k_candidate_dense, dim3(d.B), dim3(LM_TILE), 0, s, d);
+  else if (d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_candidate_window, dim3(d.B), dim3(CAND_THREADS), 0, s, d);
   else hipLaunchKernelGGL(k_candidate, dim3(d.max_tiles + 1, d.B), dim3(LM_TILE), 0, s, d);
 }
 void launch_accept(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_accept, dim3(d.B), dim3(64), 0, s, d); }
