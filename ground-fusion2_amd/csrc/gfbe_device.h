@@ -162,6 +162,7 @@ struct WinDesc {
   int lm_off;                // first landmark slot of this window in the per-landmark arrays (64-aligned)
   int lm_slots;              // padded landmark slots (multiple of LM_TILE; start-frame groups are tile aligned)
   int rec_off;               // first visual record
+  int vel_off;               // compact observation upload (BatchDev::obs_compact): first entry of fvel (the records of start frame 0 come first)
   int n_tiles;               // lm_slots / LM_TILE
   int tile_off;              // first entry of this window in tile_start[] (start frame of each tile)
   int n_imu, n_wheel;
@@ -230,6 +231,8 @@ struct BatchDev {
   double *lm_pts;             // [6][tot_lm]: pix piy piz vix viy td_i
   double *lm_obs;             // [MAXOBS][5][tot_lm]: pjx pjy vjx vjy td_j
   int *lm_rec;                // [MAXOBS][tot_lm]: record position (relative to rec_off) of factor k
+  double *fvel;               // [.][3] compact observation upload: vjx vjy td_j of the factors whose landmark starts in frame 0 (WinDesc::vel_off)
+  int obs_compact;            // 1: fobs is [tot_rec][2] — the observations already shifted to the window's td by the host (upload_one)
   double *fobs;               // [tot_rec][5] host upload only: pjx pjy vjx vjy td_j of every factor in record (pair-major) order; k_expand
                               // scatters them into lm_obs / lm_rec (the ELL rows never cross PCIe: 40 B per factor instead of ~100)
   double *lam0, *lam;         // [tot_lm], [2][tot_lm]

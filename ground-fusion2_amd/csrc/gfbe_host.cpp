@@ -703,6 +703,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<int> tile_start;
   std::vector<int> feat_off(B + 1, 0);
   std::vector<long long> j0_off(B + 1, 0);
+  int tot_n0 = 0;
   int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0, tot_gnss = 0, any_gnss = 0, gnss_dims = 0, gnss_max = 0, marg_nmax = 0;
   double algo_bytes = 0.0;
   for (int w = 0; w < B; w++) {
@@ -713,6 +714,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     ds.L = sc.L; ds.K = sc.K; ds.frame_count = win.frame_count;
     ds.lm_off = tot_lm; ds.lm_slots = sc.slots; ds.n_tiles = sc.n_tiles; ds.tile_off = (int)tile_start.size();
     ds.rec_off = tot_rec;
+    ds.vel_off = tot_n0;
+    tot_n0 += tabs ? 0 : sc.pair_begin[NF];      // (records of the pairs (0, j): pair index i * NF + j, i-major)
     for (int s = 0; s < NF; s++) for (int t = sc.sf_tile_begin[s]; t < sc.sf_tile_begin[s + 1]; t++) tile_start.push_back(s);
     if (tabs) tlayout[(size_t)w * FT_LAY_STRIDE] = tot_lm;
     tot_lm += sc.slots; tot_rec += sc.K; max_tiles = std::max(max_tiles, sc.n_tiles);
@@ -765,6 +768,12 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   d.test_fail_chol_iter = c->opt.test_fail_chol_iter;   // (test hook of the mu-retry path, 0 in production: gfbe_options)
   b->algo_bytes_lin = algo_bytes;
   for (int w = 0; w < B; w++) if (!wins[w]->ex_cam_const || !wins[w]->td_const) d.vis_full = 1;
+  // Host-fed batches that hold td and the camera extrinsic constant everywhere: the observations cross PCIe already shifted to the
+  // window's td (two doubles per factor instead of five: k_expand would apply the same shift, projectionTwoFrameOneCamFactor.cpp:
+  // 60-61, before anything reads them); velocity and td of an observation travel only for the landmarks that start in frame 0 — the
+  // marginalisation's td / extrinsic columns are the only readers (estimator.cpp:3498-3531 takes the factors with imu_i == 0).
+  // 378 -> ~200 KB of the 630 KB a 2000-landmark window uploads. (Not for gfbe_eval_factors: its records carry every td column.)
+  d.obs_compact = (!tabs && !d.vis_full && !c->want_records) ? 1 : 0;
   for (int w = 0; w < B; w++) if (wins[w]->use_plane || wins[w]->use_anchor) d.any_plane = 1;
   for (int w = 0; w < B; w++) if (wins[w]->prior && wins[w]->prior->valid) d.prior_n_max = std::max(d.prior_n_max, (int)wins[w]->prior->n);
   d.any_gnss = any_gnss; d.tot_gnss = tot_gnss; d.gnss_max_obs = gnss_max; d.marg_nmax = marg_nmax;
@@ -778,6 +787,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   gfbe_status st;
   WinDesc *h_desc = nullptr; int *h_lm_info = nullptr, *h_lm_abi = nullptr, *h_tile_start = nullptr, *h_feat_off = nullptr;
   long long *h_j0_off = nullptr;
+  double *h_fvel = nullptr;
   double *h_lm_pts = nullptr, *h_lam0 = nullptr, *h_fobs = nullptr, *h_x0 = nullptr, *h_lio = nullptr, *h_pr0 = nullptr, *h_px0 = nullptr, *h_pJ0 = nullptr;
   gfbe_imu_preint *h_imu = nullptr; gfbe_wheel_preint *h_wheel = nullptr;
   gfbe_gnss_obs *h_gnss = nullptr;
@@ -801,10 +811,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     UP(dl_feat_off, h_feat_off, B + 1); UP(dl_j0_off, h_j0_off, B + 1);
     UP(gnss_obs, h_gnss, std::max(tot_gnss, 1));
     if ((st = up_alloc(c, b, &d_pJ0c, &h_pJ0, (size_t)B * pj_row)) != GFBE_OK) return st;
-    if (!tabs) { UP(lm_info, h_lm_info, TL); UP(lm_abi, h_lm_abi, TL); UP(lm_pts, h_lm_pts, (size_t)6 * TL); UP(lam0, h_lam0, TL); UP(fobs, h_fobs, (size_t)tot_rec * 5); }
+    if (!tabs) { UP(lm_info, h_lm_info, TL); UP(lm_abi, h_lm_abi, TL); UP(lm_pts, h_lm_pts, (size_t)6 * TL); UP(lam0, h_lam0, TL); UP(fobs, h_fobs, (size_t)tot_rec * (d.obs_compact ? 2 : 5)); UP(fvel, h_fvel, d.obs_compact ? (size_t)std::max(tot_n0, 1) * 3 : 1); }
     const size_t up_end = b->dry ? b->slab_bytes : b->slab_off;
     // -- arrays the kernels expect zeroed at the start (rows past a track's length, partials of absent factors, ...)
-    if (tabs) { AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lam0, TL); d.fobs = nullptr; }
+    if (tabs) { AL(lm_info, TL); AL(lm_abi, TL); AL(lm_pts, (size_t)6 * TL); AL(lam0, TL); d.fobs = nullptr; d.fvel = nullptr; }
 #if GFBE_CLEAR_LM      // (diagnostics: the landmark rows back in the cleared region)
     AL(lm_obs, (size_t)MAXOBS * 5 * TL); AL(lm_rec, (size_t)MAXOBS * TL); AL(lm_hP, (size_t)MAXOBS * 6 * TL);
 #endif
@@ -896,13 +906,25 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
         h_lm_abi[slot] = l;
         h_lam0[slot] = win.para_Feature[l];
       }
-      double *fo = h_fobs + (size_t)ds.rec_off * 5;
+      const bool compact = d.obs_compact != 0;
+      double *fo = h_fobs + (size_t)ds.rec_off * (compact ? 2 : 5), *fv = compact ? h_fvel + (size_t)ds.vel_off * 3 : nullptr;
+      const double tdw = win.state.para_Td;
       for (int k = 0; k < sc.K; k++) {
         const int l = win.vis.feature_index[k], i = win.vis.imu_i[k], j = win.vis.imu_j[k];
         const int rel = sc.slot_rel[l];
         const int rec = sc.pair_begin[i * NF + j] + (rel - sc.sf_tile_begin[i] * LM_TILE);
-        double *f = fo + (size_t)rec * 5;
-        f[0] = win.vis.pts_j[3 * k]; f[1] = win.vis.pts_j[3 * k + 1]; f[2] = win.vis.vel_j[2 * k]; f[3] = win.vis.vel_j[2 * k + 1]; f[4] = win.vis.td_j[k];
+        if (compact) {
+          // p' = p - (td - td_obs) v: k_expand's fused multiply-add (a correctly rounded std::fma is the same number; an observation
+          // stamped with the window's td — the usual case — is not touched)
+          const double dtj = tdw - win.vis.td_j[k];
+          double *f = fo + (size_t)rec * 2;
+          f[0] = dtj == 0.0 ? win.vis.pts_j[3 * k] : std::fma(-dtj, win.vis.vel_j[2 * k], win.vis.pts_j[3 * k]);
+          f[1] = dtj == 0.0 ? win.vis.pts_j[3 * k + 1] : std::fma(-dtj, win.vis.vel_j[2 * k + 1], win.vis.pts_j[3 * k + 1]);
+          if (i == 0) { double *v = fv + (size_t)rec * 3; v[0] = win.vis.vel_j[2 * k]; v[1] = win.vis.vel_j[2 * k + 1]; v[2] = win.vis.td_j[k]; }
+        } else {
+          double *f = fo + (size_t)rec * 5;
+          f[0] = win.vis.pts_j[3 * k]; f[1] = win.vis.pts_j[3 * k + 1]; f[2] = win.vis.vel_j[2 * k]; f[3] = win.vis.vel_j[2 * k + 1]; f[4] = win.vis.td_j[k];
+        }
         if (j == i + 1) {   // the landmark's first observation travels with its first factor
           const size_t slot = (size_t)o + rel;
           h_lm_pts[0 * TL + slot] = win.vis.pts_i[3 * k]; h_lm_pts[1 * TL + slot] = win.vis.pts_i[3 * k + 1]; h_lm_pts[2 * TL + slot] = win.vis.pts_i[3 * k + 2];
@@ -911,7 +933,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       }
       b->slot_of[w].resize(sc.L);
       for (int l = 0; l < sc.L; l++) b->slot_of[w][l] = o + sc.slot_rel[l];
-      bytes += (double)sc.slots * (4 + 4 + 8 + 48) + 40.0 * sc.K;
+      bytes += (double)sc.slots * (4 + 4 + 8 + 48) + (compact ? 16.0 * sc.K + 24.0 * sc.pair_begin[NF] : 40.0 * sc.K);
     }
     // dense state
     std::memcpy(h_x0 + (size_t)w * NA, &win.state, sizeof(double) * NA);

@@ -2938,8 +2938,16 @@ __device__ __forceinline__ void expand_body(const BatchDev &d, const int w, cons
   for (int k = 0; k < m; k++) {
     const int rec = ds.pair_begin[s * NF + s + 1 + k] + pos;
     d.lm_rec[(size_t)k * TL + slot] = rec;
-    const double *f = d.fobs + ((size_t)ds.rec_off + rec) * 5;
     double *ob = d.lm_obs + (size_t)k * 5 * TL + slot;
+    if (d.obs_compact) {      // the host shifted the observation (upload_one); velocities only where the marginalisation reads them
+      const double *f = d.fobs + ((size_t)ds.rec_off + rec) * 2;
+      ob[0] = f[0]; ob[TL] = f[1];
+      const double *v = d.fvel + ((size_t)ds.vel_off + (s == 0 ? rec : 0)) * 3;
+      ob[2 * TL] = s == 0 ? v[0] : 0.0; ob[3 * TL] = s == 0 ? v[1] : 0.0;
+      ob[4 * TL] = tdw;
+      continue;
+    }
+    const double *f = d.fobs + ((size_t)ds.rec_off + rec) * 5;
     const double dtj = shift ? tdw - f[4] : 0.0;
     ob[0] = shift ? __builtin_fma(-dtj, f[2], f[0]) : f[0];
     ob[TL] = shift ? __builtin_fma(-dtj, f[3], f[1]) : f[1];

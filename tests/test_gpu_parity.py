@@ -387,3 +387,23 @@ def test_split_batch_sorts_its_windows_by_size_and_returns_them_in_place(oracle)
         np.testing.assert_array_equal(a["prior"]["J0"], b["prior"]["J0"])
         assert a["prior"]["block_id"].tolist() == b["prior"]["block_id"].tolist()
     one.close(); four.close()
+
+
+def test_constant_td_that_differs_from_the_observations_stamps(be, oracle):
+    """td is held constant (the shipped configuration) but is not the td the observations were stamped with: every observation is
+    shifted by (td - td_obs) x velocity (projectionTwoFrameOneCamFactor.cpp:60-61). Host-fed batches do that on the HOST while they
+    pack (two doubles per factor cross PCIe, velocities only for the landmarks of frame 0: upload_one); the marginalisation's td /
+    extrinsic columns still see the velocities. Against the oracle, alone and inside a throughput batch."""
+    _, snap = window_with_prior(oracle, 53, 300)
+    snap["td"] = 0.004
+    snap["vis_td_j"] = np.asarray(snap["vis_td_j"], float) + 0.001 * (np.arange(len(snap["vis_td_j"])) % 3)      # (stamps that differ between observations)
+    assert snap.get("td_const", 1) and np.abs(snap["td"] - snap["vis_td_j"]).min() > 0
+    want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD)
+    assert relerr(got["prior"]["J0"].T @ got["prior"]["J0"], want["prior"]["J0"].T @ want["prior"]["J0"]) < 1e-7
+    ids = got["prior"]["block_id"].tolist()
+    assert abi.BLK_TD in ids and abi.BLK_EX_CAM in ids                  # (the prior keeps td and the extrinsic: their columns need the velocities)
+    batch = be.solve_batch([snap] * 33, abi.MARGIN_OLD)
+    assert batch[7]["summary"]["accepted"] == got["summary"]["accepted"]
+    np.testing.assert_allclose(batch[7]["summary"]["cost_history"], got["summary"]["cost_history"], rtol=1e-7)
+    assert np.abs(batch[7]["state"]["pose"] - got["state"]["pose"]).max() < 1e-8
+    assert relerr(batch[7]["prior"]["J0"].T @ batch[7]["prior"]["J0"], got["prior"]["J0"].T @ got["prior"]["J0"]) < 1e-7
