@@ -407,3 +407,32 @@ def test_constant_td_that_differs_from_the_observations_stamps(be, oracle):
     np.testing.assert_allclose(batch[7]["summary"]["cost_history"], got["summary"]["cost_history"], rtol=1e-7)
     assert np.abs(batch[7]["state"]["pose"] - got["state"]["pose"]).max() < 1e-8
     assert relerr(batch[7]["prior"]["J0"].T @ batch[7]["prior"]["J0"], got["prior"]["J0"].T @ got["prior"]["J0"]) < 1e-7
+
+
+def test_assembled_system_of_the_two_kernel_sets_entry_by_entry(oracle):
+    """The normal equations of the FIRST linearisation (one iteration: both runs linearise at the same state) — H (lower triangle), g,
+    E after the landmark elimination — from the small-batch kernel set (k_lin_small / k_dense, k_schur_visblock_small, k_assemble)
+    and from the throughput set (k_vis<0> + k_dense_tp + k_prior_tp, k_schur, k_visasm): the same quantities summed in other
+    groupings, entry by entry through gfbe_debug_vector. Wheel and prior present; the window sits at place 5 of a 33-window batch."""
+    o = abi.default_options()
+    o.max_num_iterations = 1
+    be1 = gf.Backend(device=0, options=o)
+    _, snap = window_with_prior(oracle, 57, 260)
+    rows = list(range(0, abi.DENSE_DIM, 7)) + [66, 67, 72, 73, 100, 164, 186]
+    got = []
+    for B, w in ((1, 0), (33, 5)):
+        b = be1.batch_upload([snap] * B)
+        b.solve(abi.MARGIN_NONE)
+        H = np.array([b.debug_vector(1000 + r, w) for r in rows])
+        E = np.array([b.debug_vector(2000 + r, w)[:73] for r in range(0, 74, 3)])
+        g = b.debug_vector(3, w)
+        got.append((H, E, g, b.download()[w]["summary"]))
+        b.free()
+    be1.close()
+    (H1, E1, g1, s1), (H2, E2, g2, s2) = got
+    assert s1["iterations"] == s2["iterations"] == 1 and s1["accepted"] == s2["accepted"]
+    tri = np.array([[c <= r for c in range(abi.DENSE_DIM)] for r in rows])      # (H holds its lower triangle)
+    assert np.abs(H1[tri]).max() > 1.0 and np.abs(g1).max() > 1.0
+    assert np.abs(H1[tri] - H2[tri]).max() < 1e-11 * np.abs(H1[tri]).max()
+    assert np.abs(E1 - E2).max() < 1e-11 * np.abs(E1).max()
+    assert np.abs(g1 - g2).max() < 1e-11 * np.abs(g1).max()
