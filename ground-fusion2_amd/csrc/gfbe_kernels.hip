@@ -1119,6 +1119,7 @@ __device__ __forceinline__ void dense_tp_factor(const BatchDev &d, int mode, int
 // global-memory path (lds_n = 0).
 enum { PRIOR_REGS = 32, PRIOR_LDS_N = 90 };      // 256 threads x 32 values >= 90 x 90; 90 x 90 x 8 B = 63 KB of LDS
 static_assert(256 * PRIOR_REGS >= PRIOR_LDS_N * PRIOR_LDS_N, "k_prior_tp: a thread's share of J0");
+static_assert(ND <= 256, "k_prior_tp: one thread per row / column of the prior (n <= GFBE_DENSE_DIM) in a 256-thread workgroup");
 __global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_n) {
   extern __shared__ __attribute__((aligned(16))) double psm[];      // dx[ND] | r[ND] | partial sums [4][ND] | J0 [lds_n x lds_n]
   __shared__ double red[16];
