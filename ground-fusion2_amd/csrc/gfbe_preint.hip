@@ -2,7 +2,9 @@
 // Reference (Ground-Fusion++/vins_estimator/src/factor):
 //   IntegrationBase::{push_back, propagate, midPointIntegration}       integration_base.h:39-167
 //   WheelIntegrationBase::{push_back, propagate, midPointIntegration}  wheel_integration_base.h:41-178
-// One 64-lane wave per interval: the sample recursion is sequential; inside a sample the lanes
+// One workgroup per interval (IMU: four waves — a thread per entry of the 15 x 15 products; one robot integrates ONE interval per
+// camera frame, so the kernel's time is the latency of its sample recursion: 64 threads took ~4 us per sample; wheel: one wave): the
+// sample recursion is sequential; inside a sample the lanes
 // own entries of F*jacobian and F*cov*F^T + V*noise*V^T (the reference builds dynamic MatrixXd
 // temporaries for these per sample, integration_base.h:99,117).
 #include "gfbe_device.h"
@@ -12,10 +14,11 @@ namespace gfd {
 
 // Which of the 17 distinct 3 x 3 blocks sits at block (row / 3, column / 3) of F (5 x 5) and V (5 x 6); -1: zero.
 #define IMU_NSRC 17
+#define PREINT_IMU_THREADS 256
 __constant__ signed char IMU_FMAP[25] = {0, 1, 2, 3, 4,   -1, 5, -1, -1, 6,   -1, 7, 0, 8, 9,   -1, -1, -1, 0, -1,   -1, -1, -1, -1, 0};
 __constant__ signed char IMU_VMAP[30] = {10, 11, 12, 11, -1, -1,   -1, 13, -1, 13, -1, -1,   14, 15, 16, 15, -1, -1,   -1, -1, -1, -1, 2, -1,   -1, -1, -1, -1, -1, 2};
 
-__global__ __launch_bounds__(64) void k_preint_imu(int n, const int *off, const double *samples, const double *first,
+__global__ __launch_bounds__(PREINT_IMU_THREADS) void k_preint_imu(int n, const int *off, const double *samples, const double *first,
                                                   const double *lin, const double *noise, gfbe_imu_preint *out) {
   const int iv = blockIdx.x, t = threadIdx.x;
   if (iv >= n) return;
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(64) void k_preint_imu(int n, const int *off, const 
   vec3 dp = mk3(0, 0, 0), dv = mk3(0, 0, 0);
   quat dq; dq.x = dq.y = dq.z = 0.0; dq.w = 1.0;
   double sum_dt = 0.0;
-  for (int e = t; e < 225; e += 64) { Jm[e] = (e / 15 == e % 15) ? 1.0 : 0.0; P[e] = 0.0; }
+  for (int e = t; e < 225; e += PREINT_IMU_THREADS) { Jm[e] = (e / 15 == e % 15) ? 1.0 : 0.0; P[e] = 0.0; }
   if (t < 25) fmap[t] = IMU_FMAP[t];
   if (t < 30) vmap[t] = IMU_VMAP[t];
   if (t < 18) {
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(64) void k_preint_imu(int n, const int *off, const 
         }
       }
       __syncthreads();
-      for (int e = t; e < 225 + 270; e += 64) {
+      for (int e = t; e < 225 + 270; e += PREINT_IMU_THREADS) {
         const bool isF = e < 225;
         const int q = isF ? e : e - 225, ld = isF ? 15 : 18, r = q / ld, c = q - r * ld;
         const int m = isF ? fmap[(r / 3) * 5 + c / 3] : vmap[(r / 3) * 6 + c / 3];
@@ -88,14 +91,14 @@ __global__ __launch_bounds__(64) void k_preint_imu(int n, const int *off, const 
       }
     }
     __syncthreads();
-    for (int e = t; e < 225; e += 64) {     // T1 = F * jacobian, T2 = F * cov
+    for (int e = t; e < 225; e += PREINT_IMU_THREADS) {     // T1 = F * jacobian, T2 = F * cov
       const int i = e / 15, j = e % 15;
       double a = 0.0, b = 0.0;
       for (int k = 0; k < 15; k++) { a += F[i * 15 + k] * Jm[k * 15 + j]; b += F[i * 15 + k] * P[k * 15 + j]; }
       T1[e] = a; T2[e] = b;
     }
     __syncthreads();
-    for (int e = t; e < 225; e += 64) {     // cov = T2 * F^T + V N V^T
+    for (int e = t; e < 225; e += PREINT_IMU_THREADS) {     // cov = T2 * F^T + V N V^T
       const int i = e / 15, j = e % 15;
       double a = 0.0;
       for (int k = 0; k < 15; k++) a += T2[i * 15 + k] * F[j * 15 + k];
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(64) void k_preint_imu(int n, const int *off, const 
     for (int k = 0; k < 3; k++) { o->delta_p[k] = dp[k]; o->delta_v[k] = dv[k]; o->linearized_ba[k] = ba[k]; o->linearized_bg[k] = bg[k]; }
     o->delta_q[0] = dq.x; o->delta_q[1] = dq.y; o->delta_q[2] = dq.z; o->delta_q[3] = dq.w;
   }
-  for (int e = t; e < 225; e += 64) { o->jacobian[e] = Jm[e]; o->covariance[e] = P[e]; }
+  for (int e = t; e < 225; e += PREINT_IMU_THREADS) { o->jacobian[e] = Jm[e]; o->covariance[e] = P[e]; }
 }
 
 __global__ __launch_bounds__(64) void k_preint_wheel(int n, const int *off, const double *samples, const double *first,
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(64) void k_preint_wheel(int n, const int *off, cons
 
 void launch_preint_imu(int n, const int *off, const double *samples, const double *first, const double *lin,
                        const double *noise4, gfbe_imu_preint *out, hipStream_t s) {
-  hipLaunchKernelGGL(k_preint_imu, dim3(n), dim3(64), 0, s, n, off, samples, first, lin, noise4, out);
+  hipLaunchKernelGGL(k_preint_imu, dim3(n), dim3(PREINT_IMU_THREADS), 0, s, n, off, samples, first, lin, noise4, out);
 }
 void launch_preint_wheel(int n, const int *off, const double *samples, const double *first, const double *lin,
                          const double *noise2, gfbe_wheel_preint *out, hipStream_t s) {
