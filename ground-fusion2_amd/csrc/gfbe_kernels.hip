@@ -1340,7 +1340,6 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   __shared__ double hs[LM_TILE * HS_LD + 8];      // (+ the overrun of the last row's last block)
   const size_t TL = d.tot_lm;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const bool first = (c.iter == 0);   // Jacobi scaling is fixed at iteration 0 (TrustRegionMinimizer::IterationZero)
   // output tiles of this group: tile rows/cols >= I0 (of its first start frame), upper pairs, round-robin over the 4 waves
   // COMPACT panel (the solve; round 4): the columns of a group's panel are taken relative to its first start frame, the gradient
   // column first — column 0 = sqrt(w) g_l, dim a at 1 + a - 6 s_first — so that a tile's non-zero columns are [0, 6 (s - s_first + m0
@@ -1442,7 +1441,6 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
                                                           : (6 * (ps + ((pm0 >> 8) & 0xff) + 1) - 1) >> 4);              \
     {                                                                                                                    \
       const int s = ps, kmax = NF - 1 - s;          /* this tile's start frame */                                        \
-      const int slot = lm_off_c + (TILE) * LM_TILE + l;                                                                  \
       const bool valid = (PINFO >> 24) & 1;                                                                              \
       const int m = (PINFO >> 8) & 0xff;                                                                                 \
       const bool is_const = (PINFO >> 16) & 1;                                                                           \
