@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_ftab_erase_copy(FtabDev T, int cur) {
 // appended only when the search fails), so at most one list entry matches: workgroup (x, y) compares 64 incoming ids with a
 // tile of FT_MATCH_TILE list ids staged in LDS and the one hit, if any, writes the entry (match[] starts at -1). One thread
 // scanning the whole list (3 500 dependent global loads) took ~0.3 ms per frame of one robot.
-#define FT_MATCH_TILE 1024
+#define FT_MATCH_TILE 256     // (1024: 53 us per call for a 3 500-feature list — a thread walked 1024 LDS entries; 256: four times the workgroups, a quarter of the walk)
 __global__ __launch_bounds__(64) void k_ftab_match(FtabDev T, int cur, const int *offset, const int *fid, int *match) {
   const int w = blockIdx.z, j0 = offset[w], m = offset[w + 1] - j0, a = blockIdx.x * 64 + threadIdx.x;
   const int n = T.count[w], f0 = blockIdx.y * FT_MATCH_TILE, nt = min(n - f0, FT_MATCH_TILE);
