@@ -285,13 +285,26 @@ __global__ __launch_bounds__(256) void k_ftab_triangulate(FtabDev T, int cur, co
   const int n = T.count[w];
   const size_t base = (size_t)w * T.F;
   const double *PR = poses + 132 * (size_t)w, *tic = tic_ric + 12 * (size_t)w, *ric = tic + 3;
+  // the camera pose of every window frame (R_f ric, P_f + R_f tic), once per workgroup: every (feature, observation) formed it again
+  // from global memory — a dependent load and a 3 x 3 product per observation on the single thread that owns the feature (one robot:
+  // 99 us per call). The same products of the same operands: the same depths.
+  __shared__ double s_Rc[NOBS][9], s_tc[NOBS][3];
+  if (threadIdx.x < NOBS) {
+    const int fr = threadIdx.x;
+    double Rc[9];
+    mm3(PR + 12 * fr + 3, ric, Rc);
+    const vec3 tc = add(ld3(PR + 12 * fr), mulR(PR + 12 * fr + 3, ld3(tic)));
+    for (int q = 0; q < 9; q++) s_Rc[fr][q] = Rc[q];
+    for (int q = 0; q < 3; q++) s_tc[fr][q] = tc[q];
+  }
+  __syncthreads();
   for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < n; f += gridDim.x * blockDim.x) {
     const int m = T.nobs[cur][base + f], s = T.start[cur][base + f];
     if (m < 4 || T.depth[cur][base + f] > 0) continue;
     const double *ob = T.obs[cur] + (base + f) * NOBS * OW;
-    auto camT = [&](int fr) { return add(ld3(PR + 12 * fr), mulR(PR + 12 * fr + 3, ld3(tic))); };
+    auto camT = [&](int fr) { return mk3(s_tc[fr][0], s_tc[fr][1], s_tc[fr][2]); };
     double R0[9];
-    mm3(PR + 12 * s + 3, ric, R0);
+    for (int q = 0; q < 9; q++) R0[q] = s_Rc[s][q];
     const vec3 t0 = camT(s);
     double dnew; int fl;
     if (!with_depth) {
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(256) void k_ftab_triangulate(FtabDev T, int cur, co
       for (int q = 0; q < 16; q++) G[q] = 0.0;
       for (int o = 0; o < m; o++) {
         double R1[9], R[9];
-        mm3(PR + 12 * (s + o) + 3, ric, R1);
+        for (int q = 0; q < 9; q++) R1[q] = s_Rc[s + o][q];
         const vec3 tt = mulRT(R0, sub(camT(s + o), t0));
         tmm3(R0, R1, R);
         const vec3 mt = mulRT(R, tt);
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(256) void k_ftab_triangulate(FtabDev T, int cur, co
         const double dep = ob[i * OW + 7];
         if (dep < 0.1 || dep > T.opt.depth_threshold) continue;
         double Ri[9], R2r[9];
-        mm3(PR + 12 * (s + i) + 3, ric, Ri);
+        for (int q = 0; q < 9; q++) Ri[q] = s_Rc[s + i][q];
         const vec3 ti = camT(s + i);
         const vec3 p0 = scl(dep, ld3(ob + i * OW));
         const vec3 t2r = mulRT(R0, sub(ti, t0));
@@ -329,7 +342,7 @@ __global__ __launch_bounds__(256) void k_ftab_triangulate(FtabDev T, int cur, co
         for (int j = 0; j < m; j++) {
           if (i == j) continue;
           double Rj[9], R20[9];
-          mm3(PR + 12 * (s + j) + 3, ric, Rj);
+          for (int q = 0; q < 9; q++) Rj[q] = s_Rc[s + j][q];
           const vec3 t20 = mulRT(Ri, sub(camT(s + j), ti));
           tmm3(Ri, Rj, R20);
           const vec3 pp = sub(mulRT(R20, p0), mulRT(R20, t20));
