@@ -663,7 +663,9 @@ gfbe_status gfbe_ftab_create(gfbe_ctx *c, int32_t n_tables, int32_t cap, const g
   if (!c || !out || n_tables < 1 || cap < 1 || cap > 16384) return GFBE_BAD_INPUT;   // 16384: the LDS id list of check_outliers (64 KB)
   if (ctx_device(c) < 0) return GFBE_NO_DEVICE;
   gfbe_ftab *t = new gfbe_ftab();
-  *out = t;
+  *out = nullptr;
+  // (a failed allocation leaves nothing behind: the table built so far is destroyed and *out stays null)
+  struct Guard { gfbe_ctx *c; gfbe_ftab *t; bool armed = true; ~Guard() { if (armed) gfbe_ftab_destroy(c, t); } } guard{c, t};
   FtabDev &d = t->d;
   d.W = n_tables; d.F = cap;
   if (opt) d.opt = *opt; else gfbe_ftab_default_options(&d.opt);
@@ -682,6 +684,8 @@ gfbe_status gfbe_ftab_create(gfbe_ctx *c, int32_t n_tables, int32_t cap, const g
   FT_CHECK(c, hipHostMalloc((void **)&t->ring_h, (size_t)gfbe_ftab::RING * gfbe_ftab::RING_SLOT));
   for (int k = 0; k < gfbe_ftab::RING; k++) FT_CHECK(c, hipEventCreateWithFlags(&t->ring_ev[k], hipEventDisableTiming));
   FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
+  guard.armed = false;
+  *out = t;
   return GFBE_OK;
 }
 

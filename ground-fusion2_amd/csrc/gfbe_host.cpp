@@ -276,8 +276,9 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   if (ea == hipSuccess) ea = marg_init_device();
   if (ea == hipSuccess) ea = gnss_init_device();
   if (ea == hipSuccess) ea = dense_init_device();
-  if (ea == hipSuccess) ea = asm_tables_build(&c->asm_full, &c->asm_compact, &c->asm_compact_n, c->stream);
   if (ea != hipSuccess) { c->err = std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
+  ea = asm_tables_build(&c->asm_full, &c->asm_compact, &c->asm_compact_n, c->stream);
+  if (ea != hipSuccess) { c->err = std::string("assembly tables (hipMalloc / k_asm_table / k_asm_compact): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
   return GFBE_OK;
 }
 
@@ -1067,7 +1068,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     bool prior_sb = false;
     for (int w = 0; w < B && !prior_sb; w++)
       for (int q = 0; q < h_desc[w].prior_nblk; q++) if (h_desc[w].prior_blk_id[q] > GFBE_BLK_SB0 && h_desc[w].prior_blk_id[q] < GFBE_BLK_EX_CAM) prior_sb = true;
-    const bool compact = !prior_sb && d.nu == NC && c->asm_compact_n > 0;
+    // (GFBE_ASM_FULL, diagnostics build only: the full table for every batch — tests/test_gpu_solve_kernels.py compares the two entry by entry)
+    const bool compact = !prior_sb && d.nu == NC && c->asm_compact_n > 0 && !diag_getenv("GFBE_ASM_FULL");
     d.asm_tab = compact ? c->asm_compact : c->asm_full;
     d.asm_n = compact ? c->asm_compact_n : d.nu * (d.nu + 1) / 2;
   }
@@ -1436,11 +1438,11 @@ static gfbe_status fetch_one(gfbe_ctx *c, gfbe_batch *b) {
   }
   // A small batch (a single window's latency path) gathers and copies on the solver's own stream, behind the solve: no event to wait
   // for across streams (~15 us of a 1.45 ms call); throughput batches use the download stream, beside whatever the solver runs next.
+  // (The two waits stay unconditional: on the stream that recorded the events they cost nothing, and they keep the gather behind
+  //  the upload and the solve when the caller changed streams in between — gfbe_set_stream — or downloads without a solve.)
   hipStream_t ds = d.B < DENSE_SPLIT_MIN_B ? c->stream : c->dl;
-  if (ds != c->stream) {
-    HIPCHK(c, hipStreamWaitEvent(ds, b->ev_up, 0));
-    HIPCHK(c, hipStreamWaitEvent(ds, b->ev_done, 0));
-  }
+  HIPCHK(c, hipStreamWaitEvent(ds, b->ev_up, 0));
+  HIPCHK(c, hipStreamWaitEvent(ds, b->ev_done, 0));
   launch_gather(d, b->last_flag, ds);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(b->dl_h, d.dl_fix, b->dl_bytes, hipMemcpyDeviceToHost, ds));

@@ -1668,12 +1668,19 @@ hipError_t asm_tables_build(int **full, int **compact, int *n_compact, hipStream
   hipError_t e = hipMalloc(&f, sizeof(int4) * ASM_NTRI);
   if (e == hipSuccess) e = hipMalloc(&cmp, sizeof(int4) * (NC * (NC + 1) / 2));
   if (e == hipSuccess) e = hipMalloc(&dn, sizeof(int));
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_asm_table, dim3((ASM_NTRI + 255) / 256), dim3(256), 0, s, (int4 *)f);
-  hipLaunchKernelGGL(k_asm_compact, dim3(1), dim3(1024), 0, s, (const int4 *)f, (int4 *)cmp, dn);
-  e = hipMemcpyAsync(n_compact, dn, sizeof(int), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(dn);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_asm_table, dim3((ASM_NTRI + 255) / 256), dim3(256), 0, s, (int4 *)f);
+    hipLaunchKernelGGL(k_asm_compact, dim3(1), dim3(1024), 0, s, (const int4 *)f, (int4 *)cmp, dn);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(n_compact, dn, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  if (dn) (void)hipFree(dn);
+  if (e != hipSuccess) {     // (nothing is handed back on failure: the context frees only what it was given)
+    if (f) (void)hipFree(f);
+    if (cmp) (void)hipFree(cmp);
+    return e;
+  }
   *full = f; *compact = cmp;
   return e;
 }
@@ -2941,8 +2948,10 @@ __device__ __forceinline__ void expand_body(const BatchDev &d, const int w, cons
     if (d.obs_compact) {      // the host shifted the observation (upload_one); velocities only where the marginalisation reads them
       const double *f = d.fobs + ((size_t)ds.rec_off + rec) * 2;
       ob[0] = f[0]; ob[TL] = f[1];
-      const double *v = d.fvel + ((size_t)ds.vel_off + (s == 0 ? rec : 0)) * 3;
-      ob[2 * TL] = s == 0 ? v[0] : 0.0; ob[3 * TL] = s == 0 ? v[1] : 0.0;
+      if (s == 0) {           // (no pointer is formed for the others: a window without frame-0 records has vel_off at the end of fvel)
+        const double *v = d.fvel + ((size_t)ds.vel_off + rec) * 3;
+        ob[2 * TL] = v[0]; ob[3 * TL] = v[1];
+      } else { ob[2 * TL] = 0.0; ob[3 * TL] = 0.0; }
       ob[4 * TL] = tdw;
       continue;
     }

@@ -105,15 +105,19 @@ def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True, devic
     # are integrated again
     cache_imu, cache_wheel = {}, {}
 
-    def preintegrated(cache, slots, fn):
-        keys = [tuple(id(s) for s, _ in slot) for slot in slots]
+    def preintegrated(cache, slots, fn, lin):
+        # key of an interval: the identities of its sample AND first-sample arrays plus the linearisation point (biases / intrinsics)
+        # the integration ran at — re-propagation after a bias change integrates again. The cache entry holds references to the
+        # arrays, so an id() cannot be reused by a new array while its entry is alive (a driver that builds its arrays per frame).
+        lin_key = np.asarray(lin, dtype=np.float64).tobytes()
+        keys = [(tuple((id(s), id(f)) for s, f in slot), lin_key) for slot in slots]
         todo = [i for i, key in enumerate(keys) if key not in cache]
         if todo:
             for i, row in zip(todo, fn([merged(slots[i]) for i in todo])):
-                cache[keys[i]] = row.copy()
+                cache[keys[i]] = (row.copy(), list(slots[i]))
         for key in [key for key in cache if key not in keys]:
             del cache[key]
-        return np.stack([cache[key] for key in keys])
+        return np.stack([cache[key][0] for key in keys])
 
     out["frame_s"] = []        # wall time of every frame of the loop (the first ones include one-time allocations)
     for k in range(W, stream.n_kf):
@@ -131,11 +135,11 @@ def run_stream(engine, tables, stream, slide_fn, rgbd=False, use_mcc=True, devic
         if not device_handoff:
             snap.update(engine.build_visual_factors(abi.ftab_to_feature_list(tables.download(0))))
         snap["imu"] = preintegrated(cache_imu, imu_slots, lambda iv: engine.preintegrate_imu(
-            iv, scn.ba_est, scn.bg_est, (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)))
+            iv, scn.ba_est, scn.bg_est, (synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)), np.concatenate([scn.ba_est, scn.bg_est]))
         snap["imu_frame"] = np.arange(W, dtype=np.int32)
         if wheel_slots is not None:
             snap["wheel"] = preintegrated(cache_wheel, wheel_slots, lambda iv: engine.preintegrate_wheel(
-                iv, [1.0, 1.0, 1.0, 0.0], (synth.VEL_N_WHEEL, synth.GYR_N_WHEEL)))
+                iv, [1.0, 1.0, 1.0, 0.0], (synth.VEL_N_WHEEL, synth.GYR_N_WHEEL)), [1.0, 1.0, 1.0, 0.0])
             snap["wheel_frame"] = np.arange(W, dtype=np.int32)
         snap.update(ex_cam_const=1, ex_wheel_const=1, ix_wheel_const=1, td_const=1, td_wheel_const=1, prior=prior)
         if device_handoff:

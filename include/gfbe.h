@@ -388,7 +388,10 @@ void gfbe_ftab_default_options(gfbe_ftab_options *opt);
  * Every table operation runs in order on the context's stream. The ones without outputs (triangulate, set_depth, clear_depth,
  * remove_*) copy their arguments and return without waiting for the device; the ones that hand something back (add_frame,
  * check_outliers, get_depth_vector, size, download, gfbe_batch_upload_tables) wait for what was enqueued before them. Capacity /
- * observation-count overflow is raised by gfbe_ftab_add_frame (GFBE_BAD_INPUT, sticky). */
+ * observation-count overflow is raised by gfbe_ftab_add_frame (GFBE_BAD_INPUT, sticky).
+ * A device error of a deferred operation (its kernel has not run when the call returns) is reported by the NEXT table call that
+ * synchronises — usually add_frame or check_outliers — and gfbe_last_error then names that call, not the operation that faulted.
+ * gfbe_ftab_create leaves *out null and frees what it had allocated when any of its allocations fails. */
 gfbe_status gfbe_ftab_create(gfbe_ctx *ctx, int32_t n_tables, int32_t feature_capacity,
                              const gfbe_ftab_options *opt, gfbe_ftab **out);
 void gfbe_ftab_destroy(gfbe_ctx *ctx, gfbe_ftab *t);

@@ -73,3 +73,50 @@ def test_merged_launches_equal_the_one_kernel_per_launch_sequence():
         finally:
             be.profile_enable(False)
             be.profile_reset()
+
+
+def test_compact_assembly_table_equals_the_full_one_entry_by_entry():
+    """The compact assembly table (csrc/gfbe_kernels.hip: k_asm_compact) lists the entries of H's lower triangle a factor of a
+    reference-structured window can reach, by a hand-written structural predicate; the others are never written and read as the zeros
+    the upload left there. A factor or prior block coupling dims outside the predicate would lose entries SILENTLY. The diagnostics
+    switch GFBE_ASM_FULL=1 assembles the same batch through the full table (every entry of the 187 x 187 triangle written): H must
+    agree entry by entry — wheel, plane, anchor, LiDAR and prior windows, throughput batch included — and so must the results."""
+    import plane_cases as pc
+    assert os.path.exists(gf.backend.DIAG_SO), "run __graft_entry__.build()"
+    be = gf.Backend(device=0, so=gf.backend.DIAG_SO)
+    scn = synth.Scenario(seed=21, n_landmarks=300, use_wheel=True)
+    r0 = be.solve(scn.window(0), abi.MARGIN_OLD)
+    with_prior = scn.window(1, state=synth.shift_state_for_next_window(scn, r0["state"], 1), prior=r0["prior"])
+    pscn, psnap = pc.plane_window(seed=73, L=150, anchor=True)
+    pres = be.solve(psnap, abi.MARGIN_OLD)
+    plane_next = pc.next_plane_window(pscn, psnap, pres)            # prior with the plane blocks + plane factors + anchor-free
+    lio = dict(scn.window(0), lio=synth.lidar_block(scn, 0, n=300, seed=5, frame=7))
+    no_wheel = synth.Scenario(seed=22, n_landmarks=200, use_wheel=False).window(0)
+    cases = {"wheel + prior": [with_prior], "plane + anchor": [psnap], "plane + prior with plane blocks": [plane_next], "lidar": [lio],
+             "no wheel": [no_wheel], "throughput batch": [with_prior if i % 3 == 0 else (plane_next if i % 3 == 1 else no_wheel) for i in range(36)]}
+    nc = 187
+    old = os.environ.pop("GFBE_ASM_FULL", None)
+
+    def run(snaps):
+        b = be.batch_upload(snaps)
+        try:
+            b.solve(abi.MARGIN_OLD)
+            res = b.download()
+            H = [np.array([b.debug_vector(1000 + a, w)[:nc] for a in range(nc)]) for w in range(min(len(snaps), 3))]
+            return _digest(res), [np.tril(h) for h in H]
+        finally:
+            b.free()
+    try:
+        for name, snaps in cases.items():
+            dig_c, H_c = run(snaps)
+            os.environ["GFBE_ASM_FULL"] = "1"
+            dig_f, H_f = run(snaps)
+            os.environ.pop("GFBE_ASM_FULL")
+            for hc, hf in zip(H_c, H_f):
+                assert np.count_nonzero(hf) > 1000, name
+                np.testing.assert_array_equal(hc, hf, err_msg=name)          # (the last linearisation's H: same bits, zeros where the compact table has no entry)
+            assert dig_c == dig_f, name
+    finally:
+        os.environ.pop("GFBE_ASM_FULL", None)
+        if old is not None:
+            os.environ["GFBE_ASM_FULL"] = old
