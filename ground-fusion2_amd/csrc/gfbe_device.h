@@ -307,6 +307,7 @@ struct BatchDev {
   double *solveY;             // [B][96][104]  Yr rows of the chain, transposed (written by the elimination, read back by the back-substitution)
   int solve_ntile;            // dense tiles (16 x 16, lower triangle incl. the right-hand side row) of the largest window: sizes the dynamic LDS
   int solve_mono;             // some window's prior couples a speed-bias block other than SpeedBias[0]: the whole batch takes the monolithic k_solve
+  int solve_tw;               // the chain eliminated from both ends (k_solve_chain_tw, one workgroup per CU): small batches, where a window's latency counts
   // debug / inspection outputs (gfbe_eval_factors)
   double *dbg_imu, *dbg_wheel, *dbg_prior;  // [B][MAX_IMU][15*31], [B][MAX_WHEEL][6*23], [B][ND]
   // marginalisation

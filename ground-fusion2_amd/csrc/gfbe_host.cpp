@@ -229,7 +229,7 @@ void gfbe_default_options(gfbe_options *o) {
   o->use_graph = 0;                          // 1: replay the fixed launch sequence of gfbe_batch_solve as a hipGraph (measured: no gain)
   o->max_solver_time_in_seconds = 0.0;       // no cap (the reference: SOLVER_TIME = 0.04, estimator.cpp:3369-3376)
   o->host_threads = 0;                       // packing threads: min(hardware threads, 24)
-  o->solve_kernel = 0;                       // chain-eliminated factorisation of the reduced system (k_solve_chain)
+  o->solve_kernel = 0;                       // chain-eliminated factorisation of the reduced system (k_solve_chain_tw below 32 windows, k_solve_chain from there)
   o->test_fail_chol_iter = 0; o->test_fail_chol_count = 1;
   o->sharded_mu_retries = 1;                 // (8 = DoglegStrategy's whole mu ladder; every retry is three more launches per linearisation)
 }
@@ -1063,6 +1063,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       for (int q = 0; q < ds.prior_nblk; q++) if (ds.prior_blk_id[q] > GFBE_BLK_SB0 && ds.prior_blk_id[q] < GFBE_BLK_EX_CAM) mono = 1;
     }
     d.solve_ntile = ntile; d.solve_mono = mono;
+    // the chain kernel of the batch: the twisted one (both ends at once, eight waves, one workgroup per CU) where a window's latency
+    // counts — below DENSE_SPLIT_MIN_B windows, like the rest of the small-batch kernel set —, the classic one for throughput
+    d.solve_tw = c->opt.solve_kernel == 3 || (c->opt.solve_kernel != 2 && B < DENSE_SPLIT_MIN_B);
     // the assembly table of the context: the compact one unless a prior couples a speed-bias block other than SpeedBias[0] (entries
     // outside the set it lists) or the batch carries GNSS dims
     bool prior_sb = false;

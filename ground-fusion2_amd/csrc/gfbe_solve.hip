@@ -579,6 +579,9 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 #define GFBE_ROLE_FN __noinline__
 #endif
 #define S2_WAVES (S2_THREADS >> 6)
+#ifndef GFBE_CHAIN_ROT
+#define GFBE_CHAIN_ROT 2      // 0: wave w takes role w; k > 0: the chain role on SIMD k x (wave slot) mod 4 (see k_solve_chain)
+#endif
 enum { CH_NB = 9, CH_NC = NF, CH_ROWS = CH_NB * CH_NC, CH_BLK = CH_NB * CH_NB, RING_ROWS = 12,
        S2_MAX_NT = 6, S2_MAX_TILES = S2_MAX_NT * (S2_MAX_NT + 1) / 2, GYT_LD = 104, GYT_COLS = TB * S2_MAX_NT };
 // row stride of the Yr ring: >= 16 x tile columns and = 16 (mod 32) doubles, so that the two row groups a half-wave reads as a
@@ -697,34 +700,92 @@ __device__ __forceinline__ bool chain_block(lds_double *A, lds_double *Cb, lds_d
 #define RSTAMP(cond, i) do { } while (0)
 #endif
 #define CH_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// ---- the roles of the chain pipeline (k_solve_chain). Each is out of line — its own register allocation — and each passes
-// exactly CH_NC + 2 block barriers.
-__device__ GFBE_ROLE_FN void chain_role(lds_double *Ach, lds_double *Cch, lds_int *flag, int lane, double *rstamp) {
-  for (int s = 0; s <= CH_NC + 1; s++) {
-    const int k = CH_NC - 1 - s;
-    RSTAMP(lane == 0, 32 + s);
-    if (k >= 0) {
-      if (!chain_block(Ach + k * CH_BLK, Cch + k * CH_BLK, Ach + (k > 0 ? k - 1 : 0) * CH_BLK, lane, k > 0) && lane == 0) *flag = 1;
+// The chain's back-substitution along one segment, one wave: x_k0 is final; x_k = a_k - G_k x_(k - dk) for the cnt blocks k = k0 + dk,
+// k0 + 2 dk, ... (a_k in xs on entry, x_k on exit; G_k in block k's coupling slot). One 9 x 9 matrix-vector product per block on the
+// sequential path, the vector travelling by DPP row broadcasts.
+__device__ __forceinline__ void chain_backsub(const lds_double *Cch, lds_double *xs, int k0, int dk, int cnt, int lane) {
+  const int li = lane & 15;
+  const int lio = li < CH_NB ? li : 0;
+  double x = xs[k0 * CH_NB + lio];
+  double gn[CH_NB], gc[CH_NB];
+#pragma unroll
+  for (int m = 0; m < CH_NB; m++) gn[m] = -Cch[(k0 + dk) * CH_BLK + lio * CH_NB + m];
+  for (int j = 1; j <= cnt; j++) {
+    const int k = k0 + dk * j;
+    double acc = xs[k * CH_NB + lio];
+#pragma unroll
+    for (int m = 0; m < CH_NB; m++) gc[m] = gn[m];
+    if (j < cnt) {
+#pragma unroll
+      for (int m = 0; m < CH_NB; m++) gn[m] = -Cch[(k + dk) * CH_BLK + lio * CH_NB + m];
     }
-    RSTAMP(lane == 0 && s < 6, 46 + s);
-    CH_LDS_BARRIER();
+#pragma unroll
+    for (int m = 0; m < CH_NB; m++) asm volatile("" : "+v"(gc[m]));
+    asm volatile("" : "+v"(x), "+v"(acc));
+    asm volatile("s_nop 4" ::: "memory");
+    dpp_fmac2<0>(acc, x, gc[0]); dpp_fmac2<1>(acc, x, gc[1]); dpp_fmac2<2>(acc, x, gc[2]);
+    dpp_fmac2<3>(acc, x, gc[3]); dpp_fmac2<4>(acc, x, gc[4]); dpp_fmac2<5>(acc, x, gc[5]);
+    dpp_fmac2<6>(acc, x, gc[6]); dpp_fmac2<7>(acc, x, gc[7]); dpp_fmac2<8>(acc, x, gc[8]);
+    x = acc;
+    if (lane < CH_NB) xs[k * CH_NB + lane] = x;
   }
 }
-// Wide rows and the dense update, waves 1..3 (wv = 0..2): wave wv forms the column tiles wv and wv + 3 of Yr (16 dense columns each,
-// the right-hand side is column n) and adds every third tile of the dense update D -= sum_k Yr_k^T Yr_k one step later, both
+// ---- the roles of the chain pipeline (k_solve_chain, k_solve_chain_tw). Each is out of line — its own register allocation — and each
+// passes exactly ChainCfg<TW>::STEPS block barriers.
+//
+// Chain SEGMENTS. Classic (TW = 0, k_solve_chain): ONE segment, blocks CH_NC-1 down to 0 — eleven sequential 9-pivot steps.
+// Twisted (TW = 1, k_solve_chain_tw: the latency variant of small batches): the block-tridiagonal chain is eliminated from BOTH ends
+// at once by two chain waves — segment 0: blocks CH_NC-1 down to CH_MID, segment 1: blocks 0 up to CH_MID-1 — and the middle block
+// is the last one of segment 0, downdated by both of its neighbours (segment 1 leaves its downdate in `Amid`): six sequential steps
+// instead of eleven. Every segment has its own wide waves, its own ring of Yr rows and its own accumulators of the dense update;
+// the middle block's wide row takes the second product -Yc'_(CH_MID-1)^T Yr_(CH_MID-1) from the other segment's ring.
+// The coupling slot of block k holds S(SB_k, successor of k in its segment): SB_k-1 in segment 0, SB_k+1 in segment 1.
+enum { CH_MID = 5 };
+template <int TW> struct ChainCfg {
+  static constexpr int NB0 = TW ? CH_NC - CH_MID : CH_NC;     // blocks of segment 0 (descending from CH_NC - 1)
+  static constexpr int NB1 = TW ? CH_MID : 0;                  // blocks of segment 1 (ascending from 0)
+  static constexpr int STEPS = NB0 + 2;                        // block barriers of the pipeline (chain | wide rows | dense update: two steps of tail)
+};
+template <int TW, int SEG>
+__device__ GFBE_ROLE_FN void chain_role(lds_double *Ach, lds_double *Cch, lds_double *Amid, lds_int *flag, int lane, double *rstamp) {
+  constexpr int NB = SEG == 0 ? ChainCfg<TW>::NB0 : ChainCfg<TW>::NB1;
+  for (int s = 0; s < ChainCfg<TW>::STEPS; s++) {
+    RSTAMP(lane == 0 && SEG == 0, 32 + s);
+    if (s < NB) {
+      const int k = SEG == 0 ? CH_NC - 1 - s : s;
+      const bool has_next = SEG == 0 ? s + 1 < NB : true;
+      lds_double *An = SEG == 0 ? Ach + (k > 0 ? k - 1 : 0) * CH_BLK : (k + 1 == CH_MID ? Amid : Ach + (k + 1) * CH_BLK);
+      if (TW && SEG == 0 && k == CH_MID) {          // the middle block: segment 1's downdate (written one barrier ago)
+        for (int e = lane; e < CH_BLK; e += 64) Ach[k * CH_BLK + e] += Amid[e];
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (!chain_block(Ach + k * CH_BLK, Cch + k * CH_BLK, An, lane, has_next) && lane == 0) *flag = 1;
+    }
+    RSTAMP(lane == 0 && SEG == 0 && s < 6, 46 + s);
+    CH_LDS_BARRIER();
+  }
+  if (TW) CH_LDS_BARRIER();      // (the segments' accumulators are subtracted from the dense tiles one after the other: wide_role)
+}
+// Wide rows and the dense update of one segment, three waves (wv = 0..2): wave wv forms the column tiles wv and wv + 3 of Yr (16 dense
+// columns each, the right-hand side is column n) and adds every third tile of the dense update D -= sum_k Yr_k^T Yr_k one step later, both
 // operands from the two-block ring of Yr in LDS. Lane (lr, lk) holds rows lk, lk + 4, lk + 8 of column 16 c + lr — the operand
-// layout of v_mfma_f64_16x16x4_f64 for every product here and the layout of its result, so Yr_k+1 never leaves the registers.
+// layout of v_mfma_f64_16x16x4_f64 for every product here and the layout of its result, so Yr of the previous block never leaves the
+// registers.
 // A lone wave issues ONE instruction every ~5.4 cycles whatever it is (profiles/ubench/dp_issue_rate_mi355x.txt), so the loop is
 // written for instruction count and without divergent branches: pointers into H, into the chain blocks and into the transposed
 // Yr rows advance by a per-lane constant per block; lanes outside a 9 x 9 block read a zero slot of LDS (stride 0) and write to a
 // dump slot. (Inactive speed-bias dims: H holds exact zeros there.)
-// Returns the lane's share of v^T S v over the coupling entries it loads; |z_chain|^2 goes to *zzc_out.
-#define S2_WIDE_WAVES (S2_WAVES - 1)
+// Returns the lane's share of v^T S v over the coupling entries it loads; |z|^2 of the segment's chain rows goes to *zzc_out.
+#define S2_WIDE_WAVES 3
 #define S2_TPW ((S2_MAX_TILES + S2_WIDE_WAVES - 1) / S2_WIDE_WAVES)
 enum { CH_ZERO = 96 };     // doubles behind the chain blocks: a zero slot (first half: parked operand reads reach 36 doubles in) and a dump slot
-__device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds_double *Cch, lds_double *ring, lds_double *zslot, const lds_double *sS,
-                                         const lds_double *vS, const lds_double *rS, const lds_short *perm, const lds_int *s_lo, lds_double *zzc_out,
-                                         const glb_double *H, glb_double *gYT, int n_, int nt_, int ring_ld_, int wv_, int lane, double *rstamp) {
+template <int TW, int SEG>
+__device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds_double *Cch, lds_double *ring, const lds_double *ring_other, lds_double *zslot,
+                                         const lds_double *sS, const lds_double *vS, const lds_double *rS, const lds_short *perm, const lds_int *s_lo,
+                                         lds_double *zzc_out, const glb_double *H, glb_double *gYT, int n_, int nt_, int ring_ld_, int wv_, int lane, double *rstamp) {
+  constexpr int NB = SEG == 0 ? ChainCfg<TW>::NB0 : ChainCfg<TW>::NB1;     // blocks of this segment
+  constexpr int KF = SEG == 0 ? CH_NC - 1 : 0, SG = SEG == 0 ? -1 : 1;     // its first block, and the step to the next one
   // (wave-uniform values in scalar registers: the compiler cannot see that they are uniform — they come from LDS / the thread
   //  index — and would turn every branch on them into an EXEC-masked region)
   const int n = __builtin_amdgcn_readfirstlane(n_), nt = __builtin_amdgcn_readfirstlane(nt_);
@@ -748,12 +809,12 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
     const int bj = dense_col ? perm[jc[u]] : 0;
     sbj[u] = dense_col ? sS[bj] : 0.0; vbj2[u] = dense_col ? 2.0 * vS[bj] : 0.0;
     mrhs[u] = (on[u] && jc[u] == n) ? 1.0 : 0.0;
-    const int a0 = T_SB(CH_NC - 1) + lk;
+    const int a0 = T_SB(KF) + lk;
     dH[u] = bj < T_SB(0) ? ND : 1;
     pH[u] = H + (bj < T_SB(0) ? (size_t)a0 * ND + bj : (size_t)bj * ND + a0);
-    glb_double *col = gYT + (size_t)(col_on ? jc[u] : GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB;    // (column 95 is never a system column: the dump)
+    glb_double *col = gYT + (size_t)(col_on ? jc[u] : GYT_COLS - 1) * GYT_LD + KF * CH_NB;    // (column 95 is never a system column: the dump)
     pY[u] = col + lk;
-    pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB + 8;
+    pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYT_COLS - 1) * GYT_LD + KF * CH_NB + 8;
     pR[u] = ring + lk * ring_ld + min(TB * c, ring_ld - TB) + lr;
   }
   double yv[2][3], rpre[2][3], vsv = 0.0, zzc = 0.0;
@@ -767,21 +828,21 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
   auto load_R = [&](int u, double (&r)[3]) {
     const double r2 = pH[u][8 * dH[u]];
     r[0] = pH[u][0]; r[1] = pH[u][4 * dH[u]]; r[2] = lk == 0 ? r2 : 0.0;
-    pH[u] -= CH_NB * dH[u];
+    pH[u] += SG * CH_NB * dH[u];
   };
 #pragma unroll
   for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rpre[u]);
-  // operand pointers into the chain blocks (block CH_NC - 1 first; per-lane stride, 0 for the lanes parked on the zero slot)
-  //   a2[kk] = W_k[lr][4 kk + lk]        a1[kk] = -Yc_k+1[4 kk + lk][lr]      (G: W_kG[4 kk + lk][lr], Yc_kG[4 kk + lk][lr])
-  const int sW01 = in01 ? CH_BLK : 0, sW2 = in2 ? CH_BLK : 0;
-  const lds_double *pW01 = in01 ? Ach + (CH_NC - 1) * CH_BLK + lr * CH_NB + lk : zslot;
-  const lds_double *pW2 = in2 ? Ach + (CH_NC - 1) * CH_BLK + lr * CH_NB + 8 : zslot;
-  const lds_double *pC01 = in01 ? Cch + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot;      // (block k + 1 = CH_NC - 1 is first used at the second step)
-  const lds_double *pC2 = in2 ? Cch + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
-  const lds_double *pT01 = in01 ? Ach + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot;      // W transposed access for G (block kG)
-  const lds_double *pT2 = in2 ? Ach + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
-  lds_double *pG01 = in01 ? Cch + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot + CH_ZERO / 2;   // G output (block kG), or the dump half of the slot
-  lds_double *pG2 = in2 ? Cch + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot + CH_ZERO / 2;
+  // operand pointers into the chain blocks (block KF first; per-lane stride, 0 for the lanes parked on the zero slot)
+  //   a2[kk] = W_k[lr][4 kk + lk]        a1[kk] = -Yc_prev[4 kk + lk][lr]      (G: W_kG[4 kk + lk][lr], Yc_kG[4 kk + lk][lr])
+  const int sW01 = in01 ? SG * CH_BLK : 0, sW2 = in2 ? SG * CH_BLK : 0;
+  const lds_double *pW01 = in01 ? Ach + KF * CH_BLK + lr * CH_NB + lk : zslot;
+  const lds_double *pW2 = in2 ? Ach + KF * CH_BLK + lr * CH_NB + 8 : zslot;
+  const lds_double *pC01 = in01 ? Cch + KF * CH_BLK + lk * CH_NB + lr : zslot;      // (the previous block's Yc: first used at the segment's second block)
+  const lds_double *pC2 = in2 ? Cch + KF * CH_BLK + 8 * CH_NB + lr : zslot;
+  const lds_double *pT01 = in01 ? Ach + KF * CH_BLK + lk * CH_NB + lr : zslot;      // W transposed access for G (block kG)
+  const lds_double *pT2 = in2 ? Ach + KF * CH_BLK + 8 * CH_NB + lr : zslot;
+  lds_double *pG01 = in01 ? Cch + KF * CH_BLK + lk * CH_NB + lr : zslot + CH_ZERO / 2;   // G output (block kG), or the dump half of the slot
+  lds_double *pG2 = in2 ? Cch + KF * CH_BLK + 8 * CH_NB + lr : zslot + CH_ZERO / 2;
   const double m2 = lk == 0 ? 1.0 : 0.0;     // (row 8 + lk exists for lk == 0 only)
   // ---- dense update: tiles e = wv, wv + 3, ... of the lower triangle
   dbl4 acc[S2_TPW];
@@ -796,12 +857,16 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
     oI[q] = TB * I; oJ[q] = TB * J; tJ1[q] = v ? TB * (J + 1) : 0;     // (tJ1 = 0: never above lo_k >= 0 -> skipped)
   }
   const int ro = lk * ring_ld + lr, rblk = RING_ROWS * ring_ld;
-  for (int s = 0; s <= CH_NC + 1; s++) {
-    // (1) dense update with Yr of block kg (in the ring since the previous step)
-    const int kg = CH_NC + 1 - s;
-    if (kg >= 0 && kg < CH_NC) {
+  // first dense column block k can reach: the poses of frames >= k - 1 in the descending segment (s_lo); everything in the ascending
+  // one (the prior couples SpeedBias[0] with all it kept) and, twisted, in the middle block that inherits from it
+  auto lo_of = [&](int k) -> int { return (SEG == 1 || (TW && k == CH_MID)) ? 0 : __builtin_amdgcn_readfirstlane(s_lo[k]); };
+  for (int s = 0; s < ChainCfg<TW>::STEPS; s++) {
+    // (1) dense update with Yr of the block two positions back (in the ring since the previous step)
+    const int pg = s - 2;
+    if (pg >= 0 && pg < NB) {
+      const int kg = KF + SG * pg;
       const lds_double *rg = ring + (kg & 1) * rblk + ro;
-      const int lo = __builtin_amdgcn_readfirstlane(s_lo[kg]);
+      const int lo = lo_of(kg);
 #pragma unroll
       for (int q = 0; q < S2_TPW; q++) {
         if (tJ1[q] <= lo) continue;                               // (columns below lo_kg are zero in Yr_kg; wave-uniform)
@@ -812,15 +877,22 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
         for (int kk = 0; kk < 3; kk++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc[q], 0, 0, 0);
       }
     }
-    // (2) Yr of block k: R' = R_k - Yc_k+1^T Yr_k+1, Yr_k = W_k R'
-    const int k = CH_NC - s;
-    if (k >= 0 && k < CH_NC) {
-      const int lo = __builtin_amdgcn_readfirstlane(s_lo[k]);
+    // (2) Yr of the block one position back: R' = R_k - Yc_prev^T Yr_prev, Yr_k = W_k R'
+    const int pk = s - 1;
+    if (pk >= 0 && pk < NB) {
+      const int k = KF + SG * pk;
+      const int lo = lo_of(k);
       double a1[3], a2[3];
       a2[0] = pW01[0]; a2[1] = pW01[4]; a2[2] = pW2[0];
-      if (k + 1 < CH_NC) { a1[0] = -pC01[0]; a1[1] = -pC01[4 * CH_NB]; a1[2] = -pC2[0]; pC01 -= sW01; pC2 -= sW2; }
+      if (pk > 0) { a1[0] = -pC01[0]; a1[1] = -pC01[4 * CH_NB]; a1[2] = -pC2[0]; pC01 += sW01; pC2 += sW2; }
       else { a1[0] = 0.0; a1[1] = 0.0; a1[2] = 0.0; }
-      pW01 -= sW01; pW2 -= sW2;
+      pW01 += sW01; pW2 += sW2;
+      const bool mid = TW && SEG == 0 && k == CH_MID;            // (wave-uniform; the middle block of the twisted chain: a second predecessor)
+      double b1[3] = {0.0, 0.0, 0.0};
+      if (mid) {
+        const lds_double *cm01 = in01 ? Cch + (CH_MID - 1) * CH_BLK + lk * CH_NB + lr : zslot, *cm2 = in2 ? Cch + (CH_MID - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
+        b1[0] = -cm01[0]; b1[1] = -cm01[4 * CH_NB]; b1[2] = -cm2[0];
+      }
       double sk[3], vk[3], rk[3];
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) { const int a = T_SB(k) + min(lk + 4 * kk, CH_NB - 1); sk[kk] = sS[a]; vk[kk] = vS[a]; rk[kk] = rS[a]; }
@@ -834,14 +906,19 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
         double r[3];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) r[kk] = __builtin_fma(rpre[u][kk] * sk[kk], m1, mr * rk[kk]);
-        load_R(u, rpre[u]);                                        // (block k - 1; in flight during this block's products. The loads of
-                                                                   //  the step after block 0 read valid, unused rows of H)
+        load_R(u, rpre[u]);                                        // (the next block; in flight during this block's products. The loads of
+                                                                   //  the step after the last block read valid, unused rows of H)
         if (!zero_tile) {
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) vsv = __builtin_fma(r[kk] * vk[kk], vbj2[u], vsv);
           dbl4 rp = {r[0], r[1], r[2], 0.0};
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], yv[u][kk], rp, 0, 0, 0);
+          if (mid) {                                               // - Yc'^T Yr of the other segment's last block, from its ring
+            const lds_double *ro2 = ring_other + ((CH_MID - 1) & 1) * rblk + lk * ring_ld + min(TB * (wv + S2_WIDE_WAVES * u), ring_ld - TB) + lr;
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kk], ro2[4 * kk * ring_ld], rp, 0, 0, 0);
+          }
           dbl4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) y = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kk], rp[kk], y, 0, 0, 0);
@@ -857,27 +934,27 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
           for (int kk = 0; kk < 3; kk++) yv[u][kk] = 0.0;
         }
         pY[u][0] = yv[u][0]; pY[u][4] = yv[u][1]; pY8[u][0] = yv[u][2];
-        pY[u] -= CH_NB; pY8[u] -= CH_NB;
+        pY[u] += SG * CH_NB; pY8[u] += SG * CH_NB;
       }
     }
-    // (3) G_kG = W_kG^T Yc_kG in place of Yc_kG, one step after its last reader (the wide rows of block kG - 1): the chain's
-    //     back-substitution then needs one matrix-vector product per block
-    const int kG = CH_NC - s + 2;
-    if (wv == S2_WIDE_WAVES - 1 && kG >= 1 && kG < CH_NC) {
-      const int off = (kG - (CH_NC - 1));                          // (<= 0) blocks below the first one
-      const lds_double *t01 = pT01 + off * sW01, *t2 = pT2 + off * sW2, *c01 = pG01 + off * sW01, *c2 = pG2 + off * sW2;
+    // (3) G_kG = W_kG^T Yc_kG in place of Yc_kG, one step after its last reader (the wide rows of the next block): the chain's
+    //     back-substitution then needs one matrix-vector product per block. (The last block of segment 0 has no successor, no Yc.)
+    const int pG = s - 3;
+    if (wv == S2_WIDE_WAVES - 1 && pG >= 0 && pG < (SEG == 0 ? NB - 1 : NB)) {
+      const lds_double *t01 = pT01 + pG * sW01, *t2 = pT2 + pG * sW2, *c01 = pG01 + pG * sW01, *c2 = pG2 + pG * sW2;
       const double ag0 = t01[0], ag1 = t01[4 * CH_NB], ag2 = t2[0], bg0 = c01[0], bg1 = c01[4 * CH_NB], bg2 = c2[0];
       dbl4 gq = {0.0, 0.0, 0.0, 0.0};
       gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag0, in01 ? bg0 : 0.0, gq, 0, 0, 0);
       gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag1, in01 ? bg1 : 0.0, gq, 0, 0, 0);
       gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag2, in2 ? bg2 : 0.0, gq, 0, 0, 0);
-      lds_double *g01 = pG01 + off * sW01, *g2 = pG2 + off * sW2;
+      lds_double *g01 = pG01 + pG * sW01, *g2 = pG2 + pG * sW2;
       g01[0] = gq[0]; g01[4 * CH_NB] = gq[1]; g2[0] = gq[2];
     }
-    RSTAMP(wv == 1 && lane == 0 && s < 12, 52 + s);
+    RSTAMP(SEG == 0 && wv == 1 && lane == 0 && s < 12, 52 + s);
     CH_LDS_BARRIER();
   }
-  // dense tiles -= the accumulated products
+  // dense tiles -= the accumulated products (twisted: segment 0 first, segment 1 one barrier later — the same tiles)
+  if (TW && SEG == 1) CH_LDS_BARRIER();
 #pragma unroll
   for (int q = 0; q < S2_TPW; q++) {
     if (tJ1[q] == 0) continue;
@@ -885,6 +962,7 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
 #pragma unroll
     for (int r = 0; r < 4; r++) C[tsw(lk + 4 * r, lr)] -= acc[q][r];
   }
+  if (TW && SEG == 0) CH_LDS_BARRIER();
   // |z_chain|^2: the four lanes (lk = 0..3) of the right-hand side column
   zzc += __shfl_xor(zzc, 16, 64);
   zzc += __shfl_xor(zzc, 32, 64);
@@ -893,7 +971,12 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
   return vsv;
 }
 
-__global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int retry_pass) {
+// TW = 0: k_solve_chain (four waves: the chain role, three wide waves; two workgroups per CU — throughput batches).
+// TW = 1: k_solve_chain_tw (eight waves: two chain roles, three wide waves per segment; one workgroup per CU — small batches, where one
+//         window's latency counts: the chain is eliminated from both ends, ChainCfg above).
+template <int TW>
+__device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pass) {
+  constexpr int NWAVES = TW ? 2 * S2_WAVES : S2_WAVES;
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
@@ -903,12 +986,35 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
   __shared__ short perm[ND + TB];
   __shared__ double red[16], ys[ND + TB];                        // ys: the solution of the dense part (tile order)
   __shared__ double sS[ND], vS[ND], dS[ND], gS[ND], rS[ND], yT[ND];   // per tangent dim: Jacobi scale, Cauchy direction, D, scaled gradient, right-hand side, GN step
-  __shared__ double s_zz, s_zzc, s_vSv, zlast[TB], xs[CH_ROWS + 16], tch[CH_ROWS + 16], cterm[64];
+  __shared__ double s_zz, s_zzc[2], s_vSv, zlast[TB], xs[CH_ROWS + 16], tch[CH_ROWS + 16], cterm[64];
   __shared__ double s_keep[4];
   __shared__ int flag, s_nact, s_nch, s_lo[CH_NC + 1];
   __shared__ unsigned long long s_mask0;
   __shared__ unsigned char chact[CH_ROWS + 1];
-  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // Roles by SIMD (GFBE_CHAIN_ROT): the chain role (and the diagonal-tile step of the dense factorisation after it) is ONE wave's
+  // sequential instruction stream, and the hardware starts the four waves of every workgroup on the four SIMDs in the same order —
+  // the chain waves of the workgroups that share a CU would sit on one SIMD and halve each other's issue rate while the other three
+  // SIMDs run the mostly idle wide waves. Every wave reads the SIMD and the wave slot it runs on (HW_ID); the chain role goes to the
+  // wave on SIMD 2 x (slot of wave 0) mod 4 — co-resident workgroups occupy different slots — and the wide roles follow in order.
+  // `t` is the thread index after that rotation of the waves: everything below deals work, LDS slots and the order of every sum by
+  // it, so the result does not depend on the rotation (same operations in the same order, whatever wave runs a role).
+  int t = threadIdx.x;
+#if GFBE_CHAIN_ROT
+  if (!TW) {
+    __shared__ int s_hw[S2_WAVES];
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const int pw = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) s_hw[pw] = (int)hw;
+    __syncthreads();
+    const int target = (GFBE_CHAIN_ROT * (s_hw[0] & 15)) & 3;      // (slot of wave 0) x 2: SIMD 0 / SIMD 2 for the two workgroups of a CU
+    int pc = 0;
+#pragma unroll
+    for (int q = S2_WAVES - 1; q >= 0; q--) if (((s_hw[q] >> 4) & 3) == target) pc = q;
+    t = (((pw - pc) & (S2_WAVES - 1)) << 6) | (threadIdx.x & 63);
+  }
+#endif
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
   double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
@@ -923,6 +1029,8 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
   double *Cch = Ach + CH_NC * CH_BLK;
   double *zslot = Cch + CH_NC * CH_BLK;
   double *ring = zslot + CH_ZERO;
+  double *ring1 = ring + 2 * RING_ROWS * chain_ring_ld(d.solve_ntile);      // (twisted: segment 1's ring, then the middle block's second downdate)
+  double *Amid = ring1 + 2 * RING_ROWS * chain_ring_ld(d.solve_ntile);
   if (t < CH_ZERO) zslot[t] = 0.0;
 
   // dense dims (active, not in the chain) by a wave-level prefix count (dims 0..191 live in waves 0..2); chain activity flags
@@ -995,7 +1103,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
   }
   {
     const double pv[3] = {g2, gmax, xn2};
-    block_reduce_multi<3>(pv, 0x2u, smem);
+    block_reduce_multi_t<3>(pv, 0x2u, smem, t);
     if (t == 0) { s_keep[0] = smem[48]; s_keep[1] = smem[49]; s_keep[2] = smem[50]; }   // (needed at the very end: parked in LDS, not in registers)
   }
   __syncthreads();
@@ -1079,11 +1187,13 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
           }
         }
       }
-      if (chain_on && tt < 3 * CH_BLK) {
-        // chain blocks: the 22 blocks A_0..A_10, C_1..C_10 (C_k = S(SB_k, SB_k-1); slot 0 of the couplings is unused) are dealt over
-        // three thread groups of 81 — a thread keeps its entry (i, j) and takes every third block (inactive dims: H holds exact
-        // zeros there, the diagonal becomes 1)
-        const int grp = tt / CH_BLK, e81 = tt - CH_BLK * grp, ei = e81 / CH_NB, ej = e81 - CH_NB * ei;
+      const int tc = TW ? tt - TB * TB : tt;          // (twisted: the second half of the workgroup, beside the dense tiles)
+      if (chain_on && tc >= 0 && tc < 3 * CH_BLK) {
+        // chain blocks: the 22 blocks A_0..A_10, C_0..C_10 (C_k = S(SB_k, SB_k-1); slot 0 of the couplings is unused — twisted: C_k =
+        // S(SB_k, SB_k+1) below the middle block, whose own slot is the unused one) are dealt over three thread groups of 81 — a thread
+        // keeps its entry (i, j) and takes every third block (inactive dims: H holds exact zeros there, the diagonal becomes 1)
+        const int grp = tc / CH_BLK, e81 = tc - CH_BLK * grp, ei = e81 / CH_NB, ej = e81 - CH_NB * ei;
+        auto partner = [](int k) -> int { return TW ? (k > CH_MID ? k - 1 : (k < CH_MID ? k + 1 : k)) : (k > 0 ? k - 1 : 0); };
         constexpr int NQ = (2 * CH_NC + 2) / 3;
         double hc[NQ];
 #pragma unroll
@@ -1091,7 +1201,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
           const int kb = grp + 3 * q;                     // block slot: 0..10 diagonal blocks, 11..21 couplings
           const bool isC = kb >= CH_NC;
           const int k = isC ? kb - CH_NC : kb;
-          const int a = T_SB(min(k, CH_NC - 1)) + ei, b = (isC ? T_SB(k > 0 ? min(k, CH_NC - 1) - 1 : 0) : T_SB(min(k, CH_NC - 1))) + ej;
+          const int a = T_SB(min(k, CH_NC - 1)) + ei, b = (isC ? T_SB(partner(min(k, CH_NC - 1))) : T_SB(min(k, CH_NC - 1))) + ej;
           hc[q] = H[(size_t)max(a, b) * ND + min(a, b)];
         }
 #pragma unroll
@@ -1100,16 +1210,17 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
           if (kb >= 2 * CH_NC) continue;
           const bool isC = kb >= CH_NC;
           const int k = isC ? kb - CH_NC : kb;
-          const int a = T_SB(k) + ei, b = (isC ? T_SB(k > 0 ? k - 1 : 0) : T_SB(k)) + ej;
+          const int a = T_SB(k) + ei, b = (isC ? T_SB(partner(k)) : T_SB(k)) + ej;
           double v = hc[q] * sS[a] * sS[b];
-          if (isC) { if (k == 0) v = 0.0; }
+          if (isC) { if (k == (TW ? CH_MID : 0)) v = 0.0; }
           else if (ei == ej) v = chact[a - T_SB(0)] ? __builtin_fma(mu * dS[a], dS[a], v) : 1.0;
           vsv = __builtin_fma(v * vS[a], vS[b] * (isC ? 2.0 : 1.0), vsv);
           (isC ? Cch : Ach)[k * CH_BLK + e81] = v;
         }
       }
     }
-    if (t == 0) { flag = 0; s_zzc = 0.0; }
+    if (t == 0) { flag = 0; s_zzc[0] = 0.0; s_zzc[1] = 0.0; }
+    if (TW && t < CH_BLK) Amid[t] = 0.0;
 #if GFBE_CHAIN_STAMP
     if (t == 0) stamp[11] = (double)wall_clock64();
 #endif
@@ -1119,17 +1230,26 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
       // ---- the pipeline over the chain blocks, one block barrier per block (the roles are separate functions with their own
       //      register allocation; every role passes the same CH_NC + 2 barriers):
       //   step s: wave 0 factorises block NC-1-s | waves 1..3 form Yr of block NC-s and add Yr^T Yr of block NC+1-s
-      if (wave == 0) chain_role((lds_double *)Ach, (lds_double *)Cch, (lds_int *)&flag, lane, stamp);
-      else
-        vsv += wide_role((lds_double *)tiles, (lds_double *)Ach, (lds_double *)Cch, (lds_double *)ring, (lds_double *)zslot, (const lds_double *)sS,
-                         (const lds_double *)vS, (const lds_double *)rS, (const lds_short *)perm, (const lds_int *)s_lo, (lds_double *)&s_zzc,
-                         (const glb_double *)H, (glb_double *)gYT, n, nt, chain_ring_ld(d.solve_ntile), wave - 1, lane, stamp);
+#define WIDE_ARGS(rg, rgo, seg) (lds_double *)tiles, (lds_double *)Ach, (lds_double *)Cch, (lds_double *)(rg), (const lds_double *)(rgo), (lds_double *)zslot, \
+                         (const lds_double *)sS, (const lds_double *)vS, (const lds_double *)rS, (const lds_short *)perm, (const lds_int *)s_lo,           \
+                         (lds_double *)&s_zzc[seg], (const glb_double *)H, (glb_double *)gYT, n, nt, chain_ring_ld(d.solve_ntile)
+      if (!TW) {
+        if (wave == 0) chain_role<0, 0>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
+        else vsv += wide_role<0, 0>(WIDE_ARGS(ring, ring, 0), wave - 1, lane, stamp);
+      } else {
+        // waves 0, 1: the chain roles of the two segments; 2..4: segment 0's wide waves; 5..7: segment 1's
+        if (wave == 0) chain_role<TW, 0>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
+        else if (wave == 1) chain_role<TW, 1>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
+        else if (wave < 2 + S2_WIDE_WAVES) vsv += wide_role<TW, 0>(WIDE_ARGS(ring, ring1, 0), wave - 2, lane, stamp);
+        else vsv += wide_role<TW, 1>(WIDE_ARGS(ring1, ring, 1), wave - 2 - S2_WIDE_WAVES, lane, stamp);
+      }
+#undef WIDE_ARGS
     }
-    vsv = block_sum(vsv, red);
+    vsv = block_sum_t(vsv, red, t);
     if (t == 0) s_vSv = vsv;
     __syncthreads();
     STAMP(15);
-    chol_factor_all<S2_WAVES>((lds_double *)tiles, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
+    chol_factor_all<NWAVES>((lds_double *)tiles, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
     bool ok = (flag == 0);
     if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && (d.sharded ? retry_pass : att) < max(d.opt.test_fail_chol_count, 1)) ok = false;
     STAMP(3);
@@ -1140,8 +1260,8 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
         ys[i] = z;
         zz += z * z;
       }
-      zz = block_sum(zz, red);
-      if (t == 0) s_zz = zz + s_zzc;
+      zz = block_sum_t(zz, red, t);
+      if (t == 0) s_zz = zz + (s_zzc[0] + s_zzc[1]);
       __syncthreads();
       if (wave == 0) {
         const int cI = lane & 15, part = lane >> 4;
@@ -1205,32 +1325,10 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
           xs[t] = a;
         }
         __syncthreads();
-        if (wave == 0) {
-          const int li = lane & 15;
-          const int lio = li < CH_NB ? li : 0;
-          double x = xs[lio];
-          double gn[CH_NB], gc[CH_NB];
-#pragma unroll
-          for (int m = 0; m < CH_NB; m++) gn[m] = -Cch[1 * CH_BLK + lio * CH_NB + m];
-          for (int k = 1; k < CH_NC; k++) {
-            double acc = xs[k * CH_NB + lio];
-#pragma unroll
-            for (int m = 0; m < CH_NB; m++) gc[m] = gn[m];
-            if (k + 1 < CH_NC) {
-#pragma unroll
-              for (int m = 0; m < CH_NB; m++) gn[m] = -Cch[(k + 1) * CH_BLK + lio * CH_NB + m];
-            }
-#pragma unroll
-            for (int m = 0; m < CH_NB; m++) asm volatile("" : "+v"(gc[m]));
-            asm volatile("" : "+v"(x), "+v"(acc));
-            asm volatile("s_nop 4" ::: "memory");
-            dpp_fmac2<0>(acc, x, gc[0]); dpp_fmac2<1>(acc, x, gc[1]); dpp_fmac2<2>(acc, x, gc[2]);
-            dpp_fmac2<3>(acc, x, gc[3]); dpp_fmac2<4>(acc, x, gc[4]); dpp_fmac2<5>(acc, x, gc[5]);
-            dpp_fmac2<6>(acc, x, gc[6]); dpp_fmac2<7>(acc, x, gc[7]); dpp_fmac2<8>(acc, x, gc[8]);
-            x = acc;
-            if (lane < CH_NB) xs[k * CH_NB + lane] = x;
-          }
-        }
+        // classic: x_0 is final, x_k = a_k - G_k x_k-1 upwards. Twisted: x_CH_MID is final (the block eliminated last); segment 0's blocks
+        // upwards from it on wave 0, segment 1's downwards on wave 1 (x_k = a_k - G'_k x_k+1), side by side.
+        if (wave == 0) chain_backsub((const lds_double *)Cch, (lds_double *)xs, TW ? CH_MID : 0, 1, TW ? CH_NC - 1 - CH_MID : CH_NC - 1, lane);
+        else if (TW && wave == 1) chain_backsub((const lds_double *)Cch, (lds_double *)xs, CH_MID, -1, CH_MID, lane);
         __syncthreads();
       }
       // y back to the tangent dims: inactive dims get 0, every dim written once
@@ -1281,7 +1379,7 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
   }
   {
     const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
-    block_reduce_multi<8>(gv, 0u, smem);
+    block_reduce_multi_t<8>(gv, 0u, smem, t);
     n2 = smem[128]; gyv = smem[129]; vrhs = smem[130]; vDv = smem[131]; vDy = smem[132]; vEv = smem[133]; vEy = smem[134]; yEy = smem[135];
   }
   if (t == 0) {
@@ -1299,6 +1397,8 @@ __global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int r
   STAMP(5);
 #undef STAMP
 }
+__global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int retry_pass) { solve_chain_body<0>(d, retry_pass); }
+__global__ __launch_bounds__(2 * S2_THREADS, 2) void k_solve_chain_tw(BatchDev d, int retry_pass) { solve_chain_body<1>(d, retry_pass); }
 
 
 
@@ -1665,7 +1765,9 @@ static_assert(((NC + 1 + TB - 1) / TB) * (((NC + 1 + TB - 1) / TB) + 1) / 2 * TB
               + sizeof(short) * (NC + TB) + sizeof(double) * (16 + 2 * NC + TB + 2 + TB) + sizeof(int) * 6      // perm, red, ys, s_zz, s_vSv, zlast, flags
               + 128 /* alignment padding */ <= 160 * 1024, "k_solve: tiles + static LDS exceed a CU's 160 KB");
 static size_t solve_smem_bytes() { const int nt = (NC + 1 + TB - 1) / TB;   /* (k_solve never sees the GNSS dims: those batches take k_solve_big) */ return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
-static size_t chain_smem_bytes(int ntile) { return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + 2 * RING_ROWS * chain_ring_ld(ntile)); }
+static size_t chain_smem_bytes(int ntile, bool tw = false) {     // tw: k_solve_chain_tw — a second ring (segment 1) and the middle block's second downdate
+  return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + (tw ? 4 : 2) * RING_ROWS * chain_ring_ld(ntile) + (tw ? CH_BLK : 0));
+}
 size_t solve_chain_scratch_doubles() { return (size_t)GYT_COLS * GYT_LD; }
 // dense tiles a window with these active dims needs in k_solve_chain (host side of the kernel's own count)
 int solve_chain_tiles(const unsigned char *act) {
@@ -1681,11 +1783,14 @@ hipError_t kernels_init_device() {
   if (e != hipSuccess) return e;
   const hipError_t e2 = hipFuncSetAttribute((const void *)k_solve_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_MAX_TILES));
   if (e2 != hipSuccess) return e2;
+  const hipError_t e3 = hipFuncSetAttribute((const void *)k_solve_chain_tw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_MAX_TILES, true));
+  if (e3 != hipSuccess) return e3;
   return hipFuncSetAttribute((const void *)k_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_smem_bytes());
 }
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass) {
   if (d.solve_big) hipLaunchKernelGGL(k_solve_big, dim3(d.B), dim3(BIG_THREADS), big_smem_bytes(), s, d, retry_pass);
   else if (d.solve_mono) hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d, retry_pass);
+  else if (d.solve_tw) hipLaunchKernelGGL(k_solve_chain_tw, dim3(d.B), dim3(2 * S2_THREADS), chain_smem_bytes(d.solve_ntile, true), s, d, retry_pass);
   else hipLaunchKernelGGL(k_solve_chain, dim3(d.B), dim3(S2_THREADS), chain_smem_bytes(d.solve_ntile), s, d, retry_pass);
 }
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_rebuild_E_shard, dim3(d.B), dim3(1024), 0, s, d); }

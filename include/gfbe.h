@@ -264,7 +264,11 @@ typedef struct gfbe_options {
    *   0 (default)  the speed-bias blocks are eliminated as a chain of 9 x 9 blocks before the dense pose / extrinsic part is
    *                factorised (~70 KB of LDS, two workgroups per CU). Needs the structure every factor of the reference has:
    *                a prior that keeps a speed-bias block other than SpeedBias[0] switches its batch to 1 by itself.
-   *   1            one blocked factorisation of the whole reduced system (160 KB of LDS). Same step to rounding. */
+   *                Batches below 32 windows — the reference's call pattern is ONE — eliminate the chain from both ends at once
+   *                (eight waves, one workgroup per CU: 6 sequential block steps instead of 11), larger ones from one end (four waves, two
+   *                workgroups per CU: throughput). Same step to rounding.
+   *   1            one blocked factorisation of the whole reduced system (160 KB of LDS). Same step to rounding.
+   *   2 / 3        (tests, measurements) the one-ended / the two-ended chain kernel whatever the batch size. */
   int32_t solve_kernel;
   /* TEST HOOK (0 = off, the default; never set it in production): the first factorisation of trust-region iteration
    * `test_fail_chol_iter` is declared failed, so that DoglegStrategy's mu retry — which well-posed windows never take —
