@@ -366,6 +366,7 @@ void launch_marginalize_partials(const BatchDev &d, hipStream_t s);
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s);
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass = 0);
 int solve_chain_tiles(const unsigned char *act);
+bool solve_chain_tw_fits(int ntile);                // k_solve_chain_tw holds every row of Yr in LDS: up to five tile columns of the dense part
 size_t solve_chain_scratch_doubles();              // doubles of BatchDev::solveY per window   // dense 16 x 16 tiles k_solve_chain needs for a window with these active dims
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s);
 void launch_sys_pack(const BatchDev &d, int dir, hipStream_t s);   // landmark sharding: pack (0) / unpack (1) the partial system around its all-reduce

@@ -1065,7 +1065,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     d.solve_ntile = ntile; d.solve_mono = mono;
     // the chain kernel of the batch: the twisted one (both ends at once, eight waves, one workgroup per CU) where a window's latency
     // counts — below DENSE_SPLIT_MIN_B windows, like the rest of the small-batch kernel set —, the classic one for throughput
-    d.solve_tw = c->opt.solve_kernel == 3 || (c->opt.solve_kernel != 2 && B < DENSE_SPLIT_MIN_B);
+    // (a dense part of six tile columns — a free camera extrinsic — does not fit its LDS layout: the classic kernel whatever was asked)
+    d.solve_tw = (c->opt.solve_kernel == 3 || (c->opt.solve_kernel != 2 && B < DENSE_SPLIT_MIN_B)) && solve_chain_tw_fits(ntile);
     // the assembly table of the context: the compact one unless a prior couples a speed-bias block other than SpeedBias[0] (entries
     // outside the set it lists) or the batch carries GNSS dims
     bool prior_sb = false;

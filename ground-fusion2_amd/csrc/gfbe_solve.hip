@@ -737,14 +737,14 @@ __device__ __forceinline__ void chain_backsub(const lds_double *Cch, lds_double 
 // Twisted (TW = 1, k_solve_chain_tw: the latency variant of small batches): the block-tridiagonal chain is eliminated from BOTH ends
 // at once by two chain waves — segment 0: blocks CH_NC-1 down to CH_MID, segment 1: blocks 0 up to CH_MID-1 — and the middle block
 // is the last one of segment 0, downdated by both of its neighbours (segment 1 leaves its downdate in `Amid`): six sequential steps
-// instead of eleven. Every segment has its own wide waves, its own ring of Yr rows and its own accumulators of the dense update;
-// the middle block's wide row takes the second product -Yc'_(CH_MID-1)^T Yr_(CH_MID-1) from the other segment's ring.
+// instead of eleven. Every segment has its own wide waves (wide_role_tw); the middle block's wide row takes the second product
+// -Yc'_(CH_MID-1)^T Yr_(CH_MID-1) of the other segment's last block.
 // The coupling slot of block k holds S(SB_k, successor of k in its segment): SB_k-1 in segment 0, SB_k+1 in segment 1.
 enum { CH_MID = 5 };
 template <int TW> struct ChainCfg {
   static constexpr int NB0 = TW ? CH_NC - CH_MID : CH_NC;     // blocks of segment 0 (descending from CH_NC - 1)
   static constexpr int NB1 = TW ? CH_MID : 0;                  // blocks of segment 1 (ascending from 0)
-  static constexpr int STEPS = NB0 + 2;                        // block barriers of the pipeline (chain | wide rows | dense update: two steps of tail)
+  static constexpr int STEPS = TW ? NB0 + 1 : NB0 + 2;         // block barriers of the pipeline (chain | wide rows | classic: the dense update one more step behind)
 };
 template <int TW, int SEG>
 __device__ GFBE_ROLE_FN void chain_role(lds_double *Ach, lds_double *Cch, lds_double *Amid, lds_int *flag, int lane, double *rstamp) {
@@ -765,27 +765,22 @@ __device__ GFBE_ROLE_FN void chain_role(lds_double *Ach, lds_double *Cch, lds_do
     RSTAMP(lane == 0 && SEG == 0 && s < 6, 46 + s);
     CH_LDS_BARRIER();
   }
-  if (TW) CH_LDS_BARRIER();      // (the segments' accumulators are subtracted from the dense tiles one after the other: wide_role)
 }
-// Wide rows and the dense update of one segment, three waves (wv = 0..2): wave wv forms the column tiles wv and wv + 3 of Yr (16 dense
-// columns each, the right-hand side is column n) and adds every third tile of the dense update D -= sum_k Yr_k^T Yr_k one step later, both
+// Wide rows and the dense update, waves 1..3 (wv = 0..2): wave wv forms the column tiles wv and wv + 3 of Yr (16 dense columns each,
+// the right-hand side is column n) and adds every third tile of the dense update D -= sum_k Yr_k^T Yr_k one step later, both
 // operands from the two-block ring of Yr in LDS. Lane (lr, lk) holds rows lk, lk + 4, lk + 8 of column 16 c + lr — the operand
-// layout of v_mfma_f64_16x16x4_f64 for every product here and the layout of its result, so Yr of the previous block never leaves the
-// registers.
+// layout of v_mfma_f64_16x16x4_f64 for every product here and the layout of its result, so Yr_k+1 never leaves the registers.
 // A lone wave issues ONE instruction every ~5.4 cycles whatever it is (profiles/ubench/dp_issue_rate_mi355x.txt), so the loop is
 // written for instruction count and without divergent branches: pointers into H, into the chain blocks and into the transposed
 // Yr rows advance by a per-lane constant per block; lanes outside a 9 x 9 block read a zero slot of LDS (stride 0) and write to a
 // dump slot. (Inactive speed-bias dims: H holds exact zeros there.)
-// Returns the lane's share of v^T S v over the coupling entries it loads; |z|^2 of the segment's chain rows goes to *zzc_out.
+// Returns the lane's share of v^T S v over the coupling entries it loads; |z_chain|^2 goes to *zzc_out.
 #define S2_WIDE_WAVES 3
 #define S2_TPW ((S2_MAX_TILES + S2_WIDE_WAVES - 1) / S2_WIDE_WAVES)
 enum { CH_ZERO = 96 };     // doubles behind the chain blocks: a zero slot (first half: parked operand reads reach 36 doubles in) and a dump slot
-template <int TW, int SEG>
-__device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds_double *Cch, lds_double *ring, const lds_double *ring_other, lds_double *zslot,
-                                         const lds_double *sS, const lds_double *vS, const lds_double *rS, const lds_short *perm, const lds_int *s_lo,
-                                         lds_double *zzc_out, const glb_double *H, glb_double *gYT, int n_, int nt_, int ring_ld_, int wv_, int lane, double *rstamp) {
-  constexpr int NB = SEG == 0 ? ChainCfg<TW>::NB0 : ChainCfg<TW>::NB1;     // blocks of this segment
-  constexpr int KF = SEG == 0 ? CH_NC - 1 : 0, SG = SEG == 0 ? -1 : 1;     // its first block, and the step to the next one
+__device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds_double *Cch, lds_double *ring, lds_double *zslot, const lds_double *sS,
+                                         const lds_double *vS, const lds_double *rS, const lds_short *perm, const lds_int *s_lo, lds_double *zzc_out,
+                                         const glb_double *H, glb_double *gYT, int n_, int nt_, int ring_ld_, int wv_, int lane, double *rstamp) {
   // (wave-uniform values in scalar registers: the compiler cannot see that they are uniform — they come from LDS / the thread
   //  index — and would turn every branch on them into an EXEC-masked region)
   const int n = __builtin_amdgcn_readfirstlane(n_), nt = __builtin_amdgcn_readfirstlane(nt_);
@@ -809,12 +804,12 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
     const int bj = dense_col ? perm[jc[u]] : 0;
     sbj[u] = dense_col ? sS[bj] : 0.0; vbj2[u] = dense_col ? 2.0 * vS[bj] : 0.0;
     mrhs[u] = (on[u] && jc[u] == n) ? 1.0 : 0.0;
-    const int a0 = T_SB(KF) + lk;
+    const int a0 = T_SB(CH_NC - 1) + lk;
     dH[u] = bj < T_SB(0) ? ND : 1;
     pH[u] = H + (bj < T_SB(0) ? (size_t)a0 * ND + bj : (size_t)bj * ND + a0);
-    glb_double *col = gYT + (size_t)(col_on ? jc[u] : GYT_COLS - 1) * GYT_LD + KF * CH_NB;    // (column 95 is never a system column: the dump)
+    glb_double *col = gYT + (size_t)(col_on ? jc[u] : GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB;    // (column 95 is never a system column: the dump)
     pY[u] = col + lk;
-    pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYT_COLS - 1) * GYT_LD + KF * CH_NB + 8;
+    pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB + 8;
     pR[u] = ring + lk * ring_ld + min(TB * c, ring_ld - TB) + lr;
   }
   double yv[2][3], rpre[2][3], vsv = 0.0, zzc = 0.0;
@@ -828,21 +823,21 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
   auto load_R = [&](int u, double (&r)[3]) {
     const double r2 = pH[u][8 * dH[u]];
     r[0] = pH[u][0]; r[1] = pH[u][4 * dH[u]]; r[2] = lk == 0 ? r2 : 0.0;
-    pH[u] += SG * CH_NB * dH[u];
+    pH[u] -= CH_NB * dH[u];
   };
 #pragma unroll
   for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rpre[u]);
-  // operand pointers into the chain blocks (block KF first; per-lane stride, 0 for the lanes parked on the zero slot)
-  //   a2[kk] = W_k[lr][4 kk + lk]        a1[kk] = -Yc_prev[4 kk + lk][lr]      (G: W_kG[4 kk + lk][lr], Yc_kG[4 kk + lk][lr])
-  const int sW01 = in01 ? SG * CH_BLK : 0, sW2 = in2 ? SG * CH_BLK : 0;
-  const lds_double *pW01 = in01 ? Ach + KF * CH_BLK + lr * CH_NB + lk : zslot;
-  const lds_double *pW2 = in2 ? Ach + KF * CH_BLK + lr * CH_NB + 8 : zslot;
-  const lds_double *pC01 = in01 ? Cch + KF * CH_BLK + lk * CH_NB + lr : zslot;      // (the previous block's Yc: first used at the segment's second block)
-  const lds_double *pC2 = in2 ? Cch + KF * CH_BLK + 8 * CH_NB + lr : zslot;
-  const lds_double *pT01 = in01 ? Ach + KF * CH_BLK + lk * CH_NB + lr : zslot;      // W transposed access for G (block kG)
-  const lds_double *pT2 = in2 ? Ach + KF * CH_BLK + 8 * CH_NB + lr : zslot;
-  lds_double *pG01 = in01 ? Cch + KF * CH_BLK + lk * CH_NB + lr : zslot + CH_ZERO / 2;   // G output (block kG), or the dump half of the slot
-  lds_double *pG2 = in2 ? Cch + KF * CH_BLK + 8 * CH_NB + lr : zslot + CH_ZERO / 2;
+  // operand pointers into the chain blocks (block CH_NC - 1 first; per-lane stride, 0 for the lanes parked on the zero slot)
+  //   a2[kk] = W_k[lr][4 kk + lk]        a1[kk] = -Yc_k+1[4 kk + lk][lr]      (G: W_kG[4 kk + lk][lr], Yc_kG[4 kk + lk][lr])
+  const int sW01 = in01 ? CH_BLK : 0, sW2 = in2 ? CH_BLK : 0;
+  const lds_double *pW01 = in01 ? Ach + (CH_NC - 1) * CH_BLK + lr * CH_NB + lk : zslot;
+  const lds_double *pW2 = in2 ? Ach + (CH_NC - 1) * CH_BLK + lr * CH_NB + 8 : zslot;
+  const lds_double *pC01 = in01 ? Cch + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot;      // (block k + 1 = CH_NC - 1 is first used at the second step)
+  const lds_double *pC2 = in2 ? Cch + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
+  const lds_double *pT01 = in01 ? Ach + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot;      // W transposed access for G (block kG)
+  const lds_double *pT2 = in2 ? Ach + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
+  lds_double *pG01 = in01 ? Cch + (CH_NC - 1) * CH_BLK + lk * CH_NB + lr : zslot + CH_ZERO / 2;   // G output (block kG), or the dump half of the slot
+  lds_double *pG2 = in2 ? Cch + (CH_NC - 1) * CH_BLK + 8 * CH_NB + lr : zslot + CH_ZERO / 2;
   const double m2 = lk == 0 ? 1.0 : 0.0;     // (row 8 + lk exists for lk == 0 only)
   // ---- dense update: tiles e = wv, wv + 3, ... of the lower triangle
   dbl4 acc[S2_TPW];
@@ -857,16 +852,12 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
     oI[q] = TB * I; oJ[q] = TB * J; tJ1[q] = v ? TB * (J + 1) : 0;     // (tJ1 = 0: never above lo_k >= 0 -> skipped)
   }
   const int ro = lk * ring_ld + lr, rblk = RING_ROWS * ring_ld;
-  // first dense column block k can reach: the poses of frames >= k - 1 in the descending segment (s_lo); everything in the ascending
-  // one (the prior couples SpeedBias[0] with all it kept) and, twisted, in the middle block that inherits from it
-  auto lo_of = [&](int k) -> int { return (SEG == 1 || (TW && k == CH_MID)) ? 0 : __builtin_amdgcn_readfirstlane(s_lo[k]); };
-  for (int s = 0; s < ChainCfg<TW>::STEPS; s++) {
-    // (1) dense update with Yr of the block two positions back (in the ring since the previous step)
-    const int pg = s - 2;
-    if (pg >= 0 && pg < NB) {
-      const int kg = KF + SG * pg;
+  for (int s = 0; s <= CH_NC + 1; s++) {
+    // (1) dense update with Yr of block kg (in the ring since the previous step)
+    const int kg = CH_NC + 1 - s;
+    if (kg >= 0 && kg < CH_NC) {
       const lds_double *rg = ring + (kg & 1) * rblk + ro;
-      const int lo = lo_of(kg);
+      const int lo = __builtin_amdgcn_readfirstlane(s_lo[kg]);
 #pragma unroll
       for (int q = 0; q < S2_TPW; q++) {
         if (tJ1[q] <= lo) continue;                               // (columns below lo_kg are zero in Yr_kg; wave-uniform)
@@ -877,22 +868,15 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
         for (int kk = 0; kk < 3; kk++) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], acc[q], 0, 0, 0);
       }
     }
-    // (2) Yr of the block one position back: R' = R_k - Yc_prev^T Yr_prev, Yr_k = W_k R'
-    const int pk = s - 1;
-    if (pk >= 0 && pk < NB) {
-      const int k = KF + SG * pk;
-      const int lo = lo_of(k);
+    // (2) Yr of block k: R' = R_k - Yc_k+1^T Yr_k+1, Yr_k = W_k R'
+    const int k = CH_NC - s;
+    if (k >= 0 && k < CH_NC) {
+      const int lo = __builtin_amdgcn_readfirstlane(s_lo[k]);
       double a1[3], a2[3];
       a2[0] = pW01[0]; a2[1] = pW01[4]; a2[2] = pW2[0];
-      if (pk > 0) { a1[0] = -pC01[0]; a1[1] = -pC01[4 * CH_NB]; a1[2] = -pC2[0]; pC01 += sW01; pC2 += sW2; }
+      if (k + 1 < CH_NC) { a1[0] = -pC01[0]; a1[1] = -pC01[4 * CH_NB]; a1[2] = -pC2[0]; pC01 -= sW01; pC2 -= sW2; }
       else { a1[0] = 0.0; a1[1] = 0.0; a1[2] = 0.0; }
-      pW01 += sW01; pW2 += sW2;
-      const bool mid = TW && SEG == 0 && k == CH_MID;            // (wave-uniform; the middle block of the twisted chain: a second predecessor)
-      double b1[3] = {0.0, 0.0, 0.0};
-      if (mid) {
-        const lds_double *cm01 = in01 ? Cch + (CH_MID - 1) * CH_BLK + lk * CH_NB + lr : zslot, *cm2 = in2 ? Cch + (CH_MID - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
-        b1[0] = -cm01[0]; b1[1] = -cm01[4 * CH_NB]; b1[2] = -cm2[0];
-      }
+      pW01 -= sW01; pW2 -= sW2;
       double sk[3], vk[3], rk[3];
 #pragma unroll
       for (int kk = 0; kk < 3; kk++) { const int a = T_SB(k) + min(lk + 4 * kk, CH_NB - 1); sk[kk] = sS[a]; vk[kk] = vS[a]; rk[kk] = rS[a]; }
@@ -906,19 +890,14 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
         double r[3];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) r[kk] = __builtin_fma(rpre[u][kk] * sk[kk], m1, mr * rk[kk]);
-        load_R(u, rpre[u]);                                        // (the next block; in flight during this block's products. The loads of
-                                                                   //  the step after the last block read valid, unused rows of H)
+        load_R(u, rpre[u]);                                        // (block k - 1; in flight during this block's products. The loads of
+                                                                   //  the step after block 0 read valid, unused rows of H)
         if (!zero_tile) {
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) vsv = __builtin_fma(r[kk] * vk[kk], vbj2[u], vsv);
           dbl4 rp = {r[0], r[1], r[2], 0.0};
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], yv[u][kk], rp, 0, 0, 0);
-          if (mid) {                                               // - Yc'^T Yr of the other segment's last block, from its ring
-            const lds_double *ro2 = ring_other + ((CH_MID - 1) & 1) * rblk + lk * ring_ld + min(TB * (wv + S2_WIDE_WAVES * u), ring_ld - TB) + lr;
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kk], ro2[4 * kk * ring_ld], rp, 0, 0, 0);
-          }
           dbl4 y = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) y = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kk], rp[kk], y, 0, 0, 0);
@@ -934,27 +913,27 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
           for (int kk = 0; kk < 3; kk++) yv[u][kk] = 0.0;
         }
         pY[u][0] = yv[u][0]; pY[u][4] = yv[u][1]; pY8[u][0] = yv[u][2];
-        pY[u] += SG * CH_NB; pY8[u] += SG * CH_NB;
+        pY[u] -= CH_NB; pY8[u] -= CH_NB;
       }
     }
-    // (3) G_kG = W_kG^T Yc_kG in place of Yc_kG, one step after its last reader (the wide rows of the next block): the chain's
-    //     back-substitution then needs one matrix-vector product per block. (The last block of segment 0 has no successor, no Yc.)
-    const int pG = s - 3;
-    if (wv == S2_WIDE_WAVES - 1 && pG >= 0 && pG < (SEG == 0 ? NB - 1 : NB)) {
-      const lds_double *t01 = pT01 + pG * sW01, *t2 = pT2 + pG * sW2, *c01 = pG01 + pG * sW01, *c2 = pG2 + pG * sW2;
+    // (3) G_kG = W_kG^T Yc_kG in place of Yc_kG, one step after its last reader (the wide rows of block kG - 1): the chain's
+    //     back-substitution then needs one matrix-vector product per block
+    const int kG = CH_NC - s + 2;
+    if (wv == S2_WIDE_WAVES - 1 && kG >= 1 && kG < CH_NC) {
+      const int off = (kG - (CH_NC - 1));                          // (<= 0) blocks below the first one
+      const lds_double *t01 = pT01 + off * sW01, *t2 = pT2 + off * sW2, *c01 = pG01 + off * sW01, *c2 = pG2 + off * sW2;
       const double ag0 = t01[0], ag1 = t01[4 * CH_NB], ag2 = t2[0], bg0 = c01[0], bg1 = c01[4 * CH_NB], bg2 = c2[0];
       dbl4 gq = {0.0, 0.0, 0.0, 0.0};
       gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag0, in01 ? bg0 : 0.0, gq, 0, 0, 0);
       gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag1, in01 ? bg1 : 0.0, gq, 0, 0, 0);
       gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag2, in2 ? bg2 : 0.0, gq, 0, 0, 0);
-      lds_double *g01 = pG01 + pG * sW01, *g2 = pG2 + pG * sW2;
+      lds_double *g01 = pG01 + off * sW01, *g2 = pG2 + off * sW2;
       g01[0] = gq[0]; g01[4 * CH_NB] = gq[1]; g2[0] = gq[2];
     }
-    RSTAMP(SEG == 0 && wv == 1 && lane == 0 && s < 12, 52 + s);
+    RSTAMP(wv == 1 && lane == 0 && s < 12, 52 + s);
     CH_LDS_BARRIER();
   }
-  // dense tiles -= the accumulated products (twisted: segment 0 first, segment 1 one barrier later — the same tiles)
-  if (TW && SEG == 1) CH_LDS_BARRIER();
+  // dense tiles -= the accumulated products
 #pragma unroll
   for (int q = 0; q < S2_TPW; q++) {
     if (tJ1[q] == 0) continue;
@@ -962,13 +941,204 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
 #pragma unroll
     for (int r = 0; r < 4; r++) C[tsw(lk + 4 * r, lr)] -= acc[q][r];
   }
-  if (TW && SEG == 0) CH_LDS_BARRIER();
   // |z_chain|^2: the four lanes (lk = 0..3) of the right-hand side column
   zzc += __shfl_xor(zzc, 16, 64);
   zzc += __shfl_xor(zzc, 32, 64);
 #pragma unroll
   for (int u = 0; u < 2; u++) if (mrhs[u] != 0.0 && lk == 0) *zzc_out = zzc;
   return vsv;
+}
+
+// ---- k_solve_chain_tw: the wide rows of one segment, three waves (wv = 0..2). Wave wv forms the column tiles wv and wv + 3 of Yr, block
+// after block, one step behind its segment's chain wave: R' = R_k - Yc_prev^T Yr_prev (Yr_prev still in the registers, in the operand
+// layout), Yr_k = W_k R'. Unlike wide_role it does NOT add the dense update step by step: a window alone on the GPU is bound by the
+// latency of these per-step chains (LDS operands -> 3 + 3 dependent matrix-core instructions -> stores -> barrier), so the step carries
+// nothing else — every row of Yr stays in LDS (`Yall`, row 9 k + i, 99 rows + a zero row: 100 = 25 x 4) and the dense update
+// D -= Yr^T Yr is ONE product over all 100 rows after the pipeline, dealt over all eight waves (dense_update_tw: 25 instead of 33
+// matrix-core instructions per tile, no ring, no transposed copy of Yr in global memory: the chain's back-substitution reads Yall).
+// No column skipping either (the ascending segment's rows are full — the prior couples SpeedBias[0] with everything it kept — and
+// set the pace): entries outside a block's reach come out as the exact zeros they are.
+// The middle block (last of segment 0) takes the second product -Yc'^T Yr of segment 1's last block, read back from Yall.
+// Row stride 81: ODD, so that a thread per row walks its row without bank conflicts (the back-substitution's 99 dot products), while
+// the matrix-core operand pattern (two rows x 16 consecutive doubles per half-wave) still only collides on two of its 64 banks.
+enum { YALL_ROWS = 104, YALL_LD = 81 };     // 99 rows of Yr | row 99: zeros (the 25th group of four) | rows 100..103: dump rows of the masked third store
+template <int SEG>
+__device__ GFBE_ROLE_FN double wide_role_tw(lds_double *Ach, lds_double *Cch, lds_double *Yall, lds_double *zslot, const lds_double *sS, const lds_double *vS,
+                                            const lds_double *rS, const lds_short *perm, lds_double *zzc_out, const glb_double *H, int n_, int nt_, int ld_,
+                                            int wv_, int lane, double *rstamp) {
+  constexpr int NB = SEG == 0 ? ChainCfg<1>::NB0 : ChainCfg<1>::NB1;
+  constexpr int KF = SEG == 0 ? CH_NC - 1 : 0, SG = SEG == 0 ? -1 : 1;
+  const int n = __builtin_amdgcn_readfirstlane(n_), nt = __builtin_amdgcn_readfirstlane(nt_);
+  const int ld = __builtin_amdgcn_readfirstlane(ld_), wv = __builtin_amdgcn_readfirstlane(wv_);
+  const int lr = lane & 15, lk = lane >> 4, na = n + 1;
+  const bool in01 = lr < CH_NB, in2 = lr < CH_NB && lk == 0;
+  bool on[2];
+  int jc[2];
+  double sbj[2], vbj2[2], mrhs[2], mcol[2];
+  const glb_double *pH[2];        // S-source entry (SB_k row lk, column): H[a * ND + b] for b below the speed-bias dims, H[b * ND + a] above
+  long dH[2];
+  lds_double *pR[2], *pR8[2];     // Yall slots: (row 9 k + lk, column 16 c + lr) | row 9 k + 8 (lk == 0) or a dump row
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int c = wv + S2_WIDE_WAVES * u;
+    on[u] = c < nt;
+    jc[u] = TB * c + lr;
+    const bool dense_col = on[u] && jc[u] < n;
+    const int bj = dense_col ? perm[jc[u]] : 0;
+    sbj[u] = dense_col ? sS[bj] : 0.0; vbj2[u] = dense_col ? 2.0 * vS[bj] : 0.0;
+    mrhs[u] = (on[u] && jc[u] == n) ? 1.0 : 0.0;
+    mcol[u] = (on[u] && jc[u] < na) ? 1.0 : 0.0;
+    const int a0 = T_SB(KF) + lk;
+    dH[u] = bj < T_SB(0) ? ND : 1;
+    pH[u] = H + (bj < T_SB(0) ? (size_t)a0 * ND + bj : (size_t)bj * ND + a0);
+    const int cc = min(TB * c, ld - TB) + lr;
+    pR[u] = Yall + (KF * CH_NB + lk) * ld + cc;
+    pR8[u] = lk == 0 ? Yall + (KF * CH_NB + 8) * ld + cc : Yall + (100 + lk) * ld + cc;
+  }
+  const int sR = SG * CH_NB * ld, sR8 = lk == 0 ? SG * CH_NB * ld : 0;
+  double yv[2][3], rpre[2][3], vsv = 0.0, zzc = 0.0;
+#pragma unroll
+  for (int u = 0; u < 2; u++)
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; }
+  // rows lk, lk + 4, lk + 8 of block k (row 8 + lk exists for lk == 0 only: the other lanes' third load lands in the next block or above
+  // the diagonal, on entries nobody writes, and is replaced by zero, not multiplied by it)
+  auto load_R = [&](int u, double (&r)[3]) {
+    const double r2 = pH[u][8 * dH[u]];
+    r[0] = pH[u][0]; r[1] = pH[u][4 * dH[u]]; r[2] = lk == 0 ? r2 : 0.0;
+    pH[u] += SG * CH_NB * dH[u];
+  };
+#pragma unroll
+  for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rpre[u]);
+  const int sW01 = in01 ? SG * CH_BLK : 0, sW2 = in2 ? SG * CH_BLK : 0;
+  const lds_double *pW01 = in01 ? Ach + KF * CH_BLK + lr * CH_NB + lk : zslot;
+  const lds_double *pW2 = in2 ? Ach + KF * CH_BLK + lr * CH_NB + 8 : zslot;
+  const lds_double *pC01 = in01 ? Cch + KF * CH_BLK + lk * CH_NB + lr : zslot;      // (the previous block's Yc: first used at the segment's second block)
+  const lds_double *pC2 = in2 ? Cch + KF * CH_BLK + 8 * CH_NB + lr : zslot;
+  const double m2 = lk == 0 ? 1.0 : 0.0;
+  for (int s = 0; s < ChainCfg<1>::STEPS; s++) {
+    const int pk = s - 1;
+    if (pk >= 0 && pk < NB) {
+      const int k = KF + SG * pk;
+      double a1[3], a2[3];
+      a2[0] = pW01[0]; a2[1] = pW01[4]; a2[2] = pW2[0];
+      if (pk > 0) { a1[0] = -pC01[0]; a1[1] = -pC01[4 * CH_NB]; a1[2] = -pC2[0]; pC01 += sW01; pC2 += sW2; }
+      else { a1[0] = 0.0; a1[1] = 0.0; a1[2] = 0.0; }
+      pW01 += sW01; pW2 += sW2;
+      const bool mid = SEG == 0 && k == CH_MID;                  // (wave-uniform: the middle block has a second predecessor)
+      double b1[3] = {0.0, 0.0, 0.0};
+      if (mid) {
+        const lds_double *cm01 = in01 ? Cch + (CH_MID - 1) * CH_BLK + lk * CH_NB + lr : zslot, *cm2 = in2 ? Cch + (CH_MID - 1) * CH_BLK + 8 * CH_NB + lr : zslot;
+        b1[0] = -cm01[0]; b1[1] = -cm01[4 * CH_NB]; b1[2] = -cm2[0];
+      }
+      double sk[3], vk[3], rk[3];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) { const int a = T_SB(k) + min(lk + 4 * kk, CH_NB - 1); sk[kk] = sS[a]; vk[kk] = vS[a]; rk[kk] = rS[a]; }
+      sk[2] *= m2; rk[2] *= m2;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        if (!on[u]) continue;                                      // (wave-uniform)
+        const double m1 = mcol[u] * sbj[u], mr = mrhs[u];
+        double r[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) r[kk] = __builtin_fma(rpre[u][kk] * sk[kk], m1, mr * rk[kk]);
+        load_R(u, rpre[u]);                                        // (the next block; in flight during this block's products)
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) vsv = __builtin_fma(r[kk] * vk[kk], vbj2[u], vsv);
+        dbl4 rp = {r[0], r[1], r[2], 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], yv[u][kk], rp, 0, 0, 0);
+        if (mid) {                                                 // - Yc'^T Yr of segment 1's last block, from Yall (its ninth row by lk == 0 only)
+          const lds_double *yo = Yall + ((CH_MID - 1) * CH_NB + lk) * ld + min(TB * (wv + S2_WIDE_WAVES * u), ld - TB) + lr;
+          const double y8 = yo[8 * ld];
+          const double yb[3] = {yo[0], yo[4 * ld], lk == 0 ? y8 : 0.0};
+#pragma unroll
+          for (int kk = 0; kk < 3; kk++) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[kk], yb[kk], rp, 0, 0, 0);
+        }
+        dbl4 y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) y = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[kk], rp[kk], y, 0, 0, 0);
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) yv[u][kk] = y[kk];
+        pR[u][0] = yv[u][0]; pR[u][4 * ld] = yv[u][1]; pR8[u][0] = yv[u][2];
+        pR[u] += sR; pR8[u] += sR8;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) zzc = __builtin_fma(yv[u][kk] * mrhs[u], yv[u][kk], zzc);
+      }
+    }
+    RSTAMP(SEG == 0 && wv == 1 && lane == 0 && s < 12, 52 + s);
+    RSTAMP(SEG == 1 && wv == 1 && lane == 0 && s >= 1 && s < 7, 39 + s);
+    CH_LDS_BARRIER();
+  }
+  // |z|^2 of the segment's chain rows: the four lanes (lk = 0..3) of the right-hand side column
+  zzc += __shfl_xor(zzc, 16, 64);
+  zzc += __shfl_xor(zzc, 32, 64);
+#pragma unroll
+  for (int u = 0; u < 2; u++) if (mrhs[u] != 0.0 && lk == 0) *zzc_out = zzc;
+  return vsv;
+}
+// After the pipeline of k_solve_chain_tw, every wave: (1) the dense update D -= Yr^T Yr over all 100 rows of Yall, tiles dealt round robin;
+// (2) G_k = W_k^T Yc_k in place of Yc_k for the ten blocks that have a successor (the chain's back-substitution then needs one 9 x 9
+// matrix-vector product per block).
+__device__ __forceinline__ void dense_update_tw(lds_double *tiles, const lds_double *Yall, lds_double *Ach, lds_double *Cch, const lds_double *zslot, int nt,
+                                                int ld, int wave, int lane, int nwaves) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ntile = nt * (nt + 1) / 2;
+  // two tiles of the wave side by side (independent accumulators: no matrix-core instruction waits for the one before it), the
+  // operands of the next five row groups in flight while the current five are multiplied
+  for (int e0 = wave; e0 < ntile; e0 += 2 * nwaves) {
+    const int e1 = e0 + nwaves;
+    const bool two = e1 < ntile;                                   // (wave-uniform)
+    int I0, J0, I1 = 0, J1 = 0;
+    tri_decode(e0, I0, J0);
+    if (two) tri_decode(e1, I1, J1);
+    const lds_double *pa0 = Yall + lk * ld + min(TB * I0, ld - TB) + lr, *pb0 = Yall + lk * ld + min(TB * J0, ld - TB) + lr;
+    const lds_double *pa1 = Yall + lk * ld + min(TB * I1, ld - TB) + lr, *pb1 = Yall + lk * ld + min(TB * J1, ld - TB) + lr;
+    dbl4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    double a0[5], b0[5], a1[5], b1[5], na0[5], nb0[5], na1[5], nb1[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) { a0[q] = pa0[4 * q * ld]; b0[q] = pb0[4 * q * ld]; a1[q] = pa1[4 * q * ld]; b1[q] = pb1[4 * q * ld]; }
+#pragma unroll
+    for (int g = 0; g < 5; g++) {
+      if (g < 4) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+          const int o = 4 * (5 * (g + 1) + q) * ld;
+          na0[q] = pa0[o]; nb0[q] = pb0[o]; na1[q] = pa1[o]; nb1[q] = pb1[o];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
+        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 5; q++) { a0[q] = na0[q]; b0[q] = nb0[q]; a1[q] = na1[q]; b1[q] = nb1[q]; }
+    }
+    lds_double *C0 = tiles + (size_t)tile_idx(I0, J0) * (TB * TB);
+#pragma unroll
+    for (int r = 0; r < 4; r++) C0[tsw(lk + 4 * r, lr)] -= acc0[r];
+    if (two) {
+      lds_double *C1 = tiles + (size_t)tile_idx(I1, J1) * (TB * TB);
+#pragma unroll
+      for (int r = 0; r < 4; r++) C1[tsw(lk + 4 * r, lr)] -= acc1[r];
+    }
+  }
+  const bool in01 = lr < CH_NB, in2 = lr < CH_NB && lk == 0;
+  for (int q = wave; q < CH_NC - 1; q += nwaves) {
+    const int k = q < CH_MID ? q : q + 1;                          // (every block but the middle one)
+    const lds_double *t01 = in01 ? Ach + k * CH_BLK + lk * CH_NB + lr : zslot, *t2 = in2 ? Ach + k * CH_BLK + 8 * CH_NB + lr : zslot;
+    lds_double *c01 = Cch + k * CH_BLK + lk * CH_NB + lr, *c2 = Cch + k * CH_BLK + 8 * CH_NB + lr;
+    const double ag0 = t01[0], ag1 = t01[4 * CH_NB], ag2 = t2[0];
+    const double bg0 = in01 ? c01[0] : 0.0, bg1 = in01 ? c01[4 * CH_NB] : 0.0, bg2 = in2 ? c2[0] : 0.0;
+    dbl4 gq = {0.0, 0.0, 0.0, 0.0};
+    gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag0, bg0, gq, 0, 0, 0);
+    gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag1, bg1, gq, 0, 0, 0);
+    gq = __builtin_amdgcn_mfma_f64_16x16x4f64(ag2, bg2, gq, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();                               // (every lane has read its entries of Yc_k before anyone overwrites them)
+    if (in01) { c01[0] = gq[0]; c01[4 * CH_NB] = gq[1]; }
+    if (in2) c2[0] = gq[2];
+  }
 }
 
 // TW = 0: k_solve_chain (four waves: the chain role, three wide waves; two workgroups per CU — throughput batches).
@@ -1029,9 +1199,10 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   double *Cch = Ach + CH_NC * CH_BLK;
   double *zslot = Cch + CH_NC * CH_BLK;
   double *ring = zslot + CH_ZERO;
-  double *ring1 = ring + 2 * RING_ROWS * chain_ring_ld(d.solve_ntile);      // (twisted: segment 1's ring, then the middle block's second downdate)
-  double *Amid = ring1 + 2 * RING_ROWS * chain_ring_ld(d.solve_ntile);
+  double *Yall = ring;                                                      // (twisted: every row of Yr instead of the ring, then the middle block's second downdate)
+  double *Amid = Yall + YALL_ROWS * YALL_LD;
   if (t < CH_ZERO) zslot[t] = 0.0;
+  if (TW && t < YALL_LD) Yall[99 * YALL_LD + t] = 0.0;      // (row 99: the padding of the 25th group of four rows)
 
   // dense dims (active, not in the chain) by a wave-level prefix count (dims 0..191 live in waves 0..2); chain activity flags
   __shared__ int wcount[4];
@@ -1230,20 +1401,24 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
       // ---- the pipeline over the chain blocks, one block barrier per block (the roles are separate functions with their own
       //      register allocation; every role passes the same CH_NC + 2 barriers):
       //   step s: wave 0 factorises block NC-1-s | waves 1..3 form Yr of block NC-s and add Yr^T Yr of block NC+1-s
-#define WIDE_ARGS(rg, rgo, seg) (lds_double *)tiles, (lds_double *)Ach, (lds_double *)Cch, (lds_double *)(rg), (const lds_double *)(rgo), (lds_double *)zslot, \
-                         (const lds_double *)sS, (const lds_double *)vS, (const lds_double *)rS, (const lds_short *)perm, (const lds_int *)s_lo,           \
-                         (lds_double *)&s_zzc[seg], (const glb_double *)H, (glb_double *)gYT, n, nt, chain_ring_ld(d.solve_ntile)
-      if (!TW) {
+if (!TW) {
         if (wave == 0) chain_role<0, 0>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
-        else vsv += wide_role<0, 0>(WIDE_ARGS(ring, ring, 0), wave - 1, lane, stamp);
+        else
+          vsv += wide_role((lds_double *)tiles, (lds_double *)Ach, (lds_double *)Cch, (lds_double *)ring, (lds_double *)zslot, (const lds_double *)sS,
+                           (const lds_double *)vS, (const lds_double *)rS, (const lds_short *)perm, (const lds_int *)s_lo, (lds_double *)&s_zzc[0],
+                           (const glb_double *)H, (glb_double *)gYT, n, nt, chain_ring_ld(d.solve_ntile), wave - 1, lane, stamp);
       } else {
         // waves 0, 1: the chain roles of the two segments; 2..4: segment 0's wide waves; 5..7: segment 1's
+#define WIDE_ARGS(seg) (lds_double *)Ach, (lds_double *)Cch, (lds_double *)Yall, (lds_double *)zslot, (const lds_double *)sS, (const lds_double *)vS, \
+                       (const lds_double *)rS, (const lds_short *)perm, (lds_double *)&s_zzc[seg], (const glb_double *)H, n, nt, (int)YALL_LD
         if (wave == 0) chain_role<TW, 0>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
         else if (wave == 1) chain_role<TW, 1>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
-        else if (wave < 2 + S2_WIDE_WAVES) vsv += wide_role<TW, 0>(WIDE_ARGS(ring, ring1, 0), wave - 2, lane, stamp);
-        else vsv += wide_role<TW, 1>(WIDE_ARGS(ring1, ring, 1), wave - 2 - S2_WIDE_WAVES, lane, stamp);
-      }
+        else if (wave < 2 + S2_WIDE_WAVES) vsv += wide_role_tw<0>(WIDE_ARGS(0), wave - 2, lane, stamp);
+        else vsv += wide_role_tw<1>(WIDE_ARGS(1), wave - 2 - S2_WIDE_WAVES, lane, stamp);
 #undef WIDE_ARGS
+        dense_update_tw((lds_double *)tiles, (const lds_double *)Yall, (lds_double *)Ach, (lds_double *)Cch, (const lds_double *)zslot, nt,
+                        (int)YALL_LD, wave, lane, NWAVES);
+      }
     }
     vsv = block_sum_t(vsv, red, t);
     if (t == 0) s_vSv = vsv;
@@ -1301,7 +1476,24 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
       // ---- the chain's back-substitution: t_r = z_r - (Yr x_dense)_r for the 99 chain rows (lane = row, the transposed Yr rows
       //      read back coalesced from HBM / L2, all loads in flight), a_k = W_k^T t_k, then x_k = a_k - G_k x_k-1 on one wave
       if (chain_on) {
-        if (t < 128) {
+        if (TW) {
+          // t_r = z_r - (Yr x_dense)_r from the rows of Yall, a thread per row (odd row stride: no bank conflicts), eight loads in flight
+          if (t < 128) {
+            const int r = t < CH_ROWS ? t : CH_ROWS - 1;
+            const double *row = Yall + r * YALL_LD;
+            double s0 = 0.0, s1 = 0.0;
+            int j = 0;
+            for (; j + 8 <= n; j += 8) {
+              double v[8];
+#pragma unroll
+              for (int q = 0; q < 8; q++) v[q] = row[j + q];
+#pragma unroll
+              for (int q = 0; q < 8; q += 2) { s0 = __builtin_fma(v[q], ys[j + q], s0); s1 = __builtin_fma(v[q + 1], ys[j + q + 1], s1); }
+            }
+            for (; j < n; j++) s0 = __builtin_fma(row[j], ys[j], s0);
+            if (t < CH_ROWS) tch[t] = row[n] - (s0 + s1);
+          }
+        } else if (t < 128) {
           const int r = t < CH_ROWS ? t : CH_ROWS - 1;
           const double *col = gYT + r;
           double s0 = 0.0, s1 = 0.0;
@@ -1765,9 +1957,10 @@ static_assert(((NC + 1 + TB - 1) / TB) * (((NC + 1 + TB - 1) / TB) + 1) / 2 * TB
               + sizeof(short) * (NC + TB) + sizeof(double) * (16 + 2 * NC + TB + 2 + TB) + sizeof(int) * 6      // perm, red, ys, s_zz, s_vSv, zlast, flags
               + 128 /* alignment padding */ <= 160 * 1024, "k_solve: tiles + static LDS exceed a CU's 160 KB");
 static size_t solve_smem_bytes() { const int nt = (NC + 1 + TB - 1) / TB;   /* (k_solve never sees the GNSS dims: those batches take k_solve_big) */ return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
-static size_t chain_smem_bytes(int ntile, bool tw = false) {     // tw: k_solve_chain_tw — a second ring (segment 1) and the middle block's second downdate
-  return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + (tw ? 4 : 2) * RING_ROWS * chain_ring_ld(ntile) + (tw ? CH_BLK : 0));
+static size_t chain_smem_bytes(int ntile, bool tw = false) {     // tw: k_solve_chain_tw — every row of Yr instead of the two-block ring, and the middle block's second downdate
+  return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + (tw ? (size_t)YALL_ROWS * YALL_LD + CH_BLK : (size_t)2 * RING_ROWS * chain_ring_ld(ntile)));
 }
+bool solve_chain_tw_fits(int ntile) { return ntile <= 15; }      // (six tile columns — a free camera extrinsic — would need 169 KB of LDS: those windows keep k_solve_chain)
 size_t solve_chain_scratch_doubles() { return (size_t)GYT_COLS * GYT_LD; }
 // dense tiles a window with these active dims needs in k_solve_chain (host side of the kernel's own count)
 int solve_chain_tiles(const unsigned char *act) {
@@ -1783,7 +1976,7 @@ hipError_t kernels_init_device() {
   if (e != hipSuccess) return e;
   const hipError_t e2 = hipFuncSetAttribute((const void *)k_solve_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_MAX_TILES));
   if (e2 != hipSuccess) return e2;
-  const hipError_t e3 = hipFuncSetAttribute((const void *)k_solve_chain_tw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_MAX_TILES, true));
+  const hipError_t e3 = hipFuncSetAttribute((const void *)k_solve_chain_tw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(15, true));
   if (e3 != hipSuccess) return e3;
   return hipFuncSetAttribute((const void *)k_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_smem_bytes());
 }

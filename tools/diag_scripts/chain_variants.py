@@ -38,6 +38,10 @@ for kernel in [int(k) for k in os.environ.get("KERNELS", "2,3,1").split(",")]:
     torch.cuda.synchronize()
     prof1 = {p["name"]: 1e3 * p["total_ms"] / max(p["launches"], 1) for p in be.profile() if p["launches"]}
     be.profile_enable(False)
+    one.solve(abi.MARGIN_OLD); torch.cuda.synchronize()
+    tm = one.debug_timing(0)
+    ph = [("prologue", 0, 1), ("build", 1, 2), ("pipeline", 2, 15), ("dense chol", 15, 3), ("dense backsub", 3, 16), ("chain backsub", 16, 4), ("gram", 4, 5), ("total", 0, 5)]
+    print("   phases (us, last iteration): " + "  ".join("%s %.2f" % (n, (tm[b] - tm[a]) * 0.01) for n, a, b in ph), flush=True)
     one.free()
     if ref is None: ref = res
     print("solve_kernel %d: one window resident %.4f ms (p10 %.4f) host-to-host %.4f ms | k_solve %.1f us per launch (iter0 %.1f) | final cost %.12g, dpos vs first kernel %.2e" %
