@@ -579,9 +579,6 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 #define GFBE_ROLE_FN __noinline__
 #endif
 #define S2_WAVES (S2_THREADS >> 6)
-#ifndef GFBE_CHAIN_ROT
-#define GFBE_CHAIN_ROT 2      // 0: wave w takes role w; k > 0: the chain role on SIMD k x (wave slot) mod 4 (see k_solve_chain)
-#endif
 enum { CH_NB = 9, CH_NC = NF, CH_ROWS = CH_NB * CH_NC, CH_BLK = CH_NB * CH_NB, RING_ROWS = 12,
        S2_MAX_NT = 6, S2_MAX_TILES = S2_MAX_NT * (S2_MAX_NT + 1) / 2, GYT_LD = 104, GYT_COLS = TB * S2_MAX_NT };
 // row stride of the Yr ring: >= 16 x tile columns and = 16 (mod 32) doubles, so that the two row groups a half-wave reads as a
@@ -1150,49 +1147,50 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
-  if (c.done || c.reuse) return;
-  if (retry_pass && !c.lin_retry) return;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
+  double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
+  double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
+  double *gYT = d.solveY + (size_t)w * GYT_COLS * GYT_LD;
+  const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
+  const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
+  // ---- level 1 of the kernel's global loads: everything whose address needs nothing but the window index is requested HERE, before
+  // the first dependent use of any of it (the control block's early-exit test included) — a kernel that follows another one finds
+  // nothing in its caches, and each LEVEL of dependent loads costs 1-2 us whatever is loaded (round 5: the prologue and the build
+  // were five such levels, 11 us of a 56 us launch; now two — this one and the entries that need `perm`). The workgroup has at least
+  // 256 threads: thread a owns tangent dim a (ND = 246) and parameter block a. Nothing loaded here is used by a window / a dim / a
+  // block it does not belong to (clamped indices, values selected afterwards).
+  const int ta = min(t, ND - 1), tb = min(t, GFBE_BLK_COUNT - 1);
+  const bool l_act = ds.act[ta], l_free = ds.blk_free[tb];
+  const double l_haa = H[(size_t)ta * ND + ta], l_g = g[ta], l_sp = gsp[ta], l_eg = eg[min(ta, NV - 1)];
+  const int c_done = c.done, c_reuse = c.reuse, c_lin_retry = c.lin_retry, c_iter = c.iter, c_cur = c.cur;
+  if (c_done || c_reuse) return;
+  if (retry_pass && !c_lin_retry) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ short perm[ND + TB];
   __shared__ double red[16], ys[ND + TB];                        // ys: the solution of the dense part (tile order)
   __shared__ double sS[ND], vS[ND], dS[ND], gS[ND], rS[ND], yT[ND];   // per tangent dim: Jacobi scale, Cauchy direction, D, scaled gradient, right-hand side, GN step
   __shared__ double s_zz, s_zzc[2], s_vSv, zlast[TB], xs[CH_ROWS + 16], tch[CH_ROWS + 16], cterm[64];
   __shared__ double s_keep[4];
-  __shared__ int flag, s_nact, s_nch, s_lo[CH_NC + 1];
+  __shared__ int flag, s_nch, s_lo[CH_NC + 1];
   __shared__ unsigned long long s_mask0;
   __shared__ unsigned char chact[CH_ROWS + 1];
-  // Roles by SIMD (GFBE_CHAIN_ROT): the chain role (and the diagonal-tile step of the dense factorisation after it) is ONE wave's
-  // sequential instruction stream, and the hardware starts the four waves of every workgroup on the four SIMDs in the same order —
-  // the chain waves of the workgroups that share a CU would sit on one SIMD and halve each other's issue rate while the other three
-  // SIMDs run the mostly idle wide waves. Every wave reads the SIMD and the wave slot it runs on (HW_ID); the chain role goes to the
-  // wave on SIMD 2 x (slot of wave 0) mod 4 — co-resident workgroups occupy different slots — and the wide roles follow in order.
-  // `t` is the thread index after that rotation of the waves: everything below deals work, LDS slots and the order of every sum by
-  // it, so the result does not depend on the rotation (same operations in the same order, whatever wave runs a role).
-  int t = threadIdx.x;
-#if GFBE_CHAIN_ROT
-  if (!TW) {
-    __shared__ int s_hw[S2_WAVES];
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    const int pw = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) s_hw[pw] = (int)hw;
-    __syncthreads();
-    const int target = (GFBE_CHAIN_ROT * (s_hw[0] & 15)) & 3;      // (slot of wave 0) x 2: SIMD 0 / SIMD 2 for the two workgroups of a CU
-    int pc = 0;
-#pragma unroll
-    for (int q = S2_WAVES - 1; q >= 0; q--) if (((s_hw[q] >> 4) & 3) == target) pc = q;
-    t = (((pw - pc) & (S2_WAVES - 1)) << 6) | (threadIdx.x & 63);
-  }
-#endif
-  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
-  double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
-  double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
-  double *gYT = d.solveY + (size_t)w * GYT_COLS * GYT_LD;
-  const bool first = (c.iter == 0);
+  const bool first = (c_iter == 0);
   double *stamp = d.timing + (size_t)w * 32;
 #define STAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
   STAMP(0);
+  // the terms of the first linearisation point's cost (wave 3, summed below): requested with level 1
+  double l_term = 0.0;
+  if (first && wave == 3) {
+    if (lane < ds.n_imu) l_term = d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 2];
+    else if (lane >= 16 && lane - 16 < ds.n_wheel) l_term = d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 2];
+    else if (lane == 32) l_term = d.prior_g[(size_t)w * (ND + 2) + ND];
+    else if (lane == 33) {   // the ranks' visual-cost shares, in rank order (any world size gfbe_set_allreduce accepts: k_solve / k_solve_big loop the same way)
+      for (int r = 0; r < d.world; r++) l_term += d.xa[((size_t)w * d.world + r) * XCHG];
+    }
+    else if (lane >= 44 && lane - 44 < ds.n_plane) l_term = d.plane_part[((size_t)w * MAX_PLANE + lane - 44) * PLANE_PART + PLANE_PART - 2];
+    else if (lane == 58 && ds.use_anchor) l_term = d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
+  }
   // LDS carve-up: dense tiles | chain diagonal blocks (A_k -> W_k) | chain couplings (C_k -> Yc_k -> G_k) | zero / dump slot | two-block ring of Yr
   double *tiles = smem;
   double *Ach = smem + (size_t)d.solve_ntile * (TB * TB);
@@ -1207,7 +1205,7 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   // dense dims (active, not in the chain) by a wave-level prefix count (dims 0..191 live in waves 0..2); chain activity flags
   __shared__ int wcount[4];
   {
-    const bool act_t = (t < ND) && ds.act[t];
+    const bool act_t = (t < ND) && l_act;
     const bool on = act_t && !dim_in_chain(t);
     const unsigned long long m = __ballot(on);
     const unsigned long long mc = __ballot(act_t && dim_in_chain(t));
@@ -1222,22 +1220,68 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
       if (lane == 0 && mc) atomicAdd(&s_nch, __popcll(mc));
     }
     const int nact = wcount[0] + wcount[1] + wcount[2];
-    if (t == 0) s_nact = nact;
     for (int a = nact + t; a < ND + TB; a += blockDim.x) perm[a] = -1;
     // lo_k: first dense column the wide row of block k can reach — the poses of frames >= k - 1 (pose dims are 0..65: wave 0's mask)
     if (t <= CH_NC) s_lo[t] = (t >= 2 && t < CH_NC) ? __popcll(s_mask0 & ((1ull << (6 * (t - 1))) - 1ull)) : 0;
   }
-  if (first && wave == 3) {   // total cost of the first linearisation point: the terms side by side, summed in lane order
-    double term = 0.0;
-    if (lane < ds.n_imu) term = d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 2];
-    else if (lane >= 16 && lane - 16 < ds.n_wheel) term = d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 2];
-    else if (lane == 32) term = d.prior_g[(size_t)w * (ND + 2) + ND];
-    else if (lane == 33) {   // the ranks' visual-cost shares, in rank order (any world size gfbe_set_allreduce accepts: k_solve / k_solve_big loop the same way)
-      for (int r = 0; r < d.world; r++) term += d.xa[((size_t)w * d.world + r) * XCHG];
+  __syncthreads();        // (perm is complete: the build's entries can be requested)
+  const int n = __builtin_amdgcn_readfirstlane(wcount[0] + wcount[1] + wcount[2]);      // dense dims (wave-uniform: kept in scalar registers)
+  const int na = n + 1;                 // + the right-hand side row / column
+  const int nt = (na + TB - 1) / TB;
+  const int ntile_all = nt * (nt + 1) / 2;
+  // ---- level 2: the entries of H and E the build needs (through perm), the chain blocks, the parameter blocks of |x|^2 — all in flight
+  // while the per-dim quantities below are formed from level 1
+  constexpr int NQ = (2 * CH_NC + 2) / 3;
+  int ar[S2_MAX_NT], bc[S2_MAX_NT];
+  double hv[S2_MAX_TILES], ev[S2_MAX_TILES], hc[NQ];
+  auto chain_partner = [](int k) -> int { return TW ? (k > CH_MID ? k - 1 : (k < CH_MID ? k + 1 : k)) : (k > 0 ? k - 1 : 0); };
+  // (every array entry is defined by every thread — zero first, the loads inside wave-uniform branches)
+  {
+    const int wv = wave, tt = t;
+    const int r = (tt >> 4) & 15, cc = tt & 15;
+    const int nm1 = max(n - 1, 0);
+#pragma unroll
+    for (int I = 0; I < S2_MAX_NT; I++) { ar[I] = max((int)perm[min(I * TB + r, nm1)], 0); bc[I] = max((int)perm[min(I * TB + cc, nm1)], 0); }
+#pragma unroll
+    for (int te = 0; te < S2_MAX_TILES; te++) { hv[te] = 0.0; ev[te] = 0.0; }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) hc[q] = 0.0;
+    if (wv < TB * TB / 64) {      // the dense tiles' threads
+      // (through clamped indices, selected afterwards: straight-line code, every load in flight at once)
+      int I = 0, J = 0;
+#pragma unroll
+      for (int te = 0; te < S2_MAX_TILES; te++) {
+        if (te < ntile_all) {                                   // (wave-uniform)
+          const int hi = max(ar[I], bc[J]), lo = min(ar[I], bc[J]);
+          hv[te] = H[(size_t)hi * ND + lo];
+          ev[te] = E[min(hi, NV - 1) * NV + min(lo, NV - 1)];
+        }
+        if (++J > I) { J = 0; I++; }
+      }
     }
-    else if (lane >= 44 && lane - 44 < ds.n_plane) term = d.plane_part[((size_t)w * MAX_PLANE + lane - 44) * PLANE_PART + PLANE_PART - 2];
-    else if (lane == 58 && ds.use_anchor) term = d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
-    cterm[lane] = term;
+    if (TW ? wv >= TB * TB / 64 : true) {      // the chain blocks' threads (twisted: the second half of the workgroup, beside the dense tiles)
+      const int tc = TW ? tt - TB * TB : tt;
+      const int tcc = tc < 3 * CH_BLK ? tc : 0;
+      const int grp = tcc / CH_BLK, e81 = tcc - CH_BLK * grp, ei = e81 / CH_NB, ej = e81 - CH_NB * ei;
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int kb = grp + 3 * q;                     // block slot: 0..10 diagonal blocks, 11..21 couplings
+        const bool isC = kb >= CH_NC;
+        const int k = isC ? kb - CH_NC : kb;
+        const int a = T_SB(min(k, CH_NC - 1)) + ei, b = (isC ? T_SB(chain_partner(min(k, CH_NC - 1))) : T_SB(min(k, CH_NC - 1))) + ej;
+        hc[q] = H[(size_t)max(a, b) * ND + min(a, b)];
+      }
+    }
+  }
+  double xv[9];
+  {
+    const double *X = d.x + ((size_t)w * 2 + c_cur) * NA;
+    const int gs = (t < GFBE_BLK_COUNT && l_free) ? blk_gsize(tb) : 0, xa0 = blk_amb(tb);
+#pragma unroll
+    for (int k = 0; k < 9; k++) xv[k] = k < gs ? X[xa0 + k] : 0.0;
+  }
+  if (first && wave == 3) {   // total cost of the first linearisation point: the terms side by side, summed in lane order
+    cterm[lane] = l_term;
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
@@ -1248,88 +1292,50 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
       c.cost = cost; c.initial_cost = cost; c.cost_history[0] = cost;
     }
   }
-  const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
-  const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
   // Jacobi scaling (iteration 0 only), D = sqrt(clamp(diag)), scaled gradient, Cauchy direction
   double g2 = 0.0, gmax = 0.0, xn2 = 0.0;
-  for (int a = t; a < ND; a += blockDim.x) {
+  if (t < ND) {
+    const int a = t;
     double s = 1.0, dp = 1.0, gt = 0.0, v = 0.0;
-    if (ds.act[a]) {
-      const double haa = H[(size_t)a * ND + a];
-      s = first ? (d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(haa)) : 1.0) : gsp[a];
+    if (l_act) {
+      const double haa = l_haa;
+      s = first ? (d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(haa)) : 1.0) : l_sp;
       const double d2 = clamp_diag(s * s * haa);
-      dp = sqrt(d2); gt = s * g[a]; v = gt / d2;
+      dp = sqrt(d2); gt = s * l_g; v = gt / d2;
       g2 += gt * gt / d2;
-      gmax = fmax(gmax, fabs(g[a]));
+      gmax = fmax(gmax, fabs(l_g));
     }
     if (first) gsp[a] = s;
     gDp[a] = dp; ggts[a] = gt; gvp[a] = v;
     sS[a] = s; vS[a] = v; dS[a] = dp; gS[a] = gt;      // staged in LDS: the builds and the dogleg sums never wait for HBM
-    rS[a] = gt - (a < NV ? s * eg[a] : 0.0);           // right-hand side of the reduced system
+    rS[a] = gt - (a < NV ? s * l_eg : 0.0);            // right-hand side of the reduced system
   }
-  {
-    const double *X = d.x + ((size_t)w * 2 + c.cur) * NA;
-    for (int b = t; b < GFBE_BLK_COUNT; b += blockDim.x)
-      if (ds.blk_free[b]) for (int k = 0; k < blk_gsize(b); k++) { const double v = X[blk_amb(b) + k]; xn2 += v * v; }
-  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) xn2 += xv[k] * xv[k];    // (|x|^2 over the free parameter blocks: a block per thread, its entries in order; absent ones add an exact zero)
   {
     const double pv[3] = {g2, gmax, xn2};
-    block_reduce_multi_t<3>(pv, 0x2u, smem, t);
+    block_reduce_multi<3>(pv, 0x2u, smem);
     if (t == 0) { s_keep[0] = smem[48]; s_keep[1] = smem[49]; s_keep[2] = smem[50]; }   // (needed at the very end: parked in LDS, not in registers)
   }
   __syncthreads();
   STAMP(1);
-  const int n = __builtin_amdgcn_readfirstlane(s_nact);                 // dense dims (wave-uniform: kept in scalar registers)
-  const int na = n + 1;                 // + the right-hand side row / column
-  const int nt = (na + TB - 1) / TB;
-  const int ntile_all = nt * (nt + 1) / 2;
   const bool chain_on = __builtin_amdgcn_readfirstlane(s_nch) > 0;
 
   double mu = c.mu;
-  bool solved = false, e_valid = true;
+  bool solved = false;
   int att = 0;      // factorisation attempts of this linearisation so far (landmark sharding: the pass index counts them)
-  while (mu < GF_MAX_MU) {
-    if (!e_valid) {
-      if (d.sharded) {
-        if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
-        break;
-      }
-      rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
-      for (int a = t; a < ND; a += blockDim.x) rS[a] = gS[a] - (a < NV ? sS[a] * eg[a] : 0.0);   // (eg was rebuilt with E)
-      __syncthreads();
-    }
-    // ---- build: every global load of the thread's entries first (one round trip), then the arithmetic and the LDS stores.
+  double vsv = 0.0;
+  {
+    // ---- build: the arithmetic and the LDS stores (the entries were requested before the per-dim quantities were formed, or just above).
     //      Threads 0..255: entry (r, cc) = (t / 16, t % 16) of EVERY dense tile — the tangent dims of the thread's row r and column
-    //      cc of each tile row / column and their scale / direction entries are looked up once. Waves 4..5: the chain blocks.
-    double vsv = 0.0;
+    //      cc of each tile row / column and their scale / direction entries are looked up once. The chain blocks: the same threads
+    //      (twisted: the other half of the workgroup).
     {
-      int tt = t;
-      asm volatile("" : "+v"(tt));     // (opaque: the entry addresses are invariant in the mu-retry loop — hoisted out of it they are all spilled)
-      if (tt < TB * TB) {
-        const int r = tt >> 4, cc = tt & 15;
-        const int nm1 = max(n - 1, 0);
-        int ar[S2_MAX_NT], bc[S2_MAX_NT];
+      if (t < TB * TB) {
+        const int r = t >> 4, cc = t & 15;
         double sa[S2_MAX_NT], va[S2_MAX_NT], sb[S2_MAX_NT], vb[S2_MAX_NT], dd[S2_MAX_NT];
 #pragma unroll
-        for (int I = 0; I < S2_MAX_NT; I++) {
-          ar[I] = max((int)perm[min(I * TB + r, nm1)], 0); bc[I] = max((int)perm[min(I * TB + cc, nm1)], 0);
-          sa[I] = sS[ar[I]]; va[I] = vS[ar[I]]; sb[I] = sS[bc[I]]; vb[I] = vS[bc[I]]; dd[I] = dS[ar[I]];
-        }
-        // (loads unconditional, through clamped indices, selected afterwards: straight-line code, every load in flight at once)
-        double hv[S2_MAX_TILES], ev[S2_MAX_TILES];
-        {
-          int I = 0, J = 0;
-#pragma unroll
-          for (int te = 0; te < S2_MAX_TILES; te++) {
-            hv[te] = 0.0; ev[te] = 0.0;
-            if (te < ntile_all) {                                   // (wave-uniform)
-              const int hi = max(ar[I], bc[J]), lo = min(ar[I], bc[J]);
-              hv[te] = H[(size_t)hi * ND + lo];
-              ev[te] = E[min(hi, NV - 1) * NV + min(lo, NV - 1)];
-            }
-            if (++J > I) { J = 0; I++; }
-          }
-        }
+        for (int I = 0; I < S2_MAX_NT; I++) { sa[I] = sS[ar[I]]; va[I] = vS[ar[I]]; sb[I] = sS[bc[I]]; vb[I] = vS[bc[I]]; dd[I] = dS[ar[I]]; }
 #if GFBE_CHAIN_STAMP
         if (t == 0) stamp[8] = (double)wall_clock64();
 #endif
@@ -1358,30 +1364,19 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
           }
         }
       }
-      const int tc = TW ? tt - TB * TB : tt;          // (twisted: the second half of the workgroup, beside the dense tiles)
+      const int tc = TW ? t - TB * TB : t;          // (twisted: the second half of the workgroup, beside the dense tiles)
       if (chain_on && tc >= 0 && tc < 3 * CH_BLK) {
         // chain blocks: the 22 blocks A_0..A_10, C_0..C_10 (C_k = S(SB_k, SB_k-1); slot 0 of the couplings is unused — twisted: C_k =
         // S(SB_k, SB_k+1) below the middle block, whose own slot is the unused one) are dealt over three thread groups of 81 — a thread
         // keeps its entry (i, j) and takes every third block (inactive dims: H holds exact zeros there, the diagonal becomes 1)
         const int grp = tc / CH_BLK, e81 = tc - CH_BLK * grp, ei = e81 / CH_NB, ej = e81 - CH_NB * ei;
-        auto partner = [](int k) -> int { return TW ? (k > CH_MID ? k - 1 : (k < CH_MID ? k + 1 : k)) : (k > 0 ? k - 1 : 0); };
-        constexpr int NQ = (2 * CH_NC + 2) / 3;
-        double hc[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const int kb = grp + 3 * q;                     // block slot: 0..10 diagonal blocks, 11..21 couplings
-          const bool isC = kb >= CH_NC;
-          const int k = isC ? kb - CH_NC : kb;
-          const int a = T_SB(min(k, CH_NC - 1)) + ei, b = (isC ? T_SB(partner(min(k, CH_NC - 1))) : T_SB(min(k, CH_NC - 1))) + ej;
-          hc[q] = H[(size_t)max(a, b) * ND + min(a, b)];
-        }
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
           const int kb = grp + 3 * q;
           if (kb >= 2 * CH_NC) continue;
           const bool isC = kb >= CH_NC;
           const int k = isC ? kb - CH_NC : kb;
-          const int a = T_SB(k) + ei, b = (isC ? T_SB(partner(k)) : T_SB(k)) + ej;
+          const int a = T_SB(k) + ei, b = (isC ? T_SB(chain_partner(k)) : T_SB(k)) + ej;
           double v = hc[q] * sS[a] * sS[b];
           if (isC) { if (k == (TW ? CH_MID : 0)) v = 0.0; }
           else if (ei == ej) v = chact[a - T_SB(0)] ? __builtin_fma(mu * dS[a], dS[a], v) : 1.0;
@@ -1390,6 +1385,11 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
         }
       }
     }
+  }
+  // (The attempts of the mu ladder: the system of the first attempt is built before the loop, the next one's at the END of a failed
+  //  attempt — the ~100 registers of entries between the request and the build never live across the roles or the loop's back edge.)
+  if (mu < GF_MAX_MU) for (;;) {
+    // (the tiles and chain blocks of this attempt are in LDS: build_compute, before the loop / at the end of the failed attempt)
     if (t == 0) { flag = 0; s_zzc[0] = 0.0; s_zzc[1] = 0.0; }
     if (TW && t < CH_BLK) Amid[t] = 0.0;
 #if GFBE_CHAIN_STAMP
@@ -1420,7 +1420,7 @@ if (!TW) {
                         (int)YALL_LD, wave, lane, NWAVES);
       }
     }
-    vsv = block_sum_t(vsv, red, t);
+    vsv = block_sum(vsv, red);
     if (t == 0) s_vSv = vsv;
     __syncthreads();
     STAMP(15);
@@ -1435,7 +1435,7 @@ if (!TW) {
         ys[i] = z;
         zz += z * z;
       }
-      zz = block_sum_t(zz, red, t);
+      zz = block_sum(zz, red);
       if (t == 0) s_zz = zz + (s_zzc[0] + s_zzc[1]);
       __syncthreads();
       if (wave == 0) {
@@ -1537,8 +1537,106 @@ if (!TW) {
     __syncthreads();
     if (ok) { solved = true; break; }
     mu *= GF_MU_INC;
-    e_valid = false;
     att++;
+    if (!(mu < GF_MAX_MU)) break;
+    if (d.sharded) {
+      if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
+      break;
+    }
+    rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
+    for (int a = t; a < ND; a += blockDim.x) rS[a] = gS[a] - (a < NV ? sS[a] * eg[a] : 0.0);   // (eg was rebuilt with E)
+    __syncthreads();
+    // ---- the system of the next attempt, built in place (the cold path: loads and arithmetic in one piece, like rounds 3-4)
+    //      Threads 0..255: entry (r, cc) = (t / 16, t % 16) of EVERY dense tile — the tangent dims of the thread's row r and column
+    //      cc of each tile row / column and their scale / direction entries are looked up once. Waves 4..5: the chain blocks.
+    vsv = 0.0;
+    {
+      int tt = t;
+      asm volatile("" : "+v"(tt));     // (opaque: the entry addresses are invariant in the mu-retry loop — hoisted out of it they are all spilled)
+      if (tt < TB * TB) {
+        const int r = tt >> 4, cc = tt & 15;
+        const int nm1 = max(n - 1, 0);
+        int ar[S2_MAX_NT], bc[S2_MAX_NT];
+        double sa[S2_MAX_NT], va[S2_MAX_NT], sb[S2_MAX_NT], vb[S2_MAX_NT], dd[S2_MAX_NT];
+#pragma unroll
+        for (int I = 0; I < S2_MAX_NT; I++) {
+          ar[I] = max((int)perm[min(I * TB + r, nm1)], 0); bc[I] = max((int)perm[min(I * TB + cc, nm1)], 0);
+          sa[I] = sS[ar[I]]; va[I] = vS[ar[I]]; sb[I] = sS[bc[I]]; vb[I] = vS[bc[I]]; dd[I] = dS[ar[I]];
+        }
+        // (loads unconditional, through clamped indices, selected afterwards: straight-line code, every load in flight at once)
+        double hv[S2_MAX_TILES], ev[S2_MAX_TILES];
+        {
+          int I = 0, J = 0;
+#pragma unroll
+          for (int te = 0; te < S2_MAX_TILES; te++) {
+            hv[te] = 0.0; ev[te] = 0.0;
+            if (te < ntile_all) {                                   // (wave-uniform)
+              const int hi = max(ar[I], bc[J]), lo = min(ar[I], bc[J]);
+              hv[te] = H[(size_t)hi * ND + lo];
+              ev[te] = E[min(hi, NV - 1) * NV + min(lo, NV - 1)];
+            }
+            if (++J > I) { J = 0; I++; }
+          }
+        }
+#if GFBE_CHAIN_STAMP
+        if (t == 0) stamp[8] = (double)wall_clock64();
+#endif
+        {
+          int I = 0, J = 0;
+#pragma unroll
+          for (int te = 0; te < S2_MAX_TILES; te++) {
+            if (te < ntile_all) {
+              const int a = ar[I], b = bc[J];
+              double v = (hv[te] - ((a < NV && b < NV) ? ev[te] : 0.0)) * (sa[I] * sb[J]);
+              if (I == J && r == cc) v = __builtin_fma(mu * dd[I], dd[I], v);          // (a == b: the diagonal)
+              double q = v * va[I] * (vb[J] * (I != J ? 2.0 : 1.0));
+              if (I == nt - 1) {       // (wave-uniform: the last tile row holds the right-hand side row and the padding)
+                const int ia = I * TB + r, ib = J * TB + cc;
+                if (ia >= n || ib >= n) {
+                  q = 0.0;
+                  if (ia == n && ib < n) v = rS[b];
+                  else if (ib == n && ia < n) v = rS[a];
+                  else v = (ia == ib) ? (ia == n ? 1e200 : 1.0) : 0.0;
+                }
+              }
+              vsv += q;
+              tiles[(size_t)te * (TB * TB) + tsw(r, cc)] = v;
+            }
+            if (++J > I) { J = 0; I++; }
+          }
+        }
+      }
+      const int tc = TW ? tt - TB * TB : tt;          // (twisted: the second half of the workgroup, beside the dense tiles)
+      if (chain_on && tc >= 0 && tc < 3 * CH_BLK) {
+        // chain blocks: the 22 blocks A_0..A_10, C_0..C_10 (C_k = S(SB_k, SB_k-1); slot 0 of the couplings is unused — twisted: C_k =
+        // S(SB_k, SB_k+1) below the middle block, whose own slot is the unused one) are dealt over three thread groups of 81 — a thread
+        // keeps its entry (i, j) and takes every third block (inactive dims: H holds exact zeros there, the diagonal becomes 1)
+        const int grp = tc / CH_BLK, e81 = tc - CH_BLK * grp, ei = e81 / CH_NB, ej = e81 - CH_NB * ei;
+        auto partner = [](int k) -> int { return TW ? (k > CH_MID ? k - 1 : (k < CH_MID ? k + 1 : k)) : (k > 0 ? k - 1 : 0); };
+        double hc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int kb = grp + 3 * q;                     // block slot: 0..10 diagonal blocks, 11..21 couplings
+          const bool isC = kb >= CH_NC;
+          const int k = isC ? kb - CH_NC : kb;
+          const int a = T_SB(min(k, CH_NC - 1)) + ei, b = (isC ? T_SB(partner(min(k, CH_NC - 1))) : T_SB(min(k, CH_NC - 1))) + ej;
+          hc[q] = H[(size_t)max(a, b) * ND + min(a, b)];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int kb = grp + 3 * q;
+          if (kb >= 2 * CH_NC) continue;
+          const bool isC = kb >= CH_NC;
+          const int k = isC ? kb - CH_NC : kb;
+          const int a = T_SB(k) + ei, b = (isC ? T_SB(partner(k)) : T_SB(k)) + ej;
+          double v = hc[q] * sS[a] * sS[b];
+          if (isC) { if (k == (TW ? CH_MID : 0)) v = 0.0; }
+          else if (ei == ej) v = chact[a - T_SB(0)] ? __builtin_fma(mu * dS[a], dS[a], v) : 1.0;
+          vsv = __builtin_fma(v * vS[a], vS[b] * (isC ? 2.0 : 1.0), vsv);
+          (isC ? Cch : Ach)[k * CH_BLK + e81] = v;
+        }
+      }
+    }
   }
   if (!solved) {
     if (t == 0) { c.done = 1; c.termination = 4; c.status = GFBE_NUMERICAL_FAILURE; c.lin_fail = 1; c.mu = mu; }
@@ -1571,7 +1669,7 @@ if (!TW) {
   }
   {
     const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
-    block_reduce_multi_t<8>(gv, 0u, smem, t);
+    block_reduce_multi<8>(gv, 0u, smem);
     n2 = smem[128]; gyv = smem[129]; vrhs = smem[130]; vDv = smem[131]; vDy = smem[132]; vEv = smem[133]; vEy = smem[134]; yEy = smem[135];
   }
   if (t == 0) {
