@@ -185,6 +185,107 @@ __device__ __forceinline__ bool chol_inv_tile16(lds_double *T, int lane, int zro
   return __ballot(!((myinv > 0.0) && (myinv < 1.0e300))) == 0ull;
 }
 
+// The same tile step with the 1/sqrt chain of pivot K + 1 taken OFF the critical path (round 5). The chain of a pivot — the DPP move
+// of the diagonal entry, v_rsq_f64 (26 cycles), two Newton steps: eleven DEPENDENT instructions at ~9 cycles each — stood between
+// the updates of two pivots, with nothing else to issue (a lone wave issues an independent FP64 instruction every ~5.4 cycles, a
+// dependent one every 9). Pivot K + 1 only needs a(K+1, K+1) after the update of pivot K — ONE of its ~16 row updates. So: that
+// update first, then the move and the chain of pivot K + 1 are STARTED, and the other updates of pivot K follow in the instruction
+// stream; the chain's instructions are ordinary (schedulable) code, the updates volatile assembly in a fixed order: the compiler's
+// scheduler spreads the chain between them. The unscaled-inverse half of the updates (columns 0..K of u) is dealt over the wave's
+// four 16-lane rows like the passive columns of chain_block — row group g keeps the columns c with c mod 4 == g — which leaves
+// (15 - K) + ceil((K + 1) / 4) updates per pivot instead of 16; the groups' columns are gathered when the tile is stored.
+// Same operations on every entry as chol_inv_tile16, in the same order: bit-identical results (profiles/ubench/chol_tile_check2.hip).
+#ifndef GFBE_TILE_PIPELINED
+#define GFBE_TILE_PIPELINED 1
+#endif
+// One stage of the 1/sqrt chain (rsqrt_refined, the same operations): the value is pinned where the stage is placed in the
+// instruction stream — an empty volatile assembly statement keeps its place among the (volatile) updates around it.
+template <int S>
+__device__ __forceinline__ void rsq_stage(const double d, double &nhd, double &r, double &t) {
+  // (volatile assembly: the stage stays exactly where it is placed among the updates. An ordinary statement pinned by an empty
+  //  assembly statement is either clustered with the other stages by the scheduler — pin that only reads — or, pin that redefines,
+  //  followed by a wait state per use, the hazard recogniser knowing nothing about the definition)
+  const double c15 = 1.5;
+  if (S == 0) asm volatile("v_rsq_f64 %0, %2\n\tv_mul_f64 %1, %2, -0.5" : "=&v"(r), "=&v"(nhd) : "v"(d));
+  else if (S == 1) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(nhd), "v"(r));
+  else if (S == 2) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(t) : "v"(r), "v"(c15));
+  else if (S == 3) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r) : "v"(t));
+  else if (S == 4) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(t) : "v"(nhd), "v"(r));
+  else if (S == 5) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(t) : "v"(r), "v"(c15));
+  else if (S == 6) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r) : "v"(t));
+}
+// stage S of the next pivot's chain goes behind update number RSQ_AT[S] of the current pivot (v_rsq_f64 takes 26 cycles, a dependent
+// FP64 instruction 9, an update issues in ~5.4): whatever does not fit between the updates follows them
+__device__ constexpr int rsq_at(int S) { return S == 0 ? 0 : 3 + 2 * S; }
+template <int K>
+__device__ __forceinline__ void chol_inv_step_p(double (&row)[TB], double (&u)[TB / 4], int li, int g, double &myinv, double &inv, int zrow, lds_double *zout) {
+  const double lik = row[K] * inv;          // L[i][k] for i > k
+  double m = (li > K) ? -(lik * inv) : 0.0; // -a_ik / d for the rows below the pivot; rows <= k are final
+  myinv = (li == K) ? inv : myinv;
+  // column K of the unscaled inverse starts as e_K in the group that keeps it (rows above K never touch it)
+  u[K / 4] = (g == (K & 3) && li == K) ? 1.0 : u[K / 4];
+  asm volatile("" : "+v"(u[K / 4]), "+v"(m));   // materialised HERE (two wait states before a DPP instruction reads a VALU result)
+  if (zrow >= 0) zout[K] = lane_bcast(lik, zrow);
+  constexpr bool NEXT = K + 1 < TB;
+  double dkk = 1.0, nhd = 0.0, r = inv, t = 0.0;
+  if (NEXT) {
+    dpp_fmac<K>(row[K + 1 < TB ? K + 1 : K], m);
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(dkk) : "v"(row[K + 1 < TB ? K + 1 : K]), "n"((K + 1) & 15));
+    rsq_stage<0>(dkk, nhd, r, t);
+  }
+  constexpr int NR = K + 2 < TB ? TB - K - 2 : 0, NU = K / 4 + 1, NF = NR + NU;      // the other updates of this pivot: rows, then this group's inverse columns
+#pragma unroll
+  for (int f = 0; f < NF; f++) {
+    if (f < NR) dpp_fmac<K>(row[K + 2 + (f < NR ? f : 0)], m);
+    else dpp_fmac<K>(u[f - NR < NU ? (f >= NR ? f - NR : 0) : 0], m);      // (this group's columns 4 q + g <= K; a register whose column is > K holds an exact zero in every row)
+    if (NEXT) {
+      if (f + 1 == rsq_at(1)) rsq_stage<1>(dkk, nhd, r, t);
+      if (f + 1 == rsq_at(2)) rsq_stage<2>(dkk, nhd, r, t);
+      if (f + 1 == rsq_at(3)) rsq_stage<3>(dkk, nhd, r, t);
+      if (f + 1 == rsq_at(4)) rsq_stage<4>(dkk, nhd, r, t);
+      if (f + 1 == rsq_at(5)) rsq_stage<5>(dkk, nhd, r, t);
+      if (f + 1 == rsq_at(6)) rsq_stage<6>(dkk, nhd, r, t);
+    }
+  }
+  if (NEXT) {      // the stages that did not fit between the updates
+    if (NF < rsq_at(1)) rsq_stage<1>(dkk, nhd, r, t);
+    if (NF < rsq_at(2)) rsq_stage<2>(dkk, nhd, r, t);
+    if (NF < rsq_at(3)) rsq_stage<3>(dkk, nhd, r, t);
+    if (NF < rsq_at(4)) rsq_stage<4>(dkk, nhd, r, t);
+    if (NF < rsq_at(5)) rsq_stage<5>(dkk, nhd, r, t);
+    if (NF < rsq_at(6)) rsq_stage<6>(dkk, nhd, r, t);
+    inv = r;
+  }
+}
+__device__ __forceinline__ bool chol_inv_tile16_p(lds_double *T, int lane, int zrow, lds_double *zout, double *stamp = nullptr) {
+  double row[TB], u[TB / 4];
+  const int li = lane & 15, g = lane >> 4;
+  if (stamp && lane == 0) stamp[21] = (double)wall_clock64();
+  int lio = li;
+  asm volatile("" : "+v"(lio));               // (opaque: 16 loop-invariant tile addresses hoisted out of the panel loop would be spilled)
+#pragma unroll
+  for (int q = 0; q < TB; q++) row[q] = T[tsw(lio, q)];
+#pragma unroll
+  for (int q = 0; q < TB / 4; q++) u[q] = 0.0;
+  double myinv = 0.0, inv, d00;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(d00) : "v"(row[0]));
+  inv = rsqrt_refined(d00);
+  chol_inv_step_p<0>(row, u, li, g, myinv, inv, zrow, zout);   chol_inv_step_p<1>(row, u, li, g, myinv, inv, zrow, zout);
+  chol_inv_step_p<2>(row, u, li, g, myinv, inv, zrow, zout);   chol_inv_step_p<3>(row, u, li, g, myinv, inv, zrow, zout);
+  chol_inv_step_p<4>(row, u, li, g, myinv, inv, zrow, zout);   chol_inv_step_p<5>(row, u, li, g, myinv, inv, zrow, zout);
+  chol_inv_step_p<6>(row, u, li, g, myinv, inv, zrow, zout);   chol_inv_step_p<7>(row, u, li, g, myinv, inv, zrow, zout);
+  chol_inv_step_p<8>(row, u, li, g, myinv, inv, zrow, zout);   chol_inv_step_p<9>(row, u, li, g, myinv, inv, zrow, zout);
+  chol_inv_step_p<10>(row, u, li, g, myinv, inv, zrow, zout); chol_inv_step_p<11>(row, u, li, g, myinv, inv, zrow, zout);
+  chol_inv_step_p<12>(row, u, li, g, myinv, inv, zrow, zout); chol_inv_step_p<13>(row, u, li, g, myinv, inv, zrow, zout);
+  chol_inv_step_p<14>(row, u, li, g, myinv, inv, zrow, zout); chol_inv_step_p<15>(row, u, li, g, myinv, inv, zrow, zout);
+  if (stamp && lane == 0) stamp[22] = (double)wall_clock64();
+  // lane (g, i) stores the columns 4 q + g of row i of W (exact zeros above the diagonal: a column starts as e_c and rows < c never touch it)
+#pragma unroll
+  for (int q = 0; q < TB / 4; q++) T[tsw(lio, 4 * q + g)] = u[q] * myinv;
+  if (stamp && lane == 0) stamp[23] = (double)wall_clock64();
+  return __ballot(!((myinv > 0.0) && (myinv < 1.0e300))) == 0ull;
+}
+
 // The tile build of k_solve, out of line (its own register allocation: six tiles in flight per thread group). Returns this
 // thread's share of v^T S v.
 // (address-space-typed pointers: through generic ones every load here would be a FLAT instruction)
@@ -291,7 +392,11 @@ __device__ GFBE_SOLVE_FN void chol_factor_all(lds_double *smem, int nt, int n, i
       if (e == 0 && P + 1 < nt) {   // tile (P+1, P+1) is final now: factorise and invert it here (wave 0), ahead of the block barrier
         __threadfence_block();
         __builtin_amdgcn_wave_barrier();
+#if GFBE_TILE_PIPELINED
+        if (!chol_inv_tile16_p(C, lane, P + 2 == nt ? n % TB : -1, zlast, P == 0 ? stamp : nullptr) && lane == 0) *flag = 1;
+#else
         if (!chol_inv_tile16(C, lane, P + 2 == nt ? n % TB : -1, zlast, P == 0 ? stamp : nullptr) && lane == 0) *flag = 1;
+#endif
       }
     }
     if (P == 0) CF_STAMP(20);
@@ -1077,18 +1182,29 @@ __device__ GFBE_ROLE_FN double wide_role_tw(lds_double *Ach, lds_double *Cch, ld
 // After the pipeline of k_solve_chain_tw, every wave: (1) the dense update D -= Yr^T Yr over all 100 rows of Yall, tiles dealt round robin;
 // (2) G_k = W_k^T Yc_k in place of Yc_k for the ten blocks that have a successor (the chain's back-substitution then needs one 9 x 9
 // matrix-vector product per block).
-__device__ __forceinline__ void dense_update_tw(lds_double *tiles, const lds_double *Yall, lds_double *Ach, lds_double *Cch, const lds_double *zslot, int nt,
-                                                int ld, int wave, int lane, int nwaves) {
+__device__ __forceinline__ void dense_update_tw(lds_double *tiles, const lds_double *Yall, lds_double *Ach, lds_double *Cch, const lds_double *zslot,
+                                                const lds_int *s_lo, int nt, int ld, int wave, int lane, int nwaves) {
   const int lr = lane & 15, lk = lane >> 4;
   const int ntile = nt * (nt + 1) / 2;
-  // two tiles of the wave side by side (independent accumulators: no matrix-core instruction waits for the one before it), the
-  // operands of the next five row groups in flight while the current five are multiplied
-  for (int e0 = wave; e0 < ntile; e0 += 2 * nwaves) {
-    const int e1 = e0 + nwaves;
-    const bool two = e1 < ntile;                                   // (wave-uniform)
-    int I0, J0, I1 = 0, J1 = 0;
-    tri_decode(e0, I0, J0);
-    if (two) tri_decode(e1, I1, J1);
+  // Tiles by RANK, heaviest first: column J of the tile grid from the last one down, rows I from the last one down. A tile of column J
+  // only needs the rows of Yr whose blocks reach a dense column below 16 (J + 1) — the descending segment's blocks k > CH_MID start at
+  // s_lo[k] (everything below is an exact zero), and their rows are the LAST ones of Yall: rows 0 .. 9 (kmax + 1) - 1, in groups of
+  // four. Wave w takes the tiles of rank w and ntile - 1 - w (a heavy one with a light one) side by side — independent accumulators:
+  // no matrix-core instruction waits for the one before it —, the operands of the next five groups in flight while five are multiplied.
+  auto tile_of_rank = [&](int q, int &I, int &J, int &ng) {
+    J = nt - 1;
+    while (q >= nt - J) { q -= nt - J; J--; }
+    I = nt - 1 - q;
+    int kmax = CH_NC - 1;
+    while (kmax > CH_MID && s_lo[kmax] >= TB * (J + 1)) kmax--;
+    ng = __builtin_amdgcn_readfirstlane((CH_NB * (kmax + 1) + 3) / 4);      // groups of four rows (<= 25)
+  };
+  for (int q0 = wave; 2 * q0 < ntile; q0 += nwaves) {
+    const int q1 = ntile - 1 - q0;
+    const bool two = q1 > q0;                                      // (wave-uniform; the middle rank of an odd count stands alone)
+    int I0, J0, ng0, I1 = 0, J1 = 0, ng1 = 0;
+    tile_of_rank(q0, I0, J0, ng0);
+    if (two) tile_of_rank(q1, I1, J1, ng1);
     const lds_double *pa0 = Yall + lk * ld + min(TB * I0, ld - TB) + lr, *pb0 = Yall + lk * ld + min(TB * J0, ld - TB) + lr;
     const lds_double *pa1 = Yall + lk * ld + min(TB * I1, ld - TB) + lr, *pb1 = Yall + lk * ld + min(TB * J1, ld - TB) + lr;
     dbl4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -1097,6 +1213,7 @@ __device__ __forceinline__ void dense_update_tw(lds_double *tiles, const lds_dou
     for (int q = 0; q < 5; q++) { a0[q] = pa0[4 * q * ld]; b0[q] = pb0[4 * q * ld]; a1[q] = pa1[4 * q * ld]; b1[q] = pb1[4 * q * ld]; }
 #pragma unroll
     for (int g = 0; g < 5; g++) {
+      if (5 * g >= ng0) break;                                     // (rank q0 is the heavier tile: ng1 <= ng0)
       if (g < 4) {
 #pragma unroll
         for (int q = 0; q < 5; q++) {
@@ -1106,8 +1223,8 @@ __device__ __forceinline__ void dense_update_tw(lds_double *tiles, const lds_dou
       }
 #pragma unroll
       for (int q = 0; q < 5; q++) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
-        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
+        if (5 * g + q < ng0) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], b0[q], acc0, 0, 0, 0);
+        if (5 * g + q < ng1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], b1[q], acc1, 0, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < 5; q++) { a0[q] = na0[q]; b0[q] = nb0[q]; a1[q] = na1[q]; b1[q] = nb1[q]; }
@@ -1122,7 +1239,7 @@ __device__ __forceinline__ void dense_update_tw(lds_double *tiles, const lds_dou
     }
   }
   const bool in01 = lr < CH_NB, in2 = lr < CH_NB && lk == 0;
-  for (int q = wave; q < CH_NC - 1; q += nwaves) {
+  for (int q = nwaves - 1 - wave; q < CH_NC - 1; q += nwaves) {       // (from the last wave down: the first ones carry the heaviest tile pairs)
     const int k = q < CH_MID ? q : q + 1;                          // (every block but the middle one)
     const lds_double *t01 = in01 ? Ach + k * CH_BLK + lk * CH_NB + lr : zslot, *t2 = in2 ? Ach + k * CH_BLK + 8 * CH_NB + lr : zslot;
     lds_double *c01 = Cch + k * CH_BLK + lk * CH_NB + lr, *c2 = Cch + k * CH_BLK + 8 * CH_NB + lr;
@@ -1168,7 +1285,7 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   if (retry_pass && !c_lin_retry) return;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   __shared__ short perm[ND + TB];
-  __shared__ double red[16], ys[ND + TB];                        // ys: the solution of the dense part (tile order)
+  __shared__ double ys[ND + TB];                                 // ys: the solution of the dense part (tile order)
   __shared__ double sS[ND], vS[ND], dS[ND], gS[ND], rS[ND], yT[ND];   // per tangent dim: Jacobi scale, Cauchy direction, D, scaled gradient, right-hand side, GN step
   __shared__ double s_zz, s_zzc[2], s_vSv, zlast[TB], xs[CH_ROWS + 16], tch[CH_ROWS + 16], cterm[64];
   __shared__ double s_keep[4];
@@ -1416,13 +1533,11 @@ if (!TW) {
         else if (wave < 2 + S2_WIDE_WAVES) vsv += wide_role_tw<0>(WIDE_ARGS(0), wave - 2, lane, stamp);
         else vsv += wide_role_tw<1>(WIDE_ARGS(1), wave - 2 - S2_WIDE_WAVES, lane, stamp);
 #undef WIDE_ARGS
-        dense_update_tw((lds_double *)tiles, (const lds_double *)Yall, (lds_double *)Ach, (lds_double *)Cch, (const lds_double *)zslot, nt,
-                        (int)YALL_LD, wave, lane, NWAVES);
+        dense_update_tw((lds_double *)tiles, (const lds_double *)Yall, (lds_double *)Ach, (lds_double *)Cch, (const lds_double *)zslot,
+                        (const lds_int *)s_lo, nt, (int)YALL_LD, wave, lane, NWAVES);
       }
     }
-    vsv = block_sum(vsv, red);
-    if (t == 0) s_vSv = vsv;
-    __syncthreads();
+    __syncthreads();      // (the thread's share of v^T S v is summed with |z|^2 below: one reduction instead of two on this path)
     STAMP(15);
     chol_factor_all<NWAVES>((lds_double *)tiles, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
     bool ok = (flag == 0);
@@ -1435,8 +1550,11 @@ if (!TW) {
         ys[i] = z;
         zz += z * z;
       }
-      zz = block_sum(zz, red);
-      if (t == 0) s_zz = zz + (s_zzc[0] + s_zzc[1]);
+      {
+        const double zv[2] = {zz, vsv};
+        block_reduce_multi<2>(zv, 0u, cterm);      // (same wave-order sums as two block_sum calls; cterm: free since the prologue)
+        if (t == 0) { s_zz = cterm[32] + (s_zzc[0] + s_zzc[1]); s_vSv = cterm[33]; }
+      }
       __syncthreads();
       if (wave == 0) {
         const int cI = lane & 15, part = lane >> 4;
@@ -1788,7 +1906,11 @@ __device__ __noinline__ void big_factor(glb_double *S, int nt, int n, int lane, 
       for (int q = 0; q < 4; q++) Dgl[tsw(lk + 4 * q, lr)] = acc0[q];
       __threadfence_block();
       __builtin_amdgcn_wave_barrier();
+#if GFBE_TILE_PIPELINED
+      if (!chol_inv_tile16_p(Dgl, lane, j == nt - 1 ? n % TB : -1, zlast) && lane == 0) *flag = 1;
+#else
       if (!chol_inv_tile16(Dgl, lane, j == nt - 1 ? n % TB : -1, zlast) && lane == 0) *flag = 1;
+#endif
     }
     FSTAMP(10);
     __syncthreads();
