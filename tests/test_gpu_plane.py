@@ -50,7 +50,11 @@ def test_plane_window_both_factorisations_hold_the_plain_tolerances(oracle):
 def test_plane_in_solve_and_marginalisation(be, oracle, anchor):
     scn, snap = plane_window(anchor=anchor)
     want, got = check_solve(be, oracle, snap, abi.MARGIN_OLD)
-    assert np.abs(got["state"]["plane_R"] - want["state"]["plane_R"]).max() < 1e-9 and abs(got["state"]["plane_Z"] - want["state"]["plane_Z"]) < 1e-8
+    # (plane_R: 2e-9 in the quaternion. The roll of the ground plane is the weakest dim of this window, which stops on the function
+    #  tolerance at iteration 6; the three orders of elimination of gfbe_options.solve_kernel end 9.0e-10 (monolithic), 1.0e-10 (chain
+    #  from one end) and 1.0e-9 (chain from both ends, the default of a single window since round 5) from the oracle — rounding scatter,
+    #  tools/diag_scripts/plane_kernels.py; final cost within the plain 1e-9 for all three)
+    assert np.abs(got["state"]["plane_R"] - want["state"]["plane_R"]).max() < 2e-9 and abs(got["state"]["plane_Z"] - want["state"]["plane_Z"]) < 1e-8
     assert abi.BLK_PLANE_R in got["prior"]["block_id"].tolist()
     check_prior(want["prior"], got["prior"])
     # the next window: the prior carries the 4-wide plane block; rejected steps make it an unsettled run that stops on the
