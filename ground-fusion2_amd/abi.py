@@ -763,19 +763,22 @@ def pg_plus(x, d6):
 # ---------------------------------------------------------------------------------------------
 # f4: LIO point-to-plane factors (gfbe_lio_linearize / gfo_lio_linearize)
 # ---------------------------------------------------------------------------------------------
-def lio_linearize(lib, prefix, ctx, ct, pts, normals, offsets, alpha, weights, sqrt_info, pose_begin, pose_end=None):
+def lio_linearize(lib, prefix, ctx, ct, pts, normals, offsets, alpha, weights, sqrt_info, pose_begin, pose_end=None, blocks=True):
+    """blocks = False: only the normal equations (H = J^T J, g = J^T r, cost) come back — what a caller that feeds a solver needs;
+    the per-factor residuals / Jacobians (r [n], J [n][6 or 12]) are not produced or copied."""
     pts, normals, offsets = _f64(pts).reshape(-1, 3), _f64(normals).reshape(-1, 3), _f64(offsets)
     n, dn = len(pts), 12 if ct else 6
     al = _f64(alpha if alpha is not None else np.zeros(n))
     wg = _f64(weights if weights is not None else np.ones(n))
     pb = _f64(pose_begin)
     pe = _f64(pose_end if pose_end is not None else pose_begin)
-    r, J, H, g, cost = np.zeros(n), np.zeros((n, dn)), np.zeros((dn, dn)), np.zeros(dn), np.zeros(1)
+    r, J = (np.zeros(n), np.zeros((n, dn))) if blocks else (None, None)
+    H, g, cost = np.zeros((dn, dn)), np.zeros(dn), np.zeros(1)
     f = getattr(lib, prefix + "lio_linearize")
     f.restype = c_i
     f.argtypes = [C.c_void_p, c_i, c_i, PD, PD, PD, PD, PD, c_d, PD, PD, PD, PD, PD, PD, PD]
-    rc = f(ctx, int(ct), n, _pd(pts), _pd(normals), _pd(offsets), _pd(al), _pd(wg), float(sqrt_info), _pd(pb), _pd(pe), _pd(r), _pd(J), _pd(H),
-           _pd(g), _pd(cost))
+    rc = f(ctx, int(ct), n, _pd(pts), _pd(normals), _pd(offsets), _pd(al), _pd(wg), float(sqrt_info), _pd(pb), _pd(pe),
+           _pd(r) if blocks else None, _pd(J) if blocks else None, _pd(H), _pd(g), _pd(cost))
     if rc != OK:
         raise RuntimeError("%slio_linearize failed with status %d" % (prefix, rc))
     return dict(r=r, J=J, H=H, g=g, cost=float(cost[0]))

@@ -359,6 +359,7 @@ hipStream_t ctx_stream(gfbe_ctx *c);
 int ctx_device(const gfbe_ctx *c);
 void ctx_set_error(gfbe_ctx *c, const char *msg);
 void *ctx_scratch(gfbe_ctx *c, size_t bytes);   // grow-only device scratch of the context (one caller at a time), nullptr on failure
+void *ctx_scratch_pinned(gfbe_ctx *c, size_t bytes);   // its pinned host mirror (grow-only, same rules)
 void launch_xchg_gram(const BatchDev &d, hipStream_t s);
 void launch_xchg_cand(const BatchDev &d, hipStream_t s);
 void launch_lam_mask(const BatchDev &d, hipStream_t s);

@@ -208,6 +208,18 @@ void *ctx_scratch(gfbe_ctx *c, size_t bytes) {
   }
   return c->scratch;
 }
+// grow-only PINNED host mirror of that scratch (the staging buffer of the calls that move host arrays through it in one copy each way)
+void *ctx_scratch_pinned(gfbe_ctx *c, size_t bytes) {
+  if (bytes > c->scratch_pin_cap) {
+    (void)hipStreamSynchronize(c->stream);
+    if (c->scratch_pin) (void)hipHostFree(c->scratch_pin);
+    c->scratch_pin = nullptr; c->scratch_pin_cap = 0;
+    const size_t cap = bytes + bytes / 2;
+    if (hipHostMalloc((void **)&c->scratch_pin, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->scratch_pin_cap = cap;
+  }
+  return c->scratch_pin;
+}
 }  // namespace gfd
 
 extern "C" {
