@@ -304,6 +304,7 @@ struct BatchDev {
                               // (zeros for the windows that do not retry), summed by one all-reduce before the retry pass of k_solve
   double *sp, *Dp, *gts, *vp, *yp, *step;   // [B][ND] each
   // k_solve_chain (gfbe_solve.hip): the speed-bias blocks are eliminated before the dense factorisation
+  size_t solve_scratch_stride;   // doubles per window of solveY / solveS (dead after the solve: scratch of the marginalisation's eigen-decomposition)
   double *solveY;             // [B][96][104]  Yr rows of the chain, transposed (written by the elimination, read back by the back-substitution)
   int solve_ntile;            // dense tiles (16 x 16, lower triangle incl. the right-hand side row) of the largest window: sizes the dynamic LDS
   int solve_mono;             // some window's prior couples a speed-bias block other than SpeedBias[0]: the whole batch takes the monolithic k_solve

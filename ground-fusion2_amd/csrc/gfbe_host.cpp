@@ -879,6 +879,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(dbg_imu, (size_t)B * MAX_IMU * 15 * 31); AL(dbg_wheel, (size_t)B * MAX_WHEEL * 6 * 23); AL(dbg_prior, (size_t)B * ND);
     AL(rec, want_rec ? (size_t)tot_rec * REC : 1); AL(mV, (size_t)B * ND * ND);
     AL(vis_contrib, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) * MAXOBS * 16 * LM_TILE : 1);
+    d.solve_scratch_stride = d.solve_big ? (size_t)BIG_LD * BIG_LD : solve_chain_scratch_doubles();
     AL(solveY, d.solve_big ? 1 : (size_t)B * solve_chain_scratch_doubles());
     AL(solveS, d.solve_big ? (size_t)B * BIG_LD * BIG_LD : 1);
     AL(gnss_J, (size_t)std::max(tot_gnss, 1) * 36); AL(gnss_r, (size_t)std::max(tot_gnss, 1) * 2);

@@ -77,6 +77,15 @@ __device__ __forceinline__ int m_vp_off(int a, int b) {   // entry (a <= b) of t
   return 320 + (a - 16) * 4 + (b - 16);
 }
 
+// 1/sqrt(d) from v_rsq_f64 + two Newton steps (full FP64 accuracy; the same sequence as rsqrt_refined of gfbe_solve.hip)
+__device__ __forceinline__ double rsqrt_refined_m(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  const double hd = 0.5 * d;
+  r = r * __builtin_fma(-hd * r, r, 1.5);
+  r = r * __builtin_fma(-hd * r, r, 1.5);
+  return r;
+}
+
 struct MargShared {
   int touched[GFBE_BLK_COUNT];
   int keep_id[GFBE_MAX_PRIOR_BLOCKS];
@@ -152,6 +161,218 @@ __device__ void jacobi_eig(double *G, double *V, int n, int ld, double *lam, int
     lam[j] = s;
   }
   __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Symmetric eigen-decomposition the way Eigen's SelfAdjointEigenSolver — the reference's (marginalization_factor.cpp:281) — does it:
+// Householder tridiagonalisation, then implicit-shift QL on the tridiagonal matrix with the rotations accumulated into the
+// eigenvectors (round 5: the one-sided Jacobi above needs up to 40 sweeps on the 1e14-conditioned A' of a window — 7.7 ms for the
+// 86-dim prior, six times the rest of the call; this takes 2.2 ms: 0.22 + 0.14 + 1.9 for the three phases below).
+//   phase 1  A = Q T Q^T: n - 2 reflectors H_k = I - beta v v^T, each a symmetric matrix-vector product and a rank-2 update of the
+//            trailing block by the whole workgroup (four block barriers per reflector); v stays in column k of A below the diagonal
+//   phase 2  Q = H_0 ... H_(n-3) accumulated backwards into Z (row-major Q), then transposed in place: row j of Z = column j of Q
+//   phase 3  QL with implicit Wilkinson shifts (tqli / tql2): the rotations of a sweep are a sequential scalar recurrence — ONE lane
+//            runs it (1/sqrt by v_rsq_f64 + two Newton steps, the next entries of d / e fetched one step ahead: ~250 ns per
+//            rotation, ~11 us per sweep of the 86-dim prior, ~165 sweeps) and leaves (c, s) in LDS; the eigenvector rows are updated by the threads 64.. (one per component, the
+//            rotated column carried in a register) WHILE the lane already runs the next sweep (double-buffered lists).
+// A: n x n, row stride ld, symmetric (both triangles), destroyed. Z: n x n, row stride ld: row j = eigenvector j (unit length),
+// lam[j] its eigenvalue (unsorted). wk: 6 n + (blockDim / 128) n doubles of scratch (LDS when it fits). Returns 0, or 1 when an
+// eigenvalue has not converged after 60 sweeps (the caller falls back to the Jacobi).
+// (PD: the pointer type of the matrices and the scratch — address-space-3 pointers when everything is in LDS, the n <= MARG_LDS_N of
+//  every prior the reference builds: through generic pointers every access of the sequential lane and of the rotation loop is a
+//  FLAT instruction with twice the latency, 3.0 instead of 1.x ms measured.)
+#ifndef GFBE_EIG_NOAPPLY
+#define GFBE_EIG_NOAPPLY 0      // (timing experiment: the scalar lane alone)
+#endif
+typedef __attribute__((address_space(3))) double mlds_double;
+template <typename PD>
+__device__ int tridiag_ql_eig(PD A, PD Z, int n, int ld, double *lam, PD wk, double *stamp = nullptr) {
+#define ESTAMP(i) do { if (stamp && threadIdx.x == 0) stamp[i] = (double)wall_clock64(); } while (0)
+  ESTAMP(8);
+  const int t = threadIdx.x, nt = blockDim.x, lane = t & 63;
+  const int NPART = nt >> 7;                                  // partial sums per row of a matrix-vector product (threads / 128)
+  PD dd = wk, ee = dd + n, vv = ee + n, pv = vv + n, cs = pv + n, pp = cs + 2 * n;     // cs | pp: the two lists of (c, s) pairs of phase 3
+  __shared__ double s_beta, s_K;
+  __shared__ int s_rng[2][3], s_fail;                         // per list: first rotation, last rotation (hi < lo: none), finished
+  if (n == 1) { if (t == 0) { lam[0] = A[0]; Z[0] = 1.0; } __syncthreads(); return 0; }
+  // ---- phase 1
+  for (int k = 0; k + 2 < n; k++) {
+    const int m = n - k - 1;                                  // rows k + 1 .. n - 1
+    if (t < 64) {
+      double sig = 0.0;
+      for (int i = 1 + lane; i < m; i += 64) { const double x = A[(size_t)(k + 1 + i) * ld + k]; sig += x * x; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sig += __shfl_xor(sig, o, 64);
+      const double x0 = A[(size_t)(k + 1) * ld + k];
+      double alpha = x0, beta = 0.0, v0 = 0.0;
+      if (sig > 0.0) {
+        const double nrm = sqrt(x0 * x0 + sig);
+        alpha = x0 > 0.0 ? -nrm : nrm;
+        v0 = x0 - alpha;
+        beta = 2.0 / (v0 * v0 + sig);
+      }
+      for (int i = lane; i < m; i += 64) vv[i] = beta == 0.0 ? 0.0 : (i == 0 ? v0 : A[(size_t)(k + 1 + i) * ld + k]);
+      if (lane == 0) { dd[k] = A[(size_t)k * ld + k]; ee[k] = alpha; lam[k] = beta; s_beta = beta; A[(size_t)(k + 1) * ld + k] = v0; }
+    }
+    __syncthreads();
+    const double beta = s_beta;
+    if (beta != 0.0) {                                        // (block-uniform)
+      // p = beta A22 v: thread (i, part) sums every NPART-th term of row i — read down the COLUMN i (A22 is symmetric): lanes along i
+      for (int ib = 0; ib < m; ib += 128) {
+        const int i = ib + (t & 127), part = t >> 7;
+        if (i < m) {
+          double acc = 0.0;
+          for (int c = part; c < m; c += NPART) acc = __builtin_fma(A[(size_t)(k + 1 + c) * ld + (k + 1 + i)], vv[c], acc);
+          pp[part * n + i] = acc;
+        }
+      }
+      __syncthreads();
+      if (t < 64) {
+        double vtp = 0.0;
+        for (int i = lane; i < m; i += 64) {
+          double p = 0.0;
+          for (int q = 0; q < NPART; q++) p += pp[q * n + i];
+          p *= beta;
+          pv[i] = p;
+          vtp = __builtin_fma(vv[i], p, vtp);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vtp += __shfl_xor(vtp, o, 64);
+        if (lane == 0) s_K = 0.5 * beta * vtp;
+      }
+      __syncthreads();
+      const double K = s_K;
+      // A22 -= v w^T + w v^T, w = p - K v (every entry: the block stays symmetric)
+      for (int e = t; e < m * m; e += nt) {
+        const int i = e / m, c = e - i * m;
+        const double vi = vv[i], vc = vv[c];
+        const double wi = pv[i] - K * vi, wc = pv[c] - K * vc;
+        A[(size_t)(k + 1 + i) * ld + (k + 1 + c)] -= vi * wc + wi * vc;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    dd[n - 2] = A[(size_t)(n - 2) * ld + (n - 2)]; ee[n - 2] = A[(size_t)(n - 1) * ld + (n - 2)];
+    dd[n - 1] = A[(size_t)(n - 1) * ld + (n - 1)]; ee[n - 1] = 0.0;
+  }
+  ESTAMP(9);
+  // ---- phase 2: Z = Q (row-major), backward accumulation Q <- H_k Q on the rows / columns k + 1 ..
+  for (int e = t; e < n * n; e += nt) { const int i = e / n, j = e - i * n; Z[(size_t)i * ld + j] = i == j ? 1.0 : 0.0; }
+  __syncthreads();
+  for (int k = n - 3; k >= 0; k--) {
+    const int m = n - k - 1;
+    const double beta = lam[k];
+    if (beta == 0.0) continue;                               // (block-uniform: lam is not written in this phase)
+    for (int i = t; i < m; i += nt) vv[i] = A[(size_t)(k + 1 + i) * ld + k];
+    __syncthreads();
+    for (int jb = 0; jb < m; jb += 128) {                     // s_j = sum_i v_i Q(i, j): lanes along j
+      const int j = jb + (t & 127), part = t >> 7;
+      if (j < m) {
+        double acc = 0.0;
+        for (int i = part; i < m; i += NPART) acc = __builtin_fma(vv[i], Z[(size_t)(k + 1 + i) * ld + (k + 1 + j)], acc);
+        pp[part * n + j] = acc;
+      }
+    }
+    __syncthreads();
+    for (int j = t; j < m; j += nt) { double sj = 0.0; for (int q = 0; q < NPART; q++) sj += pp[q * n + j]; pv[j] = beta * sj; }
+    __syncthreads();
+    for (int e = t; e < m * m; e += nt) {
+      const int i = e / m, j = e - i * m;
+      Z[(size_t)(k + 1 + i) * ld + (k + 1 + j)] -= vv[i] * pv[j];
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < n * n; e += nt) {                       // in-place transpose: row j of Z = column j of Q
+    const int i = e / n, j = e - i * n;
+    if (i < j) { const double a = Z[(size_t)i * ld + j], b = Z[(size_t)j * ld + i]; Z[(size_t)i * ld + j] = b; Z[(size_t)j * ld + i] = a; }
+  }
+  if (t == 0) { s_fail = 0; s_rng[0][2] = 0; s_rng[1][2] = 0; }
+  __syncthreads();
+  ESTAMP(10);
+  int nsweep = 0;
+  // ---- phase 3. The lists: cs[(b * n + i) * 2 + {0, 1}] would need 4 n doubles; pv / pp are free now: list b lives in (b ? pp : cs)
+  int l = 0, iter = 0;                                         // (thread 0's state of the QL iteration)
+  // one sweep (or the end) into list b. e[i] couples d[i] and d[i + 1]
+  // (wave 0 runs it: the search for the first negligible off-diagonal entry at or after l — up to n dependent LDS round trips on one
+  //  lane, more than the sweep itself — is a ballot over the wave's lanes; the recurrence is lane 0's)
+  auto scalar_sweep = [&](int b) {
+    PD L = b ? pp : cs;
+    for (;;) {
+      if (l >= n) { if (lane == 0) { s_rng[b][0] = 1; s_rng[b][1] = 0; s_rng[b][2] = 1; } return; }
+      int m = n - 1;
+      for (int j0 = l; j0 < n - 1; j0 += 64) {
+        const int j = j0 + lane;
+        const bool negl = j < n - 1 && fabs(ee[j]) <= 2.220446049250313e-16 * (fabs(dd[j]) + fabs(dd[min(j + 1, n - 1)]));
+        const unsigned long long bal = __ballot(negl);
+        if (bal) { m = j0 + __builtin_ctzll(bal); break; }
+      }
+      if (m == l) { l++; iter = 0; continue; }
+      if (iter++ >= 60) { if (lane == 0) s_fail = 1; l++; iter = 0; continue; }
+      if (lane != 0) return;                                   // (the other lanes wait at the block barrier; l, iter stay in step: the sweep below changes neither)
+      // The sweep itself is lane 0's. (Measured and dropped: the whole wave running it on wave-uniform values with d / e cached in lane
+      // registers and fetched by v_readlane — 11.8 instead of 10.7 us per sweep: a lone wave issues one instruction every ~5.4 cycles
+      // whatever it is, and the loop is bound by its ~55 instructions per rotation, not by the two LDS loads.)
+      double g = (dd[l + 1] - dd[l]) / (2.0 * ee[l]);
+      double r = sqrt(g * g + 1.0);
+      g = dd[m] - dd[l] + ee[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+      double sn = 1.0, c = 1.0, p = 0.0;
+      int i = m - 1;
+      double e_i = ee[i], d_i = dd[i], d_ip1 = dd[m];          // (d[i + 1] of a step is the d[i] the step before it read: no load on the chain)
+      int lo = l;
+      for (; i >= l; i--) {
+        const double e_nx = i > l ? ee[i - 1] : 0.0, d_nx = i > l ? dd[i - 1] : 0.0;      // (the next step's entries: in flight during this one)
+        const double f = sn * e_i, bq = c * e_i;
+        const double h = f * f + g * g;
+        if (h == 0.0) { ee[i + 1] = 0.0; dd[i + 1] = d_ip1 - p; ee[m] = 0.0; lo = i + 1; break; }             // (recover from underflow: tqli)
+        const double rinv = rsqrt_refined_m(h);
+        r = h * rinv;
+        ee[i + 1] = r;
+        sn = f * rinv; c = g * rinv;
+        g = d_ip1 - p;
+        r = (d_i - g) * sn + 2.0 * c * bq;
+        p = sn * r;
+        dd[i + 1] = g + p;
+        g = c * r - bq;
+        L[2 * i] = c; L[2 * i + 1] = sn;
+        d_ip1 = d_i; e_i = e_nx; d_i = d_nx;
+      }
+      if (lo == l) { dd[l] -= p; ee[l] = g; ee[m] = 0.0; }
+      s_rng[b][0] = lo; s_rng[b][1] = m - 1; s_rng[b][2] = 0;
+      return;
+    }
+  };
+  if (t < 64) scalar_sweep(0);
+  for (int b = 0;; b ^= 1) {
+    __syncthreads();                                           // list b is complete; the rows have taken list b ^ 1
+    const int lo = s_rng[b][0], hi = s_rng[b][1], fin = s_rng[b][2];
+    if (fin) break;
+    nsweep++;
+    if (t < 64) scalar_sweep(b ^ 1);
+    else if (!GFBE_EIG_NOAPPLY && t >= 64 && t - 64 < n) {
+      // component k of the eigenvectors: rotations hi .. lo on the rows (i, i + 1) of Z, the rotated row i carried in a register
+      const int k = t - 64;
+      PD L = b ? pp : cs;
+      double z1 = Z[(size_t)(hi + 1) * ld + k];
+      if (hi >= lo) {
+        double c = L[2 * hi], sn = L[2 * hi + 1], z0 = Z[(size_t)hi * ld + k];
+        for (int i = hi; i >= lo; i--) {
+          const int ip = i > lo ? i - 1 : i;                     // (the next rotation's operands: in flight during this one)
+          const double c_n = L[2 * ip], sn_n = L[2 * ip + 1], z0_n = Z[(size_t)ip * ld + k];
+          Z[(size_t)(i + 1) * ld + k] = sn * z0 + c * z1;
+          z1 = c * z0 - sn * z1;
+          c = c_n; sn = sn_n; z0 = z0_n;
+        }
+      }
+      Z[(size_t)lo * ld + k] = z1;
+    }
+  }
+  for (int j = t; j < n; j += nt) lam[j] = dd[j];
+  __syncthreads();
+  ESTAMP(11);
+  if (stamp && t == 0) stamp[12] = (double)nsweep;
+#undef ESTAMP
+  return s_fail;
 }
 
 // Same one-sided Jacobi for n <= 16, run by ONE wave (8 column pairs x 8 lanes, wave-level
@@ -354,7 +575,8 @@ __device__ __forceinline__ int ldlt_registers(LoadA loadA, LoadB loadB, double *
 #define MARG_THREADS 1024
 #endif
 #define MARG_SQRT_PENDING (-1000000)
-#define MARG_LDS_N 94   // A' up to this size is eigen-decomposed entirely inside LDS (2 n^2 doubles)
+#define MARG_LDS_N 90   // A' up to this size is eigen-decomposed entirely inside LDS (2 n^2 doubles + the 14 n of tridiag_ql_eig's scratch)
+#define MARG_LDS_DOUBLES (2 * MARG_LDS_N * MARG_LDS_N + 14 * MARG_LDS_N)
 
 __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   const int w = blockIdx.x;
@@ -721,7 +943,15 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
   for (int e = t; e < n * n; e += blockDim.x) G[e] = A[e];
   __syncthreads();
   double *lam = d.gts + (size_t)w * ND;           // solver scratch is dead by now
-  jacobi_eig(G, Vm, n, n, lam, &cflag, &sh.sweeps);
+  // Householder + QL like Eigen's solver (round 5; the Jacobi of rounds 1-4 stays as the fallback of a sweep limit nobody has hit)
+  double *wk = in_lds ? marg_lds + 2 * (size_t)n * n : (d.solve_big ? d.solveS + (size_t)w * d.solve_scratch_stride : d.solveY + (size_t)w * d.solve_scratch_stride);
+  double *estamp = (GFBE_DIAG && w == 0) ? d.timing + (size_t)d.B * 32 : nullptr;      // (diagnostics build: phase stamps into the extra timing block)
+  if (in_lds ? tridiag_ql_eig((mlds_double *)G, (mlds_double *)Vm, n, n, lam, (mlds_double *)wk, estamp) : tridiag_ql_eig(G, Vm, n, n, lam, wk, estamp)) {
+    for (int e = t; e < n * n; e += blockDim.x) G[e] = A[e];
+    __syncthreads();
+    jacobi_eig(G, Vm, n, n, lam, &cflag, &sh.sweeps);
+  } else if (t == 0) sh.sweeps = 1;
+  __syncthreads();
   G = J0;                                         // J0 rows are written to global below
   // J0 = diag(sqrt(S)) V^T, r0 = diag(1/sqrt(S)) V^T b'   (marginalization_factor.cpp:294-302)
   // rows are ordered by ascending eigenvalue like Eigen's solver
@@ -791,12 +1021,12 @@ void launch_marginalize(const BatchDev &d, int flag, hipStream_t s) {
   launch_marginalize_finish(d, flag, s);
 }
 hipError_t marg_init_device() {   // per device, from gfbe_create (see kernels_init_device)
-  return hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 2 * MARG_LDS_N * MARG_LDS_N));
+  return hipFuncSetAttribute((const void *)k_marg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * MARG_LDS_DOUBLES));
 }
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s) {
   // dynamic LDS: the eigen-decomposition of A' (marg_sqrt = 0) wants G and V resident; with the LDL^T square root only the
   // 20-dim dense elimination of a GNSS window uses it (four 32 x 32 blocks)
-  const size_t lds = sizeof(double) * (d.opt.marg_sqrt == 1 ? 4 * 32 * 32 : 2 * MARG_LDS_N * MARG_LDS_N);
+  const size_t lds = sizeof(double) * (d.opt.marg_sqrt == 1 ? 4 * 32 * 32 : MARG_LDS_DOUBLES);
   // (throughput batches: 512-thread workgroups, two per CU, overlap each other's barrier stalls — 1.04 -> 0.92 ms for the whole
   //  marginalisation of 1024 windows; a single window keeps the 1024 threads of its one workgroup)
   hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(d.B >= DENSE_SPLIT_MIN_B ? MARG_THREADS / 2 : MARG_THREADS), lds, s, d, flag);

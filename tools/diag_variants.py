@@ -13,9 +13,7 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "ground-fusion2_amd", "csrc", "variants")
 VARIANTS = {   # name -> (extra flags, fp-contract)
     "base": ([], "off"),
-    "rot0": (["-DGFBE_CHAIN_ROT=0"], "off"),
-    "rot1": (["-DGFBE_CHAIN_ROT=1"], "off"),
-    "rot3": (["-DGFBE_CHAIN_ROT=3"], "off"),
+    "eignoapply": (["-DGFBE_EIG_NOAPPLY=1"], "off"),
     "schurabs": (["-DGFBE_SCHUR_COMPACT=0"], "off"),
     "kvis3": (["-DGFBE_KVIS_WAVES=3"], "off"),
     "densetp0": (["-DGFBE_DENSE_TP=0"], "off"),
