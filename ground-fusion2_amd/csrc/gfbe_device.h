@@ -422,4 +422,9 @@ struct gfbe_ftab {
   hipEvent_t ring_ev[RING] = {};
   bool ring_used[RING] = {};
   int ring_next = 0;
+  // gfbe_batch_upload_tables reads the tables on the context's COPY stream, beside the solves queued on the main one: it waits for
+  // ev_ops (recorded on the main stream behind every table operation) and leaves ev_read behind its last reader; the next table
+  // operation waits for that one (read_pending)
+  hipEvent_t ev_ops = nullptr, ev_read = nullptr;
+  bool read_pending = false;
 };

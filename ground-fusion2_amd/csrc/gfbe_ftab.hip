@@ -628,12 +628,15 @@ struct Staged {
 gfbe_status ft_ready(gfbe_ctx *c, gfbe_ftab *t) {
   if (!c || !t) return GFBE_BAD_INPUT;
   if (ctx_device(c) < 0) return GFBE_NO_DEVICE;
+  // (a batch upload may still be reading the tables on the copy stream: this operation runs behind it)
+  if (t->read_pending && t->ev_read) { FT_CHECK(c, hipStreamWaitEvent(ctx_stream(c), t->ev_read, 0)); t->read_pending = false; }
   return GFBE_OK;
 }
 // launch errors of the operation (the sticky table errors — capacity, observation count — are raised by k_ftab_add alone and
 // come back with gfbe_ftab_add_frame's own results)
-gfbe_status ft_finish(gfbe_ctx *c, gfbe_ftab *) {
+gfbe_status ft_finish(gfbe_ctx *c, gfbe_ftab *t) {
   FT_CHECK(c, hipGetLastError());
+  if (t && t->ev_ops) FT_CHECK(c, hipEventRecord(t->ev_ops, ctx_stream(c)));      // (what gfbe_batch_upload_tables waits for)
   return GFBE_OK;
 }
 }  // namespace
@@ -683,6 +686,9 @@ gfbe_status gfbe_ftab_create(gfbe_ctx *c, int32_t n_tables, int32_t cap, const g
   FT_CHECK(c, hipMalloc((void **)&t->ring_d, (size_t)gfbe_ftab::RING * gfbe_ftab::RING_SLOT));
   FT_CHECK(c, hipHostMalloc((void **)&t->ring_h, (size_t)gfbe_ftab::RING * gfbe_ftab::RING_SLOT));
   for (int k = 0; k < gfbe_ftab::RING; k++) FT_CHECK(c, hipEventCreateWithFlags(&t->ring_ev[k], hipEventDisableTiming));
+  FT_CHECK(c, hipEventCreateWithFlags(&t->ev_ops, hipEventDisableTiming));
+  FT_CHECK(c, hipEventCreateWithFlags(&t->ev_read, hipEventDisableTiming));
+  FT_CHECK(c, hipEventRecord(t->ev_ops, ctx_stream(c)));
   FT_CHECK(c, hipStreamSynchronize(ctx_stream(c)));
   guard.armed = false;
   *out = t;
@@ -698,6 +704,8 @@ void gfbe_ftab_destroy(gfbe_ctx *c, gfbe_ftab *t) {
   if (t->ring_d) (void)hipFree(t->ring_d);
   if (t->ring_h) (void)hipHostFree(t->ring_h);
   for (hipEvent_t e : t->ring_ev) if (e) (void)hipEventDestroy(e);
+  if (t->ev_read) { (void)hipEventSynchronize(t->ev_read); (void)hipEventDestroy(t->ev_read); }
+  if (t->ev_ops) (void)hipEventDestroy(t->ev_ops);
   delete t;
 }
 

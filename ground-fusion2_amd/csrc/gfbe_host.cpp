@@ -159,6 +159,8 @@ struct gfbe_batch {
   std::vector<PoisonEntry> poison_list;     // (GFBE_POISON_UNCLEARED test hook: the slab's arrays by name)
   // results: [dl_fix | dl_feat | dl_J0] at the end of the slab -> dl_h (pinned) in one copy
   char *dl_h = nullptr;
+  char *lay_h = nullptr;                   // table-fed batches: the pinned source of the layout table's copy
+  size_t lay_cap = 0;
   size_t dl_cap = 0, dl_bytes = 0;
   std::vector<int> feat_off;
   std::vector<long long> j0_off;
@@ -658,9 +660,14 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     if (!c->sync_event_pool.empty()) { *e = c->sync_event_pool.back(); c->sync_event_pool.pop_back(); }
     else if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) { c->err = "hipEventCreate (batch) failed"; return GFBE_DEVICE_ERROR; }
   }
-  // the stream the upload runs on: host-fed batches use the copy stream (beside a solve on the main stream); the table-fed
-  // path follows the table operations on the main stream
-  hipStream_t us = tabs ? c->stream : c->copy;
+  // the stream the upload runs on: the copy stream, beside whatever the main stream is solving. The table-fed path reads the
+  // device-resident tables there too, behind the table operations enqueued so far (gfbe_ftab::ev_ops) — round 5: it used to run on the
+  // main stream and WAITED there for its landmark counts, i.e. for every solve queued before it: 12.9 ms of host time per 1024
+  // windows, and table-fed batches slower than host-fed ones
+  // (a small table-fed batch — the one-robot frame loop — stays on the main stream behind its table operations: nothing is queued there
+  //  to wait for, and a hop across streams costs ~15 us of the frame)
+  hipStream_t us = (tabs && B < DENSE_SPLIT_MIN_B) ? c->stream : c->copy;
+  if (tabs && us != c->stream && tabs->ev_ops) HIPCHK(c, hipStreamWaitEvent(us, tabs->ev_ops, 0));
   b->slot_of.resize(B);
   b->L.resize(B);
   b->anchor_only.assign(B, 0);
@@ -1108,9 +1115,13 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     HIPCHK(c, hipMemcpy2DAsync(d.prior_J0, sizeof(double) * ND * ND, d_pJ0c, sizeof(double) * pj_row, sizeof(double) * pj_row, B, hipMemcpyDeviceToDevice, us));
   if (tabs) {   // landmark arrays straight from the device-resident tables (layout table and slot map live in the tables' own scratch)
     int *dlay = tabs->d.layout + (size_t)tab0 * FT_LAY_STRIDE, *dslot = tabs->d.ids_scratch + (size_t)tab0 * tabs->d.F;
-    HIPCHK(c, hipMemcpyAsync(dlay, tlayout.data(), sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, us));
+    // (the layout table travels from a pinned buffer the batch keeps: nobody waits for the copy)
+    b->lay_h = pin_acquire(c, sizeof(int) * tlayout.size(), &b->lay_cap);
+    if (!b->lay_h) { c->err = "hipHostMalloc(layout staging) failed"; return GFBE_DEVICE_ERROR; }
+    std::memcpy(b->lay_h, tlayout.data(), sizeof(int) * tlayout.size());
+    HIPCHK(c, hipMemcpyAsync(dlay, b->lay_h, sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, us));
     launch_ftab_pack(tabs->d, tabs->cur, tab0, B, d, dlay, dslot, us);
-    HIPCHK(c, hipStreamSynchronize(us));   // tlayout dies here
+    if (tabs->ev_read && us != c->stream) { HIPCHK(c, hipEventRecord(tabs->ev_read, us)); tabs->read_pending = true; }
   } else if (B >= DENSE_SPLIT_MIN_B) {
     launch_expand(d, us);
   }
@@ -1255,8 +1266,8 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
   for (auto &g : b->graph) if (g) (void)hipGraphExecDestroy(g);
   for (hipEvent_t e : {b->ev_up, b->ev_done, b->ev_dl}) if (e) { if (c && c->sync_event_pool.size() < 64) c->sync_event_pool.push_back(e); else (void)hipEventDestroy(e); }
   slab_release(c, b);
-  if (c) { pin_release(c, b->up_h, b->up_cap); pin_release(c, b->dl_h, b->dl_cap); }
-  else { if (b->up_h) (void)hipHostFree(b->up_h); if (b->dl_h) (void)hipHostFree(b->dl_h); }
+  if (c) { pin_release(c, b->up_h, b->up_cap); pin_release(c, b->dl_h, b->dl_cap); pin_release(c, b->lay_h, b->lay_cap); }
+  else { if (b->up_h) (void)hipHostFree(b->up_h); if (b->dl_h) (void)hipHostFree(b->dl_h); if (b->lay_h) (void)hipHostFree(b->lay_h); }
   delete b;
 }
 
