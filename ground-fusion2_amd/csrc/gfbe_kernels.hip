@@ -317,7 +317,30 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   __shared__ PCT pcs[NF];
   __shared__ FrameConst fcs;
   __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XLD];   // one [J | r] row of each of the wave's 64 factors (YM: both [Y r] rows)
+  // ---- the wave's second level of loads, ALL requested before the pair constants are staged (round 5): the landmark's slot data, its
+  // inverse depth and the first observation row need nothing but the descriptor — a wave used to fetch them one dependent round trip
+  // after the other BEHIND the staging barrier (prologue 6.3 us of a ~22 us wave under load)
   const int lane = threadIdx.x;
+  const int slot = ds.lm_off + tile * LM_TILE + lane;
+  const size_t TL = d.tot_lm;
+  // (tdc: the observations of this batch are stored shifted to the windows' constant td — expand_body — and need neither their
+  //  velocities nor their own td here; compile-time for the 7 x 7 linearisation, a launch-uniform flag for the cost pass)
+  const bool tdc = YM || (MODE == 1 && !d.vis_full);
+  const int nobq = tdc ? 2 : 5;
+  const int info = d.lm_info[slot];
+  const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
+  double vix = 0.0, viy = 0.0, tdi = 0.0;
+  if (!tdc) { vix = d.lm_pts[3 * TL + slot]; viy = d.lm_pts[4 * TL + slot]; tdi = d.lm_pts[5 * TL + slot]; }
+  const double lam = lamv[slot];
+  const double td = X[A_TD];
+  // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length hold whatever the memory held —
+  // lm_obs is not cleared at upload — and are used below the track's length only); the first one here, unconditionally
+  double nob[5] = {0.0, 0.0, 0.0, 0.0, 0.0};      // (tdc: rows 2..4 are not loaded — zero velocity, the window's td: the shift is an exact zero)
+  {
+    const double *ob = d.lm_obs + (size_t)kq * 5 * TL + slot;
+#pragma unroll
+    for (int q = 0; q < 5; q++) if (q < nobq) nob[q] = ob[q * TL];
+  }
   {
     const double *src = d.pc + (((size_t)w * 3 + (MODE == 2 ? 2 : buf)) * NPAIR + sframe * NF) * PC_DOUBLES;
     for (int j = sframe + 1; j < NF; j++)
@@ -325,29 +348,18 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     if (YM && lane < FC_DOUBLES) ((double *)&fcs)[lane] = src[(size_t)sframe * PC_DOUBLES + lane];
   }
   __syncthreads();
-  const double td = X[A_TD];
   const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
   KSTAMP(1);
-
-  const int slot = ds.lm_off + tile * LM_TILE + lane;
-  const int info = d.lm_info[slot];
   const bool valid = (info >> 24) & 1;
   const int m = valid ? ((info >> 8) & 0xff) : 0;
   const bool is_const = (info >> 16) & 1;
-  const size_t TL = d.tot_lm;
   // wave-uniform trip count (tracks are sorted longest first inside a start-frame group)
   int mmax = m;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
   double cost = 0.0;
-  const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
-  // (tdc: the observations of this batch are stored shifted to the windows' constant td — expand_body — and need neither their
-  //  velocities nor their own td here; compile-time for the 7 x 7 linearisation, a launch-uniform flag for the cost pass)
-  const bool tdc = YM || (MODE == 1 && !d.vis_full);
-  const int nobq = tdc ? 2 : 5;
-  double vix = 0.0, viy = 0.0, tdi = 0.0;
-  if (!tdc) { vix = d.lm_pts[3 * TL + slot]; viy = d.lm_pts[4 * TL + slot]; tdi = d.lm_pts[5 * TL + slot]; }
-  const double lam = lamv[slot];
+  if (tdc) nob[4] = td;
+
   // landmark row of the normal equations: pose_i (6) [| extrinsic (6) | td] — the latter only when they are free somewhere
   constexpr int NHC = FULL ? HC : 6;
   double hC[NHC], Hll = 0.0, gl = 0.0;
@@ -375,14 +387,6 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
       double *xr = xs + lane * XLD;      // panel row [g0 y0 r0 0 | g1 y1 r1 0]: the two padding columns are written once
       xr[7] = 0.0; xr[15] = 0.0;
     }
-  }
-  // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length hold whatever the memory held —
-  // lm_obs is not cleared at upload — and are used below the track's length only)
-  double nob[5] = {0.0, 0.0, 0.0, 0.0, td};      // (tdc: rows 2..4 are not loaded — zero velocity, the window's td: the shift is an exact zero)
-  {
-    const double *ob = d.lm_obs + (size_t)kq * 5 * TL + slot;
-#pragma unroll
-    for (int q = 0; q < 5; q++) if (q < nobq) nob[q] = (kq < mmax) ? ob[q * TL] : 0.0;
   }
   KSTAMP(2);
   double *contrib = KS > 1 ? d.vis_contrib + (((size_t)w * d.max_tiles + tile) * MAXOBS) * (VC_STRIDE * LM_TILE) + lane : nullptr;
