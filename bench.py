@@ -268,7 +268,7 @@ def main():
         cpu, accuracy = None, None
         if not args.no_cpu_baseline and world == 1:
             cpu, accuracy = cpu_baseline(args, abi, synth, snaps, res[: args.unique])
-        lat = single_window_latencies(args, gf, torch, be, batch_snaps[0], local_rank) if not (shard or args.no_single) else None
+        lat = single_window_latencies(args, gf, torch, be, batch_snaps[0], local_rank, snaps) if not (shard or args.no_single) else None
         out = {
             "metric": "sliding-window solves/sec (10-kf, 2k landmarks)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -317,6 +317,7 @@ def main():
                                                      "host_to_host": ref["median_ms"] / lat["marg_sqrt_1_ldlt"]["host_to_host_ms"],
                                                      "note": "the reference's eigen-decomposition marginalisation on the CPU against the product's default "
                                                              "(landmarks first + pivoted LDL^T) on the GPU: NOT like for like, the figure rounds 1-3 quoted"},
+                    "per_window": per_window_quotients(cpu, lat),
                     "with_0.04s_cap": {"cpu_ms": ref["with_cap_0.04s"]["per_window_median_ms"][0], "gpu_host_to_host_ms": lat["marg_sqrt_1_ldlt"]["host_to_host_ms_cap_0.04s"],
                                        "host_to_host": ref["with_cap_0.04s"]["per_window_median_ms"][0] / lat["marg_sqrt_1_ldlt"]["host_to_host_ms_cap_0.04s"]}}
     if world > 1:
@@ -324,6 +325,21 @@ def main():
         dist.destroy_process_group()
     if out is not None:
         print(json.dumps(out))
+
+
+def per_window_quotients(cpu, lat):
+    """CPU / GPU host-to-host quotient of every unique window of the workload (same window on both sides, medians), for the three pairs
+    of speedup_like_for_like; `mean` / `min` over the windows."""
+    out = {}
+    pairs = (("reference_cpu_vs_default_gpu", "reference_construction", "marg_sqrt_1_ldlt"), ("ldlt_vs_ldlt", "product_algorithm", "marg_sqrt_1_ldlt"),
+             ("eigen_vs_eigen", "reference_construction", "marg_sqrt_0_eigen"))
+    for name, ck, gk in pairs:
+        cw, gw = cpu[ck].get("per_window_median_ms"), lat[gk].get("per_window_host_to_host_ms")
+        if not cw or not gw or len(cw) != len(gw):
+            continue
+        q = [a / b for a, b in zip(cw, gw)]
+        out[name] = {"cpu_ms": cw, "gpu_host_to_host_ms": gw, "quotient": q, "mean": float(np.mean(q)), "min": float(np.min(q))}
+    return out
 
 
 PEAK_F64_TF = 78.6     # dense FP64 matrix-core peak of one MI355X, TFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -718,7 +734,7 @@ def cpu_baseline(args, abi, synth, snaps, gpu_res):
     return cpu, accuracy
 
 
-def single_window_latencies(args, gf, torch, be, snap, device):
+def single_window_latencies(args, gf, torch, be, snap, device, all_snaps=None):
     """One window at a time — the reference's call pattern — for both square roots of the new prior: resident re-solve (upload once) and
     gfbe_solve_window host buffers to host buffers (what Estimator::optimization() would call); medians over 200 calls after 20
     warm-ups, and host to host under the reference's 0.04 s cap."""
@@ -746,6 +762,17 @@ def single_window_latencies(args, gf, torch, be, snap, device):
             th.append(time.perf_counter() - t1)
         out[key] = {"resident_ms": float(np.median(ts[20:]) * 1e3), "host_to_host_ms": float(np.median(th[20:]) * 1e3),
                     "host_to_host_p90_ms": float(np.percentile(th[20:], 90) * 1e3), "calls": n}
+        if all_snaps is not None:      # every one of the unique windows (the CPU legs cycle through them: 45-80 ms each on one core)
+            per = []
+            for sn in all_snaps:
+                hh = abi.WindowHolder(sn)
+                tt = []
+                for i in range(5 + (40 if sqrt_mode == 1 else 10)):
+                    t1 = time.perf_counter()
+                    b2.solve_raw(hh, abi.MARGIN_OLD)
+                    tt.append(time.perf_counter() - t1)
+                per.append(float(np.median(tt[5:]) * 1e3))
+            out[key]["per_window_host_to_host_ms"] = per
         b2.close()
         if sqrt_mode == 1:
             o.max_solver_time_in_seconds = 0.04
