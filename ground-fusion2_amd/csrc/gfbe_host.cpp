@@ -1325,7 +1325,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     // gfbe_options.sharded_mu_retries times (pass k of the solve kernel hands a window that fails again on to pass k + 1 with
     // mu x 10; the last pass gives up like DoglegStrategy at max_mu)
     Timed t(c, "mu_retry_sharded", 0);
-    const int passes = std::max(1, std::min(c->opt.sharded_mu_retries, 8));
+    const int passes = std::min(std::max(c->opt.sharded_mu_retries, 0), 8);
     for (int k = 1; k <= passes; k++) {
       launch_rebuild_E_shard(d, ln.s);
       run_allreduce(c, d.Er, (int64_t)d.B * (NV * NV + NV), ln.s);

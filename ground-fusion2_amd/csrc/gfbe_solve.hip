@@ -497,7 +497,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
       if (d.sharded) {
         // landmark sharding: E for the larger mu needs every rank's landmarks — hand the window to the retry pass (rebuild on
         // all ranks, one all-reduce, k_solve again); a second failure is a failed linear solve
-        if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
+        if (retry_pass < min(max(d.opt.sharded_mu_retries, 0), 8)) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
         break;
       }
       rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
@@ -1658,7 +1658,7 @@ if (!TW) {
     att++;
     if (!(mu < GF_MAX_MU)) break;
     if (d.sharded) {
-      if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
+      if (retry_pass < min(max(d.opt.sharded_mu_retries, 0), 8)) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
       break;
     }
     rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);
@@ -2035,7 +2035,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
   while (mu < GF_MAX_MU) {
     if (!e_valid) {
       if (d.sharded) {
-        if (retry_pass < max(1, min(d.opt.sharded_mu_retries, 8))) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
+        if (retry_pass < min(max(d.opt.sharded_mu_retries, 0), 8)) { if (t == 0) { c.lin_retry = 1; c.mu = mu; } return; }     // (on to pass retry_pass + 1)
         break;
       }
       rebuild_E(d, ds, w, mu, d.E + (size_t)w * NV * NV, d.eg + (size_t)w * NV, false);

@@ -279,7 +279,9 @@ typedef struct gfbe_options {
   /* Landmark sharding (gfbe_set_allreduce) only: how many times a window whose reduced system failed to factorise is retried with
    * mu x 10 (DoglegStrategy::ComputeGaussNewtonStep retries up to max_mu = 1, i.e. 8 times from min_mu = 1e-8; the unsharded kernels
    * do so inside the solve kernel). Every retry is one more [E rebuild | all-reduce | factorisation] triple in the FIXED launch
-   * sequence of every linearisation, taken or not: default 1 (well-posed windows never take even that one); 8 reproduces Ceres. */
+   * sequence of every linearisation, taken or not: default 1 (well-posed windows never take even that one); 8 reproduces Ceres;
+   * 0: no retry — a failed factorisation ends the solve as a failed linear solve, and every linearisation carries one all-reduce
+   * less (three per trust-region iteration instead of four: the packed system and the two scalar exchanges). */
   int32_t sharded_mu_retries;
 } gfbe_options;
 
