@@ -201,6 +201,9 @@ struct WinCtl {
   int num_successful, termination, status, invalid_steps, lin_fail;
   int n_clamped;
   int lin_retry;             // landmark sharding: the factorisation failed at the previous mu; the retry pass factorises with c.mu and the rebuilt, all-reduced E
+  int lb;                    // speculative linearisation (BatchDev::spec): which set of the linearisation's outputs is current (0: the first) — next to
+                             // done / reuse: the kernels between two linearisations read it with them, before their first load of the set
+  int marg_ran;              // the marginalisation kernels handled this window in the last solve
   double radius, mu, cost, cand_cost, x_norm, cand_norm2, step_amb2;
   double G2, N2, gy, vHv, vHy, yHy, alpha, grad_max;
   double c1, c2, step_norm, model_change;
@@ -208,7 +211,6 @@ struct WinCtl {
   double cost_history[16];
   unsigned char accepted[16];
   long long t_start, t_solved, t_marg;   // device wall clock (100 MHz ticks): k_reset, k_reanchor, end of the marginalisation (0: none)
-  int marg_ran, pad1;                    // the marginalisation kernels handled this window in the last solve
 };
 
 // ---- batch: all device pointers ----------------------------------------------------------------
@@ -259,6 +261,12 @@ struct BatchDev {
   int any_plane;                     // some window of the batch has plane or anchor factors (else their workgroups are not launched)
   int prior_n_max;                   // largest prior dimension of the batch (k_prior_tp stages J0 in LDS when it fits)
   double *prior_g;            // [B][ND + 2]  J0^T r, cost
+  // ---- speculative linearisation (small batches, gfbe_options.speculative_linearization): the pass that evaluates the candidate of an
+  // iteration LINEARISES there — into the second set of the linearisation's outputs below; k_accept's tail flips WinCtl::lb when the
+  // step is accepted, and the next iteration starts at the Schur elimination (lin_view: the set WinCtl::lb names). A rejected step
+  // leaves the current set alone, exactly what DoglegStrategy's reuse needs.
+  int spec;
+  double *lm_Hll2, *lm_gl2, *lm_hC2, *lm_hP2, *vis_part2, *imu_part2, *wheel_part2, *plane_part2, *anchor_part2, *prior_g2;
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
   int sharded;                      // an all-reduce hook is installed (gfbe_set_allreduce): the launch sequence with the exchange blocks, also for world == 1

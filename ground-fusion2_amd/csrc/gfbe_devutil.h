@@ -97,6 +97,18 @@ __device__ __forceinline__ void block_reduce_multi_t(const double (&v)[NQ], unsi
   __syncthreads();
 }
 
+// Speculative linearisation (BatchDev::spec): the batch seen with set `lb` of the linearisation's outputs in the places of the first
+// set — the kernels between two linearisations index d.lm_hP, d.imu_part, ... as before. lb = 0 (and every batch without the
+// second set): the batch itself.
+__device__ __forceinline__ BatchDev lin_view(const BatchDev &d, const int lb) {
+  BatchDev v = d;
+  if (d.spec && lb) {
+    v.lm_Hll = d.lm_Hll2; v.lm_gl = d.lm_gl2; v.lm_hC = d.lm_hC2; v.lm_hP = d.lm_hP2; v.vis_part = d.vis_part2;
+    v.imu_part = d.imu_part2; v.wheel_part = d.wheel_part2; v.plane_part = d.plane_part2; v.anchor_part = d.anchor_part2; v.prior_g = d.prior_g2;
+  }
+  return v;
+}
+
 // landmark sharding: tile t of a window is evaluated by rank t % world (gfbe_set_allreduce)
 #define TILE_OWNED(d, tile) ((d).world == 1 || (tile) % (d).world == (d).rank)
 

@@ -516,8 +516,10 @@ GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose
 // Wheel factor, un-whitened: raw[6], Jraw[6][22] (caller zero-fills), columns pose_i(6) pose_j(6)
 // ex_wheel(6) sx sy sw td_wheel.
 // ---------------------------------------------------------------------------------------------
+// part / nparts (as imu_raw): the Jacobian's work is eight items dealt over `nparts` callers (item j belongs to part j % nparts; part 0
+// also writes the residual) — every caller forms the residual, each item its own intermediates: the same expressions whatever the split.
 GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const double *pose_j, const double *exw,
-                     double sx, double sy, double sw, double td, double *raw, double *Jraw, size_t es = 1) {
+                     double sx, double sy, double sw, double td, double *raw, double *Jraw, size_t es = 1, int part = 0, int nparts = 1) {
   const vec3 Pi = ld3(pose_i), Pj = ld3(pose_j), tio = ld3(exw);
   const quat Qi = ldq(pose_i + 3), Qj = ldq(pose_j + 3), qio = ldq(exw + 3);
   const double *Jm = pre->jacobian;   // 6x3
@@ -539,45 +541,80 @@ GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const d
   const vec3 world_d = sub(sub(add(mv(Rj, tio), Pj), mv(Ri, tio)), Pi);
   const vec3 rp = sub(tmv(RR, world_d), p_time);                                                              // :211
   const vec3 rq = so3log(qnormalize(qmul(qmul(qmul(qinv(q_time), qinv(qmul(Qi, qio))), Qj), qio)));           // :212
-  for (int k = 0; k < 3; k++) { raw[k * es] = rp[k]; raw[(3 + k) * es] = rq[k]; }
+  if (part == 0)
+    for (int k = 0; k < 3; k++) { raw[k * es] = rp[k]; raw[(3 + k) * es] = rq[k]; }
   if (!Jraw) return;
-  const mat3 RRT = transp(RR);
-  const mat3 Jr_inv = jr_inv_so3(rq);                                    // wheel_factor.h:106-108
-  const vec3 drdsw = scl(dsw, dq_dsw);
-  const mat3 Jr_drdsw = jr_so3(drdsw);                                   // :110-112
-  put3(Jraw, 22, 0, 0, mneg(RRT), es);                                                                            // :121
-  put3(Jraw, 22, 0, 3, madd(mul(RRT, mul(Ri, hat(tio))), tmul(rio, hat(tmv(Ri, world_d)))), es);                  // :123
-  put3(Jraw, 22, 3, 3, mneg(mul(Jr_inv, qrot(qmul(qinv(qmul(Qj, qio)), Qi)))), es);                               // :131
-  put3(Jraw, 22, 0, 6, RRT, es);                                                                                  // :150
-  put3(Jraw, 22, 0, 9, mneg(mul(qrot(qmul(qinv(qmul(Qi, qio)), Qj)), hat(tio))), es);                             // :151
-  put3(Jraw, 22, 3, 9, mul(Jr_inv, qrot(qinv(qio))), es);                                                         // :157
-  put3(Jraw, 22, 0, 12, mul(RRT, msub(Rj, Ri)), es);                                                              // :170
-  put3(Jraw, 22, 0, 15, hat(mv(RRT, world_d)), es);                                                               // :172
-  put3(Jraw, 22, 3, 15, mul(Jr_inv, msub(ident3(), qrot(qmul(qmul(qinv(qmul(Qj, qio)), Qi), qio)))), es);         // :174
-  const vec3 fw = scl(sw * dtd, lin_gyr), fv = mv(sv, scl(dtd, lin_vel));
-  const vec3 bv = mv(sv, scl(dtd, vel_1)), bw = scl(sw * dtd, gyr_1);
-  const mat3 Jrtd = jr_so3(fw), Jr_mtd = jr_so3(neg(fw));
-  const mat3 Efv = qrot(so3exp(fv)), Efw = qrot(so3exp(fw));
-  const mat3 I1 = diagm(1.0, 0.0, 0.0), I2 = diagm(0.0, 1.0, 0.0);
-  const vec3 c_sx = neg(mv(Efv, sub(add(mv(I1, scl(dtd, lin_vel)), dp_dsx), mv(Rcq, mv(I1, scl(dtd, vel_1))))));   // :199
-  const vec3 c_sy = neg(mv(Efv, sub(add(mv(I2, scl(dtd, lin_vel)), dp_dsy), mv(Rcq, mv(I2, scl(dtd, vel_1))))));   // :211
-  const vec3 inner = sub(add(fv, cp), mv(Rcq, bv));
-  const vec3 t1 = mv(Rcq, mv(hat(mv(Jr_drdsw, dq_dsw)), mv(sv, scl(dtd, vel_1))));
-  const vec3 t2 = mv(hat(mv(Jrtd, scl(dtd, lin_gyr))), inner);
-  const vec3 c_sw_p = neg(mv(Efw, add(sub(dp_dsw, t1), t2)));                                                  // :223
-  const mat3 Emr = qrot(so3exp(neg(rq))), Ebw = qrot(so3exp(bw)), RcqT = qrot(qinv(cq));
-  const vec3 u1 = add(mv(RcqT, mv(Jrtd, scl(dtd, lin_gyr))), mv(Jr_drdsw, dq_dsw));
-  const vec3 c_sw_r = neg(mv(Jr_inv, mv(Emr, mv(Ebw, u1))));                                                   // :225
-  const vec3 t3 = mv(hat(mv(Jrtd, scl(sw, lin_gyr))), inner);
-  const vec3 c_td_p = neg(mv(Efw, add(sub(mv(sv, lin_vel), mv(Rcq, mv(sv, vel_1))), t3)));                     // :236
-  const vec3 u2 = sub(mv(Ebw, mv(RcqT, mv(Jrtd, scl(sw, lin_gyr)))), mv(Jr_mtd, scl(sw, gyr_1)));
-  const vec3 c_td_r = neg(mv(Jr_inv, mv(Emr, u2)));                                                            // :237
-  for (int k = 0; k < 3; k++) {
-    Jraw[(size_t)(k * 22 + 18) * es] = c_sx[k];
-    Jraw[(size_t)(k * 22 + 19) * es] = c_sy[k];
-    Jraw[(size_t)(k * 22 + 20) * es] = c_sw_p[k]; Jraw[(size_t)((3 + k) * 22 + 20) * es] = c_sw_r[k];
-    Jraw[(size_t)(k * 22 + 21) * es] = c_td_p[k]; Jraw[(size_t)((3 + k) * 22 + 21) * es] = c_td_r[k];
+#define GF_WHEEL_ITEM(j) ((j) % nparts == part)
+  if (GF_WHEEL_ITEM(0)) {      // position rows of the sw column
+    const vec3 drdsw = scl(dsw, dq_dsw);
+    const mat3 Jr_drdsw = jr_so3(drdsw);                                   // wheel_factor.h:110-112
+    const vec3 fw = scl(sw * dtd, lin_gyr), fv = mv(sv, scl(dtd, lin_vel));
+    const vec3 bv = mv(sv, scl(dtd, vel_1));
+    const mat3 Jrtd = jr_so3(fw);
+    const mat3 Efw = qrot(so3exp(fw));
+    const vec3 inner = sub(add(fv, cp), mv(Rcq, bv));
+    const vec3 t1 = mv(Rcq, mv(hat(mv(Jr_drdsw, dq_dsw)), mv(sv, scl(dtd, vel_1))));
+    const vec3 t2 = mv(hat(mv(Jrtd, scl(dtd, lin_gyr))), inner);
+    const vec3 c_sw_p = neg(mv(Efw, add(sub(dp_dsw, t1), t2)));                                                  // :223
+    for (int k = 0; k < 3; k++) Jraw[(size_t)(k * 22 + 20) * es] = c_sw_p[k];
   }
+  if (GF_WHEEL_ITEM(1)) {      // rotation rows of the sw column
+    const mat3 Jr_inv = jr_inv_so3(rq);                                    // :106-108
+    const vec3 drdsw = scl(dsw, dq_dsw);
+    const mat3 Jr_drdsw = jr_so3(drdsw);
+    const vec3 fw = scl(sw * dtd, lin_gyr), bw = scl(sw * dtd, gyr_1);
+    const mat3 Jrtd = jr_so3(fw);
+    const mat3 Emr = qrot(so3exp(neg(rq))), Ebw = qrot(so3exp(bw)), RcqT = qrot(qinv(cq));
+    const vec3 u1 = add(mv(RcqT, mv(Jrtd, scl(dtd, lin_gyr))), mv(Jr_drdsw, dq_dsw));
+    const vec3 c_sw_r = neg(mv(Jr_inv, mv(Emr, mv(Ebw, u1))));                                                   // :225
+    for (int k = 0; k < 3; k++) Jraw[(size_t)((3 + k) * 22 + 20) * es] = c_sw_r[k];
+  }
+  if (GF_WHEEL_ITEM(2)) {      // position rows of the td_wheel column
+    const vec3 fw = scl(sw * dtd, lin_gyr), fv = mv(sv, scl(dtd, lin_vel));
+    const vec3 bv = mv(sv, scl(dtd, vel_1));
+    const mat3 Jrtd = jr_so3(fw);
+    const mat3 Efw = qrot(so3exp(fw));
+    const vec3 inner = sub(add(fv, cp), mv(Rcq, bv));
+    const vec3 t3 = mv(hat(mv(Jrtd, scl(sw, lin_gyr))), inner);
+    const vec3 c_td_p = neg(mv(Efw, add(sub(mv(sv, lin_vel), mv(Rcq, mv(sv, vel_1))), t3)));                     // :236
+    for (int k = 0; k < 3; k++) Jraw[(size_t)(k * 22 + 21) * es] = c_td_p[k];
+  }
+  if (GF_WHEEL_ITEM(3)) {      // rotation rows of the td_wheel column
+    const mat3 Jr_inv = jr_inv_so3(rq);
+    const vec3 fw = scl(sw * dtd, lin_gyr), bw = scl(sw * dtd, gyr_1);
+    const mat3 Jrtd = jr_so3(fw), Jr_mtd = jr_so3(neg(fw));
+    const mat3 Emr = qrot(so3exp(neg(rq))), Ebw = qrot(so3exp(bw)), RcqT = qrot(qinv(cq));
+    const vec3 u2 = sub(mv(Ebw, mv(RcqT, mv(Jrtd, scl(sw, lin_gyr)))), mv(Jr_mtd, scl(sw, gyr_1)));
+    const vec3 c_td_r = neg(mv(Jr_inv, mv(Emr, u2)));                                                            // :237
+    for (int k = 0; k < 3; k++) Jraw[(size_t)((3 + k) * 22 + 21) * es] = c_td_r[k];
+  }
+  if (GF_WHEEL_ITEM(4)) {      // position rows of pose_i and of pose_j's translation
+    const mat3 RRT = transp(RR);
+    put3(Jraw, 22, 0, 0, mneg(RRT), es);                                                                            // :121
+    put3(Jraw, 22, 0, 3, madd(mul(RRT, mul(Ri, hat(tio))), tmul(rio, hat(tmv(Ri, world_d)))), es);                  // :123
+    put3(Jraw, 22, 0, 6, RRT, es);                                                                                  // :150
+  }
+  if (GF_WHEEL_ITEM(5)) {      // the sx, sy columns
+    const vec3 fv = mv(sv, scl(dtd, lin_vel));
+    const mat3 Efv = qrot(so3exp(fv));
+    const mat3 I1 = diagm(1.0, 0.0, 0.0), I2 = diagm(0.0, 1.0, 0.0);
+    const vec3 c_sx = neg(mv(Efv, sub(add(mv(I1, scl(dtd, lin_vel)), dp_dsx), mv(Rcq, mv(I1, scl(dtd, vel_1))))));   // :199
+    const vec3 c_sy = neg(mv(Efv, sub(add(mv(I2, scl(dtd, lin_vel)), dp_dsy), mv(Rcq, mv(I2, scl(dtd, vel_1))))));   // :211
+    for (int k = 0; k < 3; k++) { Jraw[(size_t)(k * 22 + 18) * es] = c_sx[k]; Jraw[(size_t)(k * 22 + 19) * es] = c_sy[k]; }
+  }
+  if (GF_WHEEL_ITEM(6)) {      // rotation rows of the pose and extrinsic blocks
+    const mat3 Jr_inv = jr_inv_so3(rq);
+    put3(Jraw, 22, 3, 3, mneg(mul(Jr_inv, qrot(qmul(qinv(qmul(Qj, qio)), Qi)))), es);                               // :131
+    put3(Jraw, 22, 3, 9, mul(Jr_inv, qrot(qinv(qio))), es);                                                         // :157
+    put3(Jraw, 22, 3, 15, mul(Jr_inv, msub(ident3(), qrot(qmul(qmul(qinv(qmul(Qj, qio)), Qi), qio)))), es);         // :174
+  }
+  if (GF_WHEEL_ITEM(7)) {      // position rows of pose_j's rotation and of the extrinsic
+    const mat3 RRT = transp(RR);
+    put3(Jraw, 22, 0, 9, mneg(mul(qrot(qmul(qinv(qmul(Qi, qio)), Qj)), hat(tio))), es);                             // :151
+    put3(Jraw, 22, 0, 12, mul(RRT, msub(Rj, Ri)), es);                                                              // :170
+    put3(Jraw, 22, 0, 15, hat(mv(RRT, world_d)), es);                                                               // :172
+  }
+#undef GF_WHEEL_ITEM
 }
 
 // Prior: tangent difference of one kept block w.r.t. its linearisation point

@@ -245,6 +245,7 @@ void gfbe_default_options(gfbe_options *o) {
   o->host_threads = 0;                       // packing threads: min(hardware threads, 24)
   o->solve_kernel = 0;                       // chain-eliminated factorisation of the reduced system (k_solve_chain_tw below 32 windows, k_solve_chain from there)
   o->test_fail_chol_iter = 0; o->test_fail_chol_count = 1;
+  o->speculative_linearization = 1;
   o->sharded_mu_retries = 1;                 // (8 = DoglegStrategy's whole mu ladder; every retry is three more launches per linearisation)
 }
 
@@ -800,6 +801,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   d.nu = (any_gnss || gnss_dims) ? (int)ND : (int)NC;       // a batch without GNSS blocks never touches the last 59 tangent dims
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
   if (diag_getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics build only: force the 20-column panel)
+  // speculative linearisation (gfbe_options.speculative_linearization): batches on the fused small-batch launch sequence whose candidate
+  // costs are all formed by k_lin_small (small_fuse: no GNSS / LiDAR factors, no all-reduce hook) get a second set of the linearisation's outputs
+  d.spec = (c->opt.speculative_linearization && B < DENSE_SPLIT_MIN_B && !c->allreduce && !any_gnss && tot_lio == 0 && max_tiles > 0 &&
+            (GFBE_FUSE_SMALL & 6) == 6) ? 1 : 0;
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
   const double T1 = now();
@@ -851,6 +856,14 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(imu_part, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part, (size_t)B * MAX_WHEEL * WHEEL_PART);
     AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
     AL(prior_g, (size_t)B * (ND + 2));
+    if (d.spec) {   // the second set (BatchDev::spec), cleared like the first
+      AL(lm_Hll2, TL); AL(lm_gl2, TL); AL(lm_hC2, (size_t)HC * TL);
+      AL(imu_part2, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part2, (size_t)B * MAX_WHEEL * WHEEL_PART);
+      AL(plane_part2, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part2, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
+      AL(prior_g2, (size_t)B * (ND + 2));
+    } else {
+      d.lm_Hll2 = d.lm_gl2 = d.lm_hC2 = d.imu_part2 = d.wheel_part2 = d.plane_part2 = d.anchor_part2 = d.prior_g2 = nullptr;
+    }
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
     AL(tile_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) : 1);
     AL(win_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * 2 : 1);
@@ -869,6 +882,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(lm_hP, (size_t)MAXOBS * 6 * TL);    // (k_vis writes the rows below a track's length, k_schur masks the others per landmark: 1.0 MB per window)
 #endif
     AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE);   // (a tile's steps below its longest track are written by k_vis, the others never read)
+    if (d.spec) { AL(lm_hP2, (size_t)MAXOBS * 6 * TL); AL(vis_part2, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); }
+    else { d.lm_hP2 = nullptr; d.vis_part2 = nullptr; }
     AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);   // (k_marg / k_marg_ldlt write what they and k_gather read)
     AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)
     AL(pc, (size_t)B * 3 * NPAIR * PAIR_CONST_DOUBLES);                   // (written by the kernels that produce a state)
@@ -1288,7 +1303,7 @@ static int small_fuse(const gfbe_ctx *c, const BatchDev &d) {
 
 // One linearisation of the whole batch at the current parameters (skipped on device for windows
 // that only need a new radius).
-static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool first) {
+static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool first, bool have_lin = false) {
   const BatchDev &d = b->d;
   // the first linearisation has every window active; later ones skip windows that only shrink the radius
   // fork: dense factors on the aux stream (serial and timed on the main stream when profiling)
@@ -1300,7 +1315,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     (void)hipEventRecord(ln.join, ln.aux);
   }
   const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;   // one launch for visual tiles + dense factors (k_lin_small)
-  if (small) launch_lin_small(d, 0, ln.s);
+  if (small) { if (!have_lin) launch_lin_small(d, 0, ln.s); }     // (have_lin: the last iteration's candidate pass linearised, BatchDev::spec)
   else {
     { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
     if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
@@ -1344,8 +1359,12 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
   const BatchDev &d = b->d;
   { Timed t(c, "k_reset", 0); launch_reset(d, ln.s); }
   const int iters = std::min(c->opt.max_num_iterations, 15);
+  // speculative linearisation (BatchDev::spec): every candidate pass but the last linearises at the candidate, into the second set of
+  // outputs; an accepted step makes that set the current one and a rejected one keeps the old linearisation (DoglegStrategy's reuse)
+  // — either way the next iteration needs no linearisation launch.
+  const bool spec = d.spec && (small_fuse(c, d) & 6) == 6;
   for (int it = 0; it < iters; it++) {
-    enqueue_linearize(c, b, ln, it == 0);
+    enqueue_linearize(c, b, ln, it == 0, spec && it > 0);
     const int fuse = small_fuse(c, d);
     if (!(fuse & 2)) {
       { Timed t(c, "k_step", 0); launch_step(d, ln.s); }
@@ -1359,7 +1378,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       (void)hipEventRecord(ln.join, ln.aux);
     }
     const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;
-    if (small) launch_lin_small(d, 1, ln.s, fuse);
+    if (small) launch_lin_small(d, (spec && it + 1 < iters) ? 3 : 1, ln.s, fuse);
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
     if (d.any_gnss) { Timed t(c, "k_gnss_cost", 0); launch_gnss(d, 1, ln.s); }

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
       c.G2 = c.N2 = c.gy = c.vHv = c.vHy = c.yHy = c.alpha = c.grad_max = 0;
       c.c1 = c.c2 = c.step_norm = c.model_change = 0; c.initial_cost = 0;
       for (int i = 0; i < 16; i++) { c.cost_history[i] = 0; c.accepted[i] = 0; }
-      c.t_start = (long long)wall_clock64(); c.t_solved = 0; c.t_marg = 0; c.marg_ran = 0; c.pad1 = 0;
+      c.t_start = (long long)wall_clock64(); c.t_solved = 0; c.t_marg = 0; c.marg_ran = 0; c.lb = 0;
       d.ctl[w] = c;
     }
   }
@@ -277,21 +277,43 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 #ifndef GFBE_LIN_STAMP
 #define GFBE_LIN_STAMP 0
 #endif
+#ifndef GFBE_LIN_STAMP_MODE
+#define GFBE_LIN_STAMP_MODE 0      // which launch mode of k_lin_small the diagnostics build stamps
+#endif
 #define VC_STRIDE 16      // doubles per (step, lane) in vis_contrib: Hll, gl, hC[<= 13], cost
-template <int MODE, bool FULL, int KS = 1>
-__device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile, const int kq = 0) {
+// a landmark's candidate inverse depth x + s_l (c1 v_l + c2 y_l) and its shares of |x - x_cand|^2, |x_cand|^2 (k_candidate's landmark half)
+__device__ __forceinline__ double candidate_lm(const double lam, const double sl, const double vl, const double yl, const double c1, const double c2,
+                                               const bool free_lm, double &d2, double &n2) {
+  double lc = lam;
+  d2 = 0.0; n2 = 0.0;
+  if (free_lm) {
+    lc = lam + sl * (c1 * vl + c2 * yl);
+    d2 = (lam - lc) * (lam - lc);
+    n2 = lc * lc;
+  }
+  return lc;
+}
+// SPEC (MODE 0, speculative linearisation of a small batch: BatchDev::spec): the linearisation AT THE CANDIDATE of the iteration, in
+// the place of its cost pass — d is the view of the set the candidate's linearisation goes to (lin_view), the tile's cost goes
+// where the cost pass leaves it.
+// head (passes at the candidate): the tile first forms the candidate inverse depths of its landmarks — candidate_tile's work (the landmark
+// half of k_candidate), its loads requested with the evaluation's own and the lane's result kept in its register.
+template <int MODE, bool FULL, int KS = 1, bool SPEC = false>
+__device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile, const int kq = 0, const bool head = false) {
+  static_assert(!SPEC || MODE == 0, "the speculative pass is a linearisation");
+  constexpr bool CAND = (MODE == 1) || SPEC;      // evaluated at the candidate state
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
-  if (MODE == 0 && (c.done || c.reuse)) return;
-  if (MODE == 1 && (c.done || !c.have_step)) return;
+  if (MODE == 0 && !SPEC && (c.done || c.reuse)) return;
+  if (CAND && (c.done || !c.have_step)) return;
   // start frame of the tile from the descriptor's own table (scalar loads next to n_tiles) instead of tile_start[]: one dependent
   // memory round trip less before the pair constants can be fetched
   int sframe = 0;
 #pragma unroll
   for (int q = 1; q < NF; q++) sframe += (tile >= ds.sf_tile_begin[q]) ? 1 : 0;
   if (MODE == 2 && sframe != 0) return;
-  const int buf = (MODE == 1) ? 1 - c.cur : c.cur;
+  const int buf = CAND ? 1 - c.cur : c.cur;
   const double *X = (MODE == 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
   const double *lamv = d.lam + (size_t)buf * d.tot_lm;
 
@@ -302,6 +324,16 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #else
 #define KSTAMP(i) do { } while (0)
 #endif
+#if GFBE_LIN_STAMP
+  unsigned long long *lst = (unsigned long long *)(d.timing + (size_t)d.B * 32);
+  const bool lstamp = KS > 1 && MODE == 0 && tile == 0 && threadIdx.x == 0;
+#define LSTAMP(i) do { if (lstamp && kq == 0) lst[i] = wall_clock64(); } while (0)
+#define LSTAMP_ANY(i) do { if (lstamp) lst[i] = wall_clock64(); } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#define LSTAMP_ANY(i) do { } while (0)
+#endif
+  LSTAMP(14);
   KSTAMP(0);
   // pair (sframe, j) constants, j = sframe+1 .. 10, from the records the state's producer left (k_reset / k_candidate /
   // k_reanchor): one coalesced load instead of 12 quaternion -> matrix conversions, 10 triple products and two barriers per
@@ -331,7 +363,10 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   const double pix = d.lm_pts[0 * TL + slot], piy = d.lm_pts[1 * TL + slot], piz = d.lm_pts[2 * TL + slot];
   double vix = 0.0, viy = 0.0, tdi = 0.0;
   if (!tdc) { vix = d.lm_pts[3 * TL + slot]; viy = d.lm_pts[4 * TL + slot]; tdi = d.lm_pts[5 * TL + slot]; }
-  const double lam = lamv[slot];
+  const bool chead = CAND && head;
+  double lam = chead ? d.lam[(size_t)c.cur * TL + slot] : lamv[slot];
+  double c_sl = 0.0, c_vl = 0.0, c_yl = 0.0;
+  if (chead) { c_sl = d.lm_sl[slot]; c_vl = d.lm_vl[slot]; c_yl = d.lm_yl[slot]; }
   const double td = X[A_TD];
   // the observation of step k + 1 is fetched while step k is evaluated (rows beyond a track's length hold whatever the memory held —
   // lm_obs is not cleared at upload — and are used below the track's length only); the first one here, unconditionally
@@ -340,6 +375,15 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     const double *ob = d.lm_obs + (size_t)kq * 5 * TL + slot;
 #pragma unroll
     for (int q = 0; q < 5; q++) if (q < nobq) nob[q] = ob[q * TL];
+  }
+  // KS > 1 (round 5): the observation of the workgroup's SECOND step too — a lone wave per SIMD waited a memory round trip per step for the
+  // one requested a step ahead (and, vmcnt counting loads and stores in one queue, for the contribution stores issued before it). With
+  // five workgroups per tile a workgroup has two steps at most: no load is left inside its loop.
+  double nob2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if (KS > 1 && kq + KS < MAXOBS) {
+    const double *ob = d.lm_obs + (size_t)(kq + KS) * 5 * TL + slot;
+#pragma unroll
+    for (int q = 0; q < 5; q++) if (q < nobq) nob2[q] = ob[q * TL];
   }
   {
     const double *src = d.pc + (((size_t)w * 3 + (MODE == 2 ? 2 : buf)) * NPAIR + sframe * NF) * PC_DOUBLES;
@@ -350,6 +394,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   __syncthreads();
   const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
   KSTAMP(1);
+  LSTAMP(15);
   const bool valid = (info >> 24) & 1;
   const int m = valid ? ((info >> 8) & 0xff) : 0;
   const bool is_const = (info >> 16) & 1;
@@ -358,7 +403,17 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
   double cost = 0.0;
-  if (tdc) nob[4] = td;
+  if (tdc) { nob[4] = td; nob2[4] = td; }
+  if (chead) {      // x_cand = x + s_l (c1 v_l + c2 y_l): candidate_lm is candidate_tile's arithmetic
+    double d2, n2;
+    lam = candidate_lm(lam, c_sl, c_vl, c_yl, c.c1, c.c2, valid && !is_const && m > 0, d2, n2);
+    d.lam[(size_t)(1 - c.cur) * TL + slot] = lam;
+    d2 = wave_sum(d2); n2 = wave_sum(n2);
+    if (lane == 0) {
+      double *o = d.tile_cand + ((size_t)w * d.max_tiles + tile) * 4;
+      o[1] = d2; o[2] = n2;
+    }
+  }
 
   // landmark row of the normal equations: pose_i (6) [| extrinsic (6) | td] — the latter only when they are free somewhere
   constexpr int NHC = FULL ? HC : 6;
@@ -394,7 +449,17 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     if (k < 5) KSTAMP(3 + 5 * k);
     double r[2], Ji[12], Jj[12], Je[FULL ? 12 : 1], Jl[2], Jt[2], hp[6];
     const double pjx = nob[0], pjy = nob[1], vjx = nob[2], vjy = nob[3], tdj = nob[4];
-    if (k + KS < mmax) {
+    if (KS > 1) {      // two steps ahead
+#pragma unroll
+      for (int q = 0; q < 5; q++) nob[q] = nob2[q];
+      if constexpr (2 * KS < MAXOBS) {      // (not with five workgroups per tile: a load in the loop makes its back edge wait for the step's stores too)
+        if (k + 2 * KS < mmax) {
+          const double *ob = d.lm_obs + (size_t)(k + 2 * KS) * 5 * TL + slot;
+#pragma unroll
+          for (int q = 0; q < 5; q++) if (q < nobq) nob2[q] = ob[q * TL];
+        }
+      }
+    } else if (k + KS < mmax) {
       const double *ob = d.lm_obs + (size_t)(k + KS) * 5 * TL + slot;
 #pragma unroll
       for (int q = 0; q < 5; q++) if (q < nobq) nob[q] = ob[q * TL];
@@ -621,6 +686,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     }
     }   // (!YM)
   }
+  LSTAMP(16);
   if (KS > 1) {
     // the last of the tile's KS workgroups to get here adds the steps' contributions up, in step order
     __threadfence();
@@ -630,33 +696,59 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     last = __shfl(last, 0, 64);
     if (!last) return;
     __threadfence();
+    LSTAMP_ANY(17);
     if (lane == 0) *cnt = 0;     // (ready for the next launch)
     const double *cr = d.vis_contrib + (((size_t)w * d.max_tiles + tile) * MAXOBS) * (VC_STRIDE * LM_TILE) + lane;
-    for (int k = 0; k < m; k++) {
-      const double *cb = cr + (size_t)k * VC_STRIDE * LM_TILE;
-#define VC_LD(i) __hip_atomic_load(cb + (i) * LM_TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-      cost += VC_LD(15);
-      if (MODE != 1) {
-        Hll += VC_LD(0);
-        gl += VC_LD(1);
-        if (YM) {
+    // (round 5: ALL the steps' values are requested before the first sum — the loop used to take one memory round trip per step, ten
+    //  in a row for the tiles of start frame 0: ~6 of the ~17 us of a single window's linearisation launch. Same sums, same order.)
+    constexpr int NVC = (MODE == 1) ? 1 : (YM ? 6 : (FULL ? 16 : 9));      // cost [| Hll gl | D (3) or hC (6 [+ 7])]
+    constexpr int CH = (NVC > 9) ? 4 : MAXOBS;      // steps in flight (the 20-column panel's 16 values per step: four at a time)
+#define VC_LD(k, i) __hip_atomic_load(cr + ((size_t)(k) * VC_STRIDE + (i)) * LM_TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #pragma unroll
-          for (int q = 0; q < 3; q++) Dsum[q] += VC_LD(2 + q);
-        } else {
+    for (int k0 = 0; k0 < MAXOBS; k0 += CH) {
+      double vc[CH][NVC];
 #pragma unroll
-          for (int q = 0; q < 6; q++) { hC[q] += VC_LD(2 + q); if (FULL) hC[6 + q] += VC_LD(8 + q); }
-          if (FULL) hC[12] += VC_LD(14);
+      for (int u = 0; u < CH; u++) {
+        const int k = k0 + u;
+        if (k < MAXOBS && k < mmax) {      // (wave-uniform)
+          vc[u][0] = VC_LD(k, 15);
+          if (MODE != 1) {
+            vc[u][1] = VC_LD(k, 0); vc[u][2] = VC_LD(k, 1);
+#pragma unroll
+            for (int q = 0; q < NVC - 3; q++) vc[u][3 + q] = VC_LD(k, 2 + q);
+          }
         }
       }
-#undef VC_LD
+#pragma unroll
+      for (int u = 0; u < CH; u++) {
+        const int k = k0 + u;
+        if (k < MAXOBS && k < m) {
+          cost += vc[u][0];
+          if (MODE != 1) {
+            Hll += vc[u][1];
+            gl += vc[u][2];
+            if (YM) {
+#pragma unroll
+              for (int q = 0; q < 3; q++) Dsum[q] += vc[u][3 + q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 6; q++) { hC[q] += vc[u][3 + q]; if (FULL) hC[6 + q] += vc[u][9 + q]; }
+              if (FULL) hC[12] += vc[u][15];
+            }
+          }
+        }
+      }
     }
+#undef VC_LD
+    asm volatile("" :: "v"(cost));
+    LSTAMP_ANY(18);
   }
   if (YM) {      // the landmark's own part: D = the sum of its factors' d, and x, its position from the window's origin — the H_pl block
                  // of the start pose is [ D ; Ri^T ((x - t_i) x D) ] (lm_row_* in gfbe_devutil.h)
 #pragma unroll
     for (int q = 0; q < 3; q++) { hC[q] = Dsum[q]; hC[3 + q] = yx[q]; }
   }
-  if (MODE == 0 && valid) {
+  if (MODE == 0 && !SPEC && valid) {      // (SPEC: a batch with the second set forms sqrt(w_l) in k_schur — mu changes when the step is accepted)
     // the landmark's weight in the Schur term, w_l = s_l^2 / (s_l^2 Hll + mu clamp(s_l^2 Hll)) (Jacobi-scaled, mu-regularised), once
     // per landmark here instead of once per wave that stages it in k_schur; the Jacobi scale s_l is fixed at iteration 0
     // (TrustRegionMinimizer::IterationZero). A constant landmark has none.
@@ -678,28 +770,23 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     for (int q = 0; q < NHC; q++) d.lm_hC[(size_t)q * TL + slot] = hC[q];
   }
   KSTAMP(30);
+  LSTAMP_ANY(19);
   cost = wave_sum(cost);
   if (lane == 0) {
-    if (MODE == 1) d.tile_cand[((size_t)w * d.max_tiles + tile) * 4] = cost;
+    if (CAND) d.tile_cand[((size_t)w * d.max_tiles + tile) * 4] = cost;
     else d.tile_cost[(size_t)w * d.max_tiles + tile] = cost;
   }
 }
 
-__device__ __forceinline__ void candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
+__device__ __forceinline__ double candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
 template <int MODE, bool FULL>
 __global__ __launch_bounds__(LM_TILE, (MODE == 0 && !FULL) ? GFBE_KVIS_WAVES : 2) void k_vis(BatchDev d, int write_records) {
   // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
   // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
-  if (MODE == 1 && write_records) {
-    // (the cost pass of a throughput batch, write_records = 1: the tile first forms the candidate inverse depths of its landmarks —
-    //  the landmark half of k_candidate, the same 64 lanes and the same sums; k_candidate_dense has formed the candidate's dense
-    //  blocks and pair constants before. A launch of its own walked a window's tiles four at a time: 115 us per 2048 windows.)
-    const int w = blockIdx.x, tile = blockIdx.y;
-    const WinDesc &ds = d.desc[w];
-    const WinCtl &c = d.ctl[w];
-    if (tile < ds.n_tiles && TILE_OWNED(d, tile) && !c.done && c.have_step) candidate_tile(d, ds, c, w, tile, threadIdx.x);
-  }
-  vis_body<MODE, FULL>(d, MODE == 1 ? 0 : write_records, blockIdx.x, blockIdx.y);
+  // (the cost pass of a throughput batch, write_records = 1: the tile first forms the candidate inverse depths of its landmarks —
+  //  the landmark half of k_candidate, the same 64 lanes and the same sums (vis_body's head); k_candidate_dense has formed the candidate's
+  //  dense blocks and pair constants before. A launch of its own walked a window's tiles four at a time: 115 us per 2048 windows.)
+  vis_body<MODE, FULL>(d, MODE == 1 ? 0 : write_records, blockIdx.x, blockIdx.y, 0, MODE == 1 && write_records);
 }
 
 // =============================================================================================
@@ -859,17 +946,27 @@ __global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode) {
 
 // FUSED: small batches evaluate the raw factor inline (lane 0) — one launch less on the latency path of a single
 // window; otherwise the raw residuals / Jacobians come from k_dense_raw.
+// spec (mode 0 only; BatchDev::spec): the linearisation AT THE CANDIDATE in the place of its cost pass — d is the view of the set it goes to.
 template <bool FUSED>
-__device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debug_out, const int w, const int f) {
+__device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debug_out, const int w, const int f, const bool spec = false) {
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
-  if (mode == 0 && (c.done || c.reuse)) return;
-  if (mode == 1 && (c.done || !c.have_step)) return;
-  const int buf = (mode == 1) ? 1 - c.cur : c.cur;
+  const bool cand = mode == 1 || spec;
+  if (mode == 0 && !spec && (c.done || c.reuse)) return;
+  if (cand && (c.done || !c.have_step)) return;
+  const int buf = cand ? 1 - c.cur : c.cur;
   const double *X = (mode >= 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
   const int t = threadIdx.x, nthr = blockDim.x;      // (64 threads; 256 in k_lin_small: four waves share an inertial factor)
   __shared__ double raw[16], rw[16], Jraw[15 * 30], Jw[15 * 30], red[16];
   __shared__ double dx[ND], rp[ND];
+#if GFBE_LIN_STAMP
+  unsigned long long *dst_ = (unsigned long long *)(d.timing + (size_t)d.B * 32);
+  const int dsb_ = (mode == (GFBE_LIN_STAMP_MODE == 1 ? 1 : 0) && t == 0) ? (f == MAX_IMU ? 24 : (f == MAX_IMU + MAX_WHEEL ? 28 : -1)) : -1;
+#define DSTAMP(i) do { if (dsb_ >= 0) dst_[dsb_ + (i)] = wall_clock64(); } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
+  DSTAMP(0);
 
   if (f < MAX_IMU) {
     double *part = d.imu_part + ((size_t)w * MAX_IMU + f) * IMU_PART;
@@ -890,6 +987,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
         for (int q = t; q < 450; q += nthr) Jraw[q] = imu_nz(q / 30, q % 30) ? in[4 * (15 + q)] : 0.0;
     }
     __syncthreads();
+    DSTAMP(1);
     const double *S = d.imu_sqrt + (size_t)(ds.imu_off + f) * 225;   // upper triangular
     if (t < 15) { double s = 0.0; for (int b = t; b < 15; b++) s += S[t * 15 + b] * raw[b]; rw[t] = s; }
     if (mode != 1 && t >= 16 && t < 46) {
@@ -899,6 +997,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     __syncthreads();
     double cst = 0.0;
     if (t == 0) for (int a = 0; a < 15; a++) cst += 0.5 * rw[a] * rw[a];
+    DSTAMP(2);
     if (mode == 1) { if (t == 0) part[IMU_PART - 1] = cst; return; }
     for (int e = t; e < 930; e += nthr) {
       double s = 0.0;
@@ -906,6 +1005,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
       else { const int a = e - 900; for (int r = 0; r < 15; r++) s += Jw[r * 30 + a] * rw[r]; }
       part[e] = s;
     }
+    DSTAMP(3);
     if (t == 0) part[IMU_PART - 2] = cst;
     if (debug_out) {
       double *dbg = d.dbg_imu + ((size_t)w * MAX_IMU + f) * (15 * 31);
@@ -921,9 +1021,11 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     if (FUSED) {
       for (int q = t; q < 132; q += nthr) Jraw[q] = 0.0;
       __syncthreads();
-      if (t == 0)
+      // (lane 0 of EVERY wave takes its share of the Jacobian's four items, as for the inertial factor: one lane took ~16 us, the longest
+      //  item of a single window's linearisation launch)
+      if ((t & 63) == 0 && (mode != 1 || t == 0))
         wheel_raw(&d.wheel[ds.wheel_off + k], X + A_POSE(fi), X + A_POSE(fi + 1), X + A_EXW, X[A_IX], X[A_IX + 1], X[A_IX + 2],
-                  X[A_TDW], raw, mode == 1 ? nullptr : Jraw);
+                  X[A_TDW], raw, mode == 1 ? nullptr : Jraw, 1, t >> 6, nthr >> 6);
     } else {
       const double *in = d.raw_wheel + raw_of(k, w, d.B, RAW_WHEEL);
       if (t < 6) raw[t] = in[4 * t];
@@ -931,6 +1033,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
         for (int q = t; q < 132; q += nthr) Jraw[q] = wheel_nz(q / 22, q % 22) ? in[4 * (6 + q)] : 0.0;
     }
     __syncthreads();
+    DSTAMP(1);
     const double *S = d.wheel_sqrt + (size_t)(ds.wheel_off + k) * 36;
     if (t < 6) { double s = 0.0; for (int b = t; b < 6; b++) s += S[t * 6 + b] * raw[b]; rw[t] = s; }
     if (mode != 1 && t >= 16 && t < 38) {
@@ -940,6 +1043,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     __syncthreads();
     double cst = 0.0;
     if (t == 0) for (int a = 0; a < 6; a++) cst += 0.5 * rw[a] * rw[a];
+    DSTAMP(2);
     if (mode == 1) { if (t == 0) part[WHEEL_PART - 1] = cst; return; }
     for (int e = t; e < 506; e += nthr) {
       double s = 0.0;
@@ -947,6 +1051,7 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
       else { const int a = e - 484; for (int r = 0; r < 6; r++) s += Jw[r * 22 + a] * rw[r]; }
       part[e] = s;
     }
+    DSTAMP(3);
     if (t == 0) part[WHEEL_PART - 2] = cst;
     if (debug_out) {
       double *dbg = d.dbg_wheel + ((size_t)w * MAX_WHEEL + k) * (6 * 23);
@@ -1000,6 +1105,84 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     const double *J0 = d.prior_J0 + (size_t)w * ND * ND;
     const double *r0 = d.prior_r0 + (size_t)w * ND;
     double cst = 0.0;
+    DSTAMP(1);
+    if (nthr >= n) {
+      // round 5: J0 goes through LDS in chunks of whole rows, fetched as contiguous memory by all the threads; thread i forms r_i from
+      // its row (the products added in the old order), then thread k adds the chunk's rows to g_k (rows ascending: the old order
+      // too). One sweep over J0 instead of two, no thread walking a row of its own in memory (64 cache lines per load of a wave, a
+      // memory round trip every few entries: the prior took 13-17 us of a single window's ~17 us linearisation launch).
+      constexpr int PBUF = 4000;
+      __shared__ double pbuf[PBUF];
+      const int ld = n | 1, R = min(PBUF / ld, n);      // rows per chunk (n <= 246: at least 16)
+      double gk = 0.0;
+      for (int i0 = 0; i0 < n; i0 += R) {
+        const int rows = min(R, n - i0);
+        const double *src = J0 + (size_t)i0 * n;
+        // (the chunk's loads in flight together — eight per thread and pass —, the row / column of an entry carried along instead of divided out)
+        {
+          constexpr int LU = 8;
+          const int tot = rows * n, dr = nthr / n, dc = nthr - dr * n;      // e += nthr: (row, column) += (dr, dc), with carry
+          int r = t / n, c = t - r * n;
+          for (int e = t; e < tot; e += LU * nthr) {
+            double v[LU];
+#pragma unroll
+            for (int u = 0; u < LU; u++) v[u] = src[min(e + u * nthr, tot - 1)];
+#pragma unroll
+            for (int u = 0; u < LU; u++) {
+              if (e + u * nthr < tot) pbuf[r * ld + c] = v[u];
+              r += dr; c += dc;
+              if (c >= n) { c -= n; r++; }
+            }
+          }
+        }
+        __syncthreads();
+#if GFBE_LIN_STAMP
+        if (dsb_ >= 0) dst_[i0 == 0 ? 20 : 23] = wall_clock64();
+#endif
+        if (t >= i0 && t < i0 + rows) {
+          double s = r0[t];
+          const double *row = pbuf + (t - i0) * ld;
+          constexpr int PU = 8;      // (reads of eight entries in flight, their products added in order)
+          int k = 0;
+          for (; k + PU <= n; k += PU) {
+            double a[PU], b[PU];
+#pragma unroll
+            for (int u = 0; u < PU; u++) { a[u] = row[k + u]; b[u] = dx[k + u]; }
+#pragma unroll
+            for (int u = 0; u < PU; u++) s += a[u] * b[u];
+          }
+          for (; k < n; k++) s += row[k] * dx[k];
+          rp[t] = s;
+          cst += 0.5 * s * s;
+        }
+#if GFBE_LIN_STAMP
+        if (dsb_ >= 0 && i0 == 0) dst_[21] = wall_clock64();
+#endif
+        if (mode != 1) {
+          __syncthreads();
+#if GFBE_LIN_STAMP
+          if (dsb_ >= 0 && i0 == 0) dst_[22] = wall_clock64();
+#endif
+          if (t < n) {
+            constexpr int PU = 8;
+            int r = 0;
+            for (; r + PU <= rows; r += PU) {
+              double a[PU], b[PU];
+#pragma unroll
+              for (int u = 0; u < PU; u++) { a[u] = pbuf[(r + u) * ld + t]; b[u] = rp[i0 + r + u]; }
+#pragma unroll
+              for (int u = 0; u < PU; u++) gk += a[u] * b[u];
+            }
+            for (; r < rows; r++) gk += pbuf[r * ld + t] * rp[i0 + r];
+          }
+        }
+        __syncthreads();
+      }
+      cst = block_sum(cst, red);
+      DSTAMP(2);
+      if (mode == 1) { if (t == 0) pg[ND + 1] = cst; return; }
+      if (t < n) pg[t] = gk;
+    } else {
     for (int i = t; i < n; i += nthr) {
       double s = r0[i];
       for (int k = 0; k < n; k++) s += J0[(size_t)i * n + k] * dx[k];
@@ -1014,6 +1197,8 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
       for (int i = 0; i < n; i++) s += J0[(size_t)i * n + k] * rp[i];
       pg[k] = s;
     }
+    }
+    DSTAMP(3);
     if (t == 0) pg[ND] = cst;
     if (debug_out) for (int i = t; i < n; i += nthr) d.dbg_prior[(size_t)w * ND + i] = rp[i];
   }
@@ -1226,45 +1411,49 @@ hipError_t dense_init_device() {   // per device, from gfbe_create (see kernels_
 // Small batches (one window per camera frame is the reference's call pattern): the visual tiles and the inertial / wheel /
 // prior factors of a linearisation (MODE 0) or of a candidate evaluation (MODE 1) in ONE launch — the ~35 us of a single
 // lane evaluating an IMU factor hide behind the visual tiles instead of following them on the stream.
-__device__ __forceinline__ void candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
+__device__ __forceinline__ double candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
 struct AcceptLocal {
-  int done, have_step, iter, cur, num_successful, termination, status, reuse;
+  int done, have_step, iter, cur, num_successful, termination, status, reuse, lb;
   double cost, x_norm, model_change, radius, step_norm, mu, cand_cost;
 };
 template <class CT>
-__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane, CT &c, WinCtl &cg);
+__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane, CT &c, WinCtl &cg, const int cslot = 1);
 __device__ __forceinline__ bool arrive_last(int *cnt, const int expected, const int lane);
 // fuse (MODE 1, GFBE_FUSE_SMALL): bit 1 — a tile workgroup first forms the candidate inverse depths of its tile (the landmark half of
 // k_candidate; the dense half ran at the tail of k_lm_step_fused); bit 2 — the workgroup of a window that finishes last goes on with
 // k_accept.
+// MODE 3 (BatchDev::spec, every iteration of the batch but the last): the candidate is LINEARISED — MODE 0's work at the candidate state,
+// into the set of outputs that is not the current one — and the accepting tail makes that set the current one: the next iteration
+// starts at the Schur elimination. Costs more than MODE 1 (~17 against ~14 us for a 2k-landmark window) and saves the next MODE 0 launch.
 template <int MODE, bool FULL>
-__global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, int fuse) {
+__global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d0, int fuse) {
   const int w = blockIdx.x, y = blockIdx.y;
-  constexpr int KS = MODE != 1 ? LIN_SMALL_KS : 1;      // (the cost-only pass is too short to gain: 9 -> 12 us when split)
+  constexpr bool SPEC = MODE == 3;
+  constexpr int VM = SPEC ? 0 : MODE;                   // what vis_body / dense_body do
+  constexpr int KS = VM != 1 ? LIN_SMALL_KS : 1;      // (the cost-only pass is too short to gain: 9 -> 12 us when split)
+  // the set of the linearisation's outputs this pass writes: the current one (MODE 0: lb = 0 unless the batch is speculative), the other
+  // one (MODE 3); the cost pass and the marginalisation's set use the first whatever lb
+  const BatchDev d = (MODE == 0 || SPEC) ? lin_view(d0, SPEC ? 1 - d0.ctl[w].lb : d0.ctl[w].lb) : d0;
   // four waves per workgroup: a visual tile is one wave's work (the others leave at once); the inertial / wheel / prior items use
   // all four — the single lane that evaluated an IMU factor was the longest chain of the launch
   const bool tile_wg = y < d.max_tiles * KS;
 #if GFBE_LIN_STAMP
   // diagnostics build (tools/diag_scripts/lin_stamps.py): start of workgroup 0 and the latest end per kind of item, of the LAST launch of MODE 0
   unsigned long long *ls = (unsigned long long *)(d.timing + (size_t)d.B * 32);
-  if (MODE == 0 && y == 0 && threadIdx.x == 0) ls[0] = wall_clock64();
-  if (MODE == 0 && y == d.max_tiles * KS && threadIdx.x == 0) ls[8] = wall_clock64();                 // first inertial item starts
-  if (MODE == 0 && y == d.max_tiles * KS + MAX_IMU && threadIdx.x == 0) ls[9] = wall_clock64();       // first wheel item starts
-  if (MODE == 0 && y == d.max_tiles * KS + MAX_IMU + MAX_WHEEL && threadIdx.x == 0) ls[10] = wall_clock64();   // the prior starts
+  if (MODE == GFBE_LIN_STAMP_MODE && y == 0 && threadIdx.x == 0) ls[0] = wall_clock64();
+  if (MODE == GFBE_LIN_STAMP_MODE && y == d.max_tiles * KS && threadIdx.x == 0) ls[8] = wall_clock64();                 // first inertial item starts
+  if (MODE == GFBE_LIN_STAMP_MODE && y == d.max_tiles * KS + MAX_IMU && threadIdx.x == 0) ls[9] = wall_clock64();       // first wheel item starts
+  if (MODE == GFBE_LIN_STAMP_MODE && y == d.max_tiles * KS + MAX_IMU + MAX_WHEEL && threadIdx.x == 0) ls[10] = wall_clock64();   // the prior starts
 #endif
   if (tile_wg) {
     if (threadIdx.x >= LM_TILE) return;
-    if (MODE == 1 && (fuse & 2)) {
-      const WinDesc &ds = d.desc[w];
-      const WinCtl &c = d.ctl[w];
-      if (y < ds.n_tiles && TILE_OWNED(d, y) && !c.done && c.have_step) candidate_tile(d, ds, c, w, y, threadIdx.x);
-    }
-    vis_body<MODE, FULL, KS>(d, 0, w, y / KS, y % KS);
+    // (fuse bit 1: the tile forms its candidate inverse depths first; MODE 3: each of the tile's KS workgroups does, for its own lanes — the same values)
+    vis_body<VM, FULL, KS, SPEC>(d, 0, w, y / KS, y % KS, (MODE == 1 || SPEC) && (fuse & 2));
   } else {
-    dense_body<true>(d, MODE, 0, w, y - d.max_tiles * KS);
+    dense_body<true>(d, VM, 0, w, y - d.max_tiles * KS, SPEC);
   }
 #if GFBE_LIN_STAMP
-  if (MODE == 0 && (threadIdx.x & 63) == 0) {
+  if (MODE == GFBE_LIN_STAMP_MODE && (threadIdx.x & 63) == 0) {
     const int f = y - d.max_tiles * KS;
     const int kind = tile_wg ? 1 : (f < MAX_IMU ? 2 : (f < MAX_IMU + MAX_WHEEL ? 3 : (f == MAX_IMU + MAX_WHEEL ? 4 : 5)));
     atomicMax(ls + kind, (unsigned long long)wall_clock64());
@@ -1273,21 +1462,28 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d, 
     if (threadIdx.x == 0 && f == MAX_IMU) ls[11] = wall_clock64();                                      // first wheel item ends
   }
 #endif
-  if (MODE == 1 && (fuse & 4)) {
+  if ((MODE == 1 || SPEC) && (fuse & 4)) {
     // (a factor's four waves are done with their stores before the workgroup arrives — dense_body leaves workgroup-uniformly —; its first wave goes on)
     if (!tile_wg) { __syncthreads(); if (threadIdx.x >= 64) return; }
     // (the scalars k_accept reads are this launch's inputs: loaded before the arrival, by every workgroup — any may be the last)
     WinCtl &c = d.ctl[w];
     AcceptLocal la;
     la.done = c.done; la.have_step = c.have_step; la.iter = c.iter; la.cur = c.cur; la.num_successful = c.num_successful;
-    la.termination = c.termination; la.status = c.status; la.reuse = c.reuse;
+    la.termination = c.termination; la.status = c.status; la.reuse = c.reuse; la.lb = c.lb;
     la.cost = c.cost; la.x_norm = c.x_norm; la.model_change = c.model_change; la.radius = c.radius; la.step_norm = c.step_norm; la.mu = c.mu;
     la.cand_cost = c.cand_cost;
     if (!arrive_last(d.win_cnt + 2 * w + 1, gridDim.y, threadIdx.x)) return;
-    accept_body(d, w, threadIdx.x, la, c);
+#if GFBE_LIN_STAMP
+    if (MODE == GFBE_LIN_STAMP_MODE && threadIdx.x == 0) ls[12] = wall_clock64();      // the last workgroup has arrived
+#endif
+    accept_body(d, w, threadIdx.x, la, c, SPEC ? 2 : 1);      // (MODE 3: the candidate's costs are those of its linearisation)
     if (threadIdx.x == 0) {
+      if (SPEC) c.lb = la.lb;
       c.done = la.done; c.have_step = la.have_step; c.cur = la.cur; c.num_successful = la.num_successful; c.termination = la.termination;
       c.status = la.status; c.reuse = la.reuse; c.cost = la.cost; c.x_norm = la.x_norm; c.radius = la.radius; c.mu = la.mu; c.cand_cost = la.cand_cost;
+#if GFBE_LIN_STAMP
+      if (MODE == GFBE_LIN_STAMP_MODE) ls[13] = wall_clock64();      // the accepting tail is done
+#endif
     }
   }
 }
@@ -1375,6 +1571,8 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   // are issued together (rows beyond a track's length are zero in memory) and the NEXT tile's loads are
   // in flight while the matrix cores work on the current one.
   const int l = t & 63, part = t >> 6;
+  const bool spec_sw = !marg && d.spec;         // sqrt(w_l) from Hll, s_l and the window's mu instead of lm_sw (BatchDev::spec)
+  const double spec_mu = spec_sw ? c.mu : 0.0;
   const bool hc_full = marg || d.vis_full;      // the linearisation of a batch with constant extrinsic / td everywhere leaves rows 6..12 of lm_hC alone
   // What a thread holds of one landmark tile between its loads and its staging. DEEP (throughput batches): the tiles t + 1 AND t + 2
   // are in flight while the matrix cores work on tile t — with one tile ahead a light tile (a few tile pairs) took a whole
@@ -1398,14 +1596,15 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   // compiler's wait-count insertion can then let the younger set's loads stay in flight while the older set is staged
   // (s_waitcnt vmcnt(23+) instead of vmcnt(0)); rows a thread does not need are loaded from a neighbouring valid row and ignored.
 #define SCHUR_PV 20
-#define SCHUR_PREFETCH(PV, PHLL, PINFO, PS, TILE)                                                                   \
+#define SCHUR_PREFETCH(PV, PHLL, PSL, PINFO, PS, TILE)                                                                 \
   {                                                                                                                      \
     const int tile_ = min((TILE), te - 1);                                                                               \
     const int slot_ = lm_off_c + tile_ * LM_TILE + l;                                                                    \
     PS = sframe_of(tile_);                                                                                               \
     const int klast_ = max(NF - 2 - PS, 0);       /* last observing pose index of the tile's start frame */              \
     PINFO = d.lm_info[slot_];                                                                                            \
-    PHLL = (marg ? d.lm_Hll : d.lm_sw)[slot_];      /* solve: sqrt(w_l), left by the linearisation */                    \
+    PHLL = (marg || spec_sw ? d.lm_Hll : d.lm_sw)[slot_];      /* solve: sqrt(w_l), left by the linearisation */         \
+    if (spec_sw) PSL = d.lm_sl[slot_];              /* (speculative batches: Hll and s_l, sqrt(w_l) formed at the staging) */    \
     const double *gl_ = d.lm_gl + slot_;                                                                                 \
     _Pragma("unroll") for (int idx_ = 0; idx_ < SCHUR_PV; idx_++) {                                                      \
       const int u_ = idx_ / 6, q_ = idx_ - 6 * u_;                                                                       \
@@ -1436,7 +1635,7 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   // The tracks of a tile are sorted longest first (pm0: its first landmark, lane 0 of every wave): its rows are zero beyond the pose
   // columns of the first track's last observer, jl = the last 16-column block they reach (absolute layout: block 4 holds the
   // extrinsic / td / gradient columns of every row). Tile pairs outside are products of zeros: skipped (the accumulators keep their bits).
-#define SCHUR_RUN_TILE(PV, PHLL, PINFO, PS, TILE, REFILL)                                                           \
+#define SCHUR_RUN_TILE(PV, PHLL, PSL, PINFO, PS, TILE, REFILL)                                                          \
   {                                                                                                                      \
     __syncthreads();                                                                                                     \
     if (stamp_wg && (TILE) == tfirst) stamp[1] = (double)wall_clock64();                                                 \
@@ -1451,6 +1650,10 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
       double sw = 0.0;                                                                                                   \
       if (valid && m > 0 && (marg || !is_const))                                                                         \
         sw = marg ? sqrt((PHLL > d.opt.marg_eps) ? 1.0 / PHLL : 0.0) : PHLL;                                             \
+      if (spec_sw && valid && m > 0 && !is_const) {      /* k_vis<0>'s expression, with the mu of THIS iteration */              \
+        const double hs2_ = PSL * PSL * PHLL;                                                                            \
+        sw = sqrt(PSL * PSL / (hs2_ + spec_mu * clamp_diag(hs2_)));                                                      \
+      }                                                                                                                  \
       double *row = hs + l * HS_LD + coff;                                                                               \
       if (part == 0) {                                                                                                   \
         for (int q = compact ? 6 * s_first : 16 * I0; q < 6 * s; q++) row[q] = 0.0;                                      \
@@ -1489,19 +1692,19 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
     }                                                                                                                    \
     __syncthreads();                                                                                                     \
     if (stamp_wg && (TILE) == tfirst) stamp[2] = (double)wall_clock64();                                                 \
-    SCHUR_PREFETCH(PV, PHLL, PINFO, PS, (REFILL))          /* (past the last tile: a repeat of it, never staged) */ \
+    SCHUR_PREFETCH(PV, PHLL, PSL, PINFO, PS, (REFILL))         /* (past the last tile: a repeat of it, never staged) */ \
     SCHUR_SLOT(0, acc0)                                                                                                  \
     SCHUR_SLOT(1, acc1)                                                                                                  \
     SCHUR_SLOT(2, acc2)                                                                                                  \
     SCHUR_SLOT(3, acc3)                                                                                                  \
   }
-  double preA[SCHUR_PV], aHll = 0.0;
+  double preA[SCHUR_PV], aHll = 0.0, aSl = 0.0;
   int aInfo = 0, aS = 0;
-  SCHUR_PREFETCH(preA, aHll, aInfo, aS, tfirst)
+  SCHUR_PREFETCH(preA, aHll, aSl, aInfo, aS, tfirst)
   // (measured, round 4: TWO tiles ahead — a second register set, the compiler's wait counts letting the younger set stay in flight —
   //  was slower at two and at three workgroups per CU, 183-198 against 169-175 us per 512 windows: the kernel is not bound by the
   //  latency of its loads)
-  for (int tile = tfirst; tile < te; tile += tstep) SCHUR_RUN_TILE(preA, aHll, aInfo, aS, tile, tile + tstep)
+  for (int tile = tfirst; tile < te; tile += tstep) SCHUR_RUN_TILE(preA, aHll, aSl, aInfo, aS, tile, tile + tstep)
 #undef SCHUR_RUN_TILE
 #undef SCHUR_SLOT
 #undef SCHUR_PREFETCH
@@ -2099,8 +2302,9 @@ __global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d) {
 // others leave at once — s_barrier waits for the surviving waves only) and the start-frame blocks of the visual Hessian read different
 // outputs of the linearisation and nothing of each other: side by side instead of one after the other on a single window's
 // latency path (k_visblock_small was 6.9 us of a 154 us iteration). Same code, same bits as the two launches.
-__global__ __launch_bounds__(VB_GROUP) void k_schur_visblock_small(BatchDev d) {
+__global__ __launch_bounds__(VB_GROUP) void k_schur_visblock_small(BatchDev d0) {
   const int w = blockIdx.x, y = blockIdx.y;
+  const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   if (y < d.schur_groups) {
     if (threadIdx.x < 256) schur_body(d, 0, w, y);
   } else {
@@ -2305,8 +2509,9 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
 // ASM_E_WGS an entry of E, the last one g and eg — instead of an H entry, then an E entry, then a gradient entry one after the other:
 // the dependent memory round trips of the three parts side by side (14.1 -> 8.2 us per launch for one window).
 #define ASM_E_WGS ((NV * (NV + 1) / 2 + ASM_THREADS - 1) / ASM_THREADS)
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d, int nH) {
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d0, int nH) {
   const int w = blockIdx.y, bx = blockIdx.x;
+  const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   __shared__ AsmTab tb;
@@ -2573,26 +2778,23 @@ __global__ __launch_bounds__(64) void k_step(BatchDev d) {
 // k_candidate: x_cand = x (+) s * (c1 v + c2 y). Blocks [0, max_tiles) landmarks, block max_tiles
 // the dense parameter blocks.
 // =============================================================================================
-// landmark tile `tile` (64 lanes)
-__device__ __forceinline__ void candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t) {
+// landmark tile `tile` (64 lanes); returns the lane's candidate inverse depth
+__device__ __forceinline__ double candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t) {
   const size_t TL = d.tot_lm;
   const int slot = ds.lm_off + tile * LM_TILE + t;
   const int info = d.lm_info[slot];
   const bool valid = (info >> 24) & 1;
   const bool free_lm = valid && !((info >> 16) & 1) && ((info >> 8) & 0xff) > 0;
   const double lam = d.lam[(size_t)c.cur * TL + slot];
-  double lc = lam, d2 = 0.0, n2 = 0.0;
-  if (free_lm) {
-    lc = lam + d.lm_sl[slot] * (c.c1 * d.lm_vl[slot] + c.c2 * d.lm_yl[slot]);
-    d2 = (lam - lc) * (lam - lc);
-    n2 = lc * lc;
-  }
+  double d2, n2;
+  const double lc = candidate_lm(lam, d.lm_sl[slot], d.lm_vl[slot], d.lm_yl[slot], c.c1, c.c2, free_lm, d2, n2);
   d.lam[(size_t)(1 - c.cur) * TL + slot] = lc;
   d2 = wave_sum(d2); n2 = wave_sum(n2);
   if (t == 0) {
     double *o = d.tile_cand + ((size_t)w * d.max_tiles + tile) * 4;
     o[1] = d2; o[2] = n2;
   }
+  return lc;
 }
 // the dense parameter blocks (one wave; sp_cand: NF + 1 PoseRT of LDS; contains a block barrier: call it from every thread of the
 // workgroup or from a one-wave workgroup)
@@ -2750,9 +2952,10 @@ __device__ __forceinline__ void block_candidate(const BatchDev &d, const int w, 
 #pragma unroll
   for (int k = 0; k < MAXS; k++) if (k < q.gs) Y[q.am + k] = Yl[k];
 }
-__global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d) {
+__global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
   static_assert(GFBE_BLK_COUNT <= 128 && GFBE_BLK_RCV_DT0 <= 64, "two blocks per lane, the second one a scalar block");
   const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
+  const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
   const int t = threadIdx.x;
@@ -2815,8 +3018,10 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d) {
 // =============================================================================================
 // c: the window's trust-region scalars — WinCtl itself or a register copy (AcceptLocal: the fused tail of k_lin_small<1> loads it
 // before its workgroup arrives); cg: WinCtl in memory, for the per-iteration records (stores only).
+// cslot: where the dense factors' candidate costs are — 1: the slot the cost pass fills; 2: the cost slot of a linearisation (the
+// speculative pass: d is the view of the set it wrote, and an accepted step makes that set the current one).
 template <class CT>
-__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane, CT &c, WinCtl &cg) {
+__device__ __forceinline__ void accept_body(const BatchDev &d, const int w, const int lane, CT &c, WinCtl &cg, const int cslot) {
   const WinDesc &ds = d.desc[w];
   if (c.done || !c.have_step) return;
   double cand = 0.0, d2 = 0.0, n2 = 0.0;
@@ -2825,12 +3030,12 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
     const double *xr = d.xc + ((size_t)w * d.world + lane) * XCHG;
     cand = xr[0]; d2 = xr[1]; n2 = xr[2];
   }
-  if (lane < ds.n_imu) cand += d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - 1];
-  if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - 1];
-  if (lane == 32) { cand += d.prior_g[(size_t)w * (ND + 2) + ND + 1]; d2 += d.dense_cand[(size_t)w * 4 + 1]; n2 += d.dense_cand[(size_t)w * 4 + 2]; }
+  if (lane < ds.n_imu) cand += d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - cslot];
+  if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - cslot];
+  if (lane == 32) { cand += d.prior_g[(size_t)w * (ND + 2) + ND + 2 - cslot]; d2 += d.dense_cand[(size_t)w * 4 + 1]; n2 += d.dense_cand[(size_t)w * 4 + 2]; }
   if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 28];
-  if (lane >= 48 && lane - 48 < ds.n_plane) cand += d.plane_part[((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - 1];
-  if (lane == 58 && ds.use_anchor) cand += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 1];
+  if (lane >= 48 && lane - 48 < ds.n_plane) cand += d.plane_part[((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - cslot];
+  if (lane == 58 && ds.use_anchor) cand += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - cslot];
   if (lane == 59 && ds.gnss_factors) cand += d.gnss_cost[(size_t)w * 2 + 1];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o, 64); d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
@@ -2858,6 +3063,7 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
     if (quality > 0.75) c.radius = fmax(c.radius, 3.0 * c.step_norm);
     c.mu = fmax(GF_MIN_MU, 2.0 * c.mu / GF_MU_INC);
     c.reuse = 0;
+    if (cslot == 2) c.lb = 1 - c.lb;
   } else {
     cg.accepted[it] = 0;
     c.radius *= 0.5;
@@ -2865,7 +3071,7 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
   }
   c.have_step = 0;
 }
-__global__ __launch_bounds__(64) void k_accept(BatchDev d) { accept_body(d, blockIdx.x, threadIdx.x, d.ctl[blockIdx.x], d.ctl[blockIdx.x]); }
+__global__ __launch_bounds__(64) void k_accept(BatchDev d) { accept_body(d, blockIdx.x, threadIdx.x, d.ctl[blockIdx.x], d.ctl[blockIdx.x], 1); }
 
 // =============================================================================================
 // k_reanchor: double2vector()'s yaw / position gauge fix followed by vector2double()
@@ -3064,6 +3270,8 @@ void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse) {
   if (mode == 2) hipLaunchKernelGGL((k_lin_small<2, true>), g, b, 0, s, d, 0);   // (the marginalisation set: k_vis_split<2> + k_dense mode 2 in one launch)
   else if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d, 0);
   else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d, 0);
+  else if (mode == 3 && d.vis_full) hipLaunchKernelGGL((k_lin_small<3, true>), g, b, 0, s, d, fuse);   // (speculative: the candidate linearised)
+  else if (mode == 3) hipLaunchKernelGGL((k_lin_small<3, false>), g, b, 0, s, d, fuse);
   else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d, fuse);
 }
 void launch_pair_schur_marg(const BatchDev &d, hipStream_t s) {

@@ -48,7 +48,8 @@ __device__ __forceinline__ int tsw(int r, int c) { return r * TB + (c ^ r); }
 
 // Rebuild E for a new mu directly from the landmark rows (slow path: only after a failed Cholesky). own_only: the tiles of this
 // rank (landmark sharding; the ranks' parts are summed by an all-reduce).
-__device__ void rebuild_E(const BatchDev &d, const WinDesc &ds, int w, double mu, double *E, double *eg, bool own_only) {
+__device__ void rebuild_E(const BatchDev &d0, const WinDesc &ds, int w, double mu, double *E, double *eg, bool own_only) {
+  const BatchDev d = lin_view(d0, d0.ctl[w].lb);      // (speculative batches: the current set of the linearisation's outputs)
   const size_t TL = d.tot_lm;
   for (int e = threadIdx.x; e < NV * NV + NV; e += blockDim.x) {
     const bool isg = e >= NV * NV;

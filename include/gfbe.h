@@ -283,6 +283,13 @@ typedef struct gfbe_options {
    * 0: no retry — a failed factorisation ends the solve as a failed linear solve, and every linearisation carries one all-reduce
    * less (three per trust-region iteration instead of four: the packed system and the two scalar exchanges). */
   int32_t sharded_mu_retries;
+  /* Batches below 32 windows without GNSS / LiDAR factors or an all-reduce hook: 1 (default) — the pass that evaluates the candidate of
+   * a trust-region iteration LINEARISES there (all but the last iteration), into a second set of the linearisation's outputs; an
+   * accepted step makes it the current set, a rejected one leaves the old linearisation in place, and the next iteration starts at
+   * the landmark elimination: one launch less per iteration on a single window's latency path. The evaluations are the same ones in
+   * the same order (TrustRegionMinimizer evaluates the candidate's cost, then residuals + Jacobians at the accepted point: the
+   * same state); 0 — cost pass and linearisation separately. */
+  int32_t speculative_linearization;
 } gfbe_options;
 
 typedef struct gfbe_summary {

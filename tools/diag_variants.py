@@ -33,6 +33,9 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "ldltstamp": (["-DGFBE_LDLT_STAMP=1"], "off"),
     "clearlm": (["-DGFBE_CLEAR_LM=1"], "off"),
     "linstamp": (["-DGFBE_LIN_STAMP=1"], "off"),
+    "linstamp3": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=3"], "off"),
+    "linstamp3_512": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=3", "-DGFBE_LIN_SMALL_THREADS=512"], "off"),
+    "linstamp1": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=1"], "off"),
     "lin512": (["-DGFBE_LIN_SMALL_THREADS=512"], "off"),
     "lin1024": (["-DGFBE_LIN_SMALL_THREADS=1024"], "off"),
     "lin512ks5": (["-DGFBE_LIN_SMALL_THREADS=512", "-DGFBE_LIN_SMALL_KS=5"], "off"),
