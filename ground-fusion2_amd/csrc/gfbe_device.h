@@ -352,11 +352,11 @@ void launch_gather(const BatchDev &d, int margin_flag, hipStream_t s);   // resu
 void launch_reset(const BatchDev &d, hipStream_t s);
 // mode 0: linearise at the current parameters (writes records, landmark sums, cost partials)
 // mode 1: candidate cost only   mode 2: linearise the marginalisation set at xout (start frame 0 only)
-void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records = 0);
+void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records = 0, int spec = 0);
 void launch_pair(const BatchDev &d, int marg, hipStream_t s);
 void launch_pair_schur_marg(const BatchDev &d, hipStream_t s);   // small batches: k_pairsum (marg) + k_schur (marg) in one launch
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse = 0);   // fuse (mode 1): bit 1 candidate tiles first, bit 2 k_accept last
-void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s);
+void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s, int spec = 0);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock = 0);   // with_visblock: k_schur_visblock_small
 void launch_visblock(const BatchDev &d, hipStream_t s);
 void launch_lio_window(const BatchDev &d, int mode, hipStream_t s);
@@ -384,7 +384,7 @@ size_t sys_pack_doubles_host(int nu, int world);
 void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse = 0);   // fuse: k_step + the dense blocks of k_candidate by the last workgroup of a window
 void launch_step(const BatchDev &d, hipStream_t s);
 void launch_candidate(const BatchDev &d, hipStream_t s);
-void launch_accept(const BatchDev &d, hipStream_t s);
+void launch_accept(const BatchDev &d, hipStream_t s, int spec = 0);
 void launch_reanchor(const BatchDev &d, hipStream_t s);
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s);
 // mode 0: GNSS factors at the current parameters, added to H / g (after launch_assemble); 1: candidate cost; 2: the frame-0 factors at

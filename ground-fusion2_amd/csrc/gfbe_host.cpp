@@ -801,10 +801,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   d.nu = (any_gnss || gnss_dims) ? (int)ND : (int)NC;       // a batch without GNSS blocks never touches the last 59 tangent dims
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
   if (diag_getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics build only: force the 20-column panel)
-  // speculative linearisation (gfbe_options.speculative_linearization): batches on the fused small-batch launch sequence whose candidate
-  // costs are all formed by k_lin_small (small_fuse: no GNSS / LiDAR factors, no all-reduce hook) get a second set of the linearisation's outputs
-  d.spec = (c->opt.speculative_linearization && B < DENSE_SPLIT_MIN_B && !c->allreduce && !any_gnss && tot_lio == 0 && max_tiles > 0 &&
-            (GFBE_FUSE_SMALL & 6) == 6) ? 1 : 0;
+  // speculative linearisation (gfbe_options.speculative_linearization): batches whose candidate costs are all formed by the visual /
+  // dense-factor launches (no GNSS / LiDAR factors, no all-reduce hook) get a second set of the linearisation's outputs
+  d.spec = (c->opt.speculative_linearization && !c->allreduce && !any_gnss && tot_lio == 0 && max_tiles > 0 &&
+            (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 6) == 6)) ? 1 : 0;
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
   const double T1 = now();
@@ -882,7 +882,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(lm_hP, (size_t)MAXOBS * 6 * TL);    // (k_vis writes the rows below a track's length, k_schur masks the others per landmark: 1.0 MB per window)
 #endif
     AL(vis_part, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE);   // (a tile's steps below its longest track are written by k_vis, the others never read)
-    if (d.spec) { AL(lm_hP2, (size_t)MAXOBS * 6 * TL); AL(vis_part2, (size_t)B * std::max(max_tiles, 1) * MAXOBS * VP_STRIDE); }
+    // (the second set: the solve's linearisation only — its 7 x 7 partials take VPY_STRIDE doubles per step when no window frees the extrinsic / td)
+    if (d.spec) { AL(lm_hP2, (size_t)MAXOBS * 6 * TL); AL(vis_part2, (size_t)B * std::max(max_tiles, 1) * MAXOBS * (d.vis_full ? (size_t)VP_STRIDE : (size_t)VPY_STRIDE)); }
     else { d.lm_hP2 = nullptr; d.vis_part2 = nullptr; }
     AL(mA, (size_t)B * ND * ND); AL(mb, (size_t)B * ND); AL(mJ0, (size_t)B * ND * ND); AL(mr0, (size_t)B * ND);   // (k_marg / k_marg_ldlt write what they and k_gather read)
     AL(x, (size_t)B * 2 * NA); AL(xout, (size_t)B * NA);                 // (k_reset / k_reanchor write them before anything reads)
@@ -1307,7 +1308,8 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   const BatchDev &d = b->d;
   // the first linearisation has every window active; later ones skip windows that only shrink the radius
   // fork: dense factors on the aux stream (serial and timed on the main stream when profiling)
-  const bool overlap = !c->profiling && ln.aux && d.B >= DENSE_SPLIT_MIN_B;
+  // (have_lin: the last iteration's candidate pass linearised, BatchDev::spec)
+  const bool overlap = !c->profiling && ln.aux && d.B >= DENSE_SPLIT_MIN_B && !have_lin;
   if (overlap) {
     (void)hipEventRecord(ln.fork, ln.s);
     (void)hipStreamWaitEvent(ln.aux, ln.fork, 0);
@@ -1315,7 +1317,8 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     (void)hipEventRecord(ln.join, ln.aux);
   }
   const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;   // one launch for visual tiles + dense factors (k_lin_small)
-  if (small) { if (!have_lin) launch_lin_small(d, 0, ln.s); }     // (have_lin: the last iteration's candidate pass linearised, BatchDev::spec)
+  if (have_lin) { }
+  else if (small) launch_lin_small(d, 0, ln.s);
   else {
     { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
     if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
@@ -1362,7 +1365,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
   // speculative linearisation (BatchDev::spec): every candidate pass but the last linearises at the candidate, into the second set of
   // outputs; an accepted step makes that set the current one and a rejected one keeps the old linearisation (DoglegStrategy's reuse)
   // — either way the next iteration needs no linearisation launch.
-  const bool spec = d.spec && (small_fuse(c, d) & 6) == 6;
+  const bool spec = d.spec && (d.B >= DENSE_SPLIT_MIN_B || (small_fuse(c, d) & 6) == 6);      // (small batches: on the fused launch sequence only)
   for (int it = 0; it < iters; it++) {
     enqueue_linearize(c, b, ln, it == 0, spec && it > 0);
     const int fuse = small_fuse(c, d);
@@ -1371,25 +1374,27 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       { Timed t(c, "k_candidate", 0); launch_candidate(d, ln.s); }
     }
     const bool overlap = !c->profiling && ln.aux && d.B >= DENSE_SPLIT_MIN_B;
+    const bool lin_cand = spec && it + 1 < iters;      // this candidate pass linearises (the last one of a solve only needs the costs)
     if (overlap) {
       (void)hipEventRecord(ln.fork, ln.s);
       (void)hipStreamWaitEvent(ln.aux, ln.fork, 0);
-      launch_dense_factors(d, 1, 0, ln.aux);
+      launch_dense_factors(d, lin_cand ? 0 : 1, 0, ln.aux, lin_cand);
       (void)hipEventRecord(ln.join, ln.aux);
     }
     const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;
-    if (small) launch_lin_small(d, (spec && it + 1 < iters) ? 3 : 1, ln.s, fuse);
+    if (small) launch_lin_small(d, lin_cand ? 3 : 1, ln.s, fuse);
+    else if (lin_cand) { Timed t(c, "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s, 0, 1); }
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
     if (d.any_gnss) { Timed t(c, "k_gnss_cost", 0); launch_gnss(d, 1, ln.s); }
-    if (!small && !overlap) { Timed t(c, "k_dense_cost", 0); launch_dense_factors(d, 1, 0, ln.s); }
+    if (!small && !overlap) { Timed t(c, lin_cand ? "k_dense" : "k_dense_cost", 0); launch_dense_factors(d, lin_cand ? 0 : 1, 0, ln.s, lin_cand); }
     else if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);
     if (d.sharded) {
       Timed t(c, "allreduce_scalars", 0);
       launch_xchg_cand(d, ln.s);
       run_allreduce(c, d.xc, (int64_t)d.B * d.world * XCHG, ln.s);
     }
-    if (!(fuse & 4)) { Timed t(c, "k_accept", 0); launch_accept(d, ln.s); }
+    if (!(fuse & 4)) { Timed t(c, "k_accept", 0); launch_accept(d, ln.s, (!small && lin_cand) ? 1 : 0); }
   }
   { Timed t(c, "k_reanchor", 0); launch_reanchor(d, ln.s); }
   if (margin_flag != GFBE_MARGIN_NONE) {

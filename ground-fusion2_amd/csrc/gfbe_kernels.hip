@@ -779,14 +779,16 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 }
 
 __device__ __forceinline__ double candidate_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t);
-template <int MODE, bool FULL>
-__global__ __launch_bounds__(LM_TILE, (MODE == 0 && !FULL) ? GFBE_KVIS_WAVES : 2) void k_vis(BatchDev d, int write_records) {
+// SPEC (MODE 0; BatchDev::spec): the candidate's linearisation in the place of its cost pass, into the set of outputs that is not the current one
+template <int MODE, bool FULL, bool SPEC = false>
+__global__ __launch_bounds__(LM_TILE, (MODE == 0 && !FULL) ? GFBE_KVIS_WAVES : 2) void k_vis(BatchDev d0, int write_records) {
+  const BatchDev d = MODE == 0 ? lin_view(d0, SPEC ? 1 - d0.ctl[blockIdx.x].lb : d0.ctl[blockIdx.x].lb) : d0;
   // tile-major dispatch order (x = window): all windows' tile 0 (start frame 0, the longest tracks) first, the
   // short start-frame-7 tiles last — a longest-first schedule that shortens the tail of the launch
   // (the cost pass of a throughput batch, write_records = 1: the tile first forms the candidate inverse depths of its landmarks —
   //  the landmark half of k_candidate, the same 64 lanes and the same sums (vis_body's head); k_candidate_dense has formed the candidate's
   //  dense blocks and pair constants before. A launch of its own walked a window's tiles four at a time: 115 us per 2048 windows.)
-  vis_body<MODE, FULL>(d, MODE == 1 ? 0 : write_records, blockIdx.x, blockIdx.y, 0, MODE == 1 && write_records);
+  vis_body<MODE, FULL, 1, SPEC>(d, (MODE == 1 || SPEC) ? 0 : write_records, blockIdx.x, blockIdx.y, 0, (MODE == 1 || SPEC) && write_records);
 }
 
 // =============================================================================================
@@ -903,9 +905,11 @@ __device__ __forceinline__ bool wheel_nz(int r, int c) {
 }
 // Which inertial / wheel factors a pass evaluates (shared by k_dense_raw and k_dense):
 //   mode 0 linearise, 1 candidate cost, 2 MARGIN_OLD set at the re-anchored state (factor of frame 0), 3 nothing.
-__device__ __forceinline__ bool dense_pass_active(const WinCtl &c, int mode) {
-  if (mode == 0 && (c.done || c.reuse)) return false;
-  if (mode == 1 && (c.done || !c.have_step)) return false;
+// spec (mode 0, BatchDev::spec): the linearisation AT THE CANDIDATE in the place of the cost pass — the candidate's state, the windows
+// that have a step, the set of outputs that is not the current one.
+__device__ __forceinline__ bool dense_pass_active(const WinCtl &c, int mode, int spec = 0) {
+  if (mode == 0 && !spec && (c.done || c.reuse)) return false;
+  if ((mode == 1 || spec) && (c.done || !c.have_step)) return false;
   return true;
 }
 #define RAW_IMU (15 + 15 * 30)
@@ -917,13 +921,13 @@ __device__ __forceinline__ size_t raw_of(int f, int w, int B, int raw_len) { ret
 // wheel_factor.h:80-243) is scalar code; here one LANE = one window (factor f of 64 windows per wave), so the 64
 // lanes of the wave are all busy. Output: raw residual + raw Jacobian non-zeros, window-minor
 // (raw_imu[f][q][B]: coalesced stores here, one 32-byte sector per value for the per-factor workgroup of k_dense).
-__global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode) {
+__global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode, int spec) {
   const int f = blockIdx.x, w = blockIdx.y * 64 + threadIdx.x;
   if (w >= d.B) return;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
-  if (!dense_pass_active(c, mode)) return;
-  const int buf = (mode == 1) ? 1 - c.cur : c.cur;
+  if (!dense_pass_active(c, mode, spec)) return;
+  const int buf = (mode == 1 || spec) ? 1 - c.cur : c.cur;
   const double *X = (mode >= 2) ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + buf) * NA;
   const size_t B = d.B;
   if (f < MAX_IMU) {
@@ -1205,8 +1209,10 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d, int mode, int debug_out, int f0) {
-  dense_body<FUSED>(d, mode, debug_out, blockIdx.y, blockIdx.x + f0);
+__global__ __launch_bounds__(64, FUSED ? 1 : 4) void k_dense(BatchDev d0, int mode, int debug_out, int f0, int spec) {
+  // (the set of the linearisation's outputs this pass writes: lin_view; the marginalisation's passes and the cost pass use the first)
+  const BatchDev d = mode == 0 ? lin_view(d0, spec ? 1 - d0.ctl[blockIdx.y].lb : d0.ctl[blockIdx.y].lb) : d0;
+  dense_body<FUSED>(d, mode, debug_out, blockIdx.y, blockIdx.x + f0, spec != 0);
 }
 
 // ---- k_dense_tp: the inertial / wheel factors and the prior of throughput batches (B >= DENSE_SPLIT_MIN_B), modes 0 and 1.
@@ -1227,7 +1233,7 @@ template <> struct DenseKind<false> { enum { R = 6, C = 22, NK = 2, PART = WHEEL
 enum { DTP_X = 4 * 512, DTP_S = 4 * 256, DTP_LDS = DTP_X + DTP_S, DTP_PRIOR0 = MAX_IMU + MAX_WHEEL };
 
 template <bool IMU>
-__device__ __forceinline__ void dense_tp_factor(const BatchDev &d, int mode, int f, int w0, double *X, double *St, int *s_act) {
+__device__ __forceinline__ void dense_tp_factor(const BatchDev &d, int mode, int spec, int f, int w0, double *X, double *St, int *s_act) {
   typedef DenseKind<IMU> K;
   constexpr int R = K::R, C = K::C, NK = K::NK;
   typedef double dbl4_d __attribute__((ext_vector_type(4)));
@@ -1236,7 +1242,7 @@ __device__ __forceinline__ void dense_tp_factor(const BatchDev &d, int mode, int
   if (t < 4) {
     const int w = w0 + t;
     int act = 0;
-    if (w < B && dense_pass_active(d.ctl[w], mode)) act = f < (IMU ? d.desc[w].n_imu : d.desc[w].n_wheel) ? 1 : 2;   // 2: no such factor
+    if (w < B && dense_pass_active(d.ctl[w], mode, spec)) act = f < (IMU ? d.desc[w].n_imu : d.desc[w].n_wheel) ? 1 : 2;   // 2: no such factor
     s_act[t] = act;
   }
   for (int e = t; e < DTP_LDS; e += 256) X[e] = 0.0;      // (X and St are one array: pads and structural zeros)
@@ -1262,7 +1268,10 @@ __device__ __forceinline__ void dense_tp_factor(const BatchDev &d, int mode, int
   __syncthreads();
   const int act = s_act[wv], w = w0 + wv;       // (wave-uniform from here on; no block barrier below)
   if (act == 0) return;
-  double *part = IMU ? d.imu_part + ((size_t)w * MAX_IMU + f) * IMU_PART : d.wheel_part + ((size_t)w * MAX_WHEEL + f) * WHEEL_PART;
+  // (BatchDev::spec: the set of outputs of the window this linearisation goes to — lin_view's selection for the two arrays written here)
+  const int lset = (d.spec && mode == 0) ? (spec ? 1 - d.ctl[w].lb : d.ctl[w].lb) : 0;
+  double *part = IMU ? (lset ? d.imu_part2 : d.imu_part) + ((size_t)w * MAX_IMU + f) * IMU_PART
+                     : (lset ? d.wheel_part2 : d.wheel_part) + ((size_t)w * MAX_WHEEL + f) * WHEEL_PART;
   if (act == 2) { if (mode == 1 && lane == 0) part[K::PART - 1] = 0.0; return; }
   const double *Xw = X + wv * 512, *Sw = St + wv * 256;
   double sa[NK], xb[NK];
@@ -1309,14 +1318,15 @@ __device__ __forceinline__ void dense_tp_factor(const BatchDev &d, int mode, int
 enum { PRIOR_REGS = 32, PRIOR_LDS_N = 90 };      // 256 threads x 32 values >= 90 x 90; 90 x 90 x 8 B = 63 KB of LDS
 static_assert(256 * PRIOR_REGS >= PRIOR_LDS_N * PRIOR_LDS_N, "k_prior_tp: a thread's share of J0");
 static_assert(ND <= 256, "k_prior_tp: one thread per row / column of the prior (n <= GFBE_DENSE_DIM) in a 256-thread workgroup");
-__global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_n) {
+__global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_n, int spec) {
   extern __shared__ __attribute__((aligned(16))) double psm[];      // dx[ND] | r[ND] | partial sums [4][ND] | J0 [lds_n x lds_n]
   __shared__ double red[16];
   const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
-  if (!dense_pass_active(c, mode)) return;
-  double *pg = d.prior_g + (size_t)w * (ND + 2);
+  if (!dense_pass_active(c, mode, spec)) return;
+  // (BatchDev::spec: the set of outputs this linearisation goes to, as lin_view selects it)
+  double *pg = ((d.spec && mode == 0 && (spec ? 1 - c.lb : c.lb)) ? d.prior_g2 : d.prior_g) + (size_t)w * (ND + 2);
   const int n = ds.prior_n;
   if (n == 0) { if (t == 0) { pg[ND] = 0.0; pg[ND + 1] = 0.0; } return; }
   double *dx = psm, *rp = psm + ND, *pp = psm + 2 * ND, *sJ = psm + 6 * ND;
@@ -1328,7 +1338,7 @@ __global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_
     for (int j = 0; j < PRIOR_REGS; j++) { const int e = t + 256 * j; v[j] = e < n * n ? J0[e] : 0.0; }
   }
   const double r0t = t < n ? r0[t] : 0.0;
-  const double *X = d.x + ((size_t)w * 2 + (mode == 1 ? 1 - c.cur : c.cur)) * NA;
+  const double *X = d.x + ((size_t)w * 2 + ((mode == 1 || spec) ? 1 - c.cur : c.cur)) * NA;
   if (t < ds.prior_nblk)
     prior_block_dx(X + blk_amb(ds.prior_blk_id[t]), d.prior_x0 + (size_t)w * PRIOR_X0 + ds.prior_x0_off[t], ds.prior_blk_size[t],
                    dx + ds.prior_blk_idx[t]);
@@ -1396,12 +1406,12 @@ __global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_
   if (t == 0) pg[ND] = cst;
 }
 
-__global__ __launch_bounds__(256) void k_dense_tp(BatchDev d, int mode) {
+__global__ __launch_bounds__(256) void k_dense_tp(BatchDev d, int mode, int spec) {
   __shared__ double sm[DTP_LDS];
   __shared__ int s_act[4];
   const int slot = blockIdx.x, w0 = blockIdx.y * 4;
-  if (slot < MAX_IMU) dense_tp_factor<true>(d, mode, slot, w0, sm, sm + DTP_X, s_act);
-  else dense_tp_factor<false>(d, mode, slot - MAX_IMU, w0, sm, sm + DTP_X, s_act);
+  if (slot < MAX_IMU) dense_tp_factor<true>(d, mode, spec, slot, w0, sm, sm + DTP_X, s_act);
+  else dense_tp_factor<false>(d, mode, spec, slot - MAX_IMU, w0, sm, sm + DTP_X, s_act);
 }
 static size_t prior_tp_lds(int lds_n) { return sizeof(double) * (6 * (size_t)ND + (size_t)lds_n * lds_n); }
 hipError_t dense_init_device() {   // per device, from gfbe_create (see kernels_init_device)
@@ -1725,7 +1735,8 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
 #ifndef GFBE_SCHUR_WGS
 #define GFBE_SCHUR_WGS 4
 #endif
-__global__ __launch_bounds__(256, GFBE_SCHUR_WGS) void k_schur(BatchDev d, int marg) {
+__global__ __launch_bounds__(256, GFBE_SCHUR_WGS) void k_schur(BatchDev d0, int marg) {
+  const BatchDev d = marg ? d0 : lin_view(d0, d0.ctl[blockIdx.x].lb);
   schur_body(d, marg, blockIdx.x, blockIdx.y);   // group-major dispatch: the heavy first group of every window first
 }
 // Small batches, marginalisation: the pair sums (0, j) and the Schur partial of start frame 0 both read what the linearisation of the
@@ -2294,7 +2305,8 @@ __device__ __forceinline__ void visblock_body(const BatchDev &d, const int w, co
   ASTAMP(7);
 #undef ASTAMP
 }
-__global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d) {
+__global__ __launch_bounds__(VB_GROUP) void k_visblock_small(BatchDev d0) {
+  const BatchDev d = lin_view(d0, d0.ctl[blockIdx.y].lb);
   __shared__ double V[NV * V_LD];
   visblock_body<true, false, false>(d, blockIdx.y, blockIdx.x >> 1, blockIdx.x >> 1, blockIdx.x & 1, V);
 }
@@ -2533,8 +2545,9 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d0, int nH) {
 // 16 workgroups of 256 threads per window took 313 us per launch with the SIMDs half empty — the kernel was bound by the
 // dispatch and the table staging of its 16384 short workgroups; 2 workgroups 200 us, one 192 us; fused with k_visblock the
 // 43 KB block per window neither goes to HBM nor comes back.)
-__global__ __launch_bounds__(VB_GROUP, 4) void k_visasm(BatchDev d) {
+__global__ __launch_bounds__(VB_GROUP, 4) void k_visasm(BatchDev d0) {
   const int w = blockIdx.x;
+  const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
   __shared__ double V[NV * V_LD];
@@ -2628,8 +2641,9 @@ __device__ __forceinline__ void lm_step_tile(const BatchDev &d, const WinDesc &d
     if (t == 0) out[q] = r;
   }
 }
-__global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d) {
+__global__ __launch_bounds__(LM_TILE) void k_lm_step(BatchDev d0) {
   const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
+  const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   const WinDesc &ds = d.desc[w];
   if (tile >= ds.n_tiles || !TILE_OWNED(d, tile)) return;
   const WinCtl &c = d.ctl[w];
@@ -3071,7 +3085,11 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
   }
   c.have_step = 0;
 }
-__global__ __launch_bounds__(64) void k_accept(BatchDev d) { accept_body(d, blockIdx.x, threadIdx.x, d.ctl[blockIdx.x], d.ctl[blockIdx.x], 1); }
+__global__ __launch_bounds__(64) void k_accept(BatchDev d, int spec) {      // spec: after the candidate's linearisation (its costs, its set of outputs)
+  const int w = blockIdx.x;
+  if (spec) accept_body(lin_view(d, 1 - d.ctl[w].lb), w, threadIdx.x, d.ctl[w], d.ctl[w], 2);
+  else accept_body(d, w, threadIdx.x, d.ctl[w], d.ctl[w], 1);
+}
 
 // =============================================================================================
 // k_reanchor: double2vector()'s yaw / position gauge fix followed by vector2double()
@@ -3255,9 +3273,15 @@ void launch_reset(const BatchDev &d, hipStream_t s) {
   const int slots = d.max_tiles * LM_TILE;
   hipLaunchKernelGGL(k_reset, dim3((slots + 255) / 256 > 0 ? (slots + 255) / 256 : 1, d.B), dim3(256), 0, s, d);
 }
-void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records) {
+void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records, int spec) {
   if (d.max_tiles == 0) return;
   const dim3 g(d.B, d.max_tiles), b(LM_TILE);
+  if (mode == 0 && spec) {      // (the candidate linearised; its tiles form the candidate inverse depths first, as the cost pass's do)
+    const int head = (d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND) ? 1 : 0;
+    if (d.vis_full) hipLaunchKernelGGL((k_vis<0, true, true>), g, b, 0, s, d, head);
+    else hipLaunchKernelGGL((k_vis<0, false, true>), g, b, 0, s, d, head);
+    return;
+  }
   // (reduced panel: only when the camera extrinsic and td are constant in EVERY window of the batch and no records are asked for)
   if (mode == 0 && (d.vis_full || write_records)) hipLaunchKernelGGL((k_vis<0, true>), g, b, 0, s, d, write_records);
   else if (mode == 0) hipLaunchKernelGGL((k_vis<0, false>), g, b, 0, s, d, 0);
@@ -3281,22 +3305,22 @@ void launch_pair_schur_marg(const BatchDev &d, hipStream_t s) {
 void launch_pair(const BatchDev &d, int marg, hipStream_t s) {
   hipLaunchKernelGGL(k_pairsum, dim3(marg ? NF - 1 : NF * (NF - 1) / 2, d.B), dim3(VP_STRIDE), 0, s, d, marg);
 }
-void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s) {
+void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s, int spec) {
   const int nf = MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0);   // (+ PlaneFactors and the PoseAnchorFactor)
   if (d.B < DENSE_SPLIT_MIN_B) {
-    hipLaunchKernelGGL(k_dense<true>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out, 0);
+    hipLaunchKernelGGL(k_dense<true>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out, 0, spec);
     return;
   }
-  if (mode != 3) hipLaunchKernelGGL(k_dense_raw, dim3(MAX_IMU + MAX_WHEEL, (d.B + 63) / 64), dim3(64), 0, s, d, mode);
+  if (mode != 3) hipLaunchKernelGGL(k_dense_raw, dim3(MAX_IMU + MAX_WHEEL, (d.B + 63) / 64), dim3(64), 0, s, d, mode, spec);
   if (GFBE_DENSE_TP && mode <= 1 && !debug_out) {
     // the linearisation and the candidate cost of a throughput batch: factor slots of four windows per workgroup + the priors
-    hipLaunchKernelGGL(k_dense_tp, dim3(DTP_PRIOR0, (d.B + 3) / 4), dim3(256), 0, s, d, mode);
+    hipLaunchKernelGGL(k_dense_tp, dim3(DTP_PRIOR0, (d.B + 3) / 4), dim3(256), 0, s, d, mode, spec);
     const int lds_n = d.prior_n_max <= PRIOR_LDS_N ? d.prior_n_max : 0;
-    hipLaunchKernelGGL(k_prior_tp, dim3(d.B), dim3(256), prior_tp_lds(lds_n), s, d, mode, lds_n);
-    if (d.any_plane) hipLaunchKernelGGL(k_dense<false>, dim3(MAX_PLANE + 1, d.B), dim3(64), 0, s, d, mode, 0, DTP_PRIOR0 + 1);   // PlaneFactors, PoseAnchorFactor
+    hipLaunchKernelGGL(k_prior_tp, dim3(d.B), dim3(256), prior_tp_lds(lds_n), s, d, mode, lds_n, spec);
+    if (d.any_plane) hipLaunchKernelGGL(k_dense<false>, dim3(MAX_PLANE + 1, d.B), dim3(64), 0, s, d, mode, 0, DTP_PRIOR0 + 1, spec);   // PlaneFactors, PoseAnchorFactor
     return;
   }
-  hipLaunchKernelGGL(k_dense<false>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out, 0);
+  hipLaunchKernelGGL(k_dense<false>, dim3(nf, d.B), dim3(64), 0, s, d, mode, debug_out, 0, spec);
 }
 void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock) {
   if (d.max_tiles == 0) return;
@@ -3358,7 +3382,7 @@ void launch_candidate(const BatchDev &d, hipStream_t s) {
   else if (d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_candidate_window, dim3(d.B), dim3(CAND_THREADS), 0, s, d);
   else hipLaunchKernelGGL(k_candidate, dim3(d.max_tiles + 1, d.B), dim3(LM_TILE), 0, s, d);
 }
-void launch_accept(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_accept, dim3(d.B), dim3(64), 0, s, d); }
+void launch_accept(const BatchDev &d, hipStream_t s, int spec) { hipLaunchKernelGGL(k_accept, dim3(d.B), dim3(64), 0, s, d, spec); }
 void launch_reanchor(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_reanchor, dim3(d.B), dim3(64), 0, s, d); }
 
 }  // namespace gfd

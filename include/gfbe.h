@@ -283,12 +283,14 @@ typedef struct gfbe_options {
    * 0: no retry — a failed factorisation ends the solve as a failed linear solve, and every linearisation carries one all-reduce
    * less (three per trust-region iteration instead of four: the packed system and the two scalar exchanges). */
   int32_t sharded_mu_retries;
-  /* Batches below 32 windows without GNSS / LiDAR factors or an all-reduce hook: 1 (default) — the pass that evaluates the candidate of
-   * a trust-region iteration LINEARISES there (all but the last iteration), into a second set of the linearisation's outputs; an
-   * accepted step makes it the current set, a rejected one leaves the old linearisation in place, and the next iteration starts at
-   * the landmark elimination: one launch less per iteration on a single window's latency path. The evaluations are the same ones in
-   * the same order (TrustRegionMinimizer evaluates the candidate's cost, then residuals + Jacobians at the accepted point: the
-   * same state); 0 — cost pass and linearisation separately. */
+  /* Batches without GNSS / LiDAR factors or an all-reduce hook: 1 (default) — the pass that evaluates the candidate of a trust-region
+   * iteration LINEARISES there (every iteration but the last of a solve), into a second set of the linearisation's outputs; an accepted
+   * step makes it the current set, a rejected one leaves the old linearisation in place (DoglegStrategy's reuse), and the next
+   * iteration starts at the landmark elimination. The evaluations are TrustRegionMinimizer's own, in its order — the candidate's
+   * cost, then residuals + Jacobians at the accepted point: the same state —, so nothing a solve returns changes by a bit
+   * (tests/test_gpu_speculative.py); what goes is one evaluation pass per iteration: the cost-only pass of the visual and the dense
+   * factors (8192 resident windows: +10 % solves/s; a single window: one launch less per iteration, -3.5 %). Costs the second set:
+   * ~1.5 MB per 2k-landmark window. 0 — cost pass and linearisation separately, as in rounds 1-4. */
   int32_t speculative_linearization;
 } gfbe_options;
 

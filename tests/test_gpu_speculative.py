@@ -1,0 +1,87 @@
+"""gfbe_options.speculative_linearization (round 5): the pass that evaluates the candidate of a trust-region iteration linearises there, into
+a second set of the linearisation's outputs, and the next iteration starts at the landmark elimination — TrustRegionMinimizer's own
+order of evaluations (candidate cost, then residuals + Jacobians at the accepted point: the same state), one launch less per
+iteration. Nothing a solve returns may change by a bit: compared here with the option off on the window shapes that take the
+different paths — accepted and rejected steps, the mu retry of a failed factorisation (the weights of the landmark elimination are
+formed with the mu of the iteration, not the one the candidate pass saw), a capped iteration count (the last candidate pass only
+needs the costs), both kernel sets (one window; 33 windows), a batch with a free camera extrinsic."""
+import numpy as np
+import pytest
+
+from _gfbe_import import gf
+from test_gpu_branches import all_free
+from test_gpu_parity import window_with_prior
+from plane_cases import plane_window, next_plane_window
+
+abi, synth = gf.abi, gf.synth
+pytestmark = pytest.mark.gpu
+
+
+def _backend(spec, **kw):
+    o = abi.default_options()
+    o.speculative_linearization = spec
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return gf.Backend(device=0, options=o)
+
+
+def _same(a, b):
+    if isinstance(a, dict):
+        return set(a) == set(b) and all(_same(a[k], b[k]) for k in a)
+    if a is None or b is None:
+        return a is b
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def _identical(a, b):
+    return _same(a["state"], b["state"]) and np.array_equal(a["feature"], b["feature"]) and a["summary"] == b["summary"] and _same(a.get("prior"), b.get("prior"))
+
+
+def _windows(oracle):
+    _, w1 = window_with_prior(oracle, 91, 500)
+    _, w2 = window_with_prior(oracle, 92, 200)
+    first = synth.Scenario(seed=93, n_landmarks=300, use_wheel=True).window(0)
+    return w1, w2, first
+
+
+@pytest.mark.parametrize("kw", [{}, {"test_fail_chol_iter": 2}, {"test_fail_chol_iter": 1, "test_fail_chol_count": 3}, {"max_num_iterations": 3},
+                                {"max_num_iterations": 1}, {"solve_kernel": 1}, {"solve_kernel": 2}])
+def test_single_window_is_unchanged_bit_for_bit(oracle, kw):
+    w1, w2, first = _windows(oracle)
+    got = []
+    for spec in (0, 1):
+        be = _backend(spec, **kw)
+        got.append([be.solve(w, abi.MARGIN_OLD) for w in (w1, first)] + [be.solve(w2, abi.MARGIN_SECOND_NEW), be.solve(w1, abi.MARGIN_NONE)])
+        be.close()
+    assert all(_identical(a, b) for a, b in zip(*got))
+
+
+def test_rejected_steps_keep_the_old_linearisation(oracle):
+    """The window with every block free rejects steps (tests/test_gpu_branches.py), the plane window's successor too: a rejected candidate's
+    linearisation is dropped and the next iteration reuses the current one (DoglegStrategy's reuse)."""
+    _, w1 = window_with_prior(oracle, 94, 400)
+    scn, pw = plane_window(anchor=True)
+    be0 = _backend(0)
+    nxt = next_plane_window(scn, pw, be0.solve(pw, abi.MARGIN_OLD))
+    be0.close()
+    cases = [all_free(w1), pw, nxt]
+    got = []
+    for spec in (0, 1):
+        be = _backend(spec)
+        got.append([be.solve(w, abi.MARGIN_OLD) for w in cases])
+        be.close()
+    assert any(0 in r["summary"]["accepted"][1:] for r in got[1])        # (the case is what it claims to be)
+    assert all(_identical(a, b) for a, b in zip(*got))
+
+
+def test_throughput_kernel_set_is_unchanged_bit_for_bit(oracle):
+    """33 windows and more run the throughput kernels (k_vis, k_dense_tp, k_prior_tp, k_schur, k_visasm, k_solve_chain, k_lm_step): a plain
+    batch, and one with a free camera extrinsic (the 20-column panel; its windows reject steps)."""
+    w1, w2, first = _windows(oracle)
+    for snaps in ([w1, w2, first] * 11, [w1, all_free(w2), first, w2] * 9):
+        got = []
+        for spec in (0, 1):
+            be = _backend(spec)
+            got.append(be.solve_batch(snaps, abi.MARGIN_OLD))
+            be.close()
+        assert all(_identical(a, b) for a, b in zip(*got))

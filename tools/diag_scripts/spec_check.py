@@ -97,6 +97,27 @@ for name, snap, kw in cases():
         print("    dpose %.3e" % np.abs(np.asarray(a["state"]["pose"]) - np.asarray(b["state"]["pose"])).max())
 print("windows with differences:", bad_total)
 
+# ---- batches of 32 windows and more (the throughput kernel set): every window of the set above in one batch
+allc = cases()
+for label, pick in (("batch/plain", lambda n, kw: not kw and not n.startswith(("all_free", "plane"))), ("batch/with_free_extrinsic", lambda n, kw: not kw and not n.startswith("plane"))):
+    snaps = [sn for n, sn, kw in allc if pick(n, kw)]
+    snaps = (snaps * (40 // len(snaps) + 1))[:40]
+    res = []
+    for spec in (0, 1):
+        be = backend(spec)
+        res.append(be.solve_batch(snaps, abi.MARGIN_OLD))
+        be.close()
+    bad = [same(a, b) for a, b in zip(res[0], res[1])]
+    h = hashlib.md5()
+    for r in res[1]:
+        h.update(repr(sorted((k, np.asarray(v).tolist() if not isinstance(v, dict) else repr(v)) for k, v in r["state"].items())).encode())
+        h.update(np.ascontiguousarray(r["feature"]).tobytes()); h.update(np.asarray(r["summary"]["cost_history"]).tobytes())
+        if r.get("prior") is not None:
+            h.update(repr(sorted((k, np.asarray(v).tolist() if not isinstance(v, dict) else repr(v)) for k, v in r["prior"].items())).encode())
+    nrej = sum(1 for r in res[1] for x in r["summary"]["accepted"][1:] if not x)
+    print("%-26s %d windows, %d rejected steps  %s  digest %s" % (label, len(snaps), nrej, "identical" if not any(bad) else "DIFFERENT in %d windows %r" % (sum(1 for x in bad if x), [x for x in bad if x][:2]), h.hexdigest()[:12]), flush=True)
+    if any(bad): bad_total += 1
+print("windows / batches with differences:", bad_total)
 if os.environ.get("NOTIMES"): raise SystemExit(0)
 # ---- times
 scn = synth.Scenario(seed=20250708 + 2, n_landmarks=2000, use_wheel=True)
@@ -120,3 +141,23 @@ for spec in (0, 1, 0, 1):
     print("speculative %d: one window resident %.4f ms (p10 %.4f)  host to host %.4f ms (p10 %.4f)" %
           (spec, np.median(ts) * 1e3, np.percentile(ts, 10) * 1e3, np.median(th[20:]) * 1e3, np.percentile(th[20:], 10) * 1e3), flush=True)
     be.close()
+
+# ---- throughput: 8 unique 2k-landmark windows x 1024, resident
+snaps = []
+be0 = backend(0)
+for k in range(8):
+    scn = synth.Scenario(seed=20250708 + k, n_landmarks=2000, use_wheel=True)
+    r = be0.solve_batch([scn.window(0)], abi.MARGIN_OLD)[0]
+    snaps.append(scn.window(1, state=synth.shift_state_for_next_window(scn, r["state"], 1), prior=r["prior"]))
+be0.close()
+B = int(os.environ.get("B", "8192"))
+for spec in (0, 1, 0, 1):
+    be = backend(spec)
+    b = be.batch_upload((snaps * (B // 8 + 1))[:B])
+    for _ in range(2): b.solve(abi.MARGIN_OLD)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(6):
+        t0 = time.perf_counter(); b.solve(abi.MARGIN_OLD); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print("speculative %d: %d resident windows %.1f ms per solve, %.1fk solves/s" % (spec, B, np.median(ts) * 1e3, B / np.median(ts) / 1e3), flush=True)
+    b.free(); be.close()
