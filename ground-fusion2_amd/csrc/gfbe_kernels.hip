@@ -2966,28 +2966,10 @@ __device__ __forceinline__ void block_candidate(const BatchDev &d, const int w, 
 #pragma unroll
   for (int k = 0; k < MAXS; k++) if (k < q.gs) Y[q.am + k] = Yl[k];
 }
-__global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
-  static_assert(GFBE_BLK_COUNT <= 128 && GFBE_BLK_RCV_DT0 <= 64, "two blocks per lane, the second one a scalar block");
-  const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
-  const BatchDev d = lin_view(d0, d0.ctl[w].lb);
-  const WinDesc &ds = d.desc[w];
-  WinCtl &c = d.ctl[w];
-  const int t = threadIdx.x;
-  __shared__ double sy[NV], sv[NV];
-  __shared__ PoseRT sp_cand[NF + 1];
-  const int cur = c.cur;
-  if (tile < ds.n_tiles && !(c.done || c.reuse)) {
-    for (int a = t; a < NV; a += LM_TILE) {
-      const double s = d.sp[(size_t)w * ND + a];
-      sy[a] = s * d.yp[(size_t)w * ND + a];
-      sv[a] = s * d.vp[(size_t)w * ND + a];
-    }
-    __syncthreads();
-    __shared__ double fsteps[NF * LM_FS];
-    const bool comp = !d.vis_full;      // (workgroup-uniform: the barrier below is safe)
-    if (comp) { stage_frame_steps(d, c, w, t, sy, sv, fsteps); __syncthreads(); }
-    lm_step_tile(d, ds, c, w, tile, t, sy, sv, comp ? fsteps : nullptr);
-  }
+// k_step and the dense half of k_candidate for window w, by one wave (k_lm_step_fused: the workgroup of the window that arrives last —
+// arrive_cnt / expected —; k_step_candidate: a launch of its own). The scalars k_step reads are loaded before the arrival.
+__device__ __forceinline__ void step_and_candidate(const BatchDev &d, const WinDesc &ds, WinCtl &c, const int w, const int t, const int cur,
+                                                   PoseRT *sp_cand, int *arrive_cnt, const int expected) {
   // ---- preloads of the tail
   StepLocal lc;
   lc.done = c.done; lc.have_step = c.have_step; lc.reuse = c.reuse; lc.iter = c.iter; lc.termination = c.termination; lc.status = c.status;
@@ -3000,7 +2982,7 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
   BlockPre q0, q1;
   block_preload<9>(d, ds, w, X, t, q0);
   block_preload<1>(d, ds, w, X, t + 64, q1);
-  if (!arrive_last(d.win_cnt + 2 * w, gridDim.y, t)) return;
+  if (arrive_cnt && !arrive_last(arrive_cnt, expected, t)) return;
   // ---- k_step
   step_body(d, ds, lc, c, w, t);
   if (t == 0) {
@@ -3023,6 +3005,39 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
   if (t == GFBE_BLK_EX_CAM) sp_cand[NF] = make_pose(Yl0);
   __syncthreads();
   pair_consts_from_staged(d.pc + ((size_t)w * 3 + (1 - cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
+}
+__global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
+  static_assert(GFBE_BLK_COUNT <= 128 && GFBE_BLK_RCV_DT0 <= 64, "two blocks per lane, the second one a scalar block");
+  const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
+  const BatchDev d = lin_view(d0, d0.ctl[w].lb);
+  const WinDesc &ds = d.desc[w];
+  WinCtl &c = d.ctl[w];
+  const int t = threadIdx.x;
+  __shared__ double sy[NV], sv[NV];
+  __shared__ PoseRT sp_cand[NF + 1];
+  const int cur = c.cur;
+  if (tile < ds.n_tiles && !(c.done || c.reuse)) {
+    for (int a = t; a < NV; a += LM_TILE) {
+      const double s = d.sp[(size_t)w * ND + a];
+      sy[a] = s * d.yp[(size_t)w * ND + a];
+      sv[a] = s * d.vp[(size_t)w * ND + a];
+    }
+    __syncthreads();
+    __shared__ double fsteps[NF * LM_FS];
+    const bool comp = !d.vis_full;      // (workgroup-uniform: the barrier below is safe)
+    if (comp) { stage_frame_steps(d, c, w, t, sy, sv, fsteps); __syncthreads(); }
+    lm_step_tile(d, ds, c, w, tile, t, sy, sv, comp ? fsteps : nullptr);
+  }
+  step_and_candidate(d, ds, c, w, t, cur, sp_cand, d.win_cnt + 2 * w, gridDim.y);
+}
+
+// throughput batches (GFBE_FUSE_CAND): k_step and the dense half of k_candidate in ONE launch of one wave per window — two launches of
+// 2048 single-wave workgroups each waited their turn behind the other parts' kernels (83 + 144 us per iteration and part)
+__global__ __launch_bounds__(LM_TILE) void k_step_candidate(BatchDev d) {
+  const int w = blockIdx.x;
+  __shared__ PoseRT sp_cand[NF + 1];
+  WinCtl &c = d.ctl[w];
+  step_and_candidate(d, d.desc[w], c, w, threadIdx.x, c.cur, sp_cand, nullptr, 0);
 }
 
 // =============================================================================================
@@ -3377,6 +3392,11 @@ void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse) {
   else hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
 }
 void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
+bool launch_step_candidate(const BatchDev &d, hipStream_t s) {      // false: the batch takes launch_step + launch_candidate
+  if (!(d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND && d.max_tiles > 0)) return false;
+  hipLaunchKernelGGL(k_step_candidate, dim3(d.B), dim3(LM_TILE), 0, s, d);
+  return true;
+}
 void launch_candidate(const BatchDev &d, hipStream_t s) {
   if (d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND && d.max_tiles > 0) hipLaunchKernelGGL(k_candidate_dense, dim3(d.B), dim3(LM_TILE), 0, s, d);
   else if (d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_candidate_window, dim3(d.B), dim3(CAND_THREADS), 0, s, d);
