@@ -277,6 +277,8 @@ def main():
                                    "marginalisation prior n=%d, full optimization() = <=8 dogleg iterations + re-anchor + MARGIN_OLD" %
                                    (args.landmarks, int(np.mean(K_per)), snaps[0]["prior"]["n"]),
                        "windows_per_gpu": args.batch, "unique_windows": args.unique,
+                       "options": "gfbe_default_options (marg_sqrt = 1 LDL^T, speculative_linearization = 1: the candidate pass of an iteration is its "
+                                  "linearisation — same evaluations, same results as with 0, tests/test_gpu_speculative.py)",
                        "parallelism": ("landmark tiles of every window sharded over %d ranks, RCCL all-reduce of the partial normal equations (%s hook)" % (world, hook_kind)) if shard
                                       else "windows sharded over %d rank(s), no collective" % world},
             "roofline": roofline, "cpu_baseline": cpu, "accuracy": accuracy, "landmark_sharding": shard_info,
@@ -422,7 +424,8 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
     whole_tf = 32e6 * (K1 / 9457.0) * lin_per_solve * value / 1e12
     alg_bytes = 108.0 * units_per_launch                                   # the fused form's 12 f64 + 3 i32 per factor
     hbm_tbs = alg_bytes / (lin_ms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "k_vis<0, %s> (visual evaluate + linearise + fused [Y r]^T [Y r]; first iteration: all windows active)" % ("full 20-column panel" if full_panel else "7 x 7 panel, both rows of a factor in one 16-wide tile"),
+    return {"bound": "hbm", "kernel": "k_vis<0, %s> (visual evaluate + linearise + fused [Y r]^T [Y r]; timed on the first iteration, all windows active — the later ones launch "
+                                     "the same evaluation at the candidate, k_vis<0, ., true>, with the candidate's inverse depths formed at its head)" % ("full 20-column panel" if full_panel else "7 x 7 panel, both rows of a factor in one 16-wide tile"),
             "achieved": hbm_tbs * 1e3, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": hbm_tbs / PEAK_HBM_TBS,
             "why_hbm": "`frac` prices SURVEY 8d's algorithmic 108 B per factor (the fused form's 12 f64 + 3 i32 of INPUT per factor) over the kernel's launch "
                        "time, as the bench contract asks. The device format is leaner than that model — two doubles per observation, the landmark's "

@@ -1,8 +1,8 @@
 # Round-5 profile set (run through gpurun from the repo root: `gpurun -- 'bash profiles/scripts/profiles_r5.sh'`; writes gpurun_out/r5_*,
 # copied to profiles/ afterwards), ALL from the build at HEAD: kernel stats of the default bench workload, the four PMC passes (each in
 # its own rocprofv3 run; --pmc never with sys / hip / hsa traces), the bench line (reads the PMC summaries of THIS build), the
-# single-window kernel trace, the chain kernels' phase stamps and the three factorisations side by side, the eigen square root of the
-# prior, the GNSS window, the end-to-end loop under the tracer, the one-robot frame loop, the parity soaks.
+# single-window kernel trace, the chain kernels' phase stamps and the three factorisations side by side, the speculative linearisation on
+# against off, the eigen square root of the prior, the GNSS window, the end-to-end loop under the tracer, the one-robot frame loop, the parity soaks.
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; export GPU_MAX_HW_QUEUES=8
 cd /tmp
 rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats -d /tmp/ks -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-single --mixed 0 --no-other-configs > $R/gpurun_out/r5_bench_under_rocprof.json 2> /tmp/ks.err
@@ -22,6 +22,11 @@ cd $R
 python tools/diag_single.py 2>&1 | tail -3 | tee -a gpurun_out/r5_single.log
 (KERNELS=2,3,1 BIG=1 python tools/diag_scripts/chain_variants.py 2>&1 | grep -v amdgpu.ids; GFBE_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_chainstamp.so python tools/diag_scripts/chain_stamps.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/r5_solve_chain_phases.txt; tail -9 gpurun_out/r5_solve_chain_phases.txt
 ./profiles/ubench/chol_tile_check2 > gpurun_out/r5_chol_tile_step.txt 2>&1; head -3 gpurun_out/r5_chol_tile_step.txt
+# speculative linearisation on against off (every output bit for bit; single-window times; 8192 resident windows), the phases of the
+# candidate's linearisation launch of a single window, and what a lone wave costs on this device (the model behind the latency path)
+python tools/diag_scripts/spec_check.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_speculative.txt; tail -9 gpurun_out/r5_speculative.txt
+GFBE_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_linstamp3.so python tools/diag_scripts/lin_stamps.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_lin_small_phases.txt; tail -5 gpurun_out/r5_lin_small_phases.txt
+./profiles/ubench/lone_wave_clock > gpurun_out/r5_lone_wave.txt 2>&1; head -2 gpurun_out/r5_lone_wave.txt
 GFBE_LIB=$R/ground-fusion2_amd/csrc/libgfbe_diag.so python tools/diag_scripts/eig_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_eigen_prior.txt; cat gpurun_out/r5_eigen_prior.txt
 python tools/diag_scripts/plane_kernels.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_plane_kernels.txt
 python tools/diag_scripts/gnss_prof.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r5_gnss_window_profile.txt; head -3 gpurun_out/r5_gnss_window_profile.txt
