@@ -385,7 +385,6 @@ void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse = 0);   // fuse: 
 void launch_step(const BatchDev &d, hipStream_t s);
 void launch_candidate(const BatchDev &d, hipStream_t s);
 void launch_accept(const BatchDev &d, hipStream_t s, int spec = 0);
-bool launch_step_candidate(const BatchDev &d, hipStream_t s);
 void launch_reanchor(const BatchDev &d, hipStream_t s);
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s);
 // mode 0: GNSS factors at the current parameters, added to H / g (after launch_assemble); 1: candidate cost; 2: the frame-0 factors at

@@ -1372,9 +1372,8 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     enqueue_linearize(c, b, ln, it == 0, spec && it > 0);
     const int fuse = small_fuse(c, d);
     if (!(fuse & 2)) {
-      bool one = false;
-      { Timed t(c, "k_step", 0); one = launch_step_candidate(d, ln.s); if (!one) launch_step(d, ln.s); }      // (throughput batches: step + dense candidate in one launch)
-      if (!one) { Timed t(c, "k_candidate", 0); launch_candidate(d, ln.s); }
+      { Timed t(c, "k_step", 0); launch_step(d, ln.s); }
+      { Timed t(c, "k_candidate", 0); launch_candidate(d, ln.s); }
     }
     const bool overlap = !c->profiling && ln.aux && d.B >= DENSE_SPLIT_MIN_B;
     const bool lin_cand = spec && it + 1 < iters;      // this candidate pass linearises (the last one of a solve only needs the costs)

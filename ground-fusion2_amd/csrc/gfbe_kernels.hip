@@ -2966,46 +2966,6 @@ __device__ __forceinline__ void block_candidate(const BatchDev &d, const int w, 
 #pragma unroll
   for (int k = 0; k < MAXS; k++) if (k < q.gs) Y[q.am + k] = Yl[k];
 }
-// k_step and the dense half of k_candidate for window w, by one wave (k_lm_step_fused: the workgroup of the window that arrives last —
-// arrive_cnt / expected —; k_step_candidate: a launch of its own). The scalars k_step reads are loaded before the arrival.
-__device__ __forceinline__ void step_and_candidate(const BatchDev &d, const WinDesc &ds, WinCtl &c, const int w, const int t, const int cur,
-                                                   PoseRT *sp_cand, int *arrive_cnt, const int expected) {
-  // ---- preloads of the tail
-  StepLocal lc;
-  lc.done = c.done; lc.have_step = c.have_step; lc.reuse = c.reuse; lc.iter = c.iter; lc.termination = c.termination; lc.status = c.status;
-  lc.invalid_steps = c.invalid_steps;
-  lc.G2 = c.G2; lc.N2 = c.N2; lc.gy = c.gy; lc.vHv = c.vHv; lc.vHy = c.vHy; lc.yHy = c.yHy; lc.grad_max = c.grad_max; lc.x_norm = c.x_norm;
-  lc.alpha = c.alpha; lc.radius = c.radius; lc.c1 = c.c1; lc.c2 = c.c2; lc.step_norm = c.step_norm; lc.model_change = c.model_change;
-  lc.cost = c.cost; lc.mu = c.mu; lc.t_start = c.t_start;
-  const double *X = d.x + ((size_t)w * 2 + cur) * NA;
-  double *Y = d.x + ((size_t)w * 2 + 1 - cur) * NA;
-  BlockPre q0, q1;
-  block_preload<9>(d, ds, w, X, t, q0);
-  block_preload<1>(d, ds, w, X, t + 64, q1);
-  if (arrive_cnt && !arrive_last(arrive_cnt, expected, t)) return;
-  // ---- k_step
-  step_body(d, ds, lc, c, w, t);
-  if (t == 0) {
-    c.done = lc.done; c.have_step = lc.have_step; c.reuse = lc.reuse; c.iter = lc.iter; c.termination = lc.termination; c.status = lc.status;
-    c.invalid_steps = lc.invalid_steps;
-    c.G2 = lc.G2; c.N2 = lc.N2; c.gy = lc.gy; c.vHv = lc.vHv; c.vHy = lc.vHy; c.yHy = lc.yHy; c.grad_max = lc.grad_max; c.x_norm = lc.x_norm;
-    c.alpha = lc.alpha; c.c1 = lc.c1; c.c2 = lc.c2; c.step_norm = lc.step_norm; c.model_change = lc.model_change; c.mu = lc.mu;
-  }
-  const int go = __shfl((lc.done || !lc.have_step) ? 0 : 1, 0, 64);       // (lane 0 ran the scalar logic)
-  if (!go) return;
-  const double c1 = __shfl(lc.c1, 0, 64), c2 = __shfl(lc.c2, 0, 64);
-  // ---- the dense parameter blocks of k_candidate
-  double d2 = 0.0, n2 = 0.0, Yl0[9], Yl1[9];
-  block_candidate<9>(d, w, q0, c1, c2, Y, Yl0, d2, n2);
-  block_candidate<1>(d, w, q1, c1, c2, Y, Yl1, d2, n2);
-  d2 = wave_sum(d2); n2 = wave_sum(n2);
-  if (t == 0) { d.dense_cand[(size_t)w * 4 + 1] = d2; d.dense_cand[(size_t)w * 4 + 2] = n2; }
-  // the candidate's pose-pair constants: the poses straight from the lanes that formed them (block id = lane: Pose[t]; the camera extrinsic)
-  if (t < NF) sp_cand[t] = make_pose(Yl0);
-  if (t == GFBE_BLK_EX_CAM) sp_cand[NF] = make_pose(Yl0);
-  __syncthreads();
-  pair_consts_from_staged(d.pc + ((size_t)w * 3 + (1 - cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
-}
 __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
   static_assert(GFBE_BLK_COUNT <= 128 && GFBE_BLK_RCV_DT0 <= 64, "two blocks per lane, the second one a scalar block");
   const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
@@ -3028,16 +2988,41 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
     if (comp) { stage_frame_steps(d, c, w, t, sy, sv, fsteps); __syncthreads(); }
     lm_step_tile(d, ds, c, w, tile, t, sy, sv, comp ? fsteps : nullptr);
   }
-  step_and_candidate(d, ds, c, w, t, cur, sp_cand, d.win_cnt + 2 * w, gridDim.y);
-}
-
-// throughput batches (GFBE_FUSE_CAND): k_step and the dense half of k_candidate in ONE launch of one wave per window — two launches of
-// 2048 single-wave workgroups each waited their turn behind the other parts' kernels (83 + 144 us per iteration and part)
-__global__ __launch_bounds__(LM_TILE) void k_step_candidate(BatchDev d) {
-  const int w = blockIdx.x;
-  __shared__ PoseRT sp_cand[NF + 1];
-  WinCtl &c = d.ctl[w];
-  step_and_candidate(d, d.desc[w], c, w, threadIdx.x, c.cur, sp_cand, nullptr, 0);
+  // ---- preloads of the tail
+  StepLocal lc;
+  lc.done = c.done; lc.have_step = c.have_step; lc.reuse = c.reuse; lc.iter = c.iter; lc.termination = c.termination; lc.status = c.status;
+  lc.invalid_steps = c.invalid_steps;
+  lc.G2 = c.G2; lc.N2 = c.N2; lc.gy = c.gy; lc.vHv = c.vHv; lc.vHy = c.vHy; lc.yHy = c.yHy; lc.grad_max = c.grad_max; lc.x_norm = c.x_norm;
+  lc.alpha = c.alpha; lc.radius = c.radius; lc.c1 = c.c1; lc.c2 = c.c2; lc.step_norm = c.step_norm; lc.model_change = c.model_change;
+  lc.cost = c.cost; lc.mu = c.mu; lc.t_start = c.t_start;
+  const double *X = d.x + ((size_t)w * 2 + cur) * NA;
+  double *Y = d.x + ((size_t)w * 2 + 1 - cur) * NA;
+  BlockPre q0, q1;
+  block_preload<9>(d, ds, w, X, t, q0);
+  block_preload<1>(d, ds, w, X, t + 64, q1);
+  if (!arrive_last(d.win_cnt + 2 * w, gridDim.y, t)) return;
+  // ---- k_step
+  step_body(d, ds, lc, c, w, t);
+  if (t == 0) {
+    c.done = lc.done; c.have_step = lc.have_step; c.reuse = lc.reuse; c.iter = lc.iter; c.termination = lc.termination; c.status = lc.status;
+    c.invalid_steps = lc.invalid_steps;
+    c.G2 = lc.G2; c.N2 = lc.N2; c.gy = lc.gy; c.vHv = lc.vHv; c.vHy = lc.vHy; c.yHy = lc.yHy; c.grad_max = lc.grad_max; c.x_norm = lc.x_norm;
+    c.alpha = lc.alpha; c.c1 = lc.c1; c.c2 = lc.c2; c.step_norm = lc.step_norm; c.model_change = lc.model_change; c.mu = lc.mu;
+  }
+  const int go = __shfl((lc.done || !lc.have_step) ? 0 : 1, 0, 64);       // (lane 0 ran the scalar logic)
+  if (!go) return;
+  const double c1 = __shfl(lc.c1, 0, 64), c2 = __shfl(lc.c2, 0, 64);
+  // ---- the dense parameter blocks of k_candidate
+  double d2 = 0.0, n2 = 0.0, Yl0[9], Yl1[9];
+  block_candidate<9>(d, w, q0, c1, c2, Y, Yl0, d2, n2);
+  block_candidate<1>(d, w, q1, c1, c2, Y, Yl1, d2, n2);
+  d2 = wave_sum(d2); n2 = wave_sum(n2);
+  if (t == 0) { d.dense_cand[(size_t)w * 4 + 1] = d2; d.dense_cand[(size_t)w * 4 + 2] = n2; }
+  // the candidate's pose-pair constants: the poses straight from the lanes that formed them (block id = lane: Pose[t]; the camera extrinsic)
+  if (t < NF) sp_cand[t] = make_pose(Yl0);
+  if (t == GFBE_BLK_EX_CAM) sp_cand[NF] = make_pose(Yl0);
+  __syncthreads();
+  pair_consts_from_staged(d.pc + ((size_t)w * 3 + (1 - cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
 }
 
 // =============================================================================================
@@ -3392,11 +3377,6 @@ void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse) {
   else hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
 }
 void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
-bool launch_step_candidate(const BatchDev &d, hipStream_t s) {      // false: the batch takes launch_step + launch_candidate
-  if (!(d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND && d.max_tiles > 0)) return false;
-  hipLaunchKernelGGL(k_step_candidate, dim3(d.B), dim3(LM_TILE), 0, s, d);
-  return true;
-}
 void launch_candidate(const BatchDev &d, hipStream_t s) {
   if (d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND && d.max_tiles > 0) hipLaunchKernelGGL(k_candidate_dense, dim3(d.B), dim3(LM_TILE), 0, s, d);
   else if (d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_candidate_window, dim3(d.B), dim3(CAND_THREADS), 0, s, d);
