@@ -12,10 +12,12 @@
 #include "../../include/gfbe.h"
 
 #ifndef GFBE_LIN_SMALL_THREADS
-#define GFBE_LIN_SMALL_THREADS 256
+#define GFBE_LIN_SMALL_THREADS 256     // (four waves, one per SIMD: each has the whole register file — arch + acc — for the scalar algebra of an inertial /
+                                       //  wheel factor; eight waves = 256 registers each spilled 508 bytes per lane: 1.244 against 1.212 ms host to host)
 #endif
 #ifndef GFBE_LIN_SMALL_KS
-#define GFBE_LIN_SMALL_KS 5     // (4 -> 5 once the wheel factor and the tails were out of the way: 1.244 -> 1.227 ms per single-window solve; 10: 1.316)
+#define GFBE_LIN_SMALL_KS 4     // shares of a visual tile's observation steps (k = share, share + KS, ...): the waves of the tile's workgroup in k_lin_small
+                                // (round 5; until then five workgroups per tile: 4 -> 5 measured 1.244 -> 1.227 ms, 10: 1.316), workgroups in k_vis_split
 #endif
 
 // Small batches (< 32 windows, no landmark sharding): launches of one iteration merged on a single window's latency path. Bit 0:
@@ -73,7 +75,7 @@ enum {
   MAX_BATCH_PARTS = 16,       // upper bound of gfbe_options.split_batch (every part beyond the first owns a pair of streams)
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
   LIN_SMALL_KS = GFBE_LIN_SMALL_KS,   // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
-  LIN_SMALL_THREADS = GFBE_LIN_SMALL_THREADS,    // k_lin_small: threads per workgroup (one wave per visual tile item, four for an inertial / wheel / prior item)
+  LIN_SMALL_THREADS = GFBE_LIN_SMALL_THREADS,    // k_lin_small: threads per workgroup (LIN_SMALL_KS waves per visual tile, all of them for an inertial / wheel / prior item)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
   LIOW_WGS = 8, LIOW_PART = 32,   // LiDAR factors of a window: workgroups per window, doubles per partial (21 H | 6 g | cost | candidate cost)
@@ -345,6 +347,7 @@ hipError_t kernels_init_device();   // per-device kernel attributes (k_solve's d
 hipError_t marg_init_device();      // same for k_marg
 hipError_t gnss_init_device();      // same for k_gnss
 hipError_t dense_init_device();     // same for k_prior_tp
+hipError_t lin_small_init_device(); // same for k_lin_small
 void launch_prep(const BatchDev &d, hipStream_t s);
 void launch_upload_small(const BatchDev &d, int with_expand, hipStream_t s);   // small batches: k_expand + k_prep + k_prep_prior + k_asm_table in one launch
 void launch_expand(const BatchDev &d, hipStream_t s);                 // host upload: fobs -> lm_obs / lm_rec

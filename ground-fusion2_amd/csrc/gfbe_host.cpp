@@ -291,6 +291,7 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   if (ea == hipSuccess) ea = marg_init_device();
   if (ea == hipSuccess) ea = gnss_init_device();
   if (ea == hipSuccess) ea = dense_init_device();
+  if (ea == hipSuccess) ea = lin_small_init_device();
   if (ea != hipSuccess) { c->err = std::string("hipFuncSetAttribute(dynamic LDS): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
   ea = asm_tables_build(&c->asm_full, &c->asm_compact, &c->asm_compact_n, c->stream);
   if (ea != hipSuccess) { c->err = std::string("assembly tables (hipMalloc / k_asm_table / k_asm_compact): ") + hipGetErrorString(ea); return GFBE_DEVICE_ERROR; }
@@ -803,10 +804,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   if (diag_getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics build only: force the 20-column panel)
   // speculative linearisation (gfbe_options.speculative_linearization): batches whose candidate costs are all formed by the visual /
   // dense-factor launches (no GNSS / LiDAR factors, no all-reduce hook) get a second set of the linearisation's outputs
-  // (batches below 32 windows: up to 64 landmark tiles per window — the candidate's linearisation is five workgroups per tile, and a
-  //  10 000-landmark window (160 tiles) had its 800 waiting for each other: 2.16 -> 2.26 ms host to host, measured; 2 000 landmarks: 1.31 -> 1.28)
   d.spec = (c->opt.speculative_linearization && !c->allreduce && !any_gnss && tot_lio == 0 && max_tiles > 0 &&
-            (B >= DENSE_SPLIT_MIN_B || ((GFBE_FUSE_SMALL & 6) == 6 && max_tiles <= 64))) ? 1 : 0;
+            (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 6) == 6)) ? 1 : 0;
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
   const double T1 = now();

@@ -298,8 +298,14 @@ __device__ __forceinline__ double candidate_lm(const double lam, const double sl
 // where the cost pass leaves it.
 // head (passes at the candidate): the tile first forms the candidate inverse depths of its landmarks — candidate_tile's work (the landmark
 // half of k_candidate), its loads requested with the evaluation's own and the lane's result kept in its register.
-template <int MODE, bool FULL, int KS = 1, bool SPEC = false>
-__device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile, const int kq = 0, const bool head = false) {
+// WS (KS > 1; k_lin_small since the end of round 5): the KS shares of a tile are WAVES of one workgroup — kq = the wave, `wsm` = KS panels
+// of dynamic LDS — that meet at a workgroup barrier, where the first wave adds the contributions up: the workgroups of the other form met
+// at an atomic counter behind two device-scope fences, and the last one read the others' contributions across the XCDs (~8 us of a
+// ~17 us linearisation launch of a single window).
+template <int MODE, bool FULL, int KS = 1, bool SPEC = false, bool WS = false>
+__device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, const int w, const int tile, const int kq = 0, const bool head = false,
+                                         double *wsm = nullptr) {
+  static_assert(!WS || KS > 1, "wave shares are shares");
   static_assert(!SPEC || MODE == 0, "the speculative pass is a linearisation");
   constexpr bool CAND = (MODE == 1) || SPEC;      // evaluated at the candidate state
   const WinDesc &ds = d.desc[w];
@@ -326,7 +332,7 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #endif
 #if GFBE_LIN_STAMP
   unsigned long long *lst = (unsigned long long *)(d.timing + (size_t)d.B * 32);
-  const bool lstamp = KS > 1 && MODE == 0 && tile == 0 && threadIdx.x == 0;
+  const bool lstamp = KS > 1 && MODE == 0 && tile == 0 && (threadIdx.x & 63) == 0 && (WS || threadIdx.x == 0);
 #define LSTAMP(i) do { if (lstamp && kq == 0) lst[i] = wall_clock64(); } while (0)
 #define LSTAMP_ANY(i) do { if (lstamp) lst[i] = wall_clock64(); } while (0)
 #else
@@ -348,11 +354,12 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   constexpr int PCW = (MODE == 1) ? 12 : sizeof(PCT) / sizeof(double), XLD = FULL ? XS_LD : 17;   // (the cost pass uses Tm and u: the first twelve doubles)
   __shared__ PCT pcs[NF];
   __shared__ FrameConst fcs;
-  __shared__ double xs[(MODE == 1) ? 1 : LM_TILE * XLD];   // one [J | r] row of each of the wave's 64 factors (YM: both [Y r] rows)
+  __shared__ double xs_own[(MODE == 1 || WS) ? 1 : LM_TILE * XLD];   // one [J | r] row of each of the wave's 64 factors (YM: both [Y r] rows)
+  double *const xs = WS ? wsm + (size_t)kq * (LM_TILE * XLD) : xs_own;
   // ---- the wave's second level of loads, ALL requested before the pair constants are staged (round 5): the landmark's slot data, its
   // inverse depth and the first observation row need nothing but the descriptor — a wave used to fetch them one dependent round trip
   // after the other BEHIND the staging barrier (prologue 6.3 us of a ~22 us wave under load)
-  const int lane = threadIdx.x;
+  const int lane = WS ? (threadIdx.x & 63) : threadIdx.x;
   const int slot = ds.lm_off + tile * LM_TILE + lane;
   const size_t TL = d.tot_lm;
   // (tdc: the observations of this batch are stored shifted to the windows' constant td — expand_body — and need neither their
@@ -376,20 +383,28 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
     for (int q = 0; q < 5; q++) if (q < nobq) nob[q] = ob[q * TL];
   }
-  // KS > 1 (round 5): the observation of the workgroup's SECOND step too — a lone wave per SIMD waited a memory round trip per step for the
-  // one requested a step ahead (and, vmcnt counting loads and stores in one queue, for the contribution stores issued before it). With
-  // five workgroups per tile a workgroup has two steps at most: no load is left inside its loop.
-  double nob2[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-  if (KS > 1 && kq + KS < MAXOBS) {
-    const double *ob = d.lm_obs + (size_t)(kq + KS) * 5 * TL + slot;
+  // KS > 1 (round 5): the observations of the share's LATER steps too (k = kq + KS, kq + 2 KS: a share has two steps with five shares per
+  // tile, three with four) — a lone wave per SIMD waited a memory round trip per step for the one requested a step ahead (and, vmcnt
+  // counting loads and stores in one queue, for the contribution stores issued before it; a load inside the loop makes its back edge
+  // wait for the step's stores as well). No load is left inside the loop.
+  constexpr int NLATER = KS > 1 ? (MAXOBS + KS - 1) / KS - 1 : 0;
+  double nobl[NLATER > 0 ? NLATER : 1][5];
 #pragma unroll
-    for (int q = 0; q < 5; q++) if (q < nobq) nob2[q] = ob[q * TL];
+  for (int u = 0; u < NLATER; u++) {
+#pragma unroll
+    for (int q = 0; q < 5; q++) nobl[u][q] = 0.0;
+    if (kq + (u + 1) * KS < MAXOBS) {
+      const double *ob = d.lm_obs + (size_t)(kq + (u + 1) * KS) * 5 * TL + slot;
+#pragma unroll
+      for (int q = 0; q < 5; q++) if (q < nobq) nobl[u][q] = ob[q * TL];
+    }
   }
   {
     const double *src = d.pc + (((size_t)w * 3 + (MODE == 2 ? 2 : buf)) * NPAIR + sframe * NF) * PC_DOUBLES;
-    for (int j = sframe + 1; j < NF; j++)
+    // (WS: the records dealt over the workgroup's waves)
+    for (int j = sframe + 1 + (WS ? kq : 0); j < NF; j += (WS ? KS : 1))
       for (int q = lane; q < PCW; q += LM_TILE) ((double *)&pcs[j])[q] = src[(size_t)j * PC_DOUBLES + q];     // (the whole record is 75 doubles: two rounds)
-    if (YM && lane < FC_DOUBLES) ((double *)&fcs)[lane] = src[(size_t)sframe * PC_DOUBLES + lane];
+    if (YM && (!WS || kq == 0) && lane < FC_DOUBLES) ((double *)&fcs)[lane] = src[(size_t)sframe * PC_DOUBLES + lane];
   }
   __syncthreads();
   const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
@@ -403,7 +418,11 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
   double cost = 0.0;
-  if (tdc) { nob[4] = td; nob2[4] = td; }
+  if (tdc) {
+    nob[4] = td;
+#pragma unroll
+    for (int u = 0; u < NLATER; u++) nobl[u][4] = td;
+  }
   if (chead) {      // x_cand = x + s_l (c1 v_l + c2 y_l): candidate_lm is candidate_tile's arithmetic
     double d2, n2;
     lam = candidate_lm(lam, c_sl, c_vl, c_yl, c.c1, c.c2, valid && !is_const && m > 0, d2, n2);
@@ -449,15 +468,13 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     if (k < 5) KSTAMP(3 + 5 * k);
     double r[2], Ji[12], Jj[12], Je[FULL ? 12 : 1], Jl[2], Jt[2], hp[6];
     const double pjx = nob[0], pjy = nob[1], vjx = nob[2], vjy = nob[3], tdj = nob[4];
-    if (KS > 1) {      // two steps ahead
+    if (KS > 1) {      // the next step's observation: fetched before the loop
 #pragma unroll
-      for (int q = 0; q < 5; q++) nob[q] = nob2[q];
-      if constexpr (2 * KS < MAXOBS) {      // (not with five workgroups per tile: a load in the loop makes its back edge wait for the step's stores too)
-        if (k + 2 * KS < mmax) {
-          const double *ob = d.lm_obs + (size_t)(k + 2 * KS) * 5 * TL + slot;
+      for (int q = 0; q < 5; q++) nob[q] = nobl[0][q];
 #pragma unroll
-          for (int q = 0; q < 5; q++) if (q < nobq) nob2[q] = ob[q * TL];
-        }
+      for (int u = 0; u + 1 < NLATER; u++) {
+#pragma unroll
+        for (int q = 0; q < 5; q++) nobl[u][q] = nobl[u + 1][q];
       }
     } else if (k + KS < mmax) {
       const double *ob = d.lm_obs + (size_t)(k + KS) * 5 * TL + slot;
@@ -688,6 +705,13 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   }
   LSTAMP(16);
   if (KS > 1) {
+    if (WS) {
+      // the tile's waves meet here (a workgroup barrier orders their contribution stores before the loads below: one CU, one vector
+      // cache); the first one adds the steps' contributions up, in step order
+      __syncthreads();
+      if (kq != 0) return;
+      LSTAMP_ANY(17);
+    } else {
     // the last of the tile's KS workgroups to get here adds the steps' contributions up, in step order
     __threadfence();
     int last = 0;
@@ -698,12 +722,14 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
     __threadfence();
     LSTAMP_ANY(17);
     if (lane == 0) *cnt = 0;     // (ready for the next launch)
+    }
     const double *cr = d.vis_contrib + (((size_t)w * d.max_tiles + tile) * MAXOBS) * (VC_STRIDE * LM_TILE) + lane;
     // (round 5: ALL the steps' values are requested before the first sum — the loop used to take one memory round trip per step, ten
     //  in a row for the tiles of start frame 0: ~6 of the ~17 us of a single window's linearisation launch. Same sums, same order.)
     constexpr int NVC = (MODE == 1) ? 1 : (YM ? 6 : (FULL ? 16 : 9));      // cost [| Hll gl | D (3) or hC (6 [+ 7])]
     constexpr int CH = (NVC > 9) ? 4 : MAXOBS;      // steps in flight (the 20-column panel's 16 values per step: four at a time)
-#define VC_LD(k, i) __hip_atomic_load(cr + ((size_t)(k) * VC_STRIDE + (i)) * LM_TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define VC_LD(k, i) (WS ? __hip_atomic_load(cr + ((size_t)(k) * VC_STRIDE + (i)) * LM_TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) \
+                        : __hip_atomic_load(cr + ((size_t)(k) * VC_STRIDE + (i)) * LM_TILE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
 #pragma unroll
     for (int k0 = 0; k0 < MAXOBS; k0 += CH) {
       double vc[CH][NVC];
@@ -950,9 +976,11 @@ __global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode, int spec
 
 // FUSED: small batches evaluate the raw factor inline (lane 0) — one launch less on the latency path of a single
 // window; otherwise the raw residuals / Jacobians come from k_dense_raw.
+enum { PRIOR_CHUNK = 4000 };      // doubles of LDS the small-batch prior item stages J0 through (dense_body; k_lin_small's dynamic LDS)
 // spec (mode 0 only; BatchDev::spec): the linearisation AT THE CANDIDATE in the place of its cost pass — d is the view of the set it goes to.
 template <bool FUSED>
-__device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debug_out, const int w, const int f, const bool spec = false) {
+__device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debug_out, const int w, const int f, const bool spec = false,
+                                           double *pbuf = nullptr) {      // pbuf: PRIOR_CHUNK doubles of LDS for the prior's J0 (k_lin_small), or none
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
   const bool cand = mode == 1 || spec;
@@ -1110,13 +1138,12 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
     const double *r0 = d.prior_r0 + (size_t)w * ND;
     double cst = 0.0;
     DSTAMP(1);
-    if (nthr >= n) {
+    if (nthr >= n && pbuf) {
       // round 5: J0 goes through LDS in chunks of whole rows, fetched as contiguous memory by all the threads; thread i forms r_i from
       // its row (the products added in the old order), then thread k adds the chunk's rows to g_k (rows ascending: the old order
       // too). One sweep over J0 instead of two, no thread walking a row of its own in memory (64 cache lines per load of a wave, a
       // memory round trip every few entries: the prior took 13-17 us of a single window's ~17 us linearisation launch).
-      constexpr int PBUF = 4000;
-      __shared__ double pbuf[PBUF];
+      constexpr int PBUF = PRIOR_CHUNK;
       const int ld = n | 1, R = min(PBUF / ld, n);      // rows per chunk (n <= 246: at least 16)
       double gk = 0.0;
       for (int i0 = 0; i0 < n; i0 += R) {
@@ -1444,31 +1471,38 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d0,
   // the set of the linearisation's outputs this pass writes: the current one (MODE 0: lb = 0 unless the batch is speculative), the other
   // one (MODE 3); the cost pass and the marginalisation's set use the first whatever lb
   const BatchDev d = (MODE == 0 || SPEC) ? lin_view(d0, SPEC ? 1 - d0.ctl[w].lb : d0.ctl[w].lb) : d0;
-  // four waves per workgroup: a visual tile is one wave's work (the others leave at once); the inertial / wheel / prior items use
-  // all four — the single lane that evaluated an IMU factor was the longest chain of the launch
-  const bool tile_wg = y < d.max_tiles * KS;
+  // LIN_SMALL_THREADS / 64 waves per workgroup. A visual tile is ONE workgroup whose first KS waves take the observation steps
+  // k = wave, wave + KS, ... (vis_body's WS form; the others leave at once); the inertial / wheel / prior items use all the waves — the
+  // single lane that evaluated an inertial or a wheel factor was the longest chain of the launch. lsm: the dynamic LDS of the
+  // workgroup — the KS panels of a tile, or the prior's chunk of J0 (lin_small_lds_doubles).
+  extern __shared__ __attribute__((aligned(16))) double lsm[];
+  constexpr bool WS = KS > 1;
+  const int ny_tiles = d.max_tiles;       // (one workgroup per tile in every mode)
+  const bool tile_wg = y < ny_tiles;
 #if GFBE_LIN_STAMP
   // diagnostics build (tools/diag_scripts/lin_stamps.py): start of workgroup 0 and the latest end per kind of item, of the LAST launch of MODE 0
   unsigned long long *ls = (unsigned long long *)(d.timing + (size_t)d.B * 32);
   if (MODE == GFBE_LIN_STAMP_MODE && y == 0 && threadIdx.x == 0) ls[0] = wall_clock64();
-  if (MODE == GFBE_LIN_STAMP_MODE && y == d.max_tiles * KS && threadIdx.x == 0) ls[8] = wall_clock64();                 // first inertial item starts
-  if (MODE == GFBE_LIN_STAMP_MODE && y == d.max_tiles * KS + MAX_IMU && threadIdx.x == 0) ls[9] = wall_clock64();       // first wheel item starts
-  if (MODE == GFBE_LIN_STAMP_MODE && y == d.max_tiles * KS + MAX_IMU + MAX_WHEEL && threadIdx.x == 0) ls[10] = wall_clock64();   // the prior starts
+  if (MODE == GFBE_LIN_STAMP_MODE && y == ny_tiles && threadIdx.x == 0) ls[8] = wall_clock64();                 // first inertial item starts
+  if (MODE == GFBE_LIN_STAMP_MODE && y == ny_tiles + MAX_IMU && threadIdx.x == 0) ls[9] = wall_clock64();       // first wheel item starts
+  if (MODE == GFBE_LIN_STAMP_MODE && y == ny_tiles + MAX_IMU + MAX_WHEEL && threadIdx.x == 0) ls[10] = wall_clock64();   // the prior starts
 #endif
   if (tile_wg) {
-    if (threadIdx.x >= LM_TILE) return;
-    // (fuse bit 1: the tile forms its candidate inverse depths first; MODE 3: each of the tile's KS workgroups does, for its own lanes — the same values)
-    vis_body<VM, FULL, KS, SPEC>(d, 0, w, y / KS, y % KS, (MODE == 1 || SPEC) && (fuse & 2));
+    if (threadIdx.x >= KS * LM_TILE) return;
+    // (fuse bit 1: the tile forms its candidate inverse depths first; MODE 3: each of the tile's KS waves does, for its own lanes — the same values)
+    if constexpr (WS) vis_body<VM, FULL, KS, SPEC, true>(d, 0, w, y, threadIdx.x >> 6, SPEC && (fuse & 2), lsm);
+    else vis_body<VM, FULL, 1, SPEC, false>(d, 0, w, y, 0, MODE == 1 && (fuse & 2));
+    if (threadIdx.x >= LM_TILE) return;      // (the tile's first wave goes on: it has summed the waves' shares)
   } else {
-    dense_body<true>(d, VM, 0, w, y - d.max_tiles * KS, SPEC);
+    dense_body<true>(d, VM, 0, w, y - ny_tiles, SPEC, lsm);
   }
 #if GFBE_LIN_STAMP
   if (MODE == GFBE_LIN_STAMP_MODE && (threadIdx.x & 63) == 0) {
-    const int f = y - d.max_tiles * KS;
+    const int f = y - ny_tiles;
     const int kind = tile_wg ? 1 : (f < MAX_IMU ? 2 : (f < MAX_IMU + MAX_WHEEL ? 3 : (f == MAX_IMU + MAX_WHEEL ? 4 : 5)));
     atomicMax(ls + kind, (unsigned long long)wall_clock64());
     if (tile_wg && y == 0) ls[6] = wall_clock64();
-    if (tile_wg && y == d.max_tiles * KS - 1) ls[7] = wall_clock64();
+    if (tile_wg && y == ny_tiles - 1) ls[7] = wall_clock64();
     if (threadIdx.x == 0 && f == MAX_IMU) ls[11] = wall_clock64();                                      // first wheel item ends
   }
 #endif
@@ -3289,14 +3323,30 @@ void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records, i
   else if (d.B < DENSE_SPLIT_MIN_B) hipLaunchKernelGGL((k_vis_split<2, true>), dim3(d.B, d.max_tiles * LIN_SMALL_KS), b, 0, s, d, write_records);
   else hipLaunchKernelGGL((k_vis<2, true>), g, b, 0, s, d, write_records);
 }
+// dynamic LDS of a k_lin_small workgroup: the KS panels of a tile ([J | r] rows, 21 doubles wide; 17 for the 7 x 7 form) or the prior's chunk of J0
+static size_t lin_small_lds(bool split, bool full) {
+  const size_t panels = split ? (size_t)LIN_SMALL_KS * LM_TILE * (full ? (size_t)XS_LD : 17) : 0;
+  return sizeof(double) * std::max(panels, (size_t)PRIOR_CHUNK);
+}
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse) {
-  const dim3 g(d.B, d.max_tiles * (mode != 1 ? LIN_SMALL_KS : 1) + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LIN_SMALL_THREADS);
-  if (mode == 2) hipLaunchKernelGGL((k_lin_small<2, true>), g, b, 0, s, d, 0);   // (the marginalisation set: k_vis_split<2> + k_dense mode 2 in one launch)
-  else if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, 0, s, d, 0);
-  else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, 0, s, d, 0);
-  else if (mode == 3 && d.vis_full) hipLaunchKernelGGL((k_lin_small<3, true>), g, b, 0, s, d, fuse);   // (speculative: the candidate linearised)
-  else if (mode == 3) hipLaunchKernelGGL((k_lin_small<3, false>), g, b, 0, s, d, fuse);
-  else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, 0, s, d, fuse);
+  const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LIN_SMALL_THREADS);
+  if (mode == 2) hipLaunchKernelGGL((k_lin_small<2, true>), g, b, lin_small_lds(true, true), s, d, 0);   // (the marginalisation set: k_vis_split<2> + k_dense mode 2 in one launch)
+  else if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, lin_small_lds(true, true), s, d, 0);
+  else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, lin_small_lds(true, false), s, d, 0);
+  else if (mode == 3 && d.vis_full) hipLaunchKernelGGL((k_lin_small<3, true>), g, b, lin_small_lds(true, true), s, d, fuse);   // (speculative: the candidate linearised)
+  else if (mode == 3) hipLaunchKernelGGL((k_lin_small<3, false>), g, b, lin_small_lds(true, false), s, d, fuse);
+  else hipLaunchKernelGGL((k_lin_small<1, true>), g, b, lin_small_lds(false, true), s, d, fuse);
+}
+hipError_t lin_small_init_device() {   // per device, from gfbe_create (see kernels_init_device)
+  hipError_t e = hipSuccess;
+  auto set = [&](const void *k, size_t bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
+  set((const void *)k_lin_small<2, true>, lin_small_lds(true, true));
+  set((const void *)k_lin_small<0, true>, lin_small_lds(true, true));
+  set((const void *)k_lin_small<0, false>, lin_small_lds(true, false));
+  set((const void *)k_lin_small<3, true>, lin_small_lds(true, true));
+  set((const void *)k_lin_small<3, false>, lin_small_lds(true, false));
+  set((const void *)k_lin_small<1, true>, lin_small_lds(false, true));
+  return e;
 }
 void launch_pair_schur_marg(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles == 0) { launch_pair(d, 1, s); return; }
