@@ -348,6 +348,8 @@ hipError_t marg_init_device();      // same for k_marg
 hipError_t gnss_init_device();      // same for k_gnss
 hipError_t dense_init_device();     // same for k_prior_tp
 hipError_t lin_small_init_device(); // same for k_lin_small
+void launch_ingest_small(const void *src_host, void *dst, size_t bytes, void *z0, size_t z0_bytes, void *z1, size_t z1_bytes,
+                         const double *jsrc_host, double *jdst, int nrow, size_t row, size_t jstride, hipStream_t s);
 void launch_prep(const BatchDev &d, hipStream_t s);
 void launch_upload_small(const BatchDev &d, int with_expand, hipStream_t s);   // small batches: k_expand + k_prep + k_prep_prior + k_asm_table in one launch
 void launch_expand(const BatchDev &d, hipStream_t s);                 // host upload: fobs -> lm_obs / lm_rec

@@ -668,7 +668,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   // windows, and table-fed batches slower than host-fed ones
   // (a small table-fed batch — the one-robot frame loop — stays on the main stream behind its table operations: nothing is queued there
   //  to wait for, and a hop across streams costs ~15 us of the frame)
-  hipStream_t us = (tabs && B < DENSE_SPLIT_MIN_B) ? c->stream : c->copy;
+  // (round 5: every batch below 32 windows — its upload is two kernels now (k_ingest_small reads the pinned staging buffer itself), ~40 us
+  //  that would hide behind nothing, and the hop from the copy stream to the main stream cost 11 us of a single window's call)
+  hipStream_t us = B < DENSE_SPLIT_MIN_B ? c->stream : c->copy;
   if (tabs && us != c->stream && tabs->ev_ops) HIPCHK(c, hipStreamWaitEvent(us, tabs->ev_ops, 0));
   b->slot_of.resize(B);
   b->L.resize(B);
@@ -1116,6 +1118,15 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   }
   const double T3 = now();
   // ---- enqueue: clear what must start as zero, ONE host-to-device copy, then the preparation kernels
+  // (a small batch: all of it in one kernel that reads the pinned staging buffer across PCIe itself — k_ingest_small)
+  const bool ingest = B < DENSE_SPLIT_MIN_B && !poison_env && (b->up_end % 16) == 0 && ((b->zero_end - b->up_end) % 16) == 0;
+  if (ingest) {
+    const bool clearH = d.asm_tab == c->asm_compact;
+    launch_ingest_small(b->up_h, b->slab, b->up_end, b->slab + b->up_end, b->zero_end > b->up_end ? b->zero_end - b->up_end : 0,
+                        d.H, clearH ? sizeof(double) * (size_t)B * ND * ND : 0,
+                        pj_row > 0 ? (const double *)h_pJ0 : nullptr, d.prior_J0, pj_row > 0 ? B : 0, pj_row,
+                        (size_t)ND * ND, us);
+  } else {
   if (b->zero_end > b->up_end) HIPCHK(c, hipMemsetAsync(b->slab + b->up_end, 0, b->zero_end - b->up_end, us));
   // (test hook, tests/test_gpu_uncleared.py: the part of the slab that is NOT cleared filled with NaN bit patterns — a kernel that
   //  uses what nobody wrote poisons its results instead of finding the previous batch's numbers there)
@@ -1130,6 +1141,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   HIPCHK(c, hipMemcpyAsync(b->slab, b->up_h, b->up_end, hipMemcpyHostToDevice, us));
   if (pj_row > 0)
     HIPCHK(c, hipMemcpy2DAsync(d.prior_J0, sizeof(double) * ND * ND, d_pJ0c, sizeof(double) * pj_row, sizeof(double) * pj_row, B, hipMemcpyDeviceToDevice, us));
+  }
   if (tabs) {   // landmark arrays straight from the device-resident tables (layout table and slot map live in the tables' own scratch)
     int *dlay = tabs->d.layout + (size_t)tab0 * FT_LAY_STRIDE, *dslot = tabs->d.ids_scratch + (size_t)tab0 * tabs->d.F;
     // (the layout table travels from a pinned buffer the batch keeps: nobody waits for the copy)
@@ -1496,9 +1508,20 @@ static gfbe_status fetch_one(gfbe_ctx *c, gfbe_batch *b) {
   hipStream_t ds = d.B < DENSE_SPLIT_MIN_B ? c->stream : c->dl;
   HIPCHK(c, hipStreamWaitEvent(ds, b->ev_up, 0));
   HIPCHK(c, hipStreamWaitEvent(ds, b->ev_done, 0));
-  launch_gather(d, b->last_flag, ds);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(b->dl_h, d.dl_fix, b->dl_bytes, hipMemcpyDeviceToHost, ds));
+  if (d.B < DENSE_SPLIT_MIN_B) {
+    // (a small batch: k_gather writes the pinned staging buffer itself — the three result arrays keep their offsets —, no copy command
+    //  and no idle stream between the kernel and the copy: ~12 us of a single window's call)
+    BatchDev dg = d;
+    dg.dl_fix = (double *)b->dl_h;
+    dg.dl_feat = (double *)(b->dl_h + ((const char *)d.dl_feat - (const char *)d.dl_fix));
+    dg.dl_J0 = (double *)(b->dl_h + ((const char *)d.dl_J0 - (const char *)d.dl_fix));
+    launch_gather(dg, b->last_flag, ds);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    launch_gather(d, b->last_flag, ds);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(b->dl_h, d.dl_fix, b->dl_bytes, hipMemcpyDeviceToHost, ds));
+  }
   HIPCHK(c, hipEventRecord(b->ev_dl, ds));
   return GFBE_OK;
 }

@@ -3239,6 +3239,28 @@ __global__ __launch_bounds__(256) void k_upload_small(BatchDev d, int n_expand) 
   bx -= nf;
   if (bx < np) prep_prior_body(d, bx / PREP_PRIOR_WGS, bx % PREP_PRIOR_WGS);
 }
+// Small batches (round 5): what an upload enqueued BEFORE k_upload_small as four commands of the copy path — two clears, the host-to-device
+// copy of the staged upload region, the spread of the priors' compact J0 rows — in one kernel that READS THE PINNED HOST BUFFER itself
+// (444 KB per 2k-landmark window across PCIe by 128 workgroups) and writes the slab: between a copy command and a kernel the stream
+// idles ~9 us, between two kernels nothing (gpurun_out timeline of gfbe_solve_window: 83 us before the first kernel of the solve,
+// 15 of them the copy itself). src / dst: the staged region (16-byte units); z0 / z1: the ranges to clear; J0 rows: `nrow` rows of
+// `row` doubles at `jsrc` (inside the HOST buffer) to a stride of `jstride` doubles at `jdst`.
+enum { INGEST_WGS = 128 };
+__global__ __launch_bounds__(256) void k_ingest_small(const uint4 *src, uint4 *dst, size_t n16, uint4 *z0, size_t z0n16, uint4 *z1, size_t z1n16,
+                                                      const double *jsrc, double *jdst, int nrow, size_t row, size_t jstride) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+  for (size_t i = t; i < n16; i += nt) dst[i] = src[i];
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = t; i < z0n16; i += nt) z0[i] = z;
+  for (size_t i = t; i < z1n16; i += nt) z1[i] = z;
+  for (int r = 0; r < nrow; r++)
+    for (size_t i = t; i < row; i += nt) jdst[(size_t)r * jstride + i] = jsrc[(size_t)r * row + i];
+}
+void launch_ingest_small(const void *src_host, void *dst, size_t bytes, void *z0, size_t z0_bytes, void *z1, size_t z1_bytes,
+                         const double *jsrc_host, double *jdst, int nrow, size_t row, size_t jstride, hipStream_t s) {
+  hipLaunchKernelGGL(k_ingest_small, dim3(INGEST_WGS), dim3(256), 0, s, (const uint4 *)src_host, (uint4 *)dst, (bytes + 15) / 16,
+                     (uint4 *)z0, z0_bytes / 16, (uint4 *)z1, z1_bytes / 16, jsrc_host, jdst, nrow, row, jstride);
+}
 void launch_upload_small(const BatchDev &d, int with_expand, hipStream_t s) {
   const int n_expand = (with_expand && d.max_tiles > 0) ? (d.max_tiles * LM_TILE + 255) / 256 : 0;
   const int total = d.B * (n_expand + PREP_FACT_WGS + PREP_PRIOR_WGS);
