@@ -32,18 +32,6 @@ __device__ __forceinline__ double block_sum(double v, double *scratch /*>=16*/) 
   if (threadIdx.x == 0) for (int i = 0; i < (int)((blockDim.x + 63) >> 6); i++) r += scratch[i];
   return r;
 }
-// The same with the caller's own thread numbering (k_solve_chain deals its roles to the waves by the SIMD they run on: `t` is the
-// thread index after that permutation of the waves; the partial sums are added in the order of the ROLES, whatever wave runs them).
-__device__ __forceinline__ double block_sum_t(double v, double *scratch /*>=16*/, int t) {
-  v = wave_sum(v);
-  const int lane = t & 63, wid = t >> 6;
-  __syncthreads();
-  if (lane == 0) scratch[wid] = v;
-  __syncthreads();
-  double r = 0.0;
-  if (t == 0) for (int i = 0; i < (int)((blockDim.x + 63) >> 6); i++) r += scratch[i];
-  return r;
-}
 __device__ __forceinline__ double block_max(double v, double *scratch) {
   v = wave_max(v);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -71,25 +59,6 @@ __device__ __forceinline__ void block_reduce_multi(const double (&v)[NQ], unsign
   __syncthreads();
   if (threadIdx.x < NQ) {
     const int q = threadIdx.x;
-    double r = 0.0;
-    for (int i = 0; i < nw; i++) r = ((maxmask >> q) & 1) ? fmax(r, scratch[q * 16 + i]) : r + scratch[q * 16 + i];
-    scratch[16 * NQ + q] = r;
-  }
-  __syncthreads();
-}
-
-template <int NQ>
-__device__ __forceinline__ void block_reduce_multi_t(const double (&v)[NQ], unsigned maxmask, double *scratch, int t) {
-  const int lane = t & 63, wid = t >> 6, nw = (blockDim.x + 63) >> 6;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NQ; q++) {
-    const double r = ((maxmask >> q) & 1) ? wave_max(v[q]) : wave_sum(v[q]);
-    if (lane == 0) scratch[q * 16 + wid] = r;
-  }
-  __syncthreads();
-  if (t < NQ) {
-    const int q = t;
     double r = 0.0;
     for (int i = 0; i < nw; i++) r = ((maxmask >> q) & 1) ? fmax(r, scratch[q * 16 + i]) : r + scratch[q * 16 + i];
     scratch[16 * NQ + q] = r;

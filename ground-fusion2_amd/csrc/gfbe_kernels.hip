@@ -269,11 +269,13 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
 // MODE 0: linearise at the current point; MODE 1: candidate cost; MODE 2: marginalisation set
 // (landmarks with start_frame 0, estimator.cpp:3498-3531) at the re-anchored state.
 // =============================================================================================
-// KS > 1 (small batches, k_lin_small): the observation steps of a tile are independent pose pairs — their partials, their
-// H_pl blocks — except for three per-landmark running sums (Hll, gl, hC) and the cost. KS workgroups share a tile, workgroup
-// kq takes the steps k = kq, kq + KS, ..., every step's CONTRIBUTION to the running sums goes to a scratch array, and the
-// workgroup that arrives last (an atomic counter per tile; nobody waits for anybody) adds them up in step order: the same
-// additions in the same order as the one-wave loop of the throughput path, so the results stay bit-identical to it.
+// KS > 1 (small batches): the observation steps of a tile are independent pose pairs — their partials, their
+// H_pl blocks — except for three per-landmark running sums (Hll, gl, hC) and the cost. KS shares split a tile — waves of ONE workgroup
+// in k_lin_small (WS below, round 5), workgroups in k_vis_split (the launch sequence of the profiling mode) —, share
+// kq takes the steps k = kq, kq + KS, ..., every step's CONTRIBUTION to the running sums goes to a scratch array, and the first wave
+// behind the workgroup's barrier (the workgroup that arrives last at an atomic counter per tile in the other form; nobody waits for
+// anybody there) adds them up in step order: the same additions in the same order as the one-wave loop of the throughput path, so
+// the results stay bit-identical to it.
 #ifndef GFBE_LIN_STAMP
 #define GFBE_LIN_STAMP 0
 #endif
