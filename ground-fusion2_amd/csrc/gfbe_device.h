@@ -213,6 +213,8 @@ struct WinCtl {
   double cost_history[16];
   unsigned char accepted[16];
   long long t_start, t_solved, t_marg;   // device wall clock (100 MHz ticks): k_reset, k_reanchor, end of the marginalisation (0: none)
+  double sw_mu[2];                       // BatchDev::spec: the mu the weights lm_sw of set 0 / 1 were formed with (k_schur uses them when it is the
+                                         // window's mu — an accepted step's new mu is known to the pass that linearises its candidate — and forms them itself otherwise)
 };
 
 // ---- batch: all device pointers ----------------------------------------------------------------
@@ -268,7 +270,7 @@ struct BatchDev {
   // step is accepted, and the next iteration starts at the Schur elimination (lin_view: the set WinCtl::lb names). A rejected step
   // leaves the current set alone, exactly what DoglegStrategy's reuse needs.
   int spec;
-  double *lm_Hll2, *lm_gl2, *lm_hC2, *lm_hP2, *vis_part2, *imu_part2, *wheel_part2, *plane_part2, *anchor_part2, *prior_g2;
+  double *lm_Hll2, *lm_gl2, *lm_hC2, *lm_hP2, *lm_sw2, *vis_part2, *imu_part2, *wheel_part2, *plane_part2, *anchor_part2, *prior_g2;
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
   int sharded;                      // an all-reduce hook is installed (gfbe_set_allreduce): the launch sequence with the exchange blocks, also for world == 1

@@ -72,7 +72,7 @@ __device__ __forceinline__ void block_reduce_multi(const double (&v)[NQ], unsign
 __device__ __forceinline__ BatchDev lin_view(const BatchDev &d, const int lb) {
   BatchDev v = d;
   if (d.spec && lb) {
-    v.lm_Hll = d.lm_Hll2; v.lm_gl = d.lm_gl2; v.lm_hC = d.lm_hC2; v.lm_hP = d.lm_hP2; v.vis_part = d.vis_part2;
+    v.lm_Hll = d.lm_Hll2; v.lm_gl = d.lm_gl2; v.lm_hC = d.lm_hC2; v.lm_hP = d.lm_hP2; v.lm_sw = d.lm_sw2; v.vis_part = d.vis_part2;
     v.imu_part = d.imu_part2; v.wheel_part = d.wheel_part2; v.plane_part = d.plane_part2; v.anchor_part = d.anchor_part2; v.prior_g = d.prior_g2;
   }
   return v;
@@ -81,6 +81,8 @@ __device__ __forceinline__ BatchDev lin_view(const BatchDev &d, const int lb) {
 // landmark sharding: tile t of a window is evaluated by rank t % world (gfbe_set_allreduce)
 #define TILE_OWNED(d, tile) ((d).world == 1 || (tile) % (d).world == (d).rank)
 
+// DoglegStrategy::StepAccepted's mu (k_accept; the pass that linearises a candidate forms the landmark weights with it)
+__device__ __forceinline__ double mu_after_accept(const double mu) { return fmax(GF_MIN_MU, 2.0 * mu / GF_MU_INC); }
 __device__ __forceinline__ double clamp_diag(double x) { return fmin(fmax(x, GF_MIN_DIAG), GF_MAX_DIAG); }
 
 // ---- Landmark rows of the normal equations as k_vis<0, false> leaves them (round 4; a batch with constant extrinsic and td):

@@ -860,12 +860,12 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(plane_part, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
     AL(prior_g, (size_t)B * (ND + 2));
     if (d.spec) {   // the second set (BatchDev::spec), cleared like the first
-      AL(lm_Hll2, TL); AL(lm_gl2, TL); AL(lm_hC2, (size_t)HC * TL);
+      AL(lm_Hll2, TL); AL(lm_gl2, TL); AL(lm_hC2, (size_t)HC * TL); AL(lm_sw2, TL);
       AL(imu_part2, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part2, (size_t)B * MAX_WHEEL * WHEEL_PART);
       AL(plane_part2, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part2, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
       AL(prior_g2, (size_t)B * (ND + 2));
     } else {
-      d.lm_Hll2 = d.lm_gl2 = d.lm_hC2 = d.imu_part2 = d.wheel_part2 = d.plane_part2 = d.anchor_part2 = d.prior_g2 = nullptr;
+      d.lm_Hll2 = d.lm_gl2 = d.lm_hC2 = d.lm_sw2 = d.imu_part2 = d.wheel_part2 = d.plane_part2 = d.anchor_part2 = d.prior_g2 = nullptr;
     }
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
     AL(tile_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) : 1);

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_reset(BatchDev d) {
       c.G2 = c.N2 = c.gy = c.vHv = c.vHy = c.yHy = c.alpha = c.grad_max = 0;
       c.c1 = c.c2 = c.step_norm = c.model_change = 0; c.initial_cost = 0;
       for (int i = 0; i < 16; i++) { c.cost_history[i] = 0; c.accepted[i] = 0; }
-      c.t_start = (long long)wall_clock64(); c.t_solved = 0; c.t_marg = 0; c.marg_ran = 0; c.lb = 0;
+      c.t_start = (long long)wall_clock64(); c.t_solved = 0; c.t_marg = 0; c.marg_ran = 0; c.lb = 0; c.sw_mu[0] = -1.0; c.sw_mu[1] = -1.0;
       d.ctl[w] = c;
     }
   }
@@ -776,17 +776,22 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
 #pragma unroll
     for (int q = 0; q < 3; q++) { hC[q] = Dsum[q]; hC[3 + q] = yx[q]; }
   }
-  if (MODE == 0 && !SPEC && valid) {      // (SPEC: a batch with the second set forms sqrt(w_l) in k_schur — mu changes when the step is accepted)
+  // (one wave gets here for tile 0: the only one of a k_vis launch, the first of a k_lin_small tile workgroup)
+  if (MODE == 0 && d.spec && tile == 0 && lane == 0) d.ctl[w].sw_mu[SPEC ? 1 - c.lb : c.lb] = SPEC ? mu_after_accept(c.mu) : c.mu;
+  if (MODE == 0 && valid) {
     // the landmark's weight in the Schur term, w_l = s_l^2 / (s_l^2 Hll + mu clamp(s_l^2 Hll)) (Jacobi-scaled, mu-regularised), once
     // per landmark here instead of once per wave that stages it in k_schur; the Jacobi scale s_l is fixed at iteration 0
     // (TrustRegionMinimizer::IterationZero). A constant landmark has none.
-    const bool first = c.iter == 0;
+    // (SPEC: with the mu an accepted step leaves — this set is current only then; c.sw_mu records what the weights of a set were formed
+    //  with, and k_schur forms them itself when that is not the window's mu: after TrustRegionMinimizer::HandleInvalidStep)
+    const bool first = !SPEC && c.iter == 0;
+    const double mu_w = SPEC ? mu_after_accept(c.mu) : c.mu;
     double sl = 1.0, sw = 0.0;
     if (m > 0 && !is_const) {
       sl = first ? (d.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(Hll)) : 1.0) : d.lm_sl[slot];      // (loaded here, not ahead of the loop: two registers over
                                                                                                  //  the 128 that four waves per SIMD allow cost the kernel 6 %)
       const double hs2 = sl * sl * Hll;
-      sw = sqrt(sl * sl / (hs2 + c.mu * clamp_diag(hs2)));
+      sw = sqrt(sl * sl / (hs2 + mu_w * clamp_diag(hs2)));
     }
     if (first) d.lm_sl[slot] = sl;
     d.lm_sw[slot] = sw;
@@ -1617,7 +1622,9 @@ __device__ __forceinline__ void schur_body(const BatchDev &d, const int marg, co
   // are issued together (rows beyond a track's length are zero in memory) and the NEXT tile's loads are
   // in flight while the matrix cores work on the current one.
   const int l = t & 63, part = t >> 6;
-  const bool spec_sw = !marg && d.spec;         // sqrt(w_l) from Hll, s_l and the window's mu instead of lm_sw (BatchDev::spec)
+  // sqrt(w_l) from Hll, s_l and the window's mu instead of lm_sw: a batch with the second set (BatchDev::spec) whose current set's weights
+  // were formed with another mu (WinCtl::sw_mu)
+  const bool spec_sw = !marg && d.spec && c.sw_mu[c.lb] != c.mu;
   const double spec_mu = spec_sw ? c.mu : 0.0;
   const bool hc_full = marg || d.vis_full;      // the linearisation of a batch with constant extrinsic / td everywhere leaves rows 6..12 of lm_hC alone
   // What a thread holds of one landmark tile between its loads and its staging. DEEP (throughput batches): the tiles t + 1 AND t + 2
@@ -3111,7 +3118,7 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
     cg.cost_history[it] = cand;
     if (quality < 0.25) c.radius *= 0.5;
     if (quality > 0.75) c.radius = fmax(c.radius, 3.0 * c.step_norm);
-    c.mu = fmax(GF_MIN_MU, 2.0 * c.mu / GF_MU_INC);
+    c.mu = mu_after_accept(c.mu);
     c.reuse = 0;
     if (cslot == 2) c.lb = 1 - c.lb;
   } else {
