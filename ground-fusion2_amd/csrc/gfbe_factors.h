@@ -516,7 +516,7 @@ GF_HD void imu_raw(const gfbe_imu_preint *pre, double g_norm, const double *pose
 // Wheel factor, un-whitened: raw[6], Jraw[6][22] (caller zero-fills), columns pose_i(6) pose_j(6)
 // ex_wheel(6) sx sy sw td_wheel.
 // ---------------------------------------------------------------------------------------------
-// part / nparts (as imu_raw): the Jacobian's work is eight items dealt over `nparts` callers (item j belongs to part j % nparts; part 0
+// part / nparts (as imu_raw): the Jacobian's work is eight items (numbered 0-4, 6-8) dealt over `nparts` callers (item j belongs to part j % nparts; part 0
 // also writes the residual) — every caller forms the residual, each item its own intermediates: the same expressions whatever the split.
 GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const double *pose_j, const double *exw,
                      double sx, double sy, double sw, double td, double *raw, double *Jraw, size_t es = 1, int part = 0, int nparts = 1) {
@@ -594,7 +594,7 @@ GF_HD void wheel_raw(const gfbe_wheel_preint *pre, const double *pose_i, const d
     put3(Jraw, 22, 0, 3, madd(mul(RRT, mul(Ri, hat(tio))), tmul(rio, hat(tmv(Ri, world_d)))), es);                  // :123
     put3(Jraw, 22, 0, 6, RRT, es);                                                                                  // :150
   }
-  if (GF_WHEEL_ITEM(5)) {      // the sx, sy columns
+  if (GF_WHEEL_ITEM(8)) {      // the sx, sy columns (item 8, not 5: with four callers it goes with the lightest share — measured, profiles/r5_lin_small_phases.txt)
     const vec3 fv = mv(sv, scl(dtd, lin_vel));
     const mat3 Efv = qrot(so3exp(fv));
     const mat3 I1 = diagm(1.0, 0.0, 0.0), I2 = diagm(0.0, 1.0, 0.0);

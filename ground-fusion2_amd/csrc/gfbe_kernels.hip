@@ -1153,30 +1153,38 @@ __device__ __forceinline__ void dense_body(const BatchDev &d, int mode, int debu
       constexpr int PBUF = PRIOR_CHUNK;
       const int ld = n | 1, R = min(PBUF / ld, n);      // rows per chunk (n <= 246: at least 16)
       double gk = 0.0;
+      // (the NEXT chunk's entries are requested — sixteen per thread: PBUF <= 16 x 256 — before the current one is used: its load round
+      //  trip hides behind the two passes)
+      constexpr int LU = 16;
+      static_assert(PRIOR_CHUNK <= LU * 256, "a thread's share of a chunk");
+      double nx[LU];
+      {
+        const int tot0 = min(R, n) * n;
+#pragma unroll
+        for (int u = 0; u < LU; u++) nx[u] = (t + u * nthr < tot0) ? J0[t + u * nthr] : 0.0;
+      }
       for (int i0 = 0; i0 < n; i0 += R) {
         const int rows = min(R, n - i0);
-        const double *src = J0 + (size_t)i0 * n;
-        // (the chunk's loads in flight together — eight per thread and pass —, the row / column of an entry carried along instead of divided out)
-        {
-          constexpr int LU = 8;
+        {   // the chunk the registers hold goes to LDS: the row / column of an entry carried along instead of divided out
           const int tot = rows * n, dr = nthr / n, dc = nthr - dr * n;      // e += nthr: (row, column) += (dr, dc), with carry
           int r = t / n, c = t - r * n;
-          for (int e = t; e < tot; e += LU * nthr) {
-            double v[LU];
 #pragma unroll
-            for (int u = 0; u < LU; u++) v[u] = src[min(e + u * nthr, tot - 1)];
-#pragma unroll
-            for (int u = 0; u < LU; u++) {
-              if (e + u * nthr < tot) pbuf[r * ld + c] = v[u];
-              r += dr; c += dc;
-              if (c >= n) { c -= n; r++; }
-            }
+          for (int u = 0; u < LU; u++) {
+            if (t + u * nthr < tot) pbuf[r * ld + c] = nx[u];
+            r += dr; c += dc;
+            if (c >= n) { c -= n; r++; }
           }
         }
         __syncthreads();
 #if GFBE_LIN_STAMP
         if (dsb_ >= 0) dst_[i0 == 0 ? 20 : 23] = wall_clock64();
 #endif
+        if (i0 + rows < n) {
+          const int tot1 = min(R, n - i0 - rows) * n;
+          const double *src1 = J0 + (size_t)(i0 + rows) * n;
+#pragma unroll
+          for (int u = 0; u < LU; u++) nx[u] = (t + u * nthr < tot1) ? src1[t + u * nthr] : 0.0;
+        }
         if (t >= i0 && t < i0 + rows) {
           double s = r0[t];
           const double *row = pbuf + (t - i0) * ld;
@@ -2588,7 +2596,10 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(BatchDev d0, int nH) {
 // 16 workgroups of 256 threads per window took 313 us per launch with the SIMDs half empty — the kernel was bound by the
 // dispatch and the table staging of its 16384 short workgroups; 2 workgroups 200 us, one 192 us; fused with k_visblock the
 // 43 KB block per window neither goes to HBM nor comes back.)
-__global__ __launch_bounds__(VB_GROUP, 4) void k_visasm(BatchDev d0) {
+#ifndef GFBE_VISASM_WAVES
+#define GFBE_VISASM_WAVES 4      // waves per SIMD the register allocation of k_visasm aims at
+#endif
+__global__ __launch_bounds__(VB_GROUP, GFBE_VISASM_WAVES) void k_visasm(BatchDev d0) {
   const int w = blockIdx.x;
   const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   const WinCtl &c = d.ctl[w];
