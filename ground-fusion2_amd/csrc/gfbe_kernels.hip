@@ -3020,9 +3020,21 @@ __device__ __forceinline__ void block_candidate(const BatchDev &d, const int w, 
 #pragma unroll
   for (int k = 0; k < MAXS; k++) if (k < q.gs) Y[q.am + k] = Yl[k];
 }
+#ifndef GFBE_LMS_STAMP
+#define GFBE_LMS_STAMP 0      // diagnostics build: phase stamps of k_lm_step_fused (tools/diag_scripts/lms_stamps.py)
+#endif
 __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
   static_assert(GFBE_BLK_COUNT <= 128 && GFBE_BLK_RCV_DT0 <= 64, "two blocks per lane, the second one a scalar block");
   const int w = blockIdx.x, tile = blockIdx.y;   // tile-major dispatch (longest tracks first)
+#if GFBE_LMS_STAMP
+  unsigned long long *ms = (unsigned long long *)(d0.timing + (size_t)d0.B * 32);
+#define MSTAMP_T(i) do { if (w == 0 && tile == 0 && threadIdx.x == 0) ms[i] = wall_clock64(); } while (0)
+#define MSTAMP_L(i) do { if (w == 0 && threadIdx.x == 0) ms[i] = wall_clock64(); } while (0)
+#else
+#define MSTAMP_T(i) do { } while (0)
+#define MSTAMP_L(i) do { } while (0)
+#endif
+  MSTAMP_T(0);
   const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
@@ -3037,12 +3049,16 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
       sv[a] = s * d.vp[(size_t)w * ND + a];
     }
     __syncthreads();
+    MSTAMP_T(1);
     __shared__ double fsteps[NF * LM_FS];
     const bool comp = !d.vis_full;      // (workgroup-uniform: the barrier below is safe)
     if (comp) { stage_frame_steps(d, c, w, t, sy, sv, fsteps); __syncthreads(); }
+    MSTAMP_T(2);
     lm_step_tile(d, ds, c, w, tile, t, sy, sv, comp ? fsteps : nullptr);
+    MSTAMP_T(3);
   }
-  // ---- preloads of the tail
+  // ---- preloads of the tail (behind the landmarks' work: requested in front of it — round 5, tools/diag_scripts/lms_stamps.py — their two
+  //      dependent levels delayed the tile's own loads, the counters being in order: 17.4 -> 18.7 us per launch)
   StepLocal lc;
   lc.done = c.done; lc.have_step = c.have_step; lc.reuse = c.reuse; lc.iter = c.iter; lc.termination = c.termination; lc.status = c.status;
   lc.invalid_steps = c.invalid_steps;
@@ -3054,9 +3070,12 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
   BlockPre q0, q1;
   block_preload<9>(d, ds, w, X, t, q0);
   block_preload<1>(d, ds, w, X, t + 64, q1);
+  MSTAMP_T(4);
   if (!arrive_last(d.win_cnt + 2 * w, gridDim.y, t)) return;
+  MSTAMP_L(5);
   // ---- k_step
   step_body(d, ds, lc, c, w, t);
+  MSTAMP_L(6);
   if (t == 0) {
     c.done = lc.done; c.have_step = lc.have_step; c.reuse = lc.reuse; c.iter = lc.iter; c.termination = lc.termination; c.status = lc.status;
     c.invalid_steps = lc.invalid_steps;
@@ -3076,7 +3095,11 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
   if (t < NF) sp_cand[t] = make_pose(Yl0);
   if (t == GFBE_BLK_EX_CAM) sp_cand[NF] = make_pose(Yl0);
   __syncthreads();
+  MSTAMP_L(7);
   pair_consts_from_staged(d.pc + ((size_t)w * 3 + (1 - cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
+  MSTAMP_L(8);
+#undef MSTAMP_T
+#undef MSTAMP_L
 }
 
 // =============================================================================================

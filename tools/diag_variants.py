@@ -39,6 +39,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "linstamp3_t256ks4": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=3", "-DGFBE_LIN_SMALL_THREADS=256", "-DGFBE_LIN_SMALL_KS=4"], "off"),
     "visasm6": (["-DGFBE_VISASM_WAVES=6"], "off"),
     "visasm5": (["-DGFBE_VISASM_WAVES=5"], "off"),
+    "lmsstamp": (["-DGFBE_LMS_STAMP=1"], "off"),
     "linstamp1": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=1"], "off"),
     "lin512": (["-DGFBE_LIN_SMALL_THREADS=512"], "off"),
     "lin1024": (["-DGFBE_LIN_SMALL_THREADS=1024"], "off"),
