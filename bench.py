@@ -491,7 +491,10 @@ def pmc_summary(windows_per_launch):
                 return res
             tot = 0.0
             for fn, key in ((tag + "_pmc_fetch.txt", "FETCH_SIZE"), (tag + "_pmc_write.txt", "WRITE_SIZE")):
-                b = [x for x in blocks(fn) if pat["k_vis"] in x["head"] and ("grid=(%d," % (64 * windows_per_launch)) in x["head"]][0]   # one part of the batch
+                cand = [x for x in blocks(fn) if pat["k_vis"] in x["head"] and ("grid=(%d," % (64 * windows_per_launch)) in x["head"]]   # one part of the batch
+                # (the first iteration's launches — k_vis<0, ., false> —, the ones `avg_launch_ms` times; the later iterations launch the same
+                #  evaluation at the candidate, k_vis<0, ., true>, with the landmark half of k_candidate at its head)
+                b = ([x for x in cand if "Lb0EEEv" in x["head"]] or cand)[0]
                 tot += b["c"][key] * 1024.0
             out["k_vis"] = {"traffic": tot}
             # the other kernels of a linearisation: FETCH_SIZE + WRITE_SIZE of their largest launch (one part of the batch, first iteration)
