@@ -270,7 +270,7 @@ struct BatchDev {
   // step is accepted, and the next iteration starts at the Schur elimination (lin_view: the set WinCtl::lb names). A rejected step
   // leaves the current set alone, exactly what DoglegStrategy's reuse needs.
   int spec;
-  double *lm_Hll2, *lm_gl2, *lm_hC2, *lm_hP2, *lm_sw2, *vis_part2, *imu_part2, *wheel_part2, *plane_part2, *anchor_part2, *prior_g2;
+  double *lm_Hll2, *lm_gl2, *lm_hC2, *lm_hP2, *lm_sw2, *vis_part2, *imu_part2, *wheel_part2, *plane_part2, *anchor_part2, *prior_g2, *lio_part2;
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
   int sharded;                      // an all-reduce hook is installed (gfbe_set_allreduce): the launch sequence with the exchange blocks, also for world == 1
@@ -366,7 +366,7 @@ void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse = 0);
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s, int spec = 0);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock = 0);   // with_visblock: k_schur_visblock_small
 void launch_visblock(const BatchDev &d, hipStream_t s);
-void launch_lio_window(const BatchDev &d, int mode, hipStream_t s);
+void launch_lio_window(const BatchDev &d, int mode, hipStream_t s, int spec = 0);
 void launch_assemble(const BatchDev &d, hipStream_t s);
 // the context's assembly tables (built once per context): full[ND (ND + 1) / 2] and compact[*n_compact], both ordered by the larger dim
 hipError_t asm_tables_build(int **full, int **compact, int *n_compact, hipStream_t s);

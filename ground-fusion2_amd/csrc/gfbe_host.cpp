@@ -805,9 +805,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
   if (diag_getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics build only: force the 20-column panel)
   // speculative linearisation (gfbe_options.speculative_linearization): batches whose candidate costs are all formed by the visual /
-  // dense-factor launches (no GNSS / LiDAR factors, no all-reduce hook) get a second set of the linearisation's outputs
-  d.spec = (c->opt.speculative_linearization && !c->allreduce && !any_gnss && tot_lio == 0 && max_tiles > 0 &&
-            (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 6) == 6)) ? 1 : 0;
+  // dense-factor / LiDAR launches (no GNSS factors, no all-reduce hook) get a second set of the linearisation's outputs
+  d.spec = (c->opt.speculative_linearization && !c->allreduce && !any_gnss && max_tiles > 0 &&
+            (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 2))) ? 1 : 0;
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
   const double T1 = now();
@@ -863,9 +863,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       AL(lm_Hll2, TL); AL(lm_gl2, TL); AL(lm_hC2, (size_t)HC * TL); AL(lm_sw2, TL);
       AL(imu_part2, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part2, (size_t)B * MAX_WHEEL * WHEEL_PART);
       AL(plane_part2, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part2, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
-      AL(prior_g2, (size_t)B * (ND + 2));
+      AL(prior_g2, (size_t)B * (ND + 2)); AL(lio_part2, (size_t)B * LIOW_WGS * LIOW_PART);
     } else {
-      d.lm_Hll2 = d.lm_gl2 = d.lm_hC2 = d.lm_sw2 = d.imu_part2 = d.wheel_part2 = d.plane_part2 = d.anchor_part2 = d.prior_g2 = nullptr;
+      d.lm_Hll2 = d.lm_gl2 = d.lm_hC2 = d.lm_sw2 = d.imu_part2 = d.wheel_part2 = d.plane_part2 = d.anchor_part2 = d.prior_g2 = d.lio_part2 = nullptr;
     }
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
     AL(tile_cnt, B < DENSE_SPLIT_MIN_B ? (size_t)B * std::max(max_tiles, 1) : 1);
@@ -1336,7 +1336,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
     { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
     if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
   }
-  if (d.tot_lio > 0) { Timed t(c, "k_lio_window", 0); launch_lio_window(d, 0, ln.s); }
+  if (d.tot_lio > 0 && !have_lin) { Timed t(c, "k_lio_window", 0); launch_lio_window(d, 0, ln.s); }
   const int fuse = small_fuse(c, d);
   { Timed t(c, first ? "k_schur_iter0" : "k_schur", 0); launch_schur(d, 0, ln.s, fuse & 1); }
   if (d.vis_Hs && !(fuse & 1)) { Timed t(c, first ? "k_visblock_iter0" : "k_visblock", 0); launch_visblock(d, ln.s); }   // (throughput batches: inside k_visasm, below)
@@ -1378,7 +1378,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
   // speculative linearisation (BatchDev::spec): every candidate pass but the last linearises at the candidate, into the second set of
   // outputs; an accepted step makes that set the current one and a rejected one keeps the old linearisation (DoglegStrategy's reuse)
   // — either way the next iteration needs no linearisation launch.
-  const bool spec = d.spec && (d.B >= DENSE_SPLIT_MIN_B || (small_fuse(c, d) & 6) == 6);      // (small batches: on the fused launch sequence only)
+  const bool spec = d.spec && (d.B >= DENSE_SPLIT_MIN_B || (small_fuse(c, d) & 2));      // (small batches: on the fused launch sequence only)
   for (int it = 0; it < iters; it++) {
     enqueue_linearize(c, b, ln, it == 0, spec && it > 0);
     const int fuse = small_fuse(c, d);
@@ -1398,7 +1398,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     if (small) launch_lin_small(d, lin_cand ? 3 : 1, ln.s, fuse);
     else if (lin_cand) { Timed t(c, "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s, 0, 1); }
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
-    if (d.tot_lio > 0) { Timed t(c, "k_lio_window_cost", 0); launch_lio_window(d, 1, ln.s); }
+    if (d.tot_lio > 0) { Timed t(c, lin_cand ? "k_lio_window" : "k_lio_window_cost", 0); launch_lio_window(d, lin_cand ? 0 : 1, ln.s, lin_cand); }
     if (d.any_gnss) { Timed t(c, "k_gnss_cost", 0); launch_gnss(d, 1, ln.s); }
     if (!small && !overlap) { Timed t(c, lin_cand ? "k_dense" : "k_dense_cost", 0); launch_dense_factors(d, lin_cand ? 0 : 1, 0, ln.s, lin_cand); }
     else if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);
@@ -1407,7 +1407,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       launch_xchg_cand(d, ln.s);
       run_allreduce(c, d.xc, (int64_t)d.B * d.world * XCHG, ln.s);
     }
-    if (!(fuse & 4)) { Timed t(c, "k_accept", 0); launch_accept(d, ln.s, (!small && lin_cand) ? 1 : 0); }
+    if (!(fuse & 4)) { Timed t(c, "k_accept", 0); launch_accept(d, ln.s, lin_cand ? 1 : 0); }
   }
   { Timed t(c, "k_reanchor", 0); launch_reanchor(d, ln.s); }
   if (margin_flag != GFBE_MARGIN_NONE) {

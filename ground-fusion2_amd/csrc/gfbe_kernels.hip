@@ -837,15 +837,17 @@ __global__ __launch_bounds__(LM_TILE, 1) void k_vis_split(BatchDev d, int write_
   vis_body<MODE, FULL, LIN_SMALL_KS>(d, write_records, blockIdx.x, blockIdx.y / LIN_SMALL_KS, blockIdx.y % LIN_SMALL_KS);
 }
 
+// spec (MODE 0; BatchDev::spec): the linearisation at the candidate in the place of the cost pass, into the set of outputs that is not current
 template <int MODE>
-__global__ __launch_bounds__(256) void k_lio_window(BatchDev d) {
+__global__ __launch_bounds__(256) void k_lio_window(BatchDev d0, int spec) {
   const int w = blockIdx.y, wg = blockIdx.x, t = threadIdx.x;
-  const WinDesc &ds = d.desc[w];
+  const WinDesc &ds = d0.desc[w];
   if (ds.lio_n == 0) return;
-  const WinCtl &c = d.ctl[w];
-  if (MODE == 0 && (c.done || c.reuse)) return;
-  if (MODE == 1 && (c.done || !c.have_step)) return;
-  const int buf = (MODE == 1) ? 1 - c.cur : c.cur;
+  const WinCtl &c = d0.ctl[w];
+  if (MODE == 0 && !spec && (c.done || c.reuse)) return;
+  if ((MODE == 1 || spec) && (c.done || !c.have_step)) return;
+  const BatchDev d = MODE == 0 ? lin_view(d0, spec ? 1 - c.lb : c.lb) : d0;
+  const int buf = (MODE == 1 || spec) ? 1 - c.cur : c.cur;
   const double *X = d.x + ((size_t)w * 2 + buf) * NA + A_POSE(ds.lio_frame);
   const vec3 tw = ld3(X);
   const mat3 R = qrot(ldq(X + 3));
@@ -3124,7 +3126,7 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
   if (lane < ds.n_imu) cand += d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - cslot];
   if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - cslot];
   if (lane == 32) { cand += d.prior_g[(size_t)w * (ND + 2) + ND + 2 - cslot]; d2 += d.dense_cand[(size_t)w * 4 + 1]; n2 += d.dense_cand[(size_t)w * 4 + 2]; }
-  if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 28];
+  if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 29 - cslot];      // (28: the cost pass's slot; 27: a linearisation's)
   if (lane >= 48 && lane - 48 < ds.n_plane) cand += d.plane_part[((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - cslot];
   if (lane == 58 && ds.use_anchor) cand += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - cslot];
   if (lane == 59 && ds.gnss_factors) cand += d.gnss_cost[(size_t)w * 2 + 1];
@@ -3447,9 +3449,9 @@ void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_x
 void launch_lam_mask(const BatchDev &d, hipStream_t s) {
   if (d.max_tiles > 0) hipLaunchKernelGGL(k_lam_mask, dim3(d.max_tiles, d.B), dim3(LM_TILE), 0, s, d);
 }
-void launch_lio_window(const BatchDev &d, int mode, hipStream_t s) {
-  if (mode == 0) hipLaunchKernelGGL(k_lio_window<0>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
-  else hipLaunchKernelGGL(k_lio_window<1>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d);
+void launch_lio_window(const BatchDev &d, int mode, hipStream_t s, int spec) {
+  if (mode == 0) hipLaunchKernelGGL(k_lio_window<0>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d, spec);
+  else hipLaunchKernelGGL(k_lio_window<1>, dim3(LIOW_WGS, d.B), dim3(256), 0, s, d, 0);
 }
 void launch_visblock(const BatchDev &d, hipStream_t s) {       // (throughput batches: part of k_visasm, launch_assemble)
   if (d.vis_Hs) hipLaunchKernelGGL(k_visblock_small, dim3(d.vis_full ? (int)VS_BLOCKS : (int)NF, d.B), dim3(VB_GROUP), 0, s, d);

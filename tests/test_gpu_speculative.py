@@ -85,3 +85,19 @@ def test_throughput_kernel_set_is_unchanged_bit_for_bit(oracle):
             got.append(be.solve_batch(snaps, abi.MARGIN_OLD))
             be.close()
         assert all(_identical(a, b) for a, b in zip(*got))
+
+
+def test_lidar_windows_are_unchanged_bit_for_bit(oracle):
+    """Joint LIO + VIO windows (BASELINE configs[4]): the LiDAR factors' candidate cost is a launch of its own — k_lio_window linearises at the
+    candidate like the visual and the dense factors. One window (the accept is a launch of its own there) and a batch of 33."""
+    scn, w1 = window_with_prior(oracle, 95, 400)
+    w1 = dict(w1, lio=synth.lidar_block(scn, 1, n=1500, seed=3, outliers=0.05))
+    scn2 = synth.Scenario(seed=96, n_landmarks=300, use_wheel=True)
+    w2 = dict(scn2.window(0), lio=synth.lidar_block(scn2, 0, n=5000, seed=6, frame=7, huber_delta=0.0))
+    plain = scn2.window(0)
+    got = []
+    for spec in (0, 1):
+        be = _backend(spec)
+        got.append([be.solve(w1, abi.MARGIN_OLD), be.solve(w2, abi.MARGIN_SECOND_NEW)] + be.solve_batch([w1, plain, w2] * 11, abi.MARGIN_OLD))
+        be.close()
+    assert all(_identical(a, b) for a, b in zip(*got))
