@@ -74,7 +74,7 @@ enum {
   ANCHOR_PART = 6 * 6 + 6 + 2,
   MAX_BATCH_PARTS = 16,       // upper bound of gfbe_options.split_batch (every part beyond the first owns a pair of streams)
   BATCH_SPLIT_MIN_B = 128,    // batches at least this big are uploaded as two halves solved side by side (gfbe_options.split_batch)
-  LIN_SMALL_KS = GFBE_LIN_SMALL_KS,   // k_lin_small: workgroups per landmark tile (observation steps dealt round-robin)
+  LIN_SMALL_KS = GFBE_LIN_SMALL_KS,   // shares of a landmark tile's observation steps (dealt round-robin): waves of its workgroup in k_lin_small, workgroups in k_vis_split
   LIN_SMALL_THREADS = GFBE_LIN_SMALL_THREADS,    // k_lin_small: threads per workgroup (LIN_SMALL_KS waves per visual tile, all of them for an inertial / wheel / prior item)
   DENSE_SPLIT_MIN_B = 32,     // batches at least this big: k_dense_raw (lane = window) + aux-stream overlap of the dense factors
   VS_BLOCKS = 2 * (NF - 1),     // blocks of the split visual assembly of small batches (k_visblock_small)
@@ -291,7 +291,7 @@ struct BatchDev {
   double *zero;               // a few zeros: target of the "absent contribution" loads of k_assemble
   double *tile_cost;          // [B][max_tiles]   visual cost partials (current linearisation)
   double *vis_contrib;        // [B][max_tiles][MAXOBS][16][64] small batches: per-step contributions to Hll, gl, hC, cost (k_lin_small)
-  int *tile_cnt;              // [B][max_tiles]   arrival counter of the tile's LIN_SMALL_KS workgroups (zero between launches)
+  int *tile_cnt;              // [B][max_tiles]   arrival counter of the tile's LIN_SMALL_KS workgroups in k_vis_split (zero between launches)
   int *win_cnt;               // [B][2]           arrival counters of a window's k_lm_step / k_lin_small<1> workgroups (GFBE_FUSE_SMALL; zero between launches)
   double *tile_cand;          // [B][max_tiles][4] candidate: cost, |x-xc|^2, |xc|^2, pad
   double *tile_gram;          // [B][max_tiles][8] landmark parts of G2 N2 gy vHv vHy yHy gradmax
