@@ -270,7 +270,7 @@ struct BatchDev {
   // step is accepted, and the next iteration starts at the Schur elimination (lin_view: the set WinCtl::lb names). A rejected step
   // leaves the current set alone, exactly what DoglegStrategy's reuse needs.
   int spec;
-  double *lm_Hll2, *lm_gl2, *lm_hC2, *lm_hP2, *lm_sw2, *vis_part2, *imu_part2, *wheel_part2, *plane_part2, *anchor_part2, *prior_g2, *lio_part2;
+  double *lm_Hll2, *lm_gl2, *lm_hC2, *lm_hP2, *lm_sw2, *vis_part2, *imu_part2, *wheel_part2, *plane_part2, *anchor_part2, *prior_g2, *lio_part2, *gnss_J2, *gnss_r2, *gnss_cost2;
   // ---- landmark sharding over ranks (gfbe_set_allreduce): tile t of a window belongs to rank t % world.
   int rank, world;
   int sharded;                      // an all-reduce hook is installed (gfbe_set_allreduce): the launch sequence with the exchange blocks, also for world == 1
@@ -396,7 +396,7 @@ void launch_reanchor(const BatchDev &d, hipStream_t s);
 void launch_marginalize(const BatchDev &d, int flag, hipStream_t s);
 // mode 0: GNSS factors at the current parameters, added to H / g (after launch_assemble); 1: candidate cost; 2: the frame-0 factors at
 // the re-anchored state for MARGIN_OLD
-void launch_gnss(const BatchDev &d, int mode, hipStream_t s);
+void launch_gnss(const BatchDev &d, int mode, hipStream_t s, int sub = 0);
 
 // ---- device-resident feature tables (gfbe_ftab.hip; shared with the batch upload that reads them)
 enum { FT_NOBS = GFBE_WINDOW_SIZE + 1, FT_OW = 8, FT_BINS = NF * 8,

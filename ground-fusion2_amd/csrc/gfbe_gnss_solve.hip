@@ -98,15 +98,21 @@ enum { GN_NCLK = 5 * GFBE_WINDOW_SIZE,     // 40 DtDdtFactors (constellation-maj
        GN_LDS_OBS = 320 };                 // observations a window can stage in LDS (95 KB, beside 40 KB of cell partials); a larger window
                                            // sums from the global copy (L2), entry by entry
 
-__global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsigned lds_obs) {
+// sub (mode 0; BatchDev::spec, round 5): 0 — evaluate the factors at the current state and add their J^T J / J^T r into H / g; 1 — the
+// speculative pass: evaluate AT THE CANDIDATE into the set of outputs that is not the current one (per-observation J, r and the cost:
+// what k_accept reads), nothing is added; 2 — the iteration after an accepted speculative pass: add the sums of the current set's
+// J, r (the evaluation they came from ran at this very state). 1 + 2 perform sub 0's operations in its order.
+__global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsigned lds_obs, int sub) {
   const int w = blockIdx.x, t = threadIdx.x;
-  const WinDesc &ds = d.desc[w];
+  const WinDesc &ds = d0.desc[w];
   if (!ds.gnss_ready) return;
-  const WinCtl &c = d.ctl[w];
-  if (mode == 0 && (!ds.gnss_factors || c.done || c.reuse)) return;
-  if (mode == 1 && (!ds.gnss_factors || c.done || !c.have_step)) return;
+  const WinCtl &c = d0.ctl[w];
+  const bool ev_only = mode == 0 && sub == 1, sum_only = mode == 0 && sub == 2;
+  if (mode == 0 && !ev_only && (!ds.gnss_factors || c.done || c.reuse)) return;
+  if ((mode == 1 || ev_only) && (!ds.gnss_factors || c.done || !c.have_step)) return;
   if (mode == 2 && ds.frame_count < GFBE_WINDOW_SIZE) return;
-  const double *X = mode == 2 ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + (mode == 1 ? 1 - c.cur : c.cur)) * NA;
+  const BatchDev d = mode == 0 ? lin_view(d0, ev_only ? 1 - c.lb : c.lb) : d0;
+  const double *X = mode == 2 ? d.xout + (size_t)w * NA : d.x + ((size_t)w * 2 + ((mode == 1 || ev_only) ? 1 - c.cur : c.cur)) * NA;
   __shared__ double red[16], clk_r[GN_NCLK], s_dt[GFBE_WINDOW_SIZE];
   __shared__ int s_fb[NF + 1];
   __shared__ unsigned char s_act[GN_C];      // (the descriptor lives in global memory: what the sums below consult per entry is staged once)
@@ -129,6 +135,14 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsig
   // the first interval
   const int n_obs = mode == 2 ? ds.gnss_frame_begin[1] : ds.n_gnss, n_int = mode == 2 ? 1 : GFBE_WINDOW_SIZE;
   double cost = 0.0;
+  if (sum_only) {      // the evaluation ran in the last iteration's candidate pass: its J, r back into the staging
+    if (staged)
+      for (int k = t; k < n_obs; k += GN_THREADS) {
+        for (int q = 0; q < 36; q++) sJ[k * GN_ROW + q] = Jw[(size_t)36 * k + q];
+        sJ[k * GN_ROW + 36] = rw[2 * k]; sJ[k * GN_ROW + 37] = rw[2 * k + 1];
+        sMeta[k] = obs[k].frame | (obs[k].lower_idx << 8) | (obs[k].sys_idx << 16);
+      }
+  } else
   for (int k = t; k < n_obs; k += GN_THREADS) {
     const gfbe_gnss_obs o = obs[k];
     const int lw = mode == 2 ? 0 : o.lower_idx;
@@ -189,7 +203,8 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d, int mode, unsig
     if (t == 0) part[GN_MPART - 2] = cost;
     return;
   }
-  if (t == 0) d.gnss_cost[(size_t)w * 2] = cost;
+  if (t == 0 && !sum_only) d.gnss_cost[(size_t)w * 2] = cost;
+  if (ev_only) return;
   if (d.rank != 0) return;      // landmark sharding: like the inertial / wheel / prior factors, added once
   double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   if (staged) {
@@ -282,11 +297,11 @@ static size_t gnss_lds_bytes(unsigned n_obs) { return sizeof(double) * ((size_t)
 hipError_t gnss_init_device() {   // per device, from gfbe_create (see kernels_init_device)
   return hipFuncSetAttribute((const void *)k_gnss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnss_lds_bytes(GN_LDS_OBS));
 }
-void launch_gnss(const BatchDev &d, int mode, hipStream_t s) {
+void launch_gnss(const BatchDev &d, int mode, hipStream_t s, int sub) {
   if (!d.any_gnss) return;
   // LDS for the batch's largest window (mode 1, the candidate cost, stages nothing)
   const unsigned n = mode == 1 ? 0u : (unsigned)std::min(d.gnss_max_obs, (int)GN_LDS_OBS);
-  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), mode == 1 ? 0 : gnss_lds_bytes(n), s, d, mode, n);
+  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), mode == 1 ? 0 : gnss_lds_bytes(n), s, d, mode, n, mode == 0 ? sub : 0);
 }
 
 }  // namespace gfd

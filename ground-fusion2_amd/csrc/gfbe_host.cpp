@@ -805,8 +805,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   d.solve_big = d.nu > NC;                                  // (decided per batch: k_solve / k_solve_chain hold the 187 core dims only)
   if (diag_getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics build only: force the 20-column panel)
   // speculative linearisation (gfbe_options.speculative_linearization): batches whose candidate costs are all formed by the visual /
-  // dense-factor / LiDAR launches (no GNSS factors, no all-reduce hook) get a second set of the linearisation's outputs
-  d.spec = (c->opt.speculative_linearization && !c->allreduce && !any_gnss && max_tiles > 0 &&
+  // dense-factor / LiDAR / GNSS launches (no all-reduce hook) get a second set of the linearisation's outputs
+  d.spec = (c->opt.speculative_linearization && !c->allreduce && max_tiles > 0 &&
             (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 2))) ? 1 : 0;
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
@@ -909,6 +909,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     AL(solveY, d.solve_big ? 1 : (size_t)B * solve_chain_scratch_doubles());
     AL(solveS, d.solve_big ? (size_t)B * BIG_LD * BIG_LD : 1);
     AL(gnss_J, (size_t)std::max(tot_gnss, 1) * 36); AL(gnss_r, (size_t)std::max(tot_gnss, 1) * 2);
+    if (d.spec) { AL(gnss_J2, (size_t)std::max(tot_gnss, 1) * 36); AL(gnss_r2, (size_t)std::max(tot_gnss, 1) * 2); AL(gnss_cost2, (size_t)B * 2); }
+    else { d.gnss_J2 = d.gnss_r2 = d.gnss_cost2 = nullptr; }
     AL(gnss_cost, (size_t)B * 2); AL(gnss_marg, any_gnss ? (size_t)B * GN_MPART : 1);
     AL(dl_fix, (size_t)B * DL_FIX); AL(dl_feat, feat_off[B]); AL(dl_J0, (size_t)j0_off[B]);
     if (!b->dry) { b->up_end = up_end; b->zero_end = zero_end; }
@@ -1342,7 +1344,7 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   if (d.vis_Hs && !(fuse & 1)) { Timed t(c, first ? "k_visblock_iter0" : "k_visblock", 0); launch_visblock(d, ln.s); }   // (throughput batches: inside k_visasm, below)
   if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);   // join
   { Timed t(c, first ? "k_assemble_iter0" : "k_assemble", 0); launch_assemble(d, ln.s); }
-  if (d.any_gnss) { Timed t(c, "k_gnss", 0); launch_gnss(d, 0, ln.s); }
+  if (d.any_gnss) { Timed t(c, "k_gnss", 0); launch_gnss(d, 0, ln.s, have_lin ? 2 : 0); }      // (have_lin: the sums of the candidate pass's evaluation)
   if (d.sharded) {   // one all-reduce per linearisation, on the packed triangle of the system (164 KB per window instead of 528 KB)
     Timed t(c, "allreduce_system", 0);
     launch_sys_pack(d, 0, ln.s);
@@ -1399,7 +1401,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     else if (lin_cand) { Timed t(c, "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s, 0, 1); }
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, lin_cand ? "k_lio_window" : "k_lio_window_cost", 0); launch_lio_window(d, lin_cand ? 0 : 1, ln.s, lin_cand); }
-    if (d.any_gnss) { Timed t(c, "k_gnss_cost", 0); launch_gnss(d, 1, ln.s); }
+    if (d.any_gnss) { Timed t(c, lin_cand ? "k_gnss_eval" : "k_gnss_cost", 0); launch_gnss(d, lin_cand ? 0 : 1, ln.s, lin_cand ? 1 : 0); }
     if (!small && !overlap) { Timed t(c, lin_cand ? "k_dense" : "k_dense_cost", 0); launch_dense_factors(d, lin_cand ? 0 : 1, 0, ln.s, lin_cand); }
     else if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);
     if (d.sharded) {

@@ -3129,7 +3129,7 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
   if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 29 - cslot];      // (28: the cost pass's slot; 27: a linearisation's)
   if (lane >= 48 && lane - 48 < ds.n_plane) cand += d.plane_part[((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - cslot];
   if (lane == 58 && ds.use_anchor) cand += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - cslot];
-  if (lane == 59 && ds.gnss_factors) cand += d.gnss_cost[(size_t)w * 2 + 1];
+  if (lane == 59 && ds.gnss_factors) cand += d.gnss_cost[(size_t)w * 2 + 2 - cslot];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o, 64); d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
   if (lane != 0) return;

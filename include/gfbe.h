@@ -283,7 +283,7 @@ typedef struct gfbe_options {
    * 0: no retry — a failed factorisation ends the solve as a failed linear solve, and every linearisation carries one all-reduce
    * less (three per trust-region iteration instead of four: the packed system and the two scalar exchanges). */
   int32_t sharded_mu_retries;
-  /* Batches without GNSS factors or an all-reduce hook: 1 (default) — the pass that evaluates the candidate of a trust-region
+  /* Batches without an all-reduce hook: 1 (default) — the pass that evaluates the candidate of a trust-region
    * iteration LINEARISES there (every iteration but the last of a solve), into a second set of the linearisation's outputs; an accepted
    * step makes it the current set, a rejected one leaves the old linearisation in place (DoglegStrategy's reuse), and the next
    * iteration starts at the landmark elimination. The evaluations are TrustRegionMinimizer's own, in its order — the candidate's

@@ -101,3 +101,23 @@ def test_lidar_windows_are_unchanged_bit_for_bit(oracle):
         got.append([be.solve(w1, abi.MARGIN_OLD), be.solve(w2, abi.MARGIN_SECOND_NEW)] + be.solve_batch([w1, plain, w2] * 11, abi.MARGIN_OLD))
         be.close()
     assert all(_identical(a, b) for a, b in zip(*got))
+
+
+def test_gnss_windows_are_unchanged_bit_for_bit(oracle):
+    """GNSS windows (gfbe_window.gnss_ready): the speculative pass evaluates the pseudo-range / Doppler / clock factors at the candidate
+    (k_gnss, sub 1: per-observation J, r and the cost), the next iteration adds their sums into H (sub 2) — the operations of the one
+    launch of the other sequence, in its order. One window, its successor (prior with GNSS blocks), a small batch and 33 windows."""
+    import gnss_window_cases as gw
+    scn, tru, g1 = gw.gnss_window(seed=97, L=120, n_per_frame=6)
+    be0 = _backend(0)
+    g2 = gw.next_gnss_window(scn, tru, be0.solve(g1, abi.MARGIN_OLD), seed=97)
+    be0.close()
+    g3 = gw.gnss_window(seed=98, L=90, n_per_frame=10, anchor=True)[2]
+    plain = synth.Scenario(seed=99, n_landmarks=150, use_wheel=True).window(0)
+    got = []
+    for spec in (0, 1):
+        be = _backend(spec)
+        got.append([be.solve(g1, abi.MARGIN_OLD), be.solve(g2, abi.MARGIN_OLD), be.solve(g3, abi.MARGIN_SECOND_NEW)] +
+                   be.solve_batch([g1, plain, g3], abi.MARGIN_OLD) + be.solve_batch([g1, plain, g3] * 11, abi.MARGIN_OLD))
+        be.close()
+    assert all(_identical(a, b) for a, b in zip(*got))
