@@ -131,6 +131,14 @@ extern "C" int shim_eval_factors(const gfbe_options *opt, const gfbe_window *w, 
     if (sqrt_info_from_cov(w->imu[k].covariance, 15, S, work)) return 1;
     std::memset(Jraw, 0, sizeof Jraw);
     imu_raw(&w->imu[k], opt->g_norm, st.para_Pose[i], st.para_SpeedBias[i], st.para_Pose[i + 1], st.para_SpeedBias[i + 1], raw, Jraw);
+    for (int nparts = 2; nparts <= 8; nparts *= 2) {   // the Jacobian's items dealt over the waves of a workgroup: the same bits
+      double raw2[15], Jsplit[450];
+      std::memset(Jsplit, 0, sizeof Jsplit);
+      for (int part = nparts - 1; part >= 0; part--)
+        imu_raw(&w->imu[k], opt->g_norm, st.para_Pose[i], st.para_SpeedBias[i], st.para_Pose[i + 1], st.para_SpeedBias[i + 1], raw2, Jsplit,
+                1, part, nparts);
+      if (std::memcmp(Jsplit, Jraw, sizeof Jraw) || std::memcmp(raw2, raw, sizeof raw)) return 9;
+    }
     for (int a = 0; a < 15; a++) {
       double s = 0; for (int b = 0; b < 15; b++) s += S[a * 15 + b] * raw[b];
       imu_r[15 * k + a] = s;
@@ -144,6 +152,14 @@ extern "C" int shim_eval_factors(const gfbe_options *opt, const gfbe_window *w, 
     std::memset(Jraw, 0, sizeof Jraw);
     wheel_raw(&w->wheel[k], st.para_Pose[i], st.para_Pose[i + 1], st.para_Ex_Pose_wheel, st.para_Ix_wheel[0], st.para_Ix_wheel[1],
               st.para_Ix_wheel[2], st.para_Td_wheel, raw, Jraw);
+    for (int nparts = 2; nparts <= 8; nparts *= 2) {   // the Jacobian dealt over the waves of a workgroup (dense_body<true>): the same bits
+      double raw2[6], Jsplit[132];
+      std::memset(Jsplit, 0, sizeof Jsplit);
+      for (int part = nparts - 1; part >= 0; part--)
+        wheel_raw(&w->wheel[k], st.para_Pose[i], st.para_Pose[i + 1], st.para_Ex_Pose_wheel, st.para_Ix_wheel[0], st.para_Ix_wheel[1],
+                  st.para_Ix_wheel[2], st.para_Td_wheel, raw2, Jsplit, 1, part, nparts);
+      if (std::memcmp(Jsplit, Jraw, sizeof Jraw) || std::memcmp(raw2, raw, sizeof raw)) return 9;
+    }
     for (int a = 0; a < 6; a++) {
       double s = 0; for (int b = 0; b < 6; b++) s += S[a * 6 + b] * raw[b];
       wheel_r[6 * k + a] = s;
