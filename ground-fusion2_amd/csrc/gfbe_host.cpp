@@ -1124,6 +1124,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   const bool ingest = B < DENSE_SPLIT_MIN_B && !poison_env && (b->up_end % 16) == 0 && ((b->zero_end - b->up_end) % 16) == 0;
   if (ingest) {
     const bool clearH = d.asm_tab == c->asm_compact;
+    static_assert((sizeof(double) * ND * ND) % 16 == 0, "k_ingest_small clears H in 16-byte units");
     launch_ingest_small(b->up_h, b->slab, b->up_end, b->slab + b->up_end, b->zero_end > b->up_end ? b->zero_end - b->up_end : 0,
                         d.H, clearH ? sizeof(double) * (size_t)B * ND * ND : 0,
                         pj_row > 0 ? (const double *)h_pJ0 : nullptr, d.prior_J0, pj_row > 0 ? B : 0, pj_row,
