@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, L):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
     dist.all_gather_object(owned, mine)
     # (2) landmark sharding of one window
     orc = oracle_lib.load()
-    snap = synth.Scenario(seed=99, n_landmarks=120, use_wheel=True).window(0)
+    snap = synth.Scenario(seed=99, n_landmarks=L, use_wheel=True).window(0)
     full = gd.reduced_system(orc.linearize(snap))
     part = gd.reduced_system(orc.linearize(gd.shard_landmarks(snap, rank, world)))
     t = torch.from_numpy(part.copy())
@@ -49,11 +49,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_window_and_landmark_sharding_world2():
-    world, port = 2, _free_port()
+def _run_world(world, L=120):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, L)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -61,7 +61,21 @@ def test_window_and_landmark_sharding_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, units, tmax, owned, err in res:
-        assert units == 11 and tmax == 1.5                       # SUM of units, MAX of elapsed
+        assert units == 11 and tmax == world - 0.5               # SUM of units, MAX of elapsed
         flat = sorted(i for o in owned for i in o)
         assert flat == list(range(11))                           # disjoint cover
         assert err < 1e-12, err                                  # all-reduced partials == unsharded system
+
+
+def test_window_and_landmark_sharding_world2():
+    _run_world(2)
+
+
+def test_window_and_landmark_sharding_world3_ragged():
+    _run_world(3, L=100)                                         # 34 + 33 + 33 landmarks
+
+
+def test_landmark_sharding_world3_with_an_empty_shard():
+    # two landmarks over three ranks: rank 2 owns none and (not being rank 0) no dense factor either — an all-zero partial;
+    # the sum must still be the unsharded system
+    _run_world(3, L=2)
