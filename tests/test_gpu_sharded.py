@@ -23,7 +23,8 @@ def free_port():
 
 
 @pytest.mark.parametrize("world,L,fail_iter,kind", [(2, 2000, 0, "plain"), (3, 500, 0, "plain"), (2, 500, 2, "plain"), (2, 300, 0, "gnss"), (2, 500, 2, "retry3"),
-                                                     (2, 10000, 0, "plain")])      # (the last one: BASELINE configs[2]'s own size, 10 000 landmarks)
+                                                     (2, 10000, 0, "plain"),       # (BASELINE configs[2]'s own size, 10 000 landmarks)
+                                                     (3, 100, 0, "plain")])        # (two tiles of landmarks over three ranks: rank 2 owns none)
 def test_landmark_sharded_solve_matches_unsharded(tmp_path, world, L, fail_iter, kind):
     """fail_iter > 0: the first factorisation of that iteration is declared failed on every rank (and in the unsharded
     reference): the sharded mu retry — E rebuilt from every rank's own tiles at the larger mu, one more all-reduce, second
