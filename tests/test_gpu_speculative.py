@@ -121,3 +121,36 @@ def test_gnss_windows_are_unchanged_bit_for_bit(oracle):
                    be.solve_batch([g1, plain, g3], abi.MARGIN_OLD) + be.solve_batch([g1, plain, g3] * 11, abi.MARGIN_OLD))
         be.close()
     assert all(_identical(a, b) for a, b in zip(*got))
+
+
+def _empty_and_partial():
+    scn = synth.Scenario(seed=70, n_landmarks=100, use_wheel=True)
+    partial = scn.window(0)                       # frame_count < WINDOW_SIZE: no marginalisation (estimator.cpp:3391)
+    keep = partial["vis_imu_j"] <= 6
+    for k in list(partial):
+        if k.startswith("vis_"):
+            partial[k] = partial[k][keep]
+    partial["frame_count"] = 6
+    partial["imu"], partial["imu_frame"] = partial["imu"][:6], partial["imu_frame"][:6]
+    partial["wheel"], partial["wheel_frame"] = partial["wheel"][:6], partial["wheel_frame"][:6]
+    empty = synth.Scenario(seed=71, n_landmarks=0, use_wheel=True).window(0)      # a window without a landmark: no tile of its own
+    return empty, partial
+
+
+def test_empty_and_partial_windows_inside_a_batch(oracle):
+    """A window without landmarks (none of the batch's tiles is its own) and a partial window beside ordinary ones, in both kernel sets:
+    the same bits with the option on and off, and the same bits as each window solved alone."""
+    w1, w2, first = _windows(oracle)
+    empty, partial = _empty_and_partial()
+    alone_be = _backend(1)
+    alone = [alone_be.solve(s, abi.MARGIN_OLD) for s in (empty, w1, partial, first, w2)]
+    alone_be.close()
+    for snaps, reps in (([empty, w1, partial, first, w2], 1), ([empty, w1, partial, first, w2] * 7, 7)):
+        got = []
+        for spec in (0, 1):
+            be = _backend(spec)
+            got.append(be.solve_batch(snaps, abi.MARGIN_OLD))
+            be.close()
+        assert all(_identical(a, b) for a, b in zip(*got))
+        if reps == 1:      # (the small-batch kernel set is the single window's own: identical to the windows solved alone)
+            assert all(_identical(a, b) for a, b in zip(got[1], alone))
