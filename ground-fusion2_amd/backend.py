@@ -301,7 +301,9 @@ class Batch:
     def solve(self, margin_flag=abi.MARGIN_NONE):
         self.be.check(self.be.lib.gfbe_batch_solve(self.be.ctx, self.h, int(margin_flag)), "batch_solve")
 
-    def download(self):
+    def download(self, raise_on_failure=True):
+        """Per-window results. raise_on_failure=False: a window whose linear solves all failed (status NUMERICAL_FAILURE) does not
+        raise — every window's own outcome is in its "status" (the batch's windows are independent)."""
         n = self.n
         states = (abi.State * n)()
         feats = [np.zeros(getattr(h, "n_feature_override", h.n_feature)) for h in self.holders]
@@ -309,7 +311,9 @@ class Batch:
         priors = [abi.PriorHolder() for _ in range(n)]
         pptr = (C.POINTER(abi.Prior) * n)(*[C.pointer(p.c) for p in priors])
         sums = (abi.Summary * n)()
-        self.be.check(self.be.lib.gfbe_batch_download(self.be.ctx, self.h, states, fptr, pptr, sums), "batch_download")
+        rc = self.be.lib.gfbe_batch_download(self.be.ctx, self.h, states, fptr, pptr, sums)
+        if raise_on_failure or rc != abi.NUMERICAL_FAILURE:
+            self.be.check(rc, "batch_download")
         out = []
         for k in range(n):
             out.append(dict(state=abi.state_to_dict(states[k]), feature=feats[k],

@@ -1603,7 +1603,8 @@ extern "C" gfbe_status gfbe_batch_download(gfbe_ctx *c, gfbe_batch *b, gfbe_stat
   int done = 0;
   for (gfbe_batch *p = b; p; p = p->second) {
     const gfbe_status st = download_one(c, p, out_state, out_feature, prior_out, summary, done, b->order.empty() ? nullptr : b->order.data());
-    if (st > GFBE_NO_CONVERGENCE) return st;
+    // (a window whose linear solves all failed is ITS failure — summary[w].status —: the other parts are still unpacked)
+    if (st > GFBE_NUMERICAL_FAILURE) return st;
     if (st > worst) worst = st;
     done += p->d.B;
   }

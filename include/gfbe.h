@@ -615,7 +615,10 @@ gfbe_status gfbe_solve_window(gfbe_ctx *ctx, const gfbe_window *win, int32_t mar
                               gfbe_state *out_state, double *out_feature,
                               gfbe_prior *prior_out, gfbe_summary *summary);
 
-/* Batched form: n independent windows, one launch sequence. Arrays are per-window. */
+/* Batched form: n independent windows, one launch sequence. Arrays are per-window. The windows do not influence one another:
+ * summary[w].status is window w's own outcome, the return value the worst of them (GFBE_NO_CONVERGENCE or
+ * GFBE_NUMERICAL_FAILURE: every window's outputs have been written, a failed window's from the last state its iterations
+ * accepted; anything larger: the call itself failed and no output is valid). The same holds for gfbe_batch_download. */
 gfbe_status gfbe_solve_batch(gfbe_ctx *ctx, int32_t n_window, const gfbe_window *const *win,
                              int32_t margin_flag, gfbe_state *out_state, double *const *out_feature,
                              gfbe_prior *const *prior_out, gfbe_summary *summary);

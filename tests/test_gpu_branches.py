@@ -180,3 +180,41 @@ def test_second_new_with_an_invalid_prior_that_lists_the_second_newest_pose(be, 
     res = be.solve_batch([snap, odd], abi.MARGIN_SECOND_NEW)
     assert res[0]["prior"] is not None and res[0]["prior"]["n"] > 0
     assert res[1]["prior"] is not None and res[1]["prior"]["n"] == 0 and len(res[1]["prior"]["block_id"]) == 0
+
+
+@pytest.mark.parametrize("reps,split", [(1, 1), (12, 1), (44, 2)])
+def test_a_failing_window_is_its_own_failure_inside_a_batch(reps, split):
+    """The windows of a batch are independent (include/gfbe.h, gfbe_solve_batch): a NaN state makes every linear solve of ITS window fail
+    (GFBE_NUMERICAL_FAILURE in its summary, the worst status as the call's return value) and changes no bit of its neighbours' results
+    — in the small-batch kernel set (3 windows), the throughput set (36) and a batch solved as two parts side by side (132: the
+    failure sits in one part, the other is still unpacked)."""
+    good = [synth.Scenario(seed=9 + k, n_landmarks=100 + 40 * k, use_wheel=True).window(0) for k in range(2)]
+    nan = dict(good[0], pose=good[0]["pose"].copy())
+    nan["pose"][4, 1] = np.nan
+    o = abi.default_options()
+    o.split_batch = split
+    be = gf.Backend(device=0, options=o)
+    try:
+        alone = [be.solve(s, abi.MARGIN_OLD) for s in good]
+        snaps = [good[0], nan, good[1]] * reps
+        b = be.batch_upload(snaps)
+        try:
+            b.solve(abi.MARGIN_OLD)
+            with pytest.raises(RuntimeError, match="status 2"):
+                b.download()
+            got = b.download(raise_on_failure=False)
+        finally:
+            b.free()
+        for k, g in enumerate(got):
+            if k % 3 == 1:
+                assert g["status"] == abi.NUMERICAL_FAILURE
+                continue
+            a = alone[0 if k % 3 == 0 else 1]
+            assert g["status"] in (abi.OK, abi.NO_CONVERGENCE) and g["summary"]["accepted"] == a["summary"]["accepted"]
+            if reps == 1:      # (the small-batch kernels are the single window's own: the same bits)
+                assert np.array_equal(g["state"]["pose"], a["state"]["pose"]) and np.array_equal(g["prior"]["J0"], a["prior"]["J0"])
+            else:              # (the throughput kernels sum in another order)
+                assert np.abs(g["state"]["pose"] - a["state"]["pose"]).max() < 1e-9
+            assert np.array_equal(g["state"]["pose"], got[k % 3]["state"]["pose"])      # and the same bits wherever the window sits
+    finally:
+        be.close()
