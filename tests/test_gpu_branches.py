@@ -218,3 +218,31 @@ def test_a_failing_window_is_its_own_failure_inside_a_batch(reps, split):
             assert np.array_equal(g["state"]["pose"], got[k % 3]["state"]["pose"])      # and the same bits wherever the window sits
     finally:
         be.close()
+
+
+def _first_factor_only(snap):
+    """Every landmark keeps the first of its factors: tracks of two observations, the shortest a factor can be built from."""
+    s = dict(snap)
+    fi = np.asarray(snap["vis_feature_index"])
+    _, first = np.unique(fi, return_index=True)
+    keep = np.zeros(len(fi), bool)
+    keep[first] = True
+    for k in list(snap):
+        if k.startswith("vis_"):
+            s[k] = np.asarray(snap[k])[keep]
+    return s
+
+
+def test_shortest_tracks_one_factor_per_landmark(be, oracle):
+    """Ragged down to the minimum: every landmark seen in exactly two frames (ONE factor: the landmark's share of the visual tile's
+    observation loop is a single step, three of the four wave shares of its tile hold nothing). Against the oracle, alone and — the
+    throughput kernels — inside a batch of 34."""
+    _, snap = window_with_prior(oracle, 77, 300)
+    short = _first_factor_only(snap)
+    assert len(short["vis_feature_index"]) == len(np.unique(snap["vis_feature_index"]))
+    want, got = check_solve(be, oracle, short, abi.MARGIN_OLD)
+    many = be.solve_batch([short, snap] * 17, abi.MARGIN_OLD)
+    for g in many[0::2]:
+        assert g["summary"]["accepted"] == want["summary"]["accepted"]
+        assert np.abs(g["state"]["pose"] - got["state"]["pose"]).max() < 1e-9
+        np.testing.assert_allclose(g["feature"], got["feature"], rtol=1e-7, atol=1e-12)
