@@ -90,7 +90,11 @@ struct MiniEstimator {
     gfbe_state out;
     const int flag = frame_count < WINDOW_SIZE ? GFBE_MARGIN_NONE : (marginalization_flag == MARGIN_OLD ? GFBE_MARGIN_OLD : GFBE_MARGIN_SECOND_NEW);
     const gfbe_status rc = gfbe_solve_window(gfbe_, &w, flag, &out, lam.data(), &prior_, sum);
-    if (rc > GFBE_NO_CONVERGENCE) { std::printf("gfbe: %s\n", gfbe_last_error(gfbe_)); return rc; }   // (3 and above: the call failed, no output is valid; GFBE_NUMERICAL_FAILURE: `out` and `prior_` hold what the failed solve left — the reference, which does not look at Ceres' termination, would go on with exactly that)
+    // include/gfbe.h "FAILURE CONTRACT": rc >= GFBE_BAD_INPUT — the call failed and touched no output: keep the previous state;
+    // GFBE_NUMERICAL_FAILURE — the solve ran and failed, every output was written (the last accepted state and, in place, the prior
+    // marginalised there): go on with them, as the reference does (it never looks at Ceres' termination_type, estimator.cpp:3377-3379)
+    if (rc >= GFBE_BAD_INPUT) { std::printf("gfbe: %s\n", gfbe_last_error(gfbe_)); return rc; }
+    if (rc == GFBE_NUMERICAL_FAILURE) std::printf("gfbe: linear solve failed in this window (%s)\n", gfbe_last_error(gfbe_));
 
     // double2vector(): `out` holds the re-anchored blocks (estimator.cpp:2515-2555)
     std::memcpy(para_Pose, out.para_Pose, sizeof para_Pose);

@@ -141,7 +141,7 @@ class Window(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("max_num_iterations", c_i), ("huber_delta", c_d), ("vis_sqrt_info", c_d), ("g_norm", c_d),
+    _fields_ = [("struct_size", c_i), ("max_num_iterations", c_i), ("huber_delta", c_d), ("vis_sqrt_info", c_d), ("g_norm", c_d),
                 ("initial_trust_region_radius", c_d), ("function_tolerance", c_d), ("gradient_tolerance", c_d),
                 ("parameter_tolerance", c_d), ("min_relative_decrease", c_d), ("jacobi_scaling", c_i),
                 ("marg_eps", c_d), ("marg_sqrt", c_i), ("use_graph", c_i), ("split_batch", c_i),
@@ -164,6 +164,7 @@ class FeatureList(C.Structure):
 def default_options():
     """Solver options the reference runs with (estimator.cpp:193,2959,3364-3376; m3dgr.yaml:108-117)."""
     o = Options()
+    o.struct_size = C.sizeof(Options)
     o.max_num_iterations = 8
     o.huber_delta = 1.0
     o.vis_sqrt_info = 600.0 / 1.5

@@ -20,7 +20,7 @@ _SO = os.environ.get("GFBE_LIB") or os.path.join(_CSRC, "libgfbe.so")
 
 # Every symbol include/gfbe.h declares (checked by tests/test_abi.py on CPU).
 EXPORTS = [
-    "gfbe_default_options", "gfbe_create", "gfbe_destroy", "gfbe_last_error", "gfbe_create_note", "gfbe_version", "gfbe_set_stream",
+    "gfbe_default_options", "gfbe_options_size", "gfbe_create", "gfbe_destroy", "gfbe_last_error", "gfbe_create_note", "gfbe_version", "gfbe_set_stream",
     "gfbe_feature_count", "gfbe_visual_factor_count", "gfbe_build_visual_factors", "gfbe_set_depth",
     "gfbe_eval_factors", "gfbe_preintegrate_imu", "gfbe_preintegrate_wheel",
     "gfbe_solve_window", "gfbe_solve_batch",

@@ -226,7 +226,10 @@ void *ctx_scratch_pinned(gfbe_ctx *c, size_t bytes) {
 
 extern "C" {
 
+int32_t gfbe_options_size(void) { return (int32_t)sizeof(gfbe_options); }
+
 void gfbe_default_options(gfbe_options *o) {
+  o->struct_size = (int32_t)sizeof(gfbe_options);
   o->max_num_iterations = 8;                 // m3dgr.yaml:109
   o->huber_delta = 1.0;                      // estimator.cpp:2959
   o->vis_sqrt_info = 600.0 / 1.5;            // estimator.cpp:193, parameters.h:23
@@ -256,6 +259,15 @@ const char *gfbe_create_note(const gfbe_ctx *ctx) { return ctx ? ctx->note.c_str
 gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   if (!out) return GFBE_BAD_INPUT;
   gfbe_ctx *c = new gfbe_ctx();
+  *out = c;
+  // (only the first member is read before the size is known to be the library's own)
+  if (opt && opt->struct_size != (int32_t)sizeof(gfbe_options)) {
+    c->device = -1;
+    gfbe_default_options(&c->opt);
+    c->err = "options ABI mismatch: gfbe_options.struct_size = " + std::to_string(opt->struct_size) + ", the library's is " +
+             std::to_string(sizeof(gfbe_options)) + " (start from gfbe_default_options of the header this library was built with)";
+    return GFBE_BAD_INPUT;
+  }
   if (opt) c->opt = *opt; else gfbe_default_options(&c->opt);
   c->device = device;
   *out = c;
@@ -672,6 +684,11 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   //  that would hide behind nothing, and the hop from the copy stream to the main stream cost 11 us of a single window's call)
   hipStream_t us = B < DENSE_SPLIT_MIN_B ? c->stream : c->copy;
   if (tabs && us != c->stream && tabs->ev_ops) HIPCHK(c, hipStreamWaitEvent(us, tabs->ev_ops, 0));
+  // (a SMALL table-fed upload right behind a large one from the same tables — no table operation in between, so nobody has
+  //  waited for ev_read — rewrites the tables' shared histogram / layout / id scratch on the main stream while the large batch's pack
+  //  kernel may still read them on the copy stream: the main stream waits for the last reader first. The flag stays set: the next table
+  //  operation still orders itself behind that reader through ft_ready.)
+  if (tabs && us == c->stream && tabs->read_pending && tabs->ev_read) HIPCHK(c, hipStreamWaitEvent(us, tabs->ev_read, 0));
   b->slot_of.resize(B);
   b->L.resize(B);
   b->anchor_only.assign(B, 0);
@@ -825,7 +842,18 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   for (int pass = 0; pass < 2; pass++) {
     b->dry = pass == 0;
     if (pass == 1) {
-      if ((st = slab_acquire(c, b)) != GFBE_OK) return st;
+      st = slab_acquire(c, b);
+      if (st != GFBE_OK && d.spec) {
+        // (the second set of the linearisation's outputs is ~1 MB per 2k-landmark window — a batch that fitted the device
+        //  before the option existed must still fit: size the slab again without it; the note travels with the batch's create note)
+        d.spec = 0;
+        c->err.clear();
+        c->note = "speculative_linearization switched off for a batch: its second set of outputs did not fit the device";
+        b->slab_bytes = 0; b->up_bytes = 0; b->slab_off = 0;
+        pass = -1;
+        continue;
+      }
+      if (st != GFBE_OK) return st;
       b->up_h = pin_acquire(c, b->up_bytes, &b->up_cap);
       if (!b->up_h) { c->err = "hipHostMalloc(upload staging) failed"; return GFBE_DEVICE_ERROR; }
     }
@@ -1121,7 +1149,15 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   const double T3 = now();
   // ---- enqueue: clear what must start as zero, ONE host-to-device copy, then the preparation kernels
   // (a small batch: all of it in one kernel that reads the pinned staging buffer across PCIe itself — k_ingest_small)
-  const bool ingest = B < DENSE_SPLIT_MIN_B && !poison_env && (b->up_end % 16) == 0 && ((b->zero_end - b->up_end) % 16) == 0;
+  const bool ingest = B < DENSE_SPLIT_MIN_B && (b->up_end % 16) == 0 && ((b->zero_end - b->up_end) % 16) == 0;
+  // (test hook, tests/test_gpu_uncleared.py: the part of the slab that is NOT cleared filled with NaN bit patterns — a kernel that
+  //  uses what nobody wrote poisons its results instead of finding the previous batch's numbers there)
+  //  GFBE_POISON_UNCLEARED=1: all of it; =<array name>: that array alone. Ahead of BOTH upload paths (the hook used to
+  //  switch k_ingest_small off, so the shipped single-window upload's cleared ranges were never tested under poison).
+  if (poison_env)
+    for (const auto &pl : b->poison_list)
+      if (pl.off >= b->zero_end && (!strcmp(poison_env, "1") || !strcmp(poison_env, "clean") || !strcmp(poison_env, pl.name)))
+        HIPCHK(c, hipMemsetAsync(b->slab + pl.off, strcmp(poison_env, "clean") ? 0xFF : 0, pl.bytes, us));   // ("clean": zeros, for a scan that poisons one array at a time)
   if (ingest) {
     const bool clearH = d.asm_tab == c->asm_compact;
     static_assert((sizeof(double) * ND * ND) % 16 == 0, "k_ingest_small clears H in 16-byte units");
@@ -1131,13 +1167,6 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
                         (size_t)ND * ND, us);
   } else {
   if (b->zero_end > b->up_end) HIPCHK(c, hipMemsetAsync(b->slab + b->up_end, 0, b->zero_end - b->up_end, us));
-  // (test hook, tests/test_gpu_uncleared.py: the part of the slab that is NOT cleared filled with NaN bit patterns — a kernel that
-  //  uses what nobody wrote poisons its results instead of finding the previous batch's numbers there)
-  //  GFBE_POISON_UNCLEARED=1: all of it; =<array name>: that array alone)
-  if (poison_env)
-    for (const auto &pl : b->poison_list)
-      if (pl.off >= b->zero_end && (!strcmp(poison_env, "1") || !strcmp(poison_env, "clean") || !strcmp(poison_env, pl.name)))
-        HIPCHK(c, hipMemsetAsync(b->slab + pl.off, strcmp(poison_env, "clean") ? 0xFF : 0, pl.bytes, us));   // ("clean": zeros, for a scan that poisons one array at a time)
   // the compact assembly table writes only the entries of H some factor can reach: the others are read (as the zeros they are) by
   // the solve kernels and must start as zeros — H is not part of the cleared region (the full table writes every entry)
   if (d.asm_tab == c->asm_compact) HIPCHK(c, hipMemsetAsync(d.H, 0, sizeof(double) * (size_t)B * ND * ND, us));
@@ -1154,6 +1183,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     HIPCHK(c, hipMemcpyAsync(dlay, b->lay_h, sizeof(int) * tlayout.size(), hipMemcpyHostToDevice, us));
     launch_ftab_pack(tabs->d, tabs->cur, tab0, B, d, dlay, dslot, us);
     if (tabs->ev_read && us != c->stream) { HIPCHK(c, hipEventRecord(tabs->ev_read, us)); tabs->read_pending = true; }
+    // (and the other way round: a small upload reads the shared scratch on the MAIN stream; a large one that follows it waits for ev_ops
+    //  on the copy stream before it rewrites them — recorded again here, behind this reader)
+    else if (tabs->ev_ops && us == c->stream) HIPCHK(c, hipEventRecord(tabs->ev_ops, us));
   } else if (B >= DENSE_SPLIT_MIN_B) {
     launch_expand(d, us);
   }

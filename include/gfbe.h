@@ -224,6 +224,11 @@ typedef struct gfbe_window {
 } gfbe_window;
 
 typedef struct gfbe_options {
+  /* sizeof(gfbe_options) of the header the CALLER was compiled against, written by gfbe_default_options (always start from it).
+   * gfbe_create refuses a struct whose size is not the library's own (GFBE_BAD_INPUT, "options ABI mismatch"): the struct has grown
+   * by trailing fields from round to round, and a caller built against an older header would otherwise hand over a shorter struct
+   * whose missing fields the library reads from whatever follows it. gfbe_options_size() returns the library's. */
+  int32_t struct_size;
   int32_t max_num_iterations;   /* NUM_ITERATIONS = 8 (m3dgr.yaml:109) */
   double huber_delta;           /* HuberLoss(1.0)  (estimator.cpp:2959) */
   double vis_sqrt_info;         /* FOCAL_LENGTH/1.5 = 400 (estimator.cpp:193) */
@@ -320,6 +325,8 @@ enum { GFBE_MARGIN_OLD = 0, GFBE_MARGIN_SECOND_NEW = 1, GFBE_MARGIN_NONE = 2 };
 typedef struct gfbe_ctx gfbe_ctx;
 
 void gfbe_default_options(gfbe_options *opt);
+/* sizeof(gfbe_options) as the LIBRARY was built (gfbe_options.struct_size must equal it). */
+int32_t gfbe_options_size(void);
 
 /* device < 0: host-only context (bookkeeping functions only; every compute entry point returns
  * GFBE_NO_DEVICE). device >= 0: HIP device ordinal; fails with GFBE_NO_DEVICE if absent.
@@ -603,7 +610,17 @@ gfbe_status gfbe_preintegrate_wheel(gfbe_ctx *ctx, int32_t n_interval, const int
  *                 MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks}
  *                                                                      marginalization_factor.cpp:119-330
  * out_state / out_feature receive the re-anchored parameter blocks (what a second vector2double()
- * would produce, estimator.cpp:3398) — outputs are untouched when status is an error.
+ * would produce, estimator.cpp:3398).
+ * FAILURE CONTRACT (one rule for gfbe_solve_window, gfbe_solve_batch and gfbe_batch_download; INTEGRATION.md and
+ * examples/estimator_binding.cpp say the same; tests/test_gpu_branches.py asserts both halves through this entry point):
+ *   status <= GFBE_NUMERICAL_FAILURE (GFBE_OK, GFBE_NO_CONVERGENCE, GFBE_NUMERICAL_FAILURE): the solve RAN and every output has been
+ *     written — out_state / out_feature / the in-out prior / summary. For GFBE_NUMERICAL_FAILURE they hold what the failed solve left:
+ *     the last state its iterations accepted (the uploaded state if none was), re-anchored, and the prior marginalised at that state —
+ *     exactly what the reference goes on with, since Estimator::optimization() never looks at Ceres' termination_type
+ *     (estimator.cpp:3377-3379). A caller that wants "keep the previous state on failure" tests the status and discards the outputs.
+ *   status >= GFBE_BAD_INPUT: the CALL failed (bad argument, no device, device error) — no output has been touched.
+ * (SURVEY.md section 8b asked for "outputs untouched on failure"; that holds for failed calls. A numerically failed solve is not a failed
+ *  call: leaving its outputs unwritten would make a batch's result depend on which of its windows failed.)
  * prior_out (may be NULL when margin_flag == GFBE_MARGIN_NONE) is IN/OUT like last_marginalization_info: when a marginalisation
  * ran — margin_flag != GFBE_MARGIN_NONE and the window is full (frame_count == GFBE_WINDOW_SIZE, estimator.cpp:3391) — it
  * receives the new prior with block ids already shifted (slot i -> i-1 for MARGIN_OLD; slot 10 -> 9 for SECOND_NEW), `valid`

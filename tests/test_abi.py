@@ -41,6 +41,25 @@ def test_struct_layouts_match_header(lib):
         assert getattr(o, f) == getattr(d, f), f
 
 
+def test_options_struct_size_is_checked(lib):
+    """gfbe_options.struct_size: gfbe_default_options writes the library's sizeof, gfbe_options_size returns it, and
+    gfbe_create refuses a struct of another size instead of reading past it."""
+    lib.gfbe_options_size.restype = abi.c_i
+    assert lib.gfbe_options_size() == C.sizeof(abi.Options)
+    o = abi.Options()
+    lib.gfbe_default_options(C.byref(o))
+    assert o.struct_size == C.sizeof(abi.Options) == abi.default_options().struct_size
+    lib.gfbe_create.restype = abi.c_i
+    lib.gfbe_last_error.restype = C.c_char_p
+    for size, want in ((o.struct_size, abi.OK), (o.struct_size - 4, abi.BAD_INPUT), (0, abi.BAD_INPUT)):
+        o.struct_size = size
+        ctx = C.c_void_p()
+        assert lib.gfbe_create(C.byref(ctx), -1, C.byref(o)) == want
+        if want != abi.OK:
+            assert b"ABI mismatch" in lib.gfbe_last_error(ctx)
+        lib.gfbe_destroy(ctx)
+
+
 class HostOnly(abi.CApi):
     prefix = "gfbe_"
 

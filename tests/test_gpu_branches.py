@@ -220,6 +220,38 @@ def test_a_failing_window_is_its_own_failure_inside_a_batch(reps, split):
         be.close()
 
 
+def test_failure_contract_of_solve_window(be):
+    """include/gfbe.h, "FAILURE CONTRACT" (VERDICT round 5 item 9), through gfbe_solve_window itself: a FAILED CALL (status >= GFBE_BAD_INPUT)
+    touches no output — state, inverse depths, the in-out prior and the summary keep the caller's bytes —, a numerically failed SOLVE
+    (GFBE_NUMERICAL_FAILURE) has written all of them."""
+    import ctypes as C
+    snap = synth.Scenario(seed=9, n_landmarks=100, use_wheel=True).window(0)
+
+    def call(s, flag):
+        wh = abi.WindowHolder(s)
+        st, pr, sm = abi.State(), abi.PriorHolder(), abi.Summary()
+        feat = np.full(wh.n_feature, -7.25)
+        C.memset(C.byref(st), 0x5A, C.sizeof(st))
+        C.memset(C.byref(sm), 0x5A, C.sizeof(sm))
+        pr.c.valid = 0
+        pr.c.n = 12345
+        f = be._fn("solve_window")
+        f.restype = abi.c_i
+        rc = f(be.head, C.byref(wh.c), int(flag), C.byref(st), abi._pd(feat), C.byref(pr.c), C.byref(sm))
+        return rc, bytes(st), feat, pr, bytes(sm)
+
+    rc, st, feat, pr, sm = call(snap, 7)                  # margin_flag out of range: the call fails
+    assert rc >= abi.BAD_INPUT
+    assert st == b"\x5a" * len(st) and sm == b"\x5a" * len(sm) and np.all(feat == -7.25) and pr.c.n == 12345 and pr.c.valid == 0
+    nan = dict(snap, pose=snap["pose"].copy())
+    nan["pose"][4, 1] = np.nan
+    rc, st, feat, pr, sm = call(nan, abi.MARGIN_OLD)      # the solve runs and fails numerically: everything is written
+    assert rc == abi.NUMERICAL_FAILURE
+    assert st != b"\x5a" * len(st) and sm != b"\x5a" * len(sm) and not np.any(feat == -7.25) and pr.c.n != 12345
+    rc, st, feat, pr, sm = call(snap, abi.MARGIN_OLD)     # and a good one
+    assert rc in (abi.OK, abi.NO_CONVERGENCE) and pr.c.valid == 1 and not np.any(feat == -7.25)
+
+
 def _first_factor_only(snap):
     """Every landmark keeps the first of its factors: tracks of two observations, the shortest a factor can be built from."""
     s = dict(snap)
