@@ -146,7 +146,7 @@ class Options(C.Structure):
                 ("parameter_tolerance", c_d), ("min_relative_decrease", c_d), ("jacobi_scaling", c_i),
                 ("marg_eps", c_d), ("marg_sqrt", c_i), ("use_graph", c_i), ("split_batch", c_i),
                 ("max_solver_time_in_seconds", c_d), ("host_threads", c_i), ("solve_kernel", c_i),
-                ("test_fail_chol_iter", c_i), ("test_fail_chol_count", c_i), ("sharded_mu_retries", c_i), ("speculative_linearization", c_i)]
+                ("test_fail_chol_iter", c_i), ("test_fail_chol_count", c_i), ("sharded_mu_retries", c_i), ("speculative_linearization", c_i), ("merge_lin_schur", c_i)]
 
 
 class Summary(C.Structure):
@@ -186,6 +186,7 @@ def default_options():
     o.test_fail_chol_count = 1
     o.sharded_mu_retries = 1
     o.speculative_linearization = 1
+    o.merge_lin_schur = 0
     return o
 
 

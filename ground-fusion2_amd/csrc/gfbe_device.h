@@ -259,6 +259,9 @@ struct BatchDev {
   double *pair_part;          // [B][NF][VP_STRIDE]   marginalisation: X^T X of the pose pairs (0, j), slot j (sum of vis_part over the tiles of start frame 0)
   double *vis_part;           // [B][max_tiles][MAXOBS][VP_STRIDE]  X^T X of the 64 factors of one tile at one step, X = [J | r]
   double *schur_part;         // [B][schur_groups][SCHUR_STRIDE]  sum over the landmarks of one group of start frames
+  double *schur_part2;        // the second set's (k_linschur<SPEC>: the landmark elimination of the candidate's linearisation; nullptr without it)
+  int linschur;               // throughput batch with constant extrinsic / td, not sharded: k_linschur (evaluation + landmark elimination in one
+                              // launch) in the place of k_vis<0, false> + k_schur (gfbe_options.merge_lin_schur)
   int schur_groups;           // SCHUR_GROUPS for throughput batches; small batches: 2 NF (two workgroups per start frame), NF when sharded
   double *imu_part, *wheel_part;     // [B][MAX_IMU][IMU_PART], [B][MAX_WHEEL][WHEEL_PART]
   double *plane_part, *anchor_part;  // [B][MAX_PLANE][PLANE_PART], [B][ANCHOR_PART]   (only read for windows with n_plane / use_anchor)
@@ -365,6 +368,7 @@ void launch_pair_schur_marg(const BatchDev &d, hipStream_t s);   // small batche
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse = 0);   // fuse (mode 1): bit 1 candidate tiles first, bit 2 k_accept last
 void launch_dense_factors(const BatchDev &d, int mode, int debug_out, hipStream_t s, int spec = 0);
 void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock = 0);   // with_visblock: k_schur_visblock_small
+void launch_linschur(const BatchDev &d, int spec, int gate_mu, hipStream_t s);            // BatchDev::linschur: k_vis<0, false> + k_schur in one launch
 void launch_visblock(const BatchDev &d, hipStream_t s);
 void launch_lio_window(const BatchDev &d, int mode, hipStream_t s, int spec = 0);
 void launch_assemble(const BatchDev &d, hipStream_t s);

@@ -75,6 +75,7 @@ __device__ __forceinline__ BatchDev lin_view(const BatchDev &d, const int lb) {
     v.lm_Hll = d.lm_Hll2; v.lm_gl = d.lm_gl2; v.lm_hC = d.lm_hC2; v.lm_hP = d.lm_hP2; v.lm_sw = d.lm_sw2; v.vis_part = d.vis_part2;
     v.imu_part = d.imu_part2; v.wheel_part = d.wheel_part2; v.plane_part = d.plane_part2; v.anchor_part = d.anchor_part2; v.prior_g = d.prior_g2;
     v.lio_part = d.lio_part2; v.gnss_J = d.gnss_J2; v.gnss_r = d.gnss_r2; v.gnss_cost = d.gnss_cost2;
+    if (d.schur_part2) v.schur_part = d.schur_part2;      // (k_linschur: the landmark elimination belongs to the set)
   }
   return v;
 }

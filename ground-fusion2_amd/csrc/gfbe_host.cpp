@@ -249,6 +249,7 @@ void gfbe_default_options(gfbe_options *o) {
   o->solve_kernel = 0;                       // chain-eliminated factorisation of the reduced system (k_solve_chain_tw below 32 windows, k_solve_chain from there)
   o->test_fail_chol_iter = 0; o->test_fail_chol_count = 1;
   o->speculative_linearization = 1;
+  o->merge_lin_schur = 0;                    // 1: throughput batches run k_linschur (evaluation + landmark elimination in one launch) — measured slower, include/gfbe.h
   o->sharded_mu_retries = 1;                 // (8 = DoglegStrategy's whole mu ladder; every retry is three more launches per linearisation)
 }
 
@@ -825,6 +826,8 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   // dense-factor / LiDAR / GNSS launches (no all-reduce hook) get a second set of the linearisation's outputs
   d.spec = (c->opt.speculative_linearization && !c->allreduce && max_tiles > 0 &&
             (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 2))) ? 1 : 0;
+  // k_linschur (gfbe_options.merge_lin_schur): throughput batches on the 7 x 7 panel, every tile on this rank
+  d.linschur = (c->opt.merge_lin_schur && B >= DENSE_SPLIT_MIN_B && !d.vis_full && !c->allreduce && max_tiles > 0) ? 1 : 0;
   const size_t TL = tot_lm;
   const size_t pj_row = (size_t)pn_max * pn_max;   // J0 of the priors travels compactly: rows of pn_max^2 doubles, spread into the ND^2 slots on the device
   const double T1 = now();
@@ -892,7 +895,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       AL(imu_part2, (size_t)B * MAX_IMU * IMU_PART); AL(wheel_part2, (size_t)B * MAX_WHEEL * WHEEL_PART);
       AL(plane_part2, d.any_plane ? (size_t)B * MAX_PLANE * PLANE_PART : 1); AL(anchor_part2, d.any_plane ? (size_t)B * ANCHOR_PART : 1);
       AL(prior_g2, (size_t)B * (ND + 2)); AL(lio_part2, (size_t)B * LIOW_WGS * LIOW_PART);
+      if (d.linschur) { AL(schur_part2, (size_t)B * d.schur_groups * SCHUR_STRIDE); } else d.schur_part2 = nullptr;
     } else {
+      d.schur_part2 = nullptr;
       d.lm_Hll2 = d.lm_gl2 = d.lm_hC2 = d.lm_sw2 = d.imu_part2 = d.wheel_part2 = d.plane_part2 = d.anchor_part2 = d.prior_g2 = d.lio_part2 = nullptr;
     }
     AL(tile_cost, (size_t)B * std::max(max_tiles, 1)); AL(tile_cand, (size_t)B * std::max(max_tiles, 1) * 4);
@@ -1368,12 +1373,17 @@ static void enqueue_linearize(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, bool f
   if (have_lin) { }
   else if (small) launch_lin_small(d, 0, ln.s);
   else {
-    { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
+    if (d.linschur) { Timed t(c, first ? "k_linschur_iter0" : "k_linschur", b->algo_bytes_lin); launch_linschur(d, 0, 0, ln.s); }
+    else { Timed t(c, first ? "k_vis_lin_iter0" : "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s); }
     if (!overlap) { Timed t(c, "k_dense", 0); launch_dense_factors(d, 0, 0, ln.s); }
   }
   if (d.tot_lio > 0 && !have_lin) { Timed t(c, "k_lio_window", 0); launch_lio_window(d, 0, ln.s); }
   const int fuse = small_fuse(c, d);
-  { Timed t(c, first ? "k_schur_iter0" : "k_schur", 0); launch_schur(d, 0, ln.s, fuse & 1); }
+  if (d.linschur) {
+    // (the landmark elimination ran with the evaluation. have_lin: the candidate's pass did both; what is left is the window whose set was
+    //  formed with another mu — after an invalid step — and is evaluated again: the gated launch)
+    if (have_lin) { Timed t(c, "k_linschur_gate", 0); launch_linschur(d, 0, 1, ln.s); }
+  } else { Timed t(c, first ? "k_schur_iter0" : "k_schur", 0); launch_schur(d, 0, ln.s, fuse & 1); }
   if (d.vis_Hs && !(fuse & 1)) { Timed t(c, first ? "k_visblock_iter0" : "k_visblock", 0); launch_visblock(d, ln.s); }   // (throughput batches: inside k_visasm, below)
   if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);   // join
   { Timed t(c, first ? "k_assemble_iter0" : "k_assemble", 0); launch_assemble(d, ln.s); }
@@ -1431,6 +1441,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     }
     const bool small = !c->profiling && d.B < DENSE_SPLIT_MIN_B;
     if (small) launch_lin_small(d, lin_cand ? 3 : 1, ln.s, fuse);
+    else if (lin_cand && d.linschur) { Timed t(c, "k_linschur", b->algo_bytes_lin); launch_linschur(d, 1, 0, ln.s); }
     else if (lin_cand) { Timed t(c, "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s, 0, 1); }
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, lin_cand ? "k_lio_window" : "k_lio_window_cost", 0); launch_lio_window(d, lin_cand ? 0 : 1, ln.s, lin_cand); }

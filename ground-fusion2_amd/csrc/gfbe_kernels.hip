@@ -1792,6 +1792,308 @@ __global__ __launch_bounds__(256, GFBE_SCHUR_WGS) void k_schur(BatchDev d0, int 
   const BatchDev d = marg ? d0 : lin_view(d0, d0.ctl[blockIdx.x].lb);
   schur_body(d, marg, blockIdx.x, blockIdx.y);   // group-major dispatch: the heavy first group of every window first
 }
+// =============================================================================================
+// k_linschur (round 6): the linearisation of the visual factors AND the landmark elimination of
+// a throughput batch in ONE launch — k_vis<0, false> + k_schur(solve) — one workgroup per (window, group of start frames), four waves.
+// The two kernels exchanged every factor's d = G^T w through HBM (lm_hP: 24 B per factor written by one, re-read by the other; 465 MB + 465 MB
+// per 2048 windows) and every landmark's [D | x | g_l | sqrt(w_l)]; here a tile's rows go from the evaluating lanes' registers straight
+// into the LDS panel the matrix cores multiply. Per landmark tile (64 landmarks of one start frame, lane = landmark in EVERY wave):
+//   evaluate   role q takes the observation steps k = q, q + 4, q + 8 (one pose pair each): visual_lin_y per factor, the 7 x 7
+//              [Y r]^T [Y r] of the step's 64 factors on the matrix cores through the wave's own 64 x 17 panel (which lives INSIDE the
+//              Schur panel's storage: the two are never live together), d_k kept in registers; the wave's share of H_ll, g_l, D, cost
+//   barrier A  the four shares summed in ROLE order by every wave for its lane (same bits in all four); sqrt(w_l); role 2 stores the
+//              per-landmark outputs k_lm_step / k_candidate read (H_ll, g_l, D, x, s_l, sqrt(w_l)) and the tile's cost
+//   stage      every wave writes the H_pl blocks of ITS steps — sqrt(w_l) [ -d ; R_j^T (d x (x - t_j)) ] from registers — into the 64 x 75
+//              panel (compact columns, exactly k_schur's), role 3 (the fewest steps) the start pose's block, the gradient column and the zeros
+//   barrier B  multiply: the <= 15 tile pairs dealt over the waves as in k_schur, accumulators in registers across the group's tiles
+//   barrier C  (the next tile's evaluation overwrites the panel)
+// Same quantities as the two kernels; the landmark sums are added in another order (per role, then over the roles), so H_ll, g_l, D move
+// in their last bits against k_vis<0> — the small-batch kernel set and the 20-column / sharded paths keep the old kernels, compared at
+// tolerance like every other pair of kernel sets (tests/test_gpu_linschur.py).
+// d_k still goes to lm_hP (one write, one read by k_lm_step; the slow E rebuild of a mu retry reads it too) — see WRITE_D.
+// SPEC: the linearisation at the candidate, into the other set of outputs (vis_body's SPEC); the Schur partial then belongs to that set
+// too (schur_part2, lin_view). gate_mu (not SPEC; batches with the second set): the launch in front of every later iteration — only
+// the windows whose current set was formed with another mu than the window's (after TrustRegionMinimizer::HandleInvalidStep: mu x 10
+// on the same linearisation) are evaluated again; k_visasm records the mu of a set that is about to be solved (WinCtl::sw_mu).
+// MEASURED SLOWER than the two kernels (profiles/r6_linschur_ab.txt; gfbe_options.merge_lin_schur is 0 by default): neither kernel
+// is bound by the traffic the merge removes.
+// =============================================================================================
+#ifndef GFBE_LINSCHUR_WGS
+#define GFBE_LINSCHUR_WGS 3
+#endif
+#ifndef GFBE_LINSCHUR_WRITE_D
+#define GFBE_LINSCHUR_WRITE_D 1
+#endif
+#define LS_XLD 17
+template <bool SPEC>
+__global__ __launch_bounds__(256, GFBE_LINSCHUR_WGS) void k_linschur(BatchDev d0, int head_in, int gate_mu) {
+  const int w = blockIdx.x;
+  // heavy groups first: {0, 1}, {3, 4, 5}, {2}, {6 .. 10}
+  const int grp = blockIdx.y == 1 ? 2 : (blockIdx.y == 2 ? 1 : (int)blockIdx.y);
+  const WinCtl &c = d0.ctl[w];
+  if (c.done) return;
+  if (SPEC) { if (!c.have_step) return; }
+  else { if (c.reuse) return; if (gate_mu && c.sw_mu[c.lb] == c.mu) return; }
+  const int lbw = SPEC ? 1 - c.lb : c.lb;
+  const BatchDev d = lin_view(d0, lbw);
+  const WinDesc &ds = d.desc[w];
+  const int s_first = schur_group_first(grp, SCHUR_GROUPS), s_end = grp == SCHUR_GROUPS - 1 ? (int)NF : schur_group_first(grp + 1, SCHUR_GROUPS);
+  const int tb = ds.sf_tile_begin[s_first], te = ds.sf_tile_begin[s_end];
+  if (tb >= te) return;      // (the partial stays the zero of the upload, in both sets)
+  __shared__ double hs[LM_TILE * HS_LD + 8];      // the Schur panel; during the evaluation: the four waves' [Y r] panels (4 x 64 x 17 doubles)
+  static_assert(4 * LM_TILE * LS_XLD <= LM_TILE * HS_LD + 8, "the evaluation panels live inside the Schur panel");
+  __shared__ double Psum[4][5][LM_TILE];
+  __shared__ double Pcost[4];
+  __shared__ PairConstY pcs[NF];
+  __shared__ FrameConst fcs;
+  __shared__ double s_rt[NF][12];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  // ROLES, not waves: which observation steps / tile pairs a wave takes rotates with the window (and, for the evaluation, with the tile).
+  // Wave q of every workgroup sits on SIMD q, and role 0 is the heaviest one (steps 0, 4, 8; the first pair of every four): without the
+  // rotation SIMD 0 of a CU carries the heavy role of all its workgroups. Every sum is taken in ROLE order, so nothing depends on it.
+  // (Measured: no effect, 347 -> 342 us per 512 windows.)
+  const int rot = __builtin_amdgcn_readfirstlane((int)(((unsigned)w * 0x9E3779B1u) >> 20) + grp);
+  const int mr = (wv + rot) & 3;
+  const size_t TL = d.tot_lm;
+  const int cur = c.cur;      // (every field of the control block is read ONCE, here: a load behind the loop's stores would wait for them)
+  const int buf = SPEC ? 1 - cur : cur;
+  const double *X = d.x + ((size_t)w * 2 + buf) * NA;
+  const double *pcw = d.pc + ((size_t)w * 3 + buf) * NPAIR * PC_DOUBLES;
+  const bool chead = SPEC && head_in;
+  const double c1 = c.c1, c2 = c.c2;
+  const bool first = !SPEC && c.iter == 0;
+  const double mu_w = SPEC ? mu_after_accept(c.mu) : c.mu;
+  const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
+  const int jac_scale = d.opt.jacobi_scaling;
+  const double td = X[A_TD];
+  int sfb[NF + 1];
+#pragma unroll
+  for (int q = 0; q <= NF; q++) sfb[q] = ds.sf_tile_begin[q];
+  const int lm_off_c = ds.lm_off;
+  if (t < NF * 12) s_rt[t / 12][t % 12] = pcw[(size_t)(t / 12) * (NF + 1) * PC_DOUBLES + LM_RT_OFF + t % 12];
+  // ---- Schur side: this wave's tile pairs (compact panel, pairs numbered column-major: k_schur)
+  const int coff = 1 - 6 * s_first;
+  const int nside = (1 + 6 * (NF - s_first) + 15) / 16, npairs = nside * (nside + 1) / 2;
+  int pI[4], pJ[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int idx = 4 * q + mr;
+    pI[q] = -1; pJ[q] = -1;
+    if (idx < npairs) { int J = 0; while ((J + 1) * (J + 2) / 2 <= idx) J++; pJ[q] = J; pI[q] = idx - J * (J + 1) / 2; }
+  }
+  dbl4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  const int lr = lane & 15, lk = lane >> 4;
+  double *const xs = hs + (size_t)wave * (LM_TILE * LS_XLD);
+  // ---- what a lane holds of a tile before its evaluation (the NEXT tile's is requested before the current one is multiplied)
+  int p_info;
+  double p_pt[3], p_lam, p_sl = 1.0, p_vl = 0.0, p_yl = 0.0, p_ob[3][2];
+#define LS_PREFETCH(TILE)                                                                                           \
+  {                                                                                                                  \
+    const int er_ = (wv + rot + (TILE)) & 3;                                                                         \
+    const int tile_ = min((TILE), te - 1);                                                                           \
+    const int slot_ = lm_off_c + tile_ * LM_TILE + lane;                                                             \
+    p_info = d.lm_info[slot_];                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < 3; q++) p_pt[q] = d.lm_pts[(size_t)q * TL + slot_];                        \
+    p_lam = d.lam[(size_t)(chead ? cur : buf) * TL + slot_];                                                         \
+    if (chead) { p_vl = d.lm_vl[slot_]; p_yl = d.lm_yl[slot_]; }                                                     \
+    if (!first) p_sl = d.lm_sl[slot_];                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 3; u++) {                                                                  \
+      const int k_ = min(er_ + 4 * u, (int)MAXOBS - 1);                                                              \
+      p_ob[u][0] = d.lm_obs[((size_t)k_ * 5 + 0) * TL + slot_];                                                      \
+      p_ob[u][1] = d.lm_obs[((size_t)k_ * 5 + 1) * TL + slot_];                                                      \
+    }                                                                                                                \
+  }
+  LS_PREFETCH(tb)
+  int cur_sf = -1;
+  for (int tile = tb; tile < te; tile++) {
+    int sf = s_first;
+#pragma unroll
+    for (int q = 1; q < NF; q++) sf += (q > s_first && q < s_end && tile >= sfb[q]) ? 1 : 0;
+    if (sf != cur_sf) {      // pair records (sf, j), j > sf, and the start frame's own constants (nobody reads them during a multiply)
+      const double *src = pcw + (size_t)sf * NF * PC_DOUBLES;
+      for (int e = t; e < (NF - 1 - sf) * (int)PCY_DOUBLES; e += 256) {
+        const int j = sf + 1 + e / (int)PCY_DOUBLES, q = e % (int)PCY_DOUBLES;
+        ((double *)&pcs[j])[q] = src[(size_t)j * PC_DOUBLES + q];
+      }
+      if (t < (int)FC_DOUBLES) ((double *)&fcs)[t] = src[(size_t)sf * PC_DOUBLES + t];
+      cur_sf = sf;
+    }
+    __syncthreads();      // (C: the previous tile's multiply is over — the panel's storage is free; the records are staged)
+    const int er = (wv + rot + tile) & 3;      // this wave's role in the tile's evaluation
+    const int slot = lm_off_c + tile * LM_TILE + lane;
+    const int info = p_info;
+    const bool valid = (info >> 24) & 1;
+    const int m = valid ? ((info >> 8) & 0xff) : 0;
+    const bool is_const = (info >> 16) & 1;
+    int mmax = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
+    mmax = __builtin_amdgcn_readfirstlane(mmax);
+    double lam = p_lam;
+    const double sl_old = p_sl;
+    if (chead) {      // x_cand = x + s_l (c1 v_l + c2 y_l): candidate_tile's arithmetic (every wave forms it, role 0 stores it)
+      double d2, n2;
+      lam = candidate_lm(lam, sl_old, p_vl, p_yl, c1, c2, valid && !is_const && m > 0, d2, n2);
+      if (er == 0) {
+        d.lam[(size_t)(1 - cur) * TL + slot] = lam;
+        d2 = wave_sum(d2); n2 = wave_sum(n2);
+        if (lane == 0) { double *o = d.tile_cand + ((size_t)w * d.max_tiles + tile) * 4; o[1] = d2; o[2] = n2; }
+      }
+    }
+    const double yinv_l = 1.0 / lam;
+    const double ycx = p_pt[0] * yinv_l, ycy = p_pt[1] * yinv_l, ycz = p_pt[2] * yinv_l;
+    vec3 yf, yx;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      yf[a] = __builtin_fma(fcs.W(a, 0), ycx, __builtin_fma(fcs.W(a, 1), ycy, fcs.W(a, 2) * ycz));
+      yx[a] = (yf[a] + fcs.wt[a]) + fcs.dPc[a];      // from the window's origin P_0
+    }
+    double *xr = xs + lane * LS_XLD;
+    xr[7] = 0.0; xr[15] = 0.0;
+    double Hq = 0.0, gq = 0.0, Dq[3] = {0.0, 0.0, 0.0}, cq = 0.0, dk[3][3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+      dk[u][0] = 0.0; dk[u][1] = 0.0; dk[u][2] = 0.0;
+      const int k = er + 4 * u;
+      if (k < mmax) {      // (wave-uniform)
+        if (k < m) {
+          double r[2], g0[3], g1[3], Jl[2];
+          cq += visual_lin_y(pcs[sf + 1 + k], ycx, ycy, ycz, yf, yinv_l, td, p_ob[u][0], p_ob[u][1], 0.0, 0.0, td, sq, delta, r, g0, g1, Jl);
+          const vec3 y0 = cross3(mk3(g0[0], g0[1], g0[2]), yx), y1 = cross3(mk3(g1[0], g1[1], g1[2]), yx);
+          const double w0 = is_const ? 0.0 : Jl[0], w1 = is_const ? 0.0 : Jl[1];
+#pragma unroll
+          for (int q = 0; q < 3; q++) dk[u][q] = __builtin_fma(g0[q], w0, g1[q] * w1);      // d = G^T w
+          Hq += __builtin_fma(w0, w0, w1 * w1);
+          gq += __builtin_fma(w0, r[0], w1 * r[1]);
+#pragma unroll
+          for (int q = 0; q < 3; q++) Dq[q] += dk[u][q];
+#pragma unroll
+          for (int q = 0; q < 3; q++) { xr[q] = g0[q]; xr[3 + q] = y0[q]; xr[8 + q] = g1[q]; xr[11 + q] = y1[q]; }
+          xr[6] = r[0]; xr[14] = r[1];
+          if (GFBE_LINSCHUR_WRITE_D) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = dk[u][q];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 7; q++) { xr[q] = 0.0; xr[8 + q] = 0.0; }
+        }
+        dbl4_t a0 = {0, 0, 0, 0};
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int blk = 0; blk < LM_TILE / 4 / 8; blk++) {
+          double va[8];
+#pragma unroll
+          for (int v = 0; v < 8; v++) va[v] = xs[(4 * (8 * blk + v) + lk) * LS_XLD + lr];
+#pragma unroll
+          for (int v = 0; v < 8; v++) a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[v], va[v], a0, 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double s0 = a0[0] + __shfl_down(a0[2], 8, 64), s1 = a0[1] + __shfl_down(a0[3], 8, 64);
+        double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VPY_STRIDE;
+        if (lr < 7) {
+          { const int a = lk; if (a <= lr) vo[7 * a - a * (a - 1) / 2 + lr - a] = s0; }
+          { const int a = lk + 4; if (a <= lr) vo[7 * a - a * (a - 1) / 2 + lr - a] = s1; }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    Psum[er][0][lane] = Hq; Psum[er][1][lane] = gq;
+#pragma unroll
+    for (int q = 0; q < 3; q++) Psum[er][2 + q][lane] = Dq[q];
+    cq = wave_sum(cq);
+    if (lane == 0) Pcost[er] = cq;
+    __syncthreads();      // (A: every wave is done with its evaluation panel; the shares are visible)
+    double Hll, gl, Dv[3];
+    Hll = ((Psum[0][0][lane] + Psum[1][0][lane]) + Psum[2][0][lane]) + Psum[3][0][lane];
+    gl = ((Psum[0][1][lane] + Psum[1][1][lane]) + Psum[2][1][lane]) + Psum[3][1][lane];
+#pragma unroll
+    for (int q = 0; q < 3; q++) Dv[q] = ((Psum[0][2 + q][lane] + Psum[1][2 + q][lane]) + Psum[2][2 + q][lane]) + Psum[3][2 + q][lane];
+    // the landmark's weight in the Schur term (vis_body's expression), once per landmark, the same bits in the four waves
+    double sl = 1.0, sw = 0.0;
+    if (valid && m > 0 && !is_const) {
+      sl = first ? (jac_scale ? 1.0 / (1.0 + sqrt(Hll)) : 1.0) : sl_old;
+      const double hs2 = sl * sl * Hll;
+      sw = sqrt(sl * sl / (hs2 + mu_w * clamp_diag(hs2)));
+    }
+    if (er == 2) {      // (a light role: two steps at most)
+      if (valid) {
+        if (first) d.lm_sl[slot] = sl;
+        d.lm_sw[slot] = sw;
+        d.lm_Hll[slot] = Hll;
+        d.lm_gl[slot] = gl;
+#pragma unroll
+        for (int q = 0; q < 3; q++) { d.lm_hC[(size_t)q * TL + slot] = Dv[q]; d.lm_hC[(size_t)(3 + q) * TL + slot] = yx[q]; }
+      }
+      if (lane == 0) {
+        const double cost = ((Pcost[0] + Pcost[1]) + Pcost[2]) + Pcost[3];
+        if (SPEC) d.tile_cand[((size_t)w * d.max_tiles + tile) * 4] = cost;
+        else d.tile_cost[(size_t)w * d.max_tiles + tile] = cost;
+        if (SPEC && d.spec && tile == 0) d.ctl[w].sw_mu[lbw] = mu_w;
+      }
+    }
+    // ---- stage the panel row of the lane's landmark: this wave's observing poses; role 3 the common columns
+    {
+      const int s = sf, kmax = NF - 1 - s;
+      double *row = hs + lane * HS_LD + coff;
+      const double xl[3] = {yx[0], yx[1], yx[2]};
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int k = er + 4 * u;
+        if (k < kmax) {
+          const bool written = valid && k < m;
+          double blkk[6];
+          lm_row_block(s_rt[s + 1 + k], dk[u], xl, false, blkk);      // [ -d ; Rj^T (d x (x - t_j)) ]
+#pragma unroll
+          for (int q = 0; q < 6; q++) row[6 * (s + 1 + k) + q] = written ? sw * blkk[q] : 0.0;
+        }
+      }
+      if (er == 3) {
+        for (int q = 6 * s_first; q < 6 * s; q++) row[q] = 0.0;
+        double blk0[6];
+        lm_row_block(s_rt[s], Dv, xl, true, blk0);                      // [ D ; Ri^T ((x - t_i) x D) ]
+#pragma unroll
+        for (int q = 0; q < 6; q++) { row[6 * s + q] = sw * blk0[q]; row[T_EX + q] = 0.0; }
+        row[T_TD] = 0.0;
+        row[-coff] = sw * gl;                                           // column 0: the gradient
+        for (int q = NV + coff; q < min(16 * nside, (int)HS_LD); q++) row[q - coff] = 0.0;
+      }
+    }
+    const int m0 = (__builtin_amdgcn_readfirstlane(info) >> 8) & 0xff;      // (tracks sorted longest first: the tile's first landmark)
+    const int jl = __builtin_amdgcn_readfirstlane((6 * (sf - s_first + m0 + 1)) >> 4);
+    __syncthreads();      // (B: the panel is complete)
+    LS_PREFETCH(tile + 1)      // (past the last tile: a repeat of it, never used)
+#define LS_SLOT(Q, ACC)                                                                                 \
+    if (pI[Q] >= 0 && pJ[Q] <= jl) {                                                                    \
+      const double *pa = hs + 16 * pI[Q] + lr + lk * HS_LD, *pb = hs + 16 * pJ[Q] + lr + lk * HS_LD;   \
+      _Pragma("unroll") for (int hf = 0; hf < 2; hf++) {                                                \
+        double va[LM_TILE / 8], vb[LM_TILE / 8];                                                        \
+        _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 8; kk++) { va[kk] = pa[4 * (8 * hf + kk) * HS_LD]; vb[kk] = pb[4 * (8 * hf + kk) * HS_LD]; } \
+        _Pragma("unroll") for (int kk = 0; kk < LM_TILE / 8; kk++) ACC = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], vb[kk], ACC, 0, 0, 0); \
+      }                                                                                                 \
+    }
+    LS_SLOT(0, acc0)
+    LS_SLOT(1, acc1)
+    LS_SLOT(2, acc2)
+    LS_SLOT(3, acc3)
+#undef LS_SLOT
+  }
+#undef LS_PREFETCH
+  double *out = d.schur_part + ((size_t)w * SCHUR_GROUPS + grp) * SCHUR_STRIDE;
+#define LS_OUT(Q, ACC)                                                            \
+  if (pI[Q] >= 0) {                                                               \
+    double *o = out + (size_t)(pJ[Q] * (pJ[Q] + 1) / 2 + pI[Q]) * 256;            \
+    _Pragma("unroll") for (int r = 0; r < 4; r++) o[(lk + 4 * r) * 16 + lr] = ACC[r]; \
+  }
+  LS_OUT(0, acc0)
+  LS_OUT(1, acc1)
+  LS_OUT(2, acc2)
+  LS_OUT(3, acc3)
+#undef LS_OUT
+}
+
 // Small batches, marginalisation: the pair sums (0, j) and the Schur partial of start frame 0 both read what the linearisation of the
 // marginalisation set left and nothing of each other: one launch (GFBE_FUSE_SMALL bit 3).
 __global__ __launch_bounds__(VP_STRIDE) void k_pairsum_schur_marg(BatchDev d) {
@@ -2606,6 +2908,9 @@ __global__ __launch_bounds__(VB_GROUP, GFBE_VISASM_WAVES) void k_visasm(BatchDev
   const BatchDev d = lin_view(d0, d0.ctl[w].lb);
   const WinCtl &c = d.ctl[w];
   if (c.done || c.reuse) return;
+  // (k_linschur batches with the second set: the set that is about to be solved was formed with the window's mu — the record k_linschur's
+  //  gate in front of the next iteration compares; written here, a launch later, because the workgroups of ONE k_linschur launch read it)
+  if (d.linschur && d.spec && threadIdx.x == 0) d.ctl[w].sw_mu[c.lb] = c.mu;
   __shared__ double V[NV * V_LD];
   __shared__ AsmTab tb;
   visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
@@ -3443,6 +3748,13 @@ void launch_schur(const BatchDev &d, int marg, hipStream_t s, int with_visblock)
   if (d.max_tiles == 0) return;
   if (with_visblock && !marg && d.vis_Hs) hipLaunchKernelGGL(k_schur_visblock_small, dim3(d.B, d.schur_groups + (d.vis_full ? (int)VS_BLOCKS : (int)NF)), dim3(VB_GROUP), 0, s, d);
   else hipLaunchKernelGGL(k_schur, dim3(d.B, marg ? 1 : d.schur_groups), dim3(256), 0, s, d, marg);
+}
+void launch_linschur(const BatchDev &d, int spec, int gate_mu, hipStream_t s) {
+  if (d.max_tiles == 0) return;
+  const dim3 g(d.B, SCHUR_GROUPS), b(256);
+  const int head = GFBE_FUSE_CAND ? 1 : 0;      // (the candidate's pass: its tiles form the candidate inverse depths first, as the cost pass's do)
+  if (spec) hipLaunchKernelGGL(k_linschur<true>, g, b, 0, s, d, head, 0);
+  else hipLaunchKernelGGL(k_linschur<false>, g, b, 0, s, d, 0, gate_mu);
 }
 void launch_xchg_gram(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_gram, dim3(d.B), dim3(64), 0, s, d); }
 void launch_xchg_cand(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_xchg_cand, dim3(d.B), dim3(64), 0, s, d); }

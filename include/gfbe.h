@@ -297,6 +297,16 @@ typedef struct gfbe_options {
    * factors (8192 resident windows: +10 % solves/s; a single window: one launch less per iteration, -3.5 %). Costs the second set:
    * ~1.5 MB per 2k-landmark window. 0 — cost pass and linearisation separately, as in rounds 1-4. */
   int32_t speculative_linearization;
+  /* Throughput batches (>= 32 windows) whose windows all hold the camera extrinsic and td constant, without an all-reduce hook:
+   * 1 — the visual factors are evaluated AND the landmarks eliminated by one kernel (k_linschur: one workgroup per window and group of
+   * start frames; a landmark tile's rows go from the evaluating lanes' registers into the LDS panel the matrix cores multiply, and are
+   * not re-read from HBM by a second kernel); 0 (default) — k_vis<0> + k_schur. Same quantities, the per-landmark sums added in
+   * another order (last bits). Built in round 6 because the two kernels exchange ~1.4 GB per 2048 windows; MEASURED SLOWER on MI355X
+   * (per 512 windows: 281 us at the first iteration against 133 + 143, 325 us at a candidate against 137 + 142; 8192 resident windows:
+   * 97k against 114k solves/s, profiles/r6_linschur_ab.txt): neither kernel was bound by that traffic, and one workgroup that
+   * alternates between the two phases behind three barriers per tile overlaps worse than two kernels that each fill the device.
+   * Kept as an option with its tests (tests/test_gpu_linschur.py); DESIGN.md section 4. */
+  int32_t merge_lin_schur;
 } gfbe_options;
 
 typedef struct gfbe_summary {

@@ -925,7 +925,7 @@ using namespace gfo;
 extern "C" {
 
 void gfo_default_options(gfbe_options *o) {
-  o->struct_size = (int32_t)sizeof(gfbe_options); o->speculative_linearization = 0;   // (device options; the second is meaningless on the CPU)
+  o->struct_size = (int32_t)sizeof(gfbe_options); o->speculative_linearization = 0; o->merge_lin_schur = 0;   // (device options; the second is meaningless on the CPU)
   o->max_num_iterations = 8; o->huber_delta = 1.0; o->vis_sqrt_info = 600.0 / 1.5; o->g_norm = 9.7944;
   o->initial_trust_region_radius = 1e4; o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8; o->min_relative_decrease = 1e-3; o->jacobi_scaling = 1; o->marg_eps = 1e-8;

@@ -11,7 +11,7 @@ import numpy as np, torch
 from _gfbe_import import gf
 abi, synth = gf.abi, gf.synth
 opt = abi.default_options(); opt.split_batch = 0
-be = gf.Backend(0, options=opt)
+be = gf.Backend(0, options=opt, so=os.environ.get("GFBE_LIB"))
 scns = [synth.Scenario(seed=20250708 + 2 + 100 * u, n_landmarks=2000, use_wheel=True) for u in range(8)]
 snaps = [s.window(0) for s in scns]
 B = int(os.environ.get("B", "512"))
@@ -26,5 +26,5 @@ for rep in range(3):
         b = 3 + 5 * k
         if t[b + 4] <= 0: break
         nxt = t[b + 5] if (k < 4 and t[b + 5] > 0) else t[30]
-        print("  step %d: eval %.2f  early-wait+hP stores %.2f  MFMA half0 %.2f  half1 %.2f  partial stores %.2f  (step total %.2f us)" % (
+        print("  step %d: eval + panel row %.2f  wait for the next observation %.2f  row stores + LDS operands + MFMA %.2f  fold + partial stores %.2f  to the next step %.2f  (step total %.2f us)" % (
             k, (t[b + 1] - t[b]) * 0.01, (t[b + 2] - t[b + 1]) * 0.01, (t[b + 3] - t[b + 2]) * 0.01, (t[b + 4] - t[b + 3]) * 0.01, (nxt - t[b + 4]) * 0.01, (nxt - t[b]) * 0.01))
