@@ -193,3 +193,42 @@ def test_dogleg_loop_fixture_is_what_the_numpy_loop_produces(oracle, name):
     np.testing.assert_allclose(r["mu_history"], ref[name + "_mu_history"], rtol=1e-12)
     if name == "free_masks":      # this case is in the set because it rejects steps: radius halvings with the linearisation kept
         assert 0 in r["accepted"][1:] and min(r["radius_history"]) < 1e4
+
+
+def test_divide_and_conquer_tridiagonal():
+    """tests/dc_eig_np.py — the numpy statement of the device's divide & conquer eigensolver (tridiag_dc, gfbe_marg.hip) — against
+    numpy.linalg.eigh: residual |T V - V L|, orthogonality |V^T V - I| and the eigenvalues to a few eps |T| on random tridiagonal
+    matrices of every size class, the tridiagonal form of 1e16-conditioned SPD matrices with a near-null space (what the marginalisation's
+    A' looks like), matrices that split (zero off-diagonals), clustered and multiple eigenvalues, Wilkinson's W21+."""
+    import dc_eig_np as dc
+    import scipy.linalg as sl
+    rng = np.random.default_rng(5)
+
+    def check(d, e):
+        n = len(d)
+        T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+        lam, V = dc.dc_eig(np.asarray(d, float), np.asarray(e, float))
+        nrm = max(np.abs(T).max(), 1e-300)
+        assert np.abs(T @ V - V * lam[None, :]).max() <= 2e-14 * nrm
+        assert np.abs(V.T @ V - np.eye(n)).max() <= 2e-14
+        assert np.abs(np.sort(lam) - np.linalg.eigvalsh(T)).max() <= 2e-14 * nrm
+
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 43, 86, 87, 90):
+        check(rng.normal(size=n), rng.normal(size=n - 1))
+    for n in (61, 86):
+        for _ in range(4):
+            U = np.linalg.qr(rng.normal(size=(n, n)))[0]
+            s = 10.0 ** rng.uniform(-9, 7, n)
+            s[:4] = 1e-10 * rng.uniform(0.01, 1, 4)
+            A = (U * s) @ U.T
+            H = sl.hessenberg(0.5 * (A + A.T))
+            check(np.diag(H).copy(), np.diag(H, -1).copy())
+    n = 86
+    check(np.ones(n), np.zeros(n - 1))
+    check(2 * np.ones(n), -np.ones(n - 1))
+    check(np.ones(n), 1e-9 * np.ones(n - 1))
+    e = rng.normal(size=n - 1)
+    e[::7] = 0.0
+    check(rng.normal(size=n), e)
+    check(np.abs(np.arange(-10, 11)).astype(float), np.ones(20))
+    check(np.concatenate([np.linspace(1, 2, 40), np.linspace(1, 2, 40) + 1e-13]), 1e-7 * rng.normal(size=79))

@@ -49,6 +49,9 @@ one = be.batch_upload([snap])
 for _ in range(3): one.solve(abi.MARGIN_OLD)
 torch.cuda.synchronize()
 tm = one.debug_timing(1)
-if tm[11] > tm[8] > 0:
+if tm[11] > tm[8] > 0 and tm[12] == 0:
+    print("tridiag_ql_eig: tridiagonalise %.1f us, accumulate Q %.1f us, divide & conquer + Q_dc^T Z %.1f us" % ((tm[9] - tm[8]) * 0.01, (tm[10] - tm[9]) * 0.01, (tm[11] - tm[10]) * 0.01))
+    print("  tridiag_dc, summed over its levels (us): leaves %.1f | z + rank sort %.1f | deflation scan %.1f | rotations + secular roots %.1f | zhat %.1f | norms %.1f | vectors %.1f | Q <- Q V %.1f" % tuple(tm[13 + q] * 0.01 for q in range(8)))
+elif tm[11] > tm[8] > 0:
     print("tridiag_ql_eig: tridiagonalise %.1f us, accumulate Q %.1f us, QL %.1f us (%d sweeps: %.2f us per sweep)" % (
         (tm[9] - tm[8]) * 0.01, (tm[10] - tm[9]) * 0.01, (tm[11] - tm[10]) * 0.01, int(tm[12]), (tm[11] - tm[10]) * 0.01 / max(tm[12], 1)))
