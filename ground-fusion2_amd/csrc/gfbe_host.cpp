@@ -824,8 +824,10 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   if (diag_getenv("GFBE_VIS_FULL")) d.vis_full = 1;   // (diagnostics build only: force the 20-column panel)
   // speculative linearisation (gfbe_options.speculative_linearization): batches whose candidate costs are all formed by the visual /
   // dense-factor / LiDAR / GNSS launches (no all-reduce hook) get a second set of the linearisation's outputs
-  d.spec = (c->opt.speculative_linearization && !c->allreduce && max_tiles > 0 &&
-            (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 2))) ? 1 : 0;
+  // (round 6: also with an all-reduce hook — the landmark-sharded solve: the candidate's pass linearises its own tiles, the ranks' candidate
+  //  costs travel as before; one evaluation pass less per iteration there too. The number of collectives per iteration stays: DESIGN.md section 7)
+  d.spec = (c->opt.speculative_linearization && max_tiles > 0 &&
+            (B >= DENSE_SPLIT_MIN_B || (GFBE_FUSE_SMALL & 2) || c->allreduce)) ? 1 : 0;
   // k_linschur (gfbe_options.merge_lin_schur): throughput batches on the 7 x 7 panel, every tile on this rank
   d.linschur = (c->opt.merge_lin_schur && B >= DENSE_SPLIT_MIN_B && !d.vis_full && !c->allreduce && max_tiles > 0) ? 1 : 0;
   const size_t TL = tot_lm;
@@ -1423,7 +1425,7 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
   // speculative linearisation (BatchDev::spec): every candidate pass but the last linearises at the candidate, into the second set of
   // outputs; an accepted step makes that set the current one and a rejected one keeps the old linearisation (DoglegStrategy's reuse)
   // — either way the next iteration needs no linearisation launch.
-  const bool spec = d.spec && (d.B >= DENSE_SPLIT_MIN_B || (small_fuse(c, d) & 2));      // (small batches: on the fused launch sequence only)
+  const bool spec = d.spec && (d.B >= DENSE_SPLIT_MIN_B || (small_fuse(c, d) & 2) || d.sharded);      // (small batches: on the fused launch sequence, or sharded — its launches are never fused)
   for (int it = 0; it < iters; it++) {
     enqueue_linearize(c, b, ln, it == 0, spec && it > 0);
     const int fuse = small_fuse(c, d);
