@@ -218,7 +218,7 @@ __device__ __forceinline__ void dc_secular_root8(const int i, const int k, const
   }
   const bool last = i == k - 1;
   const double di = dl[i], dn = last ? di : dl[i + 1];
-  double lo, hi, mu, dorig;
+  double lo, hi, mu, dorig, guess = 0.0;
   int o;
   if (!last) {
     const double mid = 0.5 * (dn - di);
@@ -228,6 +228,23 @@ __device__ __forceinline__ void dc_secular_root8(const int i, const int k, const
     f = 1.0 + rho * dc_group_sum(f);
     o = f >= 0.0 ? i : i + 1;
     lo = f >= 0.0 ? 0.0 : -mid; hi = f >= 0.0 ? mid : 0.0;
+    // first guess (dlaed4's idea): the two poles next to the root kept as they are, every other term frozen at the midpoint —
+    // C + rho z_i^2 / (D_i - x) + rho z_(i+1)^2 / (D_(i+1) - x) = 0 in the origin's coordinates; the root inside the bracket, if there is one
+    {
+      const double zi = zl[i], zn = zl[i + 1], S = rho * zi * zi, R = rho * zn * zn;
+      const double Di = o == i ? 0.0 : -(dn - di), Dj = o == i ? dn - di : 0.0, xm = o == i ? mid : -mid;
+      const double C = f - S / (Di - xm) - R / (Dj - xm);
+      const double qa = C, qb = -(C * (Di + Dj) + S + R), qc = C * Di * Dj + S * Dj + R * Di;
+      double x0 = xm;
+      if (qa != 0.0) {
+        double disc = qb * qb - 4.0 * qa * qc;
+        if (disc < 0.0) disc = 0.0;
+        const double sq = sqrt(disc), qq = -0.5 * (qb + (qb >= 0.0 ? sq : -sq));
+        const double x1 = qq / qa, x2 = qq != 0.0 ? qc / qq : x1;
+        x0 = (lo < x1 && x1 < hi) ? x1 : x2;
+      } else if (qb != 0.0) x0 = -qc / qb;
+      guess = (lo < x0 && x0 < hi) ? x0 : 0.5 * (lo + hi);
+    }
   } else {
     double z2s = 0.0;
 #pragma unroll
@@ -235,7 +252,7 @@ __device__ __forceinline__ void dc_secular_root8(const int i, const int k, const
     o = i; lo = 0.0; hi = rho * dc_group_sum(z2s);
   }
   dorig = o == i ? di : dn;
-  mu = 0.5 * (lo + hi);
+  mu = last ? 0.5 * (lo + hi) : guess;
   const double Dpi = di - dorig, Dpj = dn - dorig;      // the two poles next to the root, from the origin
   for (int it = 0; it < 80; it++) {
     double psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0;
@@ -286,7 +303,7 @@ __device__ void tridiag_dc(mlds_double *Q, mlds_double *Vt, const int n, const i
   double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = (stamp && threadIdx.x == 0) ? (long long)wall_clock64() : 0;
 #define DCSTAMP(i) do { if (stamp && threadIdx.x == 0) { const long long now_ = (long long)wall_clock64(); ph[i] += (double)(now_ - tprev); tprev = now_; } } while (0)
-  const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+  const int t = threadIdx.x, nt = blockDim.x;
   mlds_double *lam = wk, *Ds = lam + n, *zs = Ds + n, *dl = zs + n, *zl = dl + n, *mu = zl + n, *zh = mu + n, *rc = zh + n, *rs = rc + n;
   mlds_int *col = (mlds_int *)(rs + n), *cidx = col + n, *orig = cidx + n, *rp = orig + n, *rq = rp + n;
   __shared__ int s_k[64], s_nrot[64], s_trig[64];
@@ -506,35 +523,58 @@ __device__ void tridiag_dc(mlds_double *Q, mlds_double *Vt, const int n, const i
     }
     __syncthreads();
     DCSTAMP(6);
-    // ---- M8: Q <- Q V on the columns of the surviving poles, in place, a wave per row: lane u holds the row's old entries of the poles
-    // u and u + 64 (read through the column list ONCE), the loop broadcasts them by v_readlane — no dependent LDS load in it
-    for (int r = wave; r < n; r += nw) {
-      int q, a, b, c; dc_geom(r, L, n, q, a, b, c);
-      const int k = s_k[q];
-      if (k >= 2) {
-        const int i0 = lane, i1 = lane + 64;
-        const int c0 = i0 < k ? cidx[a + i0] : 0, c1 = i1 < k ? cidx[a + i1] : 0;
-        const double x0 = i0 < k ? Q[(size_t)r * ld + c0] : 0.0, x1 = i1 < k ? Q[(size_t)r * ld + c1] : 0.0;
-        const mlds_double *v0 = Vt + (size_t)a * ld + a + min(i0, k - 1), *v1 = Vt + (size_t)a * ld + a + min(i1, k - 1);
-        double acc0 = 0.0, acc1 = 0.0;
-        // (eight poles at a time: the sixteen LDS loads first, then the products; poles past k: the row's entry there is a zero —
-        //  x0 / x1 of the lanes >= k — and the load is clamped to the last pole)
-        for (int u0 = 0; u0 < k; u0 += 8) {
-          double va[8], vb[8];
+    // ---- M8: Q <- Q V on the columns of the surviving poles, in place: a 4 x 4 tile of (rows, roots) per thread in registers — a merge
+    // starts at a multiple of four, so no tile straddles two merges —, sixteen products per eight LDS loads; every tile is formed before
+    // any is written (a block barrier in between). (A wave per row with the products along its lanes: 94 us summed over the levels.)
+    {
+      const int nt4 = (n + 3) >> 2;
+      for (int e0 = 0; e0 < nt4 * nt4; e0 += nt) {
+        const int e = e0 + t;
+        double acc[4][4];
 #pragma unroll
-          for (int v = 0; v < 8; v++) { const size_t ro = (size_t)min(u0 + v, k - 1) * ld; va[v] = v0[ro]; vb[v] = v1[ro]; }
+        for (int x = 0; x < 4; x++)
 #pragma unroll
-          for (int v = 0; v < 8; v++) {
-            const int u = u0 + v;
-            const double x = u < 64 ? dc_lane_bcast(x0, u & 63) : dc_lane_bcast(x1, u & 63);
-            acc0 = __builtin_fma(x, va[v], acc0);
-            acc1 = __builtin_fma(x, vb[v], acc1);
+          for (int y = 0; y < 4; y++) acc[x][y] = 0.0;
+        int r0 = 0, i0 = 0, a = 0, c = 0, k = 0;
+        bool on = false;
+        if (e < nt4 * nt4) {
+          const int ty = e / nt4, tx = e - ty * nt4;
+          r0 = 4 * ty; i0 = 4 * tx;
+          int q, b; dc_geom(r0, L, n, q, a, b, c);
+          k = s_k[q];
+          on = b < n && k >= 2 && i0 >= a && i0 - a < k;
+        }
+        if (on) {
+          const mlds_double *qr[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) qr[x] = Q + (size_t)min(r0 + x, c - 1) * ld;
+          const mlds_double *vt = Vt + (size_t)a * ld + i0;
+          for (int u0 = 0; u0 < k; u0 += 2) {
+            const int u1 = min(u0 + 1, k - 1);
+            const int ca = cidx[a + u0], cb = cidx[a + u1];
+            double xa[4], xb[4], va[4], vb[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) { xa[x] = qr[x][ca]; xb[x] = qr[x][cb]; }
+#pragma unroll
+            for (int y = 0; y < 4; y++) { va[y] = vt[(size_t)u0 * ld + y]; vb[y] = vt[(size_t)u1 * ld + y]; }
+            const double wb = u0 + 1 < k ? 1.0 : 0.0;
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+              for (int y = 0; y < 4; y++) acc[x][y] = __builtin_fma(xb[x] * wb, vb[y], __builtin_fma(xa[x], va[y], acc[x][y]));
           }
         }
-        __threadfence_block();
-        __builtin_amdgcn_wave_barrier();
-        if (i0 < k) Q[(size_t)r * ld + c0] = acc0;
-        if (i1 < k) Q[(size_t)r * ld + c1] = acc1;
+        __syncthreads();
+        if (on) {
+#pragma unroll
+          for (int y = 0; y < 4; y++) {
+            if (i0 + y - a < k) {
+              const int co = cidx[i0 + y];
+#pragma unroll
+              for (int x = 0; x < 4; x++) if (r0 + x < c) Q[(size_t)(r0 + x) * ld + co] = acc[x][y];
+            }
+          }
+        }
       }
     }
     __syncthreads();
