@@ -225,3 +225,39 @@ def test_table_fed_large_batch_two_halves(be):
         np.testing.assert_array_equal(x["state"]["pose"], y["state"]["pose"])
         np.testing.assert_array_equal(x["prior"]["J0"], y["prior"]["J0"])
     tables.close()
+
+
+def test_small_table_fed_upload_right_behind_a_large_one(be):
+    """uploads of >= 32 table-fed windows pack on the copy stream, smaller ones on the main stream, and both use the tables'
+    shared histogram / layout / slot scratch. A 1-window upload issued right behind a 64-window one from the same tables — no table
+    operation in between that would have waited for the large batch's pack kernel — must not rewrite the scratch under it, and the other
+    way round: both batches bit for bit what they are when uploaded alone, several times in a row."""
+    W = 64
+    base = [gf.stream.Stream(seed=41 + q, n_kf=12, new_per_frame=14 + 9 * q) for q in range(4)]
+    streams = [base[w % 4] for w in range(W)]
+    tables = abi.FeatureTables(be.lib, "gfbe_", be.ctx, n_tables=W, capacity=1024)
+    _fill_tables(tables, streams)
+    win = [_stream_window(be, S) for S in base]
+    snaps = [win[w % 4][0] for w in range(W)]
+    tables.triangulate([win[w % 4][1] for w in range(W)], [win[w % 4][2] for w in range(W)], with_depth=False)
+
+    def run(b):
+        b.solve(abi.MARGIN_OLD)
+        r = b.download()
+        b.free()
+        return r
+
+    want_big = run(be.batch_upload_tables(tables, snaps))
+    want_one = run(be.batch_upload_tables(tables, snaps[:1]))
+    for rep in range(4):
+        big = be.batch_upload_tables(tables, snaps)            # copy stream
+        one = be.batch_upload_tables(tables, snaps[:1])        # main stream, straight behind it
+        big2 = be.batch_upload_tables(tables, snaps)           # and a large one straight behind the small one
+        got_one, got_big, got_big2 = run(one), run(big), run(big2)
+        for want, got in ((want_one, got_one), (want_big, got_big), (want_big, got_big2)):
+            for x, y in zip(want, got):
+                assert x["summary"] == y["summary"]
+                np.testing.assert_array_equal(x["feature"], y["feature"])
+                np.testing.assert_array_equal(x["state"]["pose"], y["state"]["pose"])
+                np.testing.assert_array_equal(x["prior"]["J0"], y["prior"]["J0"])
+    tables.close()
