@@ -3,7 +3,7 @@
 panel of the Schur product) instead of k_vis<0, false> + k_schur exchanging every factor's row through HBM. Same quantities, the
 per-landmark sums added in another order: compared with the two-kernel sequence at the tolerances the other pairs of kernel sets are
 compared at (tests/test_gpu_parity.py::test_large_batch_throughput_path), with the oracle through check_solve's bounds, bit for bit with
-itself (position in the batch, repeated solves, the parts of a split batch), and bit for bit between the two launch sequences it is part
+itself (position in the batch, repeated solves, the parts of a split batch), and to rounding between the two launch sequences it is part
 of (speculative_linearization on / off: the candidate's pass runs k_linschur<SPEC>, the other sequence k_linschur<false> every iteration),
 including the in-kernel mu retry (whose slow E rebuild reads the rows k_linschur still writes for k_lm_step)."""
 import numpy as np
@@ -14,6 +14,11 @@ from test_gpu_parity import window_with_prior
 
 abi, synth = gf.abi, gf.synth
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    return gf.Backend(device=0)
 
 
 def _backend(**kw):
@@ -91,17 +96,23 @@ def test_merged_launch_against_the_oracle(be, oracle):
 
 @pytest.mark.parametrize("kw", [{}, {"test_fail_chol_iter": 2}, {"test_fail_chol_iter": 1, "test_fail_chol_count": 3}, {"max_num_iterations": 3},
                                 {"max_num_iterations": 1}])
-def test_both_launch_sequences_bit_for_bit(oracle, kw):
-    """speculative_linearization off: k_linschur<false> in front of every iteration; on: once, then k_linschur<SPEC> at every candidate and
-    the gated launch in front of the later iterations."""
+def test_both_launch_sequences(oracle, kw):
+    """speculative_linearization off: k_linschur<false> in front of every iteration, the candidate's cost from the cost pass k_vis<1>; on:
+    k_linschur<false> once, then k_linschur<SPEC> at every candidate (the gated launch in front of the later iterations). The two
+    evaluate the same factors at the same states; what differs is the ORDER in which a tile's candidate cost is summed (k_vis<1>: per
+    lane over its steps; k_linschur: per role, then over the roles), so — unlike the two-kernel sequences, which are bit-identical — the
+    costs agree to rounding and everything discrete exactly."""
     snaps = _cases(oracle)
     big = [snaps[i % len(snaps)] for i in range(34)]
     got = []
     for spec in (0, 1):
         be = _backend(speculative_linearization=spec, **kw)
         got.append(be.solve_batch(big, abi.MARGIN_OLD) + be.solve_batch(big[:33], abi.MARGIN_SECOND_NEW))
+        again = be.solve_batch(big, abi.MARGIN_OLD)
+        assert all(_identical(a, b) for a, b in zip(got[-1], again))      # (each sequence repeats itself bit for bit)
         be.close()
-    assert all(_identical(a, b) for a, b in zip(*got))
+    for a, b in zip(*got):
+        _close(a, b)
 
 
 def test_split_batch_and_constant_landmarks(oracle):
