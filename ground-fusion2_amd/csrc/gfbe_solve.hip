@@ -1806,7 +1806,10 @@ if (!TW) {
   STAMP(5);
 #undef STAMP
 }
-__global__ __launch_bounds__(S2_THREADS, 2) void k_solve_chain(BatchDev d, int retry_pass) { solve_chain_body<0>(d, retry_pass); }
+#ifndef GFBE_CHAIN_MINBLOCKS
+#define GFBE_CHAIN_MINBLOCKS 2      // workgroups per CU the register allocation of k_solve_chain aims at (2: up to 256 VGPRs; its LDS allows no more than two)
+#endif
+__global__ __launch_bounds__(S2_THREADS, GFBE_CHAIN_MINBLOCKS) void k_solve_chain(BatchDev d, int retry_pass) { solve_chain_body<0>(d, retry_pass); }
 __global__ __launch_bounds__(2 * S2_THREADS, 2) void k_solve_chain_tw(BatchDev d, int retry_pass) { solve_chain_body<1>(d, retry_pass); }
 
 
