@@ -244,7 +244,11 @@ typedef struct gfbe_options {
   /* Square root of the marginalised information A' (marginalization_factor.cpp:294-302):
    *   0  eigen-decomposition, S > eps thresholding — the reference's construction
    *   1  diagonally pivoted LDL^T with pivots > eps — same J0^T J0 / J0^T r0 up to O(n*eps) absolute
-   *      (1e-14 relative to |A'|), ~100x cheaper on the device. Default. */
+   *      (1e-14 relative to |A'|); the cheaper one on the device: 0.09 ms of a 1.15 ms call, where mode 0 — Householder
+   *      tridiagonalisation + divide & conquer since round 6 — takes 0.64 ms of a 1.72 ms call. Default.
+   *   The two square roots carry the same information J0^T J0, J0^T r0; they do NOT share the prior's constant term |r0|^2 (the
+   *   smallest kept eigenvalues of A' amplify b'): a caller that logs costs sees a constant offset between the modes (and between
+   *   mode 0 and the reference's own Eigen build), never a different step. */
   int32_t marg_sqrt;
   /* 1: gfbe_batch_solve replays its fixed kernel sequence as a hipGraph from the third call on a batch (first
    * call eager, second captured); 0 (default): eager launches — on ROCm 7.2 / MI355X the replay measured 2.50 vs
@@ -343,7 +347,9 @@ int32_t gfbe_options_size(void);
  * The solver drives up to eight HIP streams (two solver lanes with a side stream each, upload, download, the caller's): set
  * GPU_MAX_HW_QUEUES=8 in the process environment before HIP initialises — the runtime's default of four makes uploads queue
  * behind solves. The library does not touch the environment; gfbe_create returns GFBE_OK and leaves a note in gfbe_create_note
- * (never in gfbe_last_error, which only ever holds the cause of a failing call) when the variable is unset or below 8. */
+ * (never in gfbe_last_error, which only ever holds the cause of a failing call) when the variable is unset or below 8.
+ * (gfbe_batch_upload leaves a note there too when it had to switch speculative_linearization off for a batch whose second set of
+ * outputs did not fit the device.) */
 gfbe_status gfbe_create(gfbe_ctx **ctx, int device, const gfbe_options *opt);
 /* Frees the context and the device memory it caches. Batches (gfbe_batch_free) and feature tables (gfbe_ftab_destroy) made with
  * the context must be released BEFORE it. */
