@@ -56,6 +56,7 @@ __device__ __forceinline__ void mm3(const double *A, const double *B, double *C)
 }
 
 constexpr int LIO_THREADS = 256;
+constexpr int LIO_ZERO_COPY_N = 8192;     // gfbe_lio_linearize: scans up to this many residuals are read from / written to pinned host memory by the kernel itself
 constexpr int LIO_PART = 12 * 13 / 2 + 12 + 1;   // lower triangle of J^T J (78) + J^T r (12) + cost
 
 template <int CT>
@@ -168,12 +169,21 @@ extern "C" gfbe_status gfbe_lio_linearize(gfbe_ctx *c, int32_t ct, int32_t n, co
   double *dp = dev, *dnv = dp + 3 * nn, *doff = dnv + 3 * nn, *dal = doff + nn, *dw = dal + nn, *dpb = dw + nn, *dpe = dpb + 8;
   double *dpart = dev + in_d, *dr = dpart + (size_t)G * LIO_PART, *dJ = dr + (r ? nn : 0);
   gfbe_status st = GFBE_OK;
-  if (hipMemcpyAsync(dev, pin, sizeof(double) * in_d, hipMemcpyHostToDevice, s) != hipSuccess) st = GFBE_DEVICE_ERROR;
+  // A scan of the reference's size (lidarodom.cpp:929-1071 produces ~2 000 residuals per ICP iteration) is three dependent latencies —
+  // copy in, launch, copy out — around 10 us of arithmetic: 0.055 ms, where one CPU core takes 0.044. Round 6: up to
+  // LIO_ZERO_COPY_N residuals the kernel reads the pinned staging buffer across PCIe itself and writes its partial sums (and r, J) into
+  // it — ONE launch and the wait for it, no copy command (the k_ingest_small pattern of gfbe_solve_window); larger scans keep the two DMA
+  // copies, which stream faster than a kernel's loads across the bus.
+  const bool zero_copy = n <= LIO_ZERO_COPY_N;
+  if (zero_copy) {
+    dp = pin; dnv = dp + 3 * nn; doff = dnv + 3 * nn; dal = doff + nn; dw = dal + nn; dpb = dw + nn; dpe = dpb + 8;
+    dpart = pin + in_d; dr = dpart + (size_t)G * LIO_PART; dJ = dr + (r ? nn : 0);
+  } else if (hipMemcpyAsync(dev, pin, sizeof(double) * in_d, hipMemcpyHostToDevice, s) != hipSuccess) st = GFBE_DEVICE_ERROR;
   if (st == GFBE_OK) {
     if (ct) hipLaunchKernelGGL(k_lio<1>, dim3(G), dim3(LIO_THREADS), 0, s, n, dp, dnv, doff, dal, dw, sqrt_info, dpb, dpe, r ? dr : nullptr, J ? dJ : nullptr, dpart);
     else hipLaunchKernelGGL(k_lio<0>, dim3(G), dim3(LIO_THREADS), 0, s, n, dp, dnv, doff, dal, dw, sqrt_info, dpb, dpe, r ? dr : nullptr, J ? dJ : nullptr, dpart);
     double *hout = pin + in_d;
-    if (hipMemcpyAsync(hout, dpart, sizeof(double) * out_d, hipMemcpyDeviceToHost, s) != hipSuccess) st = GFBE_DEVICE_ERROR;
+    if (!zero_copy && hipMemcpyAsync(hout, dpart, sizeof(double) * out_d, hipMemcpyDeviceToHost, s) != hipSuccess) st = GFBE_DEVICE_ERROR;
     if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) st = GFBE_DEVICE_ERROR;
     if (st == GFBE_OK) {
       double tot[LIO_PART] = {0};

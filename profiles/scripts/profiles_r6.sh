@@ -21,6 +21,7 @@ rm -rf /tmp/prof_single; N=30 rocprofv3 --kernel-trace --stats -d /tmp/prof_sing
 python $R/profiles/summarize_rocpd.py /tmp/prof_single/*/*_results.db $R/gpurun_out/r6_single_trace.txt | head -14
 cd $R
 python tools/diag_single.py 2>&1 | tail -3 | tee -a gpurun_out/r6_single.log
+(KERNELS=2,3,1 BIG=1 python tools/diag_scripts/chain_variants.py 2>&1 | grep -v amdgpu.ids; GFBE_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_chainstamp.so python tools/diag_scripts/chain_stamps.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/r6_solve_chain_phases.txt; tail -9 gpurun_out/r6_solve_chain_phases.txt
 # (round 6) the eigen square root by divide & conquer against the QL build and the oracle; the whole GPU suite of the tree the set is taken from
 (GFBE_QL_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_ql.so python tools/diag_scripts/eig_dc_check.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/r6_eigen_dc_check.txt; tail -1 gpurun_out/r6_eigen_dc_check.txt
 (python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/r6_gpu_tests.txt; cat gpurun_out/r6_gpu_tests.txt
