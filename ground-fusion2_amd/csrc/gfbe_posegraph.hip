@@ -320,28 +320,39 @@ __global__ __launch_bounds__(128) void k_pg_candidate(int n, const double *Bs, c
 
 // All device buffers of one call come out of ONE allocation (a bump allocator over a slab sized by a dry run):
 // the solve makes ~30 buffers, and hipMalloc / hipFree cost more than the kernels at this problem size.
+enum { PG_RESULT_BYTES = 64 };
 struct PgBuffers {
   gfbe_ctx *c;
-  char *slab = nullptr;
-  size_t cap = 0, used = 0;
+  char *slab = nullptr, *pin = nullptr;
+  size_t cap = 0, used = 0, pin_cap = 0, pin_used = 0;
   bool dry = true;
   explicit PgBuffers(gfbe_ctx *ctx) : c(ctx) {}
   ~PgBuffers() { (void)hipStreamSynchronize(ctx_stream(c)); }
-  bool commit() {   // end of the dry run: take what was asked for from the context's grow-only scratch, restart
+  // end of the dry run: take what was asked for from the context's grow-only scratch, restart. The host arrays travel through the
+  // context's PINNED scratch (round 6: a copy from pageable memory is staged by the runtime, synchronously, piece by piece — five of
+  // them at the head of every call); its last PG_RESULT_BYTES are where the reduction kernels leave what the host decides on.
+  bool commit() {
     cap = used; used = 0; dry = false;
+    pin_cap = pin_used; pin_used = 0;
     slab = (char *)ctx_scratch(c, std::max<size_t>(cap, 256));
-    if (!slab) return false;
+    pin = (char *)ctx_scratch_pinned(c, pin_cap + PG_RESULT_BYTES);
+    if (!slab || !pin) return false;
     (void)hipMemsetAsync(slab, 0, std::max<size_t>(cap, 256), ctx_stream(c));
     return true;
   }
+  double *result() const { return (double *)(pin + pin_cap); }
   template <typename T>
   T *dev(size_t n, const T *h = nullptr) {
     const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
-    const size_t at = used;
+    const size_t at = used, pat = pin_used;
     used += bytes;
+    if (h && n) pin_used += bytes;
     if (dry) return nullptr;
     T *q = (T *)(slab + at);
-    if (h && n) (void)hipMemcpyAsync(q, h, n * sizeof(T), hipMemcpyHostToDevice, ctx_stream(c));
+    if (h && n) {
+      std::memcpy(pin + pat, h, n * sizeof(T));
+      (void)hipMemcpyAsync(q, pin + pat, n * sizeof(T), hipMemcpyHostToDevice, ctx_stream(c));
+    }
     return q;
   }
 };
@@ -374,24 +385,29 @@ __global__ __launch_bounds__(256) void k_pg_reduce1(int n, const double *a, cons
   }
   if (t < 4) partial[4 * blockIdx.x + t] = sh[t][0];
 }
-__global__ __launch_bounds__(64) void k_pg_reduce2(int nseg, const double *partial, int take_max, double *out) {
+// (out: the PINNED result slot of the call — the kernel writes what the host decides on across PCIe itself: no copy command, and none
+//  into pageable memory, between the reduction and the host's wait; out[4]: the factorisation's failure flag when one is passed)
+__global__ __launch_bounds__(64) void k_pg_reduce2(int nseg, const double *partial, int take_max, double *out, const int *fail) {
   const int t = threadIdx.x;
+  if (t == 4) out[4] = fail ? (double)*fail : 0.0;
   if (t >= 4) return;
   double v = 0.0;
   for (int q = 0; q < nseg; q++) { const double x = partial[4 * q + t]; v = (take_max && t == 0) ? fmax(v, x) : v + x; }
   out[t] = v;
 }
-// dscratch: 4 + 4 * PGR_MAXSEG doubles
-void dev_reduce(gfbe_ctx *c, int n, const double *a, const double *b, const double *c3, const double *d4, bool take_max, double *dscratch, double out[4]) {
+// dscratch: 4 * PGR_MAXSEG doubles; res: the call's pinned result slot (PgBuffers::result)
+void dev_reduce(gfbe_ctx *c, int n, const double *a, const double *b, const double *c3, const double *d4, bool take_max, double *dscratch, double *res,
+                double out[4], const int *fail = nullptr, int *hfail = nullptr) {
   const int nseg = (n + PGR_SEG - 1) / PGR_SEG;
   hipLaunchKernelGGL(k_pg_reduce1, dim3(nseg), dim3(256), 0, ctx_stream(c), n, a, b, c3, d4, take_max ? 1 : 0, dscratch + 4);
-  hipLaunchKernelGGL(k_pg_reduce2, dim3(1), dim3(64), 0, ctx_stream(c), nseg, dscratch + 4, take_max ? 1 : 0, dscratch);
-  (void)hipMemcpyAsync(out, dscratch, sizeof(double) * 4, hipMemcpyDeviceToHost, ctx_stream(c));
+  hipLaunchKernelGGL(k_pg_reduce2, dim3(1), dim3(64), 0, ctx_stream(c), nseg, dscratch + 4, take_max ? 1 : 0, res, fail);
   (void)hipStreamSynchronize(ctx_stream(c));
+  for (int q = 0; q < 4; q++) out[q] = res[q];
+  if (hfail) *hfail = res[4] != 0.0;
 }
-double host_sum(gfbe_ctx *c, const double *dptr, int n, double *dscratch, bool take_max = false) {
+double host_sum(gfbe_ctx *c, const double *dptr, int n, double *dscratch, double *res, bool take_max = false) {
   double out[4];
-  dev_reduce(c, n, dptr, nullptr, nullptr, nullptr, take_max, dscratch, out);
+  dev_reduce(c, n, dptr, nullptr, nullptr, nullptr, take_max, dscratch, res, out);
   return out[0];
 }
 
@@ -438,7 +454,7 @@ gfbe_status gfbe_pg_eval(gfbe_ctx *c, int32_t n, const double *pose, int32_t n_r
     if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_eval: device allocation failed"); return GFBE_DEVICE_ERROR; }
   }
   hipLaunchKernelGGL(k_pg_lin, dim3((n + 127) / 128), dim3(128), 0, ctx_stream(c), P, dpose, dcost, Hd, Ho, g, dr, dJ, dfr);
-  const double total = host_sum(c, dcost, n, red3);
+  const double total = host_sum(c, dcost, n, red3, buf.result());
   if (cost) *cost = total;
   if (rel_r && n_rel) (void)hipMemcpy(rel_r, dr, sizeof(double) * 6 * n_rel, hipMemcpyDeviceToHost);
   if (rel_J && n_rel) (void)hipMemcpy(rel_J, dJ, sizeof(double) * 72 * n_rel, hipMemcpyDeviceToHost);
@@ -486,7 +502,7 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
   gfbe_summary sm;
   std::memset(&sm, 0, sizeof sm);
   hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, x, per, Hd, Ho, g, (double *)nullptr, (double *)nullptr, (double *)nullptr);
-  double cost = host_sum(c, per, n, red3);
+  double cost = host_sum(c, per, n, red3, buf.result());
   sm.initial_cost = cost; sm.cost_history[0] = cost; sm.status = GFBE_NO_CONVERGENCE;
   double radius = 1e4, decrease = 2.0, x_norm;
   {
@@ -507,7 +523,7 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     // (the gradient norm of this point comes back together with the step's scalars — one host decision less per iteration;
     //  the step that was computed meanwhile is simply dropped when the gradient test ends the solve)
     if (radius < 1e-32) {
-      const double gm = host_sum(c, per4, n, red3, true);
+      const double gm = host_sum(c, per4, n, red3, buf.result(), true);
       if (gm <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; } else sm.termination = 4;
       break;
     }
@@ -521,9 +537,8 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     hipLaunchKernelGGL(k_pg_final, g64, b64, 0, s, n, Bb[cur], db[cur], y, fail);
     hipLaunchKernelGGL(k_pg_candidate, g128, b128, 0, s, n, Bs, A0, C0, d0, y, scale, x, cand, per, per2, per3);
     int hfail = 0;
-    (void)hipMemcpyAsync(&hfail, fail, sizeof(int), hipMemcpyDeviceToHost, s);
     double r4[4];
-    dev_reduce(c, n, per4, per, per2, per3, true, red3, r4);      // max |g|, model change, |step|^2, |candidate|^2
+    dev_reduce(c, n, per4, per, per2, per3, true, red3, buf.result(), r4, fail, &hfail);      // max |g|, model change, |step|^2, |candidate|^2; the failure flag
     if (r4[0] <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; break; }
     it++;
     const double model_change = r4[1];
@@ -537,7 +552,7 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
     const double step2 = r4[2], cand_x2 = r4[3];
     hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, cand, per, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
                        (double *)nullptr, (double *)nullptr);
-    const double cand_cost = host_sum(c, per, n, red3);
+    const double cand_cost = host_sum(c, per, n, red3, buf.result());
     sm.cost_history[it] = cost;
     if (std::sqrt(step2) <= 1e-8 * (x_norm + 1e-8)) { sm.termination = 2; sm.status = GFBE_OK; break; }
     const double change = cost - cand_cost;
