@@ -372,8 +372,9 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
     lin0 = prof.get("k_vis_lin") if prof.get("k_vis_lin", {}).get("launches") else prof.get("k_vis_lin_iter0")
     lin_first = prof.get("k_vis_lin_iter0") or lin0
     lin_ms = lin0["total_ms"] / max(lin0["launches"], 1)
-    units_per_launch = K_batch * nprof / max(lin0["launches"], 1)          # visual factors one launch evaluates
-    windows_per_launch = args.batch * nprof / max(lin0["launches"], 1)
+    # (one first-iteration launch per profiled solve and part: its count gives the size of a launch — the at-candidate launches have the same grid)
+    units_per_launch = K_batch * nprof / max(lin_first["launches"], 1)     # visual factors one launch evaluates
+    windows_per_launch = args.batch * nprof / max(lin_first["launches"], 1)
     full_panel = any((not s.get("ex_cam_const", 1)) or (not s.get("td_const", 1)) for s in batch_snaps[: args.unique])
     # matrix-core flops per factor: the 7 x 7 panel of round 4 (both rows of a factor in ONE 16-wide tile: 16 instructions of 2048 flop per
     # 64 factors) or the 20-column panel of a batch with a free extrinsic / td
@@ -735,48 +736,32 @@ def cpu_baseline(args, abi, synth, snaps, gpu_res):
            "ms_per_solve": ref["median_ms"], "reference_construction": ref, "product_algorithm": prod}
     if aff0 is not None and pinned_core is not None:
         os.sched_setaffinity(0, aff0)
-    # the same port on every host core (one window per thread; ctypes drops the GIL): SURVEY.md section 8d (b), north_star's "Ceres baseline
-    # timed on the host cores of the same box". Round 6: the input structures are built ONCE and shared read-only (rounds 1-5 built eight
-    # ctypes holders per thread — under the GIL, inside the timed region: on 256 threads that, not the solves, was most of the 6 s, and
-    # the figure came out at 8 x one core), every thread owns only its outputs, and the clock starts when all threads stand at a barrier.
-    import threading
-    import ctypes as C
+    # the same port on every host core: SURVEY.md section 8d (b), north_star's "Ceres baseline timed on the host cores of the same box".
+    # Round 6: one PROCESS per core (tools/cpu_all_cores.py forks them from a process that never touches the GPU), all released at a
+    # common wall-clock instant. Threads of one process — rounds 1-5, and this round's first attempt with shared read-only inputs and a
+    # start barrier — stop at ~8 x one core on a 256-thread host whatever the thread count: every solve of the port allocates and frees
+    # tens of MB (the reference construction's 2 000-dim Amm), i.e. maps and unmaps pages under the ONE address-space lock the threads
+    # share (1.87 s per solve per thread measured, against 0.068 s alone). Separate address spaces do not have that lock.
+    import pickle
+    import subprocess
+    import tempfile
     ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    counts = [0] * ncore
-    t_busy = [0.0] * ncore
     budget = min(args.cpu_seconds, 10.0) * 0.6
-    fsolve = orc._fn("solve_window")
-    fsolve.restype = abi.c_i
-    nfeat = max(h.n_feature for h in holders)
-    outs = [(abi.State(), abi.PriorHolder(), abi.Summary(), np.zeros(nfeat)) for _ in range(ncore)]
-    gate = threading.Barrier(ncore + 1)
-    deadline = [0.0]
-
-    def worker(k):   # the bare C call in the loop: no Python-side result conversion under the GIL
-        st, pr, sm, feat = outs[k]
-        i = k
-        gate.wait()
-        t0 = time.perf_counter()
-        while time.perf_counter() < deadline[0]:
-            fsolve(orc.head, C.byref(holders[i % len(holders)].c), int(abi.MARGIN_OLD), C.byref(st), abi._pd(feat), C.byref(pr.c), C.byref(sm))
-            counts[k] += 1
-            i += 1
-        t_busy[k] = time.perf_counter() - t0
-    th = [threading.Thread(target=worker, args=(k,)) for k in range(ncore)]
-    for x in th:
-        x.start()
-    deadline[0] = time.perf_counter() + budget + 0.05
-    gate.wait()
-    t_all = time.perf_counter()
-    for x in th:
-        x.join()
-    t_all = time.perf_counter() - t_all
-    done = sum(counts)
-    cpu["all_cores"] = {"value": done / t_all, "unit": "solves/s", "cores": ncore,
-                        "x_one_core": (done / t_all) / cpu["value"],
-                        "ms_per_solve_per_thread": 1e3 * sum(t_busy) / max(done, 1),
-                        "sample": "%d solves on %d threads in %.1f s from a common start (one window per thread, shared read-only inputs, reference "
-                                  "construction of the marginalisation)" % (done, ncore, t_all)}
+    try:
+        with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
+            pickle.dump({"snaps": snaps, "seconds": budget, "procs": ncore}, f)
+            path = f.name
+        t_w = time.perf_counter()
+        outp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), path], capture_output=True, text=True, timeout=60 + 4 * budget)
+        t_w = time.perf_counter() - t_w
+        os.unlink(path)
+        rec = json.loads(outp.stdout.strip().splitlines()[-1])
+        cpu["all_cores"] = {"value": rec["solves_per_s"], "unit": "solves/s", "cores": rec["procs"], "x_one_core": rec["solves_per_s"] / cpu["value"],
+                            "ms_per_solve_per_process": rec["ms_per_solve_per_process"],
+                            "sample": "%d solves by %d processes (one per host core, one window each, reference construction of the marginalisation) in %.1f s "
+                                      "from a common start; the leg took %.1f s of wall clock" % (rec["solves"], rec["procs"], rec["seconds"], t_w)}
+    except Exception as e:      # (a baseline leg must not take the bench line down)
+        cpu["all_cores"] = {"value": None, "error": repr(e)[:300]}
     return cpu, accuracy
 
 

@@ -24,7 +24,7 @@ python tools/diag_single.py 2>&1 | tail -3 | tee -a gpurun_out/r6_single.log
 (KERNELS=2,3,1 BIG=1 python tools/diag_scripts/chain_variants.py 2>&1 | grep -v amdgpu.ids; GFBE_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_chainstamp.so python tools/diag_scripts/chain_stamps.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/r6_solve_chain_phases.txt; tail -9 gpurun_out/r6_solve_chain_phases.txt
 # (round 6) the eigen square root by divide & conquer against the QL build and the oracle; the whole GPU suite of the tree the set is taken from
 (GFBE_QL_LIB=$R/ground-fusion2_amd/csrc/variants/libgfbe_ql.so python tools/diag_scripts/eig_dc_check.py 2>&1 | grep -v amdgpu.ids) > gpurun_out/r6_eigen_dc_check.txt; tail -1 gpurun_out/r6_eigen_dc_check.txt
-(python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -4) > gpurun_out/r6_gpu_tests.txt; cat gpurun_out/r6_gpu_tests.txt
+(python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|^FAILED|^ERROR") > gpurun_out/r6_gpu_tests.txt; cat gpurun_out/r6_gpu_tests.txt
 # speculative linearisation on against off (every output bit for bit; single-window times; 8192 resident windows), the phases of the
 # candidate's linearisation launch of a single window, and what a lone wave costs on this device (the model behind the latency path)
 GFBE_LIB=$R/ground-fusion2_amd/csrc/libgfbe_diag.so python tools/diag_scripts/eig_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_eigen_prior.txt; cat gpurun_out/r6_eigen_prior.txt
