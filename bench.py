@@ -748,18 +748,26 @@ def cpu_baseline(args, abi, synth, snaps, gpu_res):
     ncore = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     budget = min(args.cpu_seconds, 10.0) * 0.6
     try:
-        with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
-            pickle.dump({"snaps": snaps, "seconds": budget, "procs": ncore}, f)
-            path = f.name
-        t_w = time.perf_counter()
-        outp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), path], capture_output=True, text=True, timeout=60 + 4 * budget)
-        t_w = time.perf_counter() - t_w
-        os.unlink(path)
-        rec = json.loads(outp.stdout.strip().splitlines()[-1])
-        cpu["all_cores"] = {"value": rec["solves_per_s"], "unit": "solves/s", "cores": rec["procs"], "x_one_core": rec["solves_per_s"] / cpu["value"],
-                            "ms_per_solve_per_process": rec["ms_per_solve_per_process"],
-                            "sample": "%d solves by %d processes (one per host core, one window each, reference construction of the marginalisation) in %.1f s "
-                                      "from a common start; the leg took %.1f s of wall clock" % (rec["solves"], rec["procs"], rec["seconds"], t_w)}
+        runs = []
+        for procs in sorted({ncore, max(1, ncore // 2), max(1, ncore // 4)}, reverse=True):      # every hardware thread, every core, half the cores
+            with tempfile.NamedTemporaryFile(suffix=".pkl", delete=False) as f:
+                pickle.dump({"snaps": snaps, "seconds": budget / 2.0, "procs": procs}, f)
+                path = f.name
+            t_w = time.perf_counter()
+            outp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_all_cores.py"), path], capture_output=True, text=True, timeout=60 + 4 * budget)
+            t_w = time.perf_counter() - t_w
+            os.unlink(path)
+            rec = json.loads(outp.stdout.strip().splitlines()[-1])
+            rec["leg_wall_s"] = t_w
+            runs.append(rec)
+        best = max(runs, key=lambda r: r["solves_per_s"])
+        cpu["all_cores"] = {"value": best["solves_per_s"], "unit": "solves/s", "cores": best["procs"], "x_one_core": best["solves_per_s"] / cpu["value"],
+                            "ms_per_solve_per_process": best["ms_per_solve_per_process"],
+                            "by_process_count": {str(r["procs"]): {"solves_per_s": r["solves_per_s"], "ms_per_solve_per_process": r["ms_per_solve_per_process"], "solves": r["solves"]} for r in runs},
+                            "sample": "one process per core / hardware thread, one window each (reference construction of the marginalisation), released at a common "
+                                      "instant for %.1f s; the best of %s processes. The port does not scale with the cores: a solve's 2 000-dim Amm (32 MB) is "
+                                      "eigen-decomposed out of L3 when the process is alone and out of DRAM when every core does it at once (ms_per_solve_per_process)" %
+                                      (budget / 2.0, " / ".join(str(r["procs"]) for r in runs))}
     except Exception as e:      # (a baseline leg must not take the bench line down)
         cpu["all_cores"] = {"value": None, "error": repr(e)[:300]}
     return cpu, accuracy
