@@ -15,7 +15,9 @@ import oracle_lib
 from _gfbe_import import gf
 abi, synth = gf.abi, gf.synth
 N = int(os.environ.get("N", "40"))
-be = gf.Backend(0)
+_opt = abi.default_options()
+_opt.marg_sqrt = int(os.environ.get("MARG_SQRT", "1"))      # (0: the device takes the reference's eigen square root of the new prior — divide & conquer, round 6)
+be = gf.Backend(0, options=_opt)
 orc = oracle_lib.load()
 rng = np.random.default_rng(2026)
 worst = dict(cost=0.0, ate=0.0, rot=0.0, lam=0.0, prior=0.0)
