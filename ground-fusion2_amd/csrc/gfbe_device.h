@@ -222,6 +222,7 @@ struct BatchDev {
   int B;
   int tot_lm;                 // total padded landmark slots
   int max_tiles;              // max n_tiles over windows
+  int max_sf_tiles;           // most landmark tiles one start frame of one window has (k_vis_chunk's grid)
   WinDesc *desc;              // [B]
   WinCtl *ctl;                // [B]
   gfbe_options opt;

@@ -96,6 +96,45 @@ class HostPool {
   bool stop_ = false;
 };
 
+// Streams are taken from a process-wide pool per device and handed back at gfbe_destroy, never destroyed (round 6). The HIP runtime deals
+// streams to its hardware queues in creation order over the life of the process: the first context's eight streams land on eight queues,
+// a later context's — created after the first one's were destroyed — do not (measured: the same workload at 113.7k solves/s on the first
+// context of a process and at 105 - 106k on every later one, whatever library it came from). With the pool a later context runs on the
+// streams — and queues — the first one had.
+namespace {
+struct StreamPool {
+  struct Slot { hipStream_t s; bool busy; };
+  std::mutex m;
+  std::vector<Slot> blocking[16], nonblocking[16];
+};
+StreamPool &stream_pool() { static StreamPool p; return p; }
+// The free stream created EARLIEST is handed out first, so a context that asks in the same order as its predecessor (stream, aux, copy,
+// dl, then the lanes as split batches appear) gets the same stream in the same role.
+hipError_t stream_acquire(int device, bool nonblock, hipStream_t *out) {
+  const bool pooled = device >= 0 && device < 16;
+  StreamPool &p = stream_pool();
+  std::lock_guard<std::mutex> lk(p.m);
+  if (pooled) {
+    for (auto &sl : nonblock ? p.nonblocking[device] : p.blocking[device])
+      if (!sl.busy) { sl.busy = true; *out = sl.s; return hipSuccess; }
+  }
+  const hipError_t e = nonblock ? hipStreamCreateWithFlags(out, hipStreamNonBlocking) : hipStreamCreate(out);
+  if (e == hipSuccess && pooled) (nonblock ? p.nonblocking[device] : p.blocking[device]).push_back({*out, true});
+  return e;
+}
+void stream_release(int device, bool nonblock, hipStream_t s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s);
+  if (device >= 0 && device < 16) {
+    StreamPool &p = stream_pool();
+    std::lock_guard<std::mutex> lk(p.m);
+    for (auto &sl : nonblock ? p.nonblocking[device] : p.blocking[device])
+      if (sl.s == s) { sl.busy = false; return; }
+  }
+  (void)hipStreamDestroy(s);
+}
+}  // namespace
+
 struct gfbe_ctx {
   int device = -1;
   gfbe_options opt;
@@ -286,14 +325,14 @@ gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
     c->err = "no HIP device " + std::to_string(device) + " visible (the HIP back end has no CPU fallback)";
     return GFBE_NO_DEVICE;
   }
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || stream_acquire(device, false, &c->stream) != hipSuccess) {
     c->err = "hipSetDevice/hipStreamCreate failed";
     return GFBE_DEVICE_ERROR;
   }
   c->own_stream = true;
-  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->dl, hipStreamNonBlocking) != hipSuccess ||
+  if (stream_acquire(device, true, &c->aux) != hipSuccess ||
+      stream_acquire(device, true, &c->copy) != hipSuccess ||
+      stream_acquire(device, true, &c->dl) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     c->err = "hipStreamCreate/hipEventCreate (aux stream) failed";
@@ -318,13 +357,13 @@ void gfbe_destroy(gfbe_ctx *c) {
   if (c->asm_full) (void)hipFree(c->asm_full);
   if (c->asm_compact) (void)hipFree(c->asm_compact);
   for (auto &p : c->prof) for (auto &ev : p.pending) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
-  if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
-  if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
-  if (c->dl) { (void)hipStreamSynchronize(c->dl); (void)hipStreamDestroy(c->dl); }
+  if (c->own_stream && c->stream) stream_release(c->device, false, c->stream);
+  stream_release(c->device, true, c->aux);
+  stream_release(c->device, true, c->copy);
+  stream_release(c->device, true, c->dl);
   for (auto &sl : c->pin_cache) (void)hipHostFree(sl.first);
   for (auto &l : c->lane_pool) {
-    (void)hipStreamDestroy(l.s); (void)hipStreamDestroy(l.aux);
+    stream_release(c->device, true, l.s); stream_release(c->device, true, l.aux);
     for (hipEvent_t e : {l.fork, l.join, l.start2, l.done2}) (void)hipEventDestroy(e);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -337,9 +376,9 @@ void gfbe_destroy(gfbe_ctx *c) {
 
 gfbe_status gfbe_set_stream(gfbe_ctx *c, void *s) {
   if (!c || c->device < 0) return GFBE_NO_DEVICE;
-  if (c->own_stream && c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+  if (c->own_stream && c->stream) stream_release(c->device, false, c->stream);
   if (s) { c->stream = (hipStream_t)s; c->own_stream = false; }
-  else { if (hipStreamCreate(&c->stream) != hipSuccess) return GFBE_DEVICE_ERROR; c->own_stream = true; }
+  else { if (stream_acquire(c->device, false, &c->stream) != hipSuccess) return GFBE_DEVICE_ERROR; c->own_stream = true; }
   return GFBE_OK;
 }
 
@@ -746,6 +785,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::vector<int> feat_off(B + 1, 0);
   std::vector<long long> j0_off(B + 1, 0);
   int tot_n0 = 0;
+  int max_sf_tiles = 0;
   int tot_lm = 0, tot_rec = 0, max_tiles = 0, n_imu_tot = 0, n_wheel_tot = 0, tot_lio = 0, pn_max = 0, tot_gnss = 0, any_gnss = 0, gnss_dims = 0, gnss_max = 0, marg_nmax = 0;
   double algo_bytes = 0.0;
   for (int w = 0; w < B; w++) {
@@ -761,6 +801,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     for (int s = 0; s < NF; s++) for (int t = sc.sf_tile_begin[s]; t < sc.sf_tile_begin[s + 1]; t++) tile_start.push_back(s);
     if (tabs) tlayout[(size_t)w * FT_LAY_STRIDE] = tot_lm;
     tot_lm += sc.slots; tot_rec += sc.K; max_tiles = std::max(max_tiles, sc.n_tiles);
+    for (int s = 0; s < NF; s++) max_sf_tiles = std::max(max_sf_tiles, sc.sf_tile_begin[s + 1] - sc.sf_tile_begin[s]);
     ds.imu_off = n_imu_tot; ds.wheel_off = n_wheel_tot; ds.lio_off = tot_lio;
     n_imu_tot += win.n_imu; n_wheel_tot += win.n_wheel; tot_lio += win.lio.n > 0 ? win.lio.n : 0;
     if (win.gnss_ready) {
@@ -804,7 +845,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     marg_nmax = std::max(marg_nmax, nb);
     algo_bytes += 108.0 * sc.K;   // 12 f64 + 3 i32 per visual residual block, J never re-read by the host
   }
-  d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio;
+  d.tot_lm = tot_lm; d.max_tiles = max_tiles; d.tot_rec = tot_rec; d.tot_lio = tot_lio; d.max_sf_tiles = max_sf_tiles;
   d.rank = c->rank; d.world = c->world; d.sharded = c->allreduce ? 1 : 0;
   d.schur_groups = B >= DENSE_SPLIT_MIN_B ? SCHUR_GROUPS : (c->allreduce ? NF : 2 * NF);
   d.test_fail_chol_iter = c->opt.test_fail_chol_iter;   // (test hook of the mu-retry path, 0 in production: gfbe_options)
@@ -1219,8 +1260,8 @@ static gfbe_status make_lane(gfbe_ctx *c, gfbe_batch *a) {
     a->lane2 = {l.s, l.aux, l.fork, l.join}; a->ev_start2 = l.start2; a->ev_done2 = l.done2;
     return GFBE_OK;
   }
-  if (hipStreamCreateWithFlags(&a->lane2.s, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&a->lane2.aux, hipStreamNonBlocking) != hipSuccess ||
+  if (stream_acquire(c->device, true, &a->lane2.s) != hipSuccess ||
+      stream_acquire(c->device, true, &a->lane2.aux) != hipSuccess ||
       hipEventCreateWithFlags(&a->lane2.fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&a->lane2.join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&a->ev_start2, hipEventDisableTiming) != hipSuccess ||
@@ -1329,8 +1370,8 @@ extern "C" void gfbe_batch_free(gfbe_ctx *c, gfbe_batch *b) {
     if (c && b->lane2.s && b->lane2.aux && b->lane2.fork && b->lane2.join && b->ev_start2 && b->ev_done2 && c->lane_pool.size() < 16) {
       c->lane_pool.push_back({b->lane2.s, b->lane2.aux, b->lane2.fork, b->lane2.join, b->ev_start2, b->ev_done2});   // (idle: the part's events were waited for)
     } else {
-      if (b->lane2.s) (void)hipStreamDestroy(b->lane2.s);
-      if (b->lane2.aux) (void)hipStreamDestroy(b->lane2.aux);
+      stream_release(c ? c->device : -1, true, b->lane2.s);
+      stream_release(c ? c->device : -1, true, b->lane2.aux);
       for (hipEvent_t e : {b->lane2.fork, b->lane2.join, b->ev_start2, b->ev_done2}) if (e) (void)hipEventDestroy(e);
     }
   }

@@ -825,6 +825,192 @@ __global__ __launch_bounds__(LM_TILE, (MODE == 0 && !FULL) ? GFBE_KVIS_WAVES : 2
 }
 
 // =============================================================================================
+// k_vis_chunk (round 6): k_vis<0, false> for throughput batches with a wave that STAYS — one wave takes up to VIS_CHUNK consecutive
+// tiles of ONE start frame of its window instead of one tile. Phase stamps of a k_vis wave under load (profiles/r6_kvis_ablation.txt):
+// 6.6 us of prologue — descriptor, control block, then the landmark's data and the pair records, each a dependent round trip of 2 - 3 us
+// under load, then the LDS staging and its barrier — in front of 5.3 observation steps of ~2.4 us: a third of a wave's life. Here the pair
+// records of the start frame are staged once per wave, and a tile's landmark data (slot info, first observation, inverse depth, and what
+// the candidate's head needs) is requested while the tile before it is evaluated. Per tile the arithmetic is vis_body<0, false, 1, SPEC>'s,
+// operation for operation, in its order: every output bit for bit (the whole suite runs through it).
+// Grid: (window, start frame x sub-chunk): blockIdx.y = s * nsub + sub takes the tiles [begin(s) + VIS_CHUNK sub, + VIS_CHUNK) of start
+// frame s (start frame 0 — the longest tracks — is dispatched first).
+// =============================================================================================
+#ifndef GFBE_VIS_CHUNK
+#define GFBE_VIS_CHUNK 1
+#endif
+#ifndef VIS_CHUNK
+#define VIS_CHUNK 4
+#endif
+template <bool SPEC>
+__global__ __launch_bounds__(LM_TILE, GFBE_KVIS_WAVES) void k_vis_chunk(BatchDev d0, int head_in, int nsub) {
+  const int w = blockIdx.x;
+  const WinCtl &c = d0.ctl[w];
+  if (!SPEC && (c.done || c.reuse)) return;
+  if (SPEC && (c.done || !c.have_step)) return;
+  const int lbw = SPEC ? 1 - c.lb : c.lb;
+  const BatchDev d = lin_view(d0, lbw);
+  const WinDesc &ds = d.desc[w];
+  const int sframe = blockIdx.y / nsub, sub = blockIdx.y - sframe * nsub;
+  const int t0 = ds.sf_tile_begin[sframe] + VIS_CHUNK * sub, t1 = min(t0 + VIS_CHUNK, ds.sf_tile_begin[sframe + 1]);
+  if (t0 >= t1) return;
+  const int cur = c.cur, buf = SPEC ? 1 - cur : cur;
+  const double *X = d.x + ((size_t)w * 2 + buf) * NA;
+  const bool chead = SPEC && head_in;
+  const double c1 = c.c1, c2 = c.c2;
+  const bool first = !SPEC && c.iter == 0;
+  const double mu_w = SPEC ? mu_after_accept(c.mu) : c.mu;
+  const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
+  const int jac_scale = d.opt.jacobi_scaling;
+  const int lm_off_c = ds.lm_off;
+  constexpr int XLD = 17;
+  __shared__ PairConstY pcs[NF];
+  __shared__ FrameConst fcs;
+  __shared__ double xs[LM_TILE * XLD];
+  const int lane = threadIdx.x;
+  const size_t TL = d.tot_lm;
+  // ---- what a lane holds of a tile before its first step; the NEXT tile's is requested while the current one is evaluated
+  int p_info;
+  double p_pt[3], p_lam, p_sl = 0.0, p_vl = 0.0, p_yl = 0.0, p_ob[2];
+#define VC_PREFETCH(TILE)                                                                                           \
+  {                                                                                                                  \
+    const int slot_ = lm_off_c + (TILE) * LM_TILE + lane;                                                            \
+    p_info = d.lm_info[slot_];                                                                                       \
+    _Pragma("unroll") for (int q = 0; q < 3; q++) p_pt[q] = d.lm_pts[(size_t)q * TL + slot_];                        \
+    p_lam = d.lam[(size_t)(chead ? cur : buf) * TL + slot_];                                                         \
+    if (chead) { p_sl = d.lm_sl[slot_]; p_vl = d.lm_vl[slot_]; p_yl = d.lm_yl[slot_]; }                              \
+    p_ob[0] = d.lm_obs[slot_]; p_ob[1] = d.lm_obs[TL + slot_];                                                       \
+  }
+  VC_PREFETCH(t0)
+  const double td = X[A_TD];
+  {
+    const double *src = d.pc + (((size_t)w * 3 + buf) * NPAIR + sframe * NF) * PC_DOUBLES;
+    for (int j = sframe + 1; j < NF; j++)
+      for (int q = lane; q < (int)PCY_DOUBLES; q += LM_TILE) ((double *)&pcs[j])[q] = src[(size_t)j * PC_DOUBLES + q];
+    if (lane < (int)FC_DOUBLES) ((double *)&fcs)[lane] = src[(size_t)sframe * PC_DOUBLES + lane];
+  }
+  __syncthreads();
+  for (int tile = t0; tile < t1; tile++) {
+    const int slot = lm_off_c + tile * LM_TILE + lane;
+    const int info = p_info;
+    const double pix = p_pt[0], piy = p_pt[1], piz = p_pt[2];
+    double lam = p_lam;
+    const double c_sl = p_sl, c_vl = p_vl, c_yl = p_yl;
+    double nob[2] = {p_ob[0], p_ob[1]};
+    if (tile + 1 < t1) VC_PREFETCH(tile + 1)
+    const bool valid = (info >> 24) & 1;
+    const int m = valid ? ((info >> 8) & 0xff) : 0;
+    const bool is_const = (info >> 16) & 1;
+    int mmax = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64));
+    double cost = 0.0;
+    if (chead) {      // x_cand = x + s_l (c1 v_l + c2 y_l): candidate_lm is candidate_tile's arithmetic
+      double d2, n2;
+      lam = candidate_lm(lam, c_sl, c_vl, c_yl, c1, c2, valid && !is_const && m > 0, d2, n2);
+      d.lam[(size_t)(1 - cur) * TL + slot] = lam;
+      d2 = wave_sum(d2); n2 = wave_sum(n2);
+      if (lane == 0) {
+        double *o = d.tile_cand + ((size_t)w * d.max_tiles + tile) * 4;
+        o[1] = d2; o[2] = n2;
+      }
+    }
+    double Hll = 0.0, gl = 0.0, Dsum[3] = {0.0, 0.0, 0.0};
+    const double yinv_l = 1.0 / lam;
+    const double ycx = pix * yinv_l, ycy = piy * yinv_l, ycz = piz * yinv_l;
+    vec3 yf, ye, yx;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      yf[a] = __builtin_fma(fcs.W(a, 0), ycx, __builtin_fma(fcs.W(a, 1), ycy, fcs.W(a, 2) * ycz));
+      ye[a] = yf[a] + fcs.wt[a];
+      yx[a] = ye[a] + fcs.dPc[a];      // from the window's origin P_0
+    }
+    double *xr = xs + lane * XLD;      // panel row [g0 y0 r0 0 | g1 y1 r1 0]: the two padding columns are written once
+    xr[7] = 0.0; xr[15] = 0.0;
+    for (int k = 0; k < mmax; k++) {
+      double r[2], Jl[2], hp[3];
+      const double pjx = nob[0], pjy = nob[1];
+      if (k + 1 < mmax) {
+        const double *ob = d.lm_obs + (size_t)(k + 1) * 5 * TL + slot;
+        nob[0] = ob[0]; nob[1] = ob[TL];
+      }
+      if (k < m) {
+        double g0[3], g1[3];
+        const double ck = visual_lin_y(pcs[sframe + 1 + k], ycx, ycy, ycz, yf, yinv_l, td, pjx, pjy, 0.0, 0.0, td, sq, delta, r, g0, g1, Jl);
+        cost += ck;
+        const vec3 y0 = cross3(mk3(g0[0], g0[1], g0[2]), yx), y1 = cross3(mk3(g1[0], g1[1], g1[2]), yx);   // rows of G [x]x
+        const double w0 = is_const ? 0.0 : Jl[0], w1 = is_const ? 0.0 : Jl[1];
+        vec3 dv;
+#pragma unroll
+        for (int q = 0; q < 3; q++) dv[q] = __builtin_fma(g0[q], w0, g1[q] * w1);                         // d = G^T w
+        Hll += __builtin_fma(w0, w0, w1 * w1);
+        gl += __builtin_fma(w0, r[0], w1 * r[1]);
+#pragma unroll
+        for (int q = 0; q < 3; q++) Dsum[q] += dv[q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) hp[q] = dv[q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { xr[q] = g0[q]; xr[3 + q] = y0[q]; xr[8 + q] = g1[q]; xr[11 + q] = y1[q]; }
+        xr[6] = r[0]; xr[14] = r[1];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 7; q++) { xr[q] = 0.0; xr[8 + q] = 0.0; }
+      }
+#if GFBE_KVIS_EARLY
+#pragma unroll
+      for (int q = 0; q < 2; q++) asm volatile("" : "+v"(nob[q]));      // (the next step's observation is waited for BEFORE this step's stores are issued: vis_body)
+#endif
+      if (k < m) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) d.lm_hP[((size_t)k * 6 + q) * TL + slot] = hp[q];
+      }
+      typedef double dbl4_y __attribute__((ext_vector_type(4)));
+      dbl4_y acc0 = {0, 0, 0, 0};
+      const int lr = lane & 15, lk = lane >> 4;
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int blk = 0; blk < LM_TILE / 4 / 8; blk++) {
+        double va[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) va[u] = xs[(4 * (8 * blk + u) + lk) * XLD + lr];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc0, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double s0 = acc0[0] + __shfl_down(acc0[2], 8, 64), s1 = acc0[1] + __shfl_down(acc0[3], 8, 64);
+      double *vo = d.vis_part + (((size_t)w * d.max_tiles + tile) * MAXOBS + k) * VPY_STRIDE;
+      if (lr < 7) {      // upper triangle of the 7 x 7 sum, row-major packed: (a, b), a <= b, at 7 a - a (a - 1) / 2 + b - a
+        { const int a = lk; if (a <= lr) vo[7 * a - a * (a - 1) / 2 + lr - a] = s0; }
+        { const int a = lk + 4; if (a <= lr) vo[7 * a - a * (a - 1) / 2 + lr - a] = s1; }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (d.spec && tile == 0 && lane == 0) d.ctl[w].sw_mu[lbw] = mu_w;
+    if (valid) {
+      // the landmark's weight in the Schur term (vis_body)
+      double sl = 1.0, sw = 0.0;
+      if (m > 0 && !is_const) {
+        sl = first ? (jac_scale ? 1.0 / (1.0 + sqrt(Hll)) : 1.0) : (chead ? c_sl : d.lm_sl[slot]);
+        const double hs2 = sl * sl * Hll;
+        sw = sqrt(sl * sl / (hs2 + mu_w * clamp_diag(hs2)));
+      }
+      if (first) d.lm_sl[slot] = sl;
+      d.lm_sw[slot] = sw;
+      d.lm_Hll[slot] = Hll;
+      d.lm_gl[slot] = gl;
+#pragma unroll
+      for (int q = 0; q < 3; q++) { d.lm_hC[(size_t)q * TL + slot] = Dsum[q]; d.lm_hC[(size_t)(3 + q) * TL + slot] = yx[q]; }
+    }
+    cost = wave_sum(cost);
+    if (lane == 0) {
+      if (SPEC) d.tile_cand[((size_t)w * d.max_tiles + tile) * 4] = cost;
+      else d.tile_cost[(size_t)w * d.max_tiles + tile] = cost;
+    }
+  }
+#undef VC_PREFETCH
+}
+
+// =============================================================================================
 // k_lio_window: LiDAR point-to-plane factors attached to one window pose (gfbe_lio_block; the joint LIO + VIO solve,
 // LidarPlaneNormFactor lidarFactor.cpp:18-51 + HuberLoss lidarodom.cpp:539). LIOW_WGS workgroups stride over the
 // window's factors; every thread keeps its share of the 6 x 6 J^T J (upper triangle), J^T r and the cost in registers,
@@ -3682,6 +3868,14 @@ void launch_reset(const BatchDev &d, hipStream_t s) {
 void launch_vis(const BatchDev &d, int mode, hipStream_t s, int write_records, int spec) {
   if (d.max_tiles == 0) return;
   const dim3 g(d.B, d.max_tiles), b(LM_TILE);
+  if (GFBE_VIS_CHUNK && mode == 0 && !d.vis_full && !write_records && d.B >= DENSE_SPLIT_MIN_B && d.world == 1) {
+    // throughput batches on the 7 x 7 panel: a wave per (window, start frame, chunk of VIS_CHUNK tiles) — k_vis_chunk
+    const int nsub = (d.max_sf_tiles + VIS_CHUNK - 1) / VIS_CHUNK;
+    const dim3 gc(d.B, NF * nsub);
+    if (spec) hipLaunchKernelGGL(k_vis_chunk<true>, gc, b, 0, s, d, GFBE_FUSE_CAND ? 1 : 0, nsub);
+    else hipLaunchKernelGGL(k_vis_chunk<false>, gc, b, 0, s, d, 0, nsub);
+    return;
+  }
   if (mode == 0 && spec) {      // (the candidate linearised; its tiles form the candidate inverse depths first, as the cost pass's do)
     const int head = (d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND) ? 1 : 0;
     if (d.vis_full) hipLaunchKernelGGL((k_vis<0, true, true>), g, b, 0, s, d, head);

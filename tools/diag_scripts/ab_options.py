@@ -11,7 +11,40 @@ import numpy as np
 
 
 def main():
+    # EVERY variant in a process of its own (round 6): the first back end a process creates runs the bench workload at ~113.7k solves/s,
+    # every later one — another build, a byte-identical copy of the library, even the first library again — at ~106k (measured:
+    # default / copy / default in one process 113.7k / 106.2k / 105.3k; the copy alone 113.9k). A/B runs inside one process made
+    # whatever came second look 7 % slower than it is.
+    if "--child" not in sys.argv and len([a for a in sys.argv[1:] if not a.startswith("--") and "=" in a or a == "default"]) > 1:
+        import subprocess
+        flags = [a for a in sys.argv[1:] if a.startswith("--")]
+        vals = {}
+        i = 1
+        rest = []
+        while i < len(sys.argv):      # (flags with a value)
+            a = sys.argv[i]
+            if a in ("--batch", "--steps", "--landmarks"):
+                rest += [a, sys.argv[i + 1]]; i += 2
+            elif a.startswith("--"):
+                rest.append(a); i += 1
+            else:
+                i += 1
+        variants = [a for a in sys.argv[1:] if not a.startswith("--") and (a == "default" or "=" in a)]
+        variants = [v for k, v in enumerate(variants) if not (k > 0 and sys.argv[sys.argv.index(v) - 1] in ("--batch", "--steps", "--landmarks"))]
+        outs = []
+        for v in variants:
+            o = subprocess.run([sys.executable, os.path.abspath(__file__), v, "--child"] + rest, capture_output=True, text=True)
+            line = [l for l in o.stdout.splitlines() if l.startswith(v + " {")]
+            print(line[0] if line else (o.stdout + o.stderr)[-500:], flush=True)
+            if line:
+                outs.append((v, json.loads(line[0][len(v) + 1:])))
+        for v, r in outs[1:]:
+            b = outs[0][1]
+            print("%s vs %s: x%.4f; max rel. final-cost difference %.2e" % (v, outs[0][0], r["solves_per_s"] / b["solves_per_s"],
+                  max(abs(x - y) / x for x, y in zip(b["final_cost"], r["final_cost"]))))
+        return
     ap = argparse.ArgumentParser()
+    ap.add_argument("--child", action="store_true")
     ap.add_argument("variants", nargs="+")
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--steps", type=int, default=10)
