@@ -39,6 +39,14 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "linstamp3_t256ks4": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=3", "-DGFBE_LIN_SMALL_THREADS=256", "-DGFBE_LIN_SMALL_KS=4"], "off"),
     "visasm6": (["-DGFBE_VISASM_WAVES=6"], "off"),
     "visasm5": (["-DGFBE_VISASM_WAVES=5"], "off"),
+    "visasm3": (["-DGFBE_VISASM_WAVES=3"], "off"),
+    "schur5": (["-DGFBE_SCHUR_WGS=5"], "off"),
+    "kvis4": (["-DGFBE_KVIS_WAVES=4"], "off"),
+    "kvis2": (["-DGFBE_KVIS_WAVES=2"], "off"),
+    "chunk8": (["-DVIS_CHUNK=8"], "off"),
+    "chunk6": (["-DVIS_CHUNK=6"], "off"),
+    "nochunk": (["-DGFBE_VIS_CHUNK=0"], "off"),
+    "ql": (["-DGFBE_EIG_DC=0"], "off"),
     "lmsstamp": (["-DGFBE_LMS_STAMP=1"], "off"),
     "linstamp1": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=1"], "off"),
     "lin512": (["-DGFBE_LIN_SMALL_THREADS=512"], "off"),
