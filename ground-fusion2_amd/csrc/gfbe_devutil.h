@@ -47,9 +47,12 @@ __device__ __forceinline__ double block_max(double v, double *scratch) {
 // sums by the shuffle tree, then thread q adds the <= 16 wave values in wave order — the same order as block_sum / block_max,
 // so the results are bit-identical to NQ separate calls. scratch: (16 + 1) * NQ doubles; results in scratch[16 * NQ + q] for
 // every thread after the call.
+// tid: the thread's index in the order the sums are taken in — threadIdx.x, or the logical index of a kernel that renumbers its waves
+// (k_solve_chain: by the SIMD they sit on)
 template <int NQ>
-__device__ __forceinline__ void block_reduce_multi(const double (&v)[NQ], unsigned maxmask, double *scratch) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+__device__ __forceinline__ void block_reduce_multi(const double (&v)[NQ], unsigned maxmask, double *scratch, int tid = -1) {
+  if (tid < 0) tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6, nw = (blockDim.x + 63) >> 6;
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
@@ -57,8 +60,8 @@ __device__ __forceinline__ void block_reduce_multi(const double (&v)[NQ], unsign
     if (lane == 0) scratch[q * 16 + wid] = r;
   }
   __syncthreads();
-  if (threadIdx.x < NQ) {
-    const int q = threadIdx.x;
+  if (tid < NQ) {
+    const int q = tid;
     double r = 0.0;
     for (int i = 0; i < nw; i++) r = ((maxmask >> q) & 1) ? fmax(r, scratch[q * 16 + i]) : r + scratch[q * 16 + i];
     scratch[16 * NQ + q] = r;

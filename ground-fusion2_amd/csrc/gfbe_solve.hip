@@ -23,6 +23,7 @@ namespace gfd {
 #ifndef BUILD_UNROLL
 #define BUILD_UNROLL 6
 #endif
+#define BRM_T t      // (every kernel of this file names its thread index t; only k_solve_chain's may differ from threadIdx.x)
 #ifndef GFBE_SOLVE_INLINE
 #define GFBE_SOLVE_INLINE 0
 #endif
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   }
   {   // (the tile area is free until the build: scratch of the combined reduction)
     const double pv[3] = {g2, gmax, xn2};
-    block_reduce_multi<3>(pv, 0x2u, smem);
+    block_reduce_multi<3>(pv, 0x2u, smem, BRM_T);
     g2 = smem[48]; gmax = smem[49]; xn2 = smem[50];
   }
   __syncthreads();
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
   }
   {   // (the tiles are dead after the back-substitution: scratch of the combined reduction)
     const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
-    block_reduce_multi<8>(gv, 0u, smem);
+    block_reduce_multi<8>(gv, 0u, smem, BRM_T);
     n2 = smem[128]; gyv = smem[129]; vrhs = smem[130]; vDv = smem[131]; vDy = smem[132]; vEv = smem[133]; vEy = smem[134]; yEy = smem[135];
   }
   if (t == 0) {
@@ -678,6 +679,14 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 #define S2_THREADS 256
 #ifndef GFBE_ROLE_INLINE
 #define GFBE_ROLE_INLINE 0
+#endif
+#ifndef GFBE_WIDE_PREFETCH2
+#define GFBE_WIDE_PREFETCH2 0      // k_solve_chain's wide rows: the rows of S two blocks ahead instead of one (measured: 86.9 against 84.4 us per 512
+                                   // windows — the pipeline does not wait for those loads)
+#endif
+#ifndef GFBE_CHAIN_SIMD_ROLES
+#define GFBE_CHAIN_SIMD_ROLES 0    // k_solve_chain's waves numbered by the SIMD they sit on (measured: the pipeline 33.3 -> 31.5 us beside a second
+                                   // workgroup, the dense Cholesky 15.8 -> 19.2: 89.6 against 85.0 us per 512 windows; tools/diag_scripts/hwid)
 #endif
 #if GFBE_ROLE_INLINE
 #define GFBE_ROLE_FN __forceinline__
@@ -915,11 +924,11 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
     pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB + 8;
     pR[u] = ring + lk * ring_ld + min(TB * c, ring_ld - TB) + lr;
   }
-  double yv[2][3], rpre[2][3], vsv = 0.0, zzc = 0.0;
+  double yv[2][3], rpre[2][3], rnxt[2][3], vsv = 0.0, zzc = 0.0;
 #pragma unroll
   for (int u = 0; u < 2; u++)
 #pragma unroll
-    for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; }
+    for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; rnxt[u][kk] = 0.0; }
   // rows lk, lk + 4, lk + 8 of block k (the third only counts for lk == 0: the others read into the next block and are masked)
   // (row 8 + lk exists for lk == 0 only: the other lanes' third load lands in the next block or above the diagonal, on entries nobody
   //  writes — H is not cleared at upload — and is replaced by zero, not multiplied by it)
@@ -930,6 +939,12 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
   };
 #pragma unroll
   for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rpre[u]);
+#if GFBE_WIDE_PREFETCH2
+  // (round 6) TWO blocks ahead: beside a second workgroup on the CU — and the batch's other parts' kernels — a load takes longer than a step
+  // of the pipeline (stamps, B = 1 / 256 / 512: the pipeline 19.6 / 24.8 / 33.3 us), so the rows requested one step ahead paced the steps
+#pragma unroll
+  for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rnxt[u]);
+#endif
   // operand pointers into the chain blocks (block CH_NC - 1 first; per-lane stride, 0 for the lanes parked on the zero slot)
   //   a2[kk] = W_k[lr][4 kk + lk]        a1[kk] = -Yc_k+1[4 kk + lk][lr]      (G: W_kG[4 kk + lk][lr], Yc_kG[4 kk + lk][lr])
   const int sW01 = in01 ? CH_BLK : 0, sW2 = in2 ? CH_BLK : 0;
@@ -993,8 +1008,14 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
         double r[3];
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) r[kk] = __builtin_fma(rpre[u][kk] * sk[kk], m1, mr * rk[kk]);
+#if GFBE_WIDE_PREFETCH2
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) rpre[u][kk] = rnxt[u][kk];
+        load_R(u, rnxt[u]);                                        // (block k - 2; the loads of the two steps after block 1 read valid, unused rows of H)
+#else
         load_R(u, rpre[u]);                                        // (block k - 1; in flight during this block's products. The loads of
                                                                    //  the step after block 0 read valid, unused rows of H)
+#endif
         if (!zero_tile) {
 #pragma unroll
           for (int kk = 0; kk < 3; kk++) vsv = __builtin_fma(r[kk] * vk[kk], vbj2[u], vsv);
@@ -1099,11 +1120,11 @@ __device__ GFBE_ROLE_FN double wide_role_tw(lds_double *Ach, lds_double *Cch, ld
     pR8[u] = lk == 0 ? Yall + (KF * CH_NB + 8) * ld + cc : Yall + (100 + lk) * ld + cc;
   }
   const int sR = SG * CH_NB * ld, sR8 = lk == 0 ? SG * CH_NB * ld : 0;
-  double yv[2][3], rpre[2][3], vsv = 0.0, zzc = 0.0;
+  double yv[2][3], rpre[2][3], rnxt[2][3], vsv = 0.0, zzc = 0.0;
 #pragma unroll
   for (int u = 0; u < 2; u++)
 #pragma unroll
-    for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; }
+    for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; rnxt[u][kk] = 0.0; }
   // rows lk, lk + 4, lk + 8 of block k (row 8 + lk exists for lk == 0 only: the other lanes' third load lands in the next block or above
   // the diagonal, on entries nobody writes, and is replaced by zero, not multiplied by it)
   auto load_R = [&](int u, double (&r)[3]) {
@@ -1265,7 +1286,31 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
+#if GFBE_CHAIN_SIMD_ROLES
+  // (round 6) the waves numbered by the SIMD they sit on: wave 0 — the chain role and every serial section — of BOTH workgroups of a CU on
+  // SIMD 0, the wide waves pairwise on SIMDs 1..3. The dispatcher gives a workgroup one wave per SIMD and rotates the start, so that wave 0
+  // of one workgroup shares its SIMD with a wide wave of the other one — whose FP64 matrix-core instructions hold the FP64 vector pipe the
+  // chain's dependent instructions need (the pipeline: 19.6 us alone, 33.3 beside a second workgroup). Everything below uses the logical
+  // index t, the block sums included: the results do not depend on the placement. (Not one wave per SIMD: the physical numbering.)
+  int t_;
+  {
+    const int tp = threadIdx.x, wp = tp >> 6;
+    __shared__ int simd_of[S2_WAVES];
+    int lw = wp;
+    if (!TW) {
+      const int simd = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3u);      // HW_REG_HW_ID, SIMD_ID = bits 5:4
+      if ((tp & 63) == 0) simd_of[wp] = simd;
+      __syncthreads();
+      int m = 0;
+      for (int q = 0; q < S2_WAVES; q++) m |= 1 << simd_of[q];
+      lw = (m == 15) ? simd : wp;
+    }
+    t_ = lw * 64 + (tp & 63);
+  }
+  const int t = t_, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#else
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#endif
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
   double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
@@ -1432,7 +1477,7 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   for (int k = 0; k < 9; k++) xn2 += xv[k] * xv[k];    // (|x|^2 over the free parameter blocks: a block per thread, its entries in order; absent ones add an exact zero)
   {
     const double pv[3] = {g2, gmax, xn2};
-    block_reduce_multi<3>(pv, 0x2u, smem);
+    block_reduce_multi<3>(pv, 0x2u, smem, BRM_T);
     if (t == 0) { s_keep[0] = smem[48]; s_keep[1] = smem[49]; s_keep[2] = smem[50]; }   // (needed at the very end: parked in LDS, not in registers)
   }
   __syncthreads();
@@ -1553,7 +1598,7 @@ if (!TW) {
       }
       {
         const double zv[2] = {zz, vsv};
-        block_reduce_multi<2>(zv, 0u, cterm);      // (same wave-order sums as two block_sum calls; cterm: free since the prologue)
+        block_reduce_multi<2>(zv, 0u, cterm, BRM_T);      // (same wave-order sums as two block_sum calls; cterm: free since the prologue)
         if (t == 0) { s_zz = cterm[32] + (s_zzc[0] + s_zzc[1]); s_vSv = cterm[33]; }
       }
       __syncthreads();
@@ -1788,7 +1833,7 @@ if (!TW) {
   }
   {
     const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
-    block_reduce_multi<8>(gv, 0u, smem);
+    block_reduce_multi<8>(gv, 0u, smem, BRM_T);
     n2 = smem[128]; gyv = smem[129]; vrhs = smem[130]; vDv = smem[131]; vDy = smem[132]; vEv = smem[133]; vEy = smem[134]; yEy = smem[135];
   }
   if (t == 0) {
@@ -2025,7 +2070,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
   }
   {
     const double pv[3] = {g2, gmax, xn2};
-    block_reduce_multi<3>(pv, 0x2u, smem);
+    block_reduce_multi<3>(pv, 0x2u, smem, BRM_T);
     g2 = smem[48]; gmax = smem[49]; xn2 = smem[50];
   }
   __syncthreads();
@@ -2156,7 +2201,7 @@ __global__ __launch_bounds__(BIG_THREADS) void k_solve_big(BatchDev d, int retry
   }
   {
     const double gv[8] = {n2, gyv, vrhs, vDv, vDy, vEv, vEy, yEy};
-    block_reduce_multi<8>(gv, 0u, smem);
+    block_reduce_multi<8>(gv, 0u, smem, BRM_T);
     n2 = smem[128]; gyv = smem[129]; vrhs = smem[130]; vDv = smem[131]; vDy = smem[132]; vEv = smem[133]; vEy = smem[134]; yEy = smem[135];
   }
   if (t == 0) {
