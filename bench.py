@@ -432,7 +432,7 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
     whole_tf = useful_lin * lin_per_solve * value / 1e12
     alg_bytes = 108.0 * units_per_launch                                   # the fused form's 12 f64 + 3 i32 per factor
     hbm_tbs = alg_bytes / (lin_ms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "k_vis<0, %s, true> (visual evaluate + linearise + fused [Y r]^T [Y r] AT THE CANDIDATE, its inverse depths formed at the kernel's head: seven of the "
+    return {"bound": "hbm", "kernel": "k_vis<0, %s, true> as k_vis_chunk<true>: a wave per (window, start frame, four landmark tiles) (visual evaluate + linearise + fused [Y r]^T [Y r] AT THE CANDIDATE, its inverse depths formed at the kernel's head: seven of the "
                                      "eight launches of a solve; `first_iteration_launch_ms`: the variant of the first iteration)" % ("full 20-column panel" if full_panel else "7 x 7 panel, both rows of a factor in one 16-wide tile"),
             "achieved": hbm_tbs * 1e3, "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s", "frac": hbm_tbs / PEAK_HBM_TBS,
             "why_hbm": "`frac` prices SURVEY 8d's algorithmic 108 B per factor (the fused form's 12 f64 + 3 i32 of INPUT per factor) over the kernel's launch "
@@ -519,8 +519,9 @@ def pmc_summary(windows_per_launch):
                 return res
             tot = 0.0
             for fn, key in ((tag + "_pmc_fetch.txt", "FETCH_SIZE"), (tag + "_pmc_write.txt", "WRITE_SIZE")):
-                cand = [x for x in blocks(fn) if pat["k_vis"] in x["head"] and ("grid=(%d," % (64 * windows_per_launch)) in x["head"]]   # one part of the batch
-                b = ([x for x in cand if "Lb1EEEv" in x["head"]] or cand)[0]      # (the at-candidate variant k_vis<0, false, true>: the one timed)
+                cand = [x for x in blocks(fn) if (pat["k_vis"] in x["head"] or "k_vis_chunk" in x["head"]) and ("grid=(%d," % (64 * windows_per_launch)) in x["head"]]   # one part of the batch
+                # (the at-candidate variant, the one timed: k_vis_chunk<true> since round 6's persistent launch, k_vis<0, false, true> before)
+                b = ([x for x in cand if "k_vis_chunkILb1" in x["head"]] or [x for x in cand if "Lb1EEEv" in x["head"]] or cand)[0]
                 tot += b["c"][key] * 1024.0
             out["k_vis"] = {"traffic": tot}
             # the other kernels of a linearisation: FETCH_SIZE + WRITE_SIZE of their largest launch (one part of the batch, first iteration)
@@ -536,6 +537,8 @@ def pmc_summary(windows_per_launch):
                     out.setdefault(name, {})["traffic"] = t2
             for name, sub in pat.items():
                 bs = [x for x in blocks(tag + "_pmc_sq1.txt") if sub in x["head"] and "SQ_VALU_MFMA_BUSY_CYCLES" in x["c"]]
+                if name == "k_vis":
+                    bs = [x for x in blocks(tag + "_pmc_sq1.txt") if "k_vis_chunkILb1" in x["head"] and "SQ_VALU_MFMA_BUSY_CYCLES" in x["c"]] or bs
                 if bs:
                     b = max(bs, key=lambda x: float(x["head"].split("avg_us=")[1]))
                     us = float(b["head"].split("avg_us=")[1])

@@ -352,7 +352,8 @@ int32_t gfbe_options_size(void);
  * outputs did not fit the device.) */
 gfbe_status gfbe_create(gfbe_ctx **ctx, int device, const gfbe_options *opt);
 /* Frees the context and the device memory it caches. Batches (gfbe_batch_free) and feature tables (gfbe_ftab_destroy) made with
- * the context must be released BEFORE it. */
+ * the context must be released BEFORE it. The HIP streams the context created are kept in a process-wide pool for the next
+ * gfbe_create on the same device (a later context then runs on the hardware queues the first one had); they live until the process ends. */
 void gfbe_destroy(gfbe_ctx *ctx);
 const char *gfbe_last_error(const gfbe_ctx *ctx);
 /* Informational remarks of gfbe_create ("" when there are none); the reference has no counterpart (ROS_WARN at start-up). */
