@@ -575,6 +575,7 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
             b.solve(abi.MARGIN_OLD)
             q.append(b)
         t_up = t_dl = 0.0
+        ht = np.zeros(4)          # gfbe_host_times: upload packing | upload rest | download waiting for the device | download unpacking
         t0 = None
         n_timed = 0
         for s in range(args.e2e_steps + 2):
@@ -584,6 +585,7 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
                     dist.barrier()
                 t0 = time.perf_counter()
                 t_up = t_dl = 0.0
+                ht[:] = 0.0
             ta = time.perf_counter()
             nxt = upload((s + depth - 1) % 2)          # packs + enqueues the copy while the older batches solve
             nxt.solve(abi.MARGIN_OLD)
@@ -592,6 +594,8 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
             cur = q.popleft()
             cur.download_into(bufs)
             tc = time.perf_counter()
+            h = be.host_times()      # (the last upload and the last download of the context: the two calls just made)
+            ht += [h["upload_pack_ms"], h["upload_rest_ms"], h["download_wait_ms"], h["download_unpack_ms"]]
             cur.free()
             t_up += tb - ta
             t_dl += tc - tb
@@ -605,7 +609,13 @@ def end_to_end(args, be, gf, torch, dist, scns, snaps, ref_costs):
             cur.free()
         solves, el = gf.dist.aggregate_throughput(n_timed * B, el, dist)
         return {"value": solves / el, "unit": "solves/s", "ms_per_batch": 1e3 * el / n_timed,
-                "host_ms_in_upload_call": 1e3 * t_up / n_timed, "host_ms_in_download_call": 1e3 * t_dl / n_timed}
+                "host_ms_in_upload_call": 1e3 * t_up / n_timed, "host_ms_in_download_call": 1e3 * t_dl / n_timed,
+                # gfbe_host_times per batch: what the calling thread did (packing, the rest of the upload call + the solve's enqueue, unpacking)
+                # and how long it WAITED for the device inside the download call — host-bound when the work fills the time per batch
+                "host_ms": {"upload_packing": ht[0] / n_timed, "upload_rest_of_the_call_and_solve_enqueue": 1e3 * t_up / n_timed - ht[0] / n_timed,
+                            "download_waiting_for_the_device": ht[2] / n_timed, "download_unpacking": ht[3] / n_timed},
+                "host_work_fraction_of_the_time_per_batch": (1e3 * (t_up + t_dl) - ht[2]) / (1e3 * el),
+                "waiting_for_the_device_fraction": ht[2] / (1e3 * el)}
 
     r = pipeline(lambda q: be.batch_upload(sets[q]))
     costs = [bufs.sums[k].final_cost for k in range(min(nu, B))]

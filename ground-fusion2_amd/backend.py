@@ -20,7 +20,7 @@ _SO = os.environ.get("GFBE_LIB") or os.path.join(_CSRC, "libgfbe.so")
 
 # Every symbol include/gfbe.h declares (checked by tests/test_abi.py on CPU).
 EXPORTS = [
-    "gfbe_default_options", "gfbe_options_size", "gfbe_create", "gfbe_destroy", "gfbe_last_error", "gfbe_create_note", "gfbe_version", "gfbe_set_stream",
+    "gfbe_default_options", "gfbe_options_size", "gfbe_create", "gfbe_destroy", "gfbe_last_error", "gfbe_create_note", "gfbe_host_times", "gfbe_version", "gfbe_set_stream",
     "gfbe_feature_count", "gfbe_visual_factor_count", "gfbe_build_visual_factors", "gfbe_set_depth",
     "gfbe_eval_factors", "gfbe_preintegrate_imu", "gfbe_preintegrate_wheel",
     "gfbe_solve_window", "gfbe_solve_batch",
@@ -238,6 +238,14 @@ class Backend(abi.CApi):
             self.lib.gfbe_profile_get(self.ctx, i, C.byref(name), C.byref(launches), C.byref(ms), C.byref(by))
             out.append(dict(name=name.value.decode(), launches=launches.value, total_ms=ms.value, bytes=by.value))
         return out
+
+    def host_times(self):
+        """gfbe_host_times: ms of the calling thread in the last upload (packing | the rest) and the last download (waiting for the device | unpacking)."""
+        out = (C.c_double * 4)()
+        self.lib.gfbe_host_times.restype = None
+        self.lib.gfbe_host_times.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self.lib.gfbe_host_times(self.ctx, out)
+        return dict(upload_pack_ms=out[0], upload_rest_ms=out[1], download_wait_ms=out[2], download_unpack_ms=out[3])
 
     # ---- multi-GPU landmark sharding: the native hook (libgfbe_rccl.so: ncclAllReduce on the solver's stream)
     def set_allreduce_native(self, fn_ptr, user_ptr, rank, world_size):

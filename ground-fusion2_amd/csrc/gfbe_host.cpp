@@ -145,6 +145,7 @@ struct gfbe_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   std::string note;                                   // set by gfbe_create (never an error): gfbe_create_note
+  double host_ms[4] = {0.0, 0.0, 0.0, 0.0};           // gfbe_host_times: upload pack | upload rest | download wait | download unpack
   bool profiling = false;
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> event_pool;
@@ -295,6 +296,7 @@ void gfbe_default_options(gfbe_options *o) {
 const char *gfbe_version(void) { return "gfbe 0.1.0 (gfx950, HIP)"; }
 const char *gfbe_last_error(const gfbe_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 const char *gfbe_create_note(const gfbe_ctx *ctx) { return ctx ? ctx->note.c_str() : ""; }
+void gfbe_host_times(const gfbe_ctx *ctx, double *out4) { if (out4) for (int q = 0; q < 4; q++) out4[q] = ctx ? ctx->host_ms[q] : 0.0; }
 
 gfbe_status gfbe_create(gfbe_ctx **out, int device, const gfbe_options *opt) {
   if (!out) return GFBE_BAD_INPUT;
@@ -776,7 +778,9 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     }
   } else {
     std::atomic<int> bad(-1);
+    const auto t_scan0 = std::chrono::steady_clock::now();
     host_parallel(c, B, [&](int w) { if (!scan_window(*wins[w], w, scan[w])) { int e = -1; bad.compare_exchange_strong(e, w); } });
+    c->host_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan0).count();
     if (bad.load() >= 0) { c->err = scan[bad.load()].err; return GFBE_BAD_INPUT; }
   }
   // ---- serial: offsets of every window in the batch-wide arrays
@@ -1003,6 +1007,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   std::memcpy(h_j0_off, j0_off.data(), sizeof(long long) * (B + 1));
   std::atomic<int> bad(-1);
   std::vector<std::string> errs(B);
+  const auto t_fill0 = std::chrono::steady_clock::now();
   host_parallel(c, B, [&](int w) {
     const gfbe_window &win = *wins[w];
     const WinScan &sc = scan[w];
@@ -1168,6 +1173,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     std::memcpy(ds.ex_wheel_mask, win.ex_wheel_mask, 6);
     b->up_win_bytes[w] = bytes;
   });
+  c->host_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill0).count();
   if (bad.load() >= 0) { c->err = errs[bad.load()]; return GFBE_BAD_INPUT; }
   // k_solve_chain eliminates the speed-bias blocks as a chain: IMUFactor couples SpeedBias[k] with its neighbours only, and the
   // priors the reference builds keep SpeedBias[0] alone (estimator.cpp:3400-3433, 3600-3632). A prior with any other speed-bias
@@ -1331,7 +1337,11 @@ static gfbe_status upload_halves(gfbe_ctx *c, int32_t B, const gfbe_window *cons
 // No C++ exception crosses the C ABI (host staging vectors can throw std::bad_alloc).
 static gfbe_status upload_guarded(gfbe_ctx *c, int32_t B, const gfbe_window *const *wins, gfbe_batch **out, gfbe_ftab *tabs) {
   try {
-    return upload_halves(c, B, wins, out, tabs);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (c) c->host_ms[0] = c->host_ms[1] = 0.0;      // (gfbe_host_times: the packing passes add themselves up over the parts)
+    const gfbe_status st = upload_halves(c, B, wins, out, tabs);
+    if (c) c->host_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - c->host_ms[0];
+    return st;
   } catch (const std::exception &e) {
     if (c) c->err = std::string("gfbe_batch_upload: ") + e.what();
     if (out && *out) { gfbe_batch_free(c, *out); *out = nullptr; }
@@ -1619,7 +1629,10 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
                                 gfbe_prior *const *prior_out, gfbe_summary *summary, const int first, const int *order) {
   const BatchDev &d = b->d;
   const int B = d.B;
+  const auto t_wait0 = std::chrono::steady_clock::now();
   HIPCHK(c, hipEventSynchronize(b->ev_dl));
+  const auto t_wait1 = std::chrono::steady_clock::now();
+  c->host_ms[2] += std::chrono::duration<double, std::milli>(t_wait1 - t_wait0).count();
   b->fetched = true;
   // (the three result arrays are separate 256-byte aligned allocations at the end of the slab: offsets from the device pointers)
   const double *fix = (const double *)b->dl_h;
@@ -1668,6 +1681,7 @@ static gfbe_status download_one(gfbe_ctx *c, gfbe_batch *b, gfbe_state *out_stat
       s.bytes_uploaded = b->up_win_bytes[w]; s.bytes_downloaded = dl_bytes;
     }
   });
+  c->host_ms[3] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait1).count();
   gfbe_status worst = GFBE_OK;
   for (int w = 0; w < B; w++) {
     const int m0 = ((const int *)(fix + (size_t)w * DL_FIX + DL_OFF_META))[0];
@@ -1684,6 +1698,7 @@ extern "C" gfbe_status gfbe_batch_download(gfbe_ctx *c, gfbe_batch *b, gfbe_stat
   if (!c || !b) return GFBE_BAD_INPUT;
   if (c->device < 0) return GFBE_NO_DEVICE;
   // all parts' gathers and copies are enqueued first, then unpacked part by part
+  c->host_ms[2] = c->host_ms[3] = 0.0;      // (summed over the parts of this call)
   for (gfbe_batch *p = b; p; p = p->second) { const gfbe_status st = fetch_one(c, p); if (st != GFBE_OK) return st; }
   gfbe_status worst = GFBE_OK;
   int done = 0;

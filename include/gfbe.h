@@ -686,6 +686,12 @@ int32_t gfbe_profile_count(const gfbe_ctx *ctx);
 gfbe_status gfbe_profile_get(const gfbe_ctx *ctx, int32_t i, const char **name, int64_t *launches,
                              double *total_ms, double *algorithmic_bytes);
 void gfbe_profile_reset(gfbe_ctx *ctx);
+/* Where the calling thread spent the LAST gfbe_batch_upload(_tables) and the LAST gfbe_batch_download of this context, milliseconds on the
+ * host's clock: out4 = [ upload: scan + packing into pinned memory | upload: the rest of the call (allocation, enqueue of the copy and the
+ * expansion kernels) | download: WAITING for the device (the solve, the gather kernel, the copy) | download: unpacking into the caller's
+ * structures ]. A pipeline that keeps several batches in flight is host-bound when the first, second and fourth add up to its time per
+ * batch, and device-bound when the third is what is left (bench.py's end_to_end block reports both). */
+void gfbe_host_times(const gfbe_ctx *ctx, double *out4);
 
 /* Diagnostics: phase time stamps (10 ns ticks) of the dense solve kernel for window w of a batch. */
 gfbe_status gfbe_debug_timing(gfbe_ctx *ctx, gfbe_batch *batch, int32_t w, double *out32);
