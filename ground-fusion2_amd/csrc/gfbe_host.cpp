@@ -53,15 +53,20 @@ class HostPool {
     for (auto &t : th_) t.join();
   }
   int size() const { return (int)th_.size(); }
-  // fn(i) for i in [0, n) on `helpers` workers + the calling thread; returns when all are done
+  // fn(i) for i in [0, n) on up to `helpers` workers + the calling thread; returns when all are done. Only as many workers are woken as the
+  // job wants (round 6: a 47-thread pool sized for the packing passes woke every thread for the 15-helper unpacking of a download — 1.2 ms of
+  // work became 3.4 - 4.3): a worker JOINS a job under the lock while places are left, the caller closes the job (no places) before it waits
+  // for those who joined.
   void run(int n, int helpers, const std::function<void(int)> &fn) {
+    helpers = std::min(helpers, (int)th_.size());
     {
       std::lock_guard<std::mutex> lk(m_);
-      fn_ = &fn; n_ = n; next_.store(0); active_ = std::min(helpers, (int)th_.size()); running_ = active_; gen_++;
+      fn_ = &fn; n_ = n; next_.store(0); places_ = helpers; running_ = 0; gen_++;
     }
-    cv_.notify_all();
+    for (int i = 0; i < helpers; i++) cv_.notify_one();
     for (int i; (i = next_.fetch_add(1)) < n;) fn(i);
     std::unique_lock<std::mutex> lk(m_);
+    places_ = 0;
     done_.wait(lk, [this] { return running_ == 0; });
     fn_ = nullptr;
   }
@@ -77,20 +82,21 @@ class HostPool {
         cv_.wait(lk, [&] { return gen_ != seen; });
         seen = gen_;
         if (stop_) return;
-        if (active_ <= 0) continue;     // more workers than this job wants
-        active_--;
+        if (places_ <= 0) continue;     // the job is full, or already closed
+        places_--; running_++;
         fn = fn_; n = n_;
       }
       for (int i; (i = next_.fetch_add(1)) < n;) (*fn)(i);
-      { std::lock_guard<std::mutex> lk(m_); running_--; }
-      done_.notify_all();
+      bool last;
+      { std::lock_guard<std::mutex> lk(m_); last = --running_ == 0; }
+      if (last) done_.notify_all();
     }
   }
   std::vector<std::thread> th_;
   std::mutex m_;
   std::condition_variable cv_, done_;
   const std::function<void(int)> *fn_ = nullptr;
-  int n_ = 0, active_ = 0, running_ = 0;
+  int n_ = 0, places_ = 0, running_ = 0;
   std::atomic<int> next_{0};
   unsigned long long gen_ = 0;
   bool stop_ = false;
@@ -581,9 +587,14 @@ void pin_release(gfbe_ctx *c, char *p, size_t cap) {
 }
 
 // One window per task on the context's host threads (the caller takes part); n == 1 or host_threads == 1 runs inline.
-void host_parallel(gfbe_ctx *c, int n, const std::function<void(int)> &fn) {
-  int want = c->opt.host_threads > 0 ? c->opt.host_threads : std::min<int>(24, std::max(1u, std::thread::hardware_concurrency()));
-  // (measured, 1024 windows per batch on a 2 x 64-core host: 8 threads 40.8k, 16: 58.6k, 24: 69.5k, 32: 62-68k, 64: 50.4k, 128: 35.5k solves/s end to end)
+// heavy: the packing passes of an upload (~200 us of scan + fill per 2k-landmark window) — the default thread count is higher there than
+// for the unpacking of a download (~5 us per window: more than 16 threads only add wake-ups).
+void host_parallel(gfbe_ctx *c, int n, const std::function<void(int)> &fn, bool heavy = false) {
+  const int hc = (int)std::max(1u, std::thread::hardware_concurrency());
+  // (measured, 1024 windows per batch on a 2 x 64-core host, ONE count for both: 8 threads 40.8k, 16: 58.6k, 24: 69.5k, 32: 62-68k, 64: 50.4k,
+  //  128: 35.5k solves/s end to end. Round 6, the two jobs apart, ms per batch at 8 / 16 / 24 / 32 / 48 / 64 threads: packing 15.4 / 7.9 /
+  //  6.3 / 5.7 / 5.0 / 9.6, unpacking 1.3 / 1.2 / 1.4 / 2.4 / 3.6 / 1.0: 48 for the first when the host has the cores, 16 for the second)
+  int want = c->opt.host_threads > 0 ? c->opt.host_threads : (heavy ? (hc >= 128 ? 48 : std::min(24, hc)) : std::min(16, hc));
   want = std::min(want, n);
   if (want <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
   if (!c->pool || c->pool->size() < want - 1) c->pool.reset(new HostPool(want - 1));
@@ -779,7 +790,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
   } else {
     std::atomic<int> bad(-1);
     const auto t_scan0 = std::chrono::steady_clock::now();
-    host_parallel(c, B, [&](int w) { if (!scan_window(*wins[w], w, scan[w])) { int e = -1; bad.compare_exchange_strong(e, w); } });
+    host_parallel(c, B, [&](int w) { if (!scan_window(*wins[w], w, scan[w])) { int e = -1; bad.compare_exchange_strong(e, w); } }, true);
     c->host_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan0).count();
     if (bad.load() >= 0) { c->err = scan[bad.load()].err; return GFBE_BAD_INPUT; }
   }
@@ -1172,7 +1183,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     std::memcpy(ds.ex_cam_mask, win.ex_cam_mask, 6);
     std::memcpy(ds.ex_wheel_mask, win.ex_wheel_mask, 6);
     b->up_win_bytes[w] = bytes;
-  });
+  }, true);
   c->host_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fill0).count();
   if (bad.load() >= 0) { c->err = errs[bad.load()]; return GFBE_BAD_INPUT; }
   // k_solve_chain eliminates the speed-bias blocks as a chain: IMUFactor couples SpeedBias[k] with its neighbours only, and the

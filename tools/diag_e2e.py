@@ -23,14 +23,14 @@ bufs = gf.DownloadBuffers(B, max(h.n_feature for h in sets[0].holders))
 q = deque()
 for i in range(DEPTH - 1):
     b = be.batch_upload(sets[i % 2]); b.solve(abi.MARGIN_OLD); q.append(b)
-T = dict(upload=0.0, solve_enqueue=0.0, download=0.0, free=0.0)
+T = dict(upload=0.0, solve_enqueue=0.0, download=0.0, free=0.0, pack=0.0, wait=0.0, unpack=0.0)
 for s in range(STEPS + 2):
     if s == 2:
         torch.cuda.synchronize(); t0 = time.perf_counter(); T = {k: 0.0 for k in T}
     a = time.perf_counter(); nxt = be.batch_upload(sets[(s + DEPTH - 1) % 2])
     b_ = time.perf_counter(); nxt.solve(abi.MARGIN_OLD); q.append(nxt)
     c = time.perf_counter(); cur = q.popleft(); cur.download_into(bufs)
-    d_ = time.perf_counter(); cur.free()
+    d_ = time.perf_counter(); h = be.host_times(); T["pack"] += 1e-3 * h["upload_pack_ms"]; T["wait"] += 1e-3 * h["download_wait_ms"]; T["unpack"] += 1e-3 * h["download_unpack_ms"]; cur.free()
     e = time.perf_counter()
     T["upload"] += b_ - a; T["solve_enqueue"] += c - b_; T["download"] += d_ - c; T["free"] += e - d_
 torch.cuda.synchronize(); el = time.perf_counter() - t0
