@@ -418,6 +418,8 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": ach / peak}
         if name in pmc and "mfma_busy" in pmc[name]:
             kernels[name]["mfma_busy_pmc"] = pmc[name]["mfma_busy"]
+            if "valu_busy_at_4_cycles" in pmc[name]:      # the FP64 matrix-core instructions share the SIMD's issue with the vector ones
+                kernels[name]["simd_issue_busy_pmc"] = pmc[name]["mfma_busy"] + pmc[name]["valu_busy_at_4_cycles"]
         if name in pmc and pmc[name].get("traffic"):      # what the HBM pipe carried for this launch (PMC passes of the committed profile set)
             kernels[name]["counter_bytes_per_launch"] = pmc[name]["traffic"]
             kernels[name]["frac_of_hbm_on_counter_bytes"] = pmc[name]["traffic"] / (us * 1e-6) / 1e12 / PEAK_HBM_TBS
@@ -446,6 +448,12 @@ def roofline_block(args, prof, nprof, K_batch, batch_snaps, value, iters):
                           "frac_useful": achieved_tf / PEAK_F64_TF * useful / issued,
                           "flops_per_factor": {"issued": issued, "useful": useful, "round3_13_column_panel_issued": 1024.0, "survey_8d_full_panel": 1600.0},
                           "mfma_busy_pmc": kv.get("mfma_busy")},
+            # what the two largest kernels are bound by (round 6 ablations, profiles/r6_kvis_ablation.txt): the SIMDs' issue time. A 16 x 16 x 4
+            # FP64 matrix-core instruction holds the pipe 64 cycles (the FP64 vector rate: no faster, only fewer instructions) and shares it with
+            # the vector instructions: SQ_VALU_MFMA_BUSY_CYCLES + 4 cycles per SQ_INSTS_VALU over 1024 SIMDs x launch time x 2.4 GHz (the
+            # clock under this load is 2.1 - 2.2 GHz, and FP64 vector instructions take 6.5 - 8 cycles: a lower bound)
+            "simd_issue_view": {"mfma_busy_pmc": kv.get("mfma_busy"), "vector_busy_at_4_cycles_per_instruction_pmc": kv.get("valu_busy_at_4_cycles"),
+                                "sum": (kv.get("mfma_busy") + kv.get("valu_busy_at_4_cycles")) if (kv.get("mfma_busy") is not None and kv.get("valu_busy_at_4_cycles") is not None) else None},
             "traffic": kv.get("traffic"), "traffic_source": pmc.get("source"),
             "counters_taken_from_this_build": pmc.get("taken_from_this_build"), "counters_source_digest": pmc.get("source_digest"), "this_build_source_digest": kernel_source_digest(),
             "avg_launch_ms": lin_ms, "factors_per_launch": units_per_launch, "windows_per_launch": windows_per_launch,
@@ -481,14 +489,20 @@ def schur_tile_pairs(snaps):
 
 
 def kernel_source_digest():
-    """sha256 over the library's sources (csrc/*.hip, *.h, *.cpp, include/gfbe.h): what a committed PMC profile set is labelled with, so
+    """sha256 over the library's sources without their comments (csrc/*.hip, *.h, *.cpp, include/gfbe.h): what a committed PMC profile set is labelled with, so
     that counter-derived fields can say whether they were taken from THIS build."""
     import hashlib
     h = hashlib.sha256()
     cs = os.path.join(ROOT, "ground-fusion2_amd", "csrc")
     files = sorted(os.path.join(cs, f) for f in os.listdir(cs) if f.endswith((".hip", ".h", ".cpp")))
+    import re
     for f in files + [os.path.join(ROOT, "include", "gfbe.h")]:
-        h.update(open(f, "rb").read())
+        # (comments and white space do not make another build: a sentence corrected in gfbe.h after the profile set was taken does not
+        #  turn its counters into another library's)
+        txt = open(f, "r", errors="replace").read()
+        txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+        txt = re.sub(r"//[^\n]*", " ", txt)
+        h.update(" ".join(txt.split()).encode())
     return h.hexdigest()[:16]
 
 
@@ -543,6 +557,8 @@ def pmc_summary(windows_per_launch):
                     b = max(bs, key=lambda x: float(x["head"].split("avg_us=")[1]))
                     us = float(b["head"].split("avg_us=")[1])
                     out.setdefault(name, {})["mfma_busy"] = b["c"]["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * us * 2400.0)
+                    if "SQ_INSTS_VALU" in b["c"]:      # a wave64 vector instruction holds its SIMD's vector pipe >= 4 cycles (FP64: 6.5 - 8, profiles/ubench)
+                        out[name]["valu_busy_at_4_cycles"] = 4.0 * b["c"]["SQ_INSTS_VALU"] / (1024.0 * us * 2400.0)
             return out
         except Exception:
             continue

@@ -267,7 +267,8 @@ typedef struct gfbe_options {
    * reference's behaviour sets 0.04 (or 0.032); at 2 ms per solve it never triggers. */
   double max_solver_time_in_seconds;
   /* Host threads gfbe_batch_upload / gfbe_batch_download pack and unpack windows with (one window per task).
-   * 0 (default) = min(hardware threads, 24); 1 = the calling thread only. */
+   * 0 (default) = the library's choice per job: the packing passes of an upload min(hardware threads, 24) — 48 on a host with 128 or more
+   * hardware threads —, the unpacking of a download min(hardware threads, 16); 1 = the calling thread only. */
   int32_t host_threads;
   /* Factorisation of the reduced system (the DENSE_SCHUR linear solve of estimator.cpp:3364-3379 after the landmark elimination):
    *   0 (default)  the speed-bias blocks are eliminated as a chain of 9 x 9 blocks before the dense pose / extrinsic part is
