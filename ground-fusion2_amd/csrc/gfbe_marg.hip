@@ -906,7 +906,8 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
 #endif
 // loadA(i, j): entry (i, j) of A'; loadB(i): entry i of b' — from the compact arrays k_marg left (k_marg_ldlt), or formed on the fly
 // from the Schur operands in LDS (the LDL^T at the tail of k_marg itself).
-template <int R, class LoadA, class LoadB>
+// NT: the threads that run this function (a multiple of 64, a power of two of waves)
+template <int R, int NT = LDLT_THREADS, class LoadA, class LoadB>
 __device__ __forceinline__ int ldlt_registers(LoadA loadA, LoadB loadB, double *__restrict__ J0,
                                               double *__restrict__ r0, const int n, const double eps, double *lstamp) {
   const int t = threadIdx.x;
@@ -991,7 +992,7 @@ __device__ __forceinline__ int ldlt_registers(LoadA loadA, LoadB loadB, double *
       double cx[3];
 #pragma unroll
       for (int q = 0; q < 3; q++) cx[q] = cb[lane + 64 * q];
-      if (wv == (k & (LDLT_THREADS / 64 - 1))) {                                   // row k of J0, r0[k]
+      if (wv == (k & (NT / 64 - 1))) {                                             // row k of J0, r0[k]
         const double rs = 1.0 / sqrt(piv);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -1020,8 +1021,8 @@ __device__ __forceinline__ int ldlt_registers(LoadA loadA, LoadB loadB, double *
       LSTAMP(5);
     }
 #undef LSTAMP
-    for (int e = t + rank * n; e < n * n; e += LDLT_THREADS) J0[e] = 0.0;      // (LDLT_THREADS threads run this function, whatever the workgroup's size)
-    for (int k = t + rank; k < n; k += LDLT_THREADS) r0[k] = 0.0;
+    for (int e = t + rank * n; e < n * n; e += NT) J0[e] = 0.0;      // (NT threads run this function, whatever the workgroup's size)
+    for (int k = t + rank; k < n; k += NT) r0[k] = 0.0;
     return rank;
 }
 
@@ -1464,6 +1465,30 @@ __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
 }
 
+// Throughput batches (round 6): the priors of up to 88 dims as 8 x 8 register tiles on an 11 x 11 thread grid — TWO waves per window
+// instead of eight, 200 VGPRs: four windows per CU at once instead of two, a block barrier between two waves instead of eight, 64
+// multiply-adds per thread and pivot instead of 16. Every entry sees the operations of k_marg_ldlt<4> in its order (the tile size only
+// says which thread holds it): the same bits.
+#define LDLT_TP_THREADS 128
+#ifndef GFBE_LDLT_TP
+#define GFBE_LDLT_TP 1
+#endif
+__global__ __launch_bounds__(LDLT_TP_THREADS) void k_marg_ldlt_tp(BatchDev d) {
+  const int w = blockIdx.x;
+  int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
+  if (meta[0] != 1 || meta[3] != MARG_SQRT_PENDING) return;
+  const int n = meta[1];
+  if (n > 4 * 22) return;      // (k_marg_ldlt<8>, launched behind this kernel when the batch may hold such a prior)
+  const double *A = d.mA + (size_t)w * ND * ND;
+  const double *bv = d.mb + (size_t)w * ND;
+  double *J0 = d.mJ0 + (size_t)w * ND * ND;
+  double *r0 = d.mr0 + (size_t)w * ND;
+  double *stamp = d.timing + 24;
+  const int rank = ldlt_registers<8, LDLT_TP_THREADS>([&](int i, int j) { return A[(size_t)i * n + j]; }, [&](int i) { return bv[i]; }, J0, r0, n,
+                                                      d.opt.marg_eps, d.timing + (size_t)d.B * 32);
+  if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
+}
+
 // MARGIN_OLD: the partials of the marginalisation set at the re-anchored state (visual factors of the landmarks
 // starting in frame 0, the inertial / wheel factor of frame 0, their Schur partial)
 void launch_marginalize_partials(const BatchDev &d, hipStream_t s) {
@@ -1495,7 +1520,8 @@ void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s) {
   //  marginalisation of 1024 windows; a single window keeps the 1024 threads of its one workgroup)
   hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(d.B >= DENSE_SPLIT_MIN_B ? MARG_THREADS / 2 : MARG_THREADS), lds, s, d, flag);
   if (d.opt.marg_sqrt == 1) {
-    hipLaunchKernelGGL(k_marg_ldlt<4>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
+    if (GFBE_LDLT_TP && d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_marg_ldlt_tp, dim3(d.B), dim3(LDLT_TP_THREADS), 0, s, d);
+    else hipLaunchKernelGGL(k_marg_ldlt<4>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
     if (d.marg_nmax > 4 * 22) hipLaunchKernelGGL(k_marg_ldlt<8>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
   }
 }

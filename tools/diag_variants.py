@@ -46,6 +46,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "chunk8": (["-DVIS_CHUNK=8"], "off"),
     "chunk6": (["-DVIS_CHUNK=6"], "off"),
     "nochunk": (["-DGFBE_VIS_CHUNK=0"], "off"),
+    "noldlttp": (["-DGFBE_LDLT_TP=0"], "off"),
     "pf2": (["-DGFBE_WIDE_PREFETCH2=1"], "off"),
     "nosimdroles": (["-DGFBE_CHAIN_SIMD_ROLES=0"], "off"),
     "ql": (["-DGFBE_EIG_DC=0"], "off"),
