@@ -2519,7 +2519,9 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
 //   k_asm_table (independent loads, four entries in flight per thread); E and eg = sums of the start-frame
 //   Schur partials.
 #define VB_THREADS 1024
+#ifndef VB_GROUP
 #define VB_GROUP 512
+#endif
 #define V_LD 74
 // SPLIT (small batches): one 512-thread workgroup per (start frame, thread group, window) writes its own block
 // vis_Hs[w][2 i + group]; k_assemble adds the 20 blocks in (start frame, group) order — exactly the additions, in exactly the

@@ -1029,6 +1029,9 @@ __device__ __forceinline__ int ldlt_registers(LoadA loadA, LoadB loadB, double *
 #ifndef MARG_THREADS
 #define MARG_THREADS 1024
 #endif
+#ifndef GFBE_MARG_TP_THREADS
+#define GFBE_MARG_TP_THREADS 512      // k_marg's workgroup in throughput batches
+#endif
 #define MARG_SQRT_PENDING (-1000000)
 #define MARG_LDS_N 90   // A' up to this size is eigen-decomposed entirely inside LDS (2 n^2 doubles + the 14 n of tridiag_ql_eig's scratch)
 #define MARG_LDS_DOUBLES (2 * MARG_LDS_N * MARG_LDS_N + 14 * MARG_LDS_N)
@@ -1465,15 +1468,25 @@ __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
 }
 
-// Throughput batches (round 6): the priors of up to 88 dims as 8 x 8 register tiles on an 11 x 11 thread grid — TWO waves per window
-// instead of eight, 200 VGPRs: four windows per CU at once instead of two, a block barrier between two waves instead of eight, 64
-// multiply-adds per thread and pivot instead of 16. Every entry sees the operations of k_marg_ldlt<4> in its order (the tile size only
-// says which thread holds it): the same bits.
-#define LDLT_TP_THREADS 128
+// Throughput batches (round 6): ONE wave per window. The workgroup form above updates all n^2 entries at every pivot on eight waves (both
+// triangles, 16 entries per thread): beside the other parts' kernels what counts is the waves it holds and the FP64 instructions it issues
+// (it is bound by them: 512 windows x 86 pivots x 7744 entries x (mul + sub) at 8 cycles per instruction = the 145 us it took per launch).
+// Here the LOWER triangle only, as 9 x 9 register tiles on the 55 tiles of a 10 x 10 grid — one lane each, n <= 90: 0.6 of the
+// instructions, an eighth of the waves, no block barrier (the published row goes through LDS inside the wave). Row p_k of the symmetric
+// matrix is row p_k of the tiles left of the diagonal tile and column p_k of the tiles below it. Every entry that is kept sees the
+// operations ldlt_registers applies to it, in their order — but NOT the same bits at the end: the workgroup form updates entry (i, j)
+// with (c_i / d) c_j and entry (j, i) with (c_j / d) c_i, its matrix is symmetric to rounding only, and it publishes row p_k from the
+// upper triangle where this one reads the lower. Measured on 60 priors (tools/diag_scripts/ldlt_wave_check.py): J0^T J0 agrees to 1.1e-14
+// of its largest entry, J0^T r0 to 1.1e-12 (entries of J0 along the weakest directions move by up to 1.5e-4; one prior keeps a pivot that
+// sits on the eps threshold which the other drops). The two kernel sets are compared on tolerances everywhere (tests/test_gpu_parity.py::
+// test_large_batch_throughput_path, tools/diag_soak_batch.py: 0 discrete differences in 300 windows); inside the throughput set a window's
+// prior does not depend on the batch.
 #ifndef GFBE_LDLT_TP
 #define GFBE_LDLT_TP 1
 #endif
-__global__ __launch_bounds__(LDLT_TP_THREADS) void k_marg_ldlt_tp(BatchDev d) {
+enum { LW_R = 9, LW_G = 10, LW_TILES = LW_G * (LW_G + 1) / 2, LW_MAX_N = LW_R * LW_G, LW_CB = 128 };
+static_assert(LW_TILES <= 64 && LW_MAX_N >= 4 * 22 && LW_MAX_N <= LW_CB, "k_marg_ldlt_tp: one lane per lower tile, every prior k_marg_ldlt<4> takes");
+__global__ __launch_bounds__(64) void k_marg_ldlt_tp(BatchDev d) {
   const int w = blockIdx.x;
   int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
   if (meta[0] != 1 || meta[3] != MARG_SQRT_PENDING) return;
@@ -1483,10 +1496,109 @@ __global__ __launch_bounds__(LDLT_TP_THREADS) void k_marg_ldlt_tp(BatchDev d) {
   const double *bv = d.mb + (size_t)w * ND;
   double *J0 = d.mJ0 + (size_t)w * ND * ND;
   double *r0 = d.mr0 + (size_t)w * ND;
-  double *stamp = d.timing + 24;
-  const int rank = ldlt_registers<8, LDLT_TP_THREADS>([&](int i, int j) { return A[(size_t)i * n + j]; }, [&](int i) { return bv[i]; }, J0, r0, n,
-                                                      d.opt.marg_eps, d.timing + (size_t)d.B * 32);
-  if (threadIdx.x == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) stamp[6] = (double)wall_clock64(); }
+  const double eps = d.opt.marg_eps;
+  constexpr int R = LW_R;
+  const int lane = threadIdx.x;
+  __shared__ double colbuf[2][LW_CB];
+  colbuf[0][lane] = 0.0; colbuf[0][lane + 64] = 0.0; colbuf[1][lane] = 0.0; colbuf[1][lane + 64] = 0.0;
+  int ti = 0, tj = 0;
+  const bool owner = lane < LW_TILES;
+  if (owner) { while ((ti + 1) * (ti + 2) / 2 <= lane) ti++; tj = lane - ti * (ti + 1) / 2; }      // tile lane of the lower triangle, row-major: ti >= tj
+  double a[R][R];
+#pragma unroll
+  for (int r = 0; r < R; r++)
+#pragma unroll
+    for (int c = 0; c < R; c++) {
+      const int i = ti * R + r, j = tj * R + c;
+      a[r][c] = (owner && i < n && j < n) ? A[(size_t)i * n + j] : 0.0;
+    }
+  double dg[2], bzr[2];
+  bool alive[2];
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int i = lane + 64 * q;
+    alive[q] = i < n;
+    dg[q] = alive[q] ? A[(size_t)i * n + i] : 0.0;
+    bzr[q] = alive[q] ? bv[i] : 0.0;
+  }
+  int rank = n;
+  for (int k = 0; k < n; k++) {
+    // the largest remaining diagonal entry, smallest index among equals (ldlt_registers: three 32-bit reductions)
+    unsigned khi = 0, klo = 0;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const unsigned h = (unsigned)__double2hiint(dg[q]), l = (unsigned)__double2loint(dg[q]);
+      const bool cand = alive[q] && !(h >> 31);
+      const bool gt = cand && (h > khi || (h == khi && l > klo));
+      khi = gt ? h : khi; klo = gt ? l : klo;
+    }
+    const unsigned mh = wave_max_u32(khi);
+    const unsigned ml = wave_max_u32(khi == mh ? klo : 0u);
+    unsigned ci_ = 0xffffffffu;
+#pragma unroll
+    for (int q = 1; q >= 0; q--)
+      if (alive[q] && (unsigned)__double2hiint(dg[q]) == mh && (unsigned)__double2loint(dg[q]) == ml) ci_ = (unsigned)(lane + 64 * q);
+    const int pv = (int)wave_min_u32(ci_);
+    const double piv = __hiloint2double((int)mh, (int)ml);
+    if (!(piv > eps) || (mh | ml) == 0u) { rank = k; break; }
+    const double inv = 1.0 / piv;
+    const int pq = pv >> 6, pl = pv & 63;
+    const double zk = __shfl(pq == 0 ? bzr[0] : bzr[1], pl, 64);
+    double *cb = colbuf[k & 1];
+    const int pr = pv / R, pc = pv - pr * R;
+    if (owner && ti == pr) {                       // row p_k: its entries left of and inside the diagonal tile
+#pragma unroll
+      for (int c = 0; c < R; c++) {
+        double v = a[0][c];
+#pragma unroll
+        for (int r = 1; r < R; r++) v = pc == r ? a[r][c] : v;
+        cb[tj * R + c] = v;
+      }
+    }
+    if (owner && tj == pr && ti > pr) {            // ... and below it: column p_k of the tiles under the diagonal tile
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        double v = a[r][0];
+#pragma unroll
+        for (int c = 1; c < R; c++) v = pc == c ? a[r][c] : v;
+        cb[ti * R + r] = v;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    double cx[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) cx[q] = cb[lane + 64 * q];
+    {                                              // row k of J0, r0[k]
+      const double rs = 1.0 / sqrt(piv);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int i = lane + 64 * q;
+        if (i < n) J0[(size_t)k * n + i] = i == pv ? sqrt(piv) : (alive[q] ? cx[q] * rs : 0.0);
+      }
+      if (lane == 0) r0[k] = zk * rs;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const double li = cx[q] * inv;
+      dg[q] -= li * cx[q];
+      bzr[q] -= li * zk;
+      if (lane + 64 * q == pv) alive[q] = false;
+    }
+    if (owner) {
+      double ci[R], cj[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) { ci[r] = cb[ti * R + r] * inv; cj[r] = cb[tj * R + r]; }
+#pragma unroll
+      for (int r = 0; r < R; r++)
+#pragma unroll
+        for (int c = 0; c < R; c++) a[r][c] -= ci[r] * cj[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int e = lane + rank * n; e < n * n; e += 64) J0[e] = 0.0;
+  for (int k = lane + rank; k < n; k += 64) r0[k] = 0.0;
+  if (lane == 0) { meta[3] = -rank; d.ctl[w].t_marg = (long long)wall_clock64(); if (w == 0) d.timing[24 + 6] = (double)wall_clock64(); }
 }
 
 // MARGIN_OLD: the partials of the marginalisation set at the re-anchored state (visual factors of the landmarks
@@ -1518,9 +1630,9 @@ void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s) {
   const size_t lds = sizeof(double) * (d.opt.marg_sqrt == 1 ? 4 * 32 * 32 : MARG_LDS_DOUBLES);
   // (throughput batches: 512-thread workgroups, two per CU, overlap each other's barrier stalls — 1.04 -> 0.92 ms for the whole
   //  marginalisation of 1024 windows; a single window keeps the 1024 threads of its one workgroup)
-  hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(d.B >= DENSE_SPLIT_MIN_B ? MARG_THREADS / 2 : MARG_THREADS), lds, s, d, flag);
+  hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(d.B >= DENSE_SPLIT_MIN_B ? GFBE_MARG_TP_THREADS : MARG_THREADS), lds, s, d, flag);
   if (d.opt.marg_sqrt == 1) {
-    if (GFBE_LDLT_TP && d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_marg_ldlt_tp, dim3(d.B), dim3(LDLT_TP_THREADS), 0, s, d);
+    if (GFBE_LDLT_TP == 2 || (GFBE_LDLT_TP && d.B >= DENSE_SPLIT_MIN_B)) hipLaunchKernelGGL(k_marg_ldlt_tp, dim3(d.B), dim3(64), 0, s, d);      // (2: every batch — the bit-for-bit check against k_marg_ldlt<4>)
     else hipLaunchKernelGGL(k_marg_ldlt<4>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
     if (d.marg_nmax > 4 * 22) hipLaunchKernelGGL(k_marg_ldlt<8>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
   }

@@ -46,7 +46,12 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "chunk8": (["-DVIS_CHUNK=8"], "off"),
     "chunk6": (["-DVIS_CHUNK=6"], "off"),
     "nochunk": (["-DGFBE_VIS_CHUNK=0"], "off"),
+    "marg256": (["-DGFBE_MARG_TP_THREADS=256"], "off"),
+    "marg1024": (["-DGFBE_MARG_TP_THREADS=1024"], "off"),
+    "vb256": (["-DVB_GROUP=256", "-DGFBE_VISASM_WAVES=2"], "off"),
+    "vb384": (["-DVB_GROUP=384", "-DGFBE_VISASM_WAVES=3"], "off"),
     "noldlttp": (["-DGFBE_LDLT_TP=0"], "off"),
+    "ldlttp2": (["-DGFBE_LDLT_TP=2"], "off"),
     "pf2": (["-DGFBE_WIDE_PREFETCH2=1"], "off"),
     "nosimdroles": (["-DGFBE_CHAIN_SIMD_ROLES=0"], "off"),
     "ql": (["-DGFBE_EIG_DC=0"], "off"),
