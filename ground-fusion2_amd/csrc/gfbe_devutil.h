@@ -11,6 +11,17 @@ namespace gfd {
 #define GF_MAX_MU 1.0
 #define GF_MU_INC 10.0
 
+// (round 6) s_setprio at the head of the short, latency-bound kernels of a throughput batch: their few waves share SIMDs with the streaming
+// kernels of the batch's other parts (GFBE_PRIO_SMALL = 0: the priorities are left alone)
+#ifndef GFBE_PRIO_SMALL
+#define GFBE_PRIO_SMALL 0
+#endif
+#if GFBE_PRIO_SMALL
+#define GFBE_SMALL_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define GFBE_SMALL_KERNEL_PRIO() do { } while (0)
+#endif
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

@@ -2,13 +2,14 @@
 //   problem set-up        Ground-Fusion++/vins_estimator/src/estimator/estimator.cpp:2965-3002 (blocks, the lowspeed gate)
 //   residual blocks       estimator.cpp:3239-3291 (GnssPsrDoppFactor per observation, DtDdtFactor / DdtSmoothFactor chains)
 //   marginalisation set   estimator.cpp:3459-3496 (the factors of frame 0, drop sets {0, 1, 4, 5}, {0, 2}, {0})
-// One workgroup per window. The observations are evaluated one per thread (the arithmetic is gfbe_gnss.h, shared with
-// gfbe_gnss_eval) and their 2 x 18 Jacobians staged in LDS. The observations of frame fr that interpolate between poses lw and
-// lw + 1 form a CELL (lw in {fr - 1, fr}: 20 cells), all of whose observations reach the same 20 dims: a wave per cell sums the
-// cell's 20 x 20 block and gradient over its observations in observation order (LDS broadcasts, no divergence); every entry of
-// the normal equations the GNSS factors reach is then summed by ONE owner thread over the cells that hold both dims, in cell
-// order: no atomics, the same bits on every run. The clock factors are linear with constant Jacobians and are added in closed
-// form. (A window with more observations than fit in LDS sums entry by entry from the global copy of the Jacobians.)
+// The observations are evaluated one per thread (the arithmetic is gfbe_gnss.h, shared with gfbe_gnss_eval) and their 2 x 18
+// Jacobians staged in LDS. Every entry of the normal equations the GNSS factors reach is then summed by ONE owner thread over the
+// observations of the frames that can hold both dims, in observation order: no atomics, the same bits on every run and for every
+// shape of the launch. A window's entries are dealt over gridDim.y workgroups (round 6: one window alone on the device has 255 idle
+// CUs beside it — every workgroup stages the window's Jacobians and owns a sixteenth of the 7874 entries; rounds 3-5 summed 20 x 20
+// cell partials first, a wave per cell, and then the entries over the cells, all on one CU: 52 us per launch). The clock factors are
+// linear with constant Jacobians and are added in closed form. (A window with more observations than fit in LDS sums from the global
+// copy of the Jacobians, the same operations in the same order.)
 #include "gfbe_devutil.h"
 #include <algorithm>
 
@@ -70,40 +71,20 @@ __device__ __forceinline__ double gm_dtddt_coef(int la, int k, double dt) {
 }
 __device__ __forceinline__ double gm_smooth_coef(int la, double wgt) { return la == 16 ? wgt : (la == 21 ? -wgt : 0.0); }
 
-// ---- cells: the observations of frame fr that interpolate between poses lw and lw + 1, lw in {fr - 1, fr}: cell 2 fr + (lw == fr).
-//      All observations of a cell reach the same GN_CL = 20 dims: P_lw V_lw P_lw+1 V_lw+1 (3 each) | rcv_dt[fr][0..3] | rcv_ddt[fr] | anc
-enum { GN_CELLS = 2 * NF, GN_CL = 20, GN_CITEMS = GN_CL * (GN_CL + 1) / 2 + GN_CL, GN_CLD = 232 };   // 210 lower pairs + 20 gradient entries per cell
-__device__ __forceinline__ int gc_col(int la, int sys) {        // column of local dim la in the Jacobian of an observation of constellation sys
-  if (la < 12) return la;
-  if (la < 16) return (la - 12) == sys ? 12 : -1;
-  if (la == 16) return 13;
-  return 15 + (la - 17);
-}
-__device__ __forceinline__ int gc_loc(int c, int ce) {          // local index of compact dim c in cell ce, or -1
-  const int fr = ce >> 1, lw = fr - 1 + (ce & 1);
-  if (c < 66) {
-    const int cc = c < 33 ? c : c - 33, f = cc / 3, q = cc - 3 * f, o = c < 33 ? 0 : 3;
-    return f == lw ? o + q : (f == lw + 1 ? 6 + o + q : -1);
-  }
-  if (c < 110) return ((c - 66) >> 2) == fr ? 12 + ((c - 66) & 3) : -1;
-  if (c < 121) return (c - 110) == fr ? 16 : -1;
-  return 17 + (c - 121);
-}
-
 // 512 threads: the sums below are issue-bound integer / LDS work (a lone wave issues one instruction every ~5 cycles), two waves
 // per SIMD halve that; the per-observation evaluation keeps its 256 VGPRs.
 #define GN_THREADS 512
 enum { GN_NCLK = 5 * GFBE_WINDOW_SIZE,     // 40 DtDdtFactors (constellation-major, the reference's insertion order) + 10 DdtSmoothFactors
        GN_ROW = 38,                        // doubles per staged observation: J (2 x 18) | r (2)
-       GN_LDS_OBS = 320 };                 // observations a window can stage in LDS (95 KB, beside 40 KB of cell partials); a larger window
-                                           // sums from the global copy (L2), entry by entry
+       GN_LDS_OBS = 320,                   // observations a window can stage in LDS (95 KB); a larger window sums from the global copy (L2)
+       GN_MAX_GROUPS = 16 };               // workgroups a window's entries are dealt over (small batches)
 
 // sub (mode 0; BatchDev::spec, round 5): 0 — evaluate the factors at the current state and add their J^T J / J^T r into H / g; 1 — the
 // speculative pass: evaluate AT THE CANDIDATE into the set of outputs that is not the current one (per-observation J, r and the cost:
 // what k_accept reads), nothing is added; 2 — the iteration after an accepted speculative pass: add the sums of the current set's
 // J, r (the evaluation they came from ran at this very state). 1 + 2 perform sub 0's operations in its order.
 __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsigned lds_obs, int sub) {
-  const int w = blockIdx.x, t = threadIdx.x;
+  const int w = blockIdx.x, t = threadIdx.x, grp = blockIdx.y, ngrp = gridDim.y;     // (ngrp > 1: mode 0, sub 0 / 2 only)
   const WinDesc &ds = d0.desc[w];
   if (!ds.gnss_ready) return;
   const WinCtl &c = d0.ctl[w];
@@ -120,14 +101,14 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsi
   if (t <= NF) s_fb[t] = ds.gnss_frame_begin[t];
   if (t < GN_C) s_act[t] = ds.act[gn_tan(t)];
   double *stamp = d.timing + (size_t)d.B * 32 + 8 * mode;     // phase stamps of window 0 (diagnostics: gfbe_debug_timing(batch, B))
-#define GSTAMP(i) do { if (w == 0 && t == 0) stamp[i] = (double)wall_clock64(); } while (0)
+#define GSTAMP(i) do { if (w == 0 && t == 0 && grp == 0) stamp[i] = (double)wall_clock64(); } while (0)
   GSTAMP(0);
   // staged copy of the Jacobians / residuals and of (frame, lower_idx, constellation) per observation: the sums below walk them
   // once per entry, and a single window has no other wave to hide a global load behind (measured on one window: 400 us per
   // launch from L2)
   extern __shared__ __attribute__((aligned(16))) double gn_lds[];
   const bool staged = ds.n_gnss <= (int)lds_obs;
-  double *cellP = gn_lds, *sJ = gn_lds + GN_CELLS * GN_CLD;
+  double *sJ = gn_lds;
   int *sMeta = (int *)(sJ + (size_t)lds_obs * GN_ROW);
   const gfbe_gnss_obs *obs = d.gnss_obs + ds.gnss_off;
   double *Jw = d.gnss_J + (size_t)ds.gnss_off * 36, *rw = d.gnss_r + (size_t)ds.gnss_off * 2;
@@ -135,13 +116,12 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsi
   // the first interval
   const int n_obs = mode == 2 ? ds.gnss_frame_begin[1] : ds.n_gnss, n_int = mode == 2 ? 1 : GFBE_WINDOW_SIZE;
   double cost = 0.0;
-  if (sum_only) {      // the evaluation ran in the last iteration's candidate pass: its J, r back into the staging
-    if (staged)
-      for (int k = t; k < n_obs; k += GN_THREADS) {
-        for (int q = 0; q < 36; q++) sJ[k * GN_ROW + q] = Jw[(size_t)36 * k + q];
-        sJ[k * GN_ROW + 36] = rw[2 * k]; sJ[k * GN_ROW + 37] = rw[2 * k + 1];
-        sMeta[k] = obs[k].frame | (obs[k].lower_idx << 8) | (obs[k].sys_idx << 16);
-      }
+  if (sum_only) {      // the evaluation ran in the last iteration's candidate pass: its J, r back into the staging (coalesced: 36 | 2 doubles per observation)
+    if (staged) {
+      for (int e = t; e < 36 * n_obs; e += GN_THREADS) { const int k = e / 36; sJ[k * GN_ROW + (e - 36 * k)] = Jw[e]; }
+      for (int e = t; e < 2 * n_obs; e += GN_THREADS) sJ[(e >> 1) * GN_ROW + 36 + (e & 1)] = rw[e];
+      for (int k = t; k < n_obs; k += GN_THREADS) sMeta[k] = obs[k].frame | (obs[k].lower_idx << 8) | (obs[k].sys_idx << 16);
+    }
   } else
   for (int k = t; k < n_obs; k += GN_THREADS) {
     const gfbe_gnss_obs o = obs[k];
@@ -151,8 +131,10 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsi
                        X[A_DT + 4 * o.frame + o.sys_idx], X[A_DDT + o.frame], X[A_YAW], X + A_ANC, r, mode == 1 ? nullptr : J);
     cost += 0.5 * r[0] * r[0] + 0.5 * r[1] * r[1];
     if (mode != 1) {
-      rw[2 * k] = r[0]; rw[2 * k + 1] = r[1];
-      for (int q = 0; q < 36; q++) Jw[(size_t)36 * k + q] = J[q];
+      if (grp == 0) {      // (every workgroup of the window evaluates — the same instructions on the same inputs —, the first one keeps the results)
+        rw[2 * k] = r[0]; rw[2 * k + 1] = r[1];
+        for (int q = 0; q < 36; q++) Jw[(size_t)36 * k + q] = J[q];
+      }
       if (staged) {
         for (int q = 0; q < 36; q++) sJ[k * GN_ROW + q] = J[q];
         sJ[k * GN_ROW + 36] = r[0]; sJ[k * GN_ROW + 37] = r[1];
@@ -203,46 +185,12 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsi
     if (t == 0) part[GN_MPART - 2] = cost;
     return;
   }
-  if (t == 0 && !sum_only) d.gnss_cost[(size_t)w * 2] = cost;
+  if (t == 0 && !sum_only && grp == 0) d.gnss_cost[(size_t)w * 2] = cost;
   if (ev_only) return;
   if (d.rank != 0) return;      // landmark sharding: like the inertial / wheel / prior factors, added once
   double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
-  if (staged) {
-    // cell partials: a wave per cell, its lanes own the 230 items (four each), the observations of the cell's frame walked by the
-    // whole wave together (LDS broadcasts, no divergence), in observation order
-    const int lane = t & 63;
-    for (int ce = t >> 6; ce < GN_CELLS; ce += GN_THREADS / 64) {
-      const int fr = ce >> 1, lw = fr - 1 + (ce & 1);
-      int la[4], lb[4];
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int it = lane + 64 * j;
-        la[j] = -1; lb[j] = -1;
-        if (it < GN_CL * (GN_CL + 1) / 2) tri_decode(it, la[j], lb[j]);
-        else if (it < GN_CITEMS) { la[j] = it - GN_CL * (GN_CL + 1) / 2; lb[j] = GN_CL; }     // lb == GN_CL: the gradient entry of la
-      }
-      if (lw >= 0 && lw < GFBE_WINDOW_SIZE)
-        for (int k = s_fb[fr]; k < s_fb[fr + 1]; k++) {
-          const int mt = sMeta[k];
-          if (((mt >> 8) & 255) != lw) continue;        // (wave-uniform)
-          const int sys = mt >> 16;
-          const double *J = sJ + k * GN_ROW;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (la[j] < 0) continue;
-            const int ja = gc_col(la[j], sys), jb = lb[j] == GN_CL ? 36 : gc_col(lb[j], sys);
-            if (ja < 0 || jb < 0) continue;
-            acc[j] += lb[j] == GN_CL ? J[ja] * J[36] + J[18 + ja] * J[37] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
-          }
-        }
-#pragma unroll
-      for (int j = 0; j < 4; j++) if (lane + 64 * j < GN_CITEMS) cellP[ce * GN_CLD + lane + 64 * j] = acc[j];
-    }
-    __syncthreads();
-  }
   GSTAMP(3);
-  for (int e = t; e < GN_C * (GN_C + 1) / 2 + GN_C; e += GN_THREADS) {
+  for (int e = grp * GN_THREADS + t; e < GN_C * (GN_C + 1) / 2 + GN_C; e += ngrp * GN_THREADS) {
     const bool isg = e >= GN_C * (GN_C + 1) / 2;
     int ca, cb;
     if (isg) { ca = e - GN_C * (GN_C + 1) / 2; cb = ca; } else tri_decode(e, ca, cb);
@@ -253,20 +201,17 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsi
     gn_frames(cb, fb0, fb1);
     const int f0 = max(fa0, fb0), f1 = min(fa1, fb1);
     double s = 0.0;
-    if (f0 <= f1 && staged) {
-      // the cells of frames f0 .. f1 that hold both dims, in cell order
-      for (int ce = max(2 * f0, 1); ce <= min(2 * f1 + 1, GN_CELLS - 2); ce++) {
-        const int la = gc_loc(ca, ce), lb = isg ? 0 : gc_loc(cb, ce);
-        if (la < 0 || lb < 0) continue;
-        const int hi = max(la, lb), lo = min(la, lb);
-        s += cellP[ce * GN_CLD + (isg ? GN_CL * (GN_CL + 1) / 2 + la : hi * (hi + 1) / 2 + lo)];
-      }
-    } else if (f0 <= f1)
+    if (f0 <= f1)      // the observations of frames f0 .. f1 that hold both dims, in observation order
       for (int k = s_fb[f0]; k < s_fb[f1 + 1]; k++) {
-        {
-          const gfbe_gnss_obs &o = obs[k];
-          const int ja = gn_col(ca, o.frame, o.lower_idx, o.sys_idx), jb = isg ? 0 : gn_col(cb, o.frame, o.lower_idx, o.sys_idx);
-          if (ja < 0 || jb < 0) continue;
+        int fr, lw, sys;
+        if (staged) { const int mt = sMeta[k]; fr = mt & 255; lw = (mt >> 8) & 255; sys = mt >> 16; }
+        else { const gfbe_gnss_obs &o = obs[k]; fr = o.frame; lw = o.lower_idx; sys = o.sys_idx; }
+        const int ja = gn_col(ca, fr, lw, sys), jb = isg ? 0 : gn_col(cb, fr, lw, sys);
+        if (ja < 0 || jb < 0) continue;
+        if (staged) {
+          const double *J = sJ + k * GN_ROW;
+          s += isg ? J[ja] * J[36] + J[18 + ja] * J[37] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
+        } else {
           const double *J = Jw + (size_t)36 * k;
           s += isg ? J[ja] * rw[2 * k] + J[18 + ja] * rw[2 * k + 1] : J[ja] * J[jb] + J[18 + ja] * J[18 + jb];
         }
@@ -293,7 +238,7 @@ __global__ __launch_bounds__(GN_THREADS) void k_gnss(BatchDev d0, int mode, unsi
 #undef GSTAMP
 }
 
-static size_t gnss_lds_bytes(unsigned n_obs) { return sizeof(double) * ((size_t)GN_CELLS * GN_CLD + (size_t)n_obs * GN_ROW) + sizeof(int) * (size_t)n_obs; }
+static size_t gnss_lds_bytes(unsigned n_obs) { return sizeof(double) * ((size_t)n_obs * GN_ROW) + sizeof(int) * (size_t)n_obs; }
 hipError_t gnss_init_device() {   // per device, from gfbe_create (see kernels_init_device)
   return hipFuncSetAttribute((const void *)k_gnss, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gnss_lds_bytes(GN_LDS_OBS));
 }
@@ -301,7 +246,11 @@ void launch_gnss(const BatchDev &d, int mode, hipStream_t s, int sub) {
   if (!d.any_gnss) return;
   // LDS for the batch's largest window (mode 1, the candidate cost, stages nothing)
   const unsigned n = mode == 1 ? 0u : (unsigned)std::min(d.gnss_max_obs, (int)GN_LDS_OBS);
-  hipLaunchKernelGGL(k_gnss, dim3(d.B), dim3(GN_THREADS), mode == 1 ? 0 : gnss_lds_bytes(n), s, d, mode, n, mode == 0 ? sub : 0);
+  // the sums of a small batch: a window's entries over up to 16 workgroups (~1024 workgroups of entries at most; a window that cannot
+  // stage its observations keeps ONE workgroup: the others would read the global copy while the first one writes it)
+  int groups = 1;
+  if (mode == 0 && sub != 1 && d.gnss_max_obs <= (int)GN_LDS_OBS) groups = std::max(1, std::min((int)GN_MAX_GROUPS, 64 / std::max(d.B, 1)));
+  hipLaunchKernelGGL(k_gnss, dim3(d.B, groups), dim3(GN_THREADS), mode == 1 ? 0 : gnss_lds_bytes(n), s, d, mode, n, mode == 0 ? sub : 0);
 }
 
 }  // namespace gfd

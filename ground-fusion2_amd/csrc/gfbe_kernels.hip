@@ -1143,6 +1143,7 @@ __device__ __forceinline__ size_t raw_of(int f, int w, int B, int raw_len) { ret
 // lanes of the wave are all busy. Output: raw residual + raw Jacobian non-zeros, window-minor
 // (raw_imu[f][q][B]: coalesced stores here, one 32-byte sector per value for the per-factor workgroup of k_dense).
 __global__ __launch_bounds__(64) void k_dense_raw(BatchDev d, int mode, int spec) {
+  GFBE_SMALL_KERNEL_PRIO();
   const int f = blockIdx.x, w = blockIdx.y * 64 + threadIdx.x;
   if (w >= d.B) return;
   const WinDesc &ds = d.desc[w];
@@ -1549,6 +1550,7 @@ enum { PRIOR_REGS = 32, PRIOR_LDS_N = 90 };      // 256 threads x 32 values >= 9
 static_assert(256 * PRIOR_REGS >= PRIOR_LDS_N * PRIOR_LDS_N, "k_prior_tp: a thread's share of J0");
 static_assert(ND <= 256, "k_prior_tp: one thread per row / column of the prior (n <= GFBE_DENSE_DIM) in a 256-thread workgroup");
 __global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_n, int spec) {
+  GFBE_SMALL_KERNEL_PRIO();
   extern __shared__ __attribute__((aligned(16))) double psm[];      // dx[ND] | r[ND] | partial sums [4][ND] | J0 [lds_n x lds_n]
   __shared__ double red[16];
   const int w = blockIdx.x, t = threadIdx.x, wv = t >> 6, lane = t & 63;
@@ -1637,6 +1639,7 @@ __global__ __launch_bounds__(256) void k_prior_tp(BatchDev d, int mode, int lds_
 }
 
 __global__ __launch_bounds__(256) void k_dense_tp(BatchDev d, int mode, int spec) {
+  GFBE_SMALL_KERNEL_PRIO();
   __shared__ double sm[DTP_LDS];
   __shared__ int s_act[4];
   const int slot = blockIdx.x, w0 = blockIdx.y * 4;
@@ -3333,6 +3336,7 @@ __device__ __forceinline__ void step_body(const BatchDev &d, const WinDesc &ds, 
   c.have_step = 1;
 }
 __global__ __launch_bounds__(64) void k_step(BatchDev d) {
+  GFBE_SMALL_KERNEL_PRIO();
   const int w = blockIdx.x;
   step_body(d, d.desc[w], d.ctl[w], d.ctl[w], w, threadIdx.x);
 }
@@ -3423,6 +3427,7 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate(BatchDev d) {
 #endif
 // the dense half alone (throughput batches, GFBE_FUSE_CAND: the landmark half runs at the head of the cost pass, k_vis<1>)
 __global__ __launch_bounds__(LM_TILE) void k_candidate_dense(BatchDev d) {
+  GFBE_SMALL_KERNEL_PRIO();
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   const WinCtl &c = d.ctl[w];
@@ -3658,6 +3663,7 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
   c.have_step = 0;
 }
 __global__ __launch_bounds__(64) void k_accept(BatchDev d, int spec) {      // spec: after the candidate's linearisation (its costs, its set of outputs)
+  GFBE_SMALL_KERNEL_PRIO();
   const int w = blockIdx.x;
   if (spec) accept_body(lin_view(d, 1 - d.ctl[w].lb), w, threadIdx.x, d.ctl[w], d.ctl[w], 2);
   else accept_body(d, w, threadIdx.x, d.ctl[w], d.ctl[w], 1);

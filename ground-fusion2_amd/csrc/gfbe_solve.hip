@@ -684,6 +684,9 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 #define GFBE_WIDE_PREFETCH2 0      // k_solve_chain's wide rows: the rows of S two blocks ahead instead of one (measured: 86.9 against 84.4 us per 512
                                    // windows — the pipeline does not wait for those loads)
 #endif
+#ifndef GFBE_CHAIN_PRIO
+#define GFBE_CHAIN_PRIO 0          // k_solve_chain: s_setprio 3 for wave 0 and GFBE_CHAIN_PRIO - 1 for the wide waves (0: the priorities are left alone)
+#endif
 #ifndef GFBE_CHAIN_SIMD_ROLES
 #define GFBE_CHAIN_SIMD_ROLES 0    // k_solve_chain's waves numbered by the SIMD they sit on (measured: the pipeline 33.3 -> 31.5 us beside a second
                                    // workgroup, the dense Cholesky 15.8 -> 19.2: 89.6 against 85.0 us per 512 windows; tools/diag_scripts/hwid)
@@ -1310,6 +1313,11 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   const int t = t_, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
 #else
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#endif
+#if GFBE_CHAIN_PRIO
+  // (round 6) instruction-arbitration priority: the kernel is a chain of dependent instructions on single waves — wave 0 above all — that
+  // shares its SIMDs with the second workgroup of the CU and, in a split batch, with the streaming kernels of the other parts
+  if (!TW) { if (wave == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(GFBE_CHAIN_PRIO - 1); }
 #endif
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;

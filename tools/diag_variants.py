@@ -76,6 +76,10 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "s768i": (["-DSOLVE_THREADS=768", "-DSOLVE_WAVES_PER_EU=3", "-DBUILD_UNROLL=9", "-DGFBE_SOLVE_INLINE=1"], "off"),
     "s768u6": (["-DSOLVE_THREADS=768", "-DSOLVE_WAVES_PER_EU=3", "-DBUILD_UNROLL=6"], "off"),
     "s512i": (["-DSOLVE_THREADS=512", "-DSOLVE_WAVES_PER_EU=2", "-DGFBE_SOLVE_INLINE=1"], "off"),
+    "cprio1": (["-DGFBE_CHAIN_PRIO=1"], "off"),
+    "cprio3": (["-DGFBE_CHAIN_PRIO=3"], "off"),
+    "sprio": (["-DGFBE_PRIO_SMALL=1"], "off"),
+    "allprio": (["-DGFBE_PRIO_SMALL=1", "-DGFBE_CHAIN_PRIO=3"], "off"),
     "abl1_nomfma": (["-DGFBE_ABLATE=1"], "off"),
     "abl2_nopartstore": (["-DGFBE_ABLATE=2"], "off"),
     "abl3_nohpstore": (["-DGFBE_ABLATE=3"], "off"),
