@@ -3435,6 +3435,24 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate_dense(BatchDev d) {
   __shared__ PoseRT sp_cand[NF + 1];
   candidate_dense(d, ds, c, w, threadIdx.x, sp_cand, true);
 }
+// ... and behind k_step in ONE launch (round 6): both are one wave per window of dependent scalar work, 8 + 25 us per 512 windows as two
+// launches. Lane 0's trust-region scalars reach the other lanes of its wave through a workgroup-scope fence; the
+// arithmetic is step_body's and candidate_dense's, operand for operand.
+#ifndef GFBE_FUSE_STEP_CAND
+#define GFBE_FUSE_STEP_CAND 1
+#endif
+__global__ __launch_bounds__(LM_TILE) void k_step_candidate_dense(BatchDev d) {
+  GFBE_SMALL_KERNEL_PRIO();
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+  step_body(d, ds, d.ctl[w], d.ctl[w], w, threadIdx.x);
+  __threadfence_block();      // (one wave, one CU, one vector cache: workgroup scope — a device-scope fence writes the XCD's L2 back, measured -4 % end to end)
+  __builtin_amdgcn_wave_barrier();
+  const WinCtl &c = d.ctl[w];
+  if (c.done || !c.have_step) return;
+  __shared__ PoseRT sp_cand[NF + 1];
+  candidate_dense(d, ds, c, w, threadIdx.x, sp_cand, true);
+}
 __global__ __launch_bounds__(CAND_THREADS) void k_candidate_window(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
@@ -4007,8 +4025,13 @@ void launch_lm_step(const BatchDev &d, hipStream_t s, int fuse) {
   if (fuse) hipLaunchKernelGGL(k_lm_step_fused, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
   else hipLaunchKernelGGL(k_lm_step, dim3(d.B, d.max_tiles), dim3(LM_TILE), 0, s, d);
 }
-void launch_step(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d); }
+static bool step_candidate_fused(const BatchDev &d) { return GFBE_FUSE_STEP_CAND && LM_TILE == 64 && d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND && d.max_tiles > 0; }
+void launch_step(const BatchDev &d, hipStream_t s) {
+  if (step_candidate_fused(d)) hipLaunchKernelGGL(k_step_candidate_dense, dim3(d.B), dim3(LM_TILE), 0, s, d);      // (launch_candidate has nothing left to do)
+  else hipLaunchKernelGGL(k_step, dim3(d.B), dim3(64), 0, s, d);
+}
 void launch_candidate(const BatchDev &d, hipStream_t s) {
+  if (step_candidate_fused(d)) return;
   if (d.B >= DENSE_SPLIT_MIN_B && GFBE_FUSE_CAND && d.max_tiles > 0) hipLaunchKernelGGL(k_candidate_dense, dim3(d.B), dim3(LM_TILE), 0, s, d);
   else if (d.B >= DENSE_SPLIT_MIN_B) hipLaunchKernelGGL(k_candidate_window, dim3(d.B), dim3(CAND_THREADS), 0, s, d);
   else hipLaunchKernelGGL(k_candidate, dim3(d.max_tiles + 1, d.B), dim3(LM_TILE), 0, s, d);

@@ -80,6 +80,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "cprio3": (["-DGFBE_CHAIN_PRIO=3"], "off"),
     "sprio": (["-DGFBE_PRIO_SMALL=1"], "off"),
     "allprio": (["-DGFBE_PRIO_SMALL=1", "-DGFBE_CHAIN_PRIO=3"], "off"),
+    "nostepcand": (["-DGFBE_FUSE_STEP_CAND=0"], "off"),
     "abl1_nomfma": (["-DGFBE_ABLATE=1"], "off"),
     "abl2_nopartstore": (["-DGFBE_ABLATE=2"], "off"),
     "abl3_nohpstore": (["-DGFBE_ABLATE=3"], "off"),
