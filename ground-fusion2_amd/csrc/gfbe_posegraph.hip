@@ -9,9 +9,11 @@
 // The Levenberg-Marquardt system (Jacobi-scaled, diagonal clamp(diag) / radius) is solved by parallel block cyclic
 // reduction: log2(n) sweeps in which every pose eliminates its two neighbours at the current stride (two 6 x 6 SPD
 // solves + four 6 x 6 products per pose), instead of the length-n recurrence of a block Cholesky. The trust-region
-// loop itself (Ceres 1.14 TrustRegionMinimizer + LevenbergMarquardtStrategy, 5 iterations) runs on the host: one graph,
-// one scalar decision per iteration; the per-pose partial sums it needs come back in pose order and are summed serially
-// (fixed order). HBM- / latency-bound small-matrix work: no MFMA.
+// loop itself (Ceres 1.14 TrustRegionMinimizer + LevenbergMarquardtStrategy, 5 iterations) runs ON THE DEVICE since round 6
+// (PgState: the scalars of the loop, written by the last workgroup of the two reductions of an iteration; every kernel of a pass
+// looks at its flags first): the host enqueues max_it passes and waits once — rounds 1-5 decided on the host, two
+// synchronisations per iteration, which were most of the 5 000-pose graph's time. The candidate's pass linearises into the
+// second set of (Hd, Ho, g), so an accepted step needs no launch of its own. Latency-bound small-matrix work: no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -87,10 +89,8 @@ __device__ double huber_corrector(double sq, double delta, double *s1, double *r
 
 // Per pose i: cost share (the factor starting at i + the fixes of i) and, with Hd != nullptr, block row i of the normal
 // equations: Hd[i] (6x6), Ho[i] = block (i+1, i) (written by pose i: its own factor), g[i].
-__global__ __launch_bounds__(128) void k_pg_lin(PgDev P, const double *pose, double *cost_i, double *Hd, double *Ho, double *g,
-                                                double *rel_r, double *rel_J, double *fix_r) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n) return;
+__device__ __forceinline__ void pg_lin_body(const PgDev &P, const int i, const double *pose, double *cost_i, double *Hd, double *Ho, double *g,
+                                            double *rel_r, double *rel_J, double *fix_r) {
   double hd[36], gg[6];
   for (int q = 0; q < 36; q++) hd[q] = 0.0;
   for (int q = 0; q < 6; q++) gg[q] = 0.0;
@@ -148,15 +148,162 @@ __global__ __launch_bounds__(128) void k_pg_lin(PgDev P, const double *pose, dou
     for (int q = 0; q < 6; q++) g[(size_t)i * 6 + q] = gg[q];
   }
 }
+__global__ __launch_bounds__(128) void k_pg_lin(PgDev P, const double *pose, double *cost_i, double *Hd, double *Ho, double *g,
+                                                double *rel_r, double *rel_J, double *fix_r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n) return;
+  pg_lin_body(P, i, pose, cost_i, Hd, Ho, g, rel_r, rel_J, fix_r);
+}
+
+// ---- the Levenberg-Marquardt loop's state on the device (gfbe_pg_solve, round 6)
+struct PgState {
+  double cost, radius, decrease, x_norm, model_change, step2, cand_x2, initial_cost;
+  int it, invalid, reuse, have_scale, done, termination, status, num_successful;
+  int cur;         // which of the two pose arrays is x (the other one takes the candidate)
+  int lb;          // which set of (Hd, Ho, g) was linearised at x (the other one takes the candidate's linearisation)
+  int cand_on;     // this pass has a step to try (the decision after the solve)
+  int pad;
+  int accepted[16];
+  double cost_history[16];
+};
+struct PgSets { double *pose[2], *Hd[2], *Ho[2], *g[2]; };
+// cand = 0: the first linearisation (x into its set); 1: the candidate's cost AND linearisation, into the other set.
+// Six lanes per pose: lanes 0 and 1 evaluate the pose's two relative factors — (i - 1, i) and (i, i + 1), one call site, side by side —
+// into LDS, then lane a forms row a of the pose's blocks from them: every entry sees pg_lin_body's operations in its order (the same
+// bits), 17 -> ~7 us per launch over 5 000 poses.
+#define PGL_POSES 32
+__global__ __launch_bounds__(PGL_POSES * 6) void k_pg_lin_st(PgDev P, const PgState *st, PgSets S, int cand, double *cost_i) {
+  __shared__ double sJ[PGL_POSES][2][78];      // per pose and factor: J (6 x 12) | r (6)
+  const int f_done = st->done, f_cand = st->cand_on, f_cur = st->cur, f_lb = st->lb;
+  if (cand && (f_done || !f_cand)) return;
+  const int gidx = blockIdx.x * (PGL_POSES * 6) + threadIdx.x, i = gidx / 6, a = gidx - 6 * i, pl = threadIdx.x / 6;
+  const bool on = i < P.n;
+  const int xb = cand ? 1 - f_cur : f_cur, sb = cand ? 1 - f_lb : f_lb;
+  const double *pose = S.pose[xb];
+  double *Hd = S.Hd[sb], *Ho = S.Ho[sb], *g = S.g[sb];
+  const int kp = (on && i > 0) ? P.rel_of[i - 1] : -1, kn = on ? P.rel_of[i] : -1;
+  if (on && a < 2) {
+    const int k = a == 0 ? kp : kn, i0 = a == 0 ? i - 1 : i;
+    if (k >= 0) {
+      double r[6], J[72];
+      rel_factor(pose + 7 * (size_t)i0, pose + 7 * (size_t)(i0 + 1), P.rel_meas + 7 * (size_t)k, P.t_var, P.q_var, r, J);
+      for (int q = 0; q < 72; q++) sJ[pl][a][q] = J[q];
+      for (int q = 0; q < 6; q++) sJ[pl][a][72 + q] = r[q];
+    }
+  }
+  __syncthreads();
+  if (!on) return;
+  double hrow[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, ga = 0.0, cost = 0.0;
+  if (kp >= 0) {         // factor (i - 1, i): this pose is "j"
+    const double *J = sJ[pl][0], *r = J + 72;
+    for (int b = 0; b < 6; b++) { double sv = 0; for (int q = 0; q < 6; q++) sv += J[q * 12 + 6 + a] * J[q * 12 + 6 + b]; hrow[b] += sv; }
+    double sv = 0; for (int q = 0; q < 6; q++) sv += J[q * 12 + 6 + a] * r[q];
+    ga += sv;
+  }
+  if (kn >= 0) {         // factor (i, i + 1): this pose is "i"; it owns the cost and the off-diagonal block
+    const double *J = sJ[pl][1], *r = J + 72;
+    if (a == 0) for (int q = 0; q < 6; q++) cost += 0.5 * r[q] * r[q];
+    for (int b = 0; b < 6; b++) {
+      double sii = 0, sji = 0;
+      for (int q = 0; q < 6; q++) { sii += J[q * 12 + a] * J[q * 12 + b]; sji += J[q * 12 + 6 + a] * J[q * 12 + b]; }
+      hrow[b] += sii;
+      Ho[(size_t)i * 36 + a * 6 + b] = sji;
+    }
+    double sv = 0; for (int q = 0; q < 6; q++) sv += J[q * 12 + a] * r[q];
+    ga += sv;
+  } else if (i + 1 < P.n) {
+    for (int b = 0; b < 6; b++) Ho[(size_t)i * 36 + a * 6 + b] = 0.0;
+  }
+  for (int k = P.fix_begin[i]; k < P.fix_begin[i + 1]; k++) {
+    const double *m = P.fix_meas + 4 * k;
+    double rr[3] = {(pose[7 * (size_t)i] - m[0]) / m[3], (pose[7 * (size_t)i + 1] - m[1]) / m[3], (pose[7 * (size_t)i + 2] - m[2]) / m[3]};
+    double s1, rs, asn;
+    const double hc = huber_corrector(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2], P.delta, &s1, &rs, &asn);
+    if (a == 0) cost += hc;
+    if (a >= 3) {        // rows 3 .. 5 (the position) take the fix: column aa = a - 3 of Jc, Jc[3 q + c] = s1 ((q == c) - asn rr[q] rr[c]) / m[3]
+      const int aa = a - 3;
+      const double rra = aa == 0 ? rr[0] : (aa == 1 ? rr[1] : rr[2]);
+      double ca[3], Jc[9];
+      for (int q = 0; q < 3; q++) ca[q] = s1 * ((q == aa ? 1.0 : 0.0) - asn * rr[q] * rra) / m[3];
+      for (int q = 0; q < 3; q++) for (int b = 0; b < 3; b++) Jc[3 * q + b] = s1 * ((q == b ? 1.0 : 0.0) - asn * rr[q] * rr[b]) / m[3];
+      for (int q = 0; q < 3; q++) rr[q] *= rs;
+      for (int b = 0; b < 3; b++) { double sv = 0; for (int q = 0; q < 3; q++) sv += ca[q] * Jc[3 * q + b]; hrow[3 + b] += sv; }
+      double sv = 0; for (int q = 0; q < 3; q++) sv += ca[q] * rr[q];
+      ga += sv;
+    }
+  }
+  if (a == 0) cost_i[i] = cost;
+  for (int b = 0; b < 6; b++) Hd[(size_t)i * 36 + a * 6 + b] = hrow[b];
+  g[(size_t)i * 6 + a] = ga;
+}
+// Column a of B^-1 for an SPD 6 x 6 B (row-major, e.g. in LDS): Cholesky B = L L^T with the reciprocals of the diagonal, then
+// L z = e_a, L^T x = z. Straight-line code (a only enters as the right-hand side). Returns false if B is not SPD.
+__device__ __forceinline__ bool spd_inv_col6(const double *Bm, const int a, double *x) {
+  double L[6][6], ri[6];
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    double ds = Bm[c * 6 + c];
+#pragma unroll
+    for (int k = 0; k < c; k++) ds -= L[c][k] * L[c][k];
+    if (!(ds > 0.0) || !isfinite(ds)) return false;
+    const double lcc = sqrt(ds);
+    ri[c] = 1.0 / lcc;
+#pragma unroll
+    for (int r = c + 1; r < 6; r++) {
+      double sv = Bm[r * 6 + c];
+#pragma unroll
+      for (int k = 0; k < c; k++) sv -= L[r][k] * L[c][k];
+      L[r][c] = sv * ri[c];
+    }
+  }
+  double z[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    double sv = r == a ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < r; k++) sv -= L[r][k] * z[k];
+    z[r] = sv * ri[r];
+  }
+#pragma unroll
+  for (int r = 5; r >= 0; r--) {
+    double sv = z[r];
+#pragma unroll
+    for (int k = r + 1; k < 6; k++) sv -= L[k][r] * x[k];
+    x[r] = sv * ri[r];
+  }
+  return true;
+}
+// The six lanes of a pose hold one row of its new diagonal block each: exchanged through LDS (sB: 36 doubles per pose of the
+// workgroup; the lanes of a pose may sit in two waves: a block barrier, passed by every thread), then lane a forms column a of
+// the inverse (= row a: symmetric) — the block's Cholesky is recomputed by each of the six lanes, ONCE per block and sweep.
+__device__ __forceinline__ void pg_block_inverse(double *sB, const int pl, const int a, const bool on, const double *row, double *Binv_i, int *fail,
+                                                 const int stride = 36) {
+  if (on) {
+#pragma unroll
+    for (int b = 0; b < 6; b++) sB[pl * stride + a * 6 + b] = row[b];
+  }
+  __syncthreads();
+  if (!on) return;
+  double x[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (!spd_inv_col6(sB + pl * stride, a, x)) *fail = 1;
+#pragma unroll
+  for (int b = 0; b < 6; b++) Binv_i[a * 6 + b] = x[b];
+}
 
 // Jacobi scale (iteration 0) and the scaled LM system in cyclic-reduction form:
 //   A_i x_{i-1} + B_i x_i + C_i x_{i+1} = d_i,  B = S Hd S + D2 / radius,  A_i = S Ho_{i-1} S,  C_i = A_{i+1}^T,  d = -S g
-__global__ __launch_bounds__(192) void k_pg_system(int n, const double *Hd, const double *Ho, const double *g, double *scale, int set_scale,
-                                                   double *diag2, int keep_diag, double radius, double *B, double *d,
+__global__ __launch_bounds__(192) void k_pg_system(int n, const PgState *st, PgSets S, double *scale,
+                                                   double *diag2, double *B, double *d,
                                                    double *Bs /* unregularised S Hd S, for the model cost */, double *gmax_i,
-                                                   double *d_pcr /* the copy the cyclic reduction consumes */, int *fail) {
+                                                   double *d_pcr /* the copy the cyclic reduction consumes */, double *Binv /* the blocks' inverses, for the first sweep */,
+                                                   int *fail) {
   // six lanes per pose: lane a owns row a (scale factors of the pose's six dims are exchanged through LDS)
   __shared__ double ssc[192];
+  __shared__ double sB[32 * 36];
+  if (st->done) return;
+  const double *Hd = S.Hd[st->lb], *g = S.g[st->lb];
+  const int set_scale = !st->have_scale, keep_diag = st->reuse;
+  const double radius = st->radius;
   const int gidx = blockIdx.x * 192 + threadIdx.x, i = gidx / 6, a = gidx - 6 * i;
   const bool on = i < n;
   double sa = 1.0, ga = 0.0;
@@ -167,7 +314,8 @@ __global__ __launch_bounds__(192) void k_pg_system(int n, const double *Hd, cons
   }
   ssc[threadIdx.x] = sa;
   __syncthreads();
-  if (!on) return;
+  double brow[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (on) {
   const double *sp = ssc + (threadIdx.x - a);
   if (a == 0) {
     double gm = 0.0;
@@ -179,6 +327,7 @@ __global__ __launch_bounds__(192) void k_pg_system(int n, const double *Hd, cons
   for (int b = 0; b < 6; b++) {
     const double v = Hd[(size_t)i * 36 + a * 6 + b] * sa * sp[b];
     Bs[(size_t)i * 36 + a * 6 + b] = v;
+    brow[b] = v;
     if (b != a) B[(size_t)i * 36 + a * 6 + b] = v;
     else diag = v;
   }
@@ -186,12 +335,15 @@ __global__ __launch_bounds__(192) void k_pg_system(int n, const double *Hd, cons
   d[(size_t)i * 6 + a] = dv;
   d_pcr[(size_t)i * 6 + a] = dv;
   if (!keep_diag) diag2[(size_t)i * 6 + a] = fmin(fmax(diag, 1e-6), 1e32);
-  B[(size_t)i * 36 + a * 7] = diag + diag2[(size_t)i * 6 + a] / radius;
-  if (gidx == 0) *fail = 0;
+  brow[a] = diag + diag2[(size_t)i * 6 + a] / radius;
+  B[(size_t)i * 36 + a * 7] = brow[a];
+  }
+  pg_block_inverse(sB, threadIdx.x / 6, a, on, brow, Binv + (size_t)(on ? i : 0) * 36, fail);
 }
-__global__ __launch_bounds__(192) void k_pg_system2(int n, const double *Ho, const double *scale, double *A, double *Cc, double *A_pcr, double *C_pcr) {
+__global__ __launch_bounds__(192) void k_pg_system2(int n, const PgState *st, PgSets S, const double *scale, double *A, double *Cc, double *A_pcr, double *C_pcr) {
   const int gidx = blockIdx.x * 192 + threadIdx.x, i = gidx / 6, a = gidx - 6 * i;   // lane a owns row a of pose i
-  if (i >= n) return;
+  if (i >= n || st->done) return;
+  const double *Ho = S.Ho[st->lb];
   const double sa = scale[(size_t)i * 6 + a];
 #pragma unroll
   for (int b = 0; b < 6; b++) {
@@ -202,108 +354,140 @@ __global__ __launch_bounds__(192) void k_pg_system2(int n, const double *Ho, con
   }
 }
 
-// X = B^-1 Y for an SPD 6 x 6 B (Cholesky), Y with nc columns (row-major 6 x nc); returns false if B is not SPD
-__device__ bool spd_solve6(const double *Bm, double *Y, int nc) {
-  double L[36];
-  for (int c = 0; c < 6; c++) {
-    double ds = Bm[c * 6 + c];
-    for (int k = 0; k < c; k++) ds -= L[c * 6 + k] * L[c * 6 + k];
-    if (!(ds > 0.0) || !isfinite(ds)) return false;
-    const double lcc = sqrt(ds);
-    L[c * 6 + c] = lcc;
-    for (int a = c + 1; a < 6; a++) { double s = Bm[a * 6 + c]; for (int k = 0; k < c; k++) s -= L[a * 6 + k] * L[c * 6 + k]; L[a * 6 + c] = s / lcc; }
-  }
-  for (int j = 0; j < nc; j++) {
-    for (int a = 0; a < 6; a++) { double s = Y[a * nc + j]; for (int k = 0; k < a; k++) s -= L[a * 6 + k] * Y[k * nc + j]; Y[a * nc + j] = s / L[a * 6 + a]; }
-    for (int a = 5; a >= 0; a--) { double s = Y[a * nc + j]; for (int k = a + 1; k < 6; k++) s -= L[k * 6 + a] * Y[k * nc + j]; Y[a * nc + j] = s / L[a * 6 + a]; }
-  }
-  return true;
-}
-
 // One sweep of parallel block cyclic reduction at stride s (in -> out):
 //   alpha = -A_i B_{i-s}^-1, gamma = -C_i B_{i+s}^-1
 //   B' = B + alpha C_{i-s} + gamma A_{i+s};  d' = d + alpha d_{i-s} + gamma d_{i+s};  A' = alpha A_{i-s};  C' = gamma C_{i+s}
-// Six lanes per pose, lane a owns row a of the outputs (and element a of d'): it solves ONE 6-vector system per neighbour
-// (row a of A_i / C_i as the right-hand side; the neighbour's 6 x 6 Cholesky is recomputed by each of the six lanes) and forms
-// its row of the products — the same operations per output element as one thread per pose (bit-identical), six times the
-// parallelism on a kernel that runs at 79 waves for 5 000 poses, and 48-byte contiguous accesses per lane.
+// Six lanes per pose, lane a owns row a of the outputs (and element a of d'). Round 6: the INVERSE of every diagonal block travels
+// with it (Binv; k_pg_system forms the first ones), so that a sweep multiplies where rounds 1-5 solved: row a of alpha is row a of
+// A_i times B_{i-s}^-1 — no factorisation on the way in —, and the new block's inverse is formed once, at the end of the sweep that
+// produces it (pg_block_inverse): one 6 x 6 Cholesky per lane and sweep instead of two, no division inside the substitutions
+// (10.9 -> ~5 us per sweep of the 5 000-pose graph, whose 65 sweeps were 59 % of the solve).
 #define PCR_ROWS 32
-__global__ __launch_bounds__(PCR_ROWS * 6) void k_pg_pcr(int n, int s, const double *A, const double *B, const double *Cc, const double *d,
-                                                         double *A2, double *B2, double *C2, double *d2, int *fail) {
-  const int g = blockIdx.x * (PCR_ROWS * 6) + threadIdx.x, i = g / 6, a = g - 6 * i;
-  if (i >= n) return;
-  double Bn[6], An[6], Cn[6], dn;
-#pragma unroll
-  for (int b = 0; b < 6; b++) { Bn[b] = B[(size_t)i * 36 + a * 6 + b]; An[b] = 0.0; Cn[b] = 0.0; }
-  dn = d[(size_t)i * 6 + a];
+enum { PCR_NB = 3 * 36 + 6 };      // per neighbour: Binv | C (left neighbour) or A (right) first ... see the staging below
+__global__ __launch_bounds__(PCR_ROWS * 6) void k_pg_pcr(int n, int s, const double *A, const double *B, const double *Cc, const double *d, const double *Binv,
+                                                         double *A2, double *B2, double *C2, double *d2, double *Binv2, int *fail, const PgState *st) {
+  // the two neighbours' blocks [Binv | C | A | d] of every pose of the workgroup, staged by its six lanes together (lane a: row a of
+  // each) — a lane used to load all 228 values of both neighbours itself, the same ones as its five partners
+  __shared__ double sN[PCR_ROWS][2][PCR_NB];
+  const int done = st->done;      // (requested with the operands below, looked at behind them: one level of dependent loads less per sweep)
+  const int g = blockIdx.x * (PCR_ROWS * 6) + threadIdx.x, i = g / 6, a = g - 6 * i, pl = threadIdx.x / 6;
+  const bool on = i < n;
   const int im = i - s, ip = i + s;
-  if (im >= 0) {
-    // column a of Y = B_{i-s}^-1 A_i^T, i.e. the solve with row a of A_i; alpha[a][k] = -Y[k][a]
+  const bool hm = on && im >= 0, hp = on && ip < n;
+  double Bn[6], An[6], Cn[6], ra[6], rc[6], dn = 0.0;
+#pragma unroll
+  for (int b = 0; b < 6; b++) {
+    Bn[b] = on ? B[(size_t)i * 36 + a * 6 + b] : 0.0; An[b] = 0.0; Cn[b] = 0.0;
+    ra[b] = hm ? A[(size_t)i * 36 + a * 6 + b] : 0.0;
+    rc[b] = hp ? Cc[(size_t)i * 36 + a * 6 + b] : 0.0;
+  }
+  if (on) dn = d[(size_t)i * 6 + a];
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int j = side == 0 ? im : ip;
+    if (side == 0 ? hm : hp) {
+      double *o = sN[pl][side];
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        o[a * 6 + b] = Binv[(size_t)j * 36 + a * 6 + b];
+        o[36 + a * 6 + b] = Cc[(size_t)j * 36 + a * 6 + b];
+        o[72 + a * 6 + b] = A[(size_t)j * 36 + a * 6 + b];
+      }
+      o[108 + a] = d[(size_t)j * 6 + a];
+    }
+  }
+  __syncthreads();
+  if (done) return;
+  if (hm) {
+    // y = B_{i-s}^-1 (row a of A_i)^T; alpha[a][k] = -y[k]
+    const double *o = sN[pl][0];
     double y[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) y[k] = A[(size_t)i * 36 + a * 6 + k];
-    if (!spd_solve6(B + (size_t)im * 36, y, 1)) { *fail = 1; return; }
+    for (int k = 0; k < 6; k++) {
+      double sv = 0;
+#pragma unroll
+      for (int m = 0; m < 6; m++) sv += o[k * 6 + m] * ra[m];
+      y[k] = sv;
+    }
 #pragma unroll
     for (int b = 0; b < 6; b++) {
       double sb = 0, sa = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { sb += y[k] * Cc[(size_t)im * 36 + k * 6 + b]; sa += y[k] * A[(size_t)im * 36 + k * 6 + b]; }
+      for (int k = 0; k < 6; k++) { sb += y[k] * o[36 + k * 6 + b]; sa += y[k] * o[72 + k * 6 + b]; }
       Bn[b] -= sb;
       An[b] = -sa;
     }
     double sd = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) sd += y[k] * d[(size_t)im * 6 + k];
+    for (int k = 0; k < 6; k++) sd += y[k] * o[108 + k];
     dn -= sd;
   }
-  if (ip < n) {
+  if (hp) {
+    const double *o = sN[pl][1];
     double y[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) y[k] = Cc[(size_t)i * 36 + a * 6 + k];
-    if (!spd_solve6(B + (size_t)ip * 36, y, 1)) { *fail = 1; return; }
+    for (int k = 0; k < 6; k++) {
+      double sv = 0;
+#pragma unroll
+      for (int m = 0; m < 6; m++) sv += o[k * 6 + m] * rc[m];
+      y[k] = sv;
+    }
 #pragma unroll
     for (int b = 0; b < 6; b++) {
       double sb = 0, sc = 0;
 #pragma unroll
-      for (int k = 0; k < 6; k++) { sb += y[k] * A[(size_t)ip * 36 + k * 6 + b]; sc += y[k] * Cc[(size_t)ip * 36 + k * 6 + b]; }
+      for (int k = 0; k < 6; k++) { sb += y[k] * o[72 + k * 6 + b]; sc += y[k] * o[36 + k * 6 + b]; }
       Bn[b] -= sb;
       Cn[b] = -sc;
     }
     double sd = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) sd += y[k] * d[(size_t)ip * 6 + k];
+    for (int k = 0; k < 6; k++) sd += y[k] * o[108 + k];
     dn -= sd;
   }
+  if (on) {
 #pragma unroll
-  for (int b = 0; b < 6; b++) { B2[(size_t)i * 36 + a * 6 + b] = Bn[b]; A2[(size_t)i * 36 + a * 6 + b] = An[b]; C2[(size_t)i * 36 + a * 6 + b] = Cn[b]; }
-  d2[(size_t)i * 6 + a] = dn;
+    for (int b = 0; b < 6; b++) { B2[(size_t)i * 36 + a * 6 + b] = Bn[b]; A2[(size_t)i * 36 + a * 6 + b] = An[b]; C2[(size_t)i * 36 + a * 6 + b] = Cn[b]; }
+    d2[(size_t)i * 6 + a] = dn;
+  }
+  __syncthreads();      // (every lane is done with the staged blocks: the first 36 doubles of a pose's slot take its new diagonal block)
+  pg_block_inverse(&sN[0][0][0], pl, a, on, Bn, Binv2 + (size_t)(on ? i : 0) * 36, fail, 2 * PCR_NB);
 }
-__global__ __launch_bounds__(64) void k_pg_final(int n, const double *B, const double *d, double *y, int *fail) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double Y[6];
-  for (int q = 0; q < 6; q++) Y[q] = d[(size_t)i * 6 + q];
-  if (!spd_solve6(B + (size_t)i * 36, Y, 1)) { *fail = 1; return; }
-  for (int q = 0; q < 6; q++) y[(size_t)i * 6 + q] = Y[q];
+// after the last sweep the blocks are decoupled: y_i = B_i^-1 d_i (six lanes per pose, lane a: element a)
+__global__ __launch_bounds__(192) void k_pg_final(int n, const double *Binv, const double *d, double *y, const PgState *st) {
+  const int g = blockIdx.x * 192 + threadIdx.x, i = g / 6, a = g - 6 * i;
+  if (i >= n || st->done) return;
+  double sv = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) sv += Binv[(size_t)i * 36 + a * 6 + k] * d[(size_t)i * 6 + k];
+  y[(size_t)i * 6 + a] = sv;
 }
 
 // model cost change share -(gs . y + 1/2 y^T Hs y) of pose i, the candidate x (+) S y, |step|^2 and |x|^2 shares
-__global__ __launch_bounds__(128) void k_pg_candidate(int n, const double *Bs, const double *A, const double *Cc, const double *d, const double *y,
-                                                      const double *scale, const double *x, double *cand, double *model_i, double *step2_i,
+__global__ __launch_bounds__(192) void k_pg_candidate(int n, const double *Bs, const double *A, const double *Cc, const double *d, const double *y,
+                                                      const double *scale, const PgState *st, PgSets S, double *model_i, double *step2_i,
                                                       double *xn2_i) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double gy = 0, yHy = 0;
-  for (int a = 0; a < 6; a++) {
+  // six lanes per pose: lane a forms row a of H y (the operations of one thread per pose, in its order), lane 0 adds the six shares up
+  // in row order and retracts
+  __shared__ double sgy[192], syh[192];
+  if (st->done) return;
+  const int gidx = blockIdx.x * 192 + threadIdx.x, i = gidx / 6, a = gidx - 6 * i;
+  const double *x = S.pose[st->cur];
+  double *cand = S.pose[1 - st->cur];
+  if (i < n) {
     double s = 0;
     for (int b = 0; b < 6; b++) {
       s += Bs[(size_t)i * 36 + a * 6 + b] * y[(size_t)i * 6 + b];
       if (i > 0) s += A[(size_t)i * 36 + a * 6 + b] * y[(size_t)(i - 1) * 6 + b];
       if (i + 1 < n) s += Cc[(size_t)i * 36 + a * 6 + b] * y[(size_t)(i + 1) * 6 + b];
     }
-    gy += -d[(size_t)i * 6 + a] * y[(size_t)i * 6 + a];
-    yHy += y[(size_t)i * 6 + a] * s;
+    sgy[threadIdx.x] = -d[(size_t)i * 6 + a] * y[(size_t)i * 6 + a];
+    syh[threadIdx.x] = y[(size_t)i * 6 + a] * s;
   }
+  __syncthreads();
+  if (i >= n || a != 0) return;
+  double gy = 0, yHy = 0;
+  for (int q = 0; q < 6; q++) { gy += sgy[threadIdx.x + q]; yHy += syh[threadIdx.x + q]; }
   model_i[i] = -(gy + 0.5 * yHy);
   double d6[6];
   for (int a = 0; a < 6; a++) d6[a] = scale[(size_t)i * 6 + a] * y[(size_t)i * 6 + a];
@@ -320,7 +504,7 @@ __global__ __launch_bounds__(128) void k_pg_candidate(int n, const double *Bs, c
 
 // All device buffers of one call come out of ONE allocation (a bump allocator over a slab sized by a dry run):
 // the solve makes ~30 buffers, and hipMalloc / hipFree cost more than the kernels at this problem size.
-enum { PG_RESULT_BYTES = 64 };
+enum { PG_RESULT_BYTES = 1024 };      // (the pinned result slot: the reductions' scalars of gfbe_pg_eval, the final PgState of gfbe_pg_solve)
 struct PgBuffers {
   gfbe_ctx *c;
   char *slab = nullptr, *pin = nullptr;
@@ -341,6 +525,14 @@ struct PgBuffers {
     return true;
   }
   double *result() const { return (double *)(pin + pin_cap); }
+  // pinned host memory a kernel writes (device-accessible under the same pointer): results that cross PCIe as the kernel's own stores
+  template <typename T>
+  T *pinned(size_t n) {
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
+    const size_t pat = pin_used;
+    pin_used += bytes;
+    return dry ? nullptr : (T *)(pin + pat);
+  }
   template <typename T>
   T *dev(size_t n, const T *h = nullptr) {
     const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~(size_t)255;
@@ -394,6 +586,113 @@ __global__ __launch_bounds__(64) void k_pg_reduce2(int nseg, const double *parti
   double v = 0.0;
   for (int q = 0; q < nseg; q++) { const double x = partial[4 * q + t]; v = (take_max && t == 0) ? fmax(v, x) : v + x; }
   out[t] = v;
+}
+// The second stage of a reduction of gfbe_pg_solve, followed by what the host used to decide from its results (TrustRegionMinimizer with
+// LevenbergMarquardtStrategy as globalOpt.cpp:117-121 configures it; the statements are the host loop's of rounds 1-5, in its order):
+//   mode 0 — the first point's cost: the state of the loop is initialised;
+//   mode 1 — after the solve and the candidate (max |g|, model change, |step|^2, |candidate|^2; the factorisation's failure flag): gradient
+//            tolerance, the invalid step (LevenbergMarquardtStrategy::StepRejected through decrease), or "evaluate the candidate";
+//   mode 2 — after the candidate's evaluation (its cost): parameter / function tolerance, acceptance, the radius update.
+enum { PGD_THREADS = 1024, PGD_DIRECT_MAX = 65536 };
+__global__ __launch_bounds__(PGD_THREADS) void k_pg_decide(int n, const double *a, const double *b, const double *c3, const double *d4, int nseg, const double *partial,
+                                                           int take_max, PgState *st, int *fail, int mode, double x_norm0) {
+  const int t = threadIdx.x;
+  __shared__ double sh[4][PGD_THREADS / 64];
+  __shared__ double r[4];
+  const int f_done = mode != 0 ? st->done : 0, f_cand = st->cand_on;      // (requested with the values below, looked at behind them)
+  if (partial) {      // the second stage behind k_pg_reduce1 (graphs beyond PGD_DIRECT_MAX poses)
+    if (t < 4) {
+      double v = 0.0;
+      for (int q = 0; q < nseg; q++) { const double x = partial[4 * q + t]; v = (take_max && t == 0) ? fmax(v, x) : v + x; }
+      r[t] = v;
+    }
+    __syncthreads();
+  } else {            // the per-pose values themselves: thread t takes t, t + 1024, ... in order, then an LDS tree (fixed order)
+    double va = 0.0, vb = 0.0, vc = 0.0, vd = 0.0;
+    for (int i0 = t; i0 < n; i0 += 8 * PGD_THREADS) {      // (eight strides' values requested together: one memory round trip per 8192 poses)
+      double xa[8], xb[8], xc[8], xd[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = min(i0 + u * PGD_THREADS, n - 1);
+        xa[u] = a[i]; xb[u] = b ? b[i] : 0.0; xc[u] = c3 ? c3[i] : 0.0; xd[u] = d4 ? d4[i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i0 + u * PGD_THREADS < n) { va = take_max ? fmax(va, xa[u]) : va + xa[u]; vb += xb[u]; vc += xc[u]; vd += xd[u]; }
+    }
+    // the wave's 64 shares by a shuffle tree, the sixteen waves' in wave order (fixed order, one block barrier)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double oa = __shfl_down(va, o, 64), ob = __shfl_down(vb, o, 64), oc = __shfl_down(vc, o, 64), od = __shfl_down(vd, o, 64);
+      va = take_max ? fmax(va, oa) : va + oa; vb += ob; vc += oc; vd += od;
+    }
+    if ((t & 63) == 0) { sh[0][t >> 6] = va; sh[1][t >> 6] = vb; sh[2][t >> 6] = vc; sh[3][t >> 6] = vd; }
+    __syncthreads();
+    if (t < 4) {
+      double v = 0.0;
+      for (int q = 0; q < PGD_THREADS / 64; q++) v = (take_max && t == 0) ? fmax(v, sh[t][q]) : v + sh[t][q];
+      r[t] = v;
+    }
+    __syncthreads();
+  }
+  if (t != 0 || f_done || (mode == 2 && !f_cand)) return;
+  PgState &s = *st;
+  if (mode == 0) {
+    s.cost = r[0]; s.initial_cost = r[0]; s.cost_history[0] = r[0];
+    s.radius = 1e4; s.decrease = 2.0; s.x_norm = x_norm0;
+    s.status = GFBE_NO_CONVERGENCE;
+    return;
+  }
+  if (s.done) return;
+  if (mode == 1) {
+    s.have_scale = 1;
+    s.cand_on = 0;
+    if (s.radius < 1e-32) {      // (the host loop tested this before the solve: the step computed meanwhile is dropped)
+      if (r[0] <= 1e-10) { s.termination = 3; s.status = GFBE_OK; } else s.termination = 4;
+      s.done = 1;
+      return;
+    }
+    if (r[0] <= 1e-10) { s.termination = 3; s.status = GFBE_OK; s.done = 1; return; }
+    s.it++;
+    const int it = s.it;
+    const double model_change = r[1];
+    const int failed = *fail;      // (raised by any block that was not positive definite — k_pg_system, k_pg_pcr — and cleared here, for the next pass)
+    *fail = 0;
+    if (failed || !(model_change > 0.0)) {
+      s.accepted[it] = 0; s.cost_history[it] = s.cost;
+      if (++s.invalid >= 5) { s.termination = 4; s.status = GFBE_NUMERICAL_FAILURE; s.done = 1; return; }
+      s.radius /= s.decrease; s.decrease *= 2; s.reuse = 1;
+      return;
+    }
+    s.invalid = 0;
+    s.model_change = model_change; s.step2 = r[2]; s.cand_x2 = r[3];
+    s.cand_on = 1;
+    return;
+  }
+  if (!s.cand_on) return;
+  const int it = s.it;
+  const double cand_cost = r[0];
+  s.cost_history[it] = s.cost;
+  if (sqrt(s.step2) <= 1e-8 * (s.x_norm + 1e-8)) { s.termination = 2; s.status = GFBE_OK; s.done = 1; return; }
+  const double change = s.cost - cand_cost;
+  if (fabs(change) <= 1e-6 * s.cost) { s.termination = 1; s.status = GFBE_OK; s.done = 1; return; }
+  const double rho = change / s.model_change;
+  if (rho > 1e-3) {
+    s.cur = 1 - s.cur; s.lb = 1 - s.lb;      // (the candidate's pass linearised into the other set)
+    s.cost = cand_cost; s.x_norm = sqrt(s.cand_x2);
+    s.accepted[it] = 1; s.num_successful++; s.cost_history[it] = cand_cost;
+    s.radius = fmin(1e16, s.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3.0)));
+    s.decrease = 2.0; s.reuse = 0;
+  } else {
+    s.accepted[it] = 0;
+    s.radius /= s.decrease; s.decrease *= 2; s.reuse = 1;
+  }
+}
+// the result: x and the loop's state into the call's pinned memory (the kernel's own stores cross PCIe: no copy command)
+__global__ __launch_bounds__(256) void k_pg_finish(int n, const PgState *st, PgSets S, double *pose_out, PgState *st_out) {
+  const double *x = S.pose[st->cur];
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)7 * n; e += (size_t)gridDim.x * 256) pose_out[e] = x[e];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *st_out = *st;
 }
 // dscratch: 4 * PGR_MAXSEG doubles; res: the call's pinned result slot (PgBuffers::result)
 void dev_reduce(gfbe_ctx *c, int n, const double *a, const double *b, const double *c3, const double *d4, bool take_max, double *dscratch, double *res,
@@ -468,7 +767,7 @@ gfbe_status gfbe_pg_eval(gfbe_ctx *c, int32_t n, const double *pose, int32_t n_r
 
 gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t n_rel, const int32_t *rel_i, const double *rel_meas, double t_var,
                           double q_var, int32_t n_fix, const int32_t *fix_i, const double *fix_meas, double delta, int32_t max_it,
-                          double *pose_out, gfbe_summary *S) {
+                          double *pose_out, gfbe_summary *S_out) {
   std::vector<int> rel_of, fix_begin, fix_order;
   std::vector<double> fix_sorted;
   gfbe_status st = pg_prepare(c, n, n_rel, rel_i, n_fix, fix_i, fix_meas, rel_of, fix_begin, fix_sorted, fix_order);
@@ -476,105 +775,78 @@ gfbe_status gfbe_pg_solve(gfbe_ctx *c, int32_t n, const double *pose_in, int32_t
   if (!pose_in || !pose_out) return GFBE_BAD_INPUT;
   max_it = std::min(max_it, 15);
   hipStream_t s = ctx_stream(c);
+  static_assert(sizeof(PgState) <= PG_RESULT_BYTES, "the pinned result slot holds the loop's state");
   PgBuffers buf(c);
   PgDev P;
-  double *x, *cand, *per, *per2, *per3, *per4, *Hd, *Ho, *g, *scale, *diag2, *Bs, *A0, *C0, *Ab[2], *Bb[2], *Cb[2], *db[2], *d0, *y;
+  PgSets S;
+  double *per, *per2, *per3, *per4, *scale, *diag2, *Bs, *A0, *C0, *Ab[2], *Bb[2], *Cb[2], *db[2], *Ib[2], *d0, *y, *xo;
+  PgState *dst;
   int *fail;
   double *red3;
   for (int pass = 0; pass < 2; pass++) {
     P = {n, n_rel, n_fix, buf.dev<int>(n, rel_of.data()), buf.dev<int>(n + 1, fix_begin.data()), buf.dev<double>((size_t)7 * n_rel, rel_meas),
          buf.dev<double>((size_t)4 * n_fix, fix_sorted.data()), t_var, q_var, delta};
-    x = buf.dev<double>((size_t)7 * n, pose_in); cand = buf.dev<double>((size_t)7 * n);
+    S.pose[0] = buf.dev<double>((size_t)7 * n, pose_in); S.pose[1] = buf.dev<double>((size_t)7 * n);
     per = buf.dev<double>(n); per2 = buf.dev<double>(n); per3 = buf.dev<double>(n); per4 = buf.dev<double>(n);
-    Hd = buf.dev<double>((size_t)36 * n); Ho = buf.dev<double>((size_t)36 * n); g = buf.dev<double>((size_t)6 * n);
+    for (int q = 0; q < 2; q++) { S.Hd[q] = buf.dev<double>((size_t)36 * n); S.Ho[q] = buf.dev<double>((size_t)36 * n); S.g[q] = buf.dev<double>((size_t)6 * n); }
     scale = buf.dev<double>((size_t)6 * n); diag2 = buf.dev<double>((size_t)6 * n); Bs = buf.dev<double>((size_t)36 * n);
     A0 = buf.dev<double>((size_t)36 * n); C0 = buf.dev<double>((size_t)36 * n);
     for (int q = 0; q < 2; q++) {
       Ab[q] = buf.dev<double>((size_t)36 * n); Bb[q] = buf.dev<double>((size_t)36 * n); Cb[q] = buf.dev<double>((size_t)36 * n);
-      db[q] = buf.dev<double>((size_t)6 * n);
+      db[q] = buf.dev<double>((size_t)6 * n); Ib[q] = buf.dev<double>((size_t)36 * n);
     }
     d0 = buf.dev<double>((size_t)6 * n); y = buf.dev<double>((size_t)6 * n);
     fail = buf.dev<int>(1);
+    dst = (PgState *)buf.dev<double>((sizeof(PgState) + 7) / 8);      // (cleared with the slab: cur = lb = 0, done = 0, ...)
     red3 = buf.dev<double>(4 + 4 * (size_t)PGR_MAXSEG);
+    xo = buf.pinned<double>((size_t)7 * n);
     if (pass == 0 && !buf.commit()) { ctx_set_error(c, "gfbe_pg_solve: device allocation failed"); return GFBE_DEVICE_ERROR; }
   }
-  const dim3 g128((n + 127) / 128), b128(128), g64((n + 63) / 64), b64(64);
-  gfbe_summary sm;
-  std::memset(&sm, 0, sizeof sm);
-  hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, x, per, Hd, Ho, g, (double *)nullptr, (double *)nullptr, (double *)nullptr);
-  double cost = host_sum(c, per, n, red3, buf.result());
-  sm.initial_cost = cost; sm.cost_history[0] = cost; sm.status = GFBE_NO_CONVERGENCE;
-  double radius = 1e4, decrease = 2.0, x_norm;
+  const dim3 g6((6 * n + 191) / 192), b6(192);
+  const int nseg = (n + PGR_SEG - 1) / PGR_SEG;
+  double x_norm0;
   {
-    std::vector<double> xh((size_t)7 * n);
-    std::memcpy(xh.data(), pose_in, sizeof(double) * 7 * n);
-    double s2 = 0; for (double e : xh) s2 += e * e;
-    x_norm = std::sqrt(s2);
+    double s2 = 0;
+    for (size_t e = 0; e < (size_t)7 * n; e++) s2 += pose_in[e] * pose_in[e];
+    x_norm0 = std::sqrt(s2);
   }
-  int invalid = 0, it = 0;
-  bool reuse = false, have_scale = false;
-  while (true) {
-    if (it >= max_it) { sm.termination = 0; break; }
-    // system at the current point (B includes the LM diagonal at the current radius)
-    const dim3 g6((6 * n + 191) / 192), b6(192);
-    hipLaunchKernelGGL(k_pg_system, g6, b6, 0, s, n, Hd, Ho, g, scale, have_scale ? 0 : 1, diag2, reuse ? 1 : 0, radius, Bb[0], d0, Bs, per4, db[0], fail);
-    hipLaunchKernelGGL(k_pg_system2, g6, b6, 0, s, n, Ho, scale, A0, C0, Ab[0], Cb[0]);
-    have_scale = true;
-    // (the gradient norm of this point comes back together with the step's scalars — one host decision less per iteration;
-    //  the step that was computed meanwhile is simply dropped when the gradient test ends the solve)
-    if (radius < 1e-32) {
-      const double gm = host_sum(c, per4, n, red3, buf.result(), true);
-      if (gm <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; } else sm.termination = 4;
-      break;
-    }
+  auto reduce = [&](const double *a, const double *b, const double *c3, const double *d4, bool take_max, int mode) {
+    const bool direct = n <= (int)PGD_DIRECT_MAX;      // (one launch: the reduction and what follows from it)
+    if (!direct) hipLaunchKernelGGL(k_pg_reduce1, dim3(nseg), dim3(256), 0, s, n, a, b, c3, d4, take_max ? 1 : 0, red3 + 4);
+    hipLaunchKernelGGL(k_pg_decide, dim3(1), dim3(PGD_THREADS), 0, s, n, a, b, c3, d4, nseg, direct ? (const double *)nullptr : (const double *)(red3 + 4), take_max ? 1 : 0,
+                       dst, fail, mode, x_norm0);
+  };
+  hipLaunchKernelGGL(k_pg_lin_st, g6, b6, 0, s, P, dst, S, 0, per);
+  reduce(per, nullptr, nullptr, nullptr, false, 0);
+  // max_it passes, enqueued blindly: every kernel of a pass returns at once when the loop has ended (PgState::done), the candidate's
+  // evaluation also when the pass has no step to try
+  for (int pass = 0; pass < max_it; pass++) {
+    // system at the current point (B includes the LM diagonal at the current radius; the copies the reduction consumes; the failure flag cleared)
+    hipLaunchKernelGGL(k_pg_system, g6, b6, 0, s, n, dst, S, scale, diag2, Bb[0], d0, Bs, per4, db[0], Ib[0], fail);
+    hipLaunchKernelGGL(k_pg_system2, g6, b6, 0, s, n, dst, S, scale, A0, C0, Ab[0], Cb[0]);
     // parallel block cyclic reduction: log2(n) sweeps
-    // (k_pg_system / k_pg_system2 also wrote the copies the reduction consumes and cleared the failure flag)
     int cur = 0;
     for (int stride = 1; stride < n; stride *= 2) {
-      hipLaunchKernelGGL(k_pg_pcr, dim3((n + PCR_ROWS - 1) / PCR_ROWS), dim3(PCR_ROWS * 6), 0, s, n, stride, Ab[cur], Bb[cur], Cb[cur], db[cur], Ab[1 - cur], Bb[1 - cur], Cb[1 - cur], db[1 - cur], fail);
+      hipLaunchKernelGGL(k_pg_pcr, dim3((n + PCR_ROWS - 1) / PCR_ROWS), dim3(PCR_ROWS * 6), 0, s, n, stride, Ab[cur], Bb[cur], Cb[cur], db[cur], Ib[cur], Ab[1 - cur], Bb[1 - cur], Cb[1 - cur], db[1 - cur], Ib[1 - cur], fail, dst);
       cur = 1 - cur;
     }
-    hipLaunchKernelGGL(k_pg_final, g64, b64, 0, s, n, Bb[cur], db[cur], y, fail);
-    hipLaunchKernelGGL(k_pg_candidate, g128, b128, 0, s, n, Bs, A0, C0, d0, y, scale, x, cand, per, per2, per3);
-    int hfail = 0;
-    double r4[4];
-    dev_reduce(c, n, per4, per, per2, per3, true, red3, buf.result(), r4, fail, &hfail);      // max |g|, model change, |step|^2, |candidate|^2; the failure flag
-    if (r4[0] <= 1e-10) { sm.termination = 3; sm.status = GFBE_OK; break; }
-    it++;
-    const double model_change = r4[1];
-    if (hfail || !(model_change > 0.0)) {
-      sm.accepted[it] = 0; sm.cost_history[it] = cost;
-      if (++invalid >= 5) { sm.termination = 4; sm.status = GFBE_NUMERICAL_FAILURE; break; }
-      radius /= decrease; decrease *= 2; reuse = true;
-      continue;
-    }
-    invalid = 0;
-    const double step2 = r4[2], cand_x2 = r4[3];
-    hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, cand, per, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr,
-                       (double *)nullptr, (double *)nullptr);
-    const double cand_cost = host_sum(c, per, n, red3, buf.result());
-    sm.cost_history[it] = cost;
-    if (std::sqrt(step2) <= 1e-8 * (x_norm + 1e-8)) { sm.termination = 2; sm.status = GFBE_OK; break; }
-    const double change = cost - cand_cost;
-    if (std::fabs(change) <= 1e-6 * cost) { sm.termination = 1; sm.status = GFBE_OK; break; }
-    const double rho = change / model_change;
-    if (rho > 1e-3) {
-      std::swap(x, cand);
-      cost = cand_cost; x_norm = std::sqrt(cand_x2);
-      sm.accepted[it] = 1; sm.num_successful++; sm.cost_history[it] = cost;
-      radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)));
-      decrease = 2.0; reuse = false;
-      hipLaunchKernelGGL(k_pg_lin, g128, b128, 0, s, P, x, per, Hd, Ho, g, (double *)nullptr, (double *)nullptr, (double *)nullptr);
-    } else {
-      sm.accepted[it] = 0;
-      radius /= decrease; decrease *= 2; reuse = true;
-    }
+    hipLaunchKernelGGL(k_pg_final, g6, b6, 0, s, n, Ib[cur], db[cur], y, dst);
+    hipLaunchKernelGGL(k_pg_candidate, g6, b6, 0, s, n, Bs, A0, C0, d0, y, scale, dst, S, per, per2, per3);
+    reduce(per4, per, per2, per3, true, 1);      // max |g|, model change, |step|^2, |candidate|^2; the failure flag
+    hipLaunchKernelGGL(k_pg_lin_st, g6, b6, 0, s, P, dst, S, 1, per);      // the candidate's cost — and its linearisation, should it be accepted
+    reduce(per, nullptr, nullptr, nullptr, false, 2);
   }
-  sm.iterations = it; sm.final_cost = cost; sm.final_radius = radius;
-  (void)hipMemcpyAsync(pose_out, x, sizeof(double) * 7 * n, hipMemcpyDeviceToHost, s);
-  (void)hipStreamSynchronize(s);
-  if (S) *S = sm;
-  if (hipGetLastError() != hipSuccess) return GFBE_DEVICE_ERROR;
+  PgState *hst = (PgState *)buf.result();
+  hipLaunchKernelGGL(k_pg_finish, dim3(std::min(256, (7 * n + 255) / 256)), dim3(256), 0, s, n, dst, S, xo, hst);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { ctx_set_error(c, "gfbe_pg_solve: device error"); return GFBE_DEVICE_ERROR; }
+  std::memcpy(pose_out, xo, sizeof(double) * 7 * n);
+  gfbe_summary sm;
+  std::memset(&sm, 0, sizeof sm);
+  sm.status = hst->status; sm.termination = hst->done ? hst->termination : 0;
+  sm.iterations = hst->it; sm.num_successful = hst->num_successful;
+  sm.initial_cost = hst->initial_cost; sm.final_cost = hst->cost; sm.final_radius = hst->radius;
+  for (int q = 0; q < 16; q++) { sm.cost_history[q] = hst->cost_history[q]; sm.accepted[q] = (uint8_t)hst->accepted[q]; }
+  if (S_out) *S_out = sm;
   return sm.status == GFBE_NUMERICAL_FAILURE ? GFBE_NUMERICAL_FAILURE : GFBE_OK;
 }
 
