@@ -402,6 +402,7 @@ void launch_marginalize(const BatchDev &d, int flag, hipStream_t s);
 // mode 0: GNSS factors at the current parameters, added to H / g (after launch_assemble); 1: candidate cost; 2: the frame-0 factors at
 // the re-anchored state for MARGIN_OLD
 void launch_gnss(const BatchDev &d, int mode, hipStream_t s, int sub = 0);
+bool lin_small_takes_gnss(const BatchDev &d, int mode);   // k_lin_small's candidate passes evaluate the batch's GNSS factors themselves (gfbe_gnss_item.h)
 
 // ---- device-resident feature tables (gfbe_ftab.hip; shared with the batch upload that reads them)
 enum { FT_NOBS = GFBE_WINDOW_SIZE + 1, FT_OW = 8, FT_BINS = NF * 8,

@@ -1415,7 +1415,9 @@ static void run_allreduce(gfbe_ctx *c, double *ptr, int64_t n, hipStream_t s) {
 static int small_fuse(const gfbe_ctx *c, const BatchDev &d) {
   if (c->profiling || d.B >= DENSE_SPLIT_MIN_B || !d.vis_Hs || d.sharded || d.max_tiles == 0) return 0;
   int f = GFBE_FUSE_SMALL;
-  if (d.any_gnss || d.tot_lio > 0) f &= ~4;     // (their candidate costs are launches of their own between k_lin_small<1> and k_accept)
+  // (a LiDAR window's candidate cost — and a GNSS window's beyond the size k_lin_small takes itself — is a launch of its own between
+  //  k_lin_small<1 / 3> and k_accept)
+  if (d.tot_lio > 0 || (d.any_gnss && !lin_small_takes_gnss(d, 1))) f &= ~4;
   return f;
 }
 
@@ -1509,7 +1511,9 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
     else if (lin_cand) { Timed t(c, "k_vis_lin", b->algo_bytes_lin); launch_vis(d, 0, ln.s, 0, 1); }
     else { Timed t(c, "k_vis_cost", 0); launch_vis(d, 1, ln.s); }
     if (d.tot_lio > 0) { Timed t(c, lin_cand ? "k_lio_window" : "k_lio_window_cost", 0); launch_lio_window(d, lin_cand ? 0 : 1, ln.s, lin_cand); }
-    if (d.any_gnss) { Timed t(c, lin_cand ? "k_gnss_eval" : "k_gnss_cost", 0); launch_gnss(d, lin_cand ? 0 : 1, ln.s, lin_cand ? 1 : 0); }
+    if (d.any_gnss && !(small && lin_small_takes_gnss(d, lin_cand ? 3 : 1))) {      // (small batches: a workgroup of k_lin_small did it)
+      Timed t(c, lin_cand ? "k_gnss_eval" : "k_gnss_cost", 0); launch_gnss(d, lin_cand ? 0 : 1, ln.s, lin_cand ? 1 : 0);
+    }
     if (!small && !overlap) { Timed t(c, lin_cand ? "k_dense" : "k_dense_cost", 0); launch_dense_factors(d, lin_cand ? 0 : 1, 0, ln.s, lin_cand); }
     else if (overlap) (void)hipStreamWaitEvent(ln.s, ln.join, 0);
     if (d.sharded) {

@@ -21,6 +21,7 @@
 //   k_reanchor     Estimator::double2vector gauge fix (estimator/estimator.cpp:2501-2555)
 #include "gfbe_devutil.h"
 #include "gfbe_factors.h"
+#include "gfbe_gnss_item.h"
 #include <type_traits>
 
 namespace gfd {
@@ -1699,6 +1700,11 @@ __global__ __launch_bounds__(LIN_SMALL_THREADS, 1) void k_lin_small(BatchDev d0,
     if constexpr (WS) vis_body<VM, FULL, KS, SPEC, true>(d, 0, w, y, threadIdx.x >> 6, SPEC && (fuse & 2), lsm);
     else vis_body<VM, FULL, 1, SPEC, false>(d, 0, w, y, 0, MODE == 1 && (fuse & 2));
     if (threadIdx.x >= LM_TILE) return;      // (the tile's first wave goes on: it has summed the waves' shares)
+  } else if ((MODE == 1 || SPEC) && y - ny_tiles == MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)) {
+    // (round 6) the GNSS factors at the candidate: one more workgroup of the launch (launch_lin_small adds it for batches with GNSS
+    // windows of up to GN_ITEM_MAX_OBS observations) instead of a launch of k_gnss behind this one
+    __shared__ double gn_red[16];
+    gnss_candidate_item(d, w, SPEC, gn_red);
   } else {
     dense_body<true>(d, VM, 0, w, y - ny_tiles, SPEC, lsm);
   }
@@ -3920,8 +3926,10 @@ static size_t lin_small_lds(bool split, bool full) {
   const size_t panels = split ? (size_t)LIN_SMALL_KS * LM_TILE * (full ? (size_t)XS_LD : 17) : 0;
   return sizeof(double) * std::max(panels, (size_t)PRIOR_CHUNK);
 }
+bool lin_small_takes_gnss(const BatchDev &d, int mode) { return d.any_gnss && (mode == 1 || mode == 3) && d.gnss_max_obs <= (int)GN_ITEM_MAX_OBS; }
 void launch_lin_small(const BatchDev &d, int mode, hipStream_t s, int fuse) {
-  const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0)), b(LIN_SMALL_THREADS);
+  // (+ one workgroup per window for the GNSS factors at the candidate: gnss_candidate_item)
+  const dim3 g(d.B, d.max_tiles + MAX_IMU + MAX_WHEEL + 1 + (d.any_plane ? MAX_PLANE + 1 : 0) + (lin_small_takes_gnss(d, mode) ? 1 : 0)), b(LIN_SMALL_THREADS);
   if (mode == 2) hipLaunchKernelGGL((k_lin_small<2, true>), g, b, lin_small_lds(true, true), s, d, 0);   // (the marginalisation set: k_vis_split<2> + k_dense mode 2 in one launch)
   else if (mode == 0 && d.vis_full) hipLaunchKernelGGL((k_lin_small<0, true>), g, b, lin_small_lds(true, true), s, d, 0);
   else if (mode == 0) hipLaunchKernelGGL((k_lin_small<0, false>), g, b, lin_small_lds(true, false), s, d, 0);

@@ -1244,6 +1244,61 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
       G32[j * 32 + i] = 0.5 * (A[(size_t)sh.drop_dim[i] * ND + sh.drop_dim[j]] + A[(size_t)sh.drop_dim[j] * ND + sh.drop_dim[i]]);
     }
     __syncthreads();
+    // (round 6) the fast path of the 16-dim block below for up to 32 dims — the 20 dropped dims of a GNSS window: Cholesky factor by one
+    // wave (lane = row, two 32-lane halves doing the same), its inverse column by column, Pinv = L^-T L^-1, certified by
+    // lambda_min >= 1 / |Pinv|_F > 4 eps; the workgroup-wide Jacobi (~0.1 ms of a single window's marginalisation) only runs when the
+    // block is rank-deficient or holds tiny eigenvalues, with the reference's thresholding as before.
+    double *W32 = marg_lds + 3 * 32 * 32;      // L^-1 (lam32's block: the Jacobi, if it runs, runs afterwards)
+    for (int e = t; e < 32 * 32; e += blockDim.x) { V32[e] = G32[e]; W32[e] = 0.0; }
+    __syncthreads();
+    if (t < 64) {
+      // right-looking Cholesky in LDS (loops with run-time bounds: no register arrays in a kernel held to 128 registers), one wave
+      bool ok = true;
+      for (int k = 0; k < m; k++) {
+        const double dkk = V32[k * 32 + k];
+        if (!(dkk > 0.0) || !isfinite(dkk)) ok = false;
+        const double lkk = sqrt(dkk);
+        __builtin_amdgcn_wave_barrier();
+        if (t == k) V32[k * 32 + k] = lkk;
+        else if (t > k && t < m) V32[t * 32 + k] = V32[t * 32 + k] / lkk;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        const int nr = m - k - 1;
+        for (int idx = t; idx < nr * nr; idx += 64) {
+          const int i = k + 1 + idx / nr, j = k + 1 + idx % nr;
+          if (j <= i) V32[i * 32 + j] -= V32[i * 32 + k] * V32[j * 32 + k];
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (t < m) {                                                    // lane j: column j of L^-1 (its own earlier entries: same lane)
+        const int j = t;
+        for (int i = j; i < m; i++) {
+          double acc = (i == j) ? 1.0 : 0.0;
+          for (int k = j; k < i; k++) acc -= V32[i * 32 + k] * W32[k * 32 + j];
+          W32[i * 32 + j] = acc / V32[i * 32 + i];
+        }
+      }
+      if (t == 0) cflag = ok ? 1 : 0;
+    }
+    __syncthreads();
+    double fro32 = 0.0;
+    for (int e = t; e < 32 * 32; e += blockDim.x) {
+      const int i = e >> 5, j = e & 31;
+      double s = 0.0;
+      for (int k = 0; k < 32; k++) s += W32[k * 32 + i] * W32[k * 32 + j];
+      s = (i < m && j < m) ? s : 0.0;
+      Pinv[e] = s;
+      fro32 += s * s;
+    }
+    for (int o = 32; o > 0; o >>= 1) fro32 += __shfl_down(fro32, o, 64);
+    if ((t & 63) == 0) Pl[t >> 6] = fro32;
+    __syncthreads();
+    double fsum = 0.0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); q++) fsum += Pl[q];
+    const bool fast32 = cflag == 1 && isfinite(fsum) && 1.0 / sqrt(fsum) > 4.0 * d.opt.marg_eps;
+    __syncthreads();
+    if (!fast32) {
     jacobi_eig(G32, V32, m, 32, lam32, &cflag, nullptr);
     for (int e = t; e < m * m; e += blockDim.x) {
       const int i = e / m, j = e % m;
@@ -1252,6 +1307,7 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
       Pinv[i * 32 + j] = s;
     }
     __syncthreads();
+    }
   } else {
   for (int e = t; e < m * m; e += blockDim.x) {
     const int i = e / m, j = e % m;
@@ -1450,14 +1506,14 @@ __global__ __launch_bounds__(MARG_THREADS) void k_marg(BatchDev d, int flag) {
 
 
 // R = 4: priors of up to 88 dims (the 86 of the shipped configuration: 16 matrix registers per thread, two workgroups per CU);
-// R = 8: larger ones (up to 176). Both are launched when a batch may hold both kinds; a workgroup leaves the other kind alone.
+// R = 6: up to 132 (a GNSS window's); R = 8: larger ones (up to 176). Both are launched when a batch may hold both kinds; a workgroup leaves the other kind alone.
 template <int R>
 __global__ __launch_bounds__(LDLT_THREADS) void k_marg_ldlt(BatchDev d) {
   const int w = blockIdx.x;
   int *meta = d.mmeta + (size_t)w * (4 + 3 * GFBE_MAX_PRIOR_BLOCKS);
   if (meta[0] != 1 || meta[3] != MARG_SQRT_PENDING) return;
   const int n = meta[1];
-  if ((n <= 4 * 22) != (R == 4)) return;
+  if (R != (n <= 4 * 22 ? 4 : (n <= 6 * 22 ? 6 : 8))) return;      // (R = 6, round 6: the ~95-dim prior of a GNSS window on 36 instead of 64 entries per thread)
   const double *A = d.mA + (size_t)w * ND * ND;
   const double *bv = d.mb + (size_t)w * ND;
   double *J0 = d.mJ0 + (size_t)w * ND * ND;
@@ -1634,7 +1690,8 @@ void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s) {
   if (d.opt.marg_sqrt == 1) {
     if (GFBE_LDLT_TP == 2 || (GFBE_LDLT_TP && d.B >= DENSE_SPLIT_MIN_B)) hipLaunchKernelGGL(k_marg_ldlt_tp, dim3(d.B), dim3(64), 0, s, d);      // (2: every batch — the bit-for-bit check against k_marg_ldlt<4>)
     else hipLaunchKernelGGL(k_marg_ldlt<4>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
-    if (d.marg_nmax > 4 * 22) hipLaunchKernelGGL(k_marg_ldlt<8>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
+    if (d.marg_nmax > 4 * 22) hipLaunchKernelGGL(k_marg_ldlt<6>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
+    if (d.marg_nmax > 6 * 22) hipLaunchKernelGGL(k_marg_ldlt<8>, dim3(d.B), dim3(LDLT_THREADS), 0, s, d);
   }
 }
 
