@@ -864,7 +864,8 @@ def other_configs_leg(args, gf, torch, be, with_cpu):
       cfg3  10-kf window with 10 000 landmarks on ONE GPU (the 4-GPU landmark shard of configs[2] needs a multi-GPU node): one call,
             and 256 resident windows
       cfg4  global_fusion pose graph, 5 000 poses: gfbe_pg_solve (5 LM iterations), with an HBM view on the block-tridiagonal system
-      cfg5  the cfg-2 window + 2 000 LiDAR point-to-plane factors (joint solve), and gfbe_lio_linearize of a 2 000 / 100 000-point scan"""
+      cfg5  the cfg-2 window + 2 000 LiDAR point-to-plane factors (joint solve), and gfbe_lio_linearize of a 2 000 / 100 000-point scan
+      gnss  a 150-landmark window with the optional GNSS blocks (88 observations): one gfbe_solve_window call"""
     abi, synth = gf.abi, gf.synth
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
@@ -923,7 +924,9 @@ def other_configs_leg(args, gf, torch, be, with_cpu):
     tri_bytes = 8.0 * (5000 * (36 + 36 + 6) * 2 + 4999 * 14 + 500 * 4)
     c4 = {"poses": 5000, "host_to_host_ms": ms, "lm_iterations": it, "algorithmic_bytes_per_iteration": tri_bytes,
           "hbm_GBps_on_algorithmic_bytes": tri_bytes * it / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": tri_bytes * it / (ms * 1e-3) / 1e12 / PEAK_HBM_TBS,
-          "note": "3 MB per iteration: the solve is bound by the log-depth chain of the block cyclic reduction and the host-to-host copies, not by bandwidth"}
+          "note": "latency-bound, not bandwidth-bound (3 MB per iteration): ~22 dependent launches per Levenberg-Marquardt iteration — 13 sweeps of the "
+                  "block cyclic reduction among them — at the 5-9 us a dependent launch with one round trip to L2 costs; since round 6 the loop's "
+                  "decisions are taken on the device (one host wait per solve instead of eleven)"}
     if orc is not None:
         ref = abi.PoseGraph(orc.lib, "gfo_", None)
         t0 = time.perf_counter()
@@ -954,6 +957,10 @@ def other_configs_leg(args, gf, torch, be, with_cpu):
                 e["cpu_oracle_1core_" + key] = med_ms(lambda: abi.lio_linearize(orc.lib, "gfo_", None, 0, pts, nrm, offs, None, w, 0.8, pb, None, blocks=blocks), 5, warm=1)
         lin["plain_factor_n_%d" % n] = e
     c5["gfbe_lio_linearize_host_buffers"] = lin
+    # the optional GNSS blocks inside the window (estimator.cpp:3239-3291; gnss_enable is 0 in every shipped yaml): 150 landmarks, 88 pseudo-range /
+    # Doppler observations, solve + MARGIN_OLD — the structure-agnostic solver k_solve_big
+    import gnss_window_cases as gw
+    out["gnss_window_150_landmarks_88_observations"] = window_leg(gw.gnss_window(seed=81, L=150, n_per_frame=8)[2], 30, 5)
     c5["note"] = ("a 2 000-point scan from host buffers is one copy in, one kernel, one copy out: ~3 dependent PCIe / launch latencies, the range of one "
                   "CPU core's evaluation of 2 000 residuals; in the joint window the scan rides in the window's upload and stays resident")
     out["cfg5_joint_lvio"] = c5

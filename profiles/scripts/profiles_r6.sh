@@ -30,6 +30,10 @@ python tools/diag_single.py 2>&1 | tail -3 | tee -a gpurun_out/r6_single.log
 GFBE_LIB=$R/ground-fusion2_amd/csrc/libgfbe_diag.so python tools/diag_scripts/eig_time.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_eigen_prior.txt; cat gpurun_out/r6_eigen_prior.txt
 python tools/diag_scripts/plane_kernels.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_plane_kernels.txt
 python tools/diag_scripts/gnss_prof.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_gnss_window_profile.txt; head -3 gpurun_out/r6_gnss_window_profile.txt
+# the pose graph (BASELINE configs[3]) under the tracer and beside the oracle; the soak's one diverging gimbal-lock window against the oracle's own sensitivity
+(cd /tmp; rm -rf /tmp/pg; N=20 rocprofv3 --kernel-trace --stats -d /tmp/pg -- python $R/tools/diag_scripts/pg_trace.py 2>&1 | grep "pose graph"; python $R/profiles/summarize_rocpd.py /tmp/pg/*/*_results.db $R/gpurun_out/r6_posegraph_trace.txt | head -4)
+python tools/diag_posegraph_bench.py 2>&1 | grep "poses:" | tee -a gpurun_out/r6_posegraph_trace.txt
+python tools/diag_scripts/gimbal_divergence.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r6_gimbal_divergence.txt; tail -3 gpurun_out/r6_gimbal_divergence.txt
 cd /tmp; rm -rf /tmp/pe; B=1024 DEPTH=3 STEPS=10 rocprofv3 --kernel-trace --memory-copy-trace --stats -d /tmp/pe -- python $R/tools/diag_e2e.py > /tmp/pe.log 2>&1; grep "e2e host-fed" /tmp/pe.log > $R/gpurun_out/r6_e2e.log
 python $R/profiles/summarize_rocpd.py /tmp/pe/*/*_results.db $R/gpurun_out/r6_e2e_trace.txt | head -8; cat $R/gpurun_out/r6_e2e.log
 cd $R
