@@ -325,6 +325,7 @@ struct BatchDev {
   int solve_ntile;            // dense tiles (16 x 16, lower triangle incl. the right-hand side row) of the largest window: sizes the dynamic LDS
   int solve_mono;             // some window's prior couples a speed-bias block other than SpeedBias[0]: the whole batch takes the monolithic k_solve
   int solve_tw;               // the chain eliminated from both ends (k_solve_chain_tw, one workgroup per CU): small batches, where a window's latency counts
+  int solve_wide;             // a batch with GNSS dims (solve_big) whose windows all fit k_solve_chain_wide: the chain kernel with nine tile columns of dense dims
   // debug / inspection outputs (gfbe_eval_factors)
   double *dbg_imu, *dbg_wheel, *dbg_prior;  // [B][MAX_IMU][15*31], [B][MAX_WHEEL][6*23], [B][ND]
   // marginalisation
@@ -389,6 +390,7 @@ void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s);
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass = 0);
 int solve_chain_tiles(const unsigned char *act);
 bool solve_chain_tw_fits(int ntile);                // k_solve_chain_tw holds every row of Yr in LDS: up to five tile columns of the dense part
+bool solve_chain_wide_fits(int n_dense_max);   // a batch with GNSS dims on k_solve_chain_wide (nine tile columns of dense dims)
 size_t solve_chain_scratch_doubles();              // doubles of BatchDev::solveY per window   // dense 16 x 16 tiles k_solve_chain needs for a window with these active dims
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s);
 void launch_sys_pack(const BatchDev &d, int dir, hipStream_t s);   // landmark sharding: pack (0) / unpack (1) the partial system around its all-reduce

@@ -1197,6 +1197,15 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
       for (int q = 0; q < ds.prior_nblk; q++) if (ds.prior_blk_id[q] > GFBE_BLK_SB0 && ds.prior_blk_id[q] < GFBE_BLK_EX_CAM) mono = 1;
     }
     d.solve_ntile = ntile; d.solve_mono = mono;
+    {   // (round 6) a batch with GNSS dims: the chain kernel with nine tile columns when every window's dense part fits and the priors keep the chain's structure
+      int n_dense_max = 0;
+      for (int w = 0; w < B; w++) {
+        int nd = 0;
+        for (int a = 0; a < ND; a++) if (h_desc[w].act[a] && !(a >= T_SB(0) && a < T_SB(0) + 9 * NF)) nd++;
+        n_dense_max = std::max(n_dense_max, nd);
+      }
+      d.solve_wide = d.solve_big && !mono && c->opt.solve_kernel != 4 && solve_chain_wide_fits(n_dense_max);
+    }
     // the chain kernel of the batch: the twisted one (both ends at once, eight waves, one workgroup per CU) where a window's latency
     // counts — below DENSE_SPLIT_MIN_B windows, like the rest of the small-batch kernel set —, the classic one for throughput
     // (a dense part of six tile columns — a free camera extrinsic — does not fit its LDS layout: the classic kernel whatever was asked)

@@ -347,7 +347,9 @@ __device__ GFBE_SOLVE_FN double solve_build_tiles(lds_double *smem, const lds_sh
 // The factorisation loop of k_solve, out of line: inside this function the only live state is a handful of indices, so the
 // register-resident tile step (chol_inv_tile16: 64 VGPRs of tile and inverse rows) is inlined without spilling and without a
 // call per panel; the kernel around it saves its own registers once.
-template <int NWAVES>
+// (VAR: an instance of its own for k_solve_chain_wide — an out-of-line function shared by kernels of different launch bounds is compiled to the
+//  most permissive of them, and the two-workgroups-per-CU kernels then exceed their register budget)
+template <int NWAVES, int VAR = 0>
 __device__ GFBE_SOLVE_FN void chol_factor_all(lds_double *smem, int nt, int n, int t, lds_double *zlast, lds_int *flag, double *stamp) {
   const int lane = t & 63, wave = t >> 6;
 #define CF_STAMP(i) do { if (t == 0) stamp[i] = (double)wall_clock64(); } while (0)
@@ -684,6 +686,9 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 #define GFBE_WIDE_PREFETCH2 0      // k_solve_chain's wide rows: the rows of S two blocks ahead instead of one (measured: 86.9 against 84.4 us per 512
                                    // windows — the pipeline does not wait for those loads)
 #endif
+#ifndef GFBE_SOLVE_WIDE
+#define GFBE_SOLVE_WIDE 1          // batches with GNSS dims on k_solve_chain_wide where they fit (0: k_solve_big for all of them, rounds 3-5)
+#endif
 #ifndef GFBE_CHAIN_PRIO
 #define GFBE_CHAIN_PRIO 0          // k_solve_chain: s_setprio 3 for wave 0 and GFBE_CHAIN_PRIO - 1 for the wide waves (0: the priorities are left alone)
 #endif
@@ -698,10 +703,12 @@ __global__ __launch_bounds__(SOLVE_THREADS, SOLVE_WAVES_PER_EU) void k_solve(Bat
 #endif
 #define S2_WAVES (S2_THREADS >> 6)
 enum { CH_NB = 9, CH_NC = NF, CH_ROWS = CH_NB * CH_NC, CH_BLK = CH_NB * CH_NB, RING_ROWS = 12,
-       S2_MAX_NT = 6, S2_MAX_TILES = S2_MAX_NT * (S2_MAX_NT + 1) / 2, GYT_LD = 104, GYT_COLS = TB * S2_MAX_NT };
+       S2_MAX_NT = 6, S2_MAX_TILES = S2_MAX_NT * (S2_MAX_NT + 1) / 2, GYT_LD = 104, GYT_COLS = TB * S2_MAX_NT,
+       S2_WIDE_NT = 9, S2_WIDE_TILES = S2_WIDE_NT * (S2_WIDE_NT + 1) / 2 };      // k_solve_chain_wide (round 6): the GNSS dims as dense columns
 // row stride of the Yr ring: >= 16 x tile columns and = 16 (mod 32) doubles, so that the two row groups a half-wave reads as a
 // matrix-core operand fall into disjoint LDS banks (five tile columns -> 80, six -> 112)
 __host__ __device__ inline int chain_ring_ld(int ntile) { return ntile <= 15 ? 80 : 112; }
+enum { CHAIN_RING_LD_WIDE = 176 };      // nine tile columns (k_solve_chain_wide): 144 + 32, = 16 (mod 32)
 __host__ __device__ inline bool dim_in_chain(int a) { return a >= T_SB(0) && a < T_SB(0) + CH_ROWS; }
 typedef __attribute__((address_space(3))) unsigned char lds_uchar;
 
@@ -861,7 +868,7 @@ template <int TW> struct ChainCfg {
   static constexpr int NB1 = TW ? CH_MID : 0;                  // blocks of segment 1 (ascending from 0)
   static constexpr int STEPS = TW ? NB0 + 1 : NB0 + 2;         // block barriers of the pipeline (chain | wide rows | classic: the dense update one more step behind)
 };
-template <int TW, int SEG>
+template <int TW, int SEG, int VAR = 0>
 __device__ GFBE_ROLE_FN void chain_role(lds_double *Ach, lds_double *Cch, lds_double *Amid, lds_int *flag, int lane, double *rstamp) {
   constexpr int NB = SEG == 0 ? ChainCfg<TW>::NB0 : ChainCfg<TW>::NB1;
   for (int s = 0; s < ChainCfg<TW>::STEPS; s++) {
@@ -891,8 +898,9 @@ __device__ GFBE_ROLE_FN void chain_role(lds_double *Ach, lds_double *Cch, lds_do
 // dump slot. (Inactive speed-bias dims: H holds exact zeros there.)
 // Returns the lane's share of v^T S v over the coupling entries it loads; |z_chain|^2 goes to *zzc_out.
 #define S2_WIDE_WAVES 3
-#define S2_TPW ((S2_MAX_TILES + S2_WIDE_WAVES - 1) / S2_WIDE_WAVES)
 enum { CH_ZERO = 96 };     // doubles behind the chain blocks: a zero slot (first half: parked operand reads reach 36 doubles in) and a dump slot
+// MAXNT: tile columns of the dense part the instance holds (6: k_solve_chain; 9: k_solve_chain_wide) — NU column tiles of Yr and TPW dense tiles per wave
+template <int MAXNT>
 __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds_double *Cch, lds_double *ring, lds_double *zslot, const lds_double *sS,
                                          const lds_double *vS, const lds_double *rS, const lds_short *perm, const lds_int *s_lo, lds_double *zzc_out,
                                          const glb_double *H, glb_double *gYT, int n_, int nt_, int ring_ld_, int wv_, int lane, double *rstamp) {
@@ -900,18 +908,19 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
   //  index — and would turn every branch on them into an EXEC-masked region)
   const int n = __builtin_amdgcn_readfirstlane(n_), nt = __builtin_amdgcn_readfirstlane(nt_);
   const int ring_ld = __builtin_amdgcn_readfirstlane(ring_ld_), wv = __builtin_amdgcn_readfirstlane(wv_);
+  constexpr int NU = (MAXNT + S2_WIDE_WAVES - 1) / S2_WIDE_WAVES, S2_TPW = (MAXNT * (MAXNT + 1) / 2 + S2_WIDE_WAVES - 1) / S2_WIDE_WAVES, GYTC = TB * MAXNT;
   const int lr = lane & 15, lk = lane >> 4, na = n + 1;
   const bool in01 = lr < CH_NB, in2 = lr < CH_NB && lk == 0;
   // ---- per-lane state of the two column tiles
-  bool on[2];
-  int jc[2];
-  double sbj[2], vbj2[2], mrhs[2];
-  const glb_double *pH[2];        // S-source entry (SB_k row lk, column): H[a * ND + b] for b below the speed-bias dims, H[b * ND + a] above
-  long dH[2];
-  glb_double *pY[2], *pY8[2];     // transposed Yr rows: rows lk, lk + 4 | row 8 (lk == 0) — or the dump column
-  lds_double *pR[2];              // ring slot (row lk, column 16 c + lr)
+  bool on[NU];
+  int jc[NU];
+  double sbj[NU], vbj2[NU], mrhs[NU];
+  const glb_double *pH[NU];        // S-source entry (SB_k row lk, column): H[a * ND + b] for b below the speed-bias dims, H[b * ND + a] above
+  long dH[NU];
+  glb_double *pY[NU], *pY8[NU];     // transposed Yr rows: rows lk, lk + 4 | row 8 (lk == 0) — or the dump column
+  lds_double *pR[NU];              // ring slot (row lk, column 16 c + lr)
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
+  for (int u = 0; u < NU; u++) {
     const int c = wv + S2_WIDE_WAVES * u;
     on[u] = c < nt;
     jc[u] = TB * c + lr;
@@ -922,14 +931,14 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
     const int a0 = T_SB(CH_NC - 1) + lk;
     dH[u] = bj < T_SB(0) ? ND : 1;
     pH[u] = H + (bj < T_SB(0) ? (size_t)a0 * ND + bj : (size_t)bj * ND + a0);
-    glb_double *col = gYT + (size_t)(col_on ? jc[u] : GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB;    // (column 95 is never a system column: the dump)
+    glb_double *col = gYT + (size_t)(col_on ? jc[u] : GYTC - 1) * GYT_LD + (CH_NC - 1) * CH_NB;    // (column 95 is never a system column: the dump)
     pY[u] = col + lk;
-    pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYT_COLS - 1) * GYT_LD + (CH_NC - 1) * CH_NB + 8;
+    pY8[u] = (col_on && lk == 0) ? col + 8 : gYT + (size_t)(GYTC - 1) * GYT_LD + (CH_NC - 1) * CH_NB + 8;
     pR[u] = ring + lk * ring_ld + min(TB * c, ring_ld - TB) + lr;
   }
-  double yv[2][3], rpre[2][3], rnxt[2][3], vsv = 0.0, zzc = 0.0;
+  double yv[NU][3], rpre[NU][3], rnxt[NU][3], vsv = 0.0, zzc = 0.0;
 #pragma unroll
-  for (int u = 0; u < 2; u++)
+  for (int u = 0; u < NU; u++)
 #pragma unroll
     for (int kk = 0; kk < 3; kk++) { yv[u][kk] = 0.0; rpre[u][kk] = 0.0; rnxt[u][kk] = 0.0; }
   // rows lk, lk + 4, lk + 8 of block k (the third only counts for lk == 0: the others read into the next block and are masked)
@@ -941,12 +950,12 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
     pH[u] -= CH_NB * dH[u];
   };
 #pragma unroll
-  for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rpre[u]);
+  for (int u = 0; u < NU; u++) if (on[u]) load_R(u, rpre[u]);
 #if GFBE_WIDE_PREFETCH2
   // (round 6) TWO blocks ahead: beside a second workgroup on the CU — and the batch's other parts' kernels — a load takes longer than a step
   // of the pipeline (stamps, B = 1 / 256 / 512: the pipeline 19.6 / 24.8 / 33.3 us), so the rows requested one step ahead paced the steps
 #pragma unroll
-  for (int u = 0; u < 2; u++) if (on[u]) load_R(u, rnxt[u]);
+  for (int u = 0; u < NU; u++) if (on[u]) load_R(u, rnxt[u]);
 #endif
   // operand pointers into the chain blocks (block CH_NC - 1 first; per-lane stride, 0 for the lanes parked on the zero slot)
   //   a2[kk] = W_k[lr][4 kk + lk]        a1[kk] = -Yc_k+1[4 kk + lk][lr]      (G: W_kG[4 kk + lk][lr], Yc_kG[4 kk + lk][lr])
@@ -1003,7 +1012,7 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
       for (int kk = 0; kk < 3; kk++) { const int a = T_SB(k) + min(lk + 4 * kk, CH_NB - 1); sk[kk] = sS[a]; vk[kk] = vS[a]; rk[kk] = rS[a]; }
       sk[2] *= m2; rk[2] *= m2;
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < NU; u++) {
         if (!on[u]) continue;                                      // (wave-uniform)
         const bool zero_tile = TB * (wv + S2_WIDE_WAVES * u + 1) <= lo;      // (below the reach of block k: Yr_k is zero here; wave-uniform)
         const double reach = (jc[u] >= lo && jc[u] < na) ? 1.0 : 0.0;
@@ -1072,7 +1081,7 @@ __device__ GFBE_ROLE_FN double wide_role(lds_double *tiles, lds_double *Ach, lds
   zzc += __shfl_xor(zzc, 16, 64);
   zzc += __shfl_xor(zzc, 32, 64);
 #pragma unroll
-  for (int u = 0; u < 2; u++) if (mrhs[u] != 0.0 && lk == 0) *zzc_out = zzc;
+  for (int u = 0; u < NU; u++) if (mrhs[u] != 0.0 && lk == 0) *zzc_out = zzc;
   return vsv;
 }
 
@@ -1283,9 +1292,16 @@ __device__ __forceinline__ void dense_update_tw(lds_double *tiles, const lds_dou
 // TW = 0: k_solve_chain (four waves: the chain role, three wide waves; two workgroups per CU — throughput batches).
 // TW = 1: k_solve_chain_tw (eight waves: two chain roles, three wide waves per segment; one workgroup per CU — small batches, where one
 //         window's latency counts: the chain is eliminated from both ends, ChainCfg above).
-template <int TW>
+// MAXNT: tile columns of the dense part the instance holds — 6: k_solve_chain / k_solve_chain_tw (the 187 core dims); 9 (round 6,
+// k_solve_chain_wide): a window with GNSS blocks, whose 58 extra dims are dense columns like the poses (SpeedBias[k] couples with them
+// through the Doppler rows of the pseudo-range factors: wide rows, as with the wheel extrinsic) — 45 tiles, one workgroup per CU
+template <int TW, int MAXNT = S2_MAX_NT>
 __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pass) {
   constexpr int NWAVES = TW ? 2 * S2_WAVES : S2_WAVES;
+  constexpr int MAXTILES = MAXNT * (MAXNT + 1) / 2;
+  constexpr bool WIDE = MAXNT > S2_MAX_NT;
+  constexpr int PW = WIDE ? 4 : 3;        // waves whose threads own a tangent dim that can be dense (dims 0..191: the core; 0..245 with the GNSS blocks)
+  static_assert(!(TW && WIDE), "the two-ended kernel holds the core dims only");
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
   WinCtl &c = d.ctl[w];
@@ -1322,7 +1338,7 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
   const double *H = d.H + (size_t)w * ND * ND, *g = d.g + (size_t)w * ND;
   double *gsp = d.sp + (size_t)w * ND, *gDp = d.Dp + (size_t)w * ND, *ggts = d.gts + (size_t)w * ND;
   double *gvp = d.vp + (size_t)w * ND, *gyp = d.yp + (size_t)w * ND;
-  double *gYT = d.solveY + (size_t)w * GYT_COLS * GYT_LD;
+  double *gYT = WIDE ? d.solveS + (size_t)w * BIG_LD * BIG_LD : d.solveY + (size_t)w * GYT_COLS * GYT_LD;      // (wide: the batch is a k_solve_big batch — its scratch)
   const double *E = retry_pass ? d.Er + (size_t)w * (NV * NV + NV) : d.E + (size_t)w * NV * NV;
   const double *eg = retry_pass ? E + NV * NV : d.eg + (size_t)w * NV;
   // ---- level 1 of the kernel's global loads: everything whose address needs nothing but the window index is requested HERE, before
@@ -1361,6 +1377,7 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
     }
     else if (lane >= 44 && lane - 44 < ds.n_plane) l_term = d.plane_part[((size_t)w * MAX_PLANE + lane - 44) * PLANE_PART + PLANE_PART - 2];
     else if (lane == 58 && ds.use_anchor) l_term = d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - 2];
+    else if (WIDE && lane == 59 && ds.gnss_factors) l_term = d.gnss_cost[(size_t)w * 2];      // (k_solve_big's order: visual, inertial, wheel, prior, plane, anchor, GNSS)
   }
   // LDS carve-up: dense tiles | chain diagonal blocks (A_k -> W_k) | chain couplings (C_k -> Yc_k -> G_k) | zero / dump slot | two-block ring of Yr
   double *tiles = smem;
@@ -1380,31 +1397,31 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
     const bool on = act_t && !dim_in_chain(t);
     const unsigned long long m = __ballot(on);
     const unsigned long long mc = __ballot(act_t && dim_in_chain(t));
-    if (t < 192 && lane == 0) wcount[wave] = __popcll(m);
+    if (t < 64 * PW && lane == 0) wcount[wave] = __popcll(m);
     if (t == 0) { s_nch = 0; s_mask0 = m; }
     if (t < ND && dim_in_chain(t)) chact[t - T_SB(0)] = act_t ? 1 : 0;
     __syncthreads();
-    if (t < 192) {
+    if (t < 64 * PW) {
       int base = 0;
       for (int q = 0; q < wave; q++) base += wcount[q];
       if (on) perm[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
       if (lane == 0 && mc) atomicAdd(&s_nch, __popcll(mc));
     }
-    const int nact = wcount[0] + wcount[1] + wcount[2];
+    const int nact = WIDE ? wcount[0] + wcount[1] + wcount[2] + wcount[3] : wcount[0] + wcount[1] + wcount[2];
     for (int a = nact + t; a < ND + TB; a += blockDim.x) perm[a] = -1;
     // lo_k: first dense column the wide row of block k can reach — the poses of frames >= k - 1 (pose dims are 0..65: wave 0's mask)
     if (t <= CH_NC) s_lo[t] = (t >= 2 && t < CH_NC) ? __popcll(s_mask0 & ((1ull << (6 * (t - 1))) - 1ull)) : 0;
   }
   __syncthreads();        // (perm is complete: the build's entries can be requested)
-  const int n = __builtin_amdgcn_readfirstlane(wcount[0] + wcount[1] + wcount[2]);      // dense dims (wave-uniform: kept in scalar registers)
+  const int n = __builtin_amdgcn_readfirstlane(WIDE ? wcount[0] + wcount[1] + wcount[2] + wcount[3] : wcount[0] + wcount[1] + wcount[2]);      // dense dims (wave-uniform: kept in scalar registers)
   const int na = n + 1;                 // + the right-hand side row / column
   const int nt = (na + TB - 1) / TB;
   const int ntile_all = nt * (nt + 1) / 2;
   // ---- level 2: the entries of H and E the build needs (through perm), the chain blocks, the parameter blocks of |x|^2 — all in flight
   // while the per-dim quantities below are formed from level 1
   constexpr int NQ = (2 * CH_NC + 2) / 3;
-  int ar[S2_MAX_NT], bc[S2_MAX_NT];
-  double hv[S2_MAX_TILES], ev[S2_MAX_TILES], hc[NQ];
+  int ar[MAXNT], bc[MAXNT];
+  double hv[MAXTILES], ev[MAXTILES], hc[NQ];
   auto chain_partner = [](int k) -> int { return TW ? (k > CH_MID ? k - 1 : (k < CH_MID ? k + 1 : k)) : (k > 0 ? k - 1 : 0); };
   // (every array entry is defined by every thread — zero first, the loads inside wave-uniform branches)
   {
@@ -1412,16 +1429,16 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
     const int r = (tt >> 4) & 15, cc = tt & 15;
     const int nm1 = max(n - 1, 0);
 #pragma unroll
-    for (int I = 0; I < S2_MAX_NT; I++) { ar[I] = max((int)perm[min(I * TB + r, nm1)], 0); bc[I] = max((int)perm[min(I * TB + cc, nm1)], 0); }
+    for (int I = 0; I < MAXNT; I++) { ar[I] = max((int)perm[min(I * TB + r, nm1)], 0); bc[I] = max((int)perm[min(I * TB + cc, nm1)], 0); }
 #pragma unroll
-    for (int te = 0; te < S2_MAX_TILES; te++) { hv[te] = 0.0; ev[te] = 0.0; }
+    for (int te = 0; te < MAXTILES; te++) { hv[te] = 0.0; ev[te] = 0.0; }
 #pragma unroll
     for (int q = 0; q < NQ; q++) hc[q] = 0.0;
     if (wv < TB * TB / 64) {      // the dense tiles' threads
       // (through clamped indices, selected afterwards: straight-line code, every load in flight at once)
       int I = 0, J = 0;
 #pragma unroll
-      for (int te = 0; te < S2_MAX_TILES; te++) {
+      for (int te = 0; te < MAXTILES; te++) {
         if (te < ntile_all) {                                   // (wave-uniform)
           const int hi = max(ar[I], bc[J]), lo = min(ar[I], bc[J]);
           hv[te] = H[(size_t)hi * ND + lo];
@@ -1504,16 +1521,16 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
     {
       if (t < TB * TB) {
         const int r = t >> 4, cc = t & 15;
-        double sa[S2_MAX_NT], va[S2_MAX_NT], sb[S2_MAX_NT], vb[S2_MAX_NT], dd[S2_MAX_NT];
+        double sa[MAXNT], va[MAXNT], sb[MAXNT], vb[MAXNT], dd[MAXNT];
 #pragma unroll
-        for (int I = 0; I < S2_MAX_NT; I++) { sa[I] = sS[ar[I]]; va[I] = vS[ar[I]]; sb[I] = sS[bc[I]]; vb[I] = vS[bc[I]]; dd[I] = dS[ar[I]]; }
+        for (int I = 0; I < MAXNT; I++) { sa[I] = sS[ar[I]]; va[I] = vS[ar[I]]; sb[I] = sS[bc[I]]; vb[I] = vS[bc[I]]; dd[I] = dS[ar[I]]; }
 #if GFBE_CHAIN_STAMP
         if (t == 0) stamp[8] = (double)wall_clock64();
 #endif
         {
           int I = 0, J = 0;
 #pragma unroll
-          for (int te = 0; te < S2_MAX_TILES; te++) {
+          for (int te = 0; te < MAXTILES; te++) {
             if (te < ntile_all) {
               const int a = ar[I], b = bc[J];
               double v = (hv[te] - ((a < NV && b < NV) ? ev[te] : 0.0)) * (sa[I] * sb[J]);
@@ -1573,11 +1590,11 @@ __device__ __forceinline__ void solve_chain_body(const BatchDev &d, int retry_pa
       //      register allocation; every role passes the same CH_NC + 2 barriers):
       //   step s: wave 0 factorises block NC-1-s | waves 1..3 form Yr of block NC-s and add Yr^T Yr of block NC+1-s
 if (!TW) {
-        if (wave == 0) chain_role<0, 0>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
+        if (wave == 0) chain_role<0, 0, WIDE ? 1 : 0>((lds_double *)Ach, (lds_double *)Cch, (lds_double *)Amid, (lds_int *)&flag, lane, stamp);
         else
-          vsv += wide_role((lds_double *)tiles, (lds_double *)Ach, (lds_double *)Cch, (lds_double *)ring, (lds_double *)zslot, (const lds_double *)sS,
+          vsv += wide_role<MAXNT>((lds_double *)tiles, (lds_double *)Ach, (lds_double *)Cch, (lds_double *)ring, (lds_double *)zslot, (const lds_double *)sS,
                            (const lds_double *)vS, (const lds_double *)rS, (const lds_short *)perm, (const lds_int *)s_lo, (lds_double *)&s_zzc[0],
-                           (const glb_double *)H, (glb_double *)gYT, n, nt, chain_ring_ld(d.solve_ntile), wave - 1, lane, stamp);
+                           (const glb_double *)H, (glb_double *)gYT, n, nt, WIDE ? (int)CHAIN_RING_LD_WIDE : chain_ring_ld(d.solve_ntile), wave - 1, lane, stamp);
       } else {
         // waves 0, 1: the chain roles of the two segments; 2..4: segment 0's wide waves; 5..7: segment 1's
 #define WIDE_ARGS(seg) (lds_double *)Ach, (lds_double *)Cch, (lds_double *)Yall, (lds_double *)zslot, (const lds_double *)sS, (const lds_double *)vS, \
@@ -1593,7 +1610,7 @@ if (!TW) {
     }
     __syncthreads();      // (the thread's share of v^T S v is summed with |z|^2 below: one reduction instead of two on this path)
     STAMP(15);
-    chol_factor_all<NWAVES>((lds_double *)tiles, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
+    chol_factor_all<NWAVES, WIDE ? 1 : 0>((lds_double *)tiles, nt, n, t, (lds_double *)zlast, (lds_int *)&flag, stamp);
     bool ok = (flag == 0);
     if (d.test_fail_chol_iter > 0 && c.iter + 1 == d.test_fail_chol_iter && (d.sharded ? retry_pass : att) < max(d.opt.test_fail_chol_count, 1)) ok = false;
     STAMP(3);
@@ -1728,19 +1745,19 @@ if (!TW) {
       if (tt < TB * TB) {
         const int r = tt >> 4, cc = tt & 15;
         const int nm1 = max(n - 1, 0);
-        int ar[S2_MAX_NT], bc[S2_MAX_NT];
-        double sa[S2_MAX_NT], va[S2_MAX_NT], sb[S2_MAX_NT], vb[S2_MAX_NT], dd[S2_MAX_NT];
+        int ar[MAXNT], bc[MAXNT];
+        double sa[MAXNT], va[MAXNT], sb[MAXNT], vb[MAXNT], dd[MAXNT];
 #pragma unroll
-        for (int I = 0; I < S2_MAX_NT; I++) {
+        for (int I = 0; I < MAXNT; I++) {
           ar[I] = max((int)perm[min(I * TB + r, nm1)], 0); bc[I] = max((int)perm[min(I * TB + cc, nm1)], 0);
           sa[I] = sS[ar[I]]; va[I] = vS[ar[I]]; sb[I] = sS[bc[I]]; vb[I] = vS[bc[I]]; dd[I] = dS[ar[I]];
         }
         // (loads unconditional, through clamped indices, selected afterwards: straight-line code, every load in flight at once)
-        double hv[S2_MAX_TILES], ev[S2_MAX_TILES];
+        double hv[MAXTILES], ev[MAXTILES];
         {
           int I = 0, J = 0;
 #pragma unroll
-          for (int te = 0; te < S2_MAX_TILES; te++) {
+          for (int te = 0; te < MAXTILES; te++) {
             hv[te] = 0.0; ev[te] = 0.0;
             if (te < ntile_all) {                                   // (wave-uniform)
               const int hi = max(ar[I], bc[J]), lo = min(ar[I], bc[J]);
@@ -1756,7 +1773,7 @@ if (!TW) {
         {
           int I = 0, J = 0;
 #pragma unroll
-          for (int te = 0; te < S2_MAX_TILES; te++) {
+          for (int te = 0; te < MAXTILES; te++) {
             if (te < ntile_all) {
               const int a = ar[I], b = bc[J];
               double v = (hv[te] - ((a < NV && b < NV) ? ev[te] : 0.0)) * (sa[I] * sb[J]);
@@ -1864,6 +1881,9 @@ if (!TW) {
 #endif
 __global__ __launch_bounds__(S2_THREADS, GFBE_CHAIN_MINBLOCKS) void k_solve_chain(BatchDev d, int retry_pass) { solve_chain_body<0>(d, retry_pass); }
 __global__ __launch_bounds__(2 * S2_THREADS, 2) void k_solve_chain_tw(BatchDev d, int retry_pass) { solve_chain_body<1>(d, retry_pass); }
+// (round 6) a batch with GNSS dims on the chain kernel: nine tile columns of dense dims (<= 142 + the right-hand side), 45 tiles + ring +
+// chain blocks = 138 KB of dynamic LDS — one workgroup per CU, its four waves with the whole register file
+__global__ __launch_bounds__(S2_THREADS, 1) void k_solve_chain_wide(BatchDev d, int retry_pass) { solve_chain_body<0, S2_WIDE_NT>(d, retry_pass); }
 
 
 
@@ -2235,7 +2255,7 @@ static_assert(((NC + 1 + TB - 1) / TB) * (((NC + 1 + TB - 1) / TB) + 1) / 2 * TB
               + 128 /* alignment padding */ <= 160 * 1024, "k_solve: tiles + static LDS exceed a CU's 160 KB");
 static size_t solve_smem_bytes() { const int nt = (NC + 1 + TB - 1) / TB;   /* (k_solve never sees the GNSS dims: those batches take k_solve_big) */ return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
 static size_t chain_smem_bytes(int ntile, bool tw = false) {     // tw: k_solve_chain_tw — every row of Yr instead of the two-block ring, and the middle block's second downdate
-  return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + (tw ? (size_t)YALL_ROWS * YALL_LD + CH_BLK : (size_t)2 * RING_ROWS * chain_ring_ld(ntile)));
+  return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + (tw ? (size_t)YALL_ROWS * YALL_LD + CH_BLK : (size_t)2 * RING_ROWS * (ntile > S2_MAX_TILES ? (int)CHAIN_RING_LD_WIDE : chain_ring_ld(ntile))));
 }
 bool solve_chain_tw_fits(int ntile) { return ntile <= 15; }      // (six tile columns — a free camera extrinsic — would need 169 KB of LDS: those windows keep k_solve_chain)
 size_t solve_chain_scratch_doubles() { return (size_t)GYT_COLS * GYT_LD; }
@@ -2255,10 +2275,16 @@ hipError_t kernels_init_device() {
   if (e2 != hipSuccess) return e2;
   const hipError_t e3 = hipFuncSetAttribute((const void *)k_solve_chain_tw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(15, true));
   if (e3 != hipSuccess) return e3;
+  const hipError_t e4 = hipFuncSetAttribute((const void *)k_solve_chain_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_WIDE_TILES));
+  if (e4 != hipSuccess) return e4;
   return hipFuncSetAttribute((const void *)k_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_smem_bytes());
 }
+// a batch with GNSS dims takes the chain kernel when every window's dense part fits nine tile columns (column 143 of the transposed Yr rows
+// is the dump column: n + 1 <= 143) — else k_solve_big
+bool solve_chain_wide_fits(int n_dense_max) { return GFBE_SOLVE_WIDE && n_dense_max + 1 <= TB * S2_WIDE_NT - 1; }
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass) {
-  if (d.solve_big) hipLaunchKernelGGL(k_solve_big, dim3(d.B), dim3(BIG_THREADS), big_smem_bytes(), s, d, retry_pass);
+  if (d.solve_big && d.solve_wide) hipLaunchKernelGGL(k_solve_chain_wide, dim3(d.B), dim3(S2_THREADS), chain_smem_bytes(S2_WIDE_TILES), s, d, retry_pass);
+  else if (d.solve_big) hipLaunchKernelGGL(k_solve_big, dim3(d.B), dim3(BIG_THREADS), big_smem_bytes(), s, d, retry_pass);
   else if (d.solve_mono) hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d, retry_pass);
   else if (d.solve_tw) hipLaunchKernelGGL(k_solve_chain_tw, dim3(d.B), dim3(2 * S2_THREADS), chain_smem_bytes(d.solve_ntile, true), s, d, retry_pass);
   else hipLaunchKernelGGL(k_solve_chain, dim3(d.B), dim3(S2_THREADS), chain_smem_bytes(d.solve_ntile), s, d, retry_pass);
