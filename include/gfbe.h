@@ -278,7 +278,11 @@ typedef struct gfbe_options {
    *                (eight waves, one workgroup per CU: 6 sequential block steps instead of 11), larger ones from one end (four waves, two
    *                workgroups per CU: throughput). Same step to rounding.
    *   1            one blocked factorisation of the whole reduced system (160 KB of LDS). Same step to rounding.
-   *   2 / 3        (tests, measurements) the one-ended / the two-ended chain kernel whatever the batch size. */
+   *   2 / 3        (tests, measurements) the one-ended / the two-ended chain kernel whatever the batch size.
+   * A batch with GNSS blocks (gfbe_window.gnss_enable; 246 tangent dims instead of 187) takes the one-ended chain kernel with the
+   * 58 GNSS dims as dense columns when every window's dense part fits nine 16-wide tile columns (<= 142 dims), and the blocked
+   * out-of-LDS factorisation of rounds 3-5 otherwise;
+   *   4            (tests, measurements) that blocked factorisation for every batch with GNSS blocks. Same step to rounding. */
   int32_t solve_kernel;
   /* TEST HOOK (0 = off, the default; never set it in production): the first factorisation of trust-region iteration
    * `test_fail_chol_iter` is declared failed, so that DoglegStrategy's mu retry — which well-posed windows never take —

@@ -176,3 +176,70 @@ def test_throughput_batch_with_priors_beyond_the_lds_staging_limit(be, oracle):
     staged = be.solve_batch([plain] * 32, abi.MARGIN_OLD)[5]
     np.testing.assert_allclose(staged["summary"]["cost_history"], alone[1]["summary"]["cost_history"], rtol=1e-7)
     assert np.abs(staged["state"]["pose"] - alone[1]["state"]["pose"]).max() < 1e-8
+
+
+def _kernel_backend(kernel, iters=8):
+    o = abi.default_options()
+    o.solve_kernel, o.max_num_iterations = kernel, iters
+    return gf.Backend(device=0, options=o)
+
+
+def test_chain_kernel_with_gnss_columns_against_the_blocked_factorisation(oracle):
+    """Round 6: a batch with GNSS blocks takes k_solve_chain_wide (the speed-bias chain eliminated first, the 58 GNSS dims as dense
+    columns: gfbe_options.solve_kernel = 0) where rounds 3-5 took the blocked out-of-LDS factorisation k_solve_big (solve_kernel = 4).
+    Same Gauss-Newton step entry by entry after ONE iteration, the same Cauchy direction bit for bit (same scaling, same gradient), and
+    whole solves with the same accept / reject sequence — alone, and as windows of a throughput batch next to a window without GNSS."""
+    cases = [gw.gnss_window(seed=81, L=150, n_per_frame=8)[2], gw.gnss_window(seed=85, L=150, n_per_frame=3, anchor=True)[2]]
+    scn, tru, snap = gw.gnss_window(seed=81, L=120, n_per_frame=6)
+    cases.append(gw.next_gnss_window(scn, tru, oracle.solve(snap, abi.MARGIN_OLD), seed=81))      # (carries the ~95-dim prior with GNSS blocks)
+    for snap in cases:
+        ys = []
+        for kernel in (4, 0):
+            be = _kernel_backend(kernel, iters=1)
+            b = be.batch_upload([snap])
+            b.solve(abi.MARGIN_NONE)
+            ys.append((b.debug_vector(0), b.debug_vector(1), b.download()[0]["summary"]))
+            b.free()
+            be.close()
+        (y1, v1, s1), (y0, v0, s0) = ys
+        assert np.abs(y1).max() > 0.0 and np.abs(y1[abi.DENSE_DIM - 58:]).max() > 0.0      # (the GNSS dims take part in the step)
+        assert np.array_equal(v0, v1)
+        assert np.abs(y0 - y1).max() < 1e-7 * max(np.abs(y1).max(), 1.0), (np.abs(y0 - y1).max(), np.abs(y1).max())
+        assert s0["accepted"] == s1["accepted"] and abs(s0["final_cost"] - s1["final_cost"]) < 1e-7 * s1["final_cost"]
+    big, wide = _kernel_backend(4), _kernel_backend(0)
+    plain = synth.Scenario(seed=96, n_landmarks=120, use_wheel=True).window(0)
+    for snap in cases:
+        want, a = check_solve(big, oracle, snap, abi.MARGIN_OLD, loose=GNSS_LOOSE)
+        _, b = check_solve(wide, oracle, snap, abi.MARGIN_OLD, loose=GNSS_LOOSE)
+        assert a["summary"]["accepted"] == b["summary"]["accepted"] and a["summary"]["termination"] == b["summary"]["termination"]
+        assert abs(a["summary"]["final_cost"] - b["summary"]["final_cost"]) < 1e-8 * a["summary"]["final_cost"]
+        check_gnss_state(a, b)
+    batch = [cases[i % 3] if i % 4 else plain for i in range(36)]
+    ra, rb = big.solve_batch(batch, abi.MARGIN_OLD), wide.solve_batch(batch, abi.MARGIN_OLD)
+    for a, b in zip(ra, rb):
+        assert a["summary"]["accepted"] == b["summary"]["accepted"] and a["summary"]["iterations"] == b["summary"]["iterations"]
+        np.testing.assert_allclose(b["summary"]["cost_history"], a["summary"]["cost_history"], rtol=1e-7)
+        assert np.abs(a["state"]["pose"] - b["state"]["pose"]).max() < 1e-8
+    big.close(); wide.close()
+
+
+def test_gnss_windows_at_and_beyond_nine_tile_columns_of_dense_dims(be, oracle):
+    """Every optional block free (camera and wheel extrinsics, the wheel intrinsics, both time offsets) on top of the GNSS blocks: 141
+    dense dims + the right-hand side — the last column but one of k_solve_chain_wide's nine tile columns. With the plane blocks on top
+    (PlaneFactor on every pose: + 4 dims) the dense part no longer fits and the batch keeps the blocked factorisation — the structure
+    check of the upload (gfbe_host.cpp: solve_chain_wide_fits). Both against the oracle like any window (the window with everything free
+    stops before it has settled: the multiple of tests/test_gpu_branches.py::test_all_blocks_free_with_subset_masks)."""
+    from test_gpu_branches import all_free
+    _, _, snap = gw.gnss_window(seed=81, L=150, n_per_frame=8)
+    free = all_free(snap, masks=False)
+    want, got = check_solve(be, oracle, free, abi.MARGIN_OLD, loose=100.0 * GNSS_LOOSE)
+    check_gnss_state(want, got, loose=100.0)
+    rng = np.random.default_rng(5)
+    q = synth.so3_exp(rng.normal(0, 0.01, 3))
+    q[2] = 0.0
+    plane = dict(free)
+    plane["plane_R"] = q / np.linalg.norm(q)
+    plane["plane_Z"] = -float(plane["ex_pose_wheel"][2]) + 0.02
+    plane["plane"] = dict(noise_inv=[100.0, 100.0, 50.0], const=0)
+    want, got = check_solve(be, oracle, plane, abi.MARGIN_OLD, loose=100.0 * GNSS_LOOSE)
+    check_gnss_state(want, got, loose=100.0)
