@@ -2254,6 +2254,9 @@ static_assert(((NC + 1 + TB - 1) / TB) * (((NC + 1 + TB - 1) / TB) + 1) / 2 * TB
               + sizeof(short) * (NC + TB) + sizeof(double) * (16 + 2 * NC + TB + 2 + TB) + sizeof(int) * 6      // perm, red, ys, s_zz, s_vSv, zlast, flags
               + 128 /* alignment padding */ <= 160 * 1024, "k_solve: tiles + static LDS exceed a CU's 160 KB");
 static size_t solve_smem_bytes() { const int nt = (NC + 1 + TB - 1) / TB;   /* (k_solve never sees the GNSS dims: those batches take k_solve_big) */ return sizeof(double) * (size_t)(nt * (nt + 1) / 2) * TB * TB; }
+#ifndef GFBE_CHAIN_LDS_PAD
+#define GFBE_CHAIN_LDS_PAD 0       // (measurement) bytes of dynamic LDS k_solve_chain asks for beyond its layout: 24576 leaves ONE workgroup per CU
+#endif
 static size_t chain_smem_bytes(int ntile, bool tw = false) {     // tw: k_solve_chain_tw — every row of Yr instead of the two-block ring, and the middle block's second downdate
   return sizeof(double) * ((size_t)ntile * TB * TB + 2 * CH_NC * CH_BLK + CH_ZERO + (tw ? (size_t)YALL_ROWS * YALL_LD + CH_BLK : (size_t)2 * RING_ROWS * (ntile > S2_MAX_TILES ? (int)CHAIN_RING_LD_WIDE : chain_ring_ld(ntile))));
 }
@@ -2271,7 +2274,7 @@ int solve_chain_tiles(const unsigned char *act) {
 hipError_t kernels_init_device() {
   const hipError_t e = hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem_bytes());
   if (e != hipSuccess) return e;
-  const hipError_t e2 = hipFuncSetAttribute((const void *)k_solve_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(S2_MAX_TILES));
+  const hipError_t e2 = hipFuncSetAttribute((const void *)k_solve_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(chain_smem_bytes(S2_MAX_TILES) + GFBE_CHAIN_LDS_PAD));
   if (e2 != hipSuccess) return e2;
   const hipError_t e3 = hipFuncSetAttribute((const void *)k_solve_chain_tw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chain_smem_bytes(15, true));
   if (e3 != hipSuccess) return e3;
@@ -2287,7 +2290,7 @@ void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass) {
   else if (d.solve_big) hipLaunchKernelGGL(k_solve_big, dim3(d.B), dim3(BIG_THREADS), big_smem_bytes(), s, d, retry_pass);
   else if (d.solve_mono) hipLaunchKernelGGL(k_solve, dim3(d.B), dim3(SOLVE_THREADS), solve_smem_bytes(), s, d, retry_pass);
   else if (d.solve_tw) hipLaunchKernelGGL(k_solve_chain_tw, dim3(d.B), dim3(2 * S2_THREADS), chain_smem_bytes(d.solve_ntile, true), s, d, retry_pass);
-  else hipLaunchKernelGGL(k_solve_chain, dim3(d.B), dim3(S2_THREADS), chain_smem_bytes(d.solve_ntile), s, d, retry_pass);
+  else hipLaunchKernelGGL(k_solve_chain, dim3(d.B), dim3(S2_THREADS), chain_smem_bytes(d.solve_ntile) + GFBE_CHAIN_LDS_PAD, s, d, retry_pass);
 }
 void launch_rebuild_E_shard(const BatchDev &d, hipStream_t s) { hipLaunchKernelGGL(k_rebuild_E_shard, dim3(d.B), dim3(1024), 0, s, d); }
 

@@ -58,6 +58,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "lmsstamp": (["-DGFBE_LMS_STAMP=1"], "off"),
     "linstamp1": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=1"], "off"),
     "lin512": (["-DGFBE_LIN_SMALL_THREADS=512"], "off"),
+    "chain1wg": (["-DGFBE_CHAIN_LDS_PAD=24576"], "off"),
     "lin1024": (["-DGFBE_LIN_SMALL_THREADS=1024"], "off"),
     "lin512ks5": (["-DGFBE_LIN_SMALL_THREADS=512", "-DGFBE_LIN_SMALL_KS=5"], "off"),
     "fuse0": (["-DGFBE_FUSE_SMALL=0"], "off"),
