@@ -2453,6 +2453,22 @@ hipError_t asm_tables_build(int **full, int **compact, int *n_compact, hipStream
   return e;
 }
 
+// entry `idx` of a double array whose base is wave-uniform: the BYTE offset formed in 32 bits, so that the load is [scalar base + 32-bit
+// vector offset] instead of a 64-bit address per lane (idx < 2^29)
+// a pointer every lane of the wave holds the same value of, moved to scalar registers (a base formed from a LOADED value — the set index
+// WinCtl::lb behind lin_view — is a vector value to the compiler, whatever its lanes hold)
+template <class T> __device__ __forceinline__ T *uniform_ptr(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+// (global address space spelled out: a pointer rebuilt from two scalar halves is a generic one to the compiler — FLAT loads)
+typedef __attribute__((address_space(1))) char asm_glb_char;
+typedef __attribute__((address_space(1))) double asm_glb_double;
+// (the byte offset behind an empty assembly statement: the combiner otherwise turns zext(select(c, x, 0)) into a 64-bit select and the
+//  [scalar base + 32-bit offset] form is lost again)
+__device__ __forceinline__ double ld_u32(const double *base, unsigned idx) { unsigned bo = idx << 3; asm("" : "+v"(bo)); return *(const asm_glb_double *)((const asm_glb_char *)base + bo); }
+__device__ __forceinline__ void st_u32(double *base, unsigned idx, double v) { unsigned bo = idx << 3; asm("" : "+v"(bo)); *(asm_glb_double *)((asm_glb_char *)base + bo) = v; }
 __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab &tb, const double *Z, int w, int a) {
   const int fa = dim_frame(a);
   const double *p[2] = {Z, Z};
@@ -2474,12 +2490,46 @@ __device__ __forceinline__ double gather_g_dense(const BatchDev &d, const AsmTab
   if (tb.n_plane > 0 || tb.use_anchor) s += plane_anchor_term(d, w, tb.n_plane, tb.use_anchor, a, -1);
   return s;
 }
+// gather_g_dense for throughput batches (k_visasm, end of round 6): the same terms added in the same order, every table lookup and every
+// load unconditional at a clamped index / offset 0, the VALUE selected (see asm_H_tp)
+__device__ __forceinline__ double gather_g_dense_tp(const BatchDev &d, const AsmTab &tb, int w, int a) {
+  const double *imu_w = uniform_ptr(d.imu_part + (size_t)w * MAX_IMU * IMU_PART), *wheel_w = uniform_ptr(d.wheel_part + (size_t)w * MAX_WHEEL * WHEEL_PART);
+  const double *pg = uniform_ptr(d.prior_g + (size_t)w * (ND + 2));
+  const int fa = dim_frame(a);
+  const int q0 = tb.imu_of_frame[max(fa - 1, 0)], q1 = tb.imu_of_frame[max(fa, 0)], pm = tb.prior_map[a];
+  int qw[NF - 1];
+#pragma unroll
+  for (int i = 0; i <= NF - 2; i++) qw[i] = tb.wheel_of_frame[i];
+  const int la0 = imu_loc(a, fa - 1), la1 = imu_loc(a, fa);
+  const bool u0 = (fa >= 1) & (q0 >= 0) & (la0 >= 0), u1 = (fa >= 0) & (q1 >= 0) & (la1 >= 0);
+  const double l0 = ld_u32(imu_w, u0 ? (unsigned)(q0 * IMU_PART + 900 + la0) : 0u), l1 = ld_u32(imu_w, u1 ? (unsigned)(q1 * IMU_PART + 900 + la1) : 0u);
+  const bool wsel = tb.n_wheel > 0 && (a < 66 || a >= T_EXW);
+  const int i0 = (a < 66) ? fa - 1 : 0, i1 = (a < 66) ? fa : NF - 2;
+  bool wu[NF - 1];
+  double wl[NF - 1];
+#pragma unroll
+  for (int i = 0; i <= NF - 2; i++) {
+    const int la = wheel_loc(a, i);
+    wu[i] = wsel & (i >= i0) & (i <= i1) & (qw[i] >= 0) & (la >= 0);
+    wl[i] = ld_u32(wheel_w, wu[i] ? (unsigned)(qw[i] * WHEEL_PART + 484 + la) : 0u);
+  }
+  const bool up = tb.prior_n > 0 && pm >= 0;
+  const double pl = ld_u32(pg, up ? (unsigned)pm : 0u);
+  double s = (u0 ? l0 : 0.0) + (u1 ? l1 : 0.0);
+  double sw = s;
+#pragma unroll
+  for (int i = 0; i <= NF - 2; i++) sw += wu[i] ? wl[i] : 0.0;
+  s = wsel ? sw : s;               // (gather_g_dense skips the loop for the dims no wheel factor reaches: their sum keeps its bits, a -0.0 included)
+  s = up ? s + pl : s;
+  if (tb.n_plane > 0 || tb.use_anchor) s += plane_anchor_term(d, w, tb.n_plane, tb.use_anchor, a, -1);
+  return s;
+}
 // E(a,b), a <= b < NVP (b = 73: the gradient column): the Schur partials of the start-frame groups that reach dim a (a group
 // reaches the dims from its first start frame's pose on), loads unconditional in flight
 __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z, int w, int a, int b) {
   // compact panels (schur_body): in the partial of a group whose first start frame is s, dim x sits in column 1 + x - 6 s and the
   // gradient in column 0; entry (r, c), r <= c, of the panel product at tile pair (r >> 4, c >> 4) = slot J (J + 1) / 2 + I
-  const double *sp = d.schur_part + (size_t)w * d.schur_groups * SCHUR_STRIDE;
+  const double *sp = uniform_ptr(d.schur_part + (size_t)w * d.schur_groups * SCHUR_STRIDE);
   auto off_of = [&](int s) {
     if (!GFBE_SCHUR_COMPACT) return schur_pair(a >> 4, b >> 4) * 256 + (a & 15) * 16 + (b & 15);      // (diagnostics: the absolute layout of rounds 1-3)
     const int ca = 1 + a - 6 * s, r = b == NV ? 0 : ca, cc = b == NV ? ca : 1 + b - 6 * s;
@@ -2492,7 +2542,9 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
 #pragma unroll
     for (int f = 0; f < SCHUR_GROUPS; f++) {
       const int s = schur_group_first(f, SCHUR_GROUPS);
-      v[f] = *(6 * s <= a ? sp + (size_t)f * SCHUR_STRIDE + off_of(s) : Z);
+      const bool use = 6 * s <= a;
+      const double ld = ld_u32(sp, use ? (unsigned)(f * SCHUR_STRIDE + off_of(s)) : 0u);      // (scalar base + 32-bit offset; the value is selected, not the pointer)
+      v[f] = use ? ld : 0.0;
     }
     double sum = 0.0;
 #pragma unroll
@@ -2502,7 +2554,7 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
   if (ng == NF) {
     double v[NF];
 #pragma unroll
-    for (int f = 0; f < NF; f++) v[f] = *(6 * f <= a ? sp + (size_t)f * SCHUR_STRIDE + off_of(f) : Z);
+    for (int f = 0; f < NF; f++) { const bool use = 6 * f <= a; const double ld = ld_u32(sp, use ? (unsigned)(f * SCHUR_STRIDE + off_of(f)) : 0u); v[f] = use ? ld : 0.0; }
     double sum = 0.0;
 #pragma unroll
     for (int f = 0; f < NF; f++) sum += v[f];
@@ -2510,7 +2562,7 @@ __device__ __forceinline__ double gather_E11(const BatchDev &d, const double *Z,
   }
   double v[2 * NF];           // small batches: two partials per start frame
 #pragma unroll
-  for (int f = 0; f < 2 * NF; f++) v[f] = *(6 * (f >> 1) <= a ? sp + (size_t)f * SCHUR_STRIDE + off_of(f >> 1) : Z);
+  for (int f = 0; f < 2 * NF; f++) { const bool use = 6 * (f >> 1) <= a; const double ld = ld_u32(sp, use ? (unsigned)(f * SCHUR_STRIDE + off_of(f >> 1)) : 0u); v[f] = use ? ld : 0.0; }
   double sum = 0.0;
 #pragma unroll
   for (int f = 0; f < 2 * NF; f++) sum += v[f];
@@ -2881,6 +2933,11 @@ __global__ __launch_bounds__(VB_GROUP) void k_schur_visblock_small(BatchDev d0) 
 #ifndef ASM_THREADS
 #define ASM_THREADS 256
 #endif
+#ifndef GFBE_ASM_TP
+#define GFBE_ASM_TP 13     // k_visasm (end of round 6; every output keeps its bits): 1 = the entries of H by asm_H_tp, 2 = E by asm_E_tp (measured: no gain),
+                           // 4 = the descriptor tables requested before the visual block is gathered, 8 = the gradient's dense terms by gather_g_dense_tp
+                           // (k_assemble's as well); 0 = rounds 4-6
+#endif
 // The assembly of window w by the threads gt, gt + gn, ... of its workgroup(s). vis_w: the visual block [73][74] (vis_H in global
 // memory, or the LDS array k_visasm built it in — a generic pointer either way); tb: an LDS table of the calling kernel.
 struct AsmCommon {
@@ -2896,6 +2953,23 @@ __device__ __forceinline__ void asm_stage_tables(const BatchDev &d, const int w,
   for (int a = t; a < ND; a += blockDim.x) { tb.prior_map[a] = ds.prior_map[a]; tb.act[a] = ds.act[a]; }
   if (t < NF) { tb.imu_of_frame[t] = ds.imu_of_frame[t]; tb.wheel_of_frame[t] = ds.wheel_of_frame[t]; }
   if (t == 0) { tb.prior_n = ds.prior_n; tb.n_wheel = ds.n_wheel; tb.n_plane = ds.n_plane; tb.use_anchor = ds.use_anchor; }
+}
+// The same staging in two halves (k_visasm, end of round 6): the descriptor entries are REQUESTED before the visual block is gathered and
+// written to the LDS tables behind it — their round trip (3.6 us under load, tools/diag_scripts/schur_tile_time.py) rides with the gather's.
+struct AsmStagePre { int pm, imuf, wheelf, prior_n, n_wheel, n_plane, use_anchor; unsigned char act; };
+__device__ __forceinline__ AsmStagePre asm_stage_load(const BatchDev &d, const int w) {
+  const WinDesc &ds = d.desc[w];
+  const int t = threadIdx.x, ta = min(t, ND - 1), tf = min(t, NF - 1);
+  AsmStagePre p;
+  p.pm = ds.prior_map[ta]; p.act = ds.act[ta]; p.imuf = ds.imu_of_frame[tf]; p.wheelf = ds.wheel_of_frame[tf];
+  p.prior_n = ds.prior_n; p.n_wheel = ds.n_wheel; p.n_plane = ds.n_plane; p.use_anchor = ds.use_anchor;
+  return p;
+}
+__device__ __forceinline__ void asm_stage_store(AsmTab &tb, const AsmStagePre &p) {     // (a workgroup of >= ND threads; the caller's block barrier follows)
+  const int t = threadIdx.x;
+  if (t < ND) { tb.prior_map[t] = p.pm; tb.act[t] = p.act; }
+  if (t < NF) { tb.imu_of_frame[t] = p.imuf; tb.wheel_of_frame[t] = p.wheelf; }
+  if (t == 0) { tb.prior_n = p.prior_n; tb.n_wheel = p.n_wheel; tb.n_plane = p.n_plane; tb.use_anchor = p.use_anchor; }
 }
 __device__ __forceinline__ AsmCommon asm_common(const BatchDev &d, const int w) {
   const WinDesc &ds = d.desc[w];
@@ -3007,6 +3081,85 @@ __device__ __forceinline__ void asm_H(const BatchDev &d, const int w, const doub
     }
   }
 }
+// Throughput batches (k_visasm; end of round 6): the sums of asm_H<U, false> — the same terms in the same order, bit for bit — written
+// without a branch per contributor. asm_H's `cond ? tb.x[i] : -1` and `on = x >= 0 && tb.act[a] && tb.act[b]` compile to an EXEC-masked
+// region and a wait per LDS lookup (the compiler may not read LDS at an index it cannot prove valid), its `cond ? base + off : Z` to 64-bit
+// selects and 64-bit address arithmetic per load: ~100 instructions and five dependent waits per entry. Here every lookup reads a clamped
+// index unconditionally (one wait for all of them), every load is [wave-uniform base + 32-bit offset] (offset 0 where the contributor is
+// absent) and the VALUE is selected; the visual entry is read from the caller's LDS block as LDS; the next round's table entries are
+// requested before the current round's are decoded.
+template <int U>
+__device__ __forceinline__ void asm_H_tp(const BatchDev &d, const int w, const double *vis_lds, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
+  ASM_UNPACK(cm);
+  const bool wheel_on = dense_here && tb.n_wheel > 0, prior_on = dense_here && tb.prior_n > 0;
+  const bool pa_on = (tb.n_plane > 0 || tb.use_anchor) && dense_here;
+  const int prior_n = tb.prior_n, last = ntri - 1;
+  imu_w = uniform_ptr(imu_w); wheel_w = uniform_ptr(wheel_w); prior_w = uniform_ptr(prior_w); H = uniform_ptr(H); tab = uniform_ptr(tab);
+  int4 nxt[U];
+  typedef int asm_iv4 __attribute__((ext_vector_type(4)));      // (a plain vector type: HIP's int4 is a class, not loadable through an address-space pointer)
+  typedef __attribute__((address_space(1))) asm_iv4 glb_iv4;
+  const glb_iv4 *gtab = (const glb_iv4 *)tab;
+  auto tab_at = [&](int e) __attribute__((always_inline)) { const asm_iv4 v = gtab[e]; return make_int4(v.x, v.y, v.z, v.w); };
+#pragma unroll
+  for (int u = 0; u < U; u++) nxt[u] = tab_at(min(gt + u * gn, last));
+  for (int e0 = gt; e0 < ntri; e0 += U * gn) {
+    int4 ent[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { ent[u] = nxt[u]; valid[u] = e0 + u * gn < ntri && ent[u].x >= 0; }
+#pragma unroll
+    for (int u = 0; u < U; u++) nxt[u] = tab_at(min(e0 + (U + u) * gn, last));
+    int a[U], b[U], q0[U], q1[U], r0[U], r1[U], pma[U], pmb[U];
+    unsigned char acta[U], actb[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {      // every LDS lookup of the round, unconditionally at a clamped index
+      a[u] = valid[u] ? ent[u].x & 255 : 0; b[u] = valid[u] ? (ent[u].x >> 8) & 255 : 0;
+      acta[u] = tb.act[a[u]]; actb[u] = tb.act[b[u]];
+      q0[u] = tb.imu_of_frame[min(max((ent[u].y & 15) - 1, 0), NF - 1)]; q1[u] = tb.imu_of_frame[min(max(((ent[u].y >> 16) & 15) - 1, 0), NF - 1)];
+      r0[u] = tb.wheel_of_frame[min(max((ent[u].z & 15) - 1, 0), NF - 1)]; r1[u] = tb.wheel_of_frame[min(max(((ent[u].z >> 16) & 15) - 1, 0), NF - 1)];
+      pma[u] = tb.prior_map[a[u]]; pmb[u] = tb.prior_map[b[u]];
+    }
+    bool on[U], use[U][6];
+    double ld[U][6];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int y = ent[u].y, z = ent[u].z;
+      on[u] = valid[u] & (acta[u] != 0) & (actb[u] != 0);
+      use[u][0] = on[u] & dense_here & ((y & 15) != 0) & (q0[u] >= 0);
+      use[u][1] = on[u] & dense_here & (((y >> 16) & 15) != 0) & (q1[u] >= 0);
+      use[u][2] = on[u] & wheel_on & ((z & 15) != 0) & (r0[u] >= 0);
+      use[u][3] = on[u] & wheel_on & (((z >> 16) & 15) != 0) & (r1[u] >= 0);
+      use[u][4] = on[u] & prior_on & (pma[u] >= 0) & (pmb[u] >= 0);
+      use[u][5] = on[u] & (a[u] < NV);
+      ld[u][0] = ld_u32(imu_w, use[u][0] ? (unsigned)(q0[u] * IMU_PART + ((y >> 4) & 1023)) : 0u);
+      ld[u][1] = ld_u32(imu_w, use[u][1] ? (unsigned)(q1[u] * IMU_PART + ((y >> 20) & 1023)) : 0u);
+      ld[u][2] = ld_u32(wheel_w, use[u][2] ? (unsigned)(r0[u] * WHEEL_PART + ((z >> 4) & 1023)) : 0u);
+      ld[u][3] = ld_u32(wheel_w, use[u][3] ? (unsigned)(r1[u] * WHEEL_PART + ((z >> 20) & 1023)) : 0u);
+      ld[u][4] = ld_u32(prior_w, use[u][4] ? (unsigned)(pmb[u] * prior_n + pma[u]) : 0u);      // (asm_H: pa = prior_map[b] the row, pb = prior_map[a] the column)
+      ld[u][5] = vis_lds[use[u][5] ? b[u] * V_LD + a[u] : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!valid[u]) continue;
+      double x = (use[u][0] ? ld[u][0] : 0.0) + (use[u][1] ? ld[u][1] : 0.0) + (use[u][2] ? ld[u][2] : 0.0) + (use[u][3] ? ld[u][3] : 0.0)
+               + (use[u][4] ? ld[u][4] : 0.0) + (use[u][5] ? ld[u][5] : 0.0);
+      if (b[u] >= T_EXW && a[u] <= T_TDW && on[u] && wheel_on) {
+        // wheel extrinsic / intrinsic / td_wheel block: every wheel factor contributes (10 loads in flight)
+        const int off = part_lower(wheel_loc(b[u], 0), wheel_loc(a[u], 0), 22);   // global dims: the column does not depend on the factor
+        double ws = 0.0;
+#pragma unroll
+        for (int i = 0; i <= NF - 2; i++) {
+          const int q = tb.wheel_of_frame[i];
+          const double wl = ld_u32(wheel_w, q >= 0 ? (unsigned)(q * WHEEL_PART + off) : 0u);
+          ws += q >= 0 ? wl : 0.0;
+        }
+        x += ws;
+      }
+      if (pa_on && on[u]) x += plane_anchor_term(d, w, tb.n_plane, tb.use_anchor, a[u], b[u]);
+      st_u32(H, (unsigned)(a[u] * ND + b[u]), x);   // lower triangle only (b <= a): k_solve never reads the mirror
+    }
+  }
+}
 // E (73 x 73, symmetric): entries gt, gt + gn, ... of its triangle
 __device__ __forceinline__ void asm_E(const BatchDev &d, const int w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
   ASM_UNPACK(cm);
@@ -3024,13 +3177,42 @@ __device__ __forceinline__ void asm_E(const BatchDev &d, const int w, const AsmT
     if (two) { E[a1 * NV + b1] = ev1; E[b1 * NV + a1] = ev1; }
   }
 }
+// asm_E for throughput batches, the same entries: the triangle index decoded without loops (one correction step either way is all the
+// float square root ever needs below 2^22), both activity flags read unconditionally, the stores as [scalar base + 32-bit offset]
+__device__ __forceinline__ void tri_decode_nb(int e, int &a, int &b) {
+  a = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
+  a += ((a + 1) * (a + 2) / 2 <= e) ? 1 : 0;
+  a -= (a * (a + 1) / 2 > e) ? 1 : 0;
+  b = e - a * (a + 1) / 2;   // b <= a
+}
+__device__ __forceinline__ void asm_E_tp(const BatchDev &d, const int w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
+  ASM_UNPACK(cm);
+  constexpr int NE = NV * (NV + 1) / 2;
+  double *Eu = uniform_ptr(E);
+  for (int e = gt; e < NE; e += 2 * gn) {
+    int a0, b0, a1, b1;
+    const bool two = e + gn < NE;
+    tri_decode_nb(e, a0, b0);
+    tri_decode_nb(two ? e + gn : e, a1, b1);
+    const unsigned char fa0 = tb.act[a0], fb0 = tb.act[b0], fa1 = tb.act[a1], fb1 = tb.act[b1];
+    const double g0 = gather_E11(d, Z, w, b0, a0), g1 = gather_E11(d, Z, w, b1, a1);
+    const double ev0 = ((fa0 != 0) & (fb0 != 0)) ? g0 : 0.0, ev1 = (two & (fa1 != 0) & (fb1 != 0)) ? g1 : 0.0;
+    st_u32(Eu, (unsigned)(a0 * NV + b0), ev0);
+    st_u32(Eu, (unsigned)(b0 * NV + a0), ev0);
+    if (two) { st_u32(Eu, (unsigned)(a1 * NV + b1), ev1); st_u32(Eu, (unsigned)(b1 * NV + a1), ev1); }
+  }
+}
 // g and eg: dims gt, gt + gn, ...
 __device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const double *vis_w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
   ASM_UNPACK(cm);
   for (int a = gt; a < ND; a += gn) {
     double v = 0.0;
     if (tb.act[a]) {
+#if GFBE_ASM_TP & 8
+      v = dense_here ? gather_g_dense_tp(d, tb, w, a) : 0.0;
+#else
       v = dense_here ? gather_g_dense(d, tb, Z, w, a) : 0.0;
+#endif
       if (a < NV) {
         if (!vsplit) v += vis_w[a * V_LD + NV];
         else {
@@ -3049,20 +3231,30 @@ __device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const doub
     if (a < NV) eg[a] = tb.act[a] ? gather_E11(d, Z, w, a, NV) : 0.0;
   }
 }
-__device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, const double *vis_w, AsmTab &tb, const int gt, const int gn) {
+__device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, const double *vis_w, AsmTab &tb, const int gt, const int gn, const bool staged = false) {
 #if GFBE_DIAG
   double *astamp = d.timing + (size_t)d.B * 32 + 24;
 #define ASTAMP(i) do { if (w == 0 && gt == 0) astamp[i] = (double)wall_clock64(); } while (0)
 #else
 #define ASTAMP(i) do { } while (0)
 #endif
-  asm_stage_tables(d, w, tb);
-  __syncthreads();
+  if (!staged) {      // (staged: the caller filled tb and passed its barrier)
+    asm_stage_tables(d, w, tb);
+    __syncthreads();
+  }
   ASTAMP(4);
   const AsmCommon cm = asm_common(d, w);
-  asm_H<GFBE_ASM_U, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);     // (k_visasm: throughput batches, the visual block in the caller's LDS)
+#if GFBE_ASM_TP & 1
+  asm_H_tp<GFBE_ASM_U>(d, w, vis_w, tb, cm, gt, gn);                   // (k_visasm: throughput batches, the visual block in the caller's LDS)
+#else
+  asm_H<GFBE_ASM_U, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);
+#endif
   ASTAMP(5);
+#if GFBE_ASM_TP & 2
+  asm_E_tp(d, w, tb, cm, gt, gn);
+#else
   asm_E(d, w, tb, cm, gt, gn);
+#endif
   ASTAMP(6);
   asm_g(d, w, vis_w, tb, cm, gt, gn);
   ASTAMP(7);
@@ -3110,9 +3302,18 @@ __global__ __launch_bounds__(VB_GROUP, GFBE_VISASM_WAVES) void k_visasm(BatchDev
   if (d.linschur && d.spec && threadIdx.x == 0) d.ctl[w].sw_mu[c.lb] = c.mu;
   __shared__ double V[NV * V_LD];
   __shared__ AsmTab tb;
+  static_assert(VB_GROUP >= ND, "asm_stage_store: one table entry per thread");
+#if GFBE_ASM_TP & 4
+  const AsmStagePre pre = asm_stage_load(d, w);
+  visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
+  asm_stage_store(tb, pre);
+  __syncthreads();
+  assemble_body(d, w, V, tb, threadIdx.x, VB_GROUP, true);
+#else
   visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
   __syncthreads();
   assemble_body(d, w, V, tb, threadIdx.x, VB_GROUP);
+#endif
 }
 
 // =============================================================================================

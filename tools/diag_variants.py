@@ -59,6 +59,12 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "linstamp1": (["-DGFBE_LIN_STAMP=1", "-DGFBE_LIN_STAMP_MODE=1"], "off"),
     "lin512": (["-DGFBE_LIN_SMALL_THREADS=512"], "off"),
     "chain1wg": (["-DGFBE_CHAIN_LDS_PAD=24576"], "off"),
+    "asmtp0": (["-DGFBE_ASM_TP=0"], "off"),
+    "asmtp1": (["-DGFBE_ASM_TP=1"], "off"),
+    "asmtp3": (["-DGFBE_ASM_TP=3"], "off"),
+    "asmtp5": (["-DGFBE_ASM_TP=5"], "off"),
+    "asmtp7": (["-DGFBE_ASM_TP=7"], "off"),
+    "asmtp13": (["-DGFBE_ASM_TP=13"], "off"),
     "lin1024": (["-DGFBE_LIN_SMALL_THREADS=1024"], "off"),
     "lin512ks5": (["-DGFBE_LIN_SMALL_THREADS=512", "-DGFBE_LIN_SMALL_KS=5"], "off"),
     "fuse0": (["-DGFBE_FUSE_SMALL=0"], "off"),
