@@ -3334,6 +3334,68 @@ __device__ __forceinline__ void stage_frame_steps(const BatchDev &d, const WinCt
   }
 }
 // fs: the frames' steps in the form of lm_row_dot2 (stage_frame_steps below) when the rows are compressed, else nullptr
+// lm_step_tile for a single window's launch (k_lm_step_fused, end of round 6), the compressed-row form: the same operations on every landmark in
+// the same order, the same bits — with ONE round of loads in front of everything. lm_step_tile below asks for the landmark's record, then
+// (its track length known) for its rows one observation step at a time, then for its scalars: two dependent round trips + one per step
+// (its ISA: three loads, the arithmetic, s_waitcnt vmcnt(0), the back edge). Seven other waves of a SIMD hide that in a throughput batch
+// (a ring of rows in flight there costs a wave per SIMD and gains nothing: 56.3 against 56.2 - 58.5 us per 512 windows,
+// profiles/r6_late_experiments.txt); a single window's tile has its SIMD to itself and waits every time. Here the record, D, x, the
+// scalars and the rows of the first AHEAD + 1 steps are requested together — rows past a short track's end are allocated and never used
+// (lm_hP holds MAXOBS steps per slot) — and the rows AHEAD steps ahead stay in flight while a step is multiplied.
+template <int AHEAD>
+__device__ __forceinline__ void lm_step_tile_ahead(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t, const double *fs) {
+  static_assert(AHEAD >= 1 && AHEAD < MAXOBS, "rows of the first AHEAD + 1 observation steps exist for every slot");
+  const int s0 = d.tile_start[ds.tile_off + tile];
+  const int slot = ds.lm_off + tile * LM_TILE + t;
+  const size_t TL = d.tot_lm;
+  const int info = d.lm_info[slot];
+  double Dx[6], ring[AHEAD + 1][3];
+#pragma unroll
+  for (int q = 0; q < 6; q++) Dx[q] = d.lm_hC[(size_t)q * TL + slot];
+#pragma unroll
+  for (int a = 0; a <= AHEAD; a++)
+#pragma unroll
+    for (int q = 0; q < 3; q++) ring[a][q] = d.lm_hP[((size_t)a * 6 + q) * TL + slot];
+  const double sl = d.lm_sl[slot], Hll = d.lm_Hll[slot], gl = d.lm_gl[slot], lam = d.lam[(size_t)c.cur * TL + slot], mu = c.mu;
+  const int m = (info >> 8) & 0xff;
+  const bool free_lm = ((info >> 24) & 1) && !((info >> 16) & 1) && m > 0;
+  double p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (free_lm) {
+    double hy = 0.0, hv = 0.0;
+    lm_row_dot2(fs + s0 * LM_FS, Dx, Dx + 3, hy, hv);
+    const int mlast = m - 1;
+    for (int k = 0; k < m; k++) {
+      double dk[3], oy, ov;
+#pragma unroll
+      for (int q = 0; q < 3; q++) dk[q] = ring[0][q];
+#pragma unroll
+      for (int a = 0; a < AHEAD; a++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) ring[a][q] = ring[a + 1][q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) ring[AHEAD][q] = d.lm_hP[((size_t)min(k + 1 + AHEAD, mlast) * 6 + q) * TL + slot];
+      lm_row_dot2(fs + (s0 + 1 + k) * LM_FS, dk, Dx + 3, oy, ov);
+      hy -= oy; hv -= ov;
+    }
+    const double hll = sl * sl * Hll, d2 = clamp_diag(hll), glt = sl * gl;
+    const double yl = (glt - sl * hy) / (hll + mu * d2);
+    const double vl = glt / d2;
+    d.lm_yl[slot] = yl; d.lm_vl[slot] = vl;
+    p[0] = glt * glt / d2;                                   // G2
+    p[1] = d2 * yl * yl;                                     // N2
+    p[2] = glt * yl;                                         // gy
+    p[3] = 2.0 * vl * sl * hv + hll * vl * vl;               // vHv
+    p[4] = vl * sl * hy + yl * sl * hv + hll * vl * yl;      // vHy
+    p[5] = 2.0 * yl * sl * hy + hll * yl * yl;               // yHy
+    p[6] = fabs(gl);                                         // gradient max-norm share
+    p[7] = lam * lam;                                        // |x|^2 share
+  }
+  double *out = d.tile_gram + ((size_t)w * d.max_tiles + tile) * 8;
+  for (int q = 0; q < 8; q++) {
+    const double r = (q == 6) ? wave_max(p[q]) : wave_sum(p[q]);
+    if (t == 0) out[q] = r;
+  }
+}
 __device__ __forceinline__ void lm_step_tile(const BatchDev &d, const WinDesc &ds, const WinCtl &c, const int w, const int tile, const int t,
                                              const double *sy, const double *sv, const double *fs) {
   const int s0 = d.tile_start[ds.tile_off + tile];
@@ -3745,6 +3807,9 @@ __device__ __forceinline__ void block_candidate(const BatchDev &d, const int w, 
 #pragma unroll
   for (int k = 0; k < MAXS; k++) if (k < q.gs) Y[q.am + k] = Yl[k];
 }
+#ifndef GFBE_LMS_AHEAD
+#define GFBE_LMS_AHEAD 3      // k_lm_step_fused: rows of the observation steps in flight ahead of the one being multiplied (lm_step_tile)
+#endif
 #ifndef GFBE_LMS_STAMP
 #define GFBE_LMS_STAMP 0      // diagnostics build: phase stamps of k_lm_step_fused (tools/diag_scripts/lms_stamps.py)
 #endif
@@ -3779,6 +3844,10 @@ __global__ __launch_bounds__(LM_TILE) void k_lm_step_fused(BatchDev d0) {
     const bool comp = !d.vis_full;      // (workgroup-uniform: the barrier below is safe)
     if (comp) { stage_frame_steps(d, c, w, t, sy, sv, fsteps); __syncthreads(); }
     MSTAMP_T(2);
+#if GFBE_LMS_AHEAD > 0
+    if (comp) lm_step_tile_ahead<GFBE_LMS_AHEAD>(d, ds, c, w, tile, t, fsteps);
+    else
+#endif
     lm_step_tile(d, ds, c, w, tile, t, sy, sv, comp ? fsteps : nullptr);
     MSTAMP_T(3);
   }

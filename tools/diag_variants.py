@@ -65,6 +65,8 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "asmtp5": (["-DGFBE_ASM_TP=5"], "off"),
     "asmtp7": (["-DGFBE_ASM_TP=7"], "off"),
     "asmtp13": (["-DGFBE_ASM_TP=13"], "off"),
+    "lmsstamp0": (["-DGFBE_LMS_STAMP=1", "-DGFBE_LMS_AHEAD=0"], "off"),
+    "lmsa0": (["-DGFBE_LMS_AHEAD=0"], "off"),
     "lin1024": (["-DGFBE_LIN_SMALL_THREADS=1024"], "off"),
     "lin512ks5": (["-DGFBE_LIN_SMALL_THREADS=512", "-DGFBE_LIN_SMALL_KS=5"], "off"),
     "fuse0": (["-DGFBE_FUSE_SMALL=0"], "off"),
