@@ -326,6 +326,7 @@ struct BatchDev {
   int solve_mono;             // some window's prior couples a speed-bias block other than SpeedBias[0]: the whole batch takes the monolithic k_solve
   int solve_tw;               // the chain eliminated from both ends (k_solve_chain_tw, one workgroup per CU): small batches, where a window's latency counts
   int solve_wide;             // a batch with GNSS dims (solve_big) whose windows all fit k_solve_chain_wide: the chain kernel with nine tile columns of dense dims
+  int asm_legacy;             // diagnostics build only (GFBE_ASM_LEGACY=1 at upload): the assembly's entry loops in their form of rounds 4-6 (gfbe_kernels.hip: ASM_TP_ON)
   // debug / inspection outputs (gfbe_eval_factors)
   double *dbg_imu, *dbg_wheel, *dbg_prior;  // [B][MAX_IMU][15*31], [B][MAX_WHEEL][6*23], [B][ND]
   // marginalisation

@@ -1218,6 +1218,7 @@ static gfbe_status upload_one(gfbe_ctx *c, int32_t B, const gfbe_window *const *
     // (GFBE_ASM_FULL, diagnostics build only: the full table for every batch — tests/test_gpu_solve_kernels.py compares the two entry by entry)
     const bool compact = !prior_sb && d.nu == NC && c->asm_compact_n > 0 && !diag_getenv("GFBE_ASM_FULL");
     d.asm_tab = compact ? c->asm_compact : c->asm_full;
+    d.asm_legacy = diag_getenv("GFBE_ASM_LEGACY") ? 1 : 0;      // (diagnostics build only: diag_getenv is nullptr in the product)
     d.asm_n = compact ? c->asm_compact_n : d.nu * (d.nu + 1) / 2;
   }
   const double T3 = now();

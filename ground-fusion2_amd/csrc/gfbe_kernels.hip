@@ -2938,6 +2938,13 @@ __global__ __launch_bounds__(VB_GROUP) void k_schur_visblock_small(BatchDev d0) 
                            // 4 = the descriptor tables requested before the visual block is gathered, 8 = the gradient's dense terms by gather_g_dense_tp
                            // (k_assemble's as well); 0 = rounds 4-6
 #endif
+// which form runs: the build's choice — and, in the diagnostics build, the older form on request (BatchDev::asm_legacy, GFBE_ASM_LEGACY=1 at upload:
+// tests/test_gpu_uncleared.py compares H entry by entry and every output's bits between the two)
+#if GFBE_DIAG
+#define ASM_TP_ON(d, bit) (((GFBE_ASM_TP) & (bit)) && !(d).asm_legacy)
+#else
+#define ASM_TP_ON(d, bit) (((GFBE_ASM_TP) & (bit)) != 0)
+#endif
 // The assembly of window w by the threads gt, gt + gn, ... of its workgroup(s). vis_w: the visual block [73][74] (vis_H in global
 // memory, or the LDS array k_visasm built it in — a generic pointer either way); tb: an LDS table of the calling kernel.
 struct AsmCommon {
@@ -3208,11 +3215,8 @@ __device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const doub
   for (int a = gt; a < ND; a += gn) {
     double v = 0.0;
     if (tb.act[a]) {
-#if GFBE_ASM_TP & 8
-      v = dense_here ? gather_g_dense_tp(d, tb, w, a) : 0.0;
-#else
-      v = dense_here ? gather_g_dense(d, tb, Z, w, a) : 0.0;
-#endif
+      if (ASM_TP_ON(d, 8)) v = dense_here ? gather_g_dense_tp(d, tb, w, a) : 0.0;
+      else v = dense_here ? gather_g_dense(d, tb, Z, w, a) : 0.0;
       if (a < NV) {
         if (!vsplit) v += vis_w[a * V_LD + NV];
         else {
@@ -3244,17 +3248,11 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
   }
   ASTAMP(4);
   const AsmCommon cm = asm_common(d, w);
-#if GFBE_ASM_TP & 1
-  asm_H_tp<GFBE_ASM_U>(d, w, vis_w, tb, cm, gt, gn);                   // (k_visasm: throughput batches, the visual block in the caller's LDS)
-#else
-  asm_H<GFBE_ASM_U, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);
-#endif
+  if (ASM_TP_ON(d, 1)) asm_H_tp<GFBE_ASM_U>(d, w, vis_w, tb, cm, gt, gn);      // (k_visasm: throughput batches, the visual block in the caller's LDS)
+  else asm_H<GFBE_ASM_U, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);
   ASTAMP(5);
-#if GFBE_ASM_TP & 2
-  asm_E_tp(d, w, tb, cm, gt, gn);
-#else
-  asm_E(d, w, tb, cm, gt, gn);
-#endif
+  if (ASM_TP_ON(d, 2)) asm_E_tp(d, w, tb, cm, gt, gn);
+  else asm_E(d, w, tb, cm, gt, gn);
   ASTAMP(6);
   asm_g(d, w, vis_w, tb, cm, gt, gn);
   ASTAMP(7);
@@ -3303,17 +3301,17 @@ __global__ __launch_bounds__(VB_GROUP, GFBE_VISASM_WAVES) void k_visasm(BatchDev
   __shared__ double V[NV * V_LD];
   __shared__ AsmTab tb;
   static_assert(VB_GROUP >= ND, "asm_stage_store: one table entry per thread");
-#if GFBE_ASM_TP & 4
-  const AsmStagePre pre = asm_stage_load(d, w);
-  visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
-  asm_stage_store(tb, pre);
-  __syncthreads();
-  assemble_body(d, w, V, tb, threadIdx.x, VB_GROUP, true);
-#else
-  visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
-  __syncthreads();
-  assemble_body(d, w, V, tb, threadIdx.x, VB_GROUP);
-#endif
+  if (ASM_TP_ON(d, 4)) {
+    const AsmStagePre pre = asm_stage_load(d, w);
+    visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
+    asm_stage_store(tb, pre);
+    __syncthreads();
+    assemble_body(d, w, V, tb, threadIdx.x, VB_GROUP, true);
+  } else {
+    visblock_body<false, true, true>(d, w, 0, NF - 2, 0, V);
+    __syncthreads();
+    assemble_body(d, w, V, tb, threadIdx.x, VB_GROUP);
+  }
 }
 
 // =============================================================================================

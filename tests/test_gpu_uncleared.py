@@ -116,7 +116,17 @@ def test_compact_assembly_table_equals_the_full_one_entry_by_entry():
                 assert np.count_nonzero(hf) > 1000, name
                 np.testing.assert_array_equal(hc, hf, err_msg=name)          # (the last linearisation's H: same bits, zeros where the compact table has no entry)
             assert dig_c == dig_f, name
+            # (end of round 6) the branch-free entry loops of the assembly — asm_H_tp, the early table staging, gather_g_dense_tp: GFBE_ASM_TP —
+            # against their form of rounds 4-6 (GFBE_ASM_LEGACY=1, read at upload by the diagnostics build): the same terms in the same
+            # order, so H entry by entry and every output bit for bit
+            os.environ["GFBE_ASM_LEGACY"] = "1"
+            dig_l, H_l = run(snaps)
+            os.environ.pop("GFBE_ASM_LEGACY")
+            for hc, hl in zip(H_c, H_l):
+                np.testing.assert_array_equal(hc, hl, err_msg=name + " (legacy assembly)")
+            assert dig_c == dig_l, name + " (legacy assembly)"
     finally:
         os.environ.pop("GFBE_ASM_FULL", None)
+        os.environ.pop("GFBE_ASM_LEGACY", None)
         if old is not None:
             os.environ["GFBE_ASM_FULL"] = old
