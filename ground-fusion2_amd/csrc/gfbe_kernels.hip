@@ -38,6 +38,18 @@ namespace gfd {
 #ifndef GFBE_ASM_U
 #define GFBE_ASM_U 4       // k_visasm: entries of H a thread has in flight
 #endif
+#ifndef GFBE_ASM_TP
+#define GFBE_ASM_TP 29     // k_visasm (end of round 6; every output keeps its bits): 1 = the entries of H by asm_H_tp, 2 = E by asm_E_tp (measured: no gain),
+                           // 4 = the descriptor tables requested before the visual block is gathered, 8 = the gradient's dense terms by gather_g_dense_tp
+                           // (k_assemble's as well), 16 = the gather of the visual block's partials (visblock_y); 0 = rounds 4-6
+#endif
+// which form runs: the build's choice — and, in the diagnostics build, the older form on request (BatchDev::asm_legacy, GFBE_ASM_LEGACY=1 at upload:
+// tests/test_gpu_uncleared.py compares H entry by entry and every output's bits between the two)
+#if GFBE_DIAG
+#define ASM_TP_ON(d, bit) (((GFBE_ASM_TP) & (bit)) && !(d).asm_legacy)
+#else
+#define ASM_TP_ON(d, bit) (((GFBE_ASM_TP) & (bit)) != 0)
+#endif
 #ifndef GFBE_DENSE_TP
 #define GFBE_DENSE_TP 1    // throughput batches: k_dense_tp (matrix-core whitening / J^T J, four windows per workgroup) instead of k_dense<false>
 #endif
@@ -2649,6 +2661,26 @@ __device__ __forceinline__ void visblock_y(const BatchDev &d, const WinDesc &ds,
       else { i = 0; int rem = pq; while (rem >= NF - 1 - i) { rem -= NF - 1 - i; i++; } k = rem; }
       const int t0 = s_tile_begin[i], t1 = s_tile_begin[i + 1];
       double sum = 0.0;
+      if (!ROW && staged_m && ASM_TP_ON(d, 16)) {
+        // (end of round 6, like asm_H_tp: the tiles' step counts read unconditionally at a clamped index — one wait for the four —, the
+        //  partials loaded from the window's scalar base at a 32-bit offset, offset 0 for a tile that did not run the step, and the VALUE
+        //  selected: the same sums in the same order)
+        const double *vb = uniform_ptr(vpy);
+        for (int tt = t0; tt < t1; tt += 4) {
+          int mt[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) mt[u] = s_tile_m[min(tt + u, 255)];
+          bool on[4];
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            on[u] = (tt + u < t1) & (k < mt[u]);
+            v[u] = ld_u32(vb, on[u] ? (unsigned)(((tt + u) * MAXOBS + k) * VPY_STRIDE + en) : 0u);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) sum += on[u] ? v[u] : 0.0;
+        }
+      } else
       for (int tt = t0; tt < t1; tt += 4) {          // (tiles sorted longest first: a tile ran step k iff its first track reaches it)
         double v[4];
 #pragma unroll
@@ -2932,18 +2964,6 @@ __global__ __launch_bounds__(VB_GROUP) void k_schur_visblock_small(BatchDev d0) 
 
 #ifndef ASM_THREADS
 #define ASM_THREADS 256
-#endif
-#ifndef GFBE_ASM_TP
-#define GFBE_ASM_TP 13     // k_visasm (end of round 6; every output keeps its bits): 1 = the entries of H by asm_H_tp, 2 = E by asm_E_tp (measured: no gain),
-                           // 4 = the descriptor tables requested before the visual block is gathered, 8 = the gradient's dense terms by gather_g_dense_tp
-                           // (k_assemble's as well); 0 = rounds 4-6
-#endif
-// which form runs: the build's choice — and, in the diagnostics build, the older form on request (BatchDev::asm_legacy, GFBE_ASM_LEGACY=1 at upload:
-// tests/test_gpu_uncleared.py compares H entry by entry and every output's bits between the two)
-#if GFBE_DIAG
-#define ASM_TP_ON(d, bit) (((GFBE_ASM_TP) & (bit)) && !(d).asm_legacy)
-#else
-#define ASM_TP_ON(d, bit) (((GFBE_ASM_TP) & (bit)) != 0)
 #endif
 // The assembly of window w by the threads gt, gt + gn, ... of its workgroup(s). vis_w: the visual block [73][74] (vis_H in global
 // memory, or the LDS array k_visasm built it in — a generic pointer either way); tb: an LDS table of the calling kernel.
