@@ -39,7 +39,7 @@ namespace gfd {
 #define GFBE_ASM_U 4       // k_visasm: entries of H a thread has in flight
 #endif
 #ifndef GFBE_ASM_TP
-#define GFBE_ASM_TP 29     // k_visasm (end of round 6; every output keeps its bits): 1 = the entries of H by asm_H_tp, 2 = E by asm_E_tp (measured: no gain),
+#define GFBE_ASM_TP 29     // k_visasm (end of round 6; every output keeps its bits): 1 = the entries of H by asm_H_tp,
                            // 4 = the descriptor tables requested before the visual block is gathered, 8 = the gradient's dense terms by gather_g_dense_tp
                            // (k_assemble's as well), 16 = the gather of the visual block's partials (visblock_y); 0 = rounds 4-6
 #endif
@@ -3204,31 +3204,6 @@ __device__ __forceinline__ void asm_E(const BatchDev &d, const int w, const AsmT
     if (two) { E[a1 * NV + b1] = ev1; E[b1 * NV + a1] = ev1; }
   }
 }
-// asm_E for throughput batches, the same entries: the triangle index decoded without loops (one correction step either way is all the
-// float square root ever needs below 2^22), both activity flags read unconditionally, the stores as [scalar base + 32-bit offset]
-__device__ __forceinline__ void tri_decode_nb(int e, int &a, int &b) {
-  a = (int)((sqrtf(8.0f * e + 1.0f) - 1.0f) * 0.5f);
-  a += ((a + 1) * (a + 2) / 2 <= e) ? 1 : 0;
-  a -= (a * (a + 1) / 2 > e) ? 1 : 0;
-  b = e - a * (a + 1) / 2;   // b <= a
-}
-__device__ __forceinline__ void asm_E_tp(const BatchDev &d, const int w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
-  ASM_UNPACK(cm);
-  constexpr int NE = NV * (NV + 1) / 2;
-  double *Eu = uniform_ptr(E);
-  for (int e = gt; e < NE; e += 2 * gn) {
-    int a0, b0, a1, b1;
-    const bool two = e + gn < NE;
-    tri_decode_nb(e, a0, b0);
-    tri_decode_nb(two ? e + gn : e, a1, b1);
-    const unsigned char fa0 = tb.act[a0], fb0 = tb.act[b0], fa1 = tb.act[a1], fb1 = tb.act[b1];
-    const double g0 = gather_E11(d, Z, w, b0, a0), g1 = gather_E11(d, Z, w, b1, a1);
-    const double ev0 = ((fa0 != 0) & (fb0 != 0)) ? g0 : 0.0, ev1 = (two & (fa1 != 0) & (fb1 != 0)) ? g1 : 0.0;
-    st_u32(Eu, (unsigned)(a0 * NV + b0), ev0);
-    st_u32(Eu, (unsigned)(b0 * NV + a0), ev0);
-    if (two) { st_u32(Eu, (unsigned)(a1 * NV + b1), ev1); st_u32(Eu, (unsigned)(b1 * NV + a1), ev1); }
-  }
-}
 // g and eg: dims gt, gt + gn, ...
 __device__ __forceinline__ void asm_g(const BatchDev &d, const int w, const double *vis_w, const AsmTab &tb, const AsmCommon &cm, const int gt, const int gn) {
   ASM_UNPACK(cm);
@@ -3271,8 +3246,7 @@ __device__ __forceinline__ void assemble_body(const BatchDev &d, const int w, co
   if (ASM_TP_ON(d, 1)) asm_H_tp<GFBE_ASM_U>(d, w, vis_w, tb, cm, gt, gn);      // (k_visasm: throughput batches, the visual block in the caller's LDS)
   else asm_H<GFBE_ASM_U, false>(d, w, vis_w, tb, cm, gt, gn, nullptr);
   ASTAMP(5);
-  if (ASM_TP_ON(d, 2)) asm_E_tp(d, w, tb, cm, gt, gn);
-  else asm_E(d, w, tb, cm, gt, gn);
+  asm_E(d, w, tb, cm, gt, gn);      // (E's entries the branch-free way — loop-free triangle decode, 2 / 3 / 6 entries in flight — measured: no gain, profiles/r6_late_experiments.txt)
   ASTAMP(6);
   asm_g(d, w, vis_w, tb, cm, gt, gn);
   ASTAMP(7);

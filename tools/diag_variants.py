@@ -61,9 +61,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "chain1wg": (["-DGFBE_CHAIN_LDS_PAD=24576"], "off"),
     "asmtp0": (["-DGFBE_ASM_TP=0"], "off"),
     "asmtp1": (["-DGFBE_ASM_TP=1"], "off"),
-    "asmtp3": (["-DGFBE_ASM_TP=3"], "off"),
     "asmtp5": (["-DGFBE_ASM_TP=5"], "off"),
-    "asmtp7": (["-DGFBE_ASM_TP=7"], "off"),
     "asmtp13": (["-DGFBE_ASM_TP=13"], "off"),
     "lmsstamp0": (["-DGFBE_LMS_STAMP=1", "-DGFBE_LMS_AHEAD=0"], "off"),
     "lmsa0": (["-DGFBE_LMS_AHEAD=0"], "off"),
