@@ -3702,18 +3702,6 @@ __global__ __launch_bounds__(LM_TILE) void k_candidate_dense(BatchDev d) {
 #ifndef GFBE_FUSE_STEP_CAND
 #define GFBE_FUSE_STEP_CAND 1
 #endif
-__global__ __launch_bounds__(LM_TILE) void k_step_candidate_dense(BatchDev d) {
-  GFBE_SMALL_KERNEL_PRIO();
-  const int w = blockIdx.x;
-  const WinDesc &ds = d.desc[w];
-  step_body(d, ds, d.ctl[w], d.ctl[w], w, threadIdx.x);
-  __threadfence_block();      // (one wave, one CU, one vector cache: workgroup scope — a device-scope fence writes the XCD's L2 back, measured -4 % end to end)
-  __builtin_amdgcn_wave_barrier();
-  const WinCtl &c = d.ctl[w];
-  if (c.done || !c.have_step) return;
-  __shared__ PoseRT sp_cand[NF + 1];
-  candidate_dense(d, ds, c, w, threadIdx.x, sp_cand, true);
-}
 __global__ __launch_bounds__(CAND_THREADS) void k_candidate_window(BatchDev d) {
   const int w = blockIdx.x;
   const WinDesc &ds = d.desc[w];
@@ -3798,6 +3786,65 @@ __device__ __forceinline__ void block_candidate(const BatchDev &d, const int w, 
   }
 #pragma unroll
   for (int k = 0; k < MAXS; k++) if (k < q.gs) Y[q.am + k] = Yl[k];
+}
+#ifndef GFBE_STEP_CAND_REGS
+#define GFBE_STEP_CAND_REGS 1      // k_step_candidate_dense on register copies, like the tail of k_lm_step_fused (0: step_body on WinCtl in memory + candidate_dense)
+#endif
+__global__ __launch_bounds__(LM_TILE) void k_step_candidate_dense(BatchDev d) {
+  GFBE_SMALL_KERNEL_PRIO();
+  const int w = blockIdx.x;
+  const WinDesc &ds = d.desc[w];
+#if GFBE_STEP_CAND_REGS
+  // (end of round 6) The form above walks memory one dependent access at a time: step_body reads and writes the window's trust-region
+  // scalars in WinCtl field by field, candidate_dense's loop over a block's dims loads sp / vp / yp and stores the step entry per
+  // iteration (the store may alias the next loads: load, wait, store, nine times for a speed-bias block), re-reads the candidate it has
+  // just written for |dx|^2 and |x|^2, and the pair constants read it a third time: 28 us per launch over 512 windows. Here — the tail of
+  // k_lm_step_fused, operand for operand: StepLocal, block_preload, block_candidate, pair_consts_from_staged — everything the wave needs
+  // is requested at the start in one round, the scalars live in lane 0's registers, a lane's block in its own, the poses go to the pair
+  // constants through LDS. Same operations in the same order.
+  WinCtl &c = d.ctl[w];
+  const int t = threadIdx.x;
+  __shared__ PoseRT sp_cand[NF + 1];
+  const int cur = c.cur;
+  StepLocal lc;
+  lc.done = c.done; lc.have_step = c.have_step; lc.reuse = c.reuse; lc.iter = c.iter; lc.termination = c.termination; lc.status = c.status;
+  lc.invalid_steps = c.invalid_steps;
+  lc.G2 = c.G2; lc.N2 = c.N2; lc.gy = c.gy; lc.vHv = c.vHv; lc.vHy = c.vHy; lc.yHy = c.yHy; lc.grad_max = c.grad_max; lc.x_norm = c.x_norm;
+  lc.alpha = c.alpha; lc.radius = c.radius; lc.c1 = c.c1; lc.c2 = c.c2; lc.step_norm = c.step_norm; lc.model_change = c.model_change;
+  lc.cost = c.cost; lc.mu = c.mu; lc.t_start = c.t_start;
+  const double *X = d.x + ((size_t)w * 2 + cur) * NA;
+  double *Y = d.x + ((size_t)w * 2 + 1 - cur) * NA;
+  BlockPre q0, q1;
+  block_preload<9>(d, ds, w, X, t, q0);
+  block_preload<1>(d, ds, w, X, t + 64, q1);
+  step_body(d, ds, lc, c, w, t);
+  if (t == 0) {
+    c.done = lc.done; c.have_step = lc.have_step; c.reuse = lc.reuse; c.iter = lc.iter; c.termination = lc.termination; c.status = lc.status;
+    c.invalid_steps = lc.invalid_steps;
+    c.G2 = lc.G2; c.N2 = lc.N2; c.gy = lc.gy; c.vHv = lc.vHv; c.vHy = lc.vHy; c.yHy = lc.yHy; c.grad_max = lc.grad_max; c.x_norm = lc.x_norm;
+    c.alpha = lc.alpha; c.c1 = lc.c1; c.c2 = lc.c2; c.step_norm = lc.step_norm; c.model_change = lc.model_change; c.mu = lc.mu;
+  }
+  const int go = __shfl((lc.done || !lc.have_step) ? 0 : 1, 0, 64);       // (lane 0 ran the scalar logic)
+  if (!go) return;
+  const double c1 = __shfl(lc.c1, 0, 64), c2 = __shfl(lc.c2, 0, 64);
+  double d2 = 0.0, n2 = 0.0, Yl0[9], Yl1[9];
+  block_candidate<9>(d, w, q0, c1, c2, Y, Yl0, d2, n2);
+  block_candidate<1>(d, w, q1, c1, c2, Y, Yl1, d2, n2);
+  d2 = wave_sum(d2); n2 = wave_sum(n2);
+  if (t == 0) { d.dense_cand[(size_t)w * 4 + 1] = d2; d.dense_cand[(size_t)w * 4 + 2] = n2; }
+  if (t < NF) sp_cand[t] = make_pose(Yl0);
+  if (t == GFBE_BLK_EX_CAM) sp_cand[NF] = make_pose(Yl0);
+  __syncthreads();
+  pair_consts_from_staged(d.pc + ((size_t)w * 3 + (1 - cur)) * NPAIR * PC_DOUBLES, sp_cand, t);
+#else
+  step_body(d, ds, d.ctl[w], d.ctl[w], w, threadIdx.x);
+  __threadfence_block();      // (one wave, one CU, one vector cache: workgroup scope — a device-scope fence writes the XCD's L2 back, measured -4 % end to end)
+  __builtin_amdgcn_wave_barrier();
+  const WinCtl &c = d.ctl[w];
+  if (c.done || !c.have_step) return;
+  __shared__ PoseRT sp_cand[NF + 1];
+  candidate_dense(d, ds, c, w, threadIdx.x, sp_cand, true);
+#endif
 }
 #ifndef GFBE_LMS_AHEAD
 #define GFBE_LMS_AHEAD 3      // k_lm_step_fused: rows of the observation steps in flight ahead of the one being multiplied (lm_step_tile)
