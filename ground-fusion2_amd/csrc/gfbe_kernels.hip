@@ -3949,18 +3949,29 @@ __device__ __forceinline__ void accept_body(const BatchDev &d, const int w, cons
   const WinDesc &ds = d.desc[w];
   if (c.done || !c.have_step) return;
   double cand = 0.0, d2 = 0.0, n2 = 0.0;
+  // the dense factors' candidate costs: a lane holds at most ONE of them (lanes 0.. the inertial factors, 16.. the wheel factors, 32 the prior and
+  // the dense blocks' |dx|^2, |x|^2, 40.. the LiDAR workgroups, 48.. the plane factors, 58 the anchor, 59 GNSS) — its address is selected and the
+  // value requested BEFORE the tiles' sums (end of round 6: a conditional load per kind was seven dependent round trips of one wave), and added
+  // behind them as before: the same sums in the same order
+  static_assert(MAX_IMU <= 16 && MAX_WHEEL <= 16 && LIOW_WGS <= 8 && MAX_PLANE <= 10, "accept_body: one dense term per lane");
+  const double *tp = nullptr;
+  if (lane < ds.n_imu) tp = d.imu_part + ((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - cslot;
+  else if (lane >= 16 && lane - 16 < ds.n_wheel) tp = d.wheel_part + ((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - cslot;
+  else if (lane == 32) tp = d.prior_g + (size_t)w * (ND + 2) + ND + 2 - cslot;
+  else if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) tp = d.lio_part + ((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 29 - cslot;      // (28: the cost pass's slot; 27: a linearisation's)
+  else if (lane >= 48 && lane - 48 < ds.n_plane) tp = d.plane_part + ((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - cslot;
+  else if (lane == 58 && ds.use_anchor) tp = d.anchor_part + (size_t)w * ANCHOR_PART + ANCHOR_PART - cslot;
+  else if (lane == 59 && ds.gnss_factors) tp = d.gnss_cost + (size_t)w * 2 + 2 - cslot;
+  const bool has_term = tp != nullptr;
+  const double term = *(has_term ? tp : d.zero);
+  const double dc1 = d.dense_cand[(size_t)w * 4 + 1], dc2 = d.dense_cand[(size_t)w * 4 + 2];
   if (!d.sharded) tile_cand_sum(d, ds, w, lane, cand, d2, n2);
   else if (lane < d.world) {   // landmark sharding: the ranks' sums (k_xchg_cand + all-reduce)
     const double *xr = d.xc + ((size_t)w * d.world + lane) * XCHG;
     cand = xr[0]; d2 = xr[1]; n2 = xr[2];
   }
-  if (lane < ds.n_imu) cand += d.imu_part[((size_t)w * MAX_IMU + lane) * IMU_PART + IMU_PART - cslot];
-  if (lane >= 16 && lane - 16 < ds.n_wheel) cand += d.wheel_part[((size_t)w * MAX_WHEEL + lane - 16) * WHEEL_PART + WHEEL_PART - cslot];
-  if (lane == 32) { cand += d.prior_g[(size_t)w * (ND + 2) + ND + 2 - cslot]; d2 += d.dense_cand[(size_t)w * 4 + 1]; n2 += d.dense_cand[(size_t)w * 4 + 2]; }
-  if (ds.lio_n > 0 && lane >= 40 && lane < 40 + LIOW_WGS) cand += d.lio_part[((size_t)w * LIOW_WGS + lane - 40) * LIOW_PART + 29 - cslot];      // (28: the cost pass's slot; 27: a linearisation's)
-  if (lane >= 48 && lane - 48 < ds.n_plane) cand += d.plane_part[((size_t)w * MAX_PLANE + lane - 48) * PLANE_PART + PLANE_PART - cslot];
-  if (lane == 58 && ds.use_anchor) cand += d.anchor_part[(size_t)w * ANCHOR_PART + ANCHOR_PART - cslot];
-  if (lane == 59 && ds.gnss_factors) cand += d.gnss_cost[(size_t)w * 2 + 2 - cslot];
+  if (has_term) cand += term;
+  if (lane == 32) { d2 += dc1; n2 += dc2; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { cand += __shfl_xor(cand, o, 64); d2 += __shfl_xor(d2, o, 64); n2 += __shfl_xor(n2, o, 64); }
   if (lane != 0) return;
