@@ -35,6 +35,9 @@ namespace gfd {
 #ifndef GFBE_FUSE_CAND
 #define GFBE_FUSE_CAND 1   // throughput batches: the landmark half of k_candidate at the head of the cost pass (k_vis<1>)
 #endif
+#ifndef GFBE_PCS_ONE_ROUND
+#define GFBE_PCS_ONE_ROUND 1      // k_vis_chunk: the pair records of a wave's start frame in one round of loads (0: one dependent round trip per pair, rounds 4-6)
+#endif
 #ifndef GFBE_ASM_U
 #define GFBE_ASM_U 4       // k_visasm: entries of H a thread has in flight
 #endif
@@ -417,9 +420,31 @@ __device__ __forceinline__ void vis_body(const BatchDev &d, int write_records, c
   {
     const double *src = d.pc + (((size_t)w * 3 + (MODE == 2 ? 2 : buf)) * NPAIR + sframe * NF) * PC_DOUBLES;
     // (WS: the records dealt over the workgroup's waves)
+#if GFBE_PCS_ONE_ROUND
+    // (end of round 6, as in k_vis_chunk: every record this wave stages is requested before the first is written — the loop below is a
+    //  dependent round trip per pair; a slot beyond the window's last frame re-reads a valid entry and writes nothing)
+    {
+      constexpr int JS = WS ? KS : 1, NJ = (NF - 1 + JS - 1) / JS, NR = (PCW + LM_TILE - 1) / LM_TILE;
+      double rec[NJ][NR];
+#pragma unroll
+      for (int jj = 0; jj < NJ; jj++)
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+          rec[jj][r] = src[(size_t)min(sframe + 1 + (WS ? kq : 0) + jj * JS, NF - 1) * PC_DOUBLES + min(lane + r * LM_TILE, PCW - 1)];
+      const double fcv = src[(size_t)sframe * PC_DOUBLES + min(lane, (int)FC_DOUBLES - 1)];
+#pragma unroll
+      for (int jj = 0; jj < NJ; jj++) {
+        const int j = sframe + 1 + (WS ? kq : 0) + jj * JS;
+#pragma unroll
+        for (int r = 0; r < NR; r++) if (j < NF && lane + r * LM_TILE < PCW) ((double *)&pcs[min(j, NF - 1)])[lane + r * LM_TILE] = rec[jj][r];
+      }
+      if (YM && (!WS || kq == 0) && lane < FC_DOUBLES) ((double *)&fcs)[lane] = fcv;
+    }
+#else
     for (int j = sframe + 1 + (WS ? kq : 0); j < NF; j += (WS ? KS : 1))
       for (int q = lane; q < PCW; q += LM_TILE) ((double *)&pcs[j])[q] = src[(size_t)j * PC_DOUBLES + q];     // (the whole record is 75 doubles: two rounds)
     if (YM && (!WS || kq == 0) && lane < FC_DOUBLES) ((double *)&fcs)[lane] = src[(size_t)sframe * PC_DOUBLES + lane];
+#endif
   }
   __syncthreads();
   const double sq = d.opt.vis_sqrt_info, delta = d.opt.huber_delta;
@@ -897,9 +922,26 @@ __global__ __launch_bounds__(LM_TILE, GFBE_KVIS_WAVES) void k_vis_chunk(BatchDev
   const double td = X[A_TD];
   {
     const double *src = d.pc + (((size_t)w * 3 + buf) * NPAIR + sframe * NF) * PC_DOUBLES;
+#if GFBE_PCS_ONE_ROUND
+    // (end of round 6) every record of the start frame's pairs requested before the first is written to LDS: the loop below compiles to
+    // load, s_waitcnt vmcnt(0), ds_write per pair — up to ten dependent round trips in front of a wave's first tile (its ISA; the prologue
+    // was a third of a wave's life, profiles/r6_kvis_ablation.txt). A pair beyond the window's last frame re-reads the last record and writes nothing.
+    static_assert(PCY_DOUBLES <= LM_TILE && FC_DOUBLES <= LM_TILE, "one lane per entry of a pair record");
+    {
+      const int ql = min(lane, (int)PCY_DOUBLES - 1);
+      double rec[NF - 1];
+#pragma unroll
+      for (int jj = 0; jj < NF - 1; jj++) rec[jj] = src[(size_t)min(sframe + 1 + jj, NF - 1) * PC_DOUBLES + ql];
+      const double fcv = src[(size_t)sframe * PC_DOUBLES + min(lane, (int)FC_DOUBLES - 1)];
+#pragma unroll
+      for (int jj = 0; jj < NF - 1; jj++) if (sframe + 1 + jj < NF && lane < (int)PCY_DOUBLES) ((double *)&pcs[min(sframe + 1 + jj, NF - 1)])[lane] = rec[jj];
+      if (lane < (int)FC_DOUBLES) ((double *)&fcs)[lane] = fcv;
+    }
+#else
     for (int j = sframe + 1; j < NF; j++)
       for (int q = lane; q < (int)PCY_DOUBLES; q += LM_TILE) ((double *)&pcs[j])[q] = src[(size_t)j * PC_DOUBLES + q];
     if (lane < (int)FC_DOUBLES) ((double *)&fcs)[lane] = src[(size_t)sframe * PC_DOUBLES + lane];
+#endif
   }
   __syncthreads();
   for (int tile = t0; tile < t1; tile++) {
