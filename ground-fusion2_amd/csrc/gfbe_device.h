@@ -386,7 +386,7 @@ void *ctx_scratch_pinned(gfbe_ctx *c, size_t bytes);   // its pinned host mirror
 void launch_xchg_gram(const BatchDev &d, hipStream_t s);
 void launch_xchg_cand(const BatchDev &d, hipStream_t s);
 void launch_lam_mask(const BatchDev &d, hipStream_t s);
-void launch_marginalize_partials(const BatchDev &d, hipStream_t s);
+void launch_marginalize_partials(const BatchDev &d, hipStream_t s, bool dense_elsewhere = false);
 void launch_marginalize_finish(const BatchDev &d, int flag, hipStream_t s);
 void launch_solve(const BatchDev &d, hipStream_t s, int retry_pass = 0);
 int solve_chain_tiles(const unsigned char *act);

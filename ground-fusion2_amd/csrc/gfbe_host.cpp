@@ -1422,6 +1422,9 @@ static void run_allreduce(gfbe_ctx *c, double *ptr, int64_t n, hipStream_t s) {
 
 // GFBE_FUSE_SMALL (gfbe_device.h): which launches of an iteration are merged for this batch. Small batches on the latency path only:
 // not while profiling (per-kernel events), not with an all-reduce hook, not without landmarks (k_lm_step is not launched then).
+#ifndef GFBE_MARG_DENSE_ASIDE
+#define GFBE_MARG_DENSE_ASIDE 1      // the marginalisation's dense factors of a throughput batch on the side stream (0: in line, rounds 1-6)
+#endif
 static int small_fuse(const gfbe_ctx *c, const BatchDev &d) {
   if (c->profiling || d.B >= DENSE_SPLIT_MIN_B || !d.vis_Hs || d.sharded || d.max_tiles == 0) return 0;
   int f = GFBE_FUSE_SMALL;
@@ -1541,6 +1544,17 @@ static gfbe_status enqueue_solve(gfbe_ctx *c, gfbe_batch *b, const Lane &ln, int
       launch_marginalize_partials(d, ln.s);
       run_allreduce(c, d.pair_part, (int64_t)d.B * NF * VP_STRIDE, ln.s);
       run_allreduce(c, d.schur_part, (int64_t)d.B * d.schur_groups * SCHUR_STRIDE, ln.s);
+      launch_marginalize_finish(d, margin_flag, ln.s);
+    } else if (GFBE_MARG_DENSE_ASIDE && margin_flag == GFBE_MARGIN_OLD && !c->profiling && ln.aux && d.B >= DENSE_SPLIT_MIN_B) {
+      // (end of round 6) throughput batches: the frame-0 inertial / wheel / prior factors of the marginalisation set (k_dense<false>: a few
+      // latency-bound workgroups per window, ~40 us per launch over 512 windows) on the side stream, beside k_vis<2> / k_pairsum / k_schur —
+      // they read the re-anchored state and nothing of the visual kernels', k_marg reads them all: fork behind k_reanchor, join in front of k_marg
+      (void)hipEventRecord(ln.fork, ln.s);
+      (void)hipStreamWaitEvent(ln.aux, ln.fork, 0);
+      launch_dense_factors(d, 2, 0, ln.aux);
+      (void)hipEventRecord(ln.join, ln.aux);
+      launch_marginalize_partials(d, ln.s, true);
+      (void)hipStreamWaitEvent(ln.s, ln.join, 0);
       launch_marginalize_finish(d, margin_flag, ln.s);
     } else {
       launch_marginalize(d, margin_flag, ln.s);

@@ -1659,7 +1659,9 @@ __global__ __launch_bounds__(64) void k_marg_ldlt_tp(BatchDev d) {
 
 // MARGIN_OLD: the partials of the marginalisation set at the re-anchored state (visual factors of the landmarks
 // starting in frame 0, the inertial / wheel factor of frame 0, their Schur partial)
-void launch_marginalize_partials(const BatchDev &d, hipStream_t s) {
+// dense_elsewhere (throughput batches, end of round 6): the caller runs the frame-0 inertial / wheel / prior factors on its side stream, beside the
+// visual kernels of the marginalisation set, and joins in front of launch_marginalize_finish (gfbe_host.cpp: enqueue_solve)
+void launch_marginalize_partials(const BatchDev &d, hipStream_t s, bool dense_elsewhere) {
   if ((GFBE_FUSE_SMALL & 8) && d.B < DENSE_SPLIT_MIN_B && d.vis_Hs && !d.sharded && d.max_tiles > 0) {   // (small batches: two launches instead of four)
     launch_lin_small(d, 2, s);
     launch_pair_schur_marg(d, s);
@@ -1668,7 +1670,7 @@ void launch_marginalize_partials(const BatchDev &d, hipStream_t s) {
   }
   launch_vis(d, 2, s);
   launch_pair(d, 1, s);
-  launch_dense_factors(d, 2, 0, s);
+  if (!dense_elsewhere) launch_dense_factors(d, 2, 0, s);
   launch_gnss(d, 2, s);
   launch_schur(d, 1, s);
 }

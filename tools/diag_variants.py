@@ -63,6 +63,7 @@ VARIANTS = {   # name -> (extra flags, fp-contract)
     "asmtp1": (["-DGFBE_ASM_TP=1"], "off"),
     "asmtp5": (["-DGFBE_ASM_TP=5"], "off"),
     "asmtp13": (["-DGFBE_ASM_TP=13"], "off"),
+    "margaside0": (["-DGFBE_MARG_DENSE_ASIDE=0"], "off"),
     "pcs0": (["-DGFBE_PCS_ONE_ROUND=0"], "off"),
     "stepcand0": (["-DGFBE_STEP_CAND_REGS=0"], "off"),
     "lmsstamp0": (["-DGFBE_LMS_STAMP=1", "-DGFBE_LMS_AHEAD=0"], "off"),
